@@ -1,0 +1,10 @@
+"""MI355X-native particle-filter hot path behind the pf_initialize / pf_update! / pf_resample! /
+pf_rejuvenate! API of probcomp/GenParticleFilters.jl.  The directory name contains a
+dot, so import it through the repo-root shim:  `import gpf_amd`."""
+from . import _lib, models                                        # noqa: F401
+from .api import *                                                # noqa: F401,F403
+from .api import (DeviceParticleFilterState, ParticleFilterState, ErrorException, Tempering, mh, move_reweight,
+                  pf_initialize, pf_update, pf_resample, pf_multinomial_resample, pf_residual_resample,
+                  pf_stratified_resample, pf_rejuvenate, pf_move_accept, pf_move_reweight,
+                  effective_sample_size, get_ess, log_ml_estimate, get_lml_est, get_log_weights,
+                  get_log_norm_weights, get_norm_weights, get_traces, mean, var)

@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Same names, argument meaning and error behaviour as GenParticleFilters.jl v0.2.3 (Julia's `f!`
+is spelled `f` here; the Julia glue in julia/GenParticleFiltersAMD.jl keeps the bang):
+
+    pf_initialize(model, model_args, observations, n_particles)        src/initialize.jl:31-44
+    pf_update(state, new_args, argdiffs, observations)                 src/update.jl:12-25
+    pf_resample(state, method; priority_fn, check[, sort_particles])   src/resample.jl:19-175
+    pf_rejuvenate(state, kern, kern_args, n_iters; method)             src/rejuvenate.jl:18-90
+    effective_sample_size / get_ess / log_ml_estimate / get_lml_est /
+    get_log_weights / get_log_norm_weights / get_norm_weights          src/utils.jl:148-186
+    mean / var                                                         src/statistics.jl:13-14,48-50
+
+Every call goes through the C ABI of libgpf_hip.so (include/gpf.h); nothing is computed on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .models import NativeModel
+
+RESAMPLE_METHODS = {"multinomial": 0, "residual": 1, "stratified": 2}
+REJUVENATE_METHODS = {"move": 0, "reweight": 1}
+
+
+class ErrorException(RuntimeError):
+    """Julia's ErrorException, raised where the reference calls error(...)."""
+
+
+class Tempering:
+    """priority_fn = w -> alpha * w (reference test/resample.jl:15 uses alpha = 1/2); evaluated on the GPU."""
+
+    def __init__(self, alpha: float):
+        self.alpha = float(alpha)
+
+    def __call__(self, w):
+        return self.alpha * w
+
+
+# native rejuvenation kernels (the `kern` argument of pf_rejuvenate)
+class _NativeKernel:
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return f"<native kernel {self.name}>"
+
+
+mh = _NativeKernel("mh")                        # Gen.mh(trace, select(current step latent))
+move_reweight = _NativeKernel("move_reweight")  # move_reweight(trace, selection), src/rejuvenate.jl:125-132
+
+
+def _pd(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class DeviceParticleFilterState:
+    """Device-resident counterpart of Gen.ParticleFilterState{U} (fields traces / new_traces /
+    log_weights / log_ml_est / parents).  Owns an opaque libgpf handle."""
+
+    def __init__(self, model: NativeModel, n_particles: int, seed: int = 1, keep_prev: bool = False,
+                 device: int = 0, n_global: int | None = None, gid0: int = 0, stream: int | None = None):
+        self._L = _lib.load()
+        self.model, self.n_particles, self.seed = model, int(n_particles), int(seed)
+        self.keep_prev = bool(keep_prev)
+        self._params = np.ascontiguousarray(model.params, np.float64)
+        cfg = _lib.GpfConfig()
+        cfg.abi_version, cfg.model, cfg.n_params = _lib.ABI_VERSION, model.model_id, self._params.size
+        cfg.keep_prev, cfg.params = int(self.keep_prev), _pd(self._params)
+        cfg.n_particles = self.n_particles
+        cfg.n_global = self.n_particles if n_global is None else int(n_global)
+        cfg.gid0, cfg.seed, cfg.device, cfg.stream = int(gid0), self.seed, int(device), stream
+        self._h = C.c_void_p()
+        st = self._L.gpf_create(C.byref(cfg), C.byref(self._h))
+        if st != _lib.OK:
+            msg = self._L.gpf_last_error(None).decode()
+            self._h = None
+            raise ErrorException(f"gpf_create failed ({st}): {msg}")
+        d, w = C.c_int32(), C.c_int32()
+        self._L.gpf_state_dim(self._h, C.byref(d), C.byref(w))
+        self.dim, self.row_width = d.value, w.value
+
+    # -- plumbing
+    def _check(self, st: int):
+        if st != _lib.OK:
+            raise ErrorException(self._L.gpf_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gpf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self._L.gpf_synchronize(self._h))
+
+    # -- fields of ParticleFilterState
+    @property
+    def log_weights(self) -> np.ndarray:
+        out = np.empty(self.n_particles)
+        self._check(self._L.gpf_get_log_weights(self._h, _pd(out), out.size))
+        return out
+
+    @log_weights.setter
+    def log_weights(self, lw):
+        lw = np.ascontiguousarray(lw, np.float64)
+        self._check(self._L.gpf_set_log_weights(self._h, _pd(lw), lw.size))
+
+    @property
+    def parents(self) -> np.ndarray:
+        out = np.empty(self.n_particles, np.int64)
+        self._check(self._L.gpf_get_parents(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), out.size))
+        return out
+
+    @property
+    def log_ml_est(self) -> float:
+        # the running estimate alone = log_ml_estimate - (logsumexp(lw) - log N); exposed via get_lml_est
+        raise AttributeError("use get_lml_est(state); the running log_ml_est lives on the device")
+
+    @property
+    def traces(self) -> np.ndarray:
+        """(n_particles, row_width) Float64 rows: columns 0..dim-1 = x_t, dim..2dim-1 = x_{t-1} if keep_prev."""
+        out = np.empty((self.n_particles, self.row_width))
+        self._check(self._L.gpf_get_rows(self._h, _pd(out), out.size))
+        return out
+
+    @traces.setter
+    def traces(self, rows):
+        rows = np.ascontiguousarray(rows, np.float64)
+        self._check(self._L.gpf_set_rows(self._h, _pd(rows), rows.size))
+
+    def column(self, col: int) -> np.ndarray:
+        out = np.empty(self.n_particles)
+        self._check(self._L.gpf_get_column(self._h, int(col), _pd(out), out.size))
+        return out
+
+    # -- measurement hooks
+    def kernel_timing(self, kernel_id: int, enable: bool = True):
+        self._check(self._L.gpf_kernel_timing(self._h, kernel_id, int(enable)))
+
+    def kernel_time(self, kernel_id: int):
+        ms, cnt = C.c_double(), C.c_int64()
+        self._check(self._L.gpf_kernel_time(self._h, kernel_id, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def debug_math(self, which: int, a, b=None):
+        a = np.ascontiguousarray(a, np.float64)
+        b = a if b is None else np.ascontiguousarray(b, np.float64)
+        o1, o2 = np.empty_like(a), np.empty_like(a)
+        self._check(self._L.gpf_debug_math(self._h, which, _pd(a), _pd(b), a.size, _pd(o1), _pd(o2)))
+        return o1, o2
+
+
+ParticleFilterState = DeviceParticleFilterState
+
+
+def _obs_vector(observations) -> np.ndarray:
+    return np.ascontiguousarray(np.atleast_1d(np.asarray(observations, np.float64)))
+
+
+# ----------------------------------------------------------------------------- the four operations
+def pf_initialize(model: NativeModel, model_args: tuple, observations, n_particles: int, *, seed: int = 1,
+                  keep_prev: bool = False, device: int = 0, dynamic: bool = False, **kw) -> DeviceParticleFilterState:
+    """src/initialize.jl:31-44.  `model_args` is accepted for signature parity; native models take their
+    time-varying inputs through the per-step data vector `observations`. `dynamic` has no meaning for
+    fixed-shape device rows and is ignored."""
+    state = DeviceParticleFilterState(model, n_particles, seed=seed, keep_prev=keep_prev, device=device, **kw)
+    obs = _obs_vector(observations)
+    state._check(state._L.gpf_initialize(state._h, _pd(obs), obs.size))
+    return state
+
+
+def pf_update(state: DeviceParticleFilterState, new_args: tuple, argdiffs: tuple, observations):
+    """src/update.jl:12-25 (default proposal).  Returns `state`, like the reference (update.jl:24)."""
+    obs = _obs_vector(observations)
+    state._check(state._L.gpf_update(state._h, _pd(obs), obs.size))
+    return state
+
+
+def _resample(state, method_id: int, priority_fn, check, sort_particles: bool):
+    if check not in (True, False, "warn"):
+        raise ValueError("check must be True, 'warn' or False")
+    check_id = 2 if check is True else (1 if check == "warn" else 0)
+    inv = C.c_int32(0)
+    inv_ptr = C.byref(inv) if check_id != 0 else None          # check=false: fully asynchronous
+    if priority_fn is None or isinstance(priority_fn, Tempering):
+        alpha = float("nan") if priority_fn is None else priority_fn.alpha
+        st = state._L.gpf_resample(state._h, method_id, alpha, int(sort_particles), check_id, inv_ptr)
+    else:
+        lw = state.log_weights
+        try:
+            lp = np.ascontiguousarray(priority_fn(lw), np.float64)
+            if lp.shape != lw.shape:
+                raise TypeError
+        except TypeError:
+            lp = np.array([priority_fn(float(w)) for w in lw], np.float64)
+        st = state._L.gpf_resample_with_priorities(state._h, method_id, _pd(lp), int(sort_particles), check_id, inv_ptr)
+    if st == _lib.ERR_INVALID_WEIGHTS:
+        raise ErrorException(state._L.gpf_last_error(state._h).decode())       # error("Invalid weights.")
+    state._check(st)
+    if check == "warn" and inv.value:
+        warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")   # utils.jl:120-135
+    return state
+
+
+def pf_multinomial_resample(state, *, priority_fn=None, check="warn"):
+    """src/resample.jl:48-65"""
+    return _resample(state, 0, priority_fn, check, True)
+
+
+def pf_residual_resample(state, *, priority_fn=None, check="warn"):
+    """src/resample.jl:85-120"""
+    return _resample(state, 1, priority_fn, check, True)
+
+
+def pf_stratified_resample(state, *, priority_fn=None, check="warn", sort_particles: bool = True):
+    """src/resample.jl:143-175"""
+    return _resample(state, 2, priority_fn, check, sort_particles)
+
+
+def pf_resample(state, method: str = "multinomial", **kwargs):
+    """src/resample.jl:19-30"""
+    if method == "multinomial":
+        return pf_multinomial_resample(state, **kwargs)
+    if method == "residual":
+        return pf_residual_resample(state, **kwargs)
+    if method == "stratified":
+        return pf_stratified_resample(state, **kwargs)
+    raise ErrorException(f"Resampling method {method} not recognized.")
+
+
+def _rejuvenate(state, method_id: int, n_iters: int, want_count: bool):
+    acc = C.c_uint64(0)
+    st = state._L.gpf_rejuvenate(state._h, method_id, int(n_iters), C.byref(acc) if want_count else None)
+    state._check(st)
+    state.n_accepted = acc.value if want_count else None
+    return state
+
+
+def pf_move_accept(state, kern=mh, kern_args: tuple = (), n_iters: int = 1, *, count: bool = False):
+    """src/rejuvenate.jl:40-53 with the native mh kernel"""
+    if kern is not mh:
+        raise ErrorException("device states support the native `mh` kernel only (arbitrary Julia/Python callables are out of scope)")
+    return _rejuvenate(state, 0, n_iters, count)
+
+
+def pf_move_reweight(state, kern=move_reweight, kern_args: tuple = (), n_iters: int = 1, *, count: bool = False):
+    """src/rejuvenate.jl:74-90 with the native move_reweight kernel"""
+    if kern is not move_reweight:
+        raise ErrorException("device states support the native `move_reweight` kernel only")
+    return _rejuvenate(state, 1, n_iters, count)
+
+
+def pf_rejuvenate(state, kern=None, kern_args: tuple = (), n_iters: int = 1, *, method: str = "move", **kwargs):
+    """src/rejuvenate.jl:18-27"""
+    if method == "move":
+        return pf_move_accept(state, mh if kern is None else kern, kern_args, n_iters, **kwargs)
+    if method == "reweight":
+        return pf_move_reweight(state, move_reweight if kern is None else kern, kern_args, n_iters, **kwargs)
+    raise ErrorException(f"Method {method} not recognized.")
+
+
+# ----------------------------------------------------------------------------- summaries (src/utils.jl)
+def effective_sample_size(state) -> float:
+    out = C.c_double()
+    state._check(state._L.gpf_effective_sample_size(state._h, C.byref(out)))
+    return out.value
+
+
+get_ess = effective_sample_size
+
+
+def log_ml_estimate(state) -> float:
+    out = C.c_double()
+    state._check(state._L.gpf_log_ml_estimate(state._h, C.byref(out)))
+    return out.value
+
+
+get_lml_est = log_ml_estimate
+
+
+def get_log_weights(state) -> np.ndarray:
+    return state.log_weights
+
+
+def get_log_norm_weights(state) -> np.ndarray:
+    out = np.empty(state.n_particles)
+    state._check(state._L.gpf_get_log_norm_weights(state._h, _pd(out), out.size))
+    return out
+
+
+def get_norm_weights(state) -> np.ndarray:
+    out = np.empty(state.n_particles)
+    state._check(state._L.gpf_get_norm_weights(state._h, _pd(out), out.size))
+    return out
+
+
+def get_traces(state) -> np.ndarray:
+    return state.traces
+
+
+# ----------------------------------------------------------------------------- statistics (src/statistics.jl)
+def mean(state, addr: int) -> float:
+    """mean(state, addr): addr = column index of the current-step latent (src/statistics.jl:13-14)"""
+    out = C.c_double()
+    state._check(state._L.gpf_mean(state._h, int(addr), C.byref(out)))
+    return out.value
+
+
+def var(state, addr: int) -> float:
+    """var(state, addr), population form (src/statistics.jl:48-50)"""
+    out = C.c_double()
+    state._check(state._L.gpf_var(state._h, int(addr), C.byref(out)))
+    return out.value

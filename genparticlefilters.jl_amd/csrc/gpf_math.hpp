@@ -1,0 +1,257 @@
+// gpf_math.hpp -- deterministic numerics for the gfx950 particle-filter kernels.
+//
+// Implements DESIGN.md §3 ("numerics spec"): Philox4x32-10 counter RNG, uniform -> normal
+// conversion and exp / log / sincos(2*pi*u) / atan2 built only from IEEE-754 correctly rounded
+// operations (+ - * / sqrt fma) and integer bit manipulation.  The translation unit is compiled
+// with -ffp-contract=off, so a*b+c is two roundings unless written as gpf::fma_().
+//
+// Why: the reference (GenParticleFilters.jl) draws from Julia's unseeded global RNG
+// (src/resample.jl:59,113,162) and Julia's libm; "bit-exact ancestor indices under a fixed seed"
+// therefore needs a stream and a math library that are identical on the host and on the GPU
+// (SURVEY.md §7 H1/H2).  The CPU oracle carries an independently written C copy of this spec
+// (oracle/gpf_oracle_math.h); tests compare the two bit-for-bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GPF_HD __host__ __device__ __forceinline__
+
+namespace gpf {
+
+// ------------------------------------------------------------------ primitives
+GPF_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
+GPF_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+GPF_HD double pow2i(int e) { return u2d((uint64_t)(e + 1023) << 52); }   // 2^e, -1022 <= e <= 1023
+GPF_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+GPF_HD double sqrt_(double x) { return __builtin_sqrt(x); }
+
+GPF_HD uint64_t mulhi64(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct Philox { uint32_t w0, w1, w2, w3; };
+
+GPF_HD Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox{c0, c1, c2, c3};
+}
+
+// stream tags: which pf_* operation consumes the block
+enum : uint32_t { TAG_INIT = 1, TAG_UPDATE = 2, TAG_RESAMPLE = 3, TAG_MOVE = 4, TAG_REWEIGHT = 5 };
+
+// counter = (global particle / slot id, block index, epoch, tag); key = seed
+GPF_HD Philox rng(uint64_t seed, uint32_t gid, uint32_t blk, uint32_t epoch, uint32_t tag)
+{
+    return philox4x32_10(gid, blk, epoch, tag, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// (k + 1/2) 2^-52 with k the top 52 of the 64 bits hi:lo -- strictly inside (0,1)
+GPF_HD double u52(uint32_t hi, uint32_t lo)
+{
+    const uint64_t k = ((uint64_t)hi << 20) | (uint64_t)(lo >> 12);
+    return ((double)k + 0.5) * 0x1p-52;
+}
+GPF_HD uint64_t u64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
+
+// ------------------------------------------------------------------ log (positive normal x)
+GPF_HD double log_(double x)
+{
+    constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    constexpr double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01,
+                     L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01,
+                     L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                     L7 = 1.479819860511658591e-01;
+    const uint64_t bits = d2u(x);
+    const uint64_t man = bits & 0x000FFFFFFFFFFFFFull;
+    const bool big = man >= 0x6A09E667F3BCDull;             // mantissa of sqrt(2)
+    const int k = (int)(bits >> 52) - 1023 + (big ? 1 : 0);
+    const double m = u2d(man | (big ? 0x3FE0000000000000ull : 0x3FF0000000000000ull));
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma_(w, fma_(w, L6, L4), L2);
+    const double t2 = z * fma_(w, fma_(w, fma_(w, L7, L5), L3), L1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+// ------------------------------------------------------------------ exp
+// e = exp(x - k ln2) in ~[0.70, 1.42], |x| < 745
+GPF_HD double exp_core(double x, int& k)
+{
+    constexpr double INVLN2 = 1.44269504088896338700e+00;
+    constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    constexpr double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                     P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                     P5 = 4.13813679705723846039e-08;
+    const double t = x * INVLN2;
+    k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
+    const double dk = (double)k;
+    const double hi = x - dk * LN2_HI;
+    const double lo = dk * LN2_LO;
+    const double r = hi - lo;
+    const double rr = r * r;
+    const double c = r - rr * fma_(rr, fma_(rr, fma_(rr, fma_(rr, P5, P4), P3), P2), P1);
+    return 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+}
+
+GPF_HD double exp_(double x)
+{
+    if (x != x) return x;
+    if (x > 709.0) return __builtin_huge_val();
+    if (x < -708.0) return 0.0;
+    int k;
+    const double e = exp_core(x, k);
+    const int k1 = k / 2, k2 = k - k1;
+    return (e * pow2i(k1)) * pow2i(k2);
+}
+
+// fixed-point weight q = trunc(exp(d) 2^K + 1/2), d <= 0
+GPF_HD uint64_t exp_fix(double d, int K)
+{
+    if (!(d >= -708.0)) return 0;
+    int k;
+    const double e = exp_core(d, k);
+    const int sh = k + K;
+    if (sh < -2) return 0;
+    const double v = e * pow2i(sh) + 0.5;
+    return (uint64_t)v;
+}
+
+// ------------------------------------------------------------------ sin / cos of 2 pi u
+GPF_HD double ksin(double x)
+{
+    constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                     S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                     S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x;
+    const double p = fma_(z, fma_(z, fma_(z, fma_(z, fma_(z, S6, S5), S4), S3), S2), S1);
+    return fma_(x * z, p, x);
+}
+GPF_HD double kcos(double x)
+{
+    constexpr double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                     C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                     C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    const double p = fma_(z, fma_(z, fma_(z, fma_(z, fma_(z, C6, C5), C4), C3), C2), C1);
+    return fma_(z * z, p, fma_(z, -0.5, 1.0));
+}
+GPF_HD void sincos2pi(double u, double& sn, double& cs)
+{
+    constexpr double PIO4 = 7.85398163397448278999e-01;
+    const double a = u * 8.0;
+    const int oct = (int)a;
+    double f = a - (double)oct;
+    if (oct & 1) f = 1.0 - f;
+    const double th = f * PIO4;
+    const double s = ksin(th), c = kcos(th);
+    // octant o: angle = o*pi/4 + th (even o) or (o+1)*pi/4 - th (odd o)
+    const bool swap = ((oct + 1) & 2) != 0;        // octants 1,2,5,6: sin/cos exchange roles
+    const double cc = swap ? s : c;
+    const double ss = swap ? c : s;
+    const bool cneg = ((oct + 2) & 4) != 0;        // octants 2,3,4,5: cos negative
+    const bool sneg = (oct & 4) != 0;              // octants 4..7:    sin negative
+    cs = cneg ? -cc : cc;
+    sn = sneg ? -ss : ss;
+}
+
+// Box-Muller pair from one Philox block
+GPF_HD void normal2(const Philox& b, double& z0, double& z1)
+{
+    const double u1 = u52(b.w0, b.w1);
+    const double u2 = u52(b.w2, b.w3);
+    const double r = sqrt_(-2.0 * log_(u1));
+    double s, c;
+    sincos2pi(u2, s, c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+// ------------------------------------------------------------------ atan2
+GPF_HD double atan_small(double x)
+{
+    const double z = x * x;
+    double p = -0x1.c807c7fd8901cp-7;
+    p = fma_(p, z,  0x1.f5ea203927f08p-6);
+    p = fma_(p, z, -0x1.503b1df32251dp-5);
+    p = fma_(p, z,  0x1.829c9a46152b5p-5);
+    p = fma_(p, z, -0x1.aebd143c55a36p-5);
+    p = fma_(p, z,  0x1.e1d8e89291b2fp-5);
+    p = fma_(p, z, -0x1.1110ceddb22d6p-4);
+    p = fma_(p, z,  0x1.3b13aea970e58p-4);
+    p = fma_(p, z, -0x1.745d173561ae0p-4);
+    p = fma_(p, z,  0x1.c71c71c6ddb13p-4);
+    p = fma_(p, z, -0x1.24924924920acp-3);
+    p = fma_(p, z,  0x1.9999999999997p-3);
+    p = fma_(p, z, -0x1.5555555555555p-2);
+    return fma_(x * z, p, x);
+}
+GPF_HD double atan2_(double y, double x)
+{
+    constexpr double PI = 3.14159265358979311600e+00, PIO2 = 1.57079632679489655800e+00,
+                     PIO4 = 7.85398163397448278999e-01, T8 = 0.41421356237309503;
+    const double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
+    if (ax == 0.0 && ay == 0.0) return 0.0;
+    const bool swap = ay > ax;
+    const double t = (swap ? ax : ay) / (swap ? ay : ax);
+    double a = (t > T8) ? PIO4 + atan_small((t - 1.0) / (t + 1.0)) : atan_small(t);
+    if (swap) a = PIO2 - a;
+    if (x < 0.0) a = PI - a;
+    return y < 0.0 ? -a : a;
+}
+
+// ------------------------------------------------------------------ scalar weight summaries
+enum : int { FLAG_NAN = 1, FLAG_POSINF = 2, FLAG_ALL_NEGINF = 4 };
+
+// K = min(52, 62 - ceil(log2 N)): N 2^K <= 2^62
+GPF_HD int fix_K(int64_t n_global)
+{
+    int cl = 0;
+    while (((int64_t)1 << cl) < n_global) ++cl;
+    const int K = 62 - cl;
+    return K > 52 ? 52 : K;
+}
+// logsumexp = m + log(S 2^-K)   (resample.jl:180 / utils.jl:100 on the exact integer sum)
+GPF_HD double lse_from(double m, uint64_t S, int K, int flags)
+{
+    if (flags & (FLAG_NAN | FLAG_POSINF)) return __builtin_nan("");
+    if (flags & FLAG_ALL_NEGINF) return -__builtin_huge_val();
+    return m + log_((double)S * pow2i(-K));
+}
+// ESS = S^2 / Q   (utils.jl:163-164)
+GPF_HD double ess_from(uint64_t S, uint64_t Qhi, uint64_t Qlo)
+{
+    const double Sd = (double)S;
+    const double Qd = (double)Qhi * 0x1p64 + (double)Qlo;
+    return (Sd * Sd) / Qd;
+}
+GPF_HD int residual_shift(uint64_t S, int64_t N)
+{
+    int bl = 0;
+    while (bl < 64 && (S >> bl) != 0) ++bl;
+    int cl = 0;
+    while (((int64_t)1 << cl) < N) ++cl;
+    const int sh = bl + cl - 62;
+    return sh > 0 ? sh : 0;
+}
+
+} // namespace gpf

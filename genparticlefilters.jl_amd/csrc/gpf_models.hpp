@@ -1,0 +1,138 @@
+// gpf_models.hpp -- native state-space models: the per-particle work that the reference hands to
+// Gen's generate/update/regenerate (src/initialize.jl:40, src/update.jl:17, src/rejuvenate.jl:46,81).
+//
+// A model is a pair of device functions over a d-column Float64 state:
+//   sample(P, first, xprev, obs, rng-counter) -> x      the model's internal proposal for the new
+//                                                       latent choices (ancestral sampling)
+//   loglik(P, x, obs) -> log p(y_t | x_t)               the weight increment of the constrained obs
+// Parameter vectors P (incl. derived constants such as log sigma) are built on the host
+// (models.py) so the CPU oracle and the kernels receive bit-identical inputs.
+// Operation order inside each expression is part of the spec.
+#pragma once
+#include "gpf_math.hpp"
+
+namespace gpf {
+
+enum : int { MODEL_LGSSM2 = 1, MODEL_BEARINGS4 = 2, MODEL_SV1 = 3, MODEL_OBJECT_MOTION = 4 };
+
+constexpr int MAX_PARAMS = 16;
+constexpr int MAX_OBS = 4;
+constexpr int MAX_DIM = 4;
+
+struct ModelArgs {          // passed by value in the kernarg segment: no device copy per step
+    double P[MAX_PARAMS];
+    double obs[MAX_OBS];
+};
+
+template <int M> struct Model;
+
+// 2-D linear-Gaussian SSM: x' = A x + sq z, y = x + sr e   (BASELINE configs 2, 3)
+// P = [a11 a12 a21 a22 | sq | s0 | 1/sr | 2(log sr + log(2 pi)/2)]
+template <> struct Model<MODEL_LGSSM2> {
+    static constexpr int D = 2, NBLK = 1;
+    static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
+                              uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
+    {
+        double z0, z1;
+        normal2(rng(seed, gid, blk0, epoch, tag), z0, z1);
+        if (first) { xn[0] = P[5] * z0; xn[1] = P[5] * z1; }
+        else {
+            const double t0 = P[0] * xp[0] + P[1] * xp[1];
+            const double t1 = P[2] * xp[0] + P[3] * xp[1];
+            xn[0] = t0 + P[4] * z0;
+            xn[1] = t1 + P[4] * z1;
+        }
+    }
+    static GPF_HD double loglik(const double* P, const double* x, const double* obs)
+    {
+        const double z0 = (obs[0] - x[0]) * P[6], z1 = (obs[1] - x[1]) * P[6];
+        return -0.5 * (z0 * z0 + z1 * z1) - P[7];
+    }
+};
+
+// bearings-only tracking, x = (px, py, vx, vy)   (BASELINE config 4)
+// P = [mu0..3 | s0..3 | sp | sv | 1/sb | log sb + log(2 pi)/2]
+template <> struct Model<MODEL_BEARINGS4> {
+    static constexpr int D = 4, NBLK = 2;
+    static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
+                              uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
+    {
+        double z0, z1, z2, z3;
+        normal2(rng(seed, gid, blk0, epoch, tag), z0, z1);
+        normal2(rng(seed, gid, blk0 + 1, epoch, tag), z2, z3);
+        if (first) {
+            xn[0] = P[0] + P[4] * z0; xn[1] = P[1] + P[5] * z1;
+            xn[2] = P[2] + P[6] * z2; xn[3] = P[3] + P[7] * z3;
+        } else {
+            xn[0] = (xp[0] + xp[2]) + P[8] * z0;
+            xn[1] = (xp[1] + xp[3]) + P[8] * z1;
+            xn[2] = xp[2] + P[9] * z2;
+            xn[3] = xp[3] + P[9] * z3;
+        }
+    }
+    static GPF_HD double loglik(const double* P, const double* x, const double* obs)
+    {
+        constexpr double PI = 3.14159265358979311600e+00, TWOPI = 6.28318530717958623200e+00;
+        const double b = atan2_(x[1], x[0]);
+        double r = obs[0] - b;
+        if (r > PI) r -= TWOPI; else if (r <= -PI) r += TWOPI;
+        const double z = r * P[10];
+        return -0.5 * (z * z) - P[11];
+    }
+};
+
+// stochastic volatility, x = h   (BASELINE config 5)
+// P = [mu | phi | sigma | sigma/sqrt(1-phi^2) | log(2 pi)/2]
+template <> struct Model<MODEL_SV1> {
+    static constexpr int D = 1, NBLK = 1;
+    static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
+                              uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
+    {
+        double z0, z1;
+        normal2(rng(seed, gid, blk0, epoch, tag), z0, z1);
+        if (first) xn[0] = P[0] + P[3] * z0;
+        else       xn[0] = (P[0] + P[1] * (xp[0] - P[0])) + P[2] * z0;
+    }
+    static GPF_HD double loglik(const double* P, const double* x, const double* obs)
+    {
+        const double y = obs[0];
+        return (-0.5 * ((y * y) * exp_(-x[0])) - 0.5 * x[0]) - P[4];
+    }
+};
+
+// README object_motion (reference README.md:43-55; BASELINE config 1), x = (moving, y)
+// P = [p(moving|moving) | p(moving|still) | sigma_y | 1/sigma_obs | log sigma_obs + log(2 pi)/2]
+// obs = [y_obs, sin(t)]
+template <> struct Model<MODEL_OBJECT_MOTION> {
+    static constexpr int D = 2, NBLK = 2;
+    static GPF_HD void sample(const double* P, bool first, const double* xp, const double* obs, uint64_t seed,
+                              uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
+    {
+        const Philox b = rng(seed, gid, blk0, epoch, tag);
+        const double u = u52(b.w0, b.w1);
+        double z0, z1;
+        normal2(rng(seed, gid, blk0 + 1, epoch, tag), z0, z1);
+        const double pm = first ? 0.0 : xp[0], py = first ? 0.0 : xp[1];
+        const double p = (pm != 0.0) ? P[0] : P[1];
+        const double mv = (u < p) ? 1.0 : 0.0;
+        const double vel = (mv != 0.0) ? obs[1] : 0.0;
+        xn[0] = mv;
+        xn[1] = (py + vel) + P[2] * z0;
+    }
+    static GPF_HD double loglik(const double* P, const double* x, const double* obs)
+    {
+        const double z = (obs[0] - x[1]) * P[3];
+        return -0.5 * (z * z) - P[4];
+    }
+};
+
+inline int model_dim(int m)
+{
+    switch (m) {
+        case MODEL_LGSSM2: return 2; case MODEL_BEARINGS4: return 4;
+        case MODEL_SV1: return 1; case MODEL_OBJECT_MOTION: return 2;
+    }
+    return 0;
+}
+
+} // namespace gpf

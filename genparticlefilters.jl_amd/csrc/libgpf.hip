@@ -1,0 +1,682 @@
+// libgpf.hip -- C ABI (include/gpf.h) over the gfx950 kernels of gpf_kernels.hpp.
+//
+// Host orchestration only: which kernels run for each pf_* operation, on one HIP stream, with all
+// scalars (max, sums, log-ML estimate, residual counts) kept in device memory so that the common
+// path (check = false / :warn without reading the flag) never waits for the GPU.
+//
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared libgpf.hip -o libgpf_hip.so
+#include "../../include/gpf.h"
+#include "gpf_kernels.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gpf;
+
+namespace {
+
+thread_local std::string g_err;   // errors before a handle exists
+
+struct Timer {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+
+} // namespace
+
+struct gpf_filter {
+    gpf_config cfg{};
+    ModelArgs args{};
+    int d = 0, W = 0, K = 0;
+    double logN = 0.0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    int64_t n = 0, ntiles = 0;
+    double* rows[2] = {nullptr, nullptr};
+    int cur = 0;
+    double *lw = nullptr, *lws = nullptr, *lp = nullptr, *dtmp = nullptr;
+    uint64_t* cdf[3] = {nullptr, nullptr, nullptr};
+    uint64_t* desc[3] = {nullptr, nullptr, nullptr};
+    int32_t *anc = nullptr, *order = nullptr, *idx_in = nullptr;
+    uint64_t *keys = nullptr, *keys_out = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    double* pmax = nullptr;
+    int32_t* pflags = nullptr;
+    uint64_t* blockQ = nullptr;
+    double *partial = nullptr, *dscal = nullptr;
+    Scalars* sc = nullptr;
+    Scalars* h_sc = nullptr;       // pinned mirror
+    uint32_t epoch = 0;
+    bool initialized = false, has_prev = false, raw_valid = false;
+    Timer timers[GPF_K_COUNT];
+    std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+            return GPF_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+gpf_status fail(gpf_handle h, gpf_status s, const std::string& msg)
+{
+    if (h) h->err = msg; else g_err = msg;
+    return s;
+}
+
+constexpr int row_width(int D, bool keep) { return ((keep ? 2 * D : D) + 1) & ~1; }
+
+int grid_for(const gpf_filter* h, int64_t work_items, int blocks_per_cu)
+{
+    const int64_t need = (work_items + BLOCK - 1) / BLOCK;
+    const int64_t cap = (int64_t)h->n_cu * blocks_per_cu;
+    return (int)std::max<int64_t>(1, std::min(need, cap));
+}
+
+template <class F>
+gpf_status timed(gpf_filter* h, int id, F&& launch)
+{
+    Timer& t = h->timers[id];
+    if (!t.on) { launch(); return GPF_OK; }
+    hipEvent_t a, b;
+    HIP_TRY(h, hipEventCreate(&a));
+    HIP_TRY(h, hipEventCreate(&b));
+    HIP_TRY(h, hipEventRecord(a, h->stream));
+    launch();
+    HIP_TRY(h, hipEventRecord(b, h->stream));
+    t.ev.emplace_back(a, b);
+    return GPF_OK;
+}
+
+// ------------------------------------------------------------------ model dispatch
+template <int M, bool KEEP>
+void launch_step_t(gpf_filter* h, int grid)
+{
+    constexpr int Wc = row_width(Model<M>::D, KEEP);
+    hipLaunchKernelGGL((k_step<M, Wc, KEEP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                       h->cfg.gid0, h->n, h->rows[h->cur], h->rows[1 - h->cur], h->lw);
+}
+template <int M>
+void launch_init_t(gpf_filter* h, int grid)
+{
+    hipLaunchKernelGGL((k_init<M>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                       h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw);
+}
+template <int M, bool RW>
+void launch_move_t(gpf_filter* h, int grid, int n_iters)
+{
+    constexpr int Wc = row_width(Model<M>::D, true);
+    hipLaunchKernelGGL((k_move<M, Wc, RW>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                       h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
+                       reinterpret_cast<unsigned long long*>(&h->sc->n_accept));
+}
+
+#define DISPATCH_MODEL(h, CALL)                                                                  \
+    switch ((h)->cfg.model) {                                                                    \
+        case MODEL_LGSSM2: { constexpr int MM = MODEL_LGSSM2; CALL; } break;                     \
+        case MODEL_BEARINGS4: { constexpr int MM = MODEL_BEARINGS4; CALL; } break;               \
+        case MODEL_SV1: { constexpr int MM = MODEL_SV1; CALL; } break;                           \
+        case MODEL_OBJECT_MOTION: { constexpr int MM = MODEL_OBJECT_MOTION; CALL; } break;       \
+    }
+
+void launch_gather(gpf_filter* h, const PrioView& pv, double* lw_out)
+{
+    const double* in = h->rows[h->cur];
+    double* out = h->rows[1 - h->cur];
+    const int grid = grid_for(h, h->n * (h->W / 2), 8);
+    switch (h->W) {
+        case 2: hipLaunchKernelGGL((k_gather<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, in, out, pv, lw_out, h->n); break;
+        case 4: hipLaunchKernelGGL((k_gather<4>), dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, in, out, pv, lw_out, h->n); break;
+        case 8: hipLaunchKernelGGL((k_gather<8>), dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, in, out, pv, lw_out, h->n); break;
+    }
+}
+
+// ------------------------------------------------------------------ weight summary = max + scan (+ scalar ops)
+int scan_grid(const gpf_filter* h) { return (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, 2 * (int64_t)h->n_cu)); }
+
+gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, uint64_t* cdf, uint64_t* desc,
+                     const int32_t* order, int extra_ops)
+{
+    const int gp = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
+    gpf_status s = timed(h, GPF_K_MAX, [&] {
+        hipLaunchKernelGGL(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, pv, h->n, h->pmax, h->pflags);
+    });
+    if (s) return s;
+    HIP_TRY(h, hipMemsetAsync(desc, 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
+    InFixQ in{pv, order, h->K, 0.0, 0};
+    const int gs = scan_grid(h);
+    s = timed(h, GPF_K_SCAN, [&] {
+        hipLaunchKernelGGL((k_scan<InFixQ, true>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, h->pmax,
+                           h->pflags, gp, slot, cdf, desc, &slot->S, h->blockQ);
+    });
+    if (s) return s;
+    hipLaunchKernelGGL(k_scalar, dim3(1), dim3(BLOCK), 0, h->stream, OP_FOLD_Q | extra_ops, h->sc, slot, h->blockQ, gs,
+                       h->K, h->cfg.n_global, h->logN);
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+
+PrioView raw_view(const gpf_filter* h) { return PrioView{h->lw, nullptr, 0.0, 0}; }
+
+gpf_status ensure_raw(gpf_filter* h)
+{
+    if (h->raw_valid) return GPF_OK;
+    gpf_status s = summarize(h, raw_view(h), &h->sc->raw, h->cdf[0], h->desc[0], nullptr, 0);
+    if (s) return s;
+    h->raw_valid = true;
+    return GPF_OK;
+}
+
+gpf_status fetch_scalars(gpf_filter* h)
+{
+    HIP_TRY(h, hipMemcpyAsync(h->h_sc, h->sc, sizeof(Scalars), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GPF_OK;
+}
+
+void normalise_Q(const WSum& w, uint64_t& hi, uint64_t& lo)
+{
+    unsigned __int128 Q = (unsigned __int128)w.Ql[0] + ((unsigned __int128)w.Ql[1] << 32) +
+                          ((unsigned __int128)w.Ql[2] << 64) + ((unsigned __int128)w.Ql[3] << 96);
+    hi = (uint64_t)(Q >> 64);
+    lo = (uint64_t)Q;
+}
+
+gpf_status check_ready(gpf_handle h)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->initialized) return fail(h, GPF_ERR_STATE, "filter not initialised: call gpf_initialize (pf_initialize) first");
+    return GPF_OK;
+}
+
+gpf_status set_obs(gpf_filter* h, const double* obs, int n_obs)
+{
+    if (n_obs < 0 || n_obs > MAX_OBS || (n_obs > 0 && !obs)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad observation vector");
+    for (int i = 0; i < MAX_OBS; ++i) h->args.obs[i] = i < n_obs ? obs[i] : 0.0;
+    return GPF_OK;
+}
+
+gpf_status ensure_sort_buffers(gpf_filter* h)
+{
+    if (h->order) return GPF_OK;
+    const size_t n = (size_t)h->n;
+    HIP_TRY(h, hipMalloc(&h->order, n * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(&h->idx_in, n * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(&h->keys, n * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->keys_out, n * sizeof(uint64_t)));
+    size_t bytes = 0;
+    HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->keys, h->keys_out, h->idx_in, h->order, (int)h->n, 0, 64,
+                                                  h->stream));
+    h->sort_tmp_bytes = bytes;
+    HIP_TRY(h, hipMalloc(&h->sort_tmp, bytes));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->idx_in, h->n);
+    return GPF_OK;
+}
+
+gpf_status ensure_residual_buffers(gpf_filter* h)
+{
+    for (int i = 1; i < 3; ++i) {
+        if (!h->cdf[i]) HIP_TRY(h, hipMalloc(&h->cdf[i], (size_t)h->n * sizeof(uint64_t)));
+    }
+    return GPF_OK;
+}
+
+gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_particles, int check, int32_t* invalid)
+{
+    if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED)
+        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");          // resample.jl:28
+    if (h->cfg.n_global != h->n)
+        return fail(h, GPF_ERR_STATE, "sharded filters resample through the shard-level API (sharded.py)");
+    const bool sorted = method == GPF_RESAMPLE_STRATIFIED && sort_particles;
+    const bool need_sync = check == GPF_CHECK_TRUE || invalid != nullptr;
+    gpf_status s;
+    // sortperm(log_priorities, rev=true)  (resample.jl:156-157)
+    if (sorted) {
+        if ((s = ensure_sort_buffers(h))) return s;
+        hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, pv, h->n, h->keys);
+        HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, h->sort_tmp_bytes, h->keys, h->keys_out, h->idx_in, h->order,
+                                                      (int)h->n, 0, 64, h->stream));
+    }
+    // safe_softmax(log_priorities) (resample.jl:54) and logsumexp(log_weights) (resample.jl:180)
+    WSum* ws;
+    const int res_op = method == GPF_RESAMPLE_RESIDUAL ? OP_RESIDUAL_PREP : 0;
+    if (pv.mode == 0) {
+        ws = &h->sc->raw;
+        if (!h->raw_valid || sorted) {
+            if ((s = summarize(h, pv, ws, h->cdf[0], h->desc[0], sorted ? h->order : nullptr, 0))) return s;
+        }
+    } else {
+        if ((s = ensure_raw(h))) return s;                       // raw summary (cdf[0] is overwritten next; only S, m matter)
+        ws = &h->sc->prio;
+        if ((s = summarize(h, pv, ws, h->cdf[0], h->desc[0], sorted ? h->order : nullptr, 0))) return s;
+    }
+    h->raw_valid = false;                                        // cdf[0] no longer the plain raw CDF / lw about to change
+    if (need_sync) {
+        if ((s = fetch_scalars(h))) return s;
+        const WSum& w = pv.mode == 0 ? h->h_sc->raw : h->h_sc->prio;
+        const bool inv = w.flags != 0;
+        if (invalid) *invalid = inv ? 1 : 0;
+        if (w.flags & (FLAG_NAN | FLAG_POSINF)) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights (NaN).");
+        if (check == GPF_CHECK_TRUE && inv) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights.");   // resample.jl:55
+    }
+    // update_lml_est! (resample.jl:57,178-182) + residual shift
+    hipLaunchKernelGGL(k_scalar, dim3(1), dim3(BLOCK), 0, h->stream, OP_LML_ACCUM | res_op, h->sc, ws, h->blockQ, 0, h->K,
+                       h->cfg.n_global, h->logN);
+    // ancestors
+    SearchArgs sa{};
+    sa.cdf = h->cdf[0]; sa.desc = h->desc[0]; sa.ntiles = h->ntiles; sa.ccdf = nullptr; sa.cdesc = nullptr;
+    sa.order = sorted ? h->order : nullptr; sa.sc = h->sc; sa.ws = ws; sa.n = h->n; sa.n_global = h->cfg.n_global;
+    sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch; sa.anc = h->anc;
+    const int gsr = grid_for(h, h->n, 4);
+    if (method == GPF_RESAMPLE_RESIDUAL) {
+        if ((s = ensure_residual_buffers(h))) return s;
+        HIP_TRY(h, hipMemsetAsync(h->desc[1], 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->desc[2], 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
+        const int gs = scan_grid(h);
+        InResidual inc{h->cdf[0], h->sc, ws, h->cfg.n_global, 0};
+        InResidual inr{h->cdf[0], h->sc, ws, h->cfg.n_global, 1};
+        hipLaunchKernelGGL((k_scan<InResidual, false>), dim3(gs), dim3(BLOCK), 0, h->stream, inc, h->n, h->ntiles, nullptr, nullptr, 0,
+                           nullptr, h->cdf[1], h->desc[1], &h->sc->Ctot, nullptr);
+        hipLaunchKernelGGL((k_scan<InResidual, false>), dim3(gs), dim3(BLOCK), 0, h->stream, inr, h->n, h->ntiles, nullptr, nullptr, 0,
+                           nullptr, h->cdf[2], h->desc[2], &h->sc->Rs, nullptr);
+        sa.cdf = h->cdf[2]; sa.desc = h->desc[2]; sa.ccdf = h->cdf[1]; sa.cdesc = h->desc[1];
+    }
+    const size_t lds = ((method == GPF_RESAMPLE_RESIDUAL ? 2 : 1) * h->ntiles <= LDS_TILE_TABLE)
+                           ? (size_t)(method == GPF_RESAMPLE_RESIDUAL ? 2 : 1) * h->ntiles * sizeof(uint64_t) : 0;
+    s = timed(h, GPF_K_SEARCH, [&] {
+        switch (method) {
+            case GPF_RESAMPLE_MULTINOMIAL: hipLaunchKernelGGL((k_search<0>), dim3(gsr), dim3(BLOCK), lds, h->stream, sa); break;
+            case GPF_RESAMPLE_RESIDUAL:    hipLaunchKernelGGL((k_search<1>), dim3(gsr), dim3(BLOCK), lds, h->stream, sa); break;
+            default:                       hipLaunchKernelGGL((k_search<2>), dim3(gsr), dim3(BLOCK), lds, h->stream, sa); break;
+        }
+    });
+    if (s) return s;
+    // gather + update_weights! (resample.jl:60,190-202), update_refs! (utils.jl:10-15)
+    s = timed(h, GPF_K_GATHER, [&] { launch_gather(h, pv, pv.mode == 0 ? h->lw : h->lws); });
+    if (s) return s;
+    h->cur ^= 1;
+    if (pv.mode != 0) {
+        PrioView post{h->lws, nullptr, 0.0, 0};
+        if ((s = summarize(h, post, &h->sc->post, nullptr, h->desc[0], nullptr, 0))) return s;
+        hipLaunchKernelGGL(k_apply_post, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->sc, h->K, h->logN, h->lws, h->lw, h->n);
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->epoch += 1;
+    return GPF_OK;
+}
+
+} // namespace
+
+// =================================================================================== C ABI
+extern "C" {
+
+int gpf_abi_version(void) { return GPF_ABI_VERSION; }
+
+const char* gpf_last_error(gpf_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
+{
+    if (!cfg || !out) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null config/out");
+    *out = nullptr;
+    if (cfg->abi_version != GPF_ABI_VERSION) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "ABI version mismatch");
+    const int d = model_dim(cfg->model);
+    if (d == 0) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "unknown model id");
+    if (cfg->n_params < 0 || cfg->n_params > MAX_PARAMS || (cfg->n_params > 0 && !cfg->params))
+        return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "bad parameter vector");
+    if (cfg->n_particles < 1 || cfg->n_global < cfg->n_particles || cfg->gid0 < 0 ||
+        cfg->gid0 + cfg->n_particles > cfg->n_global || cfg->n_global >= ((int64_t)1 << 31))
+        return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "bad particle counts (need 1 <= n <= n_global < 2^31)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, GPF_ERR_NO_DEVICE, "no HIP device: libgpf_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "bad device ordinal");
+
+    gpf_filter* h = new gpf_filter();
+    h->cfg = *cfg;
+    h->cfg.params = nullptr;
+    for (int i = 0; i < cfg->n_params; ++i) h->args.P[i] = cfg->params[i];
+    h->d = d;
+    h->W = row_width(d, cfg->keep_prev != 0);
+    h->n = cfg->n_particles;
+    h->ntiles = (h->n + TILE - 1) / TILE;
+    h->K = fix_K(cfg->n_global);
+    h->logN = log_((double)cfg->n_global);
+    gpf_status st = GPF_OK;
+    auto body = [&]() -> gpf_status {
+        HIP_TRY(h, hipSetDevice(cfg->device));
+        hipDeviceProp_t prop;
+        HIP_TRY(h, hipGetDeviceProperties(&prop, cfg->device));
+        h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
+        else { HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+        const size_t n = (size_t)h->n, rb = n * (size_t)h->W * sizeof(double);
+        HIP_TRY(h, hipMalloc(&h->rows[0], rb));
+        HIP_TRY(h, hipMalloc(&h->rows[1], rb));
+        HIP_TRY(h, hipMalloc(&h->lw, n * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->lws, n * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->lp, n * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->dtmp, n * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->cdf[0], n * sizeof(uint64_t)));
+        const size_t db = (((size_t)h->ntiles * sizeof(uint64_t)) + 15) & ~(size_t)15;
+        for (int i = 0; i < 3; ++i) HIP_TRY(h, hipMalloc(&h->desc[i], db));
+        HIP_TRY(h, hipMalloc(&h->anc, n * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc(&h->pmax, MAX_PARTIALS * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->pflags, MAX_PARTIALS * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc(&h->blockQ, (size_t)4 * 2 * h->n_cu * sizeof(uint64_t) + 64));
+        HIP_TRY(h, hipMalloc(&h->partial, MAX_PARTIALS * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->dscal, 4 * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->sc, sizeof(Scalars)));
+        HIP_TRY(h, hipHostMalloc(&h->h_sc, sizeof(Scalars)));
+        HIP_TRY(h, hipMemsetAsync(h->sc, 0, sizeof(Scalars), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->lw, 0, n * sizeof(double), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->rows[0], 0, rb, h->stream));
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, h->n);   // parents = 1:N
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return GPF_OK;
+    };
+    st = body();
+    if (st != GPF_OK) { g_err = h->err; gpf_destroy(h); return st; }
+    *out = h;
+    return GPF_OK;
+}
+
+gpf_status gpf_destroy(gpf_handle h)
+{
+    if (!h) return GPF_OK;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    void* bufs[] = {h->rows[0], h->rows[1], h->lw, h->lws, h->lp, h->dtmp, h->cdf[0], h->cdf[1], h->cdf[2], h->desc[0], h->desc[1],
+                    h->desc[2], h->anc, h->order, h->idx_in, h->keys, h->keys_out, h->sort_tmp, h->pmax, h->pflags, h->blockQ,
+                    h->partial, h->dscal, h->sc};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (h->h_sc) hipHostFree(h->h_sc);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return GPF_OK;
+}
+
+gpf_status gpf_synchronize(gpf_handle h)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GPF_OK;
+}
+
+gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    gpf_status s = set_obs(h, obs, n_obs);
+    if (s) return s;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const int grid = grid_for(h, h->n, 8);
+    s = timed(h, GPF_K_STEP, [&] { DISPATCH_MODEL(h, launch_init_t<MM>(h, grid)); });
+    if (s) return s;
+    hipLaunchKernelGGL(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
+    HIP_TRY(h, hipMemsetAsync(&h->sc->lml_est, 0, sizeof(double), h->stream));                   // log_ml_est = 0.
+    HIP_TRY(h, hipGetLastError());
+    h->epoch += 1;
+    h->initialized = true;
+    h->has_prev = false;
+    h->raw_valid = false;
+    return GPF_OK;
+}
+
+gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if ((s = set_obs(h, obs, n_obs))) return s;
+    const int grid = grid_for(h, h->n, 8);
+    const bool keep = h->cfg.keep_prev != 0;
+    s = timed(h, GPF_K_STEP, [&] {
+        if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true>(h, grid))); }
+        else      { DISPATCH_MODEL(h, (launch_step_t<MM, false>(h, grid))); }
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
+    h->epoch += 1;
+    h->has_prev = true;
+    h->raw_valid = false;
+    return GPF_OK;
+}
+
+gpf_status gpf_resample(gpf_handle h, int32_t method, double priority_alpha, int32_t sort_particles, int32_t check,
+                        int32_t* invalid)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    PrioView pv = raw_view(h);
+    if (priority_alpha == priority_alpha) { pv.alpha = priority_alpha; pv.mode = 1; }
+    return resample_impl(h, method, pv, sort_particles, check, invalid);
+}
+
+gpf_status gpf_resample_with_priorities(gpf_handle h, int32_t method, const double* log_priorities, int32_t sort_particles,
+                                        int32_t check, int32_t* invalid)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!log_priorities) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null log_priorities");
+    HIP_TRY(h, hipMemcpyAsync(h->lp, log_priorities, (size_t)h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    PrioView pv{h->lw, h->lp, 0.0, 2};
+    return resample_impl(h, method, pv, sort_particles, check, invalid);
+}
+
+gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_t* n_accepted)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (method != GPF_REJUVENATE_MOVE && method != GPF_REJUVENATE_REWEIGHT)
+        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Method not recognized.");                        // rejuvenate.jl:25
+    if (!h->cfg.keep_prev) return fail(h, GPF_ERR_STATE, "gpf_rejuvenate needs keep_prev = 1 (x_{t-1} must travel with the particle)");
+    if (n_iters < 0) return fail(h, GPF_ERR_INVALID_ARGUMENT, "n_iters < 0");
+    HIP_TRY(h, hipMemsetAsync(&h->sc->n_accept, 0, sizeof(uint64_t), h->stream));
+    const int grid = grid_for(h, h->n, 8);
+    s = timed(h, GPF_K_MOVE, [&] {
+        if (method == GPF_REJUVENATE_REWEIGHT) { DISPATCH_MODEL(h, (launch_move_t<MM, true>(h, grid, n_iters))); }
+        else                                   { DISPATCH_MODEL(h, (launch_move_t<MM, false>(h, grid, n_iters))); }
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->cur ^= 1;
+    h->epoch += 1;
+    if (method == GPF_REJUVENATE_REWEIGHT) h->raw_valid = false;
+    if (n_accepted) {
+        if ((s = fetch_scalars(h))) return s;
+        *n_accepted = h->h_sc->n_accept;
+    }
+    return GPF_OK;
+}
+
+gpf_status gpf_effective_sample_size(gpf_handle h, double* out)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
+    if ((s = ensure_raw(h))) return s;
+    if ((s = fetch_scalars(h))) return s;
+    const WSum& w = h->h_sc->raw;
+    if (w.flags) { *out = std::nan(""); return GPF_OK; }
+    uint64_t hi, lo;
+    normalise_Q(w, hi, lo);
+    *out = ess_from(w.S, hi, lo);
+    return GPF_OK;
+}
+
+gpf_status gpf_log_ml_estimate(gpf_handle h, double* out)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
+    if ((s = ensure_raw(h))) return s;
+    if ((s = fetch_scalars(h))) return s;
+    const WSum& w = h->h_sc->raw;
+    *out = h->h_sc->lml_est + lse_from(w.m, w.S, h->K, w.flags) - h->logN;
+    return GPF_OK;
+}
+
+static gpf_status copy_out(gpf_handle h, const void* dsrc, void* out, size_t bytes)
+{
+    HIP_TRY(h, hipMemcpyAsync(out, dsrc, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GPF_OK;
+}
+
+gpf_status gpf_get_log_weights(gpf_handle h, double* out, int64_t n)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!out || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
+    return copy_out(h, h->lw, out, (size_t)n * sizeof(double));
+}
+
+static gpf_status norm_weights(gpf_handle h, double* out, int64_t n, int want_log)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!out || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
+    if ((s = ensure_raw(h))) return s;
+    hipLaunchKernelGGL(k_norm_weights, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->n, want_log,
+                       h->dtmp);
+    return copy_out(h, h->dtmp, out, (size_t)n * sizeof(double));
+}
+gpf_status gpf_get_log_norm_weights(gpf_handle h, double* out, int64_t n) { return norm_weights(h, out, n, 1); }
+gpf_status gpf_get_norm_weights(gpf_handle h, double* out, int64_t n) { return norm_weights(h, out, n, 0); }
+
+gpf_status gpf_get_parents(gpf_handle h, int64_t* out, int64_t n)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (!out || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
+    hipLaunchKernelGGL(k_parents, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, h->n, reinterpret_cast<int64_t*>(h->dtmp));
+    return copy_out(h, h->dtmp, out, (size_t)n * sizeof(int64_t));
+}
+
+gpf_status gpf_state_dim(gpf_handle h, int32_t* dim, int32_t* row_width_out)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (dim) *dim = h->d;
+    if (row_width_out) *row_width_out = h->W;
+    return GPF_OK;
+}
+
+gpf_status gpf_get_column(gpf_handle h, int32_t column, double* out, int64_t n)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!out || n != h->n || column < 0 || column >= h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad column/output");
+    hipLaunchKernelGGL(k_extract_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, column, h->n, h->dtmp);
+    return copy_out(h, h->dtmp, out, (size_t)n * sizeof(double));
+}
+
+gpf_status gpf_get_rows(gpf_handle h, double* out, int64_t n_doubles)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!out || n_doubles != h->n * h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
+    return copy_out(h, h->rows[h->cur], out, (size_t)n_doubles * sizeof(double));
+}
+
+gpf_status gpf_set_rows(gpf_handle h, const double* rows, int64_t n_doubles)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (!rows || n_doubles != h->n * h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
+    HIP_TRY(h, hipMemcpyAsync(h->rows[h->cur], rows, (size_t)n_doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->initialized = true;
+    return GPF_OK;
+}
+
+gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (!lw || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
+    HIP_TRY(h, hipMemcpyAsync(h->lw, lw, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->raw_valid = false;
+    h->initialized = true;
+    return GPF_OK;
+}
+
+static gpf_status wstat(gpf_handle h, int32_t column, double* out, bool variance)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!out || column < 0 || column >= h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad column/output");
+    if ((s = ensure_raw(h))) return s;
+    const int g = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_wsum, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->rows[h->cur], h->W, column, h->n, 1,
+                       nullptr, h->partial);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
+    if (variance) {
+        hipLaunchKernelGGL(k_wsum, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->rows[h->cur], h->W, column, h->n, 2,
+                           h->dscal, h->partial);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal + 1);
+    }
+    double tmp[2];
+    if ((s = copy_out(h, h->dscal, tmp, sizeof(tmp)))) return s;
+    *out = variance ? tmp[1] : tmp[0];
+    return GPF_OK;
+}
+gpf_status gpf_mean(gpf_handle h, int32_t column, double* out) { return wstat(h, column, out, false); }
+gpf_status gpf_var(gpf_handle h, int32_t column, double* out) { return wstat(h, column, out, true); }
+
+gpf_status gpf_kernel_timing(gpf_handle h, int32_t id, int32_t enable)
+{
+    if (!h || id < 0 || id >= GPF_K_COUNT) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad kernel id");
+    Timer& t = h->timers[id];
+    for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    t.ev.clear();
+    t.on = enable != 0;
+    return GPF_OK;
+}
+
+gpf_status gpf_kernel_time(gpf_handle h, int32_t id, double* total_ms, int64_t* launches)
+{
+    if (!h || id < 0 || id >= GPF_K_COUNT) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad kernel id");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    double tot = 0.0;
+    for (auto& e : h->timers[id].ev) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, e.first, e.second));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)h->timers[id].ev.size();
+    return GPF_OK;
+}
+
+gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const double* b, int64_t n, double* out, double* out2)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (!a || !out || n < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arrays");
+    double *da = nullptr, *db = nullptr, *d1 = nullptr, *d2 = nullptr;
+    const size_t bytes = (size_t)n * sizeof(double);
+    HIP_TRY(h, hipMalloc(&da, bytes)); HIP_TRY(h, hipMalloc(&db, bytes));
+    HIP_TRY(h, hipMalloc(&d1, bytes)); HIP_TRY(h, hipMalloc(&d2, bytes));
+    HIP_TRY(h, hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(db, b ? b : a, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(d2, 0, bytes, h->stream));
+    hipLaunchKernelGGL(k_debug_math, dim3(grid_for(h, n, 8)), dim3(BLOCK), 0, h->stream, which, da, db, n, h->cfg.seed, h->epoch,
+                       (uint32_t)TAG_UPDATE, d1, d2);
+    HIP_TRY(h, hipMemcpyAsync(out, d1, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (out2) HIP_TRY(h, hipMemcpyAsync(out2, d2, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    hipFree(da); hipFree(db); hipFree(d1); hipFree(d2);
+    return GPF_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,118 @@
+"""Native model descriptors: the device-side replacement of the `model::GenerativeFunction`
+argument of pf_initialize (reference src/initialize.jl:31-35).  A descriptor is just
+(model id, parameter vector); the parameter layout is that of csrc/gpf_models.hpp.
+
+The reference ships no benchmark models; the three state-space models of
+BASELINE.json and the README's object_motion are defined here, with the synthetic data
+generators of SURVEY.md §8d (data seed 20240001)."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+MODEL_LGSSM2, MODEL_BEARINGS4, MODEL_SV1, MODEL_OBJECT_MOTION = 1, 2, 3, 4
+DATA_SEED = 20240001
+_HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+@dataclass
+class NativeModel:
+    model_id: int
+    name: str
+    dim: int
+    obs_dim: int
+    params: np.ndarray
+    info: dict = field(default_factory=dict)
+
+    def row_width(self, keep_prev: bool) -> int:
+        w = 2 * self.dim if keep_prev else self.dim
+        return w + (w & 1)
+
+
+def lgssm2(theta: float = 0.1, rho: float = 0.99, sq: float = 0.1, sr: float = 0.5, s0: float = 1.0) -> NativeModel:
+    """x' = A x + N(0, sq^2 I), y = x + N(0, sr^2 I), A = rho * rot(theta), x1 ~ N(0, s0^2 I)."""
+    a11, a12 = rho * math.cos(theta), -rho * math.sin(theta)
+    a21, a22 = rho * math.sin(theta), rho * math.cos(theta)
+    p = np.array([a11, a12, a21, a22, sq, s0, 1.0 / sr, 2.0 * (math.log(sr) + _HALF_LOG_2PI)])
+    return NativeModel(MODEL_LGSSM2, "lgssm2", 2, 2, p,
+                       dict(A=np.array([[a11, a12], [a21, a22]]), sq=sq, sr=sr, s0=s0))
+
+
+def bearings4(mu=(-0.05, 0.2, 0.001, -0.055), s=(0.5, 0.3, 0.005, 0.01), sp: float = 0.001, sv: float = 0.001,
+              sb: float = 0.005) -> NativeModel:
+    p = np.array(list(mu) + list(s) + [sp, sv, 1.0 / sb, math.log(sb) + _HALF_LOG_2PI])
+    return NativeModel(MODEL_BEARINGS4, "bearings4", 4, 1, p, dict(mu=mu, s=s, sp=sp, sv=sv, sb=sb))
+
+
+def sv1(mu: float = -1.0, phi: float = 0.97, sigma: float = 0.15) -> NativeModel:
+    p = np.array([mu, phi, sigma, sigma / math.sqrt(1.0 - phi * phi), _HALF_LOG_2PI])
+    return NativeModel(MODEL_SV1, "sv1", 1, 1, p, dict(mu=mu, phi=phi, sigma=sigma))
+
+
+def object_motion(p_stay: float = 0.75, p_start: float = 0.25, sy: float = 0.01, sobs: float = 0.25) -> NativeModel:
+    """README.md:43-55 of the reference.  Per-step data vector = [y_obs, sin(t)]."""
+    p = np.array([p_stay, p_start, sy, 1.0 / sobs, math.log(sobs) + _HALF_LOG_2PI])
+    return NativeModel(MODEL_OBJECT_MOTION, "object_motion", 2, 2, p, dict(sy=sy, sobs=sobs))
+
+
+def by_name(name: str) -> NativeModel:
+    return {"lgssm2": lgssm2, "bearings4": bearings4, "sv1": sv1, "object_motion": object_motion}[name]()
+
+
+# ----------------------------------------------------------------------------- synthetic data
+def simulate(model: NativeModel, T: int, seed: int = DATA_SEED) -> np.ndarray:
+    """One trajectory from the model; returns the (T, obs_dim) array of per-step data vectors."""
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    P = model.params
+    out = np.zeros((T, model.obs_dim))
+    if model.model_id == MODEL_LGSSM2:
+        A, sq, sr, s0 = model.info["A"], model.info["sq"], model.info["sr"], model.info["s0"]
+        x = s0 * rng.standard_normal(2)
+        for t in range(T):
+            if t > 0:
+                x = A @ x + sq * rng.standard_normal(2)
+            out[t] = x + sr * rng.standard_normal(2)
+    elif model.model_id == MODEL_BEARINGS4:
+        x = np.array(P[0:4]) + np.array(P[4:8]) * rng.standard_normal(4)
+        for t in range(T):
+            if t > 0:
+                z = rng.standard_normal(4)
+                x = np.array([x[0] + x[2] + P[8] * z[0], x[1] + x[3] + P[8] * z[1], x[2] + P[9] * z[2], x[3] + P[9] * z[3]])
+            out[t, 0] = math.atan2(x[1], x[0]) + model.info["sb"] * rng.standard_normal()
+    elif model.model_id == MODEL_SV1:
+        mu, phi, sigma = P[0], P[1], P[2]
+        h = mu + P[3] * rng.standard_normal()
+        for t in range(T):
+            if t > 0:
+                h = mu + phi * (h - mu) + sigma * rng.standard_normal()
+            out[t, 0] = math.exp(0.5 * h) * rng.standard_normal()
+    elif model.model_id == MODEL_OBJECT_MOTION:
+        # README.md:87-91: still for the first half, moving for the second
+        y = 0.0
+        for t in range(1, T + 1):
+            moving = t > T // 2
+            y = y + (math.sin(t) if moving else 0.0) + model.info["sy"] * rng.standard_normal()
+            out[t - 1] = (y + model.info["sobs"] * rng.standard_normal(), math.sin(t))
+    else:
+        raise ValueError("unknown model")
+    return out
+
+
+def kalman_loglik(model: NativeModel, ys: np.ndarray) -> float:
+    """Exact log p(y_1:T) of the linear-Gaussian SSM (known answer for the particle log-ML estimate)."""
+    assert model.model_id == MODEL_LGSSM2
+    A, sq, sr, s0 = model.info["A"], model.info["sq"], model.info["sr"], model.info["s0"]
+    m, Pm = np.zeros(2), (s0 ** 2) * np.eye(2)
+    Q, R = (sq ** 2) * np.eye(2), (sr ** 2) * np.eye(2)
+    ll = 0.0
+    for t in range(ys.shape[0]):
+        if t > 0:
+            m, Pm = A @ m, A @ Pm @ A.T + Q
+        S = Pm + R
+        e = ys[t] - m
+        ll += -0.5 * (e @ np.linalg.solve(S, e) + math.log(np.linalg.det(S)) + 2.0 * math.log(2.0 * math.pi))
+        Kg = Pm @ np.linalg.inv(S)
+        m, Pm = m + Kg @ e, (np.eye(2) - Kg) @ Pm
+    return float(ll)

@@ -1,0 +1,161 @@
+/*
+ * gpf.h -- C ABI of libgpf_hip.so: the MI355X (gfx950) particle-filter hot path behind the
+ * pf_initialize / pf_update! / pf_resample! / pf_rejuvenate! API of GenParticleFilters.jl.
+ *
+ * The reference has no FFI: its boundary is Julia multiple dispatch on
+ * ParticleFilterView (reference src/view.jl:32-33).  A drop-in therefore is a new state type
+ * whose methods ccall the entry points below (julia/GenParticleFiltersAMD.jl).
+ * Every entry point names the reference method it replaces (paths relative to the reference
+ * repository root, v0.2.3).
+ *
+ * Conventions
+ *   - plain C types only; no C++/torch types cross this boundary.
+ *   - every function returns a gpf_status; nothing throws across the ABI.  The Julia glue maps
+ *     a non-zero status to error(gpf_last_error(h)) (ErrorException, like the reference's error()).
+ *   - the handle owns all device buffers; host arrays passed in or out belong to the caller.
+ *   - one handle = one host thread at a time.  Work is enqueued on one HIP stream; calls that
+ *     return a scalar or fill a host array synchronise that stream, all others are asynchronous.
+ *   - particle state is Float64; ancestor indices are reported 1-based Int64 into the
+ *     PRE-resample particle array, exactly like state.parents (reference test/resample.jl:11).
+ *   - there is no CPU fallback: gpf_create fails if no gfx950 device is usable.
+ */
+#ifndef GPF_H
+#define GPF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPF_ABI_VERSION 1
+
+typedef struct gpf_filter* gpf_handle;
+
+typedef enum {
+    GPF_OK = 0,
+    GPF_ERR_INVALID_ARGUMENT = 1,
+    GPF_ERR_INVALID_WEIGHTS = 2,   /* error("Invalid weights.")            src/resample.jl:55,92,151 */
+    GPF_ERR_UNKNOWN_METHOD = 3,    /* error("... method ... not recognized") src/resample.jl:28, src/rejuvenate.jl:25 */
+    GPF_ERR_HIP = 4,               /* a HIP runtime call failed; see gpf_last_error */
+    GPF_ERR_NO_DEVICE = 5,
+    GPF_ERR_STATE = 6              /* operation not valid in the current state (e.g. update before initialize) */
+} gpf_status;
+
+/* native models (the reference runs arbitrary Gen programs; the hot path runs these compiled ones) */
+typedef enum {
+    GPF_MODEL_LGSSM2 = 1,          /* 2-D linear-Gaussian SSM              (BASELINE configs 2,3) */
+    GPF_MODEL_BEARINGS4 = 2,       /* bearings-only tracking, 4-D          (BASELINE config 4)   */
+    GPF_MODEL_SV1 = 3,             /* stochastic volatility, 1-D           (BASELINE config 5)   */
+    GPF_MODEL_OBJECT_MOTION = 4    /* reference README.md:43-55            (BASELINE config 1)   */
+} gpf_model;
+
+/* method::Symbol of pf_resample! (src/resample.jl:19-30) */
+typedef enum { GPF_RESAMPLE_MULTINOMIAL = 0, GPF_RESAMPLE_RESIDUAL = 1, GPF_RESAMPLE_STRATIFIED = 2 } gpf_resample_method;
+/* method::Symbol of pf_rejuvenate! (src/rejuvenate.jl:18-27) */
+typedef enum { GPF_REJUVENATE_MOVE = 0, GPF_REJUVENATE_REWEIGHT = 1 } gpf_rejuvenate_method;
+/* check keyword of the resamplers: true | :warn | false (src/resample.jl:43-46) */
+typedef enum { GPF_CHECK_FALSE = 0, GPF_CHECK_WARN = 1, GPF_CHECK_TRUE = 2 } gpf_check;
+
+typedef struct {
+    int32_t  abi_version;    /* GPF_ABI_VERSION */
+    int32_t  model;          /* gpf_model */
+    int32_t  n_params;       /* <= 16 */
+    int32_t  keep_prev;      /* 1: rows also carry x_{t-1} (needed by gpf_rejuvenate) */
+    const double* params;    /* model parameters, layout in csrc/gpf_models.hpp */
+    int64_t  n_particles;    /* particles held by this handle (this shard) */
+    int64_t  n_global;       /* particles of the whole filter; == n_particles when unsharded */
+    int64_t  gid0;           /* global index of local particle 0 (RNG counters use global ids) */
+    uint64_t seed;           /* Philox key */
+    int32_t  device;         /* HIP device ordinal */
+    int32_t  reserved;
+    void*    stream;         /* hipStream_t to enqueue on, or NULL for a library-owned stream */
+} gpf_config;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int  gpf_abi_version(void);
+gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out);
+gpf_status gpf_destroy(gpf_handle h);
+const char* gpf_last_error(gpf_handle h);         /* valid until the next call on h; h may be NULL */
+gpf_status gpf_synchronize(gpf_handle h);
+
+/* ---- the four operations ------------------------------------------------------------------- */
+/* pf_initialize(model, model_args, observations, n_particles)      src/initialize.jl:31-44
+ * x_1 ~ prior, log_weights[i] = log p(obs | x_1), log_ml_est = 0, parents = 1:N. */
+gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs);
+
+/* pf_update!(state, new_args, argdiffs, observations)              src/update.jl:12-25
+ * x_t ~ p(. | x_{t-1}), log_weights[i] += log p(obs | x_t); buffers swap (update_refs!, src/utils.jl:10-15). */
+gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs);
+
+/* pf_resample!(state, method; priority_fn, check[, sort_particles])  src/resample.jl:19-175
+ *   priority_alpha: NaN -> priority_fn = nothing; otherwise priority_fn = w -> priority_alpha * w
+ *                   (the tempering family the reference's tests use, test/resample.jl:15).
+ *   sort_particles: only read by GPF_RESAMPLE_STRATIFIED (src/resample.jl:143-145, default true).
+ *   check:          GPF_CHECK_TRUE returns GPF_ERR_INVALID_WEIGHTS on invalid weights (src/resample.jl:55).
+ *   invalid:        if non-NULL receives safe_softmax's `invalid` flag (src/utils.jl:117-140); this
+ *                   synchronises the stream.  Pass NULL with check != TRUE for a fully asynchronous call.
+ * Weights containing NaN/+Inf always return GPF_ERR_INVALID_WEIGHTS when checked (the reference's
+ * Categorical constructor rejects NaN probabilities). */
+gpf_status gpf_resample(gpf_handle h, int32_t method, double priority_alpha, int32_t sort_particles,
+                        int32_t check, int32_t* invalid);
+
+/* same, with log_priorities = priority_fn.(log_weights) evaluated by the caller (any closure):
+ * log_priorities is a HOST array of n_particles doubles. */
+gpf_status gpf_resample_with_priorities(gpf_handle h, int32_t method, const double* log_priorities,
+                                        int32_t sort_particles, int32_t check, int32_t* invalid);
+
+/* pf_rejuvenate!(state, kern, kern_args, n_iters; method)          src/rejuvenate.jl:18-90
+ * native kernels: GPF_REJUVENATE_MOVE     = pf_move_accept!  with kern = Gen.mh(trace, select(current step))
+ *                 GPF_REJUVENATE_REWEIGHT = pf_move_reweight! with kern = move_reweight(trace, selection)
+ *                                           (src/rejuvenate.jl:125-132)
+ * n_accepted (may be NULL; non-NULL synchronises) replaces the per-particle @debug log
+ * (src/rejuvenate.jl:47). Requires keep_prev = 1. */
+gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_t* n_accepted);
+
+/* ---- weight summaries ---------------------------------------------------------------------- */
+/* effective_sample_size(state) / get_ess                            src/utils.jl:163-164,171 */
+gpf_status gpf_effective_sample_size(gpf_handle h, double* out);
+/* Gen.log_ml_estimate(state) / get_lml_est                          src/utils.jl:186 */
+gpf_status gpf_log_ml_estimate(gpf_handle h, double* out);
+/* Gen.get_log_weights(state) */
+gpf_status gpf_get_log_weights(gpf_handle h, double* out, int64_t n);
+/* get_log_norm_weights(state)                                       src/utils.jl:148 */
+gpf_status gpf_get_log_norm_weights(gpf_handle h, double* out, int64_t n);
+/* get_norm_weights(state)                                           src/utils.jl:156 */
+gpf_status gpf_get_norm_weights(gpf_handle h, double* out, int64_t n);
+/* state.parents (1-based, global)                                   test/resample.jl:11 */
+gpf_status gpf_get_parents(gpf_handle h, int64_t* out, int64_t n);
+
+/* ---- state access (Gen.get_traces: one latent address = one column) ------------------------- */
+gpf_status gpf_state_dim(gpf_handle h, int32_t* dim, int32_t* row_width);
+gpf_status gpf_get_column(gpf_handle h, int32_t column, double* out, int64_t n);
+gpf_status gpf_get_rows(gpf_handle h, double* out, int64_t n_doubles);          /* n_particles * row_width */
+gpf_status gpf_set_rows(gpf_handle h, const double* rows, int64_t n_doubles);   /* ParticleFilterState(trs, ws), src/initialize.jl:8-10 */
+gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n);
+
+/* ---- statistics ---------------------------------------------------------------------------- */
+/* mean(state, addr)                                                 src/statistics.jl:13-14 */
+gpf_status gpf_mean(gpf_handle h, int32_t column, double* out);
+/* var(state, addr)  (population form)                               src/statistics.jl:48-50 */
+gpf_status gpf_var(gpf_handle h, int32_t column, double* out);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
+/* kernel ids for gpf_kernel_time */
+typedef enum { GPF_K_STEP = 0, GPF_K_MAX = 1, GPF_K_SCAN = 2, GPF_K_SEARCH = 3, GPF_K_GATHER = 4,
+               GPF_K_MOVE = 5, GPF_K_COUNT = 6 } gpf_kernel_id;
+/* enable!=0: bracket every launch of kernel `id` with hipEvents on the handle's stream */
+gpf_status gpf_kernel_timing(gpf_handle h, int32_t id, int32_t enable);
+/* synchronises; total elapsed milliseconds and number of launches since timing was enabled */
+gpf_status gpf_kernel_time(gpf_handle h, int32_t id, double* total_ms, int64_t* launches);
+
+/* device-side math spec, for the bitwise host/device parity tests (tests/test_math_parity.py):
+ * which: 0 exp, 1 log, 2 sincos2pi (out=sin,out2=cos), 3 atan2(a,b), 4 sqrt, 5 a/b,
+ *        6 normal2 from counters (a=gid as double, b=blk as double; seed/epoch/tag via the handle) */
+gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const double* b, int64_t n,
+                          double* out, double* out2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPF_H */

@@ -1,0 +1,431 @@
+/*
+ * gpf_oracle.c -- TEST INFRASTRUCTURE ONLY.  CPU oracle for the particle-filter hot path.
+ *
+ * Array-level primitives in plain C that restate, for struct-of-rows Float64 particle state,
+ * the algorithms of GenParticleFilters.jl (reference @ v0.2.3, paths relative to /root/reference):
+ *   src/initialize.jl:31-44   pf_initialize            -> o_init
+ *   src/update.jl:12-25       pf_update!               -> o_step
+ *   src/rejuvenate.jl:40-90   pf_move_accept!/reweight -> o_move
+ *   src/utils.jl:100-140      lognorm/softmax/safe_softmax  -> o_max_flags, o_fixq, o_scan
+ *   src/utils.jl:163-164      effective_sample_size    -> o_ess_from
+ *   src/resample.jl:48-175    three resamplers         -> o_targets_*, o_upper_bound, o_residual_split
+ *   src/resample.jl:178-202   update_lml_est!/update_weights! -> o_lse_from (+ python composition)
+ *   src/statistics.jl:13-14,48-50  mean / var          -> o_wsum
+ * The composition of these primitives into pf_* operations is in oracle/oracle.py, which cites
+ * the reference line for every statement.
+ *
+ * PARITY STATUS: the reference cannot be executed in the build container (Julia absent) and its
+ * tests hold no golden vectors or seeds, so for RANDOM STREAMS (ancestor indices,
+ * sampled states) parity is UNPINNED: this oracle is the definition.  Deterministic arithmetic is
+ * pinned against the invariants the reference's tests assert (tests/test_oracle_reference_invariants.py)
+ * and against oracle/ref_literal.c, a line-by-line Float64 restatement of src/resample.jl and
+ * src/utils.jl driven by the same indexed uniforms.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * All integer weight arithmetic is exact and order-independent: the same inputs
+ * give the same ancestors on 1 thread, on the GPU, or sharded over G GPUs.
+ */
+#include "gpf_oracle_math.h"
+#include <stdlib.h>
+
+#define O_EXPORT __attribute__((visibility("default")))
+
+enum { O_MODEL_LGSSM2 = 1, O_MODEL_BEARINGS4 = 2, O_MODEL_SV1 = 3, O_MODEL_OBJECT_MOTION = 4 };
+enum { O_FLAG_NAN = 1, O_FLAG_POSINF = 2, O_FLAG_ALL_NEGINF = 4 };
+
+/* ------------------------------------------------------------------ scalar helpers (exported) */
+O_EXPORT double o_log_d(double x) { return o_log(x); }
+O_EXPORT double o_exp_d(double x) { return o_exp(x); }
+O_EXPORT uint64_t o_exp_fix_d(double d, int K) { return o_exp_fix(d, K); }
+O_EXPORT double o_atan2_d(double y, double x) { return o_atan2(y, x); }
+O_EXPORT void o_sincos2pi_d(double u, double *s, double *c) { o_sincos2pi(u, s, c); }
+O_EXPORT void o_philox_d(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                         uint32_t *out)
+{
+    o_philox_t r = o_philox4x32_10(c0, c1, c2, c3, k0, k1);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+O_EXPORT void o_normal2_d(uint64_t seed, uint32_t gid, uint32_t blk, uint32_t epoch, uint32_t tag,
+                          double *z0, double *z1)
+{
+    o_normal2(o_rng(seed, gid, blk, epoch, tag), z0, z1);
+}
+O_EXPORT double o_u52_d(uint64_t seed, uint32_t gid, uint32_t blk, uint32_t epoch, uint32_t tag)
+{
+    o_philox_t b = o_rng(seed, gid, blk, epoch, tag);
+    return o_u52(b.v[0], b.v[1]);
+}
+
+/* vectorised math, for the bitwise product-vs-oracle math tests */
+O_EXPORT void o_math_vec(int which, const double *a, const double *b, int64_t n, double *out, double *out2)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        switch (which) {
+            case 0: out[i] = o_exp(a[i]); break;
+            case 1: out[i] = o_log(a[i]); break;
+            case 2: o_sincos2pi(a[i], &out[i], &out2[i]); break;
+            case 3: out[i] = o_atan2(a[i], b[i]); break;
+            case 4: out[i] = sqrt(a[i]); break;
+            case 5: out[i] = a[i] / b[i]; break;
+            default: out[i] = 0.0;
+        }
+    }
+}
+
+/* K = min(52, 62 - ceil(log2 N)): N * 2^K <= 2^62, so any sum of N fixed-point weights fits in
+ * 62 bits (the top two bits of a u64 stay free for the device scan's status field). */
+O_EXPORT int o_fix_K(int64_t n_global)
+{
+    int cl = 0;
+    while (((int64_t)1 << cl) < n_global) ++cl;
+    int K = 62 - cl;
+    return K > 52 ? 52 : K;
+}
+
+/* logsumexp from the exact integer sum: m + log(S * 2^-K)  (resample.jl:180, utils.jl:100) */
+O_EXPORT double o_lse_from(double m, uint64_t S, int K, int flags)
+{
+    if (flags & (O_FLAG_NAN | O_FLAG_POSINF)) return NAN;
+    if (flags & O_FLAG_ALL_NEGINF) return -INFINITY;
+    double Sd = (double)S;                     /* correctly rounded u64 -> f64 */
+    return m + o_log(Sd * o_pow2(-K));         /* exact scaling */
+}
+/* ESS = (sum w)^2 / sum w^2 = S^2 / Q  (utils.jl:163-164; test/utils.jl:10) */
+O_EXPORT double o_ess_from(uint64_t S, uint64_t Qhi, uint64_t Qlo)
+{
+    double Sd = (double)S;
+    double Qd = (double)Qhi * 0x1p64 + (double)Qlo;
+    return (Sd * Sd) / Qd;
+}
+
+/* ------------------------------------------------------------------ models */
+static int model_dim(int model)
+{
+    switch (model) { case O_MODEL_LGSSM2: return 2; case O_MODEL_BEARINGS4: return 4;
+                     case O_MODEL_SV1: return 1; case O_MODEL_OBJECT_MOTION: return 2; }
+    return 0;
+}
+static int model_nblk(int model)
+{
+    switch (model) { case O_MODEL_LGSSM2: return 1; case O_MODEL_BEARINGS4: return 2;
+                     case O_MODEL_SV1: return 1; case O_MODEL_OBJECT_MOTION: return 2; }
+    return 0;
+}
+O_EXPORT int o_model_dim(int model) { return model_dim(model); }
+O_EXPORT int o_model_nblk(int model) { return model_nblk(model); }
+
+/* sample x_t ~ p(. | x_{t-1}) (first=0) or x_1 ~ prior (first=1); RNG blocks blk0.. of (gid,epoch,tag).
+ * This is what Gen's generate/update do for the unconstrained latent choices of the step
+ * (initialize.jl:40, update.jl:17). */
+static void model_sample(int model, const double *P, int first, const double *xp, const double *obs,
+                         uint64_t seed, uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag,
+                         double *xn)
+{
+    double z0, z1, z2, z3;
+    switch (model) {
+    case O_MODEL_LGSSM2: {
+        o_normal2(o_rng(seed, gid, blk0, epoch, tag), &z0, &z1);
+        if (first) { xn[0] = P[5] * z0; xn[1] = P[5] * z1; }
+        else {
+            double t0 = P[0] * xp[0] + P[1] * xp[1];
+            double t1 = P[2] * xp[0] + P[3] * xp[1];
+            xn[0] = t0 + P[4] * z0;
+            xn[1] = t1 + P[4] * z1;
+        }
+    } break;
+    case O_MODEL_BEARINGS4: {
+        o_normal2(o_rng(seed, gid, blk0, epoch, tag), &z0, &z1);
+        o_normal2(o_rng(seed, gid, blk0 + 1, epoch, tag), &z2, &z3);
+        if (first) {
+            xn[0] = P[0] + P[4] * z0; xn[1] = P[1] + P[5] * z1;
+            xn[2] = P[2] + P[6] * z2; xn[3] = P[3] + P[7] * z3;
+        } else {
+            xn[0] = (xp[0] + xp[2]) + P[8] * z0;
+            xn[1] = (xp[1] + xp[3]) + P[8] * z1;
+            xn[2] = xp[2] + P[9] * z2;
+            xn[3] = xp[3] + P[9] * z3;
+        }
+    } break;
+    case O_MODEL_SV1: {
+        o_normal2(o_rng(seed, gid, blk0, epoch, tag), &z0, &z1);
+        if (first) xn[0] = P[0] + P[3] * z0;
+        else       xn[0] = (P[0] + P[1] * (xp[0] - P[0])) + P[2] * z0;
+    } break;
+    case O_MODEL_OBJECT_MOTION: {
+        /* README.md:43-55: moving ~ bernoulli(moving ? 0.75 : 0.25); y ~ normal(y + vel, 0.01) */
+        o_philox_t b = o_rng(seed, gid, blk0, epoch, tag);
+        double u = o_u52(b.v[0], b.v[1]);
+        o_normal2(o_rng(seed, gid, blk0 + 1, epoch, tag), &z0, &z1);
+        double pm = first ? 0.0 : xp[0], py = first ? 0.0 : xp[1];
+        double p = (pm != 0.0) ? P[0] : P[1];
+        double mv = (u < p) ? 1.0 : 0.0;
+        double vel = (mv != 0.0) ? obs[1] : 0.0;
+        xn[0] = mv;
+        xn[1] = (py + vel) + P[2] * z0;
+    } break;
+    }
+}
+
+/* log p(y_t | x_t): the weight increment Gen returns for the newly constrained observation */
+static double model_loglik(int model, const double *P, const double *x, const double *obs)
+{
+    switch (model) {
+    case O_MODEL_LGSSM2: {
+        double z0 = (obs[0] - x[0]) * P[6], z1 = (obs[1] - x[1]) * P[6];
+        return -0.5 * (z0 * z0 + z1 * z1) - P[7];
+    }
+    case O_MODEL_BEARINGS4: {
+        const double PI = 3.14159265358979311600e+00, TWOPI = 6.28318530717958623200e+00;
+        double b = o_atan2(x[1], x[0]);
+        double r = obs[0] - b;
+        if (r > PI) r -= TWOPI; else if (r <= -PI) r += TWOPI;
+        double z = r * P[10];
+        return -0.5 * (z * z) - P[11];
+    }
+    case O_MODEL_SV1: {
+        double y = obs[0];
+        return (-0.5 * ((y * y) * o_exp(-x[0])) - 0.5 * x[0]) - P[4];
+    }
+    case O_MODEL_OBJECT_MOTION: {
+        double z = (obs[0] - x[1]) * P[3];
+        return -0.5 * (z * z) - P[4];
+    }
+    }
+    return 0.0;
+}
+
+/* pf_initialize default proposal, initialize.jl:39-41: x ~ prior, log_weights[i] = log p(y1|x) */
+O_EXPORT void o_init(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
+                     int W, const double *obs, double *rows, double *lw)
+{
+    int d = model_dim(model);
+    for (int64_t i = 0; i < n; ++i) {
+        double *r = rows + i * W;
+        for (int k = 0; k < W; ++k) r[k] = 0.0;
+        model_sample(model, P, 1, NULL, obs, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_INIT, r);
+        lw[i] = model_loglik(model, P, r, obs);
+        (void)d;
+    }
+}
+
+/* pf_update! default proposal, update.jl:15-22: x_t ~ p(.|x_{t-1}); log_weights[i] += increment.
+ * keep_prev: the row also carries x_{t-1} in columns d..2d-1. */
+O_EXPORT void o_step(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
+                     int W, int keep_prev, const double *obs, const double *rows_in, double *rows_out,
+                     double *lw)
+{
+    int d = model_dim(model);
+    for (int64_t i = 0; i < n; ++i) {
+        const double *ri = rows_in + i * W;
+        double *ro = rows_out + i * W;
+        double xn[4];
+        model_sample(model, P, 0, ri, obs, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_UPDATE, xn);
+        double ll = model_loglik(model, P, xn, obs);
+        double xp[4];
+        for (int k = 0; k < d; ++k) xp[k] = ri[k];
+        for (int k = 0; k < W; ++k) ro[k] = 0.0;
+        for (int k = 0; k < d; ++k) ro[k] = xn[k];
+        if (keep_prev) for (int k = 0; k < d; ++k) ro[d + k] = xp[k];
+        lw[i] = lw[i] + ll;
+    }
+}
+
+/* pf_move_accept! (rejuvenate.jl:40-53) with kern = Gen.mh(trace, select(current step latent)):
+ *   regenerate x_t from p(.|x_{t-1}) (or the prior when no previous step exists), accept iff
+ *   log(rand()) < weight, weight = log p(y_t|x*) - log p(y_t|x)   [Gen semantics, SURVEY App. B]
+ * pf_move_reweight! (rejuvenate.jl:74-90) with kern = move_reweight(trace, selection) (:125-132):
+ *   always move; log_weights[i] += sum of rel_weight.
+ * reweight = 0 -> move-accept, 1 -> move-reweight.  Returns number of accepted moves. */
+O_EXPORT uint64_t o_move(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
+                         int W, int has_prev, const double *obs, int n_iters, int reweight,
+                         const double *rows_in, double *rows_out, double *lw)
+{
+    int d = model_dim(model), nb = model_nblk(model);
+    uint64_t nacc = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *ri = rows_in + i * W;
+        double *ro = rows_out + i * W;
+        double x[4], xs[4];
+        const double *xp = ri + d;
+        for (int k = 0; k < d; ++k) x[k] = ri[k];
+        double llx = model_loglik(model, P, x, obs);
+        double wsum = 0.0;
+        for (int it = 0; it < n_iters; ++it) {
+            if (reweight) {
+                uint32_t blk0 = (uint32_t)(it * nb);
+                model_sample(model, P, !has_prev, xp, obs, seed, (uint32_t)(gid0 + i), blk0, epoch,
+                             O_TAG_REWEIGHT, xs);
+                double lls = model_loglik(model, P, xs, obs);
+                wsum = wsum + (lls - llx);                 /* rejuvenate.jl:82 */
+                for (int k = 0; k < d; ++k) x[k] = xs[k];
+                llx = lls;
+                nacc++;
+            } else {
+                uint32_t blk0 = (uint32_t)(it * (nb + 1));
+                model_sample(model, P, !has_prev, xp, obs, seed, (uint32_t)(gid0 + i), blk0, epoch,
+                             O_TAG_MOVE, xs);
+                double lls = model_loglik(model, P, xs, obs);
+                o_philox_t b = o_rng(seed, (uint32_t)(gid0 + i), blk0 + (uint32_t)nb, epoch, O_TAG_MOVE);
+                double lu = o_log(o_u52(b.v[0], b.v[1]));
+                if (lu < lls - llx) {                     /* Gen.mh: log(rand()) < weight */
+                    for (int k = 0; k < d; ++k) x[k] = xs[k];
+                    llx = lls;
+                    nacc++;
+                }
+            }
+        }
+        for (int k = 0; k < W; ++k) ro[k] = ri[k];
+        for (int k = 0; k < d; ++k) ro[k] = x[k];
+        if (reweight) lw[i] = lw[i] + wsum;               /* rejuvenate.jl:86 */
+    }
+    return nacc;
+}
+
+/* ------------------------------------------------------------------ weight normalisation */
+/* maximum + validity flags of safe_softmax (utils.jl:119-126): any NaN; all == -Inf; (+Inf present
+ * makes exp.(vs .- max) contain NaN -> "total weight is NaN" branch, utils.jl:134-137) */
+O_EXPORT void o_max_flags(const double *lp, int64_t n, double *m_out, int *flags_out)
+{
+    double m = -INFINITY; int nan = 0, pinf = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double v = lp[i];
+        if (v != v) nan = 1;
+        else { if (v > m) m = v; if (v == INFINITY) pinf = 1; }
+    }
+    int f = 0;
+    if (nan) f |= O_FLAG_NAN;
+    if (pinf) f |= O_FLAG_POSINF;
+    if (!nan && m == -INFINITY) f |= O_FLAG_ALL_NEGINF;
+    *m_out = m; *flags_out = f;
+}
+
+/* ws = exp.(vs .- maximum(vs)) (utils.jl:128) in K-bit fixed point; uniform fallback q=1 when
+ * invalid-but-continuable (utils.jl:123-126,130-133) */
+O_EXPORT void o_fixq(const double *lp, int64_t n, double m, int K, int uniform, uint64_t *q)
+{
+    for (int64_t i = 0; i < n; ++i) q[i] = uniform ? 1u : o_exp_fix(lp[i] - m, K);
+}
+
+/* inclusive prefix sum (the CDF every resampler walks: resample.jl:59,113,163-166), exact in u64;
+ * also sum of squares in u128 for the ESS */
+O_EXPORT uint64_t o_scan(const uint64_t *q, int64_t n, uint64_t *cdf, uint64_t *Qhi, uint64_t *Qlo)
+{
+    uint64_t s = 0; o_u128 Q = 0;
+    for (int64_t i = 0; i < n; ++i) { s += q[i]; if (cdf) cdf[i] = s; Q += (o_u128)q[i] * q[i]; }
+    if (Qhi) *Qhi = (uint64_t)(Q >> 64);
+    if (Qlo) *Qlo = (uint64_t)Q;
+    return s;
+}
+
+/* ------------------------------------------------------------------ ancestor targets */
+/* multinomial (resample.jl:59): slot j draws T = floor(U_j * S / 2^64), U_j the 64-bit uniform of
+ * counter (j, 0, epoch, RESAMPLE); ancestor = the particle whose CDF cell [cdf[a-1], cdf[a]) holds T */
+O_EXPORT void o_targets_multinomial(uint64_t seed, uint32_t epoch, int64_t j0, int64_t n, uint64_t S,
+                                    uint64_t *T)
+{
+    for (int64_t j = 0; j < n; ++j) {
+        o_philox_t b = o_rng(seed, (uint32_t)(j0 + j), 0, epoch, O_TAG_RESAMPLE);
+        T[j] = o_mulhi64(o_u64(b.v[0], b.v[1]), S);
+    }
+}
+/* stratified (resample.jl:159-167): stratum j = [L_j, L_{j+1}), L_j = floor(j*S/N) computed exactly as
+ * j*B + floor(j*rem/N) with S = N*B + rem; T = L_j + floor(U_j * len_j / 2^64).
+ * This is u = rand()*step + lower (resample.jl:162) on the integer grid of the fixed-point CDF. */
+O_EXPORT void o_targets_stratified(uint64_t seed, uint32_t epoch, int64_t j0, int64_t n, int64_t N,
+                                   uint64_t S, uint64_t *T)
+{
+    uint64_t B = S / (uint64_t)N, rem = S % (uint64_t)N;
+    for (int64_t j = 0; j < n; ++j) {
+        uint64_t jg = (uint64_t)(j0 + j);
+        uint64_t L0 = jg * B + (jg * rem) / (uint64_t)N;
+        uint64_t L1 = (jg + 1) * B + ((jg + 1) * rem) / (uint64_t)N;
+        o_philox_t b = o_rng(seed, (uint32_t)jg, 0, epoch, O_TAG_RESAMPLE);
+        T[j] = L0 + o_mulhi64(o_u64(b.v[0], b.v[1]), L1 - L0);
+    }
+}
+/* first index a with cdf[a] > T  (== the while loop of resample.jl:163-166 / inverse-CDF categorical) */
+O_EXPORT void o_upper_bound(const uint64_t *cdf, int64_t n, const uint64_t *T, int64_t m, int64_t *idx)
+{
+    for (int64_t j = 0; j < m; ++j) {
+        int64_t lo = 0, hi = n;
+        uint64_t t = T[j];
+        while (lo < hi) { int64_t mid = lo + (hi - lo) / 2; if (cdf[mid] > t) hi = mid; else lo = mid + 1; }
+        idx[j] = lo < n ? lo : n - 1;
+    }
+}
+
+/* residual (resample.jl:96-115): n_copies = floor(N*w_i) = (N*q_i) div S exactly;
+ * residual weight N*w_i - floor(N*w_i) = ((N*q_i) mod S)/S, kept as ((N*q_i) mod S) >> sh with
+ * sh = max(0, bitlen(S) + ceil_log2(N) - 62) so the residual CDF also fits 62 bits. */
+O_EXPORT int o_residual_shift(uint64_t S, int64_t N)
+{
+    int bl = 0; while (bl < 64 && (S >> bl) != 0) ++bl;
+    int cl = 0; while (((int64_t)1 << cl) < N) ++cl;
+    int sh = bl + cl - 62;
+    return sh > 0 ? sh : 0;
+}
+O_EXPORT void o_residual_split(const uint64_t *q, int64_t n, int64_t N, uint64_t S, int sh,
+                               uint64_t *c, uint64_t *r)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t nq = (uint64_t)N * q[i];
+        c[i] = nq / S;
+        r[i] = (nq % S) >> sh;
+    }
+}
+
+/* ------------------------------------------------------------------ gather, sort, statistics */
+O_EXPORT void o_gather_rows(const double *rows, int W, const int64_t *idx, int64_t n, double *out)
+{
+    for (int64_t j = 0; j < n; ++j)
+        for (int k = 0; k < W; ++k) out[j * W + k] = rows[idx[j] * W + k];
+}
+
+/* order-preserving key: Julia isless total order on floats (-0.0 < 0.0, NaN last) */
+static uint64_t f64_key(double x)
+{
+    uint64_t u = o_d2u(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+typedef struct { uint64_t key; int64_t idx; } o_kv;
+static int kv_cmp_desc(const void *a, const void *b)
+{
+    const o_kv *x = a, *y = b;
+    if (x->key != y->key) return x->key > y->key ? -1 : 1;     /* descending by value */
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);    /* stable: ties keep index order */
+}
+/* sortperm(log_priorities, rev=true), resample.jl:156-157 (stable) */
+O_EXPORT void o_argsort_desc(const double *lp, int64_t n, int64_t *order)
+{
+    o_kv *kv = (o_kv *)malloc((size_t)n * sizeof(o_kv));
+    for (int64_t i = 0; i < n; ++i) { kv[i].key = f64_key(lp[i]); kv[i].idx = i; }
+    qsort(kv, (size_t)n, sizeof(o_kv), kv_cmp_desc);
+    for (int64_t i = 0; i < n; ++i) order[i] = kv[i].idx;
+    free(kv);
+}
+
+/* sum_i q_i * f(x_i[col]) / S with f = identity (pw=1) or square of (x - c) (pw=2):
+ * statistics.jl:13-14 (mean) and :48-50 (var); sequential Float64 accumulation */
+O_EXPORT double o_wsum(const uint64_t *q, uint64_t S, const double *rows, int W, int col, int64_t n,
+                       int pw, double c)
+{
+    double acc = 0.0, Sd = (double)S;
+    for (int64_t i = 0; i < n; ++i) {
+        double w = (double)q[i] / Sd;
+        double v = rows[i * W + col];
+        if (pw == 2) { v = v - c; v = v * v; }
+        acc += w * v;
+    }
+    return acc;
+}
+
+/* synthetic data generator shared by tests/bench (DATA stream, tag 7): y = truth + noise for the SSMs */
+O_EXPORT void o_normals(uint64_t seed, uint32_t epoch, int64_t n, double *out)
+{
+    for (int64_t i = 0; i < n; i += 2) {
+        double z0, z1;
+        o_normal2(o_rng(seed, (uint32_t)(i / 2), 0, epoch, O_TAG_DATA), &z0, &z1);
+        out[i] = z0; if (i + 1 < n) out[i + 1] = z1;
+    }
+}

@@ -1,0 +1,335 @@
+"""CPU oracle for the particle-filter hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  The product (``genparticlefilters.jl_amd``) never does: it has no CPU fallback.
+
+``OracleFilter`` composes the C primitives of ``gpf_oracle.c`` into the reference's operations;
+every statement cites the line of GenParticleFilters.jl v0.2.3 (paths relative to
+``/root/reference``) it restates.  PARITY STATUS: random streams are *unpinned* against the
+reference (Julia is absent and the reference's tests hold no seeds / golden vectors, SURVEY.md
+§8c); deterministic arithmetic is pinned by ``tests/test_oracle_*.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+MODEL_LGSSM2, MODEL_BEARINGS4, MODEL_SV1, MODEL_OBJECT_MOTION = 1, 2, 3, 4
+FLAG_NAN, FLAG_POSINF, FLAG_ALL_NEGINF = 1, 2, 4
+METHODS = ("multinomial", "residual", "stratified")
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/_build/liboracle.so with gcc (seconds)."""
+    srcs = [os.path.join(_HERE, f) for f in ("gpf_oracle.c", "ref_literal.c", "gpf_oracle_math.h")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    def sig(name, res, *args):
+        f = getattr(L, name); f.restype = res; f.argtypes = list(args)
+    i32, i64, u32, u64, f64 = C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
+    pf64, pu64, pi32 = C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int)
+    sig("o_log_d", f64, f64); sig("o_exp_d", f64, f64); sig("o_exp_fix_d", u64, f64, i32)
+    sig("o_atan2_d", f64, f64, f64); sig("o_sincos2pi_d", None, f64, pf64, pf64)
+    sig("o_philox_d", None, u32, u32, u32, u32, u32, u32, _u32p)
+    sig("o_normal2_d", None, u64, u32, u32, u32, u32, pf64, pf64)
+    sig("o_u52_d", f64, u64, u32, u32, u32, u32)
+    sig("o_math_vec", None, i32, _f64p, _f64p, i64, _f64p, _f64p)
+    sig("o_fix_K", i32, i64)
+    sig("o_lse_from", f64, f64, u64, i32, i32); sig("o_ess_from", f64, u64, u64, u64)
+    sig("o_model_dim", i32, i32); sig("o_model_nblk", i32, i32)
+    sig("o_init", None, i32, _f64p, u64, u32, i64, i64, i32, _f64p, _f64p, _f64p)
+    sig("o_step", None, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, _f64p, _f64p, _f64p)
+    sig("o_move", u64, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, i32, i32, _f64p, _f64p, _f64p)
+    sig("o_max_flags", None, _f64p, i64, pf64, pi32)
+    sig("o_fixq", None, _f64p, i64, f64, i32, i32, _u64p)
+    sig("o_scan", u64, _u64p, i64, _u64p, pu64, pu64)
+    sig("o_targets_multinomial", None, u64, u32, i64, i64, u64, _u64p)
+    sig("o_targets_stratified", None, u64, u32, i64, i64, i64, u64, _u64p)
+    sig("o_upper_bound", None, _u64p, i64, _u64p, i64, _i64p)
+    sig("o_residual_shift", i32, u64, i64)
+    sig("o_residual_split", None, _u64p, i64, i64, u64, i32, _u64p, _u64p)
+    sig("o_gather_rows", None, _f64p, i32, _i64p, i64, _f64p)
+    sig("o_argsort_desc", None, _f64p, i64, _i64p)
+    sig("o_wsum", f64, _u64p, u64, _f64p, i32, i32, i64, i32, f64)
+    sig("o_normals", None, u64, u32, i64, _f64p)
+    # literal Float64 restatement (ref_literal.c)
+    sig("lit_logsumexp", f64, _f64p, i64); sig("lit_lognorm", None, _f64p, i64, _f64p)
+    sig("lit_softmax", None, _f64p, i64, _f64p); sig("lit_safe_softmax", i32, _f64p, i64, _f64p)
+    sig("lit_ess", f64, _f64p, i64)
+    sig("lit_multinomial", None, _f64p, i64, _f64p, _i64p)
+    sig("lit_residual", i64, _f64p, i64, _f64p, _i64p)
+    sig("lit_stratified", None, _f64p, _i64p, i64, _f64p, _i64p)
+    sig("lit_update_weights", None, _f64p, _f64p, _i64p, i64, _f64p)
+    _lib = L
+    return L
+
+
+# ----------------------------------------------------------------------------- thin primitive wrappers
+def olog(x: float) -> float:
+    return lib().o_log_d(float(x))
+
+
+def fix_K(n_global: int) -> int:
+    return lib().o_fix_K(int(n_global))
+
+
+def row_width(model: int, keep_prev: bool) -> int:
+    d = lib().o_model_dim(model)
+    w = 2 * d if keep_prev else d
+    return w + (w & 1)
+
+
+def max_flags(lp: np.ndarray):
+    m, f = C.c_double(), C.c_int()
+    lib().o_max_flags(np.ascontiguousarray(lp, np.float64), lp.size, C.byref(m), C.byref(f))
+    return m.value, f.value
+
+
+def fixq(lp: np.ndarray, m: float, K: int, uniform: bool = False) -> np.ndarray:
+    q = np.empty(lp.size, np.uint64)
+    lib().o_fixq(np.ascontiguousarray(lp, np.float64), lp.size, m, K, int(uniform), q)
+    return q
+
+
+def scan(q: np.ndarray):
+    cdf = np.empty(q.size, np.uint64)
+    hi, lo = C.c_uint64(), C.c_uint64()
+    S = lib().o_scan(np.ascontiguousarray(q), q.size, cdf, C.byref(hi), C.byref(lo))
+    return cdf, int(S), int(hi.value), int(lo.value)
+
+
+def upper_bound(cdf: np.ndarray, T: np.ndarray) -> np.ndarray:
+    idx = np.empty(T.size, np.int64)
+    lib().o_upper_bound(np.ascontiguousarray(cdf), cdf.size, np.ascontiguousarray(T), T.size, idx)
+    return idx
+
+
+def targets_multinomial(seed, epoch, j0, n, S) -> np.ndarray:
+    T = np.empty(n, np.uint64)
+    lib().o_targets_multinomial(seed, epoch, j0, n, S, T)
+    return T
+
+
+def targets_stratified(seed, epoch, j0, n, N, S) -> np.ndarray:
+    T = np.empty(n, np.uint64)
+    lib().o_targets_stratified(seed, epoch, j0, n, N, S, T)
+    return T
+
+
+def argsort_desc(lp: np.ndarray) -> np.ndarray:
+    order = np.empty(lp.size, np.int64)
+    lib().o_argsort_desc(np.ascontiguousarray(lp, np.float64), lp.size, order)
+    return order
+
+
+def gather_rows(rows: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    out = np.empty((idx.size, rows.shape[1]), np.float64)
+    lib().o_gather_rows(np.ascontiguousarray(rows), rows.shape[1], np.ascontiguousarray(idx, np.int64),
+                        idx.size, out)
+    return out
+
+
+def normals(seed: int, epoch: int, n: int) -> np.ndarray:
+    out = np.empty(n, np.float64)
+    lib().o_normals(seed, epoch, n, out)
+    return out
+
+
+class OracleError(RuntimeError):
+    """Mirrors Julia's ErrorException raised by error(...) in the reference."""
+
+
+class WeightSummary:
+    """m, flags, fixed-point weights, their exact CDF, S = sum q, Q = sum q^2."""
+
+    def __init__(self, lp: np.ndarray, n_global: int):
+        self.K = fix_K(n_global)
+        self.m, self.flags = max_flags(lp)
+        self.uniform = bool(self.flags & FLAG_ALL_NEGINF)
+        self.bad = bool(self.flags & (FLAG_NAN | FLAG_POSINF))
+        if self.bad:
+            self.q = np.zeros(lp.size, np.uint64)
+        else:
+            self.q = fixq(lp, self.m, self.K, self.uniform)
+        self.cdf, self.S, self.Qhi, self.Qlo = scan(self.q)
+
+    @property
+    def lse(self) -> float:
+        return lib().o_lse_from(self.m, self.S, self.K, self.flags)
+
+    @property
+    def ess(self) -> float:
+        if self.flags:
+            return float("nan")   # lognorm of all -Inf / NaN weights is NaN in the reference too
+        return lib().o_ess_from(self.S, self.Qhi, self.Qlo)
+
+
+class OracleFilter:
+    """Single-shard oracle with the state of Gen.ParticleFilterState:
+    rows (traces), log_weights, log_ml_est, parents (1-based, into the pre-resample array)."""
+
+    def __init__(self, model: int, params, n_particles: int, seed: int, keep_prev: bool = False):
+        self.model, self.n, self.seed = int(model), int(n_particles), int(seed)
+        self.params = np.ascontiguousarray(params, np.float64)
+        self.keep_prev = bool(keep_prev)
+        self.d = lib().o_model_dim(self.model)
+        self.W = row_width(self.model, self.keep_prev)
+        self.rows = np.zeros((self.n, self.W))
+        self.lw = np.zeros(self.n)
+        self.lml_est = 0.0
+        self.parents = np.arange(1, self.n + 1, dtype=np.int64)    # initialize.jl:43  collect(1:N)
+        self.epoch = 0
+        self.has_prev = False
+        self.last_obs = None
+        self.n_accepted = 0
+
+    # -- initialize.jl:31-44
+    def initialize(self, obs):
+        obs = np.ascontiguousarray(obs, np.float64)
+        lib().o_init(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, obs, self.rows, self.lw)
+        self.lml_est = 0.0
+        self.parents = np.arange(1, self.n + 1, dtype=np.int64)
+        self.epoch += 1
+        self.has_prev = False
+        self.last_obs = obs
+        return self
+
+    # -- update.jl:12-25
+    def update(self, obs):
+        obs = np.ascontiguousarray(obs, np.float64)
+        new_rows = np.empty_like(self.rows)
+        lib().o_step(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, int(self.keep_prev),
+                     obs, self.rows, new_rows, self.lw)            # :15-22
+        self.rows = new_rows                                        # update_refs!, utils.jl:10-15
+        self.epoch += 1
+        self.has_prev = True
+        self.last_obs = obs
+        return self
+
+    # -- utils.jl:148,156,163-164,171; Gen.log_ml_estimate
+    def summary(self) -> WeightSummary:
+        return WeightSummary(self.lw, self.n)
+
+    def effective_sample_size(self) -> float:
+        return self.summary().ess
+
+    def log_ml_estimate(self) -> float:
+        return self.lml_est + self.summary().lse - olog(float(self.n))
+
+    def log_norm_weights(self) -> np.ndarray:
+        return self.lw - self.summary().lse                         # lognorm, utils.jl:100
+
+    def norm_weights(self) -> np.ndarray:
+        s = self.summary()
+        return s.q.astype(np.float64) / float(s.S)                  # softmax, utils.jl:103-107
+
+    # -- resample.jl:19-30 dispatcher + :48-175
+    def resample(self, method: str = "multinomial", priority_alpha=None, log_priorities=None,
+                 sort_particles: bool = True, check="warn"):
+        if method not in METHODS:
+            raise OracleError(f"Resampling method {method} not recognized.")   # :28
+        N, lw = self.n, self.lw
+        # :51-52 / :88-89 / :147-148
+        if log_priorities is not None:
+            lp, has_prio = np.ascontiguousarray(log_priorities, np.float64), True
+        elif priority_alpha is not None:
+            lp, has_prio = float(priority_alpha) * lw, True
+        else:
+            lp, has_prio = lw, False
+        # :54 safe_softmax (utils.jl:117-140)
+        sp = WeightSummary(lp, N)
+        invalid = sp.flags != 0
+        if check is True and invalid:
+            raise OracleError("Invalid weights.")                   # :55
+        if sp.bad:
+            # NaN weights: Distributions.Categorical rejects them in the reference; we fail loudly too
+            raise OracleError("Invalid weights (NaN).")
+        # :57 update_lml_est! (:178-182) -- from the RAW log weights
+        sr = WeightSummary(lw, N) if has_prio else sp
+        self.lml_est = self.lml_est + (sr.lse - olog(float(N)))
+        epoch = self.epoch
+        if method == "multinomial":                                 # :59
+            T = targets_multinomial(self.seed, epoch, 0, N, sp.S)
+            anc = upper_bound(sp.cdf, T)
+        elif method == "stratified":                                # :155-170
+            if sort_particles:
+                order = argsort_desc(lp)                            # :156-157
+                cdf, S, _, _ = scan(sp.q[order])
+            else:
+                order, cdf, S = None, sp.cdf, sp.S
+            T = targets_stratified(self.seed, epoch, 0, N, N, S)    # :160-162
+            k = upper_bound(cdf, T)                                 # :163-166
+            anc = order[k] if order is not None else k              # :168
+        else:                                                       # residual :96-115
+            sh = lib().o_residual_shift(sp.S, N)
+            c = np.empty(N, np.uint64); r = np.empty(N, np.uint64)
+            lib().o_residual_split(sp.q, N, N, sp.S, sh, c, r)      # :99, :109
+            ccdf = np.cumsum(c, dtype=np.uint64)
+            n_res = int(ccdf[-1])                                   # n_resampled
+            anc = np.empty(N, np.int64)
+            anc[:n_res] = upper_bound(ccdf, np.arange(n_res, dtype=np.uint64))   # :101
+            if n_res < N:                                           # :108
+                rcdf, Rs, _, _ = scan(r)                            # :110 (normalisation == using Rs)
+                T = targets_multinomial(self.seed, epoch, n_res, N - n_res, Rs)
+                anc[n_res:] = upper_bound(rcdf, T)                  # :113
+        new_rows = gather_rows(self.rows, anc)                      # :60 / :103,114 / :169
+        # update_weights! :190-202
+        if not has_prio:
+            new_lw = np.zeros(N)                                    # :195
+        else:
+            log_ws = lw[anc] - lp[anc]                              # :198
+            s2 = WeightSummary(log_ws, N)
+            new_lw = log_ws + (olog(float(N)) - s2.lse)             # :200
+        self.parents = anc + 1                                      # 1-based like Julia
+        self.rows, self.lw = new_rows, new_lw                       # update_refs!
+        self.epoch += 1
+        return invalid
+
+    # -- rejuvenate.jl:18-27 dispatcher, :40-53 move-accept, :74-90 move-reweight
+    def rejuvenate(self, method: str = "move", n_iters: int = 1):
+        if method not in ("move", "reweight"):
+            raise OracleError(f"Method {method} not recognized.")   # :25
+        new_rows = np.empty_like(self.rows)
+        self.n_accepted = int(lib().o_move(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W,
+                                           int(self.has_prev), self.last_obs, int(n_iters),
+                                           int(method == "reweight"), self.rows, new_rows, self.lw))
+        self.rows = new_rows
+        self.epoch += 1
+        return self
+
+    # -- statistics.jl:13-14, 48-50
+    def mean(self, col: int) -> float:
+        s = self.summary()
+        return lib().o_wsum(s.q, s.S, self.rows, self.W, col, self.n, 1, 0.0)
+
+    def var(self, col: int) -> float:
+        s = self.summary()
+        mu = lib().o_wsum(s.q, s.S, self.rows, self.W, col, self.n, 1, 0.0)
+        return lib().o_wsum(s.q, s.S, self.rows, self.W, col, self.n, 2, mu)
+
+    def column(self, col: int) -> np.ndarray:
+        return self.rows[:, col].copy()

@@ -1,0 +1,173 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): ancestor indices bit-exact; log-weights / log-ML within 1e-6
+relative (the spec is deterministic, so in practice they are bit-identical and asserted as such
+where the arithmetic is element-wise)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6          # north_star tolerance for floating-point outputs
+
+MODELS = ["lgssm2", "bearings4", "sv1", "object_motion"]
+
+
+def make_pair(g, o, name, N, seed, keep_prev, T=6):
+    model = g.models.by_name(name)
+    ys = g.models.simulate(model, T)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=seed, keep_prev=keep_prev)
+    orc = o.OracleFilter(model.model_id, model.params, N, seed, keep_prev=keep_prev).initialize(ys[0])
+    return model, ys, st, orc
+
+
+def assert_state_equal(st, orc, exact=True):
+    rows = st.traces
+    if exact:
+        assert np.array_equal(rows, orc.rows), "particle rows differ"
+        assert np.array_equal(st.log_weights, orc.lw), "log-weights differ"
+    else:
+        np.testing.assert_allclose(rows, orc.rows, rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(st.log_weights, orc.lw, rtol=RTOL, atol=1e-9)
+
+
+# ------------------------------------------------------------------ math spec, bit for bit
+@pytest.mark.parametrize("which,lo,hi", [(0, -745.0, 20.0), (1, 1e-300, 1e300), (2, 0.0, 1.0), (3, -4.0, 4.0),
+                                         (4, 0.0, 1e10), (5, -1e3, 1e3)])
+def test_device_math_bitwise(g, o, which, lo, hi):
+    rng = np.random.default_rng(which)
+    n = 200_000
+    a = rng.uniform(lo, hi, n)
+    b = rng.uniform(lo, hi, n)
+    if which == 1:
+        a = np.exp(rng.uniform(-700, 700, n))
+    if which == 5:
+        b[b == 0] = 1.0
+    model = g.models.lgssm2()
+    st = g.DeviceParticleFilterState(model, 16)
+    d1, d2 = st.debug_math(which, a, b)
+    o1, o2 = np.empty(n), np.zeros(n)
+    o.lib().o_math_vec(which, a, b, n, o1, o2)
+    assert np.array_equal(d1.view(np.uint64), o1.view(np.uint64))
+    if which == 2:
+        assert np.array_equal(d2.view(np.uint64), o2.view(np.uint64))
+
+
+# ------------------------------------------------------------------ initialize / update (initialize.jl:31-44, update.jl:12-25)
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("keep_prev", [False, True])
+def test_initialize_update_bitwise(g, o, name, keep_prev):
+    model, ys, st, orc = make_pair(g, o, name, 5000, 11, keep_prev)
+    assert_state_equal(st, orc)
+    for t in range(1, 4):
+        g.pf_update(st, (t + 1,), (None,), ys[t])
+        orc.update(ys[t])
+        assert_state_equal(st, orc)
+    assert g.get_ess(st) == orc.effective_sample_size()
+    assert g.get_lml_est(st) == orc.log_ml_estimate()
+    np.testing.assert_allclose(g.get_norm_weights(st), orc.norm_weights(), rtol=1e-12)
+    np.testing.assert_allclose(g.get_log_norm_weights(st), orc.log_norm_weights(), rtol=1e-12, atol=1e-12)
+    assert np.array_equal(st.parents, np.arange(1, 5001))
+
+
+# ------------------------------------------------------------------ resampling (resample.jl:48-175)
+@pytest.mark.parametrize("method", ["multinomial", "residual", "stratified"])
+@pytest.mark.parametrize("N", [1, 7, 100, 2048, 2049, 50_000])
+def test_resample_ancestors_bitexact(g, o, method, N):
+    model, ys, st, orc = make_pair(g, o, "lgssm2", N, 5, False)
+    for t in range(1, 4):
+        kw = dict(sort_particles=(t % 2 == 0)) if method == "stratified" else {}
+        g.pf_resample(st, method, check=False, **kw)
+        orc.resample(method, check=False, **kw)
+        assert np.array_equal(st.parents, orc.parents), f"ancestors differ at t={t}"
+        assert_state_equal(st, orc)
+        assert g.get_lml_est(st) == orc.log_ml_estimate()
+        g.pf_update(st, (t + 1,), (None,), ys[t])
+        orc.update(ys[t])
+        assert_state_equal(st, orc)
+
+
+@pytest.mark.parametrize("method", ["multinomial", "residual", "stratified"])
+def test_resample_priorities(g, o, method):
+    """priority_fn = w -> w/2 (test/resample.jl:15-23,56-70,104-119): ancestors exact, new weights and log-ML
+    within tolerance, and logsumexp(lw) == log N afterwards."""
+    N = 10_000
+    model, ys, st, orc = make_pair(g, o, "lgssm2", N, 9, False)
+    old = g.get_lml_est(st)
+    g.pf_resample(st, method, priority_fn=g.Tempering(0.5), check=False)
+    orc.resample(method, priority_alpha=0.5, check=False)
+    assert np.array_equal(st.parents, orc.parents)
+    np.testing.assert_allclose(st.log_weights, orc.lw, rtol=RTOL, atol=1e-9)
+    assert abs(g.get_lml_est(st) - old) <= 1e-9 * abs(old)
+    # arbitrary closure -> host-evaluated priorities, same result
+    model, ys, st2, _ = make_pair(g, o, "lgssm2", N, 9, False)
+    g.pf_resample(st2, method, priority_fn=lambda w: w / 2, check=False)
+    assert np.array_equal(st2.parents, orc.parents)
+    np.testing.assert_allclose(st2.log_weights, orc.lw, rtol=RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("method", ["multinomial", "residual", "stratified"])
+def test_resample_invalid_weights(g, o, method):
+    """test/resample.jl:26-31,73-78,122-127: all -Inf weights: check=true throws, check=false leaves all zeros."""
+    N = 100
+    model, ys, st, orc = make_pair(g, o, "lgssm2", N, 2, False)
+    st.log_weights = np.full(N, -np.inf)
+    with pytest.raises(g.ErrorException):
+        g.pf_resample(st, method, check=True)
+    g.pf_resample(st, method, check=False)
+    assert np.all(st.log_weights == 0.0)
+    orc.lw[:] = -np.inf
+    orc.resample(method, check=False)
+    assert np.array_equal(st.parents, orc.parents)
+    with pytest.warns(UserWarning):
+        st.log_weights = np.full(N, -np.inf)
+        g.pf_resample(st, method, check="warn")
+    st.log_weights = np.full(N, np.nan)
+    with pytest.raises(g.ErrorException):
+        g.pf_resample(st, method, check="warn")
+    with pytest.raises(g.ErrorException):
+        g.pf_resample(st, "systematic")
+
+
+@pytest.mark.parametrize("method", ["residual", "stratified"])
+def test_uniform_weights_identity(g, o, method):
+    """test/resample.jl:36-40,83-87: equal weights => residual and stratified resampling are the identity."""
+    N = 100
+    model, ys, st, orc = make_pair(g, o, "lgssm2", N, 2, False)
+    st.log_weights = np.zeros(N)
+    before = st.traces
+    g.pf_resample(st, method)
+    assert np.array_equal(st.parents, np.arange(1, N + 1))
+    assert np.array_equal(st.traces, before)
+
+
+# ------------------------------------------------------------------ rejuvenation (rejuvenate.jl:40-90)
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("method", ["move", "reweight"])
+def test_rejuvenate_bitwise(g, o, name, method):
+    model, ys, st, orc = make_pair(g, o, name, 4000, 21, True)
+    # right after initialize (no previous step): proposals come from the prior
+    g.pf_rejuvenate(st, None, (), 2, method=method, count=True)
+    orc.rejuvenate(method, 2)
+    assert st.n_accepted == orc.n_accepted
+    assert_state_equal(st, orc)
+    for t in range(1, 4):
+        g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
+        g.pf_resample(st, "residual", check=False); orc.resample("residual", check=False)
+        g.pf_rejuvenate(st, None, (), 1, method=method, count=True); orc.rejuvenate(method, 1)
+        assert st.n_accepted == orc.n_accepted
+        assert np.array_equal(st.parents, orc.parents)
+        assert_state_equal(st, orc)
+    with pytest.raises(g.ErrorException):
+        g.pf_rejuvenate(st, None, (), 1, method="gibbs")
+
+
+# ------------------------------------------------------------------ statistics (statistics.jl:13-14,48-50)
+@pytest.mark.parametrize("name", MODELS)
+def test_mean_var(g, o, name):
+    model, ys, st, orc = make_pair(g, o, name, 30_000, 4, False)
+    g.pf_update(st, (2,), (None,), ys[1]); orc.update(ys[1])
+    for c in range(model.dim):
+        np.testing.assert_allclose(g.mean(st, c), orc.mean(c), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g.var(st, c), orc.var(c), rtol=1e-9, atol=1e-14)
+        assert np.array_equal(st.column(c), orc.column(c))

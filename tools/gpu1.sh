@@ -1,0 +1,5 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -30
