@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the particle-filter hot path (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): 2-D linear-Gaussian SSM, N = 1e6 particles per GPU, bootstrap
+proposal, multinomial resampling EVERY step, T = --steps time steps.  One bench "step" = one
+filter time step over all particles = pf_resample!(state, :multinomial) + pf_update!(state, ...).
+Metric: particle-steps/sec = (particles on all GPUs) * steps / wall seconds, inputs resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with the extra objects `roofline` (dominant kernel, HIP-event timed on
+the handle's stream) and `cpu_baseline` (the C oracle = a port of the reference algorithm, timed on
+this box's host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PER_GPU = 1_000_000
+SEED = 1
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(d: int, W: int):
+    """Algorithmic bytes per particle and launch: every input read once,
+    every output written once.  d = state columns, rows are W doubles."""
+    row = 8 * W
+    return {
+        "k_step": row + 8 + row + 8,       # R row, R lw, W row, W lw        (16d + 16)
+        "k_max_partial": 8,                # R lw
+        "k_scan": 8 + 8,                   # R lw, W cdf
+        "k_search": 8 + 4,                 # R cdf cell, W ancestor
+        "k_gather": 4 + row + row + 8,     # R ancestor, R row, W row, W lw  (16d + 12)
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import gpf_amd as g
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    model = g.models.lgssm2()
+    K, Wm = args.steps, args.warmup
+    ys = g.models.simulate(model, K + Wm + 1)
+    n_local = args.particles_per_gpu
+    n_global = n_local * world
+
+    if world == 1:
+        state = g.pf_initialize(model, (1,), ys[0], n_local, seed=SEED, device=local_rank)
+
+        def step(t):
+            g.pf_resample(state, "multinomial", check=False)
+            g.pf_update(state, (t + 1,), (None,), ys[t])
+    else:
+        from gpf_amd import sharded
+        state = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=SEED, device=local_rank)
+
+        def step(t):
+            sharded.pf_resample(state, "multinomial", check=False)
+            sharded.pf_update(state, (t + 1,), (None,), ys[t])
+
+    def barrier():
+        state.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t = 1
+    for _ in range(Wm):
+        step(t); t += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step(t); t += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = n_global * K / elapsed
+    lml = g.get_lml_est(state) if world == 1 else sharded.get_lml_est(state)
+
+    # ---- roofline of the dominant kernel: HIP events around every launch, on the handle's stream ----
+    roofline = None
+    local = state if world == 1 else state.local
+    kid_names = g._lib.KERNEL_NAMES
+    kids = [g._lib.K_STEP, g._lib.K_MAX, g._lib.K_SCAN, g._lib.K_SEARCH, g._lib.K_GATHER]
+    n_ev = min(K, 200)
+    for kid in kids:
+        local.kernel_timing(kid, True)
+    tt_ = 1
+    for _ in range(n_ev):
+        step(tt_); tt_ += 1
+    per = {}
+    for kid in kids:
+        ms, cnt = local.kernel_time(kid)
+        local.kernel_timing(kid, False)
+        if cnt:
+            per[kid_names[kid]] = (ms / cnt * 1e3, cnt)          # us per launch
+    if per and rank == 0:
+        ab = algorithmic_bytes(model.dim, local.row_width)
+        share = {k: v[0] * v[1] for k, v in per.items()}
+        dom = max(share, key=share.get)
+        us = per[dom][0]
+        achieved = ab[dom] * n_local / (us * 1e-6) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": ab[dom] * n_local, "avg_launch_us": round(us, 2),
+                    "all_kernels_us": {k: round(v[0], 2) for k, v in per.items()}}
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 / N=1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as o          # cpu_baseline leg: the only place bench.py touches oracle/
+        o.lib()
+        n_cpu, k_cpu = n_local, 30
+        orc = o.OracleFilter(model.model_id, model.params, n_cpu, SEED).initialize(ys[0])
+        c0 = time.perf_counter()
+        for s in range(1, k_cpu + 1):
+            orc.resample("multinomial", check=False)
+            orc.update(ys[s])
+        ce = time.perf_counter() - c0
+        cpu = {"value": round(n_cpu * k_cpu / ce, 1), "unit": "particle-steps/sec", "cores": 1, "kind": "port",
+               "sample": f"same workload, N={n_cpu}, first {k_cpu} steps, single-thread C oracle ({ce:.1f} s); "
+                         "reference (Julia) not runnable on this box"}
+
+    if rank == 0:
+        out = {
+            "metric": "particle-steps/sec", "value": round(value, 1), "unit": "particle-steps/sec",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2D linear-Gaussian SSM, bootstrap PF, multinomial resample every step "
+                                   "(BASELINE.json configs[1])",
+                       "particles_per_gpu": n_local, "particles_total": n_global, "T": K,
+                       "state_dim": model.dim, "parallelism": f"particle-shard x{world}"},
+            "log_ml_estimate": lml,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

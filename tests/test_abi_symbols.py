@@ -1,0 +1,44 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/gpf.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "gpf.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpf_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(g):
+    L = ctypes.CDLL(g._lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/gpf.h but not exported"
+    assert sorted(s[0] for s in g._lib.SYMBOLS) == names, "ctypes table out of sync with include/gpf.h"
+    assert L.gpf_abi_version() == 1
+
+
+def test_no_cpu_fallback(g):
+    """Without a GPU the product must fail loudly, not fall back to the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(g.ErrorException, match="no HIP device|no CPU fallback|hip"):
+        g.pf_initialize(g.models.lgssm2(), (1,), [0.0, 0.0], 16)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under the product package may import, include, link or load it."""
+    pkg = os.path.join(ROOT, "genparticlefilters.jl_amd")
+    bad = re.compile(r"(^\s*(from|import)\s+oracle\b|#include\s*[\"<][^\">]*oracle|liboracle|oracle/_build|oracle\.oracle)", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".jl")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(src), f"{f} uses oracle/"
