@@ -55,6 +55,20 @@ SYMBOLS = [
     ("gpf_kernel_timing", C.c_int, [_H, C.c_int32, C.c_int32]),
     ("gpf_kernel_time", C.c_int, [_H, C.c_int32, _pd, _pi64]),
     ("gpf_debug_math", C.c_int, [_H, C.c_int32, _pd, _pd, C.c_int64, _pd, _pd]),
+    # shard-level building blocks: device pointers are passed as integers (tensor.data_ptr())
+    ("gpf_shard_weight_max", C.c_int, [_H, C.c_void_p]),
+    ("gpf_shard_weight_scan", C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    ("gpf_shard_residual_scan", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("gpf_shard_targets", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("gpf_shard_serve", C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("gpf_shard_commit", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    ("gpf_shard_lml_est", C.c_int, [_H, _pd]),
+    # host-side scalar spec
+    ("gpf_host_fix_K", C.c_int32, [C.c_int64]),
+    ("gpf_host_log", C.c_double, [C.c_double]),
+    ("gpf_host_lse", C.c_double, [C.c_double, C.c_uint64, C.c_int32, C.c_int32]),
+    ("gpf_host_ess", C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64]),
+    ("gpf_host_math", None, [C.c_int32, _pd, _pd, C.c_int64, _pd, _pd]),
 ]
 
 _lib = None

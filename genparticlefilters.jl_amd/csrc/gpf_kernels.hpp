@@ -637,4 +637,128 @@ __global__ void k_debug_math(int which, const double* a, const double* b, int64_
     }
 }
 
+// ----------------------------------------------------------------------------- shard-level kernels (multi-GPU)
+// Sharding: GPU g owns the contiguous global particle range [gid0, gid0+n).  The weight
+// CDF is global = local inclusive scan + the sum of the lower shards' totals; output slot j (global id)
+// draws a target in GLOBAL fixed-point coordinates, the shard that owns that CDF cell looks the ancestor
+// up and returns the row.  Integer arithmetic makes the ancestors independent of the number of shards.
+constexpr int64_t SPACE_COUNTS = (int64_t)1 << 62;   // residual: target lives in the copy-count CDF
+
+__global__ void k_pack_mflags(const double* __restrict__ pmax, const int32_t* __restrict__ pflags, int np, double* out2)
+{
+    __shared__ double sm[NWAVES];
+    __shared__ int sf[NWAVES];
+    double m; int f;
+    fold_partials(pmax, pflags, np, sm, sf, m, f);
+    if (threadIdx.x == 0) { out2[0] = m; out2[1] = (double)(f & (FLAG_NAN | FLAG_POSINF)); }
+}
+__global__ void k_unpack_mflags(const double* __restrict__ in2, double* pmax, int32_t* pflags)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { pmax[0] = in2[0]; pflags[0] = (int32_t)in2[1]; }
+}
+__global__ void k_export_summary(const WSum* ws, const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5)
+{
+    // {S_local, Ql0..3}: limb sums folded over the scan blocks (exact integers)
+    __shared__ uint64_t s_q[NWAVES][4];
+    uint64_t ql[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblk; b += BLOCK)
+        for (int k = 0; k < 4; ++k) ql[k] += blockQ[(int64_t)b * 4 + k];
+    for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
+    if (lane_id() == 0) for (int k = 0; k < 4; ++k) s_q[wave_id()][k] = ql[k];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint64_t t = 0;
+        for (int w = 0; w < NWAVES; ++w) t += s_q[w][threadIdx.x];
+        out5[1 + threadIdx.x] = (int64_t)t;
+    }
+    if (threadIdx.x == 0) out5[0] = (int64_t)ws->S;
+}
+// global S (and residual shift) into the device scalar block from the gathered shard totals
+__global__ void k_set_global(const int64_t* __restrict__ S_all, int G, int64_t n_global, WSum* ws, Scalars* sc, int64_t* out2)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint64_t S = 0;
+        for (int g = 0; g < G; ++g) S += (uint64_t)S_all[g];
+        ws->S = S;
+        sc->sh = residual_shift(S, n_global);
+        (void)out2;
+    }
+}
+__global__ void k_export_residual(const Scalars* sc, int64_t* out2)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out2[0] = (int64_t)sc->Ctot; out2[1] = (int64_t)sc->Rs; }
+}
+
+// targets of this shard's output slots in GLOBAL coordinates (same arithmetic as k_search)
+template <int METHOD>
+__global__ __launch_bounds__(BLOCK) void k_targets(uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n, int64_t n_global,
+                                                   const int64_t* __restrict__ totals, int G, int64_t* __restrict__ T_out)
+{
+    uint64_t S = 0, Ctot = 0, Rs = 0;
+    for (int g = 0; g < G; ++g) {
+        S += (uint64_t)totals[g];
+        if (METHOD == 1) { Ctot += (uint64_t)totals[G + g]; Rs += (uint64_t)totals[2 * G + g]; }
+    }
+    const uint64_t N = (uint64_t)n_global;
+    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * BLOCK) {
+        const uint64_t jg = (uint64_t)(gid0 + j);
+        const Philox b = rng(seed, (uint32_t)jg, 0, epoch, TAG_RESAMPLE);
+        const uint64_t U = u64(b.w0, b.w1);
+        int64_t T;
+        if (METHOD == 0) T = (int64_t)mulhi64(U, S);
+        else if (METHOD == 2) {
+            const uint64_t B = S / N, rem = S % N;
+            const uint64_t L0 = jg * B + (jg * rem) / N;
+            const uint64_t L1 = (jg + 1) * B + ((jg + 1) * rem) / N;
+            T = (int64_t)(L0 + mulhi64(U, L1 - L0));
+        } else {
+            T = jg < Ctot ? ((int64_t)jg | SPACE_COUNTS) : (int64_t)mulhi64(U, Rs);
+        }
+        T_out[j] = T;
+    }
+}
+
+// serve requests in LOCAL coordinates: ancestor lookup in this shard's CDF + row gather
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_serve(const int64_t* __restrict__ T_local, int64_t m_req,
+                                                 const uint64_t* __restrict__ cdf, const uint64_t* __restrict__ desc,
+                                                 const uint64_t* __restrict__ ccdf, const uint64_t* __restrict__ cdesc,
+                                                 int64_t n, int64_t ntiles, int64_t gid0, const double* __restrict__ rows,
+                                                 double* __restrict__ rows_out, int64_t* __restrict__ anc_out)
+{
+    constexpr int C = W / 2;
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m_req; r += (int64_t)gridDim.x * BLOCK) {
+        const int64_t t = T_local[r];
+        int64_t a;
+        if (t & SPACE_COUNTS) a = upper_bound2(ccdf, n, cdesc, ntiles, (uint64_t)(t & ~SPACE_COUNTS));
+        else                  a = upper_bound2(cdf, n, desc, ntiles, (uint64_t)t);
+        anc_out[r] = gid0 + a;
+        const double2* src = reinterpret_cast<const double2*>(rows) + a * C;
+        double2* dst = reinterpret_cast<double2*>(rows_out) + r * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) dst[c] = src[c];
+    }
+}
+
+__global__ void k_commit(const int64_t* __restrict__ anc_in, int64_t n, int32_t* __restrict__ anc, double* __restrict__ lw)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        anc[i] = (int32_t)anc_in[i];
+        lw[i] = 0.0;                                   // update_weights!, resample.jl:195
+    }
+}
+// update_lml_est! from the gathered global summary: lml += (m + log(S 2^-K)) - log N
+__global__ void k_lml_global(const double* __restrict__ m_flags, const int64_t* __restrict__ S_all, int G, int K, double logN,
+                             Scalars* sc)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint64_t S = 0;
+        for (int g = 0; g < G; ++g) S += (uint64_t)S_all[g];
+        const double m = m_flags[0];
+        int f = (int)m_flags[1];
+        if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+        sc->lml_est = sc->lml_est + (lse_from(m, S, K, f) - logN);
+    }
+}
+
 } // namespace gpf

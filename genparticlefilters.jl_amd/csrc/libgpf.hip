@@ -55,7 +55,7 @@ struct gpf_filter {
     Scalars* sc = nullptr;
     Scalars* h_sc = nullptr;       // pinned mirror
     uint32_t epoch = 0;
-    bool initialized = false, has_prev = false, raw_valid = false;
+    bool initialized = false, has_prev = false, raw_valid = false, serve_residual = false;
     Timer timers[GPF_K_COUNT];
     std::string err;
 };
@@ -677,6 +677,174 @@ gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const do
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     hipFree(da); hipFree(db); hipFree(d1); hipFree(d2);
     return GPF_OK;
+}
+
+// =================================================================================== shard-level ABI
+static gpf_status shard_ready(gpf_handle h)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!out2) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
+    const int gp = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
+    s = timed(h, GPF_K_MAX, [&] {
+        hipLaunchKernelGGL(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, raw_view(h), h->n, h->pmax, h->pflags);
+    });
+    if (s) return s;
+    hipLaunchKernelGGL(k_pack_mflags, dim3(1), dim3(BLOCK), 0, h->stream, h->pmax, h->pflags, gp, out2);
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_weight_scan(gpf_handle h, const double* m_flags, int64_t* out5)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!m_flags || !out5) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null pointer");
+    hipLaunchKernelGGL(k_unpack_mflags, dim3(1), dim3(64), 0, h->stream, m_flags, h->pmax, h->pflags);
+    HIP_TRY(h, hipMemsetAsync(h->desc[0], 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
+    InFixQ in{raw_view(h), nullptr, h->K, 0.0, 0};
+    const int gs = scan_grid(h);
+    s = timed(h, GPF_K_SCAN, [&] {
+        hipLaunchKernelGGL((k_scan<InFixQ, true>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, h->pmax, h->pflags, 1,
+                           &h->sc->raw, h->cdf[0], h->desc[0], &h->sc->raw.S, h->blockQ);
+    });
+    if (s) return s;
+    hipLaunchKernelGGL(k_export_summary, dim3(1), dim3(BLOCK), 0, h->stream, &h->sc->raw, h->blockQ, gs, out5);
+    HIP_TRY(h, hipGetLastError());
+    h->raw_valid = false;            // sc->raw holds a LOCAL sum under a GLOBAL max: not the unsharded summary
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* S_all, int32_t G, int64_t* out2)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!S_all || !out2 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if ((s = ensure_residual_buffers(h))) return s;
+    // global S into sc->prio (the local CDF in cdf[0] stays local), residual shift from the global S
+    hipLaunchKernelGGL(k_set_global, dim3(1), dim3(64), 0, h->stream, S_all, (int)G, h->cfg.n_global, &h->sc->prio, h->sc, out2);
+    HIP_TRY(h, hipMemsetAsync(h->desc[1], 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->desc[2], 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
+    const int gs = scan_grid(h);
+    InResidual inc{h->cdf[0], h->sc, &h->sc->prio, h->cfg.n_global, 0};
+    InResidual inr{h->cdf[0], h->sc, &h->sc->prio, h->cfg.n_global, 1};
+    hipLaunchKernelGGL((k_scan<InResidual, false>), dim3(gs), dim3(BLOCK), 0, h->stream, inc, h->n, h->ntiles, nullptr, nullptr, 0, nullptr,
+                       h->cdf[1], h->desc[1], &h->sc->Ctot, nullptr);
+    hipLaunchKernelGGL((k_scan<InResidual, false>), dim3(gs), dim3(BLOCK), 0, h->stream, inr, h->n, h->ntiles, nullptr, nullptr, 0, nullptr,
+                       h->cdf[2], h->desc[2], &h->sc->Rs, nullptr);
+    hipLaunchKernelGGL(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2);
+    HIP_TRY(h, hipGetLastError());
+    h->serve_residual = true;
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_targets(gpf_handle h, int32_t method, const int64_t* totals, int32_t G, int64_t* T_out)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!totals || !T_out || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    const int grid = grid_for(h, h->n, 8);
+    s = timed(h, GPF_K_SEARCH, [&] {
+        switch (method) {
+            case GPF_RESAMPLE_MULTINOMIAL:
+                hipLaunchKernelGGL((k_targets<0>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
+                                   h->cfg.n_global, totals, (int)G, T_out); break;
+            case GPF_RESAMPLE_RESIDUAL:
+                hipLaunchKernelGGL((k_targets<1>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
+                                   h->cfg.n_global, totals, (int)G, T_out); break;
+            case GPF_RESAMPLE_STRATIFIED:
+                hipLaunchKernelGGL((k_targets<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
+                                   h->cfg.n_global, totals, (int)G, T_out); break;
+            default: break;
+        }
+    });
+    if (s) return s;
+    if (method < 0 || method > 2) return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, double* rows_out, int64_t* anc_out)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (m_req < 0 || (m_req > 0 && (!T_local || !rows_out || !anc_out))) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (m_req == 0) return GPF_OK;
+    const int grid = grid_for(h, m_req, 8);
+    // residual: requests without the count bit are looked up in the residual-weight CDF (cdf[2])
+    s = timed(h, GPF_K_GATHER, [&] {
+        const uint64_t* cdf = h->serve_residual ? h->cdf[2] : h->cdf[0];
+        const uint64_t* desc = h->serve_residual ? h->desc[2] : h->desc[0];
+        switch (h->W) {
+            case 2: hipLaunchKernelGGL((k_serve<2>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, cdf, desc, h->cdf[1], h->desc[1],
+                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
+            case 4: hipLaunchKernelGGL((k_serve<4>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, cdf, desc, h->cdf[1], h->desc[1],
+                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
+            case 8: hipLaunchKernelGGL((k_serve<8>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, cdf, desc, h->cdf[1], h->desc[1],
+                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
+        }
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_commit(gpf_handle h, const double* rows, const int64_t* anc, const double* m_flags, const int64_t* S_all, int32_t G)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!rows || !anc || !m_flags || !S_all || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    HIP_TRY(h, hipMemcpyAsync(h->rows[1 - h->cur], rows, (size_t)h->n * h->W * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_commit, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, anc, h->n, h->anc, h->lw);
+    hipLaunchKernelGGL(k_lml_global, dim3(1), dim3(64), 0, h->stream, m_flags, S_all, (int)G, h->K, h->logN, h->sc);
+    HIP_TRY(h, hipGetLastError());
+    h->cur ^= 1;
+    h->epoch += 1;
+    h->raw_valid = false;
+    h->serve_residual = false;
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_lml_est(gpf_handle h, double* out)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
+    if ((s = fetch_scalars(h))) return s;
+    *out = h->h_sc->lml_est;
+    return GPF_OK;
+}
+
+// =================================================================================== host scalar spec
+int32_t gpf_host_fix_K(int64_t n_global) { return fix_K(n_global); }
+double gpf_host_log(double x) { return log_(x); }
+double gpf_host_lse(double m, uint64_t S, int32_t K, int32_t flags)
+{
+    int f = flags;
+    if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+    return lse_from(m, S, K, f);
+}
+double gpf_host_ess(uint64_t S, uint64_t Q_hi, uint64_t Q_lo) { return ess_from(S, Q_hi, Q_lo); }
+void gpf_host_math(int32_t which, const double* a, const double* b, int64_t n, double* out, double* out2)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        switch (which) {
+            case 0: out[i] = exp_(a[i]); break;
+            case 1: out[i] = log_(a[i]); break;
+            case 2: sincos2pi(a[i], out[i], out2[i]); break;
+            case 3: out[i] = atan2_(a[i], b[i]); break;
+            case 4: out[i] = sqrt_(a[i]); break;
+            case 5: out[i] = a[i] / b[i]; break;
+            default: out[i] = 0.0;
+        }
+    }
 }
 
 } // extern "C"

@@ -1,0 +1,304 @@
+"""Multi-GPU particle filter: one process per GPU, particles sharded by contiguous global index,
+collectives through torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
+CPU tests).  DESIGN.md §6.
+
+The reference has no distributed code; what is restated here is the SAME resampling
+spec as the single-GPU path (src/resample.jl:48-120,143-175) over a global weight CDF:
+
+    phase 1   local max / flags                      -> all-gather (2 doubles per rank)
+    phase 2   local fixed-point scan under the GLOBAL max -> all-gather of the shard totals
+    (2b)      residual: copy-count and residual-weight scans -> all-gather of their totals
+    phase 3   every output slot draws its target in global coordinates; owner = searchsorted(offsets)
+              -> all-to-all of the counts, then of the local-coordinate targets
+    phase 4   owners look the ancestors up in their local CDF and gather the rows
+              -> all-to-all of rows + ancestor ids back
+    phase 5   un-permute, install, log-weights = 0, log-ML estimate += logsumexp - log N
+
+Because weights are exact integers and RNG counters are keyed by GLOBAL slot id, the ancestors are
+bit-identical to the single-GPU run for any number of shards.
+
+The routing (bucket by owner, permutations, split sizes) is plain torch tensor code and is the same
+on CPU and GPU; the arithmetic lives behind a small backend interface: `HipShardBackend` (the
+product: libgpf_hip.so through the C ABI) -- the tests inject a CPU backend built on the oracle to
+exercise the collectives with gloo.  Restrictions: priority_fn = nothing, sort_particles = false.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .api import DeviceParticleFilterState, ErrorException, _obs_vector, _pd
+
+RESAMPLE_METHODS = {"multinomial": 0, "residual": 1, "stratified": 2}
+SPACE_COUNTS = 1 << 62
+
+
+def shard_range(n_global: int, rank: int, world: int):
+    """Contiguous ranges; the first (n_global % world) ranks hold one extra particle."""
+    base, extra = divmod(n_global, world)
+    n = base + (1 if rank < extra else 0)
+    gid0 = rank * base + min(rank, extra)
+    return gid0, n
+
+
+class HipShardBackend:
+    """Shard arithmetic on the GPU through the C ABI (include/gpf.h, gpf_shard_*)."""
+
+    def __init__(self, model, n_global, gid0, n_local, seed, keep_prev, device):
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        # one explicit HIP stream shared by the kernels (through the C ABI) and torch (routing ops + collectives):
+        # torch's default stream is the NULL stream, which the library would replace by a stream of its own.
+        self.stream = torch.cuda.Stream(self.device)
+        torch.cuda.set_stream(self.stream)
+        stream = self.stream.cuda_stream
+        self.state = DeviceParticleFilterState(model, n_local, seed=seed, keep_prev=keep_prev, device=device,
+                                               n_global=n_global, gid0=gid0, stream=stream)
+        self.L, self.h = self.state._L, self.state._h
+        self.n, self.W = n_local, self.state.row_width
+
+    def _ck(self, st):
+        self.state._check(st)
+
+    def initialize(self, obs):
+        self._ck(self.L.gpf_initialize(self.h, _pd(obs), obs.size))
+
+    def update(self, obs):
+        self._ck(self.L.gpf_update(self.h, _pd(obs), obs.size))
+
+    def rejuvenate(self, method_id, n_iters):
+        self._ck(self.L.gpf_rejuvenate(self.h, method_id, n_iters, None))
+
+    def weight_max(self):
+        out = torch.empty(2, dtype=torch.float64, device=self.device)
+        self._ck(self.L.gpf_shard_weight_max(self.h, out.data_ptr()))
+        return out
+
+    def weight_scan(self, m_flags):
+        out = torch.empty(5, dtype=torch.int64, device=self.device)
+        self._ck(self.L.gpf_shard_weight_scan(self.h, m_flags.data_ptr(), out.data_ptr()))
+        return out
+
+    def residual_scan(self, S_all):
+        out = torch.empty(2, dtype=torch.int64, device=self.device)
+        self._ck(self.L.gpf_shard_residual_scan(self.h, S_all.data_ptr(), S_all.numel(), out.data_ptr()))
+        return out
+
+    def targets(self, method_id, totals, G):
+        T = torch.empty(self.n, dtype=torch.int64, device=self.device)
+        self._ck(self.L.gpf_shard_targets(self.h, method_id, totals.data_ptr(), G, T.data_ptr()))
+        return T
+
+    def serve(self, T_local):
+        m = T_local.numel()
+        rows = torch.empty((m, self.W), dtype=torch.float64, device=self.device)
+        anc = torch.empty(m, dtype=torch.int64, device=self.device)
+        if m:
+            self._ck(self.L.gpf_shard_serve(self.h, T_local.data_ptr(), m, rows.data_ptr(), anc.data_ptr()))
+        return rows, anc
+
+    def commit(self, rows, anc, m_flags, S_all):
+        rows, anc = rows.contiguous(), anc.contiguous()
+        self._ck(self.L.gpf_shard_commit(self.h, rows.data_ptr(), anc.data_ptr(), m_flags.data_ptr(), S_all.data_ptr(),
+                                         S_all.numel()))
+        self._keep = (rows, anc)            # alive until the stream has consumed them
+
+    def lml_est(self) -> float:
+        out = C.c_double()
+        self._ck(self.L.gpf_shard_lml_est(self.h, C.byref(out)))
+        return out.value
+
+    def synchronize(self):
+        self.state.synchronize()
+
+    # scalar spec on the host (same functions the kernels use)
+    def host_lse(self, m, S, K, flags):
+        return self.L.gpf_host_lse(m, S, K, flags)
+
+    def host_ess(self, S, Qhi, Qlo):
+        return self.L.gpf_host_ess(S, Qhi, Qlo)
+
+    def host_log(self, x):
+        return self.L.gpf_host_log(x)
+
+    def fix_K(self, n):
+        return self.L.gpf_host_fix_K(n)
+
+
+class ShardedParticleFilterState:
+    """One rank's view of the sharded filter (the reference's ParticleFilterState, partitioned)."""
+
+    def __init__(self, backend, model, n_global: int, rank: int, world: int, group=None):
+        self.backend, self.model, self.n_global = backend, model, int(n_global)
+        self.rank, self.world, self.group = rank, world, group
+        self.gid0, self.n_local = shard_range(n_global, rank, world)
+        self.device = backend.device
+        self.K = backend.fix_K(self.n_global)
+
+    @property
+    def local(self):
+        return self.backend.state
+
+    def synchronize(self):
+        self.backend.synchronize()
+
+    def _stage(self, t: torch.Tensor) -> torch.Tensor:
+        """gloo cannot move device tensors: stage through the host (only used by the one-GPU, two-process test;
+        on the GPU box the backend is nccl = RCCL and tensors stay in HBM)."""
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            return t.cpu()
+        return t
+
+    # ---- collectives (tiny, latency-bound: SURVEY.md §2.3 C1-C4)
+    def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return t.unsqueeze(0)
+        src = self._stage(t.contiguous().view(-1))
+        flat = torch.empty(self.world * t.numel(), dtype=t.dtype, device=src.device)
+        dist.all_gather_into_tensor(flat, src, group=self.group)
+        return flat.to(t.device).view((self.world,) + tuple(t.shape))
+
+    def _all_to_all(self, send: torch.Tensor, send_counts, recv_counts) -> torch.Tensor:
+        """variable-size all-to-all along dim 0"""
+        if self.world == 1:
+            return send
+        src = self._stage(send.contiguous())
+        out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=src.device)
+        dist.all_to_all_single(out, src, output_split_sizes=list(recv_counts),
+                               input_split_sizes=list(send_counts), group=self.group)
+        return out.to(send.device)
+
+    # ---- global weight summary: phases 1 + 2
+    def _summary(self):
+        b = self.backend
+        mf = self._all_gather(b.weight_max())                       # (G, 2)
+        m_flags = torch.stack([mf[:, 0].max(), _or_flags(mf[:, 1])])
+        tot = self._all_gather(b.weight_scan(m_flags))               # (G, 5): S_r, Ql0..3
+        return m_flags, tot
+
+    def _summary_scalars(self):
+        m_flags, tot = self._summary()
+        mf = m_flags.cpu().numpy()
+        t = tot.cpu().numpy().astype(object)
+        S = int(sum(int(x) for x in t[:, 0]))
+        Q = sum(int(sum(int(x) for x in t[:, 1 + k])) << (32 * k) for k in range(4))
+        return float(mf[0]), int(mf[1]), S, Q
+
+
+def _or_flags(f: torch.Tensor) -> torch.Tensor:
+    v = f.to(torch.int64)
+    out = torch.zeros((), dtype=torch.int64, device=f.device)
+    for bit in (1, 2):
+        out = out | (((v & bit) != 0).any().to(torch.int64) * bit)
+    return out.to(torch.float64)
+
+
+# ----------------------------------------------------------------------------- public API (sharded twins)
+def pf_initialize(model, model_args, observations, n_particles: int, *, seed: int = 1, keep_prev: bool = False,
+                  device: int = 0, group=None, backend_factory=None) -> ShardedParticleFilterState:
+    """src/initialize.jl:31-44 over all ranks: `n_particles` is the GLOBAL particle count."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    gid0, n_local = shard_range(n_particles, rank, world)
+    factory = backend_factory or HipShardBackend
+    backend = factory(model, n_particles, gid0, n_local, seed, keep_prev, device)
+    st = ShardedParticleFilterState(backend, model, n_particles, rank, world, group)
+    backend.initialize(_obs_vector(observations))
+    return st
+
+
+def pf_update(state: ShardedParticleFilterState, new_args, argdiffs, observations):
+    """src/update.jl:12-25: embarrassingly parallel, no communication."""
+    state.backend.update(_obs_vector(observations))
+    return state
+
+
+def pf_rejuvenate(state: ShardedParticleFilterState, kern=None, kern_args=(), n_iters: int = 1, *, method: str = "move"):
+    """src/rejuvenate.jl:18-90: per particle, no communication."""
+    if method not in ("move", "reweight"):
+        raise ErrorException(f"Method {method} not recognized.")
+    state.backend.rejuvenate(0 if method == "move" else 1, int(n_iters))
+    return state
+
+
+def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", *, priority_fn=None, check="warn",
+                sort_particles: bool = False):
+    """src/resample.jl:19-175 with a global CDF.  Returns `state`."""
+    if method not in RESAMPLE_METHODS:
+        raise ErrorException(f"Resampling method {method} not recognized.")
+    if priority_fn is not None:
+        raise ErrorException("sharded resampling supports priority_fn = nothing only")
+    if method == "stratified" and sort_particles:
+        raise ErrorException("sharded stratified resampling needs sort_particles=False (no global sort; SURVEY.md H8)")
+    b, G, mid = state.backend, state.world, RESAMPLE_METHODS[method]
+    m_flags, tot = state._summary()                                   # phases 1, 2
+    S_all = tot[:, 0].contiguous()
+    if check is not False:                                            # safe_softmax validity (utils.jl:117-140): host sync
+        mf = m_flags.cpu().numpy()
+        invalid = bool(int(mf[1]) != 0 or mf[0] == -np.inf)
+        if int(mf[1]) != 0 or (check is True and invalid):
+            raise ErrorException("Invalid weights.")                  # resample.jl:55
+        if invalid:
+            import warnings
+            warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")
+    if mid == 1:                                                      # residual: phase 2b
+        cr = state._all_gather(b.residual_scan(S_all))                # (G, 2): Ctot_r, Rs_r
+        totals = torch.cat([S_all, cr[:, 0], cr[:, 1]]).contiguous()
+        w_incl = torch.cumsum(cr[:, 1], 0)                            # residual-weight space
+        c_incl = torch.cumsum(cr[:, 0], 0)                            # copy-count space
+    else:
+        totals = S_all
+        w_incl = torch.cumsum(S_all, 0)
+        c_incl = None
+    T = b.targets(mid, totals, G)                                     # phase 3: global targets of own slots
+    if G == 1:
+        rows, anc = b.serve(T)                                        # local == global coordinates
+    else:
+        in_counts = (T & SPACE_COUNTS) != 0
+        Tv = T & (SPACE_COUNTS - 1)
+        owner = torch.bucketize(Tv, w_incl, right=True)
+        if c_incl is not None:
+            owner = torch.where(in_counts, torch.bucketize(Tv, c_incl, right=True), owner)
+        owner = owner.clamp_(max=G - 1)
+        w_excl = w_incl - (cr[:, 1] if mid == 1 else S_all)
+        base = w_excl[owner]
+        if c_incl is not None:
+            base = torch.where(in_counts, (c_incl - cr[:, 0])[owner], base)
+        T_local = (Tv - base) | (T & SPACE_COUNTS)
+        perm = torch.argsort(owner, stable=True)                      # bucket by owner, slot order kept inside a bucket
+        send_counts = torch.bincount(owner, minlength=G)
+        recv_counts = state._all_to_all(send_counts, [1] * G, [1] * G)           # C4
+        sc, rc = send_counts.tolist(), recv_counts.tolist()                       # host sync: split sizes
+        req = state._all_to_all(T_local[perm], sc, rc)                            # requests to the owners
+        rows_s, anc_s = b.serve(req)                                  # phase 4
+        rows_p = state._all_to_all(rows_s, rc, sc)                    # C5: rows back
+        anc_p = state._all_to_all(anc_s, rc, sc)
+        rows = torch.empty_like(rows_p); rows[perm] = rows_p          # un-permute into slot order
+        anc = torch.empty_like(anc_p); anc[perm] = anc_p
+    b.commit(rows, anc, m_flags, S_all)                               # phase 5
+    return state
+
+
+def effective_sample_size(state: ShardedParticleFilterState) -> float:
+    """src/utils.jl:163-164 over the global weights"""
+    m, flags, S, Q = state._summary_scalars()
+    if flags or m == -np.inf:
+        return float("nan")
+    return state.backend.host_ess(S, Q >> 64, Q & ((1 << 64) - 1))
+
+
+get_ess = effective_sample_size
+
+
+def log_ml_estimate(state: ShardedParticleFilterState) -> float:
+    """Gen.log_ml_estimate over the global weights"""
+    m, flags, S, Q = state._summary_scalars()
+    b = state.backend
+    return b.lml_est() + b.host_lse(m, S, state.K, flags) - b.host_log(float(state.n_global))
+
+
+get_lml_est = log_ml_estimate

@@ -155,6 +155,46 @@ gpf_status gpf_kernel_time(gpf_handle h, int32_t id, double* total_ms, int64_t* 
 gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const double* b, int64_t n,
                           double* out, double* out2);
 
+/* ---- shard-level building blocks (multi-GPU) ------------------------------------------------------
+ * A filter sharded over G GPUs is G handles created with the same seed / n_global and contiguous
+ * [gid0, gid0 + n_particles) ranges.  gpf_initialize / gpf_update / gpf_rejuvenate work per shard as they
+ * are (RNG counters use global particle ids).  Resampling needs one exchange; it is composed from the
+ * phases below by the host (sharded.py with torch.distributed = RCCL; a Julia host would use the same
+ * calls with MPI.jl/NCCL.jl).  All pointer arguments are DEVICE pointers owned by the caller; every call
+ * is asynchronous on the handle's stream.  The reference has no distributed path; these
+ * restate src/resample.jl:48-120,143-175 with a global CDF.  Supported here: priority_fn = nothing and
+ * sort_particles = false (a global sort is out of scope).
+ *
+ *   phase 1  gpf_shard_weight_max     out2 = {local max, local flags & (NaN|+Inf)} as two doubles
+ *            host: all-gather, m = max, flags = OR
+ *   phase 2  gpf_shard_weight_scan    in: global {m, flags}; local fixed-point CDF; out5 = {S_local, Ql0..3}
+ *            host: all-gather S_local (and Ql for the ESS)
+ *   phase 2b gpf_shard_residual_scan  (residual only) in: S_all[G]; out2 = {Ctot_local, Rs_local}
+ *            host: all-gather
+ *   phase 3  gpf_shard_targets        in: totals = [S_all | C_all | R_all]; T_out[n] = global targets of own slots
+ *            host: owner = searchsorted(inclusive offsets, T); all-to-all the local-coordinate targets
+ *   phase 4  gpf_shard_serve          ancestor lookup + row gather for the requests this shard owns
+ *            host: all-to-all rows and ancestors back, un-permute
+ *   phase 5  gpf_shard_commit         install rows / parents, log-weights = 0, log-ML estimate += lse - log N
+ */
+gpf_status gpf_shard_weight_max(gpf_handle h, double* out2);
+gpf_status gpf_shard_weight_scan(gpf_handle h, const double* m_flags, int64_t* out5);
+gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* S_all, int32_t G, int64_t* out2);
+gpf_status gpf_shard_targets(gpf_handle h, int32_t method, const int64_t* totals, int32_t G, int64_t* T_out);
+gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, double* rows_out, int64_t* anc_out);
+gpf_status gpf_shard_commit(gpf_handle h, const double* rows, const int64_t* anc, const double* m_flags,
+                            const int64_t* S_all, int32_t G);
+/* running log_ml_est of this shard (identical on all shards) */
+gpf_status gpf_shard_lml_est(gpf_handle h, double* out);
+
+/* ---- host-side scalar spec (no GPU needed): the same deterministic functions the kernels use ---------- */
+int32_t gpf_host_fix_K(int64_t n_global);
+double  gpf_host_log(double x);
+double  gpf_host_lse(double m, uint64_t S, int32_t K, int32_t flags);     /* m + log(S 2^-K) */
+double  gpf_host_ess(uint64_t S, uint64_t Q_hi, uint64_t Q_lo);           /* S^2 / Q */
+/* host twin of gpf_debug_math (which = 0..5) */
+void    gpf_host_math(int32_t which, const double* a, const double* b, int64_t n, double* out, double* out2);
+
 #ifdef __cplusplus
 }
 #endif

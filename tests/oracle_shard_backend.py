@@ -1,0 +1,123 @@
+"""CPU stand-in for HipShardBackend, built on the oracle's C primitives (TEST INFRASTRUCTURE).
+Lets the gloo tests drive genparticlefilters.jl_amd/sharded.py -- the real routing and collectives --
+without a GPU.  Same method names and tensor shapes as HipShardBackend."""
+import numpy as np
+import torch
+
+from oracle import oracle as o
+
+SPACE_COUNTS = 1 << 62
+
+
+class OracleShardBackend:
+    def __init__(self, model, n_global, gid0, n_local, seed, keep_prev, device):
+        self.device = torch.device("cpu")
+        self.model, self.P = model.model_id, np.ascontiguousarray(model.params, np.float64)
+        self.N, self.gid0, self.n, self.seed, self.keep_prev = n_global, gid0, n_local, seed, bool(keep_prev)
+        self.W = o.row_width(self.model, self.keep_prev)
+        self.rows = np.zeros((self.n, self.W)); self.lw = np.zeros(self.n)
+        self.parents = np.arange(gid0 + 1, gid0 + self.n + 1, dtype=np.int64)
+        self.epoch, self.has_prev, self.lml, self.obs = 0, False, 0.0, None
+        self.K = o.fix_K(n_global)
+        self.L = o.lib()
+
+    # per-particle operations
+    def initialize(self, obs):
+        self.L.o_init(self.model, self.P, self.seed, self.epoch, self.gid0, self.n, self.W, obs, self.rows, self.lw)
+        self.epoch += 1; self.has_prev = False; self.obs = obs; self.lml = 0.0
+
+    def update(self, obs):
+        new = np.empty_like(self.rows)
+        self.L.o_step(self.model, self.P, self.seed, self.epoch, self.gid0, self.n, self.W, int(self.keep_prev), obs, self.rows, new, self.lw)
+        self.rows = new; self.epoch += 1; self.has_prev = True; self.obs = obs
+
+    def rejuvenate(self, method_id, n_iters):
+        new = np.empty_like(self.rows)
+        self.L.o_move(self.model, self.P, self.seed, self.epoch, self.gid0, self.n, self.W, int(self.has_prev), self.obs, n_iters,
+                      method_id, self.rows, new, self.lw)
+        self.rows = new; self.epoch += 1
+
+    # shard phases
+    def weight_max(self):
+        m, f = o.max_flags(self.lw)
+        return torch.tensor([m, float(f & 3)], dtype=torch.float64)
+
+    def weight_scan(self, m_flags):
+        m, f = float(m_flags[0]), int(m_flags[1])
+        uniform = (m == -np.inf) and not (f & 1)
+        self.q = np.zeros(self.n, np.uint64) if f & 3 else o.fixq(self.lw, m, self.K, uniform)
+        self.cdf, S, hi, lo = o.scan(self.q)
+        Q = (hi << 64) | lo
+        return torch.tensor([S] + [(Q >> (32 * k)) & 0xFFFFFFFF for k in range(4)], dtype=torch.int64)
+
+    def residual_scan(self, S_all):
+        S = int(S_all.sum())
+        sh = self.L.o_residual_shift(S, self.N)
+        c = np.empty(self.n, np.uint64); r = np.empty(self.n, np.uint64)
+        self.L.o_residual_split(self.q, self.n, self.N, S, sh, c, r)
+        self.ccdf = np.cumsum(c, dtype=np.uint64)
+        self.rcdf, Rs, _, _ = o.scan(r)
+        self.serve_residual = True
+        return torch.tensor([int(self.ccdf[-1]) if self.n else 0, Rs], dtype=torch.int64)
+
+    def targets(self, method_id, totals, G):
+        t = totals.numpy()
+        S = int(t[:G].sum())
+        if method_id == 0:
+            T = o.targets_multinomial(self.seed, self.epoch, self.gid0, self.n, S)
+        elif method_id == 2:
+            T = o.targets_stratified(self.seed, self.epoch, self.gid0, self.n, self.N, S)
+        else:
+            Ctot, Rs = int(t[G:2 * G].sum()), int(t[2 * G:3 * G].sum())
+            T = o.targets_multinomial(self.seed, self.epoch, self.gid0, self.n, Rs)
+            jg = np.arange(self.gid0, self.gid0 + self.n, dtype=np.uint64)
+            T = np.where(jg < Ctot, jg | np.uint64(SPACE_COUNTS), T)
+        return torch.from_numpy(T.astype(np.int64))
+
+    def serve(self, T_local):
+        t = T_local.numpy().astype(np.uint64)
+        inc = (t & np.uint64(SPACE_COUNTS)) != 0
+        tv = t & np.uint64(SPACE_COUNTS - 1)
+        a = np.zeros(t.size, np.int64)
+        wcdf = self.rcdf if getattr(self, "serve_residual", False) else self.cdf
+        if (~inc).any():
+            a[~inc] = o.upper_bound(wcdf, np.ascontiguousarray(tv[~inc]))
+        if inc.any():
+            a[inc] = o.upper_bound(self.ccdf, np.ascontiguousarray(tv[inc]))
+        rows = o.gather_rows(self.rows, a) if t.size else np.zeros((0, self.W))
+        return torch.from_numpy(rows), torch.from_numpy(a + self.gid0)
+
+    def commit(self, rows, anc, m_flags, S_all):
+        self.rows = np.ascontiguousarray(rows.numpy()).copy()
+        self.parents = anc.numpy() + 1
+        self.lw = np.zeros(self.n)
+        m, f = float(m_flags[0]), int(m_flags[1])
+        if m == -np.inf and not (f & 1):
+            f |= 4
+        self.lml = self.lml + (self.L.o_lse_from(m, int(S_all.sum()), self.K, f) - o.olog(float(self.N)))
+        self.epoch += 1
+        self.serve_residual = False
+
+    def lml_est(self):
+        return self.lml
+
+    def synchronize(self):
+        pass
+
+    def host_lse(self, m, S, K, flags):
+        if m == -np.inf and not (flags & 1):
+            flags |= 4
+        return self.L.o_lse_from(m, S, K, flags)
+
+    def host_ess(self, S, Qhi, Qlo):
+        return self.L.o_ess_from(S, Qhi, Qlo)
+
+    def host_log(self, x):
+        return o.olog(x)
+
+    def fix_K(self, n):
+        return o.fix_K(n)
+
+    @property
+    def state(self):
+        return self

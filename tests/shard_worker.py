@@ -1,0 +1,39 @@
+"""Worker for tests/test_sharded_gloo.py: one rank of a world_size-2 gloo job on CPU."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out_dir):
+    import torch.distributed as dist
+    import gpf_amd as g
+    from gpf_amd import sharded
+    from oracle_shard_backend import OracleShardBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = g.models.by_name(model_name)
+        ys = g.models.simulate(model, T)
+        st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, keep_prev=rejuv is not None,
+                                   backend_factory=OracleShardBackend)
+        ess_log, lml_log = [], []
+        for t in range(1, T):
+            ess = sharded.get_ess(st)
+            ess_log.append(ess)
+            if ess_frac is None or ess < ess_frac * n_global:
+                sharded.pf_resample(st, method, check=False)
+                if rejuv:
+                    sharded.pf_rejuvenate(st, None, (), 1, method=rejuv)
+            sharded.pf_update(st, (t + 1,), (None,), ys[t])
+            lml_log.append(sharded.get_lml_est(st))
+        b = st.backend
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=b.rows, lw=b.lw, parents=b.parents, gid0=b.gid0,
+                 ess=np.array(ess_log), lml=np.array(lml_log))
+    finally:
+        dist.destroy_process_group()

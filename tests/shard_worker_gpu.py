@@ -1,0 +1,36 @@
+"""Worker for tests/test_gpu_sharded.py: one rank of a 2-process job, BOTH ranks on cuda:0 with the HIP shard
+backend; collectives staged through gloo (two ranks cannot share one GPU under RCCL)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out_dir):
+    import torch.distributed as dist
+    import gpf_amd as g
+    from gpf_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = g.models.by_name(model_name)
+        ys = g.models.simulate(model, T)
+        st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, keep_prev=rejuv is not None, device=0)
+        ess_log, lml_log = [], []
+        for t in range(1, T):
+            ess = sharded.get_ess(st); ess_log.append(ess)
+            if ess_frac is None or ess < ess_frac * n_global:
+                sharded.pf_resample(st, method, check=False)
+                if rejuv:
+                    sharded.pf_rejuvenate(st, None, (), 1, method=rejuv)
+            sharded.pf_update(st, (t + 1,), (None,), ys[t])
+            lml_log.append(sharded.get_lml_est(st))
+        loc = st.local
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents,
+                 gid0=st.gid0, ess=np.array(ess_log), lml=np.array(lml_log))
+    finally:
+        dist.destroy_process_group()

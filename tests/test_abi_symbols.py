@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     txt = open(os.path.join(ROOT, "include", "gpf.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(gpf_[a-z_0-9]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(gpf_[A-Za-z_0-9]+)\s*\(", txt)))
 
 
 def test_header_symbols_exported(g):
