@@ -61,7 +61,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("GPF_BENCH_FORCE_SHARDED") == "1"       # exercise the sharded path at world 1
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -72,7 +73,8 @@ def main():
     n_local = args.particles_per_gpu
     n_global = n_local * world
 
-    if world == 1:
+    sharded_mode = world > 1 or force_sharded
+    if not sharded_mode:
         state = g.pf_initialize(model, (1,), ys[0], n_local, seed=SEED, device=local_rank)
 
         def step(t):
@@ -107,11 +109,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = n_global * K / elapsed
-    lml = g.get_lml_est(state) if world == 1 else sharded.get_lml_est(state)
+    lml = sharded.get_lml_est(state) if sharded_mode else g.get_lml_est(state)
 
     # ---- roofline of the dominant kernel: HIP events around every launch, on the handle's stream ----
     roofline = None
-    local = state if world == 1 else state.local
+    local = state.local if sharded_mode else state
     kid_names = g._lib.KERNEL_NAMES
     kids = [g._lib.K_STEP, g._lib.K_MAX, g._lib.K_SCAN, g._lib.K_SEARCH, g._lib.K_GATHER]
     n_ev = min(K, 200)

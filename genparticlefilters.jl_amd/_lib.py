@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpf_hip.so")
+LIB_PATH = os.environ.get("GPF_LIB_OVERRIDE") or os.path.join(_HERE, "libgpf_hip.so")   # override: kernel-ablation builds only
 ABI_VERSION = 1
 
 # gpf_status

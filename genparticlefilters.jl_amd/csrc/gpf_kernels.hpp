@@ -20,7 +20,7 @@ constexpr int WAVE = 64;
 constexpr int NWAVES = BLOCK / WAVE;
 constexpr int SCAN_ITEMS = 8;
 constexpr int TILE = BLOCK * SCAN_ITEMS;          // 2048 weights per scan tile
-constexpr int MAX_PARTIALS = 1024;                // partial (max, flags) slots of the reduce kernels
+constexpr int MAX_PARTIALS = 2048;                // partial (max, flags) slots of the reduce kernels
 constexpr int LDS_TILE_TABLE = 8192;              // tile-prefix entries kept in LDS by the search kernel (64 KiB)
 
 // ----------------------------------------------------------------------------- device scalars
@@ -39,7 +39,7 @@ struct Scalars {
     uint64_t Ctot;             // residual: number of deterministic copies (n_resampled)
     uint64_t Rs;               // residual: sum of residual weights
     uint64_t n_accept;         // accepted MH moves of the last gpf_rejuvenate
-    int32_t  sh;               // residual shift
+    int32_t  timeout;          // set if a bounded inter-workgroup spin gave up (never expected)
     int32_t  pad;
 };
 
@@ -111,14 +111,40 @@ __device__ __forceinline__ uint64_t wave_scan_u64(uint64_t v)
 }
 
 // ----------------------------------------------------------------------------- K1/K2: init & step
+// per-block (max, flags) of the log-weights a kernel has just written: the first pass of safe_softmax
+// (utils.jl:119-128) rides on the kernel that produces the weights instead of re-reading them
+__device__ __forceinline__ void track_max(double v, double& m, int& f)
+{
+    if (v != v) f |= FLAG_NAN;
+    else { m = v > m ? v : m; if (v == __builtin_huge_val()) f |= FLAG_POSINF; }
+}
+__device__ __forceinline__ void block_max_store(double m, int f, double* __restrict__ pmax, int32_t* __restrict__ pflags)
+{
+    m = wave_max_f64(m);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
+    __shared__ double sm_[NWAVES];
+    __shared__ int sf_[NWAVES];
+    if (lane_id() == 0) { sm_[wave_id()] = m; sf_[wave_id()] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < NWAVES; ++w) { m = sm_[w] > m ? sm_[w] : m; f |= sf_[w]; }
+        pmax[blockIdx.x] = m;
+        pflags[blockIdx.x] = f;
+    }
+}
+
 // pf_initialize (initialize.jl:39-41) / pf_update! (update.jl:15-22): one lane per particle, row in,
 // row out, lw += log p(y|x).  Counter-based RNG: no RNG state in memory.
 template <int M>
 __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, int W, double* __restrict__ rows,
-                                                double* __restrict__ lw)
+                                                double* __restrict__ lw, double* __restrict__ pmax,
+                                                int32_t* __restrict__ pflags)
 {
     using Mo = Model<M>;
+    double bm = -__builtin_huge_val(); int bf = 0;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         double x[MAX_DIM];
         Mo::sample(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
@@ -126,20 +152,34 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
 #pragma unroll
         for (int k = 0; k < Mo::D; ++k) r[k] = x[k];
         for (int k = Mo::D; k < W; ++k) r[k] = 0.0;
-        lw[i] = Mo::loglik(a.P, x, a.obs);
+        const double ll = Mo::loglik(a.P, x, a.obs);
+        lw[i] = ll;
+        track_max(ll, bm, bf);
     }
+    block_max_store(bm, bf, pmax, pflags);
 }
 
-template <int M, int W, bool KEEP_PREV>
+// GATHER: the preceding pf_resample! left its ancestor vector pending; this kernel reads row anc[i]
+// instead of row i (new_traces .= view(traces, parents), resample.jl:60, fused into the propagate) and
+// the incoming log-weights are known to be 0 (update_weights!, resample.jl:195): lw = ll, no read.
+template <int M, int W, bool KEEP_PREV, bool GATHER>
 __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
-                                                int64_t n, const double* __restrict__ rows_in,
-                                                double* __restrict__ rows_out, double* __restrict__ lw)
+                                                int64_t n, const int32_t* __restrict__ anc,
+                                                const double* __restrict__ rows_in,
+                                                double* __restrict__ rows_out, double* __restrict__ lw,
+                                                double* __restrict__ pmax, int32_t* __restrict__ pflags)
 {
     using Mo = Model<M>;
     constexpr int D = Mo::D;
+    double bm = -__builtin_huge_val(); int bf = 0;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+#ifdef GPF_ABL_STEP_NOGATHER
+        const int64_t srow = i;
+#else
+        const int64_t srow = GATHER ? (int64_t)anc[i] : i;
+#endif
         double r[W];
-        const double2* src = reinterpret_cast<const double2*>(rows_in + i * W);
+        const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
 #pragma unroll
         for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
         double xn[MAX_DIM];
@@ -157,8 +197,11 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
         double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(o[2 * c], o[2 * c + 1]);
-        lw[i] = lw[i] + ll;
+        const double nl = GATHER ? ll : lw[i] + ll;
+        lw[i] = nl;
+        track_max(nl, bm, bf);
     }
+    block_max_store(bm, bf, pmax, pflags);
 }
 
 // K7/K8: pf_move_accept! with Gen.mh on the current step's latent (rejuvenate.jl:40-53) and
@@ -168,11 +211,13 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
                                                 int64_t n, int has_prev, int n_iters,
                                                 const double* __restrict__ rows_in,
                                                 double* __restrict__ rows_out, double* __restrict__ lw,
-                                                unsigned long long* __restrict__ n_accept)
+                                                unsigned long long* __restrict__ n_accept,
+                                                double* __restrict__ pmax, int32_t* __restrict__ pflags)
 {
     using Mo = Model<M>;
     constexpr int D = Mo::D, NB = Mo::NBLK;
     unsigned long long acc = 0;
+    double bm = -__builtin_huge_val(); int bf = 0;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         double r[W];
         const double2* src = reinterpret_cast<const double2*>(rows_in + i * W);
@@ -213,11 +258,12 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
         double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(r[2 * c], r[2 * c + 1]);
-        if (REWEIGHT) lw[i] = lw[i] + wsum;
+        if (REWEIGHT) { const double nl = lw[i] + wsum; lw[i] = nl; track_max(nl, bm, bf); }
     }
     // one atomic per wave
     unsigned long long t = wave_sum_u64(acc);
     if (lane_id() == 0 && t) atomicAdd(n_accept, t);
+    if (REWEIGHT) block_max_store(bm, bf, pmax, pflags);
 }
 
 // ----------------------------------------------------------------------------- K3: max + flags
@@ -268,13 +314,19 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ pmax, c
 }
 
 // ----------------------------------------------------------------------------- K4: fixed-point scan
-// Single-pass inclusive prefix sum with decoupled look-back over 2048-element tiles.
-// A tile descriptor is ONE naturally aligned 8-byte word {2-bit status | 62-bit value}, written
-// and polled with relaxed agent-scope atomics (the data IS the flag: no fence, placement-independent;
-// per-XCD L2s are not coherent, so plain loads/stores would not do).
-// Deadlock freedom does not rely on dispatch order: the grid is sized to be fully resident and
-// block b owns tiles b, b+G, b+2G, ... so a tile only ever waits on tiles of resident blocks.
-constexpr uint64_t DESC_AGG = 1ull << 62, DESC_PREFIX = 2ull << 62, DESC_MASK = (1ull << 62) - 1;
+// Single-pass inclusive prefix sum over 2048-element tiles.  Every tile publishes its AGGREGATE at once;
+// its exclusive prefix is then ONE round trip: the whole workgroup reads, in parallel, the aggregates of
+// all earlier tiles of the same round (<= grid-1 <= 511 words, two per lane) plus the inclusive PREFIX of
+// the last tile of the previous round, and block-reduces them.  (A classic decoupled look-back walks 64
+// predecessors per dependent L2 round trip; with <= a few thousand tiles the flat read is shorter.)
+// A descriptor is ONE naturally aligned 8-byte word {valid bit 63 | 62-bit value}, written and polled
+// with relaxed agent-scope atomics (the data IS the flag: no fence, placement-independent; per-XCD L2s
+// are not coherent, so plain loads/stores would not do).  Deadlock freedom does not rely on dispatch
+// order: the grid is sized to be fully resident and block b owns tiles b, b+G, b+2G, ...  Spins are
+// bounded (Scalars::timeout).  Descriptor buffers are double-buffered per scan channel: a launch polls
+// buffer `dcur` and zeroes `dnext` for the following launch, so no memset node is needed.
+constexpr uint64_t DESC_VALID = 1ull << 63, DESC_MASK = (1ull << 62) - 1;
+constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 __device__ __forceinline__ void desc_store(uint64_t* p, uint64_t v)
 {
@@ -284,135 +336,161 @@ __device__ __forceinline__ uint64_t desc_load(const uint64_t* p)
 {
     return __hip_atomic_load(const_cast<uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ uint64_t desc_wait(const uint64_t* p, int32_t* timeout)
+{
+    uint64_t d = desc_load(p);
+    unsigned spins = 0;
+    while (!(d & DESC_VALID)) {
+        __builtin_amdgcn_s_sleep(1);
+        d = desc_load(p);
+        if (++spins > SPIN_LIMIT) { *timeout = 1; break; }
+    }
+    return d & DESC_MASK;
+}
 
-// input functors: q[0..8) of thread t in the tile starting at base (blocked arrangement)
+// input functors: the two fixed-point weights at elements idx, idx+1 (idx even; zero beyond n)
 struct InFixQ {                // q_i = trunc(exp(p_i - m) 2^K + 1/2); uniform fallback q_i = 1
     PrioView pv;
     const int32_t* order;      // optional permutation (sort_particles, resample.jl:156-157)
     int K;
     double m; int flags;       // filled in-kernel from the partials
-    __device__ __forceinline__ void load(int64_t i0, int64_t n, uint64_t* q) const
+    __device__ __forceinline__ uint64_t one(double v, bool uniform, bool bad) const
+    {
+#ifdef GPF_ABL_SCAN_NOEXP
+        return 1 + (d2u(v) & 0xff);
+#endif
+        return uniform ? 1 : (bad ? 0 : exp_fix(v - m, K));
+    }
+    __device__ __forceinline__ void load2(int64_t idx, int64_t n, uint64_t& q0, uint64_t& q1) const
     {
         const bool uniform = (flags & FLAG_ALL_NEGINF) != 0, bad = (flags & (FLAG_NAN | FLAG_POSINF)) != 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
-            const int64_t i = i0 + k;
-            uint64_t v = 0;
-            if (i < n) {
-                if (uniform) v = 1;
-                else if (!bad) v = exp_fix(pv.at(order ? (int64_t)order[i] : i) - m, K);
-            }
-            q[k] = v;
+        if (pv.mode == 0 && order == nullptr && idx + 1 < n) {          // 16 B per lane, 1 KiB per wave-instruction
+            const double2 v = *reinterpret_cast<const double2*>(pv.lw + idx);
+            q0 = one(v.x, uniform, bad); q1 = one(v.y, uniform, bad);
+        } else {
+            q0 = idx < n ? one(pv.at(order ? (int64_t)order[idx] : idx), uniform, bad) : 0;
+            q1 = idx + 1 < n ? one(pv.at(order ? (int64_t)order[idx + 1] : idx + 1), uniform, bad) : 0;
         }
     }
 };
 struct InResidual {            // from the weight CDF: counts (N q_i) div S, or residuals ((N q_i) mod S) >> sh
-    const uint64_t* cdf;
-    const Scalars* sc;
-    const WSum* ws;            // summary of the weights being resampled
+    const uint64_t* cdf;       // padded to whole tiles (flat beyond n, so q = 0 there)
+    const WSum* ws;            // summary of the weights being resampled (S = GLOBAL sum)
     int64_t N;                 // global particle count
     int want_r;
-    __device__ __forceinline__ void load(int64_t i0, int64_t n, uint64_t* q) const
+    __device__ __forceinline__ void load2(int64_t idx, int64_t n, uint64_t& q0, uint64_t& q1) const
     {
         const uint64_t S = ws->S;
-        const int sh = sc->sh;
-        uint64_t prev = (i0 > 0 && i0 <= n) ? cdf[i0 - 1] : 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
-            const int64_t i = i0 + k;
-            uint64_t v = 0;
-            if (i < n && S != 0) {
-                const uint64_t c = cdf[i];
-                const uint64_t nq = (uint64_t)N * (c - prev);
-                prev = c;
-                v = want_r ? ((nq % S) >> sh) : (nq / S);
-            }
-            q[k] = v;
+        const int sh = residual_shift(S, N);
+        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(cdf + idx);
+        const uint64_t prev = idx > 0 ? cdf[idx - 1] : 0;
+        q0 = 0; q1 = 0;
+        if (S != 0) {
+            const uint64_t n0 = (uint64_t)N * (c.x - prev), n1 = (uint64_t)N * (c.y - c.x);
+            q0 = want_r ? ((n0 % S) >> sh) : (n0 / S);
+            q1 = want_r ? ((n1 % S) >> sh) : (n1 / S);
         }
+        if (idx >= n) q0 = 0;
+        if (idx + 1 >= n) q1 = 0;
     }
 };
 
-template <class In, bool WANT_Q>
+// where a scan writes: the CDF (padded to whole tiles) and its coarser levels, by-products of the same pass
+struct ScanOut {
+    uint64_t* cdf;             // [ntiles*2048] inclusive prefix of every element (nullptr: totals only)
+    uint64_t* t16;             // [ntiles*128]  inclusive prefix at the end of every 16-element group (one 128-B line of cdf)
+    uint64_t* t256;            // [ntiles*8]    ... of every 256-element group (one 128-B line of t16)
+};
+
+// Arrangement: wave w of the workgroup owns 512 consecutive elements of the tile as 4 rows of 128;
+// lane l holds elements 2l, 2l+1 of each row, so every global access is 16 B per lane, contiguous
+// across the wave (1 KiB per wave-instruction), for the loads AND the CDF stores.
+constexpr int SCAN_ROWS = 4;
+// MODE 0: plain scan of In; 1: fixed-point weights (folds the max partials); 2: as 1, plus sum q^2 for the ESS
+template <class In, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles,
                                                 const double* __restrict__ pmax, const int32_t* __restrict__ pflags,
-                                                int np, WSum* __restrict__ ws_out,
-                                                uint64_t* __restrict__ cdf, uint64_t* __restrict__ desc,
-                                                uint64_t* __restrict__ total_out, uint64_t* __restrict__ blockQ)
+                                                int np, WSum* __restrict__ ws_out, ScanOut out,
+                                                uint64_t* __restrict__ dcur, uint64_t* __restrict__ dnext,
+                                                uint64_t* __restrict__ total_out, uint64_t* __restrict__ blockQ,
+                                                int32_t* __restrict__ timeout)
 {
     __shared__ double sm[NWAVES];
     __shared__ int sf[NWAVES];
     __shared__ uint64_t s_wave[NWAVES];
-    __shared__ uint64_t s_excl;
-    if constexpr (WANT_Q) {
+    __shared__ uint64_t s_red[NWAVES];
+    uint64_t* const d_agg = dcur;
+    uint64_t* const d_pre = dcur + ntiles;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * BLOCK) dnext[i] = 0;
+    constexpr bool WANT_Q = MODE == 2;
+    if constexpr (MODE >= 1) {
         double m; int f;
+#ifdef GPF_ABL_SCAN_NOFOLD
+        m = 0.0; f = 0; (void)sm; (void)sf;
+#else
         fold_partials(pmax, pflags, np, sm, sf, m, f);
+#endif
         in.m = m; in.flags = f;
         if (blockIdx.x == 0 && threadIdx.x == 0) { ws_out->m = m; ws_out->flags = f; }
     }
     uint64_t ql[4] = {0, 0, 0, 0};
     const int lane = lane_id(), wv = wave_id();
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t i0 = tile * TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-        uint64_t q[SCAN_ITEMS];
-        in.load(i0, n, q);
-        uint64_t tsum = 0;
+        const int64_t wbase = tile * TILE + (int64_t)wv * (SCAN_ROWS * 2 * WAVE) + 2 * lane;
+        uint64_t p[2 * SCAN_ROWS];                     // inclusive prefixes inside the wave's 512-element chunk
+        uint64_t carry = 0;
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
+        for (int k = 0; k < SCAN_ROWS; ++k) {
+            uint64_t q0, q1;
+            in.load2(wbase + k * 2 * WAVE, n, q0, q1);
             if constexpr (WANT_Q) {
-                const uint64_t lo = q[k] * q[k], hi = __umul64hi(q[k], q[k]);
+                uint64_t lo = q0 * q0, hi = __umul64hi(q0, q0);
+                ql[0] += lo & 0xffffffffull; ql[1] += lo >> 32; ql[2] += hi & 0xffffffffull; ql[3] += hi >> 32;
+                lo = q1 * q1; hi = __umul64hi(q1, q1);
                 ql[0] += lo & 0xffffffffull; ql[1] += lo >> 32; ql[2] += hi & 0xffffffffull; ql[3] += hi >> 32;
             }
-            tsum += q[k];
-            q[k] = tsum;                               // thread-local inclusive
+            const uint64_t pair = q0 + q1;
+            const uint64_t inc = wave_scan_u64(pair);
+            p[2 * k] = carry + (inc - pair) + q0;
+            p[2 * k + 1] = p[2 * k] + q1;
+            carry += shfl_u64(inc, WAVE - 1);
         }
-        const uint64_t winc = wave_scan_u64(tsum);     // inclusive over lanes
-        if (lane == WAVE - 1) s_wave[wv] = winc;
+        if (lane == 0) s_wave[wv] = carry;             // wave total
         __syncthreads();
         uint64_t wexcl = 0, agg = 0;
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) { if (w < wv) wexcl += s_wave[w]; agg += s_wave[w]; }
-        // ---- decoupled look-back, wave 0 ----
-        if (wv == 0) {
-            uint64_t excl = 0;
-            if (tile == 0) {
-                if (lane == 0) desc_store(desc, DESC_PREFIX | agg);
-            } else {
-                if (lane == 0) desc_store(desc + tile, DESC_AGG | agg);
-                int64_t base = tile - 1;
-                while (true) {
-                    const int64_t idx = base - lane;
-                    uint64_t d = DESC_PREFIX;          // virtual tile -1: prefix 0
-                    if (idx >= 0) {
-                        d = desc_load(desc + idx);
-                        while ((d >> 62) == 0) { __builtin_amdgcn_s_sleep(1); d = desc_load(desc + idx); }
-                    }
-                    const unsigned long long pm = __ballot((d >> 62) == 2);
-                    const int first = pm ? (int)__builtin_ctzll(pm) : WAVE;   // nearest predecessor holding a prefix
-                    excl += wave_sum_u64(lane <= first ? (d & DESC_MASK) : 0);
-                    if (pm) break;
-                    base -= WAVE;
-                }
-                if (lane == 0) desc_store(desc + tile, DESC_PREFIX | (excl + agg));
-            }
-            if (lane == 0) s_excl = excl;
-        }
+        if (threadIdx.x == 0) desc_store(d_agg + tile, DESC_VALID | agg);
+        // exclusive prefix of this tile: one parallel read of the round's earlier aggregates
+        const int64_t first = (tile / gridDim.x) * gridDim.x;
+        uint64_t acc = 0;
+#ifndef GPF_ABL_SCAN_NOWAIT
+        for (int64_t idx = first + threadIdx.x; idx < tile; idx += BLOCK) acc += desc_wait(d_agg + idx, timeout);
+        if (first > 0 && threadIdx.x == BLOCK - 1) acc += desc_wait(d_pre + first - 1, timeout);
+#endif
+        acc = wave_sum_u64(acc);
+        if (lane == 0) s_red[wv] = acc;
         __syncthreads();
-        const uint64_t off = s_excl + wexcl + (winc - tsum);
-        if (cdf) {
-            if (i0 + SCAN_ITEMS <= n) {
-                ulonglong2* dst = reinterpret_cast<ulonglong2*>(cdf + i0);
+        uint64_t excl = 0;
 #pragma unroll
-                for (int c = 0; c < SCAN_ITEMS / 2; ++c) dst[c] = make_ulonglong2(off + q[2 * c], off + q[2 * c + 1]);
-            } else {
+        for (int w = 0; w < NWAVES; ++w) excl += s_red[w];
+        if (threadIdx.x == 0) desc_store(d_pre + tile, DESC_VALID | (excl + agg));
+        const uint64_t off = excl + wexcl;
+        if (out.cdf) {
 #pragma unroll
-                for (int k = 0; k < SCAN_ITEMS; ++k) if (i0 + k < n) cdf[i0 + k] = off + q[k];
+            for (int k = 0; k < SCAN_ROWS; ++k) {
+                const int64_t idx = wbase + k * 2 * WAVE;
+                const uint64_t v1 = off + p[2 * k + 1];
+                *reinterpret_cast<ulonglong2*>(out.cdf + idx) = make_ulonglong2(off + p[2 * k], v1);
+                if ((lane & 7) == 7) out.t16[(idx + 1) >> 4] = v1;                     // element idx+1 = 15 (mod 16)
+                if (lane == WAVE - 1 && (k & 1)) out.t256[(idx + 1) >> 8] = v1;         // ... = 255 (mod 256)
             }
         }
-        if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) *total_out = off + tsum;
-        __syncthreads();                                // s_wave / s_excl reuse
+        if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) *total_out = off + p[2 * SCAN_ROWS - 1];
+        __syncthreads();                                // s_wave / s_red reuse
     }
     if constexpr (WANT_Q) {
-        // block partial of the limb sums of sum q^2 (plain stores, folded later by k_scalar)
+        // block partial of the limb sums of sum q^2 (plain stores, folded on demand by k_fold_q)
         __shared__ uint64_t s_q[NWAVES][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
@@ -427,57 +505,85 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
 }
 
 // ----------------------------------------------------------------------------- scalar bookkeeping
-// one workgroup; ops on the device scalar block so that no host round trip is needed per step
-enum : int { OP_FOLD_Q = 1,          // ws->Ql = sum of block limb partials
-             OP_LML_ACCUM = 2,       // update_lml_est!  (resample.jl:178-182): lml += logsumexp(lw) - log N
-             OP_RESIDUAL_PREP = 4,   // sh = residual_shift(S, N)
-             OP_ZERO_ACCEPT = 8 };
-__global__ __launch_bounds__(BLOCK) void k_scalar(int ops, Scalars* sc, WSum* ws, const uint64_t* blockQ, int nblk,
-                                                  int K, int64_t n_global, double logN)
+// sum of the scan blocks' limb partials of sum q^2 -> ws->Ql (only needed when the ESS is asked for)
+__global__ __launch_bounds__(BLOCK) void k_fold_q(WSum* ws, const uint64_t* __restrict__ blockQ, int nblk)
 {
-    if (ops & OP_FOLD_Q) {
-        __shared__ uint64_t s_q[NWAVES][4];
-        uint64_t ql[4] = {0, 0, 0, 0};
-        for (int b = threadIdx.x; b < nblk; b += BLOCK)
-            for (int k = 0; k < 4; ++k) ql[k] += blockQ[(int64_t)b * 4 + k];
-        for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
-        if (lane_id() == 0) for (int k = 0; k < 4; ++k) s_q[wave_id()][k] = ql[k];
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            uint64_t t = 0;
-            for (int w = 0; w < NWAVES; ++w) t += s_q[w][threadIdx.x];
-            ws->Ql[threadIdx.x] = t;
-        }
-    }
-    if (threadIdx.x == 0) {
-        if (ops & OP_LML_ACCUM) sc->lml_est = sc->lml_est + (lse_from(sc->raw.m, sc->raw.S, K, sc->raw.flags) - logN);
-        if (ops & OP_RESIDUAL_PREP) sc->sh = residual_shift(ws->S, n_global);
-        if (ops & OP_ZERO_ACCEPT) sc->n_accept = 0;
+    __shared__ uint64_t s_q[NWAVES][4];
+    uint64_t ql[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblk; b += BLOCK)
+        for (int k = 0; k < 4; ++k) ql[k] += blockQ[(int64_t)b * 4 + k];
+    for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
+    if (lane_id() == 0) for (int k = 0; k < 4; ++k) s_q[wave_id()][k] = ql[k];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint64_t t = 0;
+        for (int w = 0; w < NWAVES; ++w) t += s_q[w][threadIdx.x];
+        ws->Ql[threadIdx.x] = t;
     }
 }
 
 // ----------------------------------------------------------------------------- K5: ancestor search
-// first index with cdf[i] > T: coarse over the per-tile inclusive prefixes (scan descriptors, in LDS),
-// fine inside one 16 KiB tile of the CDF
-__device__ __forceinline__ int64_t upper_bound2(const uint64_t* __restrict__ cdf, int64_t n,
-                                                const uint64_t* tp, int64_t ntiles, uint64_t T)
+// a = first index with cdf[a] > T.  The CDF comes with coarser levels written by the scan (fan-out 16):
+// top level (per-256 prefixes, or per-tile when that does not fit) is binary-searched in LDS, then each
+// further level costs ONE 128-byte line: 16 consecutive u64 loaded with 8 independent 16-B loads and
+// compared in registers.  Two dependent L2 round trips per slot instead of eleven.
+struct CdfLevels {
+    const uint64_t* cdf;  const uint64_t* t16;  const uint64_t* t256;  const uint64_t* ttile;   // ttile: descriptor words
+};
+__device__ __forceinline__ int count_le_line(const uint64_t* __restrict__ line, uint64_t T)
 {
-    int64_t lo = 0, hi = ntiles;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((tp[mid] & DESC_MASK) > T) hi = mid; else lo = mid + 1; }
-    if (lo >= ntiles) return n - 1;
-    int64_t a = lo * TILE, b = a + TILE < n ? a + TILE : n;
-    while (a < b) { const int64_t mid = (a + b) >> 1; if (cdf[mid] > T) b = mid; else a = mid + 1; }
-    return a < n ? a : n - 1;
+    const ulonglong2* v = reinterpret_cast<const ulonglong2*>(line);
+    ulonglong2 r[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = v[c];
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cnt += (r[c].x <= T) + (r[c].y <= T);
+    return cnt;
+}
+// top: LDS (or global) copy of the top level; top_is_256 selects which level it is
+__device__ __forceinline__ int64_t find_index(const CdfLevels& L, const uint64_t* top, bool top_is_256, int64_t n,
+                                              int64_t ntiles, uint64_t T)
+{
+    int64_t s256;
+#ifdef GPF_ABL_SEARCH_NOLDS
+    if (top_is_256) { s256 = (int64_t)(T % (uint64_t)(ntiles * 8)); } else
+#endif
+    if (top_is_256) {
+        int64_t lo = 0, hi = ntiles * 8;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (top[mid] > T) hi = mid; else lo = mid + 1; }
+        s256 = lo;
+    } else {
+        int64_t lo = 0, hi = ntiles;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((top[mid] & DESC_MASK) > T) hi = mid; else lo = mid + 1; }
+        if (lo >= ntiles) return n - 1;
+        const uint64_t* g = L.t256 + lo * 8;           // the tile's 8 per-256 prefixes: 64 B
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c += (g[e] <= T);
+        s256 = lo * 8 + c;
+    }
+    if (s256 >= ntiles * 8) return n - 1;
+#ifdef GPF_ABL_SEARCH_NOLINES
+    return s256 * 256 < n ? s256 * 256 : n - 1;
+#endif
+    const int64_t s16 = s256 * 16 + count_le_line(L.t16 + s256 * 16, T);
+    if (s16 >= ntiles * (TILE / 16)) return n - 1;
+    const int64_t idx = s16 * 16 + count_le_line(L.cdf + s16 * 16, T);
+    return idx < n ? idx : n - 1;
 }
 
 struct SearchArgs {
-    const uint64_t* cdf;  const uint64_t* desc;  int64_t ntiles;      // weights (or residual weights for the tail)
-    const uint64_t* ccdf; const uint64_t* cdesc;                      // residual: copy counts
+    CdfLevels w;                                                      // weights (or residual weights for the tail)
+    CdfLevels c;                                                      // residual: copy counts
+    int64_t ntiles;
     const int32_t* order;                                             // sorted stratified
-    const Scalars* sc;
+    Scalars* sc;
     const WSum* ws;                                                   // summary of the sampled weights
+    const WSum* raw;                                                  // summary of state.log_weights (log-ML estimate)
     int64_t n, n_global, gid0;
     uint64_t seed; uint32_t epoch;
+    int K; double logN;
     int32_t* anc;
 };
 
@@ -485,18 +591,26 @@ template <int METHOD>
 __global__ __launch_bounds__(BLOCK) void k_search(SearchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* tp = reinterpret_cast<uint64_t*>(smem);
-    uint64_t* ctp = tp + a.ntiles;
-    const bool in_lds = (METHOD == 1 ? 2 : 1) * a.ntiles <= LDS_TILE_TABLE;
+    uint64_t* tw = reinterpret_cast<uint64_t*>(smem);
+    constexpr int NT = METHOD == 1 ? 2 : 1;
+    const bool top256 = NT * a.ntiles * 8 <= LDS_TILE_TABLE;
+    const bool in_lds = top256 || NT * a.ntiles <= LDS_TILE_TABLE;
+    const int64_t tn = top256 ? a.ntiles * 8 : a.ntiles;
+    uint64_t* tc = tw + tn;
     if (in_lds) {
-        for (int64_t t = threadIdx.x; t < a.ntiles; t += BLOCK) {
-            tp[t] = a.desc[t];
-            if (METHOD == 1) ctp[t] = a.cdesc[t];
+        const uint64_t* srcw = top256 ? a.w.t256 : a.w.ttile;
+        const uint64_t* srcc = top256 ? a.c.t256 : a.c.ttile;
+        for (int64_t t = threadIdx.x; t < tn; t += BLOCK) {
+            tw[t] = srcw[t];
+            if (METHOD == 1) tc[t] = srcc[t];
         }
         __syncthreads();
     }
-    const uint64_t* tpp = in_lds ? tp : a.desc;
-    const uint64_t* ctpp = in_lds ? ctp : a.cdesc;
+    const uint64_t* topw = in_lds ? tw : a.w.ttile;
+    const uint64_t* topc = in_lds ? tc : a.c.ttile;
+    // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
     const uint64_t S = (METHOD == 1) ? a.sc->Rs : a.ws->S;
     const uint64_t N = (uint64_t)a.n_global;
     for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < a.n; j += (int64_t)gridDim.x * BLOCK) {
@@ -505,17 +619,17 @@ __global__ __launch_bounds__(BLOCK) void k_search(SearchArgs a)
         const uint64_t U = u64(b.w0, b.w1);
         int64_t idx;
         if (METHOD == 0) {                       // multinomial, resample.jl:59
-            idx = upper_bound2(a.cdf, a.n, tpp, a.ntiles, mulhi64(U, S));
+            idx = find_index(a.w, topw, top256, a.n, a.ntiles, mulhi64(U, S));
         } else if (METHOD == 2) {                // stratified, resample.jl:159-168
             const uint64_t B = S / N, rem = S % N;
             const uint64_t L0 = jg * B + (jg * rem) / N;
             const uint64_t L1 = (jg + 1) * B + ((jg + 1) * rem) / N;
-            const int64_t k = upper_bound2(a.cdf, a.n, tpp, a.ntiles, L0 + mulhi64(U, L1 - L0));
+            const int64_t k = find_index(a.w, topw, top256, a.n, a.ntiles, L0 + mulhi64(U, L1 - L0));
             idx = a.order ? (int64_t)a.order[k] : k;
         } else {                                 // residual, resample.jl:96-115
             const uint64_t Ctot = a.sc->Ctot;
-            if (jg < Ctot) idx = upper_bound2(a.ccdf, a.n, ctpp, a.ntiles, jg);
-            else           idx = upper_bound2(a.cdf, a.n, tpp, a.ntiles, mulhi64(U, S));
+            if (jg < Ctot) idx = find_index(a.c, topc, top256, a.n, a.ntiles, jg);
+            else           idx = find_index(a.w, topw, top256, a.n, a.ntiles, mulhi64(U, S));
         }
         a.anc[j] = (int32_t)idx;
     }
@@ -680,8 +794,7 @@ __global__ void k_set_global(const int64_t* __restrict__ S_all, int G, int64_t n
         uint64_t S = 0;
         for (int g = 0; g < G; ++g) S += (uint64_t)S_all[g];
         ws->S = S;
-        sc->sh = residual_shift(S, n_global);
-        (void)out2;
+        (void)sc; (void)n_global; (void)out2;
     }
 }
 __global__ void k_export_residual(const Scalars* sc, int64_t* out2)
@@ -721,8 +834,7 @@ __global__ __launch_bounds__(BLOCK) void k_targets(uint64_t seed, uint32_t epoch
 // serve requests in LOCAL coordinates: ancestor lookup in this shard's CDF + row gather
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_serve(const int64_t* __restrict__ T_local, int64_t m_req,
-                                                 const uint64_t* __restrict__ cdf, const uint64_t* __restrict__ desc,
-                                                 const uint64_t* __restrict__ ccdf, const uint64_t* __restrict__ cdesc,
+                                                 CdfLevels lw_, CdfLevels lc_,
                                                  int64_t n, int64_t ntiles, int64_t gid0, const double* __restrict__ rows,
                                                  double* __restrict__ rows_out, int64_t* __restrict__ anc_out)
 {
@@ -730,8 +842,8 @@ __global__ __launch_bounds__(BLOCK) void k_serve(const int64_t* __restrict__ T_l
     for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m_req; r += (int64_t)gridDim.x * BLOCK) {
         const int64_t t = T_local[r];
         int64_t a;
-        if (t & SPACE_COUNTS) a = upper_bound2(ccdf, n, cdesc, ntiles, (uint64_t)(t & ~SPACE_COUNTS));
-        else                  a = upper_bound2(cdf, n, desc, ntiles, (uint64_t)t);
+        if (t & SPACE_COUNTS) a = find_index(lc_, lc_.ttile, false, n, ntiles, (uint64_t)(t & ~SPACE_COUNTS));
+        else                  a = find_index(lw_, lw_.ttile, false, n, ntiles, (uint64_t)t);
         anc_out[r] = gid0 + a;
         const double2* src = reinterpret_cast<const double2*>(rows) + a * C;
         double2* dst = reinterpret_cast<double2*>(rows_out) + r * C;

@@ -223,11 +223,10 @@ GPF_HD double atan2_(double y, double x)
 enum : int { FLAG_NAN = 1, FLAG_POSINF = 2, FLAG_ALL_NEGINF = 4 };
 
 // K = min(52, 62 - ceil(log2 N)): N 2^K <= 2^62
+GPF_HD int ceil_log2(int64_t n) { return n > 1 ? 64 - (int)__builtin_clzll((unsigned long long)(n - 1)) : 0; }
 GPF_HD int fix_K(int64_t n_global)
 {
-    int cl = 0;
-    while (((int64_t)1 << cl) < n_global) ++cl;
-    const int K = 62 - cl;
+    const int K = 62 - ceil_log2(n_global);
     return K > 52 ? 52 : K;
 }
 // logsumexp = m + log(S 2^-K)   (resample.jl:180 / utils.jl:100 on the exact integer sum)
@@ -246,11 +245,8 @@ GPF_HD double ess_from(uint64_t S, uint64_t Qhi, uint64_t Qlo)
 }
 GPF_HD int residual_shift(uint64_t S, int64_t N)
 {
-    int bl = 0;
-    while (bl < 64 && (S >> bl) != 0) ++bl;
-    int cl = 0;
-    while (((int64_t)1 << cl) < N) ++cl;
-    const int sh = bl + cl - 62;
+    const int bl = S ? 64 - (int)__builtin_clzll((unsigned long long)S) : 0;     // bit length of S
+    const int sh = bl + ceil_log2(N) - 62;
     return sh > 0 ? sh : 0;
 }
 

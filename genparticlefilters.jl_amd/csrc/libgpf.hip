@@ -42,8 +42,12 @@ struct gpf_filter {
     double* rows[2] = {nullptr, nullptr};
     int cur = 0;
     double *lw = nullptr, *lws = nullptr, *lp = nullptr, *dtmp = nullptr;
-    uint64_t* cdf[3] = {nullptr, nullptr, nullptr};
-    uint64_t* desc[3] = {nullptr, nullptr, nullptr};
+    uint64_t* cdf[3] = {nullptr, nullptr, nullptr};     // padded to whole tiles
+    uint64_t* t16[3] = {nullptr, nullptr, nullptr};     // coarser levels written by the scan (gpf_kernels.hpp ScanOut)
+    uint64_t* t256[3] = {nullptr, nullptr, nullptr};
+    uint64_t* desc[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [channel][ping-pong]: agg | prefix
+    int dcur[3] = {0, 0, 0};
+    const uint64_t* table[3] = {nullptr, nullptr, nullptr};   // per-tile inclusive prefixes of the last scan per channel
     int32_t *anc = nullptr, *order = nullptr, *idx_in = nullptr;
     uint64_t *keys = nullptr, *keys_out = nullptr;
     void* sort_tmp = nullptr;
@@ -56,6 +60,11 @@ struct gpf_filter {
     Scalars* h_sc = nullptr;       // pinned mirror
     uint32_t epoch = 0;
     bool initialized = false, has_prev = false, raw_valid = false, serve_residual = false;
+    bool max_valid = false;        // pmax/pflags hold the block partials of the current log-weights (written by the producer kernel)
+    int max_np = 0;
+    bool raw_has_q = false;        // the raw summary's scan also accumulated sum q^2 (blockQ)
+    bool raw_q_folded = false;     // sc->raw.Ql folded from blockQ
+    bool pending_gather = false;   // a resample left (rows[cur], anc) un-gathered; log-weights are 0
     Timer timers[GPF_K_COUNT];
     std::string err;
 };
@@ -102,18 +111,24 @@ gpf_status timed(gpf_filter* h, int id, F&& launch)
 }
 
 // ------------------------------------------------------------------ model dispatch
+int step_grid(const gpf_filter* h) { return std::min(grid_for(h, h->n, 4), MAX_PARTIALS); }
+
 template <int M, bool KEEP>
 void launch_step_t(gpf_filter* h, int grid)
 {
     constexpr int Wc = row_width(Model<M>::D, KEEP);
-    hipLaunchKernelGGL((k_step<M, Wc, KEEP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                       h->cfg.gid0, h->n, h->rows[h->cur], h->rows[1 - h->cur], h->lw);
+    if (h->pending_gather)
+        hipLaunchKernelGGL((k_step<M, Wc, KEEP, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags);
+    else
+        hipLaunchKernelGGL((k_step<M, Wc, KEEP, false>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags);
 }
 template <int M>
 void launch_init_t(gpf_filter* h, int grid)
 {
     hipLaunchKernelGGL((k_init<M>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                       h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw);
+                       h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw, h->pmax, h->pflags);
 }
 template <int M, bool RW>
 void launch_move_t(gpf_filter* h, int grid, int n_iters)
@@ -121,7 +136,7 @@ void launch_move_t(gpf_filter* h, int grid, int n_iters)
     constexpr int Wc = row_width(Model<M>::D, true);
     hipLaunchKernelGGL((k_move<M, Wc, RW>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                        h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                       reinterpret_cast<unsigned long long*>(&h->sc->n_accept));
+                       reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
 }
 
 #define DISPATCH_MODEL(h, CALL)                                                                  \
@@ -144,39 +159,76 @@ void launch_gather(gpf_filter* h, const PrioView& pv, double* lw_out)
     }
 }
 
-// ------------------------------------------------------------------ weight summary = max + scan (+ scalar ops)
+PrioView raw_view(const gpf_filter* h) { return PrioView{h->lw, nullptr, 0.0, 0}; }
+
+// a pending resample gather is executed now: rows[1-cur][j] = rows[cur][anc[j]], lw = 0
+gpf_status materialize(gpf_filter* h)
+{
+    if (!h->pending_gather) return GPF_OK;
+    gpf_status s = timed(h, GPF_K_GATHER, [&] { launch_gather(h, raw_view(h), h->lw); });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
+    h->pending_gather = false;
+    h->max_valid = false;           // log-weights are all 0 now
+    return GPF_OK;
+}
+
+// ------------------------------------------------------------------ weight summary = (max) + scan
 int scan_grid(const gpf_filter* h) { return (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, 2 * (int64_t)h->n_cu)); }
 
-gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, uint64_t* cdf, uint64_t* desc,
-                     const int32_t* order, int extra_ops)
+// one scan launch on descriptor channel `ch` (0 weights, 1 residual counts, 2 residual weights)
+template <class In, int FIXQ>
+gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, bool want_cdf, uint64_t* total_out)
 {
-    const int gp = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
-    gpf_status s = timed(h, GPF_K_MAX, [&] {
-        hipLaunchKernelGGL(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, pv, h->n, h->pmax, h->pflags);
-    });
-    if (s) return s;
-    HIP_TRY(h, hipMemsetAsync(desc, 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
-    InFixQ in{pv, order, h->K, 0.0, 0};
+    uint64_t* dc = h->desc[ch][h->dcur[ch]];
+    uint64_t* dn = h->desc[ch][1 - h->dcur[ch]];
     const int gs = scan_grid(h);
-    s = timed(h, GPF_K_SCAN, [&] {
-        hipLaunchKernelGGL((k_scan<InFixQ, true>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, h->pmax,
-                           h->pflags, gp, slot, cdf, desc, &slot->S, h->blockQ);
+    const ScanOut so{want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch]};
+    gpf_status s = timed(h, GPF_K_SCAN, [&] {
+        hipLaunchKernelGGL((k_scan<In, FIXQ>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, h->pmax, h->pflags, np, slot,
+                           so, dc, dn, total_out, h->blockQ, &h->sc->timeout);
     });
     if (s) return s;
-    hipLaunchKernelGGL(k_scalar, dim3(1), dim3(BLOCK), 0, h->stream, OP_FOLD_Q | extra_ops, h->sc, slot, h->blockQ, gs,
-                       h->K, h->cfg.n_global, h->logN);
+    h->table[ch] = dc + h->ntiles;
+    h->dcur[ch] ^= 1;
+    return GPF_OK;
+}
+
+// pv: the weights to summarise; use_producer_max: pmax/pflags written by the kernel that produced lw are current
+gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cdf, const int32_t* order, bool use_producer_max,
+                     bool want_q = false)
+{
+    int np;
+    gpf_status s;
+    if (use_producer_max && h->max_valid) np = h->max_np;
+    else {
+        np = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
+        s = timed(h, GPF_K_MAX, [&] {
+            hipLaunchKernelGGL(k_max_partial, dim3(np), dim3(BLOCK), 0, h->stream, pv, h->n, h->pmax, h->pflags);
+        });
+        if (s) return s;
+        h->max_valid = false;       // pmax now describes pv, which may not be the raw log-weights
+        if (use_producer_max) { h->max_valid = true; h->max_np = np; }
+    }
+    InFixQ in{pv, order, h->K, 0.0, 0};
+    if (want_q) s = scan_launch<InFixQ, 2>(h, 0, in, np, slot, want_cdf, &slot->S);
+    else        s = scan_launch<InFixQ, 1>(h, 0, in, np, slot, want_cdf, &slot->S);
+    if (s) return s;
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
 
-PrioView raw_view(const gpf_filter* h) { return PrioView{h->lw, nullptr, 0.0, 0}; }
-
-gpf_status ensure_raw(gpf_filter* h)
+// want_q: also accumulate sum q^2 (only the ESS needs it)
+gpf_status ensure_raw(gpf_filter* h, bool want_q = false)
 {
-    if (h->raw_valid) return GPF_OK;
-    gpf_status s = summarize(h, raw_view(h), &h->sc->raw, h->cdf[0], h->desc[0], nullptr, 0);
+    gpf_status s = materialize(h);
     if (s) return s;
+    if (h->raw_valid && (!want_q || h->raw_has_q)) return GPF_OK;
+    if ((s = summarize(h, raw_view(h), &h->sc->raw, true, nullptr, true, want_q))) return s;
     h->raw_valid = true;
+    h->raw_has_q = want_q;
+    h->raw_q_folded = false;
     return GPF_OK;
 }
 
@@ -184,6 +236,7 @@ gpf_status fetch_scalars(gpf_filter* h)
 {
     HIP_TRY(h, hipMemcpyAsync(h->h_sc, h->sc, sizeof(Scalars), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->h_sc->timeout) return fail(h, GPF_ERR_HIP, "scan kernel: bounded inter-workgroup wait timed out");
     return GPF_OK;
 }
 
@@ -229,8 +282,25 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
 gpf_status ensure_residual_buffers(gpf_filter* h)
 {
     for (int i = 1; i < 3; ++i) {
-        if (!h->cdf[i]) HIP_TRY(h, hipMalloc(&h->cdf[i], (size_t)h->n * sizeof(uint64_t)));
+        if (h->cdf[i]) continue;
+        HIP_TRY(h, hipMalloc(&h->cdf[i], (size_t)h->ntiles * TILE * sizeof(uint64_t)));
+        HIP_TRY(h, hipMalloc(&h->t16[i], (size_t)h->ntiles * (TILE / 16) * sizeof(uint64_t)));
+        HIP_TRY(h, hipMalloc(&h->t256[i], (size_t)h->ntiles * (TILE / 256) * sizeof(uint64_t)));
     }
+    return GPF_OK;
+}
+
+CdfLevels levels(const gpf_filter* h, int ch) { return CdfLevels{h->cdf[ch], h->t16[ch], h->t256[ch], h->table[ch]}; }
+
+// residual: copy-count and residual-weight CDFs from the weight CDF (resample.jl:99,109); ws->S must be the GLOBAL sum
+gpf_status residual_scans(gpf_filter* h, const WSum* ws)
+{
+    gpf_status s = ensure_residual_buffers(h);
+    if (s) return s;
+    InResidual inc{h->cdf[0], ws, h->cfg.n_global, 0};
+    InResidual inr{h->cdf[0], ws, h->cfg.n_global, 1};
+    if ((s = scan_launch<InResidual, 0>(h, 1, inc, 0, nullptr, true, &h->sc->Ctot))) return s;
+    if ((s = scan_launch<InResidual, 0>(h, 2, inr, 0, nullptr, true, &h->sc->Rs))) return s;
     return GPF_OK;
 }
 
@@ -243,6 +313,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     const bool sorted = method == GPF_RESAMPLE_STRATIFIED && sort_particles;
     const bool need_sync = check == GPF_CHECK_TRUE || invalid != nullptr;
     gpf_status s;
+    if ((s = materialize(h))) return s;                          // two resamples in a row: finish the first one
     // sortperm(log_priorities, rev=true)  (resample.jl:156-157)
     if (sorted) {
         if ((s = ensure_sort_buffers(h))) return s;
@@ -252,18 +323,18 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     }
     // safe_softmax(log_priorities) (resample.jl:54) and logsumexp(log_weights) (resample.jl:180)
     WSum* ws;
-    const int res_op = method == GPF_RESAMPLE_RESIDUAL ? OP_RESIDUAL_PREP : 0;
     if (pv.mode == 0) {
         ws = &h->sc->raw;
         if (!h->raw_valid || sorted) {
-            if ((s = summarize(h, pv, ws, h->cdf[0], h->desc[0], sorted ? h->order : nullptr, 0))) return s;
+            if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, true))) return s;
         }
     } else {
         if ((s = ensure_raw(h))) return s;                       // raw summary (cdf[0] is overwritten next; only S, m matter)
         ws = &h->sc->prio;
-        if ((s = summarize(h, pv, ws, h->cdf[0], h->desc[0], sorted ? h->order : nullptr, 0))) return s;
+        if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, false))) return s;
     }
     h->raw_valid = false;                                        // cdf[0] no longer the plain raw CDF / lw about to change
+    h->raw_q_folded = false;
     if (need_sync) {
         if ((s = fetch_scalars(h))) return s;
         const WSum& w = pv.mode == 0 ? h->h_sc->raw : h->h_sc->prio;
@@ -272,30 +343,22 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         if (w.flags & (FLAG_NAN | FLAG_POSINF)) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights (NaN).");
         if (check == GPF_CHECK_TRUE && inv) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights.");   // resample.jl:55
     }
-    // update_lml_est! (resample.jl:57,178-182) + residual shift
-    hipLaunchKernelGGL(k_scalar, dim3(1), dim3(BLOCK), 0, h->stream, OP_LML_ACCUM | res_op, h->sc, ws, h->blockQ, 0, h->K,
-                       h->cfg.n_global, h->logN);
-    // ancestors
+    // ancestors (+ update_lml_est!, resample.jl:57,178-182, inside the search kernel)
     SearchArgs sa{};
-    sa.cdf = h->cdf[0]; sa.desc = h->desc[0]; sa.ntiles = h->ntiles; sa.ccdf = nullptr; sa.cdesc = nullptr;
-    sa.order = sorted ? h->order : nullptr; sa.sc = h->sc; sa.ws = ws; sa.n = h->n; sa.n_global = h->cfg.n_global;
-    sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch; sa.anc = h->anc;
-    const int gsr = grid_for(h, h->n, 4);
+    sa.w = levels(h, 0); sa.c = levels(h, 0); sa.ntiles = h->ntiles;
+    sa.order = sorted ? h->order : nullptr; sa.sc = h->sc; sa.ws = ws; sa.raw = &h->sc->raw; sa.n = h->n;
+    sa.n_global = h->cfg.n_global; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
+    sa.K = h->K; sa.logN = h->logN; sa.anc = h->anc;
+
     if (method == GPF_RESAMPLE_RESIDUAL) {
-        if ((s = ensure_residual_buffers(h))) return s;
-        HIP_TRY(h, hipMemsetAsync(h->desc[1], 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->desc[2], 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
-        const int gs = scan_grid(h);
-        InResidual inc{h->cdf[0], h->sc, ws, h->cfg.n_global, 0};
-        InResidual inr{h->cdf[0], h->sc, ws, h->cfg.n_global, 1};
-        hipLaunchKernelGGL((k_scan<InResidual, false>), dim3(gs), dim3(BLOCK), 0, h->stream, inc, h->n, h->ntiles, nullptr, nullptr, 0,
-                           nullptr, h->cdf[1], h->desc[1], &h->sc->Ctot, nullptr);
-        hipLaunchKernelGGL((k_scan<InResidual, false>), dim3(gs), dim3(BLOCK), 0, h->stream, inr, h->n, h->ntiles, nullptr, nullptr, 0,
-                           nullptr, h->cdf[2], h->desc[2], &h->sc->Rs, nullptr);
-        sa.cdf = h->cdf[2]; sa.desc = h->desc[2]; sa.ccdf = h->cdf[1]; sa.cdesc = h->desc[1];
+        if ((s = residual_scans(h, ws))) return s;
+        sa.w = levels(h, 2); sa.c = levels(h, 1);
     }
-    const size_t lds = ((method == GPF_RESAMPLE_RESIDUAL ? 2 : 1) * h->ntiles <= LDS_TILE_TABLE)
-                           ? (size_t)(method == GPF_RESAMPLE_RESIDUAL ? 2 : 1) * h->ntiles * sizeof(uint64_t) : 0;
+    const int64_t nt = method == GPF_RESAMPLE_RESIDUAL ? 2 : 1;
+    const size_t lds = nt * h->ntiles * 8 <= LDS_TILE_TABLE ? (size_t)(nt * h->ntiles * 8) * sizeof(uint64_t)
+                     : (nt * h->ntiles <= LDS_TILE_TABLE ? (size_t)(nt * h->ntiles) * sizeof(uint64_t) : 0);
+    // every block first copies the top level of the CDF into LDS: keep the grid small (persistent blocks)
+    const int gsr = grid_for(h, h->n, lds > 32768 ? 2 : 4);
     s = timed(h, GPF_K_SEARCH, [&] {
         switch (method) {
             case GPF_RESAMPLE_MULTINOMIAL: hipLaunchKernelGGL((k_search<0>), dim3(gsr), dim3(BLOCK), lds, h->stream, sa); break;
@@ -304,14 +367,20 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         }
     });
     if (s) return s;
-    // gather + update_weights! (resample.jl:60,190-202), update_refs! (utils.jl:10-15)
-    s = timed(h, GPF_K_GATHER, [&] { launch_gather(h, pv, pv.mode == 0 ? h->lw : h->lws); });
-    if (s) return s;
-    h->cur ^= 1;
-    if (pv.mode != 0) {
+    if (pv.mode == 0) {
+        // new_traces .= view(traces, parents) is deferred: the next pf_update! reads rows through anc (fused
+        // gather), any other consumer calls materialize().  Log-weights are 0 (resample.jl:195).
+        h->pending_gather = true;
+        h->max_valid = false;
+    } else {
+        // gather + update_weights! with priorities (resample.jl:60,198-200), update_refs! (utils.jl:10-15)
+        s = timed(h, GPF_K_GATHER, [&] { launch_gather(h, pv, h->lws); });
+        if (s) return s;
+        h->cur ^= 1;
         PrioView post{h->lws, nullptr, 0.0, 0};
-        if ((s = summarize(h, post, &h->sc->post, nullptr, h->desc[0], nullptr, 0))) return s;
+        if ((s = summarize(h, post, &h->sc->post, false, nullptr, false))) return s;
         hipLaunchKernelGGL(k_apply_post, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->sc, h->K, h->logN, h->lws, h->lw, h->n);
+        h->max_valid = false;
     }
     HIP_TRY(h, hipGetLastError());
     h->epoch += 1;
@@ -369,13 +438,20 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         HIP_TRY(h, hipMalloc(&h->lws, n * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->lp, n * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->dtmp, n * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->cdf[0], n * sizeof(uint64_t)));
-        const size_t db = (((size_t)h->ntiles * sizeof(uint64_t)) + 15) & ~(size_t)15;
-        for (int i = 0; i < 3; ++i) HIP_TRY(h, hipMalloc(&h->desc[i], db));
+        HIP_TRY(h, hipMalloc(&h->cdf[0], (size_t)h->ntiles * TILE * sizeof(uint64_t)));
+        HIP_TRY(h, hipMalloc(&h->t16[0], (size_t)h->ntiles * (TILE / 16) * sizeof(uint64_t)));
+        HIP_TRY(h, hipMalloc(&h->t256[0], (size_t)h->ntiles * (TILE / 256) * sizeof(uint64_t)));
+        const size_t db = (((size_t)2 * h->ntiles * sizeof(uint64_t)) + 15) & ~(size_t)15;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 2; ++j) {
+                HIP_TRY(h, hipMalloc(&h->desc[i][j], db));
+                HIP_TRY(h, hipMemsetAsync(h->desc[i][j], 0, db, h->stream));     // descriptors start invalid; kernels keep them so
+            }
         HIP_TRY(h, hipMalloc(&h->anc, n * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc(&h->pmax, MAX_PARTIALS * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->pflags, MAX_PARTIALS * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc(&h->blockQ, (size_t)4 * 2 * h->n_cu * sizeof(uint64_t) + 64));
+        h->max_np = 0;
         HIP_TRY(h, hipMalloc(&h->partial, MAX_PARTIALS * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->dscal, 4 * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->sc, sizeof(Scalars)));
@@ -399,8 +475,8 @@ gpf_status gpf_destroy(gpf_handle h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    void* bufs[] = {h->rows[0], h->rows[1], h->lw, h->lws, h->lp, h->dtmp, h->cdf[0], h->cdf[1], h->cdf[2], h->desc[0], h->desc[1],
-                    h->desc[2], h->anc, h->order, h->idx_in, h->keys, h->keys_out, h->sort_tmp, h->pmax, h->pflags, h->blockQ,
+    void* bufs[] = {h->rows[0], h->rows[1], h->lw, h->lws, h->lp, h->dtmp, h->cdf[0], h->cdf[1], h->cdf[2], h->desc[0][0], h->desc[0][1],
+                    h->desc[1][0], h->desc[1][1], h->desc[2][0], h->desc[2][1], h->t16[0], h->t16[1], h->t16[2], h->t256[0], h->t256[1], h->t256[2], h->anc, h->order, h->idx_in, h->keys, h->keys_out, h->sort_tmp, h->pmax, h->pflags, h->blockQ,
                     h->partial, h->dscal, h->sc};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
@@ -422,9 +498,11 @@ gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs)
     gpf_status s = set_obs(h, obs, n_obs);
     if (s) return s;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const int grid = grid_for(h, h->n, 8);
+    const int grid = step_grid(h);
     s = timed(h, GPF_K_STEP, [&] { DISPATCH_MODEL(h, launch_init_t<MM>(h, grid)); });
     if (s) return s;
+    h->pending_gather = false;
+    h->max_valid = true; h->max_np = grid;
     hipLaunchKernelGGL(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
     HIP_TRY(h, hipMemsetAsync(&h->sc->lml_est, 0, sizeof(double), h->stream));                   // log_ml_est = 0.
     HIP_TRY(h, hipGetLastError());
@@ -440,7 +518,7 @@ gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs)
     gpf_status s = check_ready(h);
     if (s) return s;
     if ((s = set_obs(h, obs, n_obs))) return s;
-    const int grid = grid_for(h, h->n, 8);
+    const int grid = step_grid(h);
     const bool keep = h->cfg.keep_prev != 0;
     s = timed(h, GPF_K_STEP, [&] {
         if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true>(h, grid))); }
@@ -448,6 +526,8 @@ gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs)
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
+    h->pending_gather = false;      // a pending resample gather was fused into this step
+    h->max_valid = true; h->max_np = grid;
     h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
     h->epoch += 1;
     h->has_prev = true;
@@ -484,8 +564,9 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
         return fail(h, GPF_ERR_UNKNOWN_METHOD, "Method not recognized.");                        // rejuvenate.jl:25
     if (!h->cfg.keep_prev) return fail(h, GPF_ERR_STATE, "gpf_rejuvenate needs keep_prev = 1 (x_{t-1} must travel with the particle)");
     if (n_iters < 0) return fail(h, GPF_ERR_INVALID_ARGUMENT, "n_iters < 0");
+    if ((s = materialize(h))) return s;
     HIP_TRY(h, hipMemsetAsync(&h->sc->n_accept, 0, sizeof(uint64_t), h->stream));
-    const int grid = grid_for(h, h->n, 8);
+    const int grid = step_grid(h);
     s = timed(h, GPF_K_MOVE, [&] {
         if (method == GPF_REJUVENATE_REWEIGHT) { DISPATCH_MODEL(h, (launch_move_t<MM, true>(h, grid, n_iters))); }
         else                                   { DISPATCH_MODEL(h, (launch_move_t<MM, false>(h, grid, n_iters))); }
@@ -494,7 +575,7 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;
     h->epoch += 1;
-    if (method == GPF_REJUVENATE_REWEIGHT) h->raw_valid = false;
+    if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; h->max_np = grid; }
     if (n_accepted) {
         if ((s = fetch_scalars(h))) return s;
         *n_accepted = h->h_sc->n_accept;
@@ -507,7 +588,11 @@ gpf_status gpf_effective_sample_size(gpf_handle h, double* out)
     gpf_status s = check_ready(h);
     if (s) return s;
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
-    if ((s = ensure_raw(h))) return s;
+    if ((s = ensure_raw(h, true))) return s;
+    if (!h->raw_q_folded) {
+        hipLaunchKernelGGL(k_fold_q, dim3(1), dim3(BLOCK), 0, h->stream, &h->sc->raw, h->blockQ, scan_grid(h));
+        h->raw_q_folded = true;
+    }
     if ((s = fetch_scalars(h))) return s;
     const WSum& w = h->h_sc->raw;
     if (w.flags) { *out = std::nan(""); return GPF_OK; }
@@ -541,6 +626,7 @@ gpf_status gpf_get_log_weights(gpf_handle h, double* out, int64_t n)
     gpf_status s = check_ready(h);
     if (s) return s;
     if (!out || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
+    if ((s = materialize(h))) return s;
     return copy_out(h, h->lw, out, (size_t)n * sizeof(double));
 }
 
@@ -578,6 +664,7 @@ gpf_status gpf_get_column(gpf_handle h, int32_t column, double* out, int64_t n)
     gpf_status s = check_ready(h);
     if (s) return s;
     if (!out || n != h->n || column < 0 || column >= h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad column/output");
+    if ((s = materialize(h))) return s;
     hipLaunchKernelGGL(k_extract_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, column, h->n, h->dtmp);
     return copy_out(h, h->dtmp, out, (size_t)n * sizeof(double));
 }
@@ -587,6 +674,7 @@ gpf_status gpf_get_rows(gpf_handle h, double* out, int64_t n_doubles)
     gpf_status s = check_ready(h);
     if (s) return s;
     if (!out || n_doubles != h->n * h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
+    if ((s = materialize(h))) return s;
     return copy_out(h, h->rows[h->cur], out, (size_t)n_doubles * sizeof(double));
 }
 
@@ -594,6 +682,7 @@ gpf_status gpf_set_rows(gpf_handle h, const double* rows, int64_t n_doubles)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!rows || n_doubles != h->n * h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
+    { gpf_status s = materialize(h); if (s) return s; }
     HIP_TRY(h, hipMemcpyAsync(h->rows[h->cur], rows, (size_t)n_doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->initialized = true;
@@ -604,6 +693,8 @@ gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!lw || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
+    { gpf_status s = materialize(h); if (s) return s; }
+    h->max_valid = false;
     HIP_TRY(h, hipMemcpyAsync(h->lw, lw, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->raw_valid = false;
@@ -692,11 +783,16 @@ gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!out2) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
-    const int gp = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
-    s = timed(h, GPF_K_MAX, [&] {
-        hipLaunchKernelGGL(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, raw_view(h), h->n, h->pmax, h->pflags);
-    });
-    if (s) return s;
+    if ((s = materialize(h))) return s;
+    int gp = h->max_np;
+    if (!h->max_valid) {
+        gp = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
+        s = timed(h, GPF_K_MAX, [&] {
+            hipLaunchKernelGGL(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, raw_view(h), h->n, h->pmax, h->pflags);
+        });
+        if (s) return s;
+    }
+    h->max_valid = false;            // gpf_shard_weight_scan overwrites pmax[0] with the global maximum
     hipLaunchKernelGGL(k_pack_mflags, dim3(1), dim3(BLOCK), 0, h->stream, h->pmax, h->pflags, gp, out2);
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
@@ -708,14 +804,10 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* m_flags, int64_t* o
     if (s) return s;
     if (!m_flags || !out5) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null pointer");
     hipLaunchKernelGGL(k_unpack_mflags, dim3(1), dim3(64), 0, h->stream, m_flags, h->pmax, h->pflags);
-    HIP_TRY(h, hipMemsetAsync(h->desc[0], 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
+    h->max_valid = false;
     InFixQ in{raw_view(h), nullptr, h->K, 0.0, 0};
     const int gs = scan_grid(h);
-    s = timed(h, GPF_K_SCAN, [&] {
-        hipLaunchKernelGGL((k_scan<InFixQ, true>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, h->pmax, h->pflags, 1,
-                           &h->sc->raw, h->cdf[0], h->desc[0], &h->sc->raw.S, h->blockQ);
-    });
-    if (s) return s;
+    if ((s = scan_launch<InFixQ, 2>(h, 0, in, 1, &h->sc->raw, true, &h->sc->raw.S))) return s;
     hipLaunchKernelGGL(k_export_summary, dim3(1), dim3(BLOCK), 0, h->stream, &h->sc->raw, h->blockQ, gs, out5);
     HIP_TRY(h, hipGetLastError());
     h->raw_valid = false;            // sc->raw holds a LOCAL sum under a GLOBAL max: not the unsharded summary
@@ -727,18 +819,9 @@ gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* S_all, int32_t G
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!S_all || !out2 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
-    if ((s = ensure_residual_buffers(h))) return s;
-    // global S into sc->prio (the local CDF in cdf[0] stays local), residual shift from the global S
+    // global S into sc->prio (the local CDF in cdf[0] stays local)
     hipLaunchKernelGGL(k_set_global, dim3(1), dim3(64), 0, h->stream, S_all, (int)G, h->cfg.n_global, &h->sc->prio, h->sc, out2);
-    HIP_TRY(h, hipMemsetAsync(h->desc[1], 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->desc[2], 0, (size_t)h->ntiles * sizeof(uint64_t), h->stream));
-    const int gs = scan_grid(h);
-    InResidual inc{h->cdf[0], h->sc, &h->sc->prio, h->cfg.n_global, 0};
-    InResidual inr{h->cdf[0], h->sc, &h->sc->prio, h->cfg.n_global, 1};
-    hipLaunchKernelGGL((k_scan<InResidual, false>), dim3(gs), dim3(BLOCK), 0, h->stream, inc, h->n, h->ntiles, nullptr, nullptr, 0, nullptr,
-                       h->cdf[1], h->desc[1], &h->sc->Ctot, nullptr);
-    hipLaunchKernelGGL((k_scan<InResidual, false>), dim3(gs), dim3(BLOCK), 0, h->stream, inr, h->n, h->ntiles, nullptr, nullptr, 0, nullptr,
-                       h->cdf[2], h->desc[2], &h->sc->Rs, nullptr);
+    if ((s = residual_scans(h, &h->sc->prio))) return s;
     hipLaunchKernelGGL(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2);
     HIP_TRY(h, hipGetLastError());
     h->serve_residual = true;
@@ -780,14 +863,14 @@ gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, 
     const int grid = grid_for(h, m_req, 8);
     // residual: requests without the count bit are looked up in the residual-weight CDF (cdf[2])
     s = timed(h, GPF_K_GATHER, [&] {
-        const uint64_t* cdf = h->serve_residual ? h->cdf[2] : h->cdf[0];
-        const uint64_t* desc = h->serve_residual ? h->desc[2] : h->desc[0];
+        const CdfLevels lw_ = levels(h, h->serve_residual ? 2 : 0);
+        const CdfLevels lc_ = levels(h, h->serve_residual ? 1 : 0);
         switch (h->W) {
-            case 2: hipLaunchKernelGGL((k_serve<2>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, cdf, desc, h->cdf[1], h->desc[1],
+            case 2: hipLaunchKernelGGL((k_serve<2>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, lw_, lc_,
                                        h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
-            case 4: hipLaunchKernelGGL((k_serve<4>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, cdf, desc, h->cdf[1], h->desc[1],
+            case 4: hipLaunchKernelGGL((k_serve<4>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, lw_, lc_,
                                        h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
-            case 8: hipLaunchKernelGGL((k_serve<8>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, cdf, desc, h->cdf[1], h->desc[1],
+            case 8: hipLaunchKernelGGL((k_serve<8>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, lw_, lc_,
                                        h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
         }
     });
@@ -808,6 +891,7 @@ gpf_status gpf_shard_commit(gpf_handle h, const double* rows, const int64_t* anc
     h->cur ^= 1;
     h->epoch += 1;
     h->raw_valid = false;
+    h->max_valid = false;
     h->serve_residual = false;
     return GPF_OK;
 }
