@@ -1,0 +1,155 @@
+# GenParticleFiltersAMD.jl -- Julia binding of libgpf_hip.so (include/gpf.h).
+#
+# UNTESTED in this repository's CI: the build image has no Julia (SURVEY.md F6). It is the thin `ccall`
+# layer a maintainer of GenParticleFilters.jl would add so that the device state type participates in the
+# package's generic functions.  Every method mirrors the signature of the reference method it stands in
+# for (file:line of GenParticleFilters.jl v0.2.3 in the comments).
+module GenParticleFiltersAMD
+
+import GenParticleFilters: pf_initialize, pf_update!, pf_resample!, pf_multinomial_resample!,
+    pf_residual_resample!, pf_stratified_resample!, pf_rejuvenate!, pf_move_accept!, pf_move_reweight!,
+    get_log_norm_weights, get_norm_weights, get_ess, get_lml_est
+import Gen: effective_sample_size, log_ml_estimate, get_log_weights
+import Statistics: mean, var
+
+const libgpf = get(ENV, "LIBGPF_HIP", "libgpf_hip.so")
+const GPF_ABI_VERSION = Cint(1)
+
+"Native model descriptor: replaces `model::GenerativeFunction` (src/initialize.jl:31-35)."
+struct NativeModel
+    id::Cint                 # gpf_model
+    params::Vector{Float64}  # layout of csrc/gpf_models.hpp
+    dim::Int
+end
+
+struct GpfConfig
+    abi_version::Cint; model::Cint; n_params::Cint; keep_prev::Cint
+    params::Ptr{Cdouble}
+    n_particles::Int64; n_global::Int64; gid0::Int64
+    seed::UInt64
+    device::Cint; reserved::Cint
+    stream::Ptr{Cvoid}
+end
+
+"Device-resident counterpart of Gen.ParticleFilterState (traces/new_traces/log_weights/log_ml_est/parents)."
+mutable struct DeviceParticleFilterState
+    handle::Ptr{Cvoid}
+    model::NativeModel
+    n_particles::Int
+    function DeviceParticleFilterState(model::NativeModel, n::Int; seed::Integer=1, keep_prev::Bool=false, device::Integer=0)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve model begin
+            cfg = Ref(GpfConfig(GPF_ABI_VERSION, model.id, length(model.params), keep_prev, pointer(model.params),
+                                n, n, 0, UInt64(seed), device, 0, C_NULL))
+            st = ccall((:gpf_create, libgpf), Cint, (Ref{GpfConfig}, Ref{Ptr{Cvoid}}), cfg, h)
+        end
+        st == 0 || error(unsafe_string(ccall((:gpf_last_error, libgpf), Cstring, (Ptr{Cvoid},), C_NULL)))
+        state = new(h[], model, n)
+        finalizer(s -> ccall((:gpf_destroy, libgpf), Cint, (Ptr{Cvoid},), s.handle), state)
+        return state
+    end
+end
+
+check(state, st) = st == 0 ? nothing :
+    error(unsafe_string(ccall((:gpf_last_error, libgpf), Cstring, (Ptr{Cvoid},), state.handle)))   # ErrorException
+
+# src/initialize.jl:31-44
+function pf_initialize(model::NativeModel, model_args::Tuple, observations::Vector{Float64}, n_particles::Int; kw...)
+    state = DeviceParticleFilterState(model, n_particles; kw...)
+    check(state, ccall((:gpf_initialize, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint),
+                       state.handle, observations, length(observations)))
+    return state
+end
+
+# src/update.jl:12-25
+function pf_update!(state::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Vector{Float64})
+    check(state, ccall((:gpf_update, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint),
+                       state.handle, observations, length(observations)))
+    return state
+end
+
+"priority_fn = w -> alpha*w evaluated on the GPU (test/resample.jl:15 uses alpha = 1/2)"
+struct Tempering; alpha::Float64; end
+(t::Tempering)(w) = t.alpha * w
+
+function _resample!(state, method::Int, priority_fn, check_kw, sort_particles::Bool)
+    chk = check_kw === true ? 2 : (check_kw === :warn ? 1 : 0)
+    invalid = Ref{Cint}(0)
+    inv_ptr = chk == 0 ? Ptr{Cint}(C_NULL) : Base.unsafe_convert(Ptr{Cint}, invalid)
+    GC.@preserve invalid begin
+        if priority_fn === nothing || priority_fn isa Tempering
+            alpha = priority_fn === nothing ? NaN : priority_fn.alpha
+            st = ccall((:gpf_resample, libgpf), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Cint, Ptr{Cint}),
+                       state.handle, method, alpha, sort_particles, chk, inv_ptr)
+        else    # arbitrary closure: priority_fn.(log_weights) on the host (src/resample.jl:51-52)
+            lp = priority_fn.(get_log_weights(state))
+            st = ccall((:gpf_resample_with_priorities, libgpf), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{Cint}),
+                       state.handle, method, lp, sort_particles, chk, inv_ptr)
+        end
+    end
+    check(state, st)                                            # error("Invalid weights."), src/resample.jl:55
+    check_kw === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")   # utils.jl:120-135
+    return state
+end
+
+# src/resample.jl:48-65, 85-120, 143-175, 19-30
+pf_multinomial_resample!(s::DeviceParticleFilterState; priority_fn=nothing, check=:warn) = _resample!(s, 0, priority_fn, check, true)
+pf_residual_resample!(s::DeviceParticleFilterState; priority_fn=nothing, check=:warn) = _resample!(s, 1, priority_fn, check, true)
+pf_stratified_resample!(s::DeviceParticleFilterState; priority_fn=nothing, check=:warn, sort_particles::Bool=true) =
+    _resample!(s, 2, priority_fn, check, sort_particles)
+function pf_resample!(s::DeviceParticleFilterState, method::Symbol=:multinomial; kwargs...)
+    method == :multinomial && return pf_multinomial_resample!(s; kwargs...)
+    method == :residual && return pf_residual_resample!(s; kwargs...)
+    method == :stratified && return pf_stratified_resample!(s; kwargs...)
+    error("Resampling method $method not recognized.")
+end
+
+# src/rejuvenate.jl:18-90 with the native kernels (Gen.mh / move_reweight on the current step's latent)
+function pf_rejuvenate!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1; method::Symbol=:move)
+    m = method == :move ? 0 : method == :reweight ? 1 : error("Method $method not recognized.")
+    check(s, ccall((:gpf_rejuvenate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, C_NULL))
+    return s
+end
+pf_move_accept!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1) = pf_rejuvenate!(s, kern, kern_args, n_iters; method=:move)
+pf_move_reweight!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1) = pf_rejuvenate!(s, kern, kern_args, n_iters; method=:reweight)
+
+# src/utils.jl:148-186
+function _scalar(s, sym)
+    out = Ref{Cdouble}(0)
+    check(s, ccall((sym, libgpf), Cint, (Ptr{Cvoid}, Ref{Cdouble}), s.handle, out))
+    return out[]
+end
+function _vector(s, sym)
+    out = Vector{Float64}(undef, s.n_particles)
+    check(s, ccall((sym, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64), s.handle, out, length(out)))
+    return out
+end
+effective_sample_size(s::DeviceParticleFilterState) = _scalar(s, :gpf_effective_sample_size)
+get_ess(s::DeviceParticleFilterState) = effective_sample_size(s)
+log_ml_estimate(s::DeviceParticleFilterState) = _scalar(s, :gpf_log_ml_estimate)
+get_lml_est(s::DeviceParticleFilterState) = log_ml_estimate(s)
+get_log_weights(s::DeviceParticleFilterState) = _vector(s, :gpf_get_log_weights)
+get_log_norm_weights(s::DeviceParticleFilterState) = _vector(s, :gpf_get_log_norm_weights)
+get_norm_weights(s::DeviceParticleFilterState) = _vector(s, :gpf_get_norm_weights)
+
+# state.parents (test/resample.jl:11)
+function Base.getproperty(s::DeviceParticleFilterState, name::Symbol)
+    if name === :parents
+        out = Vector{Int64}(undef, getfield(s, :n_particles))
+        check(s, ccall((:gpf_get_parents, libgpf), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64), getfield(s, :handle), out, length(out)))
+        return out
+    elseif name === :log_weights
+        return get_log_weights(s)
+    end
+    return getfield(s, name)
+end
+
+# src/statistics.jl:13-14, 48-50 -- addr = column of the current-step latent (0-based)
+function mean(s::DeviceParticleFilterState, addr::Integer)
+    out = Ref{Cdouble}(0); check(s, ccall((:gpf_mean, libgpf), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), s.handle, addr, out)); out[]
+end
+function var(s::DeviceParticleFilterState, addr::Integer)
+    out = Ref{Cdouble}(0); check(s, ccall((:gpf_var, libgpf), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), s.handle, addr, out)); out[]
+end
+
+end # module
