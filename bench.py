@@ -134,8 +134,18 @@ def main():
         dom = max(share, key=share.get)
         us = per[dom][0]
         achieved = ab[dom] * n_local / (us * 1e-6) / 1e9
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json; FETCH_SIZE +
+        # WRITE_SIZE collected in separate runs and corrected as MI355X_MICROARCH.md §HBM prescribes); only valid for
+        # the workload they were measured on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if n_local == N_PER_GPU and dom in pmc["kernels"]:
+                traffic = pmc["kernels"][dom]["traffic_bytes"]
+        except Exception:
+            traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": ab[dom] * n_local, "avg_launch_us": round(us, 2),
                     "all_kernels_us": {k: round(v[0], 2) for k, v in per.items()}}
 
