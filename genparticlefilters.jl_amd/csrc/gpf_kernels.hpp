@@ -530,6 +530,38 @@ __global__ __launch_bounds__(BLOCK) void k_fold_q(WSum* ws, const uint64_t* __re
 struct CdfLevels {
     const uint64_t* cdf;  const uint64_t* t16;  const uint64_t* t256;  const uint64_t* ttile;   // ttile: descriptor words
 };
+// Number of entries <= T in a 128-byte line (16 u64), for every lane's own (line, T) at once.
+// A lane reading its whole line alone costs 8 L1 transactions on 8 different cycles (each 16-B lane access
+// to a distinct line is its own tag lookup); here 8 lanes share one line: in round r the 8-lane group g
+// serves the slot of lane 8r+g, each lane loads 16 B of it (one line = ONE coalesced transaction), the
+// group sums its compare results and hands the count back.  8x fewer L1 transactions per slot.
+__device__ __forceinline__ int coop_count_le(const uint64_t* line, uint64_t T, ulonglong2* lds_wave)
+{
+    const int lane = lane_id(), grp = lane >> 3, sub = lane & 7;
+    // publish (line, T) of every lane's slot to the wave's 1 KiB LDS strip; LDS executes a wave's operations in order
+    lds_wave[lane] = make_ulonglong2(reinterpret_cast<uint64_t>(line), T);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ulonglong2 v[8];
+    uint64_t t[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const ulonglong2 pt = lds_wave[r * 8 + grp];   // broadcast read: 8 distinct addresses per wave
+        t[r] = pt.y;
+        v[r] = reinterpret_cast<const ulonglong2*>(pt.x)[sub];
+    }
+    int result = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const unsigned long long mx = __ballot(v[r].x <= t[r]), my = __ballot(v[r].y <= t[r]);
+        // byte g of the masks = the 8 lanes of group g = the line of slot 8r+g; lane 8r+sub wants byte `sub`
+        if (grp == r) result = __popcll((mx >> (8 * sub)) & 0xffull) + __popcll((my >> (8 * sub)) & 0xffull);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return result;
+}
+// per-lane variant for coherent targets (stratified, residual head): neighbouring lanes hit the same lines,
+// the loads coalesce by themselves and the cooperation overhead is not worth it
 __device__ __forceinline__ int count_le_line(const uint64_t* __restrict__ line, uint64_t T)
 {
     const ulonglong2* v = reinterpret_cast<const ulonglong2*>(line);
@@ -541,13 +573,13 @@ __device__ __forceinline__ int count_le_line(const uint64_t* __restrict__ line, 
     for (int c = 0; c < 8; ++c) cnt += (r[c].x <= T) + (r[c].y <= T);
     return cnt;
 }
-// top: LDS (or global) copy of the top level; top_is_256 selects which level it is
-__device__ __forceinline__ int64_t find_index(const CdfLevels& L, const uint64_t* top, bool top_is_256, int64_t n,
-                                              int64_t ntiles, uint64_t T)
+
+// top level: first per-256 group whose prefix exceeds T (or the tile level + the tile's 8 per-256 prefixes)
+__device__ __forceinline__ int64_t find_top(const CdfLevels& L, const uint64_t* top, bool top_is_256, int64_t ntiles, uint64_t T)
 {
     int64_t s256;
 #ifdef GPF_ABL_SEARCH_NOLDS
-    if (top_is_256) { s256 = (int64_t)(T % (uint64_t)(ntiles * 8)); } else
+    if (top_is_256) return (int64_t)(T % (uint64_t)(ntiles * 8));
 #endif
     if (top_is_256) {
         int64_t lo = 0, hi = ntiles * 8;
@@ -556,20 +588,31 @@ __device__ __forceinline__ int64_t find_index(const CdfLevels& L, const uint64_t
     } else {
         int64_t lo = 0, hi = ntiles;
         while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((top[mid] & DESC_MASK) > T) hi = mid; else lo = mid + 1; }
-        if (lo >= ntiles) return n - 1;
+        if (lo >= ntiles) lo = ntiles - 1;
         const uint64_t* g = L.t256 + lo * 8;           // the tile's 8 per-256 prefixes: 64 B
         int c = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) c += (g[e] <= T);
         s256 = lo * 8 + c;
     }
-    if (s256 >= ntiles * 8) return n - 1;
+    const int64_t n256 = ntiles * 8;
+    return s256 < n256 ? s256 : n256 - 1;
+}
+// coop = true is WAVE-COLLECTIVE: every lane of the wave must call it (inactive lanes pass any valid T);
+// coop must be wave-uniform.  lds_wave: 64 ulonglong2 of LDS private to the calling wave.
+__device__ __forceinline__ int64_t find_index(const CdfLevels& L, const uint64_t* top, bool top_is_256, int64_t n,
+                                              int64_t ntiles, uint64_t T, bool coop, ulonglong2* lds_wave)
+{
+    const int64_t s256 = find_top(L, top, top_is_256, ntiles, T);
 #ifdef GPF_ABL_SEARCH_NOLINES
     return s256 * 256 < n ? s256 * 256 : n - 1;
 #endif
-    const int64_t s16 = s256 * 16 + count_le_line(L.t16 + s256 * 16, T);
-    if (s16 >= ntiles * (TILE / 16)) return n - 1;
-    const int64_t idx = s16 * 16 + count_le_line(L.cdf + s16 * 16, T);
+    const uint64_t* l1 = L.t16 + s256 * 16;
+    int64_t s16 = s256 * 16 + (coop ? coop_count_le(l1, T, lds_wave) : count_le_line(l1, T));
+    const int64_t n16 = ntiles * (TILE / 16);
+    s16 = s16 < n16 ? s16 : n16 - 1;
+    const uint64_t* l2 = L.cdf + s16 * 16;
+    const int64_t idx = s16 * 16 + (coop ? coop_count_le(l2, T, lds_wave) : count_le_line(l2, T));
     return idx < n ? idx : n - 1;
 }
 
@@ -613,25 +656,39 @@ __global__ __launch_bounds__(BLOCK) void k_search(SearchArgs a)
         a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
     const uint64_t S = (METHOD == 1) ? a.sc->Rs : a.ws->S;
     const uint64_t N = (uint64_t)a.n_global;
-    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < a.n; j += (int64_t)gridDim.x * BLOCK) {
-        const uint64_t jg = (uint64_t)(a.gid0 + j);
+    // stratified: S = N B + rem, once per workgroup (u64 division is ~100 instructions)
+    __shared__ uint64_t s_div[2];
+    __shared__ ulonglong2 s_coop[BLOCK];
+    ulonglong2* const lds_wave = s_coop + wave_id() * WAVE;
+    if (METHOD == 2) {
+        if (threadIdx.x == 0) { s_div[0] = S / N; s_div[1] = S % N; }
+        __syncthreads();
+    }
+    const double invN = 1.0 / (double)N;
+    const uint64_t Ctot = (METHOD == 1) ? a.sc->Ctot : 0;
+    // the loop is wave-uniform: find_index is a wave-collective
+    for (int64_t base = (int64_t)blockIdx.x * BLOCK; base < a.n; base += (int64_t)gridDim.x * BLOCK) {
+        const int64_t j = base + threadIdx.x;
+        const bool active = j < a.n;
+        const uint64_t jg = (uint64_t)(a.gid0 + (active ? j : a.n - 1));
         const Philox b = rng(a.seed, (uint32_t)jg, 0, a.epoch, TAG_RESAMPLE);
         const uint64_t U = u64(b.w0, b.w1);
         int64_t idx;
         if (METHOD == 0) {                       // multinomial, resample.jl:59
-            idx = find_index(a.w, topw, top256, a.n, a.ntiles, mulhi64(U, S));
+            idx = find_index(a.w, topw, top256, a.n, a.ntiles, mulhi64(U, S), true, lds_wave);
         } else if (METHOD == 2) {                // stratified, resample.jl:159-168
-            const uint64_t B = S / N, rem = S % N;
-            const uint64_t L0 = jg * B + (jg * rem) / N;
-            const uint64_t L1 = (jg + 1) * B + ((jg + 1) * rem) / N;
-            const int64_t k = find_index(a.w, topw, top256, a.n, a.ntiles, L0 + mulhi64(U, L1 - L0));
+            const uint64_t B = s_div[0], rem = s_div[1];
+            const uint64_t L0 = jg * B + div_small(jg * rem, N, invN);
+            const uint64_t L1 = (jg + 1) * B + div_small((jg + 1) * rem, N, invN);
+            const int64_t k = find_index(a.w, topw, top256, a.n, a.ntiles, L0 + mulhi64(U, L1 - L0), false, lds_wave);
             idx = a.order ? (int64_t)a.order[k] : k;
         } else {                                 // residual, resample.jl:96-115
-            const uint64_t Ctot = a.sc->Ctot;
-            if (jg < Ctot) idx = find_index(a.c, topc, top256, a.n, a.ntiles, jg);
-            else           idx = find_index(a.w, topw, top256, a.n, a.ntiles, mulhi64(U, S));
+            const bool head = jg < Ctot;
+            CdfLevels L = head ? a.c : a.w;
+            const bool coop = __any(!head) != 0;            // the random tail: cooperate; all-head waves are coherent
+            idx = find_index(L, head ? topc : topw, top256, a.n, a.ntiles, head ? jg : mulhi64(U, S), coop, lds_wave);
         }
-        a.anc[j] = (int32_t)idx;
+        if (active) a.anc[j] = (int32_t)idx;
     }
 }
 
@@ -839,11 +896,16 @@ __global__ __launch_bounds__(BLOCK) void k_serve(const int64_t* __restrict__ T_l
                                                  double* __restrict__ rows_out, int64_t* __restrict__ anc_out)
 {
     constexpr int C = W / 2;
-    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m_req; r += (int64_t)gridDim.x * BLOCK) {
-        const int64_t t = T_local[r];
-        int64_t a;
-        if (t & SPACE_COUNTS) a = find_index(lc_, lc_.ttile, false, n, ntiles, (uint64_t)(t & ~SPACE_COUNTS));
-        else                  a = find_index(lw_, lw_.ttile, false, n, ntiles, (uint64_t)t);
+    __shared__ ulonglong2 s_coop[BLOCK];
+    ulonglong2* const lds_wave = s_coop + wave_id() * WAVE;
+    for (int64_t base = (int64_t)blockIdx.x * BLOCK; base < m_req; base += (int64_t)gridDim.x * BLOCK) {
+        const int64_t r = base + threadIdx.x;
+        const bool active = r < m_req;
+        const int64_t t = T_local[active ? r : m_req - 1];
+        const bool incounts = (t & SPACE_COUNTS) != 0;
+        const CdfLevels L = incounts ? lc_ : lw_;
+        const int64_t a = find_index(L, L.ttile, false, n, ntiles, (uint64_t)(t & ~SPACE_COUNTS), true, lds_wave);   // wave-collective
+        if (!active) continue;
         anc_out[r] = gid0 + a;
         const double2* src = reinterpret_cast<const double2*>(rows) + a * C;
         double2* dst = reinterpret_cast<double2*>(rows_out) + r * C;

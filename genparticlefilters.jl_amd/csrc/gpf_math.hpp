@@ -34,6 +34,19 @@ GPF_HD uint64_t mulhi64(uint64_t a, uint64_t b)
 #endif
 }
 
+// exact floor(x / d) (x < 2^62, quotient < 2^53): Float64 estimate (error < 1) + integer correction; replaces the
+// ~100-instruction u64 division of the GPU.  invd = 1.0 / (double)d.
+GPF_HD uint64_t div_small(uint64_t x, uint64_t d, double invd)
+{
+    uint64_t q = (uint64_t)((double)x * invd);
+    int64_t r = (int64_t)(x - q * d);
+    if (r < 0) { --q; r += (int64_t)d; }
+    if (r < 0) { --q; r += (int64_t)d; }
+    if (r >= (int64_t)d) { ++q; r -= (int64_t)d; }
+    if (r >= (int64_t)d) { ++q; }
+    return q;
+}
+
 // ------------------------------------------------------------------ Philox4x32-10
 struct Philox { uint32_t w0, w1, w2, w3; };
 
