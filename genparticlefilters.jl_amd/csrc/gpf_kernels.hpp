@@ -530,6 +530,21 @@ __global__ __launch_bounds__(BLOCK) void k_fold_q(WSum* ws, const uint64_t* __re
 struct CdfLevels {
     const uint64_t* cdf;  const uint64_t* t16;  const uint64_t* t256;  const uint64_t* ttile;   // ttile: descriptor words
 };
+// a pointer rebuilt from an integer is generic (flat_load: also counts on lgkmcnt and serialises behind the LDS
+// reads); the lines live in global memory, so say so
+__device__ __forceinline__ ulonglong2 load_global_16(uint64_t addr, int sub)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
+    const __attribute__((address_space(1))) u64x2* g = reinterpret_cast<const __attribute__((address_space(1))) u64x2*>(addr);
+    const u64x2 v = g[sub];
+    return make_ulonglong2(v.x, v.y);
+#else
+    (void)addr; (void)sub;
+    return make_ulonglong2(0, 0);
+#endif
+}
+
 // Number of entries <= T in a 128-byte line (16 u64), for every lane's own (line, T) at once.
 // A lane reading its whole line alone costs 8 L1 transactions on 8 different cycles (each 16-B lane access
 // to a distinct line is its own tag lookup); here 8 lanes share one line: in round r the 8-lane group g
@@ -548,7 +563,7 @@ __device__ __forceinline__ int coop_count_le(const uint64_t* line, uint64_t T, u
     for (int r = 0; r < 8; ++r) {
         const ulonglong2 pt = lds_wave[r * 8 + grp];   // broadcast read: 8 distinct addresses per wave
         t[r] = pt.y;
-        v[r] = reinterpret_cast<const ulonglong2*>(pt.x)[sub];
+        v[r] = load_global_16(pt.x, sub);
     }
     int result = 0;
 #pragma unroll
@@ -559,6 +574,32 @@ __device__ __forceinline__ int coop_count_le(const uint64_t* line, uint64_t T, u
     }
     __builtin_amdgcn_wave_barrier();
     return result;
+}
+// two independent slots per lane at once (16 line loads in flight per lane): lds_wave holds 2 x 64 entries
+__device__ __forceinline__ void coop_count_le2(const uint64_t* line0, uint64_t T0, const uint64_t* line1, uint64_t T1,
+                                               ulonglong2* lds_wave, int& c0, int& c1)
+{
+    const int lane = lane_id(), grp = lane >> 3, sub = lane & 7;
+    lds_wave[lane] = make_ulonglong2(reinterpret_cast<uint64_t>(line0), T0);
+    lds_wave[WAVE + lane] = make_ulonglong2(reinterpret_cast<uint64_t>(line1), T1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ulonglong2 v[16];
+    uint64_t t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const ulonglong2 pt = lds_wave[r * 8 + grp];
+        t[r] = pt.y;
+        v[r] = load_global_16(pt.x, sub);
+    }
+    c0 = 0; c1 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned long long mx = __ballot(v[r].x <= t[r]), my = __ballot(v[r].y <= t[r]);
+        const int c = __popcll((mx >> (8 * sub)) & 0xffull) + __popcll((my >> (8 * sub)) & 0xffull);
+        if (r < 8) { if (grp == r) c0 = c; } else { if (grp == r - 8) c1 = c; }
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 // per-lane variant for coherent targets (stratified, residual head): neighbouring lanes hit the same lines,
 // the loads coalesce by themselves and the cooperation overhead is not worth it
@@ -630,65 +671,167 @@ struct SearchArgs {
     int32_t* anc;
 };
 
+// LDS copy of the top level: one pad word per 64 entries.  The branch-free search probes at power-of-two strides;
+// unpadded, every probe of the middle steps would land in the same bank (up to 64-way conflicts).
+__host__ __device__ __forceinline__ int64_t lds_pad(int64_t i) { return i + (i >> 6); }
+
+// One fat workgroup (1024 threads = 16 waves) per CU: the top level of the CDF is copied into LDS once per CU
+// instead of once per 256-thread workgroup.
+constexpr int SBLOCK = 1024;
+#ifndef SEARCH_WAVES_PER_SIMD
+#define SEARCH_WAVES_PER_SIMD 4
+#endif
+#ifndef SEARCH_BLOCKS_PER_CU
+#define SEARCH_BLOCKS_PER_CU 1
+#endif
 template <int METHOD>
-__global__ __launch_bounds__(BLOCK) void k_search(SearchArgs a)
+__global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(SearchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* tw = reinterpret_cast<uint64_t*>(smem);
     constexpr int NT = METHOD == 1 ? 2 : 1;
     const bool top256 = NT * a.ntiles * 8 <= LDS_TILE_TABLE;
     const bool in_lds = top256 || NT * a.ntiles <= LDS_TILE_TABLE;
-    const int64_t tn = top256 ? a.ntiles * 8 : a.ntiles;
-    uint64_t* tc = tw + tn;
+    const int64_t tn = top256 ? a.ntiles * 8 : a.ntiles;             // entries of the top level
+    uint64_t* tc = tw + lds_pad(tn);
+#ifdef GPF_ABL_SEARCH_NOTABLE
+    if (false) {
+#else
     if (in_lds) {
+#endif
         const uint64_t* srcw = top256 ? a.w.t256 : a.w.ttile;
         const uint64_t* srcc = top256 ? a.c.t256 : a.c.ttile;
-        for (int64_t t = threadIdx.x; t < tn; t += BLOCK) {
-            tw[t] = srcw[t];
-            if (METHOD == 1) tc[t] = srcc[t];
+        // 16 B per lane (tn is a multiple of 8 when it is the per-256 level; the tile level is handled by the tail)
+        const int64_t tn2 = tn & ~(int64_t)1;
+        for (int64_t t = 2 * (int64_t)threadIdx.x; t < tn2; t += 2 * SBLOCK) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(srcw + t);
+            tw[lds_pad(t)] = v.x & DESC_MASK;                         // descriptor words carry a valid bit
+            tw[lds_pad(t + 1)] = v.y & DESC_MASK;
+            if (METHOD == 1) {
+                const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(srcc + t);
+                tc[lds_pad(t)] = w.x & DESC_MASK;
+                tc[lds_pad(t + 1)] = w.y & DESC_MASK;
+            }
         }
+        if (threadIdx.x == 0 && tn2 < tn) { tw[lds_pad(tn2)] = srcw[tn2] & DESC_MASK; if (METHOD == 1) tc[lds_pad(tn2)] = srcc[tn2] & DESC_MASK; }
         __syncthreads();
     }
     const uint64_t* topw = in_lds ? tw : a.w.ttile;
     const uint64_t* topc = in_lds ? tc : a.c.ttile;
+    const bool mask_top = !in_lds;                                    // global descriptor words still carry the bit
+    int steps = 0;
+    while (((int64_t)1 << steps) <= tn) ++steps;                      // ceil(log2(tn + 1))
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
+#ifndef GPF_ABL_SEARCH_NOLML
     if (blockIdx.x == 0 && threadIdx.x == 0)
+#else
+    if (false)
+#endif
         a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
     const uint64_t S = (METHOD == 1) ? a.sc->Rs : a.ws->S;
     const uint64_t N = (uint64_t)a.n_global;
     // stratified: S = N B + rem, once per workgroup (u64 division is ~100 instructions)
     __shared__ uint64_t s_div[2];
-    __shared__ ulonglong2 s_coop[BLOCK];
-    ulonglong2* const lds_wave = s_coop + wave_id() * WAVE;
+    __shared__ ulonglong2 s_coop[2 * SBLOCK];
+    ulonglong2* const lds_wave = s_coop + wave_id() * (2 * WAVE);
     if (METHOD == 2) {
         if (threadIdx.x == 0) { s_div[0] = S / N; s_div[1] = S % N; }
         __syncthreads();
     }
     const double invN = 1.0 / (double)N;
     const uint64_t Ctot = (METHOD == 1) ? a.sc->Ctot : 0;
-    // the loop is wave-uniform: find_index is a wave-collective
-    for (int64_t base = (int64_t)blockIdx.x * BLOCK; base < a.n; base += (int64_t)gridDim.x * BLOCK) {
-        const int64_t j = base + threadIdx.x;
-        const bool active = j < a.n;
-        const uint64_t jg = (uint64_t)(a.gid0 + (active ? j : a.n - 1));
-        const Philox b = rng(a.seed, (uint32_t)jg, 0, a.epoch, TAG_RESAMPLE);
-        const uint64_t U = u64(b.w0, b.w1);
-        int64_t idx;
-        if (METHOD == 0) {                       // multinomial, resample.jl:59
-            idx = find_index(a.w, topw, top256, a.n, a.ntiles, mulhi64(U, S), true, lds_wave);
-        } else if (METHOD == 2) {                // stratified, resample.jl:159-168
-            const uint64_t B = s_div[0], rem = s_div[1];
-            const uint64_t L0 = jg * B + div_small(jg * rem, N, invN);
-            const uint64_t L1 = (jg + 1) * B + div_small((jg + 1) * rem, N, invN);
-            const int64_t k = find_index(a.w, topw, top256, a.n, a.ntiles, L0 + mulhi64(U, L1 - L0), false, lds_wave);
-            idx = a.order ? (int64_t)a.order[k] : k;
-        } else {                                 // residual, resample.jl:96-115
-            const bool head = jg < Ctot;
-            CdfLevels L = head ? a.c : a.w;
-            const bool coop = __any(!head) != 0;            // the random tail: cooperate; all-head waves are coherent
-            idx = find_index(L, head ? topc : topw, top256, a.n, a.ntiles, head ? jg : mulhi64(U, S), coop, lds_wave);
+    const int64_t n256 = a.ntiles * 8, n16 = a.ntiles * (TILE / 16);
+    // two slots per lane and iteration (independent dependency chains); the loop is wave-uniform
+    for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < a.n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
+        int64_t j[2]; bool act[2], head[2]; uint64_t T[2]; const uint64_t* top[2]; const CdfLevels* L[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            j[u] = base + u * SBLOCK + threadIdx.x;
+            act[u] = j[u] < a.n;
+            const uint64_t jg = (uint64_t)(a.gid0 + (act[u] ? j[u] : a.n - 1));
+#ifdef GPF_ABL_SEARCH_NOPHILOX
+            const uint64_t U = jg * 0x9E3779B97F4A7C15ull;
+#else
+            const Philox b = rng(a.seed, (uint32_t)jg, 0, a.epoch, TAG_RESAMPLE);
+            const uint64_t U = u64(b.w0, b.w1);
+#endif
+            head[u] = false; top[u] = topw; L[u] = &a.w;
+            if (METHOD == 0) T[u] = mulhi64(U, S);                    // multinomial, resample.jl:59
+            else if (METHOD == 2) {                                   // stratified, resample.jl:159-168
+                const uint64_t B = s_div[0], rem = s_div[1];
+                const uint64_t x0 = jg * rem, q0 = div_small(x0, N, invN);
+                const uint64_t q1 = q0 + ((x0 - q0 * N) + rem >= N ? 1 : 0);      // floor((x0 + rem)/N), rem < N
+                const uint64_t L0 = jg * B + q0, L1 = (jg + 1) * B + q1;
+                T[u] = L0 + mulhi64(U, L1 - L0);
+            } else {                                                  // residual, resample.jl:96-115
+                head[u] = jg < Ctot;
+                T[u] = head[u] ? jg : mulhi64(U, S);
+                if (head[u]) { top[u] = topc; L[u] = &a.c; }
+            }
         }
-        if (active) a.anc[j] = (int32_t)idx;
+#ifdef GPF_ABL_SEARCH_ONLYT
+        if (act[0]) a.anc[j[0]] = (int32_t)(T[0] % (uint64_t)a.n);
+        if (act[1]) a.anc[j[1]] = (int32_t)(T[1] % (uint64_t)a.n);
+        continue;
+#endif
+        // coherent targets (stratified; residual waves that are all deterministic copies) read their lines per lane
+        const bool coop = METHOD == 0 ? true : (METHOD == 2 ? false : __any(!head[0] || !head[1]) != 0);
+        // top level: branch-free binary search, both slots interleaved; pos = number of entries <= T
+        int64_t pos[2] = {0, 0};
+#ifdef GPF_ABL_SEARCH_NOLDS
+        pos[0] = (int64_t)(T[0] % (uint64_t)tn); pos[1] = (int64_t)(T[1] % (uint64_t)tn);
+        for (int s = -1; s >= 0; --s) {
+#else
+        for (int s = steps - 1; s >= 0; --s) {
+#endif
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t np = pos[u] + ((int64_t)1 << s);
+                if (np <= tn) {
+                    uint64_t v = top[u][in_lds ? lds_pad(np - 1) : np - 1];
+                    if (mask_top) v &= DESC_MASK;
+                    if (v <= T[u]) pos[u] = np;
+                }
+            }
+        }
+        int64_t s256[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (top256) s256[u] = pos[u];
+            else {
+                const int64_t tile = pos[u] < a.ntiles ? pos[u] : a.ntiles - 1;
+                const uint64_t* g = L[u]->t256 + tile * 8;             // the tile's 8 per-256 prefixes: 64 B
+                int c = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c += (g[e] <= T[u]);
+                s256[u] = tile * 8 + c;
+            }
+            s256[u] = s256[u] < n256 ? s256[u] : n256 - 1;
+        }
+        int c0, c1;
+#ifdef GPF_ABL_SEARCH_NOLINES
+        if (act[0]) a.anc[j[0]] = (int32_t)(s256[0] * 256 < a.n ? s256[0] * 256 : a.n - 1);
+        if (act[1]) a.anc[j[1]] = (int32_t)(s256[1] * 256 < a.n ? s256[1] * 256 : a.n - 1);
+        continue;
+#endif
+        const uint64_t* l0 = L[0]->t16 + s256[0] * 16;
+        const uint64_t* l1 = L[1]->t16 + s256[1] * 16;
+        if (coop) coop_count_le2(l0, T[0], l1, T[1], lds_wave, c0, c1);
+        else { c0 = count_le_line(l0, T[0]); c1 = count_le_line(l1, T[1]); }
+        int64_t s16a = s256[0] * 16 + c0, s16b = s256[1] * 16 + c1;
+        s16a = s16a < n16 ? s16a : n16 - 1;
+        s16b = s16b < n16 ? s16b : n16 - 1;
+        l0 = L[0]->cdf + s16a * 16;
+        l1 = L[1]->cdf + s16b * 16;
+        if (coop) coop_count_le2(l0, T[0], l1, T[1], lds_wave, c0, c1);
+        else { c0 = count_le_line(l0, T[0]); c1 = count_le_line(l1, T[1]); }
+        int64_t idx[2] = {s16a * 16 + c0, s16b * 16 + c1};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            idx[u] = idx[u] < a.n ? idx[u] : a.n - 1;
+            if (METHOD == 2 && a.order) idx[u] = (int64_t)a.order[idx[u]];
+            if (act[u]) a.anc[j[u]] = (int32_t)idx[u];
+        }
     }
 }
 

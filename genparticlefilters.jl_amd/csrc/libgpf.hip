@@ -355,15 +355,16 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         sa.w = levels(h, 2); sa.c = levels(h, 1);
     }
     const int64_t nt = method == GPF_RESAMPLE_RESIDUAL ? 2 : 1;
-    const size_t lds = nt * h->ntiles * 8 <= LDS_TILE_TABLE ? (size_t)(nt * h->ntiles * 8) * sizeof(uint64_t)
-                     : (nt * h->ntiles <= LDS_TILE_TABLE ? (size_t)(nt * h->ntiles) * sizeof(uint64_t) : 0);
+    const int64_t top_n = nt * h->ntiles * 8 <= LDS_TILE_TABLE ? h->ntiles * 8 : (nt * h->ntiles <= LDS_TILE_TABLE ? h->ntiles : 0);
+    const size_t lds = (size_t)(nt * (lds_pad(top_n) + 1)) * sizeof(uint64_t);
     // every block first copies the top level of the CDF into LDS: keep the grid small (persistent blocks)
-    const int gsr = grid_for(h, h->n, lds > 32768 ? 2 : 4);
+    // one 1024-thread workgroup per CU, two slots per lane and iteration
+    const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu * SEARCH_BLOCKS_PER_CU));
     s = timed(h, GPF_K_SEARCH, [&] {
         switch (method) {
-            case GPF_RESAMPLE_MULTINOMIAL: hipLaunchKernelGGL((k_search<0>), dim3(gsr), dim3(BLOCK), lds, h->stream, sa); break;
-            case GPF_RESAMPLE_RESIDUAL:    hipLaunchKernelGGL((k_search<1>), dim3(gsr), dim3(BLOCK), lds, h->stream, sa); break;
-            default:                       hipLaunchKernelGGL((k_search<2>), dim3(gsr), dim3(BLOCK), lds, h->stream, sa); break;
+            case GPF_RESAMPLE_MULTINOMIAL: hipLaunchKernelGGL((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
+            case GPF_RESAMPLE_RESIDUAL:    hipLaunchKernelGGL((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
+            default:                       hipLaunchKernelGGL((k_search<2>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
         }
     });
     if (s) return s;
@@ -460,6 +461,11 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         HIP_TRY(h, hipMemsetAsync(h->lw, 0, n * sizeof(double), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->rows[0], 0, rb, h->stream));
         hipLaunchKernelGGL(k_iota, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, h->n);   // parents = 1:N
+        // k_search keeps up to LDS_TILE_TABLE top-level entries (64 KiB) + 32 KiB of cooperation strips in LDS
+        const int max_dyn = (int)((lds_pad(LDS_TILE_TABLE) + 4) * sizeof(uint64_t));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<0>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return GPF_OK;
     };
