@@ -270,6 +270,66 @@ def pf_rejuvenate(state, kern=None, kern_args: tuple = (), n_iters: int = 1, *, 
     raise ErrorException(f"Method {method} not recognized.")
 
 
+# ----------------------------------------------------------------------------- resize family (src/resize.jl)
+def _refresh_count(state):
+    n = C.c_int64()
+    state._check(state._L.gpf_n_particles(state._h, C.byref(n)))
+    state.n_particles = n.value
+
+
+def _resize(state, n_particles: int, method_id: int, priority_fn, check):
+    if check not in (True, False, "warn"):
+        raise ValueError("check must be True, 'warn' or False")
+    if priority_fn is not None and not isinstance(priority_fn, Tempering):
+        raise ErrorException("device resize supports priority_fn = nothing or Tempering(alpha)")
+    check_id = 2 if check is True else (1 if check == "warn" else 0)
+    inv = C.c_int32(0)
+    alpha = float("nan") if priority_fn is None else priority_fn.alpha
+    st = state._L.gpf_resize(state._h, int(n_particles), method_id, alpha, check_id, C.byref(inv) if check_id else None)
+    if st == _lib.ERR_INVALID_WEIGHTS:
+        raise ErrorException(state._L.gpf_last_error(state._h).decode())
+    state._check(st)
+    _refresh_count(state)
+    if check == "warn" and inv.value:
+        warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")
+    return state
+
+
+def pf_multinomial_resize(state, n_particles: int, *, priority_fn=None, check="warn"):
+    """src/resize.jl:46-68"""
+    return _resize(state, n_particles, 0, priority_fn, check)
+
+
+def pf_residual_resize(state, n_particles: int, *, priority_fn=None, check="warn"):
+    """src/resize.jl:87-124"""
+    return _resize(state, n_particles, 1, priority_fn, check)
+
+
+def pf_resize(state, n_particles: int, method: str = "multinomial", **kwargs):
+    """src/resize.jl:16-28 (:optimal is not native: it stays on the reference's CPU path)"""
+    if method == "multinomial":
+        return pf_multinomial_resize(state, n_particles, **kwargs)
+    if method == "residual":
+        return pf_residual_resize(state, n_particles, **kwargs)
+    raise ErrorException(f"Resampling method {method} not recognized.")
+
+
+def pf_replicate(state, n_replicates: int, *, layout: str = "contiguous"):
+    """src/resize.jl:236-244"""
+    state._check(state._L.gpf_replicate(state._h, int(n_replicates), int(layout != "contiguous")))
+    _refresh_count(state)
+    return state
+
+
+def pf_dereplicate(state, n_replicates: int, *, layout: str = "contiguous", method: str = "keepfirst"):
+    """src/resize.jl:267-297"""
+    if method not in ("keepfirst", "sample"):
+        raise ErrorException(f"Method {method} not recognized.")
+    state._check(state._L.gpf_dereplicate(state._h, int(n_replicates), int(layout != "contiguous"), int(method == "sample")))
+    _refresh_count(state)
+    return state
+
+
 # ----------------------------------------------------------------------------- summaries (src/utils.jl)
 def effective_sample_size(state) -> float:
     out = C.c_double()

@@ -665,7 +665,8 @@ struct SearchArgs {
     Scalars* sc;
     const WSum* ws;                                                   // summary of the sampled weights
     const WSum* raw;                                                  // summary of state.log_weights (log-ML estimate)
-    int64_t n, n_global, gid0;
+    int64_t n, n_global, gid0;                                        // n = output slots; n_global = slots of the whole filter
+    int64_t n_cells;                                                  // particles the CDF ranges over (== n except when resizing)
     uint64_t seed; uint32_t epoch;
     int K; double logN;
     int32_t* anc;
@@ -810,8 +811,8 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
         }
         int c0, c1;
 #ifdef GPF_ABL_SEARCH_NOLINES
-        if (act[0]) a.anc[j[0]] = (int32_t)(s256[0] * 256 < a.n ? s256[0] * 256 : a.n - 1);
-        if (act[1]) a.anc[j[1]] = (int32_t)(s256[1] * 256 < a.n ? s256[1] * 256 : a.n - 1);
+        if (act[0]) a.anc[j[0]] = (int32_t)(s256[0] * 256 < a.n_cells ? s256[0] * 256 : a.n_cells - 1);
+        if (act[1]) a.anc[j[1]] = (int32_t)(s256[1] * 256 < a.n_cells ? s256[1] * 256 : a.n_cells - 1);
         continue;
 #endif
         const uint64_t* l0 = L[0]->t16 + s256[0] * 16;
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
         int64_t idx[2] = {s16a * 16 + c0, s16b * 16 + c1};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            idx[u] = idx[u] < a.n ? idx[u] : a.n - 1;
+            idx[u] = idx[u] < a.n_cells ? idx[u] : a.n_cells - 1;
             if (METHOD == 2 && a.order) idx[u] = (int64_t)a.order[idx[u]];
             if (act[u]) a.anc[j[u]] = (int32_t)idx[u];
         }
@@ -1075,6 +1076,63 @@ __global__ void k_lml_global(const double* __restrict__ m_flags, const int64_t* 
         int f = (int)m_flags[1];
         if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
         sc->lml_est = sc->lml_est + (lse_from(m, S, K, f) - logN);
+    }
+}
+
+// ----------------------------------------------------------------------------- resize family (reference src/resize.jl)
+// pf_replicate! (resize.jl:236-244): parents = repeat(1:N, inner=k) (contiguous) or repeat(1:N, k) (interleaved);
+// pf_dereplicate! :keepfirst (resize.jl:267-280): parents = 1:k:N (contiguous) or 1:N/k (interleaved)
+__global__ void k_replicate_anc(int64_t n_new, int64_t n_old, int k, int interleaved, int shrink, int32_t* __restrict__ anc)
+{
+    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n_new; j += (int64_t)gridDim.x * BLOCK) {
+        int64_t a;
+        if (!shrink) a = interleaved ? j % n_old : j / k;
+        else         a = interleaved ? j : j * k;
+        anc[j] = (int32_t)a;
+    }
+}
+// rows_out[j] = rows_in[anc[j]], lw_out[j] = lw_in[anc[j]]  (traces and weights of the selected parents)
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_gather_rows_lw(const int32_t* __restrict__ anc, const double* __restrict__ rows_in,
+                                                         const double* __restrict__ lw_in, double* __restrict__ rows_out,
+                                                         double* __restrict__ lw_out, int64_t n)
+{
+    constexpr int C = W / 2;
+    const int64_t total = n * C;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t j = t / C;
+        const int c = (int)(t - j * C);
+        const int64_t a = anc[j];
+        reinterpret_cast<double2*>(rows_out)[t] = reinterpret_cast<const double2*>(rows_in)[a * C + c];
+        if (c == 0 && lw_out) lw_out[j] = lw_in[a];
+    }
+}
+// pf_dereplicate! method = :sample (resize.jl:281-293): one categorical draw per block of k replicates, with the
+// block's softmax in K_b-bit fixed point (same spec as §3.3 of DESIGN.md, N = k); new weight = logsumexp(block) - log k
+__global__ void k_dereplicate_sample(const double* __restrict__ lw, int64_t n_new, int64_t n_old, int k, int interleaved,
+                                     uint64_t seed, uint32_t epoch, int Kb, double logk, int32_t* __restrict__ anc,
+                                     double* __restrict__ lw_out)
+{
+    const int64_t stride = interleaved ? n_new : 1;
+    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n_new; j += (int64_t)gridDim.x * BLOCK) {
+        const int64_t first = interleaved ? j : j * k;
+        double m = -__builtin_huge_val();
+        bool nan = false;
+        for (int e = 0; e < k; ++e) { const double v = lw[first + e * stride]; if (v != v) nan = true; else m = v > m ? v : m; }
+        const bool uniform = !nan && m == -__builtin_huge_val();
+        uint64_t S = 0;
+        for (int e = 0; e < k; ++e) S += uniform ? 1 : exp_fix(lw[first + e * stride] - m, Kb);
+        const Philox b = rng(seed, (uint32_t)j, 0, epoch, TAG_RESAMPLE);
+        const uint64_t T = mulhi64(u64(b.w0, b.w1), S);
+        uint64_t acc = 0;
+        int pick = k - 1;
+        for (int e = 0; e < k; ++e) {
+            acc += uniform ? 1 : exp_fix(lw[first + e * stride] - m, Kb);
+            if (acc > T) { pick = e; break; }
+        }
+        anc[j] = (int32_t)(first + pick * stride);
+        const int f = nan ? FLAG_NAN : (uniform ? FLAG_ALL_NEGINF : 0);
+        lw_out[j] = lse_from(m, S, Kb, f) - logk;
     }
 }
 

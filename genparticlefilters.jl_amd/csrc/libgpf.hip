@@ -110,6 +110,71 @@ gpf_status timed(gpf_filter* h, int id, F&& launch)
     return GPF_OK;
 }
 
+// ------------------------------------------------------------------ per-N device buffers
+struct Bufs {                        // everything whose size depends on the particle count (detached copy, for resizing)
+    int64_t n = 0, ntiles = 0;
+    double* rows[2] = {nullptr, nullptr};
+    int cur = 0;
+    double *lw = nullptr, *lws = nullptr, *lp = nullptr, *dtmp = nullptr;
+    uint64_t *cdf[3] = {}, *t16[3] = {}, *t256[3] = {}, *desc[3][2] = {};
+    int32_t *anc = nullptr, *order = nullptr, *idx_in = nullptr;
+    uint64_t *keys = nullptr, *keys_out = nullptr;
+    void* sort_tmp = nullptr;
+};
+
+Bufs take_particle_buffers(gpf_filter* h)
+{
+    Bufs b;
+    b.n = h->n; b.ntiles = h->ntiles; b.cur = h->cur;
+    b.rows[0] = h->rows[0]; b.rows[1] = h->rows[1]; h->rows[0] = h->rows[1] = nullptr;
+    b.lw = h->lw; b.lws = h->lws; b.lp = h->lp; b.dtmp = h->dtmp; h->lw = h->lws = h->lp = h->dtmp = nullptr;
+    for (int i = 0; i < 3; ++i) {
+        b.cdf[i] = h->cdf[i]; b.t16[i] = h->t16[i]; b.t256[i] = h->t256[i]; h->cdf[i] = h->t16[i] = h->t256[i] = nullptr;
+        for (int j = 0; j < 2; ++j) { b.desc[i][j] = h->desc[i][j]; h->desc[i][j] = nullptr; }
+        h->table[i] = nullptr; h->dcur[i] = 0;
+    }
+    b.anc = h->anc; b.order = h->order; b.idx_in = h->idx_in; h->anc = h->order = h->idx_in = nullptr;
+    b.keys = h->keys; b.keys_out = h->keys_out; b.sort_tmp = h->sort_tmp;
+    h->keys = h->keys_out = nullptr; h->sort_tmp = nullptr; h->sort_tmp_bytes = 0;
+    return b;
+}
+
+void free_bufs(Bufs& b)
+{
+    void* p[] = {b.rows[0], b.rows[1], b.lw, b.lws, b.lp, b.dtmp, b.cdf[0], b.cdf[1], b.cdf[2], b.t16[0], b.t16[1], b.t16[2],
+                 b.t256[0], b.t256[1], b.t256[2], b.desc[0][0], b.desc[0][1], b.desc[1][0], b.desc[1][1], b.desc[2][0], b.desc[2][1],
+                 b.anc, b.order, b.idx_in, b.keys, b.keys_out, b.sort_tmp};
+    for (void* q : p) if (q) (void)hipFree(q);
+    b = Bufs();
+}
+
+// allocate the per-N buffers for h->n particles (fields must be null); sets ntiles, K, logN
+gpf_status alloc_particle_buffers(gpf_filter* h)
+{
+    h->ntiles = (h->n + TILE - 1) / TILE;
+    h->K = fix_K(h->cfg.n_global);
+    h->logN = log_((double)h->cfg.n_global);
+    h->cur = 0;
+    const size_t n = (size_t)h->n, rb = n * (size_t)h->W * sizeof(double);
+    HIP_TRY(h, hipMalloc(&h->rows[0], rb));
+    HIP_TRY(h, hipMalloc(&h->rows[1], rb));
+    HIP_TRY(h, hipMalloc(&h->lw, n * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->lws, n * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->lp, n * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->dtmp, n * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->cdf[0], (size_t)h->ntiles * TILE * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->t16[0], (size_t)h->ntiles * (TILE / 16) * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->t256[0], (size_t)h->ntiles * (TILE / 256) * sizeof(uint64_t)));
+    const size_t db = (((size_t)2 * h->ntiles * sizeof(uint64_t)) + 15) & ~(size_t)15;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j) {
+            HIP_TRY(h, hipMalloc(&h->desc[i][j], db));
+            HIP_TRY(h, hipMemsetAsync(h->desc[i][j], 0, db, h->stream));     // descriptors start invalid; kernels keep them so
+        }
+    HIP_TRY(h, hipMalloc(&h->anc, n * sizeof(int32_t)));
+    return GPF_OK;
+}
+
 // ------------------------------------------------------------------ model dispatch
 int step_grid(const gpf_filter* h) { return std::min(grid_for(h, h->n, 4), MAX_PARTIALS); }
 
@@ -147,15 +212,27 @@ void launch_move_t(gpf_filter* h, int grid, int n_iters)
         case MODEL_OBJECT_MOTION: { constexpr int MM = MODEL_OBJECT_MOTION; CALL; } break;       \
     }
 
+void launch_gather_ex(gpf_filter* h, const int32_t* anc, const double* in, double* out, const PrioView& pv, double* lw_out, int64_t n)
+{
+    const int grid = grid_for(h, n * (h->W / 2), 8);
+    switch (h->W) {
+        case 2: hipLaunchKernelGGL((k_gather<2>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, in, out, pv, lw_out, n); break;
+        case 4: hipLaunchKernelGGL((k_gather<4>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, in, out, pv, lw_out, n); break;
+        case 8: hipLaunchKernelGGL((k_gather<8>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, in, out, pv, lw_out, n); break;
+    }
+}
 void launch_gather(gpf_filter* h, const PrioView& pv, double* lw_out)
 {
-    const double* in = h->rows[h->cur];
-    double* out = h->rows[1 - h->cur];
-    const int grid = grid_for(h, h->n * (h->W / 2), 8);
+    launch_gather_ex(h, h->anc, h->rows[h->cur], h->rows[1 - h->cur], pv, lw_out, h->n);
+}
+void launch_gather_rows_lw(gpf_filter* h, const int32_t* anc, const double* rows_in, const double* lw_in, double* rows_out,
+                           double* lw_out, int64_t n)
+{
+    const int grid = grid_for(h, n * (h->W / 2), 8);
     switch (h->W) {
-        case 2: hipLaunchKernelGGL((k_gather<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, in, out, pv, lw_out, h->n); break;
-        case 4: hipLaunchKernelGGL((k_gather<4>), dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, in, out, pv, lw_out, h->n); break;
-        case 8: hipLaunchKernelGGL((k_gather<8>), dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, in, out, pv, lw_out, h->n); break;
+        case 2: hipLaunchKernelGGL((k_gather_rows_lw<2>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, rows_in, lw_in, rows_out, lw_out, n); break;
+        case 4: hipLaunchKernelGGL((k_gather_rows_lw<4>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, rows_in, lw_in, rows_out, lw_out, n); break;
+        case 8: hipLaunchKernelGGL((k_gather_rows_lw<8>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, rows_in, lw_in, rows_out, lw_out, n); break;
     }
 }
 
@@ -293,12 +370,12 @@ gpf_status ensure_residual_buffers(gpf_filter* h)
 CdfLevels levels(const gpf_filter* h, int ch) { return CdfLevels{h->cdf[ch], h->t16[ch], h->t256[ch], h->table[ch]}; }
 
 // residual: copy-count and residual-weight CDFs from the weight CDF (resample.jl:99,109); ws->S must be the GLOBAL sum
-gpf_status residual_scans(gpf_filter* h, const WSum* ws)
+gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
 {
     gpf_status s = ensure_residual_buffers(h);
     if (s) return s;
-    InResidual inc{h->cdf[0], ws, h->cfg.n_global, 0};
-    InResidual inr{h->cdf[0], ws, h->cfg.n_global, 1};
+    InResidual inc{h->cdf[0], ws, n_slots_global, 0};
+    InResidual inr{h->cdf[0], ws, n_slots_global, 1};
     if ((s = scan_launch<InResidual, 0>(h, 1, inc, 0, nullptr, true, &h->sc->Ctot))) return s;
     if ((s = scan_launch<InResidual, 0>(h, 2, inr, 0, nullptr, true, &h->sc->Rs))) return s;
     return GPF_OK;
@@ -346,12 +423,12 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     // ancestors (+ update_lml_est!, resample.jl:57,178-182, inside the search kernel)
     SearchArgs sa{};
     sa.w = levels(h, 0); sa.c = levels(h, 0); sa.ntiles = h->ntiles;
-    sa.order = sorted ? h->order : nullptr; sa.sc = h->sc; sa.ws = ws; sa.raw = &h->sc->raw; sa.n = h->n;
+    sa.order = sorted ? h->order : nullptr; sa.sc = h->sc; sa.ws = ws; sa.raw = &h->sc->raw; sa.n = h->n; sa.n_cells = h->n;
     sa.n_global = h->cfg.n_global; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
     sa.K = h->K; sa.logN = h->logN; sa.anc = h->anc;
 
     if (method == GPF_RESAMPLE_RESIDUAL) {
-        if ((s = residual_scans(h, ws))) return s;
+        if ((s = residual_scans(h, ws, h->cfg.n_global))) return s;
         sa.w = levels(h, 2); sa.c = levels(h, 1);
     }
     const int64_t nt = method == GPF_RESAMPLE_RESIDUAL ? 2 : 1;
@@ -421,9 +498,6 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
     h->d = d;
     h->W = row_width(d, cfg->keep_prev != 0);
     h->n = cfg->n_particles;
-    h->ntiles = (h->n + TILE - 1) / TILE;
-    h->K = fix_K(cfg->n_global);
-    h->logN = log_((double)cfg->n_global);
     gpf_status st = GPF_OK;
     auto body = [&]() -> gpf_status {
         HIP_TRY(h, hipSetDevice(cfg->device));
@@ -432,23 +506,8 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
         else { HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+        { gpf_status a_ = alloc_particle_buffers(h); if (a_) return a_; }
         const size_t n = (size_t)h->n, rb = n * (size_t)h->W * sizeof(double);
-        HIP_TRY(h, hipMalloc(&h->rows[0], rb));
-        HIP_TRY(h, hipMalloc(&h->rows[1], rb));
-        HIP_TRY(h, hipMalloc(&h->lw, n * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->lws, n * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->lp, n * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->dtmp, n * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->cdf[0], (size_t)h->ntiles * TILE * sizeof(uint64_t)));
-        HIP_TRY(h, hipMalloc(&h->t16[0], (size_t)h->ntiles * (TILE / 16) * sizeof(uint64_t)));
-        HIP_TRY(h, hipMalloc(&h->t256[0], (size_t)h->ntiles * (TILE / 256) * sizeof(uint64_t)));
-        const size_t db = (((size_t)2 * h->ntiles * sizeof(uint64_t)) + 15) & ~(size_t)15;
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 2; ++j) {
-                HIP_TRY(h, hipMalloc(&h->desc[i][j], db));
-                HIP_TRY(h, hipMemsetAsync(h->desc[i][j], 0, db, h->stream));     // descriptors start invalid; kernels keep them so
-            }
-        HIP_TRY(h, hipMalloc(&h->anc, n * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc(&h->pmax, MAX_PARTIALS * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->pflags, MAX_PARTIALS * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc(&h->blockQ, (size_t)4 * 2 * h->n_cu * sizeof(uint64_t) + 64));
@@ -481,9 +540,8 @@ gpf_status gpf_destroy(gpf_handle h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    void* bufs[] = {h->rows[0], h->rows[1], h->lw, h->lws, h->lp, h->dtmp, h->cdf[0], h->cdf[1], h->cdf[2], h->desc[0][0], h->desc[0][1],
-                    h->desc[1][0], h->desc[1][1], h->desc[2][0], h->desc[2][1], h->t16[0], h->t16[1], h->t16[2], h->t256[0], h->t256[1], h->t256[2], h->anc, h->order, h->idx_in, h->keys, h->keys_out, h->sort_tmp, h->pmax, h->pflags, h->blockQ,
-                    h->partial, h->dscal, h->sc};
+    { Bufs b = take_particle_buffers(h); free_bufs(b); }
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -776,6 +834,134 @@ gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const do
     return GPF_OK;
 }
 
+// =================================================================================== resize family (src/resize.jl)
+static gpf_status resize_ready(gpf_handle h)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, "resizing a sharded filter is not supported");
+    return materialize(h);
+}
+// after the particle count changed: unsharded bookkeeping
+static void set_count(gpf_filter* h, int64_t n_new)
+{
+    h->n = n_new; h->cfg.n_particles = n_new; h->cfg.n_global = n_new; h->cfg.gid0 = 0;
+    h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false; h->pending_gather = false;
+}
+
+gpf_status gpf_n_particles(gpf_handle h, int64_t* out)
+{
+    if (!h || !out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = h->n;
+    return GPF_OK;
+}
+
+gpf_status gpf_resize(gpf_handle h, int64_t n_new, int32_t method, double priority_alpha, int32_t check, int32_t* invalid)
+{
+    gpf_status s = resize_ready(h);
+    if (s) return s;
+    if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL)
+        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");             // resize.jl:26 (:optimal is not native)
+    if (n_new < 1 || n_new >= ((int64_t)1 << 31)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad n_particles");
+    const int64_t n_old = h->n;
+    PrioView pv = raw_view(h);
+    if (priority_alpha == priority_alpha) { pv.alpha = priority_alpha; pv.mode = 1; }
+    // fixed-point scale for max(n_old, n_new): both N_old 2^K and n_new 2^K must stay below 2^62
+    h->K = fix_K(std::max(n_old, n_new));
+    h->raw_valid = false;
+    WSum* ws = &h->sc->raw;
+    if ((s = summarize(h, raw_view(h), &h->sc->raw, true, nullptr, true))) return s;          // logsumexp(log_weights), resize.jl:58
+    if (pv.mode != 0) { ws = &h->sc->prio; if ((s = summarize(h, pv, ws, true, nullptr, false))) return s; }
+    if (check == GPF_CHECK_TRUE || invalid) {
+        if ((s = fetch_scalars(h))) return s;
+        const WSum& w = pv.mode == 0 ? h->h_sc->raw : h->h_sc->prio;
+        if (invalid) *invalid = w.flags != 0;
+        if ((w.flags & (FLAG_NAN | FLAG_POSINF)) || (check == GPF_CHECK_TRUE && w.flags)) {
+            h->K = fix_K(n_old);
+            return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights.");                          // resize.jl:56,97
+        }
+    }
+    SearchArgs sa{};
+    sa.w = levels(h, 0); sa.c = levels(h, 0); sa.ntiles = h->ntiles; sa.order = nullptr; sa.sc = h->sc; sa.ws = ws;
+    sa.raw = &h->sc->raw; sa.n = n_new; sa.n_cells = n_old; sa.n_global = n_new; sa.gid0 = 0; sa.seed = h->cfg.seed;
+    sa.epoch = h->epoch; sa.K = h->K; sa.logN = log_((double)n_old);
+    if (method == GPF_RESAMPLE_RESIDUAL) {
+        if ((s = residual_scans(h, ws, n_new))) return s;                                        // floor(n_particles * w), resize.jl:106
+        sa.w = levels(h, 2); sa.c = levels(h, 1);
+    }
+    const int64_t ntiles_old = h->ntiles;
+    const int Kp = h->K;
+    Bufs old = take_particle_buffers(h);                                                          // resize!(...), resize.jl:60-61
+    set_count(h, n_new);
+    if ((s = alloc_particle_buffers(h))) { free_bufs(old); return s; }
+    sa.anc = h->anc;
+    const int64_t nt = method == GPF_RESAMPLE_RESIDUAL ? 2 : 1;
+    const int64_t top_n = nt * ntiles_old * 8 <= LDS_TILE_TABLE ? ntiles_old * 8 : (nt * ntiles_old <= LDS_TILE_TABLE ? ntiles_old : 0);
+    const size_t lds = (size_t)(nt * (lds_pad(top_n) + 1)) * sizeof(uint64_t);
+    const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((n_new + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
+    if (method == GPF_RESAMPLE_RESIDUAL) hipLaunchKernelGGL((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
+    else                                 hipLaunchKernelGGL((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
+    // new_traces .= view(traces, parents) + update_weights!(state, n_particles, log_priorities)   resize.jl:64-66,424-438
+    launch_gather_ex(h, h->anc, old.rows[old.cur], h->rows[0], pv, pv.mode == 0 ? h->lw : h->lws, n_new);
+    if (pv.mode != 0) {
+        PrioView post{h->lws, nullptr, 0.0, 0};
+        if ((s = summarize(h, post, &h->sc->post, false, nullptr, false))) { free_bufs(old); return s; }
+        hipLaunchKernelGGL(k_apply_post, dim3(grid_for(h, n_new, 8)), dim3(BLOCK), 0, h->stream, h->sc, h->K, h->logN, h->lws, h->lw, n_new);
+        h->max_valid = false;
+    }
+    (void)Kp;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));                 // the old buffers are read by the kernels above
+    free_bufs(old);
+    HIP_TRY(h, hipGetLastError());
+    h->epoch += 1;
+    return GPF_OK;
+}
+
+gpf_status gpf_replicate(gpf_handle h, int32_t n_replicates, int32_t interleaved)
+{
+    gpf_status s = resize_ready(h);
+    if (s) return s;
+    if (n_replicates < 1 || h->n * (int64_t)n_replicates >= ((int64_t)1 << 31)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad n_replicates");
+    const int64_t n_old = h->n, n_new = n_old * n_replicates;
+    Bufs old = take_particle_buffers(h);
+    set_count(h, n_new);
+    if ((s = alloc_particle_buffers(h))) { free_bufs(old); return s; }
+    hipLaunchKernelGGL(k_replicate_anc, dim3(grid_for(h, n_new, 8)), dim3(BLOCK), 0, h->stream, n_new, n_old, (int)n_replicates,
+                       (int)(interleaved != 0), 0, h->anc);
+    launch_gather_rows_lw(h, h->anc, old.rows[old.cur], old.lw, h->rows[0], h->lw, n_new);     // resize.jl:240-242
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_bufs(old);
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+
+gpf_status gpf_dereplicate(gpf_handle h, int32_t n_replicates, int32_t interleaved, int32_t sample)
+{
+    gpf_status s = resize_ready(h);
+    if (s) return s;
+    if (n_replicates < 1 || h->n % n_replicates != 0)
+        return fail(h, GPF_ERR_INVALID_ARGUMENT, "the number of particles must be a multiple of n_replicates");   // resize.jl:270
+    const int64_t n_old = h->n, n_new = n_old / n_replicates;
+    Bufs old = take_particle_buffers(h);
+    set_count(h, n_new);
+    if ((s = alloc_particle_buffers(h))) { free_bufs(old); return s; }
+    const int grid = grid_for(h, n_new, 8);
+    if (sample) {                                                                                // resize.jl:281-293
+        hipLaunchKernelGGL(k_dereplicate_sample, dim3(grid), dim3(BLOCK), 0, h->stream, old.lw, n_new, n_old, (int)n_replicates,
+                           (int)(interleaved != 0), h->cfg.seed, h->epoch, fix_K(n_replicates), log_((double)n_replicates), h->anc, h->lw);
+        launch_gather_rows_lw(h, h->anc, old.rows[old.cur], old.lw, h->rows[0], nullptr, n_new);
+        h->epoch += 1;
+    } else {                                                                                     // :keepfirst, resize.jl:274-279
+        hipLaunchKernelGGL(k_replicate_anc, dim3(grid), dim3(BLOCK), 0, h->stream, n_new, n_old, (int)n_replicates,
+                           (int)(interleaved != 0), 1, h->anc);
+        launch_gather_rows_lw(h, h->anc, old.rows[old.cur], old.lw, h->rows[0], h->lw, n_new);
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_bufs(old);
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+
 // =================================================================================== shard-level ABI
 static gpf_status shard_ready(gpf_handle h)
 {
@@ -827,7 +1013,7 @@ gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* S_all, int32_t G
     if (!S_all || !out2 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     // global S into sc->prio (the local CDF in cdf[0] stays local)
     hipLaunchKernelGGL(k_set_global, dim3(1), dim3(64), 0, h->stream, S_all, (int)G, h->cfg.n_global, &h->sc->prio, h->sc, out2);
-    if ((s = residual_scans(h, &h->sc->prio))) return s;
+    if ((s = residual_scans(h, &h->sc->prio, h->cfg.n_global))) return s;
     hipLaunchKernelGGL(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2);
     HIP_TRY(h, hipGetLastError());
     h->serve_residual = true;

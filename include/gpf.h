@@ -155,6 +155,18 @@ gpf_status gpf_kernel_time(gpf_handle h, int32_t id, double* total_ms, int64_t* 
 gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const double* b, int64_t n,
                           double* out, double* out2);
 
+/* ---- resize family (src/resize.jl) --------------------------------------------------
+ * The handle stays valid; its per-particle buffers are reallocated for the new count.  Unsharded filters only. */
+gpf_status gpf_n_particles(gpf_handle h, int64_t* out);
+/* pf_resize!(state, n_particles, method; priority_fn, check)          src/resize.jl:16-124
+ * method = GPF_RESAMPLE_MULTINOMIAL | GPF_RESAMPLE_RESIDUAL (:optimal stays on the reference's CPU path);
+ * priority_alpha / check / invalid as in gpf_resample. */
+gpf_status gpf_resize(gpf_handle h, int64_t n_particles, int32_t method, double priority_alpha, int32_t check, int32_t* invalid);
+/* pf_replicate!(state, n_replicates; layout)                           src/resize.jl:236-244 */
+gpf_status gpf_replicate(gpf_handle h, int32_t n_replicates, int32_t interleaved);
+/* pf_dereplicate!(state, n_replicates; layout, method)                 src/resize.jl:267-297  (sample=0 :keepfirst, 1 :sample) */
+gpf_status gpf_dereplicate(gpf_handle h, int32_t n_replicates, int32_t interleaved, int32_t sample);
+
 /* ---- shard-level building blocks (multi-GPU) ------------------------------------------------------
  * A filter sharded over G GPUs is G handles created with the same seed / n_global and contiguous
  * [gid0, gid0 + n_particles) ranges.  gpf_initialize / gpf_update / gpf_rejuvenate work per shard as they

@@ -6,6 +6,7 @@
 # for (file:line of GenParticleFilters.jl v0.2.3 in the comments).
 module GenParticleFiltersAMD
 
+import GenParticleFilters: pf_resize!, pf_multinomial_resize!, pf_residual_resize!, pf_replicate!, pf_dereplicate!
 import GenParticleFilters: pf_initialize, pf_update!, pf_resample!, pf_multinomial_resample!,
     pf_residual_resample!, pf_stratified_resample!, pf_rejuvenate!, pf_move_accept!, pf_move_reweight!,
     get_log_norm_weights, get_norm_weights, get_ess, get_lml_est
@@ -112,6 +113,32 @@ function pf_rejuvenate!(s::DeviceParticleFilterState, kern=nothing, kern_args::T
 end
 pf_move_accept!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1) = pf_rejuvenate!(s, kern, kern_args, n_iters; method=:move)
 pf_move_reweight!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1) = pf_rejuvenate!(s, kern, kern_args, n_iters; method=:reweight)
+
+# src/resize.jl:16-124, 236-297 -- the handle stays valid, its buffers are reallocated
+function _refresh!(s)
+    n = Ref{Int64}(0); check(s, ccall((:gpf_n_particles, libgpf), Cint, (Ptr{Cvoid}, Ref{Int64}), s.handle, n)); s.n_particles = n[]; s
+end
+function _resize!(s, n::Int, method::Int, priority_fn, check_kw)
+    chk = check_kw === true ? 2 : (check_kw === :warn ? 1 : 0)
+    alpha = priority_fn === nothing ? NaN : (priority_fn::Tempering).alpha
+    invalid = Ref{Cint}(0)
+    check(s, ccall((:gpf_resize, libgpf), Cint, (Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ref{Cint}), s.handle, n, method, alpha, chk, invalid))
+    check_kw === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
+    _refresh!(s)
+end
+pf_multinomial_resize!(s::DeviceParticleFilterState, n::Int; priority_fn=nothing, check=:warn) = _resize!(s, n, 0, priority_fn, check)
+pf_residual_resize!(s::DeviceParticleFilterState, n::Int; priority_fn=nothing, check=:warn) = _resize!(s, n, 1, priority_fn, check)
+function pf_resize!(s::DeviceParticleFilterState, n::Int, method::Symbol=:multinomial; kwargs...)
+    method == :multinomial && return pf_multinomial_resize!(s, n; kwargs...)
+    method == :residual && return pf_residual_resize!(s, n; kwargs...)
+    error("Resampling method $method not recognized.")      # :optimal stays on the CPU path
+end
+function pf_replicate!(s::DeviceParticleFilterState, k::Int; layout::Symbol=:contiguous)
+    check(s, ccall((:gpf_replicate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint), s.handle, k, layout != :contiguous)); _refresh!(s)
+end
+function pf_dereplicate!(s::DeviceParticleFilterState, k::Int; layout::Symbol=:contiguous, method::Symbol=:keepfirst)
+    check(s, ccall((:gpf_dereplicate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint), s.handle, k, layout != :contiguous, method == :sample)); _refresh!(s)
+end
 
 # src/utils.jl:148-186
 function _scalar(s, sym)

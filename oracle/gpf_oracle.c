@@ -429,3 +429,32 @@ O_EXPORT void o_normals(uint64_t seed, uint32_t epoch, int64_t n, double *out)
         out[i] = z0; if (i + 1 < n) out[i + 1] = z1;
     }
 }
+
+/* ------------------------------------------------------------------ resize family (src/resize.jl) */
+/* pf_dereplicate! method=:sample (resize.jl:281-293): per block of k replicates one categorical draw from the
+ * block's softmax (K_b-bit fixed point, K_b = fix_K(k)); new weight = logsumexp(block) - log(k) */
+O_EXPORT void o_dereplicate_sample(const double *lw, int64_t n_new, int64_t n_old, int k, int interleaved,
+                                   uint64_t seed, uint32_t epoch, int64_t *anc, double *lw_out)
+{
+    (void)n_old;
+    const int Kb = o_fix_K(k);
+    const double logk = o_log((double)k);
+    const int64_t stride = interleaved ? n_new : 1;
+    for (int64_t j = 0; j < n_new; ++j) {
+        const int64_t first = interleaved ? j : j * k;
+        double m = -INFINITY; int nan = 0;
+        for (int e = 0; e < k; ++e) { double v = lw[first + e * stride]; if (v != v) nan = 1; else if (v > m) m = v; }
+        int uniform = !nan && m == -INFINITY;
+        uint64_t S = 0;
+        for (int e = 0; e < k; ++e) S += uniform ? 1 : o_exp_fix(lw[first + e * stride] - m, Kb);
+        o_philox_t b = o_rng(seed, (uint32_t)j, 0, epoch, O_TAG_RESAMPLE);
+        uint64_t T = o_mulhi64(o_u64(b.v[0], b.v[1]), S), acc = 0;
+        int pick = k - 1;
+        for (int e = 0; e < k; ++e) {
+            acc += uniform ? 1 : o_exp_fix(lw[first + e * stride] - m, Kb);
+            if (acc > T) { pick = e; break; }
+        }
+        anc[j] = first + pick * stride;
+        lw_out[j] = o_lse_from(m, S, Kb, nan ? O_FLAG_NAN : (uniform ? O_FLAG_ALL_NEGINF : 0)) - logk;
+    }
+}

@@ -76,6 +76,7 @@ def lib():
     sig("o_argsort_desc", None, _f64p, i64, _i64p)
     sig("o_wsum", f64, _u64p, u64, _f64p, i32, i32, i64, i32, f64)
     sig("o_normals", None, u64, u32, i64, _f64p)
+    sig("o_dereplicate_sample", None, _f64p, i64, i64, i32, i32, u64, u32, _i64p, _f64p)
     # literal Float64 restatement (ref_literal.c)
     sig("lit_logsumexp", f64, _f64p, i64); sig("lit_lognorm", None, _f64p, i64, _f64p)
     sig("lit_softmax", None, _f64p, i64, _f64p); sig("lit_safe_softmax", i32, _f64p, i64, _f64p)
@@ -166,8 +167,8 @@ class OracleError(RuntimeError):
 class WeightSummary:
     """m, flags, fixed-point weights, their exact CDF, S = sum q, Q = sum q^2."""
 
-    def __init__(self, lp: np.ndarray, n_global: int):
-        self.K = fix_K(n_global)
+    def __init__(self, lp: np.ndarray, n_global: int, K: int | None = None):
+        self.K = fix_K(n_global) if K is None else K
         self.m, self.flags = max_flags(lp)
         self.uniform = bool(self.flags & FLAG_ALL_NEGINF)
         self.bad = bool(self.flags & (FLAG_NAN | FLAG_POSINF))
@@ -319,6 +320,72 @@ class OracleFilter:
                                            int(method == "reweight"), self.rows, new_rows, self.lw))
         self.rows = new_rows
         self.epoch += 1
+        return self
+
+    # ------------------------------------------------------------------ resize family, src/resize.jl
+    def _set_count(self, n_new: int):
+        self.n = int(n_new)
+
+    def resize(self, n_particles: int, method: str = "multinomial", priority_alpha=None, check="warn"):
+        """pf_resize! dispatcher (resize.jl:16-28) + pf_multinomial_resize! (:46-68) / pf_residual_resize! (:87-124)"""
+        if method not in ("multinomial", "residual"):
+            raise OracleError(f"Resampling method {method} not recognized.")           # :26
+        n_old, n_new, lw = self.n, int(n_particles), self.lw
+        K = fix_K(max(n_old, n_new))                  # both N_old 2^K and n_new 2^K below 2^62 (DESIGN.md §3.3)
+        lp, has_prio = (lw, False) if priority_alpha is None else (float(priority_alpha) * lw, True)
+        sp = WeightSummary(lp, n_old, K)                                                # safe_softmax, :54/:96
+        invalid = sp.flags != 0
+        if (check is True and invalid) or sp.bad:
+            raise OracleError("Invalid weights.")                                       # :56/:97
+        sr = WeightSummary(lw, n_old, K) if has_prio else sp
+        self.lml_est = self.lml_est + (sr.lse - olog(float(n_old)))                     # update_lml_est!, :58/:99
+        epoch = self.epoch
+        if method == "multinomial":
+            anc = upper_bound(sp.cdf, targets_multinomial(self.seed, epoch, 0, n_new, sp.S))   # :63
+        else:
+            sh = lib().o_residual_shift(sp.S, n_new)
+            c = np.empty(n_old, np.uint64); r = np.empty(n_old, np.uint64)
+            lib().o_residual_split(sp.q, n_old, n_new, sp.S, sh, c, r)                  # floor(n_particles * w), :106
+            ccdf = np.cumsum(c, dtype=np.uint64)
+            n_res = int(ccdf[-1])
+            anc = np.empty(n_new, np.int64)
+            anc[:n_res] = upper_bound(ccdf, np.arange(n_res, dtype=np.uint64))
+            if n_res < n_new:                                                           # :115-122
+                rcdf, Rs, _, _ = scan(r)
+                anc[n_res:] = upper_bound(rcdf, targets_multinomial(self.seed, epoch, n_res, n_new - n_res, Rs))
+        new_rows = gather_rows(self.rows, anc)                                          # :64
+        if not has_prio:                                                                # update_weights!(state, n, lp), :424-438
+            new_lw = np.zeros(n_new)
+        else:
+            log_ws = lw[anc] - lp[anc]
+            new_lw = log_ws + (olog(float(n_new)) - WeightSummary(log_ws, n_new).lse)
+        self.parents, self.rows, self.lw = anc + 1, new_rows, new_lw
+        self._set_count(n_new)
+        self.epoch += 1
+        return invalid
+
+    def replicate(self, n_replicates: int, layout: str = "contiguous"):
+        """pf_replicate!, resize.jl:236-244"""
+        k, n_old = int(n_replicates), self.n
+        idx = np.repeat(np.arange(n_old), k) if layout == "contiguous" else np.tile(np.arange(n_old), k)
+        self.parents, self.rows, self.lw = idx + 1, self.rows[idx].copy(), self.lw[idx].copy()
+        self._set_count(n_old * k)
+        return self
+
+    def dereplicate(self, n_replicates: int, layout: str = "contiguous", method: str = "keepfirst"):
+        """pf_dereplicate!, resize.jl:267-297"""
+        k, n_old = int(n_replicates), self.n
+        assert n_old % k == 0                                                           # :270
+        n_new = n_old // k
+        if method == "keepfirst":                                                       # :272-277
+            idx = np.arange(0, n_old, k) if layout == "contiguous" else np.arange(n_new)
+            new_lw = self.lw[idx].copy()
+        else:                                                                           # :278-293
+            idx = np.empty(n_new, np.int64); new_lw = np.empty(n_new)
+            lib().o_dereplicate_sample(self.lw, n_new, n_old, k, int(layout != "contiguous"), self.seed, self.epoch, idx, new_lw)
+            self.epoch += 1
+        self.parents, self.rows, self.lw = idx + 1, self.rows[idx].copy(), new_lw
+        self._set_count(n_new)
         return self
 
     # -- statistics.jl:13-14, 48-50
