@@ -550,10 +550,20 @@ __device__ __forceinline__ ulonglong2 load_global_16(uint64_t addr, int sub)
 // to a distinct line is its own tag lookup); here 8 lanes share one line: in round r the 8-lane group g
 // serves the slot of lane 8r+g, each lane loads 16 B of it (one line = ONE coalesced transaction), the
 // group sums its compare results and hands the count back.  8x fewer L1 transactions per slot.
+// sum of an int over each aligned group of 8 lanes, by DPP (no LDS traffic): xor 1, xor 2 inside the quad,
+// then the mirrored lane of the other quad
+__device__ __forceinline__ int group8_sum(int c)
+{
+    c += __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
+    c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+    c += __builtin_amdgcn_update_dpp(0, c, 0x141, 0xF, 0xF, false);    // row_half_mirror: lane i <- lane 7-i
+    return c;
+}
+// In round r the 8-lane group g serves ITS OWN member 8g+r: the member's (line, T) is broadcast through the wave's
+// LDS strip, each lane loads 16 B of the line (one coalesced transaction per line), compares, the group sums.
 __device__ __forceinline__ int coop_count_le(const uint64_t* line, uint64_t T, ulonglong2* lds_wave)
 {
-    const int lane = lane_id(), grp = lane >> 3, sub = lane & 7;
-    // publish (line, T) of every lane's slot to the wave's 1 KiB LDS strip; LDS executes a wave's operations in order
+    const int lane = lane_id(), sub = lane & 7, gbase = lane & ~7;
     lds_wave[lane] = make_ulonglong2(reinterpret_cast<uint64_t>(line), T);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -561,16 +571,15 @@ __device__ __forceinline__ int coop_count_le(const uint64_t* line, uint64_t T, u
     uint64_t t[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const ulonglong2 pt = lds_wave[r * 8 + grp];   // broadcast read: 8 distinct addresses per wave
+        const ulonglong2 pt = lds_wave[gbase + r];     // broadcast read inside the group
         t[r] = pt.y;
         v[r] = load_global_16(pt.x, sub);
     }
     int result = 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const unsigned long long mx = __ballot(v[r].x <= t[r]), my = __ballot(v[r].y <= t[r]);
-        // byte g of the masks = the 8 lanes of group g = the line of slot 8r+g; lane 8r+sub wants byte `sub`
-        if (grp == r) result = __popcll((mx >> (8 * sub)) & 0xffull) + __popcll((my >> (8 * sub)) & 0xffull);
+        const int c = group8_sum((int)(v[r].x <= t[r]) + (int)(v[r].y <= t[r]));
+        result = sub == r ? c : result;
     }
     __builtin_amdgcn_wave_barrier();
     return result;
@@ -579,7 +588,7 @@ __device__ __forceinline__ int coop_count_le(const uint64_t* line, uint64_t T, u
 __device__ __forceinline__ void coop_count_le2(const uint64_t* line0, uint64_t T0, const uint64_t* line1, uint64_t T1,
                                                ulonglong2* lds_wave, int& c0, int& c1)
 {
-    const int lane = lane_id(), grp = lane >> 3, sub = lane & 7;
+    const int lane = lane_id(), sub = lane & 7, gbase = lane & ~7;
     lds_wave[lane] = make_ulonglong2(reinterpret_cast<uint64_t>(line0), T0);
     lds_wave[WAVE + lane] = make_ulonglong2(reinterpret_cast<uint64_t>(line1), T1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -588,16 +597,15 @@ __device__ __forceinline__ void coop_count_le2(const uint64_t* line0, uint64_t T
     uint64_t t[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const ulonglong2 pt = lds_wave[r * 8 + grp];
+        const ulonglong2 pt = lds_wave[(r >> 3) * WAVE + gbase + (r & 7)];
         t[r] = pt.y;
         v[r] = load_global_16(pt.x, sub);
     }
     c0 = 0; c1 = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const unsigned long long mx = __ballot(v[r].x <= t[r]), my = __ballot(v[r].y <= t[r]);
-        const int c = __popcll((mx >> (8 * sub)) & 0xffull) + __popcll((my >> (8 * sub)) & 0xffull);
-        if (r < 8) { if (grp == r) c0 = c; } else { if (grp == r - 8) c1 = c; }
+        const int c = group8_sum((int)(v[r].x <= t[r]) + (int)(v[r].y <= t[r]));
+        if (r < 8) c0 = sub == r ? c : c0; else c1 = sub == (r - 8) ? c : c1;
     }
     __builtin_amdgcn_wave_barrier();
 }

@@ -329,6 +329,7 @@ gpf_status check_ready(gpf_handle h)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!h->initialized) return fail(h, GPF_ERR_STATE, "filter not initialised: call gpf_initialize (pf_initialize) first");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));       // launches go to the calling thread's current device
     return GPF_OK;
 }
 

@@ -272,13 +272,18 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
         perm = torch.argsort(owner, stable=True)                      # bucket by owner, slot order kept inside a bucket
         send_counts = torch.bincount(owner, minlength=G)
         recv_counts = state._all_to_all(send_counts, [1] * G, [1] * G)           # C4
-        sc, rc = send_counts.tolist(), recv_counts.tolist()                       # host sync: split sizes
+        both = torch.stack([send_counts, recv_counts]).tolist()                  # ONE host sync: the split sizes
+        sc, rc = both[0], both[1]
         req = state._all_to_all(T_local[perm], sc, rc)                            # requests to the owners
         rows_s, anc_s = b.serve(req)                                  # phase 4
-        rows_p = state._all_to_all(rows_s, rc, sc)                    # C5: rows back
-        anc_p = state._all_to_all(anc_s, rc, sc)
-        rows = torch.empty_like(rows_p); rows[perm] = rows_p          # un-permute into slot order
-        anc = torch.empty_like(anc_p); anc[perm] = anc_p
+        # C5: rows and ancestor ids travel back in ONE all-to-all (the id rides as an extra Float64-typed column)
+        packed = torch.cat([rows_s, anc_s.view(torch.float64).unsqueeze(1)], dim=1)
+        back = state._all_to_all(packed, rc, sc)
+        W = rows_s.shape[1]
+        rows = torch.empty((T.numel(), W), dtype=torch.float64, device=back.device)
+        rows[perm] = back[:, :W]                                      # un-permute into slot order
+        anc = torch.empty(T.numel(), dtype=torch.int64, device=back.device)
+        anc[perm] = back[:, W].contiguous().view(torch.int64)
     b.commit(rows, anc, m_flags, S_all)                               # phase 5
     return state
 
