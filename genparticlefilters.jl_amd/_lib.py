@@ -59,6 +59,11 @@ SYMBOLS = [
     ("gpf_resize", C.c_int, [_H, C.c_int64, C.c_int32, C.c_double, C.c_int32, _pi32]),
     ("gpf_replicate", C.c_int, [_H, C.c_int32, C.c_int32]),
     ("gpf_dereplicate", C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32]),
+    ("gpf_history_enable", C.c_int, [_H, C.c_int32]),
+    ("gpf_history_steps", C.c_int, [_H, _pi32]),
+    ("gpf_history_column", C.c_int, [_H, C.c_int32, C.c_int32, _pd, C.c_int64]),
+    ("gpf_history_mean", C.c_int, [_H, C.c_int32, C.c_int32, _pd]),
+    ("gpf_history_var", C.c_int, [_H, C.c_int32, C.c_int32, _pd]),
     # shard-level building blocks: device pointers are passed as integers (tensor.data_ptr())
     ("gpf_shard_weight_max", C.c_int, [_H, C.c_void_p]),
     ("gpf_shard_weight_scan", C.c_int, [_H, C.c_void_p, C.c_void_p]),

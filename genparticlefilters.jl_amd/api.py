@@ -64,7 +64,8 @@ class DeviceParticleFilterState:
     log_weights / log_ml_est / parents).  Owns an opaque libgpf handle."""
 
     def __init__(self, model: NativeModel, n_particles: int, seed: int = 1, keep_prev: bool = False,
-                 device: int = 0, n_global: int | None = None, gid0: int = 0, stream: int | None = None):
+                 device: int = 0, n_global: int | None = None, gid0: int = 0, stream: int | None = None,
+                 history: int = 0):
         self._L = _lib.load()
         self.model, self.n_particles, self.seed = model, int(n_particles), int(seed)
         self.keep_prev = bool(keep_prev)
@@ -84,6 +85,8 @@ class DeviceParticleFilterState:
         d, w = C.c_int32(), C.c_int32()
         self._L.gpf_state_dim(self._h, C.byref(d), C.byref(w))
         self.dim, self.row_width = d.value, w.value
+        if history:                      # trajectory store for `history` time steps (persistent-trace queries)
+            self._check(self._L.gpf_history_enable(self._h, int(history)))
 
     # -- plumbing
     def _check(self, st: int):
@@ -142,6 +145,12 @@ class DeviceParticleFilterState:
     def column(self, col: int) -> np.ndarray:
         out = np.empty(self.n_particles)
         self._check(self._L.gpf_get_column(self._h, int(col), _pd(out), out.size))
+        return out
+
+    def history_column(self, step: int, col: int) -> np.ndarray:
+        """trace[step => col] of every current particle (step is 1-based like the Julia address t => :name)"""
+        out = np.empty(self.n_particles)
+        self._check(self._L.gpf_history_column(self._h, int(step), int(col), _pd(out), out.size))
         return out
 
     # -- measurement hooks
@@ -370,15 +379,22 @@ def get_traces(state) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------- statistics (src/statistics.jl)
-def mean(state, addr: int) -> float:
-    """mean(state, addr): addr = column index of the current-step latent (src/statistics.jl:13-14)"""
+def mean(state, addr) -> float:
+    """mean(state, addr), src/statistics.jl:13-14.  addr = column of the current-step latent, or a pair
+    (t, column) for a PAST choice `t => column` (reference README.md:97; needs pf_initialize(..., history=T))"""
     out = C.c_double()
-    state._check(state._L.gpf_mean(state._h, int(addr), C.byref(out)))
+    if isinstance(addr, tuple):
+        state._check(state._L.gpf_history_mean(state._h, int(addr[0]), int(addr[1]), C.byref(out)))
+    else:
+        state._check(state._L.gpf_mean(state._h, int(addr), C.byref(out)))
     return out.value
 
 
-def var(state, addr: int) -> float:
-    """var(state, addr), population form (src/statistics.jl:48-50)"""
+def var(state, addr) -> float:
+    """var(state, addr), population form (src/statistics.jl:48-50); addr as in mean()"""
     out = C.c_double()
-    state._check(state._L.gpf_var(state._h, int(addr), C.byref(out)))
+    if isinstance(addr, tuple):
+        state._check(state._L.gpf_history_var(state._h, int(addr[0]), int(addr[1]), C.byref(out)))
+    else:
+        state._check(state._L.gpf_var(state._h, int(addr), C.byref(out)))
     return out.value

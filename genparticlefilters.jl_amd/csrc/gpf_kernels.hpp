@@ -1144,4 +1144,54 @@ __global__ void k_dereplicate_sample(const double* __restrict__ lw, int64_t n_ne
     }
 }
 
+// ----------------------------------------------------------------------------- trajectory store
+// Gen traces are persistent: mean(state, 5 => :moving) (reference README.md:97) reads a PAST choice of every
+// surviving particle.  The device keeps, per time step, the step's latent columns (final particle order of that
+// step) and the composed ancestor map of the resamples that happened during the step.
+__global__ void k_hist_snapshot(const double* __restrict__ rows, int W, int d, int64_t n, double* __restrict__ out)
+{
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < n * d; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i = t / d;
+        out[t] = rows[i * W + (t - i * d)];
+    }
+}
+// B[j] = first resample of the step ? anc[j] : B_old[anc[j]]
+__global__ void k_hist_compose(const int32_t* __restrict__ anc, const int32_t* __restrict__ b_old, int64_t n, int32_t* __restrict__ b_new)
+{
+    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * BLOCK)
+        b_new[j] = b_old ? b_old[anc[j]] : anc[j];
+}
+// value of column `col` of step `t` along the ancestry of every current particle: follow B_T, B_{T-1}, ..., B_{t+1}
+__global__ void k_hist_column(const int32_t* const* __restrict__ maps, int n_maps, const double* __restrict__ hx, int d, int col,
+                              int64_t n, double* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        int64_t idx = i;
+        for (int s = 0; s < n_maps; ++s) { const int32_t* m = maps[s]; if (m) idx = m[idx]; }
+        out[i] = hx[idx * d + col];
+    }
+}
+// sum_i w_i f(v_i) over a plain value array (same weights / reduction as k_wsum)
+__global__ __launch_bounds__(BLOCK) void k_wsum_values(const double* __restrict__ lw, const WSum* ws, int K,
+                                                       const double* __restrict__ values, int64_t n, int pw,
+                                                       const double* center, double* __restrict__ partial)
+{
+    const double m = ws->m;
+    const double Sd = (double)ws->S;
+    const bool uniform = (ws->flags & FLAG_ALL_NEGINF) != 0;
+    const double c = center ? *center : 0.0;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint64_t q = uniform ? 1 : exp_fix(lw[i] - m, K);
+        double v = values[i];
+        if (pw == 2) { v = v - c; v = v * v; }
+        acc += ((double)q / Sd) * v;
+    }
+    acc = wave_sum_f64(acc);
+    __shared__ double s[NWAVES];
+    if (lane_id() == 0) s[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < NWAVES; ++w) t += s[w]; partial[blockIdx.x] = t; }
+}
+
 } // namespace gpf

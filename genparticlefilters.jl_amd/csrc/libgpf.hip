@@ -65,6 +65,14 @@ struct gpf_filter {
     bool raw_has_q = false;        // the raw summary's scan also accumulated sum q^2 (blockQ)
     bool raw_q_folded = false;     // sc->raw.Ql folded from blockQ
     bool pending_gather = false;   // a resample left (rows[cur], anc) un-gathered; log-weights are 0
+    // trajectory store (gpf_history_enable): per recorded step the d latent columns in the step's final particle
+    // order, and the composed ancestor map of the resamples that happened during that step (nullptr = identity)
+    bool hist_on = false;
+    int hist_cap = 0;
+    std::vector<double*> hist_x;         // [step] n*d doubles (nullptr until snapshotted)
+    std::vector<int32_t*> hist_map;      // [step] n int32 or nullptr
+    int hist_step = -1;                  // index of the current step (0 = after gpf_initialize)
+    const int32_t** hist_dev_maps = nullptr;
     Timer timers[GPF_K_COUNT];
     std::string err;
 };
@@ -248,6 +256,49 @@ gpf_status materialize(gpf_filter* h)
     h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
     h->pending_gather = false;
     h->max_valid = false;           // log-weights are all 0 now
+    return GPF_OK;
+}
+
+// ------------------------------------------------------------------ trajectory store
+void hist_clear(gpf_filter* h)
+{
+    for (double* p : h->hist_x) if (p) (void)hipFree(p);
+    for (int32_t* p : h->hist_map) if (p) (void)hipFree(p);
+    h->hist_x.clear(); h->hist_map.clear(); h->hist_step = -1;
+}
+// snapshot the latent columns of the CURRENT step (final order: called when the step is over, or at query time)
+gpf_status hist_snapshot(gpf_filter* h)
+{
+    if (!h->hist_on || h->hist_step < 0) return GPF_OK;
+    gpf_status s = materialize(h);
+    if (s) return s;
+    double*& dst = h->hist_x[h->hist_step];
+    if (!dst) HIP_TRY(h, hipMalloc(&dst, (size_t)h->n * h->d * sizeof(double)));
+    hipLaunchKernelGGL(k_hist_snapshot, dim3(grid_for(h, h->n * h->d, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, h->d, h->n, dst);
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+// a resample happened during the current step: compose its ancestors into the step's map
+gpf_status hist_on_resample(gpf_filter* h)
+{
+    if (!h->hist_on || h->hist_step < 0) return GPF_OK;
+    int32_t* old = h->hist_map[h->hist_step];
+    int32_t* neu = nullptr;
+    HIP_TRY(h, hipMalloc(&neu, (size_t)h->n * sizeof(int32_t)));
+    hipLaunchKernelGGL(k_hist_compose, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, old, h->n, neu);
+    HIP_TRY(h, hipGetLastError());
+    if (old) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(old); }
+    h->hist_map[h->hist_step] = neu;
+    return GPF_OK;
+}
+gpf_status hist_begin_step(gpf_filter* h, bool first)
+{
+    if (!h->hist_on) return GPF_OK;
+    if (first) hist_clear(h);
+    else { gpf_status s = hist_snapshot(h); if (s) return s; }     // the step that ends now, in its final order
+    if ((int)h->hist_x.size() >= h->hist_cap) return fail(h, GPF_ERR_STATE, "trajectory store full: raise max_steps of gpf_history_enable");
+    h->hist_x.push_back(nullptr); h->hist_map.push_back(nullptr);
+    h->hist_step = (int)h->hist_x.size() - 1;
     return GPF_OK;
 }
 
@@ -446,6 +497,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         }
     });
     if (s) return s;
+    if ((s = hist_on_resample(h))) return s;
     if (pv.mode == 0) {
         // new_traces .= view(traces, parents) is deferred: the next pf_update! reads rows through anc (fused
         // gather), any other consumer calls materialize().  Log-weights are 0 (resample.jl:195).
@@ -541,6 +593,8 @@ gpf_status gpf_destroy(gpf_handle h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    hist_clear(h);
+    if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
     void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc};
     for (void* b : bufs) if (b) hipFree(b);
@@ -563,6 +617,7 @@ gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs)
     gpf_status s = set_obs(h, obs, n_obs);
     if (s) return s;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if ((s = hist_begin_step(h, true))) return s;
     const int grid = step_grid(h);
     s = timed(h, GPF_K_STEP, [&] { DISPATCH_MODEL(h, launch_init_t<MM>(h, grid)); });
     if (s) return s;
@@ -583,6 +638,7 @@ gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs)
     gpf_status s = check_ready(h);
     if (s) return s;
     if ((s = set_obs(h, obs, n_obs))) return s;
+    if ((s = hist_begin_step(h, false))) return s;
     const int grid = step_grid(h);
     const bool keep = h->cfg.keep_prev != 0;
     s = timed(h, GPF_K_STEP, [&] {
@@ -841,6 +897,7 @@ static gpf_status resize_ready(gpf_handle h)
     gpf_status s = check_ready(h);
     if (s) return s;
     if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, "resizing a sharded filter is not supported");
+    if (h->hist_on) return fail(h, GPF_ERR_STATE, "resizing a filter with a trajectory store is not supported");
     return materialize(h);
 }
 // after the particle count changed: unsharded bookkeeping
@@ -962,6 +1019,77 @@ gpf_status gpf_dereplicate(gpf_handle h, int32_t n_replicates, int32_t interleav
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
+
+// =================================================================================== trajectory store
+gpf_status gpf_history_enable(gpf_handle h, int32_t max_steps)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (max_steps < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "max_steps < 1");
+    if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, "the trajectory store is not available for sharded filters");
+    if (h->initialized) return fail(h, GPF_ERR_STATE, "enable the trajectory store before gpf_initialize");
+    h->hist_on = true; h->hist_cap = max_steps;
+    if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
+    HIP_TRY(h, hipMalloc(&h->hist_dev_maps, (size_t)max_steps * sizeof(int32_t*)));
+    return GPF_OK;
+}
+
+gpf_status gpf_history_steps(gpf_handle h, int32_t* n_steps)
+{
+    if (!h || !n_steps) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    *n_steps = h->hist_on ? (int32_t)h->hist_x.size() : 0;
+    return GPF_OK;
+}
+
+// column `column` of time step `step` (1-based, like the t of the Julia address t => :name) into h->dtmp
+static gpf_status history_values(gpf_handle h, int32_t step, int32_t column)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!h->hist_on) return fail(h, GPF_ERR_STATE, "trajectory store not enabled (gpf_history_enable)");
+    const int T = (int)h->hist_x.size();
+    if (step < 1 || step > T || column < 0 || column >= h->d) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad step/column");
+    if ((s = hist_snapshot(h))) return s;                         // the current step, in its current order
+    // maps of steps T, T-1, ..., step+1 (0-based indices T-1 ... step), applied in that order
+    std::vector<const int32_t*> maps;
+    for (int q = T - 1; q >= step; --q) maps.push_back(h->hist_map[q]);
+    if (!maps.empty())
+        HIP_TRY(h, hipMemcpyAsync(h->hist_dev_maps, maps.data(), maps.size() * sizeof(int32_t*), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));                   // `maps` is a host temporary
+    hipLaunchKernelGGL(k_hist_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->hist_dev_maps, (int)maps.size(),
+                       h->hist_x[step - 1], h->d, (int)column, h->n, h->dtmp);
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+
+gpf_status gpf_history_column(gpf_handle h, int32_t step, int32_t column, double* out, int64_t n)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (!out || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
+    gpf_status s = history_values(h, step, column);
+    if (s) return s;
+    return copy_out(h, h->dtmp, out, (size_t)n * sizeof(double));
+}
+
+static gpf_status history_stat(gpf_handle h, int32_t step, int32_t column, double* out, bool variance)
+{
+    if (!h || !out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    gpf_status s = history_values(h, step, column);
+    if (s) return s;
+    if ((s = ensure_raw(h))) return s;
+    const int g = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 1, nullptr, h->partial);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
+    if (variance) {
+        hipLaunchKernelGGL(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 2, h->dscal, h->partial);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal + 1);
+    }
+    double tmp[2];
+    if ((s = copy_out(h, h->dscal, tmp, sizeof(tmp)))) return s;
+    *out = variance ? tmp[1] : tmp[0];
+    return GPF_OK;
+}
+gpf_status gpf_history_mean(gpf_handle h, int32_t step, int32_t column, double* out) { return history_stat(h, step, column, out, false); }
+gpf_status gpf_history_var(gpf_handle h, int32_t step, int32_t column, double* out) { return history_stat(h, step, column, out, true); }
 
 // =================================================================================== shard-level ABI
 static gpf_status shard_ready(gpf_handle h)

@@ -167,6 +167,18 @@ gpf_status gpf_replicate(gpf_handle h, int32_t n_replicates, int32_t interleaved
 /* pf_dereplicate!(state, n_replicates; layout, method)                 src/resize.jl:267-297  (sample=0 :keepfirst, 1 :sample) */
 gpf_status gpf_dereplicate(gpf_handle h, int32_t n_replicates, int32_t interleaved, int32_t sample);
 
+/* ---- trajectory store ------------------------------------------------------------------
+ * Gen traces are persistent, so the reference can ask for a PAST choice of every surviving particle:
+ * mean(state, 5 => :moving) (reference README.md:97-104, src/statistics.jl:13-14 with a past address).
+ * With the store enabled the handle keeps, per time step, the step's latent columns and the composed ancestor map
+ * of the resamples of that step (8d + 4 bytes per particle and step); queries follow the ancestry of each
+ * current particle.  `step` is 1-based (step 1 = gpf_initialize).  Unsharded filters only. */
+gpf_status gpf_history_enable(gpf_handle h, int32_t max_steps);          /* before gpf_initialize */
+gpf_status gpf_history_steps(gpf_handle h, int32_t* n_steps);
+gpf_status gpf_history_column(gpf_handle h, int32_t step, int32_t column, double* out, int64_t n);   /* trace[step => column] per particle */
+gpf_status gpf_history_mean(gpf_handle h, int32_t step, int32_t column, double* out);               /* mean(state, step => column) */
+gpf_status gpf_history_var(gpf_handle h, int32_t step, int32_t column, double* out);                /* var(state, step => column)  */
+
 /* ---- shard-level building blocks (multi-GPU) ------------------------------------------------------
  * A filter sharded over G GPUs is G handles created with the same seed / n_global and contiguous
  * [gid0, gid0 + n_particles) ranges.  gpf_initialize / gpf_update / gpf_rejuvenate work per shard as they

@@ -179,4 +179,13 @@ function var(s::DeviceParticleFilterState, addr::Integer)
     out = Ref{Cdouble}(0); check(s, ccall((:gpf_var, libgpf), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), s.handle, addr, out)); out[]
 end
 
+# past choices along the surviving ancestry, README.md:97-104: mean(state, 5 => 0) == mean(state, 5 => :moving)
+# (needs the trajectory store: gpf_history_enable before pf_initialize)
+function mean(s::DeviceParticleFilterState, addr::Pair{<:Integer,<:Integer})
+    out = Ref{Cdouble}(0); check(s, ccall((:gpf_history_mean, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cdouble}), s.handle, addr.first, addr.second, out)); out[]
+end
+function var(s::DeviceParticleFilterState, addr::Pair{<:Integer,<:Integer})
+    out = Ref{Cdouble}(0); check(s, ccall((:gpf_history_var, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cdouble}), s.handle, addr.first, addr.second, out)); out[]
+end
+
 end # module

@@ -193,7 +193,9 @@ class OracleFilter:
     """Single-shard oracle with the state of Gen.ParticleFilterState:
     rows (traces), log_weights, log_ml_est, parents (1-based, into the pre-resample array)."""
 
-    def __init__(self, model: int, params, n_particles: int, seed: int, keep_prev: bool = False):
+    def __init__(self, model: int, params, n_particles: int, seed: int, keep_prev: bool = False, history: bool = False):
+        self.history = bool(history)
+        self.hist_x, self.hist_map = [], []      # per step: latent columns (final order of the step), composed ancestors
         self.model, self.n, self.seed = int(model), int(n_particles), int(seed)
         self.params = np.ascontiguousarray(params, np.float64)
         self.keep_prev = bool(keep_prev)
@@ -211,6 +213,7 @@ class OracleFilter:
     # -- initialize.jl:31-44
     def initialize(self, obs):
         obs = np.ascontiguousarray(obs, np.float64)
+        self.hist_x, self.hist_map = [None], [None]
         lib().o_init(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, obs, self.rows, self.lw)
         self.lml_est = 0.0
         self.parents = np.arange(1, self.n + 1, dtype=np.int64)
@@ -222,6 +225,9 @@ class OracleFilter:
     # -- update.jl:12-25
     def update(self, obs):
         obs = np.ascontiguousarray(obs, np.float64)
+        if self.history:                                            # the step that ends now, in its final order
+            self.hist_x[-1] = self.rows[:, :self.d].copy()
+            self.hist_x.append(None); self.hist_map.append(None)
         new_rows = np.empty_like(self.rows)
         lib().o_step(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, int(self.keep_prev),
                      obs, self.rows, new_rows, self.lw)            # :15-22
@@ -297,6 +303,8 @@ class OracleFilter:
                 rcdf, Rs, _, _ = scan(r)                            # :110 (normalisation == using Rs)
                 T = targets_multinomial(self.seed, epoch, n_res, N - n_res, Rs)
                 anc[n_res:] = upper_bound(rcdf, T)                  # :113
+        if self.history:                                            # persistent traces: remember who descends from whom
+            self.hist_map[-1] = anc.copy() if self.hist_map[-1] is None else self.hist_map[-1][anc]
         new_rows = gather_rows(self.rows, anc)                      # :60 / :103,114 / :169
         # update_weights! :190-202
         if not has_prio:
@@ -400,3 +408,24 @@ class OracleFilter:
 
     def column(self, col: int) -> np.ndarray:
         return self.rows[:, col].copy()
+
+    # -- trajectory store: statistics.jl:13-14,48-50 with a PAST address (README.md:97-104), step is 1-based
+    def history_column(self, step: int, col: int) -> np.ndarray:
+        T = len(self.hist_x)
+        self.hist_x[-1] = self.rows[:, :self.d].copy()
+        idx = np.arange(self.n)
+        for q in range(T - 1, step - 1, -1):
+            if self.hist_map[q] is not None:
+                idx = self.hist_map[q][idx]
+        return self.hist_x[step - 1][idx, col]
+
+    def history_mean(self, step: int, col: int) -> float:
+        s = self.summary()
+        v = np.ascontiguousarray(self.history_column(step, col)).reshape(-1, 1)
+        return lib().o_wsum(s.q, s.S, v, 1, 0, self.n, 1, 0.0)
+
+    def history_var(self, step: int, col: int) -> float:
+        s = self.summary()
+        v = np.ascontiguousarray(self.history_column(step, col)).reshape(-1, 1)
+        mu = lib().o_wsum(s.q, s.S, v, 1, 0, self.n, 1, 0.0)
+        return lib().o_wsum(s.q, s.S, v, 1, 0, self.n, 2, mu)
