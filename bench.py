@@ -149,6 +149,25 @@ def main():
                     "algorithmic_bytes_per_launch": ab[dom] * n_local, "avg_launch_us": round(us, 2),
                     "all_kernels_us": {k: round(v[0], 2) for k, v in per.items()}}
 
+    # ---- the stand-alone resample gather (BASELINE.json names it): the hot loop above fuses the gather into the next
+    #      propagate, so time k_gather itself on the same state by asking for the ESS between resample and update
+    gather = None
+    if not sharded_mode and rank == 0:
+        gather = {}
+        W = state.row_width
+        gbytes = (4 + 8 * W + 8 * W + 8) * n_local                # R anc, R row (random), W row, W lw = 16d + 12
+        for meth, kw in (("multinomial", {}), ("stratified", {"sort_particles": False})):
+            state.kernel_timing(g._lib.K_GATHER, True)
+            for i in range(30):
+                g.pf_resample(state, meth, check=False, **kw)
+                g.get_ess(state)                                   # forces materialize() = the stand-alone k_gather
+                g.pf_update(state, (i + 2,), (None,), ys[1 + i])
+            ms, cnt = state.kernel_time(g._lib.K_GATHER)
+            state.kernel_timing(g._lib.K_GATHER, False)
+            us = ms / max(cnt, 1) * 1e3
+            gather[meth] = {"avg_launch_us": round(us, 2), "achieved": round(gbytes / us / 1e3, 1), "unit": "GB/s",
+                            "frac": round(gbytes / us / 1e3 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": gbytes}
+
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 / N=1 only ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -175,7 +194,7 @@ def main():
                        "particles_per_gpu": n_local, "particles_total": n_global, "T": K,
                        "state_dim": model.dim, "parallelism": f"particle-shard x{world}"},
             "log_ml_estimate": lml,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "resample_gather_kernel": gather,
         }
         print(json.dumps(out))
     if dist is not None:
