@@ -561,29 +561,6 @@ __device__ __forceinline__ int group8_sum(int c)
 }
 // In round r the 8-lane group g serves ITS OWN member 8g+r: the member's (line, T) is broadcast through the wave's
 // LDS strip, each lane loads 16 B of the line (one coalesced transaction per line), compares, the group sums.
-__device__ __forceinline__ int coop_count_le(const uint64_t* line, uint64_t T, ulonglong2* lds_wave)
-{
-    const int lane = lane_id(), sub = lane & 7, gbase = lane & ~7;
-    lds_wave[lane] = make_ulonglong2(reinterpret_cast<uint64_t>(line), T);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    ulonglong2 v[8];
-    uint64_t t[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const ulonglong2 pt = lds_wave[gbase + r];     // broadcast read inside the group
-        t[r] = pt.y;
-        v[r] = load_global_16(pt.x, sub);
-    }
-    int result = 0;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int c = group8_sum((int)(v[r].x <= t[r]) + (int)(v[r].y <= t[r]));
-        result = sub == r ? c : result;
-    }
-    __builtin_amdgcn_wave_barrier();
-    return result;
-}
 // two independent slots per lane at once (16 line loads in flight per lane): lds_wave holds 2 x 64 entries
 __device__ __forceinline__ void coop_count_le2(const uint64_t* line0, uint64_t T0, const uint64_t* line1, uint64_t T1,
                                                ulonglong2* lds_wave, int& c0, int& c1)
@@ -623,48 +600,6 @@ __device__ __forceinline__ int count_le_line(const uint64_t* __restrict__ line, 
     return cnt;
 }
 
-// top level: first per-256 group whose prefix exceeds T (or the tile level + the tile's 8 per-256 prefixes)
-__device__ __forceinline__ int64_t find_top(const CdfLevels& L, const uint64_t* top, bool top_is_256, int64_t ntiles, uint64_t T)
-{
-    int64_t s256;
-#ifdef GPF_ABL_SEARCH_NOLDS
-    if (top_is_256) return (int64_t)(T % (uint64_t)(ntiles * 8));
-#endif
-    if (top_is_256) {
-        int64_t lo = 0, hi = ntiles * 8;
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (top[mid] > T) hi = mid; else lo = mid + 1; }
-        s256 = lo;
-    } else {
-        int64_t lo = 0, hi = ntiles;
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((top[mid] & DESC_MASK) > T) hi = mid; else lo = mid + 1; }
-        if (lo >= ntiles) lo = ntiles - 1;
-        const uint64_t* g = L.t256 + lo * 8;           // the tile's 8 per-256 prefixes: 64 B
-        int c = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) c += (g[e] <= T);
-        s256 = lo * 8 + c;
-    }
-    const int64_t n256 = ntiles * 8;
-    return s256 < n256 ? s256 : n256 - 1;
-}
-// coop = true is WAVE-COLLECTIVE: every lane of the wave must call it (inactive lanes pass any valid T);
-// coop must be wave-uniform.  lds_wave: 64 ulonglong2 of LDS private to the calling wave.
-__device__ __forceinline__ int64_t find_index(const CdfLevels& L, const uint64_t* top, bool top_is_256, int64_t n,
-                                              int64_t ntiles, uint64_t T, bool coop, ulonglong2* lds_wave)
-{
-    const int64_t s256 = find_top(L, top, top_is_256, ntiles, T);
-#ifdef GPF_ABL_SEARCH_NOLINES
-    return s256 * 256 < n ? s256 * 256 : n - 1;
-#endif
-    const uint64_t* l1 = L.t16 + s256 * 16;
-    int64_t s16 = s256 * 16 + (coop ? coop_count_le(l1, T, lds_wave) : count_le_line(l1, T));
-    const int64_t n16 = ntiles * (TILE / 16);
-    s16 = s16 < n16 ? s16 : n16 - 1;
-    const uint64_t* l2 = L.cdf + s16 * 16;
-    const int64_t idx = s16 * 16 + (coop ? coop_count_le(l2, T, lds_wave) : count_le_line(l2, T));
-    return idx < n ? idx : n - 1;
-}
-
 struct SearchArgs {
     CdfLevels w;                                                      // weights (or residual weights for the tail)
     CdfLevels c;                                                      // residual: copy counts
@@ -693,43 +628,117 @@ constexpr int SBLOCK = 1024;
 #ifndef SEARCH_BLOCKS_PER_CU
 #define SEARCH_BLOCKS_PER_CU 1
 #endif
+// ---- the search core shared by k_search (single GPU) and k_serve (sharded): top level in LDS + two line levels
+struct SearchTop {
+    const uint64_t* topw; const uint64_t* topc;      // top level of the weight CDF / of the residual copy-count CDF
+    int64_t tn;                                      // entries of the top level
+    int steps;                                       // ceil(log2(tn + 1))
+    bool top256, in_lds, mask_top;
+};
+// block-collective: copy the top level(s) into LDS (smem: dynamic LDS, (two ? 2 : 1) * (lds_pad(tn) + 1) words)
+__device__ __forceinline__ SearchTop search_prologue(const CdfLevels& w, const CdfLevels& c, bool two, int64_t ntiles, uint64_t* smem)
+{
+    SearchTop st;
+    const int nt = two ? 2 : 1;
+    st.top256 = nt * ntiles * 8 <= LDS_TILE_TABLE;
+    st.in_lds = st.top256 || nt * ntiles <= LDS_TILE_TABLE;
+    st.tn = st.top256 ? ntiles * 8 : ntiles;
+    uint64_t* tw = smem;
+    uint64_t* tc = tw + lds_pad(st.tn);
+#ifdef GPF_ABL_SEARCH_NOTABLE
+    if (false) {
+#else
+    if (st.in_lds) {
+#endif
+        const uint64_t* srcw = st.top256 ? w.t256 : w.ttile;
+        const uint64_t* srcc = st.top256 ? c.t256 : c.ttile;
+        // 16 B per lane (tn is a multiple of 8 when it is the per-256 level; the tile level is handled by the tail)
+        const int64_t tn2 = st.tn & ~(int64_t)1;
+        for (int64_t t = 2 * (int64_t)threadIdx.x; t < tn2; t += 2 * (int64_t)blockDim.x) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(srcw + t);
+            tw[lds_pad(t)] = v.x & DESC_MASK;                         // descriptor words carry a valid bit
+            tw[lds_pad(t + 1)] = v.y & DESC_MASK;
+            if (two) {
+                const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(srcc + t);
+                tc[lds_pad(t)] = x.x & DESC_MASK;
+                tc[lds_pad(t + 1)] = x.y & DESC_MASK;
+            }
+        }
+        if (threadIdx.x == 0 && tn2 < st.tn) { tw[lds_pad(tn2)] = srcw[tn2] & DESC_MASK; if (two) tc[lds_pad(tn2)] = srcc[tn2] & DESC_MASK; }
+        __syncthreads();
+    }
+    st.topw = st.in_lds ? tw : w.ttile;
+    st.topc = st.in_lds ? tc : c.ttile;
+    st.mask_top = !st.in_lds;                                         // global descriptor words still carry the bit
+    st.steps = 0;
+    while (((int64_t)1 << st.steps) <= st.tn) ++st.steps;
+    return st;
+}
+// two slots per lane: idx[u] = first index of L[u] whose prefix exceeds T[u].  WAVE-COLLECTIVE when coop (wave-uniform).
+__device__ __forceinline__ void search_pair(const SearchTop& st, const CdfLevels* const L[2], const uint64_t* const top[2],
+                                            const uint64_t T[2], bool coop, ulonglong2* lds_wave, int64_t n_cells, int64_t ntiles,
+                                            int64_t idx[2])
+{
+    const int64_t n256 = ntiles * 8, n16 = ntiles * (TILE / 16);
+    // top level: branch-free binary search, both slots interleaved; pos = number of entries <= T
+    int64_t pos[2] = {0, 0};
+#ifdef GPF_ABL_SEARCH_NOLDS
+    pos[0] = (int64_t)(T[0] % (uint64_t)st.tn); pos[1] = (int64_t)(T[1] % (uint64_t)st.tn);
+    for (int s = -1; s >= 0; --s) {
+#else
+    for (int s = st.steps - 1; s >= 0; --s) {
+#endif
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t np = pos[u] + ((int64_t)1 << s);
+            if (np <= st.tn) {
+                uint64_t v = top[u][st.in_lds ? lds_pad(np - 1) : np - 1];
+                if (st.mask_top) v &= DESC_MASK;
+                if (v <= T[u]) pos[u] = np;
+            }
+        }
+    }
+    int64_t s256[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (st.top256) s256[u] = pos[u];
+        else {
+            const int64_t tile = pos[u] < ntiles ? pos[u] : ntiles - 1;
+            const uint64_t* g = L[u]->t256 + tile * 8;             // the tile's 8 per-256 prefixes: 64 B
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c += (g[e] <= T[u]);
+            s256[u] = tile * 8 + c;
+        }
+        s256[u] = s256[u] < n256 ? s256[u] : n256 - 1;
+    }
+#ifdef GPF_ABL_SEARCH_NOLINES
+    idx[0] = s256[0] * 256 < n_cells ? s256[0] * 256 : n_cells - 1;
+    idx[1] = s256[1] * 256 < n_cells ? s256[1] * 256 : n_cells - 1;
+    return;
+#endif
+    int c0, c1;
+    const uint64_t* l0 = L[0]->t16 + s256[0] * 16;
+    const uint64_t* l1 = L[1]->t16 + s256[1] * 16;
+    if (coop) coop_count_le2(l0, T[0], l1, T[1], lds_wave, c0, c1);
+    else { c0 = count_le_line(l0, T[0]); c1 = count_le_line(l1, T[1]); }
+    int64_t s16a = s256[0] * 16 + c0, s16b = s256[1] * 16 + c1;
+    s16a = s16a < n16 ? s16a : n16 - 1;
+    s16b = s16b < n16 ? s16b : n16 - 1;
+    l0 = L[0]->cdf + s16a * 16;
+    l1 = L[1]->cdf + s16b * 16;
+    if (coop) coop_count_le2(l0, T[0], l1, T[1], lds_wave, c0, c1);
+    else { c0 = count_le_line(l0, T[0]); c1 = count_le_line(l1, T[1]); }
+    idx[0] = s16a * 16 + c0; idx[1] = s16b * 16 + c1;
+    idx[0] = idx[0] < n_cells ? idx[0] : n_cells - 1;
+    idx[1] = idx[1] < n_cells ? idx[1] : n_cells - 1;
+}
+
 template <int METHOD>
 __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(SearchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* tw = reinterpret_cast<uint64_t*>(smem);
-    constexpr int NT = METHOD == 1 ? 2 : 1;
-    const bool top256 = NT * a.ntiles * 8 <= LDS_TILE_TABLE;
-    const bool in_lds = top256 || NT * a.ntiles <= LDS_TILE_TABLE;
-    const int64_t tn = top256 ? a.ntiles * 8 : a.ntiles;             // entries of the top level
-    uint64_t* tc = tw + lds_pad(tn);
-#ifdef GPF_ABL_SEARCH_NOTABLE
-    if (false) {
-#else
-    if (in_lds) {
-#endif
-        const uint64_t* srcw = top256 ? a.w.t256 : a.w.ttile;
-        const uint64_t* srcc = top256 ? a.c.t256 : a.c.ttile;
-        // 16 B per lane (tn is a multiple of 8 when it is the per-256 level; the tile level is handled by the tail)
-        const int64_t tn2 = tn & ~(int64_t)1;
-        for (int64_t t = 2 * (int64_t)threadIdx.x; t < tn2; t += 2 * SBLOCK) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(srcw + t);
-            tw[lds_pad(t)] = v.x & DESC_MASK;                         // descriptor words carry a valid bit
-            tw[lds_pad(t + 1)] = v.y & DESC_MASK;
-            if (METHOD == 1) {
-                const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(srcc + t);
-                tc[lds_pad(t)] = w.x & DESC_MASK;
-                tc[lds_pad(t + 1)] = w.y & DESC_MASK;
-            }
-        }
-        if (threadIdx.x == 0 && tn2 < tn) { tw[lds_pad(tn2)] = srcw[tn2] & DESC_MASK; if (METHOD == 1) tc[lds_pad(tn2)] = srcc[tn2] & DESC_MASK; }
-        __syncthreads();
-    }
-    const uint64_t* topw = in_lds ? tw : a.w.ttile;
-    const uint64_t* topc = in_lds ? tc : a.c.ttile;
-    const bool mask_top = !in_lds;                                    // global descriptor words still carry the bit
-    int steps = 0;
-    while (((int64_t)1 << steps) <= tn) ++steps;                      // ceil(log2(tn + 1))
+    const SearchTop st = search_prologue(a.w, a.c, METHOD == 1, a.ntiles, reinterpret_cast<uint64_t*>(smem));
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
 #ifndef GPF_ABL_SEARCH_NOLML
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -749,7 +758,6 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
     }
     const double invN = 1.0 / (double)N;
     const uint64_t Ctot = (METHOD == 1) ? a.sc->Ctot : 0;
-    const int64_t n256 = a.ntiles * 8, n16 = a.ntiles * (TILE / 16);
     // two slots per lane and iteration (independent dependency chains); the loop is wave-uniform
     for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < a.n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
         int64_t j[2]; bool act[2], head[2]; uint64_t T[2]; const uint64_t* top[2]; const CdfLevels* L[2];
@@ -764,7 +772,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
             const Philox b = rng(a.seed, (uint32_t)jg, 0, a.epoch, TAG_RESAMPLE);
             const uint64_t U = u64(b.w0, b.w1);
 #endif
-            head[u] = false; top[u] = topw; L[u] = &a.w;
+            head[u] = false; top[u] = st.topw; L[u] = &a.w;
             if (METHOD == 0) T[u] = mulhi64(U, S);                    // multinomial, resample.jl:59
             else if (METHOD == 2) {                                   // stratified, resample.jl:159-168
                 const uint64_t B = s_div[0], rem = s_div[1];
@@ -775,69 +783,20 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
             } else {                                                  // residual, resample.jl:96-115
                 head[u] = jg < Ctot;
                 T[u] = head[u] ? jg : mulhi64(U, S);
-                if (head[u]) { top[u] = topc; L[u] = &a.c; }
+                if (head[u]) { top[u] = st.topc; L[u] = &a.c; }
             }
         }
 #ifdef GPF_ABL_SEARCH_ONLYT
-        if (act[0]) a.anc[j[0]] = (int32_t)(T[0] % (uint64_t)a.n);
-        if (act[1]) a.anc[j[1]] = (int32_t)(T[1] % (uint64_t)a.n);
+        if (act[0]) a.anc[j[0]] = (int32_t)(T[0] % (uint64_t)a.n_cells);
+        if (act[1]) a.anc[j[1]] = (int32_t)(T[1] % (uint64_t)a.n_cells);
         continue;
 #endif
         // coherent targets (stratified; residual waves that are all deterministic copies) read their lines per lane
         const bool coop = METHOD == 0 ? true : (METHOD == 2 ? false : __any(!head[0] || !head[1]) != 0);
-        // top level: branch-free binary search, both slots interleaved; pos = number of entries <= T
-        int64_t pos[2] = {0, 0};
-#ifdef GPF_ABL_SEARCH_NOLDS
-        pos[0] = (int64_t)(T[0] % (uint64_t)tn); pos[1] = (int64_t)(T[1] % (uint64_t)tn);
-        for (int s = -1; s >= 0; --s) {
-#else
-        for (int s = steps - 1; s >= 0; --s) {
-#endif
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int64_t np = pos[u] + ((int64_t)1 << s);
-                if (np <= tn) {
-                    uint64_t v = top[u][in_lds ? lds_pad(np - 1) : np - 1];
-                    if (mask_top) v &= DESC_MASK;
-                    if (v <= T[u]) pos[u] = np;
-                }
-            }
-        }
-        int64_t s256[2];
+        int64_t idx[2];
+        search_pair(st, L, top, T, coop, lds_wave, a.n_cells, a.ntiles, idx);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (top256) s256[u] = pos[u];
-            else {
-                const int64_t tile = pos[u] < a.ntiles ? pos[u] : a.ntiles - 1;
-                const uint64_t* g = L[u]->t256 + tile * 8;             // the tile's 8 per-256 prefixes: 64 B
-                int c = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) c += (g[e] <= T[u]);
-                s256[u] = tile * 8 + c;
-            }
-            s256[u] = s256[u] < n256 ? s256[u] : n256 - 1;
-        }
-        int c0, c1;
-#ifdef GPF_ABL_SEARCH_NOLINES
-        if (act[0]) a.anc[j[0]] = (int32_t)(s256[0] * 256 < a.n_cells ? s256[0] * 256 : a.n_cells - 1);
-        if (act[1]) a.anc[j[1]] = (int32_t)(s256[1] * 256 < a.n_cells ? s256[1] * 256 : a.n_cells - 1);
-        continue;
-#endif
-        const uint64_t* l0 = L[0]->t16 + s256[0] * 16;
-        const uint64_t* l1 = L[1]->t16 + s256[1] * 16;
-        if (coop) coop_count_le2(l0, T[0], l1, T[1], lds_wave, c0, c1);
-        else { c0 = count_le_line(l0, T[0]); c1 = count_le_line(l1, T[1]); }
-        int64_t s16a = s256[0] * 16 + c0, s16b = s256[1] * 16 + c1;
-        s16a = s16a < n16 ? s16a : n16 - 1;
-        s16b = s16b < n16 ? s16b : n16 - 1;
-        l0 = L[0]->cdf + s16a * 16;
-        l1 = L[1]->cdf + s16b * 16;
-        if (coop) coop_count_le2(l0, T[0], l1, T[1], lds_wave, c0, c1);
-        else { c0 = count_le_line(l0, T[0]); c1 = count_le_line(l1, T[1]); }
-        int64_t idx[2] = {s16a * 16 + c0, s16b * 16 + c1};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            idx[u] = idx[u] < a.n_cells ? idx[u] : a.n_cells - 1;
             if (METHOD == 2 && a.order) idx[u] = (int64_t)a.order[idx[u]];
             if (act[u]) a.anc[j[u]] = (int32_t)idx[u];
         }
@@ -1040,29 +999,42 @@ __global__ __launch_bounds__(BLOCK) void k_targets(uint64_t seed, uint32_t epoch
     }
 }
 
-// serve requests in LOCAL coordinates: ancestor lookup in this shard's CDF + row gather
+// serve requests in LOCAL coordinates: ancestor lookup in this shard's CDF (same core as k_search) + row gather
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_serve(const int64_t* __restrict__ T_local, int64_t m_req,
-                                                 CdfLevels lw_, CdfLevels lc_,
-                                                 int64_t n, int64_t ntiles, int64_t gid0, const double* __restrict__ rows,
-                                                 double* __restrict__ rows_out, int64_t* __restrict__ anc_out)
+__global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_serve(const int64_t* __restrict__ T_local, int64_t m_req,
+                                                                          CdfLevels lw_, CdfLevels lc_, int two_tables,
+                                                                          int64_t n, int64_t ntiles, int64_t gid0,
+                                                                          const double* __restrict__ rows,
+                                                                          double* __restrict__ rows_out, int64_t* __restrict__ anc_out)
 {
     constexpr int C = W / 2;
-    __shared__ ulonglong2 s_coop[BLOCK];
-    ulonglong2* const lds_wave = s_coop + wave_id() * WAVE;
-    for (int64_t base = (int64_t)blockIdx.x * BLOCK; base < m_req; base += (int64_t)gridDim.x * BLOCK) {
-        const int64_t r = base + threadIdx.x;
-        const bool active = r < m_req;
-        const int64_t t = T_local[active ? r : m_req - 1];
-        const bool incounts = (t & SPACE_COUNTS) != 0;
-        const CdfLevels L = incounts ? lc_ : lw_;
-        const int64_t a = find_index(L, L.ttile, false, n, ntiles, (uint64_t)(t & ~SPACE_COUNTS), true, lds_wave);   // wave-collective
-        if (!active) continue;
-        anc_out[r] = gid0 + a;
-        const double2* src = reinterpret_cast<const double2*>(rows) + a * C;
-        double2* dst = reinterpret_cast<double2*>(rows_out) + r * C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SearchTop st = search_prologue(lw_, lc_, two_tables != 0, ntiles, reinterpret_cast<uint64_t*>(smem));
+    __shared__ ulonglong2 s_coop[2 * SBLOCK];
+    ulonglong2* const lds_wave = s_coop + wave_id() * (2 * WAVE);
+    for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < m_req; base += (int64_t)gridDim.x * 2 * SBLOCK) {
+        int64_t r[2]; bool act[2]; uint64_t T[2]; const uint64_t* top[2]; const CdfLevels* L[2];
 #pragma unroll
-        for (int c = 0; c < C; ++c) dst[c] = src[c];
+        for (int u = 0; u < 2; ++u) {
+            r[u] = base + u * SBLOCK + threadIdx.x;
+            act[u] = r[u] < m_req;
+            const int64_t t = T_local[act[u] ? r[u] : m_req - 1];
+            const bool incounts = (t & SPACE_COUNTS) != 0;
+            T[u] = (uint64_t)(t & ~SPACE_COUNTS);
+            top[u] = incounts ? st.topc : st.topw;
+            L[u] = incounts ? &lc_ : &lw_;
+        }
+        int64_t idx[2];
+        search_pair(st, L, top, T, true, lds_wave, n, ntiles, idx);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!act[u]) continue;
+            anc_out[r[u]] = gid0 + idx[u];
+            const double2* src = reinterpret_cast<const double2*>(rows) + idx[u] * C;
+            double2* dst = reinterpret_cast<double2*>(rows_out) + r[u] * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) dst[c] = src[c];
+        }
     }
 }
 
@@ -1192,6 +1164,94 @@ __global__ __launch_bounds__(BLOCK) void k_wsum_values(const double* __restrict_
     if (lane_id() == 0) s[wave_id()] = acc;
     __syncthreads();
     if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < NWAVES; ++w) t += s[w]; partial[blockIdx.x] = t; }
+}
+
+// ----------------------------------------------------------------------------- shard routing (stable partition by owner)
+// owner(T) = first shard whose inclusive total exceeds T (weight space, or copy-count space for flagged targets);
+// requests are grouped by owner, slot order kept inside a group, and rewritten in the owner's LOCAL coordinates.
+constexpr int MAX_SHARDS = 16;
+struct RouteArgs {
+    const int64_t* T;          // [n] global targets (bit 62: copy-count space)
+    const int64_t* w_incl;     // [G] inclusive shard totals, weight (or residual-weight) space
+    const int64_t* c_incl;     // [G] inclusive shard totals, copy-count space (or nullptr)
+    int G; int64_t n;
+    int32_t* block_counts;     // [nblocks][MAX_SHARDS]
+    int64_t* T_sorted; int64_t* perm; int64_t* counts;
+};
+__device__ __forceinline__ int route_owner(const RouteArgs& a, int64_t t, int64_t& t_local)
+{
+    const bool incounts = (t & SPACE_COUNTS) != 0;
+    const int64_t v = t & ~SPACE_COUNTS;
+    const int64_t* incl = incounts ? a.c_incl : a.w_incl;
+    int g = 0;
+    while (g < a.G - 1 && incl[g] <= v) ++g;
+    t_local = (v - (g ? incl[g - 1] : 0)) | (t & SPACE_COUNTS);
+    return g;
+}
+__global__ __launch_bounds__(BLOCK) void k_route_count(RouteArgs a)
+{
+    __shared__ int s_cnt[MAX_SHARDS];
+    if (threadIdx.x < MAX_SHARDS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (j < a.n) { int64_t tl; atomicAdd(&s_cnt[route_owner(a, a.T[j], tl)], 1); }
+    __syncthreads();
+    if (threadIdx.x < MAX_SHARDS) a.block_counts[(int64_t)blockIdx.x * MAX_SHARDS + threadIdx.x] = s_cnt[threadIdx.x];
+}
+// one workgroup: exclusive offsets in (owner-major, block-minor) order, in place; totals per owner
+__global__ __launch_bounds__(BLOCK) void k_route_scan(int32_t* block_counts, int64_t nblocks, int G, int64_t* counts)
+{
+    __shared__ int64_t s_part[BLOCK];
+    __shared__ int64_t s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+        // chunked scan over the blocks of owner g
+        for (int64_t c0 = 0; c0 < nblocks; c0 += BLOCK) {
+            const int64_t b = c0 + threadIdx.x;
+            const int64_t v = b < nblocks ? block_counts[b * MAX_SHARDS + g] : 0;
+            s_part[threadIdx.x] = v;
+            __syncthreads();
+            for (int d = 1; d < BLOCK; d <<= 1) {                 // Hillis-Steele inclusive scan in LDS
+                const int64_t add = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+                __syncthreads();
+                s_part[threadIdx.x] += add;
+                __syncthreads();
+            }
+            const int64_t excl = s_base + s_part[threadIdx.x] - v;
+            if (b < nblocks) block_counts[b * MAX_SHARDS + g] = (int32_t)excl;
+            __syncthreads();
+            if (threadIdx.x == BLOCK - 1) s_base += s_part[BLOCK - 1];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) counts[g] = s_base - (g ? 0 : 0);
+        __syncthreads();
+    }
+    // counts[g] currently holds the inclusive total through owner g: make them per-owner counts
+    if (threadIdx.x == 0) { for (int g = G - 1; g > 0; --g) counts[g] -= counts[g - 1]; }
+}
+__global__ __launch_bounds__(BLOCK) void k_route_scatter(RouteArgs a)
+{
+    __shared__ int s_wave[NWAVES][MAX_SHARDS];
+    const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = j < a.n;
+    int64_t tl = 0;
+    const int g = active ? route_owner(a, a.T[j], tl) : -1;
+    const int lane = lane_id(), wv = wave_id();
+    int rank = 0;
+    for (int q = 0; q < a.G; ++q) {                               // rank among the wave's lanes with the same owner
+        const unsigned long long m = __ballot(g == q);
+        if (g == q) rank = __popcll(m & ((1ull << lane) - 1));
+        if (lane == 0) s_wave[wv][q] = __popcll(m);
+    }
+    __syncthreads();
+    if (active) {
+        int before = 0;
+        for (int w = 0; w < wv; ++w) before += s_wave[w][g];
+        const int64_t pos = (int64_t)a.block_counts[(int64_t)blockIdx.x * MAX_SHARDS + g] + before + rank;
+        a.T_sorted[pos] = tl;
+        a.perm[pos] = j;
+    }
 }
 
 } // namespace gpf

@@ -73,6 +73,7 @@ struct gpf_filter {
     std::vector<int32_t*> hist_map;      // [step] n int32 or nullptr
     int hist_step = -1;                  // index of the current step (0 = after gpf_initialize)
     const int32_t** hist_dev_maps = nullptr;
+    int32_t* route_counts = nullptr;     // shard routing scratch: [n/256][MAX_SHARDS]
     Timer timers[GPF_K_COUNT];
     std::string err;
 };
@@ -578,6 +579,9 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<0>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_serve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_serve<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_serve<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return GPF_OK;
     };
@@ -596,7 +600,7 @@ gpf_status gpf_destroy(gpf_handle h)
     hist_clear(h);
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc};
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->route_counts};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1175,23 +1179,43 @@ gpf_status gpf_shard_targets(gpf_handle h, int32_t method, const int64_t* totals
     return GPF_OK;
 }
 
+gpf_status gpf_shard_route(gpf_handle h, const int64_t* T, const int64_t* w_incl, const int64_t* c_incl, int32_t G,
+                           int64_t* T_sorted, int64_t* perm, int64_t* counts)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!T || !w_incl || !T_sorted || !perm || !counts || G < 1 || G > MAX_SHARDS) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    const int64_t nblocks = (h->n + BLOCK - 1) / BLOCK;
+    if (!h->route_counts) HIP_TRY(h, hipMalloc(&h->route_counts, (size_t)nblocks * MAX_SHARDS * sizeof(int32_t)));
+    RouteArgs a{T, w_incl, c_incl ? c_incl : w_incl, (int)G, h->n, h->route_counts, T_sorted, perm, counts};
+    hipLaunchKernelGGL(k_route_count, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, a);
+    hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(BLOCK), 0, h->stream, h->route_counts, nblocks, (int)G, counts);
+    hipLaunchKernelGGL(k_route_scatter, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+
 gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, double* rows_out, int64_t* anc_out)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (m_req < 0 || (m_req > 0 && (!T_local || !rows_out || !anc_out))) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     if (m_req == 0) return GPF_OK;
-    const int grid = grid_for(h, m_req, 8);
     // residual: requests without the count bit are looked up in the residual-weight CDF (cdf[2])
+    const int two = h->serve_residual ? 1 : 0;
+    const int64_t nt = two ? 2 : 1;
+    const int64_t top_n = nt * h->ntiles * 8 <= LDS_TILE_TABLE ? h->ntiles * 8 : (nt * h->ntiles <= LDS_TILE_TABLE ? h->ntiles : 0);
+    const size_t lds = (size_t)(nt * (lds_pad(top_n) + 1)) * sizeof(uint64_t);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((m_req + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
     s = timed(h, GPF_K_GATHER, [&] {
         const CdfLevels lw_ = levels(h, h->serve_residual ? 2 : 0);
         const CdfLevels lc_ = levels(h, h->serve_residual ? 1 : 0);
         switch (h->W) {
-            case 2: hipLaunchKernelGGL((k_serve<2>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, lw_, lc_,
+            case 2: hipLaunchKernelGGL((k_serve<2>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
                                        h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
-            case 4: hipLaunchKernelGGL((k_serve<4>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, lw_, lc_,
+            case 4: hipLaunchKernelGGL((k_serve<4>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
                                        h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
-            case 8: hipLaunchKernelGGL((k_serve<8>), dim3(grid), dim3(BLOCK), 0, h->stream, T_local, m_req, lw_, lc_,
+            case 8: hipLaunchKernelGGL((k_serve<8>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
                                        h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
         }
     });

@@ -93,6 +93,14 @@ class HipShardBackend:
         self._ck(self.L.gpf_shard_targets(self.h, method_id, totals.data_ptr(), G, T.data_ptr()))
         return T
 
+    def route(self, T, w_incl, c_incl):
+        G = w_incl.numel()
+        Ts = torch.empty_like(T); perm = torch.empty_like(T)
+        counts = torch.empty(G, dtype=torch.int64, device=self.device)
+        self._ck(self.L.gpf_shard_route(self.h, T.data_ptr(), w_incl.data_ptr(), c_incl.data_ptr() if c_incl is not None else None,
+                                        G, Ts.data_ptr(), perm.data_ptr(), counts.data_ptr()))
+        return Ts, perm, counts
+
     def serve(self, T_local):
         m = T_local.numel()
         rows = torch.empty((m, self.W), dtype=torch.float64, device=self.device)
@@ -258,23 +266,12 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
     if G == 1:
         rows, anc = b.serve(T)                                        # local == global coordinates
     else:
-        in_counts = (T & SPACE_COUNTS) != 0
-        Tv = T & (SPACE_COUNTS - 1)
-        owner = torch.bucketize(Tv, w_incl, right=True)
-        if c_incl is not None:
-            owner = torch.where(in_counts, torch.bucketize(Tv, c_incl, right=True), owner)
-        owner = owner.clamp_(max=G - 1)
-        w_excl = w_incl - (cr[:, 1] if mid == 1 else S_all)
-        base = w_excl[owner]
-        if c_incl is not None:
-            base = torch.where(in_counts, (c_incl - cr[:, 0])[owner], base)
-        T_local = (Tv - base) | (T & SPACE_COUNTS)
-        perm = torch.argsort(owner, stable=True)                      # bucket by owner, slot order kept inside a bucket
-        send_counts = torch.bincount(owner, minlength=G)
+        # phase 3b: owner of every target, stable grouping by owner, local coordinates (one library call)
+        T_sorted, perm, send_counts = b.route(T, w_incl.contiguous(), None if c_incl is None else c_incl.contiguous())
         recv_counts = state._all_to_all(send_counts, [1] * G, [1] * G)           # C4
         both = torch.stack([send_counts, recv_counts]).tolist()                  # ONE host sync: the split sizes
         sc, rc = both[0], both[1]
-        req = state._all_to_all(T_local[perm], sc, rc)                            # requests to the owners
+        req = state._all_to_all(T_sorted, sc, rc)                                 # requests to the owners
         rows_s, anc_s = b.serve(req)                                  # phase 4
         # C5: rows and ancestor ids travel back in ONE all-to-all (the id rides as an extra Float64-typed column)
         packed = torch.cat([rows_s, anc_s.view(torch.float64).unsqueeze(1)], dim=1)

@@ -205,6 +205,11 @@ gpf_status gpf_shard_weight_max(gpf_handle h, double* out2);
 gpf_status gpf_shard_weight_scan(gpf_handle h, const double* m_flags, int64_t* out5);
 gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* S_all, int32_t G, int64_t* out2);
 gpf_status gpf_shard_targets(gpf_handle h, int32_t method, const int64_t* totals, int32_t G, int64_t* T_out);
+/* phase 3b: route the targets: owner = first shard whose inclusive total (w_incl[G]; c_incl[G] for copy-count-space
+ * targets, may be NULL) exceeds the target.  T_sorted[n] = local-coordinate targets grouped by owner (slot order kept
+ * inside a group), perm[n] = output slot of each entry, counts[G] = entries per owner.  G <= 16. */
+gpf_status gpf_shard_route(gpf_handle h, const int64_t* T, const int64_t* w_incl, const int64_t* c_incl, int32_t G,
+                           int64_t* T_sorted, int64_t* perm, int64_t* counts);
 gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, double* rows_out, int64_t* anc_out);
 gpf_status gpf_shard_commit(gpf_handle h, const double* rows, const int64_t* anc, const double* m_flags,
                             const int64_t* S_all, int32_t G);

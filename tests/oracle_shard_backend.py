@@ -74,6 +74,23 @@ class OracleShardBackend:
             T = np.where(jg < Ctot, jg | np.uint64(SPACE_COUNTS), T)
         return torch.from_numpy(T.astype(np.int64))
 
+    def route(self, T, w_incl, c_incl):
+        t = T.numpy().astype(np.uint64)
+        inc = (t & np.uint64(SPACE_COUNTS)) != 0
+        tv = (t & np.uint64(SPACE_COUNTS - 1)).astype(np.int64)
+        w = w_incl.numpy(); G = w.size
+        owner = np.minimum(np.searchsorted(w, tv, side="right"), G - 1)
+        base = np.concatenate([[0], w[:-1]])[owner]
+        if c_incl is not None:
+            c = c_incl.numpy()
+            oc = np.minimum(np.searchsorted(c, tv, side="right"), G - 1)
+            owner = np.where(inc, oc, owner)
+            base = np.where(inc, np.concatenate([[0], c[:-1]])[oc], base)
+        tl = (tv - base) | (T.numpy() & SPACE_COUNTS)
+        perm = np.argsort(owner, kind="stable")
+        return (torch.from_numpy(tl[perm].astype(np.int64)), torch.from_numpy(perm.astype(np.int64)),
+                torch.from_numpy(np.bincount(owner, minlength=G).astype(np.int64)))
+
     def serve(self, T_local):
         t = T_local.numpy().astype(np.uint64)
         inc = (t & np.uint64(SPACE_COUNTS)) != 0
