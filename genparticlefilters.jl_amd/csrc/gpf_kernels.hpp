@@ -934,9 +934,14 @@ __global__ void k_pack_mflags(const double* __restrict__ pmax, const int32_t* __
     fold_partials(pmax, pflags, np, sm, sf, m, f);
     if (threadIdx.x == 0) { out2[0] = m; out2[1] = (double)(f & (FLAG_NAN | FLAG_POSINF)); }
 }
-__global__ void k_unpack_mflags(const double* __restrict__ in2, double* pmax, int32_t* pflags)
+// the gathered (max, flags) of all G shards -> the global pair, where k_scan expects its partials
+__global__ void k_unpack_mflags(const double* __restrict__ mf_all, int G, double* pmax, int32_t* pflags)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { pmax[0] = in2[0]; pflags[0] = (int32_t)in2[1]; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double m = -__builtin_huge_val(); int f = 0;
+        for (int g = 0; g < G; ++g) { const double v = mf_all[2 * g]; m = v > m ? v : m; f |= (int)mf_all[2 * g + 1]; }
+        pmax[0] = m; pflags[0] = f;
+    }
 }
 __global__ void k_export_summary(const WSum* ws, const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5)
 {
@@ -956,13 +961,29 @@ __global__ void k_export_summary(const WSum* ws, const uint64_t* __restrict__ bl
     if (threadIdx.x == 0) out5[0] = (int64_t)ws->S;
 }
 // global S (and residual shift) into the device scalar block from the gathered shard totals
-__global__ void k_set_global(const int64_t* __restrict__ S_all, int G, int64_t n_global, WSum* ws, Scalars* sc, int64_t* out2)
+// tot_all = the gathered {S_local, Ql0..3} of all G shards -> the global S
+__global__ void k_set_global(const int64_t* __restrict__ tot_all, int G, WSum* ws)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint64_t S = 0;
-        for (int g = 0; g < G; ++g) S += (uint64_t)S_all[g];
+        for (int g = 0; g < G; ++g) S += (uint64_t)tot_all[5 * g];
         ws->S = S;
-        (void)sc; (void)n_global; (void)out2;
+    }
+}
+// totals[3G] = [S_all | C_all | R_all], inclusive offsets w_incl[G] (weight or residual-weight space), c_incl[G]
+__global__ void k_shard_offsets(const int64_t* __restrict__ tot_all, const int64_t* __restrict__ cr_all, int G, int64_t* out /*[5G]*/)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t w = 0, c = 0;
+        for (int g = 0; g < G; ++g) {
+            out[g] = tot_all[5 * g];
+            out[G + g] = cr_all ? cr_all[2 * g] : 0;
+            out[2 * G + g] = cr_all ? cr_all[2 * g + 1] : 0;
+            w += cr_all ? cr_all[2 * g + 1] : tot_all[5 * g];
+            c += cr_all ? cr_all[2 * g] : 0;
+            out[3 * G + g] = w;
+            out[4 * G + g] = c;
+        }
     }
 }
 __global__ void k_export_residual(const Scalars* sc, int64_t* out2)
@@ -1005,9 +1026,9 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_serve(const i
                                                                           CdfLevels lw_, CdfLevels lc_, int two_tables,
                                                                           int64_t n, int64_t ntiles, int64_t gid0,
                                                                           const double* __restrict__ rows,
-                                                                          double* __restrict__ rows_out, int64_t* __restrict__ anc_out)
+                                                                          double* __restrict__ packed_out)
 {
-    constexpr int C = W / 2;
+    // packed_out[r] = [row (W doubles) | global ancestor id (int64 bits)]: rows and ids travel back in one message
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchTop st = search_prologue(lw_, lc_, two_tables != 0, ntiles, reinterpret_cast<uint64_t*>(smem));
     __shared__ ulonglong2 s_coop[2 * SBLOCK];
@@ -1029,31 +1050,42 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_serve(const i
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (!act[u]) continue;
-            anc_out[r[u]] = gid0 + idx[u];
-            const double2* src = reinterpret_cast<const double2*>(rows) + idx[u] * C;
-            double2* dst = reinterpret_cast<double2*>(rows_out) + r[u] * C;
+            const double* src = rows + idx[u] * W;
+            double* dst = packed_out + r[u] * (W + 1);
 #pragma unroll
-            for (int c = 0; c < C; ++c) dst[c] = src[c];
+            for (int c = 0; c < W; ++c) dst[c] = src[c];
+            dst[W] = u2d((uint64_t)(gid0 + idx[u]));
         }
     }
 }
 
-__global__ void k_commit(const int64_t* __restrict__ anc_in, int64_t n, int32_t* __restrict__ anc, double* __restrict__ lw)
+// install the returned population: entry k of the routed order belongs to output slot perm[k]
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_commit_permuted(const double* __restrict__ packed, const int64_t* __restrict__ perm, int64_t n,
+                                                          double* __restrict__ rows_new, int32_t* __restrict__ anc, double* __restrict__ lw)
 {
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-        anc[i] = (int32_t)anc_in[i];
-        lw[i] = 0.0;                                   // update_weights!, resample.jl:195
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < n; k += (int64_t)gridDim.x * BLOCK) {
+        const int64_t j = perm[k];
+        const double* src = packed + k * (W + 1);
+        double* dst = rows_new + j * W;
+#pragma unroll
+        for (int c = 0; c < W; ++c) dst[c] = src[c];
+        anc[j] = (int32_t)d2u(src[W]);
+        lw[j] = 0.0;                                   // update_weights!, resample.jl:195
     }
 }
 // update_lml_est! from the gathered global summary: lml += (m + log(S 2^-K)) - log N
-__global__ void k_lml_global(const double* __restrict__ m_flags, const int64_t* __restrict__ S_all, int G, int K, double logN,
+__global__ void k_lml_global(const double* __restrict__ mf_all, const int64_t* __restrict__ tot_all, int G, int K, double logN,
                              Scalars* sc)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint64_t S = 0;
-        for (int g = 0; g < G; ++g) S += (uint64_t)S_all[g];
-        const double m = m_flags[0];
-        int f = (int)m_flags[1];
+        double m = -__builtin_huge_val();
+        int f = 0;
+        for (int g = 0; g < G; ++g) {
+            S += (uint64_t)tot_all[5 * g];
+            const double v = mf_all[2 * g]; m = v > m ? v : m; f |= (int)mf_all[2 * g + 1];
+        }
         if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
         sc->lml_est = sc->lml_est + (lse_from(m, S, K, f) - logN);
     }

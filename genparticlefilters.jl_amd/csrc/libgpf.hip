@@ -74,6 +74,7 @@ struct gpf_filter {
     int hist_step = -1;                  // index of the current step (0 = after gpf_initialize)
     const int32_t** hist_dev_maps = nullptr;
     int32_t* route_counts = nullptr;     // shard routing scratch: [n/256][MAX_SHARDS]
+    int64_t* route_offsets = nullptr;    // [5][MAX_SHARDS]: shard totals and inclusive offsets of the current resample
     Timer timers[GPF_K_COUNT];
     std::string err;
 };
@@ -600,7 +601,7 @@ gpf_status gpf_destroy(gpf_handle h)
     hist_clear(h);
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->route_counts};
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->route_counts, h->route_offsets};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1123,12 +1124,12 @@ gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
     return GPF_OK;
 }
 
-gpf_status gpf_shard_weight_scan(gpf_handle h, const double* m_flags, int64_t* out5)
+gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, int64_t* out5)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
-    if (!m_flags || !out5) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null pointer");
-    hipLaunchKernelGGL(k_unpack_mflags, dim3(1), dim3(64), 0, h->stream, m_flags, h->pmax, h->pflags);
+    if (!mf_all || !out5 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    hipLaunchKernelGGL(k_unpack_mflags, dim3(1), dim3(64), 0, h->stream, mf_all, (int)G, h->pmax, h->pflags);
     h->max_valid = false;
     InFixQ in{raw_view(h), nullptr, h->K, 0.0, 0};
     const int gs = scan_grid(h);
@@ -1139,13 +1140,13 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* m_flags, int64_t* o
     return GPF_OK;
 }
 
-gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* S_all, int32_t G, int64_t* out2)
+gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t G, int64_t* out2)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
-    if (!S_all || !out2 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (!tot_all || !out2 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     // global S into sc->prio (the local CDF in cdf[0] stays local)
-    hipLaunchKernelGGL(k_set_global, dim3(1), dim3(64), 0, h->stream, S_all, (int)G, h->cfg.n_global, &h->sc->prio, h->sc, out2);
+    hipLaunchKernelGGL(k_set_global, dim3(1), dim3(64), 0, h->stream, tot_all, (int)G, &h->sc->prio);
     if ((s = residual_scans(h, &h->sc->prio, h->cfg.n_global))) return s;
     hipLaunchKernelGGL(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2);
     HIP_TRY(h, hipGetLastError());
@@ -1153,41 +1154,38 @@ gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* S_all, int32_t G
     return GPF_OK;
 }
 
-gpf_status gpf_shard_targets(gpf_handle h, int32_t method, const int64_t* totals, int32_t G, int64_t* T_out)
+gpf_status gpf_shard_route(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G,
+                           int64_t* T_sorted, int64_t* perm, int64_t* counts)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
-    if (!totals || !T_out || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (method < 0 || method > 2) return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");
+    if (!tot_all || !T_sorted || !perm || !counts || G < 1 || G > MAX_SHARDS || (method == GPF_RESAMPLE_RESIDUAL && !cr_all))
+        return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    const int64_t nblocks = (h->n + BLOCK - 1) / BLOCK;
+    if (!h->route_counts) {
+        HIP_TRY(h, hipMalloc(&h->route_counts, (size_t)nblocks * MAX_SHARDS * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc(&h->route_offsets, (size_t)5 * MAX_SHARDS * sizeof(int64_t)));
+    }
+    int64_t* off = h->route_offsets;             // [S_all | C_all | R_all | w_incl | c_incl], each G long
+    hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(64), 0, h->stream, tot_all, method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr, (int)G, off);
+    int64_t* T = reinterpret_cast<int64_t*>(h->dtmp);
     const int grid = grid_for(h, h->n, 8);
     s = timed(h, GPF_K_SEARCH, [&] {
         switch (method) {
             case GPF_RESAMPLE_MULTINOMIAL:
                 hipLaunchKernelGGL((k_targets<0>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
-                                   h->cfg.n_global, totals, (int)G, T_out); break;
+                                   h->cfg.n_global, off, (int)G, T); break;
             case GPF_RESAMPLE_RESIDUAL:
                 hipLaunchKernelGGL((k_targets<1>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
-                                   h->cfg.n_global, totals, (int)G, T_out); break;
-            case GPF_RESAMPLE_STRATIFIED:
+                                   h->cfg.n_global, off, (int)G, T); break;
+            default:
                 hipLaunchKernelGGL((k_targets<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
-                                   h->cfg.n_global, totals, (int)G, T_out); break;
-            default: break;
+                                   h->cfg.n_global, off, (int)G, T); break;
         }
     });
     if (s) return s;
-    if (method < 0 || method > 2) return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");
-    HIP_TRY(h, hipGetLastError());
-    return GPF_OK;
-}
-
-gpf_status gpf_shard_route(gpf_handle h, const int64_t* T, const int64_t* w_incl, const int64_t* c_incl, int32_t G,
-                           int64_t* T_sorted, int64_t* perm, int64_t* counts)
-{
-    gpf_status s = shard_ready(h);
-    if (s) return s;
-    if (!T || !w_incl || !T_sorted || !perm || !counts || G < 1 || G > MAX_SHARDS) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
-    const int64_t nblocks = (h->n + BLOCK - 1) / BLOCK;
-    if (!h->route_counts) HIP_TRY(h, hipMalloc(&h->route_counts, (size_t)nblocks * MAX_SHARDS * sizeof(int32_t)));
-    RouteArgs a{T, w_incl, c_incl ? c_incl : w_incl, (int)G, h->n, h->route_counts, T_sorted, perm, counts};
+    RouteArgs a{T, off + 3 * G, off + 4 * G, (int)G, h->n, h->route_counts, T_sorted, perm, counts};
     hipLaunchKernelGGL(k_route_count, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, a);
     hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(BLOCK), 0, h->stream, h->route_counts, nblocks, (int)G, counts);
     hipLaunchKernelGGL(k_route_scatter, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, a);
@@ -1195,11 +1193,11 @@ gpf_status gpf_shard_route(gpf_handle h, const int64_t* T, const int64_t* w_incl
     return GPF_OK;
 }
 
-gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, double* rows_out, int64_t* anc_out)
+gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, double* packed_out)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
-    if (m_req < 0 || (m_req > 0 && (!T_local || !rows_out || !anc_out))) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (m_req < 0 || (m_req > 0 && (!T_local || !packed_out))) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     if (m_req == 0) return GPF_OK;
     // residual: requests without the count bit are looked up in the residual-weight CDF (cdf[2])
     const int two = h->serve_residual ? 1 : 0;
@@ -1212,11 +1210,11 @@ gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, 
         const CdfLevels lc_ = levels(h, h->serve_residual ? 1 : 0);
         switch (h->W) {
             case 2: hipLaunchKernelGGL((k_serve<2>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
-                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
+                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], packed_out); break;
             case 4: hipLaunchKernelGGL((k_serve<4>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
-                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
+                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], packed_out); break;
             case 8: hipLaunchKernelGGL((k_serve<8>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
-                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], rows_out, anc_out); break;
+                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], packed_out); break;
         }
     });
     if (s) return s;
@@ -1224,14 +1222,19 @@ gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, 
     return GPF_OK;
 }
 
-gpf_status gpf_shard_commit(gpf_handle h, const double* rows, const int64_t* anc, const double* m_flags, const int64_t* S_all, int32_t G)
+gpf_status gpf_shard_commit(gpf_handle h, const double* packed, const int64_t* perm, const double* mf_all, const int64_t* tot_all, int32_t G)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
-    if (!rows || !anc || !m_flags || !S_all || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
-    HIP_TRY(h, hipMemcpyAsync(h->rows[1 - h->cur], rows, (size_t)h->n * h->W * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    hipLaunchKernelGGL(k_commit, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, anc, h->n, h->anc, h->lw);
-    hipLaunchKernelGGL(k_lml_global, dim3(1), dim3(64), 0, h->stream, m_flags, S_all, (int)G, h->K, h->logN, h->sc);
+    if (!packed || !perm || !mf_all || !tot_all || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    const int grid = grid_for(h, h->n, 8);
+    double* out = h->rows[1 - h->cur];
+    switch (h->W) {
+        case 2: hipLaunchKernelGGL((k_commit_permuted<2>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
+        case 4: hipLaunchKernelGGL((k_commit_permuted<4>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
+        case 8: hipLaunchKernelGGL((k_commit_permuted<8>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
+    }
+    hipLaunchKernelGGL(k_lml_global, dim3(1), dim3(64), 0, h->stream, mf_all, tot_all, (int)G, h->K, h->logN, h->sc);
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;
     h->epoch += 1;

@@ -78,42 +78,36 @@ class HipShardBackend:
         self._ck(self.L.gpf_shard_weight_max(self.h, out.data_ptr()))
         return out
 
-    def weight_scan(self, m_flags):
+    def weight_scan(self, mf_all):
         out = torch.empty(5, dtype=torch.int64, device=self.device)
-        self._ck(self.L.gpf_shard_weight_scan(self.h, m_flags.data_ptr(), out.data_ptr()))
+        self._ck(self.L.gpf_shard_weight_scan(self.h, mf_all.data_ptr(), mf_all.shape[0], out.data_ptr()))
         return out
 
-    def residual_scan(self, S_all):
+    def residual_scan(self, tot_all):
         out = torch.empty(2, dtype=torch.int64, device=self.device)
-        self._ck(self.L.gpf_shard_residual_scan(self.h, S_all.data_ptr(), S_all.numel(), out.data_ptr()))
+        self._ck(self.L.gpf_shard_residual_scan(self.h, tot_all.data_ptr(), tot_all.shape[0], out.data_ptr()))
         return out
 
-    def targets(self, method_id, totals, G):
-        T = torch.empty(self.n, dtype=torch.int64, device=self.device)
-        self._ck(self.L.gpf_shard_targets(self.h, method_id, totals.data_ptr(), G, T.data_ptr()))
-        return T
-
-    def route(self, T, w_incl, c_incl):
-        G = w_incl.numel()
-        Ts = torch.empty_like(T); perm = torch.empty_like(T)
+    def route(self, method_id, tot_all, cr_all):
+        G = tot_all.shape[0]
+        Ts = torch.empty(self.n, dtype=torch.int64, device=self.device)
+        perm = torch.empty(self.n, dtype=torch.int64, device=self.device)
         counts = torch.empty(G, dtype=torch.int64, device=self.device)
-        self._ck(self.L.gpf_shard_route(self.h, T.data_ptr(), w_incl.data_ptr(), c_incl.data_ptr() if c_incl is not None else None,
-                                        G, Ts.data_ptr(), perm.data_ptr(), counts.data_ptr()))
+        self._ck(self.L.gpf_shard_route(self.h, method_id, tot_all.data_ptr(), cr_all.data_ptr() if cr_all is not None else None, G,
+                                        Ts.data_ptr(), perm.data_ptr(), counts.data_ptr()))
         return Ts, perm, counts
 
     def serve(self, T_local):
         m = T_local.numel()
-        rows = torch.empty((m, self.W), dtype=torch.float64, device=self.device)
-        anc = torch.empty(m, dtype=torch.int64, device=self.device)
+        packed = torch.empty((m, self.W + 1), dtype=torch.float64, device=self.device)
         if m:
-            self._ck(self.L.gpf_shard_serve(self.h, T_local.data_ptr(), m, rows.data_ptr(), anc.data_ptr()))
-        return rows, anc
+            self._ck(self.L.gpf_shard_serve(self.h, T_local.data_ptr(), m, packed.data_ptr()))
+        return packed
 
-    def commit(self, rows, anc, m_flags, S_all):
-        rows, anc = rows.contiguous(), anc.contiguous()
-        self._ck(self.L.gpf_shard_commit(self.h, rows.data_ptr(), anc.data_ptr(), m_flags.data_ptr(), S_all.data_ptr(),
-                                         S_all.numel()))
-        self._keep = (rows, anc)            # alive until the stream has consumed them
+    def commit(self, packed, perm, mf_all, tot_all):
+        packed = packed.contiguous()
+        self._ck(self.L.gpf_shard_commit(self.h, packed.data_ptr(), perm.data_ptr(), mf_all.data_ptr(), tot_all.data_ptr(), tot_all.shape[0]))
+        self._keep = (packed, perm, mf_all, tot_all)      # alive until the stream has consumed them
 
     def lml_est(self) -> float:
         out = C.c_double()
@@ -183,26 +177,20 @@ class ShardedParticleFilterState:
     # ---- global weight summary: phases 1 + 2
     def _summary(self):
         b = self.backend
-        mf = self._all_gather(b.weight_max())                       # (G, 2)
-        m_flags = torch.stack([mf[:, 0].max(), _or_flags(mf[:, 1])])
-        tot = self._all_gather(b.weight_scan(m_flags))               # (G, 5): S_r, Ql0..3
-        return m_flags, tot
+        mf_all = self._all_gather(b.weight_max()).contiguous()           # (G, 2): max, flags & (NaN | +Inf)
+        tot_all = self._all_gather(b.weight_scan(mf_all)).contiguous()    # (G, 5): S_r, Ql0..3
+        return mf_all, tot_all
 
     def _summary_scalars(self):
-        m_flags, tot = self._summary()
-        mf = m_flags.cpu().numpy()
-        t = tot.cpu().numpy().astype(object)
+        mf_all, tot_all = self._summary()
+        mf = mf_all.cpu().numpy()
+        t = tot_all.cpu().numpy().astype(object)
+        flags = 0
+        for f in mf[:, 1]:
+            flags |= int(f)
         S = int(sum(int(x) for x in t[:, 0]))
         Q = sum(int(sum(int(x) for x in t[:, 1 + k])) << (32 * k) for k in range(4))
-        return float(mf[0]), int(mf[1]), S, Q
-
-
-def _or_flags(f: torch.Tensor) -> torch.Tensor:
-    v = f.to(torch.int64)
-    out = torch.zeros((), dtype=torch.int64, device=f.device)
-    for bit in (1, 2):
-        out = out | (((v & bit) != 0).any().to(torch.int64) * bit)
-    return out.to(torch.float64)
+        return float(mf[:, 0].max()), flags, S, Q
 
 
 # ----------------------------------------------------------------------------- public API (sharded twins)
@@ -243,45 +231,30 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
     if method == "stratified" and sort_particles:
         raise ErrorException("sharded stratified resampling needs sort_particles=False (no global sort; SURVEY.md H8)")
     b, G, mid = state.backend, state.world, RESAMPLE_METHODS[method]
-    m_flags, tot = state._summary()                                   # phases 1, 2
-    S_all = tot[:, 0].contiguous()
+    mf_all, tot_all = state._summary()                                # phases 1, 2
     if check is not False:                                            # safe_softmax validity (utils.jl:117-140): host sync
-        mf = m_flags.cpu().numpy()
-        invalid = bool(int(mf[1]) != 0 or mf[0] == -np.inf)
-        if int(mf[1]) != 0 or (check is True and invalid):
+        mf = mf_all.cpu().numpy()
+        flags = 0
+        for f in mf[:, 1]:
+            flags |= int(f)
+        invalid = bool(flags != 0 or mf[:, 0].max() == -np.inf)
+        if flags != 0 or (check is True and invalid):
             raise ErrorException("Invalid weights.")                  # resample.jl:55
         if invalid:
             import warnings
             warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")
-    if mid == 1:                                                      # residual: phase 2b
-        cr = state._all_gather(b.residual_scan(S_all))                # (G, 2): Ctot_r, Rs_r
-        totals = torch.cat([S_all, cr[:, 0], cr[:, 1]]).contiguous()
-        w_incl = torch.cumsum(cr[:, 1], 0)                            # residual-weight space
-        c_incl = torch.cumsum(cr[:, 0], 0)                            # copy-count space
-    else:
-        totals = S_all
-        w_incl = torch.cumsum(S_all, 0)
-        c_incl = None
-    T = b.targets(mid, totals, G)                                     # phase 3: global targets of own slots
+    cr_all = state._all_gather(b.residual_scan(tot_all)).contiguous() if mid == 1 else None     # phase 2b: (G, 2)
+    T_sorted, perm, send_counts = b.route(mid, tot_all, cr_all)       # phase 3: targets, owners, stable grouping
     if G == 1:
-        rows, anc = b.serve(T)                                        # local == global coordinates
+        back = b.serve(T_sorted)                                      # local == global coordinates
     else:
-        # phase 3b: owner of every target, stable grouping by owner, local coordinates (one library call)
-        T_sorted, perm, send_counts = b.route(T, w_incl.contiguous(), None if c_incl is None else c_incl.contiguous())
         recv_counts = state._all_to_all(send_counts, [1] * G, [1] * G)           # C4
         both = torch.stack([send_counts, recv_counts]).tolist()                  # ONE host sync: the split sizes
         sc, rc = both[0], both[1]
         req = state._all_to_all(T_sorted, sc, rc)                                 # requests to the owners
-        rows_s, anc_s = b.serve(req)                                  # phase 4
-        # C5: rows and ancestor ids travel back in ONE all-to-all (the id rides as an extra Float64-typed column)
-        packed = torch.cat([rows_s, anc_s.view(torch.float64).unsqueeze(1)], dim=1)
-        back = state._all_to_all(packed, rc, sc)
-        W = rows_s.shape[1]
-        rows = torch.empty((T.numel(), W), dtype=torch.float64, device=back.device)
-        rows[perm] = back[:, :W]                                      # un-permute into slot order
-        anc = torch.empty(T.numel(), dtype=torch.int64, device=back.device)
-        anc[perm] = back[:, W].contiguous().view(torch.int64)
-    b.commit(rows, anc, m_flags, S_all)                               # phase 5
+        packed = b.serve(req)                                         # phase 4: rows + ancestor ids of the requests
+        back = state._all_to_all(packed, rc, sc)                      # C5: back to the requesters, routed order
+    b.commit(back, perm, mf_all, tot_all)                             # phase 5: scatter by perm, weights, log-ML
     return state
 
 

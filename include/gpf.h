@@ -190,29 +190,30 @@ gpf_status gpf_history_var(gpf_handle h, int32_t step, int32_t column, double* o
  * sort_particles = false (a global sort is out of scope).
  *
  *   phase 1  gpf_shard_weight_max     out2 = {local max, local flags & (NaN|+Inf)} as two doubles
- *            host: all-gather, m = max, flags = OR
- *   phase 2  gpf_shard_weight_scan    in: global {m, flags}; local fixed-point CDF; out5 = {S_local, Ql0..3}
- *            host: all-gather S_local (and Ql for the ESS)
- *   phase 2b gpf_shard_residual_scan  (residual only) in: S_all[G]; out2 = {Ctot_local, Rs_local}
- *            host: all-gather
- *   phase 3  gpf_shard_targets        in: totals = [S_all | C_all | R_all]; T_out[n] = global targets of own slots
- *            host: owner = searchsorted(inclusive offsets, T); all-to-all the local-coordinate targets
- *   phase 4  gpf_shard_serve          ancestor lookup + row gather for the requests this shard owns
- *            host: all-to-all rows and ancestors back, un-permute
- *   phase 5  gpf_shard_commit         install rows / parents, log-weights = 0, log-ML estimate += lse - log N
+ *            host: all-gather -> mf_all[G][2]
+ *   phase 2  gpf_shard_weight_scan    in: mf_all (combined in the kernel); local fixed-point CDF; out5 = {S_local, Ql0..3}
+ *            host: all-gather -> tot_all[G][5]
+ *   phase 2b gpf_shard_residual_scan  (residual only) in: tot_all; out2 = {Ctot_local, Rs_local}
+ *            host: all-gather -> cr_all[G][2]
+ *   phase 3  gpf_shard_route          global targets of this shard's slots, owner = first shard whose inclusive total
+ *                                     exceeds the target, stable grouping by owner, local coordinates:
+ *                                     T_sorted[n], perm[n] (output slot of each entry), counts[G] (entries per owner)
+ *            host: all-to-all counts, then all-to-all of T_sorted with those split sizes
+ *   phase 4  gpf_shard_serve          ancestor lookup + row gather for the m_req requests this shard owns;
+ *                                     packed_out[m_req][W+1] = row | global ancestor id (int64 bits)
+ *            host: all-to-all packed rows back (reverse split sizes)
+ *   phase 5  gpf_shard_commit         scatter by perm into the new population, parents, log-weights = 0,
+ *                                     log-ML estimate += logsumexp - log N (from mf_all, tot_all)
+ * G <= 16.
  */
 gpf_status gpf_shard_weight_max(gpf_handle h, double* out2);
-gpf_status gpf_shard_weight_scan(gpf_handle h, const double* m_flags, int64_t* out5);
-gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* S_all, int32_t G, int64_t* out2);
-gpf_status gpf_shard_targets(gpf_handle h, int32_t method, const int64_t* totals, int32_t G, int64_t* T_out);
-/* phase 3b: route the targets: owner = first shard whose inclusive total (w_incl[G]; c_incl[G] for copy-count-space
- * targets, may be NULL) exceeds the target.  T_sorted[n] = local-coordinate targets grouped by owner (slot order kept
- * inside a group), perm[n] = output slot of each entry, counts[G] = entries per owner.  G <= 16. */
-gpf_status gpf_shard_route(gpf_handle h, const int64_t* T, const int64_t* w_incl, const int64_t* c_incl, int32_t G,
+gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, int64_t* out5);
+gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t G, int64_t* out2);
+gpf_status gpf_shard_route(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G,
                            int64_t* T_sorted, int64_t* perm, int64_t* counts);
-gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, double* rows_out, int64_t* anc_out);
-gpf_status gpf_shard_commit(gpf_handle h, const double* rows, const int64_t* anc, const double* m_flags,
-                            const int64_t* S_all, int32_t G);
+gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, double* packed_out);
+gpf_status gpf_shard_commit(gpf_handle h, const double* packed, const int64_t* perm, const double* mf_all,
+                            const int64_t* tot_all, int32_t G);
 /* running log_ml_est of this shard (identical on all shards) */
 gpf_status gpf_shard_lml_est(gpf_handle h, double* out);
 

@@ -37,21 +37,29 @@ class OracleShardBackend:
                       method_id, self.rows, new, self.lw)
         self.rows = new; self.epoch += 1
 
-    # shard phases
+    # shard phases (same signatures and tensor shapes as HipShardBackend)
     def weight_max(self):
         m, f = o.max_flags(self.lw)
         return torch.tensor([m, float(f & 3)], dtype=torch.float64)
 
-    def weight_scan(self, m_flags):
-        m, f = float(m_flags[0]), int(m_flags[1])
+    @staticmethod
+    def _combine(mf_all):
+        mf = mf_all.numpy()
+        flags = 0
+        for f in mf[:, 1]:
+            flags |= int(f)
+        return float(mf[:, 0].max()), flags
+
+    def weight_scan(self, mf_all):
+        m, f = self._combine(mf_all)
         uniform = (m == -np.inf) and not (f & 1)
         self.q = np.zeros(self.n, np.uint64) if f & 3 else o.fixq(self.lw, m, self.K, uniform)
         self.cdf, S, hi, lo = o.scan(self.q)
         Q = (hi << 64) | lo
         return torch.tensor([S] + [(Q >> (32 * k)) & 0xFFFFFFFF for k in range(4)], dtype=torch.int64)
 
-    def residual_scan(self, S_all):
-        S = int(S_all.sum())
+    def residual_scan(self, tot_all):
+        S = int(tot_all[:, 0].sum())
         sh = self.L.o_residual_shift(S, self.N)
         c = np.empty(self.n, np.uint64); r = np.empty(self.n, np.uint64)
         self.L.o_residual_split(self.q, self.n, self.N, S, sh, c, r)
@@ -60,33 +68,30 @@ class OracleShardBackend:
         self.serve_residual = True
         return torch.tensor([int(self.ccdf[-1]) if self.n else 0, Rs], dtype=torch.int64)
 
-    def targets(self, method_id, totals, G):
-        t = totals.numpy()
-        S = int(t[:G].sum())
+    def route(self, method_id, tot_all, cr_all):
+        t = tot_all.numpy(); G = t.shape[0]
+        S = int(t[:, 0].sum())
         if method_id == 0:
-            T = o.targets_multinomial(self.seed, self.epoch, self.gid0, self.n, S)
+            T = o.targets_multinomial(self.seed, self.epoch, self.gid0, self.n, S).astype(np.int64)
         elif method_id == 2:
-            T = o.targets_stratified(self.seed, self.epoch, self.gid0, self.n, self.N, S)
+            T = o.targets_stratified(self.seed, self.epoch, self.gid0, self.n, self.N, S).astype(np.int64)
         else:
-            Ctot, Rs = int(t[G:2 * G].sum()), int(t[2 * G:3 * G].sum())
-            T = o.targets_multinomial(self.seed, self.epoch, self.gid0, self.n, Rs)
-            jg = np.arange(self.gid0, self.gid0 + self.n, dtype=np.uint64)
-            T = np.where(jg < Ctot, jg | np.uint64(SPACE_COUNTS), T)
-        return torch.from_numpy(T.astype(np.int64))
-
-    def route(self, T, w_incl, c_incl):
-        t = T.numpy().astype(np.uint64)
-        inc = (t & np.uint64(SPACE_COUNTS)) != 0
-        tv = (t & np.uint64(SPACE_COUNTS - 1)).astype(np.int64)
-        w = w_incl.numpy(); G = w.size
+            cr = cr_all.numpy()
+            Ctot, Rs = int(cr[:, 0].sum()), int(cr[:, 1].sum())
+            T = o.targets_multinomial(self.seed, self.epoch, self.gid0, self.n, Rs).astype(np.int64)
+            jg = np.arange(self.gid0, self.gid0 + self.n, dtype=np.int64)
+            T = np.where(jg < Ctot, jg | SPACE_COUNTS, T)
+        inc = (T & SPACE_COUNTS) != 0
+        tv = T & (SPACE_COUNTS - 1)
+        w = np.cumsum(cr_all.numpy()[:, 1] if method_id == 1 else t[:, 0])
         owner = np.minimum(np.searchsorted(w, tv, side="right"), G - 1)
         base = np.concatenate([[0], w[:-1]])[owner]
-        if c_incl is not None:
-            c = c_incl.numpy()
+        if method_id == 1:
+            c = np.cumsum(cr_all.numpy()[:, 0])
             oc = np.minimum(np.searchsorted(c, tv, side="right"), G - 1)
             owner = np.where(inc, oc, owner)
             base = np.where(inc, np.concatenate([[0], c[:-1]])[oc], base)
-        tl = (tv - base) | (T.numpy() & SPACE_COUNTS)
+        tl = (tv - base) | (T & SPACE_COUNTS)
         perm = np.argsort(owner, kind="stable")
         return (torch.from_numpy(tl[perm].astype(np.int64)), torch.from_numpy(perm.astype(np.int64)),
                 torch.from_numpy(np.bincount(owner, minlength=G).astype(np.int64)))
@@ -102,16 +107,19 @@ class OracleShardBackend:
         if inc.any():
             a[inc] = o.upper_bound(self.ccdf, np.ascontiguousarray(tv[inc]))
         rows = o.gather_rows(self.rows, a) if t.size else np.zeros((0, self.W))
-        return torch.from_numpy(rows), torch.from_numpy(a + self.gid0)
+        packed = np.concatenate([rows, (a + self.gid0).view(np.float64).reshape(-1, 1)], axis=1)
+        return torch.from_numpy(np.ascontiguousarray(packed))
 
-    def commit(self, rows, anc, m_flags, S_all):
-        self.rows = np.ascontiguousarray(rows.numpy()).copy()
-        self.parents = anc.numpy() + 1
-        self.lw = np.zeros(self.n)
-        m, f = float(m_flags[0]), int(m_flags[1])
+    def commit(self, packed, perm, mf_all, tot_all):
+        pk = np.ascontiguousarray(packed.numpy()); pm = perm.numpy()
+        rows = np.empty((self.n, self.W)); anc = np.empty(self.n, np.int64)
+        rows[pm] = pk[:, :self.W]
+        anc[pm] = np.ascontiguousarray(pk[:, self.W]).view(np.int64)
+        self.rows, self.parents, self.lw = rows, anc + 1, np.zeros(self.n)
+        m, f = self._combine(mf_all)
         if m == -np.inf and not (f & 1):
             f |= 4
-        self.lml = self.lml + (self.L.o_lse_from(m, int(S_all.sum()), self.K, f) - o.olog(float(self.N)))
+        self.lml = self.lml + (self.L.o_lse_from(m, int(tot_all[:, 0].sum()), self.K, f) - o.olog(float(self.N)))
         self.epoch += 1
         self.serve_residual = False
 
