@@ -8,17 +8,20 @@ spec as the single-GPU path (src/resample.jl:48-120,143-175) over a global weigh
     phase 1   local max / flags                      -> all-gather (2 doubles per rank)
     phase 2   local fixed-point scan under the GLOBAL max -> all-gather of the shard totals
     (2b)      residual: copy-count and residual-weight scans -> all-gather of their totals
-    phase 3   every output slot draws its target in global coordinates; owner = searchsorted(offsets)
-              -> all-to-all of the counts, then of the local-coordinate targets
+    phase 3   every output slot draws its target in global coordinates, owner = first shard whose inclusive
+              total exceeds it, requests grouped by owner (stable) in the owner's local coordinates
+              -> all-to-all of the counts (one host sync for the split sizes), all-to-all of the requests
     phase 4   owners look the ancestors up in their local CDF and gather the rows
-              -> all-to-all of rows + ancestor ids back
-    phase 5   un-permute, install, log-weights = 0, log-ML estimate += logsumexp - log N
+              -> ONE all-to-all of [row | ancestor id] back
+    phase 5   scatter into slot order, log-weights = 0, log-ML estimate += logsumexp - log N
+
+Every phase is one C-ABI call (gpf_shard_*) and at most one collective; the host only moves buffers.
 
 Because weights are exact integers and RNG counters are keyed by GLOBAL slot id, the ancestors are
 bit-identical to the single-GPU run for any number of shards.
 
-The routing (bucket by owner, permutations, split sizes) is plain torch tensor code and is the same
-on CPU and GPU; the arithmetic lives behind a small backend interface: `HipShardBackend` (the
+The collectives and their split sizes are plain torch.distributed code, the same on CPU and GPU; the
+arithmetic and the routing live behind a small backend interface: `HipShardBackend` (the
 product: libgpf_hip.so through the C ABI) -- the tests inject a CPU backend built on the oracle to
 exercise the collectives with gloo.  Restrictions: priority_fn = nothing, sort_particles = false.
 """
