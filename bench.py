@@ -59,13 +59,20 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # functional check of the multi-rank code path on a 1-GPU box: every rank on cuda:0, collectives staged through gloo
+    one_device = os.environ.get("GPF_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     force_sharded = os.environ.get("GPF_BENCH_FORCE_SHARDED") == "1"       # exercise the sharded path at world 1
     if world > 1 or force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     model = g.models.lgssm2()
     K, Wm = args.steps, args.warmup
@@ -105,7 +112,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     value = n_global * K / elapsed
