@@ -176,7 +176,7 @@ def main():
                             "frac": round(gbytes / us / 1e3 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": gbytes}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 / N=1 only ----
-    cpu = None
+    cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as o          # cpu_baseline leg: the only place bench.py touches oracle/
         o.lib()
@@ -190,6 +190,18 @@ def main():
         cpu = {"value": round(n_cpu * k_cpu / ce, 1), "unit": "particle-steps/sec", "cores": 1, "kind": "port",
                "sample": f"same workload, N={n_cpu}, first {k_cpu} steps, single-thread C oracle ({ce:.1f} s); "
                          "reference (Julia) not runnable on this box"}
+        # the same sample on all host cores (OpenMP over particles; the prefix sum stays sequential)
+        ncores = os.cpu_count() or 1
+        used = o.set_threads(ncores)
+        orc = o.OracleFilter(model.model_id, model.params, n_cpu, SEED).initialize(ys[0])
+        c0 = time.perf_counter()
+        for s in range(1, k_cpu + 1):
+            orc.resample("multinomial", check=False)
+            orc.update(ys[s])
+        ce = time.perf_counter() - c0
+        o.set_threads(1)
+        cpu_all = {"value": round(n_cpu * k_cpu / ce, 1), "unit": "particle-steps/sec", "cores": used, "kind": "port",
+                   "sample": f"same sample, OpenMP over particles on {used} threads ({ce:.1f} s)"}
 
     if rank == 0:
         out = {
@@ -201,7 +213,7 @@ def main():
                        "particles_per_gpu": n_local, "particles_total": n_global, "T": K,
                        "state_dim": model.dim, "parallelism": f"particle-shard x{world}"},
             "log_ml_estimate": lml,
-            "roofline": roofline, "cpu_baseline": cpu, "resample_gather_kernel": gather,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "resample_gather_kernel": gather,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -28,11 +28,26 @@
  */
 #include "gpf_oracle_math.h"
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define O_EXPORT __attribute__((visibility("default")))
 
 enum { O_MODEL_LGSSM2 = 1, O_MODEL_BEARINGS4 = 2, O_MODEL_SV1 = 3, O_MODEL_OBJECT_MOTION = 4 };
 enum { O_FLAG_NAN = 1, O_FLAG_POSINF = 2, O_FLAG_ALL_NEGINF = 4 };
+
+/* Threads for the per-particle loops (counter-based RNG: results do not depend on the thread count).
+ * 1 = the reference's execution model (single-threaded Julia); >1 only for the "all host cores" CPU baseline. */
+O_EXPORT int o_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------ scalar helpers (exported) */
 O_EXPORT double o_log_d(double x) { return o_log(x); }
@@ -200,6 +215,7 @@ O_EXPORT void o_init(int model, const double *P, uint64_t seed, uint32_t epoch, 
                      int W, const double *obs, double *rows, double *lw)
 {
     int d = model_dim(model);
+    #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double *r = rows + i * W;
         for (int k = 0; k < W; ++k) r[k] = 0.0;
@@ -216,6 +232,7 @@ O_EXPORT void o_step(int model, const double *P, uint64_t seed, uint32_t epoch, 
                      double *lw)
 {
     int d = model_dim(model);
+    #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         const double *ri = rows_in + i * W;
         double *ro = rows_out + i * W;
@@ -243,6 +260,7 @@ O_EXPORT uint64_t o_move(int model, const double *P, uint64_t seed, uint32_t epo
 {
     int d = model_dim(model), nb = model_nblk(model);
     uint64_t nacc = 0;
+    #pragma omp parallel for schedule(static) reduction(+:nacc)
     for (int64_t i = 0; i < n; ++i) {
         const double *ri = rows_in + i * W;
         double *ro = rows_out + i * W;
@@ -304,6 +322,7 @@ O_EXPORT void o_max_flags(const double *lp, int64_t n, double *m_out, int *flags
  * invalid-but-continuable (utils.jl:123-126,130-133) */
 O_EXPORT void o_fixq(const double *lp, int64_t n, double m, int K, int uniform, uint64_t *q)
 {
+    #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) q[i] = uniform ? 1u : o_exp_fix(lp[i] - m, K);
 }
 
@@ -324,6 +343,7 @@ O_EXPORT uint64_t o_scan(const uint64_t *q, int64_t n, uint64_t *cdf, uint64_t *
 O_EXPORT void o_targets_multinomial(uint64_t seed, uint32_t epoch, int64_t j0, int64_t n, uint64_t S,
                                     uint64_t *T)
 {
+    #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < n; ++j) {
         o_philox_t b = o_rng(seed, (uint32_t)(j0 + j), 0, epoch, O_TAG_RESAMPLE);
         T[j] = o_mulhi64(o_u64(b.v[0], b.v[1]), S);
@@ -336,6 +356,7 @@ O_EXPORT void o_targets_stratified(uint64_t seed, uint32_t epoch, int64_t j0, in
                                    uint64_t S, uint64_t *T)
 {
     uint64_t B = S / (uint64_t)N, rem = S % (uint64_t)N;
+    #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < n; ++j) {
         uint64_t jg = (uint64_t)(j0 + j);
         uint64_t L0 = jg * B + (jg * rem) / (uint64_t)N;
@@ -347,6 +368,7 @@ O_EXPORT void o_targets_stratified(uint64_t seed, uint32_t epoch, int64_t j0, in
 /* first index a with cdf[a] > T  (== the while loop of resample.jl:163-166 / inverse-CDF categorical) */
 O_EXPORT void o_upper_bound(const uint64_t *cdf, int64_t n, const uint64_t *T, int64_t m, int64_t *idx)
 {
+    #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < m; ++j) {
         int64_t lo = 0, hi = n;
         uint64_t t = T[j];
@@ -368,6 +390,7 @@ O_EXPORT int o_residual_shift(uint64_t S, int64_t N)
 O_EXPORT void o_residual_split(const uint64_t *q, int64_t n, int64_t N, uint64_t S, int sh,
                                uint64_t *c, uint64_t *r)
 {
+    #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         uint64_t nq = (uint64_t)N * q[i];
         c[i] = nq / S;
@@ -378,6 +401,7 @@ O_EXPORT void o_residual_split(const uint64_t *q, int64_t n, int64_t N, uint64_t
 /* ------------------------------------------------------------------ gather, sort, statistics */
 O_EXPORT void o_gather_rows(const double *rows, int W, const int64_t *idx, int64_t n, double *out)
 {
+    #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < n; ++j)
         for (int k = 0; k < W; ++k) out[j * W + k] = rows[idx[j] * W + k];
 }

@@ -76,6 +76,7 @@ def lib():
     sig("o_argsort_desc", None, _f64p, i64, _i64p)
     sig("o_wsum", f64, _u64p, u64, _f64p, i32, i32, i64, i32, f64)
     sig("o_normals", None, u64, u32, i64, _f64p)
+    sig("o_set_threads", i32, i32)
     sig("o_dereplicate_sample", None, _f64p, i64, i64, i32, i32, u64, u32, _i64p, _f64p)
     # literal Float64 restatement (ref_literal.c)
     sig("lit_logsumexp", f64, _f64p, i64); sig("lit_lognorm", None, _f64p, i64, _f64p)
@@ -85,8 +86,14 @@ def lib():
     sig("lit_residual", i64, _f64p, i64, _f64p, _i64p)
     sig("lit_stratified", None, _f64p, _i64p, i64, _f64p, _i64p)
     sig("lit_update_weights", None, _f64p, _f64p, _i64p, i64, _f64p)
+    L.o_set_threads(1)            # the reference is single-threaded; bench.py raises this for its all-cores leg only
     _lib = L
     return L
+
+
+def set_threads(n: int) -> int:
+    """OpenMP threads of the per-particle loops (results are independent of it); returns the count in effect"""
+    return lib().o_set_threads(int(n))
 
 
 # ----------------------------------------------------------------------------- thin primitive wrappers
