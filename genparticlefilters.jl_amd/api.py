@@ -51,6 +51,9 @@ class _NativeKernel:
         return f"<native kernel {self.name}>"
 
 
+# native proposal for the custom-proposal forms of pf_initialize / pf_update (src/initialize.jl:46-62, src/update.jl:79-96)
+locally_optimal = _NativeKernel("locally_optimal")     # exact conditional q(x_t | x_{t-1}, y_t); lgssm2 only
+
 mh = _NativeKernel("mh")                        # Gen.mh(trace, select(current step latent))
 move_reweight = _NativeKernel("move_reweight")  # move_reweight(trace, selection), src/rejuvenate.jl:125-132
 
@@ -178,21 +181,40 @@ def _obs_vector(observations) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------- the four operations
-def pf_initialize(model: NativeModel, model_args: tuple, observations, n_particles: int, *, seed: int = 1,
+def pf_initialize(model: NativeModel, model_args: tuple, observations, *rest, seed: int = 1,
                   keep_prev: bool = False, device: int = 0, dynamic: bool = False, **kw) -> DeviceParticleFilterState:
     """src/initialize.jl:31-44.  `model_args` is accepted for signature parity; native models take their
     time-varying inputs through the per-step data vector `observations`. `dynamic` has no meaning for
     fixed-shape device rows and is ignored."""
+    # pf_initialize(model, args, obs, n_particles)  or  pf_initialize(model, args, obs, proposal, proposal_args, n_particles)
+    if len(rest) == 1:
+        proposal, n_particles = None, rest[0]
+    elif len(rest) == 3:
+        proposal, n_particles = rest[0], rest[2]
+        if proposal is not locally_optimal:
+            raise ErrorException("device filters support the native `locally_optimal` proposal only")
+    else:
+        raise TypeError("pf_initialize(model, model_args, observations, [proposal, proposal_args,] n_particles)")
     state = DeviceParticleFilterState(model, n_particles, seed=seed, keep_prev=keep_prev, device=device, **kw)
     obs = _obs_vector(observations)
-    state._check(state._L.gpf_initialize(state._h, _pd(obs), obs.size))
+    if proposal is None:
+        state._check(state._L.gpf_initialize(state._h, _pd(obs), obs.size))
+    else:
+        state._check(state._L.gpf_initialize_proposal(state._h, _pd(obs), obs.size, 1))
     return state
 
 
-def pf_update(state: DeviceParticleFilterState, new_args: tuple, argdiffs: tuple, observations):
-    """src/update.jl:12-25 (default proposal).  Returns `state`, like the reference (update.jl:24)."""
+def pf_update(state: DeviceParticleFilterState, new_args: tuple, argdiffs: tuple, observations,
+              proposal=None, proposal_args: tuple = ()):
+    """src/update.jl:12-25 (default proposal) and :79-96 (custom proposal: log weight = model_score_diff -
+    fwd_proposal_score, src/translate.jl:86-105).  Returns `state`, like the reference (update.jl:24)."""
     obs = _obs_vector(observations)
-    state._check(state._L.gpf_update(state._h, _pd(obs), obs.size))
+    if proposal is None:
+        state._check(state._L.gpf_update(state._h, _pd(obs), obs.size))
+    elif proposal is locally_optimal:
+        state._check(state._L.gpf_update_proposal(state._h, _pd(obs), obs.size, 1))
+    else:
+        raise ErrorException("device filters support the native `locally_optimal` proposal only")
     return state
 
 

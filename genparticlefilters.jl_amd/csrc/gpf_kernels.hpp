@@ -137,7 +137,7 @@ __device__ __forceinline__ void block_max_store(double m, int f, double* __restr
 
 // pf_initialize (initialize.jl:39-41) / pf_update! (update.jl:15-22): one lane per particle, row in,
 // row out, lw += log p(y|x).  Counter-based RNG: no RNG state in memory.
-template <int M>
+template <int M, bool PROP = false>
 __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, int W, double* __restrict__ rows,
                                                 double* __restrict__ lw, double* __restrict__ pmax,
@@ -147,12 +147,16 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
     double bm = -__builtin_huge_val(); int bf = 0;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         double x[MAX_DIM];
-        Mo::sample(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+        double ll;
+        if constexpr (PROP) ll = Mo::propose(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+        else {
+            Mo::sample(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+            ll = Mo::loglik(a.P, x, a.obs);
+        }
         double* r = rows + i * W;
 #pragma unroll
         for (int k = 0; k < Mo::D; ++k) r[k] = x[k];
         for (int k = Mo::D; k < W; ++k) r[k] = 0.0;
-        const double ll = Mo::loglik(a.P, x, a.obs);
         lw[i] = ll;
         track_max(ll, bm, bf);
     }
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
 // GATHER: the preceding pf_resample! left its ancestor vector pending; this kernel reads row anc[i]
 // instead of row i (new_traces .= view(traces, parents), resample.jl:60, fused into the propagate) and
 // the incoming log-weights are known to be 0 (update_weights!, resample.jl:195): lw = ll, no read.
-template <int M, int W, bool KEEP_PREV, bool GATHER>
+template <int M, int W, bool KEEP_PREV, bool GATHER, bool PROP = false>
 __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
@@ -183,8 +187,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
 #pragma unroll
         for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
         double xn[MAX_DIM];
-        Mo::sample(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
-        const double ll = Mo::loglik(a.P, xn, a.obs);
+        double ll;
+        if constexpr (PROP) ll = Mo::propose(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
+        else {
+            Mo::sample(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
+            ll = Mo::loglik(a.P, xn, a.obs);
+        }
         double o[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) o[k] = 0.0;

@@ -15,7 +15,7 @@ namespace gpf {
 
 enum : int { MODEL_LGSSM2 = 1, MODEL_BEARINGS4 = 2, MODEL_SV1 = 3, MODEL_OBJECT_MOTION = 4 };
 
-constexpr int MAX_PARAMS = 16;
+constexpr int MAX_PARAMS = 24;
 constexpr int MAX_OBS = 4;
 constexpr int MAX_DIM = 4;
 
@@ -27,9 +27,31 @@ struct ModelArgs {          // passed by value in the kernarg segment: no device
 template <int M> struct Model;
 
 // 2-D linear-Gaussian SSM: x' = A x + sq z, y = x + sr e   (BASELINE configs 2, 3)
-// P = [a11 a12 a21 a22 | sq | s0 | 1/sr | 2(log sr + log(2 pi)/2)]
+// P = [a11 a12 a21 a22 | sq | s0 | 1/sr | 2(log sr + log(2 pi)/2) |
+//      locally optimal proposal, transition: gain sv 1/sv 2(log sv + ..) 1/sq 2(log sq + ..) | initial: gain0 sv0 1/sv0 2(log sv0 + ..) 1/s0 2(log s0 + ..)]
 template <> struct Model<MODEL_LGSSM2> {
     static constexpr int D = 2, NBLK = 1;
+    static constexpr bool HAS_PROPOSAL = true;
+    // custom-proposal update (reference src/update.jl:79-96, src/translate.jl:86-105 without transform;
+    // src/initialize.jl:46-62): x ~ q(. | x_{t-1}, y_t), the locally optimal proposal of the linear-Gaussian model;
+    // returns log_weight = model_score_diff - fwd_proposal_score = [log p(x|x_{t-1}) + log p(y|x)] - log q(x)
+    static GPF_HD double propose(const double* P, bool first, const double* xp, const double* obs, uint64_t seed,
+                                 uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
+    {
+        double z0, z1;
+        normal2(rng(seed, gid, blk0, epoch, tag), z0, z1);
+        const double mu0 = first ? 0.0 : P[0] * xp[0] + P[1] * xp[1];
+        const double mu1 = first ? 0.0 : P[2] * xp[0] + P[3] * xp[1];
+        const int o = first ? 14 : 8;                  // gain, sv, 1/sv, cq, 1/s_prior, c_prior
+        const double m0 = mu0 + P[o] * (obs[0] - mu0), m1 = mu1 + P[o] * (obs[1] - mu1);
+        xn[0] = m0 + P[o + 1] * z0;
+        xn[1] = m1 + P[o + 1] * z1;
+        const double a0 = (xn[0] - mu0) * P[o + 4], a1 = (xn[1] - mu1) * P[o + 4];
+        const double lt = -0.5 * (a0 * a0 + a1 * a1) - P[o + 5];
+        const double b0 = (xn[0] - m0) * P[o + 2], b1 = (xn[1] - m1) * P[o + 2];
+        const double lq = -0.5 * (b0 * b0 + b1 * b1) - P[o + 3];
+        return (lt + loglik(P, xn, obs)) - lq;
+    }
     static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
                               uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
     {
@@ -54,6 +76,7 @@ template <> struct Model<MODEL_LGSSM2> {
 // P = [mu0..3 | s0..3 | sp | sv | 1/sb | log sb + log(2 pi)/2]
 template <> struct Model<MODEL_BEARINGS4> {
     static constexpr int D = 4, NBLK = 2;
+    static constexpr bool HAS_PROPOSAL = false;
     static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
                               uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
     {
@@ -85,6 +108,7 @@ template <> struct Model<MODEL_BEARINGS4> {
 // P = [mu | phi | sigma | sigma/sqrt(1-phi^2) | log(2 pi)/2]
 template <> struct Model<MODEL_SV1> {
     static constexpr int D = 1, NBLK = 1;
+    static constexpr bool HAS_PROPOSAL = false;
     static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
                               uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
     {
@@ -105,6 +129,7 @@ template <> struct Model<MODEL_SV1> {
 // obs = [y_obs, sin(t)]
 template <> struct Model<MODEL_OBJECT_MOTION> {
     static constexpr int D = 2, NBLK = 2;
+    static constexpr bool HAS_PROPOSAL = false;
     static GPF_HD void sample(const double* P, bool first, const double* xp, const double* obs, uint64_t seed,
                               uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
     {

@@ -188,22 +188,35 @@ gpf_status alloc_particle_buffers(gpf_filter* h)
 // ------------------------------------------------------------------ model dispatch
 int step_grid(const gpf_filter* h) { return std::min(grid_for(h, h->n, 4), MAX_PARTIALS); }
 
-template <int M, bool KEEP>
+template <int M, bool KEEP, bool PROP = false>
 void launch_step_t(gpf_filter* h, int grid)
 {
     constexpr int Wc = row_width(Model<M>::D, KEEP);
-    if (h->pending_gather)
-        hipLaunchKernelGGL((k_step<M, Wc, KEEP, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+    if constexpr (PROP && !Model<M>::HAS_PROPOSAL) { (void)h; (void)grid; return; }
+    else if (h->pending_gather)
+        hipLaunchKernelGGL((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags);
     else
-        hipLaunchKernelGGL((k_step<M, Wc, KEEP, false>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+        hipLaunchKernelGGL((k_step<M, Wc, KEEP, false, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags);
 }
-template <int M>
+template <int M, bool PROP = false>
 void launch_init_t(gpf_filter* h, int grid)
 {
-    hipLaunchKernelGGL((k_init<M>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                       h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw, h->pmax, h->pflags);
+    if constexpr (PROP && !Model<M>::HAS_PROPOSAL) { (void)h; (void)grid; return; }
+    else
+        hipLaunchKernelGGL((k_init<M, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                           h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw, h->pmax, h->pflags);
+}
+bool model_has_proposal(int model)
+{
+    switch (model) {
+        case MODEL_LGSSM2: return Model<MODEL_LGSSM2>::HAS_PROPOSAL;
+        case MODEL_BEARINGS4: return Model<MODEL_BEARINGS4>::HAS_PROPOSAL;
+        case MODEL_SV1: return Model<MODEL_SV1>::HAS_PROPOSAL;
+        case MODEL_OBJECT_MOTION: return Model<MODEL_OBJECT_MOTION>::HAS_PROPOSAL;
+    }
+    return false;
 }
 template <int M, bool RW>
 void launch_move_t(gpf_filter* h, int grid, int n_iters)
@@ -616,15 +629,19 @@ gpf_status gpf_synchronize(gpf_handle h)
     return GPF_OK;
 }
 
-gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs)
+static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs, bool prop)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (prop && !model_has_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no native proposal");
     gpf_status s = set_obs(h, obs, n_obs);
     if (s) return s;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if ((s = hist_begin_step(h, true))) return s;
     const int grid = step_grid(h);
-    s = timed(h, GPF_K_STEP, [&] { DISPATCH_MODEL(h, launch_init_t<MM>(h, grid)); });
+    s = timed(h, GPF_K_STEP, [&] {
+        if (prop) { DISPATCH_MODEL(h, (launch_init_t<MM, true>(h, grid))); }
+        else      { DISPATCH_MODEL(h, (launch_init_t<MM, false>(h, grid))); }
+    });
     if (s) return s;
     h->pending_gather = false;
     h->max_valid = true; h->max_np = grid;
@@ -638,17 +655,30 @@ gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs)
     return GPF_OK;
 }
 
-gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs)
+gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs) { return initialize_impl(h, obs, n_obs, false); }
+gpf_status gpf_initialize_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal)
+{
+    if (proposal != GPF_PROPOSAL_LOCALLY_OPTIMAL) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown proposal id");
+    return initialize_impl(h, obs, n_obs, true);
+}
+
+static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, bool prop)
 {
     gpf_status s = check_ready(h);
     if (s) return s;
+    if (prop && !model_has_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no native proposal");
     if ((s = set_obs(h, obs, n_obs))) return s;
     if ((s = hist_begin_step(h, false))) return s;
     const int grid = step_grid(h);
     const bool keep = h->cfg.keep_prev != 0;
     s = timed(h, GPF_K_STEP, [&] {
-        if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true>(h, grid))); }
-        else      { DISPATCH_MODEL(h, (launch_step_t<MM, false>(h, grid))); }
+        if (prop) {
+            if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true, true>(h, grid))); }
+            else      { DISPATCH_MODEL(h, (launch_step_t<MM, false, true>(h, grid))); }
+        } else {
+            if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true>(h, grid))); }
+            else      { DISPATCH_MODEL(h, (launch_step_t<MM, false>(h, grid))); }
+        }
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
@@ -659,6 +689,13 @@ gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs)
     h->has_prev = true;
     h->raw_valid = false;
     return GPF_OK;
+}
+
+gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs) { return update_impl(h, obs, n_obs, false); }
+gpf_status gpf_update_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal)
+{
+    if (proposal != GPF_PROPOSAL_LOCALLY_OPTIMAL) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown proposal id");
+    return update_impl(h, obs, n_obs, true);
 }
 
 gpf_status gpf_resample(gpf_handle h, int32_t method, double priority_alpha, int32_t sort_particles, int32_t check,

@@ -35,7 +35,11 @@ def lgssm2(theta: float = 0.1, rho: float = 0.99, sq: float = 0.1, sr: float = 0
     """x' = A x + N(0, sq^2 I), y = x + N(0, sr^2 I), A = rho * rot(theta), x1 ~ N(0, s0^2 I)."""
     a11, a12 = rho * math.cos(theta), -rho * math.sin(theta)
     a21, a22 = rho * math.sin(theta), rho * math.cos(theta)
-    p = np.array([a11, a12, a21, a22, sq, s0, 1.0 / sr, 2.0 * (math.log(sr) + _HALF_LOG_2PI)])
+    def prop(prior_sd):      # locally optimal proposal given a N(mu, prior_sd^2 I) prior and y = x + N(0, sr^2 I)
+        gain = prior_sd ** 2 / (prior_sd ** 2 + sr ** 2)
+        sv = math.sqrt(prior_sd ** 2 * sr ** 2 / (prior_sd ** 2 + sr ** 2))
+        return [gain, sv, 1.0 / sv, 2.0 * (math.log(sv) + _HALF_LOG_2PI), 1.0 / prior_sd, 2.0 * (math.log(prior_sd) + _HALF_LOG_2PI)]
+    p = np.array([a11, a12, a21, a22, sq, s0, 1.0 / sr, 2.0 * (math.log(sr) + _HALF_LOG_2PI)] + prop(sq) + prop(s0))
     return NativeModel(MODEL_LGSSM2, "lgssm2", 2, 2, p,
                        dict(A=np.array([[a11, a12], [a21, a22]]), sq=sq, sr=sr, s0=s0))
 

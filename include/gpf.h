@@ -60,7 +60,7 @@ typedef enum { GPF_CHECK_FALSE = 0, GPF_CHECK_WARN = 1, GPF_CHECK_TRUE = 2 } gpf
 typedef struct {
     int32_t  abi_version;    /* GPF_ABI_VERSION */
     int32_t  model;          /* gpf_model */
-    int32_t  n_params;       /* <= 16 */
+    int32_t  n_params;       /* <= 24 */
     int32_t  keep_prev;      /* 1: rows also carry x_{t-1} (needed by gpf_rejuvenate) */
     const double* params;    /* model parameters, layout in csrc/gpf_models.hpp */
     int64_t  n_particles;    /* particles held by this handle (this shard) */
@@ -87,6 +87,14 @@ gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs);
 /* pf_update!(state, new_args, argdiffs, observations)              src/update.jl:12-25
  * x_t ~ p(. | x_{t-1}), log_weights[i] += log p(obs | x_t); buffers swap (update_refs!, src/utils.jl:10-15). */
 gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs);
+
+/* pf_initialize(model, args, obs, proposal, proposal_args, n)        src/initialize.jl:46-62
+ * pf_update!(state, new_args, argdiffs, obs, proposal, proposal_args) src/update.jl:79-96 (+ src/translate.jl:86-105)
+ * with a NATIVE proposal: new latents x ~ q(. | x_{t-1}, y_t); log_weights[i] += [log p(x | x_{t-1}) + log p(y | x)] - log q(x).
+ * GPF_PROPOSAL_LOCALLY_OPTIMAL: the exact conditional of the linear-Gaussian model (GPF_MODEL_LGSSM2 only). */
+typedef enum { GPF_PROPOSAL_LOCALLY_OPTIMAL = 1 } gpf_proposal;
+gpf_status gpf_initialize_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal);
+gpf_status gpf_update_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal);
 
 /* pf_resample!(state, method; priority_fn, check[, sort_particles])  src/resample.jl:19-175
  *   priority_alpha: NaN -> priority_fn = nothing; otherwise priority_fn = w -> priority_alpha * w

@@ -69,6 +69,18 @@ function pf_update!(state::DeviceParticleFilterState, new_args::Tuple, argdiffs:
     return state
 end
 
+"Native proposal for pf_initialize / pf_update! (src/initialize.jl:46-62, src/update.jl:79-96): exact conditional of the LG-SSM"
+struct LocallyOptimal end
+function pf_initialize(model::NativeModel, model_args::Tuple, observations::Vector{Float64}, proposal::LocallyOptimal, proposal_args::Tuple, n_particles::Int; kw...)
+    state = DeviceParticleFilterState(model, n_particles; kw...)
+    check(state, ccall((:gpf_initialize_proposal, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), state.handle, observations, length(observations), 1))
+    return state
+end
+function pf_update!(state::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Vector{Float64}, proposal::LocallyOptimal, proposal_args::Tuple)
+    check(state, ccall((:gpf_update_proposal, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), state.handle, observations, length(observations), 1))
+    return state
+end
+
 "priority_fn = w -> alpha*w evaluated on the GPU (test/resample.jl:15 uses alpha = 1/2)"
 struct Tempering; alpha::Float64; end
 (t::Tempering)(w) = t.alpha * w

@@ -210,6 +210,54 @@ static double model_loglik(int model, const double *P, const double *x, const do
     return 0.0;
 }
 
+/* custom-proposal initialize / update (initialize.jl:46-62; update.jl:79-96 + translate.jl:86-105): native locally
+ * optimal proposal of the linear-Gaussian model; returns log_weight = model_score_diff - fwd_proposal_score */
+static double model_propose(int model, const double *P, int first, const double *xp, const double *obs,
+                            uint64_t seed, uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double *xn)
+{
+    if (model != O_MODEL_LGSSM2) return NAN;
+    double z0, z1;
+    o_normal2(o_rng(seed, gid, blk0, epoch, tag), &z0, &z1);
+    double mu0 = first ? 0.0 : P[0] * xp[0] + P[1] * xp[1];
+    double mu1 = first ? 0.0 : P[2] * xp[0] + P[3] * xp[1];
+    int o = first ? 14 : 8;
+    double m0 = mu0 + P[o] * (obs[0] - mu0), m1 = mu1 + P[o] * (obs[1] - mu1);
+    xn[0] = m0 + P[o + 1] * z0;
+    xn[1] = m1 + P[o + 1] * z1;
+    double a0 = (xn[0] - mu0) * P[o + 4], a1 = (xn[1] - mu1) * P[o + 4];
+    double lt = -0.5 * (a0 * a0 + a1 * a1) - P[o + 5];                 /* log p(x | x_prev) */
+    double b0 = (xn[0] - m0) * P[o + 2], b1 = (xn[1] - m1) * P[o + 2];
+    double lq = -0.5 * (b0 * b0 + b1 * b1) - P[o + 3];                 /* log q(x) */
+    return (lt + model_loglik(model, P, xn, obs)) - lq;
+}
+O_EXPORT void o_init_proposal(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
+                              int W, const double *obs, double *rows, double *lw)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double *r = rows + i * W;
+        for (int k = 0; k < W; ++k) r[k] = 0.0;
+        lw[i] = model_propose(model, P, 1, NULL, obs, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_INIT, r);   /* initialize.jl:58 */
+    }
+}
+O_EXPORT void o_step_proposal(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
+                              int W, int keep_prev, const double *obs, const double *rows_in, double *rows_out, double *lw)
+{
+    int d = model_dim(model);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double *ri = rows_in + i * W;
+        double *ro = rows_out + i * W;
+        double xn[4], xp[4];
+        double w = model_propose(model, P, 0, ri, obs, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_UPDATE, xn);
+        for (int k = 0; k < d; ++k) xp[k] = ri[k];
+        for (int k = 0; k < W; ++k) ro[k] = 0.0;
+        for (int k = 0; k < d; ++k) ro[k] = xn[k];
+        if (keep_prev) for (int k = 0; k < d; ++k) ro[d + k] = xp[k];
+        lw[i] = lw[i] + w;                                              /* translate.jl:103, update.jl:40 */
+    }
+}
+
 /* pf_initialize default proposal, initialize.jl:39-41: x ~ prior, log_weights[i] = log p(y1|x) */
 O_EXPORT void o_init(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
                      int W, const double *obs, double *rows, double *lw)

@@ -63,6 +63,8 @@ def lib():
     sig("o_model_dim", i32, i32); sig("o_model_nblk", i32, i32)
     sig("o_init", None, i32, _f64p, u64, u32, i64, i64, i32, _f64p, _f64p, _f64p)
     sig("o_step", None, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, _f64p, _f64p, _f64p)
+    sig("o_init_proposal", None, i32, _f64p, u64, u32, i64, i64, i32, _f64p, _f64p, _f64p)
+    sig("o_step_proposal", None, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, _f64p, _f64p, _f64p)
     sig("o_move", u64, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, i32, i32, _f64p, _f64p, _f64p)
     sig("o_max_flags", None, _f64p, i64, pf64, pi32)
     sig("o_fixq", None, _f64p, i64, f64, i32, i32, _u64p)
@@ -218,10 +220,11 @@ class OracleFilter:
         self.n_accepted = 0
 
     # -- initialize.jl:31-44
-    def initialize(self, obs):
+    def initialize(self, obs, proposal: bool = False):
         obs = np.ascontiguousarray(obs, np.float64)
         self.hist_x, self.hist_map = [None], [None]
-        lib().o_init(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, obs, self.rows, self.lw)
+        f = lib().o_init_proposal if proposal else lib().o_init          # initialize.jl:46-62 / :31-44
+        f(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, obs, self.rows, self.lw)
         self.lml_est = 0.0
         self.parents = np.arange(1, self.n + 1, dtype=np.int64)
         self.epoch += 1
@@ -230,14 +233,15 @@ class OracleFilter:
         return self
 
     # -- update.jl:12-25
-    def update(self, obs):
+    def update(self, obs, proposal: bool = False):
         obs = np.ascontiguousarray(obs, np.float64)
         if self.history:                                            # the step that ends now, in its final order
             self.hist_x[-1] = self.rows[:, :self.d].copy()
             self.hist_x.append(None); self.hist_map.append(None)
         new_rows = np.empty_like(self.rows)
-        lib().o_step(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, int(self.keep_prev),
-                     obs, self.rows, new_rows, self.lw)            # :15-22
+        f = lib().o_step_proposal if proposal else lib().o_step          # update.jl:79-96 / :12-25
+        f(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, int(self.keep_prev),
+          obs, self.rows, new_rows, self.lw)                        # :15-22
         self.rows = new_rows                                        # update_refs!, utils.jl:10-15
         self.epoch += 1
         self.has_prev = True
