@@ -620,6 +620,7 @@ struct SearchArgs {
     int64_t n_cells;                                                  // particles the CDF ranges over (== n except when resizing)
     uint64_t seed; uint32_t epoch;
     int K; double logN;
+    int update_lml;                                                   // 0 for sub-state views (resample.jl:185-187)
     int32_t* anc;
 };
 
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
     const SearchTop st = search_prologue(a.w, a.c, METHOD == 1, a.ntiles, reinterpret_cast<uint64_t*>(smem));
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
 #ifndef GPF_ABL_SEARCH_NOLML
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    if (a.update_lml && blockIdx.x == 0 && threadIdx.x == 0)
 #else
     if (false)
 #endif
@@ -773,11 +774,12 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
         for (int u = 0; u < 2; ++u) {
             j[u] = base + u * SBLOCK + threadIdx.x;
             act[u] = j[u] < a.n;
-            const uint64_t jg = (uint64_t)(a.gid0 + (act[u] ? j[u] : a.n - 1));
+            const uint64_t jl = (uint64_t)(act[u] ? j[u] : a.n - 1);   // slot index inside this filter / view
+            const uint64_t jg = jl;                                    // (k_search is never used on shards: slot == local index)
 #ifdef GPF_ABL_SEARCH_NOPHILOX
             const uint64_t U = jg * 0x9E3779B97F4A7C15ull;
 #else
-            const Philox b = rng(a.seed, (uint32_t)jg, 0, a.epoch, TAG_RESAMPLE);
+            const Philox b = rng(a.seed, (uint32_t)(a.gid0 + jl), 0, a.epoch, TAG_RESAMPLE);   // RNG keyed by the global id
             const uint64_t U = u64(b.w0, b.w1);
 #endif
             head[u] = false; top[u] = st.topw; L[u] = &a.w;
@@ -1292,6 +1294,20 @@ __global__ __launch_bounds__(BLOCK) void k_route_scatter(RouteArgs a)
         a.T_sorted[pos] = tl;
         a.perm[pos] = j;
     }
+}
+
+// ----------------------------------------------------------------------------- sub-state views (src/view.jl, resample.jl:205-218)
+// after resampling a view: every log-weight = logsumexp(view) - log n (the block keeps its total mass, resample.jl:210)
+__global__ void k_view_fill_weights(double* __restrict__ lw, int64_t n, const WSum* ws, int K, double logN)
+{
+    const double v = lse_from(ws->m, ws->S, K, ws->flags) - logN;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) lw[i] = v;
+}
+// with priorities: lw = log_ws + (logsumexp(view weights) - logsumexp(log_ws))   (resample.jl:213-216)
+__global__ void k_view_apply_post(const Scalars* sc, int K, const double* __restrict__ lws, double* __restrict__ lw, int64_t n)
+{
+    const double off = lse_from(sc->raw.m, sc->raw.S, K, sc->raw.flags) - lse_from(sc->post.m, sc->post.S, K, sc->post.flags);
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) lw[i] = lws[i] + off;
 }
 
 } // namespace gpf

@@ -73,6 +73,11 @@ struct gpf_filter {
     std::vector<int32_t*> hist_map;      // [step] n int32 or nullptr
     int hist_step = -1;                  // index of the current step (0 = after gpf_initialize)
     const int32_t** hist_dev_maps = nullptr;
+    // sub-state view (src/view.jl:16-48): this handle aliases particles [view_start, view_start + n) of `parent`
+    gpf_filter* parent = nullptr;
+    int64_t view_start = 0;
+    uint64_t generation = 0;             // bumped when the per-particle buffers are reallocated (views check it)
+    uint64_t parent_generation = 0;
     int32_t* route_counts = nullptr;     // shard routing scratch: [n/256][MAX_SHARDS]
     int64_t* route_offsets = nullptr;    // [5][MAX_SHARDS]: shard totals and inclusive offsets of the current resample
     Timer timers[GPF_K_COUNT];
@@ -89,6 +94,8 @@ namespace {
             return GPF_ERR_HIP;                                                                 \
         }                                                                                       \
     } while (0)
+
+gpf_status materialize(gpf_filter* h);
 
 gpf_status fail(gpf_handle h, gpf_status s, const std::string& msg)
 {
@@ -391,9 +398,45 @@ void normalise_Q(const WSum& w, uint64_t& hi, uint64_t& lo)
     lo = (uint64_t)Q;
 }
 
+// A view re-derives its aliased pointers from the parent on every call (the parent may have swapped its row buffers),
+// shares the parent's epoch counter, and forces a pending gather of the parent first.
+gpf_status view_enter(gpf_filter* v)
+{
+    gpf_filter* p = v->parent;
+    if (p->generation != v->parent_generation) return fail(v, GPF_ERR_STATE, "stale view: the parent filter was resized or re-created");
+    if (!p->initialized) return fail(v, GPF_ERR_STATE, "parent filter not initialised");
+    gpf_status s = materialize(p);
+    if (s) { v->err = p->err; return s; }
+    const int64_t o = v->view_start;
+    v->rows[0] = p->rows[p->cur] + o * v->W;
+    v->rows[1] = p->rows[1 - p->cur] + o * v->W;
+    v->cur = 0;
+    v->lw = p->lw + o;
+    v->anc = p->anc + o;
+    v->epoch = p->epoch;
+    v->has_prev = p->has_prev;
+    v->initialized = true;
+    return GPF_OK;
+}
+// after a mutating call on a view: update_refs! for sub-states copies back (utils.jl:17-20); parent caches are stale
+gpf_status view_exit(gpf_filter* v)
+{
+    if (!v->parent) return GPF_OK;
+    gpf_filter* p = v->parent;
+    if (v->cur == 1) {
+        HIP_TRY(v, hipMemcpyAsync(v->rows[0], v->rows[1], (size_t)v->n * v->W * sizeof(double), hipMemcpyDeviceToDevice, v->stream));
+        v->cur = 0;
+    }
+    p->epoch = v->epoch;
+    p->has_prev = p->has_prev || v->has_prev;
+    p->raw_valid = false; p->max_valid = false; p->raw_has_q = false; p->raw_q_folded = false;
+    return GPF_OK;
+}
+
 gpf_status check_ready(gpf_handle h)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (h->parent) { gpf_status vs = view_enter(h); if (vs) return vs; }
     if (!h->initialized) return fail(h, GPF_ERR_STATE, "filter not initialised: call gpf_initialize (pf_initialize) first");
     HIP_TRY(h, hipSetDevice(h->cfg.device));       // launches go to the calling thread's current device
     return GPF_OK;
@@ -493,6 +536,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     sa.order = sorted ? h->order : nullptr; sa.sc = h->sc; sa.ws = ws; sa.raw = &h->sc->raw; sa.n = h->n; sa.n_cells = h->n;
     sa.n_global = h->cfg.n_global; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
     sa.K = h->K; sa.logN = h->logN; sa.anc = h->anc;
+    sa.update_lml = h->parent ? 0 : 1;                           // sub-states do not track the estimate (resample.jl:185-187)
 
     if (method == GPF_RESAMPLE_RESIDUAL) {
         if ((s = residual_scans(h, ws, h->cfg.n_global))) return s;
@@ -513,6 +557,23 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     });
     if (s) return s;
     if ((s = hist_on_resample(h))) return s;
+    if (h->parent) {
+        // sub-state (resample.jl:205-218): eager gather; weights keep the block's total mass
+        s = timed(h, GPF_K_GATHER, [&] { launch_gather(h, pv, pv.mode == 0 ? h->lw : h->lws); });
+        if (s) return s;
+        h->cur ^= 1;
+        if (pv.mode == 0) {
+            hipLaunchKernelGGL(k_view_fill_weights, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->lw, h->n, &h->sc->raw, h->K, h->logN);
+        } else {
+            PrioView post{h->lws, nullptr, 0.0, 0};
+            if ((s = summarize(h, post, &h->sc->post, false, nullptr, false))) return s;
+            hipLaunchKernelGGL(k_view_apply_post, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->sc, h->K, h->lws, h->lw, h->n);
+        }
+        h->max_valid = false;
+        HIP_TRY(h, hipGetLastError());
+        h->epoch += 1;
+        return view_exit(h);
+    }
     if (pv.mode == 0) {
         // new_traces .= view(traces, parents) is deferred: the next pf_update! reads rows through anc (fused
         // gather), any other consumer calls materialize().  Log-weights are 0 (resample.jl:195).
@@ -613,6 +674,7 @@ gpf_status gpf_destroy(gpf_handle h)
     for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     hist_clear(h);
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
+    if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
     void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->route_counts, h->route_offsets};
     for (void* b : bufs) if (b) hipFree(b);
@@ -633,6 +695,8 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (prop && !model_has_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no native proposal");
+    if (h->parent) return fail(h, GPF_ERR_STATE, "gpf_initialize on a sub-state view");
+    h->generation += 1;
     gpf_status s = set_obs(h, obs, n_obs);
     if (s) return s;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
@@ -688,7 +752,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, bo
     h->epoch += 1;
     h->has_prev = true;
     h->raw_valid = false;
-    return GPF_OK;
+    return view_exit(h);            // sub-state: copy back (utils.jl:17-20)
 }
 
 gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs) { return update_impl(h, obs, n_obs, false); }
@@ -739,6 +803,7 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
     h->cur ^= 1;
     h->epoch += 1;
     if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; h->max_np = grid; }
+    if ((s = view_exit(h))) return s;
     if (n_accepted) {
         if ((s = fetch_scalars(h))) return s;
         *n_accepted = h->h_sc->n_accept;
@@ -773,7 +838,12 @@ gpf_status gpf_log_ml_estimate(gpf_handle h, double* out)
     if ((s = ensure_raw(h))) return s;
     if ((s = fetch_scalars(h))) return s;
     const WSum& w = h->h_sc->raw;
-    *out = h->h_sc->lml_est + lse_from(w.m, w.S, h->K, w.flags) - h->logN;
+    double base = h->h_sc->lml_est;
+    if (h->parent) {                                             // source.log_ml_est (utils.jl:174-178)
+        if ((s = fetch_scalars(h->parent))) { h->err = h->parent->err; return s; }
+        base = h->parent->h_sc->lml_est;
+    }
+    *out = base + lse_from(w.m, w.S, h->K, w.flags) - h->logN;
     return GPF_OK;
 }
 
@@ -845,6 +915,7 @@ gpf_status gpf_set_rows(gpf_handle h, const double* rows, int64_t n_doubles)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!rows || n_doubles != h->n * h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
+    if (h->parent) { gpf_status s = view_enter(h); if (s) return s; }
     { gpf_status s = materialize(h); if (s) return s; }
     HIP_TRY(h, hipMemcpyAsync(h->rows[h->cur], rows, (size_t)n_doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -856,6 +927,7 @@ gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!lw || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
+    if (h->parent) { gpf_status s = view_enter(h); if (s) return s; h->parent->raw_valid = false; h->parent->max_valid = false; }
     { gpf_status s = materialize(h); if (s) return s; }
     h->max_valid = false;
     HIP_TRY(h, hipMemcpyAsync(h->lw, lw, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -933,6 +1005,57 @@ gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const do
     return GPF_OK;
 }
 
+// =================================================================================== sub-state views (src/view.jl)
+gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_handle* out)
+{
+    if (!parent || !out) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (parent->parent) return fail(parent, GPF_ERR_STATE, "views of views are not supported");
+    if (parent->cfg.n_global != parent->n) return fail(parent, GPF_ERR_STATE, "views of sharded filters are not supported (shards play that role)");
+    if (start < 0 || count < 1 || start + count > parent->n) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view range out of bounds");
+    gpf_filter* v = new gpf_filter();
+    v->cfg = parent->cfg;
+    v->cfg.n_particles = count; v->cfg.n_global = count;          // a sub-state normalises over its own particles
+    v->cfg.gid0 = parent->cfg.gid0 + start;                        // ... but RNG counters keep the global particle id
+    v->args = parent->args;
+    v->d = parent->d; v->W = parent->W; v->n = count; v->n_cu = parent->n_cu;
+    v->stream = parent->stream; v->own_stream = false;
+    v->parent = parent; v->view_start = start; v->parent_generation = parent->generation;
+    auto body = [&]() -> gpf_status {
+        HIP_TRY(v, hipSetDevice(v->cfg.device));
+        // scratch of its own (weight levels, descriptors, partials, scalars); rows / lw / anc alias the parent
+        v->ntiles = (v->n + TILE - 1) / TILE;
+        v->K = fix_K(count);
+        v->logN = log_((double)count);
+        const size_t n = (size_t)count;
+        HIP_TRY(v, hipMalloc(&v->lws, n * sizeof(double)));
+        HIP_TRY(v, hipMalloc(&v->lp, n * sizeof(double)));
+        HIP_TRY(v, hipMalloc(&v->dtmp, n * sizeof(double)));
+        HIP_TRY(v, hipMalloc(&v->cdf[0], (size_t)v->ntiles * TILE * sizeof(uint64_t)));
+        HIP_TRY(v, hipMalloc(&v->t16[0], (size_t)v->ntiles * (TILE / 16) * sizeof(uint64_t)));
+        HIP_TRY(v, hipMalloc(&v->t256[0], (size_t)v->ntiles * (TILE / 256) * sizeof(uint64_t)));
+        const size_t db = (((size_t)2 * v->ntiles * sizeof(uint64_t)) + 15) & ~(size_t)15;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 2; ++j) {
+                HIP_TRY(v, hipMalloc(&v->desc[i][j], db));
+                HIP_TRY(v, hipMemsetAsync(v->desc[i][j], 0, db, v->stream));
+            }
+        HIP_TRY(v, hipMalloc(&v->pmax, MAX_PARTIALS * sizeof(double)));
+        HIP_TRY(v, hipMalloc(&v->pflags, MAX_PARTIALS * sizeof(int32_t)));
+        HIP_TRY(v, hipMalloc(&v->blockQ, (size_t)4 * 2 * v->n_cu * sizeof(uint64_t) + 64));
+        HIP_TRY(v, hipMalloc(&v->partial, MAX_PARTIALS * sizeof(double)));
+        HIP_TRY(v, hipMalloc(&v->dscal, 4 * sizeof(double)));
+        HIP_TRY(v, hipMalloc(&v->sc, sizeof(Scalars)));
+        HIP_TRY(v, hipHostMalloc(&v->h_sc, sizeof(Scalars)));
+        HIP_TRY(v, hipMemsetAsync(v->sc, 0, sizeof(Scalars), v->stream));
+        return GPF_OK;
+    };
+    gpf_status st = body();
+    if (st != GPF_OK) { parent->err = v->err; gpf_destroy(v); return st; }
+    *out = v;
+    return GPF_OK;
+}
+
 // =================================================================================== resize family (src/resize.jl)
 static gpf_status resize_ready(gpf_handle h)
 {
@@ -940,6 +1063,8 @@ static gpf_status resize_ready(gpf_handle h)
     if (s) return s;
     if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, "resizing a sharded filter is not supported");
     if (h->hist_on) return fail(h, GPF_ERR_STATE, "resizing a filter with a trajectory store is not supported");
+    if (h->parent) return fail(h, GPF_ERR_STATE, "a sub-state view cannot be resized");
+    h->generation += 1;                  // views of this filter become stale
     return materialize(h);
 }
 // after the particle count changed: unsharded bookkeeping
@@ -984,7 +1109,7 @@ gpf_status gpf_resize(gpf_handle h, int64_t n_new, int32_t method, double priori
     SearchArgs sa{};
     sa.w = levels(h, 0); sa.c = levels(h, 0); sa.ntiles = h->ntiles; sa.order = nullptr; sa.sc = h->sc; sa.ws = ws;
     sa.raw = &h->sc->raw; sa.n = n_new; sa.n_cells = n_old; sa.n_global = n_new; sa.gid0 = 0; sa.seed = h->cfg.seed;
-    sa.epoch = h->epoch; sa.K = h->K; sa.logN = log_((double)n_old);
+    sa.epoch = h->epoch; sa.K = h->K; sa.logN = log_((double)n_old); sa.update_lml = 1;
     if (method == GPF_RESAMPLE_RESIDUAL) {
         if ((s = residual_scans(h, ws, n_new))) return s;                                        // floor(n_particles * w), resize.jl:106
         sa.w = levels(h, 2); sa.c = levels(h, 1);

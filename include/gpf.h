@@ -163,6 +163,16 @@ gpf_status gpf_kernel_time(gpf_handle h, int32_t id, double* total_ms, int64_t* 
 gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const double* b, int64_t n,
                           double* out, double* out2);
 
+/* ---- sub-state views (src/view.jl:16-48) -----------------------------------------------------
+ * state[idxs] / view(state, idxs) for a contiguous range: a handle that ALIASES particles [start, start+count) of
+ * `parent` (their rows, log-weights and parents) and owns only its scratch.  Every gpf_* operation works on it with the
+ * sub-state semantics of the reference: pf_update!/pf_rejuvenate! touch only the range (update_refs! copies back,
+ * src/utils.jl:17-20); pf_resample! resamples inside the range with LOCAL ancestor indices, leaves the log-ML estimate
+ * alone and resets the weights to the block's average so its total mass is preserved (src/resample.jl:185-187,205-218);
+ * gpf_log_ml_estimate = source.log_ml_est + logsumexp(view) - log n (src/utils.jl:174-178).  RNG counters keep the
+ * global particle ids.  Destroy with gpf_destroy; a view becomes stale when the parent is resized or re-initialised. */
+gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_handle* out);
+
 /* ---- resize family (src/resize.jl) --------------------------------------------------
  * The handle stays valid; its per-particle buffers are reallocated for the new count.  Unsharded filters only. */
 gpf_status gpf_n_particles(gpf_handle h, int64_t* out);

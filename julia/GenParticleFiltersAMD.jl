@@ -51,6 +51,18 @@ mutable struct DeviceParticleFilterState
     end
 end
 
+# state[a:b] / view(state, a:b): ParticleFilterSubState over a contiguous range (src/view.jl:35-48); every method of this
+# file accepts the returned object (it is a DeviceParticleFilterState whose handle aliases the source's particles)
+function Base.getindex(s::DeviceParticleFilterState, r::UnitRange{Int})
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(s, ccall((:gpf_view_create, libgpf), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), getfield(s, :handle), first(r) - 1, length(r), h))
+    v = ccall(:jl_new_struct_uninit, Any, (Any,), DeviceParticleFilterState)::DeviceParticleFilterState   # bypass the allocating constructor
+    setfield!(v, :handle, h[]); setfield!(v, :model, getfield(s, :model)); setfield!(v, :n_particles, length(r))
+    finalizer(x -> ccall((:gpf_destroy, libgpf), Cint, (Ptr{Cvoid},), getfield(x, :handle)), v)
+    return v
+end
+Base.view(s::DeviceParticleFilterState, r::UnitRange{Int}) = s[r]
+
 check(state, st) = st == 0 ? nothing :
     error(unsafe_string(ccall((:gpf_last_error, libgpf), Cstring, (Ptr{Cvoid},), state.handle)))   # ErrorException
 

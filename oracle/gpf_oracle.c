@@ -413,6 +413,18 @@ O_EXPORT void o_targets_stratified(uint64_t seed, uint32_t epoch, int64_t j0, in
         T[j] = L0 + o_mulhi64(o_u64(b.v[0], b.v[1]), L1 - L0);
     }
 }
+/* sub-state views: strata are LOCAL to the view (index j of n), the RNG counter keeps the global particle id gid0 + j */
+O_EXPORT void o_targets_stratified_view(uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n, uint64_t S, uint64_t *T)
+{
+    uint64_t B = S / (uint64_t)n, rem = S % (uint64_t)n;
+    for (int64_t j = 0; j < n; ++j) {
+        uint64_t jl = (uint64_t)j;
+        uint64_t L0 = jl * B + (jl * rem) / (uint64_t)n;
+        uint64_t L1 = (jl + 1) * B + ((jl + 1) * rem) / (uint64_t)n;
+        o_philox_t b = o_rng(seed, (uint32_t)(gid0 + j), 0, epoch, O_TAG_RESAMPLE);
+        T[j] = L0 + o_mulhi64(o_u64(b.v[0], b.v[1]), L1 - L0);
+    }
+}
 /* first index a with cdf[a] > T  (== the while loop of resample.jl:163-166 / inverse-CDF categorical) */
 O_EXPORT void o_upper_bound(const uint64_t *cdf, int64_t n, const uint64_t *T, int64_t m, int64_t *idx)
 {

@@ -71,6 +71,7 @@ def lib():
     sig("o_scan", u64, _u64p, i64, _u64p, pu64, pu64)
     sig("o_targets_multinomial", None, u64, u32, i64, i64, u64, _u64p)
     sig("o_targets_stratified", None, u64, u32, i64, i64, i64, u64, _u64p)
+    sig("o_targets_stratified_view", None, u64, u32, i64, i64, u64, _u64p)
     sig("o_upper_bound", None, _u64p, i64, _u64p, i64, _i64p)
     sig("o_residual_shift", i32, u64, i64)
     sig("o_residual_split", None, _u64p, i64, i64, u64, i32, _u64p, _u64p)
@@ -440,3 +441,116 @@ class OracleFilter:
         v = np.ascontiguousarray(self.history_column(step, col)).reshape(-1, 1)
         mu = lib().o_wsum(s.q, s.S, v, 1, 0, self.n, 1, 0.0)
         return lib().o_wsum(s.q, s.S, v, 1, 0, self.n, 2, mu)
+
+
+class OracleSubState:
+    """ParticleFilterSubState (view.jl:16-48) over the contiguous range [start, start+count) of an OracleFilter:
+    numpy views alias the source's arrays; semantics of resample.jl:185-187,205-218 and utils.jl:17-20,174-178."""
+
+    def __init__(self, source: OracleFilter, start: int, count: int):
+        self.source, self.start, self.n = source, int(start), int(count)
+        self.sl = slice(self.start, self.start + self.n)
+        self.last_obs = source.last_obs
+        self.n_accepted = 0
+
+    # aliases of the source's arrays (the source may swap its row buffer: always re-derive)
+    @property
+    def rows(self): return self.source.rows[self.sl]
+    @property
+    def lw(self): return self.source.lw[self.sl]
+    @property
+    def parents(self): return self.source.parents[self.sl]
+
+    def summary(self) -> WeightSummary:
+        return WeightSummary(np.ascontiguousarray(self.lw), self.n)
+
+    def effective_sample_size(self) -> float:
+        return self.summary().ess
+
+    def log_ml_estimate(self) -> float:                                 # utils.jl:174-178
+        return self.source.lml_est + self.summary().lse - olog(float(self.n))
+
+    def update(self, obs, proposal: bool = False):                      # update.jl:12-25 on the view + utils.jl:17-20
+        s = self.source
+        obs = np.ascontiguousarray(obs, np.float64)
+        rin = np.ascontiguousarray(self.rows); lw = np.ascontiguousarray(self.lw)
+        rout = np.empty_like(rin)
+        f = lib().o_step_proposal if proposal else lib().o_step
+        f(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.keep_prev), obs, rin, rout, lw)
+        s.rows[self.sl] = rout; s.lw[self.sl] = lw
+        s.epoch += 1; s.has_prev = True; self.last_obs = obs
+        return self
+
+    def rejuvenate(self, method: str = "move", n_iters: int = 1):
+        s = self.source
+        rin = np.ascontiguousarray(self.rows); lw = np.ascontiguousarray(self.lw)
+        rout = np.empty_like(rin)
+        self.n_accepted = int(lib().o_move(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.has_prev),
+                                           self.last_obs, int(n_iters), int(method == "reweight"), rin, rout, lw))
+        s.rows[self.sl] = rout; s.lw[self.sl] = lw
+        s.epoch += 1
+        return self
+
+    def resample(self, method: str = "multinomial", priority_alpha=None, sort_particles: bool = True, check="warn"):
+        if method not in METHODS:
+            raise OracleError(f"Resampling method {method} not recognized.")
+        s, N = self.source, self.n
+        lw = np.ascontiguousarray(self.lw)
+        lp, has_prio = (lw, False) if priority_alpha is None else (float(priority_alpha) * lw, True)
+        sp = WeightSummary(lp, N)
+        invalid = sp.flags != 0
+        if (check is True and invalid) or sp.bad:
+            raise OracleError("Invalid weights.")
+        sr = WeightSummary(lw, N) if has_prio else sp                   # update_lml_est! is a no-op (resample.jl:185-187)
+        epoch = s.epoch
+        if method == "multinomial":
+            anc = upper_bound(sp.cdf, targets_multinomial(s.seed, epoch, self.start, N, sp.S))
+        elif method == "stratified":
+            if sort_particles:
+                order = argsort_desc(lp); cdf, S, _, _ = scan(sp.q[order])
+            else:
+                order, cdf, S = None, sp.cdf, sp.S
+            # strata are local to the view, RNG counters keep the global particle id
+            T = _targets_stratified_view(s.seed, epoch, self.start, N, S)
+            k = upper_bound(cdf, T)
+            anc = order[k] if order is not None else k
+        else:
+            sh = lib().o_residual_shift(sp.S, N)
+            c = np.empty(N, np.uint64); r = np.empty(N, np.uint64)
+            lib().o_residual_split(sp.q, N, N, sp.S, sh, c, r)
+            ccdf = np.cumsum(c, dtype=np.uint64); n_res = int(ccdf[-1])
+            anc = np.empty(N, np.int64)
+            anc[:n_res] = upper_bound(ccdf, np.arange(n_res, dtype=np.uint64))
+            if n_res < N:
+                rcdf, Rs, _, _ = scan(r)
+                anc[n_res:] = upper_bound(rcdf, targets_multinomial(s.seed, epoch, self.start + n_res, N - n_res, Rs))
+        new_rows = gather_rows(np.ascontiguousarray(self.rows), anc)
+        if not has_prio:
+            new_lw = np.full(N, sr.lse - olog(float(N)))                # resample.jl:210
+        else:
+            log_ws = lw[anc] - lp[anc]                                  # :213
+            new_lw = log_ws + (sr.lse - WeightSummary(log_ws, N).lse)   # :215-216
+        s.rows[self.sl] = new_rows; s.lw[self.sl] = new_lw
+        s.parents[self.sl] = anc + 1                                    # local to the view, like the reference
+        s.epoch += 1
+        return invalid
+
+    def mean(self, col: int) -> float:
+        s = self.summary()
+        return lib().o_wsum(s.q, s.S, np.ascontiguousarray(self.rows), self.source.W, col, self.n, 1, 0.0)
+
+
+def _targets_stratified_view(seed, epoch, start, n, S) -> np.ndarray:
+    """stratified targets with LOCAL stratum index j and RNG counter keyed by the global id start + j"""
+    T = np.empty(n, np.uint64)
+    lib().o_targets_stratified_view(seed, epoch, start, n, S, T)
+    return T
+
+
+def _oracle_getitem(self, idx):
+    start, stop, step = idx.indices(self.n)
+    assert step == 1 and stop > start
+    return OracleSubState(self, start, stop - start)
+
+
+OracleFilter.__getitem__ = _oracle_getitem

@@ -1,0 +1,97 @@
+"""Sub-state views (reference src/view.jl, test/resample.jl:130-162, test/update.jl:179-189,
+test/rejuvenate.jl:73-103): block-wise operations on contiguous ranges of one filter."""
+import numpy as np
+import pytest
+
+METHODS = ["multinomial", "residual", "stratified"]
+
+
+def lgssm(g, o, N=100, seed=3, keep_prev=True, T=4):
+    m = g.models.lgssm2(); ys = g.models.simulate(m, T)
+    return m, ys, o.OracleFilter(m.model_id, m.params, N, seed, keep_prev=keep_prev).initialize(ys[0])
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("alpha", [None, 0.5])
+def test_oracle_blockwise_resampling(g, o, method, alpha):
+    """test/resample.jl:130-162: resample two 50-particle views independently; per view new == old[parents] and the
+    view's log-ML estimate is unchanged; globally the traces follow the concatenated parents and the log-ML is unchanged."""
+    m, ys, f = lgssm(g, o)
+    old_full, lml_full, parents_full = f.rows.copy(), f.log_ml_estimate(), []
+    for a in (0, 50):
+        v = f[a:a + 50]
+        old, lml = v.rows.copy(), v.log_ml_estimate()
+        v.resample(method, priority_alpha=alpha)
+        assert np.array_equal(v.rows, old[v.parents - 1])            # :151
+        assert abs(v.log_ml_estimate() - lml) < 1e-9                 # :152
+        parents_full += list(a + v.parents - 1)                       # :153
+    assert np.array_equal(f.rows, old_full[np.array(parents_full)])  # :158
+    assert abs(f.log_ml_estimate() - lml_full) < 1e-9                # :160
+    assert f.lml_est == 0.0                                           # sub-states never touch the running estimate
+
+
+def test_oracle_per_view_update_and_rejuvenation(g, o):
+    """test/update.jl:179-189 (each half updated with its own observation) and test/rejuvenate.jl:73-103 (move on one
+    view, reweight on the other: only the touched half changes)."""
+    m, ys, f = lgssm(g, o)
+    lw0, rows0 = f.lw.copy(), f.rows.copy()
+    f[0:50].update(ys[1]); f[50:100].update(ys[2])
+    assert np.all(f.lw != lw0) and np.all(f.rows[:, :2] != rows0[:, :2])
+    sr = m.info["sr"]
+    for sl, y in ((slice(0, 50), ys[1]), (slice(50, 100), ys[2])):
+        want = sum(-0.5 * ((y[k] - f.rows[sl, k]) / sr) ** 2 - np.log(sr) - 0.5 * np.log(2 * np.pi) for k in range(2))
+        np.testing.assert_allclose(f.lw[sl] - lw0[sl], want, rtol=1e-10, atol=1e-10)
+    lw1, rows1 = f.lw.copy(), f.rows.copy()
+    a = f[0:50]; a.last_obs = ys[1]; a.rejuvenate("move", 1)
+    b = f[50:100]; b.last_obs = ys[2]; b.rejuvenate("reweight", 1)
+    assert np.array_equal(f.lw[:50], lw1[:50])                        # move-accept leaves weights alone
+    assert np.all(f.lw[50:] != lw1[50:]) and np.all(f.rows[50:, :2] != rows1[50:, :2])
+    assert np.array_equal(f.rows[:50, 2:4], rows1[:50, 2:4])           # x_{t-1} untouched
+
+
+# ------------------------------------------------------------------------------------------ GPU parity
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("alpha", [None, 0.5])
+@pytest.mark.parametrize("N,cut", [(100, 50), (10_000, 3_000)])
+def test_hip_views_bitexact(g, o, method, alpha, N, cut):
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 5)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=6, keep_prev=True)
+    orc = o.OracleFilter(model.model_id, model.params, N, 6, keep_prev=True).initialize(ys[0])
+    pf = None if alpha is None else g.Tempering(alpha)
+    kw = dict(sort_particles=True) if method == "stratified" else {}
+    lml_full = g.get_lml_est(st)
+    for (a, b), y in (((0, cut), ys[1]), ((cut, N), ys[2])):
+        sv, ov = st[a:b], orc[a:b]
+        assert sv.n_particles == b - a
+        g.pf_update(sv, (2,), (None,), y); ov.update(y)
+        assert g.get_ess(sv) == ov.effective_sample_size()
+        lml_v = g.get_lml_est(sv)
+        assert lml_v == ov.log_ml_estimate()
+        g.pf_resample(sv, method, priority_fn=pf, check=False, **kw); ov.resample(method, priority_alpha=alpha, check=False, **kw)
+        assert np.array_equal(sv.parents, ov.parents)                 # local to the view
+        np.testing.assert_allclose(g.get_lml_est(sv), lml_v, rtol=1e-9)
+        g.pf_rejuvenate(sv, g.mh, (), 1); ov.rejuvenate("move", 1)
+        assert np.array_equal(sv.traces, ov.rows) and np.array_equal(sv.log_weights, ov.lw)
+    # the source sees everything the views did
+    assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw)
+    assert np.array_equal(st.parents, orc.parents)
+    assert g.get_lml_est(st) == orc.log_ml_estimate() and g.get_ess(st) == orc.effective_sample_size()
+    # and keeps working as a whole
+    g.pf_resample(st, "multinomial", check=False); orc.resample("multinomial", check=False)
+    g.pf_update(st, (3,), (None,), ys[3]); orc.update(ys[3])
+    assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.parents, orc.parents)
+
+
+@pytest.mark.gpu
+def test_hip_view_errors(g, o):
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    st = g.pf_initialize(model, (1,), ys[0], 100, seed=1)
+    v = st[10:60]
+    with pytest.raises(g.ErrorException):
+        st[50:200][0:1]                                   # out of bounds / view of a view
+    with pytest.raises(g.ErrorException):
+        g.pf_resize(v, 10)
+    g.pf_resize(st, 80)
+    with pytest.raises(g.ErrorException):
+        g.get_ess(v)                                      # stale after the parent was resized
