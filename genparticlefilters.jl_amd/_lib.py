@@ -67,6 +67,7 @@ SYMBOLS = [
     ("gpf_history_column", C.c_int, [_H, C.c_int32, C.c_int32, _pd, C.c_int64]),
     ("gpf_history_mean", C.c_int, [_H, C.c_int32, C.c_int32, _pd]),
     ("gpf_history_var", C.c_int, [_H, C.c_int32, C.c_int32, _pd]),
+    ("gpf_proportion", C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, _pd]),
     # shard-level building blocks: device pointers are passed as integers (tensor.data_ptr())
     ("gpf_shard_weight_max", C.c_int, [_H, C.c_void_p]),
     ("gpf_shard_weight_scan", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p]),

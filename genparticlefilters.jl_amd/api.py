@@ -453,3 +453,19 @@ def var(state, addr) -> float:
     else:
         state._check(state._L.gpf_var(state._h, int(addr), C.byref(out)))
     return out.value
+
+
+def proportionmap(state, addr, max_values: int = 256) -> dict:
+    """proportionmap(state, addr), src/statistics.jl:91-101: {value: sum of normalised weights of the particles holding it}
+    for a discrete-valued column (addr = column, or (t, column) for a past choice).  The distinct values are read from
+    the column; each proportion is a weighted reduction on the device."""
+    step, col = (int(addr[0]), int(addr[1])) if isinstance(addr, tuple) else (0, int(addr))
+    vals = np.unique(state.history_column(step, col) if step else state.column(col))
+    if vals.size > max_values:
+        raise ErrorException(f"proportionmap: {vals.size} distinct values; the column does not look discrete")
+    out = {}
+    for v in vals:
+        p = C.c_double()
+        state._check(state._L.gpf_proportion(state._h, step, col, float(v), C.byref(p)))
+        out[float(v)] = p.value
+    return out

@@ -1188,8 +1188,9 @@ __global__ void k_hist_column(const int32_t* const* __restrict__ maps, int n_map
 // sum_i w_i f(v_i) over a plain value array (same weights / reduction as k_wsum)
 __global__ __launch_bounds__(BLOCK) void k_wsum_values(const double* __restrict__ lw, const WSum* ws, int K,
                                                        const double* __restrict__ values, int64_t n, int pw,
-                                                       const double* center, double* __restrict__ partial)
+                                                       const double* center, double match, double* __restrict__ partial)
 {
+    // pw = 1: sum w v;  2: sum w (v - *center)^2;  3: sum w [v == match]  (proportionmap, statistics.jl:91-101)
     const double m = ws->m;
     const double Sd = (double)ws->S;
     const bool uniform = (ws->flags & FLAG_ALL_NEGINF) != 0;
@@ -1199,6 +1200,7 @@ __global__ __launch_bounds__(BLOCK) void k_wsum_values(const double* __restrict_
         const uint64_t q = uniform ? 1 : exp_fix(lw[i] - m, K);
         double v = values[i];
         if (pw == 2) { v = v - c; v = v * v; }
+        if (pw == 3) v = (v == match) ? 1.0 : 0.0;
         acc += ((double)q / Sd) * v;
     }
     acc = wave_sum_f64(acc);

@@ -1244,16 +1244,35 @@ static gpf_status history_stat(gpf_handle h, int32_t step, int32_t column, doubl
     if (s) return s;
     if ((s = ensure_raw(h))) return s;
     const int g = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 1, nullptr, h->partial);
+    hipLaunchKernelGGL(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 1, nullptr, 0.0, h->partial);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
     if (variance) {
-        hipLaunchKernelGGL(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 2, h->dscal, h->partial);
+        hipLaunchKernelGGL(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 2, h->dscal, 0.0, h->partial);
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal + 1);
     }
     double tmp[2];
     if ((s = copy_out(h, h->dscal, tmp, sizeof(tmp)))) return s;
     *out = variance ? tmp[1] : tmp[0];
     return GPF_OK;
+}
+// proportionmap(state, addr)[value] (statistics.jl:91-101): normalised weight of the particles whose column equals `value`;
+// step = 0: the current step's column, step >= 1: a past choice along the ancestry (trajectory store)
+gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double value, double* out)
+{
+    if (!h || !out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    gpf_status s;
+    if (step > 0) { if ((s = history_values(h, step, column))) return s; }
+    else {
+        if ((s = check_ready(h))) return s;
+        if (column < 0 || column >= h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad column");
+        if ((s = materialize(h))) return s;
+        hipLaunchKernelGGL(k_extract_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, column, h->n, h->dtmp);
+    }
+    if ((s = ensure_raw(h))) return s;
+    const int g = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 3, nullptr, value, h->partial);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
+    return copy_out(h, h->dscal, out, sizeof(double));
 }
 gpf_status gpf_history_mean(gpf_handle h, int32_t step, int32_t column, double* out) { return history_stat(h, step, column, out, false); }
 gpf_status gpf_history_var(gpf_handle h, int32_t step, int32_t column, double* out) { return history_stat(h, step, column, out, true); }

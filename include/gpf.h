@@ -196,6 +196,9 @@ gpf_status gpf_history_steps(gpf_handle h, int32_t* n_steps);
 gpf_status gpf_history_column(gpf_handle h, int32_t step, int32_t column, double* out, int64_t n);   /* trace[step => column] per particle */
 gpf_status gpf_history_mean(gpf_handle h, int32_t step, int32_t column, double* out);               /* mean(state, step => column) */
 gpf_status gpf_history_var(gpf_handle h, int32_t step, int32_t column, double* out);                /* var(state, step => column)  */
+/* proportionmap(state, addr)[value]  (src/statistics.jl:91-101): normalised weight of the particles whose column == value;
+ * step = 0 -> current step's column, step >= 1 -> past choice (trajectory store) */
+gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double value, double* out);
 
 /* ---- shard-level building blocks (multi-GPU) ------------------------------------------------------
  * A filter sharded over G GPUs is G handles created with the same seed / n_global and contiguous

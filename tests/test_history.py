@@ -129,6 +129,9 @@ def test_hip_readme_example(g, o):
                 g.pf_rejuvenate(st, g.mh, ()); orc.rejuvenate("move", 1)
             g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
         est.append([g.mean(st, (t, 0)) for t in range(1, 11)])
+        pm = g.proportionmap(st, (6, 0))                                  # statistics.jl:91-101 on a past 0/1 choice
+        assert set(pm) <= {0.0, 1.0} and abs(sum(pm.values()) - 1.0) < 1e-12 and abs(pm.get(1.0, 0.0) - est[-1][5]) < 1e-12
+        assert abs(sum(g.proportionmap(st, 0).values()) - 1.0) < 1e-12
         np.testing.assert_allclose(est[-1], [orc.history_mean(t, 0) for t in range(1, 11)], rtol=1e-9, atol=1e-12)
         assert g.get_lml_est(st) == orc.log_ml_estimate()
     assert np.abs(np.mean(est, axis=0) - exact).max() < 0.1, (np.mean(est, axis=0), exact)
