@@ -9,6 +9,7 @@
 #include "gpf_kernels.hpp"
 
 #include <hipcub/hipcub.hpp>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -22,6 +23,13 @@ using namespace gpf;
 namespace {
 
 thread_local std::string g_err;   // errors before a handle exists
+
+// Kernel timing (gpf_kernel_timing): inside timed() the launch carries a start/stop event pair that the runtime
+// stamps at the kernel's own begin and end (hipExtLaunchKernel), so the elapsed time is the dispatch's duration, the
+// same quantity rocprofv3 --kernel-trace reports -- not launch gap + kernel as with events recorded around the launch.
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+#define GPF_LAUNCH(kernel, grid, block, lds, stream, ...) \
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_ev_start, g_ev_stop, 0, __VA_ARGS__)
 
 struct Timer {
     bool on = false;
@@ -120,9 +128,9 @@ gpf_status timed(gpf_filter* h, int id, F&& launch)
     hipEvent_t a, b;
     HIP_TRY(h, hipEventCreate(&a));
     HIP_TRY(h, hipEventCreate(&b));
-    HIP_TRY(h, hipEventRecord(a, h->stream));
-    launch();
-    HIP_TRY(h, hipEventRecord(b, h->stream));
+    g_ev_start = a; g_ev_stop = b;
+    launch();                       // exactly one GPF_LAUNCH
+    g_ev_start = g_ev_stop = nullptr;
     t.ev.emplace_back(a, b);
     return GPF_OK;
 }
@@ -193,7 +201,10 @@ gpf_status alloc_particle_buffers(gpf_filter* h)
 }
 
 // ------------------------------------------------------------------ model dispatch
-int step_grid(const gpf_filter* h) { return std::min(grid_for(h, h->n, 4), MAX_PARTIALS); }
+#ifndef STEP_BLOCKS_PER_CU
+#define STEP_BLOCKS_PER_CU 4
+#endif
+int step_grid(const gpf_filter* h) { return std::min(grid_for(h, h->n, STEP_BLOCKS_PER_CU), MAX_PARTIALS); }
 
 template <int M, bool KEEP, bool PROP = false>
 void launch_step_t(gpf_filter* h, int grid)
@@ -201,10 +212,10 @@ void launch_step_t(gpf_filter* h, int grid)
     constexpr int Wc = row_width(Model<M>::D, KEEP);
     if constexpr (PROP && !Model<M>::HAS_PROPOSAL) { (void)h; (void)grid; return; }
     else if (h->pending_gather)
-        hipLaunchKernelGGL((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+        GPF_LAUNCH((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags);
     else
-        hipLaunchKernelGGL((k_step<M, Wc, KEEP, false, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+        GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags);
 }
 template <int M, bool PROP = false>
@@ -212,7 +223,7 @@ void launch_init_t(gpf_filter* h, int grid)
 {
     if constexpr (PROP && !Model<M>::HAS_PROPOSAL) { (void)h; (void)grid; return; }
     else
-        hipLaunchKernelGGL((k_init<M, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+        GPF_LAUNCH((k_init<M, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw, h->pmax, h->pflags);
 }
 bool model_has_proposal(int model)
@@ -229,7 +240,7 @@ template <int M, bool RW>
 void launch_move_t(gpf_filter* h, int grid, int n_iters)
 {
     constexpr int Wc = row_width(Model<M>::D, true);
-    hipLaunchKernelGGL((k_move<M, Wc, RW>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+    GPF_LAUNCH((k_move<M, Wc, RW>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                        h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
                        reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
 }
@@ -246,9 +257,9 @@ void launch_gather_ex(gpf_filter* h, const int32_t* anc, const double* in, doubl
 {
     const int grid = grid_for(h, n * (h->W / 2), 8);
     switch (h->W) {
-        case 2: hipLaunchKernelGGL((k_gather<2>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, in, out, pv, lw_out, n); break;
-        case 4: hipLaunchKernelGGL((k_gather<4>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, in, out, pv, lw_out, n); break;
-        case 8: hipLaunchKernelGGL((k_gather<8>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, in, out, pv, lw_out, n); break;
+        case 2: GPF_LAUNCH((k_gather<2>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, in, out, pv, lw_out, n); break;
+        case 4: GPF_LAUNCH((k_gather<4>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, in, out, pv, lw_out, n); break;
+        case 8: GPF_LAUNCH((k_gather<8>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, in, out, pv, lw_out, n); break;
     }
 }
 void launch_gather(gpf_filter* h, const PrioView& pv, double* lw_out)
@@ -260,9 +271,9 @@ void launch_gather_rows_lw(gpf_filter* h, const int32_t* anc, const double* rows
 {
     const int grid = grid_for(h, n * (h->W / 2), 8);
     switch (h->W) {
-        case 2: hipLaunchKernelGGL((k_gather_rows_lw<2>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, rows_in, lw_in, rows_out, lw_out, n); break;
-        case 4: hipLaunchKernelGGL((k_gather_rows_lw<4>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, rows_in, lw_in, rows_out, lw_out, n); break;
-        case 8: hipLaunchKernelGGL((k_gather_rows_lw<8>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, rows_in, lw_in, rows_out, lw_out, n); break;
+        case 2: GPF_LAUNCH((k_gather_rows_lw<2>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, rows_in, lw_in, rows_out, lw_out, n); break;
+        case 4: GPF_LAUNCH((k_gather_rows_lw<4>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, rows_in, lw_in, rows_out, lw_out, n); break;
+        case 8: GPF_LAUNCH((k_gather_rows_lw<8>), dim3(grid), dim3(BLOCK), 0, h->stream, anc, rows_in, lw_in, rows_out, lw_out, n); break;
     }
 }
 
@@ -296,7 +307,7 @@ gpf_status hist_snapshot(gpf_filter* h)
     if (s) return s;
     double*& dst = h->hist_x[h->hist_step];
     if (!dst) HIP_TRY(h, hipMalloc(&dst, (size_t)h->n * h->d * sizeof(double)));
-    hipLaunchKernelGGL(k_hist_snapshot, dim3(grid_for(h, h->n * h->d, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, h->d, h->n, dst);
+    GPF_LAUNCH(k_hist_snapshot, dim3(grid_for(h, h->n * h->d, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, h->d, h->n, dst);
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
@@ -307,7 +318,7 @@ gpf_status hist_on_resample(gpf_filter* h)
     int32_t* old = h->hist_map[h->hist_step];
     int32_t* neu = nullptr;
     HIP_TRY(h, hipMalloc(&neu, (size_t)h->n * sizeof(int32_t)));
-    hipLaunchKernelGGL(k_hist_compose, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, old, h->n, neu);
+    GPF_LAUNCH(k_hist_compose, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, old, h->n, neu);
     HIP_TRY(h, hipGetLastError());
     if (old) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(old); }
     h->hist_map[h->hist_step] = neu;
@@ -336,7 +347,7 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
     const int gs = scan_grid(h);
     const ScanOut so{want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch]};
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
-        hipLaunchKernelGGL((k_scan<In, FIXQ>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, h->pmax, h->pflags, np, slot,
+        GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, h->pmax, h->pflags, np, slot,
                            so, dc, dn, total_out, h->blockQ, &h->sc->timeout);
     });
     if (s) return s;
@@ -355,7 +366,7 @@ gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cd
     else {
         np = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
         s = timed(h, GPF_K_MAX, [&] {
-            hipLaunchKernelGGL(k_max_partial, dim3(np), dim3(BLOCK), 0, h->stream, pv, h->n, h->pmax, h->pflags);
+            GPF_LAUNCH(k_max_partial, dim3(np), dim3(BLOCK), 0, h->stream, pv, h->n, h->pmax, h->pflags);
         });
         if (s) return s;
         h->max_valid = false;       // pmax now describes pv, which may not be the raw log-weights
@@ -462,7 +473,7 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
                                                   h->stream));
     h->sort_tmp_bytes = bytes;
     HIP_TRY(h, hipMalloc(&h->sort_tmp, bytes));
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->idx_in, h->n);
+    GPF_LAUNCH(k_iota, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->idx_in, h->n);
     return GPF_OK;
 }
 
@@ -504,7 +515,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     // sortperm(log_priorities, rev=true)  (resample.jl:156-157)
     if (sorted) {
         if ((s = ensure_sort_buffers(h))) return s;
-        hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, pv, h->n, h->keys);
+        GPF_LAUNCH(k_sort_keys, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, pv, h->n, h->keys);
         HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, h->sort_tmp_bytes, h->keys, h->keys_out, h->idx_in, h->order,
                                                       (int)h->n, 0, 64, h->stream));
     }
@@ -550,9 +561,9 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu * SEARCH_BLOCKS_PER_CU));
     s = timed(h, GPF_K_SEARCH, [&] {
         switch (method) {
-            case GPF_RESAMPLE_MULTINOMIAL: hipLaunchKernelGGL((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
-            case GPF_RESAMPLE_RESIDUAL:    hipLaunchKernelGGL((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
-            default:                       hipLaunchKernelGGL((k_search<2>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
+            case GPF_RESAMPLE_MULTINOMIAL: GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
+            case GPF_RESAMPLE_RESIDUAL:    GPF_LAUNCH((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
+            default:                       GPF_LAUNCH((k_search<2>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
         }
     });
     if (s) return s;
@@ -563,11 +574,11 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         if (s) return s;
         h->cur ^= 1;
         if (pv.mode == 0) {
-            hipLaunchKernelGGL(k_view_fill_weights, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->lw, h->n, &h->sc->raw, h->K, h->logN);
+            GPF_LAUNCH(k_view_fill_weights, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->lw, h->n, &h->sc->raw, h->K, h->logN);
         } else {
             PrioView post{h->lws, nullptr, 0.0, 0};
             if ((s = summarize(h, post, &h->sc->post, false, nullptr, false))) return s;
-            hipLaunchKernelGGL(k_view_apply_post, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->sc, h->K, h->lws, h->lw, h->n);
+            GPF_LAUNCH(k_view_apply_post, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->sc, h->K, h->lws, h->lw, h->n);
         }
         h->max_valid = false;
         HIP_TRY(h, hipGetLastError());
@@ -586,7 +597,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         h->cur ^= 1;
         PrioView post{h->lws, nullptr, 0.0, 0};
         if ((s = summarize(h, post, &h->sc->post, false, nullptr, false))) return s;
-        hipLaunchKernelGGL(k_apply_post, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->sc, h->K, h->logN, h->lws, h->lw, h->n);
+        GPF_LAUNCH(k_apply_post, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->sc, h->K, h->logN, h->lws, h->lw, h->n);
         h->max_valid = false;
     }
     HIP_TRY(h, hipGetLastError());
@@ -648,7 +659,7 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         HIP_TRY(h, hipMemsetAsync(h->sc, 0, sizeof(Scalars), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->lw, 0, n * sizeof(double), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->rows[0], 0, rb, h->stream));
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, h->n);   // parents = 1:N
+        GPF_LAUNCH(k_iota, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, h->n);   // parents = 1:N
         // k_search keeps up to LDS_TILE_TABLE top-level entries (64 KiB) + 32 KiB of cooperation strips in LDS
         const int max_dyn = (int)((lds_pad(LDS_TILE_TABLE) + 4) * sizeof(uint64_t));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<0>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
@@ -709,7 +720,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
     if (s) return s;
     h->pending_gather = false;
     h->max_valid = true; h->max_np = grid;
-    hipLaunchKernelGGL(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
+    GPF_LAUNCH(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
     HIP_TRY(h, hipMemsetAsync(&h->sc->lml_est, 0, sizeof(double), h->stream));                   // log_ml_est = 0.
     HIP_TRY(h, hipGetLastError());
     h->epoch += 1;
@@ -818,7 +829,7 @@ gpf_status gpf_effective_sample_size(gpf_handle h, double* out)
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
     if ((s = ensure_raw(h, true))) return s;
     if (!h->raw_q_folded) {
-        hipLaunchKernelGGL(k_fold_q, dim3(1), dim3(BLOCK), 0, h->stream, &h->sc->raw, h->blockQ, scan_grid(h));
+        GPF_LAUNCH(k_fold_q, dim3(1), dim3(BLOCK), 0, h->stream, &h->sc->raw, h->blockQ, scan_grid(h));
         h->raw_q_folded = true;
     }
     if ((s = fetch_scalars(h))) return s;
@@ -869,7 +880,7 @@ static gpf_status norm_weights(gpf_handle h, double* out, int64_t n, int want_lo
     if (s) return s;
     if (!out || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
     if ((s = ensure_raw(h))) return s;
-    hipLaunchKernelGGL(k_norm_weights, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->n, want_log,
+    GPF_LAUNCH(k_norm_weights, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->n, want_log,
                        h->dtmp);
     return copy_out(h, h->dtmp, out, (size_t)n * sizeof(double));
 }
@@ -880,7 +891,7 @@ gpf_status gpf_get_parents(gpf_handle h, int64_t* out, int64_t n)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!out || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
-    hipLaunchKernelGGL(k_parents, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, h->n, reinterpret_cast<int64_t*>(h->dtmp));
+    GPF_LAUNCH(k_parents, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, h->n, reinterpret_cast<int64_t*>(h->dtmp));
     return copy_out(h, h->dtmp, out, (size_t)n * sizeof(int64_t));
 }
 
@@ -898,7 +909,7 @@ gpf_status gpf_get_column(gpf_handle h, int32_t column, double* out, int64_t n)
     if (s) return s;
     if (!out || n != h->n || column < 0 || column >= h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad column/output");
     if ((s = materialize(h))) return s;
-    hipLaunchKernelGGL(k_extract_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, column, h->n, h->dtmp);
+    GPF_LAUNCH(k_extract_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, column, h->n, h->dtmp);
     return copy_out(h, h->dtmp, out, (size_t)n * sizeof(double));
 }
 
@@ -944,13 +955,13 @@ static gpf_status wstat(gpf_handle h, int32_t column, double* out, bool variance
     if (!out || column < 0 || column >= h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad column/output");
     if ((s = ensure_raw(h))) return s;
     const int g = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_wsum, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->rows[h->cur], h->W, column, h->n, 1,
+    GPF_LAUNCH(k_wsum, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->rows[h->cur], h->W, column, h->n, 1,
                        nullptr, h->partial);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
+    GPF_LAUNCH(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
     if (variance) {
-        hipLaunchKernelGGL(k_wsum, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->rows[h->cur], h->W, column, h->n, 2,
+        GPF_LAUNCH(k_wsum, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->rows[h->cur], h->W, column, h->n, 2,
                            h->dscal, h->partial);
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal + 1);
+        GPF_LAUNCH(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal + 1);
     }
     double tmp[2];
     if ((s = copy_out(h, h->dscal, tmp, sizeof(tmp)))) return s;
@@ -996,7 +1007,7 @@ gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const do
     HIP_TRY(h, hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(db, b ? b : a, bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(d2, 0, bytes, h->stream));
-    hipLaunchKernelGGL(k_debug_math, dim3(grid_for(h, n, 8)), dim3(BLOCK), 0, h->stream, which, da, db, n, h->cfg.seed, h->epoch,
+    GPF_LAUNCH(k_debug_math, dim3(grid_for(h, n, 8)), dim3(BLOCK), 0, h->stream, which, da, db, n, h->cfg.seed, h->epoch,
                        (uint32_t)TAG_UPDATE, d1, d2);
     HIP_TRY(h, hipMemcpyAsync(out, d1, bytes, hipMemcpyDeviceToHost, h->stream));
     if (out2) HIP_TRY(h, hipMemcpyAsync(out2, d2, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1124,14 +1135,14 @@ gpf_status gpf_resize(gpf_handle h, int64_t n_new, int32_t method, double priori
     const int64_t top_n = nt * ntiles_old * 8 <= LDS_TILE_TABLE ? ntiles_old * 8 : (nt * ntiles_old <= LDS_TILE_TABLE ? ntiles_old : 0);
     const size_t lds = (size_t)(nt * (lds_pad(top_n) + 1)) * sizeof(uint64_t);
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((n_new + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
-    if (method == GPF_RESAMPLE_RESIDUAL) hipLaunchKernelGGL((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
-    else                                 hipLaunchKernelGGL((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
+    if (method == GPF_RESAMPLE_RESIDUAL) GPF_LAUNCH((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
+    else                                 GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
     // new_traces .= view(traces, parents) + update_weights!(state, n_particles, log_priorities)   resize.jl:64-66,424-438
     launch_gather_ex(h, h->anc, old.rows[old.cur], h->rows[0], pv, pv.mode == 0 ? h->lw : h->lws, n_new);
     if (pv.mode != 0) {
         PrioView post{h->lws, nullptr, 0.0, 0};
         if ((s = summarize(h, post, &h->sc->post, false, nullptr, false))) { free_bufs(old); return s; }
-        hipLaunchKernelGGL(k_apply_post, dim3(grid_for(h, n_new, 8)), dim3(BLOCK), 0, h->stream, h->sc, h->K, h->logN, h->lws, h->lw, n_new);
+        GPF_LAUNCH(k_apply_post, dim3(grid_for(h, n_new, 8)), dim3(BLOCK), 0, h->stream, h->sc, h->K, h->logN, h->lws, h->lw, n_new);
         h->max_valid = false;
     }
     (void)Kp;
@@ -1151,7 +1162,7 @@ gpf_status gpf_replicate(gpf_handle h, int32_t n_replicates, int32_t interleaved
     Bufs old = take_particle_buffers(h);
     set_count(h, n_new);
     if ((s = alloc_particle_buffers(h))) { free_bufs(old); return s; }
-    hipLaunchKernelGGL(k_replicate_anc, dim3(grid_for(h, n_new, 8)), dim3(BLOCK), 0, h->stream, n_new, n_old, (int)n_replicates,
+    GPF_LAUNCH(k_replicate_anc, dim3(grid_for(h, n_new, 8)), dim3(BLOCK), 0, h->stream, n_new, n_old, (int)n_replicates,
                        (int)(interleaved != 0), 0, h->anc);
     launch_gather_rows_lw(h, h->anc, old.rows[old.cur], old.lw, h->rows[0], h->lw, n_new);     // resize.jl:240-242
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1172,12 +1183,12 @@ gpf_status gpf_dereplicate(gpf_handle h, int32_t n_replicates, int32_t interleav
     if ((s = alloc_particle_buffers(h))) { free_bufs(old); return s; }
     const int grid = grid_for(h, n_new, 8);
     if (sample) {                                                                                // resize.jl:281-293
-        hipLaunchKernelGGL(k_dereplicate_sample, dim3(grid), dim3(BLOCK), 0, h->stream, old.lw, n_new, n_old, (int)n_replicates,
+        GPF_LAUNCH(k_dereplicate_sample, dim3(grid), dim3(BLOCK), 0, h->stream, old.lw, n_new, n_old, (int)n_replicates,
                            (int)(interleaved != 0), h->cfg.seed, h->epoch, fix_K(n_replicates), log_((double)n_replicates), h->anc, h->lw);
         launch_gather_rows_lw(h, h->anc, old.rows[old.cur], old.lw, h->rows[0], nullptr, n_new);
         h->epoch += 1;
     } else {                                                                                     // :keepfirst, resize.jl:274-279
-        hipLaunchKernelGGL(k_replicate_anc, dim3(grid), dim3(BLOCK), 0, h->stream, n_new, n_old, (int)n_replicates,
+        GPF_LAUNCH(k_replicate_anc, dim3(grid), dim3(BLOCK), 0, h->stream, n_new, n_old, (int)n_replicates,
                            (int)(interleaved != 0), 1, h->anc);
         launch_gather_rows_lw(h, h->anc, old.rows[old.cur], old.lw, h->rows[0], h->lw, n_new);
     }
@@ -1222,7 +1233,7 @@ static gpf_status history_values(gpf_handle h, int32_t step, int32_t column)
     if (!maps.empty())
         HIP_TRY(h, hipMemcpyAsync(h->hist_dev_maps, maps.data(), maps.size() * sizeof(int32_t*), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));                   // `maps` is a host temporary
-    hipLaunchKernelGGL(k_hist_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->hist_dev_maps, (int)maps.size(),
+    GPF_LAUNCH(k_hist_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->hist_dev_maps, (int)maps.size(),
                        h->hist_x[step - 1], h->d, (int)column, h->n, h->dtmp);
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
@@ -1244,11 +1255,11 @@ static gpf_status history_stat(gpf_handle h, int32_t step, int32_t column, doubl
     if (s) return s;
     if ((s = ensure_raw(h))) return s;
     const int g = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 1, nullptr, 0.0, h->partial);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
+    GPF_LAUNCH(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 1, nullptr, 0.0, h->partial);
+    GPF_LAUNCH(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
     if (variance) {
-        hipLaunchKernelGGL(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 2, h->dscal, 0.0, h->partial);
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal + 1);
+        GPF_LAUNCH(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 2, h->dscal, 0.0, h->partial);
+        GPF_LAUNCH(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal + 1);
     }
     double tmp[2];
     if ((s = copy_out(h, h->dscal, tmp, sizeof(tmp)))) return s;
@@ -1266,12 +1277,12 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
         if ((s = check_ready(h))) return s;
         if (column < 0 || column >= h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad column");
         if ((s = materialize(h))) return s;
-        hipLaunchKernelGGL(k_extract_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, column, h->n, h->dtmp);
+        GPF_LAUNCH(k_extract_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, column, h->n, h->dtmp);
     }
     if ((s = ensure_raw(h))) return s;
     const int g = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 3, nullptr, value, h->partial);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
+    GPF_LAUNCH(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 3, nullptr, value, h->partial);
+    GPF_LAUNCH(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
     return copy_out(h, h->dscal, out, sizeof(double));
 }
 gpf_status gpf_history_mean(gpf_handle h, int32_t step, int32_t column, double* out) { return history_stat(h, step, column, out, false); }
@@ -1295,12 +1306,12 @@ gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
     if (!h->max_valid) {
         gp = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
         s = timed(h, GPF_K_MAX, [&] {
-            hipLaunchKernelGGL(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, raw_view(h), h->n, h->pmax, h->pflags);
+            GPF_LAUNCH(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, raw_view(h), h->n, h->pmax, h->pflags);
         });
         if (s) return s;
     }
     h->max_valid = false;            // gpf_shard_weight_scan overwrites pmax[0] with the global maximum
-    hipLaunchKernelGGL(k_pack_mflags, dim3(1), dim3(BLOCK), 0, h->stream, h->pmax, h->pflags, gp, out2);
+    GPF_LAUNCH(k_pack_mflags, dim3(1), dim3(BLOCK), 0, h->stream, h->pmax, h->pflags, gp, out2);
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
@@ -1310,12 +1321,12 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!mf_all || !out5 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
-    hipLaunchKernelGGL(k_unpack_mflags, dim3(1), dim3(64), 0, h->stream, mf_all, (int)G, h->pmax, h->pflags);
+    GPF_LAUNCH(k_unpack_mflags, dim3(1), dim3(64), 0, h->stream, mf_all, (int)G, h->pmax, h->pflags);
     h->max_valid = false;
     InFixQ in{raw_view(h), nullptr, h->K, 0.0, 0};
     const int gs = scan_grid(h);
     if ((s = scan_launch<InFixQ, 2>(h, 0, in, 1, &h->sc->raw, true, &h->sc->raw.S))) return s;
-    hipLaunchKernelGGL(k_export_summary, dim3(1), dim3(BLOCK), 0, h->stream, &h->sc->raw, h->blockQ, gs, out5);
+    GPF_LAUNCH(k_export_summary, dim3(1), dim3(BLOCK), 0, h->stream, &h->sc->raw, h->blockQ, gs, out5);
     HIP_TRY(h, hipGetLastError());
     h->raw_valid = false;            // sc->raw holds a LOCAL sum under a GLOBAL max: not the unsharded summary
     return GPF_OK;
@@ -1327,9 +1338,9 @@ gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t
     if (s) return s;
     if (!tot_all || !out2 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     // global S into sc->prio (the local CDF in cdf[0] stays local)
-    hipLaunchKernelGGL(k_set_global, dim3(1), dim3(64), 0, h->stream, tot_all, (int)G, &h->sc->prio);
+    GPF_LAUNCH(k_set_global, dim3(1), dim3(64), 0, h->stream, tot_all, (int)G, &h->sc->prio);
     if ((s = residual_scans(h, &h->sc->prio, h->cfg.n_global))) return s;
-    hipLaunchKernelGGL(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2);
+    GPF_LAUNCH(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2);
     HIP_TRY(h, hipGetLastError());
     h->serve_residual = true;
     return GPF_OK;
@@ -1349,27 +1360,27 @@ gpf_status gpf_shard_route(gpf_handle h, int32_t method, const int64_t* tot_all,
         HIP_TRY(h, hipMalloc(&h->route_offsets, (size_t)5 * MAX_SHARDS * sizeof(int64_t)));
     }
     int64_t* off = h->route_offsets;             // [S_all | C_all | R_all | w_incl | c_incl], each G long
-    hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(64), 0, h->stream, tot_all, method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr, (int)G, off);
+    GPF_LAUNCH(k_shard_offsets, dim3(1), dim3(64), 0, h->stream, tot_all, method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr, (int)G, off);
     int64_t* T = reinterpret_cast<int64_t*>(h->dtmp);
     const int grid = grid_for(h, h->n, 8);
     s = timed(h, GPF_K_SEARCH, [&] {
         switch (method) {
             case GPF_RESAMPLE_MULTINOMIAL:
-                hipLaunchKernelGGL((k_targets<0>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
+                GPF_LAUNCH((k_targets<0>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
                                    h->cfg.n_global, off, (int)G, T); break;
             case GPF_RESAMPLE_RESIDUAL:
-                hipLaunchKernelGGL((k_targets<1>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
+                GPF_LAUNCH((k_targets<1>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
                                    h->cfg.n_global, off, (int)G, T); break;
             default:
-                hipLaunchKernelGGL((k_targets<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
+                GPF_LAUNCH((k_targets<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
                                    h->cfg.n_global, off, (int)G, T); break;
         }
     });
     if (s) return s;
     RouteArgs a{T, off + 3 * G, off + 4 * G, (int)G, h->n, h->route_counts, T_sorted, perm, counts};
-    hipLaunchKernelGGL(k_route_count, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, a);
-    hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(BLOCK), 0, h->stream, h->route_counts, nblocks, (int)G, counts);
-    hipLaunchKernelGGL(k_route_scatter, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, a);
+    GPF_LAUNCH(k_route_count, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, a);
+    GPF_LAUNCH(k_route_scan, dim3(1), dim3(BLOCK), 0, h->stream, h->route_counts, nblocks, (int)G, counts);
+    GPF_LAUNCH(k_route_scatter, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
@@ -1390,11 +1401,11 @@ gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, 
         const CdfLevels lw_ = levels(h, h->serve_residual ? 2 : 0);
         const CdfLevels lc_ = levels(h, h->serve_residual ? 1 : 0);
         switch (h->W) {
-            case 2: hipLaunchKernelGGL((k_serve<2>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
+            case 2: GPF_LAUNCH((k_serve<2>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
                                        h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], packed_out); break;
-            case 4: hipLaunchKernelGGL((k_serve<4>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
+            case 4: GPF_LAUNCH((k_serve<4>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
                                        h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], packed_out); break;
-            case 8: hipLaunchKernelGGL((k_serve<8>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
+            case 8: GPF_LAUNCH((k_serve<8>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
                                        h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], packed_out); break;
         }
     });
@@ -1411,11 +1422,11 @@ gpf_status gpf_shard_commit(gpf_handle h, const double* packed, const int64_t* p
     const int grid = grid_for(h, h->n, 8);
     double* out = h->rows[1 - h->cur];
     switch (h->W) {
-        case 2: hipLaunchKernelGGL((k_commit_permuted<2>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
-        case 4: hipLaunchKernelGGL((k_commit_permuted<4>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
-        case 8: hipLaunchKernelGGL((k_commit_permuted<8>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
+        case 2: GPF_LAUNCH((k_commit_permuted<2>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
+        case 4: GPF_LAUNCH((k_commit_permuted<4>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
+        case 8: GPF_LAUNCH((k_commit_permuted<8>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
     }
-    hipLaunchKernelGGL(k_lml_global, dim3(1), dim3(64), 0, h->stream, mf_all, tot_all, (int)G, h->K, h->logN, h->sc);
+    GPF_LAUNCH(k_lml_global, dim3(1), dim3(64), 0, h->stream, mf_all, tot_all, (int)G, h->K, h->logN, h->sc);
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;
     h->epoch += 1;
