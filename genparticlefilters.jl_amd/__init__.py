@@ -8,4 +8,4 @@ from .api import (DeviceParticleFilterState, DeviceParticleFilterSubState, Parti
                   pf_stratified_resample, pf_rejuvenate, pf_move_accept, pf_move_reweight,
                   pf_resize, pf_multinomial_resize, pf_residual_resize, pf_replicate, pf_dereplicate,
                   effective_sample_size, get_ess, log_ml_estimate, get_lml_est, get_log_weights,
-                  get_log_norm_weights, get_norm_weights, get_traces, mean, var, proportionmap)
+                  get_log_norm_weights, get_norm_weights, get_traces, sample_unweighted_traces, mean, var, proportionmap)

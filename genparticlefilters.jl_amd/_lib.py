@@ -52,6 +52,7 @@ SYMBOLS = [
     ("gpf_get_rows", C.c_int, [_H, _pd, C.c_int64]),
     ("gpf_set_rows", C.c_int, [_H, _pd, C.c_int64]),
     ("gpf_set_log_weights", C.c_int, [_H, _pd, C.c_int64]),
+    ("gpf_sample_unweighted", C.c_int, [_H, C.c_int64, _pd, _pi64]),
     ("gpf_mean", C.c_int, [_H, C.c_int32, _pd]),
     ("gpf_var", C.c_int, [_H, C.c_int32, _pd]),
     ("gpf_kernel_timing", C.c_int, [_H, C.c_int32, C.c_int32]),

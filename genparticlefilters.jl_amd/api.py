@@ -433,6 +433,15 @@ def get_traces(state) -> np.ndarray:
     return state.traces
 
 
+def sample_unweighted_traces(state, n_samples: int, return_indices: bool = False):
+    """Gen.sample_unweighted_traces(state, n_samples) (src/utils.jl:189-194 extends it to sub-states): n i.i.d. particles drawn
+    with probability proportional to their weights; the filter itself is left untouched."""
+    rows = np.empty((int(n_samples), state.row_width))
+    idx = np.empty(int(n_samples), np.int64)
+    state._check(state._L.gpf_sample_unweighted(state._h, int(n_samples), _pd(rows), idx.ctypes.data_as(C.POINTER(C.c_int64))))
+    return (rows, idx) if return_indices else rows
+
+
 # ----------------------------------------------------------------------------- statistics (src/statistics.jl)
 def mean(state, addr) -> float:
     """mean(state, addr), src/statistics.jl:13-14.  addr = column of the current-step latent, or a pair

@@ -1016,6 +1016,42 @@ gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const do
     return GPF_OK;
 }
 
+// Gen.sample_unweighted_traces(state, n_samples) (reference src/utils.jl:7,189-194): n i.i.d. draws from the normalised
+// weights, WITHOUT touching the filter (no log-ML update, weights unchanged).  Same CDF + search kernels as a resample.
+gpf_status gpf_sample_unweighted(gpf_handle h, int64_t n_samples, double* rows_out, int64_t* idx_out)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (n_samples < 1 || n_samples >= ((int64_t)1 << 31) || !rows_out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, "not available on shards");
+    if ((s = ensure_raw(h))) return s;                            // CDF of state.log_weights in cdf[0]
+    if ((s = fetch_scalars(h))) return s;
+    if (h->h_sc->raw.flags & (FLAG_NAN | FLAG_POSINF)) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights (NaN).");
+    int32_t* anc = nullptr; double* rows = nullptr; int64_t* idx64 = nullptr;
+    HIP_TRY(h, hipMalloc(&anc, (size_t)n_samples * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(&rows, (size_t)n_samples * h->W * sizeof(double)));
+    SearchArgs sa{};
+    sa.w = levels(h, 0); sa.c = levels(h, 0); sa.ntiles = h->ntiles; sa.order = nullptr; sa.sc = h->sc; sa.ws = &h->sc->raw;
+    sa.raw = &h->sc->raw; sa.n = n_samples; sa.n_cells = h->n; sa.n_global = n_samples; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed;
+    sa.epoch = h->epoch; sa.K = h->K; sa.logN = h->logN; sa.update_lml = 0; sa.anc = anc;
+    const int64_t top_n = h->ntiles * 8 <= LDS_TILE_TABLE ? h->ntiles * 8 : (h->ntiles <= LDS_TILE_TABLE ? h->ntiles : 0);
+    const size_t lds = (size_t)(lds_pad(top_n) + 1) * sizeof(uint64_t);
+    const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((n_samples + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
+    GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
+    launch_gather_rows_lw(h, anc, h->rows[h->cur], h->lw, rows, nullptr, n_samples);
+    HIP_TRY(h, hipMemcpyAsync(rows_out, rows, (size_t)n_samples * h->W * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (idx_out) {
+        HIP_TRY(h, hipMalloc(&idx64, (size_t)n_samples * sizeof(int64_t)));
+        GPF_LAUNCH(k_parents, dim3(grid_for(h, n_samples, 8)), dim3(BLOCK), 0, h->stream, anc, n_samples, idx64);
+        HIP_TRY(h, hipMemcpyAsync(idx_out, idx64, (size_t)n_samples * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(anc); (void)hipFree(rows); if (idx64) (void)hipFree(idx64);
+    h->epoch += 1;
+    if (h->parent) h->parent->epoch = h->epoch;
+    return GPF_OK;
+}
+
 // =================================================================================== sub-state views (src/view.jl)
 gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_handle* out)
 {

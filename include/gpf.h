@@ -142,6 +142,11 @@ gpf_status gpf_get_rows(gpf_handle h, double* out, int64_t n_doubles);          
 gpf_status gpf_set_rows(gpf_handle h, const double* rows, int64_t n_doubles);   /* ParticleFilterState(trs, ws), src/initialize.jl:8-10 */
 gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n);
 
+/* Gen.sample_unweighted_traces(state, n_samples)                    src/utils.jl:7,189-194
+ * n_samples i.i.d. draws from the normalised weights; the filter is not modified.  rows_out: HOST [n_samples][row_width];
+ * idx_out (may be NULL): HOST 1-based indices of the drawn particles. */
+gpf_status gpf_sample_unweighted(gpf_handle h, int64_t n_samples, double* rows_out, int64_t* idx_out);
+
 /* ---- statistics ---------------------------------------------------------------------------- */
 /* mean(state, addr)                                                 src/statistics.jl:13-14 */
 gpf_status gpf_mean(gpf_handle h, int32_t column, double* out);

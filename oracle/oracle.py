@@ -408,6 +408,15 @@ class OracleFilter:
         self._set_count(n_new)
         return self
 
+    # -- Gen.sample_unweighted_traces (utils.jl:189-194): categorical draws, state untouched
+    def sample_unweighted(self, n_samples: int):
+        s = self.summary()
+        if s.bad:
+            raise OracleError("Invalid weights (NaN).")
+        idx = upper_bound(s.cdf, targets_multinomial(self.seed, self.epoch, 0, int(n_samples), s.S))
+        self.epoch += 1
+        return self.rows[idx].copy(), idx + 1
+
     # -- statistics.jl:13-14, 48-50
     def mean(self, col: int) -> float:
         s = self.summary()

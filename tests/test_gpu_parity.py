@@ -171,3 +171,18 @@ def test_mean_var(g, o, name):
         np.testing.assert_allclose(g.mean(st, c), orc.mean(c), rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(g.var(st, c), orc.var(c), rtol=1e-9, atol=1e-14)
         assert np.array_equal(st.column(c), orc.column(c))
+
+
+# ------------------------------------------------------------------ Gen.sample_unweighted_traces (utils.jl:189-194)
+@pytest.mark.parametrize("n_samples", [10, 5000, 40_000])
+def test_sample_unweighted_traces(g, o, n_samples):
+    model, ys, st, orc = make_pair(g, o, "lgssm2", 20_000, 8, False)
+    before = (st.traces, st.log_weights, g.get_lml_est(st))
+    rows, idx = g.sample_unweighted_traces(st, n_samples, return_indices=True)
+    orows, oidx = orc.sample_unweighted(n_samples)
+    assert np.array_equal(idx, oidx) and np.array_equal(rows, orows)
+    assert np.array_equal(rows, before[0][idx - 1])
+    assert np.array_equal(st.traces, before[0]) and np.array_equal(st.log_weights, before[1]) and g.get_lml_est(st) == before[2]
+    if n_samples >= 5000:                                  # high-weight particles are drawn more often
+        cnt = np.bincount(idx - 1, minlength=20_000)
+        assert np.corrcoef(cnt, g.get_norm_weights(st))[0, 1] > 0.5
