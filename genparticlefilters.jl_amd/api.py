@@ -369,12 +369,19 @@ def pf_residual_resize(state, n_particles: int, *, priority_fn=None, check="warn
     return _resize(state, n_particles, 1, priority_fn, check)
 
 
+def pf_optimal_resize(state, n_particles: int, *, check="warn"):
+    """src/resize.jl:149-200 (Fearnhead & Clifford): n_particles must not exceed the current count"""
+    return _resize(state, n_particles, 3, None, check)
+
+
 def pf_resize(state, n_particles: int, method: str = "multinomial", **kwargs):
-    """src/resize.jl:16-28 (:optimal is not native: it stays on the reference's CPU path)"""
+    """src/resize.jl:16-28"""
     if method == "multinomial":
         return pf_multinomial_resize(state, n_particles, **kwargs)
     if method == "residual":
         return pf_residual_resize(state, n_particles, **kwargs)
+    if method == "optimal":
+        return pf_optimal_resize(state, n_particles, **kwargs)
     raise ErrorException(f"Resampling method {method} not recognized.")
 
 

@@ -41,6 +41,8 @@ struct Scalars {
     uint64_t n_accept;         // accepted MH moves of the last gpf_rejuvenate
     int32_t  timeout;          // set if a bounded inter-workgroup spin gave up (never expected)
     int32_t  pad;
+    long long opt_d;           // optimal resize: threshold position in the descending order (-1: none)
+    uint64_t opt_a, opt_B;     // optimal resize: inverse weight threshold c = a S / B as the exact pair (a, B)
 };
 
 // how the resampler sees the weights: log_priorities = priority_fn.(log_weights) (resample.jl:51-52)
@@ -403,6 +405,34 @@ struct InResidual {            // from the weight CDF: counts (N q_i) div S, or 
     }
 };
 
+// a <= ... products of a 31-bit count and a 62-bit weight need 128 bits:  B <= a * k
+__device__ __forceinline__ bool le_mul(uint64_t B, uint64_t a, uint64_t k)
+{
+    return __umul64hi(a, k) != 0 || B <= a * k;
+}
+struct InOptimal {             // optimal resize (resize.jl:156-167): keep flags [c w_i >= 1], or the weights of the others
+    const double* lw;
+    const WSum* ws;            // summary of state.log_weights
+    const Scalars* sc;         // (opt_a, opt_B)
+    int K;
+    int mode;                  // 0: keep flags; 1: q_i of the particles not kept; 2: 1 for every particle not kept
+    __device__ __forceinline__ uint64_t one(int64_t i, double m, bool uniform, bool bad, uint64_t a, uint64_t B) const
+    {
+        const uint64_t q = uniform ? 1 : (bad ? 0 : exp_fix(lw[i] - m, K));
+        const bool keep = le_mul(B, a, q);
+        return mode == 0 ? (uint64_t)keep : (keep ? 0 : (mode == 2 ? 1 : q));
+    }
+    __device__ __forceinline__ void load2(int64_t idx, int64_t n, uint64_t& q0, uint64_t& q1) const
+    {
+        const double m = ws->m;
+        const int fl = ws->flags;
+        const bool uniform = (fl & FLAG_ALL_NEGINF) != 0, bad = (fl & (FLAG_NAN | FLAG_POSINF)) != 0;
+        const uint64_t a = sc->opt_a, B = sc->opt_B;
+        q0 = idx < n ? one(idx, m, uniform, bad, a, B) : 0;
+        q1 = idx + 1 < n ? one(idx + 1, m, uniform, bad, a, B) : 0;
+    }
+};
+
 // where a scan writes: the CDF (padded to whole tiles) and its coarser levels, by-products of the same pass
 struct ScanOut {
     uint64_t* cdf;             // [ntiles*2048] inclusive prefix of every element (nullptr: totals only)
@@ -755,13 +785,13 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
     if (false)
 #endif
         a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
-    const uint64_t S = (METHOD == 1) ? a.sc->Rs : a.ws->S;
+    const uint64_t S = (METHOD == 1 || METHOD == 3) ? a.sc->Rs : a.ws->S;
     const uint64_t N = (uint64_t)a.n_global;
     // stratified: S = N B + rem, once per workgroup (u64 division is ~100 instructions)
     __shared__ uint64_t s_div[2];
     __shared__ ulonglong2 s_coop[2 * SBLOCK];
     ulonglong2* const lds_wave = s_coop + wave_id() * (2 * WAVE);
-    if (METHOD == 2) {
+    if (METHOD == 2 || METHOD == 3) {
         if (threadIdx.x == 0) { s_div[0] = S / N; s_div[1] = S % N; }
         __syncthreads();
     }
@@ -779,7 +809,8 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
 #ifdef GPF_ABL_SEARCH_NOPHILOX
             const uint64_t U = jg * 0x9E3779B97F4A7C15ull;
 #else
-            const Philox b = rng(a.seed, (uint32_t)(a.gid0 + jl), 0, a.epoch, TAG_RESAMPLE);   // RNG keyed by the global id
+            // RNG keyed by the global id; systematic sampling (METHOD 3) draws ONE uniform for all slots
+            const Philox b = rng(a.seed, METHOD == 3 ? 0u : (uint32_t)(a.gid0 + jl), 0, a.epoch, TAG_RESAMPLE);
             const uint64_t U = u64(b.w0, b.w1);
 #endif
             head[u] = false; top[u] = st.topw; L[u] = &a.w;
@@ -790,6 +821,8 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
                 const uint64_t q1 = q0 + ((x0 - q0 * N) + rem >= N ? 1 : 0);      // floor((x0 + rem)/N), rem < N
                 const uint64_t L0 = jg * B + q0, L1 = (jg + 1) * B + q1;
                 T[u] = L0 + mulhi64(U, L1 - L0);
+            } else if (METHOD == 3) {                                 // systematic: floor((j S + floor(U S)) / n), resize.jl:170-178
+                T[u] = jg * s_div[0] + (jg * s_div[1] + mulhi64(U, S)) / N;
             } else {                                                  // residual, resample.jl:96-115
                 head[u] = jg < Ctot;
                 T[u] = head[u] ? jg : mulhi64(U, S);
@@ -802,7 +835,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
         continue;
 #endif
         // coherent targets (stratified; residual waves that are all deterministic copies) read their lines per lane
-        const bool coop = METHOD == 0 ? true : (METHOD == 2 ? false : __any(!head[0] || !head[1]) != 0);
+        const bool coop = METHOD == 0 ? true : (METHOD == 2 || METHOD == 3 ? false : __any(!head[0] || !head[1]) != 0);
         int64_t idx[2];
         search_pair(st, L, top, T, coop, lds_wave, a.n_cells, a.ntiles, idx);
 #pragma unroll
@@ -1129,6 +1162,51 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows_lw(const int32_t* __restr
         if (c == 0 && lw_out) lw_out[j] = lw_in[a];
     }
 }
+// ---- pf_optimal_resize! (resize.jl:149-219) in exact fixed point
+// find_inv_w_threshold (resize.jl:203-219) on the DESCENDING order: position d holds kappa = q_(d), A = d weights
+// before it and B = S - C[d-1] from it on; the reference's first kappa (ascending) with B / kappa + A <= n is the
+// LARGEST such d.  The condition is constant over ties, and d < n is necessary.
+__global__ __launch_bounds__(BLOCK) void k_opt_threshold(const uint64_t* __restrict__ cdf_desc, const WSum* ws, int64_t n_new,
+                                                         int64_t n_old, Scalars* sc)
+{
+    const uint64_t S = ws->S;
+    const int64_t lim = n_new < n_old ? n_new : n_old;
+    long long best = -1;
+    for (int64_t d = (int64_t)blockIdx.x * BLOCK + threadIdx.x; d < lim; d += (int64_t)gridDim.x * BLOCK) {
+        const uint64_t prev = d > 0 ? cdf_desc[d - 1] : 0;
+        const uint64_t kappa = cdf_desc[d] - prev;
+        if (kappa > 0 && le_mul(S - prev, (uint64_t)(n_new - d), kappa)) best = d;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { const long long o = __shfl_xor(best, s, WAVE); best = o > best ? o : best; }
+    if (lane_id() == 0 && best >= 0) atomicMax(&sc->opt_d, best);
+}
+// c = (n - A) / B, or float(n) when no kappa qualifies (resize.jl:215,218), as the pair (a, B): c w_i >= 1 <=> a q_i >= B
+__global__ void k_opt_params(const uint64_t* __restrict__ cdf_desc, const WSum* ws, int64_t n_new, Scalars* sc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long d = sc->opt_d;
+    sc->opt_a = d < 0 ? (uint64_t)n_new : (uint64_t)(n_new - d);
+    sc->opt_B = d <= 0 ? ws->S : ws->S - cdf_desc[d - 1];
+}
+// parents[1:n_keep] .= findall(keep_idxs) (resize.jl:159,180) from the inclusive scan of the keep flags
+__global__ __launch_bounds__(BLOCK) void k_opt_keep_scatter(const uint64_t* __restrict__ keepcdf, int64_t n_old, int32_t* __restrict__ anc)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_old; i += (int64_t)gridDim.x * BLOCK) {
+        const uint64_t c = keepcdf[i], p = i > 0 ? keepcdf[i - 1] : 0;
+        if (c != p) anc[p] = (int32_t)i;
+    }
+}
+// log_weights (resize.jl:189-195): kept particles keep theirs, the others get logsumexp - log c; all + log(n / n_old)
+__global__ __launch_bounds__(BLOCK) void k_opt_weights(double* __restrict__ lw, int64_t n, const Scalars* sc, const WSum* ws, int K,
+                                                       double log_n_ratio)
+{
+    const int64_t n_keep = (int64_t)sc->Ctot;
+    const double rw = lse_from(ws->m, sc->opt_B, K, ws->flags) - log_((double)sc->opt_a);
+    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * BLOCK)
+        lw[j] = (j < n_keep ? lw[j] : rw) + log_n_ratio;
+}
+
 // pf_dereplicate! method = :sample (resize.jl:281-293): one categorical draw per block of k replicates, with the
 // block's softmax in K_b-bit fixed point (same spec as §3.3 of DESIGN.md, N = k); new weight = logsumexp(block) - log k
 __global__ void k_dereplicate_sample(const double* __restrict__ lw, int64_t n_new, int64_t n_old, int k, int interleaved,

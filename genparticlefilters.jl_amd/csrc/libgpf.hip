@@ -1128,12 +1128,82 @@ gpf_status gpf_n_particles(gpf_handle h, int64_t* out)
     return GPF_OK;
 }
 
+// pf_optimal_resize! (resize.jl:149-200): keep every particle with c w_i >= 1, resample the rest by systematic
+// sampling, in exact fixed point.  n_new <= n_old.
+static gpf_status resize_optimal(gpf_handle h, int64_t n_new, int32_t check, int32_t* invalid)
+{
+    const int64_t n_old = h->n;
+    if (n_new < 1 || n_new > n_old) return fail(h, GPF_ERR_INVALID_ARGUMENT, "optimal resize: need 1 <= n_particles <= current count");   // resize.jl:185
+    gpf_status s;
+    // sort(weights) (resize.jl:204), descending; safe_softmax + logsumexp (resize.jl:152,190) over that order
+    if ((s = ensure_sort_buffers(h))) return s;
+    if ((s = ensure_residual_buffers(h))) return s;
+    const PrioView pv = raw_view(h);
+    GPF_LAUNCH(k_sort_keys, dim3(grid_for(h, n_old, 8)), dim3(BLOCK), 0, h->stream, pv, n_old, h->keys);
+    HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, h->sort_tmp_bytes, h->keys, h->keys_out, h->idx_in, h->order,
+                                                  (int)n_old, 0, 64, h->stream));
+    WSum* ws = &h->sc->raw;
+    h->raw_valid = false;
+    if ((s = summarize(h, pv, ws, true, h->order, true))) return s;
+    HIP_TRY(h, hipMemsetAsync(&h->sc->opt_d, 0xff, sizeof(long long), h->stream));
+    GPF_LAUNCH(k_opt_threshold, dim3(grid_for(h, n_new, 8)), dim3(BLOCK), 0, h->stream, h->cdf[0], ws, n_new, n_old, h->sc);
+    GPF_LAUNCH(k_opt_params, dim3(1), dim3(1), 0, h->stream, h->cdf[0], ws, n_new, h->sc);
+    // keep flags -> compaction offsets (channel 1); weights of the others -> their CDF (channel 2)
+    InOptimal ik{h->lw, ws, h->sc, h->K, 0}, iw{h->lw, ws, h->sc, h->K, 1};
+    if ((s = scan_launch<InOptimal, 0>(h, 1, ik, 0, nullptr, true, &h->sc->Ctot))) return s;
+    if ((s = scan_launch<InOptimal, 0>(h, 2, iw, 0, nullptr, true, &h->sc->Rs))) return s;
+    if ((s = fetch_scalars(h))) return s;
+    const WSum& w = h->h_sc->raw;
+    const int64_t n_keep = (int64_t)h->h_sc->Ctot, n_res = n_new - n_keep;
+    bool inv = w.flags != 0;
+    if ((w.flags & (FLAG_NAN | FLAG_POSINF)) || (check == GPF_CHECK_TRUE && inv)) {
+        if (invalid) *invalid = 1;
+        return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights.");                              // resize.jl:153
+    }
+    if (n_res > 0 && h->h_sc->Rs == 0) {
+        // every particle that is not kept has weight 0 at this resolution: uniform among them (safe_softmax, resize.jl:166-168)
+        inv = true;
+        if (check == GPF_CHECK_TRUE) { if (invalid) *invalid = 1; return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights."); }
+        InOptimal iu{h->lw, ws, h->sc, h->K, 2};
+        if ((s = scan_launch<InOptimal, 0>(h, 2, iu, 0, nullptr, true, &h->sc->Rs))) return s;
+    }
+    if (invalid) *invalid = inv ? 1 : 0;
+    const CdfLevels lv = levels(h, 2);
+    const uint64_t* keepcdf = h->cdf[1];
+    const int64_t ntiles_old = h->ntiles;
+    const int K = h->K;
+    Bufs old = take_particle_buffers(h);
+    set_count(h, n_new);
+    if ((s = alloc_particle_buffers(h))) { free_bufs(old); return s; }
+    GPF_LAUNCH(k_opt_keep_scatter, dim3(grid_for(h, n_old, 8)), dim3(BLOCK), 0, h->stream, keepcdf, n_old, h->anc);
+    if (n_res > 0) {
+        SearchArgs sa{};
+        sa.w = lv; sa.c = lv; sa.ntiles = ntiles_old; sa.order = nullptr; sa.sc = h->sc; sa.ws = ws; sa.raw = ws;
+        sa.n = n_res; sa.n_cells = n_old; sa.n_global = n_res; sa.gid0 = 0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
+        sa.K = K; sa.logN = 0.0; sa.update_lml = 0; sa.anc = h->anc + n_keep;
+        const int64_t top_n = ntiles_old * 8 <= LDS_TILE_TABLE ? ntiles_old * 8 : (ntiles_old <= LDS_TILE_TABLE ? ntiles_old : 0);
+        const size_t lds = (size_t)(lds_pad(top_n) + 1) * sizeof(uint64_t);
+        const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((n_res + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
+        GPF_LAUNCH((k_search<3>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
+    }
+    // new_traces .= view(traces, parents); log_weights (resize.jl:189-197)
+    launch_gather_rows_lw(h, h->anc, old.rows[old.cur], old.lw, h->rows[0], h->lw, n_new);
+    const double ratio = log_((double)n_new) - log_((double)n_old);
+    GPF_LAUNCH(k_opt_weights, dim3(grid_for(h, n_new, 8)), dim3(BLOCK), 0, h->stream, h->lw, n_new, h->sc, ws, K, ratio);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_bufs(old);
+    HIP_TRY(h, hipGetLastError());
+    h->epoch += 1;
+    return GPF_OK;
+}
+
 gpf_status gpf_resize(gpf_handle h, int64_t n_new, int32_t method, double priority_alpha, int32_t check, int32_t* invalid)
 {
     gpf_status s = resize_ready(h);
     if (s) return s;
+    if (method == GPF_RESAMPLE_OPTIMAL) return resize_optimal(h, n_new, check, invalid);          // resize.jl:22-23
     if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL)
-        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");             // resize.jl:26 (:optimal is not native)
+        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");             // resize.jl:26
     if (n_new < 1 || n_new >= ((int64_t)1 << 31)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad n_particles");
     const int64_t n_old = h->n;
     PrioView pv = raw_view(h);

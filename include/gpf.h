@@ -51,7 +51,8 @@ typedef enum {
 } gpf_model;
 
 /* method::Symbol of pf_resample! (src/resample.jl:19-30) */
-typedef enum { GPF_RESAMPLE_MULTINOMIAL = 0, GPF_RESAMPLE_RESIDUAL = 1, GPF_RESAMPLE_STRATIFIED = 2 } gpf_resample_method;
+typedef enum { GPF_RESAMPLE_MULTINOMIAL = 0, GPF_RESAMPLE_RESIDUAL = 1, GPF_RESAMPLE_STRATIFIED = 2,
+               GPF_RESAMPLE_OPTIMAL = 3 /* gpf_resize only: pf_optimal_resize!, src/resize.jl:149-219 */ } gpf_resample_method;
 /* method::Symbol of pf_rejuvenate! (src/rejuvenate.jl:18-27) */
 typedef enum { GPF_REJUVENATE_MOVE = 0, GPF_REJUVENATE_REWEIGHT = 1 } gpf_rejuvenate_method;
 /* check keyword of the resamplers: true | :warn | false (src/resample.jl:43-46) */
@@ -182,8 +183,12 @@ gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_
  * The handle stays valid; its per-particle buffers are reallocated for the new count.  Unsharded filters only. */
 gpf_status gpf_n_particles(gpf_handle h, int64_t* out);
 /* pf_resize!(state, n_particles, method; priority_fn, check)          src/resize.jl:16-124
- * method = GPF_RESAMPLE_MULTINOMIAL | GPF_RESAMPLE_RESIDUAL (:optimal stays on the reference's CPU path);
- * priority_alpha / check / invalid as in gpf_resample. */
+ * method = GPF_RESAMPLE_MULTINOMIAL | GPF_RESAMPLE_RESIDUAL | GPF_RESAMPLE_OPTIMAL;
+ * priority_alpha / check / invalid as in gpf_resample.
+ * GPF_RESAMPLE_OPTIMAL = pf_optimal_resize! (src/resize.jl:149-219, Fearnhead & Clifford): needs n_particles <= current
+ * count, ignores priority_alpha (the reference takes no priority_fn there); particles with c w_i >= 1 are kept with
+ * their weights, the rest are resampled by systematic sampling (one uniform) and share logsumexp - log c; the
+ * log-ML estimate is not touched. */
 gpf_status gpf_resize(gpf_handle h, int64_t n_particles, int32_t method, double priority_alpha, int32_t check, int32_t* invalid);
 /* pf_replicate!(state, n_replicates; layout)                           src/resize.jl:236-244 */
 gpf_status gpf_replicate(gpf_handle h, int32_t n_replicates, int32_t interleaved);

@@ -152,10 +152,12 @@ function _resize!(s, n::Int, method::Int, priority_fn, check_kw)
 end
 pf_multinomial_resize!(s::DeviceParticleFilterState, n::Int; priority_fn=nothing, check=:warn) = _resize!(s, n, 0, priority_fn, check)
 pf_residual_resize!(s::DeviceParticleFilterState, n::Int; priority_fn=nothing, check=:warn) = _resize!(s, n, 1, priority_fn, check)
+pf_optimal_resize!(s::DeviceParticleFilterState, n::Int; check=:warn) = _resize!(s, n, 3, nothing, check)        # src/resize.jl:149-200
 function pf_resize!(s::DeviceParticleFilterState, n::Int, method::Symbol=:multinomial; kwargs...)
     method == :multinomial && return pf_multinomial_resize!(s, n; kwargs...)
     method == :residual && return pf_residual_resize!(s, n; kwargs...)
-    error("Resampling method $method not recognized.")      # :optimal stays on the CPU path
+    method == :optimal && return pf_optimal_resize!(s, n; kwargs...)
+    error("Resampling method $method not recognized.")
 end
 function pf_replicate!(s::DeviceParticleFilterState, k::Int; layout::Symbol=:contiguous)
     check(s, ccall((:gpf_replicate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint), s.handle, k, layout != :contiguous)); _refresh!(s)
@@ -210,6 +212,15 @@ function mean(s::DeviceParticleFilterState, addr::Pair{<:Integer,<:Integer})
 end
 function var(s::DeviceParticleFilterState, addr::Pair{<:Integer,<:Integer})
     out = Ref{Cdouble}(0); check(s, ccall((:gpf_history_var, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cdouble}), s.handle, addr.first, addr.second, out)); out[]
+end
+
+# Gen.sample_unweighted_traces(state, n) (src/utils.jl:189-194): rows of the drawn particles (n x row_width) and their indices
+function sample_unweighted_traces(s::DeviceParticleFilterState, n::Int)
+    dim = Ref{Cint}(0); w = Ref{Cint}(0)
+    check(s, ccall((:gpf_state_dim, libgpf), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), s.handle, dim, w))
+    rows = Matrix{Float64}(undef, w[], n); idx = Vector{Int64}(undef, n)
+    check(s, ccall((:gpf_sample_unweighted, libgpf), Cint, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Int64}), s.handle, n, rows, idx))
+    permutedims(rows)[:, 1:dim[]], idx
 end
 
 end # module

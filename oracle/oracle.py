@@ -89,6 +89,8 @@ def lib():
     sig("lit_residual", i64, _f64p, i64, _f64p, _i64p)
     sig("lit_stratified", None, _f64p, _i64p, i64, _f64p, _i64p)
     sig("lit_update_weights", None, _f64p, _f64p, _i64p, i64, _f64p)
+    sig("lit_inv_w_threshold", f64, _f64p, i64, i64)
+    sig("lit_systematic", i64, _f64p, i64, i64, f64, _i64p)
     L.o_set_threads(1)            # the reference is single-threaded; bench.py raises this for its all-cores leg only
     _lib = L
     return L
@@ -348,6 +350,8 @@ class OracleFilter:
 
     def resize(self, n_particles: int, method: str = "multinomial", priority_alpha=None, check="warn"):
         """pf_resize! dispatcher (resize.jl:16-28) + pf_multinomial_resize! (:46-68) / pf_residual_resize! (:87-124)"""
+        if method == "optimal":
+            return self.optimal_resize(n_particles, check=check)                        # :22-23
         if method not in ("multinomial", "residual"):
             raise OracleError(f"Resampling method {method} not recognized.")           # :26
         n_old, n_new, lw = self.n, int(n_particles), self.lw
@@ -382,6 +386,56 @@ class OracleFilter:
         self.parents, self.rows, self.lw = anc + 1, new_rows, new_lw
         self._set_count(n_new)
         self.epoch += 1
+        return invalid
+
+    def optimal_resize(self, n_particles: int, check="warn"):
+        """pf_optimal_resize! (resize.jl:149-200) with find_inv_w_threshold (resize.jl:203-219) in exact fixed point
+        (DESIGN.md §8b): the inverse weight threshold c is the exact pair (a, B), c w_i >= 1 <=> a q_i >= B."""
+        n_old, n = self.n, int(n_particles)
+        if n < 1 or n > n_old:
+            raise OracleError("optimal resize: need 1 <= n_particles <= current count")      # :185
+        s = WeightSummary(self.lw, n_old)                                                   # safe_softmax, :152
+        invalid = s.flags != 0
+        if (check is True and invalid) or s.bad:
+            raise OracleError("Invalid weights.")                                           # :153
+        q = [int(v) for v in s.q]
+        S = s.S
+        qs = sorted(q, reverse=True)                                                        # sort(weights), :204
+        pre = [0]
+        for v in qs:
+            pre.append(pre[-1] + v)
+        a, B = n, S                                                                         # float(n_particles), :218
+        for d in range(n - 1, -1, -1):       # first kappa ascending = largest position d descending; A = d, B = S - pre[d]
+            if qs[d] > 0 and S - pre[d] <= (n - d) * qs[d]:                                 # B / kappa + A <= n, :212-213
+                a, B = n - d, S - pre[d]                                                    # (n - A) / B, :215
+                break
+        keep = np.array([a * v >= B for v in q], bool)                                      # inv_w_thresh .* weights .>= 1, :156
+        keep_idx = np.flatnonzero(keep)
+        n_keep = keep_idx.size
+        n_res = n - n_keep
+        anc = np.empty(n, np.int64)
+        anc[:n_keep] = keep_idx                                                             # :180
+        if n_res > 0:
+            sq = np.where(keep, 0, s.q).astype(np.uint64)
+            scdf, Bp, _, _ = scan(sq)
+            if Bp == 0:                                                                     # safe_softmax of the rest, :166-168
+                invalid = True
+                if check is True:
+                    raise OracleError("Invalid weights.")
+                scdf, Bp, _, _ = scan(np.where(keep, 0, 1).astype(np.uint64))
+            x = int(targets_multinomial(self.seed, self.epoch, 0, 1, Bp)[0])                # u = rand() * step_size, :171
+            beta, rho = divmod(Bp, n_res)
+            T = np.array([m * beta + (m * rho + x) // n_res for m in range(n_res)], np.uint64)
+            anc[n_keep:] = upper_bound(scdf, T)                                             # :172-178
+        ratio = olog(float(n)) - olog(float(n_old))                                         # :189
+        rw = lib().o_lse_from(s.m, B, s.K, s.flags) - olog(float(a))                        # log_tot_weight - log(inv_w_thresh), :192
+        new_lw = np.empty(n)
+        new_lw[:n_keep] = self.lw[keep_idx] + ratio                                         # :194
+        new_lw[n_keep:] = rw + ratio                                                        # :195
+        self.parents, self.rows, self.lw = anc + 1, gather_rows(self.rows, anc), new_lw     # :197
+        self._set_count(n)
+        self.epoch += 1
+        self.n_keep = n_keep
         return invalid
 
     def replicate(self, n_replicates: int, layout: str = "contiguous"):

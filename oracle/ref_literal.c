@@ -24,6 +24,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #define L_EXPORT __attribute__((visibility("default")))
 
@@ -150,4 +151,44 @@ L_EXPORT void lit_update_weights(const double *lw, const double *lp, const int64
     double l = lit_logsumexp(t, n);
     for (int64_t j = 0; j < n; ++j) lw_out[j] = t[j] + (log((double)n) - l);  /* :200 */
     free(t);
+}
+
+/* resize.jl:203-219 find_inv_w_threshold: the Float64 formulation (ascending sort, running A and B) */
+static int cmp_f64(const void *a, const void *b)
+{
+    const double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+L_EXPORT double lit_inv_w_threshold(const double *w, int64_t n_old, int64_t n_particles)
+{
+    double *s = (double *)malloc((size_t)n_old * sizeof(double));
+    memcpy(s, w, (size_t)n_old * sizeof(double));
+    qsort(s, (size_t)n_old, sizeof(double), cmp_f64);            /* :204 */
+    int64_t A = n_old;                                           /* :206 */
+    double B = 0.0, c = (double)n_particles;                     /* :207, :218 */
+    for (int64_t k = 0; k < n_old; ++k) {
+        const double kappa = s[k];
+        A -= 1;                                                  /* :209 */
+        B += kappa;                                              /* :210 */
+        const double n_check = B / kappa + (double)A;            /* :212 */
+        const double eps = nextafter(fabs(n_check), INFINITY) - fabs(n_check);
+        if (n_check <= (double)n_particles + eps) {              /* :213 */
+            c = ((double)n_particles - (double)A) / B;           /* :215 */
+            break;
+        }
+    }
+    free(s);
+    return c;
+}
+/* resize.jl:170-178: systematic sampling among the particles that are not kept; returns the number of picks */
+L_EXPORT int64_t lit_systematic(const double *w_norm, int64_t n_strat, int64_t n_resample, double rand01, int64_t *picks)
+{
+    const double step = 1.0 / (double)n_resample;                /* :170 */
+    double u = rand01 * step;                                    /* :171 */
+    int64_t c = 0;
+    for (int64_t i = 0; i < n_strat; ++i) {
+        u = u - w_norm[i];                                       /* :173 */
+        if (u < 0) { picks[c++] = i; u += step; }                /* :174-177 */
+    }
+    return c;
 }
