@@ -1013,127 +1013,254 @@ __global__ void k_set_global(const int64_t* __restrict__ tot_all, int G, WSum* w
         ws->S = S;
     }
 }
-// totals[3G] = [S_all | C_all | R_all], inclusive offsets w_incl[G] (weight or residual-weight space), c_incl[G]
-__global__ void k_shard_offsets(const int64_t* __restrict__ tot_all, const int64_t* __restrict__ cr_all, int G, int64_t* out /*[5G]*/)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int64_t w = 0, c = 0;
-        for (int g = 0; g < G; ++g) {
-            out[g] = tot_all[5 * g];
-            out[G + g] = cr_all ? cr_all[2 * g] : 0;
-            out[2 * G + g] = cr_all ? cr_all[2 * g + 1] : 0;
-            w += cr_all ? cr_all[2 * g + 1] : tot_all[5 * g];
-            c += cr_all ? cr_all[2 * g] : 0;
-            out[3 * G + g] = w;
-            out[4 * G + g] = c;
-        }
-    }
-}
 __global__ void k_export_residual(const Scalars* sc, int64_t* out2)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) { out2[0] = (int64_t)sc->Ctot; out2[1] = (int64_t)sc->Rs; }
 }
 
-// targets of this shard's output slots in GLOBAL coordinates (same arithmetic as k_search)
-template <int METHOD>
-__global__ __launch_bounds__(BLOCK) void k_targets(uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n, int64_t n_global,
-                                                   const int64_t* __restrict__ totals, int G, int64_t* __restrict__ T_out)
+// ---- sharded resampling, the PUSH exchange.  RNG counters are keyed by the GLOBAL slot id, so every
+// shard can evaluate the target of EVERY output slot itself (Philox is pure ALU work): the owner of a target finds
+// out on its own which slots draw from it, looks the ancestors up and pushes [row | slot | ancestor id] to the shard
+// that holds the slot.  No request message exists.  Pass 1 walks all slots in chunks that never straddle a shard
+// boundary, compacts each chunk's hits in LDS and appends them to the staging list of the slot's shard (one global
+// atomic per chunk; the order of chunks inside a list is arbitrary, every entry names its slot); it also counts what
+// this shard will receive from whom.  Pass 2 looks the staged hits up (same core as k_search) and packs the rows.
+constexpr int MAX_SHARDS = 64;
+constexpr int PUSH_CHUNK = 2048;                  // output slots per chunk
+struct PushArgs {
+    uint64_t seed; uint32_t epoch;
+    int64_t n_global;
+    int G, me;
+    const int64_t* tot_all;                       // [G][5] gathered {S_local, Ql0..3}
+    const int64_t* cr_all;                        // [G][2] gathered residual {Ctot_local, Rs_local}, or nullptr
+    int64_t bounds[MAX_SHARDS + 1];               // first global slot of every shard
+    int64_t chunk0[MAX_SHARDS + 1];               // first chunk of every shard's slots
+    int64_t nchunks;
+    ulonglong2* stage;                            // [n_global]: hits for shard g's slots at stage + bounds[g]: {T_local | space << 62, slot inside g}
+    int64_t* counts;                              // [2G]: entries sent to each shard | received from each shard
+};
+struct PushTables {                               // LDS copy of the per-shard tables
+    int64_t w_incl[MAX_SHARDS], c_incl[MAX_SHARDS], bounds[MAX_SHARDS + 1], chunk0[MAX_SHARDS + 1];
+};
+__device__ __forceinline__ void push_tables(const PushArgs& a, PushTables& t)
 {
-    uint64_t S = 0, Ctot = 0, Rs = 0;
-    for (int g = 0; g < G; ++g) {
-        S += (uint64_t)totals[g];
-        if (METHOD == 1) { Ctot += (uint64_t)totals[G + g]; Rs += (uint64_t)totals[2 * G + g]; }
-    }
-    const uint64_t N = (uint64_t)n_global;
-    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * BLOCK) {
-        const uint64_t jg = (uint64_t)(gid0 + j);
-        const Philox b = rng(seed, (uint32_t)jg, 0, epoch, TAG_RESAMPLE);
-        const uint64_t U = u64(b.w0, b.w1);
-        int64_t T;
-        if (METHOD == 0) T = (int64_t)mulhi64(U, S);
-        else if (METHOD == 2) {
-            const uint64_t B = S / N, rem = S % N;
-            const uint64_t L0 = jg * B + (jg * rem) / N;
-            const uint64_t L1 = (jg + 1) * B + ((jg + 1) * rem) / N;
-            T = (int64_t)(L0 + mulhi64(U, L1 - L0));
-        } else {
-            T = jg < Ctot ? ((int64_t)jg | SPACE_COUNTS) : (int64_t)mulhi64(U, Rs);
+    // inclusive shard totals of the sampled space (weights, or residual weights) and of the residual copy counts
+    if (threadIdx.x == 0) {
+        int64_t w = 0, c = 0;
+        for (int g = 0; g < a.G; ++g) {
+            w += a.cr_all ? a.cr_all[2 * g + 1] : a.tot_all[5 * g];
+            c += a.cr_all ? a.cr_all[2 * g] : 0;
+            t.w_incl[g] = w; t.c_incl[g] = c;
         }
-        T_out[j] = T;
+    }
+    for (int g = threadIdx.x; g <= a.G; g += blockDim.x) { t.bounds[g] = a.bounds[g]; t.chunk0[g] = a.chunk0[g]; }
+    __syncthreads();
+}
+// the slots [j0, j1) of chunk c and the shard g that holds them
+__device__ __forceinline__ int push_chunk(const PushArgs& a, const PushTables& t, int64_t c, int64_t& j0, int64_t& j1)
+{
+    int g = 0;
+    while (g < a.G - 1 && c >= t.chunk0[g + 1]) ++g;
+    j0 = t.bounds[g] + (c - t.chunk0[g]) * PUSH_CHUNK;
+    j1 = j0 + PUSH_CHUNK < t.bounds[g + 1] ? j0 + PUSH_CHUNK : t.bounds[g + 1];
+    return g;
+}
+struct PushScal { uint64_t Sw, Ctot, B, rem; double invN; };
+template <int METHOD>
+__device__ __forceinline__ PushScal push_scalars(const PushArgs& a, const PushTables& t)
+{
+    PushScal s;
+    s.Sw = (uint64_t)t.w_incl[a.G - 1];           // total of the sampled space: weights, or residual weights
+    s.Ctot = METHOD == 1 ? (uint64_t)t.c_incl[a.G - 1] : 0;
+    s.B = METHOD == 2 ? s.Sw / (uint64_t)a.n_global : 0;
+    s.rem = METHOD == 2 ? s.Sw % (uint64_t)a.n_global : 0;
+    s.invN = 1.0 / (double)a.n_global;
+    return s;
+}
+// target of global slot jg, same arithmetic as k_search; space 1 = the residual copy-count CDF
+template <int METHOD>
+__device__ __forceinline__ void push_target(const PushArgs& a, const PushScal& s, uint64_t jg, uint64_t& T, int& space)
+{
+    const Philox b = rng(a.seed, (uint32_t)jg, 0, a.epoch, TAG_RESAMPLE);
+    const uint64_t U = u64(b.w0, b.w1);
+    const uint64_t N = (uint64_t)a.n_global;
+    space = 0;
+    if (METHOD == 0) T = mulhi64(U, s.Sw);
+    else if (METHOD == 2) {
+        const uint64_t x0 = jg * s.rem, q0 = div_small(x0, N, s.invN);
+        const uint64_t q1 = q0 + ((x0 - q0 * N) + s.rem >= N ? 1 : 0);
+        const uint64_t L0 = jg * s.B + q0, L1 = (jg + 1) * s.B + q1;
+        T = L0 + mulhi64(U, L1 - L0);
+    } else {
+        if (jg < s.Ctot) { space = 1; T = jg; } else T = mulhi64(U, s.Sw);
     }
 }
-
-// serve requests in LOCAL coordinates: ancestor lookup in this shard's CDF (same core as k_search) + row gather
-template <int W>
-__global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_serve(const int64_t* __restrict__ T_local, int64_t m_req,
-                                                                          CdfLevels lw_, CdfLevels lc_, int two_tables,
-                                                                          int64_t n, int64_t ntiles, int64_t gid0,
-                                                                          const double* __restrict__ rows,
-                                                                          double* __restrict__ packed_out)
+// owner = first shard whose inclusive total exceeds T; T_local in the owner's coordinates
+__device__ __forceinline__ int push_owner(const PushTables& t, int G, int space, uint64_t T, uint64_t& T_local)
 {
-    // packed_out[r] = [row (W doubles) | global ancestor id (int64 bits)]: rows and ids travel back in one message
+    const int64_t* incl = space ? t.c_incl : t.w_incl;
+    int h = 0;
+    while (h < G - 1 && (uint64_t)incl[h] <= T) ++h;
+    T_local = T - (h ? (uint64_t)incl[h - 1] : 0);
+    return h;
+}
+// stratified: the strata of slots [j0, j1) cover [L(j0), L(j1)); a chunk that misses this shard's CDF range has no hit
+template <int METHOD>
+__device__ __forceinline__ bool push_chunk_misses(const PushArgs& a, const PushTables& t, const PushScal& s, int64_t j0, int64_t j1)
+{
+    if (METHOD != 2) return false;
+    const uint64_t N = (uint64_t)a.n_global;
+    const uint64_t lo = a.me ? (uint64_t)t.w_incl[a.me - 1] : 0, hi = (uint64_t)t.w_incl[a.me];
+    const uint64_t La = (uint64_t)j0 * s.B + ((uint64_t)j0 * s.rem) / N, Lb = (uint64_t)j1 * s.B + ((uint64_t)j1 * s.rem) / N;
+    return Lb <= lo || La >= hi;
+}
+
+// pass 1: stage the hits (slots whose target this shard owns), count them per destination, and count who owns the
+// targets of this shard's own slots
+constexpr int PUSH_SCAN_BLOCK = 512;
+template <int METHOD>
+__global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
+{
+    constexpr int R = PUSH_CHUNK / PUSH_SCAN_BLOCK, NW = PUSH_SCAN_BLOCK / WAVE;
+    __shared__ PushTables t;
+    __shared__ unsigned int s_recv[MAX_SHARDS];
+    __shared__ unsigned int s_wtot[NW];
+    __shared__ unsigned long long s_base;
+    if (threadIdx.x < MAX_SHARDS) s_recv[threadIdx.x] = 0;
+    push_tables(a, t);
+    const PushScal sc = push_scalars<METHOD>(a, t);
+    const int lane = lane_id(), wv = (int)threadIdx.x / WAVE;
+    unsigned recv_cnt = 0;                        // lane h counts the wave's own-slot targets owned by shard h
+    for (int64_t c = blockIdx.x; c < a.nchunks; c += gridDim.x) {
+        int64_t j0, j1;
+        const int g = push_chunk(a, t, c, j0, j1);
+        if (g != a.me && push_chunk_misses<METHOD>(a, t, sc, j0, j1)) continue;       // block-uniform
+        uint64_t Tl[R];
+        unsigned hits = 0;                                                            // bit r: round r is a hit
+#pragma unroll
+        for (int r = 0; r < R; ++r) {                                                 // R independent Philox chains per lane
+            const int64_t j = j0 + (int64_t)threadIdx.x * R + r;       // R consecutive slots per lane: staged in slot order
+            uint64_t T = 0; int space = 0, h = -1;
+            Tl[r] = 0;
+            if (j < j1) {
+                push_target<METHOD>(a, sc, (uint64_t)j, T, space);
+                h = push_owner(t, a.G, space, T, Tl[r]);
+                Tl[r] |= (uint64_t)space << 62;
+            }
+            if (g == a.me) {                                                          // block-uniform
+                for (int q = 0; q < a.G; ++q) {
+                    const unsigned n = (unsigned)__popcll(__ballot(h == q));
+                    if (lane == q) recv_cnt += n;
+                }
+            }
+            hits |= (h == a.me ? 1u : 0u) << r;
+        }
+        // exclusive position of this lane's hits inside the chunk; ONE global atomic per chunk reserves the chunk's range
+        const unsigned cnt = (unsigned)__popc(hits);
+        unsigned incl = cnt;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { const unsigned o = __shfl_up(incl, d, WAVE); if (lane >= d) incl += o; }
+        if (lane == WAVE - 1) s_wtot[wv] = incl;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const unsigned v = s_wtot[w]; before += w < wv ? v : 0; total += v; }
+        if (threadIdx.x == 0 && total)
+            s_base = atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + g), (unsigned long long)total);
+        __syncthreads();
+        if (cnt) {
+            ulonglong2* dst = a.stage + t.bounds[g] + s_base + before + (incl - cnt);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (hits >> r & 1u)
+                    *dst++ = make_ulonglong2(Tl[r], (uint64_t)(j0 + (int64_t)threadIdx.x * R + r - t.bounds[g]));
+        }
+    }
+    if (recv_cnt) atomicAdd(&s_recv[lane], recv_cnt);
+    __syncthreads();
+    if (threadIdx.x < a.G && s_recv[threadIdx.x])
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + a.G + threadIdx.x), (unsigned long long)s_recv[threadIdx.x]);
+}
+// pass 2: every staged hit is looked up in this shard's CDF (same core as k_search) and pushed with its row:
+// packed_out[e] = [row (W doubles) | (slot inside its shard) << 32 | global ancestor id], grouped by destination shard
+template <int METHOD, int W>
+__global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs a, CdfLevels lw_, CdfLevels lc_, int64_t n, int64_t ntiles,
+                                                                         int64_t gid0, const double* __restrict__ rows,
+                                                                         int64_t capacity, double* __restrict__ packed_out)
+{
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SearchTop st = search_prologue(lw_, lc_, two_tables != 0, ntiles, reinterpret_cast<uint64_t*>(smem));
+    const SearchTop st = search_prologue(lw_, lc_, METHOD == 1, ntiles, reinterpret_cast<uint64_t*>(smem));
     __shared__ ulonglong2 s_coop[2 * SBLOCK];
+    __shared__ int64_t s_off[MAX_SHARDS + 1];     // first entry of every destination in the send buffer
+    __shared__ int64_t s_bnd[MAX_SHARDS + 1];
     ulonglong2* const lds_wave = s_coop + wave_id() * (2 * WAVE);
-    for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < m_req; base += (int64_t)gridDim.x * 2 * SBLOCK) {
-        int64_t r[2]; bool act[2]; uint64_t T[2]; const uint64_t* top[2]; const CdfLevels* L[2];
+    if (threadIdx.x == 0) {
+        int64_t o = 0;
+        for (int g = 0; g < a.G; ++g) { s_off[g] = o; o += a.counts[g]; s_bnd[g] = a.bounds[g]; }
+        s_off[a.G] = o;
+    }
+    __syncthreads();
+    const int64_t total = s_off[a.G] < capacity ? s_off[a.G] : capacity;
+    for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < total; base += (int64_t)gridDim.x * 2 * SBLOCK) {
+        int64_t e[2]; bool act[2]; uint64_t T[2], slot[2]; const uint64_t* top[2]; const CdfLevels* L[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            r[u] = base + u * SBLOCK + threadIdx.x;
-            act[u] = r[u] < m_req;
-            const int64_t t = T_local[act[u] ? r[u] : m_req - 1];
-            const bool incounts = (t & SPACE_COUNTS) != 0;
-            T[u] = (uint64_t)(t & ~SPACE_COUNTS);
+            e[u] = base + u * SBLOCK + threadIdx.x;
+            act[u] = e[u] < total;
+            const int64_t ee = act[u] ? e[u] : total - 1;
+            int g = 0;
+            while (g < a.G - 1 && ee >= s_off[g + 1]) ++g;
+            const ulonglong2 q = a.stage[s_bnd[g] + (ee - s_off[g])];
+            const bool incounts = (q.x >> 62) != 0;
+            T[u] = q.x & DESC_MASK;
+            slot[u] = q.y;
             top[u] = incounts ? st.topc : st.topw;
             L[u] = incounts ? &lc_ : &lw_;
         }
         int64_t idx[2];
-        search_pair(st, L, top, T, true, lds_wave, n, ntiles, idx);
+        search_pair(st, L, top, T, METHOD != 2, lds_wave, n, ntiles, idx);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (!act[u]) continue;
             const double* src = rows + idx[u] * W;
-            double* dst = packed_out + r[u] * (W + 1);
+            double* dst = packed_out + e[u] * (W + 1);
 #pragma unroll
             for (int c = 0; c < W; ++c) dst[c] = src[c];
-            dst[W] = u2d((uint64_t)(gid0 + idx[u]));
+            dst[W] = u2d((slot[u] << 32) | (uint64_t)(gid0 + idx[u]));
         }
     }
 }
 
-// install the returned population: entry k of the routed order belongs to output slot perm[k]
+// install the received population: every entry names its slot
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_commit_permuted(const double* __restrict__ packed, const int64_t* __restrict__ perm, int64_t n,
-                                                          double* __restrict__ rows_new, int32_t* __restrict__ anc, double* __restrict__ lw)
+__global__ __launch_bounds__(BLOCK) void k_commit_packed(const double* __restrict__ packed, int64_t m, double* __restrict__ rows_new,
+                                                         int32_t* __restrict__ anc, double* __restrict__ lw,
+                                                         const double* __restrict__ mf_all, const int64_t* __restrict__ tot_all, int G, int K,
+                                                         double logN, Scalars* sc)
 {
-    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < n; k += (int64_t)gridDim.x * BLOCK) {
-        const int64_t j = perm[k];
-        const double* src = packed + k * (W + 1);
-        double* dst = rows_new + j * W;
-#pragma unroll
-        for (int c = 0; c < W; ++c) dst[c] = src[c];
-        anc[j] = (int32_t)d2u(src[W]);
-        lw[j] = 0.0;                                   // update_weights!, resample.jl:195
-    }
-}
-// update_lml_est! from the gathered global summary: lml += (m + log(S 2^-K)) - log N
-__global__ void k_lml_global(const double* __restrict__ mf_all, const int64_t* __restrict__ tot_all, int G, int K, double logN,
-                             Scalars* sc)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    // update_lml_est! (resample.jl:178-182) from the gathered global summary: lml += (m + log(S 2^-K)) - log N
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint64_t S = 0;
-        double m = -__builtin_huge_val();
+        double mx = -__builtin_huge_val();
         int f = 0;
         for (int g = 0; g < G; ++g) {
             S += (uint64_t)tot_all[5 * g];
-            const double v = mf_all[2 * g]; m = v > m ? v : m; f |= (int)mf_all[2 * g + 1];
+            const double v = mf_all[2 * g]; mx = v > mx ? v : mx; f |= (int)mf_all[2 * g + 1];
         }
-        if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
-        sc->lml_est = sc->lml_est + (lse_from(m, S, K, f) - logN);
+        if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+        sc->lml_est = sc->lml_est + (lse_from(mx, S, K, f) - logN);
+    }
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < m; k += (int64_t)gridDim.x * BLOCK) {
+        const double* src = packed + k * (W + 1);
+        const uint64_t meta = d2u(src[W]);
+        const int64_t j = (int64_t)(meta >> 32);
+        double* dst = rows_new + j * W;
+#pragma unroll
+        for (int c = 0; c < W; ++c) dst[c] = src[c];
+        anc[j] = (int32_t)(meta & 0xffffffffull);
+        lw[j] = 0.0;                                   // update_weights!, resample.jl:195
     }
 }
-
 // ----------------------------------------------------------------------------- resize family (reference src/resize.jl)
 // pf_replicate! (resize.jl:236-244): parents = repeat(1:N, inner=k) (contiguous) or repeat(1:N, k) (interleaved);
 // pf_dereplicate! :keepfirst (resize.jl:267-280): parents = 1:k:N (contiguous) or 1:N/k (interleaved)
@@ -1286,94 +1413,6 @@ __global__ __launch_bounds__(BLOCK) void k_wsum_values(const double* __restrict_
     if (lane_id() == 0) s[wave_id()] = acc;
     __syncthreads();
     if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < NWAVES; ++w) t += s[w]; partial[blockIdx.x] = t; }
-}
-
-// ----------------------------------------------------------------------------- shard routing (stable partition by owner)
-// owner(T) = first shard whose inclusive total exceeds T (weight space, or copy-count space for flagged targets);
-// requests are grouped by owner, slot order kept inside a group, and rewritten in the owner's LOCAL coordinates.
-constexpr int MAX_SHARDS = 16;
-struct RouteArgs {
-    const int64_t* T;          // [n] global targets (bit 62: copy-count space)
-    const int64_t* w_incl;     // [G] inclusive shard totals, weight (or residual-weight) space
-    const int64_t* c_incl;     // [G] inclusive shard totals, copy-count space (or nullptr)
-    int G; int64_t n;
-    int32_t* block_counts;     // [nblocks][MAX_SHARDS]
-    int64_t* T_sorted; int64_t* perm; int64_t* counts;
-};
-__device__ __forceinline__ int route_owner(const RouteArgs& a, int64_t t, int64_t& t_local)
-{
-    const bool incounts = (t & SPACE_COUNTS) != 0;
-    const int64_t v = t & ~SPACE_COUNTS;
-    const int64_t* incl = incounts ? a.c_incl : a.w_incl;
-    int g = 0;
-    while (g < a.G - 1 && incl[g] <= v) ++g;
-    t_local = (v - (g ? incl[g - 1] : 0)) | (t & SPACE_COUNTS);
-    return g;
-}
-__global__ __launch_bounds__(BLOCK) void k_route_count(RouteArgs a)
-{
-    __shared__ int s_cnt[MAX_SHARDS];
-    if (threadIdx.x < MAX_SHARDS) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (j < a.n) { int64_t tl; atomicAdd(&s_cnt[route_owner(a, a.T[j], tl)], 1); }
-    __syncthreads();
-    if (threadIdx.x < MAX_SHARDS) a.block_counts[(int64_t)blockIdx.x * MAX_SHARDS + threadIdx.x] = s_cnt[threadIdx.x];
-}
-// one workgroup: exclusive offsets in (owner-major, block-minor) order, in place; totals per owner
-__global__ __launch_bounds__(BLOCK) void k_route_scan(int32_t* block_counts, int64_t nblocks, int G, int64_t* counts)
-{
-    __shared__ int64_t s_part[BLOCK];
-    __shared__ int64_t s_base;
-    if (threadIdx.x == 0) s_base = 0;
-    __syncthreads();
-    for (int g = 0; g < G; ++g) {
-        // chunked scan over the blocks of owner g
-        for (int64_t c0 = 0; c0 < nblocks; c0 += BLOCK) {
-            const int64_t b = c0 + threadIdx.x;
-            const int64_t v = b < nblocks ? block_counts[b * MAX_SHARDS + g] : 0;
-            s_part[threadIdx.x] = v;
-            __syncthreads();
-            for (int d = 1; d < BLOCK; d <<= 1) {                 // Hillis-Steele inclusive scan in LDS
-                const int64_t add = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
-                __syncthreads();
-                s_part[threadIdx.x] += add;
-                __syncthreads();
-            }
-            const int64_t excl = s_base + s_part[threadIdx.x] - v;
-            if (b < nblocks) block_counts[b * MAX_SHARDS + g] = (int32_t)excl;
-            __syncthreads();
-            if (threadIdx.x == BLOCK - 1) s_base += s_part[BLOCK - 1];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) counts[g] = s_base - (g ? 0 : 0);
-        __syncthreads();
-    }
-    // counts[g] currently holds the inclusive total through owner g: make them per-owner counts
-    if (threadIdx.x == 0) { for (int g = G - 1; g > 0; --g) counts[g] -= counts[g - 1]; }
-}
-__global__ __launch_bounds__(BLOCK) void k_route_scatter(RouteArgs a)
-{
-    __shared__ int s_wave[NWAVES][MAX_SHARDS];
-    const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = j < a.n;
-    int64_t tl = 0;
-    const int g = active ? route_owner(a, a.T[j], tl) : -1;
-    const int lane = lane_id(), wv = wave_id();
-    int rank = 0;
-    for (int q = 0; q < a.G; ++q) {                               // rank among the wave's lanes with the same owner
-        const unsigned long long m = __ballot(g == q);
-        if (g == q) rank = __popcll(m & ((1ull << lane) - 1));
-        if (lane == 0) s_wave[wv][q] = __popcll(m);
-    }
-    __syncthreads();
-    if (active) {
-        int before = 0;
-        for (int w = 0; w < wv; ++w) before += s_wave[w][g];
-        const int64_t pos = (int64_t)a.block_counts[(int64_t)blockIdx.x * MAX_SHARDS + g] + before + rank;
-        a.T_sorted[pos] = tl;
-        a.perm[pos] = j;
-    }
 }
 
 // ----------------------------------------------------------------------------- sub-state views (src/view.jl, resample.jl:205-218)

@@ -86,8 +86,9 @@ struct gpf_filter {
     int64_t view_start = 0;
     uint64_t generation = 0;             // bumped when the per-particle buffers are reallocated (views check it)
     uint64_t parent_generation = 0;
-    int32_t* route_counts = nullptr;     // shard routing scratch: [n/256][MAX_SHARDS]
-    int64_t* route_offsets = nullptr;    // [5][MAX_SHARDS]: shard totals and inclusive offsets of the current resample
+    ulonglong2* push_stage = nullptr;    // push exchange: staged hits, one 16-byte entry per global output slot at most
+    int64_t push_cap = 0;
+    bool push_counted = false;
     Timer timers[GPF_K_COUNT];
     std::string err;
 };
@@ -608,6 +609,16 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
 } // namespace
 
 // =================================================================================== C ABI
+template <int METHOD>
+static void launch_push(gpf_filter* h, const PushArgs& a, int grid, size_t lds, const CdfLevels& lw_, const CdfLevels& lc_, int64_t capacity, double* out)
+{
+    switch (h->W) {
+        case 2: GPF_LAUNCH((k_push<METHOD, 2>), dim3(grid), dim3(SBLOCK), lds, h->stream, a, lw_, lc_, h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], capacity, out); break;
+        case 4: GPF_LAUNCH((k_push<METHOD, 4>), dim3(grid), dim3(SBLOCK), lds, h->stream, a, lw_, lc_, h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], capacity, out); break;
+        case 8: GPF_LAUNCH((k_push<METHOD, 8>), dim3(grid), dim3(SBLOCK), lds, h->stream, a, lw_, lc_, h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], capacity, out); break;
+    }
+}
+
 extern "C" {
 
 int gpf_abi_version(void) { return GPF_ABI_VERSION; }
@@ -665,9 +676,12 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<0>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_serve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_serve<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_serve<8>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+#define GPF_PUSH_ATTR(M, W) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_push<M, W>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn))
+        GPF_PUSH_ATTR(0, 2); GPF_PUSH_ATTR(0, 4); GPF_PUSH_ATTR(0, 8);
+        GPF_PUSH_ATTR(1, 2); GPF_PUSH_ATTR(1, 4); GPF_PUSH_ATTR(1, 8);
+        GPF_PUSH_ATTR(2, 2); GPF_PUSH_ATTR(2, 4); GPF_PUSH_ATTR(2, 8);
+#undef GPF_PUSH_ATTR
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return GPF_OK;
     };
@@ -687,7 +701,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->route_counts, h->route_offsets};
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1452,67 +1466,78 @@ gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t
     return GPF_OK;
 }
 
-gpf_status gpf_shard_route(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G,
-                           int64_t* T_sorted, int64_t* perm, int64_t* counts)
+// fill the argument block of the push kernels; bounds: HOST int64[G+1], first global slot of every shard
+static gpf_status push_args(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
+                            const int64_t* bounds, int64_t* counts, PushArgs& a)
 {
-    gpf_status s = shard_ready(h);
-    if (s) return s;
     if (method < 0 || method > 2) return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");
-    if (!tot_all || !T_sorted || !perm || !counts || G < 1 || G > MAX_SHARDS || (method == GPF_RESAMPLE_RESIDUAL && !cr_all))
+    if (!tot_all || !bounds || !counts || G < 1 || G > MAX_SHARDS || me < 0 || me >= G || (method == GPF_RESAMPLE_RESIDUAL && !cr_all))
         return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
-    const int64_t nblocks = (h->n + BLOCK - 1) / BLOCK;
-    if (!h->route_counts) {
-        HIP_TRY(h, hipMalloc(&h->route_counts, (size_t)nblocks * MAX_SHARDS * sizeof(int32_t)));
-        HIP_TRY(h, hipMalloc(&h->route_offsets, (size_t)5 * MAX_SHARDS * sizeof(int64_t)));
+    if (bounds[0] != 0 || bounds[G] != h->cfg.n_global || bounds[me] != h->cfg.gid0 || bounds[me + 1] != h->cfg.gid0 + h->n)
+        return fail(h, GPF_ERR_INVALID_ARGUMENT, "shard bounds do not match this filter's global range");
+    a.seed = h->cfg.seed; a.epoch = h->epoch; a.n_global = h->cfg.n_global; a.G = G; a.me = me;
+    int64_t c = 0;
+    for (int g = 0; g < G; ++g) {
+        if (bounds[g + 1] < bounds[g]) return fail(h, GPF_ERR_INVALID_ARGUMENT, "shard bounds must be non-decreasing");
+        a.bounds[g] = bounds[g]; a.chunk0[g] = c;
+        c += (bounds[g + 1] - bounds[g] + PUSH_CHUNK - 1) / PUSH_CHUNK;
     }
-    int64_t* off = h->route_offsets;             // [S_all | C_all | R_all | w_incl | c_incl], each G long
-    GPF_LAUNCH(k_shard_offsets, dim3(1), dim3(64), 0, h->stream, tot_all, method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr, (int)G, off);
-    int64_t* T = reinterpret_cast<int64_t*>(h->dtmp);
-    const int grid = grid_for(h, h->n, 8);
-    s = timed(h, GPF_K_SEARCH, [&] {
-        switch (method) {
-            case GPF_RESAMPLE_MULTINOMIAL:
-                GPF_LAUNCH((k_targets<0>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
-                                   h->cfg.n_global, off, (int)G, T); break;
-            case GPF_RESAMPLE_RESIDUAL:
-                GPF_LAUNCH((k_targets<1>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
-                                   h->cfg.n_global, off, (int)G, T); break;
-            default:
-                GPF_LAUNCH((k_targets<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->cfg.seed, h->epoch, h->cfg.gid0, h->n,
-                                   h->cfg.n_global, off, (int)G, T); break;
-        }
-    });
-    if (s) return s;
-    RouteArgs a{T, off + 3 * G, off + 4 * G, (int)G, h->n, h->route_counts, T_sorted, perm, counts};
-    GPF_LAUNCH(k_route_count, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, a);
-    GPF_LAUNCH(k_route_scan, dim3(1), dim3(BLOCK), 0, h->stream, h->route_counts, nblocks, (int)G, counts);
-    GPF_LAUNCH(k_route_scatter, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, a);
-    HIP_TRY(h, hipGetLastError());
+    a.bounds[G] = bounds[G]; a.chunk0[G] = c; a.nchunks = c;
+    if (h->cfg.n_global > h->push_cap) {                       // staging list: one 16-byte entry per GLOBAL output slot at most
+        if (h->push_stage) (void)hipFree(h->push_stage);
+        h->push_stage = nullptr; h->push_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->push_stage, (size_t)h->cfg.n_global * sizeof(ulonglong2)));
+        h->push_cap = h->cfg.n_global;
+    }
+    a.tot_all = tot_all; a.cr_all = method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr; a.stage = h->push_stage; a.counts = counts;
     return GPF_OK;
 }
 
-gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, double* packed_out)
+gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
+                                const int64_t* bounds, int64_t* counts)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
-    if (m_req < 0 || (m_req > 0 && (!T_local || !packed_out))) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
-    if (m_req == 0) return GPF_OK;
-    // residual: requests without the count bit are looked up in the residual-weight CDF (cdf[2])
-    const int two = h->serve_residual ? 1 : 0;
+    PushArgs a;
+    if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, counts, a))) return s;
+    HIP_TRY(h, hipMemsetAsync(counts, 0, (size_t)2 * G * sizeof(int64_t), h->stream));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.nchunks, (int64_t)h->n_cu * 8));
+    s = timed(h, GPF_K_SEARCH, [&] {
+        switch (method) {
+            case GPF_RESAMPLE_MULTINOMIAL: GPF_LAUNCH((k_push_scan<0>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a); break;
+            case GPF_RESAMPLE_RESIDUAL:    GPF_LAUNCH((k_push_scan<1>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a); break;
+            default:                       GPF_LAUNCH((k_push_scan<2>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a); break;
+        }
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->push_counted = true;
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
+                          const int64_t* bounds, int64_t* counts, int64_t capacity, double* packed_out)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!h->push_counted) return fail(h, GPF_ERR_STATE, "gpf_shard_push needs gpf_shard_push_count of the same resample first");
+    if (capacity < 0 || (capacity > 0 && !packed_out)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    PushArgs a;
+    if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, counts, a))) return s;
+    if (capacity == 0) return GPF_OK;
+    const bool two = method == GPF_RESAMPLE_RESIDUAL;
+    if (two && !h->serve_residual) return fail(h, GPF_ERR_STATE, "residual push needs gpf_shard_residual_scan first");
     const int64_t nt = two ? 2 : 1;
     const int64_t top_n = nt * h->ntiles * 8 <= LDS_TILE_TABLE ? h->ntiles * 8 : (nt * h->ntiles <= LDS_TILE_TABLE ? h->ntiles : 0);
     const size_t lds = (size_t)(nt * (lds_pad(top_n) + 1)) * sizeof(uint64_t);
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((m_req + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((capacity + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));
+    const CdfLevels lw_ = levels(h, two ? 2 : 0);
+    const CdfLevels lc_ = levels(h, two ? 1 : 0);
     s = timed(h, GPF_K_GATHER, [&] {
-        const CdfLevels lw_ = levels(h, h->serve_residual ? 2 : 0);
-        const CdfLevels lc_ = levels(h, h->serve_residual ? 1 : 0);
-        switch (h->W) {
-            case 2: GPF_LAUNCH((k_serve<2>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
-                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], packed_out); break;
-            case 4: GPF_LAUNCH((k_serve<4>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
-                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], packed_out); break;
-            case 8: GPF_LAUNCH((k_serve<8>), dim3(grid), dim3(SBLOCK), lds, h->stream, T_local, m_req, lw_, lc_, two,
-                                       h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], packed_out); break;
+        switch (method) {
+            case GPF_RESAMPLE_MULTINOMIAL: launch_push<0>(h, a, grid, lds, lw_, lc_, capacity, packed_out); break;
+            case GPF_RESAMPLE_RESIDUAL:    launch_push<1>(h, a, grid, lds, lw_, lc_, capacity, packed_out); break;
+            default:                       launch_push<2>(h, a, grid, lds, lw_, lc_, capacity, packed_out); break;
         }
     });
     if (s) return s;
@@ -1520,25 +1545,26 @@ gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, 
     return GPF_OK;
 }
 
-gpf_status gpf_shard_commit(gpf_handle h, const double* packed, const int64_t* perm, const double* mf_all, const int64_t* tot_all, int32_t G)
+gpf_status gpf_shard_commit(gpf_handle h, const double* packed, int64_t m, const double* mf_all, const int64_t* tot_all, int32_t G)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
-    if (!packed || !perm || !mf_all || !tot_all || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (!packed || !mf_all || !tot_all || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (m != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "a shard must receive exactly one entry per output slot");
     const int grid = grid_for(h, h->n, 8);
     double* out = h->rows[1 - h->cur];
     switch (h->W) {
-        case 2: GPF_LAUNCH((k_commit_permuted<2>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
-        case 4: GPF_LAUNCH((k_commit_permuted<4>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
-        case 8: GPF_LAUNCH((k_commit_permuted<8>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, perm, h->n, out, h->anc, h->lw); break;
+        case 2: GPF_LAUNCH((k_commit_packed<2>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, m, out, h->anc, h->lw, mf_all, tot_all, (int)G, h->K, h->logN, h->sc); break;
+        case 4: GPF_LAUNCH((k_commit_packed<4>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, m, out, h->anc, h->lw, mf_all, tot_all, (int)G, h->K, h->logN, h->sc); break;
+        case 8: GPF_LAUNCH((k_commit_packed<8>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, m, out, h->anc, h->lw, mf_all, tot_all, (int)G, h->K, h->logN, h->sc); break;
     }
-    GPF_LAUNCH(k_lml_global, dim3(1), dim3(64), 0, h->stream, mf_all, tot_all, (int)G, h->K, h->logN, h->sc);
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;
     h->epoch += 1;
     h->raw_valid = false;
     h->max_valid = false;
     h->serve_residual = false;
+    h->push_counted = false;
     return GPF_OK;
 }
 

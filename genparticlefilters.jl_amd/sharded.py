@@ -8,12 +8,13 @@ spec as the single-GPU path (src/resample.jl:48-120,143-175) over a global weigh
     phase 1   local max / flags                      -> all-gather (2 doubles per rank)
     phase 2   local fixed-point scan under the GLOBAL max -> all-gather of the shard totals
     (2b)      residual: copy-count and residual-weight scans -> all-gather of their totals
-    phase 3   every output slot draws its target in global coordinates, owner = first shard whose inclusive
-              total exceeds it, requests grouped by owner (stable) in the owner's local coordinates
-              -> all-to-all of the counts (one host sync for the split sizes), all-to-all of the requests
-    phase 4   owners look the ancestors up in their local CDF and gather the rows
-              -> ONE all-to-all of [row | ancestor id] back
-    phase 5   scatter into slot order, log-weights = 0, log-ML estimate += logsumexp - log N
+    phase 3   RNG counters are keyed by the GLOBAL slot id, so every shard evaluates the target of EVERY output slot
+              itself (owner = first shard whose inclusive total exceeds it) and learns, without any message, which
+              slots draw from its own particles and what it will receive from whom
+              -> one host sync (the all-to-all split sizes); no request traffic, no count exchange
+    phase 4   owners look the ancestors up in their local CDF, gather the rows and pack them by destination
+              -> ONE all-to-all of [row | slot | ancestor id]
+    phase 5   scatter by slot, log-weights = 0, log-ML estimate += logsumexp - log N
 
 Every phase is one C-ABI call (gpf_shard_*) and at most one collective; the host only moves buffers.
 
@@ -28,6 +29,7 @@ exercise the collectives with gloo.  Restrictions: priority_fn = nothing, sort_p
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -91,26 +93,27 @@ class HipShardBackend:
         self._ck(self.L.gpf_shard_residual_scan(self.h, tot_all.data_ptr(), tot_all.shape[0], out.data_ptr()))
         return out
 
-    def route(self, method_id, tot_all, cr_all):
+    def push_count(self, method_id, tot_all, cr_all, me, bounds):
         G = tot_all.shape[0]
-        Ts = torch.empty(self.n, dtype=torch.int64, device=self.device)
-        perm = torch.empty(self.n, dtype=torch.int64, device=self.device)
-        counts = torch.empty(G, dtype=torch.int64, device=self.device)
-        self._ck(self.L.gpf_shard_route(self.h, method_id, tot_all.data_ptr(), cr_all.data_ptr() if cr_all is not None else None, G,
-                                        Ts.data_ptr(), perm.data_ptr(), counts.data_ptr()))
-        return Ts, perm, counts
+        self._bounds = (C.c_int64 * (G + 1))(*bounds)
+        counts = torch.empty(2 * G, dtype=torch.int64, device=self.device)
+        self._ck(self.L.gpf_shard_push_count(self.h, method_id, tot_all.data_ptr(), cr_all.data_ptr() if cr_all is not None else None, G, me,
+                                             self._bounds, counts.data_ptr()))
+        return counts
 
-    def serve(self, T_local):
-        m = T_local.numel()
-        packed = torch.empty((m, self.W + 1), dtype=torch.float64, device=self.device)
-        if m:
-            self._ck(self.L.gpf_shard_serve(self.h, T_local.data_ptr(), m, packed.data_ptr()))
-        return packed
+    def push(self, method_id, tot_all, cr_all, me, bounds, counts, capacity):
+        """packs at most `capacity` entries (the caller checks the counts afterwards and calls again if they did not fit)"""
+        G = tot_all.shape[0]
+        if getattr(self, "_sendbuf", None) is None or self._sendbuf.shape[0] < capacity:
+            self._sendbuf = torch.empty((capacity, self.W + 1), dtype=torch.float64, device=self.device)
+        self._ck(self.L.gpf_shard_push(self.h, method_id, tot_all.data_ptr(), cr_all.data_ptr() if cr_all is not None else None, G, me,
+                                       self._bounds, counts.data_ptr(), capacity, self._sendbuf.data_ptr() if capacity else None))
+        return self._sendbuf
 
-    def commit(self, packed, perm, mf_all, tot_all):
+    def commit(self, packed, mf_all, tot_all):
         packed = packed.contiguous()
-        self._ck(self.L.gpf_shard_commit(self.h, packed.data_ptr(), perm.data_ptr(), mf_all.data_ptr(), tot_all.data_ptr(), tot_all.shape[0]))
-        self._keep = (packed, perm, mf_all, tot_all)      # alive until the stream has consumed them
+        self._ck(self.L.gpf_shard_commit(self.h, packed.data_ptr(), packed.shape[0], mf_all.data_ptr(), tot_all.data_ptr(), tot_all.shape[0]))
+        self._keep = (packed, mf_all, tot_all)             # alive until the stream has consumed them
 
     def lml_est(self) -> float:
         out = C.c_double()
@@ -141,6 +144,7 @@ class ShardedParticleFilterState:
         self.backend, self.model, self.n_global = backend, model, int(n_global)
         self.rank, self.world, self.group = rank, world, group
         self.gid0, self.n_local = shard_range(n_global, rank, world)
+        self.bounds = [shard_range(n_global, r, world)[0] for r in range(world)] + [int(n_global)]
         self.device = backend.device
         self.K = backend.fix_K(self.n_global)
 
@@ -247,17 +251,19 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
             import warnings
             warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")
     cr_all = state._all_gather(b.residual_scan(tot_all)).contiguous() if mid == 1 else None     # phase 2b: (G, 2)
-    T_sorted, perm, send_counts = b.route(mid, tot_all, cr_all)       # phase 3: targets, owners, stable grouping
-    if G == 1:
-        back = b.serve(T_sorted)                                      # local == global coordinates
-    else:
-        recv_counts = state._all_to_all(send_counts, [1] * G, [1] * G)           # C4
-        both = torch.stack([send_counts, recv_counts]).tolist()                  # ONE host sync: the split sizes
-        sc, rc = both[0], both[1]
-        req = state._all_to_all(T_sorted, sc, rc)                                 # requests to the owners
-        packed = b.serve(req)                                         # phase 4: rows + ancestor ids of the requests
-        back = state._all_to_all(packed, rc, sc)                      # C5: back to the requesters, routed order
-    b.commit(back, perm, mf_all, tot_all)                             # phase 5: scatter by perm, weights, log-ML
+    counts = b.push_count(mid, tot_all, cr_all, state.rank, state.bounds)   # phase 3: who owns the target of which slot
+    # phase 4 is enqueued BEFORE the host learns the counts, into a buffer sized for a balanced exchange with slack
+    # (any size is correct: the kernel stops at the capacity, and the call is repeated if the counts say it overflowed)
+    cap = min(state.n_global, 2 * state.n_local + 65536)
+    if os.environ.get("GPF_PUSH_CAPACITY"):                           # tests: force the overflow path
+        cap = int(os.environ["GPF_PUSH_CAPACITY"])
+    buf = b.push(mid, tot_all, cr_all, state.rank, state.bounds, counts, cap)          # look up, gather, pack
+    c = counts.tolist()                                               # ONE host sync (the all-to-all split sizes), behind phase 4
+    sc, rc = c[:G], c[G:]
+    if sum(sc) > cap:                                                 # skewed weights: this shard serves more than 2x its share
+        buf = b.push(mid, tot_all, cr_all, state.rank, state.bounds, counts, sum(sc))
+    back = state._all_to_all(buf[:sum(sc)], sc, rc)                   # the exchange: [row | slot | ancestor id]
+    b.commit(back, mf_all, tot_all)                                   # phase 5: scatter by slot, weights, log-ML
     return state
 
 

@@ -226,25 +226,28 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
  *            host: all-gather -> tot_all[G][5]
  *   phase 2b gpf_shard_residual_scan  (residual only) in: tot_all; out2 = {Ctot_local, Rs_local}
  *            host: all-gather -> cr_all[G][2]
- *   phase 3  gpf_shard_route          global targets of this shard's slots, owner = first shard whose inclusive total
- *                                     exceeds the target, stable grouping by owner, local coordinates:
- *                                     T_sorted[n], perm[n] (output slot of each entry), counts[G] (entries per owner)
- *            host: all-to-all counts, then all-to-all of T_sorted with those split sizes
- *   phase 4  gpf_shard_serve          ancestor lookup + row gather for the m_req requests this shard owns;
- *                                     packed_out[m_req][W+1] = row | global ancestor id (int64 bits)
- *            host: all-to-all packed rows back (reverse split sizes)
- *   phase 5  gpf_shard_commit         scatter by perm into the new population, parents, log-weights = 0,
- *                                     log-ML estimate += logsumexp - log N (from mf_all, tot_all)
- * G <= 16.
+ *   phase 3  gpf_shard_push_count     RNG counters are keyed by the GLOBAL slot id, so every shard evaluates the target of
+ *                                     EVERY output slot itself and finds which of them fall into its own part of the
+ *                                     global CDF (owner = first shard whose inclusive total exceeds the target): no
+ *                                     request message exists.  counts[2G] = entries this shard will send to each shard |
+ *                                     entries it will receive from each shard.
+ *            host: read counts (the one host sync of a resample: the all-to-all split sizes), allocate the send buffer
+ *   phase 4  gpf_shard_push           ancestor lookup + row gather for every slot this shard owns the target of;
+ *                                     packed_out[sum(sent)][W+1] = row | (slot inside its shard) << 32 | global ancestor id,
+ *                                     grouped by destination shard, slot order inside a group (deterministic)
+ *            host: ONE all-to-all of packed rows (8W+8 bytes per slot that changes shard)
+ *   phase 5  gpf_shard_commit         scatter the m = n_particles received entries by their slot into the new population,
+ *                                     parents, log-weights = 0, log-ML estimate += logsumexp - log N (from mf_all, tot_all)
+ * me = this shard's index; bounds = HOST int64[G+1], first global slot of every shard (bounds[G] = n_global).  G <= 64.
  */
 gpf_status gpf_shard_weight_max(gpf_handle h, double* out2);
 gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, int64_t* out5);
 gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t G, int64_t* out2);
-gpf_status gpf_shard_route(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G,
-                           int64_t* T_sorted, int64_t* perm, int64_t* counts);
-gpf_status gpf_shard_serve(gpf_handle h, const int64_t* T_local, int64_t m_req, double* packed_out);
-gpf_status gpf_shard_commit(gpf_handle h, const double* packed, const int64_t* perm, const double* mf_all,
-                            const int64_t* tot_all, int32_t G);
+gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
+                                const int64_t* bounds, int64_t* counts);
+gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
+                          const int64_t* bounds, int64_t* counts, int64_t capacity, double* packed_out);
+gpf_status gpf_shard_commit(gpf_handle h, const double* packed, int64_t m, const double* mf_all, const int64_t* tot_all, int32_t G);
 /* running log_ml_est of this shard (identical on all shards) */
 gpf_status gpf_shard_lml_est(gpf_handle h, double* out);
 

@@ -68,53 +68,69 @@ class OracleShardBackend:
         self.serve_residual = True
         return torch.tensor([int(self.ccdf[-1]) if self.n else 0, Rs], dtype=torch.int64)
 
-    def route(self, method_id, tot_all, cr_all):
+    def _all_targets(self, method_id, tot_all, cr_all):
+        """target, space and owner of EVERY global output slot (every shard can evaluate them: counters use global ids)"""
         t = tot_all.numpy(); G = t.shape[0]
         S = int(t[:, 0].sum())
+        inc = np.zeros(self.N, bool)
         if method_id == 0:
-            T = o.targets_multinomial(self.seed, self.epoch, self.gid0, self.n, S).astype(np.int64)
+            T = o.targets_multinomial(self.seed, self.epoch, 0, self.N, S).astype(np.int64)
         elif method_id == 2:
-            T = o.targets_stratified(self.seed, self.epoch, self.gid0, self.n, self.N, S).astype(np.int64)
+            T = o.targets_stratified(self.seed, self.epoch, 0, self.N, self.N, S).astype(np.int64)
         else:
             cr = cr_all.numpy()
             Ctot, Rs = int(cr[:, 0].sum()), int(cr[:, 1].sum())
-            T = o.targets_multinomial(self.seed, self.epoch, self.gid0, self.n, Rs).astype(np.int64)
-            jg = np.arange(self.gid0, self.gid0 + self.n, dtype=np.int64)
-            T = np.where(jg < Ctot, jg | SPACE_COUNTS, T)
-        inc = (T & SPACE_COUNTS) != 0
-        tv = T & (SPACE_COUNTS - 1)
+            T = o.targets_multinomial(self.seed, self.epoch, 0, self.N, Rs).astype(np.int64)
+            jg = np.arange(self.N, dtype=np.int64)
+            inc = jg < Ctot
+            T = np.where(inc, jg, T)
         w = np.cumsum(cr_all.numpy()[:, 1] if method_id == 1 else t[:, 0])
-        owner = np.minimum(np.searchsorted(w, tv, side="right"), G - 1)
+        owner = np.minimum(np.searchsorted(w, T, side="right"), G - 1)
         base = np.concatenate([[0], w[:-1]])[owner]
         if method_id == 1:
             c = np.cumsum(cr_all.numpy()[:, 0])
-            oc = np.minimum(np.searchsorted(c, tv, side="right"), G - 1)
+            oc = np.minimum(np.searchsorted(c, T, side="right"), G - 1)
             owner = np.where(inc, oc, owner)
             base = np.where(inc, np.concatenate([[0], c[:-1]])[oc], base)
-        tl = (tv - base) | (T & SPACE_COUNTS)
-        perm = np.argsort(owner, kind="stable")
-        return (torch.from_numpy(tl[perm].astype(np.int64)), torch.from_numpy(perm.astype(np.int64)),
-                torch.from_numpy(np.bincount(owner, minlength=G).astype(np.int64)))
+        return T - base, inc, owner
 
-    def serve(self, T_local):
-        t = T_local.numpy().astype(np.uint64)
-        inc = (t & np.uint64(SPACE_COUNTS)) != 0
-        tv = t & np.uint64(SPACE_COUNTS - 1)
-        a = np.zeros(t.size, np.int64)
+    def push_count(self, method_id, tot_all, cr_all, me, bounds):
+        G = tot_all.shape[0]
+        self._tl, self._inc, self._owner = self._all_targets(method_id, tot_all, cr_all)
+        b = np.asarray(bounds)
+        self._dest = np.searchsorted(b[1:], np.arange(self.N), side="right")          # shard that holds each slot
+        mine = self._owner == me
+        send = np.bincount(self._dest[mine], minlength=G)
+        recv = np.bincount(self._owner[self._dest == me], minlength=G)
+        self._bounds = b
+        return torch.from_numpy(np.concatenate([send, recv]).astype(np.int64))
+
+    def push(self, method_id, tot_all, cr_all, me, bounds, counts, capacity):
+        hits = np.flatnonzero(self._owner == me)               # slot order = grouped by destination, slot order inside
+        tl, inc = self._tl[hits].astype(np.uint64), self._inc[hits]
+        a = np.zeros(hits.size, np.int64)
         wcdf = self.rcdf if getattr(self, "serve_residual", False) else self.cdf
         if (~inc).any():
-            a[~inc] = o.upper_bound(wcdf, np.ascontiguousarray(tv[~inc]))
+            a[~inc] = o.upper_bound(wcdf, np.ascontiguousarray(tl[~inc]))
         if inc.any():
-            a[inc] = o.upper_bound(self.ccdf, np.ascontiguousarray(tv[inc]))
-        rows = o.gather_rows(self.rows, a) if t.size else np.zeros((0, self.W))
-        packed = np.concatenate([rows, (a + self.gid0).view(np.float64).reshape(-1, 1)], axis=1)
-        return torch.from_numpy(np.ascontiguousarray(packed))
+            a[inc] = o.upper_bound(self.ccdf, np.ascontiguousarray(tl[inc]))
+        rows = o.gather_rows(self.rows, a) if hits.size else np.zeros((0, self.W))
+        slot_local = hits - self._bounds[self._dest[hits]]
+        meta = ((slot_local.astype(np.uint64) << np.uint64(32)) | (a + self.gid0).astype(np.uint64)).view(np.float64)
+        out = np.full((capacity, self.W + 1), np.nan)          # like the device buffer: entries beyond the capacity are dropped
+        k = min(capacity, hits.size)
+        out[:k] = np.concatenate([rows, meta.reshape(-1, 1)], axis=1)[:k]
+        return torch.from_numpy(out)
 
-    def commit(self, packed, perm, mf_all, tot_all):
-        pk = np.ascontiguousarray(packed.numpy()); pm = perm.numpy()
+    def commit(self, packed, mf_all, tot_all):
+        pk = np.ascontiguousarray(packed.numpy())
+        assert pk.shape[0] == self.n
+        meta = np.ascontiguousarray(pk[:, self.W]).view(np.uint64)
+        slot = (meta >> np.uint64(32)).astype(np.int64)
+        assert np.array_equal(np.sort(slot), np.arange(self.n))                       # every slot exactly once
         rows = np.empty((self.n, self.W)); anc = np.empty(self.n, np.int64)
-        rows[pm] = pk[:, :self.W]
-        anc[pm] = np.ascontiguousarray(pk[:, self.W]).view(np.int64)
+        rows[slot] = pk[:, :self.W]
+        anc[slot] = (meta & np.uint64(0xFFFFFFFF)).astype(np.int64)
         self.rows, self.parents, self.lw = rows, anc + 1, np.zeros(self.n)
         m, f = self._combine(mf_all)
         if m == -np.inf and not (f & 1):

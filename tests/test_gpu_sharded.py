@@ -46,3 +46,10 @@ def test_world1_sharded_equals_unsharded(g, o):
         sharded.pf_update(a, (t + 1,), (None,), ys[t]); g.pf_update(b, (t + 1,), (None,), ys[t])
         assert np.array_equal(a.local.traces, b.traces) and np.array_equal(a.local.log_weights, b.log_weights)
     assert sharded.get_lml_est(a) == g.get_lml_est(b) and sharded.get_ess(a) == g.get_ess(b)
+
+
+def test_hip_push_overflow_path(g, o, tmp_path, monkeypatch):
+    """send buffer smaller than the exchange: the kernel stops at the capacity, the host repeats the push at the right size"""
+    monkeypatch.setenv("GPF_PUSH_CAPACITY", "1000")
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[0])
+    test_world1_sharded_equals_unsharded(g, o)

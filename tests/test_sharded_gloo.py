@@ -59,3 +59,9 @@ def test_sharded_equals_single(g, o, tmp_path, case, world):
     assert np.array_equal(rows, f.rows) and np.array_equal(lw, f.lw)
     for p in parts:                                     # every rank sees the same global summaries
         assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
+
+
+def test_sharded_push_overflow_path(g, o, tmp_path, monkeypatch):
+    """a send buffer that is too small for the exchange: the counts reveal it and the push is repeated at the right size"""
+    monkeypatch.setenv("GPF_PUSH_CAPACITY", "7")
+    test_sharded_equals_single(g, o, tmp_path, CASES[2], 2)
