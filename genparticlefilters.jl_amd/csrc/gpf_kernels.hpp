@@ -1100,19 +1100,23 @@ __device__ __forceinline__ int push_owner(const PushTables& t, int G, int space,
 {
     const int64_t* incl = space ? t.c_incl : t.w_incl;
     int h = 0;
-    while (h < G - 1 && (uint64_t)incl[h] <= T) ++h;
+    if (G <= 8) {                                 // one node: branch-free count, the table reads are LDS broadcasts
+#pragma unroll
+        for (int g = 0; g < 7; ++g) h += (g < G - 1 && (uint64_t)incl[g] <= T) ? 1 : 0;
+    } else {
+        while (h < G - 1 && (uint64_t)incl[h] <= T) ++h;
+    }
     T_local = T - (h ? (uint64_t)incl[h - 1] : 0);
     return h;
 }
-// stratified: the strata of slots [j0, j1) cover [L(j0), L(j1)); a chunk that misses this shard's CDF range has no hit
+// stratified: the strata of slots [j0, j1) cover [L(j0), L(j1)), L(j) = j B + floor(j rem / N) in [j B, j B + rem]; a chunk
+// whose strata certainly miss this shard's CDF range has no hit (conservative bounds: no division per chunk)
 template <int METHOD>
 __device__ __forceinline__ bool push_chunk_misses(const PushArgs& a, const PushTables& t, const PushScal& s, int64_t j0, int64_t j1)
 {
     if (METHOD != 2) return false;
-    const uint64_t N = (uint64_t)a.n_global;
     const uint64_t lo = a.me ? (uint64_t)t.w_incl[a.me - 1] : 0, hi = (uint64_t)t.w_incl[a.me];
-    const uint64_t La = (uint64_t)j0 * s.B + ((uint64_t)j0 * s.rem) / N, Lb = (uint64_t)j1 * s.B + ((uint64_t)j1 * s.rem) / N;
-    return Lb <= lo || La >= hi;
+    return (uint64_t)j1 * s.B + s.rem <= lo || (uint64_t)j0 * s.B >= hi;
 }
 
 // pass 1: stage the hits (slots whose target this shard owns), count them per destination, and count who owns the
