@@ -135,8 +135,14 @@ def main():
         local.kernel_timing(kid, False)
         if cnt:
             per[kid_names[kid]] = (ms / cnt * 1e3, cnt)          # us per launch
+    if sharded_mode:
+        # the sharded resample times its two kernels under the search / gather ids: k_push_scan (every shard evaluates the
+        # targets of ALL output slots and stages its hits: W 16 B per hit) and k_push (R staged hit, R cdf cell, R row, W packed row)
+        per = {{"k_search": "k_push_scan", "k_gather": "k_push"}.get(k, k): v for k, v in per.items()}
     if per and rank == 0:
         ab = algorithmic_bytes(model.dim, local.row_width)
+        ab["k_push_scan"] = 16
+        ab["k_push"] = 16 + 8 + 8 * local.row_width + 8 * local.row_width + 8
         share = {k: v[0] * v[1] for k, v in per.items()}
         dom = max(share, key=share.get)
         us = per[dom][0]
@@ -174,6 +180,30 @@ def main():
             us = ms / max(cnt, 1) * 1e3
             gather[meth] = {"avg_launch_us": round(us, 2), "achieved": round(gbytes / us / 1e3, 1), "unit": "GB/s",
                             "frac": round(gbytes / us / 1e3 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": gbytes}
+
+    # ---- sharded runs: the same filter with STRATIFIED resampling (BASELINE.json configs[2]: monotone targets, almost no
+    #      row leaves its shard), reported beside the headline multinomial workload, same timing protocol
+    strat = None
+    if sharded_mode:
+        ks = min(K, 200)
+
+        def step_s(tq):
+            sharded.pf_resample(state, "stratified", check=False)
+            sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % K])
+        for i in range(5):
+            step_s(i)
+        barrier()
+        s0 = time.perf_counter()
+        for i in range(ks):
+            step_s(i)
+        barrier()
+        se = time.perf_counter() - s0
+        if dist is not None:
+            tt = torch.tensor([se], dtype=torch.float64, device="cpu" if one_device else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            se = float(tt.item())
+        strat = {"workload": "same filter, stratified resample every step, sort_particles=false (BASELINE.json configs[2])",
+                 "value": round(n_global * ks / se, 1), "unit": "particle-steps/sec", "steps": ks, "ms_per_step": round(se / ks * 1e3, 5)}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 / N=1 only ----
     cpu = cpu_all = None
@@ -215,6 +245,7 @@ def main():
                        "state_dim": model.dim, "parallelism": f"particle-shard x{world}"},
             "log_ml_estimate": lml,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
+            "stratified_variant": strat,
         }
         print(json.dumps(out))
     if dist is not None:
