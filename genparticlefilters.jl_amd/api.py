@@ -219,33 +219,76 @@ def pf_initialize(model: NativeModel, model_args: tuple, observations, *rest, se
     """src/initialize.jl:31-44.  `model_args` is accepted for signature parity; native models take their
     time-varying inputs through the per-step data vector `observations`. `dynamic` has no meaning for
     fixed-shape device rows and is ignored."""
-    # pf_initialize(model, args, obs, n_particles)  or  pf_initialize(model, args, obs, proposal, proposal_args, n_particles)
+    # pf_initialize(model, args, obs, n_particles) | (model, args, obs, strata, n_particles; layout) |
+    # (model, args, obs, proposal, proposal_args, n_particles)
+    layout = kw.pop("layout", "contiguous")                        # initialize.jl:66
+    strata = None
     if len(rest) == 1:
         proposal, n_particles = None, rest[0]
+    elif len(rest) == 2:
+        proposal, strata, n_particles = None, _strata_values(model, rest[0]), rest[1]
     elif len(rest) == 3:
         proposal, n_particles = rest[0], rest[2]
         if proposal is not locally_optimal:
             raise ErrorException("device filters support the native `locally_optimal` proposal only")
     else:
-        raise TypeError("pf_initialize(model, model_args, observations, [proposal, proposal_args,] n_particles)")
+        raise TypeError("pf_initialize(model, model_args, observations, [strata, | proposal, proposal_args,] n_particles)")
     state = DeviceParticleFilterState(model, n_particles, seed=seed, keep_prev=keep_prev, device=device, **kw)
     obs = _obs_vector(observations)
-    if proposal is None:
+    if strata is not None:
+        state._check(state._L.gpf_initialize_strata(state._h, _pd(obs), obs.size, _pd(strata), strata.size, int(_layout_id(layout))))
+    elif proposal is None:
         state._check(state._L.gpf_initialize(state._h, _pd(obs), obs.size))
     else:
         state._check(state._L.gpf_initialize_proposal(state._h, _pd(obs), obs.size, 1))
     return state
 
 
+def choiceproduct(*choices):
+    """src/utils.jl:57-98: the strata as a list of choice maps {address: value}: `choiceproduct(("moving", [False, True]))`.
+    A dict {address: values} or several (address, values) tuples give the Cartesian product."""
+    import itertools
+    if len(choices) == 1 and isinstance(choices[0], dict):
+        choices = tuple(choices[0].items())
+    return [dict(c) for c in itertools.product(*[[(addr, v) for v in vals] for addr, vals in choices])]
+
+
+def _layout_id(layout) -> bool:
+    if layout not in ("contiguous", "interleaved"):
+        raise ValueError("layout must be 'contiguous' or 'interleaved'")
+    return layout == "interleaved"
+
+
+def _strata_values(model, strata) -> np.ndarray:
+    """strata: an iterable of choice maps over the model's ONE discrete latent address (or of plain values)"""
+    addr = model.info.get("strata_address")
+    if addr is None:
+        raise ErrorException(f"model {model.name} has no discrete latent to stratify over")
+    vals = []
+    for st in strata:
+        if isinstance(st, dict):
+            if set(st.keys()) != {addr}:
+                raise ErrorException(f"device strata constrain the address {addr!r} only, got {sorted(st.keys())}")
+            st = st[addr]
+        vals.append(float(st))
+    if not 1 <= len(vals) <= 8:
+        raise ErrorException("1..8 strata supported")
+    return np.ascontiguousarray(vals, np.float64)
+
+
 def pf_update(state: DeviceParticleFilterState, new_args: tuple, argdiffs: tuple, observations,
-              proposal=None, proposal_args: tuple = ()):
-    """src/update.jl:12-25 (default proposal) and :79-96 (custom proposal: log weight = model_score_diff -
-    fwd_proposal_score, src/translate.jl:86-105).  Returns `state`, like the reference (update.jl:24)."""
+              proposal=None, proposal_args: tuple = (), *, layout: str = "interleaved"):
+    """src/update.jl:12-25 (default proposal), :79-96 (custom proposal: log weight = model_score_diff -
+    fwd_proposal_score, src/translate.jl:86-105) and :193-210 (stratified: the 5th argument is the strata).
+    Returns `state`, like the reference (update.jl:24)."""
     obs = _obs_vector(observations)
     if proposal is None:
         state._check(state._L.gpf_update(state._h, _pd(obs), obs.size))
     elif proposal is locally_optimal:
         state._check(state._L.gpf_update_proposal(state._h, _pd(obs), obs.size, 1))
+    elif isinstance(proposal, (list, tuple)) or hasattr(proposal, "__iter__"):
+        strata = _strata_values(state.model, proposal)
+        state._check(state._L.gpf_update_strata(state._h, _pd(obs), obs.size, _pd(strata), strata.size, int(_layout_id(layout))))
     else:
         raise ErrorException("device filters support the native `locally_optimal` proposal only")
     return state

@@ -137,9 +137,22 @@ __device__ __forceinline__ void block_max_store(double m, int f, double* __restr
     }
 }
 
+// stratified_map! (utils.jl:29-55): K strata, block size B = n div K; particle i < K B belongs to stratum i div B
+// (:contiguous) or i mod K (:interleaved); the n - K B remaining particles draw a stratum uniformly (sample(strata, R)),
+// here from one more Philox block of the particle (block index NBLK, behind the model's own blocks)
+template <class Mo>
+__device__ __forceinline__ int stratum_of(const ModelArgs& a, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t i, int64_t n, uint32_t tag)
+{
+    const int64_t K = a.n_strata, B = n / K;
+    if (i < K * B) return (int)(a.interleaved ? i % K : i / B);
+    const Philox b = rng(seed, (uint32_t)(gid0 + i), (uint32_t)Mo::NBLK, epoch, tag);
+    return (int)mulhi64(u64(b.w0, b.w1), (uint64_t)K);
+}
+
 // pf_initialize (initialize.jl:39-41) / pf_update! (update.jl:15-22): one lane per particle, row in,
 // row out, lw += log p(y|x).  Counter-based RNG: no RNG state in memory.
-template <int M, bool PROP = false>
+// MODE 0: the model's own sampler; 1: native custom proposal; 2: stratified (the discrete latent constrained per stratum)
+template <int M, int MODE = 0>
 __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, int W, double* __restrict__ rows,
                                                 double* __restrict__ lw, double* __restrict__ pmax,
@@ -150,8 +163,12 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         double x[MAX_DIM];
         double ll;
-        if constexpr (PROP) ll = Mo::propose(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
-        else {
+        if constexpr (MODE == 1) ll = Mo::propose(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+        else if constexpr (MODE == 2) {
+            const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
+            const double lp = Mo::sample_stratum(a.P, true, nullptr, a.obs, v, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+            ll = (lp + Mo::loglik(a.P, x, a.obs)) + a.logK;                      // initialize.jl:103-104
+        } else {
             Mo::sample(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
             ll = Mo::loglik(a.P, x, a.obs);
         }
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
 // GATHER: the preceding pf_resample! left its ancestor vector pending; this kernel reads row anc[i]
 // instead of row i (new_traces .= view(traces, parents), resample.jl:60, fused into the propagate) and
 // the incoming log-weights are known to be 0 (update_weights!, resample.jl:195): lw = ll, no read.
-template <int M, int W, bool KEEP_PREV, bool GATHER, bool PROP = false>
+template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0>
 __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
@@ -190,8 +207,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
         for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
         double xn[MAX_DIM];
         double ll;
-        if constexpr (PROP) ll = Mo::propose(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
-        else {
+        if constexpr (MODE == 1) ll = Mo::propose(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
+        else if constexpr (MODE == 2) {
+            const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_UPDATE)];
+            const double lp = Mo::sample_stratum(a.P, false, r, a.obs, v, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
+            ll = (lp + Mo::loglik(a.P, xn, a.obs)) + a.logK;                     // update.jl:201-206
+        } else {
             Mo::sample(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
             ll = Mo::loglik(a.P, xn, a.obs);
         }

@@ -18,10 +18,15 @@ enum : int { MODEL_LGSSM2 = 1, MODEL_BEARINGS4 = 2, MODEL_SV1 = 3, MODEL_OBJECT_
 constexpr int MAX_PARAMS = 24;
 constexpr int MAX_OBS = 4;
 constexpr int MAX_DIM = 4;
+constexpr int MAX_STRATA = 8;
 
 struct ModelArgs {          // passed by value in the kernarg segment: no device copy per step
     double P[MAX_PARAMS];
     double obs[MAX_OBS];
+    // stratified initialisation / update (reference src/initialize.jl:92-109, src/update.jl:193-210, src/utils.jl:29-55)
+    double strata[MAX_STRATA];   // value of the model's discrete latent in each stratum
+    double logK;                 // log(n_strata)
+    int32_t n_strata, interleaved;
 };
 
 template <int M> struct Model;
@@ -30,6 +35,7 @@ template <int M> struct Model;
 // P = [a11 a12 a21 a22 | sq | s0 | 1/sr | 2(log sr + log(2 pi)/2) |
 //      locally optimal proposal, transition: gain sv 1/sv 2(log sv + ..) 1/sq 2(log sq + ..) | initial: gain0 sv0 1/sv0 2(log sv0 + ..) 1/s0 2(log s0 + ..)]
 template <> struct Model<MODEL_LGSSM2> {
+    static constexpr bool HAS_STRATA = false;
     static constexpr int D = 2, NBLK = 1;
     static constexpr bool HAS_PROPOSAL = true;
     // custom-proposal update (reference src/update.jl:79-96, src/translate.jl:86-105 without transform;
@@ -75,6 +81,7 @@ template <> struct Model<MODEL_LGSSM2> {
 // bearings-only tracking, x = (px, py, vx, vy)   (BASELINE config 4)
 // P = [mu0..3 | s0..3 | sp | sv | 1/sb | log sb + log(2 pi)/2]
 template <> struct Model<MODEL_BEARINGS4> {
+    static constexpr bool HAS_STRATA = false;
     static constexpr int D = 4, NBLK = 2;
     static constexpr bool HAS_PROPOSAL = false;
     static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
@@ -107,6 +114,7 @@ template <> struct Model<MODEL_BEARINGS4> {
 // stochastic volatility, x = h   (BASELINE config 5)
 // P = [mu | phi | sigma | sigma/sqrt(1-phi^2) | log(2 pi)/2]
 template <> struct Model<MODEL_SV1> {
+    static constexpr bool HAS_STRATA = false;
     static constexpr int D = 1, NBLK = 1;
     static constexpr bool HAS_PROPOSAL = false;
     static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
@@ -125,11 +133,29 @@ template <> struct Model<MODEL_SV1> {
 };
 
 // README object_motion (reference README.md:43-55; BASELINE config 1), x = (moving, y)
-// P = [p(moving|moving) | p(moving|still) | sigma_y | 1/sigma_obs | log sigma_obs + log(2 pi)/2]
+// P = [p(moving|moving) | p(moving|still) | sigma_y | 1/sigma_obs | log sigma_obs + log(2 pi)/2 |
+//      log p(moving|moving) | log(1 - p(moving|moving)) | log p(moving|still) | log(1 - p(moving|still))]
 // obs = [y_obs, sin(t)]
 template <> struct Model<MODEL_OBJECT_MOTION> {
     static constexpr int D = 2, NBLK = 2;
     static constexpr bool HAS_PROPOSAL = false;
+    static constexpr bool HAS_STRATA = true;
+    // stratified generate / update: `moving` is constrained to the stratum's value (merge(stratum, observations),
+    // initialize.jl:102, update.jl:200); y is sampled as usual.  Returns log p(moving = value | moving_{t-1}), the part of
+    // the weight increment Gen adds for the constrained latent choice.
+    static GPF_HD double sample_stratum(const double* P, bool first, const double* xp, const double* obs, double value,
+                                        uint64_t seed, uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
+    {
+        double z0, z1;
+        normal2(rng(seed, gid, blk0 + 1, epoch, tag), z0, z1);
+        const double pm = first ? 0.0 : xp[0], py = first ? 0.0 : xp[1];
+        const double mv = (value != 0.0) ? 1.0 : 0.0;
+        const double lp = (pm != 0.0) ? ((mv != 0.0) ? P[5] : P[6]) : ((mv != 0.0) ? P[7] : P[8]);
+        const double vel = (mv != 0.0) ? obs[1] : 0.0;
+        xn[0] = mv;
+        xn[1] = (py + vel) + P[2] * z0;
+        return lp;
+    }
     static GPF_HD void sample(const double* P, bool first, const double* xp, const double* obs, uint64_t seed,
                               uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
     {

@@ -207,11 +207,12 @@ gpf_status alloc_particle_buffers(gpf_filter* h)
 #endif
 int step_grid(const gpf_filter* h) { return std::min(grid_for(h, h->n, STEP_BLOCKS_PER_CU), MAX_PARTIALS); }
 
-template <int M, bool KEEP, bool PROP = false>
+// PROP 0: the model's own sampler; 1: native custom proposal; 2: stratified
+template <int M, bool KEEP, int PROP = 0>
 void launch_step_t(gpf_filter* h, int grid)
 {
     constexpr int Wc = row_width(Model<M>::D, KEEP);
-    if constexpr (PROP && !Model<M>::HAS_PROPOSAL) { (void)h; (void)grid; return; }
+    if constexpr ((PROP == 1 && !Model<M>::HAS_PROPOSAL) || (PROP == 2 && !Model<M>::HAS_STRATA)) { (void)h; (void)grid; return; }
     else if (h->pending_gather)
         GPF_LAUNCH((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags);
@@ -219,10 +220,10 @@ void launch_step_t(gpf_filter* h, int grid)
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags);
 }
-template <int M, bool PROP = false>
+template <int M, int PROP = 0>
 void launch_init_t(gpf_filter* h, int grid)
 {
-    if constexpr (PROP && !Model<M>::HAS_PROPOSAL) { (void)h; (void)grid; return; }
+    if constexpr ((PROP == 1 && !Model<M>::HAS_PROPOSAL) || (PROP == 2 && !Model<M>::HAS_STRATA)) { (void)h; (void)grid; return; }
     else
         GPF_LAUNCH((k_init<M, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw, h->pmax, h->pflags);
@@ -234,6 +235,16 @@ bool model_has_proposal(int model)
         case MODEL_BEARINGS4: return Model<MODEL_BEARINGS4>::HAS_PROPOSAL;
         case MODEL_SV1: return Model<MODEL_SV1>::HAS_PROPOSAL;
         case MODEL_OBJECT_MOTION: return Model<MODEL_OBJECT_MOTION>::HAS_PROPOSAL;
+    }
+    return false;
+}
+bool model_has_strata(int model)
+{
+    switch (model) {
+        case MODEL_LGSSM2: return Model<MODEL_LGSSM2>::HAS_STRATA;
+        case MODEL_BEARINGS4: return Model<MODEL_BEARINGS4>::HAS_STRATA;
+        case MODEL_SV1: return Model<MODEL_SV1>::HAS_STRATA;
+        case MODEL_OBJECT_MOTION: return Model<MODEL_OBJECT_MOTION>::HAS_STRATA;
     }
     return false;
 }
@@ -716,10 +727,11 @@ gpf_status gpf_synchronize(gpf_handle h)
     return GPF_OK;
 }
 
-static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs, bool prop)
+static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs, int prop)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
-    if (prop && !model_has_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no native proposal");
+    if (prop == 1 && !model_has_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no native proposal");
+    if (prop == 2 && !model_has_strata(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no discrete latent to stratify over");
     if (h->parent) return fail(h, GPF_ERR_STATE, "gpf_initialize on a sub-state view");
     h->generation += 1;
     gpf_status s = set_obs(h, obs, n_obs);
@@ -728,8 +740,9 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
     if ((s = hist_begin_step(h, true))) return s;
     const int grid = step_grid(h);
     s = timed(h, GPF_K_STEP, [&] {
-        if (prop) { DISPATCH_MODEL(h, (launch_init_t<MM, true>(h, grid))); }
-        else      { DISPATCH_MODEL(h, (launch_init_t<MM, false>(h, grid))); }
+        if (prop == 1)      { DISPATCH_MODEL(h, (launch_init_t<MM, 1>(h, grid))); }
+        else if (prop == 2) { DISPATCH_MODEL(h, (launch_init_t<MM, 2>(h, grid))); }
+        else                { DISPATCH_MODEL(h, (launch_init_t<MM, 0>(h, grid))); }
     });
     if (s) return s;
     h->pending_gather = false;
@@ -744,26 +757,30 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
     return GPF_OK;
 }
 
-gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs) { return initialize_impl(h, obs, n_obs, false); }
+gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs) { return initialize_impl(h, obs, n_obs, 0); }
 gpf_status gpf_initialize_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal)
 {
     if (proposal != GPF_PROPOSAL_LOCALLY_OPTIMAL) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown proposal id");
-    return initialize_impl(h, obs, n_obs, true);
+    return initialize_impl(h, obs, n_obs, 1);
 }
 
-static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, bool prop)
+static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, int prop)
 {
     gpf_status s = check_ready(h);
     if (s) return s;
-    if (prop && !model_has_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no native proposal");
+    if (prop == 1 && !model_has_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no native proposal");
+    if (prop == 2 && !model_has_strata(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no discrete latent to stratify over");
     if ((s = set_obs(h, obs, n_obs))) return s;
     if ((s = hist_begin_step(h, false))) return s;
     const int grid = step_grid(h);
     const bool keep = h->cfg.keep_prev != 0;
     s = timed(h, GPF_K_STEP, [&] {
-        if (prop) {
-            if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true, true>(h, grid))); }
-            else      { DISPATCH_MODEL(h, (launch_step_t<MM, false, true>(h, grid))); }
+        if (prop == 1) {
+            if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true, 1>(h, grid))); }
+            else      { DISPATCH_MODEL(h, (launch_step_t<MM, false, 1>(h, grid))); }
+        } else if (prop == 2) {
+            if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true, 2>(h, grid))); }
+            else      { DISPATCH_MODEL(h, (launch_step_t<MM, false, 2>(h, grid))); }
         } else {
             if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true>(h, grid))); }
             else      { DISPATCH_MODEL(h, (launch_step_t<MM, false>(h, grid))); }
@@ -780,11 +797,33 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, bo
     return view_exit(h);            // sub-state: copy back (utils.jl:17-20)
 }
 
-gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs) { return update_impl(h, obs, n_obs, false); }
+gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs) { return update_impl(h, obs, n_obs, 0); }
 gpf_status gpf_update_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal)
 {
     if (proposal != GPF_PROPOSAL_LOCALLY_OPTIMAL) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown proposal id");
-    return update_impl(h, obs, n_obs, true);
+    return update_impl(h, obs, n_obs, 1);
+}
+
+// stratified initialisation / update: the strata are values of the model's discrete latent
+static gpf_status set_strata(gpf_handle h, const double* values, int32_t n_strata, int32_t interleaved)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (!values || n_strata < 1 || n_strata > MAX_STRATA) return fail(h, GPF_ERR_INVALID_ARGUMENT, "need 1..8 strata");
+    if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, "stratified initialisation / update of a sharded filter is not supported");
+    for (int k = 0; k < MAX_STRATA; ++k) h->args.strata[k] = k < n_strata ? values[k] : 0.0;
+    h->args.n_strata = n_strata; h->args.interleaved = interleaved != 0;
+    h->args.logK = log_((double)n_strata);
+    return GPF_OK;
+}
+gpf_status gpf_initialize_strata(gpf_handle h, const double* obs, int32_t n_obs, const double* values, int32_t n_strata, int32_t interleaved)
+{
+    gpf_status s = set_strata(h, values, n_strata, interleaved);
+    return s ? s : initialize_impl(h, obs, n_obs, 2);
+}
+gpf_status gpf_update_strata(gpf_handle h, const double* obs, int32_t n_obs, const double* values, int32_t n_strata, int32_t interleaved)
+{
+    gpf_status s = set_strata(h, values, n_strata, interleaved);
+    return s ? s : update_impl(h, obs, n_obs, 2);
 }
 
 gpf_status gpf_resample(gpf_handle h, int32_t method, double priority_alpha, int32_t sort_particles, int32_t check,

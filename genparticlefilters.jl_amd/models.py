@@ -57,8 +57,10 @@ def sv1(mu: float = -1.0, phi: float = 0.97, sigma: float = 0.15) -> NativeModel
 
 def object_motion(p_stay: float = 0.75, p_start: float = 0.25, sy: float = 0.01, sobs: float = 0.25) -> NativeModel:
     """README.md:43-55 of the reference.  Per-step data vector = [y_obs, sin(t)]."""
-    p = np.array([p_stay, p_start, sy, 1.0 / sobs, math.log(sobs) + _HALF_LOG_2PI])
-    return NativeModel(MODEL_OBJECT_MOTION, "object_motion", 2, 2, p, dict(sy=sy, sobs=sobs))
+    p = np.array([p_stay, p_start, sy, 1.0 / sobs, math.log(sobs) + _HALF_LOG_2PI,
+                  math.log(p_stay), math.log1p(-p_stay), math.log(p_start), math.log1p(-p_start)])   # stratified init/update
+    return NativeModel(MODEL_OBJECT_MOTION, "object_motion", 2, 2, p, dict(sy=sy, sobs=sobs, p_stay=p_stay, p_start=p_start,
+                                                                          strata_address="moving"))
 
 
 def by_name(name: str) -> NativeModel:

@@ -97,6 +97,14 @@ typedef enum { GPF_PROPOSAL_LOCALLY_OPTIMAL = 1 } gpf_proposal;
 gpf_status gpf_initialize_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal);
 gpf_status gpf_update_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal);
 
+/* Stratified initialisation / update over a discrete latent          src/initialize.jl:92-109, src/update.jl:193-210,
+ * stratified_map! src/utils.jl:29-55.  values[k] = the value the model's discrete latent is constrained to in stratum k
+ * (GPF_MODEL_OBJECT_MOTION: `moving`, 0 or 1); K = n_strata <= 8, block size B = n div K; particle i < K B belongs to
+ * stratum i div B (interleaved = 0, :contiguous) or i mod K (interleaved = 1); the remaining particles draw their stratum
+ * uniformly.  log_weights[i] (+)= log p(latent = value | parents) + log p(obs | x) + log K. */
+gpf_status gpf_initialize_strata(gpf_handle h, const double* obs, int32_t n_obs, const double* values, int32_t n_strata, int32_t interleaved);
+gpf_status gpf_update_strata(gpf_handle h, const double* obs, int32_t n_obs, const double* values, int32_t n_strata, int32_t interleaved);
+
 /* pf_resample!(state, method; priority_fn, check[, sort_particles])  src/resample.jl:19-175
  *   priority_alpha: NaN -> priority_fn = nothing; otherwise priority_fn = w -> priority_alpha * w
  *                   (the tempering family the reference's tests use, test/resample.jl:15).

@@ -214,6 +214,17 @@ function var(s::DeviceParticleFilterState, addr::Pair{<:Integer,<:Integer})
     out = Ref{Cdouble}(0); check(s, ccall((:gpf_history_var, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cdouble}), s.handle, addr.first, addr.second, out)); out[]
 end
 
+# stratified initialisation / update (src/initialize.jl:92-109, src/update.jl:193-210): strata = values of the model's discrete latent
+function pf_initialize(model::NativeModel, args::Tuple, obs::Vector{Float64}, strata::Vector{Float64}, n::Int; layout::Symbol=:contiguous, kwargs...)
+    s = DeviceParticleFilterState(model, n; kwargs...)
+    check(s, ccall((:gpf_initialize_strata, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint),
+                   s.handle, obs, length(obs), strata, length(strata), layout != :contiguous)); s
+end
+function pf_update!(s::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, obs::Vector{Float64}, strata::Vector{Float64}; layout::Symbol=:interleaved)
+    check(s, ccall((:gpf_update_strata, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint),
+                   s.handle, obs, length(obs), strata, length(strata), layout != :contiguous)); s
+end
+
 # Gen.sample_unweighted_traces(state, n) (src/utils.jl:189-194): rows of the drawn particles (n x row_width) and their indices
 function sample_unweighted_traces(s::DeviceParticleFilterState, n::Int)
     dim = Ref{Cint}(0); w = Ref{Cint}(0)

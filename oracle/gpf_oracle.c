@@ -258,6 +258,65 @@ O_EXPORT void o_step_proposal(int model, const double *P, uint64_t seed, uint32_
     }
 }
 
+/* stratified initialisation / update (initialize.jl:92-109, update.jl:193-210): the model's discrete latent is
+ * constrained to the stratum's value (merge(stratum, observations)); returns log p(latent = value | parents), the part
+ * of the weight increment Gen adds for the constrained latent choice.  Only the object_motion model has one. */
+static double model_sample_stratum(int model, const double *P, int first, const double *xp, const double *obs, double value,
+                                   uint64_t seed, uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double *xn)
+{
+    double z0, z1;
+    (void)model;                                                        /* O_MODEL_OBJECT_MOTION, README.md:43-55 */
+    o_normal2(o_rng(seed, gid, blk0 + 1, epoch, tag), &z0, &z1);
+    double pm = first ? 0.0 : xp[0], py = first ? 0.0 : xp[1];
+    double mv = (value != 0.0) ? 1.0 : 0.0;
+    double lp = (pm != 0.0) ? ((mv != 0.0) ? P[5] : P[6]) : ((mv != 0.0) ? P[7] : P[8]);
+    double vel = (mv != 0.0) ? obs[1] : 0.0;
+    xn[0] = mv;
+    xn[1] = (py + vel) + P[2] * z0;
+    return lp;
+}
+/* stratified_map! (utils.jl:29-55): block size B = n div K; i < K B -> stratum i div B (:contiguous) or i mod K
+ * (:interleaved); the remaining particles draw a stratum uniformly (sample(strata, n_remaining), utils.jl:47) from one
+ * more Philox block of the particle (block index = the model's block count) */
+static int stratum_of(int model, int K, int interleaved, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t i, int64_t n, uint32_t tag)
+{
+    int64_t B = n / K;
+    if (i < (int64_t)K * B) return (int)(interleaved ? i % K : i / B);
+    o_philox_t b = o_rng(seed, (uint32_t)(gid0 + i), (uint32_t)model_nblk(model), epoch, tag);
+    return (int)o_mulhi64(((uint64_t)b.v[0] << 32) | b.v[1], (uint64_t)K);
+}
+O_EXPORT void o_init_strata(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n, int W,
+                            const double *obs, const double *values, int K, int interleaved, double logK, double *rows, double *lw)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double *r = rows + i * W;
+        for (int k = 0; k < W; ++k) r[k] = 0.0;
+        double v = values[stratum_of(model, K, interleaved, seed, epoch, gid0, i, n, O_TAG_INIT)];
+        double lp = model_sample_stratum(model, P, 1, NULL, obs, v, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_INIT, r);
+        lw[i] = (lp + model_loglik(model, P, r, obs)) + logK;           /* initialize.jl:103-104 */
+    }
+}
+O_EXPORT void o_step_strata(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n, int W, int keep_prev,
+                            const double *obs, const double *values, int K, int interleaved, double logK,
+                            const double *rows_in, double *rows_out, double *lw)
+{
+    int d = model_dim(model);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double *ri = rows_in + i * W;
+        double *ro = rows_out + i * W;
+        double xn[4], xp[4];
+        double v = values[stratum_of(model, K, interleaved, seed, epoch, gid0, i, n, O_TAG_UPDATE)];
+        double lp = model_sample_stratum(model, P, 0, ri, obs, v, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_UPDATE, xn);
+        for (int k = 0; k < d; ++k) xp[k] = ri[k];
+        for (int k = 0; k < W; ++k) ro[k] = 0.0;
+        for (int k = 0; k < d; ++k) ro[k] = xn[k];
+        if (keep_prev) for (int k = 0; k < d; ++k) ro[d + k] = xp[k];
+        lw[i] = lw[i] + ((lp + model_loglik(model, P, xn, obs)) + logK); /* update.jl:201-206 */
+    }
+}
+
 /* pf_initialize default proposal, initialize.jl:39-41: x ~ prior, log_weights[i] = log p(y1|x) */
 O_EXPORT void o_init(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
                      int W, const double *obs, double *rows, double *lw)

@@ -65,6 +65,8 @@ def lib():
     sig("o_step", None, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, _f64p, _f64p, _f64p)
     sig("o_init_proposal", None, i32, _f64p, u64, u32, i64, i64, i32, _f64p, _f64p, _f64p)
     sig("o_step_proposal", None, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, _f64p, _f64p, _f64p)
+    sig("o_init_strata", None, i32, _f64p, u64, u32, i64, i64, i32, _f64p, _f64p, i32, i32, f64, _f64p, _f64p)
+    sig("o_step_strata", None, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, _f64p, i32, i32, f64, _f64p, _f64p, _f64p)
     sig("o_move", u64, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, i32, i32, _f64p, _f64p, _f64p)
     sig("o_max_flags", None, _f64p, i64, pf64, pi32)
     sig("o_fixq", None, _f64p, i64, f64, i32, i32, _u64p)
@@ -223,11 +225,16 @@ class OracleFilter:
         self.n_accepted = 0
 
     # -- initialize.jl:31-44
-    def initialize(self, obs, proposal: bool = False):
+    def initialize(self, obs, proposal: bool = False, strata=None, layout: str = "contiguous"):
         obs = np.ascontiguousarray(obs, np.float64)
         self.hist_x, self.hist_map = [None], [None]
-        f = lib().o_init_proposal if proposal else lib().o_init          # initialize.jl:46-62 / :31-44
-        f(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, obs, self.rows, self.lw)
+        if strata is not None:                                           # initialize.jl:92-109 + stratified_map!, utils.jl:29-55
+            v = np.ascontiguousarray(strata, np.float64)
+            lib().o_init_strata(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, obs, v, v.size,
+                                int(layout != "contiguous"), olog(float(v.size)), self.rows, self.lw)
+        else:
+            f = lib().o_init_proposal if proposal else lib().o_init      # initialize.jl:46-62 / :31-44
+            f(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, obs, self.rows, self.lw)
         self.lml_est = 0.0
         self.parents = np.arange(1, self.n + 1, dtype=np.int64)
         self.epoch += 1
@@ -236,15 +243,20 @@ class OracleFilter:
         return self
 
     # -- update.jl:12-25
-    def update(self, obs, proposal: bool = False):
+    def update(self, obs, proposal: bool = False, strata=None, layout: str = "interleaved"):
         obs = np.ascontiguousarray(obs, np.float64)
         if self.history:                                            # the step that ends now, in its final order
             self.hist_x[-1] = self.rows[:, :self.d].copy()
             self.hist_x.append(None); self.hist_map.append(None)
         new_rows = np.empty_like(self.rows)
-        f = lib().o_step_proposal if proposal else lib().o_step          # update.jl:79-96 / :12-25
-        f(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, int(self.keep_prev),
-          obs, self.rows, new_rows, self.lw)                        # :15-22
+        if strata is not None:                                           # update.jl:193-210 + stratified_map!, utils.jl:29-55
+            v = np.ascontiguousarray(strata, np.float64)
+            lib().o_step_strata(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, int(self.keep_prev), obs, v, v.size,
+                                int(layout != "contiguous"), olog(float(v.size)), self.rows, new_rows, self.lw)
+        else:
+            f = lib().o_step_proposal if proposal else lib().o_step      # update.jl:79-96 / :12-25
+            f(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, int(self.keep_prev),
+              obs, self.rows, new_rows, self.lw)                    # :15-22
         self.rows = new_rows                                        # update_refs!, utils.jl:10-15
         self.epoch += 1
         self.has_prev = True
@@ -533,13 +545,18 @@ class OracleSubState:
     def log_ml_estimate(self) -> float:                                 # utils.jl:174-178
         return self.source.lml_est + self.summary().lse - olog(float(self.n))
 
-    def update(self, obs, proposal: bool = False):                      # update.jl:12-25 on the view + utils.jl:17-20
+    def update(self, obs, proposal: bool = False, strata=None, layout: str = "interleaved"):   # update.jl:12-25 / :193-210 on the view + utils.jl:17-20
         s = self.source
         obs = np.ascontiguousarray(obs, np.float64)
         rin = np.ascontiguousarray(self.rows); lw = np.ascontiguousarray(self.lw)
         rout = np.empty_like(rin)
-        f = lib().o_step_proposal if proposal else lib().o_step
-        f(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.keep_prev), obs, rin, rout, lw)
+        if strata is not None:
+            v = np.ascontiguousarray(strata, np.float64)
+            lib().o_step_strata(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.keep_prev), obs, v, v.size,
+                                int(layout != "contiguous"), olog(float(v.size)), rin, rout, lw)
+        else:
+            f = lib().o_step_proposal if proposal else lib().o_step
+            f(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.keep_prev), obs, rin, rout, lw)
         s.rows[self.sl] = rout; s.lw[self.sl] = lw
         s.epoch += 1; s.has_prev = True; self.last_obs = obs
         return self
