@@ -111,3 +111,35 @@ def test_large_single_gpu_8e6_properties(g):
     st.log_weights = np.zeros(N)
     g.pf_resample(st, "residual", check=False)
     assert np.array_equal(st.parents, np.arange(1, N + 1))
+
+
+def test_maximum_size_64e6_global_top_level(g):
+    """N = 2^26 on one GPU: the top level of the CDF (32768 tile prefixes) no longer fits the search kernel's LDS table, so the
+    search walks it in global memory; K = 36-bit weights.  Size-independent properties only."""
+    N = 1 << 26
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=11)
+    lml0, ess0 = g.get_lml_est(st), g.get_ess(st)
+    assert 0.05 * N < ess0 < N
+    x0 = st.traces[:, 0].copy()
+    w = np.exp(st.log_weights - st.log_weights.max())
+    g.pf_resample(st, "stratified", sort_particles=False, check=False)
+    par = st.parents
+    assert par[0] >= 1 and par[-1] <= N and np.all(np.diff(par) >= 0)            # monotone ancestors
+    assert np.array_equal(st.traces[:, 0], x0[par - 1])
+    assert abs(g.get_lml_est(st) - lml0) <= 1e-9 * abs(lml0)
+    # stratified: every particle gets floor(N w) or ceil(N w) children up to the stratum jitter (within 2)
+    counts = np.bincount(par - 1, minlength=N)
+    expect = N * w / w.sum()
+    assert np.max(np.abs(counts - expect)) <= 2.0
+    del counts, expect, w
+    g.pf_update(st, (2,), (None,), ys[1])
+    lml1 = g.get_lml_est(st)
+    g.pf_resample(st, "multinomial", check=False)
+    par = st.parents
+    assert par.min() >= 1 and par.max() <= N
+    assert abs(g.get_lml_est(st) - lml1) <= 1e-9 * abs(lml1)
+    st.log_weights = np.zeros(N)
+    g.pf_resample(st, "residual", check=False)
+    assert np.array_equal(st.parents, np.arange(1, N + 1))
+    st.close()
