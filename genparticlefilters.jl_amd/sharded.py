@@ -39,6 +39,8 @@ from . import _lib
 from .api import DeviceParticleFilterState, ErrorException, _obs_vector, _pd
 
 RESAMPLE_METHODS = {"multinomial": 0, "residual": 1, "stratified": 2}
+# tests: issue the real collectives even in a 1-rank process group (exercises the RCCL call path on a 1-GPU box)
+_FORCE_COLLECTIVES = os.environ.get("GPF_SHARD_FORCE_COLLECTIVES") == "1"
 SPACE_COUNTS = 1 << 62
 
 
@@ -164,7 +166,7 @@ class ShardedParticleFilterState:
 
     # ---- collectives (tiny, latency-bound: SURVEY.md §2.3 C1-C4)
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.world == 1 and not _FORCE_COLLECTIVES:
             return t.unsqueeze(0)
         src = self._stage(t.contiguous().view(-1))
         flat = torch.empty(self.world * t.numel(), dtype=t.dtype, device=src.device)
@@ -173,7 +175,7 @@ class ShardedParticleFilterState:
 
     def _all_to_all(self, send: torch.Tensor, send_counts, recv_counts) -> torch.Tensor:
         """variable-size all-to-all along dim 0"""
-        if self.world == 1:
+        if self.world == 1 and not _FORCE_COLLECTIVES:
             return send
         src = self._stage(send.contiguous())
         out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=src.device)

@@ -9,13 +9,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out_dir):
+def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out_dir, backend="gloo"):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if backend == "nccl":
+        os.environ["GPF_SHARD_FORCE_COLLECTIVES"] = "1"     # read at import of gpf_amd.sharded
+    import torch
     import torch.distributed as dist
     import gpf_amd as g
     from gpf_amd import sharded
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         model = g.models.by_name(model_name)
         ys = g.models.simulate(model, T)

@@ -53,3 +53,17 @@ def test_hip_push_overflow_path(g, o, tmp_path, monkeypatch):
     monkeypatch.setenv("GPF_PUSH_CAPACITY", "1000")
     test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[0])
     test_world1_sharded_equals_unsharded(g, o)
+
+
+@pytest.mark.parametrize("case", CASES[:3], ids=[f"{c[0]}-{c[1]}" for c in CASES[:3]])
+def test_rccl_collectives_one_rank(g, o, tmp_path, case):
+    """the REAL collectives (all_gather_into_tensor, all_to_all_single with split sizes) on the nccl = RCCL backend in a
+    1-rank process group: the call path the multi-GPU runs take, as far as a 1-GPU box can exercise it"""
+    model_name, method, n_global, T, ess_frac, rejuv = case
+    n_global *= 20
+    mp.spawn(shard_worker_gpu.run, args=(1, free_port(), model_name, method, n_global, T, ess_frac, rejuv, str(tmp_path), "nccl"),
+             nprocs=1, join=True)
+    f, ess_log, lml_log = single(g, o, model_name, method, n_global, T, ess_frac, rejuv)
+    p = np.load(os.path.join(tmp_path, "rank0.npz"))
+    assert np.array_equal(p["parents"], f.parents) and np.array_equal(p["rows"], f.rows) and np.array_equal(p["lw"], f.lw)
+    assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
