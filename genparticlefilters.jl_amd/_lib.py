@@ -73,7 +73,7 @@ SYMBOLS = [
     ("gpf_proportion", C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, _pd]),
     # shard-level building blocks: device pointers are passed as integers (tensor.data_ptr())
     ("gpf_shard_weight_max", C.c_int, [_H, C.c_void_p]),
-    ("gpf_shard_weight_scan", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("gpf_shard_weight_scan", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("gpf_shard_residual_scan", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p]),
     ("gpf_shard_push_count", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
     ("gpf_shard_push", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_void_p, C.c_int64,

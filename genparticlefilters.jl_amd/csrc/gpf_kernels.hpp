@@ -465,7 +465,8 @@ struct ScanOut {
 // lane l holds elements 2l, 2l+1 of each row, so every global access is 16 B per lane, contiguous
 // across the wave (1 KiB per wave-instruction), for the loads AND the CDF stores.
 constexpr int SCAN_ROWS = 4;
-// MODE 0: plain scan of In; 1: fixed-point weights (folds the max partials); 2: as 1, plus sum q^2 for the ESS
+// MODE 0: plain scan of In; 1: fixed-point weights (folds the max partials); 2: as 1, plus sum q^2 for the ESS;
+// 3 / 4: as 1 / 2 with the maximum and flags taken from the np gathered (max, flags) pairs of the shards (pmax = mf_all)
 template <class In, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles,
                                                 const double* __restrict__ pmax, const int32_t* __restrict__ pflags,
@@ -481,13 +482,18 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
     uint64_t* const d_agg = dcur;
     uint64_t* const d_pre = dcur + ntiles;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * BLOCK) dnext[i] = 0;
-    constexpr bool WANT_Q = MODE == 2;
+    constexpr bool WANT_Q = MODE == 2 || MODE == 4;
     if constexpr (MODE >= 1) {
         double m; int f;
 #ifdef GPF_ABL_SCAN_NOFOLD
         m = 0.0; f = 0; (void)sm; (void)sf;
 #else
-        fold_partials(pmax, pflags, np, sm, sf, m, f);
+        if constexpr (MODE >= 3) {
+            m = -__builtin_huge_val(); f = 0;
+            for (int g = 0; g < np; ++g) { const double v = pmax[2 * g]; m = v > m ? v : m; f |= (int)pmax[2 * g + 1]; }
+            if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+            (void)sm; (void)sf;
+        } else fold_partials(pmax, pflags, np, sm, sf, m, f);
 #endif
         in.m = m; in.flags = f;
         if (blockIdx.x == 0 && threadIdx.x == 0) { ws_out->m = m; ws_out->flags = f; }
@@ -998,18 +1004,9 @@ __global__ void k_pack_mflags(const double* __restrict__ pmax, const int32_t* __
     fold_partials(pmax, pflags, np, sm, sf, m, f);
     if (threadIdx.x == 0) { out2[0] = m; out2[1] = (double)(f & (FLAG_NAN | FLAG_POSINF)); }
 }
-// the gathered (max, flags) of all G shards -> the global pair, where k_scan expects its partials
-__global__ void k_unpack_mflags(const double* __restrict__ mf_all, int G, double* pmax, int32_t* pflags)
+// {Ql0..3} -> out5[1..4]: limb sums of sum q^2 folded over the scan blocks (exact integers); out5[0] = S_local is written by the scan
+__global__ void k_export_q(const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double m = -__builtin_huge_val(); int f = 0;
-        for (int g = 0; g < G; ++g) { const double v = mf_all[2 * g]; m = v > m ? v : m; f |= (int)mf_all[2 * g + 1]; }
-        pmax[0] = m; pflags[0] = f;
-    }
-}
-__global__ void k_export_summary(const WSum* ws, const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5)
-{
-    // {S_local, Ql0..3}: limb sums folded over the scan blocks (exact integers)
     __shared__ uint64_t s_q[NWAVES][4];
     uint64_t ql[4] = {0, 0, 0, 0};
     for (int b = threadIdx.x; b < nblk; b += BLOCK)
@@ -1022,7 +1019,6 @@ __global__ void k_export_summary(const WSum* ws, const uint64_t* __restrict__ bl
         for (int w = 0; w < NWAVES; ++w) t += s_q[w][threadIdx.x];
         out5[1 + threadIdx.x] = (int64_t)t;
     }
-    if (threadIdx.x == 0) out5[0] = (int64_t)ws->S;
 }
 // global S (and residual shift) into the device scalar block from the gathered shard totals
 // tot_all = the gathered {S_local, Ql0..3} of all G shards -> the global S

@@ -352,14 +352,16 @@ int scan_grid(const gpf_filter* h) { return (int)std::max<int64_t>(1, std::min<i
 
 // one scan launch on descriptor channel `ch` (0 weights, 1 residual counts, 2 residual weights)
 template <class In, int FIXQ>
-gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, bool want_cdf, uint64_t* total_out)
+gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, bool want_cdf, uint64_t* total_out,
+                       const double* mf_all = nullptr)
 {
+    const double* pmax = mf_all ? mf_all : h->pmax;
     uint64_t* dc = h->desc[ch][h->dcur[ch]];
     uint64_t* dn = h->desc[ch][1 - h->dcur[ch]];
     const int gs = scan_grid(h);
     const ScanOut so{want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch]};
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
-        GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, h->pmax, h->pflags, np, slot,
+        GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, pmax, h->pflags, np, slot,
                            so, dc, dn, total_out, h->blockQ, &h->sc->timeout);
     });
     if (s) return s;
@@ -1475,19 +1477,23 @@ gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
     return GPF_OK;
 }
 
-gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, int64_t* out5)
+gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, int32_t want_q, int64_t* out5)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!mf_all || !out5 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
-    GPF_LAUNCH(k_unpack_mflags, dim3(1), dim3(64), 0, h->stream, mf_all, (int)G, h->pmax, h->pflags);
     h->max_valid = false;
     InFixQ in{raw_view(h), nullptr, h->K, 0.0, 0};
     const int gs = scan_grid(h);
-    if ((s = scan_launch<InFixQ, 2>(h, 0, in, 1, &h->sc->raw, true, &h->sc->raw.S))) return s;
-    GPF_LAUNCH(k_export_summary, dim3(1), dim3(BLOCK), 0, h->stream, &h->sc->raw, h->blockQ, gs, out5);
+    // the scan folds the gathered (max, flags) pairs itself and writes the shard total straight into out5[0]
+    if (want_q) {
+        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all))) return s;
+        GPF_LAUNCH(k_export_q, dim3(1), dim3(BLOCK), 0, h->stream, h->blockQ, gs, out5);
+    } else {
+        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all))) return s;
+    }
     HIP_TRY(h, hipGetLastError());
-    h->raw_valid = false;            // sc->raw holds a LOCAL sum under a GLOBAL max: not the unsharded summary
+    h->raw_valid = false;            // sc->raw holds the GLOBAL max but no sum: not the unsharded summary
     return GPF_OK;
 }
 

@@ -85,9 +85,9 @@ class HipShardBackend:
         self._ck(self.L.gpf_shard_weight_max(self.h, out.data_ptr()))
         return out
 
-    def weight_scan(self, mf_all):
-        out = torch.empty(5, dtype=torch.int64, device=self.device)
-        self._ck(self.L.gpf_shard_weight_scan(self.h, mf_all.data_ptr(), mf_all.shape[0], out.data_ptr()))
+    def weight_scan(self, mf_all, want_q=True):
+        out = torch.empty(5, dtype=torch.int64, device=self.device)      # [1:5] stay undefined without want_q: nobody reads them
+        self._ck(self.L.gpf_shard_weight_scan(self.h, mf_all.data_ptr(), mf_all.shape[0], int(want_q), out.data_ptr()))
         return out
 
     def residual_scan(self, tot_all):
@@ -184,10 +184,10 @@ class ShardedParticleFilterState:
         return out.to(send.device)
 
     # ---- global weight summary: phases 1 + 2
-    def _summary(self):
+    def _summary(self, want_q=True):
         b = self.backend
         mf_all = self._all_gather(b.weight_max()).contiguous()           # (G, 2): max, flags & (NaN | +Inf)
-        tot_all = self._all_gather(b.weight_scan(mf_all)).contiguous()    # (G, 5): S_r, Ql0..3
+        tot_all = self._all_gather(b.weight_scan(mf_all, want_q)).contiguous()    # (G, 5): S_r, Ql0..3 (limbs: ESS only)
         return mf_all, tot_all
 
     def _summary_scalars(self):
@@ -240,7 +240,7 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
     if method == "stratified" and sort_particles:
         raise ErrorException("sharded stratified resampling needs sort_particles=False (no global sort; SURVEY.md H8)")
     b, G, mid = state.backend, state.world, RESAMPLE_METHODS[method]
-    mf_all, tot_all = state._summary()                                # phases 1, 2
+    mf_all, tot_all = state._summary(want_q=False)                    # phases 1, 2 (no sum q^2: only the ESS needs it)
     if check is not False:                                            # safe_softmax validity (utils.jl:117-140): host sync
         mf = mf_all.cpu().numpy()
         flags = 0

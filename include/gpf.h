@@ -231,6 +231,7 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
  *   phase 1  gpf_shard_weight_max     out2 = {local max, local flags & (NaN|+Inf)} as two doubles
  *            host: all-gather -> mf_all[G][2]
  *   phase 2  gpf_shard_weight_scan    in: mf_all (combined in the kernel); local fixed-point CDF; out5 = {S_local, Ql0..3}
+ *                                     (the limbs of sum q^2 only when want_q != 0: the ESS needs them, a resample does not)
  *            host: all-gather -> tot_all[G][5]
  *   phase 2b gpf_shard_residual_scan  (residual only) in: tot_all; out2 = {Ctot_local, Rs_local}
  *            host: all-gather -> cr_all[G][2]
@@ -249,7 +250,7 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
  * me = this shard's index; bounds = HOST int64[G+1], first global slot of every shard (bounds[G] = n_global).  G <= 64.
  */
 gpf_status gpf_shard_weight_max(gpf_handle h, double* out2);
-gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, int64_t* out5);
+gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, int32_t want_q, int64_t* out5);
 gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t G, int64_t* out2);
 gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
                                 const int64_t* bounds, int64_t* counts);

@@ -50,7 +50,7 @@ class OracleShardBackend:
             flags |= int(f)
         return float(mf[:, 0].max()), flags
 
-    def weight_scan(self, mf_all):
+    def weight_scan(self, mf_all, want_q=True):
         m, f = self._combine(mf_all)
         uniform = (m == -np.inf) and not (f & 1)
         self.q = np.zeros(self.n, np.uint64) if f & 3 else o.fixq(self.lw, m, self.K, uniform)

@@ -18,7 +18,7 @@ for method in os.environ.get("PUSH_METHODS", "multinomial,stratified,residual").
         b = sharded.HipShardBackend(model, G * n, me * n, n, 1, False, 0)
         b.initialize(ys[0]); b.update(ys[1])
         mf = b.weight_max(); mf_all = mf.unsqueeze(0).repeat(G, 1).contiguous()
-        tot = b.weight_scan(mf_all); tot_all = tot.unsqueeze(0).repeat(G, 1).contiguous()
+        tot = b.weight_scan(mf_all, False); tot_all = tot.unsqueeze(0).repeat(G, 1).contiguous()
         cr_all = None
         if mid == 1:
             cr = b.residual_scan(tot_all); cr_all = cr.unsqueeze(0).repeat(G, 1).contiguous()
