@@ -185,26 +185,57 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
 // GATHER: the preceding pf_resample! left its ancestor vector pending; this kernel reads row anc[i]
 // instead of row i (new_traces .= view(traces, parents), resample.jl:60, fused into the propagate) and
 // the incoming log-weights are known to be 0 (update_weights!, resample.jl:195): lw = ll, no read.
-template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0>
+// PACKED (sharded filters): the preceding resample left the population as the received exchange buffer
+// [row | slot << 32 | global ancestor id] (gpf_shard_commit); entry k is propagated straight into its slot, the
+// scatter pass (k_commit_packed) and its round trip through HBM disappear, the log-ML update rides along.
+struct PackedCommit {
+    const double* packed;      // [n][W + 1], or nullptr
+    int32_t* anc;              // parents of the committed population
+    const double* mf_all; const int64_t* tot_all; int G, K; double logN; Scalars* sc;   // update_lml_est! from the gathered summaries
+};
+template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
                                                 double* __restrict__ rows_out, double* __restrict__ lw,
-                                                double* __restrict__ pmax, int32_t* __restrict__ pflags)
+                                                double* __restrict__ pmax, int32_t* __restrict__ pflags, PackedCommit pc)
 {
     using Mo = Model<M>;
     constexpr int D = Mo::D;
     double bm = -__builtin_huge_val(); int bf = 0;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if constexpr (PACKED) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            uint64_t S = 0;
+            double mx = -__builtin_huge_val();
+            int f = 0;
+            for (int g = 0; g < pc.G; ++g) {
+                S += (uint64_t)pc.tot_all[5 * g];
+                const double v = pc.mf_all[2 * g]; mx = v > mx ? v : mx; f |= (int)pc.mf_all[2 * g + 1];
+            }
+            if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+            pc.sc->lml_est = pc.sc->lml_est + (lse_from(mx, S, pc.K, f) - pc.logN);
+        }
+    }
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < n; e += (int64_t)gridDim.x * BLOCK) {
+        int64_t i = e;                                  // the slot this lane fills
+        double r[W];
+        if constexpr (PACKED) {
+            const double* src = pc.packed + e * (W + 1);
+#pragma unroll
+            for (int c = 0; c < W; ++c) r[c] = src[c];
+            const uint64_t meta = d2u(src[W]);
+            i = (int64_t)(meta >> 32);
+            pc.anc[i] = (int32_t)(meta & 0xffffffffull);
+        } else {
 #ifdef GPF_ABL_STEP_NOGATHER
         const int64_t srow = i;
 #else
         const int64_t srow = GATHER ? (int64_t)anc[i] : i;
 #endif
-        double r[W];
         const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
 #pragma unroll
         for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
+        }
         double xn[MAX_DIM];
         double ll;
         if constexpr (MODE == 1) ll = Mo::propose(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
@@ -228,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
         double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(o[2 * c], o[2 * c + 1]);
-        const double nl = GATHER ? ll : lw[i] + ll;
+        const double nl = (GATHER || PACKED) ? ll : lw[i] + ll;      // after a resample the incoming log-weights are 0
         lw[i] = nl;
         track_max(nl, bm, bf);
     }

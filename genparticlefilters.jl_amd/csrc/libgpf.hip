@@ -73,6 +73,8 @@ struct gpf_filter {
     bool raw_has_q = false;        // the raw summary's scan also accumulated sum q^2 (blockQ)
     bool raw_q_folded = false;     // sc->raw.Ql folded from blockQ
     bool pending_gather = false;   // a resample left (rows[cur], anc) un-gathered; log-weights are 0
+    bool pending_packed = false;   // sharded: the resampled population is still the received exchange buffer (gpf_shard_commit)
+    const double* pend_packed = nullptr; const double* pend_mf = nullptr; const int64_t* pend_tot = nullptr; int pend_G = 0;
     // trajectory store (gpf_history_enable): per recorded step the d latent columns in the step's final particle
     // order, and the composed ancestor map of the resamples that happened during that step (nullptr = identity)
     bool hist_on = false;
@@ -213,12 +215,16 @@ void launch_step_t(gpf_filter* h, int grid)
 {
     constexpr int Wc = row_width(Model<M>::D, KEEP);
     if constexpr ((PROP == 1 && !Model<M>::HAS_PROPOSAL) || (PROP == 2 && !Model<M>::HAS_STRATA)) { (void)h; (void)grid; return; }
-    else if (h->pending_gather)
+    else if (h->pending_packed) {
+        const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc};
+        GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags, pc);
+    } else if (h->pending_gather)
         GPF_LAUNCH((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags);
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags, PackedCommit{});
     else
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags);
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags, PackedCommit{});
 }
 template <int M, int PROP = 0>
 void launch_init_t(gpf_filter* h, int grid)
@@ -294,6 +300,20 @@ PrioView raw_view(const gpf_filter* h) { return PrioView{h->lw, nullptr, 0.0, 0}
 // a pending resample gather is executed now: rows[1-cur][j] = rows[cur][anc[j]], lw = 0
 gpf_status materialize(gpf_filter* h)
 {
+    if (h->pending_packed) {                                     // scatter the received exchange buffer by slot (+ log-ML update)
+        const int grid = grid_for(h, h->n, 8);
+        double* out = h->rows[1 - h->cur];
+        switch (h->W) {
+            case 2: GPF_LAUNCH((k_commit_packed<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, h->n, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc); break;
+            case 4: GPF_LAUNCH((k_commit_packed<4>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, h->n, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc); break;
+            case 8: GPF_LAUNCH((k_commit_packed<8>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, h->n, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc); break;
+        }
+        HIP_TRY(h, hipGetLastError());
+        h->cur ^= 1;
+        h->pending_packed = false;
+        h->max_valid = false;
+        return GPF_OK;
+    }
     if (!h->pending_gather) return GPF_OK;
     gpf_status s = timed(h, GPF_K_GATHER, [&] { launch_gather(h, raw_view(h), h->lw); });
     if (s) return s;
@@ -748,6 +768,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
     });
     if (s) return s;
     h->pending_gather = false;
+    h->pending_packed = false;
     h->max_valid = true; h->max_np = grid;
     GPF_LAUNCH(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
     HIP_TRY(h, hipMemsetAsync(&h->sc->lml_est, 0, sizeof(double), h->stream));                   // log_ml_est = 0.
@@ -791,6 +812,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
     h->pending_gather = false;      // a pending resample gather was fused into this step
+    h->pending_packed = false;      // ... or a pending sharded commit
     h->max_valid = true; h->max_np = grid;
     h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
     h->epoch += 1;
@@ -946,6 +968,7 @@ gpf_status gpf_get_parents(gpf_handle h, int64_t* out, int64_t n)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!out || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
+    if (h->pending_packed) { gpf_status s = materialize(h); if (s) return s; }   // a deferred sharded commit also carries the parents
     GPF_LAUNCH(k_parents, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, h->n, reinterpret_cast<int64_t*>(h->dtmp));
     return copy_out(h, h->dtmp, out, (size_t)n * sizeof(int64_t));
 }
@@ -1174,6 +1197,7 @@ static void set_count(gpf_filter* h, int64_t n_new)
 {
     h->n = n_new; h->cfg.n_particles = n_new; h->cfg.n_global = n_new; h->cfg.gid0 = 0;
     h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false; h->pending_gather = false;
+    h->pending_packed = false;
 }
 
 gpf_status gpf_n_particles(gpf_handle h, int64_t* out)
@@ -1596,15 +1620,11 @@ gpf_status gpf_shard_commit(gpf_handle h, const double* packed, int64_t m, const
     if (s) return s;
     if (!packed || !mf_all || !tot_all || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     if (m != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "a shard must receive exactly one entry per output slot");
-    const int grid = grid_for(h, h->n, 8);
-    double* out = h->rows[1 - h->cur];
-    switch (h->W) {
-        case 2: GPF_LAUNCH((k_commit_packed<2>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, m, out, h->anc, h->lw, mf_all, tot_all, (int)G, h->K, h->logN, h->sc); break;
-        case 4: GPF_LAUNCH((k_commit_packed<4>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, m, out, h->anc, h->lw, mf_all, tot_all, (int)G, h->K, h->logN, h->sc); break;
-        case 8: GPF_LAUNCH((k_commit_packed<8>), dim3(grid), dim3(BLOCK), 0, h->stream, packed, m, out, h->anc, h->lw, mf_all, tot_all, (int)G, h->K, h->logN, h->sc); break;
-    }
-    HIP_TRY(h, hipGetLastError());
-    h->cur ^= 1;
+    // Deferred like the single-GPU gather: the next gpf_update propagates the entries straight out of
+    // the exchange buffer into their slots (k_step<PACKED>); any other consumer scatters first (materialize()).
+    // packed / mf_all / tot_all must stay alive and unchanged until then (the caller keeps them until the next commit).
+    h->pending_packed = true;
+    h->pend_packed = packed; h->pend_mf = mf_all; h->pend_tot = tot_all; h->pend_G = G;
     h->epoch += 1;
     h->raw_valid = false;
     h->max_valid = false;
@@ -1618,6 +1638,7 @@ gpf_status gpf_shard_lml_est(gpf_handle h, double* out)
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
+    if ((s = materialize(h))) return s;                          // a deferred commit also carries the log-ML update
     if ((s = fetch_scalars(h))) return s;
     *out = h->h_sc->lml_est;
     return GPF_OK;
