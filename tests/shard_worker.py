@@ -28,7 +28,7 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
             ess_log.append(ess)
             if ess_frac is None or ess < ess_frac * n_global:
                 sharded.pf_resample(st, method, check=False)
-                if rejuv:
+                if rejuv and rejuv != "keep":
                     sharded.pf_rejuvenate(st, None, (), 1, method=rejuv)
             sharded.pf_update(st, (t + 1,), (None,), ys[t])
             lml_log.append(sharded.get_lml_est(st))

@@ -28,7 +28,7 @@ def single(g, o, model_name, method, n_global, T, ess_frac, rejuv):
         ess = f.effective_sample_size(); ess_log.append(ess)
         if ess_frac is None or ess < ess_frac * n_global:
             f.resample(method, sort_particles=False, check=False)
-            if rejuv:
+            if rejuv and rejuv != "keep":
                 f.rejuvenate(rejuv, 1)
         f.update(ys[t]); lml_log.append(f.log_ml_estimate())
     return f, np.array(ess_log), np.array(lml_log)
@@ -40,6 +40,8 @@ CASES = [
     ("lgssm2", "residual", 3000, 5, None, None),
     ("bearings4", "residual", 2000, 6, 0.5, "move"),        # BASELINE config 4 shape: ESS-triggered residual + MH
     ("sv1", "multinomial", 1500, 5, None, "reweight"),       # BASELINE config 5 shape
+    ("bearings4", "multinomial", 1200, 4, None, "keep"),     # rows carry x_{t-1} (keep_prev) but nothing rejuvenates: the
+                                                             # resampled population goes straight into the next propagate
 ]
 
 
