@@ -14,6 +14,7 @@ the handle's stream) and `cpu_baseline` (the C oracle = a port of the reference 
 this box's host cores on a bounded sample; rank 0, N=1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -105,12 +106,16 @@ def main():
     t = 1
     for _ in range(Wm):
         step(t); t += 1
+    # the host loop is Python: a generation-2 garbage collection (tens of ms, once per ~1000 sharded steps) would be
+    # charged to the filter.  Like timeit, keep the collector out of the timed region (objects made so far are frozen).
+    gc.collect(); gc.freeze(); gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(K):
         step(t); t += 1
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -192,12 +197,14 @@ def main():
             sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % K])
         for i in range(5):
             step_s(i)
+        gc.collect(); gc.disable()
         barrier()
         s0 = time.perf_counter()
         for i in range(ks):
             step_s(i)
         barrier()
         se = time.perf_counter() - s0
+        gc.enable()
         if dist is not None:
             tt = torch.tensor([se], dtype=torch.float64, device="cpu" if one_device else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

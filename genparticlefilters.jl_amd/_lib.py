@@ -75,9 +75,9 @@ SYMBOLS = [
     ("gpf_shard_weight_max", C.c_int, [_H, C.c_void_p]),
     ("gpf_shard_weight_scan", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("gpf_shard_residual_scan", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p]),
-    ("gpf_shard_push_count", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
-    ("gpf_shard_push", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_void_p, C.c_int64,
-                                 C.c_void_p]),
+    ("gpf_shard_push_count", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    ("gpf_shard_counts", C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64)]),
+    ("gpf_shard_push", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int64, C.c_void_p]),
     ("gpf_shard_commit", C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
     ("gpf_shard_lml_est", C.c_int, [_H, _pd]),
     # host-side scalar spec

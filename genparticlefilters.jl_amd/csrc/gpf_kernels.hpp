@@ -21,6 +21,7 @@ constexpr int NWAVES = BLOCK / WAVE;
 constexpr int SCAN_ITEMS = 8;
 constexpr int TILE = BLOCK * SCAN_ITEMS;          // 2048 weights per scan tile
 constexpr int MAX_PARTIALS = 2048;                // partial (max, flags) slots of the reduce kernels
+constexpr int MAX_SHARDS = 64;                    // shards (GPUs) of one filter
 constexpr int LDS_TILE_TABLE = 8192;              // tile-prefix entries kept in LDS by the search kernel (64 KiB)
 
 // ----------------------------------------------------------------------------- device scalars
@@ -504,8 +505,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
                                                 int np, WSum* __restrict__ ws_out, ScanOut out,
                                                 uint64_t* __restrict__ dcur, uint64_t* __restrict__ dnext,
                                                 uint64_t* __restrict__ total_out, uint64_t* __restrict__ blockQ,
-                                                int32_t* __restrict__ timeout)
+                                                int32_t* __restrict__ timeout, int64_t* __restrict__ zero128)
 {
+    // sharded resamples: the exchange counters of the push pass that follows are cleared here (no memset node)
+    if (zero128 && blockIdx.x == 0 && threadIdx.x < 2 * MAX_SHARDS) zero128[threadIdx.x] = 0;
     __shared__ double sm[NWAVES];
     __shared__ int sf[NWAVES];
     __shared__ uint64_t s_wave[NWAVES];
@@ -1073,7 +1076,6 @@ __global__ void k_export_residual(const Scalars* sc, int64_t* out2)
 // boundary, compacts each chunk's hits in LDS and appends them to the staging list of the slot's shard (one global
 // atomic per chunk; the order of chunks inside a list is arbitrary, every entry names its slot); it also counts what
 // this shard will receive from whom.  Pass 2 looks the staged hits up (same core as k_search) and packs the rows.
-constexpr int MAX_SHARDS = 64;
 constexpr int PUSH_CHUNK = 2048;                  // output slots per chunk
 struct PushArgs {
     uint64_t seed; uint32_t epoch;
@@ -1086,6 +1088,8 @@ struct PushArgs {
     int64_t nchunks;
     ulonglong2* stage;                            // [n_global]: hits for shard g's slots at stage + bounds[g]: {T_local | space << 62, slot inside g}
     int64_t* counts;                              // [2G]: entries sent to each shard | received from each shard
+    int64_t* host_counts;                         // pinned host mirror [2 * MAX_SHARDS + 1]: k_push publishes the counts + a ticket
+    int64_t ticket;
 };
 struct PushTables {                               // LDS copy of the per-shard tables
     int64_t w_incl[MAX_SHARDS], c_incl[MAX_SHARDS], bounds[MAX_SHARDS + 1], chunk0[MAX_SHARDS + 1];
@@ -1250,6 +1254,13 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
         int64_t o = 0;
         for (int g = 0; g < a.G; ++g) { s_off[g] = o; o += a.counts[g]; s_bnd[g] = a.bounds[g]; }
         s_off[a.G] = o;
+        // the host needs the counts for the all-to-all split sizes: publish them to pinned host memory NOW, so the host
+        // reads them while this kernel is still looking ancestors up (system-scope stores, ticket last)
+        if (blockIdx.x == 0 && a.host_counts) {
+            for (int g = 0; g < 2 * a.G; ++g)
+                __hip_atomic_store(a.host_counts + g, a.counts[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     __syncthreads();
     const int64_t total = s_off[a.G] < capacity ? s_off[a.G] : capacity;

@@ -88,6 +88,11 @@ struct gpf_filter {
     int64_t view_start = 0;
     uint64_t generation = 0;             // bumped when the per-particle buffers are reallocated (views check it)
     uint64_t parent_generation = 0;
+    int64_t* shard_counts = nullptr;     // [2 * MAX_SHARDS] exchange counters of the current resample (device) + pinned mirror
+    int64_t* h_shard_counts = nullptr;
+    hipEvent_t ev_sync = nullptr;
+    int64_t push_ticket = 0;             // bumped by every gpf_shard_push launch; k_push publishes it with the counts
+    bool counts_published = false;
     ulonglong2* push_stage = nullptr;    // push exchange: staged hits, one 16-byte entry per global output slot at most
     int64_t push_cap = 0;
     bool push_counted = false;
@@ -373,7 +378,7 @@ int scan_grid(const gpf_filter* h) { return (int)std::max<int64_t>(1, std::min<i
 // one scan launch on descriptor channel `ch` (0 weights, 1 residual counts, 2 residual weights)
 template <class In, int FIXQ>
 gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, bool want_cdf, uint64_t* total_out,
-                       const double* mf_all = nullptr)
+                       const double* mf_all = nullptr, int64_t* zero128 = nullptr)
 {
     const double* pmax = mf_all ? mf_all : h->pmax;
     uint64_t* dc = h->desc[ch][h->dcur[ch]];
@@ -382,7 +387,7 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
     const ScanOut so{want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch]};
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
         GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, pmax, h->pflags, np, slot,
-                           so, dc, dn, total_out, h->blockQ, &h->sc->timeout);
+                           so, dc, dn, total_out, h->blockQ, &h->sc->timeout, zero128);
     });
     if (s) return s;
     h->table[ch] = dc + h->ntiles;
@@ -734,9 +739,11 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage};
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
+    if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
+    if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return GPF_OK;
@@ -1506,15 +1513,20 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!mf_all || !out5 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (!h->shard_counts) {
+        HIP_TRY(h, hipMalloc(&h->shard_counts, (size_t)2 * MAX_SHARDS * sizeof(int64_t)));
+        HIP_TRY(h, hipHostMalloc(&h->h_shard_counts, (size_t)(2 * MAX_SHARDS + 1) * sizeof(int64_t)));
+        h->h_shard_counts[2 * MAX_SHARDS] = 0;
+    }
     h->max_valid = false;
     InFixQ in{raw_view(h), nullptr, h->K, 0.0, 0};
     const int gs = scan_grid(h);
     // the scan folds the gathered (max, flags) pairs itself and writes the shard total straight into out5[0]
     if (want_q) {
-        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all))) return s;
+        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, h->shard_counts))) return s;
         GPF_LAUNCH(k_export_q, dim3(1), dim3(BLOCK), 0, h->stream, h->blockQ, gs, out5);
     } else {
-        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all))) return s;
+        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, h->shard_counts))) return s;
     }
     HIP_TRY(h, hipGetLastError());
     h->raw_valid = false;            // sc->raw holds the GLOBAL max but no sum: not the unsharded summary
@@ -1537,10 +1549,10 @@ gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t
 
 // fill the argument block of the push kernels; bounds: HOST int64[G+1], first global slot of every shard
 static gpf_status push_args(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
-                            const int64_t* bounds, int64_t* counts, PushArgs& a)
+                            const int64_t* bounds, PushArgs& a)
 {
     if (method < 0 || method > 2) return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");
-    if (!tot_all || !bounds || !counts || G < 1 || G > MAX_SHARDS || me < 0 || me >= G || (method == GPF_RESAMPLE_RESIDUAL && !cr_all))
+    if (!tot_all || !bounds || G < 1 || G > MAX_SHARDS || me < 0 || me >= G || (method == GPF_RESAMPLE_RESIDUAL && !cr_all))
         return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     if (bounds[0] != 0 || bounds[G] != h->cfg.n_global || bounds[me] != h->cfg.gid0 || bounds[me + 1] != h->cfg.gid0 + h->n)
         return fail(h, GPF_ERR_INVALID_ARGUMENT, "shard bounds do not match this filter's global range");
@@ -1558,18 +1570,19 @@ static gpf_status push_args(gpf_handle h, int32_t method, const int64_t* tot_all
         HIP_TRY(h, hipMalloc(&h->push_stage, (size_t)h->cfg.n_global * sizeof(ulonglong2)));
         h->push_cap = h->cfg.n_global;
     }
-    a.tot_all = tot_all; a.cr_all = method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr; a.stage = h->push_stage; a.counts = counts;
+    a.tot_all = tot_all; a.cr_all = method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr; a.stage = h->push_stage; a.counts = h->shard_counts; a.host_counts = h->h_shard_counts; a.ticket = h->push_ticket;
     return GPF_OK;
 }
 
 gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
-                                const int64_t* bounds, int64_t* counts)
+                                const int64_t* bounds)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
+    if (!h->shard_counts) return fail(h, GPF_ERR_STATE, "gpf_shard_push_count needs gpf_shard_weight_scan of the same resample first");
     PushArgs a;
-    if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, counts, a))) return s;
-    HIP_TRY(h, hipMemsetAsync(counts, 0, (size_t)2 * G * sizeof(int64_t), h->stream));
+    if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, a))) return s;    // the counters were cleared by the weight scan
+    h->counts_published = false;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.nchunks, (int64_t)h->n_cu * 8));
     s = timed(h, GPF_K_SEARCH, [&] {
         switch (method) {
@@ -1584,16 +1597,40 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
     return GPF_OK;
 }
 
+gpf_status gpf_shard_counts(gpf_handle h, int32_t G, int64_t* host_counts)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!host_counts || G < 1 || G > MAX_SHARDS || !h->shard_counts || !h->push_counted) return fail(h, GPF_ERR_STATE, "no counted resample");
+    if (h->counts_published) {
+        // k_push publishes the counts to pinned host memory when it STARTS: poll the ticket (the kernel keeps running)
+        volatile int64_t* tk = h->h_shard_counts + 2 * MAX_SHARDS;
+        uint64_t spins = 0;
+        while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->push_ticket) {
+            if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess &&
+                __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->push_ticket)
+                return fail(h, GPF_ERR_HIP, "the push kernel finished without publishing its counts");
+        }
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->h_shard_counts, h->shard_counts, (size_t)2 * MAX_SHARDS * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    for (int g = 0; g < G; ++g) { host_counts[g] = h->h_shard_counts[g]; host_counts[G + g] = h->h_shard_counts[G + g]; }
+    return GPF_OK;
+}
+
 gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
-                          const int64_t* bounds, int64_t* counts, int64_t capacity, double* packed_out)
+                          const int64_t* bounds, int64_t capacity, double* packed_out)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!h->push_counted) return fail(h, GPF_ERR_STATE, "gpf_shard_push needs gpf_shard_push_count of the same resample first");
     if (capacity < 0 || (capacity > 0 && !packed_out)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    h->push_ticket += 1;
     PushArgs a;
-    if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, counts, a))) return s;
+    if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, a))) return s;
     if (capacity == 0) return GPF_OK;
+    h->counts_published = true;
     const bool two = method == GPF_RESAMPLE_RESIDUAL;
     if (two && !h->serve_residual) return fail(h, GPF_ERR_STATE, "residual push needs gpf_shard_residual_scan first");
     const int64_t nt = two ? 2 : 1;

@@ -98,18 +98,22 @@ class HipShardBackend:
     def push_count(self, method_id, tot_all, cr_all, me, bounds):
         G = tot_all.shape[0]
         self._bounds = (C.c_int64 * (G + 1))(*bounds)
-        counts = torch.empty(2 * G, dtype=torch.int64, device=self.device)
         self._ck(self.L.gpf_shard_push_count(self.h, method_id, tot_all.data_ptr(), cr_all.data_ptr() if cr_all is not None else None, G, me,
-                                             self._bounds, counts.data_ptr()))
-        return counts
+                                             self._bounds))
 
-    def push(self, method_id, tot_all, cr_all, me, bounds, counts, capacity):
+    def counts(self, G):
+        """entries sent to each shard | received from each shard; synchronises the stream"""
+        out = (C.c_int64 * (2 * G))()
+        self._ck(self.L.gpf_shard_counts(self.h, G, out))
+        return list(out)
+
+    def push(self, method_id, tot_all, cr_all, me, bounds, capacity):
         """packs at most `capacity` entries (the caller checks the counts afterwards and calls again if they did not fit)"""
         G = tot_all.shape[0]
         if getattr(self, "_sendbuf", None) is None or self._sendbuf.shape[0] < capacity:
             self._sendbuf = torch.empty((capacity, self.W + 1), dtype=torch.float64, device=self.device)
         self._ck(self.L.gpf_shard_push(self.h, method_id, tot_all.data_ptr(), cr_all.data_ptr() if cr_all is not None else None, G, me,
-                                       self._bounds, counts.data_ptr(), capacity, self._sendbuf.data_ptr() if capacity else None))
+                                       self._bounds, capacity, self._sendbuf.data_ptr() if capacity else None))
         return self._sendbuf
 
     def commit(self, packed, mf_all, tot_all):
@@ -253,17 +257,17 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
             import warnings
             warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")
     cr_all = state._all_gather(b.residual_scan(tot_all)).contiguous() if mid == 1 else None     # phase 2b: (G, 2)
-    counts = b.push_count(mid, tot_all, cr_all, state.rank, state.bounds)   # phase 3: who owns the target of which slot
+    b.push_count(mid, tot_all, cr_all, state.rank, state.bounds)     # phase 3: who owns the target of which slot
     # phase 4 is enqueued BEFORE the host learns the counts, into a buffer sized for a balanced exchange with slack
     # (any size is correct: the kernel stops at the capacity, and the call is repeated if the counts say it overflowed)
     cap = min(state.n_global, 2 * state.n_local + 65536)
     if os.environ.get("GPF_PUSH_CAPACITY"):                           # tests: force the overflow path
         cap = int(os.environ["GPF_PUSH_CAPACITY"])
-    buf = b.push(mid, tot_all, cr_all, state.rank, state.bounds, counts, cap)          # look up, gather, pack
-    c = counts.tolist()                                               # ONE host sync (the all-to-all split sizes), behind phase 4
+    buf = b.push(mid, tot_all, cr_all, state.rank, state.bounds, cap)                  # look up, gather, pack
+    c = b.counts(G)                                                   # ONE host sync (the all-to-all split sizes), behind phase 4
     sc, rc = c[:G], c[G:]
     if sum(sc) > cap:                                                 # skewed weights: this shard serves more than 2x its share
-        buf = b.push(mid, tot_all, cr_all, state.rank, state.bounds, counts, sum(sc))
+        buf = b.push(mid, tot_all, cr_all, state.rank, state.bounds, sum(sc))
     back = state._all_to_all(buf[:sum(sc)], sc, rc)                   # the exchange: [row | slot | ancestor id]
     b.commit(back, mf_all, tot_all)                                   # phase 5: scatter by slot, weights, log-ML
     return state

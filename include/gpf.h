@@ -238,9 +238,9 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
  *   phase 3  gpf_shard_push_count     RNG counters are keyed by the GLOBAL slot id, so every shard evaluates the target of
  *                                     EVERY output slot itself and finds which of them fall into its own part of the
  *                                     global CDF (owner = first shard whose inclusive total exceeds the target): no
- *                                     request message exists.  counts[2G] = entries this shard will send to each shard |
- *                                     entries it will receive from each shard.
- *            host: read counts (the one host sync of a resample: the all-to-all split sizes), allocate the send buffer
+ *                                     request message exists.  The pass also counts the entries this shard will send to
+ *                                     each shard and receive from each shard (counters cleared by gpf_shard_weight_scan).
+ *            host: gpf_shard_counts (the one host sync of a resample: the all-to-all split sizes)
  *   phase 4  gpf_shard_push           ancestor lookup + row gather for every slot this shard owns the target of;
  *                                     packed_out[sum(sent)][W+1] = row | (slot inside its shard) << 32 | global ancestor id,
  *                                     grouped by destination shard, slot order inside a group (deterministic)
@@ -253,9 +253,11 @@ gpf_status gpf_shard_weight_max(gpf_handle h, double* out2);
 gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, int32_t want_q, int64_t* out5);
 gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t G, int64_t* out2);
 gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
-                                const int64_t* bounds, int64_t* counts);
+                                const int64_t* bounds);
+/* the counts of the last gpf_shard_push_count as HOST int64[2G] (sent to each shard | received from each shard); synchronises */
+gpf_status gpf_shard_counts(gpf_handle h, int32_t G, int64_t* host_counts);
 gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
-                          const int64_t* bounds, int64_t* counts, int64_t capacity, double* packed_out);
+                          const int64_t* bounds, int64_t capacity, double* packed_out);
 gpf_status gpf_shard_commit(gpf_handle h, const double* packed, int64_t m, const double* mf_all, const int64_t* tot_all, int32_t G);
 /* running log_ml_est of this shard (identical on all shards) */
 gpf_status gpf_shard_lml_est(gpf_handle h, double* out);

@@ -103,9 +103,12 @@ class OracleShardBackend:
         send = np.bincount(self._dest[mine], minlength=G)
         recv = np.bincount(self._owner[self._dest == me], minlength=G)
         self._bounds = b
-        return torch.from_numpy(np.concatenate([send, recv]).astype(np.int64))
+        self._counts = [int(x) for x in np.concatenate([send, recv])]
 
-    def push(self, method_id, tot_all, cr_all, me, bounds, counts, capacity):
+    def counts(self, G):
+        return list(self._counts)
+
+    def push(self, method_id, tot_all, cr_all, me, bounds, capacity):
         hits = np.flatnonzero(self._owner == me)               # slot order = grouped by destination, slot order inside
         tl, inc = self._tl[hits].astype(np.uint64), self._inc[hits]
         a = np.zeros(hits.size, np.int64)

@@ -27,9 +27,10 @@ for method in os.environ.get("PUSH_METHODS", "multinomial,stratified,residual").
             st.kernel_timing(g._lib.K_SEARCH, True); st.kernel_timing(g._lib.K_GATHER, True)
             b.synchronize(); t0 = time.perf_counter()
             for _ in range(iters if phase == "timed" else 3):
-                counts = b.push_count(mid, tot_all, cr_all, me, bounds)
-                c = counts.tolist()
-                packed = b.push(mid, tot_all, cr_all, me, bounds, counts, sum(c[:G]))  # noqa
+                tot = b.weight_scan(mf_all, False)                     # clears the exchange counters
+                b.push_count(mid, tot_all, cr_all, me, bounds)
+                packed = b.push(mid, tot_all, cr_all, me, bounds, 2 * n + 65536)  # noqa
+                c = b.counts(G)
             b.synchronize(); wall = (time.perf_counter() - t0) / iters * 1e6
         cms, cc = st.kernel_time(g._lib.K_SEARCH); pms, pc = st.kernel_time(g._lib.K_GATHER)
         print(json.dumps(dict(method=method, G=G, n_local=n, sent=c[:G], recv=c[G:], count_us=round(cms / cc * 1e3, 2),
