@@ -186,3 +186,45 @@ def test_sample_unweighted_traces(g, o, n_samples):
     if n_samples >= 5000:                                  # high-weight particles are drawn more often
         cnt = np.bincount(idx - 1, minlength=20_000)
         assert np.corrcoef(cnt, g.get_norm_weights(st))[0, 1] > 0.5
+
+
+# ------------------------------------------------------------------ adversarial weight vectors
+def _weight_patterns(N, rng):
+    i = np.arange(N, dtype=np.float64)
+    pats = {
+        "one_dominant": np.where(i == N // 3, 0.0, -700.0),                    # every other weight underflows to q = 0
+        "two_clusters": np.where(i % 2 == 0, 0.0, -30.0),
+        "geometric": -0.01 * i,
+        "mostly_neginf": np.where(rng.random(N) < 0.01, rng.normal(size=N), -np.inf),
+        "underflow_edge": -745.0 + 45.0 * rng.random(N),                       # exp(lw) spans the subnormal edge
+        "block_ties": np.floor(i / 37.0) * -0.5,
+        "tiny_differences": 1e-15 * rng.integers(0, 4, N),
+        "huge_offset": 1e6 + rng.normal(size=N),                               # only differences matter
+        "first_and_last": np.where((i == 0) | (i == N - 1), 0.0, -50.0),
+    }
+    pats["mostly_neginf"][N - 1] = 0.0                                         # at least one finite weight
+    return pats
+
+
+@pytest.mark.parametrize("N", [4097, 70_001])
+def test_adversarial_weights_all_resamplers(g, o, N):
+    """weight vectors chosen to stress the fixed-point normalisation, the CDF levels and the search boundaries:
+    ancestors, weights, ESS and log-ML must still equal the oracle bit for bit, for every resampler and the optimal resize"""
+    rng = np.random.default_rng(1234 + N)
+    for name, lw in _weight_patterns(N, rng).items():
+        for method, kw in (("multinomial", {}), ("residual", {}), ("stratified", {"sort_particles": True}),
+                           ("stratified", {"sort_particles": False})):
+            model, ys, st, orc = make_pair(g, o, "lgssm2", N, 17, False, T=3)
+            st.log_weights = lw; orc.lw[:] = lw
+            assert g.get_ess(st) == orc.effective_sample_size() or (np.isnan(g.get_ess(st)) and np.isnan(orc.effective_sample_size())), name
+            assert g.get_lml_est(st) == orc.log_ml_estimate(), name
+            g.pf_resample(st, method, check=False, **kw); orc.resample(method, check=False, **kw)
+            assert np.array_equal(st.parents, orc.parents), f"{name} / {method} {kw}"
+            assert_state_equal(st, orc)
+            g.pf_update(st, (2,), (None,), ys[1]); orc.update(ys[1])
+            assert_state_equal(st, orc)
+        model, ys, st, orc = make_pair(g, o, "lgssm2", N, 17, False, T=3)
+        st.log_weights = lw; orc.lw[:] = lw
+        g.pf_resize(st, N // 3, "optimal", check=False); orc.resize(N // 3, "optimal", check=False)
+        assert np.array_equal(st.parents, orc.parents), f"{name} / optimal resize"
+        assert_state_equal(st, orc)
