@@ -41,3 +41,36 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
                  gid0=st.gid0, ess=np.array(ess_log), lml=np.array(lml_log))
     finally:
         dist.destroy_process_group()
+
+
+def skew_weights(n_global, pattern):
+    """global log-weight vectors that put all (or nothing) of the mass on single shards"""
+    i = np.arange(n_global, dtype=np.float64)
+    if pattern == "all_on_first_shard":
+        return np.where(i < n_global // 7, -0.001 * i, -np.inf)
+    if pattern == "single_particle":
+        return np.where(i == n_global - 2, 0.0, -800.0)
+    if pattern == "middle_band":
+        return np.where((i > 0.45 * n_global) & (i < 0.55 * n_global), 0.0, -40.0)
+    raise ValueError(pattern)
+
+
+def run_skew(rank, world, port, method, n_global, pattern, out_dir):
+    import torch.distributed as dist
+    import gpf_amd as g
+    from gpf_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = g.models.lgssm2()
+        ys = g.models.simulate(model, 3)
+        st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, device=0)
+        loc = st.local
+        loc.log_weights = skew_weights(n_global, pattern)[st.gid0:st.gid0 + st.n_local]
+        sharded.pf_resample(st, method, check=False)
+        sharded.pf_update(st, (2,), (None,), ys[1])
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents, gid0=st.gid0,
+                 lml=sharded.get_lml_est(st))
+    finally:
+        dist.destroy_process_group()

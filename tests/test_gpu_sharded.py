@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import shard_worker_gpu  # noqa: E402
-from test_sharded_gloo import CASES, free_port, single  # noqa: E402
+from test_sharded_gloo import CASES, free_port, single, single_skew  # noqa: E402
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
@@ -67,3 +67,18 @@ def test_rccl_collectives_one_rank(g, o, tmp_path, case):
     p = np.load(os.path.join(tmp_path, "rank0.npz"))
     assert np.array_equal(p["parents"], f.parents) and np.array_equal(p["rows"], f.rows) and np.array_equal(p["lw"], f.lw)
     assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
+
+
+@pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+def test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern):
+    """one shard owns every target (its push exceeds the balanced-size send buffer: the overflow path runs for real),
+    the others own none (zero-length sends)"""
+    world, n_global = 3, 300_000          # 2 n_local + 64 Ki < n_global: the shard that owns everything overflows its send buffer
+    mp.spawn(shard_worker_gpu.run_skew, args=(world, free_port(), method, n_global, pattern, str(tmp_path)), nprocs=world, join=True)
+    f = single_skew(g, o, method, n_global, pattern)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
+    assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
+    assert all(float(p["lml"]) == f.log_ml_estimate() for p in parts)

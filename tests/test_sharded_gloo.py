@@ -67,3 +67,26 @@ def test_sharded_push_overflow_path(g, o, tmp_path, monkeypatch):
     """a send buffer that is too small for the exchange: the counts reveal it and the push is repeated at the right size"""
     monkeypatch.setenv("GPF_PUSH_CAPACITY", "7")
     test_sharded_equals_single(g, o, tmp_path, CASES[2], 2)
+
+
+def single_skew(g, o, method, n_global, pattern):
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    f = o.OracleFilter(model.model_id, model.params, n_global, 77).initialize(ys[0])
+    f.lw[:] = shard_worker.skew_weights(n_global, pattern)
+    f.resample(method, sort_particles=False, check=False)
+    f.update(ys[1])
+    return f
+
+
+@pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+def test_sharded_skewed_weights(g, o, tmp_path, method, pattern):
+    """shards that own every target (their push overflows the balanced-size send buffer) next to shards that own none"""
+    world, n_global = 3, 5000
+    mp.spawn(shard_worker.run_skew, args=(world, free_port(), method, n_global, pattern, str(tmp_path)), nprocs=world, join=True)
+    f = single_skew(g, o, method, n_global, pattern)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
+    assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
+    assert all(float(p["lml"]) == f.log_ml_estimate() for p in parts)
