@@ -1,0 +1,46 @@
+"""The C ABI from a compiled host (examples/lgssm_filter.c): it builds against include/gpf.h with plain gcc and links
+libgpf_hip.so (CPU box: build + link only); on the GPU its output equals the Python host's bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "examples", "lgssm_filter.c")
+LIBDIR = os.path.join(ROOT, "genparticlefilters.jl_amd")
+
+
+def build(tmp_path):
+    exe = os.path.join(tmp_path, "lgssm_filter")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-std=c11", "-I" + os.path.join(ROOT, "include"), SRC, "-o", exe,
+                           os.path.join(LIBDIR, "libgpf_hip.so"), "-Wl,-rpath," + LIBDIR, "-Wl,--allow-shlib-undefined"])
+    return exe
+
+
+def test_c_example_builds_and_links(g, tmp_path):
+    """plain C11 against the header, no C++/HIP/torch types needed (no GPU: nothing is run)"""
+    exe = build(str(tmp_path))
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,method,ess_fraction", [("lgssm2", 0, 2.0), ("sv1", 2, 0.5), ("object_motion", 1, 0.5)])
+def test_c_example_equals_python_host(g, tmp_path, name, method, ess_fraction):
+    exe = build(str(tmp_path))
+    model = g.models.by_name(name); T, N, seed = 12, 20_000, 31
+    ys = g.models.simulate(model, T)
+    inp = os.path.join(tmp_path, "input.txt")
+    with open(inp, "w") as f:
+        f.write(f"{model.model_id} {model.params.size}\n" + " ".join(repr(float(v)) for v in model.params) + "\n")
+        f.write(f"{ys.shape[1]} {T}\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in ys) + "\n")
+    out = subprocess.check_output([exe, inp, str(N), str(seed), str(method), str(ess_fraction)], text=True).split()
+    lml, ess, mean0, var0, n_res = float(out[0]), float(out[1]), float(out[2]), float(out[3]), int(out[4])
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=seed)
+    mname = ["multinomial", "residual", "stratified"][method]
+    k = 0
+    for t in range(1, T):
+        if g.get_ess(st) < ess_fraction * N:
+            g.pf_resample(st, mname, check=False, **({"sort_particles": False} if method == 2 else {})); k += 1
+        g.pf_update(st, (t + 1,), (None,), ys[t])
+    assert (lml, ess, mean0, var0, n_res) == (g.get_lml_est(st), g.get_ess(st), g.mean(st, 0), g.var(st, 0), k)
