@@ -269,9 +269,11 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
 
 // K7/K8: pf_move_accept! with Gen.mh on the current step's latent (rejuvenate.jl:40-53) and
 // pf_move_reweight! with move_reweight(trace, selection) (rejuvenate.jl:74-90, :125-132)
-template <int M, int W, bool REWEIGHT>
+// GATHER: a pf_resample! left its ancestor vector pending; the move reads row anc[i] (new_traces .= view(traces, parents),
+// resample.jl:60, fused) and the incoming log-weights are 0 (resample.jl:195), exactly like k_step<GATHER>.
+template <int M, int W, bool REWEIGHT, bool GATHER = false>
 __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
-                                                int64_t n, int has_prev, int n_iters,
+                                                int64_t n, int has_prev, int n_iters, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
                                                 double* __restrict__ rows_out, double* __restrict__ lw,
                                                 unsigned long long* __restrict__ n_accept,
@@ -283,7 +285,8 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
     double bm = -__builtin_huge_val(); int bf = 0;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         double r[W];
-        const double2* src = reinterpret_cast<const double2*>(rows_in + i * W);
+        const int64_t srow = GATHER ? (int64_t)anc[i] : i;
+        const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
         double x[MAX_DIM], xs[MAX_DIM];
@@ -321,7 +324,8 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
         double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(r[2 * c], r[2 * c + 1]);
-        if (REWEIGHT) { const double nl = lw[i] + wsum; lw[i] = nl; track_max(nl, bm, bf); }
+        if (REWEIGHT) { const double nl = (GATHER ? 0.0 : lw[i]) + wsum; lw[i] = nl; track_max(nl, bm, bf); }
+        else if (GATHER) lw[i] = 0.0;
     }
     // one atomic per wave
     unsigned long long t = wave_sum_u64(acc);

@@ -263,9 +263,14 @@ template <int M, bool RW>
 void launch_move_t(gpf_filter* h, int grid, int n_iters)
 {
     constexpr int Wc = row_width(Model<M>::D, true);
-    GPF_LAUNCH((k_move<M, Wc, RW>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                       h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                       reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
+    if (h->pending_gather)           // the resample gather rides on the move (rows read through anc, incoming weights 0)
+        GPF_LAUNCH((k_move<M, Wc, RW, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                           h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
+                           reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
+    else
+        GPF_LAUNCH((k_move<M, Wc, RW, false>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                           h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
+                           reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
 }
 
 #define DISPATCH_MODEL(h, CALL)                                                                  \
@@ -886,7 +891,8 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
         return fail(h, GPF_ERR_UNKNOWN_METHOD, "Method not recognized.");                        // rejuvenate.jl:25
     if (!h->cfg.keep_prev) return fail(h, GPF_ERR_STATE, "gpf_rejuvenate needs keep_prev = 1 (x_{t-1} must travel with the particle)");
     if (n_iters < 0) return fail(h, GPF_ERR_INVALID_ARGUMENT, "n_iters < 0");
-    if ((s = materialize(h))) return s;
+    if (h->pending_packed && (s = materialize(h))) return s;     // sharded deferred commit: scatter first
+    const bool fused_gather = h->pending_gather;                 // a pending resample gather rides on the move kernel
     HIP_TRY(h, hipMemsetAsync(&h->sc->n_accept, 0, sizeof(uint64_t), h->stream));
     const int grid = step_grid(h);
     s = timed(h, GPF_K_MOVE, [&] {
@@ -897,6 +903,7 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;
     h->epoch += 1;
+    if (fused_gather) { h->pending_gather = false; h->max_valid = false; }   // log-weights are all 0 now (resample.jl:195)
     if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; h->max_np = grid; }
     if ((s = view_exit(h))) return s;
     if (n_accepted) {

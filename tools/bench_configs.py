@@ -1,5 +1,6 @@
 """Single-GPU timing of the BASELINE.json configs other than the headline one (per-GPU sizes), with per-kernel
 HIP-event times.  Not the driver's bench; numbers go to DESIGN.md / BASELINE table."""
+import gc
 import json
 import os
 import sys
@@ -38,11 +39,13 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
     for _ in range(warm):
         step(t); t += 1
     st.synchronize(); n_res = 0
+    gc.collect(); gc.disable()          # as bench.py: keep generation-2 collections (tens of ms) out of the timed loop
     t0 = time.perf_counter()
     for _ in range(steps):
         step(t); t += 1
     st.synchronize()
     el = time.perf_counter() - t0
+    gc.enable()
     kids = list(g._lib.KERNEL_NAMES)
     for k in kids:
         st.kernel_timing(k, True)
