@@ -177,6 +177,16 @@ template <> struct Model<MODEL_OBJECT_MOTION> {
     }
 };
 
+// length of the per-step data vector (observations, plus covariates such as sin(t) for object_motion)
+inline int model_obs_dim(int m)
+{
+    switch (m) {
+        case MODEL_LGSSM2: return 2; case MODEL_BEARINGS4: return 1;
+        case MODEL_SV1: return 1; case MODEL_OBJECT_MOTION: return 2;
+    }
+    return 0;
+}
+
 inline int model_dim(int m)
 {
     switch (m) {

@@ -500,6 +500,10 @@ gpf_status check_ready(gpf_handle h)
 gpf_status set_obs(gpf_filter* h, const double* obs, int n_obs)
 {
     if (n_obs < 0 || n_obs > MAX_OBS || (n_obs > 0 && !obs)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad observation vector");
+    // a native model's step is defined by its full data vector: an empty choicemap() (no constraint, weight 0) has no
+    // device meaning and must not silently become "observed zeros"
+    if (n_obs != model_obs_dim(h->cfg.model))
+        return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model takes " + std::to_string(model_obs_dim(h->cfg.model)) + " observation values per step");
     for (int i = 0; i < MAX_OBS; ++i) h->args.obs[i] = i < n_obs ? obs[i] : 0.0;
     return GPF_OK;
 }

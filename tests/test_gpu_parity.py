@@ -228,3 +228,19 @@ def test_adversarial_weights_all_resamplers(g, o, N):
         g.pf_resize(st, N // 3, "optimal", check=False); orc.resize(N // 3, "optimal", check=False)
         assert np.array_equal(st.parents, orc.parents), f"{name} / optimal resize"
         assert_state_equal(st, orc)
+
+
+def test_invalid_arguments_fail_loudly(g):
+    """wrong observation length (an empty choicemap() has no device meaning), zero particles, update before initialize"""
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 2)
+    with pytest.raises(Exception):
+        g.pf_initialize(model, (1,), np.zeros(0), 100)
+    with pytest.raises(Exception):
+        g.pf_initialize(model, (1,), np.zeros(3), 100)
+    with pytest.raises(Exception):
+        g.pf_initialize(model, (1,), ys[0], 0)
+    st = g.pf_initialize(model, (1,), ys[0], 100)
+    with pytest.raises(Exception):
+        g.pf_update(st, (2,), (None,), np.zeros(1))
+    g.pf_update(st, (2,), (None,), ys[1])                      # the handle is still usable after a rejected call
+    assert np.isfinite(g.get_lml_est(st))
