@@ -440,28 +440,6 @@ struct InFixQ {                // q_i = trunc(exp(p_i - m) 2^K + 1/2); uniform f
         }
     }
 };
-struct InResidual {            // from the weight CDF: counts (N q_i) div S, or residuals ((N q_i) mod S) >> sh
-    const uint64_t* cdf;       // padded to whole tiles (flat beyond n, so q = 0 there)
-    const WSum* ws;            // summary of the weights being resampled (S = GLOBAL sum)
-    int64_t N;                 // global particle count
-    int want_r;
-    __device__ __forceinline__ void load2(int64_t idx, int64_t n, uint64_t& q0, uint64_t& q1) const
-    {
-        const uint64_t S = ws->S;
-        const int sh = residual_shift(S, N);
-        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(cdf + idx);
-        const uint64_t prev = idx > 0 ? cdf[idx - 1] : 0;
-        q0 = 0; q1 = 0;
-        if (S != 0) {
-            const uint64_t n0 = (uint64_t)N * (c.x - prev), n1 = (uint64_t)N * (c.y - c.x);
-            q0 = want_r ? ((n0 % S) >> sh) : (n0 / S);
-            q1 = want_r ? ((n1 % S) >> sh) : (n1 / S);
-        }
-        if (idx >= n) q0 = 0;
-        if (idx + 1 >= n) q1 = 0;
-    }
-};
-
 // a <= ... products of a 31-bit count and a 62-bit weight need 128 bits:  B <= a * k
 __device__ __forceinline__ bool le_mul(uint64_t B, uint64_t a, uint64_t k)
 {
@@ -604,6 +582,88 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
             for (int w = 0; w < NWAVES; ++w) t += s_q[w][threadIdx.x];
             blockQ[(int64_t)blockIdx.x * 4 + threadIdx.x] = t;
         }
+    }
+}
+
+// Residual resampling needs TWO prefix sums over the same elements: the copy counts c_i = (N q_i) div S and the
+// residual weights r_i = ((N q_i) mod S) >> sh (resample.jl:99,109).  One pass computes both: one read of the weight CDF,
+// ONE 64-bit division per element (quotient and remainder), two descriptor channels polled in the same round trip.
+// Same tile / descriptor protocol as k_scan (channel A = counts, channel B = residual weights).
+struct Scan2Chan { ScanOut out; uint64_t* dcur; uint64_t* dnext; uint64_t* total_out; };
+__global__ __launch_bounds__(BLOCK) void k_scan_residual2(const uint64_t* __restrict__ cdf, const WSum* ws, int64_t Nslots,
+                                                          int64_t n, int64_t ntiles, Scan2Chan A, Scan2Chan B,
+                                                          int32_t* __restrict__ timeout)
+{
+    __shared__ uint64_t s_wave[2][NWAVES];
+    __shared__ uint64_t s_red[2][NWAVES];
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * BLOCK) { A.dnext[i] = 0; B.dnext[i] = 0; }
+    const uint64_t S = ws->S;
+    const int sh = residual_shift(S, Nslots);
+    const int lane = lane_id(), wv = wave_id();
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t wbase = tile * TILE + (int64_t)wv * (SCAN_ROWS * 2 * WAVE) + 2 * lane;
+        uint64_t pa[2 * SCAN_ROWS], pb[2 * SCAN_ROWS];
+        uint64_t ca = 0, cb = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ROWS; ++k) {
+            const int64_t idx = wbase + k * 2 * WAVE;
+            const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(cdf + idx);      // padded to whole tiles, flat beyond n
+            const uint64_t prev = idx > 0 ? cdf[idx - 1] : 0;
+            uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (S != 0) {
+                const uint64_t n0 = (uint64_t)Nslots * (c.x - prev), n1 = (uint64_t)Nslots * (c.y - c.x);
+                a0 = n0 / S; b0 = (n0 - a0 * S) >> sh;
+                a1 = n1 / S; b1 = (n1 - a1 * S) >> sh;
+            }
+            if (idx >= n) { a0 = 0; b0 = 0; }
+            if (idx + 1 >= n) { a1 = 0; b1 = 0; }
+            const uint64_t paira = a0 + a1, pairb = b0 + b1;
+            const uint64_t inca = wave_scan_u64(paira), incb = wave_scan_u64(pairb);
+            pa[2 * k] = ca + (inca - paira) + a0; pa[2 * k + 1] = pa[2 * k] + a1;
+            pb[2 * k] = cb + (incb - pairb) + b0; pb[2 * k + 1] = pb[2 * k] + b1;
+            ca += shfl_u64(inca, WAVE - 1); cb += shfl_u64(incb, WAVE - 1);
+        }
+        if (lane == 0) { s_wave[0][wv] = ca; s_wave[1][wv] = cb; }
+        __syncthreads();
+        uint64_t wexa = 0, agga = 0, wexb = 0, aggb = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) {
+            if (w < wv) { wexa += s_wave[0][w]; wexb += s_wave[1][w]; }
+            agga += s_wave[0][w]; aggb += s_wave[1][w];
+        }
+        if (threadIdx.x == 0) { desc_store(A.dcur + tile, DESC_VALID | agga); desc_store(B.dcur + tile, DESC_VALID | aggb); }
+        const int64_t first = (tile / gridDim.x) * gridDim.x;
+        uint64_t acca = 0, accb = 0;
+        for (int64_t idx = first + threadIdx.x; idx < tile; idx += BLOCK) {
+            acca += desc_wait(A.dcur + idx, timeout);
+            accb += desc_wait(B.dcur + idx, timeout);
+        }
+        if (first > 0 && threadIdx.x == BLOCK - 1) {
+            acca += desc_wait(A.dcur + ntiles + first - 1, timeout);
+            accb += desc_wait(B.dcur + ntiles + first - 1, timeout);
+        }
+        acca = wave_sum_u64(acca); accb = wave_sum_u64(accb);
+        if (lane == 0) { s_red[0][wv] = acca; s_red[1][wv] = accb; }
+        __syncthreads();
+        uint64_t exa = 0, exb = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) { exa += s_red[0][w]; exb += s_red[1][w]; }
+        if (threadIdx.x == 0) {
+            desc_store(A.dcur + ntiles + tile, DESC_VALID | (exa + agga));
+            desc_store(B.dcur + ntiles + tile, DESC_VALID | (exb + aggb));
+        }
+        const uint64_t offa = exa + wexa, offb = exb + wexb;
+#pragma unroll
+        for (int k = 0; k < SCAN_ROWS; ++k) {
+            const int64_t idx = wbase + k * 2 * WAVE;
+            const uint64_t va = offa + pa[2 * k + 1], vb = offb + pb[2 * k + 1];
+            *reinterpret_cast<ulonglong2*>(A.out.cdf + idx) = make_ulonglong2(offa + pa[2 * k], va);
+            *reinterpret_cast<ulonglong2*>(B.out.cdf + idx) = make_ulonglong2(offb + pb[2 * k], vb);
+            if ((lane & 7) == 7) { A.out.t16[(idx + 1) >> 4] = va; B.out.t16[(idx + 1) >> 4] = vb; }
+            if (lane == WAVE - 1 && (k & 1)) { A.out.t256[(idx + 1) >> 8] = va; B.out.t256[(idx + 1) >> 8] = vb; }
+        }
+        if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) { *A.total_out = offa + pa[2 * SCAN_ROWS - 1]; *B.total_out = offb + pb[2 * SCAN_ROWS - 1]; }
+        __syncthreads();                                // s_wave / s_red reuse
     }
 }
 

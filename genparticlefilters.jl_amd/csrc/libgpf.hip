@@ -543,10 +543,23 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
 {
     gpf_status s = ensure_residual_buffers(h);
     if (s) return s;
-    InResidual inc{h->cdf[0], ws, n_slots_global, 0};
-    InResidual inr{h->cdf[0], ws, n_slots_global, 1};
-    if ((s = scan_launch<InResidual, 0>(h, 1, inc, 0, nullptr, true, &h->sc->Ctot))) return s;
-    if ((s = scan_launch<InResidual, 0>(h, 2, inr, 0, nullptr, true, &h->sc->Rs))) return s;
+    // both prefix sums in one pass (one read of the weight CDF, one division per element)
+    Scan2Chan ch[2];
+    for (int c = 0; c < 2; ++c) {
+        const int id = 1 + c;
+        uint64_t* dc = h->desc[id][h->dcur[id]];
+        ch[c].out = ScanOut{h->cdf[id], h->t16[id], h->t256[id]};
+        ch[c].dcur = dc; ch[c].dnext = h->desc[id][1 - h->dcur[id]];
+        ch[c].total_out = c == 0 ? &h->sc->Ctot : &h->sc->Rs;
+        h->table[id] = dc + h->ntiles;
+        h->dcur[id] ^= 1;
+    }
+    const int gs = scan_grid(h);
+    s = timed(h, GPF_K_SCAN, [&] {
+        GPF_LAUNCH(k_scan_residual2, dim3(gs), dim3(BLOCK), 0, h->stream, h->cdf[0], ws, n_slots_global, h->n, h->ntiles, ch[0], ch[1], &h->sc->timeout);
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
 
