@@ -122,6 +122,9 @@ def main():
         elapsed = float(tt.item())
     value = n_global * K / elapsed
     lml = sharded.get_lml_est(state) if sharded_mode else g.get_lml_est(state)
+    # BASELINE.json's metric also names the log-ML error: the model is linear-Gaussian, so the exact log p(y_1:T) of the
+    # observations consumed so far is a Kalman recursion away (host, NumPy)
+    lml_exact = g.models.kalman_loglik(model, ys[:t]) if rank == 0 else None
 
     # ---- roofline of the dominant kernel: HIP events around every launch, on the handle's stream ----
     roofline = None
@@ -250,7 +253,7 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "particles_per_gpu": n_local, "particles_total": n_global, "T": K,
                        "state_dim": model.dim, "parallelism": f"particle-shard x{world}"},
-            "log_ml_estimate": lml,
+            "log_ml_estimate": lml, "log_ml_exact_kalman": lml_exact, "log_ml_abs_error": abs(lml - lml_exact),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
             "stratified_variant": strat,
         }
