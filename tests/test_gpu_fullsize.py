@@ -143,3 +143,31 @@ def test_maximum_size_64e6_global_top_level(g):
     g.pf_resample(st, "residual", check=False)
     assert np.array_equal(st.parents, np.arange(1, N + 1))
     st.close()
+
+
+def test_config5_lml_estimator_spread_gpu_equals_cpu(g, o):
+    """BASELINE config 5 asks for the log-ML estimator variance against the CPU: at N = 2e4 the GPU and the CPU oracle give the
+    same estimates bit for bit over six seeds (so the same variance); at N = 2e6 the spread shrinks by about sqrt(100)"""
+    model = g.models.sv1(); T = 120; ys = g.models.simulate(model, T)
+
+    def run_gpu(N, seed):
+        st = g.pf_initialize(model, (1,), ys[0], N, seed=seed, keep_prev=True)
+        for t in range(1, T):
+            g.pf_resample(st, "multinomial", check=False); g.pf_rejuvenate(st, g.move_reweight, (), 1, method="reweight")
+            g.pf_update(st, (t + 1,), (None,), ys[t])
+        v = g.get_lml_est(st); st.close(); return v
+
+    def run_cpu(N, seed):
+        f = o.OracleFilter(model.model_id, model.params, N, seed, keep_prev=True).initialize(ys[0])
+        for t in range(1, T):
+            f.resample("multinomial", check=False); f.rejuvenate("reweight", 1); f.update(ys[t])
+        return f.log_ml_estimate()
+
+    small_gpu = np.array([run_gpu(20_000, s) for s in range(1, 7)])
+    small_cpu = np.array([run_cpu(20_000, s) for s in range(1, 7)])
+    assert np.array_equal(small_gpu, small_cpu)
+    big = np.array([run_gpu(2_000_000, s) for s in range(1, 13)])
+    ratio = small_gpu.std(ddof=1) / big.std(ddof=1)
+    print(f"log-ML std: N=2e4 {small_gpu.std(ddof=1):.4f} (GPU == CPU), N=2e6 {big.std(ddof=1):.4f}, ratio {ratio:.1f}")
+    assert 3.0 < ratio < 35.0                           # sqrt(100) = 10 within the noise of a dozen seeds
+    assert abs(big.mean() - small_gpu.mean()) < 4 * small_gpu.std(ddof=1)
