@@ -243,10 +243,16 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
  *            host: gpf_shard_counts (the one host sync of a resample: the all-to-all split sizes)
  *   phase 4  gpf_shard_push           ancestor lookup + row gather for every slot this shard owns the target of;
  *                                     packed_out[sum(sent)][W+1] = row | (slot inside its shard) << 32 | global ancestor id,
- *                                     grouped by destination shard, slot order inside a group (deterministic)
+ *                                     grouped by destination shard (any order inside a group: every entry names its slot).
+ *                                     Packs at most `capacity` entries; may be enqueued before gpf_shard_counts (it publishes
+ *                                     the counts to pinned host memory when it starts) and called again with a larger buffer
+ *                                     if the counts say it overflowed.
  *            host: ONE all-to-all of packed rows (8W+8 bytes per slot that changes shard)
- *   phase 5  gpf_shard_commit         scatter the m = n_particles received entries by their slot into the new population,
- *                                     parents, log-weights = 0, log-ML estimate += logsumexp - log N (from mf_all, tot_all)
+ *   phase 5  gpf_shard_commit         the m = n_particles received entries become the new population: parents, log-weights = 0,
+ *                                     log-ML estimate += logsumexp - log N (from mf_all, tot_all).  DEFERRED: the next gpf_update
+ *                                     propagates the entries straight out of `packed` into their slots, any other call scatters
+ *                                     them first; packed / mf_all / tot_all must stay alive and unchanged until the next
+ *                                     gpf_shard_commit on this handle.
  * me = this shard's index; bounds = HOST int64[G+1], first global slot of every shard (bounds[G] = n_global).  G <= 64.
  */
 gpf_status gpf_shard_weight_max(gpf_handle h, double* out2);
