@@ -244,3 +244,38 @@ def test_invalid_arguments_fail_loudly(g):
         g.pf_update(st, (2,), (None,), np.zeros(1))
     g.pf_update(st, (2,), (None,), ys[1])                      # the handle is still usable after a rejected call
     assert np.isfinite(g.get_lml_est(st))
+
+
+def test_no_device_memory_leak_over_handle_lifetimes(g):
+    """create / use every code path that allocates lazily / destroy, many times: free device memory must come back"""
+    import torch
+    from gpf_amd import sharded
+    model = g.models.bearings4(); ys = g.models.simulate(model, 4)
+
+    def cycle():
+        st = g.pf_initialize(model, (1,), ys[0], 200_000, seed=3, keep_prev=True, history=8)
+        g.pf_resample(st, "stratified", check=False, sort_particles=True)          # sort buffers
+        g.pf_rejuvenate(st, g.mh, (), 1)
+        g.pf_update(st, (2,), (None,), ys[1])
+        g.pf_resample(st, "residual", check=False)                                  # residual channels
+        g.pf_update(st[1000:5000], (3,), (None,), ys[2])                            # a view
+        g.mean(st, (1, 0)); g.get_ess(st)
+        st.close()
+        st = g.pf_initialize(model, (1,), ys[0], 200_000, seed=3)
+        g.pf_resize(st, 50_000, "optimal", check=False); g.pf_replicate(st, 3); g.sample_unweighted_traces(st, 1000)
+        st.close()
+        sh = sharded.pf_initialize(model, (1,), ys[0], 200_000, seed=3)             # staging list, counters, pinned mirror, event
+        sharded.pf_resample(sh, "multinomial", check=False); sharded.pf_update(sh, (2,), (None,), ys[1])
+        sharded.get_lml_est(sh)
+        sh.local.close()
+
+    import gc
+    for _ in range(3):
+        cycle()
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()      # torch's own cache is not the library's
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 lifetimes"
