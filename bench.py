@@ -215,6 +215,32 @@ def main():
         strat = {"workload": "same filter, stratified resample every step, sort_particles=false (BASELINE.json configs[2])",
                  "value": round(n_global * ks / se, 1), "unit": "particle-steps/sec", "steps": ks, "ms_per_step": round(se / ks * 1e3, 5)}
 
+    # ---- ... and the communication-free "island" mode (every shard resamples locally with the reference's sub-state
+    #      semantics): a different estimator, reported for comparison only
+    island = None
+    if sharded_mode:
+        ki = min(K, 200)
+
+        def step_i(tq):
+            sharded.pf_resample(state, "multinomial", check=False, local=True)
+            sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % K])
+        for i in range(5):
+            step_i(i)
+        gc.collect(); gc.disable()
+        barrier()
+        i0 = time.perf_counter()
+        for i in range(ki):
+            step_i(i)
+        barrier()
+        ie = time.perf_counter() - i0
+        gc.enable()
+        if dist is not None:
+            tt = torch.tensor([ie], dtype=torch.float64, device="cpu" if one_device else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ie = float(tt.item())
+        island = {"workload": "same filter, every shard resamples its own particles (multinomial, sub-state semantics), no exchange",
+                  "value": round(n_global * ki / ie, 1), "unit": "particle-steps/sec", "steps": ki, "ms_per_step": round(ie / ki * 1e3, 5)}
+
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 / N=1 only ----
     cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -255,7 +281,7 @@ def main():
                        "state_dim": model.dim, "parallelism": f"particle-shard x{world}"},
             "log_ml_estimate": lml, "log_ml_exact_kalman": lml_exact, "log_ml_abs_error": abs(lml - lml_exact),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
-            "stratified_variant": strat,
+            "stratified_variant": strat, "local_resample_variant": island,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -1167,7 +1167,6 @@ gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_
     if (!parent || !out) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (parent->parent) return fail(parent, GPF_ERR_STATE, "views of views are not supported");
-    if (parent->cfg.n_global != parent->n) return fail(parent, GPF_ERR_STATE, "views of sharded filters are not supported (shards play that role)");
     if (start < 0 || count < 1 || start + count > parent->n) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view range out of bounds");
     gpf_filter* v = new gpf_filter();
     v->cfg = parent->cfg;

@@ -121,6 +121,14 @@ class HipShardBackend:
         self._ck(self.L.gpf_shard_commit(self.h, packed.data_ptr(), packed.shape[0], mf_all.data_ptr(), tot_all.data_ptr(), tot_all.shape[0]))
         self._keep = (packed, mf_all, tot_all)             # alive until the stream has consumed them
 
+    def local_resample(self, method, priority_fn, check, sort_particles):
+        """resample THIS shard's particles among themselves with the reference's sub-state semantics: a view of the whole shard"""
+        from . import api
+        if getattr(self, "_view", None) is None:
+            self._view = self.state[0:self.n]
+        kw = {"sort_particles": sort_particles} if method == "stratified" else {}      # only the stratified resampler reads it
+        api.pf_resample(self._view, method, priority_fn=priority_fn, check=check, **kw)
+
     def lml_est(self) -> float:
         out = C.c_double()
         self._ck(self.L.gpf_shard_lml_est(self.h, C.byref(out)))
@@ -235,10 +243,20 @@ def pf_rejuvenate(state: ShardedParticleFilterState, kern=None, kern_args=(), n_
 
 
 def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", *, priority_fn=None, check="warn",
-                sort_particles: bool = False):
-    """src/resample.jl:19-175 with a global CDF.  Returns `state`."""
+                sort_particles: bool = False, local: bool = False):
+    """src/resample.jl:19-175 with a global CDF.  Returns `state`.
+
+    local=True: the communication-free alternative of SURVEY.md §8e ("island" filter): every shard resamples its own
+    particles with the reference's SUB-STATE semantics (src/resample.jl:185-187,205-218) -- ancestors inside the shard,
+    log-weights reset to the shard's average so its total mass is kept, the running log-ML estimate untouched; the global
+    estimate stays log_ml_est + logsumexp(all weights) - log N (src/utils.jl:174-178).  A different (higher-variance when
+    shard masses diverge) estimator than the global resample; equal to pf_resample!(state[shard range], ...) on an unsharded
+    state, which is how it is tested.  priority_fn / sort_particles are supported here."""
     if method not in RESAMPLE_METHODS:
         raise ErrorException(f"Resampling method {method} not recognized.")
+    if local:
+        state.backend.local_resample(method, priority_fn, check, sort_particles)
+        return state
     if priority_fn is not None:
         raise ErrorException("sharded resampling supports priority_fn = nothing only")
     if method == "stratified" and sort_particles:

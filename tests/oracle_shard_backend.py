@@ -142,6 +142,17 @@ class OracleShardBackend:
         self.epoch += 1
         self.serve_residual = False
 
+    def local_resample(self, method, priority_fn, check, sort_particles):
+        """sub-state resample of this shard (resample.jl:185-187,205-218): the oracle's OracleSubState over local arrays, with
+        the RNG offset of the shard's first global particle"""
+        v = o.OracleSubState.__new__(o.OracleSubState)
+        v.source, v.start, v.n, v.sl, v.last_obs, v.n_accepted = self, self.gid0, self.n, slice(0, self.n), self.obs, 0
+        v.resample(method, priority_alpha=None if priority_fn is None else priority_fn.alpha, sort_particles=sort_particles, check=check)
+
+    @property
+    def lml_est_value(self):
+        return self.lml
+
     def lml_est(self):
         return self.lml
 

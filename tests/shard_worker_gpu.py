@@ -74,3 +74,25 @@ def run_skew(rank, world, port, method, n_global, pattern, out_dir):
                  lml=sharded.get_lml_est(st))
     finally:
         dist.destroy_process_group()
+
+
+def run_local(rank, world, port, method, n_global, out_dir):
+    import torch.distributed as dist
+    import gpf_amd as g
+    from gpf_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = g.models.lgssm2(); ys = g.models.simulate(model, 5)
+        st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, device=0)
+        lml = []
+        for t in range(1, 5):
+            sharded.pf_resample(st, method, check=False, local=True, sort_particles=(t % 2 == 0))
+            sharded.pf_update(st, (t + 1,), (None,), ys[t])
+            lml.append(sharded.get_lml_est(st))
+        loc = st.local
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents, gid0=st.gid0,
+                 n=st.n_local, lml=np.array(lml), ess=sharded.get_ess(st))
+    finally:
+        dist.destroy_process_group()

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import shard_worker_gpu  # noqa: E402
-from test_sharded_gloo import CASES, free_port, single, single_skew  # noqa: E402
+from test_sharded_gloo import CASES, free_port, single, single_local, single_skew  # noqa: E402
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
@@ -82,3 +82,17 @@ def test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern):
     assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
     assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
     assert all(float(p["lml"]) == f.log_ml_estimate() for p in parts)
+
+
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+def test_hip_local_resample_equals_substate_resamples(g, o, tmp_path, method):
+    """island mode on the GPU: every shard resamples through a view of itself; equals the oracle's sub-state resamples"""
+    world, n_global = 2, 60_001
+    mp.spawn(shard_worker_gpu.run_local, args=(world, free_port(), method, n_global, str(tmp_path)), nprocs=world, join=True)
+    f, lml = single_local(g, o, method, n_global, world)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
+    assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
+    for p in parts:
+        assert np.array_equal(p["lml"], lml) and float(p["ess"]) == f.effective_sample_size()

@@ -90,3 +90,35 @@ def test_sharded_skewed_weights(g, o, tmp_path, method, pattern):
     assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
     assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
     assert all(float(p["lml"]) == f.log_ml_estimate() for p in parts)
+
+
+def single_local(g, o, method, n_global, world):
+    """the unsharded oracle with pf_resample!(state[shard range], ...) for every shard range (resample.jl:205-218)"""
+    from gpf_amd.sharded import shard_range
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 5)
+    f = o.OracleFilter(model.model_id, model.params, n_global, 77).initialize(ys[0])
+    lml = []
+    for t in range(1, 5):
+        epoch = f.epoch
+        for r in range(world):
+            gid0, n = shard_range(n_global, r, world)
+            f.epoch = epoch                                  # the shards resample concurrently: same epoch, disjoint global ids
+            f[gid0:gid0 + n].resample(method, sort_particles=(t % 2 == 0), check=False)
+        f.update(ys[t])
+        lml.append(f.log_ml_estimate())
+    return f, np.array(lml)
+
+
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_local_resample_equals_substate_resamples(g, o, tmp_path, method, world):
+    """island mode (the communication-free alternative) == sub-state resamples of the unsharded oracle"""
+    n_global = 3001
+    mp.spawn(shard_worker.run_local, args=(world, free_port(), method, n_global, str(tmp_path)), nprocs=world, join=True)
+    f, lml = single_local(g, o, method, n_global, world)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
+    assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)      # local to each shard, like the reference's views
+    for p in parts:
+        assert np.array_equal(p["lml"], lml) and float(p["ess"]) == f.effective_sample_size()
