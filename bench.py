@@ -86,7 +86,7 @@ def main():
         state = g.pf_initialize(model, (1,), ys[0], n_local, seed=SEED, device=local_rank)
 
         def step(t):
-            g.pf_resample(state, "multinomial", check=False)
+            g.pf_resample(state, "multinomial")                   # the reference's defaults: priority_fn = nothing, check = :warn
             g.pf_update(state, (t + 1,), (None,), ys[t])
     else:
         from gpf_amd import sharded

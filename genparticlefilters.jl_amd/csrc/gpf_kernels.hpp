@@ -478,6 +478,11 @@ struct ScanOut {
 // Arrangement: wave w of the workgroup owns 512 consecutive elements of the tile as 4 rows of 128;
 // lane l holds elements 2l, 2l+1 of each row, so every global access is 16 B per lane, contiguous
 // across the wave (1 KiB per wave-instruction), for the loads AND the CDF stores.
+struct ScanExtras {            // optional side jobs of a scan launch
+    int64_t* zero128;          // clear 2 * MAX_SHARDS exchange counters (sharded resample), or nullptr
+    int64_t* host_flags;       // pinned host {flags, ticket}: publish the validity flags of the weights, or nullptr
+    int64_t ticket;
+};
 constexpr int SCAN_ROWS = 4;
 // MODE 0: plain scan of In; 1: fixed-point weights (folds the max partials); 2: as 1, plus sum q^2 for the ESS;
 // 3 / 4: as 1 / 2 with the maximum and flags taken from the np gathered (max, flags) pairs of the shards (pmax = mf_all)
@@ -487,10 +492,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
                                                 int np, WSum* __restrict__ ws_out, ScanOut out,
                                                 uint64_t* __restrict__ dcur, uint64_t* __restrict__ dnext,
                                                 uint64_t* __restrict__ total_out, uint64_t* __restrict__ blockQ,
-                                                int32_t* __restrict__ timeout, int64_t* __restrict__ zero128)
+                                                int32_t* __restrict__ timeout, ScanExtras ex)
 {
     // sharded resamples: the exchange counters of the push pass that follows are cleared here (no memset node)
-    if (zero128 && blockIdx.x == 0 && threadIdx.x < 2 * MAX_SHARDS) zero128[threadIdx.x] = 0;
+    if (ex.zero128 && blockIdx.x == 0 && threadIdx.x < 2 * MAX_SHARDS) ex.zero128[threadIdx.x] = 0;
     __shared__ double sm[NWAVES];
     __shared__ int sf[NWAVES];
     __shared__ uint64_t s_wave[NWAVES];
@@ -512,7 +517,15 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
         } else fold_partials(pmax, pflags, np, sm, sf, m, f);
 #endif
         in.m = m; in.flags = f;
-        if (blockIdx.x == 0 && threadIdx.x == 0) { ws_out->m = m; ws_out->flags = f; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ws_out->m = m; ws_out->flags = f;
+            // check = true / :warn (resample.jl:54-55): the host learns safe_softmax's validity flags NOW, from pinned memory,
+            // while this kernel and the ancestor search behind it keep running (no stream synchronisation, no idle gap)
+            if (ex.host_flags) {
+                __hip_atomic_store(ex.host_flags, (int64_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(ex.host_flags + 1, ex.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
     uint64_t ql[4] = {0, 0, 0, 0};
     const int lane = lane_id(), wv = wave_id();

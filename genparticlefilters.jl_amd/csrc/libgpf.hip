@@ -90,6 +90,8 @@ struct gpf_filter {
     uint64_t parent_generation = 0;
     int64_t* shard_counts = nullptr;     // [2 * MAX_SHARDS] exchange counters of the current resample (device) + pinned mirror
     int64_t* h_shard_counts = nullptr;
+    int64_t* h_flags = nullptr;          // pinned {validity flags, ticket} published by the weight scan of a checked resample
+    int64_t flag_ticket = 0;
     hipEvent_t ev_sync = nullptr;
     int64_t push_ticket = 0;             // bumped by every gpf_shard_push launch; k_push publishes it with the counts
     bool counts_published = false;
@@ -383,7 +385,7 @@ int scan_grid(const gpf_filter* h) { return (int)std::max<int64_t>(1, std::min<i
 // one scan launch on descriptor channel `ch` (0 weights, 1 residual counts, 2 residual weights)
 template <class In, int FIXQ>
 gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, bool want_cdf, uint64_t* total_out,
-                       const double* mf_all = nullptr, int64_t* zero128 = nullptr)
+                       const double* mf_all = nullptr, ScanExtras ex = ScanExtras{nullptr, nullptr, 0})
 {
     const double* pmax = mf_all ? mf_all : h->pmax;
     uint64_t* dc = h->desc[ch][h->dcur[ch]];
@@ -392,7 +394,7 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
     const ScanOut so{want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch]};
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
         GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, pmax, h->pflags, np, slot,
-                           so, dc, dn, total_out, h->blockQ, &h->sc->timeout, zero128);
+                           so, dc, dn, total_out, h->blockQ, &h->sc->timeout, ex);
     });
     if (s) return s;
     h->table[ch] = dc + h->ntiles;
@@ -402,8 +404,14 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
 
 // pv: the weights to summarise; use_producer_max: pmax/pflags written by the kernel that produced lw are current
 gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cdf, const int32_t* order, bool use_producer_max,
-                     bool want_q = false)
+                     bool want_q = false, bool publish_flags = false)
 {
+    ScanExtras ex{nullptr, nullptr, 0};
+    if (publish_flags) {
+        if (!h->h_flags) { HIP_TRY(h, hipHostMalloc(&h->h_flags, 2 * sizeof(int64_t))); h->h_flags[0] = h->h_flags[1] = 0; }
+        h->flag_ticket += 1;
+        ex.host_flags = h->h_flags; ex.ticket = h->flag_ticket;
+    }
     int np;
     gpf_status s;
     if (use_producer_max && h->max_valid) np = h->max_np;
@@ -417,8 +425,8 @@ gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cd
         if (use_producer_max) { h->max_valid = true; h->max_np = np; }
     }
     InFixQ in{pv, order, h->K, 0.0, 0};
-    if (want_q) s = scan_launch<InFixQ, 2>(h, 0, in, np, slot, want_cdf, &slot->S);
-    else        s = scan_launch<InFixQ, 1>(h, 0, in, np, slot, want_cdf, &slot->S);
+    if (want_q) s = scan_launch<InFixQ, 2>(h, 0, in, np, slot, want_cdf, &slot->S, nullptr, ex);
+    else        s = scan_launch<InFixQ, 1>(h, 0, in, np, slot, want_cdf, &slot->S, nullptr, ex);
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
@@ -582,24 +590,40 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     }
     // safe_softmax(log_priorities) (resample.jl:54) and logsumexp(log_weights) (resample.jl:180)
     WSum* ws;
+    bool published = false;                                      // the scan of THIS call publishes the flags to pinned memory
     if (pv.mode == 0) {
         ws = &h->sc->raw;
         if (!h->raw_valid || sorted) {
-            if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, true))) return s;
+            if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, true, false, need_sync))) return s;
+            published = need_sync;
         }
     } else {
         if ((s = ensure_raw(h))) return s;                       // raw summary (cdf[0] is overwritten next; only S, m matter)
         ws = &h->sc->prio;
-        if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, false))) return s;
+        if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, false, false, need_sync))) return s;
+        published = need_sync;
     }
     h->raw_valid = false;                                        // cdf[0] no longer the plain raw CDF / lw about to change
     h->raw_q_folded = false;
     if (need_sync) {
-        if ((s = fetch_scalars(h))) return s;
-        const WSum& w = pv.mode == 0 ? h->h_sc->raw : h->h_sc->prio;
-        const bool inv = w.flags != 0;
+        int flags;
+        if (published) {
+            // safe_softmax's flags are known when the scan STARTS (it folds the per-block maxima first): poll the ticket; the
+            // scan keeps running and the search below is enqueued behind it without a gap
+            volatile int64_t* tk = h->h_flags + 1;
+            uint64_t spins = 0;
+            while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket) {
+                if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket)
+                    return fail(h, GPF_ERR_HIP, "the weight scan finished without publishing its flags");
+            }
+            flags = (int)h->h_flags[0];
+        } else {
+            if ((s = fetch_scalars(h))) return s;
+            flags = (pv.mode == 0 ? h->h_sc->raw : h->h_sc->prio).flags;
+        }
+        const bool inv = flags != 0;
         if (invalid) *invalid = inv ? 1 : 0;
-        if (w.flags & (FLAG_NAN | FLAG_POSINF)) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights (NaN).");
+        if (flags & (FLAG_NAN | FLAG_POSINF)) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights (NaN).");
         if (check == GPF_CHECK_TRUE && inv) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights.");   // resample.jl:55
     }
     // ancestors (+ update_lml_est!, resample.jl:57,178-182, inside the search kernel)
@@ -765,6 +789,7 @@ gpf_status gpf_destroy(gpf_handle h)
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
+    if (h->h_flags) hipHostFree(h->h_flags);
     if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1546,10 +1571,10 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     const int gs = scan_grid(h);
     // the scan folds the gathered (max, flags) pairs itself and writes the shard total straight into out5[0]
     if (want_q) {
-        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, h->shard_counts))) return s;
+        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, nullptr, 0}))) return s;
         GPF_LAUNCH(k_export_q, dim3(1), dim3(BLOCK), 0, h->stream, h->blockQ, gs, out5);
     } else {
-        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, h->shard_counts))) return s;
+        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, nullptr, 0}))) return s;
     }
     HIP_TRY(h, hipGetLastError());
     h->raw_valid = false;            // sc->raw holds the GLOBAL max but no sum: not the unsharded summary
