@@ -74,6 +74,7 @@ SYMBOLS = [
     # shard-level building blocks: device pointers are passed as integers (tensor.data_ptr())
     ("gpf_shard_weight_max", C.c_int, [_H, C.c_void_p]),
     ("gpf_shard_weight_scan", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("gpf_shard_flags", C.c_int, [_H, _pi32]),
     ("gpf_shard_residual_scan", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_void_p]),
     ("gpf_shard_push_count", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     ("gpf_shard_counts", C.c_int, [_H, C.c_int32, C.POINTER(C.c_int64)]),

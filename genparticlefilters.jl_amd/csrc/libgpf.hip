@@ -1569,15 +1569,33 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     h->max_valid = false;
     InFixQ in{raw_view(h), nullptr, h->K, 0.0, 0};
     const int gs = scan_grid(h);
-    // the scan folds the gathered (max, flags) pairs itself and writes the shard total straight into out5[0]
+    // the scan folds the gathered (max, flags) pairs itself and writes the shard total straight into out5[0]; it also
+    // publishes the global validity flags to pinned host memory (gpf_shard_flags)
+    if (!h->h_flags) { HIP_TRY(h, hipHostMalloc(&h->h_flags, 2 * sizeof(int64_t))); h->h_flags[0] = h->h_flags[1] = 0; }
+    h->flag_ticket += 1;
     if (want_q) {
-        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, nullptr, 0}))) return s;
+        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, h->h_flags, h->flag_ticket}))) return s;
         GPF_LAUNCH(k_export_q, dim3(1), dim3(BLOCK), 0, h->stream, h->blockQ, gs, out5);
     } else {
-        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, nullptr, 0}))) return s;
+        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, h->h_flags, h->flag_ticket}))) return s;
     }
     HIP_TRY(h, hipGetLastError());
     h->raw_valid = false;            // sc->raw holds the GLOBAL max but no sum: not the unsharded summary
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_flags(gpf_handle h, int32_t* flags_out)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!flags_out || !h->h_flags || h->flag_ticket == 0) return fail(h, GPF_ERR_STATE, "gpf_shard_flags needs gpf_shard_weight_scan first");
+    volatile int64_t* tk = h->h_flags + 1;
+    uint64_t spins = 0;
+    while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket) {
+        if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket)
+            return fail(h, GPF_ERR_HIP, "the weight scan finished without publishing its flags");
+    }
+    *flags_out = (int32_t)h->h_flags[0];
     return GPF_OK;
 }
 

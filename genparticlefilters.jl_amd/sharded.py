@@ -90,6 +90,12 @@ class HipShardBackend:
         self._ck(self.L.gpf_shard_weight_scan(self.h, mf_all.data_ptr(), mf_all.shape[0], int(want_q), out.data_ptr()))
         return out
 
+    def scan_flags(self) -> int:
+        """validity flags of the global weights, as soon as the weight scan has started (no stream synchronisation)"""
+        out = C.c_int32()
+        self._ck(self.L.gpf_shard_flags(self.h, C.byref(out)))
+        return out.value
+
     def residual_scan(self, tot_all):
         out = torch.empty(2, dtype=torch.int64, device=self.device)
         self._ck(self.L.gpf_shard_residual_scan(self.h, tot_all.data_ptr(), tot_all.shape[0], out.data_ptr()))
@@ -263,15 +269,11 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
         raise ErrorException("sharded stratified resampling needs sort_particles=False (no global sort; SURVEY.md H8)")
     b, G, mid = state.backend, state.world, RESAMPLE_METHODS[method]
     mf_all, tot_all = state._summary(want_q=False)                    # phases 1, 2 (no sum q^2: only the ESS needs it)
-    if check is not False:                                            # safe_softmax validity (utils.jl:117-140): host sync
-        mf = mf_all.cpu().numpy()
-        flags = 0
-        for f in mf[:, 1]:
-            flags |= int(f)
-        invalid = bool(flags != 0 or mf[:, 0].max() == -np.inf)
-        if flags != 0 or (check is True and invalid):
+    if check is not False:                                            # safe_softmax validity (utils.jl:117-140), no stream sync
+        flags = b.scan_flags()
+        if (flags & 3) or (check is True and flags):
             raise ErrorException("Invalid weights.")                  # resample.jl:55
-        if invalid:
+        if flags:
             import warnings
             warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")
     cr_all = state._all_gather(b.residual_scan(tot_all)).contiguous() if mid == 1 else None     # phase 2b: (G, 2)

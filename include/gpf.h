@@ -258,6 +258,9 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
  */
 gpf_status gpf_shard_weight_max(gpf_handle h, double* out2);
 gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, int32_t want_q, int64_t* out5);
+/* safe_softmax's validity flags of the GLOBAL weights (bit 0 NaN, bit 1 +Inf, bit 2 all -Inf), published to pinned host memory by
+ * the last gpf_shard_weight_scan when it starts: the host polls, the stream is not synchronised (check = true / :warn) */
+gpf_status gpf_shard_flags(gpf_handle h, int32_t* flags_out);
 gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t G, int64_t* out2);
 gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
                                 const int64_t* bounds);

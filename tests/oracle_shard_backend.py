@@ -53,10 +53,14 @@ class OracleShardBackend:
     def weight_scan(self, mf_all, want_q=True):
         m, f = self._combine(mf_all)
         uniform = (m == -np.inf) and not (f & 1)
+        self._flags = f | (4 if uniform else 0)
         self.q = np.zeros(self.n, np.uint64) if f & 3 else o.fixq(self.lw, m, self.K, uniform)
         self.cdf, S, hi, lo = o.scan(self.q)
         Q = (hi << 64) | lo
         return torch.tensor([S] + [(Q >> (32 * k)) & 0xFFFFFFFF for k in range(4)], dtype=torch.int64)
+
+    def scan_flags(self):
+        return self._flags
 
     def residual_scan(self, tot_all):
         S = int(tot_all[:, 0].sum())

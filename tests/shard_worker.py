@@ -96,3 +96,45 @@ def run_local(rank, world, port, method, n_global, out_dir):
                  lml=np.array(lml), ess=sharded.get_ess(st))
     finally:
         dist.destroy_process_group()
+
+
+def run_check(rank, world, port, n_global, out_dir, gpu=False):
+    """validity checks of a sharded resample: all weights -Inf (uniform fallback, warning or error), NaN (always an error)"""
+    import warnings
+    import torch.distributed as dist
+    import gpf_amd as g
+    from gpf_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+        if gpu:
+            st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, device=0)
+            setw = lambda v: setattr(st.local, "log_weights", np.full(st.n_local, v))
+            get = lambda: (st.local.traces, st.local.log_weights, st.local.parents)
+        else:
+            from oracle_shard_backend import OracleShardBackend
+            st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, backend_factory=OracleShardBackend)
+            def setw(v): st.backend.lw[:] = v
+            get = lambda: (st.backend.rows, st.backend.lw, st.backend.parents)
+        res = {}
+        setw(-np.inf)
+        try:
+            sharded.pf_resample(st, "multinomial", check=True); res["true_raised"] = False
+        except g.ErrorException:
+            res["true_raised"] = True
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            sharded.pf_resample(st, "multinomial", check="warn")
+        res["warned"] = any("Invalid weights" in str(w.message) for w in wl)
+        rows, lw, parents = get()
+        if rank == 0:
+            setw(float("nan"))                       # NaN on ONE shard only: every shard must see the global flag
+        try:
+            sharded.pf_resample(st, "multinomial", check="warn"); res["nan_raised"] = False
+        except g.ErrorException:
+            res["nan_raised"] = True
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=rows, lw=lw, parents=parents, **res)
+    finally:
+        dist.destroy_process_group()

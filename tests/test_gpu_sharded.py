@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import shard_worker_gpu  # noqa: E402
-from test_sharded_gloo import CASES, free_port, single, single_local, single_skew  # noqa: E402
+from test_sharded_gloo import CASES, _check_single, free_port, single, single_local, single_skew  # noqa: E402
+import shard_worker  # noqa: E402
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
@@ -96,3 +97,14 @@ def test_hip_local_resample_equals_substate_resamples(g, o, tmp_path, method):
     assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
     for p in parts:
         assert np.array_equal(p["lml"], lml) and float(p["ess"]) == f.effective_sample_size()
+
+
+def test_hip_sharded_validity_checks(g, o, tmp_path):
+    world, n_global = 2, 50_000
+    mp.spawn(shard_worker.run_check, args=(world, free_port(), n_global, str(tmp_path), True), nprocs=world, join=True)
+    f = _check_single(g, o, n_global)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    for p in parts:
+        assert bool(p["true_raised"]) and bool(p["warned"]) and bool(p["nan_raised"])
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)

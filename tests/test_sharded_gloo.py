@@ -122,3 +122,24 @@ def test_sharded_local_resample_equals_substate_resamples(g, o, tmp_path, method
     assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)      # local to each shard, like the reference's views
     for p in parts:
         assert np.array_equal(p["lml"], lml) and float(p["ess"]) == f.effective_sample_size()
+
+
+def _check_single(g, o, n_global):
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    f = o.OracleFilter(model.model_id, model.params, n_global, 77).initialize(ys[0])
+    f.lw[:] = -np.inf
+    f.resample("multinomial", check=False)
+    return f
+
+
+def test_sharded_validity_checks(g, o, tmp_path):
+    """check = true raises, check = :warn warns and falls back to uniform weights (resample.jl:54-55), NaN on one shard is an
+    error on every shard -- all without synchronising the stream (the flags come from pinned memory)"""
+    world, n_global = 2, 2500
+    mp.spawn(shard_worker.run_check, args=(world, free_port(), n_global, str(tmp_path)), nprocs=world, join=True)
+    f = _check_single(g, o, n_global)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    for p in parts:
+        assert bool(p["true_raised"]) and bool(p["warned"]) and bool(p["nan_raised"])
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
