@@ -93,7 +93,7 @@ def main():
         state = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=SEED, device=local_rank)
 
         def step(t):
-            sharded.pf_resample(state, "multinomial", check=False)
+            sharded.pf_resample(state, "multinomial", check=False)   # (check = :warn polls one more pinned flag per resample: +6 us)
             sharded.pf_update(state, (t + 1,), (None,), ys[t])
 
     def barrier():
