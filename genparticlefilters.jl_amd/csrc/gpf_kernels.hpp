@@ -680,6 +680,21 @@ __global__ __launch_bounds__(BLOCK) void k_scan_residual2(const uint64_t* __rest
     }
 }
 
+// the device scalar block -> its pinned host mirror, ticket last: the host polls the ticket instead of synchronising the
+// stream (a hipMemcpyAsync + hipStreamSynchronize pair costs ~13 us of wake-up latency per getter; this costs the launch)
+__global__ void k_publish_scalars(const Scalars* sc, Scalars* host, long long* host_ticket, long long ticket)
+{
+    constexpr int NW = (int)(sizeof(Scalars) / sizeof(unsigned long long));
+    static_assert(sizeof(Scalars) % sizeof(unsigned long long) == 0, "Scalars must be a whole number of 8-byte words");
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(sc);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(host);
+    for (int i = threadIdx.x; i < NW; i += blockDim.x)
+        __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ----------------------------------------------------------------------------- scalar bookkeeping
 // sum of the scan blocks' limb partials of sum q^2 -> ws->Ql (only needed when the ESS is asked for)
 __global__ __launch_bounds__(BLOCK) void k_fold_q(WSum* ws, const uint64_t* __restrict__ blockQ, int nblk)

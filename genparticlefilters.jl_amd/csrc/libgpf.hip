@@ -66,6 +66,7 @@ struct gpf_filter {
     double *partial = nullptr, *dscal = nullptr;
     Scalars* sc = nullptr;
     Scalars* h_sc = nullptr;       // pinned mirror
+    long long* h_sc_ticket = nullptr; long long sc_ticket = 0;   // k_publish_scalars -> host polling (fetch_scalars)
     uint32_t epoch = 0;
     bool initialized = false, has_prev = false, raw_valid = false, serve_residual = false;
     bool max_valid = false;        // pmax/pflags hold the block partials of the current log-weights (written by the producer kernel)
@@ -447,8 +448,16 @@ gpf_status ensure_raw(gpf_filter* h, bool want_q = false)
 
 gpf_status fetch_scalars(gpf_filter* h)
 {
-    HIP_TRY(h, hipMemcpyAsync(h->h_sc, h->sc, sizeof(Scalars), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!h->h_sc_ticket) { HIP_TRY(h, hipHostMalloc(&h->h_sc_ticket, sizeof(long long))); *h->h_sc_ticket = 0; }
+    h->sc_ticket += 1;
+    GPF_LAUNCH(k_publish_scalars, dim3(1), dim3(64), 0, h->stream, h->sc, h->h_sc, h->h_sc_ticket, h->sc_ticket);
+    HIP_TRY(h, hipGetLastError());
+    volatile long long* tk = h->h_sc_ticket;
+    uint64_t spins = 0;
+    while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->sc_ticket) {
+        if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->sc_ticket)
+            return fail(h, GPF_ERR_HIP, "the scalar block was not published");
+    }
     if (h->h_sc->timeout) return fail(h, GPF_ERR_HIP, "scan kernel: bounded inter-workgroup wait timed out");
     return GPF_OK;
 }
@@ -788,6 +797,7 @@ gpf_status gpf_destroy(gpf_handle h)
     void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
+    if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
     if (h->h_flags) hipHostFree(h->h_flags);
     if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
