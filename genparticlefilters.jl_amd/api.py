@@ -207,6 +207,7 @@ class DeviceParticleFilterSubState(DeviceParticleFilterState):
 
 ParticleFilterState = DeviceParticleFilterState
 ParticleFilterSubState = DeviceParticleFilterSubState
+ParticleFilterView = (DeviceParticleFilterState, DeviceParticleFilterSubState)      # src/view.jl:32-33 (Union; use with isinstance)
 
 
 def _obs_vector(observations) -> np.ndarray:
