@@ -494,9 +494,33 @@ def sample_unweighted_traces(state, n_samples: int, return_indices: bool = False
 
 
 # ----------------------------------------------------------------------------- statistics (src/statistics.jl)
-def mean(state, addr) -> float:
+def _addr_values(state, addr) -> np.ndarray:
+    """the values at one address over all particles: a column of the current step, or (t, column) for a past choice"""
+    return state.history_column(int(addr[0]), int(addr[1])) if isinstance(addr, tuple) else state.column(int(addr))
+
+
+def _functional(f, state, addrs):
+    if not addrs:
+        raise ErrorException("native models have no return value: give at least one address")
+    vals = [_addr_values(state, a) for a in addrs]
+    try:
+        fv = np.asarray(f(*vals), np.float64)
+        if fv.shape != vals[0].shape:
+            raise TypeError
+    except (TypeError, ValueError):
+        fv = np.array([f(*xs) for xs in zip(*vals)], np.float64)              # scalar closure: broadcast(f, ...)
+    return fv
+
+
+def mean(*args) -> float:
     """mean(state, addr), src/statistics.jl:13-14.  addr = column of the current-step latent, or a pair
-    (t, column) for a PAST choice `t => column` (reference README.md:97; needs pf_initialize(..., history=T))"""
+    (t, column) for a PAST choice `t => column` (reference README.md:97; needs pf_initialize(..., history=T)).
+    mean(f, state, addrs...), src/statistics.jl:28-35: weighted mean of a host closure of the values at the addresses
+    (the values and the normalised weights are read back; f may be vectorised over NumPy arrays or scalar)."""
+    if callable(args[0]):
+        f, state, addrs = args[0], args[1], args[2:]
+        return float(np.sum(get_norm_weights(state) * _functional(f, state, addrs)))
+    state, addr = args
     out = C.c_double()
     if isinstance(addr, tuple):
         state._check(state._L.gpf_history_mean(state._h, int(addr[0]), int(addr[1]), C.byref(out)))
@@ -505,8 +529,15 @@ def mean(state, addr) -> float:
     return out.value
 
 
-def var(state, addr) -> float:
-    """var(state, addr), population form (src/statistics.jl:48-50); addr as in mean()"""
+def var(*args) -> float:
+    """var(state, addr), population form (src/statistics.jl:48-50); addr as in mean().
+    var(f, state, addrs...), src/statistics.jl:65-76: var(fvals, Weights(w), corrected=false)."""
+    if callable(args[0]):
+        f, state, addrs = args[0], args[1], args[2:]
+        w, fv = get_norm_weights(state), _functional(f, state, addrs)
+        mu = np.sum(w * fv) / np.sum(w)
+        return float(np.sum(w * (fv - mu) ** 2) / np.sum(w))
+    state, addr = args
     out = C.c_double()
     if isinstance(addr, tuple):
         state._check(state._L.gpf_history_var(state._h, int(addr[0]), int(addr[1]), C.byref(out)))

@@ -279,3 +279,18 @@ def test_no_device_memory_leak_over_handle_lifetimes(g):
     gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 lifetimes"
+
+
+def test_mean_var_functional_forms(g, o):
+    """mean(f, state, addrs...) / var(f, state, addrs...) (src/statistics.jl:28-38, 65-82; test/statistics.jl): host closures
+    over one or several addresses, vectorised or scalar; consistent with the plain forms"""
+    model, ys, st, orc = make_pair(g, o, "lgssm2", 5000, 4, False)
+    g.pf_update(st, (2,), (None,), ys[1])
+    m0, v0 = g.mean(st, 0), g.var(st, 0)
+    assert abs(g.mean(lambda x: x, st, 0) - m0) < 1e-12 and abs(g.var(lambda x: x, st, 0) - v0) < 1e-12
+    w = g.get_norm_weights(st); X = st.traces
+    np.testing.assert_allclose(g.mean(lambda x, y: x * y, st, 0, 1), np.sum(w * X[:, 0] * X[:, 1]), rtol=1e-12)
+    np.testing.assert_allclose(g.mean(lambda x: float(x) ** 2 if x > 0 else 0.0, st, 1),          # scalar closure with a branch
+                               np.sum(w * np.where(X[:, 1] > 0, X[:, 1] ** 2, 0.0)), rtol=1e-12)
+    fv = np.hypot(X[:, 0], X[:, 1]); mu = np.sum(w * fv)
+    np.testing.assert_allclose(g.var(np.hypot, st, 0, 1), np.sum(w * (fv - mu) ** 2), rtol=1e-10)
