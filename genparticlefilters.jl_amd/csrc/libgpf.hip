@@ -68,7 +68,7 @@ struct gpf_filter {
     Scalars* h_sc = nullptr;       // pinned mirror
     long long* h_sc_ticket = nullptr; long long sc_ticket = 0;   // k_publish_scalars -> host polling (fetch_scalars)
     uint32_t epoch = 0;
-    bool initialized = false, has_prev = false, raw_valid = false, serve_residual = false;
+    bool initialized = false, has_prev = false, raw_valid = false, residual_scanned = false;
     bool max_valid = false;        // pmax/pflags hold the block partials of the current log-weights (written by the producer kernel)
     int max_np = 0;
     bool raw_has_q = false;        // the raw summary's scan also accumulated sum q^2 (blockQ)
@@ -93,7 +93,6 @@ struct gpf_filter {
     int64_t* h_shard_counts = nullptr;
     int64_t* h_flags = nullptr;          // pinned {validity flags, ticket} published by the weight scan of a checked resample
     int64_t flag_ticket = 0;
-    hipEvent_t ev_sync = nullptr;
     int64_t push_ticket = 0;             // bumped by every gpf_shard_push launch; k_push publishes it with the counts
     bool counts_published = false;
     ulonglong2* push_stage = nullptr;    // push exchange: staged hits, one 16-byte entry per global output slot at most
@@ -800,7 +799,6 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
     if (h->h_flags) hipHostFree(h->h_flags);
-    if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return GPF_OK;
@@ -1619,7 +1617,7 @@ gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t
     if ((s = residual_scans(h, &h->sc->prio, h->cfg.n_global))) return s;
     GPF_LAUNCH(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2);
     HIP_TRY(h, hipGetLastError());
-    h->serve_residual = true;
+    h->residual_scanned = true;
     return GPF_OK;
 }
 
@@ -1708,7 +1706,7 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
     if (capacity == 0) return GPF_OK;
     h->counts_published = true;
     const bool two = method == GPF_RESAMPLE_RESIDUAL;
-    if (two && !h->serve_residual) return fail(h, GPF_ERR_STATE, "residual push needs gpf_shard_residual_scan first");
+    if (two && !h->residual_scanned) return fail(h, GPF_ERR_STATE, "residual push needs gpf_shard_residual_scan first");
     const int64_t nt = two ? 2 : 1;
     const int64_t top_n = nt * h->ntiles * 8 <= LDS_TILE_TABLE ? h->ntiles * 8 : (nt * h->ntiles <= LDS_TILE_TABLE ? h->ntiles : 0);
     const size_t lds = (size_t)(nt * (lds_pad(top_n) + 1)) * sizeof(uint64_t);
@@ -1741,7 +1739,7 @@ gpf_status gpf_shard_commit(gpf_handle h, const double* packed, int64_t m, const
     h->epoch += 1;
     h->raw_valid = false;
     h->max_valid = false;
-    h->serve_residual = false;
+    h->residual_scanned = false;
     h->push_counted = false;
     return GPF_OK;
 }
