@@ -22,6 +22,15 @@ using namespace gpf;
 
 namespace {
 
+// polite busy-wait on a pinned-memory ticket (x86 PAUSE; a plain compiler barrier elsewhere)
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
 thread_local std::string g_err;   // errors before a handle exists
 
 // Kernel timing (gpf_kernel_timing): inside timed() the launch carries a start/stop event pair that the runtime
@@ -454,6 +463,7 @@ gpf_status fetch_scalars(gpf_filter* h)
     volatile long long* tk = h->h_sc_ticket;
     uint64_t spins = 0;
     while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->sc_ticket) {
+        cpu_relax();
         if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->sc_ticket)
             return fail(h, GPF_ERR_HIP, "the scalar block was not published");
     }
@@ -621,7 +631,8 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
             volatile int64_t* tk = h->h_flags + 1;
             uint64_t spins = 0;
             while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket) {
-                if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket)
+                cpu_relax();
+        if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket)
                     return fail(h, GPF_ERR_HIP, "the weight scan finished without publishing its flags");
             }
             flags = (int)h->h_flags[0];
@@ -1600,6 +1611,7 @@ gpf_status gpf_shard_flags(gpf_handle h, int32_t* flags_out)
     volatile int64_t* tk = h->h_flags + 1;
     uint64_t spins = 0;
     while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket) {
+        cpu_relax();
         if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket)
             return fail(h, GPF_ERR_HIP, "the weight scan finished without publishing its flags");
     }
@@ -1681,7 +1693,8 @@ gpf_status gpf_shard_counts(gpf_handle h, int32_t G, int64_t* host_counts)
         volatile int64_t* tk = h->h_shard_counts + 2 * MAX_SHARDS;
         uint64_t spins = 0;
         while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->push_ticket) {
-            if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess &&
+            cpu_relax();
+        if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess &&
                 __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->push_ticket)
                 return fail(h, GPF_ERR_HIP, "the push kernel finished without publishing its counts");
         }
