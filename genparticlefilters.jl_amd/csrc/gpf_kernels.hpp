@@ -825,43 +825,62 @@ struct SearchTop {
     const uint64_t* topw; const uint64_t* topc;      // top level of the weight CDF / of the residual copy-count CDF
     int64_t tn;                                      // entries of the top level
     int steps;                                       // ceil(log2(tn + 1))
+    int gshift;                                      // !top256: one top entry = the prefix at the end of 2^gshift tiles
     bool top256, in_lds, mask_top;
 };
+// shape of the LDS top level for a CDF of `ntiles` tiles (nt tables side by side): the per-256 prefixes when they fit, else
+// the prefix at the end of every g-th tile with the smallest power of two g that fits (g = 1 up to 16.7 M particles, 8 up
+// to 134 M, ...): the table always lives in LDS, whatever N is
+__host__ __device__ __forceinline__ void search_top_shape(int64_t ntiles, int nt, bool& top256, int& gshift, int64_t& tn)
+{
+    top256 = nt * ntiles * 8 <= LDS_TILE_TABLE;
+    gshift = 0;
+    if (top256) { tn = ntiles * 8; return; }
+    while (nt * ((ntiles + ((int64_t)1 << gshift) - 1) >> gshift) > LDS_TILE_TABLE) ++gshift;
+    tn = (ntiles + ((int64_t)1 << gshift) - 1) >> gshift;
+}
+__host__ inline size_t search_lds_bytes(int64_t ntiles, int nt)
+{
+    bool t256; int gs; int64_t tn;
+    search_top_shape(ntiles, nt, t256, gs, tn);
+    return (size_t)(nt * (lds_pad(tn) + 1)) * sizeof(uint64_t);
+}
 // block-collective: copy the top level(s) into LDS (smem: dynamic LDS, (two ? 2 : 1) * (lds_pad(tn) + 1) words)
 __device__ __forceinline__ SearchTop search_prologue(const CdfLevels& w, const CdfLevels& c, bool two, int64_t ntiles, uint64_t* smem)
 {
     SearchTop st;
     const int nt = two ? 2 : 1;
-    st.top256 = nt * ntiles * 8 <= LDS_TILE_TABLE;
-    st.in_lds = st.top256 || nt * ntiles <= LDS_TILE_TABLE;
-    st.tn = st.top256 ? ntiles * 8 : ntiles;
+    search_top_shape(ntiles, nt, st.top256, st.gshift, st.tn);
+    st.in_lds = true;
     uint64_t* tw = smem;
     uint64_t* tc = tw + lds_pad(st.tn);
-#ifdef GPF_ABL_SEARCH_NOTABLE
-    if (false) {
-#else
-    if (st.in_lds) {
-#endif
-        const uint64_t* srcw = st.top256 ? w.t256 : w.ttile;
-        const uint64_t* srcc = st.top256 ? c.t256 : c.ttile;
-        // 16 B per lane (tn is a multiple of 8 when it is the per-256 level; the tile level is handled by the tail)
-        const int64_t tn2 = st.tn & ~(int64_t)1;
-        for (int64_t t = 2 * (int64_t)threadIdx.x; t < tn2; t += 2 * (int64_t)blockDim.x) {
+#ifndef GPF_ABL_SEARCH_NOTABLE
+    if (st.top256) {
+        const uint64_t* srcw = w.t256;
+        const uint64_t* srcc = c.t256;
+        // 16 B per lane (the per-256 level has a multiple of 8 entries)
+        for (int64_t t = 2 * (int64_t)threadIdx.x; t < st.tn; t += 2 * (int64_t)blockDim.x) {
             const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(srcw + t);
-            tw[lds_pad(t)] = v.x & DESC_MASK;                         // descriptor words carry a valid bit
-            tw[lds_pad(t + 1)] = v.y & DESC_MASK;
+            tw[lds_pad(t)] = v.x; tw[lds_pad(t + 1)] = v.y;
             if (two) {
                 const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(srcc + t);
-                tc[lds_pad(t)] = x.x & DESC_MASK;
-                tc[lds_pad(t + 1)] = x.y & DESC_MASK;
+                tc[lds_pad(t)] = x.x; tc[lds_pad(t + 1)] = x.y;
             }
         }
-        if (threadIdx.x == 0 && tn2 < st.tn) { tw[lds_pad(tn2)] = srcw[tn2] & DESC_MASK; if (two) tc[lds_pad(tn2)] = srcc[tn2] & DESC_MASK; }
-        __syncthreads();
+    } else {
+        // prefix at the end of every 2^gshift-th tile, from the tiles' descriptor words (they carry a valid bit)
+        const int64_t g = (int64_t)1 << st.gshift;
+        for (int64_t t = threadIdx.x; t < st.tn; t += blockDim.x) {
+            const int64_t last = ((t + 1) * g < ntiles ? (t + 1) * g : ntiles) - 1;
+            tw[lds_pad(t)] = w.ttile[last] & DESC_MASK;
+            if (two) tc[lds_pad(t)] = c.ttile[last] & DESC_MASK;
+        }
     }
-    st.topw = st.in_lds ? tw : w.ttile;
-    st.topc = st.in_lds ? tc : c.ttile;
-    st.mask_top = !st.in_lds;                                         // global descriptor words still carry the bit
+    __syncthreads();
+#endif
+    st.topw = tw;
+    st.topc = tc;
+    st.mask_top = false;
     st.steps = 0;
     while (((int64_t)1 << st.steps) <= st.tn) ++st.steps;
     return st;
@@ -895,7 +914,14 @@ __device__ __forceinline__ void search_pair(const SearchTop& st, const CdfLevels
     for (int u = 0; u < 2; ++u) {
         if (st.top256) s256[u] = pos[u];
         else {
-            const int64_t tile = pos[u] < ntiles ? pos[u] : ntiles - 1;
+            int64_t tile = pos[u] << st.gshift;
+            if (st.gshift) {                                      // inside the group of 2^gshift tiles: their descriptor prefixes
+                const int64_t hi = tile + ((int64_t)1 << st.gshift) < ntiles ? tile + ((int64_t)1 << st.gshift) : ntiles;
+                int64_t cnt = 0;
+                for (int64_t e = tile; e < hi; ++e) cnt += ((L[u]->ttile[e] & DESC_MASK) <= T[u]);
+                tile += cnt;
+            }
+            tile = tile < ntiles ? tile : ntiles - 1;
             const uint64_t* g = L[u]->t256 + tile * 8;             // the tile's 8 per-256 prefixes: 64 B
             int c = 0;
 #pragma unroll

@@ -658,8 +658,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         sa.w = levels(h, 2); sa.c = levels(h, 1);
     }
     const int64_t nt = method == GPF_RESAMPLE_RESIDUAL ? 2 : 1;
-    const int64_t top_n = nt * h->ntiles * 8 <= LDS_TILE_TABLE ? h->ntiles * 8 : (nt * h->ntiles <= LDS_TILE_TABLE ? h->ntiles : 0);
-    const size_t lds = (size_t)(nt * (lds_pad(top_n) + 1)) * sizeof(uint64_t);
+    const size_t lds = search_lds_bytes(h->ntiles, (int)nt);
     // every block first copies the top level of the CDF into LDS: keep the grid small (persistent blocks)
     // one 1024-thread workgroup per CU, two slots per lane and iteration
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu * SEARCH_BLOCKS_PER_CU));
@@ -1187,8 +1186,7 @@ gpf_status gpf_sample_unweighted(gpf_handle h, int64_t n_samples, double* rows_o
     sa.w = levels(h, 0); sa.c = levels(h, 0); sa.ntiles = h->ntiles; sa.order = nullptr; sa.sc = h->sc; sa.ws = &h->sc->raw;
     sa.raw = &h->sc->raw; sa.n = n_samples; sa.n_cells = h->n; sa.n_global = n_samples; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed;
     sa.epoch = h->epoch; sa.K = h->K; sa.logN = h->logN; sa.update_lml = 0; sa.anc = anc;
-    const int64_t top_n = h->ntiles * 8 <= LDS_TILE_TABLE ? h->ntiles * 8 : (h->ntiles <= LDS_TILE_TABLE ? h->ntiles : 0);
-    const size_t lds = (size_t)(lds_pad(top_n) + 1) * sizeof(uint64_t);
+    const size_t lds = search_lds_bytes(h->ntiles, 1);
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((n_samples + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
     GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
     launch_gather_rows_lw(h, anc, h->rows[h->cur], h->lw, rows, nullptr, n_samples);
@@ -1334,8 +1332,7 @@ static gpf_status resize_optimal(gpf_handle h, int64_t n_new, int32_t check, int
         sa.w = lv; sa.c = lv; sa.ntiles = ntiles_old; sa.order = nullptr; sa.sc = h->sc; sa.ws = ws; sa.raw = ws;
         sa.n = n_res; sa.n_cells = n_old; sa.n_global = n_res; sa.gid0 = 0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
         sa.K = K; sa.logN = 0.0; sa.update_lml = 0; sa.anc = h->anc + n_keep;
-        const int64_t top_n = ntiles_old * 8 <= LDS_TILE_TABLE ? ntiles_old * 8 : (ntiles_old <= LDS_TILE_TABLE ? ntiles_old : 0);
-        const size_t lds = (size_t)(lds_pad(top_n) + 1) * sizeof(uint64_t);
+        const size_t lds = search_lds_bytes(ntiles_old, 1);
         const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((n_res + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
         GPF_LAUNCH((k_search<3>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
     }
@@ -1391,8 +1388,7 @@ gpf_status gpf_resize(gpf_handle h, int64_t n_new, int32_t method, double priori
     if ((s = alloc_particle_buffers(h))) { free_bufs(old); return s; }
     sa.anc = h->anc;
     const int64_t nt = method == GPF_RESAMPLE_RESIDUAL ? 2 : 1;
-    const int64_t top_n = nt * ntiles_old * 8 <= LDS_TILE_TABLE ? ntiles_old * 8 : (nt * ntiles_old <= LDS_TILE_TABLE ? ntiles_old : 0);
-    const size_t lds = (size_t)(nt * (lds_pad(top_n) + 1)) * sizeof(uint64_t);
+    const size_t lds = search_lds_bytes(ntiles_old, (int)nt);
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((n_new + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
     if (method == GPF_RESAMPLE_RESIDUAL) GPF_LAUNCH((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
     else                                 GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
@@ -1721,8 +1717,7 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
     const bool two = method == GPF_RESAMPLE_RESIDUAL;
     if (two && !h->residual_scanned) return fail(h, GPF_ERR_STATE, "residual push needs gpf_shard_residual_scan first");
     const int64_t nt = two ? 2 : 1;
-    const int64_t top_n = nt * h->ntiles * 8 <= LDS_TILE_TABLE ? h->ntiles * 8 : (nt * h->ntiles <= LDS_TILE_TABLE ? h->ntiles : 0);
-    const size_t lds = (size_t)(nt * (lds_pad(top_n) + 1)) * sizeof(uint64_t);
+    const size_t lds = search_lds_bytes(h->ntiles, (int)nt);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((capacity + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));
     const CdfLevels lw_ = levels(h, two ? 2 : 0);
     const CdfLevels lc_ = levels(h, two ? 1 : 0);
