@@ -42,3 +42,22 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".jl")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not bad.search(src), f"{f} uses oracle/"
+
+
+def test_julia_glue_matches_header():
+    """julia/GenParticleFiltersAMD.jl cannot be run here (no Julia in the image); at least every ccall it makes must name an
+    entry point of include/gpf.h with the same number of arguments"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jl = open(os.path.join(root, "julia", "GenParticleFiltersAMD.jl")).read()
+    hdr = open(os.path.join(root, "include", "gpf.h")).read()
+    names = set(re.findall(r"\(:([a-z_A-Z0-9]+), libgpf\)", jl))
+    assert len(names) >= 20
+    for n in sorted(names):
+        h = re.search(r"\b%s\s*\(([^;]*?)\);" % n, hdr, re.S)
+        assert h, f"{n} is not declared in include/gpf.h"
+        m = re.search(r"\(:%s, libgpf\), [A-Za-z]+, \(([^)]*)\)" % n, jl)
+        assert m, n
+        ja = [a for a in m.group(1).split(",") if a.strip()]
+        ha = [a for a in h.group(1).split(",") if a.strip() and a.strip() != "void"]
+        assert len(ja) == len(ha), f"{n}: {len(ja)} ccall argument types, {len(ha)} parameters in the header"
