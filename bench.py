@@ -283,9 +283,20 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
             "stratified_variant": strat, "local_resample_variant": island,
         }
-        print(json.dumps(out))
+    else:
+        out = None
     if dist is not None:
         dist.destroy_process_group()
+    if out is not None:
+        # the JSON line is the LAST thing on stdout: libraries in this process (RCCL prints "Librccl path : ..." through C stdio)
+        # get their buffered output flushed first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
