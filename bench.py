@@ -285,16 +285,22 @@ def main():
         }
     else:
         out = None
-    if dist is not None:
-        dist.destroy_process_group()
-    if out is not None:
-        # the JSON line is the LAST thing on stdout: libraries in this process (RCCL prints "Librccl path : ..." through C stdio)
-        # get their buffered output flushed first
+
+    def flush_c_stdio():
         try:
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+    # The JSON line must be the LAST thing on the job's stdout.  RCCL prints a banner ("RCCL version ...", "Librccl path ...")
+    # through C stdio, buffered until exit when stdout is a pipe: every rank flushes it now, all ranks meet, and only then
+    # does rank 0 print.
+    if dist is not None:
+        flush_c_stdio(); sys.stdout.flush()
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        flush_c_stdio()
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
 
