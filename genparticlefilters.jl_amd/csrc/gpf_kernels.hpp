@@ -715,7 +715,7 @@ __global__ __launch_bounds__(BLOCK) void k_fold_q(WSum* ws, const uint64_t* __re
 
 // ----------------------------------------------------------------------------- K5: ancestor search
 // a = first index with cdf[a] > T.  The CDF comes with coarser levels written by the scan (fan-out 16):
-// top level (per-256 prefixes, or per-tile when that does not fit) is binary-searched in LDS, then each
+// top level (per-256 prefixes, or the prefix of every 2^g-th tile when those do not fit) is binary-searched in LDS, then each
 // further level costs ONE 128-byte line: 16 consecutive u64 loaded with 8 independent 16-B loads and
 // compared in registers.  Two dependent L2 round trips per slot instead of eleven.
 struct CdfLevels {
@@ -826,7 +826,7 @@ struct SearchTop {
     int64_t tn;                                      // entries of the top level
     int steps;                                       // ceil(log2(tn + 1))
     int gshift;                                      // !top256: one top entry = the prefix at the end of 2^gshift tiles
-    bool top256, in_lds, mask_top;
+    bool top256;
 };
 // shape of the LDS top level for a CDF of `ntiles` tiles (nt tables side by side): the per-256 prefixes when they fit, else
 // the prefix at the end of every g-th tile with the smallest power of two g that fits (g = 1 up to 16.7 M particles, 8 up
@@ -851,7 +851,6 @@ __device__ __forceinline__ SearchTop search_prologue(const CdfLevels& w, const C
     SearchTop st;
     const int nt = two ? 2 : 1;
     search_top_shape(ntiles, nt, st.top256, st.gshift, st.tn);
-    st.in_lds = true;
     uint64_t* tw = smem;
     uint64_t* tc = tw + lds_pad(st.tn);
 #ifndef GPF_ABL_SEARCH_NOTABLE
@@ -880,7 +879,6 @@ __device__ __forceinline__ SearchTop search_prologue(const CdfLevels& w, const C
 #endif
     st.topw = tw;
     st.topc = tc;
-    st.mask_top = false;
     st.steps = 0;
     while (((int64_t)1 << st.steps) <= st.tn) ++st.steps;
     return st;
@@ -903,8 +901,7 @@ __device__ __forceinline__ void search_pair(const SearchTop& st, const CdfLevels
         for (int u = 0; u < 2; ++u) {
             const int64_t np = pos[u] + ((int64_t)1 << s);
             if (np <= st.tn) {
-                uint64_t v = top[u][st.in_lds ? lds_pad(np - 1) : np - 1];
-                if (st.mask_top) v &= DESC_MASK;
+                const uint64_t v = top[u][lds_pad(np - 1)];
                 if (v <= T[u]) pos[u] = np;
             }
         }

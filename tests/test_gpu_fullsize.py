@@ -114,8 +114,8 @@ def test_large_single_gpu_8e6_properties(g):
 
 
 def test_maximum_size_64e6_global_top_level(g):
-    """N = 2^26 on one GPU: the top level of the CDF (32768 tile prefixes) no longer fits the search kernel's LDS table, so the
-    search walks it in global memory; K = 36-bit weights.  Size-independent properties only."""
+    """N = 2^26 on one GPU: the 32768 tile prefixes no longer fit the search kernel's LDS table, so the top level becomes the
+    prefix of every 8th tile followed by one read of the group's 8 tile prefixes; K = 36-bit weights.  Size-independent properties only."""
     N = 1 << 26
     model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
     st = g.pf_initialize(model, (1,), ys[0], N, seed=11)
