@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_PER_GPU = 1_000_000
+AUX_STEPS = 30             # steps of the stand-alone gather leg and of the cpu_baseline sample
 SEED = 1
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -77,7 +78,10 @@ def main():
 
     model = g.models.lgssm2()
     K, Wm = args.steps, args.warmup
-    ys = g.models.simulate(model, K + Wm + 1)
+    # every leg below indexes observations by its own loop counter: never fewer rows than any leg touches
+    # (the gather and cpu_baseline legs run a fixed 30 steps whatever --steps says)
+    n_obs = max(K + Wm + 1, AUX_STEPS + 2)
+    ys = g.models.simulate(model, n_obs)
     n_local = args.particles_per_gpu
     n_global = n_local * world
 
@@ -179,7 +183,7 @@ def main():
         gbytes = (4 + 8 * W + 8 * W + 8) * n_local                # R anc, R row (random), W row, W lw = 16d + 12
         for meth, kw in (("multinomial", {}), ("stratified", {"sort_particles": False})):
             state.kernel_timing(g._lib.K_GATHER, True)
-            for i in range(30):
+            for i in range(AUX_STEPS):
                 g.pf_resample(state, meth, check=False, **kw)
                 g.get_ess(state)                                   # forces materialize() = the stand-alone k_gather
                 g.pf_update(state, (i + 2,), (None,), ys[1 + i])
@@ -197,7 +201,7 @@ def main():
 
         def step_s(tq):
             sharded.pf_resample(state, "stratified", check=False)
-            sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % K])
+            sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % (n_obs - 1)])
         for i in range(5):
             step_s(i)
         gc.collect(); gc.disable()
@@ -223,7 +227,7 @@ def main():
 
         def step_i(tq):
             sharded.pf_resample(state, "multinomial", check=False, local=True)
-            sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % K])
+            sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % (n_obs - 1)])
         for i in range(5):
             step_i(i)
         gc.collect(); gc.disable()
@@ -246,7 +250,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as o          # cpu_baseline leg: the only place bench.py touches oracle/
         o.lib()
-        n_cpu, k_cpu = n_local, 30
+        n_cpu, k_cpu = n_local, AUX_STEPS
         orc = o.OracleFilter(model.model_id, model.params, n_cpu, SEED).initialize(ys[0])
         c0 = time.perf_counter()
         for s in range(1, k_cpu + 1):

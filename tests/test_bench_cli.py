@@ -1,0 +1,109 @@
+"""bench.py's command line, on the CPU: main() runs against a stand-in for `gpf_amd` (same host interface, the
+oracle underneath, fake kernel timers) with the driver's own flags and with degenerate ones, and must print exactly
+ONE JSON line carrying `roofline` and `cpu_baseline`.  Round 1's bench indexed observations past the end whenever
+--steps + --warmup < 30 (the gather and cpu_baseline legs run a fixed number of steps); this keeps that from coming back.
+The real library path of the same command is covered by tests/test_gpu_bench_cli.py on the GPU box."""
+import importlib
+import io
+import json
+import sys
+import types
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+
+class _FakeState:
+    """What bench.py touches on a DeviceParticleFilterState."""
+
+    def __init__(self, o, model, obs, n, seed):
+        self.orc = o.OracleFilter(model.model_id, model.params, n, seed).initialize(obs)
+        self.row_width = model.row_width(False)
+        self._timing = {}
+        self._count = {}
+
+    def synchronize(self):
+        pass
+
+    def kernel_timing(self, kid, on):
+        self._timing[kid] = bool(on)
+        if on:
+            self._count[kid] = 0
+
+    def kernel_time(self, kid):
+        c = self._count.get(kid, 0)
+        return 0.02 * c, c                         # 20 us per launch
+
+    def _launched(self, *kids):
+        for k in kids:
+            if self._timing.get(k):
+                self._count[k] = self._count.get(k, 0) + 1
+
+
+def _install_stub(monkeypatch, o):
+    import gpf_amd as real
+    stub = types.ModuleType("gpf_amd")
+    stub.models, stub._lib = real.models, real._lib
+    L = real._lib
+
+    def pf_initialize(model, args, obs, n, seed=1, device=0):
+        return _FakeState(o, model, obs, n, seed)
+
+    def pf_resample(state, method="multinomial", check="warn", **kw):
+        state.orc.resample(method, check=False, **kw)
+        state._launched(L.K_SCAN, L.K_SEARCH)
+        state.pending = True
+
+    def pf_update(state, args, argdiffs, obs):
+        state.orc.update(np.asarray(obs, float))
+        state._launched(L.K_STEP)
+        state.pending = False
+
+    def get_ess(state):
+        if getattr(state, "pending", False):
+            state._launched(L.K_GATHER)
+            state.pending = False
+        return state.orc.effective_sample_size()
+
+    def get_lml_est(state):
+        return state.orc.log_ml_estimate()
+
+    for f in (pf_initialize, pf_resample, pf_update, get_ess, get_lml_est):
+        setattr(stub, f.__name__, f)
+    monkeypatch.setitem(sys.modules, "gpf_amd", stub)
+    import torch
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *_a, **_k: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *_a, **_k: None)
+
+
+@pytest.mark.parametrize("argv", [
+    ["--gpus", "1", "--steps", "20", "--warmup", "5"],          # the driver's command line (BENCH_r01 crashed on it)
+    ["--steps", "1", "--warmup", "0"],
+    ["--steps", "3", "--warmup", "40"],
+    ["--steps", "100", "--warmup", "2"],
+])
+def test_bench_main_prints_one_json_line(argv, o, built, monkeypatch):
+    _install_stub(monkeypatch, o)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPF_BENCH_FORCE_SHARDED", "GPF_BENCH_ONE_DEVICE"):
+        monkeypatch.delenv(k, raising=False)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--particles-per-gpu", "512"] + argv)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.main()
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    steps = int(argv[argv.index("--steps") + 1])
+    assert out["steps"] == steps and out["n_gpus"] == 1 and out["unit"] == "particle-steps/sec"
+    assert out["dtype"] == "f64" and out["higher_is_better"] is True and out["vs_baseline"] is None
+    assert "configs[1]" in out["config"]["workload"] and "model" not in out["config"]
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    r = out["roofline"]
+    assert r is not None and r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and "traffic" in r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = out["cpu_baseline"]
+    assert c is not None and c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["sample"]
+    assert set(out["resample_gather_kernel"]) == {"multinomial", "stratified"}
+    assert np.isfinite(out["log_ml_estimate"]) and np.isfinite(out["log_ml_abs_error"])
