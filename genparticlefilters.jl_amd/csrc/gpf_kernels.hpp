@@ -31,6 +31,9 @@ struct WSum {                  // summary of one weight vector
     int32_t  pad;
     uint64_t S;                // sum of fixed-point weights
     uint64_t Ql[4];            // 32-bit limbs sums of sum q^2 (un-normalised)
+    // strata of S over the filter's output slots, left by the scan that produced S: S = N sB + srem, sinv = N / S
+    uint64_t sB, srem;
+    double   sinv;
 };
 struct Scalars {
     WSum     prio;             // weights the resampler samples from (log_priorities)
@@ -482,6 +485,7 @@ struct ScanExtras {            // optional side jobs of a scan launch
     int64_t* zero128;          // clear 2 * MAX_SHARDS exchange counters (sharded resample), or nullptr
     int64_t* host_flags;       // pinned host {flags, ticket}: publish the validity flags of the weights, or nullptr
     int64_t ticket;
+    int64_t n_slots;           // > 0: also write ws_out->{sB, srem, sinv}, the strata of the total over n_slots slots
 };
 constexpr int SCAN_ROWS = 4;
 // MODE 0: plain scan of In; 1: fixed-point weights (folds the max partials); 2: as 1, plus sum q^2 for the ESS;
@@ -494,6 +498,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
                                                 uint64_t* __restrict__ total_out, uint64_t* __restrict__ blockQ,
                                                 int32_t* __restrict__ timeout, ScanExtras ex)
 {
+    // (ex.n_slots: the thread that ends up with the total also leaves the stratum width of S over n_slots output slots)
     // sharded resamples: the exchange counters of the push pass that follows are cleared here (no memset node)
     if (ex.zero128 && blockIdx.x == 0 && threadIdx.x < 2 * MAX_SHARDS) ex.zero128[threadIdx.x] = 0;
     __shared__ double sm[NWAVES];
@@ -580,7 +585,17 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
                 if (lane == WAVE - 1 && (k & 1)) out.t256[(idx + 1) >> 8] = v1;         // ... = 255 (mod 256)
             }
         }
-        if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) *total_out = off + p[2 * SCAN_ROWS - 1];
+        if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) {
+            const uint64_t Stot = off + p[2 * SCAN_ROWS - 1];
+            *total_out = Stot;
+            if constexpr (MODE >= 1) {
+                if (ex.n_slots > 0) {                   // one thread per launch: a true 64-bit division is fine here
+                    const uint64_t Bq = Stot / (uint64_t)ex.n_slots;
+                    ws_out->sB = Bq; ws_out->srem = Stot - Bq * (uint64_t)ex.n_slots;
+                    ws_out->sinv = (double)ex.n_slots / (double)Stot;
+                }
+            }
+        }
         __syncthreads();                                // s_wave / s_red reuse
     }
     if constexpr (WANT_Q) {
@@ -803,6 +818,7 @@ struct SearchArgs {
     int64_t n_cells;                                                  // particles the CDF ranges over (== n except when resizing)
     uint64_t seed; uint32_t epoch;
     int K; double logN;
+    double invN;                                                      // 1 / n_global (stratified)
     int update_lml;                                                   // 0 for sub-state views (resample.jl:185-187)
     int32_t* anc;
 };
@@ -976,19 +992,17 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
     // two slots per lane and iteration (independent dependency chains); the loop is wave-uniform
     for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < a.n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
         int64_t j[2]; bool act[2], head[2]; uint64_t T[2]; const uint64_t* top[2]; const CdfLevels* L[2];
+        // the lane's two CONSECUTIVE slots share one Philox block when their ids form an aligned pair (gfp_math.hpp
+        // resample_u64); RNG keyed by the global id; systematic sampling (METHOD 3) draws ONE uniform for all slots
+        const uint32_t s0 = (uint32_t)(a.gid0 + base + 2 * (int64_t)threadIdx.x);
+        const Philox pb0 = rng(a.seed, METHOD == 3 ? 0u : s0 >> 1, 0, a.epoch, TAG_RESAMPLE);
+        const Philox pb1 = (METHOD != 3 && (s0 & 1u)) ? rng(a.seed, (s0 >> 1) + 1u, 0, a.epoch, TAG_RESAMPLE) : pb0;   // kernel-uniform branch
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            j[u] = base + u * SBLOCK + threadIdx.x;
+            j[u] = base + 2 * (int64_t)threadIdx.x + u;
             act[u] = j[u] < a.n;
-            const uint64_t jl = (uint64_t)(act[u] ? j[u] : a.n - 1);   // slot index inside this filter / view
-            const uint64_t jg = jl;                                    // (k_search is never used on shards: slot == local index)
-#ifdef GPF_ABL_SEARCH_NOPHILOX
-            const uint64_t U = jg * 0x9E3779B97F4A7C15ull;
-#else
-            // RNG keyed by the global id; systematic sampling (METHOD 3) draws ONE uniform for all slots
-            const Philox b = rng(a.seed, METHOD == 3 ? 0u : (uint32_t)(a.gid0 + jl), 0, a.epoch, TAG_RESAMPLE);
-            const uint64_t U = u64(b.w0, b.w1);
-#endif
+            const uint64_t jg = (uint64_t)j[u];                        // slot index inside this filter / view (never used on shards)
+            const uint64_t U = METHOD == 3 ? u64(pb0.w0, pb0.w1) : resample_pick(u ? pb1 : pb0, s0 + (uint32_t)u);
             head[u] = false; top[u] = st.topw; L[u] = &a.w;
             if (METHOD == 0) T[u] = mulhi64(U, S);                    // multinomial, resample.jl:59
             else if (METHOD == 2) {                                   // stratified, resample.jl:159-168
@@ -1019,6 +1033,257 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
             if (METHOD == 2 && a.order) idx[u] = (int64_t)a.order[idx[u]];
             if (act[u]) a.anc[j[u]] = (int32_t)idx[u];
         }
+    }
+}
+
+// ----------------------------------------------------------------------------- K5b: stratified search = a streaming merge
+// Stratified targets are monotone in the slot index (resample.jl:159-168 walks strata and weights with two pointers).
+// A workgroup owns MJB consecutive slots; their targets lie in [L(j0), L(j0 + MJB)), i.e. in ONE contiguous range of CDF
+// cells, found with two cooperative 128-ary searches of the per-256 level.  The range is streamed (16 B per lane) and the
+// merge runs from the CELL side: cell i resolves every slot with a target below cdf[i], and that count is closed-form --
+// the stratum t that contains cdf[i] (one Float64 multiply, off by one at most) plus a look at the targets of the
+// neighbouring slots, kept in LDS.  The first slot NOT resolved by cells <= i belongs to a cell >= i + 1: an LDS max
+// of (i + 1) at that slot, then ONE inclusive max-scan over the slots yields every ancestor.  No per-slot search, no
+// dependent memory round trip per slot: 8 N bytes in, 4 N bytes out.
+constexpr int MBLOCK = 256;
+#ifndef GPF_MSLOTS
+#define GPF_MSLOTS 8
+#endif
+constexpr int MSLOTS = GPF_MSLOTS;                 // consecutive slots per lane (16-byte ancestor stores)
+constexpr int MJB = MBLOCK * MSLOTS;               // slots per workgroup
+constexpr int64_t MONO_WIDE = 16 * (int64_t)MJB;   // a cell range wider than this is searched per slot, not streamed
+
+// Block-cooperative: A0 / A1 = number of entries of arr[0..cnt) (ascending) that are <= L0 / <= L1 (L0 <= L1).
+// Fast path, ONE global round trip of one coalesced 8-byte load per thread: a 256-entry window around `guess` (for
+// exchangeable weights the CDF is close to linear, so the caller's guess is a few entries off at most); accepted only if the
+// window brackets both answers.  Otherwise 256-ary rounds over the whole array.  `between()` runs after the window's loads
+// have been issued and before their values are needed: the caller's ALU work hides the round trip.
+template <class Between>
+__device__ __forceinline__ void block_count_le_pair(const uint64_t* __restrict__ arr, int64_t cnt, int64_t guess, uint64_t L0, uint64_t L1,
+                                                    int (*s_cnt)[2][NWAVES], int64_t& A0, int64_t& A1, Between&& between)
+{
+    const int tid = (int)threadIdx.x;
+    const uint64_t Lq[2] = {L0, L1};
+    int par = 0;
+    {
+        int64_t w_lo = guess - MBLOCK / 2;
+        w_lo = w_lo + MBLOCK > cnt ? cnt - MBLOCK : w_lo;
+        w_lo = w_lo < 0 ? 0 : w_lo;
+        const int64_t w_hi = w_lo + MBLOCK < cnt ? w_lo + MBLOCK : cnt;
+        const uint64_t v = w_lo + tid < w_hi ? arr[w_lo + tid] : ~0ull;
+        between();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = (int)__popcll(__ballot(v <= Lq[q]));
+            if (lane_id() == 0) s_cnt[par][q][wave_id()] = c;
+        }
+        __syncthreads();
+        int64_t k0 = 0, k1 = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) { k0 += s_cnt[par][0][w]; k1 += s_cnt[par][1][w]; }
+        par ^= 1;
+        if ((k0 > 0 || w_lo == 0) && (k1 < w_hi - w_lo || w_hi == cnt)) { A0 = w_lo + k0; A1 = w_lo + k1; return; }   // block-uniform
+    }
+    int64_t lo[2] = {0, 0}, hi[2] = {cnt, cnt};    // invariant: lo <= answer <= hi
+    while (hi[0] > lo[0] || hi[1] > lo[1]) {       // block-uniform
+        int64_t step[2]; uint64_t v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t len = hi[q] - lo[q];
+            step[q] = len <= MBLOCK ? 1 : (len + MBLOCK - 1) / MBLOCK;
+            const int64_t p = lo[q] + (int64_t)(tid + 1) * step[q] - 1;
+            v[q] = p < hi[q] ? arr[p] : ~0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = (int)__popcll(__ballot(v[q] <= Lq[q]));
+            if (lane_id() == 0) s_cnt[par][q][wave_id()] = c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (hi[q] > lo[q]) {
+                int64_t k = 0;
+#pragma unroll
+                for (int w = 0; w < NWAVES; ++w) k += s_cnt[par][q][w];
+                const int64_t nlo = lo[q] + k * step[q];
+                const int64_t cap = step[q] == 1 ? nlo : nlo + step[q] - 1;        // the first probe that failed bounds the answer
+                hi[q] = cap < hi[q] ? cap : hi[q];
+                lo[q] = nlo;
+            }
+        }
+        par ^= 1;
+    }
+    A0 = lo[0]; A1 = lo[1];
+}
+
+// (4 waves per SIMD = 4 workgroups per CU: a 10^6-slot launch is ONE resident round of workgroups)
+__global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
+{
+    static_assert(MSLOTS % 4 == 0, "ancestors leave the lane as 16-byte stores");
+    __shared__ __attribute__((aligned(16))) uint64_t s_T[MJB + 4];   // targets of the block's slots (+inf beyond n, and as padding)
+    __shared__ __attribute__((aligned(16))) uint32_t s_mark[MJB];
+    __shared__ int s_cnt[2][2][NWAVES];
+    __shared__ uint32_t s_wmax[NWAVES];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
+    // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
+    if (a.update_lml && blockIdx.x == 0 && tid == 0)
+        a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
+    const uint64_t N = (uint64_t)a.n_global;
+    const double invN = a.invN;
+    // S = N B + rem; stratum j is [L(j), L(j+1)), L(j) = j B + floor(j rem / N)   (DESIGN.md §3.3); B, rem and N / S
+    // were left beside S by the scan that produced it
+    const uint64_t B = a.ws->sB, rem = a.ws->srem;
+    const int64_t j0 = (int64_t)blockIdx.x * MJB;
+    const uint64_t q0 = div_small((uint64_t)j0 * rem, N, invN), r0 = (uint64_t)j0 * rem - q0 * N;
+    const uint64_t Lj0 = (uint64_t)j0 * B + q0;
+    const uint64_t Lj1 = Lj0 + (uint64_t)MJB * B + div_small(r0 + (uint64_t)MJB * rem, N, invN);
+    // ---- the CDF cells the block's targets can fall into, at per-256 granularity (two 128-ary searches of the per-256
+    //      level), with the block's targets computed while the probes are in flight: MSLOTS consecutive slots per lane,
+    //      one Philox block per aligned slot pair (gpf_math.hpp resample_u64; one more block when the run starts odd),
+    //      strata boundaries by running remainder (no division per slot)
+    constexpr int NPB = MSLOTS / 2;
+    const uint64_t t0 = (uint64_t)(MSLOTS * tid);
+    const uint32_t s0 = (uint32_t)(a.gid0 + j0 + (int64_t)t0), sb = s0 >> 1;
+    const bool odd = (s0 & 1u) != 0;                   // kernel-uniform
+    const int64_t n256 = a.ntiles * 8;
+    int64_t A0, A1;
+    // (the guess: were the weights equal, slot j0's target would fall into cell j0 n_cells / N)
+    const int64_t guess = (int64_t)((double)j0 * ((double)a.n_cells * invN)) >> 8;
+    block_count_le_pair(a.w.t256, n256, guess, Lj0, Lj1 - 1, s_cnt, A0, A1, [&]() {
+        uint64_t U[MSLOTS];
+        if (!odd) {
+#pragma unroll
+            for (int q = 0; q < NPB; ++q) {
+                const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
+                U[2 * q] = u64(b.w0, b.w1); U[2 * q + 1] = u64(b.w2, b.w3);
+            }
+        } else {                                       // the run starts on the odd half of a block: one block more
+#pragma unroll
+            for (int q = 0; q <= NPB; ++q) {
+                const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
+                if (q > 0) U[2 * q - 1] = u64(b.w0, b.w1);
+                if (q < NPB) U[2 * q] = u64(b.w2, b.w3);
+            }
+        }
+        const uint64_t x = r0 + t0 * rem, qq = div_small(x, N, invN);
+        uint64_t rr = x - qq * N, L = Lj0 + t0 * B + qq;
+        uint64_t T[MSLOTS];
+#pragma unroll
+        for (int k = 0; k < MSLOTS; ++k) {
+            const int64_t j = j0 + (int64_t)t0 + k;
+            const uint64_t r2 = rr + rem;
+            const bool carry = r2 >= N;
+            const uint64_t Ln = L + B + (carry ? 1 : 0);
+            rr = carry ? r2 - N : r2;
+            T[k] = j < a.n ? L + mulhi64(U[k], Ln - L) : ~0ull;                         // resample.jl:162
+            L = Ln;
+        }
+#pragma unroll
+        for (int k = 0; k < MSLOTS; k += 2) *reinterpret_cast<ulonglong2*>(s_T + MSLOTS * tid + k) = make_ulonglong2(T[k], T[k + 1]);
+        if (tid < 4) s_T[MJB + tid] = ~0ull;
+#pragma unroll
+        for (int k = 0; k < MSLOTS; k += 4) *reinterpret_cast<uint4*>(s_mark + MSLOTS * tid + k) = make_uint4(0u, 0u, 0u, 0u);
+    });
+    const int64_t g_lo = A0 < n256 ? A0 : n256 - 1, g_hi = A1 < n256 ? A1 : n256 - 1;
+    const int64_t i_start = g_lo * 256, i_end = g_hi * 256 + 256;
+    if (tid == 0) s_mark[0] = (uint32_t)i_start;
+    __syncthreads();
+    uint32_t res[MSLOTS];
+    if (i_end - i_start <= MONO_WIDE) {
+        // ---- stream the cells; cell i resolves e = #{slots of the block with a target < cdf[i]} slots
+        const double inv_step = a.ws->sinv;
+        const uint64_t* cbase = a.w.cdf + i_start;
+        const uint32_t ncell = (uint32_t)(i_end - i_start), ibase = (uint32_t)i_start + 1u;
+        constexpr int CPF = 6;                                            // 16-byte loads in flight per lane: 3072 cells per sweep
+        for (uint32_t i0 = 0; i0 < ncell; i0 += 2u * MBLOCK * CPF) {
+            ulonglong2 cc[CPF];
+#pragma unroll
+            for (int r = 0; r < CPF; ++r) {
+                const uint32_t i = i0 + 2u * MBLOCK * r + 2u * (uint32_t)tid;
+                cc[r] = i < ncell ? *reinterpret_cast<const ulonglong2*>(cbase + i) : make_ulonglong2(~0ull, ~0ull);
+            }
+#pragma unroll
+            for (int r = 0; r < CPF; ++r) {
+                const uint32_t i = i0 + 2u * MBLOCK * r + 2u * (uint32_t)tid;
+                if (i0 + 2u * MBLOCK * r >= ncell) break;                 // block-uniform
+                // cells at or below L(j0) resolve nothing: only the LAST of them (cells ascend) bounds slot 0
+                const uint64_t below = __ballot(cc[r].y <= Lj0);
+                if (cc[r].y <= Lj0) {
+                    if (lane == (int)__popcll(below) - 1) atomicMax(&s_mark[0], ibase + i + 1u);
+                    continue;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint64_t c = u ? cc[r].y : cc[r].x;
+                    if (c >= Lj1) continue;                               // every slot of the block is resolved by then
+                    uint32_t e = 0;
+                    if (c > Lj0) {
+                        // c lies in stratum t of the block, t within [te - 1, te + 2] (L(j) = L(j0) + t step +- 1, step >= 1)
+                        const int te = (int)((double)(c - Lj0) * inv_step);
+                        const int b = te > 0 ? (te < MJB ? te - 1 : MJB - 1) : 0;
+                        e = (uint32_t)b + (s_T[b] < c) + (s_T[b + 1] < c) + (s_T[b + 2] < c) + (s_T[b + 3] < c);
+                    }
+                    atomicMax(&s_mark[e], ibase + i + (uint32_t)u);       // slot e belongs to a cell >= i + 1
+                }
+            }
+        }
+        __syncthreads();
+        // ---- inclusive max-scan over the slots
+#pragma unroll
+        for (int k = 0; k < MSLOTS; k += 4) {
+            const uint4 m = *reinterpret_cast<const uint4*>(s_mark + MSLOTS * tid + k);
+            res[k] = m.x; res[k + 1] = m.y; res[k + 2] = m.z; res[k + 3] = m.w;
+        }
+#pragma unroll
+        for (int k = 1; k < MSLOTS; ++k) res[k] = res[k] > res[k - 1] ? res[k] : res[k - 1];
+        uint32_t inc = res[MSLOTS - 1];
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(inc, d, WAVE); if (lane >= d) inc = o > inc ? o : inc; }
+        if (lane == WAVE - 1) s_wmax[wv] = inc;
+        uint32_t pre = __shfl_up(inc, 1, WAVE);
+        if (lane == 0) pre = 0;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) if (w < wv) pre = s_wmax[w] > pre ? s_wmax[w] : pre;
+#pragma unroll
+        for (int k = 0; k < MSLOTS; ++k) res[k] = res[k] > pre ? res[k] : pre;
+    } else {
+        // ---- a few slots over very many cells (e.g. the light tail of a sorted order): per-slot search of the range
+        //      (rolled loop over the lane's slots, targets and results through LDS: keeps the streaming path's registers)
+        const int64_t n16 = a.ntiles * (TILE / 16);
+#pragma unroll 1
+        for (int k = 0; k < MSLOTS; ++k) {
+            const uint64_t Tk = s_T[MSLOTS * tid + k];
+            int64_t lo = g_lo, hi = g_hi;                                 // the per-256 group of the answer is in [lo, hi]
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.w.t256[mid] <= Tk) lo = mid + 1; else hi = mid; }
+            int64_t s16 = lo * 16 + count_le_line(a.w.t16 + lo * 16, Tk);
+            s16 = s16 < n16 ? s16 : n16 - 1;
+            s_mark[MSLOTS * tid + k] = (uint32_t)(s16 * 16 + count_le_line(a.w.cdf + s16 * 16, Tk));
+        }
+#pragma unroll
+        for (int k = 0; k < MSLOTS; k += 4) {
+            const uint4 m = *reinterpret_cast<const uint4*>(s_mark + MSLOTS * tid + k);
+            res[k] = m.x; res[k + 1] = m.y; res[k + 2] = m.z; res[k + 3] = m.w;
+        }
+    }
+    // ---- parents[j] = order[i_old]   (resample.jl:168)
+    const int64_t jb = j0 + MSLOTS * tid;
+    int32_t out[MSLOTS];
+    const uint32_t last = (uint32_t)(a.n_cells - 1);
+#pragma unroll
+    for (int k = 0; k < MSLOTS; ++k) {
+        uint32_t idx = res[k] < last ? res[k] : last;
+        if (a.order && jb + k < a.n) idx = (uint32_t)a.order[idx];
+        out[k] = (int32_t)idx;
+    }
+    int32_t* dst = a.anc + jb;
+    if (jb + MSLOTS <= a.n && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < MSLOTS; k += 4) *reinterpret_cast<int4*>(dst + k) = make_int4(out[k], out[k + 1], out[k + 2], out[k + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < MSLOTS; ++k) if (jb + k < a.n) dst[k] = out[k];
     }
 }
 
@@ -1248,8 +1513,7 @@ __device__ __forceinline__ PushScal push_scalars(const PushArgs& a, const PushTa
 template <int METHOD>
 __device__ __forceinline__ void push_target(const PushArgs& a, const PushScal& s, uint64_t jg, uint64_t& T, int& space)
 {
-    const Philox b = rng(a.seed, (uint32_t)jg, 0, a.epoch, TAG_RESAMPLE);
-    const uint64_t U = u64(b.w0, b.w1);
+    const uint64_t U = resample_u64(a.seed, (uint32_t)jg, a.epoch);
     const uint64_t N = (uint64_t)a.n_global;
     space = 0;
     if (METHOD == 0) T = mulhi64(U, s.Sw);

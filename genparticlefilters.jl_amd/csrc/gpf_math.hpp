@@ -80,6 +80,13 @@ GPF_HD double u52(uint32_t hi, uint32_t lo)
     return ((double)k + 0.5) * 0x1p-52;
 }
 GPF_HD uint64_t u64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
+// The resample stream: ONE Philox block serves TWO output slots -- slot id s reads block s >> 1, words (0,1) when s is
+// even, (2,3) when odd.  Every slot keeps its own 64-bit uniform, indexed by the slot id alone.
+GPF_HD uint64_t resample_pick(const Philox& b, uint32_t slot) { return (slot & 1u) ? u64(b.w2, b.w3) : u64(b.w0, b.w1); }
+GPF_HD uint64_t resample_u64(uint64_t seed, uint32_t slot, uint32_t epoch)
+{
+    return resample_pick(rng(seed, slot >> 1, 0, epoch, TAG_RESAMPLE), slot);
+}
 
 // ------------------------------------------------------------------ log (positive normal x)
 GPF_HD double log_(double x)

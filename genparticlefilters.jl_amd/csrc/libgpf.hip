@@ -394,7 +394,7 @@ int scan_grid(const gpf_filter* h) { return (int)std::max<int64_t>(1, std::min<i
 // one scan launch on descriptor channel `ch` (0 weights, 1 residual counts, 2 residual weights)
 template <class In, int FIXQ>
 gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, bool want_cdf, uint64_t* total_out,
-                       const double* mf_all = nullptr, ScanExtras ex = ScanExtras{nullptr, nullptr, 0})
+                       const double* mf_all = nullptr, ScanExtras ex = ScanExtras{nullptr, nullptr, 0, 0})
 {
     const double* pmax = mf_all ? mf_all : h->pmax;
     uint64_t* dc = h->desc[ch][h->dcur[ch]];
@@ -415,7 +415,7 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
 gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cdf, const int32_t* order, bool use_producer_max,
                      bool want_q = false, bool publish_flags = false)
 {
-    ScanExtras ex{nullptr, nullptr, 0};
+    ScanExtras ex{nullptr, nullptr, 0, h->cfg.n_global};
     if (publish_flags) {
         if (!h->h_flags) { HIP_TRY(h, hipHostMalloc(&h->h_flags, 2 * sizeof(int64_t))); h->h_flags[0] = h->h_flags[1] = 0; }
         h->flag_ticket += 1;
@@ -650,7 +650,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     sa.w = levels(h, 0); sa.c = levels(h, 0); sa.ntiles = h->ntiles;
     sa.order = sorted ? h->order : nullptr; sa.sc = h->sc; sa.ws = ws; sa.raw = &h->sc->raw; sa.n = h->n; sa.n_cells = h->n;
     sa.n_global = h->cfg.n_global; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
-    sa.K = h->K; sa.logN = h->logN; sa.anc = h->anc;
+    sa.K = h->K; sa.logN = h->logN; sa.anc = h->anc; sa.invN = 1.0 / (double)h->cfg.n_global;
     sa.update_lml = h->parent ? 0 : 1;                           // sub-states do not track the estimate (resample.jl:185-187)
 
     if (method == GPF_RESAMPLE_RESIDUAL) {
@@ -666,7 +666,8 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         switch (method) {
             case GPF_RESAMPLE_MULTINOMIAL: GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
             case GPF_RESAMPLE_RESIDUAL:    GPF_LAUNCH((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
-            default:                       GPF_LAUNCH((k_search<2>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
+            default:                       // monotone targets: a streaming merge, MJB slots per workgroup
+                GPF_LAUNCH(k_search_strat, dim3((unsigned)((h->n + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa); break;
         }
     });
     if (s) return s;
@@ -1589,10 +1590,10 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     if (!h->h_flags) { HIP_TRY(h, hipHostMalloc(&h->h_flags, 2 * sizeof(int64_t))); h->h_flags[0] = h->h_flags[1] = 0; }
     h->flag_ticket += 1;
     if (want_q) {
-        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, h->h_flags, h->flag_ticket}))) return s;
+        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, h->h_flags, h->flag_ticket, 0}))) return s;
         GPF_LAUNCH(k_export_q, dim3(1), dim3(BLOCK), 0, h->stream, h->blockQ, gs, out5);
     } else {
-        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, h->h_flags, h->flag_ticket}))) return s;
+        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, h->h_flags, h->flag_ticket, 0}))) return s;
     }
     HIP_TRY(h, hipGetLastError());
     h->raw_valid = false;            // sc->raw holds the GLOBAL max but no sum: not the unsharded summary

@@ -71,6 +71,12 @@ O_EXPORT double o_u52_d(uint64_t seed, uint32_t gid, uint32_t blk, uint32_t epoc
     o_philox_t b = o_rng(seed, gid, blk, epoch, tag);
     return o_u52(b.v[0], b.v[1]);
 }
+/* the resample uniform of output slot `slot` as a 52-bit Float64 (top 52 of the 64 bits the spec uses) */
+O_EXPORT double o_resample_u52_d(uint64_t seed, uint32_t slot, uint32_t epoch)
+{
+    const uint64_t U = o_resample_u64(seed, slot, epoch);
+    return o_u52((uint32_t)(U >> 32), (uint32_t)U);
+}
 
 /* vectorised math, for the bitwise product-vs-oracle math tests */
 O_EXPORT void o_math_vec(int which, const double *a, const double *b, int64_t n, double *out, double *out2)
@@ -446,14 +452,13 @@ O_EXPORT uint64_t o_scan(const uint64_t *q, int64_t n, uint64_t *cdf, uint64_t *
 
 /* ------------------------------------------------------------------ ancestor targets */
 /* multinomial (resample.jl:59): slot j draws T = floor(U_j * S / 2^64), U_j the 64-bit uniform of
- * counter (j, 0, epoch, RESAMPLE); ancestor = the particle whose CDF cell [cdf[a-1], cdf[a]) holds T */
+ * slot j of the resample stream (o_resample_u64: block j >> 1, word pair j & 1); ancestor = the particle whose CDF cell [cdf[a-1], cdf[a]) holds T */
 O_EXPORT void o_targets_multinomial(uint64_t seed, uint32_t epoch, int64_t j0, int64_t n, uint64_t S,
                                     uint64_t *T)
 {
     #pragma omp parallel for schedule(static)
     for (int64_t j = 0; j < n; ++j) {
-        o_philox_t b = o_rng(seed, (uint32_t)(j0 + j), 0, epoch, O_TAG_RESAMPLE);
-        T[j] = o_mulhi64(o_u64(b.v[0], b.v[1]), S);
+        T[j] = o_mulhi64(o_resample_u64(seed, (uint32_t)(j0 + j), epoch), S);
     }
 }
 /* stratified (resample.jl:159-167): stratum j = [L_j, L_{j+1}), L_j = floor(j*S/N) computed exactly as
@@ -468,8 +473,7 @@ O_EXPORT void o_targets_stratified(uint64_t seed, uint32_t epoch, int64_t j0, in
         uint64_t jg = (uint64_t)(j0 + j);
         uint64_t L0 = jg * B + (jg * rem) / (uint64_t)N;
         uint64_t L1 = (jg + 1) * B + ((jg + 1) * rem) / (uint64_t)N;
-        o_philox_t b = o_rng(seed, (uint32_t)jg, 0, epoch, O_TAG_RESAMPLE);
-        T[j] = L0 + o_mulhi64(o_u64(b.v[0], b.v[1]), L1 - L0);
+        T[j] = L0 + o_mulhi64(o_resample_u64(seed, (uint32_t)jg, epoch), L1 - L0);
     }
 }
 /* sub-state views: strata are LOCAL to the view (index j of n), the RNG counter keeps the global particle id gid0 + j */
@@ -480,8 +484,7 @@ O_EXPORT void o_targets_stratified_view(uint64_t seed, uint32_t epoch, int64_t g
         uint64_t jl = (uint64_t)j;
         uint64_t L0 = jl * B + (jl * rem) / (uint64_t)n;
         uint64_t L1 = (jl + 1) * B + ((jl + 1) * rem) / (uint64_t)n;
-        o_philox_t b = o_rng(seed, (uint32_t)(gid0 + j), 0, epoch, O_TAG_RESAMPLE);
-        T[j] = L0 + o_mulhi64(o_u64(b.v[0], b.v[1]), L1 - L0);
+        T[j] = L0 + o_mulhi64(o_resample_u64(seed, (uint32_t)(gid0 + j), epoch), L1 - L0);
     }
 }
 /* first index a with cdf[a] > T  (== the while loop of resample.jl:163-166 / inverse-CDF categorical) */

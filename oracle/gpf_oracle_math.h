@@ -74,6 +74,14 @@ static inline double o_u52(uint32_t hi, uint32_t lo)
 }
 static inline uint64_t o_u64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
 static inline uint64_t o_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((o_u128)a * b) >> 64); }
+/* The resample stream (tag RESAMPLE): ONE Philox block serves TWO output slots -- slot id s reads block s >> 1,
+ * words (0,1) when s is even and words (2,3) when it is odd.  Each slot still has its own
+ * independent 64-bit uniform, indexed by the slot id alone. */
+static inline uint64_t o_resample_u64(uint64_t seed, uint32_t slot, uint32_t epoch)
+{
+    o_philox_t b = o_rng(seed, slot >> 1, 0, epoch, O_TAG_RESAMPLE);
+    return (slot & 1u) ? o_u64(b.v[2], b.v[3]) : o_u64(b.v[0], b.v[1]);
+}
 
 /* ---------------------------------------------------------------- log */
 /* natural log of a positive, finite, NORMAL double (callers never pass subnormals).

@@ -61,7 +61,7 @@ def test_spec_equals_literal_float64(g, o, lw, seed):
     L = o.lib()
     w = np.empty(N)
     assert L.lit_safe_softmax(lw, N, w) == 0
-    u = np.array([L.o_u52_d(seed, j, 0, 0, 3) for j in range(N)])
+    u = np.array([L.o_resample_u52_d(seed, j, 0) for j in range(N)])
     f = make(g, o, lw, seed)
     f.resample("multinomial")
     par = np.empty(N, np.int64); L.lit_multinomial(w, N, u, par)

@@ -6,7 +6,7 @@ import pytest
 
 def uniforms(o, seed, epoch, n, j0=0):
     """U52 of the resample stream (tag 3) for slots j0..j0+n-1: top 52 bits of the 64-bit U the spec uses."""
-    return np.array([o.lib().o_u52_d(seed, j0 + j, 0, epoch, 3) for j in range(n)])
+    return np.array([o.lib().o_resample_u52_d(seed, j0 + j, epoch) for j in range(n)])
 
 
 @pytest.mark.parametrize("N", [10, 100, 1000])
