@@ -116,6 +116,21 @@ __device__ __forceinline__ uint64_t wave_scan_u64(uint64_t v)
     return v;
 }
 
+// inclusive max-scan of a u32 across the 64 lanes, by DPP (no LDS crossbar round trips): Hillis-Steele inside each row of
+// 16, then the row totals travel with row_bcast15 / row_bcast31.  Lanes without a source read the identity 0.
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v)
+{
+#define GPF_DPP_MAX(ctrl, rmask) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, false); v = o_ > v ? o_ : v; }
+    GPF_DPP_MAX(0x111, 0xF)   // row_shr:1
+    GPF_DPP_MAX(0x112, 0xF)   // row_shr:2
+    GPF_DPP_MAX(0x114, 0xF)   // row_shr:4
+    GPF_DPP_MAX(0x118, 0xF)   // row_shr:8
+    GPF_DPP_MAX(0x142, 0xA)   // row_bcast:15 -> rows 1, 3
+    GPF_DPP_MAX(0x143, 0xC)   // row_bcast:31 -> rows 2, 3
+#undef GPF_DPP_MAX
+    return v;
+}
+
 // ----------------------------------------------------------------------------- K1/K2: init & step
 // per-block (max, flags) of the log-weights a kernel has just written: the first pass of safe_softmax
 // (utils.jl:119-128) rides on the kernel that produces the weights instead of re-reading them
@@ -1057,13 +1072,14 @@ constexpr int64_t MONO_WIDE = 16 * (int64_t)MJB;   // a cell range wider than th
 // Fast path, ONE global round trip of one coalesced 8-byte load per thread: a 256-entry window around `guess` (for
 // exchangeable weights the CDF is close to linear, so the caller's guess is a few entries off at most); accepted only if the
 // window brackets both answers.  Otherwise 256-ary rounds over the whole array.  `between()` runs after the window's loads
-// have been issued and before their values are needed: the caller's ALU work hides the round trip.
+// have been issued and before their values are needed -- it also produces the two bounds (L0, L1), so that whatever THEY
+// wait for (device scalars) and the caller's ALU work hide the round trip.
 template <class Between>
-__device__ __forceinline__ void block_count_le_pair(const uint64_t* __restrict__ arr, int64_t cnt, int64_t guess, uint64_t L0, uint64_t L1,
+__device__ __forceinline__ void block_count_le_pair(const uint64_t* __restrict__ arr, int64_t cnt, int64_t guess,
                                                     int (*s_cnt)[2][NWAVES], int64_t& A0, int64_t& A1, Between&& between)
 {
     const int tid = (int)threadIdx.x;
-    const uint64_t Lq[2] = {L0, L1};
+    uint64_t Lq[2];
     int par = 0;
     {
         int64_t w_lo = guess - MBLOCK / 2;
@@ -1071,7 +1087,7 @@ __device__ __forceinline__ void block_count_le_pair(const uint64_t* __restrict__
         w_lo = w_lo < 0 ? 0 : w_lo;
         const int64_t w_hi = w_lo + MBLOCK < cnt ? w_lo + MBLOCK : cnt;
         const uint64_t v = w_lo + tid < w_hi ? arr[w_lo + tid] : ~0ull;
-        between();
+        between(Lq[0], Lq[1]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = (int)__popcll(__ballot(v <= Lq[q]));
@@ -1131,14 +1147,8 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
         a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
     const uint64_t N = (uint64_t)a.n_global;
     const double invN = a.invN;
-    // S = N B + rem; stratum j is [L(j), L(j+1)), L(j) = j B + floor(j rem / N)   (DESIGN.md §3.3); B, rem and N / S
-    // were left beside S by the scan that produced it
-    const uint64_t B = a.ws->sB, rem = a.ws->srem;
     const int64_t j0 = (int64_t)blockIdx.x * MJB;
-    const uint64_t q0 = div_small((uint64_t)j0 * rem, N, invN), r0 = (uint64_t)j0 * rem - q0 * N;
-    const uint64_t Lj0 = (uint64_t)j0 * B + q0;
-    const uint64_t Lj1 = Lj0 + (uint64_t)MJB * B + div_small(r0 + (uint64_t)MJB * rem, N, invN);
-    // ---- the CDF cells the block's targets can fall into, at per-256 granularity (two 128-ary searches of the per-256
+    // ---- the CDF cells the block's targets can fall into, at per-256 granularity (block_count_le_pair on the per-256
     //      level), with the block's targets computed while the probes are in flight: MSLOTS consecutive slots per lane,
     //      one Philox block per aligned slot pair (gpf_math.hpp resample_u64; one more block when the run starts odd),
     //      strata boundaries by running remainder (no division per slot)
@@ -1148,9 +1158,17 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
     const bool odd = (s0 & 1u) != 0;                   // kernel-uniform
     const int64_t n256 = a.ntiles * 8;
     int64_t A0, A1;
+    uint64_t Lj0, Lj1;
     // (the guess: were the weights equal, slot j0's target would fall into cell j0 n_cells / N)
     const int64_t guess = (int64_t)((double)j0 * ((double)a.n_cells * invN)) >> 8;
-    block_count_le_pair(a.w.t256, n256, guess, Lj0, Lj1 - 1, s_cnt, A0, A1, [&]() {
+    block_count_le_pair(a.w.t256, n256, guess, s_cnt, A0, A1, [&](uint64_t& L0, uint64_t& L1) {
+        // S = N B + rem; stratum j is [L(j), L(j+1)), L(j) = j B + floor(j rem / N)   (DESIGN.md §3.3); B, rem and N / S
+        // were left beside S by the scan that produced it
+        const uint64_t B = a.ws->sB, rem = a.ws->srem;
+        const uint64_t q0 = div_small((uint64_t)j0 * rem, N, invN), r0 = (uint64_t)j0 * rem - q0 * N;
+        Lj0 = (uint64_t)j0 * B + q0;
+        Lj1 = Lj0 + (uint64_t)MJB * B + div_small(r0 + (uint64_t)MJB * rem, N, invN);
+        L0 = Lj0; L1 = Lj1 - 1;
         uint64_t U[MSLOTS];
         if (!odd) {
 #pragma unroll
@@ -1237,12 +1255,9 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
         }
 #pragma unroll
         for (int k = 1; k < MSLOTS; ++k) res[k] = res[k] > res[k - 1] ? res[k] : res[k - 1];
-        uint32_t inc = res[MSLOTS - 1];
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(inc, d, WAVE); if (lane >= d) inc = o > inc ? o : inc; }
+        const uint32_t inc = wave_scan_max_u32(res[MSLOTS - 1]);
         if (lane == WAVE - 1) s_wmax[wv] = inc;
-        uint32_t pre = __shfl_up(inc, 1, WAVE);
-        if (lane == 0) pre = 0;
+        uint32_t pre = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 reads 0)
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) if (w < wv) pre = s_wmax[w] > pre ? s_wmax[w] : pre;
