@@ -491,7 +491,22 @@ struct ScanOut {
     uint64_t* cdf;             // [ntiles*2048] inclusive prefix of every element (nullptr: totals only)
     uint64_t* t16;             // [ntiles*128]  inclusive prefix at the end of every 16-element group (one 128-B line of cdf)
     uint64_t* t256;            // [ntiles*8]    ... of every 256-element group (one 128-B line of t16)
+    uint32_t* k32;             // [ntiles*64]   (prefix at the end of every 32-element group) >> KEY_SHIFT: the 4-byte keys k_search_multi keeps in LDS
+    // k_search_multi's two narrow levels below a key group of G = 32 << logg cells (nullptr / -1: not wanted):
+    uint16_t* off16;           // [ntiles*2048] every prefix as a 16-bit offset inside its key group (key_quant)
+    uint16_t* coarse;          // [ntiles*2048 / CS] the offsets of cells CS-1 (mod CS), CS = G / 8: one 16-byte row per key group
+    int logg;
 };
+constexpr int KEY_SHIFT = 30;  // S < 2^62, so (prefix >> 30) fits 32 bits whatever N is
+// A key group spans the prefixes [klo << 30, (khi + 1) << 30) (klo / khi: the 4-byte keys at its two ends).  Inside it a
+// prefix -- and a target -- is quantised to 16 bits by ONE shift: x -> (x - (klo << 30)) >> sh, sh = 14 + ceil(log2(khi - klo + 1)).
+// The map is monotone and the SAME on the producer (scan) and consumer (search) side, so
+//     off(cell) < off(T) => prefix < T,   off(cell) > off(T) => prefix > T,   equal offsets: the exact prefixes decide.
+__device__ __forceinline__ int key_quant_shift(uint32_t klo, uint32_t khi)
+{
+    const uint64_t w = (uint64_t)khi - klo + 1;
+    return (KEY_SHIFT - 16) + (w > 1 ? 64 - (int)__builtin_clzll(w - 1) : 0);
+}
 
 // Arrangement: wave w of the workgroup owns 512 consecutive elements of the tile as 4 rows of 128;
 // lane l holds elements 2l, 2l+1 of each row, so every global access is 16 B per lane, contiguous
@@ -552,10 +567,12 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t wbase = tile * TILE + (int64_t)wv * (SCAN_ROWS * 2 * WAVE) + 2 * lane;
         uint64_t p[2 * SCAN_ROWS];                     // inclusive prefixes inside the wave's 512-element chunk
+        uint64_t cb[SCAN_ROWS];                        // the chunk's total before each row
         uint64_t carry = 0;
 #pragma unroll
         for (int k = 0; k < SCAN_ROWS; ++k) {
             uint64_t q0, q1;
+            cb[k] = carry;
             in.load2(wbase + k * 2 * WAVE, n, q0, q1);
             if constexpr (WANT_Q) {
                 uint64_t lo = q0 * q0, hi = __umul64hi(q0, q0);
@@ -597,7 +614,28 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
                 const uint64_t v1 = off + p[2 * k + 1];
                 *reinterpret_cast<ulonglong2*>(out.cdf + idx) = make_ulonglong2(off + p[2 * k], v1);
                 if ((lane & 7) == 7) out.t16[(idx + 1) >> 4] = v1;                     // element idx+1 = 15 (mod 16)
+                if ((lane & 15) == 15) out.k32[(idx + 1) >> 5] = (uint32_t)(v1 >> KEY_SHIFT);   // ... = 31 (mod 32)
                 if (lane == WAVE - 1 && (k & 1)) out.t256[(idx + 1) >> 8] = v1;         // ... = 255 (mod 256)
+                if (out.off16) {                                                        // kernel-uniform
+                    // 16-bit offsets inside the key group (16 << logg lanes of this row): klo = key of the previous group
+                    const int GL = 16 << out.logg;
+                    const uint32_t kv = (uint32_t)(v1 >> KEY_SHIFT);
+                    const uint32_t khi = (uint32_t)__shfl((int)kv, lane | (GL - 1), WAVE);
+                    const uint32_t kprev = (uint32_t)__shfl((int)kv, ((lane & ~(GL - 1)) - 1) & (WAVE - 1), WAVE);
+                    const uint32_t klo = lane < GL ? (uint32_t)((off + cb[k]) >> KEY_SHIFT) : kprev;
+                    const int sh = key_quant_shift(klo, khi);
+                    const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
+                    const uint32_t o0 = (uint32_t)((off + p[2 * k] - kb) >> sh), o1 = (uint32_t)((v1 - kb) >> sh);
+                    reinterpret_cast<uint32_t*>(out.off16)[idx >> 1] = o0 | (o1 << 16);
+                    // the coarse row: offsets of the cells CS-1 (mod CS), CS = 4 << logg, two per 4-byte store
+                    if (out.logg == 0) {
+                        const uint32_t part = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o1, 0x55, 0xF, 0xF, false);    // quad_perm [1,1,1,1]
+                        if ((lane & 3) == 3) reinterpret_cast<uint32_t*>(out.coarse)[(idx + 1) >> 3] = part | (o1 << 16);
+                    } else {
+                        const uint32_t part = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o1, 0x114, 0xF, 0xF, false);   // row_shr:4
+                        if ((lane & 7) == 7) reinterpret_cast<uint32_t*>(out.coarse)[(idx + 1) >> 4] = part | (o1 << 16);
+                    }
+                }
             }
         }
         if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) {
@@ -703,6 +741,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_residual2(const uint64_t* __rest
             *reinterpret_cast<ulonglong2*>(A.out.cdf + idx) = make_ulonglong2(offa + pa[2 * k], va);
             *reinterpret_cast<ulonglong2*>(B.out.cdf + idx) = make_ulonglong2(offb + pb[2 * k], vb);
             if ((lane & 7) == 7) { A.out.t16[(idx + 1) >> 4] = va; B.out.t16[(idx + 1) >> 4] = vb; }
+            if ((lane & 15) == 15) { A.out.k32[(idx + 1) >> 5] = (uint32_t)(va >> KEY_SHIFT); B.out.k32[(idx + 1) >> 5] = (uint32_t)(vb >> KEY_SHIFT); }
             if (lane == WAVE - 1 && (k & 1)) { A.out.t256[(idx + 1) >> 8] = va; B.out.t256[(idx + 1) >> 8] = vb; }
         }
         if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) { *A.total_out = offa + pa[2 * SCAN_ROWS - 1]; *B.total_out = offb + pb[2 * SCAN_ROWS - 1]; }
@@ -750,6 +789,8 @@ __global__ __launch_bounds__(BLOCK) void k_fold_q(WSum* ws, const uint64_t* __re
 // compared in registers.  Two dependent L2 round trips per slot instead of eleven.
 struct CdfLevels {
     const uint64_t* cdf;  const uint64_t* t16;  const uint64_t* t256;  const uint64_t* ttile;   // ttile: descriptor words
+    const uint32_t* k32;                                                                        // 4-byte keys per 32 cells (ScanOut::k32)
+    const uint16_t* off16; const uint16_t* coarse; int logg;                                    // ScanOut::off16 / coarse / logg
 };
 // a pointer rebuilt from an integer is generic (flat_load: also counts on lgkmcnt and serialises behind the LDS
 // reads); the lines live in global memory, so say so
@@ -1048,6 +1089,165 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
             if (METHOD == 2 && a.order) idx[u] = (int64_t)a.order[idx[u]];
             if (act[u]) a.anc[j[u]] = (int32_t)idx[u];
         }
+    }
+}
+
+// ----------------------------------------------------------------------------- K5a: i.i.d. targets, 4-byte keys in LDS
+// rand!(Categorical(weights), parents) (resample.jl:59): N independent targets, no locality to exploit.  What a slot
+// costs is (a) instructions and (b) bytes fetched from arrays too large for the XCD's 4 MB L2 -- random 128-byte lines
+// of the 8 N-byte CDF come over the fabric, and that traffic, not the ALU, bounded the line-counting search.  Here a
+// slot touches the CDF itself only when two 16-bit offsets tie (about 1e-3 of the slots):
+//   level 1, LDS: the prefix at the end of every G = 32 << LOGG cells as a 4-byte key (prefix >> KEY_SHIFT, ScanOut::k32;
+//            122 KB at 10^6 particles, one 1024-thread workgroup per CU), uniform binary search, 32-bit compares;
+//            key < (T >> KEY_SHIFT) => prefix <= T, key > => prefix > T, equal keys: the exact prefix decides;
+//   level 2, one 16-byte read per lane: the group's coarse row, the 16-bit offsets (key_quant_shift) of every
+//            (G/8)-th cell -> which run of CS = G / 8 cells;
+//   level 3, one CS*2-byte read per lane: the offsets of that run -> the cell.  Equal offsets: the exact prefixes decide.
+// Both offset arrays are written by the scan (ScanOut::off16 / coarse), 2.5 N bytes together: they stay in L2.
+constexpr int MULTI_LDS_BUDGET = 160 * 1024 - 1024;
+__host__ __device__ __forceinline__ int64_t multi_groups(int64_t ntiles, int logg) { return (ntiles * (TILE / 32)) >> logg; }
+// LDS copy of the keys: one pad word per 32 entries.  The uniform binary search probes at power-of-two strides; unpadded,
+// every probe of the middle steps would land in the same bank (64-way conflicts)
+__host__ __device__ __forceinline__ uint32_t kpad(uint32_t i) { return i + (i >> 5); }
+__host__ inline size_t multi_lds_bytes(int64_t ntiles, int logg) { return (size_t)(kpad((uint32_t)multi_groups(ntiles, logg)) + 1) * sizeof(uint32_t); }
+// smallest LOGG whose key table fits (-1: none; the caller falls back to k_search)
+__host__ inline int multi_logg(int64_t ntiles)
+{
+    for (int g = 0; g <= 1; ++g) if (multi_lds_bytes(ntiles, g) <= (size_t)MULTI_LDS_BUDGET) return g;
+    return -1;
+}
+// number of 16-bit halves of x that are < the halves of qq (qq = q | q << 16), as 0/1 per half; and != qq
+typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
+__device__ __forceinline__ uint32_t pk_lt(uint32_t x, uint32_t qq)
+{
+    const u16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, qq), __builtin_bit_cast(u16x2, x));   // > 0 iff x < q
+    const u16x2 one = {1, 1};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(d, one));
+}
+__device__ __forceinline__ uint32_t pk_ne(uint32_t x, uint32_t qq)
+{
+    const u16x2 one = {1, 1};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x ^ qq), one));
+}
+
+template <int LOGG>
+__global__ __launch_bounds__(SBLOCK, 4) void k_search_multi(SearchArgs a)
+{
+    constexpr int G = 32 << LOGG, CS = G / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* const keys = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t ng = (uint32_t)multi_groups(a.ntiles, LOGG);         // >= 64 >> LOGG
+    // ---- the key table: 16 B per lane from the scan's key level (every (1 << LOGG)-th key)
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.w.k32);
+        if (LOGG == 0) {
+            for (uint32_t q = threadIdx.x; q < ng / 4; q += SBLOCK) {
+                const uint4 v = src[q];
+                uint32_t* d = keys + kpad(4 * q);                          // 4 q .. 4 q + 3 share their pad offset
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (uint32_t q = threadIdx.x; q < ng / 2; q += SBLOCK) {
+                const uint4 v = src[q];
+                uint32_t* d = keys + kpad(2 * q);
+                d[0] = v.y; d[1] = v.w;
+            }
+        }
+    }
+    // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
+    if (a.update_lml && blockIdx.x == 0 && threadIdx.x == 0)
+        a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
+    const uint64_t S = a.ws->S;
+    uint32_t p2 = 1;                                                     // largest power of two <= ng
+    while (2 * p2 <= ng) p2 *= 2;
+    __syncthreads();
+    for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < a.n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
+        // the lane's two consecutive slots; one Philox block for both when their ids form an aligned pair (resample_u64)
+        const int64_t j0 = base + 2 * (int64_t)threadIdx.x;
+        const uint32_t s0 = (uint32_t)(a.gid0 + j0);
+        const Philox pb0 = rng(a.seed, s0 >> 1, 0, a.epoch, TAG_RESAMPLE);
+        const Philox pb1 = (s0 & 1u) ? rng(a.seed, (s0 >> 1) + 1u, 0, a.epoch, TAG_RESAMPLE) : pb0;   // kernel-uniform branch
+        uint64_t T[2]; uint32_t t[2], pos[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            T[u] = mulhi64(resample_pick(u ? pb1 : pb0, s0 + (uint32_t)u), S);                       // resample.jl:59
+            t[u] = (uint32_t)(T[u] >> KEY_SHIFT);
+            pos[u] = keys[kpad(p2 - 1)] < t[u] ? ng - p2 : 0u;         // uniform binary search: no bounds checks below
+        }
+        for (uint32_t h = p2 >> 1; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) pos[u] += keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
+        }
+        bool amb = false;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t k = keys[kpad(pos[u])];                       // pos <= ng - 1 here
+            pos[u] += k < t[u] ? 1u : 0u;                                // pos = number of keys < t: those groups end at or below T
+            amb = amb || k == t[u] || (k < t[u] && pos[u] < ng && keys[kpad(pos[u])] == t[u]);
+        }
+        if (__any(amb)) {
+            // equal keys: the exact prefix decides (rare: one key value in 2^32 S / (2^30 groups) per slot)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                while (pos[u] < ng && keys[kpad(pos[u])] == t[u] && a.w.cdf[(int64_t)pos[u] * G + (G - 1)] <= T[u]) ++pos[u];
+        }
+        // ---- inside the key group: the target as a 16-bit offset, then two narrow reads
+        uint32_t g[2], qq[2], run[2];
+        uint4 row[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            g[u] = pos[u] < ng ? pos[u] : ng - 1;
+            const uint32_t klo = g[u] ? keys[kpad(g[u] - 1)] : 0u, khi = keys[kpad(g[u])];
+            const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
+            const uint64_t d = T[u] > kb ? T[u] - kb : 0;
+            uint32_t q = (uint32_t)(d >> key_quant_shift(klo, khi));
+            q = q < 65535u ? q : 65535u;
+            qq[u] = q | (q << 16);
+            row[u] = *reinterpret_cast<const uint4*>(a.w.coarse + (size_t)g[u] * 8);
+        }
+        bool tie[2];
+        int64_t idx[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // run = number of coarse offsets < q (the last one, the group's end, is >= q: T lies in this group)
+            uint32_t c = pk_lt(row[u].x, qq[u]) + pk_lt(row[u].y, qq[u]) + pk_lt(row[u].z, qq[u]) + pk_lt(row[u].w, qq[u]);
+            c = (c & 0xffffu) + (c >> 16);
+            run[u] = c < 8u ? c : 7u;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint16_t* fine = a.w.off16 + (size_t)g[u] * G + run[u] * CS;
+            uint32_t lt, ne;
+            if (CS == 4) {
+                const uint2 f = *reinterpret_cast<const uint2*>(fine);
+                lt = pk_lt(f.x, qq[u]) + pk_lt(f.y, qq[u]);
+                ne = pk_ne(f.x, qq[u]) + pk_ne(f.y, qq[u]);
+            } else {
+                const uint4 f = *reinterpret_cast<const uint4*>(fine);
+                lt = pk_lt(f.x, qq[u]) + pk_lt(f.y, qq[u]) + pk_lt(f.z, qq[u]) + pk_lt(f.w, qq[u]);
+                ne = pk_ne(f.x, qq[u]) + pk_ne(f.y, qq[u]) + pk_ne(f.z, qq[u]) + pk_ne(f.w, qq[u]);
+            }
+            lt = (lt & 0xffffu) + (lt >> 16); ne = (ne & 0xffffu) + (ne >> 16);
+            tie[u] = ne != (uint32_t)CS;
+            idx[u] = (int64_t)g[u] * G + run[u] * CS + lt;
+        }
+        if (__any(tie[0] || tie[1])) {
+            // a cell of the run shares the target's offset: the exact prefixes decide.  Every cell before the run is below T
+            // (its run's coarse offset is < q); walk from the run's first cell -- equal offsets may continue into later runs
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!tie[u]) continue;
+                int64_t i = (int64_t)g[u] * G + run[u] * CS;
+                const int64_t end = (int64_t)g[u] * G + G;
+                while (i < end && a.w.cdf[i] <= T[u]) ++i;
+                idx[u] = i;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) idx[u] = idx[u] < a.n_cells ? idx[u] : a.n_cells - 1;
+        int32_t* dst = a.anc + j0;
+        if (j0 + 1 < a.n && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) *reinterpret_cast<int2*>(dst) = make_int2((int32_t)idx[0], (int32_t)idx[1]);
+        else { if (j0 < a.n) dst[0] = (int32_t)idx[0]; if (j0 + 1 < a.n) dst[1] = (int32_t)idx[1]; }
     }
 }
 

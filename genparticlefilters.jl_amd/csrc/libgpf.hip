@@ -131,6 +131,19 @@ gpf_status fail(gpf_handle h, gpf_status s, const std::string& msg)
 }
 
 constexpr int row_width(int D, bool keep) { return ((keep ? 2 * D : D) + 1) & ~1; }
+// one buffer per scan channel holds the per-256 level (8 u64 per tile) followed by the 4-byte key level (64 u32 per tile)
+// one buffer per scan channel: the per-256 level (8 u64 per tile), the 4-byte key level (64 u32 per tile), the 16-bit
+// in-group offsets (2048 u16 per tile) and their coarse rows (<= 512 u16 per tile) -- gpf_kernels.hpp ScanOut
+size_t t256_bytes(int64_t ntiles) { return (size_t)ntiles * ((TILE / 256) * sizeof(uint64_t) + (TILE / 32) * sizeof(uint32_t) + TILE * sizeof(uint16_t) + (TILE / 4) * sizeof(uint16_t)); }
+uint32_t* k32_of(uint64_t* t256, int64_t ntiles) { return reinterpret_cast<uint32_t*>(t256 + ntiles * (TILE / 256)); }
+uint16_t* off16_of(uint64_t* t256, int64_t ntiles) { return reinterpret_cast<uint16_t*>(k32_of(t256, ntiles) + ntiles * (TILE / 32)); }
+uint16_t* coarse_of(uint64_t* t256, int64_t ntiles) { return off16_of(t256, ntiles) + ntiles * TILE; }
+// channel 0 (the weights) carries the offset levels when k_search_multi can take the filter (multi_logg >= 0)
+ScanOut scan_out(uint64_t* cdf, uint64_t* t16, uint64_t* t256, int64_t ntiles, bool with_offsets)
+{
+    const int logg = with_offsets ? multi_logg(ntiles) : -1;
+    return ScanOut{cdf, t16, t256, k32_of(t256, ntiles), logg >= 0 ? off16_of(t256, ntiles) : nullptr, logg >= 0 ? coarse_of(t256, ntiles) : nullptr, logg};
+}
 
 int grid_for(const gpf_filter* h, int64_t work_items, int blocks_per_cu)
 {
@@ -208,7 +221,7 @@ gpf_status alloc_particle_buffers(gpf_filter* h)
     HIP_TRY(h, hipMalloc(&h->dtmp, n * sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->cdf[0], (size_t)h->ntiles * TILE * sizeof(uint64_t)));
     HIP_TRY(h, hipMalloc(&h->t16[0], (size_t)h->ntiles * (TILE / 16) * sizeof(uint64_t)));
-    HIP_TRY(h, hipMalloc(&h->t256[0], (size_t)h->ntiles * (TILE / 256) * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->t256[0], t256_bytes(h->ntiles)));
     const size_t db = (((size_t)2 * h->ntiles * sizeof(uint64_t)) + 15) & ~(size_t)15;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 2; ++j) {
@@ -400,7 +413,7 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
     uint64_t* dc = h->desc[ch][h->dcur[ch]];
     uint64_t* dn = h->desc[ch][1 - h->dcur[ch]];
     const int gs = scan_grid(h);
-    const ScanOut so{want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch]};
+    const ScanOut so = scan_out(want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch], h->ntiles, ch == 0);
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
         GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, pmax, h->pflags, np, slot,
                            so, dc, dn, total_out, h->blockQ, &h->sc->timeout, ex);
@@ -557,12 +570,17 @@ gpf_status ensure_residual_buffers(gpf_filter* h)
         if (h->cdf[i]) continue;
         HIP_TRY(h, hipMalloc(&h->cdf[i], (size_t)h->ntiles * TILE * sizeof(uint64_t)));
         HIP_TRY(h, hipMalloc(&h->t16[i], (size_t)h->ntiles * (TILE / 16) * sizeof(uint64_t)));
-        HIP_TRY(h, hipMalloc(&h->t256[i], (size_t)h->ntiles * (TILE / 256) * sizeof(uint64_t)));
+        HIP_TRY(h, hipMalloc(&h->t256[i], t256_bytes(h->ntiles)));
     }
     return GPF_OK;
 }
 
-CdfLevels levels(const gpf_filter* h, int ch) { return CdfLevels{h->cdf[ch], h->t16[ch], h->t256[ch], h->table[ch]}; }
+CdfLevels levels(const gpf_filter* h, int ch)
+{
+    const int logg = ch == 0 ? multi_logg(h->ntiles) : -1;
+    return CdfLevels{h->cdf[ch], h->t16[ch], h->t256[ch], h->table[ch], k32_of(h->t256[ch], h->ntiles),
+                     logg >= 0 ? off16_of(h->t256[ch], h->ntiles) : nullptr, logg >= 0 ? coarse_of(h->t256[ch], h->ntiles) : nullptr, logg};
+}
 
 // residual: copy-count and residual-weight CDFs from the weight CDF (resample.jl:99,109); ws->S must be the GLOBAL sum
 gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
@@ -574,7 +592,7 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
     for (int c = 0; c < 2; ++c) {
         const int id = 1 + c;
         uint64_t* dc = h->desc[id][h->dcur[id]];
-        ch[c].out = ScanOut{h->cdf[id], h->t16[id], h->t256[id]};
+        ch[c].out = scan_out(h->cdf[id], h->t16[id], h->t256[id], h->ntiles, false);
         ch[c].dcur = dc; ch[c].dnext = h->desc[id][1 - h->dcur[id]];
         ch[c].total_out = c == 0 ? &h->sc->Ctot : &h->sc->Rs;
         h->table[id] = dc + h->ntiles;
@@ -587,6 +605,16 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
+}
+
+// ancestors of i.i.d. targets: k_search_multi (4-byte keys of every 32 / 64 cells in LDS) while the key table fits, else k_search<0>
+void launch_multinomial_search(gpf_filter* h, const SearchArgs& sa)
+{
+    const int logg = sa.w.off16 ? sa.w.logg : -1;                // the offset levels exist for channel 0 only
+    const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((sa.n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));
+    if (logg == 0)      GPF_LAUNCH((k_search_multi<0>), dim3(gsr), dim3(SBLOCK), multi_lds_bytes(sa.ntiles, 0), h->stream, sa);
+    else if (logg == 1) GPF_LAUNCH((k_search_multi<1>), dim3(gsr), dim3(SBLOCK), multi_lds_bytes(sa.ntiles, 1), h->stream, sa);
+    else                GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), search_lds_bytes(sa.ntiles, 1), h->stream, sa);
 }
 
 gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_particles, int check, int32_t* invalid)
@@ -664,7 +692,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu * SEARCH_BLOCKS_PER_CU));
     s = timed(h, GPF_K_SEARCH, [&] {
         switch (method) {
-            case GPF_RESAMPLE_MULTINOMIAL: GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
+            case GPF_RESAMPLE_MULTINOMIAL: launch_multinomial_search(h, sa); break;
             case GPF_RESAMPLE_RESIDUAL:    GPF_LAUNCH((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
             default:                       // monotone targets: a streaming merge, MJB slots per workgroup
                 GPF_LAUNCH(k_search_strat, dim3((unsigned)((h->n + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa); break;
@@ -780,6 +808,8 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_multi<0>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_multi<1>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
 #define GPF_PUSH_ATTR(M, W) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_push<M, W>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn))
         GPF_PUSH_ATTR(0, 2); GPF_PUSH_ATTR(0, 4); GPF_PUSH_ATTR(0, 8);
         GPF_PUSH_ATTR(1, 2); GPF_PUSH_ATTR(1, 4); GPF_PUSH_ATTR(1, 8);
@@ -1169,6 +1199,27 @@ gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const do
     return GPF_OK;
 }
 
+gpf_status gpf_debug_levels(gpf_handle h, int32_t which, void* out, int64_t* n_bytes)
+{
+    if (!h || !out || !n_bytes) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    const int64_t nt = h->ntiles;
+    const int logg = multi_logg(nt);
+    const void* src = nullptr; int64_t bytes = 0;
+    switch (which) {
+        case 0: src = h->cdf[0]; bytes = nt * TILE * 8; break;
+        case 1: src = h->t16[0]; bytes = nt * (TILE / 16) * 8; break;
+        case 2: src = h->t256[0]; bytes = nt * (TILE / 256) * 8; break;
+        case 3: src = k32_of(h->t256[0], nt); bytes = nt * (TILE / 32) * 4; break;
+        case 4: src = off16_of(h->t256[0], nt); bytes = logg >= 0 ? nt * TILE * 2 : 0; break;
+        case 5: src = coarse_of(h->t256[0], nt); bytes = logg >= 0 ? (nt * TILE / (4 << logg)) * 2 : 0; break;
+        default: return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad level");
+    }
+    if (bytes > *n_bytes) return fail(h, GPF_ERR_INVALID_ARGUMENT, "output too small");
+    *n_bytes = bytes;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return bytes ? copy_out(h, src, out, (size_t)bytes) : GPF_OK;
+}
+
 // Gen.sample_unweighted_traces(state, n_samples) (reference src/utils.jl:7,189-194): n i.i.d. draws from the normalised
 // weights, WITHOUT touching the filter (no log-ML update, weights unchanged).  Same CDF + search kernels as a resample.
 gpf_status gpf_sample_unweighted(gpf_handle h, int64_t n_samples, double* rows_out, int64_t* idx_out)
@@ -1187,9 +1238,7 @@ gpf_status gpf_sample_unweighted(gpf_handle h, int64_t n_samples, double* rows_o
     sa.w = levels(h, 0); sa.c = levels(h, 0); sa.ntiles = h->ntiles; sa.order = nullptr; sa.sc = h->sc; sa.ws = &h->sc->raw;
     sa.raw = &h->sc->raw; sa.n = n_samples; sa.n_cells = h->n; sa.n_global = n_samples; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed;
     sa.epoch = h->epoch; sa.K = h->K; sa.logN = h->logN; sa.update_lml = 0; sa.anc = anc;
-    const size_t lds = search_lds_bytes(h->ntiles, 1);
-    const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((n_samples + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
-    GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
+    launch_multinomial_search(h, sa);
     launch_gather_rows_lw(h, anc, h->rows[h->cur], h->lw, rows, nullptr, n_samples);
     HIP_TRY(h, hipMemcpyAsync(rows_out, rows, (size_t)n_samples * h->W * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (idx_out) {
@@ -1231,7 +1280,7 @@ gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_
         HIP_TRY(v, hipMalloc(&v->dtmp, n * sizeof(double)));
         HIP_TRY(v, hipMalloc(&v->cdf[0], (size_t)v->ntiles * TILE * sizeof(uint64_t)));
         HIP_TRY(v, hipMalloc(&v->t16[0], (size_t)v->ntiles * (TILE / 16) * sizeof(uint64_t)));
-        HIP_TRY(v, hipMalloc(&v->t256[0], (size_t)v->ntiles * (TILE / 256) * sizeof(uint64_t)));
+        HIP_TRY(v, hipMalloc(&v->t256[0], t256_bytes(v->ntiles)));
         const size_t db = (((size_t)2 * v->ntiles * sizeof(uint64_t)) + 15) & ~(size_t)15;
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 2; ++j) {
@@ -1392,7 +1441,7 @@ gpf_status gpf_resize(gpf_handle h, int64_t n_new, int32_t method, double priori
     const size_t lds = search_lds_bytes(ntiles_old, (int)nt);
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((n_new + 2 * SBLOCK - 1) / (2 * SBLOCK), h->n_cu));
     if (method == GPF_RESAMPLE_RESIDUAL) GPF_LAUNCH((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
-    else                                 GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa);
+    else                                 launch_multinomial_search(h, sa);
     // new_traces .= view(traces, parents) + update_weights!(state, n_particles, log_priorities)   resize.jl:64-66,424-438
     launch_gather_ex(h, h->anc, old.rows[old.cur], h->rows[0], pv, pv.mode == 0 ? h->lw : h->lws, n_new);
     if (pv.mode != 0) {

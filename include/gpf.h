@@ -277,6 +277,11 @@ int32_t gpf_host_fix_K(int64_t n_global);
 double  gpf_host_log(double x);
 double  gpf_host_lse(double m, uint64_t S, int32_t K, int32_t flags);     /* m + log(S 2^-K) */
 double  gpf_host_ess(uint64_t S, uint64_t Q_hi, uint64_t Q_lo);           /* S^2 / Q */
+/* test hook: copy one level of the weight CDF left by the last scan of channel 0 to the host.
+ * which: 0 cdf (u64 per padded cell), 1 per-16 prefixes (u64), 2 per-256 prefixes (u64), 3 4-byte keys (u32 per 32 cells),
+ * 4 16-bit in-group offsets (u16 per padded cell), 5 coarse offset rows (u16).  *n_bytes: capacity in, bytes written out. */
+gpf_status gpf_debug_levels(gpf_handle h, int32_t which, void* out, int64_t* n_bytes);
+
 /* host twin of gpf_debug_math (which = 0..5) */
 void    gpf_host_math(int32_t which, const double* a, const double* b, int64_t n, double* out, double* out2);
 
