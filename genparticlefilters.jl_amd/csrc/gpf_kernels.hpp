@@ -1130,57 +1130,102 @@ __device__ __forceinline__ uint32_t pk_ne(uint32_t x, uint32_t qq)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x ^ qq), one));
 }
 
+#ifndef GPF_MULTI_NS
+#define GPF_MULTI_NS 4
+#endif
 template <int LOGG>
 __global__ __launch_bounds__(SBLOCK, 4) void k_search_multi(SearchArgs a)
 {
-    constexpr int G = 32 << LOGG, CS = G / 8;
+    constexpr int G = 32 << LOGG, CS = G / 8, NS = GPF_MULTI_NS;             // NS = 2 or 4 slots per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* const keys = reinterpret_cast<uint32_t*>(smem);
     const uint32_t ng = (uint32_t)multi_groups(a.ntiles, LOGG);         // >= 64 >> LOGG
-    // ---- the key table: 16 B per lane from the scan's key level (every (1 << LOGG)-th key)
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(a.w.k32);
-        if (LOGG == 0) {
-            for (uint32_t q = threadIdx.x; q < ng / 4; q += SBLOCK) {
-                const uint4 v = src[q];
-                uint32_t* d = keys + kpad(4 * q);                          // 4 q .. 4 q + 3 share their pad offset
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            for (uint32_t q = threadIdx.x; q < ng / 2; q += SBLOCK) {
-                const uint4 v = src[q];
-                uint32_t* d = keys + kpad(2 * q);
-                d[0] = v.y; d[1] = v.w;
-            }
-        }
-    }
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
     if (a.update_lml && blockIdx.x == 0 && threadIdx.x == 0)
         a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
+    // ---- the key table: 16 B per lane from the scan's key level (every (1 << LOGG)-th key).  The loads are issued first,
+    //      the first targets are computed while they are in flight, then the table is written
+    constexpr int KT = (MULTI_LDS_BUDGET / 4 / (LOGG == 0 ? 4 : 2) + SBLOCK - 1) / SBLOCK;   // 16-byte source loads per lane that cover any table within the budget
+    const uint32_t nq = LOGG == 0 ? ng / 4 : ng / 2;
+    uint4 kv[KT];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.w.k32);
+#pragma unroll
+        for (int r = 0; r < KT; ++r) { const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK; if (q < nq) kv[r] = src[q]; }
+    }
     const uint64_t S = a.ws->S;
     uint32_t p2 = 1;                                                     // largest power of two <= ng
     while (2 * p2 <= ng) p2 *= 2;
-    __syncthreads();
-    for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < a.n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
-        // the lane's two consecutive slots; one Philox block for both when their ids form an aligned pair (resample_u64)
-        const int64_t j0 = base + 2 * (int64_t)threadIdx.x;
-        const uint32_t s0 = (uint32_t)(a.gid0 + j0);
-        const Philox pb0 = rng(a.seed, s0 >> 1, 0, a.epoch, TAG_RESAMPLE);
-        const Philox pb1 = (s0 & 1u) ? rng(a.seed, (s0 >> 1) + 1u, 0, a.epoch, TAG_RESAMPLE) : pb0;   // kernel-uniform branch
-        uint64_t T[2]; uint32_t t[2], pos[2];
+    const float kscale = (float)ng / (float)((S >> KEY_SHIFT) + 1);      // groups per key unit: where a key would sit were the CDF linear
+    // the lane's NS consecutive slots from slot `base` on (independent chains: the LDS and L2 round trips of one hide
+    // behind the others); one Philox block per aligned slot pair (resample_u64), one more block when the run starts odd
+    auto targets = [&](int64_t base, uint64_t* T) {
+        const uint32_t s0 = (uint32_t)(a.gid0 + base + NS * (int64_t)threadIdx.x), sb = s0 >> 1;
+        if (!(s0 & 1u)) {                                                // kernel-uniform
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            T[u] = mulhi64(resample_pick(u ? pb1 : pb0, s0 + (uint32_t)u), S);                       // resample.jl:59
-            t[u] = (uint32_t)(T[u] >> KEY_SHIFT);
-            pos[u] = keys[kpad(p2 - 1)] < t[u] ? ng - p2 : 0u;         // uniform binary search: no bounds checks below
+            for (int q = 0; q < NS / 2; ++q) {
+                const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
+                T[2 * q] = mulhi64(u64(b.w0, b.w1), S); T[2 * q + 1] = mulhi64(u64(b.w2, b.w3), S);     // resample.jl:59
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q <= NS / 2; ++q) {
+                const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
+                if (q > 0) T[2 * q - 1] = mulhi64(u64(b.w0, b.w1), S);
+                if (q < NS / 2) T[2 * q] = mulhi64(u64(b.w2, b.w3), S);
+            }
         }
-        for (uint32_t h = p2 >> 1; h >= 1; h >>= 1) {
+    };
+    const int64_t stride = (int64_t)gridDim.x * NS * SBLOCK;
+    int64_t base = (int64_t)blockIdx.x * NS * SBLOCK;
+    uint64_t T[NS];
+    targets(base, T);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) pos[u] += keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
+    for (int r = 0; r < KT; ++r) {
+        const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK;
+        if (q < nq) {
+            if (LOGG == 0) { uint32_t* d = keys + kpad(4 * q); d[0] = kv[r].x; d[1] = kv[r].y; d[2] = kv[r].z; d[3] = kv[r].w; }   // 4 q .. 4 q + 3 share their pad offset
+            else { uint32_t* d = keys + kpad(2 * q); d[0] = kv[r].y; d[1] = kv[r].w; }
+        }
+    }
+    __syncthreads();
+    constexpr uint32_t WIN = 512;                                        // interpolation window of the key search
+    for (; base < a.n; base += stride) {
+        const int64_t j0 = base + NS * (int64_t)threadIdx.x;
+        uint32_t t[NS], pos[NS];
+        // ---- number of keys < t.  Fast path: the CDF of exchangeable weights is close to linear, so a window of WIN keys
+        //      around the interpolated position brackets the answer (checked); else the uniform binary search of the whole table
+        bool inwin = ng >= 2 * WIN;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            t[u] = (uint32_t)(T[u] >> KEY_SHIFT);
+            const uint32_t pe = (uint32_t)((float)t[u] * kscale);
+            uint32_t lo = pe > WIN / 2 ? pe - WIN / 2 : 0u;
+            lo = lo + WIN > ng ? ng - WIN : lo;
+            pos[u] = lo;
+        }
+        if (inwin) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u)
+                inwin = inwin && (pos[u] == 0u || keys[kpad(pos[u] - 1)] < t[u]) && keys[kpad(pos[u] + WIN - 1)] >= t[u];
+        }
+        if (__all(inwin)) {
+#pragma unroll
+            for (uint32_t h = WIN / 2; h >= 1; h >>= 1) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) pos[u] += keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) pos[u] = keys[kpad(p2 - 1)] < t[u] ? ng - p2 : 0u;          // uniform binary search: no bounds checks below
+            for (uint32_t h = p2 >> 1; h >= 1; h >>= 1) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) pos[u] += keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
+            }
         }
         bool amb = false;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NS; ++u) {
             const uint32_t k = keys[kpad(pos[u])];                       // pos <= ng - 1 here
             pos[u] += k < t[u] ? 1u : 0u;                                // pos = number of keys < t: those groups end at or below T
             amb = amb || k == t[u] || (k < t[u] && pos[u] < ng && keys[kpad(pos[u])] == t[u]);
@@ -1188,14 +1233,14 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_search_multi(SearchArgs a)
         if (__any(amb)) {
             // equal keys: the exact prefix decides (rare: one key value in 2^32 S / (2^30 groups) per slot)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < NS; ++u)
                 while (pos[u] < ng && keys[kpad(pos[u])] == t[u] && a.w.cdf[(int64_t)pos[u] * G + (G - 1)] <= T[u]) ++pos[u];
         }
         // ---- inside the key group: the target as a 16-bit offset, then two narrow reads
-        uint32_t g[2], qq[2], run[2];
-        uint4 row[2];
+        uint32_t g[NS], qq[NS], run[NS];
+        uint4 row[NS];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NS; ++u) {
             g[u] = pos[u] < ng ? pos[u] : ng - 1;
             const uint32_t klo = g[u] ? keys[kpad(g[u] - 1)] : 0u, khi = keys[kpad(g[u])];
             const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
@@ -1205,49 +1250,60 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_search_multi(SearchArgs a)
             qq[u] = q | (q << 16);
             row[u] = *reinterpret_cast<const uint4*>(a.w.coarse + (size_t)g[u] * 8);
         }
-        bool tie[2];
-        int64_t idx[2];
+        bool tie[NS];
+        uint32_t idx[NS];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NS; ++u) {
             // run = number of coarse offsets < q (the last one, the group's end, is >= q: T lies in this group)
             uint32_t c = pk_lt(row[u].x, qq[u]) + pk_lt(row[u].y, qq[u]) + pk_lt(row[u].z, qq[u]) + pk_lt(row[u].w, qq[u]);
             c = (c & 0xffffu) + (c >> 16);
             run[u] = c < 8u ? c : 7u;
         }
+        uint4 fine[NS];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint16_t* fine = a.w.off16 + (size_t)g[u] * G + run[u] * CS;
-            uint32_t lt, ne;
-            if (CS == 4) {
-                const uint2 f = *reinterpret_cast<const uint2*>(fine);
-                lt = pk_lt(f.x, qq[u]) + pk_lt(f.y, qq[u]);
-                ne = pk_ne(f.x, qq[u]) + pk_ne(f.y, qq[u]);
-            } else {
-                const uint4 f = *reinterpret_cast<const uint4*>(fine);
-                lt = pk_lt(f.x, qq[u]) + pk_lt(f.y, qq[u]) + pk_lt(f.z, qq[u]) + pk_lt(f.w, qq[u]);
-                ne = pk_ne(f.x, qq[u]) + pk_ne(f.y, qq[u]) + pk_ne(f.z, qq[u]) + pk_ne(f.w, qq[u]);
+        for (int u = 0; u < NS; ++u) {
+            const uint16_t* fp = a.w.off16 + (size_t)(g[u] * (uint32_t)G + run[u] * (uint32_t)CS);
+            if (CS == 4) { const uint2 f = *reinterpret_cast<const uint2*>(fp); fine[u] = make_uint4(f.x, f.y, 0xffffffffu, 0xffffffffu); }
+            else fine[u] = *reinterpret_cast<const uint4*>(fp);
+        }
+        bool anytie = false;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            uint32_t lt = pk_lt(fine[u].x, qq[u]) + pk_lt(fine[u].y, qq[u]);
+            uint32_t ne = pk_ne(fine[u].x, qq[u]) + pk_ne(fine[u].y, qq[u]);
+            if (CS != 4) {
+                lt += pk_lt(fine[u].z, qq[u]) + pk_lt(fine[u].w, qq[u]);
+                ne += pk_ne(fine[u].z, qq[u]) + pk_ne(fine[u].w, qq[u]);
             }
             lt = (lt & 0xffffu) + (lt >> 16); ne = (ne & 0xffffu) + (ne >> 16);
             tie[u] = ne != (uint32_t)CS;
-            idx[u] = (int64_t)g[u] * G + run[u] * CS + lt;
+            anytie = anytie || tie[u];
+            idx[u] = g[u] * (uint32_t)G + run[u] * (uint32_t)CS + lt;
         }
-        if (__any(tie[0] || tie[1])) {
+        if (__any(anytie)) {
             // a cell of the run shares the target's offset: the exact prefixes decide.  Every cell before the run is below T
             // (its run's coarse offset is < q); walk from the run's first cell -- equal offsets may continue into later runs
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NS; ++u) {
                 if (!tie[u]) continue;
-                int64_t i = (int64_t)g[u] * G + run[u] * CS;
-                const int64_t end = (int64_t)g[u] * G + G;
+                uint32_t i = g[u] * (uint32_t)G + run[u] * (uint32_t)CS;
+                const uint32_t end = g[u] * (uint32_t)G + (uint32_t)G;
                 while (i < end && a.w.cdf[i] <= T[u]) ++i;
                 idx[u] = i;
             }
         }
+        const uint32_t last = (uint32_t)(a.n_cells - 1);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) idx[u] = idx[u] < a.n_cells ? idx[u] : a.n_cells - 1;
+        for (int u = 0; u < NS; ++u) idx[u] = idx[u] < last ? idx[u] : last;
         int32_t* dst = a.anc + j0;
-        if (j0 + 1 < a.n && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) *reinterpret_cast<int2*>(dst) = make_int2((int32_t)idx[0], (int32_t)idx[1]);
-        else { if (j0 < a.n) dst[0] = (int32_t)idx[0]; if (j0 + 1 < a.n) dst[1] = (int32_t)idx[1]; }
+        if (j0 + NS <= a.n && (reinterpret_cast<uintptr_t>(dst) & (4 * NS - 1)) == 0) {
+            if (NS == 4) *reinterpret_cast<int4*>(dst) = make_int4((int32_t)idx[0], (int32_t)idx[1], (int32_t)idx[2], (int32_t)idx[3]);
+            else *reinterpret_cast<int2*>(dst) = make_int2((int32_t)idx[0], (int32_t)idx[1]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) if (j0 + u < a.n) dst[u] = (int32_t)idx[u];
+        }
+        if (base + stride < a.n) targets(base + stride, T);
     }
 }
 

@@ -611,7 +611,7 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
 void launch_multinomial_search(gpf_filter* h, const SearchArgs& sa)
 {
     const int logg = sa.w.off16 ? sa.w.logg : -1;                // the offset levels exist for channel 0 only
-    const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((sa.n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));
+    const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((sa.n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));   // (k_search_multi strides by its own slots per lane)
     if (logg == 0)      GPF_LAUNCH((k_search_multi<0>), dim3(gsr), dim3(SBLOCK), multi_lds_bytes(sa.ntiles, 0), h->stream, sa);
     else if (logg == 1) GPF_LAUNCH((k_search_multi<1>), dim3(gsr), dim3(SBLOCK), multi_lds_bytes(sa.ntiles, 1), h->stream, sa);
     else                GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), search_lds_bytes(sa.ntiles, 1), h->stream, sa);
