@@ -246,11 +246,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
             i = (int64_t)(meta >> 32);
             pc.anc[i] = (int32_t)(meta & 0xffffffffull);
         } else {
-#ifdef GPF_ABL_STEP_NOGATHER
-        const int64_t srow = i;
-#else
         const int64_t srow = GATHER ? (int64_t)anc[i] : i;
-#endif
         const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
 #pragma unroll
         for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
@@ -441,9 +437,6 @@ struct InFixQ {                // q_i = trunc(exp(p_i - m) 2^K + 1/2); uniform f
     double m; int flags;       // filled in-kernel from the partials
     __device__ __forceinline__ uint64_t one(double v, bool uniform, bool bad) const
     {
-#ifdef GPF_ABL_SCAN_NOEXP
-        return 1 + (d2u(v) & 0xff);
-#endif
         return uniform ? 1 : (bad ? 0 : exp_fix(v - m, K));
     }
     __device__ __forceinline__ void load2(int64_t idx, int64_t n, uint64_t& q0, uint64_t& q1) const
@@ -541,16 +534,12 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
     constexpr bool WANT_Q = MODE == 2 || MODE == 4;
     if constexpr (MODE >= 1) {
         double m; int f;
-#ifdef GPF_ABL_SCAN_NOFOLD
-        m = 0.0; f = 0; (void)sm; (void)sf;
-#else
         if constexpr (MODE >= 3) {
             m = -__builtin_huge_val(); f = 0;
             for (int g = 0; g < np; ++g) { const double v = pmax[2 * g]; m = v > m ? v : m; f |= (int)pmax[2 * g + 1]; }
             if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
             (void)sm; (void)sf;
         } else fold_partials(pmax, pflags, np, sm, sf, m, f);
-#endif
         in.m = m; in.flags = f;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             ws_out->m = m; ws_out->flags = f;
@@ -595,10 +584,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
         // exclusive prefix of this tile: one parallel read of the round's earlier aggregates
         const int64_t first = (tile / gridDim.x) * gridDim.x;
         uint64_t acc = 0;
-#ifndef GPF_ABL_SCAN_NOWAIT
         for (int64_t idx = first + threadIdx.x; idx < tile; idx += BLOCK) acc += desc_wait(d_agg + idx, timeout);
         if (first > 0 && threadIdx.x == BLOCK - 1) acc += desc_wait(d_pre + first - 1, timeout);
-#endif
         acc = wave_sum_u64(acc);
         if (lane == 0) s_red[wv] = acc;
         __syncthreads();
@@ -925,7 +912,6 @@ __device__ __forceinline__ SearchTop search_prologue(const CdfLevels& w, const C
     search_top_shape(ntiles, nt, st.top256, st.gshift, st.tn);
     uint64_t* tw = smem;
     uint64_t* tc = tw + lds_pad(st.tn);
-#ifndef GPF_ABL_SEARCH_NOTABLE
     if (st.top256) {
         const uint64_t* srcw = w.t256;
         const uint64_t* srcc = c.t256;
@@ -948,7 +934,6 @@ __device__ __forceinline__ SearchTop search_prologue(const CdfLevels& w, const C
         }
     }
     __syncthreads();
-#endif
     st.topw = tw;
     st.topc = tc;
     st.steps = 0;
@@ -963,12 +948,7 @@ __device__ __forceinline__ void search_pair(const SearchTop& st, const CdfLevels
     const int64_t n256 = ntiles * 8, n16 = ntiles * (TILE / 16);
     // top level: branch-free binary search, both slots interleaved; pos = number of entries <= T
     int64_t pos[2] = {0, 0};
-#ifdef GPF_ABL_SEARCH_NOLDS
-    pos[0] = (int64_t)(T[0] % (uint64_t)st.tn); pos[1] = (int64_t)(T[1] % (uint64_t)st.tn);
-    for (int s = -1; s >= 0; --s) {
-#else
     for (int s = st.steps - 1; s >= 0; --s) {
-#endif
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t np = pos[u] + ((int64_t)1 << s);
@@ -999,11 +979,6 @@ __device__ __forceinline__ void search_pair(const SearchTop& st, const CdfLevels
         }
         s256[u] = s256[u] < n256 ? s256[u] : n256 - 1;
     }
-#ifdef GPF_ABL_SEARCH_NOLINES
-    idx[0] = s256[0] * 256 < n_cells ? s256[0] * 256 : n_cells - 1;
-    idx[1] = s256[1] * 256 < n_cells ? s256[1] * 256 : n_cells - 1;
-    return;
-#endif
     int c0, c1;
     const uint64_t* l0 = L[0]->t16 + s256[0] * 16;
     const uint64_t* l1 = L[1]->t16 + s256[1] * 16;
@@ -1027,23 +1002,18 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchTop st = search_prologue(a.w, a.c, METHOD == 1, a.ntiles, reinterpret_cast<uint64_t*>(smem));
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
-#ifndef GPF_ABL_SEARCH_NOLML
     if (a.update_lml && blockIdx.x == 0 && threadIdx.x == 0)
-#else
-    if (false)
-#endif
         a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
     const uint64_t S = (METHOD == 1 || METHOD == 3) ? a.sc->Rs : a.ws->S;
     const uint64_t N = (uint64_t)a.n_global;
-    // stratified: S = N B + rem, once per workgroup (u64 division is ~100 instructions)
+    // systematic: S = N B + rem, once per workgroup (u64 division is ~100 instructions)
     __shared__ uint64_t s_div[2];
     __shared__ ulonglong2 s_coop[2 * SBLOCK];
     ulonglong2* const lds_wave = s_coop + wave_id() * (2 * WAVE);
-    if (METHOD == 2 || METHOD == 3) {
+    if (METHOD == 3) {
         if (threadIdx.x == 0) { s_div[0] = S / N; s_div[1] = S % N; }
         __syncthreads();
     }
-    const double invN = 1.0 / (double)N;
     const uint64_t Ctot = (METHOD == 1) ? a.sc->Ctot : 0;
     // two slots per lane and iteration (independent dependency chains); the loop is wave-uniform
     for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < a.n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
@@ -1061,13 +1031,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
             const uint64_t U = METHOD == 3 ? u64(pb0.w0, pb0.w1) : resample_pick(u ? pb1 : pb0, s0 + (uint32_t)u);
             head[u] = false; top[u] = st.topw; L[u] = &a.w;
             if (METHOD == 0) T[u] = mulhi64(U, S);                    // multinomial, resample.jl:59
-            else if (METHOD == 2) {                                   // stratified, resample.jl:159-168
-                const uint64_t B = s_div[0], rem = s_div[1];
-                const uint64_t x0 = jg * rem, q0 = div_small(x0, N, invN);
-                const uint64_t q1 = q0 + ((x0 - q0 * N) + rem >= N ? 1 : 0);      // floor((x0 + rem)/N), rem < N
-                const uint64_t L0 = jg * B + q0, L1 = (jg + 1) * B + q1;
-                T[u] = L0 + mulhi64(U, L1 - L0);
-            } else if (METHOD == 3) {                                 // systematic: floor((j S + floor(U S)) / n), resize.jl:170-178
+            else if (METHOD == 3) {                                 // systematic: floor((j S + floor(U S)) / n), resize.jl:170-178
                 T[u] = jg * s_div[0] + (jg * s_div[1] + mulhi64(U, S)) / N;
             } else {                                                  // residual, resample.jl:96-115
                 head[u] = jg < Ctot;
@@ -1075,18 +1039,12 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
                 if (head[u]) { top[u] = st.topc; L[u] = &a.c; }
             }
         }
-#ifdef GPF_ABL_SEARCH_ONLYT
-        if (act[0]) a.anc[j[0]] = (int32_t)(T[0] % (uint64_t)a.n_cells);
-        if (act[1]) a.anc[j[1]] = (int32_t)(T[1] % (uint64_t)a.n_cells);
-        continue;
-#endif
         // coherent targets (stratified; residual waves that are all deterministic copies) read their lines per lane
-        const bool coop = METHOD == 0 ? true : (METHOD == 2 || METHOD == 3 ? false : __any(!head[0] || !head[1]) != 0);
+        const bool coop = METHOD == 0 ? true : (METHOD == 3 ? false : __any(!head[0] || !head[1]) != 0);
         int64_t idx[2];
         search_pair(st, L, top, T, coop, lds_wave, a.n_cells, a.ntiles, idx);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (METHOD == 2 && a.order) idx[u] = (int64_t)a.order[idx[u]];
             if (act[u]) a.anc[j[u]] = (int32_t)idx[u];
         }
     }
@@ -1288,7 +1246,13 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_search_multi(SearchArgs a)
                 if (!tie[u]) continue;
                 uint32_t i = g[u] * (uint32_t)G + run[u] * (uint32_t)CS;
                 const uint32_t end = g[u] * (uint32_t)G + (uint32_t)G;
-                while (i < end && a.w.cdf[i] <= T[u]) ++i;
+                // the run's CS exact prefixes in one round trip; only a run that lies entirely at or below T walks on
+                const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(a.w.cdf + i);
+                uint32_t c = 0;
+#pragma unroll
+                for (int e = 0; e < CS / 2; ++e) { const ulonglong2 v = cp[e]; c += (uint32_t)(v.x <= T[u]) + (uint32_t)(v.y <= T[u]); }
+                i += c;
+                if (c == (uint32_t)CS) while (i < end && a.w.cdf[i] <= T[u]) ++i;
                 idx[u] = i;
             }
         }

@@ -98,6 +98,10 @@ struct gpf_filter {
     int64_t view_start = 0;
     uint64_t generation = 0;             // bumped when the per-particle buffers are reallocated (views check it)
     uint64_t parent_generation = 0;
+    uint64_t mutations = 0;              // bumped by every change of the rows / log-weights of this filter (through any handle)
+    uint64_t seen_mutations = 0;         // view: the parent's counter when this view's cached summaries were valid
+    int32_t* h_timeout = nullptr;        // pinned: set by a scan whose bounded inter-workgroup wait gave up (checked on the host)
+    int scan_blocks_per_cu = 2;          // resident scan workgroups per CU the launch may rely on (occupancy query)
     int64_t* shard_counts = nullptr;     // [2 * MAX_SHARDS] exchange counters of the current resample (device) + pinned mirror
     int64_t* h_shard_counts = nullptr;
     int64_t* h_flags = nullptr;          // pinned {validity flags, ticket} published by the weight scan of a checked resample
@@ -402,7 +406,9 @@ gpf_status hist_begin_step(gpf_filter* h, bool first)
 }
 
 // ------------------------------------------------------------------ weight summary = (max) + scan
-int scan_grid(const gpf_filter* h) { return (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, 2 * (int64_t)h->n_cu)); }
+// The scan's inter-workgroup protocol needs every workgroup of the launch resident at once (block b owns tiles b, b + G, ...
+// and waits for lower tiles of its round): at most scan_blocks_per_cu per CU, from the occupancy query at gpf_create.
+int scan_grid(const gpf_filter* h) { return (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, (int64_t)h->scan_blocks_per_cu * h->n_cu)); }
 
 // one scan launch on descriptor channel `ch` (0 weights, 1 residual counts, 2 residual weights)
 template <class In, int FIXQ>
@@ -416,7 +422,7 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
     const ScanOut so = scan_out(want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch], h->ntiles, ch == 0);
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
         GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, pmax, h->pflags, np, slot,
-                           so, dc, dn, total_out, h->blockQ, &h->sc->timeout, ex);
+                           so, dc, dn, total_out, h->blockQ, h->h_timeout, ex);
     });
     if (s) return s;
     h->table[ch] = dc + h->ntiles;
@@ -467,21 +473,39 @@ gpf_status ensure_raw(gpf_filter* h, bool want_q = false)
     return GPF_OK;
 }
 
+// Poll a pinned ticket that a kernel on h->stream publishes.  A failed kernel never writes it: any stream status other than
+// "not ready" is terminal (re-read once, then report), so a faulting kernel cannot hang the host -- or, in a multi-rank job,
+// its peers in the next collective.
+gpf_status wait_ticket(gpf_filter* h, volatile int64_t* tk, int64_t want, const char* what)
+{
+    uint64_t spins = 0;
+    while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != want) {
+        cpu_relax();
+        if ((++spins & 0x3fff) != 0) continue;
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipErrorNotReady) continue;
+        if (__atomic_load_n(tk, __ATOMIC_ACQUIRE) == want) break;
+        if (q == hipSuccess) return fail(h, GPF_ERR_HIP, std::string(what) + ": the stream drained without the ticket being published");
+        return fail(h, GPF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(q));
+    }
+    return GPF_OK;
+}
+// a scan whose bounded inter-workgroup wait gave up leaves garbage prefixes behind: fail loudly at the next host touch point
+gpf_status check_scan_timeout(gpf_filter* h)
+{
+    if (h->h_timeout && __atomic_load_n(h->h_timeout, __ATOMIC_ACQUIRE) != 0)
+        return fail(h, GPF_ERR_HIP, "scan kernel: bounded inter-workgroup wait timed out (workgroups not co-resident?); results are invalid");
+    return GPF_OK;
+}
+
 gpf_status fetch_scalars(gpf_filter* h)
 {
     if (!h->h_sc_ticket) { HIP_TRY(h, hipHostMalloc(&h->h_sc_ticket, sizeof(long long))); *h->h_sc_ticket = 0; }
     h->sc_ticket += 1;
     GPF_LAUNCH(k_publish_scalars, dim3(1), dim3(64), 0, h->stream, h->sc, h->h_sc, h->h_sc_ticket, h->sc_ticket);
     HIP_TRY(h, hipGetLastError());
-    volatile long long* tk = h->h_sc_ticket;
-    uint64_t spins = 0;
-    while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->sc_ticket) {
-        cpu_relax();
-        if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->sc_ticket)
-            return fail(h, GPF_ERR_HIP, "the scalar block was not published");
-    }
-    if (h->h_sc->timeout) return fail(h, GPF_ERR_HIP, "scan kernel: bounded inter-workgroup wait timed out");
-    return GPF_OK;
+    { gpf_status w = wait_ticket(h, reinterpret_cast<volatile int64_t*>(h->h_sc_ticket), (int64_t)h->sc_ticket, "scalar block"); if (w) return w; }
+    return check_scan_timeout(h);
 }
 
 void normalise_Q(const WSum& w, uint64_t& hi, uint64_t& lo)
@@ -490,6 +514,16 @@ void normalise_Q(const WSum& w, uint64_t& hi, uint64_t& lo)
                           ((unsigned __int128)w.Ql[2] << 64) + ((unsigned __int128)w.Ql[3] << 96);
     hi = (uint64_t)(Q >> 64);
     lo = (uint64_t)Q;
+}
+
+// Every change of a filter's rows / log-weights -- through the filter itself or through any view of it -- bumps the ROOT's
+// mutation counter.  A view's cached summaries (raw CDF, sum q^2, producer maxima) describe the weights at the value it last
+// saw; view_enter drops them when the counter has moved (the reference's SubArray views are live, src/view.jl:35-48).
+void mutated(gpf_filter* h)
+{
+    gpf_filter* root = h->parent ? h->parent : h;
+    root->mutations += 1;
+    if (h->parent) h->seen_mutations = root->mutations;          // its own change: this view's bookkeeping is already current
 }
 
 // A view re-derives its aliased pointers from the parent on every call (the parent may have swapped its row buffers),
@@ -510,6 +544,10 @@ gpf_status view_enter(gpf_filter* v)
     v->epoch = p->epoch;
     v->has_prev = p->has_prev;
     v->initialized = true;
+    if (v->seen_mutations != p->mutations) {                     // the aliased weights changed behind this view's back
+        v->raw_valid = false; v->raw_has_q = false; v->raw_q_folded = false; v->max_valid = false;
+        v->seen_mutations = p->mutations;
+    }
     return GPF_OK;
 }
 // after a mutating call on a view: update_refs! for sub-states copies back (utils.jl:17-20); parent caches are stale
@@ -600,7 +638,7 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
     }
     const int gs = scan_grid(h);
     s = timed(h, GPF_K_SCAN, [&] {
-        GPF_LAUNCH(k_scan_residual2, dim3(gs), dim3(BLOCK), 0, h->stream, h->cdf[0], ws, n_slots_global, h->n, h->ntiles, ch[0], ch[1], &h->sc->timeout);
+        GPF_LAUNCH(k_scan_residual2, dim3(gs), dim3(BLOCK), 0, h->stream, h->cdf[0], ws, n_slots_global, h->n, h->ntiles, ch[0], ch[1], h->h_timeout);
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
@@ -626,6 +664,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     const bool sorted = method == GPF_RESAMPLE_STRATIFIED && sort_particles;
     const bool need_sync = check == GPF_CHECK_TRUE || invalid != nullptr;
     gpf_status s;
+    if ((s = check_scan_timeout(h))) return s;                   // an earlier scan gave up: do not build on its CDF
     if ((s = materialize(h))) return s;                          // two resamples in a row: finish the first one
     // sortperm(log_priorities, rev=true)  (resample.jl:156-157)
     if (sorted) {
@@ -656,13 +695,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         if (published) {
             // safe_softmax's flags are known when the scan STARTS (it folds the per-block maxima first): poll the ticket; the
             // scan keeps running and the search below is enqueued behind it without a gap
-            volatile int64_t* tk = h->h_flags + 1;
-            uint64_t spins = 0;
-            while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket) {
-                cpu_relax();
-        if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket)
-                    return fail(h, GPF_ERR_HIP, "the weight scan finished without publishing its flags");
-            }
+            if ((s = wait_ticket(h, h->h_flags + 1, h->flag_ticket, "weight scan flags"))) return s;
             flags = (int)h->h_flags[0];
         } else {
             if ((s = fetch_scalars(h))) return s;
@@ -715,6 +748,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         h->max_valid = false;
         HIP_TRY(h, hipGetLastError());
         h->epoch += 1;
+        mutated(h);
         return view_exit(h);
     }
     if (pv.mode == 0) {
@@ -734,6 +768,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     }
     HIP_TRY(h, hipGetLastError());
     h->epoch += 1;
+    mutated(h);
     return GPF_OK;
 }
 
@@ -798,6 +833,22 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         HIP_TRY(h, hipMalloc(&h->dscal, 4 * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->sc, sizeof(Scalars)));
         HIP_TRY(h, hipHostMalloc(&h->h_sc, sizeof(Scalars)));
+        HIP_TRY(h, hipHostMalloc(&h->h_timeout, sizeof(int32_t)));
+        *h->h_timeout = 0;
+        {   // resident scan workgroups per CU: the smallest answer over the scan kernels, never more than 2 (what the tile
+            // schedule was tuned for), one fewer than the API says when it says more (the API can over-count by one)
+            int nb = 2;
+            const void* scans[] = {reinterpret_cast<const void*>(&k_scan<InFixQ, 1>), reinterpret_cast<const void*>(&k_scan<InFixQ, 2>),
+                                   reinterpret_cast<const void*>(&k_scan<InFixQ, 3>), reinterpret_cast<const void*>(&k_scan<InFixQ, 4>),
+                                   reinterpret_cast<const void*>(&k_scan<InOptimal, 0>), reinterpret_cast<const void*>(&k_scan_residual2)};
+            for (const void* f : scans) {
+                int q = 0;
+                HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, f, BLOCK, 0));
+                if (q < 1) return fail(h, GPF_ERR_HIP, "a scan kernel cannot be resident on this device");
+                nb = std::min(nb, q > 2 ? q - 1 : q);
+            }
+            h->scan_blocks_per_cu = std::max(1, std::min(nb, 2));
+        }
         HIP_TRY(h, hipMemsetAsync(h->sc, 0, sizeof(Scalars), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->lw, 0, n * sizeof(double), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->rows[0], 0, rb, h->stream));
@@ -806,7 +857,6 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         const int max_dyn = (int)((lds_pad(LDS_TILE_TABLE) + 4) * sizeof(uint64_t));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<0>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_multi<0>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_multi<1>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
@@ -840,6 +890,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
     if (h->h_flags) hipHostFree(h->h_flags);
+    if (h->h_timeout) hipHostFree(h->h_timeout);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return GPF_OK;
@@ -849,7 +900,7 @@ gpf_status gpf_synchronize(gpf_handle h)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return GPF_OK;
+    return check_scan_timeout(h);
 }
 
 static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs, int prop)
@@ -880,6 +931,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
     h->initialized = true;
     h->has_prev = false;
     h->raw_valid = false;
+    mutated(h);
     return GPF_OK;
 }
 
@@ -921,6 +973,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
     h->epoch += 1;
     h->has_prev = true;
     h->raw_valid = false;
+    mutated(h);
     return view_exit(h);            // sub-state: copy back (utils.jl:17-20)
 }
 
@@ -996,6 +1049,7 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
     h->epoch += 1;
     if (fused_gather) { h->pending_gather = false; h->max_valid = false; }   // log-weights are all 0 now (resample.jl:195)
     if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; h->max_np = grid; }
+    mutated(h);
     if ((s = view_exit(h))) return s;
     if (n_accepted) {
         if ((s = fetch_scalars(h))) return s;
@@ -1071,7 +1125,8 @@ gpf_status gpf_get_norm_weights(gpf_handle h, double* out, int64_t n) { return n
 
 gpf_status gpf_get_parents(gpf_handle h, int64_t* out, int64_t n)
 {
-    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    gpf_status s0 = check_ready(h);                             // views: generation check + pointers; device; initialised
+    if (s0) return s0;
     if (!out || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
     if (h->pending_packed) { gpf_status s = materialize(h); if (s) return s; }   // a deferred sharded commit also carries the parents
     GPF_LAUNCH(k_parents, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, h->n, reinterpret_cast<int64_t*>(h->dtmp));
@@ -1109,11 +1164,13 @@ gpf_status gpf_set_rows(gpf_handle h, const double* rows, int64_t n_doubles)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!rows || n_doubles != h->n * h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (h->parent) { gpf_status s = view_enter(h); if (s) return s; }
     { gpf_status s = materialize(h); if (s) return s; }
     HIP_TRY(h, hipMemcpyAsync(h->rows[h->cur], rows, (size_t)n_doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->initialized = true;
+    mutated(h);
     return GPF_OK;
 }
 
@@ -1121,6 +1178,7 @@ gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!lw || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (h->parent) { gpf_status s = view_enter(h); if (s) return s; h->parent->raw_valid = false; h->parent->max_valid = false; }
     { gpf_status s = materialize(h); if (s) return s; }
     h->max_valid = false;
@@ -1128,6 +1186,7 @@ gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->raw_valid = false;
     h->initialized = true;
+    mutated(h);
     return GPF_OK;
 }
 
@@ -1294,6 +1353,9 @@ gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_
         HIP_TRY(v, hipMalloc(&v->dscal, 4 * sizeof(double)));
         HIP_TRY(v, hipMalloc(&v->sc, sizeof(Scalars)));
         HIP_TRY(v, hipHostMalloc(&v->h_sc, sizeof(Scalars)));
+        HIP_TRY(v, hipHostMalloc(&v->h_timeout, sizeof(int32_t)));
+        *v->h_timeout = 0;
+        v->scan_blocks_per_cu = parent->scan_blocks_per_cu;
         HIP_TRY(v, hipMemsetAsync(v->sc, 0, sizeof(Scalars), v->stream));
         return GPF_OK;
     };
@@ -1654,13 +1716,7 @@ gpf_status gpf_shard_flags(gpf_handle h, int32_t* flags_out)
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!flags_out || !h->h_flags || h->flag_ticket == 0) return fail(h, GPF_ERR_STATE, "gpf_shard_flags needs gpf_shard_weight_scan first");
-    volatile int64_t* tk = h->h_flags + 1;
-    uint64_t spins = 0;
-    while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket) {
-        cpu_relax();
-        if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess && __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->flag_ticket)
-            return fail(h, GPF_ERR_HIP, "the weight scan finished without publishing its flags");
-    }
+    if ((s = wait_ticket(h, h->h_flags + 1, h->flag_ticket, "weight scan flags"))) return s;
     *flags_out = (int32_t)h->h_flags[0];
     return GPF_OK;
 }
@@ -1736,14 +1792,7 @@ gpf_status gpf_shard_counts(gpf_handle h, int32_t G, int64_t* host_counts)
     if (!host_counts || G < 1 || G > MAX_SHARDS || !h->shard_counts || !h->push_counted) return fail(h, GPF_ERR_STATE, "no counted resample");
     if (h->counts_published) {
         // k_push publishes the counts to pinned host memory when it STARTS: poll the ticket (the kernel keeps running)
-        volatile int64_t* tk = h->h_shard_counts + 2 * MAX_SHARDS;
-        uint64_t spins = 0;
-        while (__atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->push_ticket) {
-            cpu_relax();
-        if ((++spins & 0xfffff) == 0 && hipStreamQuery(h->stream) == hipSuccess &&
-                __atomic_load_n(tk, __ATOMIC_ACQUIRE) != h->push_ticket)
-                return fail(h, GPF_ERR_HIP, "the push kernel finished without publishing its counts");
-        }
+        if ((s = wait_ticket(h, h->h_shard_counts + 2 * MAX_SHARDS, h->push_ticket, "push counts"))) return s;
     } else {
         HIP_TRY(h, hipMemcpyAsync(h->h_shard_counts, h->shard_counts, (size_t)2 * MAX_SHARDS * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1799,6 +1848,7 @@ gpf_status gpf_shard_commit(gpf_handle h, const double* packed, int64_t m, const
     h->max_valid = false;
     h->residual_scanned = false;
     h->push_counted = false;
+    mutated(h);
     return GPF_OK;
 }
 

@@ -95,3 +95,31 @@ def test_hip_view_errors(g, o):
     g.pf_resize(st, 80)
     with pytest.raises(g.ErrorException):
         g.get_ess(v)                                      # stale after the parent was resized
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", METHODS)
+def test_hip_views_are_live(g, o, method):
+    """A view held across changes made through the source or through an OVERLAPPING view answers for the weights as they
+    are now (the reference's sub-states are SubArray views, src/view.jl:35-48), and odd view starts (the lane's slot run
+    starts on the odd half of a Philox block) resample bit for bit."""
+    N = 4000
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 6)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=9, keep_prev=True)
+    orc = o.OracleFilter(model.model_id, model.params, N, 9, keep_prev=True).initialize(ys[0])
+    kw = dict(sort_particles=False) if method == "stratified" else {}
+    v, ov = st[501:2604], orc[501:2604]                      # odd start, odd length
+    w, ow = st[2000:3500], orc[2000:3500]                    # overlaps v
+    assert g.get_ess(v) == ov.effective_sample_size() and g.get_lml_est(v) == ov.log_ml_estimate()
+    g.pf_update(st, (2,), (None,), ys[1]); orc.update(ys[1])                    # through the source
+    assert g.get_ess(v) == ov.effective_sample_size() and g.get_lml_est(v) == ov.log_ml_estimate()
+    g.pf_update(w, (3,), (None,), ys[2]); ow.update(ys[2])                      # through the overlapping view
+    assert g.get_ess(v) == ov.effective_sample_size() and g.get_lml_est(v) == ov.log_ml_estimate()
+    g.pf_update(v, (3,), (None,), ys[3]); ov.update(ys[3])
+    g.pf_update(st, (4,), (None,), ys[4]); orc.update(ys[4])
+    g.pf_resample(v, method, check=False, **kw); ov.resample(method, check=False, **kw)      # stale producer maxima would break this
+    assert np.array_equal(v.parents, ov.parents)
+    assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw)
+    assert g.get_ess(w) == ow.effective_sample_size()
+    assert g.get_ess(st) == orc.effective_sample_size() and g.get_lml_est(st) == orc.log_ml_estimate()
+    assert np.array_equal(v.parents, st.parents[501:2604])   # parents of a view alias the source's
