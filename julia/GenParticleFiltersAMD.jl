@@ -6,11 +6,11 @@
 # for (file:line of GenParticleFilters.jl v0.2.3 in the comments).
 module GenParticleFiltersAMD
 
-import GenParticleFilters: pf_resize!, pf_multinomial_resize!, pf_residual_resize!, pf_replicate!, pf_dereplicate!
+import GenParticleFilters: pf_resize!, pf_multinomial_resize!, pf_residual_resize!, pf_optimal_resize!, pf_replicate!, pf_dereplicate!
 import GenParticleFilters: pf_initialize, pf_update!, pf_resample!, pf_multinomial_resample!,
     pf_residual_resample!, pf_stratified_resample!, pf_rejuvenate!, pf_move_accept!, pf_move_reweight!,
     get_log_norm_weights, get_norm_weights, get_ess, get_lml_est
-import Gen: effective_sample_size, log_ml_estimate, get_log_weights
+import Gen: effective_sample_size, log_ml_estimate, get_log_weights, sample_unweighted_traces
 import Statistics: mean, var
 
 const libgpf = get(ENV, "LIBGPF_HIP", "libgpf_hip.so")
@@ -46,7 +46,13 @@ mutable struct DeviceParticleFilterState
         end
         st == 0 || error(unsafe_string(ccall((:gpf_last_error, libgpf), Cstring, (Ptr{Cvoid},), C_NULL)))
         state = new(h[], model, n)
-        finalizer(s -> ccall((:gpf_destroy, libgpf), Cint, (Ptr{Cvoid},), s.handle), state)
+        finalizer(s -> ccall((:gpf_destroy, libgpf), Cint, (Ptr{Cvoid},), getfield(s, :handle)), state)
+        return state
+    end
+    # wrap an existing handle (a sub-state view created by gpf_view_create)
+    function DeviceParticleFilterState(handle::Ptr{Cvoid}, model::NativeModel, n::Int)
+        state = new(handle, model, n)
+        finalizer(s -> ccall((:gpf_destroy, libgpf), Cint, (Ptr{Cvoid},), getfield(s, :handle)), state)
         return state
     end
 end
@@ -56,10 +62,7 @@ end
 function Base.getindex(s::DeviceParticleFilterState, r::UnitRange{Int})
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(s, ccall((:gpf_view_create, libgpf), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), getfield(s, :handle), first(r) - 1, length(r), h))
-    v = ccall(:jl_new_struct_uninit, Any, (Any,), DeviceParticleFilterState)::DeviceParticleFilterState   # bypass the allocating constructor
-    setfield!(v, :handle, h[]); setfield!(v, :model, getfield(s, :model)); setfield!(v, :n_particles, length(r))
-    finalizer(x -> ccall((:gpf_destroy, libgpf), Cint, (Ptr{Cvoid},), getfield(x, :handle)), v)
-    return v
+    return DeviceParticleFilterState(h[], getfield(s, :model), length(r))
 end
 Base.view(s::DeviceParticleFilterState, r::UnitRange{Int}) = s[r]
 
