@@ -53,6 +53,16 @@ class _NativeKernel:
 
 # native proposal for the custom-proposal forms of pf_initialize / pf_update (src/initialize.jl:46-62, src/update.jl:79-96)
 locally_optimal = _NativeKernel("locally_optimal")     # exact conditional q(x_t | x_{t-1}, y_t); lgssm2 only
+# the proposals of the reference's own tests for line_model as one native proposal: slope ~ uniform_discrete(0, 0) at the
+# first step (test/initialize.jl:16-17), outlier ~ bernoulli(0.0) at every step (test/initialize.jl:18-19, test/update.jl:42-43)
+line_fixed = _NativeKernel("line_fixed")
+_PROPOSAL_IDS = {"locally_optimal": 1, "line_fixed": 2}
+
+
+def _proposal_id(proposal) -> int:
+    if not isinstance(proposal, _NativeKernel) or proposal.name not in _PROPOSAL_IDS:
+        raise ErrorException("device filters support native proposals only (`locally_optimal`, `line_fixed`)")
+    return _PROPOSAL_IDS[proposal.name]
 
 mh = _NativeKernel("mh")                        # Gen.mh(trace, select(current step latent))
 move_reweight = _NativeKernel("move_reweight")  # move_reweight(trace, selection), src/rejuvenate.jl:125-132
@@ -227,11 +237,10 @@ def pf_initialize(model: NativeModel, model_args: tuple, observations, *rest, se
     if len(rest) == 1:
         proposal, n_particles = None, rest[0]
     elif len(rest) == 2:
-        proposal, strata, n_particles = None, _strata_values(model, rest[0]), rest[1]
+        proposal, strata, n_particles = None, _strata_values(model, rest[0], "initialize"), rest[1]
     elif len(rest) == 3:
         proposal, n_particles = rest[0], rest[2]
-        if proposal is not locally_optimal:
-            raise ErrorException("device filters support the native `locally_optimal` proposal only")
+        _proposal_id(proposal)
     else:
         raise TypeError("pf_initialize(model, model_args, observations, [strata, | proposal, proposal_args,] n_particles)")
     state = DeviceParticleFilterState(model, n_particles, seed=seed, keep_prev=keep_prev, device=device, **kw)
@@ -241,7 +250,7 @@ def pf_initialize(model: NativeModel, model_args: tuple, observations, *rest, se
     elif proposal is None:
         state._check(state._L.gpf_initialize(state._h, _pd(obs), obs.size))
     else:
-        state._check(state._L.gpf_initialize_proposal(state._h, _pd(obs), obs.size, 1))
+        state._check(state._L.gpf_initialize_proposal(state._h, _pd(obs), obs.size, _proposal_id(proposal)))
     return state
 
 
@@ -260,9 +269,12 @@ def _layout_id(layout) -> bool:
     return layout == "interleaved"
 
 
-def _strata_values(model, strata) -> np.ndarray:
-    """strata: an iterable of choice maps over the model's ONE discrete latent address (or of plain values)"""
+def _strata_values(model, strata, phase: str = "update") -> np.ndarray:
+    """strata: an iterable of choice maps over the model's ONE discrete latent address (or of plain values); a model may
+    stratify a different address at its first step (`phase` = "initialize") than later ("update")"""
     addr = model.info.get("strata_address")
+    if isinstance(addr, dict):
+        addr = addr[phase]
     if addr is None:
         raise ErrorException(f"model {model.name} has no discrete latent to stratify over")
     vals = []
@@ -285,13 +297,13 @@ def pf_update(state: DeviceParticleFilterState, new_args: tuple, argdiffs: tuple
     obs = _obs_vector(observations)
     if proposal is None:
         state._check(state._L.gpf_update(state._h, _pd(obs), obs.size))
-    elif proposal is locally_optimal:
-        state._check(state._L.gpf_update_proposal(state._h, _pd(obs), obs.size, 1))
+    elif isinstance(proposal, _NativeKernel):
+        state._check(state._L.gpf_update_proposal(state._h, _pd(obs), obs.size, _proposal_id(proposal)))
     elif isinstance(proposal, (list, tuple)) or hasattr(proposal, "__iter__"):
         strata = _strata_values(state.model, proposal)
         state._check(state._L.gpf_update_strata(state._h, _pd(obs), obs.size, _pd(strata), strata.size, int(_layout_id(layout))))
     else:
-        raise ErrorException("device filters support the native `locally_optimal` proposal only")
+        _proposal_id(proposal)
     return state
 
 

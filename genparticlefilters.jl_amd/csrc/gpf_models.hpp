@@ -13,7 +13,7 @@
 
 namespace gpf {
 
-enum : int { MODEL_LGSSM2 = 1, MODEL_BEARINGS4 = 2, MODEL_SV1 = 3, MODEL_OBJECT_MOTION = 4 };
+enum : int { MODEL_LGSSM2 = 1, MODEL_BEARINGS4 = 2, MODEL_SV1 = 3, MODEL_OBJECT_MOTION = 4, MODEL_LINE = 5 };
 
 constexpr int MAX_PARAMS = 24;
 constexpr int MAX_OBS = 4;
@@ -177,12 +177,67 @@ template <> struct Model<MODEL_OBJECT_MOTION> {
     }
 };
 
+// line_model, the fixture model of the reference's own tests (reference test/runtests.jl:3-16):
+//     slope ~ uniform_discrete(-2, 2);   step t:  x = t;  outlier ~ bernoulli(0.1);  y ~ normal(x * slope, outlier ? 10 : 1)
+// Particle row = (slope, outlier of the current step).  obs = [y_t, x_t]; x_t = 0 stands for model args (0,): no step has
+// happened yet (pf_initialize(line_model, (0,), choicemap(), n), test/initialize.jl:4), nothing is observed, the weight is 0.
+// P = [p_out | 1/s_in | 1/s_out | log s_in + log(2 pi)/2 | log s_out + log(2 pi)/2 | log p_out | log(1 - p_out) |
+//      -log(n_slopes) | lowest slope | n_slopes]
+// One Philox block per particle and step: words (0,1) the slope (first step only), words (2,3) the outlier.
+template <> struct Model<MODEL_LINE> {
+    static constexpr int D = 2, NBLK = 1;
+    static constexpr bool HAS_PROPOSAL = true;
+    static constexpr bool HAS_STRATA = true;
+    static GPF_HD void sample(const double* P, bool first, const double* xp, const double* obs, uint64_t seed,
+                              uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
+    {
+        const Philox b = rng(seed, gid, blk0, epoch, tag);
+        xn[0] = first ? P[8] + (double)mulhi64(u64(b.w0, b.w1), (uint64_t)P[9]) : xp[0];      // uniform_discrete(lo, lo + n - 1)
+        xn[1] = (obs[1] != 0.0 && u52(b.w2, b.w3) < P[0]) ? 1.0 : 0.0;                         // bernoulli(p_out)
+    }
+    static GPF_HD double loglik(const double* P, const double* x, const double* obs)
+    {
+        if (obs[1] == 0.0) return 0.0;                                                         // model args (0,): no observation
+        const bool out = x[1] != 0.0;
+        const double z = (obs[0] - obs[1] * x[0]) * (out ? P[2] : P[1]);
+        return -0.5 * (z * z) - (out ? P[4] : P[3]);
+    }
+    // The custom proposals of the reference's tests as ONE native proposal (test/initialize.jl:16-19, test/update.jl:42-43):
+    // slope ~ uniform_discrete(0, 0) at the first step, outlier ~ bernoulli(0.0) at every step.  Both are deterministic
+    // (proposal score 0), so log_weight = model score of the proposed choices + log p(y | x)   (initialize.jl:58, translate.jl:103)
+    static GPF_HD double propose(const double* P, bool first, const double* xp, const double* obs, uint64_t, uint32_t,
+                                 uint32_t, uint32_t, uint32_t, double* xn)
+    {
+        xn[0] = first ? 0.0 : xp[0];
+        xn[1] = 0.0;
+        double w = first ? P[7] : 0.0;                                                         // log p(slope = 0) = log(1/5), test/initialize.jl:21
+        if (obs[1] != 0.0) w = (w + P[6]) + loglik(P, xn, obs);                                // log p(outlier = false) + log p(y | .)
+        return w;
+    }
+    // stratified initialise (strata over `slope`, test/initialize.jl:39-64) / update (strata over the step's `outlier`,
+    // test/update.jl:13-40): the stratified choice is constrained, the other one is sampled as usual; returns the log
+    // probability of the constrained choice
+    static GPF_HD double sample_stratum(const double* P, bool first, const double* xp, const double* obs, double value,
+                                        uint64_t seed, uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
+    {
+        const Philox b = rng(seed, gid, blk0, epoch, tag);
+        if (first) {
+            xn[0] = value;
+            xn[1] = (obs[1] != 0.0 && u52(b.w2, b.w3) < P[0]) ? 1.0 : 0.0;
+            return P[7];
+        }
+        xn[0] = xp[0];
+        xn[1] = value != 0.0 ? 1.0 : 0.0;
+        return value != 0.0 ? P[5] : P[6];
+    }
+};
+
 // length of the per-step data vector (observations, plus covariates such as sin(t) for object_motion)
 inline int model_obs_dim(int m)
 {
     switch (m) {
         case MODEL_LGSSM2: return 2; case MODEL_BEARINGS4: return 1;
-        case MODEL_SV1: return 1; case MODEL_OBJECT_MOTION: return 2;
+        case MODEL_SV1: return 1; case MODEL_OBJECT_MOTION: return 2; case MODEL_LINE: return 2;
     }
     return 0;
 }
@@ -191,7 +246,7 @@ inline int model_dim(int m)
 {
     switch (m) {
         case MODEL_LGSSM2: return 2; case MODEL_BEARINGS4: return 4;
-        case MODEL_SV1: return 1; case MODEL_OBJECT_MOTION: return 2;
+        case MODEL_SV1: return 1; case MODEL_OBJECT_MOTION: return 2; case MODEL_LINE: return 2;
     }
     return 0;
 }

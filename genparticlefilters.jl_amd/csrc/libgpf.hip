@@ -274,6 +274,7 @@ bool model_has_proposal(int model)
         case MODEL_BEARINGS4: return Model<MODEL_BEARINGS4>::HAS_PROPOSAL;
         case MODEL_SV1: return Model<MODEL_SV1>::HAS_PROPOSAL;
         case MODEL_OBJECT_MOTION: return Model<MODEL_OBJECT_MOTION>::HAS_PROPOSAL;
+        case MODEL_LINE: return Model<MODEL_LINE>::HAS_PROPOSAL;
     }
     return false;
 }
@@ -284,6 +285,7 @@ bool model_has_strata(int model)
         case MODEL_BEARINGS4: return Model<MODEL_BEARINGS4>::HAS_STRATA;
         case MODEL_SV1: return Model<MODEL_SV1>::HAS_STRATA;
         case MODEL_OBJECT_MOTION: return Model<MODEL_OBJECT_MOTION>::HAS_STRATA;
+        case MODEL_LINE: return Model<MODEL_LINE>::HAS_STRATA;
     }
     return false;
 }
@@ -307,6 +309,7 @@ void launch_move_t(gpf_filter* h, int grid, int n_iters)
         case MODEL_BEARINGS4: { constexpr int MM = MODEL_BEARINGS4; CALL; } break;               \
         case MODEL_SV1: { constexpr int MM = MODEL_SV1; CALL; } break;                           \
         case MODEL_OBJECT_MOTION: { constexpr int MM = MODEL_OBJECT_MOTION; CALL; } break;       \
+        case MODEL_LINE: { constexpr int MM = MODEL_LINE; CALL; } break;                         \
     }
 
 void launch_gather_ex(gpf_filter* h, const int32_t* anc, const double* in, double* out, const PrioView& pv, double* lw_out, int64_t n)
@@ -936,9 +939,17 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
 }
 
 gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs) { return initialize_impl(h, obs, n_obs, 0); }
+// the native proposal a model has: the locally optimal one (lgssm2), the reference tests' fixed proposals (line_model)
+static bool proposal_matches(gpf_handle h, int32_t proposal)
+{
+    if (!h) return true;                                          // reported by the callee
+    if (proposal == GPF_PROPOSAL_LOCALLY_OPTIMAL) return h->cfg.model != MODEL_LINE;
+    if (proposal == GPF_PROPOSAL_LINE_FIXED) return h->cfg.model == MODEL_LINE;
+    return false;
+}
 gpf_status gpf_initialize_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal)
 {
-    if (proposal != GPF_PROPOSAL_LOCALLY_OPTIMAL) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown proposal id");
+    if (!proposal_matches(h, proposal)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown proposal id for this model");
     return initialize_impl(h, obs, n_obs, 1);
 }
 
@@ -980,7 +991,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
 gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs) { return update_impl(h, obs, n_obs, 0); }
 gpf_status gpf_update_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal)
 {
-    if (proposal != GPF_PROPOSAL_LOCALLY_OPTIMAL) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown proposal id");
+    if (!proposal_matches(h, proposal)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown proposal id for this model");
     return update_impl(h, obs, n_obs, 1);
 }
 

@@ -12,7 +12,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-MODEL_LGSSM2, MODEL_BEARINGS4, MODEL_SV1, MODEL_OBJECT_MOTION = 1, 2, 3, 4
+MODEL_LGSSM2, MODEL_BEARINGS4, MODEL_SV1, MODEL_OBJECT_MOTION, MODEL_LINE = 1, 2, 3, 4, 5
 DATA_SEED = 20240001
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
@@ -63,8 +63,24 @@ def object_motion(p_stay: float = 0.75, p_start: float = 0.25, sy: float = 0.01,
                                                                           strata_address="moving"))
 
 
+def line_model(p_out: float = 0.1, s_in: float = 1.0, s_out: float = 10.0, slope_lo: int = -2, slope_hi: int = 2) -> NativeModel:
+    """The fixture model of the reference's own tests (test/runtests.jl:3-16): slope ~ uniform_discrete(-2, 2);
+    step t: x = t, outlier ~ bernoulli(0.1), y ~ normal(x * slope, outlier ? 10 : 1).  Particle row = (slope, outlier_t);
+    per-step data vector = [y_t, x_t] (`line_obs`); x_t = 0 stands for model args (0,): no step yet, nothing observed."""
+    n = slope_hi - slope_lo + 1
+    p = np.array([p_out, 1.0 / s_in, 1.0 / s_out, math.log(s_in) + _HALF_LOG_2PI, math.log(s_out) + _HALF_LOG_2PI,
+                  math.log(p_out), math.log1p(-p_out), -math.log(n), float(slope_lo), float(n)])
+    return NativeModel(MODEL_LINE, "line_model", 2, 2, p, dict(p_out=p_out, s_in=s_in, s_out=s_out, slopes=list(range(slope_lo, slope_hi + 1)),
+                                                                strata_address={"initialize": "slope", "update": "outlier"}))
+
+
+def line_obs(t: int, slope: float = 0.0) -> np.ndarray:
+    """line_choicemap of the reference's tests for ONE step (test/runtests.jl:22-23): y_t = t * slope, with the step index."""
+    return np.array([t * slope, float(t)])
+
+
 def by_name(name: str) -> NativeModel:
-    return {"lgssm2": lgssm2, "bearings4": bearings4, "sv1": sv1, "object_motion": object_motion}[name]()
+    return {"lgssm2": lgssm2, "bearings4": bearings4, "sv1": sv1, "object_motion": object_motion, "line_model": line_model}[name]()
 
 
 # ----------------------------------------------------------------------------- synthetic data
@@ -101,6 +117,11 @@ def simulate(model: NativeModel, T: int, seed: int = DATA_SEED) -> np.ndarray:
             moving = t > T // 2
             y = y + (math.sin(t) if moving else 0.0) + model.info["sy"] * rng.standard_normal()
             out[t - 1] = (y + model.info["sobs"] * rng.standard_normal(), math.sin(t))
+    elif model.model_id == MODEL_LINE:
+        slope = float(rng.integers(int(P[8]), int(P[8] + P[9])))
+        for t in range(1, T + 1):
+            out_t = rng.random() < P[0]
+            out[t - 1] = (t * slope + (model.info["s_out"] if out_t else model.info["s_in"]) * rng.standard_normal(), float(t))
     else:
         raise ValueError("unknown model")
     return out

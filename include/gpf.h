@@ -47,7 +47,8 @@ typedef enum {
     GPF_MODEL_LGSSM2 = 1,          /* 2-D linear-Gaussian SSM              (BASELINE configs 2,3) */
     GPF_MODEL_BEARINGS4 = 2,       /* bearings-only tracking, 4-D          (BASELINE config 4)   */
     GPF_MODEL_SV1 = 3,             /* stochastic volatility, 1-D           (BASELINE config 5)   */
-    GPF_MODEL_OBJECT_MOTION = 4    /* reference README.md:43-55            (BASELINE config 1)   */
+    GPF_MODEL_OBJECT_MOTION = 4,   /* reference README.md:43-55            (BASELINE config 1)   */
+    GPF_MODEL_LINE = 5             /* line_model, the fixture of the reference's tests (test/runtests.jl:3-16) */
 } gpf_model;
 
 /* method::Symbol of pf_resample! (src/resample.jl:19-30) */
@@ -92,8 +93,10 @@ gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs);
 /* pf_initialize(model, args, obs, proposal, proposal_args, n)        src/initialize.jl:46-62
  * pf_update!(state, new_args, argdiffs, obs, proposal, proposal_args) src/update.jl:79-96 (+ src/translate.jl:86-105)
  * with a NATIVE proposal: new latents x ~ q(. | x_{t-1}, y_t); log_weights[i] += [log p(x | x_{t-1}) + log p(y | x)] - log q(x).
- * GPF_PROPOSAL_LOCALLY_OPTIMAL: the exact conditional of the linear-Gaussian model (GPF_MODEL_LGSSM2 only). */
-typedef enum { GPF_PROPOSAL_LOCALLY_OPTIMAL = 1 } gpf_proposal;
+ * GPF_PROPOSAL_LOCALLY_OPTIMAL: the exact conditional of the linear-Gaussian model (GPF_MODEL_LGSSM2 only).
+ * GPF_PROPOSAL_LINE_FIXED: the proposals of the reference's own tests for GPF_MODEL_LINE, slope ~ uniform_discrete(0, 0) at
+ * the first step and outlier ~ bernoulli(0.0) at every step (test/initialize.jl:16-19, test/update.jl:42-43). */
+typedef enum { GPF_PROPOSAL_LOCALLY_OPTIMAL = 1, GPF_PROPOSAL_LINE_FIXED = 2 } gpf_proposal;
 gpf_status gpf_initialize_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal);
 gpf_status gpf_update_proposal(gpf_handle h, const double* obs, int32_t n_obs, int32_t proposal);
 

@@ -34,7 +34,7 @@
 
 #define O_EXPORT __attribute__((visibility("default")))
 
-enum { O_MODEL_LGSSM2 = 1, O_MODEL_BEARINGS4 = 2, O_MODEL_SV1 = 3, O_MODEL_OBJECT_MOTION = 4 };
+enum { O_MODEL_LGSSM2 = 1, O_MODEL_BEARINGS4 = 2, O_MODEL_SV1 = 3, O_MODEL_OBJECT_MOTION = 4, O_MODEL_LINE = 5 };
 enum { O_FLAG_NAN = 1, O_FLAG_POSINF = 2, O_FLAG_ALL_NEGINF = 4 };
 
 /* Threads for the per-particle loops (counter-based RNG: results do not depend on the thread count).
@@ -124,13 +124,13 @@ O_EXPORT double o_ess_from(uint64_t S, uint64_t Qhi, uint64_t Qlo)
 static int model_dim(int model)
 {
     switch (model) { case O_MODEL_LGSSM2: return 2; case O_MODEL_BEARINGS4: return 4;
-                     case O_MODEL_SV1: return 1; case O_MODEL_OBJECT_MOTION: return 2; }
+                     case O_MODEL_SV1: return 1; case O_MODEL_OBJECT_MOTION: return 2; case O_MODEL_LINE: return 2; }
     return 0;
 }
 static int model_nblk(int model)
 {
     switch (model) { case O_MODEL_LGSSM2: return 1; case O_MODEL_BEARINGS4: return 2;
-                     case O_MODEL_SV1: return 1; case O_MODEL_OBJECT_MOTION: return 2; }
+                     case O_MODEL_SV1: return 1; case O_MODEL_OBJECT_MOTION: return 2; case O_MODEL_LINE: return 1; }
     return 0;
 }
 O_EXPORT int o_model_dim(int model) { return model_dim(model); }
@@ -185,6 +185,13 @@ static void model_sample(int model, const double *P, int first, const double *xp
         xn[0] = mv;
         xn[1] = (py + vel) + P[2] * z0;
     } break;
+    case O_MODEL_LINE: {
+        /* reference test/runtests.jl:3-16: slope ~ uniform_discrete(-2, 2) once (line_model :13); per step (line_step :3-8)
+         * outlier ~ bernoulli(0.1).  obs = [y_t, x_t]; x_t = 0 is model args (0,): no step yet, no outlier choice */
+        o_philox_t b = o_rng(seed, gid, blk0, epoch, tag);
+        xn[0] = first ? P[8] + (double)o_mulhi64(o_u64(b.v[0], b.v[1]), (uint64_t)P[9]) : xp[0];
+        xn[1] = (obs[1] != 0.0 && o_u52(b.v[2], b.v[3]) < P[0]) ? 1.0 : 0.0;
+    } break;
     }
 }
 
@@ -212,6 +219,13 @@ static double model_loglik(int model, const double *P, const double *x, const do
         double z = (obs[0] - x[1]) * P[3];
         return -0.5 * (z * z) - P[4];
     }
+    case O_MODEL_LINE: {
+        /* y ~ normal(x * slope, outlier ? 10. : 1.)  (test/runtests.jl:6); nothing observed at model args (0,) */
+        if (obs[1] == 0.0) return 0.0;
+        int out = x[1] != 0.0;
+        double z = (obs[0] - obs[1] * x[0]) * (out ? P[2] : P[1]);
+        return -0.5 * (z * z) - (out ? P[4] : P[3]);
+    }
     }
     return 0.0;
 }
@@ -221,6 +235,17 @@ static double model_loglik(int model, const double *P, const double *x, const do
 static double model_propose(int model, const double *P, int first, const double *xp, const double *obs,
                             uint64_t seed, uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double *xn)
 {
+    if (model == O_MODEL_LINE) {
+        /* the reference tests' proposals as one native proposal: slope ~ uniform_discrete(0, 0) at the first step
+         * (test/initialize.jl:16-17), outlier ~ bernoulli(0.0) at every step (test/initialize.jl:18-19, test/update.jl:42-43);
+         * both deterministic (proposal score 0): weight = model score of the proposed choices + log p(y | .) */
+        (void)seed; (void)gid; (void)blk0; (void)epoch; (void)tag;
+        xn[0] = first ? 0.0 : xp[0];
+        xn[1] = 0.0;
+        double w = first ? P[7] : 0.0;                                  /* log(1/5): test/initialize.jl:21 */
+        if (obs[1] != 0.0) w = (w + P[6]) + model_loglik(model, P, xn, obs);
+        return w;
+    }
     if (model != O_MODEL_LGSSM2) return NAN;
     double z0, z1;
     o_normal2(o_rng(seed, gid, blk0, epoch, tag), &z0, &z1);
@@ -271,8 +296,20 @@ static double model_sample_stratum(int model, const double *P, int first, const 
                                    uint64_t seed, uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double *xn)
 {
     double z0, z1;
-    (void)model;                                                        /* O_MODEL_OBJECT_MOTION, README.md:43-55 */
-    o_normal2(o_rng(seed, gid, blk0 + 1, epoch, tag), &z0, &z1);
+    if (model == O_MODEL_LINE) {
+        /* strata over `slope` at the first step (test/initialize.jl:39-64), over the step's `outlier` afterwards
+         * (test/update.jl:13-40); the other choice is sampled as usual */
+        o_philox_t b = o_rng(seed, gid, blk0, epoch, tag);
+        if (first) {
+            xn[0] = value;
+            xn[1] = (obs[1] != 0.0 && o_u52(b.v[2], b.v[3]) < P[0]) ? 1.0 : 0.0;
+            return P[7];
+        }
+        xn[0] = xp[0];
+        xn[1] = value != 0.0 ? 1.0 : 0.0;
+        return value != 0.0 ? P[5] : P[6];
+    }
+    o_normal2(o_rng(seed, gid, blk0 + 1, epoch, tag), &z0, &z1);                        /* O_MODEL_OBJECT_MOTION, README.md:43-55 */
     double pm = first ? 0.0 : xp[0], py = first ? 0.0 : xp[1];
     double mv = (value != 0.0) ? 1.0 : 0.0;
     double lp = (pm != 0.0) ? ((mv != 0.0) ? P[5] : P[6]) : ((mv != 0.0) ? P[7] : P[8]);

@@ -20,7 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 
-MODEL_LGSSM2, MODEL_BEARINGS4, MODEL_SV1, MODEL_OBJECT_MOTION = 1, 2, 3, 4
+MODEL_LGSSM2, MODEL_BEARINGS4, MODEL_SV1, MODEL_OBJECT_MOTION, MODEL_LINE = 1, 2, 3, 4, 5
 FLAG_NAN, FLAG_POSINF, FLAG_ALL_NEGINF = 1, 2, 4
 METHODS = ("multinomial", "residual", "stratified")
 
