@@ -261,6 +261,12 @@ static double model_propose(int model, const double *P, int first, const double 
     double lq = -0.5 * (b0 * b0 + b1 * b1) - P[o + 3];                 /* log q(x) */
     return (lt + model_loglik(model, P, xn, obs)) - lq;
 }
+/* log p(y_t | x_t) of given particle rows: the deterministic part of a step, for the reference-twin fixtures
+ * (julia/reference_twins.jl evaluates the same quantity with Gen.project on the @gen twin) */
+O_EXPORT void o_loglik_rows(int model, const double *P, const double *rows, int W, int64_t n, const double *obs, double *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = model_loglik(model, P, rows + i * W, obs);
+}
 O_EXPORT void o_init_proposal(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
                               int W, const double *obs, double *rows, double *lw)
 {

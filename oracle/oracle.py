@@ -58,6 +58,7 @@ def lib():
     sig("o_normal2_d", None, u64, u32, u32, u32, u32, pf64, pf64)
     sig("o_u52_d", f64, u64, u32, u32, u32, u32)
     sig("o_resample_u52_d", f64, u64, u32, u32)
+    sig("o_loglik_rows", None, C.c_int, _f64p, _f64p, C.c_int, i64, _f64p, _f64p)
     sig("o_math_vec", None, i32, _f64p, _f64p, i64, _f64p, _f64p)
     sig("o_fix_K", i32, i64)
     sig("o_lse_from", f64, f64, u64, i32, i32); sig("o_ess_from", f64, u64, u64, u64)
