@@ -34,10 +34,11 @@ def algorithmic_bytes(d: int, W: int):
     every output written once.  d = state columns, rows are W doubles."""
     row = 8 * W
     return {
-        "k_step": row + 8 + row + 8,       # R row, R lw, W row, W lw        (16d + 16)
+        "k_step": 4 + row + row + 8,       # fused gather form, the one the hot loop launches: R ancestor, R row (random),
+                                           # W row, W lw (incoming weights are 0 after a resample: not read)   (16d + 12)
         "k_max_partial": 8,                # R lw
         "k_scan": 8 + 8,                   # R lw, W cdf
-        "k_search": 8 + 4,                 # R cdf cell, W ancestor
+        "k_search": 8 + 4,                 # R cdf cell, W ancestor (k_search_multi reads 2-byte offsets instead: fewer bytes, same figure kept)
         "k_gather": 4 + row + row + 8,     # R ancestor, R row, W row, W lw  (16d + 12)
     }
 

@@ -1,0 +1,17 @@
+# usage: bash tools/gpu_round.sh TAG   -- the round's evidence in one GPU call: bench line (long run + the driver's command),
+# rocprofv3 kernel stats of the same command, FETCH_SIZE / WRITE_SIZE passes, per-config times
+set -x
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd $R
+python bench.py --steps 1000 --warmup 20 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -2 gpurun_out/${TAG}_bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_cmd.json 2>> gpurun_out/${TAG}_bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 200 --warmup 10 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+f=$(find $R/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/${TAG}_kernel_stats.csv && head -12 "$f"
+tail -1 $R/gpurun_out/prof_$TAG.log > $R/gpurun_out/${TAG}_bench_under_rocprof.json
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_${TAG}_$C -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$C.log 2>&1
+  f=$(find $R/gpurun_out/pmc_${TAG}_$C -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/${TAG}_pmc_$C.csv
+done
+cd $R; python tools/bench_configs.py > gpurun_out/${TAG}_configs.log 2>&1; cut -c1-300 gpurun_out/${TAG}_configs.log
+rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE

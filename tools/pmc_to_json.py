@@ -1,5 +1,5 @@
 """profiles/<tag>_pmc_{FETCH,WRITE}_SIZE.csv (rocprofv3 --pmc, one counter per pass) -> profiles/pmc_traffic.json
-usage: python tools/pmc_to_json.py r01e"""
+usage: python tools/pmc_to_json.py r02"""
 import collections
 import csv
 import json
@@ -7,21 +7,24 @@ import sys
 
 tag = sys.argv[1]
 out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean KiB per launch of bench.py's "
-                "workload (N=1e6, d=2).  gfx950: FETCH_SIZE reads 1/2 of the bytes of wide coalesced streaming reads "
-                "(MI355X_MICROARCH.md §HBM) -> doubled for the streaming kernel (k_scan) only; kernels dominated by random "
-                "line/sector reads (k_search, k_step with the fused gather) are uncalibrated and reported raw.",
+                "workload (N=1e6, d=2).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies every 128-byte fabric read "
+                "request as 64 bytes, so it is DOUBLED.  That holds for the random-line kernels too: the request-size counters of "
+                "the stand-alone gather (profiles/r02_gather_requests.txt: 836 K TCC_EA0_RDREQ_128B, 0 of 32 B / 64 B) give 107 MB "
+                "against FETCH_SIZE = 52.3 MB.  WRITE_SIZE is exact.  traffic_bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024.",
        "tag": tag, "kernels": {}}
+PATTERNS = (("k_step", "k_step<1, 2, false, true"), ("k_scan", "k_scan<gpf::InFixQ, 1>"), ("k_search", "k_search_multi<0>"),
+            ("k_search_strat", "k_search_strat"), ("k_gather", "k_gather<2>"))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f"profiles/{tag}_pmc_{c}.csv")):
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         # the instantiations bench.py's timed loop launches (multinomial, fused gather, no sum q^2)
-        short = next((name for name, pat in (("k_step", "k_step<1, 2, false, true"), ("k_scan", "k_scan<gpf::InFixQ, 1>"),
-                                             ("k_search", "k_search<0>"), ("k_gather", "k_gather<2>")) if pat in k), None)
+        short = next((name for name, pat in PATTERNS if pat in k), None)
         if short:
             out["kernels"].setdefault(short, {})[c] = round(sum(v) / len(v), 2)
 for k, d in out["kernels"].items():
-    d["traffic_bytes"] = int((d["FETCH_SIZE"] * (2 if k == "k_scan" else 1) + d["WRITE_SIZE"]) * 1024)
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["traffic_bytes"] = int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out["kernels"]))
