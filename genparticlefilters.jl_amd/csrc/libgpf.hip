@@ -8,7 +8,6 @@
 #include "../../include/gpf.h"
 #include "gpf_kernels.hpp"
 
-#include <hipcub/hipcub.hpp>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -455,7 +454,7 @@ gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cd
         h->max_valid = false;       // pmax now describes pv, which may not be the raw log-weights
         if (use_producer_max) { h->max_valid = true; h->max_np = np; }
     }
-    InFixQ in{pv, order, h->K, 0.0, 0};
+    InFixQ in{pv, order, order ? h->keys : nullptr, h->K, 0.0, 0};     // (after sort_desc the sorted keys are in h->keys)
     if (want_q) s = scan_launch<InFixQ, 2>(h, 0, in, np, slot, want_cdf, &slot->S, nullptr, ex);
     else        s = scan_launch<InFixQ, 1>(h, 0, in, np, slot, want_cdf, &slot->S, nullptr, ex);
     if (s) return s;
@@ -596,12 +595,34 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
     HIP_TRY(h, hipMalloc(&h->idx_in, n * sizeof(int32_t)));
     HIP_TRY(h, hipMalloc(&h->keys, n * sizeof(uint64_t)));
     HIP_TRY(h, hipMalloc(&h->keys_out, n * sizeof(uint64_t)));
-    size_t bytes = 0;
-    HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->keys, h->keys_out, h->idx_in, h->order, (int)h->n, 0, 64,
-                                                  h->stream));
-    h->sort_tmp_bytes = bytes;
-    HIP_TRY(h, hipMalloc(&h->sort_tmp, bytes));
-    GPF_LAUNCH(k_iota, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->idx_in, h->n);
+    h->sort_tmp_bytes = sort_ws_bytes(h->n);
+    HIP_TRY(h, hipMalloc(&h->sort_tmp, h->sort_tmp_bytes));
+    return GPF_OK;
+}
+
+// order = sortperm(log_priorities, rev=true) (resample.jl:156-157) into h->order: keys + digit histograms in one pass, then
+// eight onesweep digit passes (gpf_kernels.hpp K10).  Key buffers alternate keys -> keys_out -> keys ...; the payload
+// starts as the element index and alternates idx_in -> order, so the eighth pass leaves the permutation in h->order.
+gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
+{
+    gpf_status s = ensure_sort_buffers(h);
+    if (s) return s;
+    static_assert(SORT_BINS == BLOCK, "one thread per digit bin");
+    uint32_t* hist = reinterpret_cast<uint32_t*>(h->sort_tmp);
+    uint32_t* ticket = hist + SORT_PASSES * SORT_BINS;
+    uint64_t* desc = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(h->sort_tmp) + sort_ws_desc_offset());
+    const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
+    HIP_TRY(h, hipMemsetAsync(h->sort_tmp, 0, sort_ws_bytes(n), h->stream));
+    // (one workgroup per CU: every workgroup ends with up to 2048 global atomic adds into the same 2048 counters)
+    GPF_LAUNCH(k_sort_keys_hist, dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
+    for (int p = 0; p < SORT_PASSES; ++p) {
+        const uint64_t* kin = (p & 1) ? h->keys_out : h->keys;
+        uint64_t* kout = (p & 1) ? h->keys : h->keys_out;
+        const int32_t* vin = p == 0 ? nullptr : ((p & 1) ? h->idx_in : h->order);
+        int32_t* vout = (p & 1) ? h->order : h->idx_in;
+        GPF_LAUNCH(k_sort_pass, dim3((unsigned)nt), dim3(BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout);
+    }
+    HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
 
@@ -671,10 +692,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     if ((s = materialize(h))) return s;                          // two resamples in a row: finish the first one
     // sortperm(log_priorities, rev=true)  (resample.jl:156-157)
     if (sorted) {
-        if ((s = ensure_sort_buffers(h))) return s;
-        GPF_LAUNCH(k_sort_keys, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, pv, h->n, h->keys);
-        HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, h->sort_tmp_bytes, h->keys, h->keys_out, h->idx_in, h->order,
-                                                      (int)h->n, 0, 64, h->stream));
+        if ((s = sort_desc(h, pv, h->n))) return s;
     }
     // safe_softmax(log_priorities) (resample.jl:54) and logsumexp(log_weights) (resample.jl:180)
     WSum* ws;
@@ -1410,12 +1428,9 @@ static gpf_status resize_optimal(gpf_handle h, int64_t n_new, int32_t check, int
     if (n_new < 1 || n_new > n_old) return fail(h, GPF_ERR_INVALID_ARGUMENT, "optimal resize: need 1 <= n_particles <= current count");   // resize.jl:185
     gpf_status s;
     // sort(weights) (resize.jl:204), descending; safe_softmax + logsumexp (resize.jl:152,190) over that order
-    if ((s = ensure_sort_buffers(h))) return s;
     if ((s = ensure_residual_buffers(h))) return s;
     const PrioView pv = raw_view(h);
-    GPF_LAUNCH(k_sort_keys, dim3(grid_for(h, n_old, 8)), dim3(BLOCK), 0, h->stream, pv, n_old, h->keys);
-    HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, h->sort_tmp_bytes, h->keys, h->keys_out, h->idx_in, h->order,
-                                                  (int)n_old, 0, 64, h->stream));
+    if ((s = sort_desc(h, pv, n_old))) return s;
     WSum* ws = &h->sc->raw;
     h->raw_valid = false;
     if ((s = summarize(h, pv, ws, true, h->order, true))) return s;
@@ -1705,7 +1720,7 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
         h->h_shard_counts[2 * MAX_SHARDS] = 0;
     }
     h->max_valid = false;
-    InFixQ in{raw_view(h), nullptr, h->K, 0.0, 0};
+    InFixQ in{raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
     const int gs = scan_grid(h);
     // the scan folds the gathered (max, flags) pairs itself and writes the shard total straight into out5[0]; it also
     // publishes the global validity flags to pinned host memory (gpf_shard_flags)
