@@ -284,6 +284,10 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "particles_per_gpu": n_local, "particles_total": n_global, "T": K,
                        "state_dim": model.dim, "parallelism": f"particle-shard x{world}"},
+            "shard_engine": (None if not sharded_mode else
+                             (f"library: gpf_shard_resample on libgpf's own RCCL communicator of {world} rank(s)"
+                              if getattr(state.backend, "lib_comm", False) else
+                              f"python: sharded.py composes the phases over torch.distributed ({dist.get_backend() if dist is not None and dist.is_initialized() else 'no'} backend, {world} rank(s))")),
             "log_ml_estimate": lml, "log_ml_exact_kalman": lml_exact, "log_ml_abs_error": abs(lml - lml_exact),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
             "stratified_variant": strat, "local_resample_variant": island,

@@ -82,6 +82,12 @@ SYMBOLS = [
     ("gpf_shard_push", C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int64, C.c_void_p]),
     ("gpf_shard_commit", C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
     ("gpf_shard_lml_est", C.c_int, [_H, _pd]),
+    ("gpf_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("gpf_comm_create", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
+    ("gpf_comm_destroy", C.c_int, [_H]),
+    ("gpf_shard_resample", C.c_int, [_H, C.c_int32, C.c_int32, _pi32]),
+    ("gpf_shard_effective_sample_size", C.c_int, [_H, _pd]),
+    ("gpf_shard_log_ml_estimate", C.c_int, [_H, _pd]),
     # host-side scalar spec
     ("gpf_host_fix_K", C.c_int32, [C.c_int64]),
     ("gpf_host_log", C.c_double, [C.c_double]),

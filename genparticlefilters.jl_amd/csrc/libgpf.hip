@@ -9,6 +9,8 @@
 #include "gpf_kernels.hpp"
 
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h>        // types and enums only: librccl is loaded with dlopen (gpf_comm_create), nothing links against it
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -99,6 +101,11 @@ struct gpf_filter {
     uint64_t parent_generation = 0;
     uint64_t mutations = 0;              // bumped by every change of the rows / log-weights of this filter (through any handle)
     uint64_t seen_mutations = 0;         // view: the parent's counter when this view's cached summaries were valid
+    // multi-GPU: the library's own RCCL communicator and the device scratch of gpf_shard_resample
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    double *sh_mf = nullptr, *sh_mf_all = nullptr; int64_t *sh_tot = nullptr, *sh_tot_all = nullptr, *sh_cr = nullptr, *sh_cr_all = nullptr;
+    double *sh_send = nullptr, *sh_recv = nullptr; int64_t sh_send_cap = 0, sh_recv_cap = 0;
     int32_t* h_timeout = nullptr;        // pinned: set by a scan whose bounded inter-workgroup wait gave up (checked on the host)
     int scan_blocks_per_cu = 2;          // resident scan workgroups per CU the launch may rely on (occupancy query)
     int64_t* shard_counts = nullptr;     // [2 * MAX_SHARDS] exchange counters of the current resample (device) + pinned mirror
@@ -901,6 +908,7 @@ gpf_status gpf_destroy(gpf_handle h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    gpf_comm_destroy(h);
     hist_clear(h);
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers
@@ -1889,7 +1897,249 @@ gpf_status gpf_shard_lml_est(gpf_handle h, double* out)
     return GPF_OK;
 }
 
+} // extern "C"
+
+// =================================================================================== the sharded resample in one call
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+// librccl, once per process: the copy that is already mapped (a host such as PyTorch brings its own) or the ROCm one
+bool rccl_load(std::string& err)
+{
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    void* L = nullptr;
+    for (const char* n : names) if ((L = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!L) for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((L = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!L) { err = std::string("librccl not found: ") + dlerror(); return false; }
+#define GPF_RCCL_SYM(field, name) *reinterpret_cast<void**>(&g_rccl.field) = dlsym(L, name); if (!g_rccl.field) { err = std::string("librccl lacks ") + name; return false; }
+    GPF_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") GPF_RCCL_SYM(CommInitRank, "ncclCommInitRank") GPF_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    GPF_RCCL_SYM(AllGather, "ncclAllGather") GPF_RCCL_SYM(Send, "ncclSend") GPF_RCCL_SYM(Recv, "ncclRecv")
+    GPF_RCCL_SYM(GroupStart, "ncclGroupStart") GPF_RCCL_SYM(GroupEnd, "ncclGroupEnd") GPF_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef GPF_RCCL_SYM
+    g_rccl.lib = L;
+    return true;
+}
+#define NCCL_TRY(h, expr)                                                                       \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess) return fail(h, GPF_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+// all-gather of `count` elements per rank on the handle's stream; a 1-rank communicator still goes through RCCL when the
+// environment asks for it (GPF_SHARD_FORCE_COLLECTIVES=1: exercises the call path on a 1-GPU box), else it is a copy
+gpf_status shard_all_gather(gpf_filter* h, const void* src, void* dst, size_t count, ncclDataType_t dt, size_t elem)
+{
+    static const bool force = getenv("GPF_SHARD_FORCE_COLLECTIVES") && !strcmp(getenv("GPF_SHARD_FORCE_COLLECTIVES"), "1");
+    if (h->comm_world == 1 && !(force && h->comm)) {
+        HIP_TRY(h, hipMemcpyAsync(dst, src, count * elem, hipMemcpyDeviceToDevice, h->stream));
+        return GPF_OK;
+    }
+    NCCL_TRY(h, g_rccl.AllGather(src, dst, count, dt, h->comm, h->stream));
+    return GPF_OK;
+}
+gpf_status shard_scratch(gpf_filter* h)
+{
+    if (h->sh_mf) return GPF_OK;
+    const size_t G = (size_t)h->comm_world;
+    HIP_TRY(h, hipMalloc(&h->sh_mf, 2 * sizeof(double)));       HIP_TRY(h, hipMalloc(&h->sh_mf_all, 2 * G * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->sh_tot, 5 * sizeof(int64_t)));     HIP_TRY(h, hipMalloc(&h->sh_tot_all, 5 * G * sizeof(int64_t)));
+    HIP_TRY(h, hipMalloc(&h->sh_cr, 2 * sizeof(int64_t)));      HIP_TRY(h, hipMalloc(&h->sh_cr_all, 2 * G * sizeof(int64_t)));
+    HIP_TRY(h, hipMemsetAsync(h->sh_tot, 0, 5 * sizeof(int64_t), h->stream));
+    return GPF_OK;
+}
+// phases 1 + 2 of DESIGN.md §6: (max, flags) and {S, sum q^2 limbs} of every shard, gathered on every rank
+gpf_status shard_summary(gpf_filter* h, int want_q)
+{
+    gpf_status s = shard_scratch(h);
+    if (s) return s;
+    if ((s = gpf_shard_weight_max(h, h->sh_mf))) return s;
+    if ((s = shard_all_gather(h, h->sh_mf, h->sh_mf_all, 2, ncclDouble, sizeof(double)))) return s;
+    if ((s = gpf_shard_weight_scan(h, h->sh_mf_all, h->comm_world, want_q, h->sh_tot))) return s;
+    return shard_all_gather(h, h->sh_tot, h->sh_tot_all, 5, ncclInt64, sizeof(int64_t));
+}
+// the gathered summaries on the host: global max, flags, S and sum q^2
+gpf_status shard_scalars(gpf_filter* h, double& m, int& flags, uint64_t& S, uint64_t& Qhi, uint64_t& Qlo)
+{
+    const int G = h->comm_world;
+    std::vector<double> mf(2 * (size_t)G); std::vector<int64_t> tot(5 * (size_t)G);
+    HIP_TRY(h, hipMemcpyAsync(mf.data(), h->sh_mf_all, mf.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(tot.data(), h->sh_tot_all, tot.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    m = -HUGE_VAL; flags = 0; S = 0;
+    unsigned __int128 Q = 0;
+    for (int g = 0; g < G; ++g) {
+        m = std::max(m, mf[2 * g]); flags |= (int)mf[2 * g + 1]; S += (uint64_t)tot[5 * g];
+        for (int k = 0; k < 4; ++k) Q += (unsigned __int128)(uint64_t)tot[5 * g + 1 + k] << (32 * k);
+    }
+    if (!(flags & FLAG_NAN) && m == -HUGE_VAL) flags |= FLAG_ALL_NEGINF;
+    Qhi = (uint64_t)(Q >> 64); Qlo = (uint64_t)Q;
+    return check_scan_timeout(h);
+}
+} // namespace
+
+extern "C" {
+
+gpf_status gpf_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null id");
+    std::string err;
+    if (!rccl_load(err)) return fail(nullptr, GPF_ERR_HIP, err);
+    static_assert(sizeof(ncclUniqueId) == 128, "the ABI hands the id over as 128 bytes");
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return fail(nullptr, GPF_ERR_HIP, "ncclGetUniqueId failed");
+    memcpy(id128, &id, sizeof(id));
+    return GPF_OK;
+}
+
+gpf_status gpf_comm_create(gpf_handle h, const void* id128, int32_t rank, int32_t world)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (world < 1 || world > MAX_SHARDS || rank < 0 || rank >= world) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad rank / world (<= 64 shards)");
+    if (h->parent) return fail(h, GPF_ERR_STATE, "a sub-state view has no communicator");
+    if (h->comm || h->sh_mf) return fail(h, GPF_ERR_STATE, "the handle already has a communicator");
+    if (world > 1 && !id128) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null id");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    h->comm_rank = rank; h->comm_world = world;
+    if (id128) {                                                 // (world == 1 without an id: no RCCL at all)
+        std::string err;
+        if (!rccl_load(err)) return fail(h, GPF_ERR_HIP, err);
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof(id));
+        NCCL_TRY(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
+    }
+    return shard_scratch(h);
+}
+
+gpf_status gpf_comm_destroy(gpf_handle h)
+{
+    if (!h) return GPF_OK;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
+    void* bufs[] = {h->sh_mf, h->sh_mf_all, h->sh_tot, h->sh_tot_all, h->sh_cr, h->sh_cr_all, h->sh_send, h->sh_recv};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    h->sh_mf = h->sh_mf_all = nullptr; h->sh_tot = h->sh_tot_all = h->sh_cr = h->sh_cr_all = nullptr;
+    h->sh_send = h->sh_recv = nullptr; h->sh_send_cap = h->sh_recv_cap = 0;
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED)
+        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");             // resample.jl:28
+    if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_shard_resample needs gpf_comm_create first");
+    const int G = h->comm_world, me = h->comm_rank;
+    const int64_t n = h->n, E = h->W + 1;
+    // shard bounds from the contiguous-range rule every rank applies to its own gpf_config (ranks ordered by gid0)
+    std::vector<int64_t> bounds((size_t)G + 1);
+    {
+        const int64_t base = h->cfg.n_global / G, extra = h->cfg.n_global % G;
+        for (int g = 0; g <= G; ++g) bounds[g] = (int64_t)g * base + std::min<int64_t>(g, extra);
+        if (bounds[me] != h->cfg.gid0 || bounds[me + 1] != h->cfg.gid0 + n)
+            return fail(h, GPF_ERR_STATE, "this shard's (gid0, n_particles) is not rank's contiguous share of n_global");
+    }
+    if ((s = shard_summary(h, 0))) return s;                      // phases 1, 2
+    if (check != GPF_CHECK_FALSE || invalid) {                    // safe_softmax validity (utils.jl:117-140): pinned flags, no stream sync
+        int32_t flags = 0;
+        if ((s = gpf_shard_flags(h, &flags))) return s;
+        if (invalid) *invalid = flags != 0;
+        if (flags & (FLAG_NAN | FLAG_POSINF)) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights (NaN).");
+        if (check == GPF_CHECK_TRUE && flags) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights.");   // resample.jl:55
+    }
+    const int64_t* cr_all = nullptr;
+    if (method == GPF_RESAMPLE_RESIDUAL) {                        // phase 2b
+        if ((s = gpf_shard_residual_scan(h, h->sh_tot_all, G, h->sh_cr))) return s;
+        if ((s = shard_all_gather(h, h->sh_cr, h->sh_cr_all, 2, ncclInt64, sizeof(int64_t)))) return s;
+        cr_all = h->sh_cr_all;
+    }
+    if ((s = gpf_shard_push_count(h, method, h->sh_tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
+    // phase 4 is enqueued before the host learns the counts, into a send buffer sized for a balanced exchange with slack;
+    // the kernel stops at the capacity and the push is repeated if the counts say it overflowed
+    auto ensure = [&](double*& buf, int64_t& cap, int64_t want) -> gpf_status {
+        if (cap >= want) return GPF_OK;
+        if (buf) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(buf); buf = nullptr; cap = 0; }
+        HIP_TRY(h, hipMalloc(&buf, (size_t)want * E * sizeof(double)));
+        cap = want;
+        return GPF_OK;
+    };
+    int64_t cap = std::min<int64_t>(h->cfg.n_global, 2 * n + 65536);
+    if (const char* e = getenv("GPF_PUSH_CAPACITY")) cap = atoll(e);                                  // tests: force the overflow path
+    if ((s = ensure(h->sh_send, h->sh_send_cap, std::max<int64_t>(cap, 1)))) return s;
+    if ((s = ensure(h->sh_recv, h->sh_recv_cap, n))) return s;
+    if ((s = gpf_shard_push(h, method, h->sh_tot_all, cr_all, G, me, bounds.data(), cap, h->sh_send))) return s;
+    std::vector<int64_t> counts(2 * (size_t)G);
+    if ((s = gpf_shard_counts(h, G, counts.data()))) return s;   // ONE host wait (the exchange's split sizes), behind phase 4
+    int64_t n_send = 0, n_recv = 0;
+    for (int g = 0; g < G; ++g) { n_send += counts[g]; n_recv += counts[G + g]; }
+    if (n_recv != n) return fail(h, GPF_ERR_STATE, "exchange counts do not add up to the shard's slots");
+    if (n_send > cap) {                                           // skewed weights: this shard serves more than its buffer held
+        if ((s = ensure(h->sh_send, h->sh_send_cap, n_send))) return s;
+        if ((s = gpf_shard_push(h, method, h->sh_tot_all, cr_all, G, me, bounds.data(), n_send, h->sh_send))) return s;
+    }
+    // the exchange: [row | slot | ancestor id], grouped point-to-point sends and receives (one pair per peer)
+    static const bool force = getenv("GPF_SHARD_FORCE_COLLECTIVES") && !strcmp(getenv("GPF_SHARD_FORCE_COLLECTIVES"), "1");
+    if (G == 1 && !(force && h->comm)) {
+        HIP_TRY(h, hipMemcpyAsync(h->sh_recv, h->sh_send, (size_t)n * E * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        NCCL_TRY(h, g_rccl.GroupStart());
+        int64_t so = 0, ro = 0;
+        for (int g = 0; g < G; ++g) {
+            if (counts[g]) NCCL_TRY(h, g_rccl.Send(h->sh_send + so * E, (size_t)(counts[g] * E), ncclDouble, g, h->comm, h->stream));
+            if (counts[G + g]) NCCL_TRY(h, g_rccl.Recv(h->sh_recv + ro * E, (size_t)(counts[G + g] * E), ncclDouble, g, h->comm, h->stream));
+            so += counts[g]; ro += counts[G + g];
+        }
+        NCCL_TRY(h, g_rccl.GroupEnd());
+    }
+    return gpf_shard_commit(h, h->sh_recv, n, h->sh_mf_all, h->sh_tot_all, G);                      // phase 5 (deferred)
+}
+
+gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
+    if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "needs gpf_comm_create first");
+    if ((s = shard_summary(h, 1))) return s;
+    double m; int flags; uint64_t S, Qhi, Qlo;
+    if ((s = shard_scalars(h, m, flags, S, Qhi, Qlo))) return s;
+    *out = flags ? std::nan("") : ess_from(S, Qhi, Qlo);
+    return GPF_OK;
+}
+
+gpf_status gpf_shard_log_ml_estimate(gpf_handle h, double* out)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
+    if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "needs gpf_comm_create first");
+    if ((s = shard_summary(h, 0))) return s;
+    double m; int flags; uint64_t S, Qhi, Qlo;
+    if ((s = shard_scalars(h, m, flags, S, Qhi, Qlo))) return s;
+    double base;
+    if ((s = gpf_shard_lml_est(h, &base))) return s;
+    *out = base + lse_from(m, S, h->K, flags) - h->logN;
+    return GPF_OK;
+}
+
+} // extern "C"
+
 // =================================================================================== host scalar spec
+extern "C" {
 int32_t gpf_host_fix_K(int64_t n_global) { return fix_K(n_global); }
 double gpf_host_log(double x) { return log_(x); }
 double gpf_host_lse(double m, uint64_t S, int32_t K, int32_t flags)

@@ -67,6 +67,7 @@ class HipShardBackend:
                                                n_global=n_global, gid0=gid0, stream=stream)
         self.L, self.h = self.state._L, self.state._h
         self.n, self.W = n_local, self.state.row_width
+        self.lib_comm = False
 
     def _ck(self, st):
         self.state._check(st)
@@ -126,6 +127,40 @@ class HipShardBackend:
         packed = packed.contiguous()
         self._ck(self.L.gpf_shard_commit(self.h, packed.data_ptr(), packed.shape[0], mf_all.data_ptr(), tot_all.data_ptr(), tot_all.shape[0]))
         self._keep = (packed, mf_all, tot_all)             # alive until the stream has consumed them
+
+    # ---- the library's own communicator: the whole resample behind one C-ABI call (gpf_shard_resample)
+    def comm_create(self, rank: int, world: int, group=None):
+        """RCCL communicator owned by libgpf (gpf_comm_create).  The 128-byte id is made by rank 0 and handed round with
+        torch.distributed's object broadcast -- any channel would do, the library only needs the bytes."""
+        idbuf = None
+        if world > 1 or _FORCE_COLLECTIVES:
+            blob = [None]
+            if rank == 0:
+                raw = (C.c_char * 128)()
+                self._ck(self.L.gpf_comm_unique_id(C.cast(raw, C.c_void_p)))
+                blob = [bytes(raw)]
+            if world > 1:
+                dist.broadcast_object_list(blob, src=0, group=group)
+            idbuf = (C.c_char * 128).from_buffer_copy(blob[0])
+        self._ck(self.L.gpf_comm_create(self.h, C.cast(idbuf, C.c_void_p) if idbuf is not None else None, rank, world))
+        self.lib_comm = True
+
+    def shard_resample(self, method_id: int, check) -> bool:
+        """pf_resample!(state, method; check) over all shards, collectives issued by the library; returns `invalid`"""
+        chk = 2 if check is True else (1 if check == "warn" else 0)
+        inv = C.c_int32(0)
+        self._ck(self.L.gpf_shard_resample(self.h, method_id, chk, C.byref(inv) if chk else None))
+        return bool(inv.value)
+
+    def shard_ess(self) -> float:
+        out = C.c_double()
+        self._ck(self.L.gpf_shard_effective_sample_size(self.h, C.byref(out)))
+        return out.value
+
+    def shard_lml(self) -> float:
+        out = C.c_double()
+        self._ck(self.L.gpf_shard_log_ml_estimate(self.h, C.byref(out)))
+        return out.value
 
     def local_resample(self, method, priority_fn, check, sort_particles):
         """resample THIS shard's particles among themselves with the reference's sub-state semantics: a view of the whole shard"""
@@ -230,6 +265,11 @@ def pf_initialize(model, model_args, observations, n_particles: int, *, seed: in
     factory = backend_factory or HipShardBackend
     backend = factory(model, n_particles, gid0, n_local, seed, keep_prev, device)
     st = ShardedParticleFilterState(backend, model, n_particles, rank, world, group)
+    # engine: "library" = gpf_shard_resample with the library's own RCCL communicator (the default wherever the process group
+    # is RCCL, and for a single rank), "python" = the phase-by-phase composition below (gloo tests, oracle backend)
+    engine = os.environ.get("GPF_SHARD_ENGINE") or ("library" if hasattr(backend, "comm_create") and (world == 1 or dist.get_backend(group) == "nccl") else "python")
+    if engine == "library":
+        backend.comm_create(rank, world, group)
     backend.initialize(_obs_vector(observations))
     return st
 
@@ -268,6 +308,15 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
     if method == "stratified" and sort_particles:
         raise ErrorException("sharded stratified resampling needs sort_particles=False (no global sort; SURVEY.md H8)")
     b, G, mid = state.backend, state.world, RESAMPLE_METHODS[method]
+    if getattr(b, "lib_comm", False):                                 # the whole exchange inside the library (RCCL)
+        try:
+            invalid = b.shard_resample(mid, check)
+        except ErrorException as e:
+            raise ErrorException("Invalid weights.") if "Invalid weights" in str(e) else e
+        if invalid and check == "warn":
+            import warnings
+            warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")
+        return state
     mf_all, tot_all = state._summary(want_q=False)                    # phases 1, 2 (no sum q^2: only the ESS needs it)
     if check is not False:                                            # safe_softmax validity (utils.jl:117-140), no stream sync
         flags = b.scan_flags()
@@ -295,6 +344,8 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
 
 def effective_sample_size(state: ShardedParticleFilterState) -> float:
     """src/utils.jl:163-164 over the global weights"""
+    if getattr(state.backend, "lib_comm", False):
+        return state.backend.shard_ess()
     m, flags, S, Q = state._summary_scalars()
     if flags or m == -np.inf:
         return float("nan")
@@ -306,6 +357,8 @@ get_ess = effective_sample_size
 
 def log_ml_estimate(state: ShardedParticleFilterState) -> float:
     """Gen.log_ml_estimate over the global weights"""
+    if getattr(state.backend, "lib_comm", False):
+        return state.backend.shard_lml()
     m, flags, S, Q = state._summary_scalars()
     b = state.backend
     return b.lml_est() + b.host_lse(m, S, state.K, flags) - b.host_log(float(state.n_global))

@@ -280,6 +280,26 @@ int32_t gpf_host_fix_K(int64_t n_global);
 double  gpf_host_log(double x);
 double  gpf_host_lse(double m, uint64_t S, int32_t K, int32_t flags);     /* m + log(S 2^-K) */
 double  gpf_host_ess(uint64_t S, uint64_t Q_hi, uint64_t Q_lo);           /* S^2 / Q */
+/* ---- the sharded resample behind ONE call (multi-GPU hosts need nothing but these five entry points) -----------------
+ * A filter whose handle was created with n_global > n_particles is one shard of a filter spread over `world` processes, one
+ * GPU each.  gpf_comm_create gives the handle an RCCL communicator (librccl is loaded with dlopen the first time; nothing is
+ * linked against it); gpf_shard_resample then runs the whole global resample of DESIGN.md §6 -- weight maximum, all-gather,
+ * fixed-point scan under the global maximum, all-gather of the shard totals (+ the residual counts), push count / push,
+ * ONE variable-size exchange of packed rows (grouped ncclSend / ncclRecv: point-to-point pairs over xGMI), deferred commit --
+ * on the handle's stream, every collective issued by the library.  It stands in for pf_resample!(state, method; check)
+ * (src/resample.jl:19-30) on a sharded state; priority_fn and sort_particles are not available across shards.
+ *   gpf_comm_unique_id: 128-byte id made by ONE process (ncclGetUniqueId) and handed to all others by the host's own means
+ *   (MPI, Distributed.jl, torch.distributed, a file);  rank r of `world` owns the global range [gid0, gid0 + n) its
+ *   gpf_config names; ranks are ordered by gid0.
+ *   gpf_shard_effective_sample_size / gpf_shard_log_ml_estimate: the getters of src/utils.jl:163-186 over ALL shards
+ *   (two all-gathers each; every rank gets the same value). */
+gpf_status gpf_comm_unique_id(void* id128);
+gpf_status gpf_comm_create(gpf_handle h, const void* id128, int32_t rank, int32_t world);
+gpf_status gpf_comm_destroy(gpf_handle h);
+gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid);
+gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out);
+gpf_status gpf_shard_log_ml_estimate(gpf_handle h, double* out);
+
 /* test hook: copy one level of the weight CDF left by the last scan of channel 0 to the host.
  * which: 0 cdf (u64 per padded cell), 1 per-16 prefixes (u64), 2 per-256 prefixes (u64), 3 4-byte keys (u32 per 32 cells),
  * 4 16-bit in-group offsets (u16 per padded cell), 5 coarse offset rows (u16).  *n_bytes: capacity in, bytes written out. */

@@ -9,8 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out_dir, backend="gloo"):
+def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out_dir, backend="gloo", engine=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
+    if engine:
+        os.environ["GPF_SHARD_ENGINE"] = engine            # "library": gpf_shard_resample (libgpf's own RCCL communicator); "python": sharded.py composes the phases
     os.environ["MASTER_PORT"] = str(port)
     if backend == "nccl":
         os.environ["GPF_SHARD_FORCE_COLLECTIVES"] = "1"     # read at import of gpf_amd.sharded

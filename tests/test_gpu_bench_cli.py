@@ -23,3 +23,38 @@ def test_driver_command_line(built, argv):
     assert r and r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and r["kernel"]
     assert c and c["cores"] == 1 and c["kind"] == "port" and c["value"] > 0
     assert out["log_ml_abs_error"] < 1.0
+
+
+def _last_json(stdout):
+    return json.loads([ln for ln in stdout.strip().splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_device_smoke(built):
+    """the driver's multi-GPU command line with two ranks, both on cuda:0 (collectives staged through gloo: RCCL refuses two
+    ranks on one device): exercises rank/world plumbing, the sharded legs and the barrier + max-over-ranks timing"""
+    env = dict(os.environ, GPF_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--particles-per-gpu", "200000"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _last_json(p.stdout)
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["config"]["particles_total"] == 400000
+    assert out["scaling"] == "weak" and out["value"] > 0
+    assert out["stratified_variant"]["value"] > 0 and out["local_resample_variant"]["value"] > 0
+    assert out["shard_engine"].startswith("python") and out["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_sharded_path_with_rccl_one_rank(built):
+    """one rank, the sharded code path, every collective issued by the library on a real (1-rank) RCCL communicator"""
+    env = dict(os.environ, GPF_BENCH_FORCE_SHARDED="1", GPF_SHARD_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29733",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _last_json(p.stdout)
+    assert out["n_gpus"] == 1 and out["shard_engine"].startswith("library") and out["value"] > 5e7
+    assert out["roofline"]["kernel"] in ("k_push", "k_push_scan", "k_step", "k_scan")
+    assert abs(out["log_ml_abs_error"]) < 1.0

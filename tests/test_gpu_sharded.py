@@ -56,13 +56,16 @@ def test_hip_push_overflow_path(g, o, tmp_path, monkeypatch):
     test_world1_sharded_equals_unsharded(g, o)
 
 
+@pytest.mark.parametrize("engine", ["library", "python"])
 @pytest.mark.parametrize("case", CASES[:3], ids=[f"{c[0]}-{c[1]}" for c in CASES[:3]])
-def test_rccl_collectives_one_rank(g, o, tmp_path, case):
-    """the REAL collectives (all_gather_into_tensor, all_to_all_single with split sizes) on the nccl = RCCL backend in a
-    1-rank process group: the call path the multi-GPU runs take, as far as a 1-GPU box can exercise it"""
+def test_rccl_collectives_one_rank(g, o, tmp_path, case, engine):
+    """the REAL collectives on RCCL in a 1-rank group: the call path the multi-GPU runs take, as far as a 1-GPU box can
+    exercise it.  engine = library: gpf_shard_resample -- ncclAllGather and the grouped ncclSend / ncclRecv exchange issued by
+    libgpf on its own communicator (gpf_comm_create), what a Julia host gets for one ccall;  engine = python: sharded.py
+    composes the phases with torch.distributed (all_gather_into_tensor, all_to_all_single with split sizes)"""
     model_name, method, n_global, T, ess_frac, rejuv = case
     n_global *= 20
-    mp.spawn(shard_worker_gpu.run, args=(1, free_port(), model_name, method, n_global, T, ess_frac, rejuv, str(tmp_path), "nccl"),
+    mp.spawn(shard_worker_gpu.run, args=(1, free_port(), model_name, method, n_global, T, ess_frac, rejuv, str(tmp_path), "nccl", engine),
              nprocs=1, join=True)
     f, ess_log, lml_log = single(g, o, model_name, method, n_global, T, ess_frac, rejuv)
     p = np.load(os.path.join(tmp_path, "rank0.npz"))
