@@ -237,4 +237,59 @@ function sample_unweighted_traces(s::DeviceParticleFilterState, n::Int)
     permutedims(rows)[:, 1:dim[]], idx
 end
 
+# ---------------------------------------------------------------- multi-GPU: one process per GPU, the exchange inside libgpf
+# A shard of a filter of `n_global` particles: rank r of `world` holds the contiguous global range that starts at gid0 (the
+# first n_global % world ranks hold one particle more).  The communicator is libgpf's own (RCCL); the host only carries the
+# 128-byte id from rank 0 to the others, e.g.  id = MPI.bcast(rank == 0 ? comm_unique_id() : nothing, 0, comm).
+mutable struct ShardedDeviceParticleFilterState
+    handle::Ptr{Cvoid}
+    model::NativeModel
+    n_particles::Int          # this shard
+    n_global::Int
+    rank::Int
+    world::Int
+end
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    ccall((:gpf_comm_unique_id, libgpf), Cint, (Ptr{UInt8},), id) == 0 || error("gpf_comm_unique_id failed")
+    return id
+end
+function pf_initialize(model::NativeModel, model_args::Tuple, observations::Vector{Float64}, n_global::Int, id::Vector{UInt8},
+                       rank::Int, world::Int; seed::Integer=1, keep_prev::Bool=false, device::Integer=0)
+    base, extra = divrem(n_global, world)
+    n = base + (rank < extra ? 1 : 0); gid0 = rank * base + min(rank, extra)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve model begin
+        cfg = Ref(GpfConfig(GPF_ABI_VERSION, model.id, length(model.params), keep_prev, pointer(model.params),
+                            n, n_global, gid0, UInt64(seed), device, 0, C_NULL))
+        ccall((:gpf_create, libgpf), Cint, (Ref{GpfConfig}, Ref{Ptr{Cvoid}}), cfg, h) == 0 ||
+            error(unsafe_string(ccall((:gpf_last_error, libgpf), Cstring, (Ptr{Cvoid},), C_NULL)))
+    end
+    s = ShardedDeviceParticleFilterState(h[], model, n, n_global, rank, world)
+    finalizer(x -> ccall((:gpf_destroy, libgpf), Cint, (Ptr{Cvoid},), x.handle), s)
+    check(s, ccall((:gpf_comm_create, libgpf), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), s.handle, id, rank, world))
+    check(s, ccall((:gpf_initialize, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), s.handle, observations, length(observations)))
+    return s
+end
+function pf_update!(s::ShardedDeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Vector{Float64})
+    check(s, ccall((:gpf_update, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), s.handle, observations, length(observations))); s
+end
+function pf_rejuvenate!(s::ShardedDeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1; method::Symbol=:move)
+    m = method == :move ? 0 : method == :reweight ? 1 : error("Method $method not recognized.")
+    check(s, ccall((:gpf_rejuvenate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, C_NULL)); s
+end
+# src/resample.jl:19-30 over all shards: ONE call, every collective issued by the library
+function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multinomial; check=:warn)
+    m = method == :multinomial ? 0 : method == :residual ? 1 : method == :stratified ? 2 : error("Resampling method $method not recognized.")
+    chk = check === true ? 2 : (check === :warn ? 1 : 0)
+    invalid = Ref{Cint}(0)
+    check(s, ccall((:gpf_shard_resample, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cint}), s.handle, m, chk, invalid))
+    check === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
+    return s
+end
+effective_sample_size(s::ShardedDeviceParticleFilterState) = _scalar(s, :gpf_shard_effective_sample_size)
+get_ess(s::ShardedDeviceParticleFilterState) = effective_sample_size(s)
+log_ml_estimate(s::ShardedDeviceParticleFilterState) = _scalar(s, :gpf_shard_log_ml_estimate)
+get_lml_est(s::ShardedDeviceParticleFilterState) = log_ml_estimate(s)
+
 end # module
