@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
 //            (G/8)-th cell -> which run of CS = G / 8 cells;
 //   level 3, one CS*2-byte read per lane: the offsets of that run -> the cell.  Equal offsets: the exact prefixes decide.
 // Both offset arrays are written by the scan (ScanOut::off16 / coarse), 2.5 N bytes together: they stay in L2.
-constexpr int MULTI_LDS_BUDGET = 160 * 1024 - 1024;
+constexpr int MULTI_LDS_BUDGET = 160 * 1024 - 2048;            // (the kernels keep up to ~1 KiB of static LDS besides the table)
 __host__ __device__ __forceinline__ int64_t multi_groups(int64_t ntiles, int logg) { return (ntiles * (TILE / 32)) >> logg; }
 // LDS copy of the keys: one pad word per 32 entries.  The uniform binary search probes at power-of-two strides; unpadded,
 // every probe of the middle steps would land in the same bank (64-way conflicts)
@@ -1109,30 +1109,165 @@ __device__ __forceinline__ uint32_t pk_ne(uint32_t x, uint32_t qq)
 #ifndef GPF_MULTI_NS
 #define GPF_MULTI_NS 4
 #endif
+struct MultiTable { const uint32_t* keys; uint32_t ng, p2; float kscale; };      // the LDS key table of k_search_multi
+constexpr uint32_t MULTI_WIN = 512;                // interpolation window of the key search
+
+// idx[u] = first cell whose prefix exceeds T[u], for the lane's NS independent targets (wave-collective: the fast paths are
+// taken when every lane of the wave can take them).  Levels as described above; LOGG as in the key table.
+template <int LOGG, int NS>
+__device__ __forceinline__ void multi_lookup(const MultiTable& tb, const CdfLevels& w, int64_t n_cells, const uint64_t (&T)[NS], uint32_t (&idx)[NS])
+{
+    constexpr int G = 32 << LOGG, CS = G / 8;
+    constexpr uint32_t WIN = MULTI_WIN;
+    uint32_t t[NS], pos[NS];
+    // ---- number of keys < t.  Fast path: the CDF of exchangeable weights is close to linear, so a window of WIN keys
+    //      around the interpolated position brackets the answer (checked); else the uniform binary search of the whole table
+    bool inwin = tb.ng >= 2 * WIN;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        t[u] = (uint32_t)(T[u] >> KEY_SHIFT);
+        const uint32_t pe = (uint32_t)((float)t[u] * tb.kscale);
+        uint32_t lo = pe > WIN / 2 ? pe - WIN / 2 : 0u;
+        lo = lo + WIN > tb.ng ? tb.ng - WIN : lo;
+        pos[u] = lo;
+    }
+    if (inwin) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+            inwin = inwin && (pos[u] == 0u || tb.keys[kpad(pos[u] - 1)] < t[u]) && tb.keys[kpad(pos[u] + WIN - 1)] >= t[u];
+    }
+    if (__all(inwin)) {
+#pragma unroll
+        for (uint32_t h = WIN / 2; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) pos[u] += tb.keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) pos[u] = tb.keys[kpad(tb.p2 - 1)] < t[u] ? tb.ng - tb.p2 : 0u;          // uniform binary search: no bounds checks below
+        for (uint32_t h = tb.p2 >> 1; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) pos[u] += tb.keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
+        }
+    }
+    bool amb = false;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const uint32_t k = tb.keys[kpad(pos[u])];                       // pos <= tb.ng - 1 here
+        pos[u] += k < t[u] ? 1u : 0u;                                // pos = number of keys < t: those groups end at or below T
+        amb = amb || k == t[u] || (k < t[u] && pos[u] < tb.ng && tb.keys[kpad(pos[u])] == t[u]);
+    }
+    if (__any(amb)) {
+        // equal keys: the exact prefix decides (rare: one key value in 2^32 S / (2^30 groups) per slot)
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+            while (pos[u] < tb.ng && tb.keys[kpad(pos[u])] == t[u] && w.cdf[(int64_t)pos[u] * G + (G - 1)] <= T[u]) ++pos[u];
+    }
+    // ---- inside the key group: the target as a 16-bit offset, then two narrow reads
+    uint32_t g[NS], qq[NS], run[NS];
+    uint4 row[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        g[u] = pos[u] < tb.ng ? pos[u] : tb.ng - 1;
+        const uint32_t klo = g[u] ? tb.keys[kpad(g[u] - 1)] : 0u, khi = tb.keys[kpad(g[u])];
+        const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
+        const uint64_t d = T[u] > kb ? T[u] - kb : 0;
+        uint32_t q = (uint32_t)(d >> key_quant_shift(klo, khi));
+        q = q < 65535u ? q : 65535u;
+        qq[u] = q | (q << 16);
+        row[u] = *reinterpret_cast<const uint4*>(w.coarse + (size_t)g[u] * 8);
+    }
+    bool tie[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        // run = number of coarse offsets < q (the last one, the group's end, is >= q: T lies in this group)
+        uint32_t c = pk_lt(row[u].x, qq[u]) + pk_lt(row[u].y, qq[u]) + pk_lt(row[u].z, qq[u]) + pk_lt(row[u].w, qq[u]);
+        c = (c & 0xffffu) + (c >> 16);
+        run[u] = c < 8u ? c : 7u;
+    }
+    uint4 fine[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const uint16_t* fp = w.off16 + (size_t)(g[u] * (uint32_t)G + run[u] * (uint32_t)CS);
+        if (CS == 4) { const uint2 f = *reinterpret_cast<const uint2*>(fp); fine[u] = make_uint4(f.x, f.y, 0xffffffffu, 0xffffffffu); }
+        else fine[u] = *reinterpret_cast<const uint4*>(fp);
+    }
+    bool anytie = false;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        uint32_t lt = pk_lt(fine[u].x, qq[u]) + pk_lt(fine[u].y, qq[u]);
+        uint32_t ne = pk_ne(fine[u].x, qq[u]) + pk_ne(fine[u].y, qq[u]);
+        if (CS != 4) {
+            lt += pk_lt(fine[u].z, qq[u]) + pk_lt(fine[u].w, qq[u]);
+            ne += pk_ne(fine[u].z, qq[u]) + pk_ne(fine[u].w, qq[u]);
+        }
+        lt = (lt & 0xffffu) + (lt >> 16); ne = (ne & 0xffffu) + (ne >> 16);
+        tie[u] = ne != (uint32_t)CS;
+        anytie = anytie || tie[u];
+        idx[u] = g[u] * (uint32_t)G + run[u] * (uint32_t)CS + lt;
+    }
+    if (__any(anytie)) {
+        // a cell of the run shares the target's offset: the exact prefixes decide.  Every cell before the run is below T
+        // (its run's coarse offset is < q); walk from the run's first cell -- equal offsets may continue into later runs
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (!tie[u]) continue;
+            uint32_t i = g[u] * (uint32_t)G + run[u] * (uint32_t)CS;
+            const uint32_t end = g[u] * (uint32_t)G + (uint32_t)G;
+            // the run's CS exact prefixes in one round trip; only a run that lies entirely at or below T walks on
+            const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(w.cdf + i);
+            uint32_t c = 0;
+#pragma unroll
+            for (int e = 0; e < CS / 2; ++e) { const ulonglong2 v = cp[e]; c += (uint32_t)(v.x <= T[u]) + (uint32_t)(v.y <= T[u]); }
+            i += c;
+            if (c == (uint32_t)CS) while (i < end && w.cdf[i] <= T[u]) ++i;
+            idx[u] = i;
+        }
+    }
+    const uint32_t last = (uint32_t)(n_cells - 1);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) idx[u] = idx[u] < last ? idx[u] : last;
+}
+
+// block-collective: the key table into LDS, 16 B per lane from the scan's key level (every (1 << LOGG)-th key).  The loads are
+// issued first, `between()` runs while they are in flight (the caller's first targets), then the table is written.
+template <int LOGG, class Between>
+__device__ __forceinline__ MultiTable multi_table_load(const CdfLevels& w, int64_t ntiles, uint64_t S, uint32_t* keys, Between&& between)
+{
+    constexpr int KT = (MULTI_LDS_BUDGET / 4 / (LOGG == 0 ? 4 : 2) + SBLOCK - 1) / SBLOCK;   // 16-byte source loads per lane that cover any table within the budget
+    MultiTable tb;
+    tb.keys = keys;
+    tb.ng = (uint32_t)multi_groups(ntiles, LOGG);                       // >= 64 >> LOGG
+    const uint32_t nq = LOGG == 0 ? tb.ng / 4 : tb.ng / 2;
+    uint4 kv[KT];
+    const uint4* src = reinterpret_cast<const uint4*>(w.k32);
+#pragma unroll
+    for (int r = 0; r < KT; ++r) { const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK; if (q < nq) kv[r] = src[q]; }
+    tb.p2 = 1;                                                           // largest power of two <= ng
+    while (2 * tb.p2 <= tb.ng) tb.p2 *= 2;
+    tb.kscale = (float)tb.ng / (float)((S >> KEY_SHIFT) + 1);            // groups per key unit: where a key would sit were the CDF linear
+    between();
+#pragma unroll
+    for (int r = 0; r < KT; ++r) {
+        const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK;
+        if (q < nq) {
+            if (LOGG == 0) { uint32_t* d = keys + kpad(4 * q); d[0] = kv[r].x; d[1] = kv[r].y; d[2] = kv[r].z; d[3] = kv[r].w; }   // 4 q .. 4 q + 3 share their pad offset
+            else { uint32_t* d = keys + kpad(2 * q); d[0] = kv[r].y; d[1] = kv[r].w; }
+        }
+    }
+    __syncthreads();
+    return tb;
+}
+
 template <int LOGG>
 __global__ __launch_bounds__(SBLOCK, 4) void k_search_multi(SearchArgs a)
 {
-    constexpr int G = 32 << LOGG, CS = G / 8, NS = GPF_MULTI_NS;             // NS = 2 or 4 slots per lane
+    constexpr int NS = GPF_MULTI_NS;                                     // 2 or 4 slots per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* const keys = reinterpret_cast<uint32_t*>(smem);
-    const uint32_t ng = (uint32_t)multi_groups(a.ntiles, LOGG);         // >= 64 >> LOGG
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
     if (a.update_lml && blockIdx.x == 0 && threadIdx.x == 0)
         a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
-    // ---- the key table: 16 B per lane from the scan's key level (every (1 << LOGG)-th key).  The loads are issued first,
-    //      the first targets are computed while they are in flight, then the table is written
-    constexpr int KT = (MULTI_LDS_BUDGET / 4 / (LOGG == 0 ? 4 : 2) + SBLOCK - 1) / SBLOCK;   // 16-byte source loads per lane that cover any table within the budget
-    const uint32_t nq = LOGG == 0 ? ng / 4 : ng / 2;
-    uint4 kv[KT];
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(a.w.k32);
-#pragma unroll
-        for (int r = 0; r < KT; ++r) { const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK; if (q < nq) kv[r] = src[q]; }
-    }
     const uint64_t S = a.ws->S;
-    uint32_t p2 = 1;                                                     // largest power of two <= ng
-    while (2 * p2 <= ng) p2 *= 2;
-    const float kscale = (float)ng / (float)((S >> KEY_SHIFT) + 1);      // groups per key unit: where a key would sit were the CDF linear
     // the lane's NS consecutive slots from slot `base` on (independent chains: the LDS and L2 round trips of one hide
     // behind the others); one Philox block per aligned slot pair (resample_u64), one more block when the run starts odd
     auto targets = [&](int64_t base, uint64_t* T) {
@@ -1155,128 +1290,11 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_search_multi(SearchArgs a)
     const int64_t stride = (int64_t)gridDim.x * NS * SBLOCK;
     int64_t base = (int64_t)blockIdx.x * NS * SBLOCK;
     uint64_t T[NS];
-    targets(base, T);
-#pragma unroll
-    for (int r = 0; r < KT; ++r) {
-        const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK;
-        if (q < nq) {
-            if (LOGG == 0) { uint32_t* d = keys + kpad(4 * q); d[0] = kv[r].x; d[1] = kv[r].y; d[2] = kv[r].z; d[3] = kv[r].w; }   // 4 q .. 4 q + 3 share their pad offset
-            else { uint32_t* d = keys + kpad(2 * q); d[0] = kv[r].y; d[1] = kv[r].w; }
-        }
-    }
-    __syncthreads();
-    constexpr uint32_t WIN = 512;                                        // interpolation window of the key search
+    const MultiTable tb = multi_table_load<LOGG>(a.w, a.ntiles, S, reinterpret_cast<uint32_t*>(smem), [&]() { targets(base, T); });
     for (; base < a.n; base += stride) {
         const int64_t j0 = base + NS * (int64_t)threadIdx.x;
-        uint32_t t[NS], pos[NS];
-        // ---- number of keys < t.  Fast path: the CDF of exchangeable weights is close to linear, so a window of WIN keys
-        //      around the interpolated position brackets the answer (checked); else the uniform binary search of the whole table
-        bool inwin = ng >= 2 * WIN;
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            t[u] = (uint32_t)(T[u] >> KEY_SHIFT);
-            const uint32_t pe = (uint32_t)((float)t[u] * kscale);
-            uint32_t lo = pe > WIN / 2 ? pe - WIN / 2 : 0u;
-            lo = lo + WIN > ng ? ng - WIN : lo;
-            pos[u] = lo;
-        }
-        if (inwin) {
-#pragma unroll
-            for (int u = 0; u < NS; ++u)
-                inwin = inwin && (pos[u] == 0u || keys[kpad(pos[u] - 1)] < t[u]) && keys[kpad(pos[u] + WIN - 1)] >= t[u];
-        }
-        if (__all(inwin)) {
-#pragma unroll
-            for (uint32_t h = WIN / 2; h >= 1; h >>= 1) {
-#pragma unroll
-                for (int u = 0; u < NS; ++u) pos[u] += keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < NS; ++u) pos[u] = keys[kpad(p2 - 1)] < t[u] ? ng - p2 : 0u;          // uniform binary search: no bounds checks below
-            for (uint32_t h = p2 >> 1; h >= 1; h >>= 1) {
-#pragma unroll
-                for (int u = 0; u < NS; ++u) pos[u] += keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
-            }
-        }
-        bool amb = false;
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            const uint32_t k = keys[kpad(pos[u])];                       // pos <= ng - 1 here
-            pos[u] += k < t[u] ? 1u : 0u;                                // pos = number of keys < t: those groups end at or below T
-            amb = amb || k == t[u] || (k < t[u] && pos[u] < ng && keys[kpad(pos[u])] == t[u]);
-        }
-        if (__any(amb)) {
-            // equal keys: the exact prefix decides (rare: one key value in 2^32 S / (2^30 groups) per slot)
-#pragma unroll
-            for (int u = 0; u < NS; ++u)
-                while (pos[u] < ng && keys[kpad(pos[u])] == t[u] && a.w.cdf[(int64_t)pos[u] * G + (G - 1)] <= T[u]) ++pos[u];
-        }
-        // ---- inside the key group: the target as a 16-bit offset, then two narrow reads
-        uint32_t g[NS], qq[NS], run[NS];
-        uint4 row[NS];
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            g[u] = pos[u] < ng ? pos[u] : ng - 1;
-            const uint32_t klo = g[u] ? keys[kpad(g[u] - 1)] : 0u, khi = keys[kpad(g[u])];
-            const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
-            const uint64_t d = T[u] > kb ? T[u] - kb : 0;
-            uint32_t q = (uint32_t)(d >> key_quant_shift(klo, khi));
-            q = q < 65535u ? q : 65535u;
-            qq[u] = q | (q << 16);
-            row[u] = *reinterpret_cast<const uint4*>(a.w.coarse + (size_t)g[u] * 8);
-        }
-        bool tie[NS];
         uint32_t idx[NS];
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            // run = number of coarse offsets < q (the last one, the group's end, is >= q: T lies in this group)
-            uint32_t c = pk_lt(row[u].x, qq[u]) + pk_lt(row[u].y, qq[u]) + pk_lt(row[u].z, qq[u]) + pk_lt(row[u].w, qq[u]);
-            c = (c & 0xffffu) + (c >> 16);
-            run[u] = c < 8u ? c : 7u;
-        }
-        uint4 fine[NS];
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            const uint16_t* fp = a.w.off16 + (size_t)(g[u] * (uint32_t)G + run[u] * (uint32_t)CS);
-            if (CS == 4) { const uint2 f = *reinterpret_cast<const uint2*>(fp); fine[u] = make_uint4(f.x, f.y, 0xffffffffu, 0xffffffffu); }
-            else fine[u] = *reinterpret_cast<const uint4*>(fp);
-        }
-        bool anytie = false;
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            uint32_t lt = pk_lt(fine[u].x, qq[u]) + pk_lt(fine[u].y, qq[u]);
-            uint32_t ne = pk_ne(fine[u].x, qq[u]) + pk_ne(fine[u].y, qq[u]);
-            if (CS != 4) {
-                lt += pk_lt(fine[u].z, qq[u]) + pk_lt(fine[u].w, qq[u]);
-                ne += pk_ne(fine[u].z, qq[u]) + pk_ne(fine[u].w, qq[u]);
-            }
-            lt = (lt & 0xffffu) + (lt >> 16); ne = (ne & 0xffffu) + (ne >> 16);
-            tie[u] = ne != (uint32_t)CS;
-            anytie = anytie || tie[u];
-            idx[u] = g[u] * (uint32_t)G + run[u] * (uint32_t)CS + lt;
-        }
-        if (__any(anytie)) {
-            // a cell of the run shares the target's offset: the exact prefixes decide.  Every cell before the run is below T
-            // (its run's coarse offset is < q); walk from the run's first cell -- equal offsets may continue into later runs
-#pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                if (!tie[u]) continue;
-                uint32_t i = g[u] * (uint32_t)G + run[u] * (uint32_t)CS;
-                const uint32_t end = g[u] * (uint32_t)G + (uint32_t)G;
-                // the run's CS exact prefixes in one round trip; only a run that lies entirely at or below T walks on
-                const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(a.w.cdf + i);
-                uint32_t c = 0;
-#pragma unroll
-                for (int e = 0; e < CS / 2; ++e) { const ulonglong2 v = cp[e]; c += (uint32_t)(v.x <= T[u]) + (uint32_t)(v.y <= T[u]); }
-                i += c;
-                if (c == (uint32_t)CS) while (i < end && a.w.cdf[i] <= T[u]) ++i;
-                idx[u] = i;
-            }
-        }
-        const uint32_t last = (uint32_t)(a.n_cells - 1);
-#pragma unroll
-        for (int u = 0; u < NS; ++u) idx[u] = idx[u] < last ? idx[u] : last;
+        multi_lookup<LOGG, NS>(tb, a.w, a.n_cells, T, idx);
         int32_t* dst = a.anc + j0;
         if (j0 + NS <= a.n && (reinterpret_cast<uintptr_t>(dst) & (4 * NS - 1)) == 0) {
             if (NS == 4) *reinterpret_cast<int4*>(dst) = make_int4((int32_t)idx[0], (int32_t)idx[1], (int32_t)idx[2], (int32_t)idx[3]);
@@ -1933,9 +1951,8 @@ __device__ __forceinline__ PushScal push_scalars(const PushArgs& a, const PushTa
 }
 // target of global slot jg, same arithmetic as k_search; space 1 = the residual copy-count CDF
 template <int METHOD>
-__device__ __forceinline__ void push_target(const PushArgs& a, const PushScal& s, uint64_t jg, uint64_t& T, int& space)
+__device__ __forceinline__ void push_target(const PushArgs& a, const PushScal& s, uint64_t jg, uint64_t U, uint64_t& T, int& space)
 {
-    const uint64_t U = resample_u64(a.seed, (uint32_t)jg, a.epoch);
     const uint64_t N = (uint64_t)a.n_global;
     space = 0;
     if (METHOD == 0) T = mulhi64(U, s.Sw);
@@ -1994,13 +2011,32 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
         if (g != a.me && push_chunk_misses<METHOD>(a, t, sc, j0, j1)) continue;       // block-uniform
         uint64_t Tl[R];
         unsigned hits = 0;                                                            // bit r: round r is a hit
+        // the lane's R consecutive slots: one Philox block per aligned slot pair (resample_u64), one more when the run starts odd
+        uint64_t U[R];
+        {
+            const uint32_t s0 = (uint32_t)(j0 + (int64_t)threadIdx.x * R), sb = s0 >> 1;
+            if (!(s0 & 1u)) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {                                                 // R independent Philox chains per lane
+                for (int q = 0; q < R / 2; ++q) {
+                    const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
+                    U[2 * q] = u64(b.w0, b.w1); U[2 * q + 1] = u64(b.w2, b.w3);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q <= R / 2; ++q) {
+                    const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
+                    if (q > 0) U[2 * q - 1] = u64(b.w0, b.w1);
+                    if (q < R / 2) U[2 * q] = u64(b.w2, b.w3);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
             const int64_t j = j0 + (int64_t)threadIdx.x * R + r;       // R consecutive slots per lane: staged in slot order
             uint64_t T = 0; int space = 0, h = -1;
             Tl[r] = 0;
             if (j < j1) {
-                push_target<METHOD>(a, sc, (uint64_t)j, T, space);
+                push_target<METHOD>(a, sc, (uint64_t)j, U[r], T, space);
                 h = push_owner(t, a.G, space, T, Tl[r]);
                 Tl[r] |= (uint64_t)space << 62;
             }

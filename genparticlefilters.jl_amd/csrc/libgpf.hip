@@ -1943,7 +1943,7 @@ gpf_status shard_all_gather(gpf_filter* h, const void* src, void* dst, size_t co
 {
     static const bool force = getenv("GPF_SHARD_FORCE_COLLECTIVES") && !strcmp(getenv("GPF_SHARD_FORCE_COLLECTIVES"), "1");
     if (h->comm_world == 1 && !(force && h->comm)) {
-        HIP_TRY(h, hipMemcpyAsync(dst, src, count * elem, hipMemcpyDeviceToDevice, h->stream));
+        if (dst != src) HIP_TRY(h, hipMemcpyAsync(dst, src, count * elem, hipMemcpyDeviceToDevice, h->stream));
         return GPF_OK;
     }
     NCCL_TRY(h, g_rccl.AllGather(src, dst, count, dt, h->comm, h->stream));
@@ -1953,9 +1953,16 @@ gpf_status shard_scratch(gpf_filter* h)
 {
     if (h->sh_mf) return GPF_OK;
     const size_t G = (size_t)h->comm_world;
-    HIP_TRY(h, hipMalloc(&h->sh_mf, 2 * sizeof(double)));       HIP_TRY(h, hipMalloc(&h->sh_mf_all, 2 * G * sizeof(double)));
-    HIP_TRY(h, hipMalloc(&h->sh_tot, 5 * sizeof(int64_t)));     HIP_TRY(h, hipMalloc(&h->sh_tot_all, 5 * G * sizeof(int64_t)));
-    HIP_TRY(h, hipMalloc(&h->sh_cr, 2 * sizeof(int64_t)));      HIP_TRY(h, hipMalloc(&h->sh_cr_all, 2 * G * sizeof(int64_t)));
+    HIP_TRY(h, hipMalloc(&h->sh_mf, 2 * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->sh_tot, 5 * sizeof(int64_t)));
+    HIP_TRY(h, hipMalloc(&h->sh_cr, 2 * sizeof(int64_t)));
+    if (h->comm_world == 1 && !h->comm) {                        // one shard, no communicator: the "gathered" arrays ARE the local ones
+        h->sh_mf_all = h->sh_mf; h->sh_tot_all = h->sh_tot; h->sh_cr_all = h->sh_cr;
+    } else {
+        HIP_TRY(h, hipMalloc(&h->sh_mf_all, 2 * G * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->sh_tot_all, 5 * G * sizeof(int64_t)));
+        HIP_TRY(h, hipMalloc(&h->sh_cr_all, 2 * G * sizeof(int64_t)));
+    }
     HIP_TRY(h, hipMemsetAsync(h->sh_tot, 0, 5 * sizeof(int64_t), h->stream));
     return GPF_OK;
 }
@@ -2029,7 +2036,8 @@ gpf_status gpf_comm_destroy(gpf_handle h)
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
-    void* bufs[] = {h->sh_mf, h->sh_mf_all, h->sh_tot, h->sh_tot_all, h->sh_cr, h->sh_cr_all, h->sh_send, h->sh_recv};
+    void* bufs[] = {h->sh_mf, h->sh_mf_all != h->sh_mf ? h->sh_mf_all : nullptr, h->sh_tot, h->sh_tot_all != h->sh_tot ? h->sh_tot_all : nullptr,
+                    h->sh_cr, h->sh_cr_all != h->sh_cr ? h->sh_cr_all : nullptr, h->sh_send, h->sh_recv};
     for (void* b : bufs) if (b) (void)hipFree(b);
     h->sh_mf = h->sh_mf_all = nullptr; h->sh_tot = h->sh_tot_all = h->sh_cr = h->sh_cr_all = nullptr;
     h->sh_send = h->sh_recv = nullptr; h->sh_send_cap = h->sh_recv_cap = 0;
@@ -2080,7 +2088,9 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
     int64_t cap = std::min<int64_t>(h->cfg.n_global, 2 * n + 65536);
     if (const char* e = getenv("GPF_PUSH_CAPACITY")) cap = atoll(e);                                  // tests: force the overflow path
     if ((s = ensure(h->sh_send, h->sh_send_cap, std::max<int64_t>(cap, 1)))) return s;
-    if ((s = ensure(h->sh_recv, h->sh_recv_cap, n))) return s;
+    static const bool force = getenv("GPF_SHARD_FORCE_COLLECTIVES") && !strcmp(getenv("GPF_SHARD_FORCE_COLLECTIVES"), "1");
+    const bool exchange = G > 1 || (force && h->comm);            // one shard: what it "sends" is what it "receives"
+    if (exchange && (s = ensure(h->sh_recv, h->sh_recv_cap, n))) return s;
     if ((s = gpf_shard_push(h, method, h->sh_tot_all, cr_all, G, me, bounds.data(), cap, h->sh_send))) return s;
     std::vector<int64_t> counts(2 * (size_t)G);
     if ((s = gpf_shard_counts(h, G, counts.data()))) return s;   // ONE host wait (the exchange's split sizes), behind phase 4
@@ -2092,10 +2102,7 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
         if ((s = gpf_shard_push(h, method, h->sh_tot_all, cr_all, G, me, bounds.data(), n_send, h->sh_send))) return s;
     }
     // the exchange: [row | slot | ancestor id], grouped point-to-point sends and receives (one pair per peer)
-    static const bool force = getenv("GPF_SHARD_FORCE_COLLECTIVES") && !strcmp(getenv("GPF_SHARD_FORCE_COLLECTIVES"), "1");
-    if (G == 1 && !(force && h->comm)) {
-        HIP_TRY(h, hipMemcpyAsync(h->sh_recv, h->sh_send, (size_t)n * E * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    } else {
+    if (exchange) {
         NCCL_TRY(h, g_rccl.GroupStart());
         int64_t so = 0, ro = 0;
         for (int g = 0; g < G; ++g) {
@@ -2105,7 +2112,7 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
         }
         NCCL_TRY(h, g_rccl.GroupEnd());
     }
-    return gpf_shard_commit(h, h->sh_recv, n, h->sh_mf_all, h->sh_tot_all, G);                      // phase 5 (deferred)
+    return gpf_shard_commit(h, exchange ? h->sh_recv : h->sh_send, n, h->sh_mf_all, h->sh_tot_all, G);                      // phase 5 (deferred)
 }
 
 gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out)
