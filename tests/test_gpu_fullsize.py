@@ -63,6 +63,22 @@ def test_sorted_stratified_and_uniform_identity_1e6(g, o):
         assert np.array_equal(st.parents, np.arange(1, N + 1))
 
 
+@pytest.mark.parametrize("N", [2_600_001, 1_050_000])
+def test_sort_beyond_one_super_group_and_search_levels(g, o, N):
+    """> 256 sort tiles (the super-group plane of the look-back), odd N (partial last tile), many equal keys (the update
+    step's weights of resampled duplicates tie), and the i.i.d. search with 64-cell key groups (N > 1.04 M) / fall-back
+    to the per-256 table (N > 2.09 M): sorted stratified and multinomial against the oracle"""
+    model, ys, st, orc = pair(g, o, "lgssm2", N, 9, False, 4)
+    for t in range(1, 3):
+        g.pf_resample(st, "stratified", sort_particles=True, check=False); orc.resample("stratified", sort_particles=True, check=False)
+        assert np.array_equal(st.parents, orc.parents)
+        g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
+        g.pf_resample(st, "multinomial", check=False); orc.resample("multinomial", check=False)
+        assert np.array_equal(st.parents, orc.parents)
+        g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
+    same(st, orc)
+
+
 def test_config4_bearings_ess_residual_mh_1e6(g, o):
     N, T = 1_000_000, 6
     model, ys, st, orc = pair(g, o, "bearings4", N, 4, True, T)
