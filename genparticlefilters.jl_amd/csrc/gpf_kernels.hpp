@@ -454,19 +454,32 @@ struct InFixQ {                // q_i = trunc(exp(p_i - m) 2^K + 1/2); uniform f
     {
         return uniform ? 1 : (bad ? 0 : exp_fix(v - m, K));
     }
-    __device__ __forceinline__ void load2(int64_t idx, int64_t n, uint64_t& q0, uint64_t& q1) const
+    // the two log-priorities at idx, idx + 1 (anything beyond n): needs neither the maximum nor the flags, so a scan can
+    // have its first tile's loads in flight while it folds the partial maxima
+    __device__ __forceinline__ void raw2(int64_t idx, int64_t n, double& v0, double& v1) const
     {
-        const bool uniform = (flags & FLAG_ALL_NEGINF) != 0, bad = (flags & (FLAG_NAN | FLAG_POSINF)) != 0;
         if (pv.mode == 0 && order == nullptr && idx + 1 < n) {          // 16 B per lane, 1 KiB per wave-instruction
             const double2 v = *reinterpret_cast<const double2*>(pv.lw + idx);
-            q0 = one(v.x, uniform, bad); q1 = one(v.y, uniform, bad);
+            v0 = v.x; v1 = v.y;
         } else if (sorted_keys && idx + 1 < n) {
             const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(sorted_keys + idx);
-            q0 = one(sort_key_value(k.x), uniform, bad); q1 = one(sort_key_value(k.y), uniform, bad);
+            v0 = sort_key_value(k.x); v1 = sort_key_value(k.y);
         } else {
-            q0 = idx < n ? one(pv.at(order ? (int64_t)order[idx] : idx), uniform, bad) : 0;
-            q1 = idx + 1 < n ? one(pv.at(order ? (int64_t)order[idx + 1] : idx + 1), uniform, bad) : 0;
+            v0 = idx < n ? pv.at(order ? (int64_t)order[idx] : idx) : 0.0;
+            v1 = idx + 1 < n ? pv.at(order ? (int64_t)order[idx + 1] : idx + 1) : 0.0;
         }
+    }
+    __device__ __forceinline__ void conv2(int64_t idx, int64_t n, double v0, double v1, uint64_t& q0, uint64_t& q1) const
+    {
+        const bool uniform = (flags & FLAG_ALL_NEGINF) != 0, bad = (flags & (FLAG_NAN | FLAG_POSINF)) != 0;
+        q0 = idx < n ? one(v0, uniform, bad) : 0;
+        q1 = idx + 1 < n ? one(v1, uniform, bad) : 0;
+    }
+    __device__ __forceinline__ void load2(int64_t idx, int64_t n, uint64_t& q0, uint64_t& q1) const
+    {
+        double v0, v1;
+        raw2(idx, n, v0, v1);
+        conv2(idx, n, v0, v1, q0, q1);
     }
 };
 // a <= ... products of a 31-bit count and a 62-bit weight need 128 bits:  B <= a * k
@@ -550,6 +563,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
     uint64_t* const d_pre = dcur + ntiles;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * BLOCK) dnext[i] = 0;
     constexpr bool WANT_Q = MODE == 2 || MODE == 4;
+    // the first tile's log-weights are loaded BEFORE the partial maxima are folded (they need neither m nor the flags)
+    double pre[2 * SCAN_ROWS];
+    if constexpr (MODE >= 1) {
+        const int64_t wb0 = (int64_t)blockIdx.x * TILE + (int64_t)wave_id() * (SCAN_ROWS * 2 * WAVE) + 2 * lane_id();
+#pragma unroll
+        for (int k = 0; k < SCAN_ROWS; ++k) in.raw2(wb0 + k * 2 * WAVE, n, pre[2 * k], pre[2 * k + 1]);
+    }
     if constexpr (MODE >= 1) {
         double m; int f;
         if constexpr (MODE >= 3) {
@@ -580,7 +600,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
         for (int k = 0; k < SCAN_ROWS; ++k) {
             uint64_t q0, q1;
             cb[k] = carry;
-            in.load2(wbase + k * 2 * WAVE, n, q0, q1);
+            if constexpr (MODE >= 1) {
+                if (tile == blockIdx.x) in.conv2(wbase + k * 2 * WAVE, n, pre[2 * k], pre[2 * k + 1], q0, q1);
+                else in.load2(wbase + k * 2 * WAVE, n, q0, q1);
+            } else in.load2(wbase + k * 2 * WAVE, n, q0, q1);
             if constexpr (WANT_Q) {
                 uint64_t lo = q0 * q0, hi = __umul64hi(q0, q0);
                 ql[0] += lo & 0xffffffffull; ql[1] += lo >> 32; ql[2] += hi & 0xffffffffull; ql[3] += hi >> 32;
