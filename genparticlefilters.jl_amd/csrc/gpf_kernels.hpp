@@ -890,6 +890,13 @@ __device__ __forceinline__ int count_le_line(const uint64_t* __restrict__ line, 
     return cnt;
 }
 
+// sharded stratified resampling (k_strat_plan): strata are contiguous in slot order and the shards' CDF ranges are contiguous
+// in target order, so the global slots a shard serves are ONE range
+struct ShardPlan {
+    WSum ws;                                                          // the GLOBAL weight sum and its strata constants
+    int64_t first, count;                                             // this shard serves the global slots [first, first + count)
+    uint64_t t_off;                                                   // where this shard's CDF starts in the global one
+};
 struct SearchArgs {
     CdfLevels w;                                                      // weights (or residual weights for the tail)
     CdfLevels c;                                                      // residual: copy counts
@@ -898,6 +905,7 @@ struct SearchArgs {
     Scalars* sc;
     const WSum* ws;                                                   // summary of the sampled weights
     const WSum* raw;                                                  // summary of state.log_weights (log-ML estimate)
+    const ShardPlan* plan;                                            // k_search_strat on a shard: slots and target offset (ws = &plan->ws)
     int64_t n, n_global, gid0;                                        // n = output slots; n_global = slots of the whole filter
     int64_t n_cells;                                                  // particles the CDF ranges over (== n except when resizing)
     uint64_t seed; uint32_t epoch;
@@ -1345,7 +1353,7 @@ constexpr int MBLOCK = 256;
 #endif
 constexpr int MSLOTS = GPF_MSLOTS;                 // consecutive slots per lane (16-byte ancestor stores)
 constexpr int MJB = MBLOCK * MSLOTS;               // slots per workgroup
-constexpr int64_t MONO_WIDE = 16 * (int64_t)MJB;   // a cell range wider than this is searched per slot, not streamed
+constexpr int64_t MONO_WIDE = 8 * (int64_t)MJB;    // a cell range wider than this is searched per slot, not streamed
 
 // Block-cooperative: A0 / A1 = number of entries of arr[0..cnt) (ascending) that are <= L0 / <= L1 (L0 <= L1).
 // Fast path, ONE global round trip of one coalesced 8-byte load per thread: a 256-entry window around `guess` (for
@@ -1427,26 +1435,38 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
     const uint64_t N = (uint64_t)a.n_global;
     const double invN = a.invN;
     const int64_t j0 = (int64_t)blockIdx.x * MJB;
+    // a shard serves the global slots [first, first + count) out of its own CDF, which starts at t_off in the global one:
+    // strata and RNG counters by GLOBAL slot, targets and strata bounds shifted into local coordinates (signed: the first
+    // served stratum may start below the shard's range)
+    const int64_t n_out = a.plan ? (a.plan->count < a.n ? a.plan->count : a.n) : a.n;
+    if (j0 >= n_out) return;                                          // (the grid of a shard is sized for the send buffer)
+    const int64_t sbase = a.plan ? a.plan->first : 0;                 // strata: global slot of the launch's slot 0
+    const int64_t pbase = a.plan ? a.plan->first : a.gid0;            // RNG counters
+    const int64_t t_off = a.plan ? (int64_t)a.plan->t_off : 0;
     // ---- the CDF cells the block's targets can fall into, at per-256 granularity (block_count_le_pair on the per-256
     //      level), with the block's targets computed while the probes are in flight: MSLOTS consecutive slots per lane,
     //      one Philox block per aligned slot pair (gpf_math.hpp resample_u64; one more block when the run starts odd),
     //      strata boundaries by running remainder (no division per slot)
     constexpr int NPB = MSLOTS / 2;
     const uint64_t t0 = (uint64_t)(MSLOTS * tid);
-    const uint32_t s0 = (uint32_t)(a.gid0 + j0 + (int64_t)t0), sb = s0 >> 1;
+    const uint32_t s0 = (uint32_t)(pbase + j0 + (int64_t)t0), sb = s0 >> 1;
     const bool odd = (s0 & 1u) != 0;                   // kernel-uniform
     const int64_t n256 = a.ntiles * 8;
     int64_t A0, A1;
-    uint64_t Lj0, Lj1;
-    // (the guess: were the weights equal, slot j0's target would fall into cell j0 n_cells / N)
-    const int64_t guess = (int64_t)((double)j0 * ((double)a.n_cells * invN)) >> 8;
+    uint64_t Lj0, Lj1;                                                 // strata bounds of the block, local, clamped at 0
+    int64_t Lj0s;                                                      // ... unclamped
+    // (the guess: were the weights equal, slot j0's target would fall into cell j0 n_cells / n_out)
+    const int64_t guess = (int64_t)((double)j0 * (a.plan ? (double)a.n_cells / (double)n_out : (double)a.n_cells * invN)) >> 8;
     block_count_le_pair(a.w.t256, n256, guess, s_cnt, A0, A1, [&](uint64_t& L0, uint64_t& L1) {
         // S = N B + rem; stratum j is [L(j), L(j+1)), L(j) = j B + floor(j rem / N)   (DESIGN.md §3.3); B, rem and N / S
         // were left beside S by the scan that produced it
         const uint64_t B = a.ws->sB, rem = a.ws->srem;
-        const uint64_t q0 = div_small((uint64_t)j0 * rem, N, invN), r0 = (uint64_t)j0 * rem - q0 * N;
-        Lj0 = (uint64_t)j0 * B + q0;
-        Lj1 = Lj0 + (uint64_t)MJB * B + div_small(r0 + (uint64_t)MJB * rem, N, invN);
+        const uint64_t jg0 = (uint64_t)(sbase + j0);
+        const uint64_t q0 = div_small(jg0 * rem, N, invN), r0 = jg0 * rem - q0 * N;
+        const uint64_t Lg0 = jg0 * B + q0;                                              // global
+        Lj0s = (int64_t)Lg0 - t_off;
+        Lj0 = Lj0s > 0 ? (uint64_t)Lj0s : 0;
+        Lj1 = (uint64_t)(Lj0s + (int64_t)((uint64_t)MJB * B + div_small(r0 + (uint64_t)MJB * rem, N, invN)));
         L0 = Lj0; L1 = Lj1 - 1;
         uint64_t U[MSLOTS];
         if (!odd) {
@@ -1464,16 +1484,17 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
             }
         }
         const uint64_t x = r0 + t0 * rem, qq = div_small(x, N, invN);
-        uint64_t rr = x - qq * N, L = Lj0 + t0 * B + qq;
+        uint64_t rr = x - qq * N;
+        int64_t L = Lj0s + (int64_t)(t0 * B + qq);                                      // local: a target of a served slot is >= 0
         uint64_t T[MSLOTS];
 #pragma unroll
         for (int k = 0; k < MSLOTS; ++k) {
             const int64_t j = j0 + (int64_t)t0 + k;
             const uint64_t r2 = rr + rem;
             const bool carry = r2 >= N;
-            const uint64_t Ln = L + B + (carry ? 1 : 0);
+            const int64_t Ln = L + (int64_t)B + (carry ? 1 : 0);
             rr = carry ? r2 - N : r2;
-            T[k] = j < a.n ? L + mulhi64(U[k], Ln - L) : ~0ull;                         // resample.jl:162
+            T[k] = j < n_out ? (uint64_t)(L + (int64_t)mulhi64(U[k], (uint64_t)(Ln - L))) : ~0ull;   // resample.jl:162
             L = Ln;
         }
 #pragma unroll
@@ -1517,7 +1538,7 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
                     uint32_t e = 0;
                     if (c > Lj0) {
                         // c lies in stratum t of the block, t within [te - 1, te + 2] (L(j) = L(j0) + t step +- 1, step >= 1)
-                        const int te = (int)((double)(c - Lj0) * inv_step);
+                        const int te = (int)((double)((int64_t)c - Lj0s) * inv_step);
                         const int b = te > 0 ? (te < MJB ? te - 1 : MJB - 1) : 0;
                         e = (uint32_t)b + (s_T[b] < c) + (s_T[b + 1] < c) + (s_T[b + 2] < c) + (s_T[b + 3] < c);
                     }
@@ -1543,23 +1564,42 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
 #pragma unroll
         for (int k = 0; k < MSLOTS; ++k) res[k] = res[k] > pre ? res[k] : pre;
     } else {
-        // ---- a few slots over very many cells (e.g. the light tail of a sorted order): per-slot search of the range
-        //      (rolled loop over the lane's slots, targets and results through LDS: keeps the streaming path's registers)
+        // ---- a few slots over very many cells (e.g. the light tail of a sorted order): per-slot search of the range.
+        //      The range's per-256 entries are staged in LDS (over s_mark) and searched there; the two line counts below
+        //      them (per-16 level, cells) are dependent global reads, two slots of the lane in flight at a time.  Targets
+        //      are read from and results written to the lane's own s_T entries (rolled loop: the streaming path's registers).
         const int64_t n16 = a.ntiles * (TILE / 16);
-#pragma unroll 1
-        for (int k = 0; k < MSLOTS; ++k) {
-            const uint64_t Tk = s_T[MSLOTS * tid + k];
-            int64_t lo = g_lo, hi = g_hi;                                 // the per-256 group of the answer is in [lo, hi]
+        constexpr int WIDE_ENTRIES = MJB / 2;                             // u64 entries that fit s_mark
+        uint64_t* const s_w = reinterpret_cast<uint64_t*>(s_mark);
+        const int64_t nent = g_hi - g_lo;                                 // entries [g_lo, g_hi) decide the group
+        const bool staged = nent <= WIDE_ENTRIES;                         // block-uniform
+        __syncthreads();                                                  // s_mark[0] above
+        if (staged) for (int64_t i = tid; i < nent; i += MBLOCK) s_w[i] = a.w.t256[g_lo + i];
+        __syncthreads();
+        auto group_of = [&](uint64_t Tk) {
+            if (staged) {
+                int lo = 0, len = (int)nent;
+                while (len > 0) { const int half = len >> 1; if (s_w[lo + half] <= Tk) { lo += half + 1; len -= half + 1; } else len = half; }
+                return g_lo + lo;
+            }
+            int64_t lo = g_lo, hi = g_hi;
             while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.w.t256[mid] <= Tk) lo = mid + 1; else hi = mid; }
-            int64_t s16 = lo * 16 + count_le_line(a.w.t16 + lo * 16, Tk);
-            s16 = s16 < n16 ? s16 : n16 - 1;
-            s_mark[MSLOTS * tid + k] = (uint32_t)(s16 * 16 + count_le_line(a.w.cdf + s16 * 16, Tk));
+            return lo;
+        };
+#pragma unroll 1
+        for (int k = 0; k < MSLOTS; k += 2) {
+            const uint64_t Ta = s_T[MSLOTS * tid + k], Tb = s_T[MSLOTS * tid + k + 1];
+            const int64_t ga = group_of(Ta), gb = group_of(Tb);
+            const int ca = count_le_line(a.w.t16 + ga * 16, Ta), cb = count_le_line(a.w.t16 + gb * 16, Tb);
+            int64_t sa = ga * 16 + ca, sb2 = gb * 16 + cb;
+            sa = sa < n16 ? sa : n16 - 1;
+            sb2 = sb2 < n16 ? sb2 : n16 - 1;
+            const int da = count_le_line(a.w.cdf + sa * 16, Ta), db = count_le_line(a.w.cdf + sb2 * 16, Tb);
+            s_T[MSLOTS * tid + k] = (uint64_t)(sa * 16 + da);
+            s_T[MSLOTS * tid + k + 1] = (uint64_t)(sb2 * 16 + db);
         }
 #pragma unroll
-        for (int k = 0; k < MSLOTS; k += 4) {
-            const uint4 m = *reinterpret_cast<const uint4*>(s_mark + MSLOTS * tid + k);
-            res[k] = m.x; res[k + 1] = m.y; res[k + 2] = m.z; res[k + 3] = m.w;
-        }
+        for (int k = 0; k < MSLOTS; ++k) res[k] = (uint32_t)s_T[MSLOTS * tid + k];
     }
     // ---- parents[j] = order[i_old]   (resample.jl:168)
     const int64_t jb = j0 + MSLOTS * tid;
@@ -1568,16 +1608,16 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
 #pragma unroll
     for (int k = 0; k < MSLOTS; ++k) {
         uint32_t idx = res[k] < last ? res[k] : last;
-        if (a.order && jb + k < a.n) idx = (uint32_t)a.order[idx];
+        if (a.order && jb + k < n_out) idx = (uint32_t)a.order[idx];
         out[k] = (int32_t)idx;
     }
     int32_t* dst = a.anc + jb;
-    if (jb + MSLOTS <= a.n && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    if (jb + MSLOTS <= n_out && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
 #pragma unroll
         for (int k = 0; k < MSLOTS; k += 4) *reinterpret_cast<int4*>(dst + k) = make_int4(out[k], out[k + 1], out[k + 2], out[k + 3]);
     } else {
 #pragma unroll
-        for (int k = 0; k < MSLOTS; ++k) if (jb + k < a.n) dst[k] = out[k];
+        for (int k = 0; k < MSLOTS; ++k) if (jb + k < n_out) dst[k] = out[k];
     }
 }
 
@@ -1653,16 +1693,14 @@ __global__ void k_iota(int32_t* v, int64_t n)
 // ----------------------------------------------------------------------------- K10: stable descending sort
 // order = sortperm(log_priorities, rev=true) (resample.jl:156-157; stable: ties keep ascending index order).
 // Least-significant-digit radix sort of the order-preserving 64-bit key with the particle index as payload: 8 passes of
-// 8 bits, each ONE kernel ("onesweep"): a workgroup takes the next tile by ticket, ranks its 4096 keys by digit (wave-level
+// 8 bits, each ONE kernel ("onesweep"): a workgroup of 1024 threads takes the next tile by ticket, ranks its 4096 keys by digit (wave-level
 // match + per-wave counters in LDS), learns the global offset of each of its 256 digit bins by a decoupled look-back over
 // the earlier tiles' descriptors ({valid | count} in one 8-byte word, relaxed agent-scope atomics as in k_scan), reorders
 // the tile in LDS so that every digit's run leaves as contiguous stores, and scatters.  The histograms of all eight digits
 // come from the key-generation pass.  24 N bytes of traffic per pass.
-#ifndef GPF_SORT_ITEMS
-#define GPF_SORT_ITEMS 16
-#endif
-constexpr int SORT_ITEMS = GPF_SORT_ITEMS;
-constexpr int SORT_TILE = BLOCK * SORT_ITEMS;      // 4096 keys per workgroup
+constexpr int SORT_TILE = 4096;                    // keys per workgroup
+constexpr int SORT_BLOCK = 1024, SORT_WAVES = SORT_BLOCK / WAVE;   // many waves with few keys each: the chain ticket -> load ->
+constexpr int SORT_ITEMS = SORT_TILE / SORT_BLOCK;                 // rank -> look-back -> scatter is latency, not bandwidth
 constexpr int SORT_PASSES = 8, SORT_BINS = 256;
 constexpr uint64_t SORT_VALID = 1ull << 62, SORT_VAL = (1ull << 62) - 1;   // descriptor = {valid | count}
 // workspace: [8][256] u32 histograms | [8] u32 tile tickets | pad | per pass: [ntiles | ntiles/16 | ntiles/256][256] u64 descriptors
@@ -1689,32 +1727,33 @@ __global__ __launch_bounds__(BLOCK) void k_sort_keys_hist(PrioView pv, int64_t n
 }
 
 // one digit pass.  vals_in == nullptr: the payload is the element's index (first pass).
-__global__ __launch_bounds__(BLOCK) void k_sort_pass(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                      uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
                                                      int pass, const uint32_t* __restrict__ hist, uint32_t* __restrict__ ticket,
                                                      uint64_t* __restrict__ desc, int32_t* __restrict__ timeout)
 {
-    __shared__ uint32_t s_cnt[NWAVES][SORT_BINS];      // per-wave digit counts, then exclusive offsets of the wave inside the tile's bin
+    __shared__ uint32_t s_cnt[SORT_WAVES][SORT_BINS];      // per-wave digit counts, then exclusive offsets of the wave inside the tile's bin
     __shared__ uint32_t s_lstart[SORT_BINS];           // first position of the bin in the tile's sorted order
     __shared__ int64_t s_gbase[SORT_BINS];             // global position of the bin's first element of this tile, minus s_lstart
-    __shared__ uint32_t s_scan[NWAVES];
+    __shared__ uint32_t s_scan[SORT_WAVES];
     __shared__ uint64_t s_keys[SORT_TILE];
     __shared__ int32_t s_vals[SORT_TILE];
     __shared__ uint32_t s_tile;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
     const int shift = 8 * pass;
     if (tid == 0) s_tile = atomicAdd(ticket + pass, 1u);
-    for (int i = tid; i < NWAVES * SORT_BINS; i += BLOCK) (&s_cnt[0][0])[i] = 0;
+    for (int i = tid; i < SORT_WAVES * SORT_BINS; i += SORT_BLOCK) (&s_cnt[0][0])[i] = 0;
     // exclusive scan of the digit's histogram: where each bin starts in the output
-    const uint32_t hv = hist[pass * SORT_BINS + tid];
+    const bool binthr = tid < SORT_BINS;               // the first four waves double as "thread = bin"
+    const uint32_t hv = binthr ? hist[pass * SORT_BINS + tid] : 0u;
     uint32_t hinc = hv;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(hinc, d, WAVE); if (lane >= d) hinc += o; }
-    if (lane == WAVE - 1) s_scan[wv] = hinc;
+    if (binthr && lane == WAVE - 1) s_scan[wv] = hinc;
     __syncthreads();
     uint32_t hbase = hinc - hv;
 #pragma unroll
-    for (int w = 0; w < NWAVES; ++w) if (w < wv) hbase += s_scan[w];
+    for (int w = 0; w < SORT_BINS / WAVE; ++w) if (w < wv) hbase += s_scan[w];
     const int64_t tile = s_tile;
     const int64_t t0 = tile * SORT_TILE;
     // ---- load (wave-striped: element = t0 + wave * 1024 + item * 64 + lane), rank inside the wave by digit
@@ -1744,24 +1783,26 @@ __global__ __launch_bounds__(BLOCK) void k_sort_pass(const uint64_t* __restrict_
     __syncthreads();
     // ---- per bin (thread = bin): offsets of the waves inside the bin, the tile's count, the bin's start inside the tile
     uint32_t tcnt = 0;
+    if (binthr) {
 #pragma unroll
-    for (int w = 0; w < NWAVES; ++w) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = tcnt; tcnt += c; }
+        for (int w = 0; w < SORT_WAVES; ++w) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = tcnt; tcnt += c; }
+    }
     uint32_t linc = tcnt;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(linc, d, WAVE); if (lane >= d) linc += o; }
     __syncthreads();                                        // s_scan reuse
-    if (lane == WAVE - 1) s_scan[wv] = linc;
+    if (binthr && lane == WAVE - 1) s_scan[wv] = linc;
     // the tile's aggregate is published NOW; the tile is then reordered in LDS (local information only) while the other
     // tiles publish theirs, and only then are the earlier tiles' words read
     {
         const size_t nt_ = gridDim.x, ng_ = (nt_ + 15) / 16, nsg_ = (nt_ + 255) / 256;
-        __hip_atomic_store(desc + ((size_t)pass * (nt_ + ng_ + nsg_) + (size_t)tile) * SORT_BINS + tid, SORT_VALID | tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (binthr) __hip_atomic_store(desc + ((size_t)pass * (nt_ + ng_ + nsg_) + (size_t)tile) * SORT_BINS + tid, SORT_VALID | tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     uint32_t lstart = linc - tcnt;
 #pragma unroll
-    for (int w = 0; w < NWAVES; ++w) if (w < wv) lstart += s_scan[w];
-    s_lstart[tid] = lstart;
+    for (int w = 0; w < SORT_BINS / WAVE; ++w) if (w < wv) lstart += s_scan[w];
+    if (binthr) s_lstart[tid] = lstart;
     __syncthreads();
     // ---- reorder inside the tile: afterwards every digit's run leaves as contiguous stores
 #pragma unroll
@@ -1782,7 +1823,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_pass(const uint64_t* __restrict_
     //      everything up to the super-group's end, published by its last tile).
     //      excl(tile) = PRE[super-group before] + sum of GT of the earlier groups of this super-group + sum of AGG of the earlier
     //      tiles of this group: at most 1 + 15 + 15 words, two or three round trips whatever the number of tiles.
-    {
+    if (binthr) {
         const size_t nt = gridDim.x, ng = (nt + 15) / 16, nsg = (nt + 255) / 256;
         uint64_t* const agg = desc + ((size_t)pass * (nt + ng + nsg)) * SORT_BINS + tid;      // this pass, this bin
         uint64_t* const gt = agg + nt * SORT_BINS;
@@ -1814,12 +1855,12 @@ __global__ __launch_bounds__(BLOCK) void k_sort_pass(const uint64_t* __restrict_
         if ((tile & 255) == 255) __hip_atomic_store(pre + (size_t)sg * SORT_BINS, SORT_VALID | (e_ + tcnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         excl = e_;
     }
-    s_gbase[tid] = (int64_t)hbase + (int64_t)excl - (int64_t)lstart;
+    if (binthr) s_gbase[tid] = (int64_t)hbase + (int64_t)excl - (int64_t)lstart;
     __syncthreads();
     const int64_t nvalid = n - t0 < SORT_TILE ? n - t0 : SORT_TILE;
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; ++k) {
-        const int lp = k * BLOCK + tid;
+        const int lp = k * SORT_BLOCK + tid;
         if (lp < nvalid) {
             const uint64_t kk = s_keys[lp];
             const int64_t g = s_gbase[(uint32_t)(kk >> shift) & 0xffu] + lp;
@@ -1960,33 +2001,23 @@ __device__ __forceinline__ int push_chunk(const PushArgs& a, const PushTables& t
     j1 = j0 + PUSH_CHUNK < t.bounds[g + 1] ? j0 + PUSH_CHUNK : t.bounds[g + 1];
     return g;
 }
-struct PushScal { uint64_t Sw, Ctot, B, rem; double invN; };
+struct PushScal { uint64_t Sw, Ctot; };
 template <int METHOD>
 __device__ __forceinline__ PushScal push_scalars(const PushArgs& a, const PushTables& t)
 {
     PushScal s;
     s.Sw = (uint64_t)t.w_incl[a.G - 1];           // total of the sampled space: weights, or residual weights
     s.Ctot = METHOD == 1 ? (uint64_t)t.c_incl[a.G - 1] : 0;
-    s.B = METHOD == 2 ? s.Sw / (uint64_t)a.n_global : 0;
-    s.rem = METHOD == 2 ? s.Sw % (uint64_t)a.n_global : 0;
-    s.invN = 1.0 / (double)a.n_global;
     return s;
 }
 // target of global slot jg, same arithmetic as k_search; space 1 = the residual copy-count CDF
 template <int METHOD>
 __device__ __forceinline__ void push_target(const PushArgs& a, const PushScal& s, uint64_t jg, uint64_t U, uint64_t& T, int& space)
 {
-    const uint64_t N = (uint64_t)a.n_global;
+    static_assert(METHOD == 0 || METHOD == 1, "stratified shards take k_strat_plan + k_search_strat");
     space = 0;
     if (METHOD == 0) T = mulhi64(U, s.Sw);
-    else if (METHOD == 2) {
-        const uint64_t x0 = jg * s.rem, q0 = div_small(x0, N, s.invN);
-        const uint64_t q1 = q0 + ((x0 - q0 * N) + s.rem >= N ? 1 : 0);
-        const uint64_t L0 = jg * s.B + q0, L1 = (jg + 1) * s.B + q1;
-        T = L0 + mulhi64(U, L1 - L0);
-    } else {
-        if (jg < s.Ctot) { space = 1; T = jg; } else T = mulhi64(U, s.Sw);
-    }
+    else if (jg < s.Ctot) { space = 1; T = jg; } else T = mulhi64(U, s.Sw);
 }
 // owner = first shard whose inclusive total exceeds T; T_local in the owner's coordinates
 __device__ __forceinline__ int push_owner(const PushTables& t, int G, int space, uint64_t T, uint64_t& T_local)
@@ -2002,16 +2033,6 @@ __device__ __forceinline__ int push_owner(const PushTables& t, int G, int space,
     T_local = T - (h ? (uint64_t)incl[h - 1] : 0);
     return h;
 }
-// stratified: the strata of slots [j0, j1) cover [L(j0), L(j1)), L(j) = j B + floor(j rem / N) in [j B, j B + rem]; a chunk
-// whose strata certainly miss this shard's CDF range has no hit (conservative bounds: no division per chunk)
-template <int METHOD>
-__device__ __forceinline__ bool push_chunk_misses(const PushArgs& a, const PushTables& t, const PushScal& s, int64_t j0, int64_t j1)
-{
-    if (METHOD != 2) return false;
-    const uint64_t lo = a.me ? (uint64_t)t.w_incl[a.me - 1] : 0, hi = (uint64_t)t.w_incl[a.me];
-    return (uint64_t)j1 * s.B + s.rem <= lo || (uint64_t)j0 * s.B >= hi;
-}
-
 // pass 1: stage the hits (slots whose target this shard owns), count them per destination, and count who owns the
 // targets of this shard's own slots
 constexpr int PUSH_SCAN_BLOCK = 512;
@@ -2031,7 +2052,6 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
     for (int64_t c = blockIdx.x; c < a.nchunks; c += gridDim.x) {
         int64_t j0, j1;
         const int g = push_chunk(a, t, c, j0, j1);
-        if (g != a.me && push_chunk_misses<METHOD>(a, t, sc, j0, j1)) continue;       // block-uniform
         uint64_t Tl[R];
         unsigned hits = 0;                                                            // bit r: round r is a hit
         // the lane's R consecutive slots: one Philox block per aligned slot pair (resample_u64), one more when the run starts odd
@@ -2141,7 +2161,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
             L[u] = incounts ? &lc_ : &lw_;
         }
         int64_t idx[2];
-        search_pair(st, L, top, T, METHOD != 2, lds_wave, n, ntiles, idx);
+        search_pair(st, L, top, T, true, lds_wave, n, ntiles, idx);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (!act[u]) continue;
@@ -2151,6 +2171,86 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
             for (int c = 0; c < W; ++c) dst[c] = src[c];
             dst[W] = u2d((slot[u] << 32) | (uint64_t)(gid0 + idx[u]));
         }
+    }
+}
+
+// ---- sharded STRATIFIED resampling needs none of the above.  Stratum j is [L(j), L(j+1)) with L ascending in j, and shard h
+// owns the targets in [lo_h, lo_(h+1)) (lo = exclusive totals): the slots shard h serves are the contiguous range
+// [F[h], F[h+1]), F[h] = first slot whose target is >= lo_h -- the stratum that contains lo_h, or the one after it, decided by
+// that one slot's target.  One small workgroup derives F from the gathered totals (every shard the same), the exchange
+// counts follow by intersecting slot ranges, and the ancestors of the served slots come from k_search_strat (streaming merge
+// over the shard's own CDF) -- no pass over the global slots, no staging list.
+__global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
+{
+    __shared__ int64_t F[MAX_SHARDS + 1];
+    const int h = (int)threadIdx.x;
+    const uint64_t N = (uint64_t)a.n_global;
+    uint64_t S = 0, lo = 0, lo_me = 0;
+    for (int g = 0; g < a.G; ++g) {
+        const uint64_t v = (uint64_t)a.tot_all[5 * g];
+        if (g < h) lo += v;
+        if (g < a.me) lo_me += v;
+        S += v;
+    }
+    const uint64_t B = S / N, rem = S % N;
+    if (h <= a.G) {
+        int64_t f;
+        if (h == 0) f = 0;
+        else if (h == a.G || lo >= S) f = (int64_t)N;
+        else {
+            auto L = [&](uint64_t j) { return j * B + j * rem / N; };
+            uint64_t j = (uint64_t)((double)lo * ((double)N / (double)S));   // the stratum that contains lo: estimate, then exact
+            j = j < N ? j : N - 1;
+            while (j + 1 < N && L(j + 1) <= lo) ++j;
+            while (j > 0 && L(j) > lo) --j;
+            const uint64_t L0 = L(j), L1 = L(j + 1);
+            const uint64_t T = L0 + mulhi64(resample_u64(a.seed, (uint32_t)j, a.epoch), L1 - L0);             // resample.jl:162
+            f = (int64_t)(T >= lo ? j : j + 1);
+        }
+        F[h] = f;
+    }
+    __syncthreads();
+    if (h < a.G) {
+        // sent to shard h: the served slots that lie in h's slot range; received from shard h: h's served slots in this shard's range
+        const int64_t s0 = F[a.me] > a.bounds[h] ? F[a.me] : a.bounds[h], s1 = F[a.me + 1] < a.bounds[h + 1] ? F[a.me + 1] : a.bounds[h + 1];
+        const int64_t r0 = F[h] > a.bounds[a.me] ? F[h] : a.bounds[a.me], r1 = F[h + 1] < a.bounds[a.me + 1] ? F[h + 1] : a.bounds[a.me + 1];
+        const int64_t ns = s1 > s0 ? s1 - s0 : 0, nr = r1 > r0 ? r1 - r0 : 0;
+        a.counts[h] = ns; a.counts[a.G + h] = nr;
+        if (a.host_counts) {
+            __hip_atomic_store(a.host_counts + h, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.host_counts + a.G + h, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (h == 0) {
+        plan->ws.S = S; plan->ws.sB = B; plan->ws.srem = rem; plan->ws.sinv = (double)N / (double)S;
+        plan->first = F[a.me]; plan->count = F[a.me + 1] - F[a.me]; plan->t_off = lo_me;
+    }
+    __syncthreads();
+    if (h == 0 && a.host_counts) {
+        __threadfence_system();
+        __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// packed_out[e] = [row of the ancestor | (slot inside its shard) << 32 | global ancestor id] for the served slots in slot
+// order -- which IS grouped by destination shard.  The ancestors ascend: the row reads coalesce.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_push_pack(PushArgs a, const ShardPlan* __restrict__ plan, const int32_t* __restrict__ idx, int64_t gid0,
+                                                     const double* __restrict__ rows, int64_t capacity, double* __restrict__ packed_out)
+{
+    __shared__ int64_t s_bnd[MAX_SHARDS + 1];
+    for (int g = threadIdx.x; g <= a.G; g += BLOCK) s_bnd[g] = a.bounds[g];
+    __syncthreads();
+    const int64_t first = plan->first, total = plan->count < capacity ? plan->count : capacity;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t jg = first + e;
+        int lo = 0, hi = a.G - 1;                                     // the shard that holds slot jg
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_bnd[mid] <= jg) lo = mid; else hi = mid - 1; }
+        const int64_t i = idx[e];
+        const double2* src = reinterpret_cast<const double2*>(rows + i * W);
+        double* dst = packed_out + e * (W + 1);
+#pragma unroll
+        for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }
+        dst[W] = u2d(((uint64_t)(jg - s_bnd[lo]) << 32) | (uint64_t)(gid0 + i));
     }
 }
 

@@ -115,6 +115,7 @@ struct gpf_filter {
     int64_t push_ticket = 0;             // bumped by every gpf_shard_push launch; k_push publishes it with the counts
     bool counts_published = false;
     ulonglong2* push_stage = nullptr;    // push exchange: staged hits, one 16-byte entry per global output slot at most
+    ShardPlan* shard_plan = nullptr;     // sharded stratified resampling: the slot range this shard serves (k_strat_plan)
     int64_t push_cap = 0;
     bool push_counted = false;
     Timer timers[GPF_K_COUNT];
@@ -627,7 +628,7 @@ gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
         uint64_t* kout = (p & 1) ? h->keys : h->keys_out;
         const int32_t* vin = p == 0 ? nullptr : ((p & 1) ? h->idx_in : h->order);
         int32_t* vout = (p & 1) ? h->order : h->idx_in;
-        GPF_LAUNCH(k_sort_pass, dim3((unsigned)nt), dim3(BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout);
+        GPF_LAUNCH(k_sort_pass, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout);
     }
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
@@ -913,7 +914,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts};
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
@@ -1805,13 +1806,23 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
     PushArgs a;
     if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, a))) return s;    // the counters were cleared by the weight scan
     h->counts_published = false;
+    if (method == GPF_RESAMPLE_STRATIFIED) {
+        // contiguous strata x contiguous shard ranges: the plan (served slot range, exchange counts) is closed-form; the
+        // counts go to the host right away
+        if (!h->shard_plan) HIP_TRY(h, hipMalloc(&h->shard_plan, sizeof(ShardPlan)));
+        h->push_ticket += 1;
+        a.ticket = h->push_ticket;
+        s = timed(h, GPF_K_SEARCH, [&] { GPF_LAUNCH(k_strat_plan, dim3(1), dim3(128), 0, h->stream, a, h->shard_plan); });
+        if (s) return s;
+        HIP_TRY(h, hipGetLastError());
+        h->counts_published = true;
+        h->push_counted = true;
+        return GPF_OK;
+    }
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.nchunks, (int64_t)h->n_cu * 8));
     s = timed(h, GPF_K_SEARCH, [&] {
-        switch (method) {
-            case GPF_RESAMPLE_MULTINOMIAL: GPF_LAUNCH((k_push_scan<0>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a); break;
-            case GPF_RESAMPLE_RESIDUAL:    GPF_LAUNCH((k_push_scan<1>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a); break;
-            default:                       GPF_LAUNCH((k_push_scan<2>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a); break;
-        }
+        if (method == GPF_RESAMPLE_MULTINOMIAL) GPF_LAUNCH((k_push_scan<0>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a);
+        else                                    GPF_LAUNCH((k_push_scan<1>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a);
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
@@ -1842,8 +1853,34 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
     if (s) return s;
     if (!h->push_counted) return fail(h, GPF_ERR_STATE, "gpf_shard_push needs gpf_shard_push_count of the same resample first");
     if (capacity < 0 || (capacity > 0 && !packed_out)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
-    h->push_ticket += 1;
     PushArgs a;
+    if (method == GPF_RESAMPLE_STRATIFIED) {
+        if (!h->shard_plan) return fail(h, GPF_ERR_STATE, "gpf_shard_push needs gpf_shard_push_count of the same resample first");
+        if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, a))) return s;
+        if (capacity == 0) return GPF_OK;
+        // ancestors of the served slots (a streaming merge over the shard's own CDF), then rows packed in slot order; both
+        // grids are sized for the send buffer and stop at the served count, which only the device knows
+        const int64_t cap = std::min<int64_t>(capacity, h->cfg.n_global);
+        SearchArgs sa{};
+        sa.w = levels(h, 0); sa.c = sa.w; sa.ntiles = h->ntiles;
+        sa.order = nullptr; sa.sc = h->sc; sa.ws = &h->shard_plan->ws; sa.raw = &h->sc->raw; sa.plan = h->shard_plan;
+        sa.n = cap; sa.n_cells = h->n; sa.n_global = h->cfg.n_global; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
+        sa.K = h->K; sa.logN = h->logN; sa.anc = reinterpret_cast<int32_t*>(h->push_stage); sa.invN = 1.0 / (double)h->cfg.n_global;
+        sa.update_lml = 0;                                            // the commit carries the log-ML update
+        const int gp = grid_for(h, cap, 8);
+        s = timed(h, GPF_K_GATHER, [&] {
+            GPF_LAUNCH(k_search_strat, dim3((unsigned)((cap + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa);
+            switch (h->W) {
+                case 2: GPF_LAUNCH((k_push_pack<2>), dim3(gp), dim3(BLOCK), 0, h->stream, a, h->shard_plan, sa.anc, h->cfg.gid0, h->rows[h->cur], capacity, packed_out); break;
+                case 4: GPF_LAUNCH((k_push_pack<4>), dim3(gp), dim3(BLOCK), 0, h->stream, a, h->shard_plan, sa.anc, h->cfg.gid0, h->rows[h->cur], capacity, packed_out); break;
+                case 8: GPF_LAUNCH((k_push_pack<8>), dim3(gp), dim3(BLOCK), 0, h->stream, a, h->shard_plan, sa.anc, h->cfg.gid0, h->rows[h->cur], capacity, packed_out); break;
+            }
+        });
+        if (s) return s;
+        HIP_TRY(h, hipGetLastError());
+        return GPF_OK;
+    }
+    h->push_ticket += 1;
     if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, a))) return s;
     if (capacity == 0) return GPF_OK;
     h->counts_published = true;
@@ -1855,11 +1892,8 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
     const CdfLevels lw_ = levels(h, two ? 2 : 0);
     const CdfLevels lc_ = levels(h, two ? 1 : 0);
     s = timed(h, GPF_K_GATHER, [&] {
-        switch (method) {
-            case GPF_RESAMPLE_MULTINOMIAL: launch_push<0>(h, a, grid, lds, lw_, lc_, capacity, packed_out); break;
-            case GPF_RESAMPLE_RESIDUAL:    launch_push<1>(h, a, grid, lds, lw_, lc_, capacity, packed_out); break;
-            default:                       launch_push<2>(h, a, grid, lds, lw_, lc_, capacity, packed_out); break;
-        }
+        if (method == GPF_RESAMPLE_MULTINOMIAL) launch_push<0>(h, a, grid, lds, lw_, lc_, capacity, packed_out);
+        else                                    launch_push<1>(h, a, grid, lds, lw_, lc_, capacity, packed_out);
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
