@@ -1143,64 +1143,19 @@ __device__ __forceinline__ uint32_t pk_ne(uint32_t x, uint32_t qq)
 struct MultiTable { const uint32_t* keys; uint32_t ng, p2; float kscale; };      // the LDS key table of k_search_multi
 constexpr uint32_t MULTI_WIN = 512;                // interpolation window of the key search
 
-// idx[u] = first cell whose prefix exceeds T[u], for the lane's NS independent targets (wave-collective: the fast paths are
-// taken when every lane of the wave can take them).  Levels as described above; LOGG as in the key table.
-template <int LOGG, int NS>
-__device__ __forceinline__ void multi_lookup(const MultiTable& tb, const CdfLevels& w, int64_t n_cells, const uint64_t (&T)[NS], uint32_t (&idx)[NS])
+// the second half of the lookup: pos[u] = the key group that holds T[u] (number of groups that end at or below it); the
+// target becomes a 16-bit offset inside the group, then two narrow reads.  key(i) = key of group i (LDS table or global level).
+template <int LOGG, int NS, class KeyFn>
+__device__ __forceinline__ void multi_inside(KeyFn&& key, uint32_t ng, const CdfLevels& w, int64_t n_cells, const uint64_t (&T)[NS],
+                                             const uint32_t (&pos)[NS], uint32_t (&idx)[NS])
 {
     constexpr int G = 32 << LOGG, CS = G / 8;
-    constexpr uint32_t WIN = MULTI_WIN;
-    uint32_t t[NS], pos[NS];
-    // ---- number of keys < t.  Fast path: the CDF of exchangeable weights is close to linear, so a window of WIN keys
-    //      around the interpolated position brackets the answer (checked); else the uniform binary search of the whole table
-    bool inwin = tb.ng >= 2 * WIN;
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        t[u] = (uint32_t)(T[u] >> KEY_SHIFT);
-        const uint32_t pe = (uint32_t)((float)t[u] * tb.kscale);
-        uint32_t lo = pe > WIN / 2 ? pe - WIN / 2 : 0u;
-        lo = lo + WIN > tb.ng ? tb.ng - WIN : lo;
-        pos[u] = lo;
-    }
-    if (inwin) {
-#pragma unroll
-        for (int u = 0; u < NS; ++u)
-            inwin = inwin && (pos[u] == 0u || tb.keys[kpad(pos[u] - 1)] < t[u]) && tb.keys[kpad(pos[u] + WIN - 1)] >= t[u];
-    }
-    if (__all(inwin)) {
-#pragma unroll
-        for (uint32_t h = WIN / 2; h >= 1; h >>= 1) {
-#pragma unroll
-            for (int u = 0; u < NS; ++u) pos[u] += tb.keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < NS; ++u) pos[u] = tb.keys[kpad(tb.p2 - 1)] < t[u] ? tb.ng - tb.p2 : 0u;          // uniform binary search: no bounds checks below
-        for (uint32_t h = tb.p2 >> 1; h >= 1; h >>= 1) {
-#pragma unroll
-            for (int u = 0; u < NS; ++u) pos[u] += tb.keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
-        }
-    }
-    bool amb = false;
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        const uint32_t k = tb.keys[kpad(pos[u])];                       // pos <= tb.ng - 1 here
-        pos[u] += k < t[u] ? 1u : 0u;                                // pos = number of keys < t: those groups end at or below T
-        amb = amb || k == t[u] || (k < t[u] && pos[u] < tb.ng && tb.keys[kpad(pos[u])] == t[u]);
-    }
-    if (__any(amb)) {
-        // equal keys: the exact prefix decides (rare: one key value in 2^32 S / (2^30 groups) per slot)
-#pragma unroll
-        for (int u = 0; u < NS; ++u)
-            while (pos[u] < tb.ng && tb.keys[kpad(pos[u])] == t[u] && w.cdf[(int64_t)pos[u] * G + (G - 1)] <= T[u]) ++pos[u];
-    }
-    // ---- inside the key group: the target as a 16-bit offset, then two narrow reads
     uint32_t g[NS], qq[NS], run[NS];
     uint4 row[NS];
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-        g[u] = pos[u] < tb.ng ? pos[u] : tb.ng - 1;
-        const uint32_t klo = g[u] ? tb.keys[kpad(g[u] - 1)] : 0u, khi = tb.keys[kpad(g[u])];
+        g[u] = pos[u] < ng ? pos[u] : ng - 1;
+        const uint32_t klo = g[u] ? key(g[u] - 1) : 0u, khi = key(g[u]);
         const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
         const uint64_t d = T[u] > kb ? T[u] - kb : 0;
         uint32_t q = (uint32_t)(d >> key_quant_shift(klo, khi));
@@ -1258,6 +1213,60 @@ __device__ __forceinline__ void multi_lookup(const MultiTable& tb, const CdfLeve
     const uint32_t last = (uint32_t)(n_cells - 1);
 #pragma unroll
     for (int u = 0; u < NS; ++u) idx[u] = idx[u] < last ? idx[u] : last;
+}
+
+// idx[u] = first cell whose prefix exceeds T[u], for the lane's NS independent targets (wave-collective: the fast paths are
+// taken when every lane of the wave can take them).  Levels as described above; LOGG as in the key table.
+template <int LOGG, int NS>
+__device__ __forceinline__ void multi_lookup(const MultiTable& tb, const CdfLevels& w, int64_t n_cells, const uint64_t (&T)[NS], uint32_t (&idx)[NS])
+{
+    constexpr int G = 32 << LOGG, CS = G / 8;
+    constexpr uint32_t WIN = MULTI_WIN;
+    uint32_t t[NS], pos[NS];
+    // ---- number of keys < t.  Fast path: the CDF of exchangeable weights is close to linear, so a window of WIN keys
+    //      around the interpolated position brackets the answer (checked); else the uniform binary search of the whole table
+    bool inwin = tb.ng >= 2 * WIN;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        t[u] = (uint32_t)(T[u] >> KEY_SHIFT);
+        const uint32_t pe = (uint32_t)((float)t[u] * tb.kscale);
+        uint32_t lo = pe > WIN / 2 ? pe - WIN / 2 : 0u;
+        lo = lo + WIN > tb.ng ? tb.ng - WIN : lo;
+        pos[u] = lo;
+    }
+    if (inwin) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+            inwin = inwin && (pos[u] == 0u || tb.keys[kpad(pos[u] - 1)] < t[u]) && tb.keys[kpad(pos[u] + WIN - 1)] >= t[u];
+    }
+    if (__all(inwin)) {
+#pragma unroll
+        for (uint32_t h = WIN / 2; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) pos[u] += tb.keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) pos[u] = tb.keys[kpad(tb.p2 - 1)] < t[u] ? tb.ng - tb.p2 : 0u;          // uniform binary search: no bounds checks below
+        for (uint32_t h = tb.p2 >> 1; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) pos[u] += tb.keys[kpad(pos[u] + h - 1)] < t[u] ? h : 0u;
+        }
+    }
+    bool amb = false;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const uint32_t k = tb.keys[kpad(pos[u])];                       // pos <= tb.ng - 1 here
+        pos[u] += k < t[u] ? 1u : 0u;                                // pos = number of keys < t: those groups end at or below T
+        amb = amb || k == t[u] || (k < t[u] && pos[u] < tb.ng && tb.keys[kpad(pos[u])] == t[u]);
+    }
+    if (__any(amb)) {
+        // equal keys: the exact prefix decides (rare: one key value in 2^32 S / (2^30 groups) per slot)
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+            while (pos[u] < tb.ng && tb.keys[kpad(pos[u])] == t[u] && w.cdf[(int64_t)pos[u] * G + (G - 1)] <= T[u]) ++pos[u];
+    }
+    multi_inside<LOGG, NS>([&](uint32_t i) { return tb.keys[kpad(i)]; }, tb.ng, w, n_cells, T, pos, idx);
 }
 
 // block-collective: the key table into LDS, 16 B per lane from the scan's key level (every (1 << LOGG)-th key).  The loads are
@@ -1980,14 +1989,19 @@ struct PushTables {                               // LDS copy of the per-shard t
 };
 __device__ __forceinline__ void push_tables(const PushArgs& a, PushTables& t)
 {
-    // inclusive shard totals of the sampled space (weights, or residual weights) and of the residual copy counts
-    if (threadIdx.x == 0) {
-        int64_t w = 0, c = 0;
-        for (int g = 0; g < a.G; ++g) {
-            w += a.cr_all ? a.cr_all[2 * g + 1] : a.tot_all[5 * g];
-            c += a.cr_all ? a.cr_all[2 * g] : 0;
-            t.w_incl[g] = w; t.c_incl[g] = c;
+    // inclusive shard totals of the sampled space (weights, or residual weights) and of the residual copy counts: the
+    // first wave, one shard per lane (G <= MAX_SHARDS = 64)
+    static_assert(MAX_SHARDS <= WAVE, "one lane per shard");
+    if (threadIdx.x < WAVE) {
+        const int g = (int)threadIdx.x;
+        uint64_t w = g < a.G ? (uint64_t)(a.cr_all ? a.cr_all[2 * g + 1] : a.tot_all[5 * g]) : 0;
+        uint64_t c = g < a.G && a.cr_all ? (uint64_t)a.cr_all[2 * g] : 0;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint64_t ow = shfl_up_u64(w, d), oc = shfl_up_u64(c, d);
+            if (g >= d) { w += ow; c += oc; }
         }
+        if (g < a.G) { t.w_incl[g] = (int64_t)w; t.c_incl[g] = (int64_t)c; }
     }
     for (int g = threadIdx.x; g <= a.G; g += blockDim.x) { t.bounds[g] = a.bounds[g]; t.chunk0[g] = a.chunk0[g]; }
     __syncthreads();
@@ -2049,6 +2063,9 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
     const PushScal sc = push_scalars<METHOD>(a, t);
     const int lane = lane_id(), wv = (int)threadIdx.x / WAVE;
     unsigned recv_cnt = 0;                        // lane h counts the wave's own-slot targets owned by shard h
+    // this shard's range of the sampled space(s); the last shard also takes a target at the very end (push_owner's clamp)
+    const uint64_t w_lo = a.me ? (uint64_t)t.w_incl[a.me - 1] : 0, w_hi = a.me == a.G - 1 ? ~0ull : (uint64_t)t.w_incl[a.me];
+    const uint64_t c_lo = a.me ? (uint64_t)t.c_incl[a.me - 1] : 0, c_hi = a.me == a.G - 1 ? ~0ull : (uint64_t)t.c_incl[a.me];
     for (int64_t c = blockIdx.x; c < a.nchunks; c += gridDim.x) {
         int64_t j0, j1;
         const int g = push_chunk(a, t, c, j0, j1);
@@ -2080,7 +2097,12 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
             Tl[r] = 0;
             if (j < j1) {
                 push_target<METHOD>(a, sc, (uint64_t)j, U[r], T, space);
-                h = push_owner(t, a.G, space, T, Tl[r]);
+                if (g == a.me) h = push_owner(t, a.G, space, T, Tl[r]);              // own slots: who serves them (receive counts)
+                else {                                                                // other shards' slots: only "is it mine?"
+                    const uint64_t lo = space ? c_lo : w_lo, hi = space ? c_hi : w_hi;
+                    h = (T >= lo && T < hi) ? a.me : -1;
+                    Tl[r] = T - lo;
+                }
                 Tl[r] |= (uint64_t)space << 62;
             }
             if (g == a.me) {                                                          // block-uniform
@@ -2251,6 +2273,56 @@ __global__ __launch_bounds__(BLOCK) void k_push_pack(PushArgs a, const ShardPlan
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }
         dst[W] = u2d(((uint64_t)(jg - s_bnd[lo]) << 32) | (uint64_t)(gid0 + i));
+    }
+}
+
+// k_push for multinomial shards whose CDF carries the offset levels of k_search_multi: the 4-byte key table in LDS, four staged
+// hits per lane in flight.  What bounds these kernels is the number of DIVERGENT global loads per entry (each costs the CU's L1
+// about four cycles per lane): here the coarse row, the fine run and the particle's row -- the keys never leave LDS.
+template <int LOGG, int W>
+__global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels lw_, int64_t n, int64_t ntiles, int64_t gid0,
+                                                          const double* __restrict__ rows, int64_t capacity, double* __restrict__ packed_out)
+{
+    constexpr int NE = GPF_MULTI_NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int64_t s_off[MAX_SHARDS + 1];     // first entry of every destination in the send buffer
+    __shared__ int64_t s_bnd[MAX_SHARDS + 1];
+    if (threadIdx.x == 0) {
+        int64_t o = 0;
+        for (int g = 0; g < a.G; ++g) { s_off[g] = o; o += a.counts[g]; s_bnd[g] = a.bounds[g]; }
+        s_off[a.G] = o;
+        if (blockIdx.x == 0 && a.host_counts) {   // (as in k_push: the host reads the counts while the look-ups run)
+            for (int g = 0; g < 2 * a.G; ++g)
+                __hip_atomic_store(a.host_counts + g, a.counts[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    const MultiTable tb = multi_table_load<LOGG>(lw_, ntiles, (uint64_t)a.tot_all[5 * a.me], reinterpret_cast<uint32_t*>(smem), [] {});
+    const int64_t total = s_off[a.G] < capacity ? s_off[a.G] : capacity;
+    for (int64_t base = (int64_t)blockIdx.x * NE * SBLOCK; base < total; base += (int64_t)gridDim.x * NE * SBLOCK) {
+        int64_t e[NE]; bool act[NE]; uint64_t T[NE]; uint32_t slot[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            e[u] = base + u * SBLOCK + threadIdx.x;
+            act[u] = e[u] < total;
+            const int64_t ee = act[u] ? e[u] : total - 1;
+            int g = 0;
+            while (g < a.G - 1 && ee >= s_off[g + 1]) ++g;
+            const ulonglong2 q = a.stage[s_bnd[g] + (ee - s_off[g])];
+            T[u] = q.x & DESC_MASK;
+            slot[u] = (uint32_t)q.y;
+        }
+        uint32_t idx[NE];
+        multi_lookup<LOGG, NE>(tb, lw_, n, T, idx);
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            if (!act[u]) continue;
+            const double2* src = reinterpret_cast<const double2*>(rows + (int64_t)idx[u] * W);
+            double* dst = packed_out + e[u] * (W + 1);
+#pragma unroll
+            for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }
+            dst[W] = u2d(((uint64_t)slot[u] << 32) | (uint64_t)(gid0 + idx[u]));
+        }
     }
 }
 

@@ -814,6 +814,14 @@ static void launch_push(gpf_filter* h, const PushArgs& a, int grid, size_t lds, 
     }
 }
 
+static void launch_push_multi(gpf_filter* h, const PushArgs& a, int grid, const CdfLevels& lw_, int64_t capacity, double* out)
+{
+#define GPF_PN(LG, WW) GPF_LAUNCH((k_push_multi<LG, WW>), dim3(grid), dim3(SBLOCK), multi_lds_bytes(h->ntiles, LG), h->stream, a, lw_, h->n, h->ntiles, h->cfg.gid0, h->rows[h->cur], capacity, out)
+    if (lw_.logg == 0) { switch (h->W) { case 2: GPF_PN(0, 2); break; case 4: GPF_PN(0, 4); break; case 8: GPF_PN(0, 8); break; } }
+    else               { switch (h->W) { case 2: GPF_PN(1, 2); break; case 4: GPF_PN(1, 4); break; case 8: GPF_PN(1, 8); break; } }
+#undef GPF_PN
+}
+
 extern "C" {
 
 int gpf_abi_version(void) { return GPF_ABI_VERSION; }
@@ -892,7 +900,8 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
 #define GPF_PUSH_ATTR(M, W) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_push<M, W>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn))
         GPF_PUSH_ATTR(0, 2); GPF_PUSH_ATTR(0, 4); GPF_PUSH_ATTR(0, 8);
         GPF_PUSH_ATTR(1, 2); GPF_PUSH_ATTR(1, 4); GPF_PUSH_ATTR(1, 8);
-        GPF_PUSH_ATTR(2, 2); GPF_PUSH_ATTR(2, 4); GPF_PUSH_ATTR(2, 8);
+#define GPF_PN_ATTR(LG, W) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_push_multi<LG, W>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET))
+        GPF_PN_ATTR(0, 2); GPF_PN_ATTR(0, 4); GPF_PN_ATTR(0, 8); GPF_PN_ATTR(1, 2); GPF_PN_ATTR(1, 4); GPF_PN_ATTR(1, 8);
 #undef GPF_PUSH_ATTR
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return GPF_OK;
@@ -1891,9 +1900,12 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((capacity + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));
     const CdfLevels lw_ = levels(h, two ? 2 : 0);
     const CdfLevels lc_ = levels(h, two ? 1 : 0);
+    const bool narrow = method == GPF_RESAMPLE_MULTINOMIAL && lw_.off16 != nullptr;
+    const int gridn = (int)std::max<int64_t>(1, std::min<int64_t>((capacity + 4 * SBLOCK - 1) / (4 * SBLOCK), (int64_t)h->n_cu));
     s = timed(h, GPF_K_GATHER, [&] {
-        if (method == GPF_RESAMPLE_MULTINOMIAL) launch_push<0>(h, a, grid, lds, lw_, lc_, capacity, packed_out);
-        else                                    launch_push<1>(h, a, grid, lds, lw_, lc_, capacity, packed_out);
+        if (narrow)                                  launch_push_multi(h, a, gridn, lw_, capacity, packed_out);
+        else if (method == GPF_RESAMPLE_MULTINOMIAL) launch_push<0>(h, a, grid, lds, lw_, lc_, capacity, packed_out);
+        else                                         launch_push<1>(h, a, grid, lds, lw_, lc_, capacity, packed_out);
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
