@@ -81,7 +81,7 @@ def main():
     K, Wm = args.steps, args.warmup
     # every leg below indexes observations by its own loop counter: never fewer rows than any leg touches
     # (the gather and cpu_baseline legs run a fixed 30 steps whatever --steps says)
-    n_obs = max(K + Wm + 1, AUX_STEPS + 2)
+    n_obs = max(K + Wm + 3, AUX_STEPS + 2)       # (+2: the guarded first steps of the sharded engine)
     ys = g.models.simulate(model, n_obs)
     n_local = args.particles_per_gpu
     n_global = n_local * world
@@ -89,13 +89,46 @@ def main():
     sharded_mode = world > 1 or force_sharded
     if not sharded_mode:
         state = g.pf_initialize(model, (1,), ys[0], n_local, seed=SEED, device=local_rank)
+        t_first = 1
 
         def step(t):
             g.pf_resample(state, "multinomial")                   # the reference's defaults: priority_fn = nothing, check = :warn
             g.pf_update(state, (t + 1,), (None,), ys[t])
     else:
         from gpf_amd import sharded
-        state = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=SEED, device=local_rank)
+
+        # The library engine (gpf_shard_resample on libgpf's own RCCL communicator) has only ever met one-rank communicators
+        # in the build environment.  Its first collective steps run under a guard: if any rank fails to create the
+        # communicator or to run them, ALL ranks fall back to the phase-by-phase engine over torch.distributed.
+        engine_note = None
+
+        def make_state():
+            st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=SEED, device=local_rank)
+            for tp in (1, 2):                                        # two steps before the counted warm-up
+                sharded.pf_resample(st, "multinomial", check=False)
+                sharded.pf_update(st, (tp + 1,), (None,), ys[tp])
+            st.synchronize()
+            return st
+
+        ok, err = 1, ""
+        try:
+            state = make_state()
+        except Exception as e:                                       # noqa: BLE001 -- any failure means: use the other engine
+            ok, err = 0, repr(e)
+        if dist is not None and world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if one_device else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok_all = int(flag.item())
+        else:
+            ok_all = ok
+        if not ok_all:
+            if os.environ.get("GPF_SHARD_ENGINE") == "python":
+                raise SystemExit(f"sharded engine failed: {err}")
+            engine_note = f"fell back from the library engine ({err or 'another rank failed'})"
+            print(f"[bench rank {rank}] {engine_note}", file=sys.stderr)
+            os.environ["GPF_SHARD_ENGINE"] = "python"
+            state = make_state()
+        t_first = 3
 
         def step(t):
             sharded.pf_resample(state, "multinomial", check=False)   # (check = :warn polls one more pinned flag per resample: +6 us)
@@ -108,7 +141,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    t = 1
+    t = t_first
     for _ in range(Wm):
         step(t); t += 1
     # the host loop is Python: a generation-2 garbage collection (tens of ms, once per ~1000 sharded steps) would be
@@ -287,7 +320,8 @@ def main():
             "shard_engine": (None if not sharded_mode else
                              (f"library: gpf_shard_resample on libgpf's own RCCL communicator of {world} rank(s)"
                               if getattr(state.backend, "lib_comm", False) else
-                              f"python: sharded.py composes the phases over torch.distributed ({dist.get_backend() if dist is not None and dist.is_initialized() else 'no'} backend, {world} rank(s))")),
+                              f"python: sharded.py composes the phases over torch.distributed ({dist.get_backend() if dist is not None and dist.is_initialized() else 'no'} backend, {world} rank(s))"
+                              + (f"; {engine_note}" if engine_note else ""))),
             "log_ml_estimate": lml, "log_ml_exact_kalman": lml_exact, "log_ml_abs_error": abs(lml - lml_exact),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
             "stratified_variant": strat, "local_resample_variant": island,

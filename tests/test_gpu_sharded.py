@@ -53,6 +53,7 @@ def test_hip_push_overflow_path(g, o, tmp_path, monkeypatch):
     """send buffer smaller than the exchange: the kernel stops at the capacity, the host repeats the push at the right size"""
     monkeypatch.setenv("GPF_PUSH_CAPACITY", "1000")
     test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[0])
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[1])    # stratified: the served slot range is cut at the capacity
     test_world1_sharded_equals_unsharded(g, o)
 
 
