@@ -41,6 +41,7 @@ SYMBOLS = [
     ("gpf_initialize_strata", C.c_int, [_H, _pd, C.c_int32, _pd, C.c_int32, C.c_int32]),
     ("gpf_update_strata", C.c_int, [_H, _pd, C.c_int32, _pd, C.c_int32, C.c_int32]),
     ("gpf_resample", C.c_int, [_H, C.c_int32, C.c_double, C.c_int32, C.c_int32, _pi32]),
+    ("gpf_resample_local", C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, _pi32]),
     ("gpf_resample_with_priorities", C.c_int, [_H, C.c_int32, _pd, C.c_int32, C.c_int32, _pi32]),
     ("gpf_rejuvenate", C.c_int, [_H, C.c_int32, C.c_int32, _pu64]),
     ("gpf_effective_sample_size", C.c_int, [_H, _pd]),

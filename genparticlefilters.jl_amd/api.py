@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import warnings
 
 import numpy as np
@@ -205,6 +206,7 @@ class DeviceParticleFilterSubState(DeviceParticleFilterState):
 
     def __init__(self, source: DeviceParticleFilterState, start: int, count: int):
         self.source = source                     # keeps the parent alive
+        self.start = int(start)
         self._L = source._L
         self.model, self.seed, self.keep_prev = source.model, source.seed, source.keep_prev
         self.n_particles, self.dim, self.row_width = int(count), source.dim, source.row_width
@@ -313,7 +315,14 @@ def _resample(state, method_id: int, priority_fn, check, sort_particles: bool):
     check_id = 2 if check is True else (1 if check == "warn" else 0)
     inv = C.c_int32(0)
     inv_ptr = C.byref(inv) if check_id != 0 else None          # check=false: fully asynchronous
-    if priority_fn is None or isinstance(priority_fn, Tempering):
+    err_handle = state._h
+    if (priority_fn is None and isinstance(state, DeviceParticleFilterSubState) and state.start == 0
+            and state.n_particles == state.source.n_particles and os.environ.get("GPF_VIEW_RESAMPLE") != "eager"):
+        # pf_resample!(state[1:end], ...): the library resamples the whole filter with the sub-state semantics itself
+        # (gpf_resample_local: same result, no eager gather, no copies through the view handle)
+        err_handle = state.source._h
+        st = state._L.gpf_resample_local(err_handle, method_id, int(sort_particles), check_id, inv_ptr)
+    elif priority_fn is None or isinstance(priority_fn, Tempering):
         alpha = float("nan") if priority_fn is None else priority_fn.alpha
         st = state._L.gpf_resample(state._h, method_id, alpha, int(sort_particles), check_id, inv_ptr)
     else:
@@ -325,9 +334,8 @@ def _resample(state, method_id: int, priority_fn, check, sort_particles: bool):
         except TypeError:
             lp = np.array([priority_fn(float(w)) for w in lw], np.float64)
         st = state._L.gpf_resample_with_priorities(state._h, method_id, _pd(lp), int(sort_particles), check_id, inv_ptr)
-    if st == _lib.ERR_INVALID_WEIGHTS:
-        raise ErrorException(state._L.gpf_last_error(state._h).decode())       # error("Invalid weights.")
-    state._check(st)
+    if st != _lib.OK:
+        raise ErrorException(state._L.gpf_last_error(err_handle).decode())     # error("Invalid weights."), ...
     if check == "warn" and inv.value:
         warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")   # utils.jl:120-135
     return state

@@ -40,6 +40,7 @@ struct Scalars {
     WSum     raw;              // state.log_weights (log-ML estimate, ESS)
     WSum     post;             // log_ws after a prioritised resample (update_weights!, resample.jl:198-200)
     double   lml_est;          // state.log_ml_est
+    double   lw_fill;          // log-weight every particle carries after a whole-shard sub-state resample (gpf_resample_local)
     uint64_t Ctot;             // residual: number of deterministic copies (n_resampled)
     uint64_t Rs;               // residual: sum of residual weights
     uint64_t n_accept;         // accepted MH moves of the last gpf_rejuvenate
@@ -224,6 +225,7 @@ struct PackedCommit {
     const double* packed;      // [n][W + 1], or nullptr
     int32_t* anc;              // parents of the committed population
     const double* mf_all; const int64_t* tot_all; int G, K; double logN; Scalars* sc;   // update_lml_est! from the gathered summaries
+    const double* lw_fill;     // GATHER after gpf_resample_local: the incoming log-weights are this constant, not 0 (resample.jl:210)
 };
 template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
@@ -287,7 +289,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
         double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(o[2 * c], o[2 * c + 1]);
-        const double nl = (GATHER || PACKED) ? ll : lw[i] + ll;      // after a resample the incoming log-weights are 0
+        const double nl = (GATHER || PACKED) ? ((GATHER && pc.lw_fill) ? *pc.lw_fill + ll : ll)   // after a resample the incoming
+                                             : lw[i] + ll;                                    // log-weights are 0 (or one constant)
         lw[i] = nl;
         track_max(nl, bm, bf);
     }
@@ -911,7 +914,8 @@ struct SearchArgs {
     uint64_t seed; uint32_t epoch;
     int K; double logN;
     double invN;                                                      // 1 / n_global (stratified)
-    int update_lml;                                                   // 0 for sub-state views (resample.jl:185-187)
+    int update_lml;                                                   // 0 for sub-state views (resample.jl:185-187); 2: whole-shard
+                                                                      // sub-state, the kept mass goes to sc->lw_fill (resample.jl:210)
     int32_t* anc;
 };
 
@@ -1045,6 +1049,13 @@ __device__ __forceinline__ void search_pair(const SearchTop& st, const CdfLevels
     idx[1] = idx[1] < n_cells ? idx[1] : n_cells - 1;
 }
 
+// once per resample: update_lml_est! (resample.jl:57,178-182), or for a whole-shard sub-state the log-weight its particles keep
+__device__ __forceinline__ void resample_bookkeeping(const SearchArgs& a)
+{
+    const double v = lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN;
+    if (a.update_lml == 2) a.sc->lw_fill = v;                    // resample.jl:210: every log-weight = logsumexp - log n
+    else a.sc->lml_est = a.sc->lml_est + v;
+}
 template <int METHOD>
 __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(SearchArgs a)
 {
@@ -1052,7 +1063,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
     const SearchTop st = search_prologue(a.w, a.c, METHOD == 1, a.ntiles, reinterpret_cast<uint64_t*>(smem));
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
     if (a.update_lml && blockIdx.x == 0 && threadIdx.x == 0)
-        a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
+        resample_bookkeeping(a);
     const uint64_t S = (METHOD == 1 || METHOD == 3) ? a.sc->Rs : a.ws->S;
     const uint64_t N = (uint64_t)a.n_global;
     // systematic: S = N B + rem, once per workgroup (u64 division is ~100 instructions)
@@ -1306,7 +1317,7 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_search_multi(SearchArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
     if (a.update_lml && blockIdx.x == 0 && threadIdx.x == 0)
-        a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
+        resample_bookkeeping(a);
     const uint64_t S = a.ws->S;
     // the lane's NS consecutive slots from slot `base` on (independent chains: the LDS and L2 round trips of one hide
     // behind the others); one Philox block per aligned slot pair (resample_u64), one more block when the run starts odd
@@ -1440,7 +1451,7 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
     if (a.update_lml && blockIdx.x == 0 && tid == 0)
-        a.sc->lml_est = a.sc->lml_est + (lse_from(a.raw->m, a.raw->S, a.K, a.raw->flags) - a.logN);
+        resample_bookkeeping(a);
     const uint64_t N = (uint64_t)a.n_global;
     const double invN = a.invN;
     const int64_t j0 = (int64_t)blockIdx.x * MJB;
@@ -2512,6 +2523,11 @@ __global__ __launch_bounds__(BLOCK) void k_wsum_values(const double* __restrict_
 
 // ----------------------------------------------------------------------------- sub-state views (src/view.jl, resample.jl:205-218)
 // after resampling a view: every log-weight = logsumexp(view) - log n (the block keeps its total mass, resample.jl:210)
+__global__ void k_fill_from(double* __restrict__ lw, int64_t n, const double* __restrict__ value)
+{
+    const double v = *value;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) lw[i] = v;
+}
 __global__ void k_view_fill_weights(double* __restrict__ lw, int64_t n, const WSum* ws, int K, double logN)
 {
     const double v = lse_from(ws->m, ws->S, K, ws->flags) - logN;

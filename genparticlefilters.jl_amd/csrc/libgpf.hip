@@ -84,6 +84,7 @@ struct gpf_filter {
     bool raw_has_q = false;        // the raw summary's scan also accumulated sum q^2 (blockQ)
     bool raw_q_folded = false;     // sc->raw.Ql folded from blockQ
     bool pending_gather = false;   // a resample left (rows[cur], anc) un-gathered; log-weights are 0
+    bool pending_fill = false;     // ... or, after gpf_resample_local, the constant sc->lw_fill
     bool pending_packed = false;   // sharded: the resampled population is still the received exchange buffer (gpf_shard_commit)
     const double* pend_packed = nullptr; const double* pend_mf = nullptr; const int64_t* pend_tot = nullptr; int pend_G = 0;
     // trajectory store (gpf_history_enable): per recorded step the d latent columns in the step's final particle
@@ -259,9 +260,12 @@ void launch_step_t(gpf_filter* h, int grid)
         const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc};
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags, pc);
-    } else if (h->pending_gather)
+    } else if (h->pending_gather) {
+        PackedCommit pc{};
+        pc.lw_fill = h->pending_fill ? &h->sc->lw_fill : nullptr;
         GPF_LAUNCH((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags, PackedCommit{});
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags, pc);
+    }
     else
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags, PackedCommit{});
@@ -365,9 +369,10 @@ gpf_status materialize(gpf_filter* h)
     if (!h->pending_gather) return GPF_OK;
     gpf_status s = timed(h, GPF_K_GATHER, [&] { launch_gather(h, raw_view(h), h->lw); });
     if (s) return s;
+    if (h->pending_fill) GPF_LAUNCH(k_fill_from, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->lw, h->n, &h->sc->lw_fill);
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
-    h->pending_gather = false;
+    h->pending_gather = false; h->pending_fill = false;
     h->max_valid = false;           // log-weights are all 0 now
     return GPF_OK;
 }
@@ -687,7 +692,7 @@ void launch_multinomial_search(gpf_filter* h, const SearchArgs& sa)
     else                GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), search_lds_bytes(sa.ntiles, 1), h->stream, sa);
 }
 
-gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_particles, int check, int32_t* invalid)
+gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_particles, int check, int32_t* invalid, bool local = false)
 {
     if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED)
         return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");          // resample.jl:28
@@ -741,7 +746,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     sa.order = sorted ? h->order : nullptr; sa.sc = h->sc; sa.ws = ws; sa.raw = &h->sc->raw; sa.n = h->n; sa.n_cells = h->n;
     sa.n_global = h->cfg.n_global; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
     sa.K = h->K; sa.logN = h->logN; sa.anc = h->anc; sa.invN = 1.0 / (double)h->cfg.n_global;
-    sa.update_lml = h->parent ? 0 : 1;                           // sub-states do not track the estimate (resample.jl:185-187)
+    sa.update_lml = local ? 2 : (h->parent ? 0 : 1);             // sub-states do not track the estimate (resample.jl:185-187)
 
     if (method == GPF_RESAMPLE_RESIDUAL) {
         if ((s = residual_scans(h, ws, h->cfg.n_global))) return s;
@@ -784,6 +789,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         // new_traces .= view(traces, parents) is deferred: the next pf_update! reads rows through anc (fused
         // gather), any other consumer calls materialize().  Log-weights are 0 (resample.jl:195).
         h->pending_gather = true;
+        h->pending_fill = local;
         h->max_valid = false;
     } else {
         // gather + update_weights! with priorities (resample.jl:60,198-200), update_refs! (utils.jl:10-15)
@@ -960,7 +966,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
         else                { DISPATCH_MODEL(h, (launch_init_t<MM, 0>(h, grid))); }
     });
     if (s) return s;
-    h->pending_gather = false;
+    h->pending_gather = false; h->pending_fill = false;
     h->pending_packed = false;
     h->max_valid = true; h->max_np = grid;
     GPF_LAUNCH(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
@@ -1013,7 +1019,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
-    h->pending_gather = false;      // a pending resample gather was fused into this step
+    h->pending_gather = false; h->pending_fill = false;      // a pending resample gather was fused into this step
     h->pending_packed = false;      // ... or a pending sharded commit
     h->max_valid = true; h->max_np = grid;
     h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
@@ -1063,6 +1069,24 @@ gpf_status gpf_resample(gpf_handle h, int32_t method, double priority_alpha, int
     return resample_impl(h, method, pv, sort_particles, check, invalid);
 }
 
+// pf_resample!(state[1:n], method) on a whole filter or shard (src/resample.jl:185-187,205-218) without the view's copies: it
+// normalises over its OWN n particles (strata, fixed-point scale and log n of n, not of n_global), leaves log_ml_est alone and
+// every particle keeps the log-weight logsumexp - log n.  The gather stays deferred like gpf_resample's.
+gpf_status gpf_resample_local(gpf_handle h, int32_t method, int32_t sort_particles, int32_t check, int32_t* invalid)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (h->parent) return fail(h, GPF_ERR_STATE, "gpf_resample_local on a sub-state view: resample the view itself");
+    if ((s = materialize(h))) return s;
+    struct Scope {                                               // the filter as its own population for the duration of the call
+        gpf_filter* h; int K; double logN; int64_t ng;
+        explicit Scope(gpf_filter* f) : h(f), K(f->K), logN(f->logN), ng(f->cfg.n_global)
+        { h->K = fix_K(h->n); h->logN = log_((double)h->n); h->cfg.n_global = h->n; h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; }
+        ~Scope() { h->K = K; h->logN = logN; h->cfg.n_global = ng; h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; }
+    } scope(h);
+    return resample_impl(h, method, raw_view(h), sort_particles, check, invalid, true);
+}
+
 gpf_status gpf_resample_with_priorities(gpf_handle h, int32_t method, const double* log_priorities, int32_t sort_particles,
                                         int32_t check, int32_t* invalid)
 {
@@ -1083,6 +1107,7 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
     if (!h->cfg.keep_prev) return fail(h, GPF_ERR_STATE, "gpf_rejuvenate needs keep_prev = 1 (x_{t-1} must travel with the particle)");
     if (n_iters < 0) return fail(h, GPF_ERR_INVALID_ARGUMENT, "n_iters < 0");
     if (h->pending_packed && (s = materialize(h))) return s;     // sharded deferred commit: scatter first
+    if (h->pending_fill && (s = materialize(h))) return s;       // (the move kernel's fused gather assumes incoming weights 0)
     const bool fused_gather = h->pending_gather;                 // a pending resample gather rides on the move kernel
     HIP_TRY(h, hipMemsetAsync(&h->sc->n_accept, 0, sizeof(uint64_t), h->stream));
     const int grid = step_grid(h);
@@ -1094,7 +1119,7 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;
     h->epoch += 1;
-    if (fused_gather) { h->pending_gather = false; h->max_valid = false; }   // log-weights are all 0 now (resample.jl:195)
+    if (fused_gather) { h->pending_gather = false; h->pending_fill = false; h->max_valid = false; }   // log-weights are all 0 now (resample.jl:195)
     if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; h->max_np = grid; }
     mutated(h);
     if ((s = view_exit(h))) return s;
@@ -1427,7 +1452,7 @@ static gpf_status resize_ready(gpf_handle h)
 static void set_count(gpf_filter* h, int64_t n_new)
 {
     h->n = n_new; h->cfg.n_particles = n_new; h->cfg.n_global = n_new; h->cfg.gid0 = 0;
-    h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false; h->pending_gather = false;
+    h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false; h->pending_gather = false; h->pending_fill = false;
     h->pending_packed = false;
 }
 

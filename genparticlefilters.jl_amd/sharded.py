@@ -165,6 +165,21 @@ class HipShardBackend:
     def local_resample(self, method, priority_fn, check, sort_particles):
         """resample THIS shard's particles among themselves with the reference's sub-state semantics: a view of the whole shard"""
         from . import api
+        if priority_fn is None:
+            # the library's own whole-shard sub-state resample: same result as the view below, without its eager gather and copies
+            if check not in (True, False, "warn"):
+                raise ValueError("check must be True, 'warn' or False")
+            check_id = 2 if check is True else (1 if check == "warn" else 0)
+            inv = C.c_int32(0)
+            st = self.L.gpf_resample_local(self.h, RESAMPLE_METHODS[method], int(bool(sort_particles)), check_id,
+                                           C.byref(inv) if check_id else None)
+            if st == _lib.ERR_INVALID_WEIGHTS:
+                raise ErrorException(self.L.gpf_last_error(self.h).decode())
+            self._ck(st)
+            if check == "warn" and inv.value:
+                import warnings
+                warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")
+            return
         if getattr(self, "_view", None) is None:
             self._view = self.state[0:self.n]
         kw = {"sort_particles": sort_particles} if method == "stratified" else {}      # only the stratified resampler reads it

@@ -120,6 +120,12 @@ gpf_status gpf_update_strata(gpf_handle h, const double* obs, int32_t n_obs, con
 gpf_status gpf_resample(gpf_handle h, int32_t method, double priority_alpha, int32_t sort_particles,
                         int32_t check, int32_t* invalid);
 
+/* pf_resample!(state[1:n], method; check, sort_particles) on the WHOLE filter (or shard): the sub-state semantics of
+ * src/resample.jl:185-187,205-218 -- normalised over its own n particles, log_ml_est untouched, every particle keeps
+ * the log-weight logsumexp(log_weights) - log n -- without the copies a view handle makes; the gather stays deferred
+ * like gpf_resample's.  On a shard of a sharded filter this is the communication-free "island" resample. */
+gpf_status gpf_resample_local(gpf_handle h, int32_t method, int32_t sort_particles, int32_t check, int32_t* invalid);
+
 /* same, with log_priorities = priority_fn.(log_weights) evaluated by the caller (any closure):
  * log_priorities is a HOST array of n_particles doubles. */
 gpf_status gpf_resample_with_priorities(gpf_handle h, int32_t method, const double* log_priorities,

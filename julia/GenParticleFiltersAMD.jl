@@ -68,6 +68,7 @@ Base.view(s::DeviceParticleFilterState, r::UnitRange{Int}) = s[r]
 
 check(state, st) = st == 0 ? nothing :
     error(unsafe_string(ccall((:gpf_last_error, libgpf), Cstring, (Ptr{Cvoid},), state.handle)))   # ErrorException
+const _status = check        # for methods whose keyword argument is called `check`, like the reference's pf_resample!
 
 # src/initialize.jl:31-44
 function pf_initialize(model::NativeModel, model_args::Tuple, observations::Vector{Float64}, n_particles::Int; kw...)
@@ -278,12 +279,18 @@ function pf_rejuvenate!(s::ShardedDeviceParticleFilterState, kern=nothing, kern_
     m = method == :move ? 0 : method == :reweight ? 1 : error("Method $method not recognized.")
     check(s, ccall((:gpf_rejuvenate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, C_NULL)); s
 end
-# src/resample.jl:19-30 over all shards: ONE call, every collective issued by the library
-function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multinomial; check=:warn)
+# src/resample.jl:19-30 over all shards: ONE call, every collective issued by the library.
+# local_only = true: the communication-free "island" resample, pf_resample!(state[shard range], method) on every shard
+# (sub-state semantics, src/resample.jl:185-187,205-218), also one call (gpf_resample_local).
+function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multinomial; check=:warn, sort_particles::Bool=false,
+                      local_only::Bool=false)
     m = method == :multinomial ? 0 : method == :residual ? 1 : method == :stratified ? 2 : error("Resampling method $method not recognized.")
     chk = check === true ? 2 : (check === :warn ? 1 : 0)
     invalid = Ref{Cint}(0)
-    check(s, ccall((:gpf_shard_resample, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cint}), s.handle, m, chk, invalid))
+    st = local_only ?
+        ccall((:gpf_resample_local, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ref{Cint}), s.handle, m, sort_particles ? 1 : 0, chk, invalid) :
+        ccall((:gpf_shard_resample, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cint}), s.handle, m, chk, invalid)
+    _status(s, st)                                # (the keyword `check` shadows the status helper of that name in this method)
     check === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
     return s
 end

@@ -123,3 +123,49 @@ def test_hip_views_are_live(g, o, method):
     assert g.get_ess(w) == ow.effective_sample_size()
     assert g.get_ess(st) == orc.effective_sample_size() and g.get_lml_est(st) == orc.log_ml_estimate()
     assert np.array_equal(v.parents, st.parents[501:2604])   # parents of a view alias the source's
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("follow", ["update", "rejuvenate", "getters", "resample"])
+def test_hip_whole_view_resample_is_the_library_local_resample(g, o, monkeypatch, method, follow):
+    """pf_resample!(state[1:end], method): gpf_resample_local (deferred gather, the kept log-weight as one device constant)
+    must equal the view handle's eager path AND the oracle's sub-state resample, whatever consumes the result next"""
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 5); N = 20_000
+    kw = dict(sort_particles=True) if method == "stratified" else {}
+
+    def run(eager):
+        if eager:
+            monkeypatch.setenv("GPF_VIEW_RESAMPLE", "eager")
+        else:
+            monkeypatch.delenv("GPF_VIEW_RESAMPLE", raising=False)
+        st = g.pf_initialize(model, (1,), ys[0], N, seed=9, keep_prev=True)
+        g.pf_update(st, (2,), (None,), ys[1])
+        lml0 = g.get_lml_est(st)
+        g.pf_resample(st[0:N], method, check="warn", **kw)
+        if follow == "update":
+            g.pf_update(st, (3,), (None,), ys[2])
+        elif follow == "rejuvenate":
+            g.pf_rejuvenate(st, g.mh, (), 1)
+        elif follow == "resample":
+            g.pf_resample(st, "multinomial", check=False)
+            g.pf_update(st, (3,), (None,), ys[2])
+        out = (st.parents.copy(), st.traces.copy(), st.log_weights.copy(), g.get_lml_est(st), g.get_ess(st))
+        if follow == "getters":
+            np.testing.assert_allclose(out[3], lml0, rtol=1e-12)       # a sub-state resample keeps the estimate (resample.jl:185-187)
+        return out
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    orc = o.OracleFilter(model.model_id, model.params, N, 9, keep_prev=True).initialize(ys[0])
+    orc.update(ys[1])
+    orc[0:N].resample(method, check=False, **kw)
+    if follow == "update":
+        orc.update(ys[2])
+    elif follow == "rejuvenate":
+        orc.rejuvenate("move", 1)
+    elif follow == "resample":
+        orc.resample("multinomial", check=False); orc.update(ys[2])
+    assert np.array_equal(b[0], orc.parents) and np.array_equal(b[1], orc.rows) and np.array_equal(b[2], orc.lw)
+    assert b[3] == orc.log_ml_estimate() and b[4] == orc.effective_sample_size()
