@@ -1991,7 +1991,11 @@ bool rccl_load(std::string& err)
     if (g_rccl.lib) return true;
     const char* names[] = {"librccl.so", "librccl.so.1"};
     void* L = nullptr;
-    for (const char* n : names) if ((L = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    // tests: GPF_RCCL_LIBRARY names a library with the same nine entry points (tests/loopback_rccl: several ranks on one GPU)
+    if (const char* over = getenv("GPF_RCCL_LIBRARY")) {
+        if (!(L = dlopen(over, RTLD_NOW | RTLD_LOCAL))) { err = std::string("GPF_RCCL_LIBRARY: ") + dlerror(); return false; }
+    }
+    if (!L) for (const char* n : names) if ((L = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
     if (!L) for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((L = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!L) { err = std::string("librccl not found: ") + dlerror(); return false; }
 #define GPF_RCCL_SYM(field, name) *reinterpret_cast<void**>(&g_rccl.field) = dlsym(L, name); if (!g_rccl.field) { err = std::string("librccl lacks ") + name; return false; }

@@ -29,6 +29,7 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
         model = g.models.by_name(model_name)
         ys = g.models.simulate(model, T)
         st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, keep_prev=rejuv is not None, device=0)
+        assert st.backend.lib_comm == (os.environ.get("GPF_SHARD_ENGINE", "python" if backend == "gloo" else "library") == "library")
         ess_log, lml_log = [], []
         for t in range(1, T):
             ess = sharded.get_ess(st); ess_log.append(ess)
@@ -68,6 +69,7 @@ def run_skew(rank, world, port, method, n_global, pattern, out_dir):
         model = g.models.lgssm2()
         ys = g.models.simulate(model, 3)
         st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, device=0)
+        assert st.backend.lib_comm == (os.environ.get("GPF_SHARD_ENGINE", "python") == "library")
         loc = st.local
         loc.log_weights = skew_weights(n_global, pattern)[st.gid0:st.gid0 + st.n_local]
         sharded.pf_resample(st, method, check=False)

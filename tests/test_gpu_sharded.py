@@ -16,10 +16,9 @@ import shard_worker  # noqa: E402
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
-def test_hip_shards_equal_single_oracle(g, o, tmp_path, case):
+def test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=2):
     model_name, method, n_global, T, ess_frac, rejuv = case
     n_global *= 20                       # a few scan tiles per shard
-    world = 2
     mp.spawn(shard_worker_gpu.run, args=(world, free_port(), model_name, method, n_global, T, ess_frac, rejuv, str(tmp_path)),
              nprocs=world, join=True)
     f, ess_log, lml_log = single(g, o, model_name, method, n_global, T, ess_frac, rejuv)
@@ -72,6 +71,37 @@ def test_rccl_collectives_one_rank(g, o, tmp_path, case, engine):
     p = np.load(os.path.join(tmp_path, "rank0.npz"))
     assert np.array_equal(p["parents"], f.parents) and np.array_equal(p["rows"], f.rows) and np.array_equal(p["lw"], f.lw)
     assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
+
+
+@pytest.fixture(scope="module")
+def loopback_lib(tmp_path_factory):
+    """tests/loopback_rccl: the nine RCCL entry points libgpf calls, over files in /dev/shm (several ranks on ONE GPU)"""
+    import subprocess
+    out = tmp_path_factory.mktemp("loopback") / "libloopback_rccl.so"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(HERE, "loopback_rccl", "loopback_rccl.cpp"),
+                    "-o", str(out)], check=True)
+    return str(out)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
+def test_library_engine_several_ranks_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, case, world):
+    """gpf_shard_resample / gpf_shard_effective_sample_size / gpf_shard_log_ml_estimate -- the library engine, its all-gathers and
+    its grouped send / receive exchange with real counts and offsets -- with 2 and 3 ranks.  Real RCCL refuses two ranks on one
+    device and the build environment has no multi-GPU box, so the transport under the library is the loopback stand-in; every
+    line of libgpf's own multi-rank code runs.  Result: bit-identical to the single-shard oracle."""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
+    monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
+
+
+@pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+def test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern):
+    """zero-length sends, one shard serving everything (send-buffer overflow and the repeated push) through the library engine"""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
+    monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern)
 
 
 @pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
