@@ -137,12 +137,29 @@ class HipShardBackend:
             blob = [None]
             if rank == 0:
                 raw = (C.c_char * 128)()
-                self._ck(self.L.gpf_comm_unique_id(C.cast(raw, C.c_void_p)))
-                blob = [bytes(raw)]
+                try:
+                    self._ck(self.L.gpf_comm_unique_id(C.cast(raw, C.c_void_p)))
+                    blob = [bytes(raw)]
+                except ErrorException as e:                      # every rank must learn it, or the others wait for the id forever
+                    blob = [("error", str(e))]
             if world > 1:
                 dist.broadcast_object_list(blob, src=0, group=group)
+            if isinstance(blob[0], tuple):
+                raise ErrorException(f"gpf_comm_unique_id failed on rank 0: {blob[0][1]}")
             idbuf = (C.c_char * 128).from_buffer_copy(blob[0])
-        self._ck(self.L.gpf_comm_create(self.h, C.cast(idbuf, C.c_void_p) if idbuf is not None else None, rank, world))
+        ok, err = 1, ""
+        try:
+            self._ck(self.L.gpf_comm_create(self.h, C.cast(idbuf, C.c_void_p) if idbuf is not None else None, rank, world))
+        except ErrorException as e:
+            ok, err = 0, str(e)
+        if world > 1:                                            # all ranks use the library engine, or none does
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if not int(flag.item()) and ok:
+                err = "gpf_comm_create failed on another rank"
+            ok = int(flag.item())
+        if not ok:
+            raise ErrorException(err)
         self.lib_comm = True
 
     def shard_resample(self, method_id: int, check) -> bool:

@@ -58,3 +58,34 @@ def test_sharded_path_with_rccl_one_rank(built):
     assert out["n_gpus"] == 1 and out["shard_engine"].startswith("library") and out["value"] > 5e7
     assert out["roofline"]["kernel"] in ("k_push", "k_push_scan", "k_step", "k_scan")
     assert abs(out["log_ml_abs_error"]) < 1.0
+
+
+@pytest.mark.gpu
+def test_two_ranks_library_engine_over_loopback(built, tmp_path):
+    """`bench.py --gpus 2` through the LIBRARY engine (gpf_shard_resample: what the driver's multi-GPU runs take), two ranks on
+    cuda:0 with tests/loopback_rccl under it; and the guard: with a transport that cannot be loaded every rank falls back to
+    the torch.distributed engine together and says so"""
+    lib = tmp_path / "libloopback_rccl.so"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "loopback_rccl", "loopback_rccl.cpp"),
+                    "-o", str(lib)], check=True)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29735", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+           "--particles-per-gpu", "200000"]
+    env = dict(os.environ, GPF_BENCH_ONE_DEVICE="1", GPF_SHARD_ENGINE="library", GPF_RCCL_LIBRARY=str(lib))
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _last_json(p.stdout)
+    assert out["n_gpus"] == 2 and out["shard_engine"].startswith("library") and "fell back" not in out["shard_engine"]
+    ref = out["log_ml_estimate"]
+    # the same run through the python engine: same filter, same estimate, bit for bit
+    p2 = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, GPF_BENCH_ONE_DEVICE="1"), capture_output=True, text=True, timeout=900)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    assert _last_json(p2.stdout)["log_ml_estimate"] == ref
+    # a transport that does not exist: the guard moves both ranks to the python engine
+    env_bad = dict(os.environ, GPF_BENCH_ONE_DEVICE="1", GPF_RCCL_LIBRARY=str(tmp_path / "missing.so"))
+    env_bad.pop("GPF_SHARD_ENGINE", None)
+    cmd_bad = list(cmd); cmd_bad[cmd_bad.index("29735")] = "29737"
+    p3 = subprocess.run(cmd_bad, cwd=ROOT, env=dict(env_bad, GPF_BENCH_TRY_LIBRARY="1"), capture_output=True, text=True, timeout=900)
+    assert p3.returncode == 0, p3.stderr[-3000:]
+    out3 = _last_json(p3.stdout)
+    assert out3["shard_engine"].startswith("python") and "fell back" in out3["shard_engine"] and out3["log_ml_estimate"] == ref
