@@ -31,6 +31,20 @@ def test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=2):
         assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
 
 
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+@pytest.mark.parametrize("n_global,world", [(10, 3), (3, 3), (257, 2)])
+def test_hip_tiny_shards(g, o, tmp_path, method, n_global, world):
+    """shards of 1 to a few particles (fewer slots than a workgroup handles, shard totals that differ a lot)"""
+    mp.spawn(shard_worker_gpu.run, args=(world, free_port(), "lgssm2", method, n_global, 5, None, None, str(tmp_path)), nprocs=world, join=True)
+    f, ess_log, lml_log = single(g, o, "lgssm2", method, n_global, 5, None, None)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
+    assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
+    for p in parts:
+        assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
+
+
 def test_world1_sharded_equals_unsharded(g, o):
     """G = 1 through sharded.py (no process group) equals the plain single-GPU API."""
     from gpf_amd import sharded
