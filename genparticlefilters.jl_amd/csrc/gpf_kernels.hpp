@@ -2080,6 +2080,26 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
     for (int64_t c = blockIdx.x; c < a.nchunks; c += gridDim.x) {
         int64_t j0, j1;
         const int g = push_chunk(a, t, c, j0, j1);
+        if (METHOD == 1 && (uint64_t)j1 <= sc.Ctot) {                                 // block-uniform
+            // the chunk lies in the residual resampler's deterministic head (resample.jl:96-106): slot j is the j-th copy, its
+            // target is j itself in the copy-count space -- no uniform to draw, and the hits are ONE range of slots
+            const uint64_t h0 = (uint64_t)j0 > c_lo ? (uint64_t)j0 : c_lo, h1 = (uint64_t)j1 < c_hi ? (uint64_t)j1 : c_hi;
+            const unsigned total = h1 > h0 ? (unsigned)(h1 - h0) : 0u;
+            if (g == a.me && wv == 0 && lane < a.G) {                                 // who serves this shard's own slots
+                const uint64_t q0 = lane ? (uint64_t)t.c_incl[lane - 1] : 0, q1 = lane == a.G - 1 ? ~0ull : (uint64_t)t.c_incl[lane];
+                const uint64_t r0 = (uint64_t)j0 > q0 ? (uint64_t)j0 : q0, r1 = (uint64_t)j1 < q1 ? (uint64_t)j1 : q1;
+                if (r1 > r0) recv_cnt += (unsigned)(r1 - r0);
+            }
+            if (total) {                                                              // block-uniform
+                if (threadIdx.x == 0) s_base = atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + g), (unsigned long long)total);
+                __syncthreads();
+                ulonglong2* dst = a.stage + t.bounds[g] + s_base;
+                for (unsigned k = threadIdx.x; k < total; k += PUSH_SCAN_BLOCK)
+                    dst[k] = make_ulonglong2((h0 + k - c_lo) | (1ull << 62), h0 + k - (uint64_t)t.bounds[g]);
+                __syncthreads();                                                      // s_base
+            }
+            continue;
+        }
         uint64_t Tl[R];
         unsigned hits = 0;                                                            // bit r: round r is a hit
         // the lane's R consecutive slots: one Philox block per aligned slot pair (resample_u64), one more when the run starts odd
