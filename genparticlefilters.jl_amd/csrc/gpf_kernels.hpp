@@ -683,7 +683,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
         __syncthreads();                                // s_wave / s_red reuse
     }
     if constexpr (WANT_Q) {
-        // block partial of the limb sums of sum q^2 (plain stores, folded on demand by k_fold_q)
+        // block partial of the limb sums of sum q^2 (plain stores, folded on demand by k_publish_scalars)
         __shared__ uint64_t s_q[NWAVES][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
@@ -782,37 +782,38 @@ __global__ __launch_bounds__(BLOCK) void k_scan_residual2(const uint64_t* __rest
 
 // the device scalar block -> its pinned host mirror, ticket last: the host polls the ticket instead of synchronising the
 // stream (a hipMemcpyAsync + hipStreamSynchronize pair costs ~13 us of wake-up latency per getter; this costs the launch)
-__global__ void k_publish_scalars(const Scalars* sc, Scalars* host, long long* host_ticket, long long ticket)
+// blockQ != nullptr: the limb partials of sum q^2 that the scan blocks left (only the ESS needs them) are folded into sc->raw.Ql
+// on the way -- one launch for "fold + publish" (the ESS-triggered loop of BASELINE config 4 asks for the ESS every step).
+// Launched with ONE wave.
+__global__ void k_publish_scalars(Scalars* sc, Scalars* host, long long* host_ticket, long long ticket,
+                                  const uint64_t* __restrict__ blockQ, int nblk)
 {
     constexpr int NW = (int)(sizeof(Scalars) / sizeof(unsigned long long));
     static_assert(sizeof(Scalars) % sizeof(unsigned long long) == 0, "Scalars must be a whole number of 8-byte words");
+    constexpr int QW = (int)((offsetof(Scalars, raw) + offsetof(WSum, Ql)) / sizeof(unsigned long long));
+    uint64_t q[4] = {0, 0, 0, 0};
+    const bool fold = blockQ != nullptr;
+    if (fold) {
+        for (int b = threadIdx.x; b < nblk; b += WAVE)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] += blockQ[(int64_t)b * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = wave_sum_u64(q[k]);                 // every lane holds the totals
+        if (threadIdx.x < 4) sc->raw.Ql[threadIdx.x] = threadIdx.x == 0 ? q[0] : threadIdx.x == 1 ? q[1] : threadIdx.x == 2 ? q[2] : q[3];
+    }
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(sc);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(host);
-    for (int i = threadIdx.x; i < NW; i += blockDim.x)
-        __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = threadIdx.x; i < NW; i += blockDim.x) {
+        unsigned long long v = src[i];
+        if (fold && i >= QW && i < QW + 4) v = i == QW ? q[0] : i == QW + 1 ? q[1] : i == QW + 2 ? q[2] : q[3];   // (not read back: just written)
+        __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ----------------------------------------------------------------------------- scalar bookkeeping
-// sum of the scan blocks' limb partials of sum q^2 -> ws->Ql (only needed when the ESS is asked for)
-__global__ __launch_bounds__(BLOCK) void k_fold_q(WSum* ws, const uint64_t* __restrict__ blockQ, int nblk)
-{
-    __shared__ uint64_t s_q[NWAVES][4];
-    uint64_t ql[4] = {0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblk; b += BLOCK)
-        for (int k = 0; k < 4; ++k) ql[k] += blockQ[(int64_t)b * 4 + k];
-    for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
-    if (lane_id() == 0) for (int k = 0; k < 4; ++k) s_q[wave_id()][k] = ql[k];
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        uint64_t t = 0;
-        for (int w = 0; w < NWAVES; ++w) t += s_q[w][threadIdx.x];
-        ws->Ql[threadIdx.x] = t;
-    }
-}
-
 // ----------------------------------------------------------------------------- K5: ancestor search
 // a = first index with cdf[a] > T.  The CDF comes with coarser levels written by the scan (fan-out 16):
 // top level (per-256 prefixes, or the prefix of every 2^g-th tile when those do not fit) is binary-searched in LDS, then each

@@ -513,11 +513,12 @@ gpf_status check_scan_timeout(gpf_filter* h)
     return GPF_OK;
 }
 
-gpf_status fetch_scalars(gpf_filter* h)
+gpf_status fetch_scalars(gpf_filter* h, bool fold_raw_q = false)
 {
     if (!h->h_sc_ticket) { HIP_TRY(h, hipHostMalloc(&h->h_sc_ticket, sizeof(long long))); *h->h_sc_ticket = 0; }
     h->sc_ticket += 1;
-    GPF_LAUNCH(k_publish_scalars, dim3(1), dim3(64), 0, h->stream, h->sc, h->h_sc, h->h_sc_ticket, h->sc_ticket);
+    GPF_LAUNCH(k_publish_scalars, dim3(1), dim3(WAVE), 0, h->stream, h->sc, h->h_sc, h->h_sc_ticket, h->sc_ticket,
+               fold_raw_q ? h->blockQ : nullptr, fold_raw_q ? scan_grid(h) : 0);
     HIP_TRY(h, hipGetLastError());
     { gpf_status w = wait_ticket(h, reinterpret_cast<volatile int64_t*>(h->h_sc_ticket), (int64_t)h->sc_ticket, "scalar block"); if (w) return w; }
     return check_scan_timeout(h);
@@ -1136,11 +1137,9 @@ gpf_status gpf_effective_sample_size(gpf_handle h, double* out)
     if (s) return s;
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
     if ((s = ensure_raw(h, true))) return s;
-    if (!h->raw_q_folded) {
-        GPF_LAUNCH(k_fold_q, dim3(1), dim3(BLOCK), 0, h->stream, &h->sc->raw, h->blockQ, scan_grid(h));
-        h->raw_q_folded = true;
-    }
-    if ((s = fetch_scalars(h))) return s;
+    const bool fold = !h->raw_q_folded;                          // the scan blocks' limb partials of sum q^2: folded by the publish kernel
+    if ((s = fetch_scalars(h, fold))) return s;
+    h->raw_q_folded = true;
     const WSum& w = h->h_sc->raw;
     if (w.flags) { *out = std::nan(""); return GPF_OK; }
     uint64_t hi, lo;
