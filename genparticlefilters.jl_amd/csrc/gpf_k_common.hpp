@@ -1,0 +1,136 @@
+// constants, device scalars, wave helpers  (part of gpf_kernels.hpp; include that header, not this file)
+#pragma once
+
+namespace gpf {
+
+constexpr int BLOCK = 256;
+constexpr int WAVE = 64;
+constexpr int NWAVES = BLOCK / WAVE;
+constexpr int SCAN_ITEMS = 8;
+constexpr int TILE = BLOCK * SCAN_ITEMS;          // 2048 weights per scan tile
+constexpr int MAX_PARTIALS = 2048;                // partial (max, flags) slots of the reduce kernels
+constexpr int MAX_SHARDS = 64;                    // shards (GPUs) of one filter
+constexpr int LDS_TILE_TABLE = 8192;              // tile-prefix entries kept in LDS by the search kernel (64 KiB)
+
+// ----------------------------------------------------------------------------- device scalars
+struct WSum {                  // summary of one weight vector
+    double   m;                // maximum
+    int32_t  flags;            // FLAG_NAN | FLAG_POSINF | FLAG_ALL_NEGINF  (safe_softmax, utils.jl:119-137)
+    int32_t  pad;
+    uint64_t S;                // sum of fixed-point weights
+    uint64_t Ql[4];            // 32-bit limbs sums of sum q^2 (un-normalised)
+    // strata of S over the filter's output slots, left by the scan that produced S: S = N sB + srem, sinv = N / S
+    uint64_t sB, srem;
+    double   sinv;
+};
+struct Scalars {
+    WSum     prio;             // weights the resampler samples from (log_priorities)
+    WSum     raw;              // state.log_weights (log-ML estimate, ESS)
+    WSum     post;             // log_ws after a prioritised resample (update_weights!, resample.jl:198-200)
+    double   lml_est;          // state.log_ml_est
+    double   lw_fill;          // log-weight every particle carries after a whole-shard sub-state resample (gpf_resample_local)
+    uint64_t Ctot;             // residual: number of deterministic copies (n_resampled)
+    uint64_t Rs;               // residual: sum of residual weights
+    uint64_t n_accept;         // accepted MH moves of the last gpf_rejuvenate
+    int32_t  timeout;          // set if a bounded inter-workgroup spin gave up (never expected)
+    int32_t  pad;
+    long long opt_d;           // optimal resize: threshold position in the descending order (-1: none)
+    uint64_t opt_a, opt_B;     // optimal resize: inverse weight threshold c = a S / B as the exact pair (a, B)
+};
+
+// how the resampler sees the weights: log_priorities = priority_fn.(log_weights) (resample.jl:51-52)
+struct PrioView {
+    const double* lw;          // state.log_weights
+    const double* lp;          // explicit priorities (mode 2) or nullptr
+    double alpha;              // mode 1: lp_i = alpha * lw_i
+    int mode;                  // 0 none, 1 alpha, 2 explicit
+    __device__ __forceinline__ double at(int64_t i) const
+    {
+        return mode == 0 ? lw[i] : (mode == 1 ? alpha * lw[i] : lp[i]);
+    }
+};
+
+// ----------------------------------------------------------------------------- wave helpers
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_up(lo, d, WAVE); hi = __shfl_up(hi, d, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, WAVE); hi = __shfl_xor(hi, m, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src, WAVE); hi = __shfl(hi, src, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double o = u2d(shfl_xor_u64(d2u(v), m));
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += u2d(shfl_xor_u64(d2u(v), m));
+    return v;
+}
+// inclusive scan across the 64 lanes
+__device__ __forceinline__ uint64_t wave_scan_u64(uint64_t v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint64_t o = shfl_up_u64(v, d);
+        if (l >= d) v += o;
+    }
+    return v;
+}
+
+// inclusive max-scan of a u32 across the 64 lanes, by DPP (no LDS crossbar round trips): Hillis-Steele inside each row of
+// 16, then the row totals travel with row_bcast15 / row_bcast31.  Lanes without a source read the identity 0.
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v)
+{
+#define GPF_DPP_MAX(ctrl, rmask) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xF, false); v = o_ > v ? o_ : v; }
+    GPF_DPP_MAX(0x111, 0xF)   // row_shr:1
+    GPF_DPP_MAX(0x112, 0xF)   // row_shr:2
+    GPF_DPP_MAX(0x114, 0xF)   // row_shr:4
+    GPF_DPP_MAX(0x118, 0xF)   // row_shr:8
+    GPF_DPP_MAX(0x142, 0xA)   // row_bcast:15 -> rows 1, 3
+    GPF_DPP_MAX(0x143, 0xC)   // row_bcast:31 -> rows 2, 3
+#undef GPF_DPP_MAX
+    return v;
+}
+
+// order-preserving key of Julia's isless on Float64 (-0.0 < 0.0); descending sort = ascending on ~key (K10), and its inverse
+__device__ __forceinline__ uint64_t sort_key_desc(double v)
+{
+    const uint64_t u = d2u(v);
+    const uint64_t asc = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    return ~asc;                              // ascending radix sort on ~key == descending by value, ties by index
+}
+__device__ __forceinline__ double sort_key_value(uint64_t key)
+{
+    const uint64_t asc = ~key;
+    return u2d((asc >> 63) ? (asc & 0x7fffffffffffffffull) : ~asc);
+}
+
+} // namespace gpf

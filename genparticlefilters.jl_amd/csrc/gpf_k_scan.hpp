@@ -1,0 +1,455 @@
+// K3/K4: maximum + validity flags, fixed-point weights and their CDF levels in one pass, scalar publication  (part of gpf_kernels.hpp; include that header, not this file)
+#pragma once
+
+namespace gpf {
+// ----------------------------------------------------------------------------- K3: max + flags
+// maximum(vs), any(isnan), all(== -Inf) of safe_softmax (utils.jl:119-128): per-block partials; the
+// consumers (k_scan, k_scalar) fold the <= MAX_PARTIALS partials themselves (no finalize launch).
+__global__ __launch_bounds__(BLOCK) void k_max_partial(PrioView pv, int64_t n, double* __restrict__ pmax,
+                                                       int32_t* __restrict__ pflags)
+{
+    double m = -__builtin_huge_val();
+    int f = 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const double v = pv.at(i);
+        if (v != v) f |= FLAG_NAN;
+        else { m = v > m ? v : m; if (v == __builtin_huge_val()) f |= FLAG_POSINF; }
+    }
+    m = wave_max_f64(m);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
+    __shared__ double sm[NWAVES];
+    __shared__ int sf[NWAVES];
+    if (lane_id() == 0) { sm[wave_id()] = m; sf[wave_id()] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < NWAVES; ++w) { m = sm[w] > m ? sm[w] : m; f |= sf[w]; }
+        pmax[blockIdx.x] = m;
+        pflags[blockIdx.x] = f;
+    }
+}
+
+// fold the partials: every lane of the block ends with (m, flags); needs 2 LDS arrays of NWAVES
+__device__ __forceinline__ void fold_partials(const double* __restrict__ pmax, const int32_t* __restrict__ pflags,
+                                              int np, double* sm, int* sf, double& m_out, int& f_out)
+{
+    double m = -__builtin_huge_val();
+    int f = 0;
+    for (int i = threadIdx.x; i < np; i += BLOCK) { const double v = pmax[i]; m = v > m ? v : m; f |= pflags[i]; }
+    m = wave_max_f64(m);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
+    if (lane_id() == 0) { sm[wave_id()] = m; sf[wave_id()] = f; }
+    __syncthreads();
+    m = sm[0]; f = sf[0];
+#pragma unroll
+    for (int w = 1; w < NWAVES; ++w) { m = sm[w] > m ? sm[w] : m; f |= sf[w]; }
+    if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+    m_out = m; f_out = f;
+    __syncthreads();
+}
+
+// ----------------------------------------------------------------------------- K4: fixed-point scan
+// Single-pass inclusive prefix sum over 2048-element tiles.  Every tile publishes its AGGREGATE at once;
+// its exclusive prefix is then ONE round trip: the whole workgroup reads, in parallel, the aggregates of
+// all earlier tiles of the same round (<= grid-1 <= 511 words, two per lane) plus the inclusive PREFIX of
+// the last tile of the previous round, and block-reduces them.  (A classic decoupled look-back walks 64
+// predecessors per dependent L2 round trip; with <= a few thousand tiles the flat read is shorter.)
+// A descriptor is ONE naturally aligned 8-byte word {valid bit 63 | 62-bit value}, written and polled
+// with relaxed agent-scope atomics (the data IS the flag: no fence, placement-independent; per-XCD L2s
+// are not coherent, so plain loads/stores would not do).  Deadlock freedom does not rely on dispatch
+// order: the grid is sized to be fully resident and block b owns tiles b, b+G, b+2G, ...  Spins are
+// bounded (Scalars::timeout).  Descriptor buffers are double-buffered per scan channel: a launch polls
+// buffer `dcur` and zeroes `dnext` for the following launch, so no memset node is needed.
+constexpr uint64_t DESC_VALID = 1ull << 63, DESC_MASK = (1ull << 62) - 1;
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ void desc_store(uint64_t* p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t desc_load(const uint64_t* p)
+{
+    return __hip_atomic_load(const_cast<uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t desc_wait(const uint64_t* p, int32_t* timeout)
+{
+    uint64_t d = desc_load(p);
+    unsigned spins = 0;
+    while (!(d & DESC_VALID)) {
+        __builtin_amdgcn_s_sleep(1);
+        d = desc_load(p);
+        if (++spins > SPIN_LIMIT) { *timeout = 1; break; }
+    }
+    return d & DESC_MASK;
+}
+
+// input functors: the two fixed-point weights at elements idx, idx+1 (idx even; zero beyond n)
+struct InFixQ {                // q_i = trunc(exp(p_i - m) 2^K + 1/2); uniform fallback q_i = 1
+    PrioView pv;
+    const int32_t* order;      // optional permutation (sort_particles, resample.jl:156-157)
+    const uint64_t* sorted_keys;   // with `order`: the sorted keys themselves -- key i IS log_priorities[order[i]] (sort_key_value),
+                                   // read in streaming order instead of 8-byte random reads through `order`
+    int K;
+    double m; int flags;       // filled in-kernel from the partials
+    __device__ __forceinline__ uint64_t one(double v, bool uniform, bool bad) const
+    {
+        return uniform ? 1 : (bad ? 0 : exp_fix(v - m, K));
+    }
+    // the two log-priorities at idx, idx + 1 (anything beyond n): needs neither the maximum nor the flags, so a scan can
+    // have its first tile's loads in flight while it folds the partial maxima
+    __device__ __forceinline__ void raw2(int64_t idx, int64_t n, double& v0, double& v1) const
+    {
+        if (pv.mode == 0 && order == nullptr && idx + 1 < n) {          // 16 B per lane, 1 KiB per wave-instruction
+            const double2 v = *reinterpret_cast<const double2*>(pv.lw + idx);
+            v0 = v.x; v1 = v.y;
+        } else if (sorted_keys && idx + 1 < n) {
+            const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(sorted_keys + idx);
+            v0 = sort_key_value(k.x); v1 = sort_key_value(k.y);
+        } else {
+            v0 = idx < n ? pv.at(order ? (int64_t)order[idx] : idx) : 0.0;
+            v1 = idx + 1 < n ? pv.at(order ? (int64_t)order[idx + 1] : idx + 1) : 0.0;
+        }
+    }
+    __device__ __forceinline__ void conv2(int64_t idx, int64_t n, double v0, double v1, uint64_t& q0, uint64_t& q1) const
+    {
+        const bool uniform = (flags & FLAG_ALL_NEGINF) != 0, bad = (flags & (FLAG_NAN | FLAG_POSINF)) != 0;
+        q0 = idx < n ? one(v0, uniform, bad) : 0;
+        q1 = idx + 1 < n ? one(v1, uniform, bad) : 0;
+    }
+    __device__ __forceinline__ void load2(int64_t idx, int64_t n, uint64_t& q0, uint64_t& q1) const
+    {
+        double v0, v1;
+        raw2(idx, n, v0, v1);
+        conv2(idx, n, v0, v1, q0, q1);
+    }
+};
+// a <= ... products of a 31-bit count and a 62-bit weight need 128 bits:  B <= a * k
+__device__ __forceinline__ bool le_mul(uint64_t B, uint64_t a, uint64_t k)
+{
+    return __umul64hi(a, k) != 0 || B <= a * k;
+}
+struct InOptimal {             // optimal resize (resize.jl:156-167): keep flags [c w_i >= 1], or the weights of the others
+    const double* lw;
+    const WSum* ws;            // summary of state.log_weights
+    const Scalars* sc;         // (opt_a, opt_B)
+    int K;
+    int mode;                  // 0: keep flags; 1: q_i of the particles not kept; 2: 1 for every particle not kept
+    __device__ __forceinline__ uint64_t one(int64_t i, double m, bool uniform, bool bad, uint64_t a, uint64_t B) const
+    {
+        const uint64_t q = uniform ? 1 : (bad ? 0 : exp_fix(lw[i] - m, K));
+        const bool keep = le_mul(B, a, q);
+        return mode == 0 ? (uint64_t)keep : (keep ? 0 : (mode == 2 ? 1 : q));
+    }
+    __device__ __forceinline__ void load2(int64_t idx, int64_t n, uint64_t& q0, uint64_t& q1) const
+    {
+        const double m = ws->m;
+        const int fl = ws->flags;
+        const bool uniform = (fl & FLAG_ALL_NEGINF) != 0, bad = (fl & (FLAG_NAN | FLAG_POSINF)) != 0;
+        const uint64_t a = sc->opt_a, B = sc->opt_B;
+        q0 = idx < n ? one(idx, m, uniform, bad, a, B) : 0;
+        q1 = idx + 1 < n ? one(idx + 1, m, uniform, bad, a, B) : 0;
+    }
+};
+
+// where a scan writes: the CDF (padded to whole tiles) and its coarser levels, by-products of the same pass
+struct ScanOut {
+    uint64_t* cdf;             // [ntiles*2048] inclusive prefix of every element (nullptr: totals only)
+    uint64_t* t16;             // [ntiles*128]  inclusive prefix at the end of every 16-element group (one 128-B line of cdf)
+    uint64_t* t256;            // [ntiles*8]    ... of every 256-element group (one 128-B line of t16)
+    uint32_t* k32;             // [ntiles*64]   (prefix at the end of every 32-element group) >> KEY_SHIFT: the 4-byte keys k_search_multi keeps in LDS
+    // k_search_multi's two narrow levels below a key group of G = 32 << logg cells (nullptr / -1: not wanted):
+    uint16_t* off16;           // [ntiles*2048] every prefix as a 16-bit offset inside its key group (key_quant)
+    uint16_t* coarse;          // [ntiles*2048 / CS] the offsets of cells CS-1 (mod CS), CS = G / 8: one 16-byte row per key group
+    int logg;
+};
+constexpr int KEY_SHIFT = 30;  // S < 2^62, so (prefix >> 30) fits 32 bits whatever N is
+// A key group spans the prefixes [klo << 30, (khi + 1) << 30) (klo / khi: the 4-byte keys at its two ends).  Inside it a
+// prefix -- and a target -- is quantised to 16 bits by ONE shift: x -> (x - (klo << 30)) >> sh, sh = 14 + ceil(log2(khi - klo + 1)).
+// The map is monotone and the SAME on the producer (scan) and consumer (search) side, so
+//     off(cell) < off(T) => prefix < T,   off(cell) > off(T) => prefix > T,   equal offsets: the exact prefixes decide.
+__device__ __forceinline__ int key_quant_shift(uint32_t klo, uint32_t khi)
+{
+    const uint64_t w = (uint64_t)khi - klo + 1;
+    return (KEY_SHIFT - 16) + (w > 1 ? 64 - (int)__builtin_clzll(w - 1) : 0);
+}
+
+// Arrangement: wave w of the workgroup owns 512 consecutive elements of the tile as 4 rows of 128;
+// lane l holds elements 2l, 2l+1 of each row, so every global access is 16 B per lane, contiguous
+// across the wave (1 KiB per wave-instruction), for the loads AND the CDF stores.
+struct ScanExtras {            // optional side jobs of a scan launch
+    int64_t* zero128;          // clear 2 * MAX_SHARDS exchange counters (sharded resample), or nullptr
+    int64_t* host_flags;       // pinned host {flags, ticket}: publish the validity flags of the weights, or nullptr
+    int64_t ticket;
+    int64_t n_slots;           // > 0: also write ws_out->{sB, srem, sinv}, the strata of the total over n_slots slots
+};
+constexpr int SCAN_ROWS = 4;
+// MODE 0: plain scan of In; 1: fixed-point weights (folds the max partials); 2: as 1, plus sum q^2 for the ESS;
+// 3 / 4: as 1 / 2 with the maximum and flags taken from the np gathered (max, flags) pairs of the shards (pmax = mf_all)
+template <class In, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles,
+                                                const double* __restrict__ pmax, const int32_t* __restrict__ pflags,
+                                                int np, WSum* __restrict__ ws_out, ScanOut out,
+                                                uint64_t* __restrict__ dcur, uint64_t* __restrict__ dnext,
+                                                uint64_t* __restrict__ total_out, uint64_t* __restrict__ blockQ,
+                                                int32_t* __restrict__ timeout, ScanExtras ex)
+{
+    // (ex.n_slots: the thread that ends up with the total also leaves the stratum width of S over n_slots output slots)
+    // sharded resamples: the exchange counters of the push pass that follows are cleared here (no memset node)
+    if (ex.zero128 && blockIdx.x == 0 && threadIdx.x < 2 * MAX_SHARDS) ex.zero128[threadIdx.x] = 0;
+    __shared__ double sm[NWAVES];
+    __shared__ int sf[NWAVES];
+    __shared__ uint64_t s_wave[NWAVES];
+    __shared__ uint64_t s_red[NWAVES];
+    uint64_t* const d_agg = dcur;
+    uint64_t* const d_pre = dcur + ntiles;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * BLOCK) dnext[i] = 0;
+    constexpr bool WANT_Q = MODE == 2 || MODE == 4;
+    // the first tile's log-weights are loaded BEFORE the partial maxima are folded (they need neither m nor the flags)
+    double pre[2 * SCAN_ROWS];
+    if constexpr (MODE >= 1) {
+        const int64_t wb0 = (int64_t)blockIdx.x * TILE + (int64_t)wave_id() * (SCAN_ROWS * 2 * WAVE) + 2 * lane_id();
+#pragma unroll
+        for (int k = 0; k < SCAN_ROWS; ++k) in.raw2(wb0 + k * 2 * WAVE, n, pre[2 * k], pre[2 * k + 1]);
+    }
+    if constexpr (MODE >= 1) {
+        double m; int f;
+        if constexpr (MODE >= 3) {
+            m = -__builtin_huge_val(); f = 0;
+            for (int g = 0; g < np; ++g) { const double v = pmax[2 * g]; m = v > m ? v : m; f |= (int)pmax[2 * g + 1]; }
+            if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+            (void)sm; (void)sf;
+        } else fold_partials(pmax, pflags, np, sm, sf, m, f);
+        in.m = m; in.flags = f;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ws_out->m = m; ws_out->flags = f;
+            // check = true / :warn (resample.jl:54-55): the host learns safe_softmax's validity flags NOW, from pinned memory,
+            // while this kernel and the ancestor search behind it keep running (no stream synchronisation, no idle gap)
+            if (ex.host_flags) {
+                __hip_atomic_store(ex.host_flags, (int64_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(ex.host_flags + 1, ex.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    uint64_t ql[4] = {0, 0, 0, 0};
+    const int lane = lane_id(), wv = wave_id();
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t wbase = tile * TILE + (int64_t)wv * (SCAN_ROWS * 2 * WAVE) + 2 * lane;
+        uint64_t p[2 * SCAN_ROWS];                     // inclusive prefixes inside the wave's 512-element chunk
+        uint64_t cb[SCAN_ROWS];                        // the chunk's total before each row
+        uint64_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ROWS; ++k) {
+            uint64_t q0, q1;
+            cb[k] = carry;
+            if constexpr (MODE >= 1) {
+                if (tile == blockIdx.x) in.conv2(wbase + k * 2 * WAVE, n, pre[2 * k], pre[2 * k + 1], q0, q1);
+                else in.load2(wbase + k * 2 * WAVE, n, q0, q1);
+            } else in.load2(wbase + k * 2 * WAVE, n, q0, q1);
+            if constexpr (WANT_Q) {
+                uint64_t lo = q0 * q0, hi = __umul64hi(q0, q0);
+                ql[0] += lo & 0xffffffffull; ql[1] += lo >> 32; ql[2] += hi & 0xffffffffull; ql[3] += hi >> 32;
+                lo = q1 * q1; hi = __umul64hi(q1, q1);
+                ql[0] += lo & 0xffffffffull; ql[1] += lo >> 32; ql[2] += hi & 0xffffffffull; ql[3] += hi >> 32;
+            }
+            const uint64_t pair = q0 + q1;
+            const uint64_t inc = wave_scan_u64(pair);
+            p[2 * k] = carry + (inc - pair) + q0;
+            p[2 * k + 1] = p[2 * k] + q1;
+            carry += shfl_u64(inc, WAVE - 1);
+        }
+        if (lane == 0) s_wave[wv] = carry;             // wave total
+        __syncthreads();
+        uint64_t wexcl = 0, agg = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) { if (w < wv) wexcl += s_wave[w]; agg += s_wave[w]; }
+        if (threadIdx.x == 0) desc_store(d_agg + tile, DESC_VALID | agg);
+        // exclusive prefix of this tile: one parallel read of the round's earlier aggregates
+        const int64_t first = (tile / gridDim.x) * gridDim.x;
+        uint64_t acc = 0;
+        for (int64_t idx = first + threadIdx.x; idx < tile; idx += BLOCK) acc += desc_wait(d_agg + idx, timeout);
+        if (first > 0 && threadIdx.x == BLOCK - 1) acc += desc_wait(d_pre + first - 1, timeout);
+        acc = wave_sum_u64(acc);
+        if (lane == 0) s_red[wv] = acc;
+        __syncthreads();
+        uint64_t excl = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) excl += s_red[w];
+        if (threadIdx.x == 0) desc_store(d_pre + tile, DESC_VALID | (excl + agg));
+        const uint64_t off = excl + wexcl;
+        if (out.cdf) {
+#pragma unroll
+            for (int k = 0; k < SCAN_ROWS; ++k) {
+                const int64_t idx = wbase + k * 2 * WAVE;
+                const uint64_t v1 = off + p[2 * k + 1];
+                *reinterpret_cast<ulonglong2*>(out.cdf + idx) = make_ulonglong2(off + p[2 * k], v1);
+                if ((lane & 7) == 7) out.t16[(idx + 1) >> 4] = v1;                     // element idx+1 = 15 (mod 16)
+                if ((lane & 15) == 15) out.k32[(idx + 1) >> 5] = (uint32_t)(v1 >> KEY_SHIFT);   // ... = 31 (mod 32)
+                if (lane == WAVE - 1 && (k & 1)) out.t256[(idx + 1) >> 8] = v1;         // ... = 255 (mod 256)
+                if (out.off16) {                                                        // kernel-uniform
+                    // 16-bit offsets inside the key group (16 << logg lanes of this row): klo = key of the previous group
+                    const int GL = 16 << out.logg;
+                    const uint32_t kv = (uint32_t)(v1 >> KEY_SHIFT);
+                    const uint32_t khi = (uint32_t)__shfl((int)kv, lane | (GL - 1), WAVE);
+                    const uint32_t kprev = (uint32_t)__shfl((int)kv, ((lane & ~(GL - 1)) - 1) & (WAVE - 1), WAVE);
+                    const uint32_t klo = lane < GL ? (uint32_t)((off + cb[k]) >> KEY_SHIFT) : kprev;
+                    const int sh = key_quant_shift(klo, khi);
+                    const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
+                    const uint32_t o0 = (uint32_t)((off + p[2 * k] - kb) >> sh), o1 = (uint32_t)((v1 - kb) >> sh);
+                    reinterpret_cast<uint32_t*>(out.off16)[idx >> 1] = o0 | (o1 << 16);
+                    // the coarse row: offsets of the cells CS-1 (mod CS), CS = 4 << logg, two per 4-byte store
+                    if (out.logg == 0) {
+                        const uint32_t part = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o1, 0x55, 0xF, 0xF, false);    // quad_perm [1,1,1,1]
+                        if ((lane & 3) == 3) reinterpret_cast<uint32_t*>(out.coarse)[(idx + 1) >> 3] = part | (o1 << 16);
+                    } else {
+                        const uint32_t part = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o1, 0x114, 0xF, 0xF, false);   // row_shr:4
+                        if ((lane & 7) == 7) reinterpret_cast<uint32_t*>(out.coarse)[(idx + 1) >> 4] = part | (o1 << 16);
+                    }
+                }
+            }
+        }
+        if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) {
+            const uint64_t Stot = off + p[2 * SCAN_ROWS - 1];
+            *total_out = Stot;
+            if constexpr (MODE >= 1) {
+                if (ex.n_slots > 0) {                   // one thread per launch: a true 64-bit division is fine here
+                    const uint64_t Bq = Stot / (uint64_t)ex.n_slots;
+                    ws_out->sB = Bq; ws_out->srem = Stot - Bq * (uint64_t)ex.n_slots;
+                    ws_out->sinv = (double)ex.n_slots / (double)Stot;
+                }
+            }
+        }
+        __syncthreads();                                // s_wave / s_red reuse
+    }
+    if constexpr (WANT_Q) {
+        // block partial of the limb sums of sum q^2 (plain stores, folded on demand by k_publish_scalars)
+        __shared__ uint64_t s_q[NWAVES][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
+        if (lane == 0) { for (int k = 0; k < 4; ++k) s_q[wv][k] = ql[k]; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            uint64_t t = 0;
+            for (int w = 0; w < NWAVES; ++w) t += s_q[w][threadIdx.x];
+            blockQ[(int64_t)blockIdx.x * 4 + threadIdx.x] = t;
+        }
+    }
+}
+
+// Residual resampling needs TWO prefix sums over the same elements: the copy counts c_i = (N q_i) div S and the
+// residual weights r_i = ((N q_i) mod S) >> sh (resample.jl:99,109).  One pass computes both: one read of the weight CDF,
+// ONE 64-bit division per element (quotient and remainder), two descriptor channels polled in the same round trip.
+// Same tile / descriptor protocol as k_scan (channel A = counts, channel B = residual weights).
+struct Scan2Chan { ScanOut out; uint64_t* dcur; uint64_t* dnext; uint64_t* total_out; };
+__global__ __launch_bounds__(BLOCK) void k_scan_residual2(const uint64_t* __restrict__ cdf, const WSum* ws, int64_t Nslots,
+                                                          int64_t n, int64_t ntiles, Scan2Chan A, Scan2Chan B,
+                                                          int32_t* __restrict__ timeout)
+{
+    __shared__ uint64_t s_wave[2][NWAVES];
+    __shared__ uint64_t s_red[2][NWAVES];
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * BLOCK) { A.dnext[i] = 0; B.dnext[i] = 0; }
+    const uint64_t S = ws->S;
+    const int sh = residual_shift(S, Nslots);
+    const int lane = lane_id(), wv = wave_id();
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t wbase = tile * TILE + (int64_t)wv * (SCAN_ROWS * 2 * WAVE) + 2 * lane;
+        uint64_t pa[2 * SCAN_ROWS], pb[2 * SCAN_ROWS];
+        uint64_t ca = 0, cb = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ROWS; ++k) {
+            const int64_t idx = wbase + k * 2 * WAVE;
+            const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(cdf + idx);      // padded to whole tiles, flat beyond n
+            const uint64_t prev = idx > 0 ? cdf[idx - 1] : 0;
+            uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (S != 0) {
+                const uint64_t n0 = (uint64_t)Nslots * (c.x - prev), n1 = (uint64_t)Nslots * (c.y - c.x);
+                a0 = n0 / S; b0 = (n0 - a0 * S) >> sh;
+                a1 = n1 / S; b1 = (n1 - a1 * S) >> sh;
+            }
+            if (idx >= n) { a0 = 0; b0 = 0; }
+            if (idx + 1 >= n) { a1 = 0; b1 = 0; }
+            const uint64_t paira = a0 + a1, pairb = b0 + b1;
+            const uint64_t inca = wave_scan_u64(paira), incb = wave_scan_u64(pairb);
+            pa[2 * k] = ca + (inca - paira) + a0; pa[2 * k + 1] = pa[2 * k] + a1;
+            pb[2 * k] = cb + (incb - pairb) + b0; pb[2 * k + 1] = pb[2 * k] + b1;
+            ca += shfl_u64(inca, WAVE - 1); cb += shfl_u64(incb, WAVE - 1);
+        }
+        if (lane == 0) { s_wave[0][wv] = ca; s_wave[1][wv] = cb; }
+        __syncthreads();
+        uint64_t wexa = 0, agga = 0, wexb = 0, aggb = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) {
+            if (w < wv) { wexa += s_wave[0][w]; wexb += s_wave[1][w]; }
+            agga += s_wave[0][w]; aggb += s_wave[1][w];
+        }
+        if (threadIdx.x == 0) { desc_store(A.dcur + tile, DESC_VALID | agga); desc_store(B.dcur + tile, DESC_VALID | aggb); }
+        const int64_t first = (tile / gridDim.x) * gridDim.x;
+        uint64_t acca = 0, accb = 0;
+        for (int64_t idx = first + threadIdx.x; idx < tile; idx += BLOCK) {
+            acca += desc_wait(A.dcur + idx, timeout);
+            accb += desc_wait(B.dcur + idx, timeout);
+        }
+        if (first > 0 && threadIdx.x == BLOCK - 1) {
+            acca += desc_wait(A.dcur + ntiles + first - 1, timeout);
+            accb += desc_wait(B.dcur + ntiles + first - 1, timeout);
+        }
+        acca = wave_sum_u64(acca); accb = wave_sum_u64(accb);
+        if (lane == 0) { s_red[0][wv] = acca; s_red[1][wv] = accb; }
+        __syncthreads();
+        uint64_t exa = 0, exb = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) { exa += s_red[0][w]; exb += s_red[1][w]; }
+        if (threadIdx.x == 0) {
+            desc_store(A.dcur + ntiles + tile, DESC_VALID | (exa + agga));
+            desc_store(B.dcur + ntiles + tile, DESC_VALID | (exb + aggb));
+        }
+        const uint64_t offa = exa + wexa, offb = exb + wexb;
+#pragma unroll
+        for (int k = 0; k < SCAN_ROWS; ++k) {
+            const int64_t idx = wbase + k * 2 * WAVE;
+            const uint64_t va = offa + pa[2 * k + 1], vb = offb + pb[2 * k + 1];
+            *reinterpret_cast<ulonglong2*>(A.out.cdf + idx) = make_ulonglong2(offa + pa[2 * k], va);
+            *reinterpret_cast<ulonglong2*>(B.out.cdf + idx) = make_ulonglong2(offb + pb[2 * k], vb);
+            if ((lane & 7) == 7) { A.out.t16[(idx + 1) >> 4] = va; B.out.t16[(idx + 1) >> 4] = vb; }
+            if ((lane & 15) == 15) { A.out.k32[(idx + 1) >> 5] = (uint32_t)(va >> KEY_SHIFT); B.out.k32[(idx + 1) >> 5] = (uint32_t)(vb >> KEY_SHIFT); }
+            if (lane == WAVE - 1 && (k & 1)) { A.out.t256[(idx + 1) >> 8] = va; B.out.t256[(idx + 1) >> 8] = vb; }
+        }
+        if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) { *A.total_out = offa + pa[2 * SCAN_ROWS - 1]; *B.total_out = offb + pb[2 * SCAN_ROWS - 1]; }
+        __syncthreads();                                // s_wave / s_red reuse
+    }
+}
+
+// the device scalar block -> its pinned host mirror, ticket last: the host polls the ticket instead of synchronising the
+// stream (a hipMemcpyAsync + hipStreamSynchronize pair costs ~13 us of wake-up latency per getter; this costs the launch)
+// blockQ != nullptr: the limb partials of sum q^2 that the scan blocks left (only the ESS needs them) are folded into sc->raw.Ql
+// on the way -- one launch for "fold + publish" (the ESS-triggered loop of BASELINE config 4 asks for the ESS every step).
+// Launched with ONE wave.
+__global__ void k_publish_scalars(Scalars* sc, Scalars* host, long long* host_ticket, long long ticket,
+                                  const uint64_t* __restrict__ blockQ, int nblk)
+{
+    constexpr int NW = (int)(sizeof(Scalars) / sizeof(unsigned long long));
+    static_assert(sizeof(Scalars) % sizeof(unsigned long long) == 0, "Scalars must be a whole number of 8-byte words");
+    constexpr int QW = (int)((offsetof(Scalars, raw) + offsetof(WSum, Ql)) / sizeof(unsigned long long));
+    uint64_t q[4] = {0, 0, 0, 0};
+    const bool fold = blockQ != nullptr;
+    if (fold) {
+        for (int b = threadIdx.x; b < nblk; b += WAVE)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] += blockQ[(int64_t)b * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = wave_sum_u64(q[k]);                 // every lane holds the totals
+        if (threadIdx.x < 4) sc->raw.Ql[threadIdx.x] = threadIdx.x == 0 ? q[0] : threadIdx.x == 1 ? q[1] : threadIdx.x == 2 ? q[2] : q[3];
+    }
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(sc);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(host);
+    for (int i = threadIdx.x; i < NW; i += blockDim.x) {
+        unsigned long long v = src[i];
+        if (fold && i >= QW && i < QW + 4) v = i == QW ? q[0] : i == QW + 1 ? q[1] : i == QW + 2 ? q[2] : q[3];   // (not read back: just written)
+        __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+} // namespace gpf

@@ -1,0 +1,466 @@
+// shard-level kernels: summaries, the push exchange, the stratified plan, packed commit  (part of gpf_kernels.hpp; include that header, not this file)
+#pragma once
+
+namespace gpf {
+// ----------------------------------------------------------------------------- shard-level kernels (multi-GPU)
+// Sharding: GPU g owns the contiguous global particle range [gid0, gid0+n).  The weight
+// CDF is global = local inclusive scan + the sum of the lower shards' totals; output slot j (global id)
+// draws a target in GLOBAL fixed-point coordinates, the shard that owns that CDF cell looks the ancestor
+// up and returns the row.  Integer arithmetic makes the ancestors independent of the number of shards.
+constexpr int64_t SPACE_COUNTS = (int64_t)1 << 62;   // residual: target lives in the copy-count CDF
+
+__global__ void k_pack_mflags(const double* __restrict__ pmax, const int32_t* __restrict__ pflags, int np, double* out2)
+{
+    __shared__ double sm[NWAVES];
+    __shared__ int sf[NWAVES];
+    double m; int f;
+    fold_partials(pmax, pflags, np, sm, sf, m, f);
+    if (threadIdx.x == 0) { out2[0] = m; out2[1] = (double)(f & (FLAG_NAN | FLAG_POSINF)); }
+}
+// {Ql0..3} -> out5[1..4]: limb sums of sum q^2 folded over the scan blocks (exact integers); out5[0] = S_local is written by the scan
+__global__ void k_export_q(const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5)
+{
+    __shared__ uint64_t s_q[NWAVES][4];
+    uint64_t ql[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblk; b += BLOCK)
+        for (int k = 0; k < 4; ++k) ql[k] += blockQ[(int64_t)b * 4 + k];
+    for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
+    if (lane_id() == 0) for (int k = 0; k < 4; ++k) s_q[wave_id()][k] = ql[k];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint64_t t = 0;
+        for (int w = 0; w < NWAVES; ++w) t += s_q[w][threadIdx.x];
+        out5[1 + threadIdx.x] = (int64_t)t;
+    }
+}
+// global S (and residual shift) into the device scalar block from the gathered shard totals
+// tot_all = the gathered {S_local, Ql0..3} of all G shards -> the global S
+__global__ void k_set_global(const int64_t* __restrict__ tot_all, int G, WSum* ws)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint64_t S = 0;
+        for (int g = 0; g < G; ++g) S += (uint64_t)tot_all[5 * g];
+        ws->S = S;
+    }
+}
+__global__ void k_export_residual(const Scalars* sc, int64_t* out2)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out2[0] = (int64_t)sc->Ctot; out2[1] = (int64_t)sc->Rs; }
+}
+
+// ---- sharded resampling, the PUSH exchange.  RNG counters are keyed by the GLOBAL slot id, so every
+// shard can evaluate the target of EVERY output slot itself (Philox is pure ALU work): the owner of a target finds
+// out on its own which slots draw from it, looks the ancestors up and pushes [row | slot | ancestor id] to the shard
+// that holds the slot.  No request message exists.  Pass 1 walks all slots in chunks that never straddle a shard
+// boundary, compacts each chunk's hits in LDS and appends them to the staging list of the slot's shard (one global
+// atomic per chunk; the order of chunks inside a list is arbitrary, every entry names its slot); it also counts what
+// this shard will receive from whom.  Pass 2 looks the staged hits up (same core as k_search) and packs the rows.
+constexpr int PUSH_CHUNK = 2048;                  // output slots per chunk
+struct PushArgs {
+    uint64_t seed; uint32_t epoch;
+    int64_t n_global;
+    int G, me;
+    const int64_t* tot_all;                       // [G][5] gathered {S_local, Ql0..3}
+    const int64_t* cr_all;                        // [G][2] gathered residual {Ctot_local, Rs_local}, or nullptr
+    int64_t bounds[MAX_SHARDS + 1];               // first global slot of every shard
+    int64_t chunk0[MAX_SHARDS + 1];               // first chunk of every shard's slots
+    int64_t nchunks;
+    ulonglong2* stage;                            // [n_global]: hits for shard g's slots at stage + bounds[g]: {T_local | space << 62, slot inside g}
+    int64_t* counts;                              // [2G]: entries sent to each shard | received from each shard
+    int64_t* host_counts;                         // pinned host mirror [2 * MAX_SHARDS + 1]: k_push publishes the counts + a ticket
+    int64_t ticket;
+};
+struct PushTables {                               // LDS copy of the per-shard tables
+    int64_t w_incl[MAX_SHARDS], c_incl[MAX_SHARDS], bounds[MAX_SHARDS + 1], chunk0[MAX_SHARDS + 1];
+};
+__device__ __forceinline__ void push_tables(const PushArgs& a, PushTables& t)
+{
+    // inclusive shard totals of the sampled space (weights, or residual weights) and of the residual copy counts: the
+    // first wave, one shard per lane (G <= MAX_SHARDS = 64)
+    static_assert(MAX_SHARDS <= WAVE, "one lane per shard");
+    if (threadIdx.x < WAVE) {
+        const int g = (int)threadIdx.x;
+        uint64_t w = g < a.G ? (uint64_t)(a.cr_all ? a.cr_all[2 * g + 1] : a.tot_all[5 * g]) : 0;
+        uint64_t c = g < a.G && a.cr_all ? (uint64_t)a.cr_all[2 * g] : 0;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint64_t ow = shfl_up_u64(w, d), oc = shfl_up_u64(c, d);
+            if (g >= d) { w += ow; c += oc; }
+        }
+        if (g < a.G) { t.w_incl[g] = (int64_t)w; t.c_incl[g] = (int64_t)c; }
+    }
+    for (int g = threadIdx.x; g <= a.G; g += blockDim.x) { t.bounds[g] = a.bounds[g]; t.chunk0[g] = a.chunk0[g]; }
+    __syncthreads();
+}
+// the slots [j0, j1) of chunk c and the shard g that holds them
+__device__ __forceinline__ int push_chunk(const PushArgs& a, const PushTables& t, int64_t c, int64_t& j0, int64_t& j1)
+{
+    int g = 0;
+    while (g < a.G - 1 && c >= t.chunk0[g + 1]) ++g;
+    j0 = t.bounds[g] + (c - t.chunk0[g]) * PUSH_CHUNK;
+    j1 = j0 + PUSH_CHUNK < t.bounds[g + 1] ? j0 + PUSH_CHUNK : t.bounds[g + 1];
+    return g;
+}
+struct PushScal { uint64_t Sw, Ctot; };
+template <int METHOD>
+__device__ __forceinline__ PushScal push_scalars(const PushArgs& a, const PushTables& t)
+{
+    PushScal s;
+    s.Sw = (uint64_t)t.w_incl[a.G - 1];           // total of the sampled space: weights, or residual weights
+    s.Ctot = METHOD == 1 ? (uint64_t)t.c_incl[a.G - 1] : 0;
+    return s;
+}
+// target of global slot jg, same arithmetic as k_search; space 1 = the residual copy-count CDF
+template <int METHOD>
+__device__ __forceinline__ void push_target(const PushArgs& a, const PushScal& s, uint64_t jg, uint64_t U, uint64_t& T, int& space)
+{
+    static_assert(METHOD == 0 || METHOD == 1, "stratified shards take k_strat_plan + k_search_strat");
+    space = 0;
+    if (METHOD == 0) T = mulhi64(U, s.Sw);
+    else if (jg < s.Ctot) { space = 1; T = jg; } else T = mulhi64(U, s.Sw);
+}
+// owner = first shard whose inclusive total exceeds T; T_local in the owner's coordinates
+__device__ __forceinline__ int push_owner(const PushTables& t, int G, int space, uint64_t T, uint64_t& T_local)
+{
+    const int64_t* incl = space ? t.c_incl : t.w_incl;
+    int h = 0;
+    if (G <= 8) {                                 // one node: branch-free count, the table reads are LDS broadcasts
+#pragma unroll
+        for (int g = 0; g < 7; ++g) h += (g < G - 1 && (uint64_t)incl[g] <= T) ? 1 : 0;
+    } else {
+        while (h < G - 1 && (uint64_t)incl[h] <= T) ++h;
+    }
+    T_local = T - (h ? (uint64_t)incl[h - 1] : 0);
+    return h;
+}
+// pass 1: stage the hits (slots whose target this shard owns), count them per destination, and count who owns the
+// targets of this shard's own slots
+constexpr int PUSH_SCAN_BLOCK = 512;
+template <int METHOD>
+__global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
+{
+    constexpr int R = PUSH_CHUNK / PUSH_SCAN_BLOCK, NW = PUSH_SCAN_BLOCK / WAVE;
+    __shared__ PushTables t;
+    __shared__ unsigned int s_recv[MAX_SHARDS];
+    __shared__ unsigned int s_wtot[NW];
+    __shared__ unsigned long long s_base;
+    if (threadIdx.x < MAX_SHARDS) s_recv[threadIdx.x] = 0;
+    push_tables(a, t);
+    const PushScal sc = push_scalars<METHOD>(a, t);
+    const int lane = lane_id(), wv = (int)threadIdx.x / WAVE;
+    unsigned recv_cnt = 0;                        // lane h counts the wave's own-slot targets owned by shard h
+    // this shard's range of the sampled space(s); the last shard also takes a target at the very end (push_owner's clamp)
+    const uint64_t w_lo = a.me ? (uint64_t)t.w_incl[a.me - 1] : 0, w_hi = a.me == a.G - 1 ? ~0ull : (uint64_t)t.w_incl[a.me];
+    const uint64_t c_lo = a.me ? (uint64_t)t.c_incl[a.me - 1] : 0, c_hi = a.me == a.G - 1 ? ~0ull : (uint64_t)t.c_incl[a.me];
+    for (int64_t c = blockIdx.x; c < a.nchunks; c += gridDim.x) {
+        int64_t j0, j1;
+        const int g = push_chunk(a, t, c, j0, j1);
+        if (METHOD == 1 && (uint64_t)j1 <= sc.Ctot) {                                 // block-uniform
+            // the chunk lies in the residual resampler's deterministic head (resample.jl:96-106): slot j is the j-th copy, its
+            // target is j itself in the copy-count space -- no uniform to draw, and the hits are ONE range of slots
+            const uint64_t h0 = (uint64_t)j0 > c_lo ? (uint64_t)j0 : c_lo, h1 = (uint64_t)j1 < c_hi ? (uint64_t)j1 : c_hi;
+            const unsigned total = h1 > h0 ? (unsigned)(h1 - h0) : 0u;
+            if (g == a.me && wv == 0 && lane < a.G) {                                 // who serves this shard's own slots
+                const uint64_t q0 = lane ? (uint64_t)t.c_incl[lane - 1] : 0, q1 = lane == a.G - 1 ? ~0ull : (uint64_t)t.c_incl[lane];
+                const uint64_t r0 = (uint64_t)j0 > q0 ? (uint64_t)j0 : q0, r1 = (uint64_t)j1 < q1 ? (uint64_t)j1 : q1;
+                if (r1 > r0) recv_cnt += (unsigned)(r1 - r0);
+            }
+            if (total) {                                                              // block-uniform
+                if (threadIdx.x == 0) s_base = atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + g), (unsigned long long)total);
+                __syncthreads();
+                ulonglong2* dst = a.stage + t.bounds[g] + s_base;
+                for (unsigned k = threadIdx.x; k < total; k += PUSH_SCAN_BLOCK)
+                    dst[k] = make_ulonglong2((h0 + k - c_lo) | (1ull << 62), h0 + k - (uint64_t)t.bounds[g]);
+                __syncthreads();                                                      // s_base
+            }
+            continue;
+        }
+        uint64_t Tl[R];
+        unsigned hits = 0;                                                            // bit r: round r is a hit
+        // the lane's R consecutive slots: one Philox block per aligned slot pair (resample_u64), one more when the run starts odd
+        uint64_t U[R];
+        {
+            const uint32_t s0 = (uint32_t)(j0 + (int64_t)threadIdx.x * R), sb = s0 >> 1;
+            if (!(s0 & 1u)) {
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) {
+                    const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
+                    U[2 * q] = u64(b.w0, b.w1); U[2 * q + 1] = u64(b.w2, b.w3);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q <= R / 2; ++q) {
+                    const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
+                    if (q > 0) U[2 * q - 1] = u64(b.w0, b.w1);
+                    if (q < R / 2) U[2 * q] = u64(b.w2, b.w3);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t j = j0 + (int64_t)threadIdx.x * R + r;       // R consecutive slots per lane: staged in slot order
+            uint64_t T = 0; int space = 0, h = -1;
+            Tl[r] = 0;
+            if (j < j1) {
+                push_target<METHOD>(a, sc, (uint64_t)j, U[r], T, space);
+                if (g == a.me) h = push_owner(t, a.G, space, T, Tl[r]);              // own slots: who serves them (receive counts)
+                else {                                                                // other shards' slots: only "is it mine?"
+                    const uint64_t lo = space ? c_lo : w_lo, hi = space ? c_hi : w_hi;
+                    h = (T >= lo && T < hi) ? a.me : -1;
+                    Tl[r] = T - lo;
+                }
+                Tl[r] |= (uint64_t)space << 62;
+            }
+            if (g == a.me) {                                                          // block-uniform
+                for (int q = 0; q < a.G; ++q) {
+                    const unsigned n = (unsigned)__popcll(__ballot(h == q));
+                    if (lane == q) recv_cnt += n;
+                }
+            }
+            hits |= (h == a.me ? 1u : 0u) << r;
+        }
+        // exclusive position of this lane's hits inside the chunk; ONE global atomic per chunk reserves the chunk's range
+        const unsigned cnt = (unsigned)__popc(hits);
+        unsigned incl = cnt;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { const unsigned o = __shfl_up(incl, d, WAVE); if (lane >= d) incl += o; }
+        if (lane == WAVE - 1) s_wtot[wv] = incl;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const unsigned v = s_wtot[w]; before += w < wv ? v : 0; total += v; }
+        if (threadIdx.x == 0 && total)
+            s_base = atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + g), (unsigned long long)total);
+        __syncthreads();
+        if (cnt) {
+            ulonglong2* dst = a.stage + t.bounds[g] + s_base + before + (incl - cnt);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (hits >> r & 1u)
+                    *dst++ = make_ulonglong2(Tl[r], (uint64_t)(j0 + (int64_t)threadIdx.x * R + r - t.bounds[g]));
+        }
+    }
+    if (recv_cnt) atomicAdd(&s_recv[lane], recv_cnt);
+    __syncthreads();
+    if (threadIdx.x < a.G && s_recv[threadIdx.x])
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + a.G + threadIdx.x), (unsigned long long)s_recv[threadIdx.x]);
+}
+// pass 2: every staged hit is looked up in this shard's CDF (same core as k_search) and pushed with its row:
+// packed_out[e] = [row (W doubles) | (slot inside its shard) << 32 | global ancestor id], grouped by destination shard
+template <int METHOD, int W>
+__global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs a, CdfLevels lw_, CdfLevels lc_, int64_t n, int64_t ntiles,
+                                                                         int64_t gid0, const double* __restrict__ rows,
+                                                                         int64_t capacity, double* __restrict__ packed_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SearchTop st = search_prologue(lw_, lc_, METHOD == 1, ntiles, reinterpret_cast<uint64_t*>(smem));
+    __shared__ ulonglong2 s_coop[2 * SBLOCK];
+    __shared__ int64_t s_off[MAX_SHARDS + 1];     // first entry of every destination in the send buffer
+    __shared__ int64_t s_bnd[MAX_SHARDS + 1];
+    ulonglong2* const lds_wave = s_coop + wave_id() * (2 * WAVE);
+    if (threadIdx.x == 0) {
+        int64_t o = 0;
+        for (int g = 0; g < a.G; ++g) { s_off[g] = o; o += a.counts[g]; s_bnd[g] = a.bounds[g]; }
+        s_off[a.G] = o;
+        // the host needs the counts for the all-to-all split sizes: publish them to pinned host memory NOW, so the host
+        // reads them while this kernel is still looking ancestors up (system-scope stores, ticket last)
+        if (blockIdx.x == 0 && a.host_counts) {
+            for (int g = 0; g < 2 * a.G; ++g)
+                __hip_atomic_store(a.host_counts + g, a.counts[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();
+    const int64_t total = s_off[a.G] < capacity ? s_off[a.G] : capacity;
+    for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < total; base += (int64_t)gridDim.x * 2 * SBLOCK) {
+        int64_t e[2]; bool act[2]; uint64_t T[2], slot[2]; const uint64_t* top[2]; const CdfLevels* L[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            e[u] = base + u * SBLOCK + threadIdx.x;
+            act[u] = e[u] < total;
+            const int64_t ee = act[u] ? e[u] : total - 1;
+            int g = 0;
+            while (g < a.G - 1 && ee >= s_off[g + 1]) ++g;
+            const ulonglong2 q = a.stage[s_bnd[g] + (ee - s_off[g])];
+            const bool incounts = (q.x >> 62) != 0;
+            T[u] = q.x & DESC_MASK;
+            slot[u] = q.y;
+            top[u] = incounts ? st.topc : st.topw;
+            L[u] = incounts ? &lc_ : &lw_;
+        }
+        int64_t idx[2];
+        search_pair(st, L, top, T, true, lds_wave, n, ntiles, idx);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!act[u]) continue;
+            const double* src = rows + idx[u] * W;
+            double* dst = packed_out + e[u] * (W + 1);
+#pragma unroll
+            for (int c = 0; c < W; ++c) dst[c] = src[c];
+            dst[W] = u2d((slot[u] << 32) | (uint64_t)(gid0 + idx[u]));
+        }
+    }
+}
+
+// ---- sharded STRATIFIED resampling needs none of the above.  Stratum j is [L(j), L(j+1)) with L ascending in j, and shard h
+// owns the targets in [lo_h, lo_(h+1)) (lo = exclusive totals): the slots shard h serves are the contiguous range
+// [F[h], F[h+1]), F[h] = first slot whose target is >= lo_h -- the stratum that contains lo_h, or the one after it, decided by
+// that one slot's target.  One small workgroup derives F from the gathered totals (every shard the same), the exchange
+// counts follow by intersecting slot ranges, and the ancestors of the served slots come from k_search_strat (streaming merge
+// over the shard's own CDF) -- no pass over the global slots, no staging list.
+__global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
+{
+    __shared__ int64_t F[MAX_SHARDS + 1];
+    const int h = (int)threadIdx.x;
+    const uint64_t N = (uint64_t)a.n_global;
+    uint64_t S = 0, lo = 0, lo_me = 0;
+    for (int g = 0; g < a.G; ++g) {
+        const uint64_t v = (uint64_t)a.tot_all[5 * g];
+        if (g < h) lo += v;
+        if (g < a.me) lo_me += v;
+        S += v;
+    }
+    const uint64_t B = S / N, rem = S % N;
+    if (h <= a.G) {
+        int64_t f;
+        if (h == 0) f = 0;
+        else if (h == a.G || lo >= S) f = (int64_t)N;
+        else {
+            auto L = [&](uint64_t j) { return j * B + j * rem / N; };
+            uint64_t j = (uint64_t)((double)lo * ((double)N / (double)S));   // the stratum that contains lo: estimate, then exact
+            j = j < N ? j : N - 1;
+            while (j + 1 < N && L(j + 1) <= lo) ++j;
+            while (j > 0 && L(j) > lo) --j;
+            const uint64_t L0 = L(j), L1 = L(j + 1);
+            const uint64_t T = L0 + mulhi64(resample_u64(a.seed, (uint32_t)j, a.epoch), L1 - L0);             // resample.jl:162
+            f = (int64_t)(T >= lo ? j : j + 1);
+        }
+        F[h] = f;
+    }
+    __syncthreads();
+    if (h < a.G) {
+        // sent to shard h: the served slots that lie in h's slot range; received from shard h: h's served slots in this shard's range
+        const int64_t s0 = F[a.me] > a.bounds[h] ? F[a.me] : a.bounds[h], s1 = F[a.me + 1] < a.bounds[h + 1] ? F[a.me + 1] : a.bounds[h + 1];
+        const int64_t r0 = F[h] > a.bounds[a.me] ? F[h] : a.bounds[a.me], r1 = F[h + 1] < a.bounds[a.me + 1] ? F[h + 1] : a.bounds[a.me + 1];
+        const int64_t ns = s1 > s0 ? s1 - s0 : 0, nr = r1 > r0 ? r1 - r0 : 0;
+        a.counts[h] = ns; a.counts[a.G + h] = nr;
+        if (a.host_counts) {
+            __hip_atomic_store(a.host_counts + h, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.host_counts + a.G + h, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (h == 0) {
+        plan->ws.S = S; plan->ws.sB = B; plan->ws.srem = rem; plan->ws.sinv = (double)N / (double)S;
+        plan->first = F[a.me]; plan->count = F[a.me + 1] - F[a.me]; plan->t_off = lo_me;
+    }
+    __syncthreads();
+    if (h == 0 && a.host_counts) {
+        __threadfence_system();
+        __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// packed_out[e] = [row of the ancestor | (slot inside its shard) << 32 | global ancestor id] for the served slots in slot
+// order -- which IS grouped by destination shard.  The ancestors ascend: the row reads coalesce.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_push_pack(PushArgs a, const ShardPlan* __restrict__ plan, const int32_t* __restrict__ idx, int64_t gid0,
+                                                     const double* __restrict__ rows, int64_t capacity, double* __restrict__ packed_out)
+{
+    __shared__ int64_t s_bnd[MAX_SHARDS + 1];
+    for (int g = threadIdx.x; g <= a.G; g += BLOCK) s_bnd[g] = a.bounds[g];
+    __syncthreads();
+    const int64_t first = plan->first, total = plan->count < capacity ? plan->count : capacity;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
+        const int64_t jg = first + e;
+        int lo = 0, hi = a.G - 1;                                     // the shard that holds slot jg
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_bnd[mid] <= jg) lo = mid; else hi = mid - 1; }
+        const int64_t i = idx[e];
+        const double2* src = reinterpret_cast<const double2*>(rows + i * W);
+        double* dst = packed_out + e * (W + 1);
+#pragma unroll
+        for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }
+        dst[W] = u2d(((uint64_t)(jg - s_bnd[lo]) << 32) | (uint64_t)(gid0 + i));
+    }
+}
+
+// k_push for multinomial shards whose CDF carries the offset levels of k_search_multi: the 4-byte key table in LDS, four staged
+// hits per lane in flight.  What bounds these kernels is the number of DIVERGENT global loads per entry (each costs the CU's L1
+// about four cycles per lane): here the coarse row, the fine run and the particle's row -- the keys never leave LDS.
+template <int LOGG, int W>
+__global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels lw_, int64_t n, int64_t ntiles, int64_t gid0,
+                                                          const double* __restrict__ rows, int64_t capacity, double* __restrict__ packed_out)
+{
+    constexpr int NE = GPF_MULTI_NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int64_t s_off[MAX_SHARDS + 1];     // first entry of every destination in the send buffer
+    __shared__ int64_t s_bnd[MAX_SHARDS + 1];
+    if (threadIdx.x == 0) {
+        int64_t o = 0;
+        for (int g = 0; g < a.G; ++g) { s_off[g] = o; o += a.counts[g]; s_bnd[g] = a.bounds[g]; }
+        s_off[a.G] = o;
+        if (blockIdx.x == 0 && a.host_counts) {   // (as in k_push: the host reads the counts while the look-ups run)
+            for (int g = 0; g < 2 * a.G; ++g)
+                __hip_atomic_store(a.host_counts + g, a.counts[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    const MultiTable tb = multi_table_load<LOGG>(lw_, ntiles, (uint64_t)a.tot_all[5 * a.me], reinterpret_cast<uint32_t*>(smem), [] {});
+    const int64_t total = s_off[a.G] < capacity ? s_off[a.G] : capacity;
+    for (int64_t base = (int64_t)blockIdx.x * NE * SBLOCK; base < total; base += (int64_t)gridDim.x * NE * SBLOCK) {
+        int64_t e[NE]; bool act[NE]; uint64_t T[NE]; uint32_t slot[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            e[u] = base + u * SBLOCK + threadIdx.x;
+            act[u] = e[u] < total;
+            const int64_t ee = act[u] ? e[u] : total - 1;
+            int g = 0;
+            while (g < a.G - 1 && ee >= s_off[g + 1]) ++g;
+            const ulonglong2 q = a.stage[s_bnd[g] + (ee - s_off[g])];
+            T[u] = q.x & DESC_MASK;
+            slot[u] = (uint32_t)q.y;
+        }
+        uint32_t idx[NE];
+        multi_lookup<LOGG, NE>(tb, lw_, n, T, idx);
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            if (!act[u]) continue;
+            const double2* src = reinterpret_cast<const double2*>(rows + (int64_t)idx[u] * W);
+            double* dst = packed_out + e[u] * (W + 1);
+#pragma unroll
+            for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }
+            dst[W] = u2d(((uint64_t)slot[u] << 32) | (uint64_t)(gid0 + idx[u]));
+        }
+    }
+}
+
+// install the received population: every entry names its slot
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_commit_packed(const double* __restrict__ packed, int64_t m, double* __restrict__ rows_new,
+                                                         int32_t* __restrict__ anc, double* __restrict__ lw,
+                                                         const double* __restrict__ mf_all, const int64_t* __restrict__ tot_all, int G, int K,
+                                                         double logN, Scalars* sc)
+{
+    // update_lml_est! (resample.jl:178-182) from the gathered global summary: lml += (m + log(S 2^-K)) - log N
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t S = 0;
+        double mx = -__builtin_huge_val();
+        int f = 0;
+        for (int g = 0; g < G; ++g) {
+            S += (uint64_t)tot_all[5 * g];
+            const double v = mf_all[2 * g]; mx = v > mx ? v : mx; f |= (int)mf_all[2 * g + 1];
+        }
+        if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+        sc->lml_est = sc->lml_est + (lse_from(mx, S, K, f) - logN);
+    }
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < m; k += (int64_t)gridDim.x * BLOCK) {
+        const double* src = packed + k * (W + 1);
+        const uint64_t meta = d2u(src[W]);
+        const int64_t j = (int64_t)(meta >> 32);
+        double* dst = rows_new + j * W;
+#pragma unroll
+        for (int c = 0; c < W; ++c) dst[c] = src[c];
+        anc[j] = (int32_t)(meta & 0xffffffffull);
+        lw[j] = 0.0;                                   // update_weights!, resample.jl:195
+    }
+}
+
+} // namespace gpf

@@ -1,0 +1,222 @@
+// K10: stable descending radix sort (onesweep)  (part of gpf_kernels.hpp; include that header, not this file)
+#pragma once
+
+namespace gpf {
+// ----------------------------------------------------------------------------- K10: stable descending sort
+// order = sortperm(log_priorities, rev=true) (resample.jl:156-157; stable: ties keep ascending index order).
+// Least-significant-digit radix sort of the order-preserving 64-bit key with the particle index as payload: 8 passes of
+// 8 bits, each ONE kernel ("onesweep"): a workgroup of 1024 threads takes the next tile by ticket, ranks its 4096 keys by digit (wave-level
+// match + per-wave counters in LDS), learns the global offset of each of its 256 digit bins by a decoupled look-back over
+// the earlier tiles' descriptors ({valid | count} in one 8-byte word, relaxed agent-scope atomics as in k_scan), reorders
+// the tile in LDS so that every digit's run leaves as contiguous stores, and scatters.  The histograms of all eight digits
+// come from the key-generation pass.  24 N bytes of traffic per pass.
+constexpr int SORT_TILE = 4096;                    // keys per workgroup
+constexpr int SORT_BLOCK = 1024, SORT_WAVES = SORT_BLOCK / WAVE;   // many waves with few keys each: the chain ticket -> load ->
+constexpr int SORT_ITEMS = SORT_TILE / SORT_BLOCK;                 // rank -> look-back -> scatter is latency, not bandwidth
+constexpr int SORT_PASSES = 8, SORT_BINS = 256;
+constexpr uint64_t SORT_VALID = 1ull << 62, SORT_VAL = (1ull << 62) - 1;   // descriptor = {valid | count}
+// workspace: [8][256] u32 histograms | [8] u32 tile tickets | pad | per pass: [ntiles | ntiles/16 | ntiles/256][256] u64 descriptors
+__host__ __device__ __forceinline__ size_t sort_ws_desc_offset() { return (size_t)(SORT_PASSES * SORT_BINS + 64) * sizeof(uint32_t); }
+__host__ inline size_t sort_ws_bytes(int64_t n)
+{
+    const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
+    return sort_ws_desc_offset() + (size_t)SORT_PASSES * (nt + (nt + 15) / 16 + (nt + 255) / 256) * SORT_BINS * sizeof(uint64_t);
+}
+// keys of the log-priorities + the histograms of all eight digits in one pass over the weights
+__global__ __launch_bounds__(BLOCK) void k_sort_keys_hist(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s_h[SORT_PASSES][SORT_BINS];
+    for (int i = threadIdx.x; i < SORT_PASSES * SORT_BINS; i += BLOCK) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const uint64_t k = sort_key_desc(pv.at(i));
+        keys[i] = k;
+#pragma unroll
+        for (int p = 0; p < SORT_PASSES; ++p) atomicAdd(&s_h[p][(k >> (8 * p)) & 0xff], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SORT_PASSES * SORT_BINS; i += BLOCK) { const uint32_t c = (&s_h[0][0])[i]; if (c) atomicAdd(hist + i, c); }
+}
+
+// one digit pass.  vals_in == nullptr: the payload is the element's index (first pass).
+__global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                                                     uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
+                                                     int pass, const uint32_t* __restrict__ hist, uint32_t* __restrict__ ticket,
+                                                     uint64_t* __restrict__ desc, int32_t* __restrict__ timeout)
+{
+    __shared__ uint32_t s_cnt[SORT_WAVES][SORT_BINS];      // per-wave digit counts, then exclusive offsets of the wave inside the tile's bin
+    __shared__ uint32_t s_lstart[SORT_BINS];           // first position of the bin in the tile's sorted order
+    __shared__ int64_t s_gbase[SORT_BINS];             // global position of the bin's first element of this tile, minus s_lstart
+    __shared__ uint32_t s_scan[SORT_WAVES];
+    __shared__ uint64_t s_keys[SORT_TILE];
+    __shared__ int32_t s_vals[SORT_TILE];
+    __shared__ uint32_t s_tile;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int shift = 8 * pass;
+    if (tid == 0) s_tile = atomicAdd(ticket + pass, 1u);
+    for (int i = tid; i < SORT_WAVES * SORT_BINS; i += SORT_BLOCK) (&s_cnt[0][0])[i] = 0;
+    // exclusive scan of the digit's histogram: where each bin starts in the output
+    const bool binthr = tid < SORT_BINS;               // the first four waves double as "thread = bin"
+    const uint32_t hv = binthr ? hist[pass * SORT_BINS + tid] : 0u;
+    uint32_t hinc = hv;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(hinc, d, WAVE); if (lane >= d) hinc += o; }
+    if (binthr && lane == WAVE - 1) s_scan[wv] = hinc;
+    __syncthreads();
+    uint32_t hbase = hinc - hv;
+#pragma unroll
+    for (int w = 0; w < SORT_BINS / WAVE; ++w) if (w < wv) hbase += s_scan[w];
+    const int64_t tile = s_tile;
+    const int64_t t0 = tile * SORT_TILE;
+    // ---- load (wave-striped: element = t0 + wave * 1024 + item * 64 + lane), rank inside the wave by digit
+    uint64_t key[SORT_ITEMS]; int32_t val[SORT_ITEMS]; uint32_t rank[SORT_ITEMS];
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const int64_t i = t0 + wv * (WAVE * SORT_ITEMS) + it * WAVE + lane;
+        key[it] = i < n ? keys_in[i] : ~0ull;
+        val[it] = i < n ? (vals_in ? vals_in[i] : (int32_t)i) : 0;
+    }
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const int64_t i = t0 + wv * (WAVE * SORT_ITEMS) + it * WAVE + lane;
+        const bool valid = i < n;
+        const uint32_t d = (uint32_t)(key[it] >> shift) & 0xffu;
+        uint64_t peers = __ballot(valid);                 // lanes with the same digit (invalid lanes take no part)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { const uint64_t m = __ballot((d >> b) & 1u); peers &= ((d >> b) & 1u) ? m : ~m; }
+        const uint32_t prev = s_cnt[wv][d];
+        rank[it] = prev + (uint32_t)__popcll(peers & lt_mask);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt_mask) == 0) s_cnt[wv][d] = prev + (uint32_t)__popcll(peers);     // the group's lowest lane
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- per bin (thread = bin): offsets of the waves inside the bin, the tile's count, the bin's start inside the tile
+    uint32_t tcnt = 0;
+    if (binthr) {
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = tcnt; tcnt += c; }
+    }
+    uint32_t linc = tcnt;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(linc, d, WAVE); if (lane >= d) linc += o; }
+    __syncthreads();                                        // s_scan reuse
+    if (binthr && lane == WAVE - 1) s_scan[wv] = linc;
+    // the tile's aggregate is published NOW; the tile is then reordered in LDS (local information only) while the other
+    // tiles publish theirs, and only then are the earlier tiles' words read
+    {
+        const size_t nt_ = gridDim.x, ng_ = (nt_ + 15) / 16, nsg_ = (nt_ + 255) / 256;
+        if (binthr) __hip_atomic_store(desc + ((size_t)pass * (nt_ + ng_ + nsg_) + (size_t)tile) * SORT_BINS + tid, SORT_VALID | tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    uint32_t lstart = linc - tcnt;
+#pragma unroll
+    for (int w = 0; w < SORT_BINS / WAVE; ++w) if (w < wv) lstart += s_scan[w];
+    if (binthr) s_lstart[tid] = lstart;
+    __syncthreads();
+    // ---- reorder inside the tile: afterwards every digit's run leaves as contiguous stores
+#pragma unroll
+    for (int it = 0; it < SORT_ITEMS; ++it) {
+        const int64_t i = t0 + wv * (WAVE * SORT_ITEMS) + it * WAVE + lane;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(key[it] >> shift) & 0xffu;
+            const uint32_t lp = s_lstart[d] + s_cnt[wv][d] + rank[it];
+            s_keys[lp] = key[it]; s_vals[lp] = val[it];
+        }
+    }
+    uint64_t excl = 0;
+    // ---- global number of this bin's elements in earlier tiles.  Tiles are taken by ticket, so every earlier tile is running
+    //      or done, and the tiles of a launch mostly start TOGETHER: a one-word-per-hop look-back would crawl through a chain
+    //      of tiles that are all still looking back themselves.  Three planes of {valid | count} words instead, every read
+    //      independent of the others:  AGG[tile] (published right after ranking),  GT[group of 16 tiles] (the group's total,
+    //      published by the group's last tile from the 16 aggregates),  PRE[super-group of 256 tiles] (inclusive prefix of
+    //      everything up to the super-group's end, published by its last tile).
+    //      excl(tile) = PRE[super-group before] + sum of GT of the earlier groups of this super-group + sum of AGG of the earlier
+    //      tiles of this group: at most 1 + 15 + 15 words, two or three round trips whatever the number of tiles.
+    if (binthr) {
+        const size_t nt = gridDim.x, ng = (nt + 15) / 16, nsg = (nt + 255) / 256;
+        uint64_t* const agg = desc + ((size_t)pass * (nt + ng + nsg)) * SORT_BINS + tid;      // this pass, this bin
+        uint64_t* const gt = agg + nt * SORT_BINS;
+        uint64_t* const pre = gt + ng * SORT_BINS;
+        auto wait_word = [&](const uint64_t* p) {
+            uint64_t v = __hip_atomic_load(const_cast<uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (!(v & SORT_VALID)) {
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(const_cast<uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > SPIN_LIMIT) { *timeout = 1; break; }
+            }
+            return v & SORT_VAL;
+        };
+        // sum of words p[0], p[stride], ..., cnt <= 15 of them: all loads first, then the (rare) waits
+        auto sum_words = [&](const uint64_t* p, int cnt) {
+            uint64_t v[15], acc = 0;
+#pragma unroll
+            for (int e = 0; e < 15; ++e) v[e] = e < cnt ? __hip_atomic_load(const_cast<uint64_t*>(p + (size_t)e * SORT_BINS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SORT_VALID;
+#pragma unroll
+            for (int e = 0; e < 15; ++e) acc += (v[e] & SORT_VALID) ? (v[e] & SORT_VAL) : wait_word(p + (size_t)e * SORT_BINS);
+            return acc;
+        };
+        const int64_t k = tile & 15, g = tile >> 4, gk = g & 15, sg = tile >> 8;
+        const uint64_t in_group = sum_words(agg + (size_t)(tile - k) * SORT_BINS, (int)k);
+        if (k == 15) __hip_atomic_store(gt + (size_t)g * SORT_BINS, SORT_VALID | (in_group + tcnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t e_ = in_group + sum_words(gt + (size_t)(g - gk) * SORT_BINS, (int)gk);
+        if (sg > 0) e_ += wait_word(pre + (size_t)(sg - 1) * SORT_BINS);
+        if ((tile & 255) == 255) __hip_atomic_store(pre + (size_t)sg * SORT_BINS, SORT_VALID | (e_ + tcnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        excl = e_;
+    }
+    if (binthr) s_gbase[tid] = (int64_t)hbase + (int64_t)excl - (int64_t)lstart;
+    __syncthreads();
+    const int64_t nvalid = n - t0 < SORT_TILE ? n - t0 : SORT_TILE;
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) {
+        const int lp = k * SORT_BLOCK + tid;
+        if (lp < nvalid) {
+            const uint64_t kk = s_keys[lp];
+            const int64_t g = s_gbase[(uint32_t)(kk >> shift) & 0xffu] + lp;
+            keys_out[g] = kk; vals_out[g] = s_vals[lp];
+        }
+    }
+}
+
+__global__ void k_extract_column(const double* __restrict__ rows, int W, int col, int64_t n, double* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = rows[i * W + col];
+}
+__global__ void k_parents(const int32_t* __restrict__ anc, int64_t n, int64_t* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (int64_t)anc[i] + 1;
+}
+// get_log_norm_weights / get_norm_weights (utils.jl:100,103-107,148,156)
+__global__ void k_norm_weights(const double* __restrict__ lw, const WSum* ws, int K, int64_t n, int want_log,
+                               double* __restrict__ out)
+{
+    const double m = ws->m;
+    const double lse = lse_from(m, ws->S, K, ws->flags);
+    const double Sd = (double)ws->S;
+    const bool uniform = (ws->flags & FLAG_ALL_NEGINF) != 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        if (want_log) out[i] = lw[i] - lse;
+        else out[i] = (double)(uniform ? 1 : exp_fix(lw[i] - m, K)) / Sd;
+    }
+}
+__global__ void k_debug_math(int which, const double* a, const double* b, int64_t n, uint64_t seed, uint32_t epoch,
+                             uint32_t tag, double* out, double* out2)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        switch (which) {
+            case 0: out[i] = exp_(a[i]); break;
+            case 1: out[i] = log_(a[i]); break;
+            case 2: sincos2pi(a[i], out[i], out2[i]); break;
+            case 3: out[i] = atan2_(a[i], b[i]); break;
+            case 4: out[i] = sqrt_(a[i]); break;
+            case 5: out[i] = a[i] / b[i]; break;
+            case 6: normal2(rng(seed, (uint32_t)a[i], (uint32_t)b[i], epoch, tag), out[i], out2[i]); break;
+            default: out[i] = 0.0;
+        }
+    }
+}
+
+} // namespace gpf

@@ -1,0 +1,223 @@
+// K1/K2: initialise, propagate (with the fused resample gather / sharded commit), rejuvenation moves  (part of gpf_kernels.hpp; include that header, not this file)
+#pragma once
+
+namespace gpf {
+// ----------------------------------------------------------------------------- K1/K2: init & step
+// per-block (max, flags) of the log-weights a kernel has just written: the first pass of safe_softmax
+// (utils.jl:119-128) rides on the kernel that produces the weights instead of re-reading them
+__device__ __forceinline__ void track_max(double v, double& m, int& f)
+{
+    if (v != v) f |= FLAG_NAN;
+    else { m = v > m ? v : m; if (v == __builtin_huge_val()) f |= FLAG_POSINF; }
+}
+__device__ __forceinline__ void block_max_store(double m, int f, double* __restrict__ pmax, int32_t* __restrict__ pflags)
+{
+    m = wave_max_f64(m);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
+    __shared__ double sm_[NWAVES];
+    __shared__ int sf_[NWAVES];
+    if (lane_id() == 0) { sm_[wave_id()] = m; sf_[wave_id()] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < NWAVES; ++w) { m = sm_[w] > m ? sm_[w] : m; f |= sf_[w]; }
+        pmax[blockIdx.x] = m;
+        pflags[blockIdx.x] = f;
+    }
+}
+
+// stratified_map! (utils.jl:29-55): K strata, block size B = n div K; particle i < K B belongs to stratum i div B
+// (:contiguous) or i mod K (:interleaved); the n - K B remaining particles draw a stratum uniformly (sample(strata, R)),
+// here from one more Philox block of the particle (block index NBLK, behind the model's own blocks)
+template <class Mo>
+__device__ __forceinline__ int stratum_of(const ModelArgs& a, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t i, int64_t n, uint32_t tag)
+{
+    const int64_t K = a.n_strata, B = n / K;
+    if (i < K * B) return (int)(a.interleaved ? i % K : i / B);
+    const Philox b = rng(seed, (uint32_t)(gid0 + i), (uint32_t)Mo::NBLK, epoch, tag);
+    return (int)mulhi64(u64(b.w0, b.w1), (uint64_t)K);
+}
+
+// pf_initialize (initialize.jl:39-41) / pf_update! (update.jl:15-22): one lane per particle, row in,
+// row out, lw += log p(y|x).  Counter-based RNG: no RNG state in memory.
+// MODE 0: the model's own sampler; 1: native custom proposal; 2: stratified (the discrete latent constrained per stratum)
+template <int M, int MODE = 0>
+__global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
+                                                int64_t n, int W, double* __restrict__ rows,
+                                                double* __restrict__ lw, double* __restrict__ pmax,
+                                                int32_t* __restrict__ pflags)
+{
+    using Mo = Model<M>;
+    double bm = -__builtin_huge_val(); int bf = 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        double x[MAX_DIM];
+        double ll;
+        if constexpr (MODE == 1) ll = Mo::propose(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+        else if constexpr (MODE == 2) {
+            const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
+            const double lp = Mo::sample_stratum(a.P, true, nullptr, a.obs, v, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+            ll = (lp + Mo::loglik(a.P, x, a.obs)) + a.logK;                      // initialize.jl:103-104
+        } else {
+            Mo::sample(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+            ll = Mo::loglik(a.P, x, a.obs);
+        }
+        double* r = rows + i * W;
+#pragma unroll
+        for (int k = 0; k < Mo::D; ++k) r[k] = x[k];
+        for (int k = Mo::D; k < W; ++k) r[k] = 0.0;
+        lw[i] = ll;
+        track_max(ll, bm, bf);
+    }
+    block_max_store(bm, bf, pmax, pflags);
+}
+
+// GATHER: the preceding pf_resample! left its ancestor vector pending; this kernel reads row anc[i]
+// instead of row i (new_traces .= view(traces, parents), resample.jl:60, fused into the propagate) and
+// the incoming log-weights are known to be 0 (update_weights!, resample.jl:195): lw = ll, no read.
+// PACKED (sharded filters): the preceding resample left the population as the received exchange buffer
+// [row | slot << 32 | global ancestor id] (gpf_shard_commit); entry k is propagated straight into its slot, the
+// scatter pass (k_commit_packed) and its round trip through HBM disappear, the log-ML update rides along.
+struct PackedCommit {
+    const double* packed;      // [n][W + 1], or nullptr
+    int32_t* anc;              // parents of the committed population
+    const double* mf_all; const int64_t* tot_all; int G, K; double logN; Scalars* sc;   // update_lml_est! from the gathered summaries
+    const double* lw_fill;     // GATHER after gpf_resample_local: the incoming log-weights are this constant, not 0 (resample.jl:210)
+};
+template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false>
+__global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
+                                                int64_t n, const int32_t* __restrict__ anc,
+                                                const double* __restrict__ rows_in,
+                                                double* __restrict__ rows_out, double* __restrict__ lw,
+                                                double* __restrict__ pmax, int32_t* __restrict__ pflags, PackedCommit pc)
+{
+    using Mo = Model<M>;
+    constexpr int D = Mo::D;
+    double bm = -__builtin_huge_val(); int bf = 0;
+    if constexpr (PACKED) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            uint64_t S = 0;
+            double mx = -__builtin_huge_val();
+            int f = 0;
+            for (int g = 0; g < pc.G; ++g) {
+                S += (uint64_t)pc.tot_all[5 * g];
+                const double v = pc.mf_all[2 * g]; mx = v > mx ? v : mx; f |= (int)pc.mf_all[2 * g + 1];
+            }
+            if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+            pc.sc->lml_est = pc.sc->lml_est + (lse_from(mx, S, pc.K, f) - pc.logN);
+        }
+    }
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < n; e += (int64_t)gridDim.x * BLOCK) {
+        int64_t i = e;                                  // the slot this lane fills
+        double r[W];
+        if constexpr (PACKED) {
+            const double* src = pc.packed + e * (W + 1);
+#pragma unroll
+            for (int c = 0; c < W; ++c) r[c] = src[c];
+            const uint64_t meta = d2u(src[W]);
+            i = (int64_t)(meta >> 32);
+            pc.anc[i] = (int32_t)(meta & 0xffffffffull);
+        } else {
+        const int64_t srow = GATHER ? (int64_t)anc[i] : i;
+        const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
+#pragma unroll
+        for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
+        }
+        double xn[MAX_DIM];
+        double ll;
+        if constexpr (MODE == 1) ll = Mo::propose(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
+        else if constexpr (MODE == 2) {
+            const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_UPDATE)];
+            const double lp = Mo::sample_stratum(a.P, false, r, a.obs, v, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
+            ll = (lp + Mo::loglik(a.P, xn, a.obs)) + a.logK;                     // update.jl:201-206
+        } else {
+            Mo::sample(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
+            ll = Mo::loglik(a.P, xn, a.obs);
+        }
+        double o[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) o[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) o[k] = xn[k];
+        if (KEEP_PREV) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) o[D + k] = r[k];
+        }
+        double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
+#pragma unroll
+        for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(o[2 * c], o[2 * c + 1]);
+        const double nl = (GATHER || PACKED) ? ((GATHER && pc.lw_fill) ? *pc.lw_fill + ll : ll)   // after a resample the incoming
+                                             : lw[i] + ll;                                    // log-weights are 0 (or one constant)
+        lw[i] = nl;
+        track_max(nl, bm, bf);
+    }
+    block_max_store(bm, bf, pmax, pflags);
+}
+
+// K7/K8: pf_move_accept! with Gen.mh on the current step's latent (rejuvenate.jl:40-53) and
+// pf_move_reweight! with move_reweight(trace, selection) (rejuvenate.jl:74-90, :125-132)
+// GATHER: a pf_resample! left its ancestor vector pending; the move reads row anc[i] (new_traces .= view(traces, parents),
+// resample.jl:60, fused) and the incoming log-weights are 0 (resample.jl:195), exactly like k_step<GATHER>.
+template <int M, int W, bool REWEIGHT, bool GATHER = false>
+__global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
+                                                int64_t n, int has_prev, int n_iters, const int32_t* __restrict__ anc,
+                                                const double* __restrict__ rows_in,
+                                                double* __restrict__ rows_out, double* __restrict__ lw,
+                                                unsigned long long* __restrict__ n_accept,
+                                                double* __restrict__ pmax, int32_t* __restrict__ pflags)
+{
+    using Mo = Model<M>;
+    constexpr int D = Mo::D, NB = Mo::NBLK;
+    unsigned long long acc = 0;
+    double bm = -__builtin_huge_val(); int bf = 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        double r[W];
+        const int64_t srow = GATHER ? (int64_t)anc[i] : i;
+        const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
+#pragma unroll
+        for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
+        double x[MAX_DIM], xs[MAX_DIM];
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = r[k];
+        const double* xp = r + D;                    // x_{t-1} (valid when has_prev)
+        double llx = Mo::loglik(a.P, x, a.obs);
+        double wsum = 0.0;
+        const uint32_t gid = (uint32_t)(gid0 + i);
+        for (int it = 0; it < n_iters; ++it) {
+            if (REWEIGHT) {
+                Mo::sample(a.P, !has_prev, xp, a.obs, seed, gid, (uint32_t)(it * NB), epoch, TAG_REWEIGHT, xs);
+                const double lls = Mo::loglik(a.P, xs, a.obs);
+                wsum = wsum + (lls - llx);
+#pragma unroll
+                for (int k = 0; k < D; ++k) x[k] = xs[k];
+                llx = lls;
+                ++acc;
+            } else {
+                const uint32_t blk0 = (uint32_t)(it * (NB + 1));
+                Mo::sample(a.P, !has_prev, xp, a.obs, seed, gid, blk0, epoch, TAG_MOVE, xs);
+                const double lls = Mo::loglik(a.P, xs, a.obs);
+                const Philox b = rng(seed, gid, blk0 + NB, epoch, TAG_MOVE);
+                const double lu = log_(u52(b.w0, b.w1));
+                if (lu < lls - llx) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) x[k] = xs[k];
+                    llx = lls;
+                    ++acc;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) r[k] = x[k];
+        double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
+#pragma unroll
+        for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(r[2 * c], r[2 * c + 1]);
+        if (REWEIGHT) { const double nl = (GATHER ? 0.0 : lw[i]) + wsum; lw[i] = nl; track_max(nl, bm, bf); }
+        else if (GATHER) lw[i] = 0.0;
+    }
+    // one atomic per wave
+    unsigned long long t = wave_sum_u64(acc);
+    if (lane_id() == 0 && t) atomicAdd(n_accept, t);
+    if (REWEIGHT) block_max_store(bm, bf, pmax, pflags);
+}
+
+} // namespace gpf
