@@ -89,7 +89,11 @@ struct ShardPlan {
     WSum ws;                                                          // the GLOBAL weight sum and its strata constants
     int64_t first, count;                                             // this shard serves the global slots [first, first + count)
     uint64_t t_off;                                                   // where this shard's CDF starts in the global one
+    int32_t n_shards, pad;
+    int64_t bounds[MAX_SHARDS + 1];                                   // first global slot of every shard (the packed entries name slots inside their shard)
 };
+// k_search_strat on a shard packs the exchange entries itself: [row | slot inside its shard << 32 | global ancestor id]
+struct PackOut { const double* rows; double* packed; int64_t capacity, gid0; int W; };
 struct SearchArgs {
     CdfLevels w;                                                      // weights (or residual weights for the tail)
     CdfLevels c;                                                      // residual: copy counts
@@ -104,6 +108,7 @@ struct SearchArgs {
     uint64_t seed; uint32_t epoch;
     int K; double logN;
     double invN;                                                      // 1 / n_global (stratified)
+    PackOut pack;                                                     // plan != nullptr && pack.packed: no ancestor array, packed rows instead
     int update_lml;                                                   // 0 for sub-state views (resample.jl:185-187); 2: whole-shard
                                                                       // sub-state, the kept mass goes to sc->lw_fill (resample.jl:210)
     int32_t* anc;
@@ -811,10 +816,43 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
 #pragma unroll
         for (int k = 0; k < MSLOTS; ++k) res[k] = (uint32_t)s_T[MSLOTS * tid + k];
     }
-    // ---- parents[j] = order[i_old]   (resample.jl:168)
     const int64_t jb = j0 + MSLOTS * tid;
-    int32_t out[MSLOTS];
     const uint32_t last = (uint32_t)(a.n_cells - 1);
+    if (a.plan && a.pack.packed) {
+        // ---- a shard: the served slots leave as exchange entries in slot order (which is grouped by destination shard).  The
+        //      ancestors go through LDS so that neighbouring LANES take neighbouring entries: the packed stores are contiguous
+        //      and the row reads (ascending ancestors) coalesce
+        int64_t* const s_bnd = reinterpret_cast<int64_t*>(s_T);        // the targets are spent
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MSLOTS; ++k) s_mark[MSLOTS * tid + k] = res[k] < last ? res[k] : last;
+        const int G = a.plan->n_shards;
+        for (int g = tid; g <= G; g += MBLOCK) s_bnd[g] = a.plan->bounds[g];
+        __syncthreads();
+        const int64_t lim = n_out < a.pack.capacity ? n_out : a.pack.capacity;
+        int lo = 0;
+        {
+            const int64_t jg = sbase + j0 + tid;                         // the shard that holds the lane's first entry
+            int hi = G - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_bnd[mid] <= jg) lo = mid; else hi = mid - 1; }
+        }
+        const int W = a.pack.W;
+#pragma unroll
+        for (int k = 0; k < MSLOTS; ++k) {
+            const int64_t e = j0 + k * MBLOCK + tid;
+            if (e >= lim) break;
+            const int64_t jg = sbase + e;
+            while (lo < G - 1 && s_bnd[lo + 1] <= jg) ++lo;
+            const int64_t i = s_mark[k * MBLOCK + tid];
+            const double2* src = reinterpret_cast<const double2*>(a.pack.rows + i * W);
+            double* dst = a.pack.packed + e * (W + 1);
+            for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }
+            dst[W] = u2d(((uint64_t)(jg - s_bnd[lo]) << 32) | (uint64_t)(a.pack.gid0 + i));
+        }
+        return;
+    }
+    // ---- parents[j] = order[i_old]   (resample.jl:168)
+    int32_t out[MSLOTS];
 #pragma unroll
     for (int k = 0; k < MSLOTS; ++k) {
         uint32_t idx = res[k] < last ? res[k] : last;

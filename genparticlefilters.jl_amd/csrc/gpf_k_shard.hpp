@@ -306,8 +306,8 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
 // owns the targets in [lo_h, lo_(h+1)) (lo = exclusive totals): the slots shard h serves are the contiguous range
 // [F[h], F[h+1]), F[h] = first slot whose target is >= lo_h -- the stratum that contains lo_h, or the one after it, decided by
 // that one slot's target.  One small workgroup derives F from the gathered totals (every shard the same), the exchange
-// counts follow by intersecting slot ranges, and the ancestors of the served slots come from k_search_strat (streaming merge
-// over the shard's own CDF) -- no pass over the global slots, no staging list.
+// counts follow by intersecting slot ranges, and the served slots' ancestors AND their packed rows come from k_search_strat
+// (streaming merge over the shard's own CDF, SearchArgs::pack) -- no pass over the global slots, no staging list.
 __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
 {
     __shared__ int64_t F[MAX_SHARDS + 1];
@@ -352,36 +352,15 @@ __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
     if (h == 0) {
         plan->ws.S = S; plan->ws.sB = B; plan->ws.srem = rem; plan->ws.sinv = (double)N / (double)S;
         plan->first = F[a.me]; plan->count = F[a.me + 1] - F[a.me]; plan->t_off = lo_me;
+        plan->n_shards = a.G;
     }
+    if (h <= a.G) plan->bounds[h] = a.bounds[h];
     __syncthreads();
     if (h == 0 && a.host_counts) {
         __threadfence_system();
         __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-// packed_out[e] = [row of the ancestor | (slot inside its shard) << 32 | global ancestor id] for the served slots in slot
-// order -- which IS grouped by destination shard.  The ancestors ascend: the row reads coalesce.
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_push_pack(PushArgs a, const ShardPlan* __restrict__ plan, const int32_t* __restrict__ idx, int64_t gid0,
-                                                     const double* __restrict__ rows, int64_t capacity, double* __restrict__ packed_out)
-{
-    __shared__ int64_t s_bnd[MAX_SHARDS + 1];
-    for (int g = threadIdx.x; g <= a.G; g += BLOCK) s_bnd[g] = a.bounds[g];
-    __syncthreads();
-    const int64_t first = plan->first, total = plan->count < capacity ? plan->count : capacity;
-    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * BLOCK) {
-        const int64_t jg = first + e;
-        int lo = 0, hi = a.G - 1;                                     // the shard that holds slot jg
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_bnd[mid] <= jg) lo = mid; else hi = mid - 1; }
-        const int64_t i = idx[e];
-        const double2* src = reinterpret_cast<const double2*>(rows + i * W);
-        double* dst = packed_out + e * (W + 1);
-#pragma unroll
-        for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }
-        dst[W] = u2d(((uint64_t)(jg - s_bnd[lo]) << 32) | (uint64_t)(gid0 + i));
-    }
-}
-
 // k_push for multinomial shards whose CDF carries the offset levels of k_search_multi: the 4-byte key table in LDS, four staged
 // hits per lane in flight.  What bounds these kernels is the number of DIVERGENT global loads per entry (each costs the CU's L1
 // about four cycles per lane): here the coarse row, the fine run and the particle's row -- the keys never leave LDS.

@@ -1891,23 +1891,18 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
         if (!h->shard_plan) return fail(h, GPF_ERR_STATE, "gpf_shard_push needs gpf_shard_push_count of the same resample first");
         if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, a))) return s;
         if (capacity == 0) return GPF_OK;
-        // ancestors of the served slots (a streaming merge over the shard's own CDF), then rows packed in slot order; both
-        // grids are sized for the send buffer and stop at the served count, which only the device knows
+        // ancestors of the served slots (a streaming merge over the shard's own CDF) and, in the same kernel, their rows packed in
+        // slot order; the grid is sized for the send buffer and stops at the served count, which only the device knows
         const int64_t cap = std::min<int64_t>(capacity, h->cfg.n_global);
         SearchArgs sa{};
         sa.w = levels(h, 0); sa.c = sa.w; sa.ntiles = h->ntiles;
         sa.order = nullptr; sa.sc = h->sc; sa.ws = &h->shard_plan->ws; sa.raw = &h->sc->raw; sa.plan = h->shard_plan;
         sa.n = cap; sa.n_cells = h->n; sa.n_global = h->cfg.n_global; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
-        sa.K = h->K; sa.logN = h->logN; sa.anc = reinterpret_cast<int32_t*>(h->push_stage); sa.invN = 1.0 / (double)h->cfg.n_global;
+        sa.K = h->K; sa.logN = h->logN; sa.anc = nullptr; sa.invN = 1.0 / (double)h->cfg.n_global;
         sa.update_lml = 0;                                            // the commit carries the log-ML update
-        const int gp = grid_for(h, cap, 8);
+        sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W};
         s = timed(h, GPF_K_GATHER, [&] {
             GPF_LAUNCH(k_search_strat, dim3((unsigned)((cap + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa);
-            switch (h->W) {
-                case 2: GPF_LAUNCH((k_push_pack<2>), dim3(gp), dim3(BLOCK), 0, h->stream, a, h->shard_plan, sa.anc, h->cfg.gid0, h->rows[h->cur], capacity, packed_out); break;
-                case 4: GPF_LAUNCH((k_push_pack<4>), dim3(gp), dim3(BLOCK), 0, h->stream, a, h->shard_plan, sa.anc, h->cfg.gid0, h->rows[h->cur], capacity, packed_out); break;
-                case 8: GPF_LAUNCH((k_push_pack<8>), dim3(gp), dim3(BLOCK), 0, h->stream, a, h->shard_plan, sa.anc, h->cfg.gid0, h->rows[h->cur], capacity, packed_out); break;
-            }
         });
         if (s) return s;
         HIP_TRY(h, hipGetLastError());
