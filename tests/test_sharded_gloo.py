@@ -40,6 +40,7 @@ CASES = [
     ("lgssm2", "residual", 3000, 5, None, None),
     ("bearings4", "residual", 2000, 6, 0.5, "move"),        # BASELINE config 4 shape: ESS-triggered residual + MH
     ("sv1", "multinomial", 1500, 5, None, "reweight"),       # BASELINE config 5 shape
+    ("bearings4", "stratified", 1600, 5, 0.6, "move"),       # ESS-triggered stratified + MH: the deferred packed commit is scattered by the move
     ("bearings4", "multinomial", 1200, 4, None, "keep"),     # rows carry x_{t-1} (keep_prev) but nothing rejuvenates: the
                                                              # resampled population goes straight into the next propagate
 ]
