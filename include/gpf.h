@@ -245,11 +245,13 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
  *            host: all-gather -> tot_all[G][5]
  *   phase 2b gpf_shard_residual_scan  (residual only) in: tot_all; out2 = {Ctot_local, Rs_local}
  *            host: all-gather -> cr_all[G][2]
- *   phase 3  gpf_shard_push_count     RNG counters are keyed by the GLOBAL slot id, so every shard evaluates the target of
- *                                     EVERY output slot itself and finds which of them fall into its own part of the
- *                                     global CDF (owner = first shard whose inclusive total exceeds the target): no
- *                                     request message exists.  The pass also counts the entries this shard will send to
- *                                     each shard and receive from each shard (counters cleared by gpf_shard_weight_scan).
+ *   phase 3  gpf_shard_push_count     RNG counters are keyed by the GLOBAL slot id, so every shard can work out by itself which
+ *                                     output slots draw from ITS part of the global CDF (owner = first shard whose inclusive
+ *                                     total exceeds the target): no request message exists.  Multinomial / residual: one pass
+ *                                     over the targets of all output slots (residual: the deterministic head in closed form);
+ *                                     stratified: the served slots are ONE contiguous range, found in closed form.  The phase
+ *                                     also yields the number of entries this shard will send to and receive from each shard
+ *                                     (counters cleared by gpf_shard_weight_scan).
  *            host: gpf_shard_counts (the one host sync of a resample: the all-to-all split sizes)
  *   phase 4  gpf_shard_push           ancestor lookup + row gather for every slot this shard owns the target of;
  *                                     packed_out[sum(sent)][W+1] = row | (slot inside its shard) << 32 | global ancestor id,
