@@ -85,6 +85,11 @@ struct gpf_filter {
     bool raw_q_folded = false;     // sc->raw.Ql folded from blockQ
     bool pending_gather = false;   // a resample left (rows[cur], anc) un-gathered; log-weights are 0
     bool pending_fill = false;     // ... or, after gpf_resample_local, the constant sc->lw_fill
+    // the 16-bit offset levels of the weight channel (k_search_multi / k_push_multi) cost the scan ~1.4 us: only written when a
+    // multinomial search will read them
+    bool want_offsets = true;      // what the next scan of channel 0 writes
+    bool ch0_offsets = false;      // what the last scan of channel 0 wrote
+    bool offsets_hint = true;      // was the last resample multinomial?  (scans that run ahead of a resample: the ESS getter)
     bool pending_packed = false;   // sharded: the resampled population is still the received exchange buffer (gpf_shard_commit)
     const double* pend_packed = nullptr; const double* pend_mf = nullptr; const int64_t* pend_tot = nullptr; int pend_G = 0;
     // trajectory store (gpf_history_enable): per recorded step the d latent columns in the step's final particle
@@ -434,7 +439,9 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
     uint64_t* dc = h->desc[ch][h->dcur[ch]];
     uint64_t* dn = h->desc[ch][1 - h->dcur[ch]];
     const int gs = scan_grid(h);
-    const ScanOut so = scan_out(want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch], h->ntiles, ch == 0);
+    const bool offsets = ch == 0 && h->want_offsets && want_cdf;
+    const ScanOut so = scan_out(want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch], h->ntiles, offsets);
+    if (ch == 0 && want_cdf) h->ch0_offsets = offsets && so.off16 != nullptr;
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
         GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(BLOCK), 0, h->stream, in, h->n, h->ntiles, pmax, h->pflags, np, slot,
                            so, dc, dn, total_out, h->blockQ, h->h_timeout, ex);
@@ -481,7 +488,10 @@ gpf_status ensure_raw(gpf_filter* h, bool want_q = false)
     gpf_status s = materialize(h);
     if (s) return s;
     if (h->raw_valid && (!want_q || h->raw_has_q)) return GPF_OK;
-    if ((s = summarize(h, raw_view(h), &h->sc->raw, true, nullptr, true, want_q))) return s;
+    h->want_offsets = h->offsets_hint;                           // a resample that follows may reuse this CDF
+    s = summarize(h, raw_view(h), &h->sc->raw, true, nullptr, true, want_q);
+    h->want_offsets = true;
+    if (s) return s;
     h->raw_valid = true;
     h->raw_has_q = want_q;
     h->raw_q_folded = false;
@@ -653,7 +663,7 @@ gpf_status ensure_residual_buffers(gpf_filter* h)
 
 CdfLevels levels(const gpf_filter* h, int ch)
 {
-    const int logg = ch == 0 ? multi_logg(h->ntiles) : -1;
+    const int logg = ch == 0 && h->ch0_offsets ? multi_logg(h->ntiles) : -1;
     return CdfLevels{h->cdf[ch], h->t16[ch], h->t256[ch], h->table[ch], k32_of(h->t256[ch], h->ntiles),
                      logg >= 0 ? off16_of(h->t256[ch], h->ntiles) : nullptr, logg >= 0 ? coarse_of(h->t256[ch], h->ntiles) : nullptr, logg};
 }
@@ -701,6 +711,11 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         return fail(h, GPF_ERR_STATE, "sharded filters resample through the shard-level API (sharded.py)");
     const bool sorted = method == GPF_RESAMPLE_STRATIFIED && sort_particles;
     const bool need_sync = check == GPF_CHECK_TRUE || invalid != nullptr;
+    // only the multinomial search reads the offset levels: the scans of this call write them for it alone
+    const bool need_off = method == GPF_RESAMPLE_MULTINOMIAL && multi_logg(h->ntiles) >= 0;
+    struct OffScope { gpf_filter* h; ~OffScope() { h->want_offsets = true; } } off_scope{h};
+    h->want_offsets = need_off;
+    h->offsets_hint = need_off;
     gpf_status s;
     if ((s = check_scan_timeout(h))) return s;                   // an earlier scan gave up: do not build on its CDF
     if ((s = materialize(h))) return s;                          // two resamples in a row: finish the first one
@@ -713,12 +728,13 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     bool published = false;                                      // the scan of THIS call publishes the flags to pinned memory
     if (pv.mode == 0) {
         ws = &h->sc->raw;
-        if (!h->raw_valid || sorted) {
+        if (!h->raw_valid || sorted || (need_off && !h->ch0_offsets)) {
             if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, true, false, need_sync))) return s;
             published = need_sync;
         }
     } else {
         if ((s = ensure_raw(h))) return s;                       // raw summary (cdf[0] is overwritten next; only S, m matter)
+        h->want_offsets = need_off;
         ws = &h->sc->prio;
         if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, false, false, need_sync))) return s;
         published = need_sync;
@@ -2130,7 +2146,10 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
         if (bounds[me] != h->cfg.gid0 || bounds[me + 1] != h->cfg.gid0 + n)
             return fail(h, GPF_ERR_STATE, "this shard's (gid0, n_particles) is not rank's contiguous share of n_global");
     }
-    if ((s = shard_summary(h, 0))) return s;                      // phases 1, 2
+    h->want_offsets = method == GPF_RESAMPLE_MULTINOMIAL;         // (the offset levels serve k_push_multi only)
+    s = shard_summary(h, 0);                                      // phases 1, 2
+    h->want_offsets = true;
+    if (s) return s;
     if (check != GPF_CHECK_FALSE || invalid) {                    // safe_softmax validity (utils.jl:117-140): pinned flags, no stream sync
         int32_t flags = 0;
         if ((s = gpf_shard_flags(h, &flags))) return s;
