@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_PER_GPU = 1_000_000
-AUX_STEPS = 30             # steps of the stand-alone gather leg and of the cpu_baseline sample
+AUX_STEPS = 30             # steps of the stand-alone gather leg
+CPU_STEPS = 80             # steps of the cpu_baseline sample: ~13 s on one host core at N = 1e6 (a bounded sample of the same workload)
 SEED = 1
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -81,7 +82,7 @@ def main():
     K, Wm = args.steps, args.warmup
     # every leg below indexes observations by its own loop counter: never fewer rows than any leg touches
     # (the gather and cpu_baseline legs run a fixed 30 steps whatever --steps says)
-    n_obs = max(K + Wm + 3, AUX_STEPS + 2)       # (+2: the guarded first steps of the sharded engine)
+    n_obs = max(K + Wm + 3, AUX_STEPS + 2, CPU_STEPS + 2)       # (+2: the guarded first steps of the sharded engine)
     ys = g.models.simulate(model, n_obs)
     n_local = args.particles_per_gpu
     n_global = n_local * world
@@ -289,7 +290,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as o          # cpu_baseline leg: the only place bench.py touches oracle/
         o.lib()
-        n_cpu, k_cpu = n_local, AUX_STEPS
+        n_cpu, k_cpu = n_local, CPU_STEPS
         orc = o.OracleFilter(model.model_id, model.params, n_cpu, SEED).initialize(ys[0])
         c0 = time.perf_counter()
         for s in range(1, k_cpu + 1):
