@@ -1874,7 +1874,10 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
         h->push_counted = true;
         return GPF_OK;
     }
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.nchunks, (int64_t)h->n_cu * 8));
+#ifndef PUSH_SCAN_BLOCKS_PER_CU
+#define PUSH_SCAN_BLOCKS_PER_CU 8
+#endif
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.nchunks, (int64_t)h->n_cu * PUSH_SCAN_BLOCKS_PER_CU));
     s = timed(h, GPF_K_SEARCH, [&] {
         if (method == GPF_RESAMPLE_MULTINOMIAL) GPF_LAUNCH((k_push_scan<0>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a);
         else                                    GPF_LAUNCH((k_push_scan<1>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a);
