@@ -270,16 +270,18 @@ def test_no_device_memory_leak_over_handle_lifetimes(g):
         sh.local.close()
 
     import gc
-    for _ in range(3):
-        cycle()
-    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()      # torch's own cache is not the library's
-    free0, _ = torch.cuda.mem_get_info()
-    for _ in range(25):
-        cycle()
-    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
-    free1, _ = torch.cuda.mem_get_info()
-    # (one leaked particle buffer per lifetime would be >= 25 x 1.6 MB x several; the runtime's own pools move by tens of MiB)
-    assert free0 - free1 < 256 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 lifetimes"
+
+    def free_after(k):
+        for _ in range(k):
+            cycle()
+        gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()      # torch's own cache is not the library's
+        return torch.cuda.mem_get_info()[0]
+
+    free_after(3)
+    free0 = free_after(12)              # the HIP runtime's own pools have settled by now
+    free1 = free_after(25)
+    # a leak grows with the number of lifetimes (one 200 000-particle column per lifetime = 40 MB here); pools do not
+    assert free0 - free1 < 32 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 lifetimes"
 
 
 def test_mean_var_functional_forms(g, o):
