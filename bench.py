@@ -147,12 +147,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the host loop is Python: a generation-2 garbage collection (tens of ms, once per ~1000 sharded steps) would be
+    # charged to the filter.  Like timeit, keep the collector out of the timed region (objects made so far are frozen).
+    # Done BEFORE the warm-up: the collection itself idles the GPU for tens of ms, long enough for its clocks to drop -- with
+    # it between warm-up and timed loop a 20-step run paid ~100 us of ramp-up (5 us per step).
+    gc.collect(); gc.freeze(); gc.disable()
     t = t_first
     for _ in range(Wm):
         step(t); t += 1
-    # the host loop is Python: a generation-2 garbage collection (tens of ms, once per ~1000 sharded steps) would be
-    # charged to the filter.  Like timeit, keep the collector out of the timed region (objects made so far are frozen).
-    gc.collect(); gc.freeze(); gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(K):
