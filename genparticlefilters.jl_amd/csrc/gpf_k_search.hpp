@@ -467,10 +467,25 @@ __device__ __forceinline__ void multi_lookup(const MultiTable& tb, const CdfLeve
         amb = amb || k == t[u] || (k < t[u] && pos[u] < tb.ng && tb.keys[kpad(pos[u])] == t[u]);
     }
     if (__any(amb)) {
-        // equal keys: the exact prefix decides (rare: one key value in 2^32 S / (2^30 groups) per slot)
+        // equal keys: the exact prefixes decide (rare: one key value in 2^32 S / (2^30 groups) per slot).  The run of groups that
+        // share the key can be LONG -- all the mass on one particle leaves tens of thousands of groups with key 0 before it --
+        // so it is bisected: its end from the key table (number of keys <= t), then the first group of the run whose exact end
+        // prefix exceeds T.  (A linear walk cost 12.7 ms per launch on such weights.)
 #pragma unroll
-        for (int u = 0; u < NS; ++u)
-            while (pos[u] < tb.ng && tb.keys[kpad(pos[u])] == t[u] && w.cdf[(int64_t)pos[u] * G + (G - 1)] <= T[u]) ++pos[u];
+        for (int u = 0; u < NS; ++u) {
+            if (!(pos[u] < tb.ng && tb.keys[kpad(pos[u])] == t[u])) continue;
+            uint32_t lo = pos[u], hi = tb.ng;                           // keys[lo] == t; find the first index with key > t
+            {
+                uint32_t a = lo + 1, b = tb.ng;
+                while (a < b) { const uint32_t mid = (a + b) >> 1; if (tb.keys[kpad(mid)] <= t[u]) a = mid + 1; else b = mid; }
+                hi = a;
+            }
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (w.cdf[(int64_t)mid * G + (G - 1)] <= T[u]) lo = mid + 1; else hi = mid;
+            }
+            pos[u] = lo;
+        }
     }
     multi_inside<LOGG, NS>([&](uint32_t i) { return tb.keys[kpad(i)]; }, tb.ng, w, n_cells, T, pos, idx);
 }

@@ -187,3 +187,29 @@ def test_config5_lml_estimator_spread_gpu_equals_cpu(g, o):
     print(f"log-ML std: N=2e4 {small_gpu.std(ddof=1):.4f} (GPU == CPU), N=2e6 {big.std(ddof=1):.4f}, ratio {ratio:.1f}")
     assert 3.0 < ratio < 35.0                           # sqrt(100) = 10 within the noise of a dozen seeds
     assert abs(big.mean() - small_gpu.mean()) < 4 * small_gpu.std(ddof=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+def test_search_time_does_not_depend_on_how_the_weights_are_spread(g, method):
+    """weight collapse is what particle filters resample FOR: all the mass on one particle, on 1 % of them, and the ESS-collapsed
+    weights of a long run must cost about what well-spread weights cost.  (The key-table search once walked linearly through
+    the tens of thousands of equal keys in front of a single heavy particle: 12.7 ms per launch instead of 19 us.)"""
+    N = 1_000_000
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    i = np.arange(N, dtype=np.float64)
+    cases = {"one particle": np.where(i == 777_777, 0.0, -800.0), "1 % of the particles": np.where(i % 100 == 0, 0.0, -60.0),
+             "spread": -0.5 * ((i % 1000) / 300.0) ** 2}
+    kw = {"sort_particles": False} if method == "stratified" else {}
+    for name, lw in cases.items():
+        st = g.pf_initialize(model, (1,), ys[0], N, seed=1)
+        st.kernel_timing(g._lib.K_SEARCH, True)
+        for _ in range(4):
+            st.log_weights = lw
+            g.pf_resample(st, method, check=False, **kw)
+        st.synchronize()
+        ms, cnt = st.kernel_time(g._lib.K_SEARCH)
+        if name == "one particle":
+            assert np.all(st.parents == 777_778)                       # 1-based
+        st.close()
+        assert ms / cnt < 0.5, f"{method}, {name}: {ms / cnt * 1e3:.1f} us per search"      # 0.5 ms: 25x the usual time, 25x below the bug
