@@ -61,7 +61,7 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ pmax, c
 // order: the grid is sized to be fully resident and block b owns tiles b, b+G, b+2G, ...  Spins are
 // bounded (Scalars::timeout).  Descriptor buffers are double-buffered per scan channel: a launch polls
 // buffer `dcur` and zeroes `dnext` for the following launch, so no memset node is needed.
-constexpr uint64_t DESC_VALID = 1ull << 63, DESC_MASK = (1ull << 62) - 1;
+constexpr uint64_t DESC_VALID = 1ull << 63, DESC_MASK = (1ull << 63) - 1;   // (a prefix can be 2^62 itself: N a power of two, all weights at the maximum)
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 __device__ __forceinline__ void desc_store(uint64_t* p, uint64_t v)
@@ -163,7 +163,11 @@ struct ScanOut {
     uint16_t* coarse;          // [ntiles*2048 / CS] the offsets of cells CS-1 (mod CS), CS = G / 8: one 16-byte row per key group
     int logg;
 };
-constexpr int KEY_SHIFT = 30;  // S < 2^62, so (prefix >> 30) fits 32 bits whatever N is
+constexpr int KEY_SHIFT = 30;  // S <= 2^62: (prefix >> 30) fits 32 bits whatever N is, once the one value 2^62 is saturated
+// S = 2^62 exactly when N >= 1024 is a power of two and EVERY weight equals the maximum (a second resample right after a
+// resample: all log-weights 0).  For the keys and the 16-bit offsets such a prefix counts as 2^62 - 1: the maps stay monotone, no
+// target (T < S) can lie between the two values, and equal keys / offsets are decided by the exact prefixes anyway.
+__device__ __forceinline__ uint64_t key_sat(uint64_t prefix) { return prefix < (1ull << 62) ? prefix : (1ull << 62) - 1; }
 // A key group spans the prefixes [klo << 30, (khi + 1) << 30) (klo / khi: the 4-byte keys at its two ends).  Inside it a
 // prefix -- and a target -- is quantised to 16 bits by ONE shift: x -> (x - (klo << 30)) >> sh, sh = 14 + ceil(log2(khi - klo + 1)).
 // The map is monotone and the SAME on the producer (scan) and consumer (search) side, so
@@ -284,18 +288,18 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
                 const uint64_t v1 = off + p[2 * k + 1];
                 *reinterpret_cast<ulonglong2*>(out.cdf + idx) = make_ulonglong2(off + p[2 * k], v1);
                 if ((lane & 7) == 7) out.t16[(idx + 1) >> 4] = v1;                     // element idx+1 = 15 (mod 16)
-                if ((lane & 15) == 15) out.k32[(idx + 1) >> 5] = (uint32_t)(v1 >> KEY_SHIFT);   // ... = 31 (mod 32)
+                if ((lane & 15) == 15) out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(v1) >> KEY_SHIFT);   // ... = 31 (mod 32)
                 if (lane == WAVE - 1 && (k & 1)) out.t256[(idx + 1) >> 8] = v1;         // ... = 255 (mod 256)
                 if (out.off16) {                                                        // kernel-uniform
                     // 16-bit offsets inside the key group (16 << logg lanes of this row): klo = key of the previous group
                     const int GL = 16 << out.logg;
-                    const uint32_t kv = (uint32_t)(v1 >> KEY_SHIFT);
+                    const uint32_t kv = (uint32_t)(key_sat(v1) >> KEY_SHIFT);
                     const uint32_t khi = (uint32_t)__shfl((int)kv, lane | (GL - 1), WAVE);
                     const uint32_t kprev = (uint32_t)__shfl((int)kv, ((lane & ~(GL - 1)) - 1) & (WAVE - 1), WAVE);
-                    const uint32_t klo = lane < GL ? (uint32_t)((off + cb[k]) >> KEY_SHIFT) : kprev;
+                    const uint32_t klo = lane < GL ? (uint32_t)(key_sat(off + cb[k]) >> KEY_SHIFT) : kprev;
                     const int sh = key_quant_shift(klo, khi);
                     const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
-                    const uint32_t o0 = (uint32_t)((off + p[2 * k] - kb) >> sh), o1 = (uint32_t)((v1 - kb) >> sh);
+                    const uint32_t o0 = (uint32_t)((key_sat(off + p[2 * k]) - kb) >> sh), o1 = (uint32_t)((key_sat(v1) - kb) >> sh);
                     reinterpret_cast<uint32_t*>(out.off16)[idx >> 1] = o0 | (o1 << 16);
                     // the coarse row: offsets of the cells CS-1 (mod CS), CS = 4 << logg, two per 4-byte store
                     if (out.logg == 0) {
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_residual2(const uint64_t* __rest
             *reinterpret_cast<ulonglong2*>(A.out.cdf + idx) = make_ulonglong2(offa + pa[2 * k], va);
             *reinterpret_cast<ulonglong2*>(B.out.cdf + idx) = make_ulonglong2(offb + pb[2 * k], vb);
             if ((lane & 7) == 7) { A.out.t16[(idx + 1) >> 4] = va; B.out.t16[(idx + 1) >> 4] = vb; }
-            if ((lane & 15) == 15) { A.out.k32[(idx + 1) >> 5] = (uint32_t)(va >> KEY_SHIFT); B.out.k32[(idx + 1) >> 5] = (uint32_t)(vb >> KEY_SHIFT); }
+            if ((lane & 15) == 15) { A.out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(va) >> KEY_SHIFT); B.out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(vb) >> KEY_SHIFT); }
             if (lane == WAVE - 1 && (k & 1)) { A.out.t256[(idx + 1) >> 8] = va; B.out.t256[(idx + 1) >> 8] = vb; }
         }
         if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) { *A.total_out = offa + pa[2 * SCAN_ROWS - 1]; *B.total_out = offb + pb[2 * SCAN_ROWS - 1]; }

@@ -8,6 +8,7 @@ namespace gpf {
 // draws a target in GLOBAL fixed-point coordinates, the shard that owns that CDF cell looks the ancestor
 // up and returns the row.  Integer arithmetic makes the ancestors independent of the number of shards.
 constexpr int64_t SPACE_COUNTS = (int64_t)1 << 62;   // residual: target lives in the copy-count CDF
+constexpr uint64_t STAGE_T_MASK = (1ull << 62) - 1;  // a staged target (T_local < S_local <= 2^62) below its space bit
 
 __global__ void k_pack_mflags(const double* __restrict__ pmax, const int32_t* __restrict__ pflags, int np, double* out2)
 {
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
             while (g < a.G - 1 && ee >= s_off[g + 1]) ++g;
             const ulonglong2 q = a.stage[s_bnd[g] + (ee - s_off[g])];
             const bool incounts = (q.x >> 62) != 0;
-            T[u] = q.x & DESC_MASK;
+            T[u] = q.x & STAGE_T_MASK;
             slot[u] = q.y;
             top[u] = incounts ? st.topc : st.topw;
             L[u] = incounts ? &lc_ : &lw_;
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels 
             int g = 0;
             while (g < a.G - 1 && ee >= s_off[g + 1]) ++g;
             const ulonglong2 q = a.stage[s_bnd[g] + (ee - s_off[g])];
-            T[u] = q.x & DESC_MASK;
+            T[u] = q.x & STAGE_T_MASK;
             slot[u] = (uint32_t)q.y;
         }
         uint32_t idx[NE];

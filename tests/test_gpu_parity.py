@@ -297,3 +297,21 @@ def test_mean_var_functional_forms(g, o):
                                np.sum(w * np.where(X[:, 1] > 0, X[:, 1] ** 2, 0.0)), rtol=1e-12)
     fv = np.hypot(X[:, 0], X[:, 1]); mu = np.sum(w * fv)
     np.testing.assert_allclose(g.var(np.hypot, st, 0, 1), np.sum(w * (fv - mu) ** 2), rtol=1e-10)
+
+
+@pytest.mark.parametrize("N", [1024, 2048, 4096, 65536, 1 << 20])
+def test_all_weights_equal_power_of_two(g, o, N):
+    """S = N 2^K = 2^62 EXACTLY when N >= 1024 is a power of two and every weight equals the maximum -- e.g. a second resample right
+    after a resample (all log-weights 0).  The 4-byte keys (prefix >> 30) and the descriptor words must cope with that one
+    value (found by tests/test_gpu_fuzz.py: the last key overflowed to 0 and every slot got the same ancestor)."""
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=44)
+    orc = o.OracleFilter(model.model_id, model.params, N, 44).initialize(ys[0])
+    for method, kw in (("multinomial", {}), ("multinomial", {}), ("residual", {}), ("stratified", {"sort_particles": True}),
+                       ("stratified", {"sort_particles": False}), ("multinomial", {})):
+        g.pf_resample(st, method, check=False, **kw); orc.resample(method, check=False, **kw)
+        assert np.array_equal(st.parents, orc.parents), (method, kw)
+        assert g.get_ess(st) == orc.effective_sample_size() == N
+    g.pf_update(st, (2,), (None,), ys[1]); orc.update(ys[1])
+    assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw)
+    st.close()

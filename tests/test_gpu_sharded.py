@@ -62,6 +62,22 @@ def test_world1_sharded_equals_unsharded(g, o):
     assert sharded.get_lml_est(a) == g.get_lml_est(b) and sharded.get_ess(a) == g.get_ess(b)
 
 
+@pytest.mark.parametrize("N", [1024, 4096, 1 << 17])
+def test_world1_uniform_weights_power_of_two(g, o, N):
+    """S = 2^62 exactly (all weights equal, N a power of two): the staged targets, the key table and the descriptors of the
+    sharded path against the unsharded one"""
+    from gpf_amd import sharded
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    a = sharded.pf_initialize(model, (1,), ys[0], N, seed=5)
+    b = g.pf_initialize(model, (1,), ys[0], N, seed=5)
+    for method in ("multinomial", "multinomial", "stratified", "residual", "multinomial"):
+        sharded.pf_resample(a, method, check=False)
+        g.pf_resample(b, method, check=False, **({"sort_particles": False} if method == "stratified" else {}))
+        assert np.array_equal(a.local.parents, b.parents), method
+    sharded.pf_update(a, (2,), (None,), ys[1]); g.pf_update(b, (2,), (None,), ys[1])
+    assert np.array_equal(a.local.traces, b.traces) and np.array_equal(a.local.log_weights, b.log_weights)
+
+
 def test_hip_push_overflow_path(g, o, tmp_path, monkeypatch):
     """send buffer smaller than the exchange: the kernel stops at the capacity, the host repeats the push at the right size"""
     monkeypatch.setenv("GPF_PUSH_CAPACITY", "1000")
