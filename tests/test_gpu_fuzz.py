@@ -3,6 +3,7 @@ resamples of every kind, rejuvenation, getters that force the deferred gather, s
 parents stay bit-identical and the scalar getters equal.  (The deferred gather / deferred constant / cached summaries / live views
 are a state machine; this walks it at random.)"""
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -12,12 +13,33 @@ N_SEEDS = int(os.environ.get("GPF_FUZZ_SEEDS", "12"))           # GPF_FUZZ_SEEDS
 METHODS = ["multinomial", "residual", "stratified"]
 
 
+def same(a, b):
+    return a == b or (np.isnan(a) and np.isnan(b))
+
+
+def both(dev, orc, tag):
+    """run the device call and the oracle call; both raise "Invalid weights" or neither does.  True: both raised"""
+    err = []
+    for f in (dev, orc):
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                f()
+            err.append(None)
+        except Exception as e:                                          # noqa: BLE001
+            err.append(str(e))
+    assert (err[0] is None) == (err[1] is None), (err, tag)
+    if err[0] is not None:
+        assert "Invalid weights" in err[0] and "Invalid weights" in err[1], (err, tag)
+    return err[0] is not None
+
+
 def check(g, st, orc, tag):
     assert np.array_equal(st.traces, orc.rows), tag
-    assert np.array_equal(st.log_weights, orc.lw), tag
+    assert np.array_equal(st.log_weights, orc.lw, equal_nan=True), tag
     assert np.array_equal(st.parents, orc.parents), tag
-    assert g.get_ess(st) == orc.effective_sample_size() or (np.isnan(g.get_ess(st)) and np.isnan(orc.effective_sample_size())), tag
-    assert g.get_lml_est(st) == orc.log_ml_estimate(), tag
+    assert same(g.get_ess(st), orc.effective_sample_size()), tag
+    assert same(g.get_lml_est(st), orc.log_ml_estimate()), tag
 
 
 @pytest.mark.parametrize("seed", range(N_SEEDS))
@@ -33,21 +55,33 @@ def test_random_api_sequences(g, o, seed):
     t = 1
     log = []
     for step in range(T):
-        op = rng.choice(["update", "resample", "rejuvenate", "getters", "view", "whole_view", "resize", "nothing"],
-                        p=[0.25, 0.22, 0.12, 0.1, 0.12, 0.07, 0.07, 0.05])
+        op = rng.choice(["update", "resample", "rejuvenate", "getters", "view", "whole_view", "resize", "set_weights"],
+                        p=[0.25, 0.22, 0.12, 0.08, 0.12, 0.07, 0.07, 0.07])
         n = st.n_particles
         if op == "update":
             g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t]); t += 1
         elif op == "resample":
             m = str(rng.choice(METHODS)); alpha = None if rng.random() < 0.7 else 0.5
             kw = {"sort_particles": bool(rng.random() < 0.5)} if m == "stratified" else {}
-            g.pf_resample(st, m, priority_fn=None if alpha is None else g.Tempering(alpha), check=False, **kw)
-            orc.resample(m, priority_alpha=alpha, check=False, **kw)
+            # check = :warn, so that NaN weights (-inf weights under a priority: lw - lp = NaN) raise on both sides
+            if both(lambda: g.pf_resample(st, m, priority_fn=None if alpha is None else g.Tempering(alpha), check="warn", **kw),
+                    lambda: orc.resample(m, priority_alpha=alpha, check="warn", **kw), log[-4:]):
+                st.close()
+                return                                                  # error("Invalid weights."): the run ends, as a host's would
             op = f"resample {m} {alpha} {kw}"
         elif op == "rejuvenate":
             meth = str(rng.choice(["move", "reweight"])); it = int(rng.integers(1, 3))
             g.pf_rejuvenate(st, g.mh if meth == "move" else g.move_reweight, (), it, method=meth); orc.rejuvenate(meth, it)
             op = f"rejuvenate {meth} {it}"
+        elif op == "set_weights":
+            # ParticleFilterState(trs, ws): weights no filter step would produce -- equal, collapsed, with zeros, far apart
+            kind = str(rng.choice(["equal", "one heavy", "some -inf", "wide", "two values", "all -inf"]))
+            i = np.arange(n, dtype=np.float64)
+            lw = {"equal": np.full(n, -3.25), "one heavy": np.where(i == int(rng.integers(n)), 0.0, -745.0),
+                  "some -inf": np.where(rng.random(n) < 0.7, -np.inf, -rng.random(n)), "wide": -700.0 * rng.random(n),
+                  "two values": np.where(i % 3 == 0, -1.0, -1.0 - 2.0 ** -40), "all -inf": np.full(n, -np.inf)}[kind]
+            st.log_weights = lw; orc.lw = lw.copy()
+            op = f"set_weights {kind}"
         elif op == "getters":
             np.testing.assert_allclose(g.mean(st, 0), orc.mean(0), rtol=1e-9, atol=1e-12)
             np.testing.assert_allclose(g.var(st, 0), orc.var(0), rtol=1e-9, atol=1e-12)
@@ -61,11 +95,13 @@ def test_random_api_sequences(g, o, seed):
                 g.pf_update(sv, (t + 1,), (None,), ys[t]); ov.update(ys[t])          # (only the view's particles advance)
             elif sub == "resample":
                 m = str(rng.choice(METHODS)); kw = {"sort_particles": bool(rng.random() < 0.5)} if m == "stratified" else {}
-                g.pf_resample(sv, m, check=False, **kw); ov.resample(m, check=False, **kw)
+                if both(lambda: g.pf_resample(sv, m, check="warn", **kw), lambda: ov.resample(m, check="warn", **kw), log[-4:]):
+                    st.close()
+                    return
                 assert np.array_equal(sv.parents, ov.parents)
             else:
                 g.pf_rejuvenate(sv, g.mh, (), 1); ov.rejuvenate("move", 1)
-            assert g.get_ess(sv) == ov.effective_sample_size() and g.get_lml_est(sv) == ov.log_ml_estimate()
+            assert same(g.get_ess(sv), ov.effective_sample_size()) and same(g.get_lml_est(sv), ov.log_ml_estimate())
             op = f"{op}[{a}:{b}] {sub}"
         elif op == "resize":
             kind = rng.choice(["multinomial", "residual", "optimal", "replicate"])
@@ -78,9 +114,12 @@ def test_random_api_sequences(g, o, seed):
                 n_new = max(8, int(n * rng.choice([0.5, 1.0, 1.5])))
                 if kind == "optimal":
                     n_new = min(n_new, n)
-                    g.pf_resize(st, n_new, "optimal", check=False); orc.optimal_resize(n_new, check=False)
+                    bad = both(lambda: g.pf_resize(st, n_new, "optimal", check="warn"), lambda: orc.optimal_resize(n_new, check="warn"), log[-4:])
                 else:
-                    g.pf_resize(st, n_new, str(kind), check=False); orc.resize(n_new, str(kind), check=False)
+                    bad = both(lambda: g.pf_resize(st, n_new, str(kind), check="warn"), lambda: orc.resize(n_new, str(kind), check="warn"), log[-4:])
+                if bad:
+                    st.close()
+                    return
             op = f"resize {kind}"
         log.append(op)
         check(g, st, orc, f"seed {seed} {name} N={N} after {log[-6:]}")
