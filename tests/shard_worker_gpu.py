@@ -100,3 +100,51 @@ def run_local(rank, world, port, method, n_global, out_dir):
                  n=st.n_local, lml=np.array(lml), ess=sharded.get_ess(st))
     finally:
         dist.destroy_process_group()
+
+
+def fuzz_ops(seed, T):
+    """the operation list of one sharded fuzz run (the same on every rank and in the parent's oracle run)"""
+    rng = np.random.default_rng(7000 + seed)
+    ops = []
+    for _ in range(T):
+        op = str(rng.choice(["update", "resample", "rejuvenate", "getters", "local", "set_weights"], p=[0.3, 0.3, 0.1, 0.1, 0.1, 0.1]))
+        ops.append((op, str(rng.choice(["multinomial", "stratified", "residual"])), str(rng.choice(["equal", "one heavy", "some -inf", "wide"])),
+                    int(rng.integers(1 << 30))))
+    return ops
+
+
+def fuzz_weights(kind, n_global, salt):
+    r = np.random.default_rng(salt)
+    i = np.arange(n_global, dtype=np.float64)
+    return {"equal": np.full(n_global, -3.25), "one heavy": np.where(i == salt % n_global, 0.0, -745.0),
+            "some -inf": np.where(r.random(n_global) < 0.7, -np.inf, -r.random(n_global)), "wide": -700.0 * r.random(n_global)}[kind]
+
+
+def run_fuzz(rank, world, port, seed, n_global, T, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import gpf_amd as g
+    from gpf_amd import sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = g.models.bearings4(); ys = g.models.simulate(model, T + 2)
+        st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, keep_prev=True, device=0)
+        t, scal = 1, []
+        for op, method, kind, salt in fuzz_ops(seed, T):
+            if op == "update":
+                sharded.pf_update(st, (t + 1,), (None,), ys[t]); t += 1
+            elif op == "resample":
+                sharded.pf_resample(st, method, check=False)
+            elif op == "rejuvenate":
+                sharded.pf_rejuvenate(st, None, (), 1, method="move")
+            elif op == "getters":
+                scal.append((sharded.get_ess(st), sharded.get_lml_est(st)))
+            elif op == "local":
+                sharded.pf_resample(st, method, check=False, local=True, sort_particles=bool(salt & 1))
+            else:
+                st.local.log_weights = fuzz_weights(kind, n_global, salt)[st.gid0:st.gid0 + st.n_local]
+        loc = st.local
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents, n=st.n_local,
+                 scal=np.array(scal, dtype=np.float64).reshape(-1, 2), lml=sharded.get_lml_est(st))
+    finally:
+        dist.destroy_process_group()

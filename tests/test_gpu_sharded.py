@@ -172,3 +172,47 @@ def test_hip_sharded_validity_checks(g, o, tmp_path):
         assert bool(p["true_raised"]) and bool(p["warned"]) and bool(p["nan_raised"])
     assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
     assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
+
+
+@pytest.mark.parametrize("engine", ["library", "python"])
+@pytest.mark.parametrize("seed,world,n_global", [(s_, 2 + s_ % 2, [6000, 6001, 40_000, 2048, 1024, 9999][s_ % 6])
+                                                 for s_ in range(int(os.environ.get("GPF_FUZZ_SHARD_SEEDS", "4")))])
+def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib, seed, world, n_global, engine):
+    """random sequences of updates, global resamples (all three), rejuvenation, global getters, island resamples and adversarial
+    weight vectors on a sharded filter (2 - 3 ranks on one GPU; library engine over the loopback transport / python engine over
+    gloo) against ONE oracle filter: the global resample is the unsharded one bit for bit, the island resample is the sub-state
+    resample of each shard's range"""
+    if engine == "library":
+        monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    else:
+        monkeypatch.setenv("GPF_SHARD_ENGINE", "python")
+    T = 30
+    mp.spawn(shard_worker_gpu.run_fuzz, args=(world, free_port(), seed, n_global, T, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    model = g.models.bearings4(); ys = g.models.simulate(model, T + 2)
+    f = o.OracleFilter(model.model_id, model.params, n_global, 77, keep_prev=True).initialize(ys[0])
+    bounds = np.concatenate([[0], np.cumsum([int(p["n"]) for p in parts])])
+    t, scal = 1, []
+    for op, method, kind, salt in shard_worker_gpu.fuzz_ops(seed, T):
+        if op == "update":
+            f.update(ys[t]); t += 1
+        elif op == "resample":
+            f.resample(method, check=False, **({"sort_particles": False} if method == "stratified" else {}))
+        elif op == "rejuvenate":
+            f.rejuvenate("move", 1)
+        elif op == "getters":
+            scal.append((f.effective_sample_size(), f.log_ml_estimate()))
+        elif op == "local":
+            epoch = f.epoch
+            for r in range(world):
+                f.epoch = epoch                                  # the shards resample concurrently: same epoch, disjoint global ids
+                f[int(bounds[r]):int(bounds[r + 1])].resample(method, check=False, **({"sort_particles": bool(salt & 1)} if method == "stratified" else {}))
+        else:
+            f.lw = shard_worker_gpu.fuzz_weights(kind, n_global, salt).copy()
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
+    assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw, equal_nan=True)
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
+    ref = np.array(scal, dtype=np.float64).reshape(-1, 2)
+    for p in parts:
+        assert np.array_equal(p["scal"], ref, equal_nan=True)
+        assert float(p["lml"]) == f.log_ml_estimate() or (np.isnan(float(p["lml"])) and np.isnan(f.log_ml_estimate()))
