@@ -47,7 +47,7 @@ def test_random_api_sequences(g, o, seed):
     rng = np.random.default_rng(1000 + seed)
     name = ["lgssm2", "bearings4", "sv1"][seed % 3]
     model = g.models.by_name(name)
-    N = int(rng.choice([37, 1000, 4099, 70_001]))
+    N = int(rng.choice([1, 2, 5, 37, 1000, 4099, 70_001, 300_000], p=[0.05, 0.05, 0.08, 0.2, 0.2, 0.2, 0.17, 0.05]))
     T = 40
     ys = g.models.simulate(model, T + 2)
     st = g.pf_initialize(model, (1,), ys[0], N, seed=seed + 5, keep_prev=True)
