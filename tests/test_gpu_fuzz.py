@@ -59,7 +59,12 @@ def test_random_api_sequences(g, o, seed):
                         p=[0.25, 0.22, 0.12, 0.08, 0.12, 0.07, 0.07, 0.07])
         n = st.n_particles
         if op == "update":
-            g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t]); t += 1
+            if name == "lgssm2" and rng.random() < 0.3:               # the native locally optimal proposal (update.jl:79-96)
+                g.pf_update(st, (t + 1,), (None,), ys[t], g.locally_optimal, ()); orc.update(ys[t], proposal=True)
+                op = "update (proposal)"
+            else:
+                g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
+            t += 1
         elif op == "resample":
             m = str(rng.choice(METHODS)); alpha = None if rng.random() < 0.7 else 0.5
             kw = {"sort_particles": bool(rng.random() < 0.5)} if m == "stratified" else {}
