@@ -213,3 +213,22 @@ def test_search_time_does_not_depend_on_how_the_weights_are_spread(g, method):
             assert np.all(st.parents == 777_778)                       # 1-based
         st.close()
         assert ms / cnt < 0.5, f"{method}, {name}: {ms / cnt * 1e3:.1f} us per search"      # 0.5 ms: 25x the usual time, 25x below the bug
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ntiles,extra", [(612, 0), (612, 1), (1024, 1), (1224, 1), (1225, 5)])
+def test_sizes_where_the_search_changes_its_tables(g, o, ntiles, extra):
+    """the ancestor searches pick their LDS tables by size: 32-cell key groups up to 612 scan tiles (1.25 M particles), 64-cell
+    groups up to 1224 tiles, the per-256 level as top table up to 1024 tiles, tile descriptors beyond; one filter on each side of
+    every boundary, all three resamplers against the oracle"""
+    N = ntiles * 2048 + extra
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=9)
+    orc = o.OracleFilter(model.model_id, model.params, N, 9).initialize(ys[0])
+    for t, (method, kw) in enumerate((("multinomial", {}), ("stratified", {"sort_particles": False}), ("residual", {}))):
+        g.pf_resample(st, method, check=False, **kw); orc.resample(method, check=False, **kw)
+        assert np.array_equal(st.parents, orc.parents), (N, method)
+        if t < 2:
+            g.pf_update(st, (t + 2,), (None,), ys[t + 1]); orc.update(ys[t + 1])
+    assert g.get_lml_est(st) == orc.log_ml_estimate()
+    st.close()
