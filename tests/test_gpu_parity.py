@@ -315,3 +315,24 @@ def test_all_weights_equal_power_of_two(g, o, N):
     g.pf_update(st, (2,), (None,), ys[1]); orc.update(ys[1])
     assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw)
     st.close()
+
+
+def test_three_filters_on_three_streams_nothing_synchronises(g, o):
+    """handles own their streams: three filters stepped in turn with check = false (nothing ever waits) run concurrently on the
+    device -- the inter-workgroup protocols of scan and sort (tickets, bounded waits) must hold with other kernels resident"""
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 20)
+    N, methods = 300_000, ["multinomial", "stratified", "residual"]
+    sts = [g.pf_initialize(model, (1,), ys[0], N, seed=s) for s in (1, 2, 3)]
+    for t in range(1, 16):
+        for k, st in enumerate(sts):
+            m = methods[(t + k) % 3]
+            g.pf_resample(st, m, check=False, **({"sort_particles": bool(t % 2)} if m == "stratified" else {}))
+            g.pf_update(st, (t + 1,), (None,), ys[t])
+    for k, st in enumerate(sts):
+        orc = o.OracleFilter(model.model_id, model.params, N, k + 1).initialize(ys[0])
+        for t in range(1, 16):
+            m = methods[(t + k) % 3]
+            orc.resample(m, check=False, **({"sort_particles": bool(t % 2)} if m == "stratified" else {})); orc.update(ys[t])
+        assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw) and np.array_equal(st.parents, orc.parents)
+        assert g.get_lml_est(st) == orc.log_ml_estimate()
+        st.close()
