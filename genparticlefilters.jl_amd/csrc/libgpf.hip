@@ -1411,6 +1411,9 @@ gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_
     if (!parent || !out) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (parent->parent) return fail(parent, GPF_ERR_STATE, "views of views are not supported");
+    // the trajectory store keeps ONE ancestor map and one set of columns per time step for the whole filter: a sub-state that
+    // resamples or advances only its own particles would leave it describing something else -- refuse instead of going stale
+    if (parent->hist_on) return fail(parent, GPF_ERR_STATE, "a filter with a trajectory store has no sub-state views");
     if (start < 0 || count < 1 || start + count > parent->n) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view range out of bounds");
     gpf_filter* v = new gpf_filter();
     v->cfg = parent->cfg;

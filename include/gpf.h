@@ -194,7 +194,9 @@ gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const do
  * alone and resets the weights to the block's average so its total mass is preserved (src/resample.jl:185-187,205-218);
  * gpf_log_ml_estimate = source.log_ml_est + logsumexp(view) - log n (src/utils.jl:174-178).  RNG counters keep the
  * global particle ids.  Destroy with gpf_destroy; a view becomes stale when the parent is resized or re-initialised.
- * A view of a SHARD handle is allowed: resampling it is the communication-free local ("island") resample of that shard. */
+ * A view of a SHARD handle is allowed: resampling it is the communication-free local ("island") resample of that shard.
+ * A filter with a trajectory store (gpf_history_enable) has no views (GPF_ERR_STATE): the store keeps one ancestor map and one
+ * set of columns per time step for the WHOLE filter. */
 gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_handle* out);
 
 /* ---- resize family (src/resize.jl) --------------------------------------------------

@@ -50,14 +50,20 @@ def test_random_api_sequences(g, o, seed):
     N = int(rng.choice([1, 2, 5, 37, 1000, 4099, 70_001, 300_000], p=[0.05, 0.05, 0.08, 0.2, 0.2, 0.2, 0.17, 0.05]))
     T = 40
     ys = g.models.simulate(model, T + 2)
-    st = g.pf_initialize(model, (1,), ys[0], N, seed=seed + 5, keep_prev=True)
-    orc = o.OracleFilter(model.model_id, model.params, N, seed + 5, keep_prev=True).initialize(ys[0])
+    hist = seed % 4 == 3                                              # every fourth run keeps the trajectory store
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=seed + 5, keep_prev=True, history=T + 2 if hist else 0)
+    orc = o.OracleFilter(model.model_id, model.params, N, seed + 5, keep_prev=True, history=hist).initialize(ys[0])
     t = 1
     log = []
     for step in range(T):
         op = rng.choice(["update", "resample", "rejuvenate", "getters", "view", "whole_view", "resize", "set_weights"],
                         p=[0.25, 0.22, 0.12, 0.08, 0.12, 0.07, 0.07, 0.07])
         n = st.n_particles
+        if hist and op in ("resize", "view", "whole_view"):
+            if op != "resize":
+                with pytest.raises(g.ErrorException):                   # one ancestor map per step for the whole filter: no sub-states
+                    st[0:max(1, n // 2)]
+            op = "getters"                                              # (nor can such a filter be resized)
         if op == "update":
             if name == "lgssm2" and rng.random() < 0.3:               # the native locally optimal proposal (update.jl:79-96)
                 g.pf_update(st, (t + 1,), (None,), ys[t], g.locally_optimal, ()); orc.update(ys[t], proposal=True)
@@ -88,6 +94,9 @@ def test_random_api_sequences(g, o, seed):
             st.log_weights = lw; orc.lw = lw.copy()
             op = f"set_weights {kind}"
         elif op == "getters":
+            if hist:                                                    # a past choice along the surviving ancestry (README.md:97-104)
+                step_q = int(rng.integers(1, t + 1)); c = int(rng.integers(model.dim))
+                assert np.array_equal(st.history_column(step_q, c), orc.history_column(step_q, c)), (step_q, c, log[-6:])
             np.testing.assert_allclose(g.mean(st, 0), orc.mean(0), rtol=1e-9, atol=1e-12)
             np.testing.assert_allclose(g.var(st, 0), orc.var(0), rtol=1e-9, atol=1e-12)
         elif op in ("view", "whole_view"):

@@ -258,10 +258,10 @@ def test_no_device_memory_leak_over_handle_lifetimes(g):
         g.pf_rejuvenate(st, g.mh, (), 1)
         g.pf_update(st, (2,), (None,), ys[1])
         g.pf_resample(st, "residual", check=False)                                  # residual channels
-        g.pf_update(st[1000:5000], (3,), (None,), ys[2])                            # a view
         g.mean(st, (1, 0)); g.get_ess(st)
         st.close()
         st = g.pf_initialize(model, (1,), ys[0], 200_000, seed=3)
+        g.pf_update(st[1000:5000], (3,), (None,), ys[2])                            # a view
         g.pf_resize(st, 50_000, "optimal", check=False); g.pf_replicate(st, 3); g.sample_unweighted_traces(st, 1000)
         st.close()
         sh = sharded.pf_initialize(model, (1,), ys[0], 200_000, seed=3)             # staging list, counters, pinned mirror, event
