@@ -138,3 +138,59 @@ def test_random_api_sequences(g, o, seed):
         log.append(op)
         check(g, st, orc, f"seed {seed} {name} N={N} after {log[-6:]}")
     st.close()
+
+
+@pytest.mark.parametrize("seed", range(max(4, N_SEEDS // 3)))
+def test_random_api_sequences_discrete_latent_models(g, o, seed):
+    """the same walk on the models with a discrete latent (README's object_motion, the reference tests' line_model): plain and
+    STRATIFIED initialisation / updates (src/initialize.jl:92-109, src/update.jl:193-210; both layouts), every resampler, MH,
+    views"""
+    rng = np.random.default_rng(5000 + seed)
+    name = ["object_motion", "line_model"][seed % 2]
+    model = g.models.by_name(name)
+    N = int(rng.choice([10, 100, 1000, 5001, 40_000]))
+    T = 25
+    if name == "line_model":
+        ys = [g.models.line_obs(0)] + [g.models.line_obs(t, float(rng.integers(-2, 3))) + np.array([rng.normal(), 0.0]) for t in range(1, T + 2)]
+    else:
+        ys = g.models.simulate(model, T + 2)
+    strata0 = [0.0, 1.0] if name == "object_motion" else [-2.0, -1.0, 0.0, 1.0, 2.0]      # moving / slope
+    strata_t = [0.0, 1.0]                                                                 # moving / outlier
+    lay0 = str(rng.choice(["contiguous", "interleaved"]))
+    if rng.random() < 0.5:
+        st = g.pf_initialize(model, (0,), ys[0], strata0, N, seed=seed + 3, keep_prev=True, layout=lay0)
+        orc = o.OracleFilter(model.model_id, model.params, N, seed + 3, keep_prev=True).initialize(ys[0], strata=strata0, layout=lay0)
+    else:
+        st = g.pf_initialize(model, (0,), ys[0], N, seed=seed + 3, keep_prev=True)
+        orc = o.OracleFilter(model.model_id, model.params, N, seed + 3, keep_prev=True).initialize(ys[0])
+    check(g, st, orc, "init")
+    t, log = 1, []
+    for step in range(T):
+        op = str(rng.choice(["update", "update_strata", "resample", "rejuvenate", "view_strata", "getters"], p=[0.25, 0.2, 0.25, 0.12, 0.08, 0.1]))
+        n = st.n_particles
+        if op == "update":
+            g.pf_update(st, (t,), (None,), ys[t]); orc.update(ys[t]); t += 1
+        elif op == "update_strata":
+            lay = str(rng.choice(["contiguous", "interleaved"]))
+            k = [strata_t, [1.0, 0.0, 1.0]][int(rng.integers(2))]
+            g.pf_update(st, (t,), (None,), ys[t], k, layout=lay); orc.update(ys[t], strata=k, layout=lay); t += 1
+            op = f"update_strata {k} {lay}"
+        elif op == "resample":
+            m = str(rng.choice(METHODS)); kw = {"sort_particles": bool(rng.random() < 0.5)} if m == "stratified" else {}
+            if both(lambda: g.pf_resample(st, m, check="warn", **kw), lambda: orc.resample(m, check="warn", **kw), log[-4:]):
+                st.close()
+                return
+            op = f"resample {m} {kw}"
+        elif op == "rejuvenate":
+            g.pf_rejuvenate(st, g.mh, (), 1); orc.rejuvenate("move", 1)
+        elif op == "view_strata":
+            a, b = sorted(int(x) for x in rng.choice(n + 1, 2, replace=False))
+            if b - a < 4:
+                continue
+            g.pf_update(st[a:b], (t,), (None,), ys[t], strata_t, layout="contiguous"); orc[a:b].update(ys[t], strata=strata_t, layout="contiguous")
+            op = f"view_strata[{a}:{b}]"
+        else:
+            np.testing.assert_allclose(g.mean(st, 0), orc.mean(0), rtol=1e-9, atol=1e-12)
+        log.append(op)
+        check(g, st, orc, f"seed {seed} {name} N={N} after {log[-6:]}")
+    st.close()
