@@ -232,3 +232,30 @@ def test_sizes_where_the_search_changes_its_tables(g, o, ntiles, extra):
             g.pf_update(st, (t + 2,), (None,), ys[t + 1]); orc.update(ys[t + 1])
     assert g.get_lml_est(st) == orc.log_ml_estimate()
     st.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["all equal", "one particle", "one particle, rest -inf", "1 % heavy", "ascending ramp", "descending ramp",
+                                  "two values alternating", "first half -inf", "denormal-scale spread", "heavy tail at the end"])
+def test_extreme_weight_vectors_at_full_size(g, o, case):
+    """N = 10^6 (the benchmark size: every search takes its full-size path -- key table with the interpolation window, wide and
+    streaming blocks of the stratified merge, three-plane look-back of the sort) x weight vectors no filter step would produce x
+    every resampler variant, ancestors against the oracle"""
+    N = 1_000_000
+    i = np.arange(N, dtype=np.float64)
+    rng = np.random.default_rng(1)
+    lw = {"all equal": np.zeros(N), "one particle": np.where(i == 777_777, 0.0, -800.0), "one particle, rest -inf": np.where(i == 5, 0.0, -np.inf),
+          "1 % heavy": np.where(i % 100 == 0, 0.0, -60.0), "ascending ramp": i * 1e-5, "descending ramp": -i * 1e-5,
+          "two values alternating": np.where(i % 2 == 0, 0.0, -1e-9), "first half -inf": np.where(i < N / 2, -np.inf, -0.5 * rng.standard_normal(N) ** 2),
+          "denormal-scale spread": -700.0 - 40.0 * rng.random(N), "heavy tail at the end": np.where(i > N - 300, 0.0, -30.0 - 1e-5 * i)}[case]
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 2)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=1)
+    orc = o.OracleFilter(model.model_id, model.params, N, 1).initialize(ys[0])
+    for method, kw, alpha in (("multinomial", {}, None), ("residual", {}, None), ("stratified", {"sort_particles": False}, None),
+                              ("stratified", {"sort_particles": True}, None), ("multinomial", {}, 0.5)):
+        st.log_weights = lw; orc.lw = lw.copy()
+        g.pf_resample(st, method, priority_fn=None if alpha is None else g.Tempering(alpha), check=False, **kw)
+        orc.resample(method, priority_alpha=alpha, check=False, **kw)
+        assert np.array_equal(st.parents, orc.parents), (case, method, kw, alpha)
+        assert np.array_equal(st.log_weights, orc.lw, equal_nan=True), (case, method, kw, alpha)
+    st.close()
