@@ -35,7 +35,7 @@ def both(dev, orc, tag):
 
 
 def check(g, st, orc, tag):
-    assert np.array_equal(st.traces, orc.rows), tag
+    assert np.array_equal(st.traces, orc.rows, equal_nan=True), tag
     assert np.array_equal(st.log_weights, orc.lw, equal_nan=True), tag
     assert np.array_equal(st.parents, orc.parents), tag
     assert same(g.get_ess(st), orc.effective_sample_size()), tag
@@ -68,6 +68,11 @@ def test_random_api_sequences(g, o, seed):
             if name == "lgssm2" and rng.random() < 0.3:               # the native locally optimal proposal (update.jl:79-96)
                 g.pf_update(st, (t + 1,), (None,), ys[t], g.locally_optimal, ()); orc.update(ys[t], proposal=True)
                 op = "update (proposal)"
+            elif rng.random() < 0.1:                                    # an observation far outside anything the model expects
+                with np.errstate(over="ignore"):
+                    y = np.asarray(ys[t], np.float64) * float(rng.choice([1e3, 1e150, 1e308, -1e308]))      # (may overflow to inf: wanted)
+                g.pf_update(st, (t + 1,), (None,), y); orc.update(y)
+                op = "update (extreme observation)"
             else:
                 g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
             t += 1
