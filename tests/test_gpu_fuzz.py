@@ -104,6 +104,14 @@ def test_random_api_sequences(g, o, seed):
                 assert np.array_equal(st.history_column(step_q, c), orc.history_column(step_q, c)), (step_q, c, log[-6:])
             np.testing.assert_allclose(g.mean(st, 0), orc.mean(0), rtol=1e-9, atol=1e-12)
             np.testing.assert_allclose(g.var(st, 0), orc.var(0), rtol=1e-9, atol=1e-12)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                np.testing.assert_allclose(g.get_norm_weights(st), orc.norm_weights(), rtol=1e-12, atol=0, equal_nan=True)
+                np.testing.assert_allclose(g.get_log_norm_weights(st), orc.log_norm_weights(), rtol=1e-12, atol=1e-12, equal_nan=True)
+            out = {}                                                    # Gen.sample_unweighted_traces (utils.jl:189-194)
+            if not both(lambda: out.update(d=g.sample_unweighted_traces(st, 64, return_indices=True)),
+                        lambda: out.update(o=orc.sample_unweighted(64)), log[-4:]):
+                assert np.array_equal(out["d"][1], out["o"][1]) and np.array_equal(out["d"][0], out["o"][0], equal_nan=True)
         elif op in ("view", "whole_view"):
             a, b = (0, n) if op == "whole_view" else sorted(int(x) for x in rng.choice(n + 1, 2, replace=False))
             if b - a < 2:
