@@ -77,11 +77,18 @@ def test_random_api_sequences(g, o, seed):
                 g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
             t += 1
         elif op == "resample":
-            m = str(rng.choice(METHODS)); alpha = None if rng.random() < 0.7 else 0.5
+            m = str(rng.choice(METHODS)); alpha = None if rng.random() < 0.6 else (0.5 if rng.random() < 0.6 else "closure")
             kw = {"sort_particles": bool(rng.random() < 0.5)} if m == "stratified" else {}
+            closure = lambda w: 0.25 * w - 0.125 * np.abs(w) ** 0.5      # an arbitrary priority_fn: evaluated by the host (resample.jl:51-52)
+            if alpha == "closure":
+                dev = lambda: g.pf_resample(st, m, priority_fn=closure, check="warn", **kw)
+                lp = closure(orc.lw)
+                orf = lambda: orc.resample(m, log_priorities=lp, check="warn", **kw)
+            else:
+                dev = lambda: g.pf_resample(st, m, priority_fn=None if alpha is None else g.Tempering(alpha), check="warn", **kw)
+                orf = lambda: orc.resample(m, priority_alpha=alpha, check="warn", **kw)
             # check = :warn, so that NaN weights (-inf weights under a priority: lw - lp = NaN) raise on both sides
-            if both(lambda: g.pf_resample(st, m, priority_fn=None if alpha is None else g.Tempering(alpha), check="warn", **kw),
-                    lambda: orc.resample(m, priority_alpha=alpha, check="warn", **kw), log[-4:]):
+            if both(dev, orf, log[-4:]):
                 st.close()
                 return                                                  # error("Invalid weights."): the run ends, as a host's would
             op = f"resample {m} {alpha} {kw}"
