@@ -140,7 +140,8 @@ def run_fuzz(rank, world, port, seed, n_global, T, out_dir):
             elif op == "getters":
                 scal.append((sharded.get_ess(st), sharded.get_lml_est(st)))
             elif op == "local":
-                sharded.pf_resample(st, method, check=False, local=True, sort_particles=bool(salt & 1))
+                sharded.pf_resample(st, method, check=False, local=True, sort_particles=bool(salt & 1),
+                                    priority_fn=g.Tempering(0.5) if salt & 2 else None)        # (with a priority: through a view of the shard)
             else:
                 st.local.log_weights = fuzz_weights(kind, n_global, salt)[st.gid0:st.gid0 + st.n_local]
         loc = st.local

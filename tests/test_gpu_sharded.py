@@ -206,7 +206,8 @@ def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib,
             epoch = f.epoch
             for r in range(world):
                 f.epoch = epoch                                  # the shards resample concurrently: same epoch, disjoint global ids
-                f[int(bounds[r]):int(bounds[r + 1])].resample(method, check=False, **({"sort_particles": bool(salt & 1)} if method == "stratified" else {}))
+                f[int(bounds[r]):int(bounds[r + 1])].resample(method, check=False, priority_alpha=0.5 if salt & 2 else None,
+                                                              **({"sort_particles": bool(salt & 1)} if method == "stratified" else {}))
         else:
             f.lw = shard_worker_gpu.fuzz_weights(kind, n_global, salt).copy()
     assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
