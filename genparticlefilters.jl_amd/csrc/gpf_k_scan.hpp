@@ -162,6 +162,8 @@ struct ScanOut {
     uint16_t* off16;           // [ntiles*2048] every prefix as a 16-bit offset inside its key group (key_quant)
     uint16_t* coarse;          // [ntiles*2048 / CS] the offsets of cells CS-1 (mod CS), CS = G / 8: one 16-byte row per key group
     int logg;
+    uint32_t* k32s;            // [ntiles*64 >> sample] every (1 << sample)-th key, compact: the LDS table of k_search_multi_s (nullptr: not wanted)
+    int sample;
 };
 constexpr int KEY_SHIFT = 30;  // S <= 2^62: (prefix >> 30) fits 32 bits whatever N is, once the one value 2^62 is saturated
 // S = 2^62 exactly when N >= 1024 is a power of two and EVERY weight equals the maximum (a second resample right after a
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
                 if ((lane & 7) == 7) out.t16[(idx + 1) >> 4] = v1;                     // element idx+1 = 15 (mod 16)
                 if ((lane & 15) == 15) out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(v1) >> KEY_SHIFT);   // ... = 31 (mod 32)
                 if (lane == WAVE - 1 && (k & 1)) out.t256[(idx + 1) >> 8] = v1;         // ... = 255 (mod 256)
+                if (out.k32s && lane == WAVE - 1) out.k32s[(idx + 1) >> 7] = (uint32_t)(key_sat(v1) >> KEY_SHIFT);   // (sample == 2) element idx+1 = 127 (mod 128)
                 if (out.off16) {                                                        // kernel-uniform
                     // 16-bit offsets inside the key group (16 << logg lanes of this row): klo = key of the previous group
                     const int GL = 16 << out.logg;

@@ -12,6 +12,7 @@ struct CdfLevels {
     const uint64_t* cdf;  const uint64_t* t16;  const uint64_t* t256;  const uint64_t* ttile;   // ttile: descriptor words
     const uint32_t* k32;                                                                        // 4-byte keys per 32 cells (ScanOut::k32)
     const uint16_t* off16; const uint16_t* coarse; int logg;                                    // ScanOut::off16 / coarse / logg
+    const uint32_t* k32s; int sample;                                                           // ScanOut::k32s / sample (k_search_multi_s)
 };
 // a pointer rebuilt from an integer is generic (flat_load: also counts on lgkmcnt and serialises behind the LDS
 // reads); the lines live in global memory, so say so
@@ -329,6 +330,18 @@ __host__ inline int multi_logg(int64_t ntiles)
     for (int g = 0; g <= 1; ++g) if (multi_lds_bytes(ntiles, g) <= (size_t)MULTI_LDS_BUDGET) return g;
     return -1;
 }
+// Beyond that (2.5 M particles) the levels stay those of 32-cell key groups and LDS keeps every (1 << s)-th key (ScanOut::k32s,
+// written by the scan): the table search ends at a super-group of 32 << s cells, whose 1 << s keys are one more narrow read
+// (16 bytes for s = 2: up to 5 M particles).  Measured against the two-line search (k_search<0>), multinomial, ns per slot:
+// 3 M 19.8 / 25.6, 4 M 21.5 / 26.3, 5 M 24.1 / 27.5 (s = 2);  6 M 27.4 / 28.4, 8 M 31.0 / 29.9 (s = 3);  16 M 38.9 / 33.5 (s = 4):
+// only s = 2 pays (wider super-groups cost more key reads than the narrow levels save).  0: not in this regime.
+constexpr int MULTI_SAMPLE_MAX = 2;
+__host__ inline int multi_sample(int64_t ntiles)
+{
+    if (multi_logg(ntiles) >= 0) return 0;
+    for (int s = 2; s <= MULTI_SAMPLE_MAX; ++s) if (multi_lds_bytes(ntiles, s) <= (size_t)MULTI_LDS_BUDGET) return s;
+    return 0;
+}
 // number of 16-bit halves of x that are < the halves of qq (qq = q | q << 16), as 0/1 per half; and != qq
 typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
 __device__ __forceinline__ uint32_t pk_lt(uint32_t x, uint32_t qq)
@@ -351,17 +364,32 @@ constexpr uint32_t MULTI_WIN = 512;                // interpolation window of th
 
 // the second half of the lookup: pos[u] = the key group that holds T[u] (number of groups that end at or below it); the
 // target becomes a 16-bit offset inside the group, then two narrow reads.  key(i) = key of group i (LDS table or global level).
+template <int LOGG, int NS>
+__device__ __forceinline__ void multi_inside_k(const uint32_t (&g)[NS], const uint32_t (&klo_)[NS], const uint32_t (&khi_)[NS], const CdfLevels& w,
+                                               int64_t n_cells, const uint64_t (&T)[NS], uint32_t (&idx)[NS]);
 template <int LOGG, int NS, class KeyFn>
 __device__ __forceinline__ void multi_inside(KeyFn&& key, uint32_t ng, const CdfLevels& w, int64_t n_cells, const uint64_t (&T)[NS],
                                              const uint32_t (&pos)[NS], uint32_t (&idx)[NS])
 {
-    constexpr int G = 32 << LOGG, CS = G / 8;
-    uint32_t g[NS], qq[NS], run[NS];
-    uint4 row[NS];
+    uint32_t g[NS], klo[NS], khi[NS];
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
         g[u] = pos[u] < ng ? pos[u] : ng - 1;
-        const uint32_t klo = g[u] ? key(g[u] - 1) : 0u, khi = key(g[u]);
+        klo[u] = g[u] ? key(g[u] - 1) : 0u; khi[u] = key(g[u]);
+    }
+    multi_inside_k<LOGG, NS>(g, klo, khi, w, n_cells, T, idx);
+}
+// ... with the group and the keys at its two ends given (g = key group of 32 << LOGG cells that holds T)
+template <int LOGG, int NS>
+__device__ __forceinline__ void multi_inside_k(const uint32_t (&g)[NS], const uint32_t (&klo_)[NS], const uint32_t (&khi_)[NS], const CdfLevels& w,
+                                               int64_t n_cells, const uint64_t (&T)[NS], uint32_t (&idx)[NS])
+{
+    constexpr int G = 32 << LOGG, CS = G / 8;
+    uint32_t qq[NS], run[NS];
+    uint4 row[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const uint32_t klo = klo_[u], khi = khi_[u];
         const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
         const uint64_t d = T[u] > kb ? T[u] - kb : 0;
         uint32_t q = (uint32_t)(d >> key_quant_shift(klo, khi));
@@ -423,12 +451,13 @@ __device__ __forceinline__ void multi_inside(KeyFn&& key, uint32_t ng, const Cdf
 
 // idx[u] = first cell whose prefix exceeds T[u], for the lane's NS independent targets (wave-collective: the fast paths are
 // taken when every lane of the wave can take them).  Levels as described above; LOGG as in the key table.
-template <int LOGG, int NS>
-__device__ __forceinline__ void multi_lookup(const MultiTable& tb, const CdfLevels& w, int64_t n_cells, const uint64_t (&T)[NS], uint32_t (&idx)[NS])
+// first half: pos[u] = number of table entries (one per G = 32 << GS cells) whose group ends at or below T[u]
+template <int GS, int NS>
+__device__ __forceinline__ void multi_find(const MultiTable& tb, const CdfLevels& w, const uint64_t (&T)[NS], uint32_t (&pos)[NS])
 {
-    constexpr int G = 32 << LOGG, CS = G / 8;
+    constexpr int G = 32 << GS;
     constexpr uint32_t WIN = MULTI_WIN;
-    uint32_t t[NS], pos[NS];
+    uint32_t t[NS];
     // ---- number of keys < t.  Fast path: the CDF of exchangeable weights is close to linear, so a window of WIN keys
     //      around the interpolated position brackets the answer (checked); else the uniform binary search of the whole table
     bool inwin = tb.ng >= 2 * WIN;
@@ -487,6 +516,12 @@ __device__ __forceinline__ void multi_lookup(const MultiTable& tb, const CdfLeve
             pos[u] = lo;
         }
     }
+}
+template <int LOGG, int NS>
+__device__ __forceinline__ void multi_lookup(const MultiTable& tb, const CdfLevels& w, int64_t n_cells, const uint64_t (&T)[NS], uint32_t (&idx)[NS])
+{
+    uint32_t pos[NS];
+    multi_find<LOGG, NS>(tb, w, T, pos);
     multi_inside<LOGG, NS>([&](uint32_t i) { return tb.keys[kpad(i)]; }, tb.ng, w, n_cells, T, pos, idx);
 }
 
@@ -518,6 +553,86 @@ __device__ __forceinline__ MultiTable multi_table_load(const CdfLevels& w, int64
     }
     __syncthreads();
     return tb;
+}
+
+// ---- the sampled regime (multi_sample): table entry = key of a super-group of 32 << SS cells
+template <int SS>
+__device__ __forceinline__ MultiTable multi_table_load_sampled(const CdfLevels& w, int64_t ntiles, uint64_t S, uint32_t* keys)
+{
+    constexpr int KT = (MULTI_LDS_BUDGET / 4 / 4 + SBLOCK - 1) / SBLOCK;
+    MultiTable tb;
+    tb.keys = keys;
+    tb.ng = (uint32_t)multi_groups(ntiles, SS);                         // a multiple of 4 (64 >> SS per tile, SS <= 4)
+    const uint32_t nq = tb.ng / 4;
+    const uint4* src = reinterpret_cast<const uint4*>(w.k32s);
+    uint4 kv[KT];
+#pragma unroll
+    for (int r = 0; r < KT; ++r) { const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK; if (q < nq) kv[r] = src[q]; }
+    tb.p2 = 1;
+    while (2 * tb.p2 <= tb.ng) tb.p2 *= 2;
+    tb.kscale = (float)tb.ng / (float)((S >> KEY_SHIFT) + 1);
+#pragma unroll
+    for (int r = 0; r < KT; ++r) {
+        const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK;
+        if (q < nq) { uint32_t* d = keys + kpad(4 * q); d[0] = kv[r].x; d[1] = kv[r].y; d[2] = kv[r].z; d[3] = kv[r].w; }
+    }
+    __syncthreads();
+    return tb;
+}
+template <int SS, int NS>
+__device__ __forceinline__ void multi_lookup_sampled(const MultiTable& tb, const CdfLevels& w, int64_t n_cells, const uint64_t (&T)[NS], uint32_t (&idx)[NS])
+{
+    constexpr int NK = 1 << SS;                                         // 32-cell key groups per super-group
+    uint32_t pos[NS];
+    multi_find<SS, NS>(tb, w, T, pos);                                  // the super-group (ties on sampled keys: exact prefixes at super-group ends)
+    const uint32_t ng0 = tb.ng << SS;
+    uint32_t g[NS], klo[NS], khi[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const uint32_t sg = pos[u] < tb.ng ? pos[u] : tb.ng - 1;
+        const uint32_t t = (uint32_t)(T[u] >> KEY_SHIFT);
+        uint32_t kk[NK];                                                // the super-group's keys: NK * 4 contiguous bytes
+        const uint4* kp = reinterpret_cast<const uint4*>(w.k32 + ((size_t)sg << SS));
+#pragma unroll
+        for (int q = 0; q < NK / 4; ++q) { const uint4 v = kp[q]; kk[4 * q] = v.x; kk[4 * q + 1] = v.y; kk[4 * q + 2] = v.z; kk[4 * q + 3] = v.w; }
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < NK; ++q) c += (uint32_t)(kk[q] < t);
+        c = c < (uint32_t)NK ? c : (uint32_t)NK - 1;                  // (the super-group holds T: its last group ends above it)
+        const uint32_t base = sg << SS;
+        uint32_t kc = kk[0];                                            // key of group c, from registers
+#pragma unroll
+        for (int q = 1; q < NK; ++q) kc = (uint32_t)q == c ? kk[q] : kc;
+        if (kc == t)                                                    // equal keys: the exact prefixes decide (rare; at most NK - 1 steps)
+            while (c < (uint32_t)NK - 1 && w.k32[base + c] == t && w.cdf[(int64_t)(base + c) * 32 + 31] <= T[u]) ++c;
+        g[u] = base + c < ng0 ? base + c : ng0 - 1;
+        uint32_t lo = sg ? tb.keys[kpad(sg - 1)] : 0u, hi = kk[0];       // keys at the two ends of group base + c, picked from registers
+#pragma unroll
+        for (int q = 1; q < NK; ++q) { lo = (uint32_t)q == c ? kk[q - 1] : lo; hi = (uint32_t)q == c ? kk[q] : hi; }
+        klo[u] = lo; khi[u] = hi;
+    }
+    multi_inside_k<0, NS>(g, klo, khi, w, n_cells, T, idx);
+}
+template <int SS>
+__global__ __launch_bounds__(SBLOCK, 4) void k_search_multi_s(SearchArgs a)
+{
+    constexpr int NS = 2;                                               // (the super-group keys cost registers)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (a.update_lml && blockIdx.x == 0 && threadIdx.x == 0) resample_bookkeeping(a);
+    const uint64_t S = a.ws->S;
+    const MultiTable tb = multi_table_load_sampled<SS>(a.w, a.ntiles, S, reinterpret_cast<uint32_t*>(smem));
+    const int64_t stride = (int64_t)gridDim.x * NS * SBLOCK;
+    for (int64_t base = (int64_t)blockIdx.x * NS * SBLOCK; base < a.n; base += stride) {
+        const int64_t j0 = base + NS * (int64_t)threadIdx.x;
+        const uint32_t s0 = (uint32_t)(a.gid0 + j0);
+        const Philox b0 = rng(a.seed, s0 >> 1, 0, a.epoch, TAG_RESAMPLE);
+        const Philox b1 = (s0 & 1u) ? rng(a.seed, (s0 >> 1) + 1u, 0, a.epoch, TAG_RESAMPLE) : b0;          // kernel-uniform
+        uint64_t T[NS] = {mulhi64(resample_pick(b0, s0), S), mulhi64(resample_pick(b1, s0 + 1u), S)};       // resample.jl:59
+        uint32_t idx[NS];
+        multi_lookup_sampled<SS, NS>(tb, a.w, a.n_cells, T, idx);
+        if (j0 < a.n) a.anc[j0] = (int32_t)idx[0];
+        if (j0 + 1 < a.n) a.anc[j0 + 1] = (int32_t)idx[1];
+    }
 }
 
 template <int LOGG>

@@ -151,15 +151,20 @@ constexpr int row_width(int D, bool keep) { return ((keep ? 2 * D : D) + 1) & ~1
 // one buffer per scan channel holds the per-256 level (8 u64 per tile) followed by the 4-byte key level (64 u32 per tile)
 // one buffer per scan channel: the per-256 level (8 u64 per tile), the 4-byte key level (64 u32 per tile), the 16-bit
 // in-group offsets (2048 u16 per tile) and their coarse rows (<= 512 u16 per tile) -- gpf_kernels.hpp ScanOut
-size_t t256_bytes(int64_t ntiles) { return (size_t)ntiles * ((TILE / 256) * sizeof(uint64_t) + (TILE / 32) * sizeof(uint32_t) + TILE * sizeof(uint16_t) + (TILE / 4) * sizeof(uint16_t)); }
+// ... and, beyond 2.5 M particles, the compact copy of every 4th / 8th / 16th key (<= 16 u32 per tile)
+size_t t256_bytes(int64_t ntiles) { return (size_t)ntiles * ((TILE / 256) * sizeof(uint64_t) + (TILE / 32) * sizeof(uint32_t) + TILE * sizeof(uint16_t) + (TILE / 4) * sizeof(uint16_t) + 16 * sizeof(uint32_t)); }
 uint32_t* k32_of(uint64_t* t256, int64_t ntiles) { return reinterpret_cast<uint32_t*>(t256 + ntiles * (TILE / 256)); }
 uint16_t* off16_of(uint64_t* t256, int64_t ntiles) { return reinterpret_cast<uint16_t*>(k32_of(t256, ntiles) + ntiles * (TILE / 32)); }
 uint16_t* coarse_of(uint64_t* t256, int64_t ntiles) { return off16_of(t256, ntiles) + ntiles * TILE; }
+uint32_t* k32s_of(uint64_t* t256, int64_t ntiles) { return reinterpret_cast<uint32_t*>(coarse_of(t256, ntiles) + ntiles * (TILE / 4)); }
 // channel 0 (the weights) carries the offset levels when k_search_multi can take the filter (multi_logg >= 0)
 ScanOut scan_out(uint64_t* cdf, uint64_t* t16, uint64_t* t256, int64_t ntiles, bool with_offsets)
 {
-    const int logg = with_offsets ? multi_logg(ntiles) : -1;
-    return ScanOut{cdf, t16, t256, k32_of(t256, ntiles), logg >= 0 ? off16_of(t256, ntiles) : nullptr, logg >= 0 ? coarse_of(t256, ntiles) : nullptr, logg};
+    int logg = with_offsets ? multi_logg(ntiles) : -1;
+    const int sample = with_offsets && logg < 0 ? multi_sample(ntiles) : 0;       // beyond 2.5 M particles: 32-cell levels + sampled keys
+    if (sample > 0) logg = 0;
+    return ScanOut{cdf, t16, t256, k32_of(t256, ntiles), logg >= 0 ? off16_of(t256, ntiles) : nullptr, logg >= 0 ? coarse_of(t256, ntiles) : nullptr, logg,
+                   sample > 0 ? k32s_of(t256, ntiles) : nullptr, sample};
 }
 
 int grid_for(const gpf_filter* h, int64_t work_items, int blocks_per_cu)
@@ -669,9 +674,12 @@ gpf_status ensure_residual_buffers(gpf_filter* h)
 
 CdfLevels levels(const gpf_filter* h, int ch)
 {
-    const int logg = ch == 0 && h->ch0_offsets ? multi_logg(h->ntiles) : -1;
+    int logg = ch == 0 && h->ch0_offsets ? multi_logg(h->ntiles) : -1;
+    const int sample = ch == 0 && h->ch0_offsets && logg < 0 ? multi_sample(h->ntiles) : 0;
+    if (sample > 0) logg = 0;
     return CdfLevels{h->cdf[ch], h->t16[ch], h->t256[ch], h->table[ch], k32_of(h->t256[ch], h->ntiles),
-                     logg >= 0 ? off16_of(h->t256[ch], h->ntiles) : nullptr, logg >= 0 ? coarse_of(h->t256[ch], h->ntiles) : nullptr, logg};
+                     logg >= 0 ? off16_of(h->t256[ch], h->ntiles) : nullptr, logg >= 0 ? coarse_of(h->t256[ch], h->ntiles) : nullptr, logg,
+                     sample > 0 ? k32s_of(h->t256[ch], h->ntiles) : nullptr, sample};
 }
 
 // residual: copy-count and residual-weight CDFs from the weight CDF (resample.jl:99,109); ws->S must be the GLOBAL sum
@@ -702,7 +710,14 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
 // ancestors of i.i.d. targets: k_search_multi (4-byte keys of every 32 / 64 cells in LDS) while the key table fits, else k_search<0>
 void launch_multinomial_search(gpf_filter* h, const SearchArgs& sa)
 {
-    const int logg = sa.w.off16 ? sa.w.logg : -1;                // the offset levels exist for channel 0 only
+    const int logg = sa.w.off16 && sa.w.sample == 0 ? sa.w.logg : -1;   // the offset levels exist for channel 0 only
+    if (sa.w.off16 && sa.w.sample > 0) {                         // 2.5 M .. 5 M particles: sampled key table
+        const int gss = (int)std::max<int64_t>(1, std::min<int64_t>((sa.n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));
+        const size_t lds = multi_lds_bytes(sa.ntiles, sa.w.sample);
+        static_assert(MULTI_SAMPLE_MAX == 2, "one instantiation");
+        GPF_LAUNCH((k_search_multi_s<2>), dim3(gss), dim3(SBLOCK), lds, h->stream, sa);
+        return;
+    }
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((sa.n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));   // (k_search_multi strides by its own slots per lane)
     if (logg == 0)      GPF_LAUNCH((k_search_multi<0>), dim3(gsr), dim3(SBLOCK), multi_lds_bytes(sa.ntiles, 0), h->stream, sa);
     else if (logg == 1) GPF_LAUNCH((k_search_multi<1>), dim3(gsr), dim3(SBLOCK), multi_lds_bytes(sa.ntiles, 1), h->stream, sa);
@@ -718,7 +733,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     const bool sorted = method == GPF_RESAMPLE_STRATIFIED && sort_particles;
     const bool need_sync = check == GPF_CHECK_TRUE || invalid != nullptr;
     // only the multinomial search reads the offset levels: the scans of this call write them for it alone
-    const bool need_off = method == GPF_RESAMPLE_MULTINOMIAL && multi_logg(h->ntiles) >= 0;
+    const bool need_off = method == GPF_RESAMPLE_MULTINOMIAL && (multi_logg(h->ntiles) >= 0 || multi_sample(h->ntiles) > 0);
     struct OffScope { gpf_filter* h; ~OffScope() { h->want_offsets = true; } } off_scope{h};
     h->want_offsets = need_off;
     h->offsets_hint = need_off;
@@ -926,6 +941,7 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search<3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_multi<0>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_multi<1>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_multi_s<2>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
 #define GPF_PUSH_ATTR(M, W) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_push<M, W>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn))
         GPF_PUSH_ATTR(0, 2); GPF_PUSH_ATTR(0, 4); GPF_PUSH_ATTR(0, 8);
         GPF_PUSH_ATTR(1, 2); GPF_PUSH_ATTR(1, 4); GPF_PUSH_ATTR(1, 8);
@@ -1947,7 +1963,7 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((capacity + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));
     const CdfLevels lw_ = levels(h, two ? 2 : 0);
     const CdfLevels lc_ = levels(h, two ? 1 : 0);
-    const bool narrow = method == GPF_RESAMPLE_MULTINOMIAL && lw_.off16 != nullptr;
+    const bool narrow = method == GPF_RESAMPLE_MULTINOMIAL && lw_.off16 != nullptr && lw_.sample == 0;
     const int gridn = (int)std::max<int64_t>(1, std::min<int64_t>((capacity + 4 * SBLOCK - 1) / (4 * SBLOCK), (int64_t)h->n_cu));
     s = timed(h, GPF_K_GATHER, [&] {
         if (narrow)                                  launch_push_multi(h, a, gridn, lw_, capacity, packed_out);
