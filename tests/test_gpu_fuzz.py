@@ -10,6 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 N_SEEDS = int(os.environ.get("GPF_FUZZ_SEEDS", "12"))           # GPF_FUZZ_SEEDS=300 for a longer hunt
+OFFSET = int(os.environ.get("GPF_FUZZ_OFFSET", "0"))             # ... GPF_FUZZ_OFFSET=100000 for other sequences
 METHODS = ["multinomial", "residual", "stratified"]
 
 
@@ -44,7 +45,7 @@ def check(g, st, orc, tag):
 
 @pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_api_sequences(g, o, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + OFFSET + seed)
     name = ["lgssm2", "bearings4", "sv1"][seed % 3]
     model = g.models.by_name(name)
     N = int(rng.choice([1, 2, 5, 37, 1000, 4099, 70_001, 300_000], p=[0.05, 0.05, 0.08, 0.2, 0.2, 0.2, 0.17, 0.05]))
@@ -165,7 +166,7 @@ def test_random_api_sequences_discrete_latent_models(g, o, seed):
     """the same walk on the models with a discrete latent (README's object_motion, the reference tests' line_model): plain and
     STRATIFIED initialisation / updates (src/initialize.jl:92-109, src/update.jl:193-210; both layouts), every resampler, MH,
     views"""
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + OFFSET + seed)
     name = ["object_motion", "line_model"][seed % 2]
     model = g.models.by_name(name)
     N = int(rng.choice([10, 100, 1000, 5001, 40_000]))
