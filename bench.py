@@ -44,6 +44,64 @@ def algorithmic_bytes(d: int, W: int):
     }
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv, timeout_s: float) -> int:
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment (how the driver starts a scaling run):
+    start the N ranks as a CHILD job -- this process has not imported torch and never touches a GPU, so nothing that has
+    initialised HIP is replaced -- relay its output, print the job's JSON line as the LAST stdout line and return the
+    job's exit code.  Any rank failing makes torch.distributed.run (and so this process) exit non-zero.  The child tree is
+    killed and the exit code is non-zero if no JSON line arrives within `timeout_s`."""
+    import signal
+    import subprocess
+    import threading
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT, start_new_session=True)
+    lines = []
+
+    def pump():
+        for ln in child.stdout:
+            lines.append(ln.rstrip("\n"))
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    timed_out = False
+    try:
+        rc = child.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        try:
+            os.killpg(child.pid, signal.SIGKILL)               # the exact process group this function started
+        except ProcessLookupError:
+            pass
+        child.wait()
+        rc = 124
+    th.join(timeout=10)
+    js = [ln for ln in lines if ln.startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if not js or ln is not js[-1]:
+            print(ln, file=sys.stderr)                         # RCCL banners etc.: kept, but off the JSON channel
+    if timed_out:
+        print(f"[bench] no result after {timeout_s:.0f} s: killed the {n}-rank job", file=sys.stderr, flush=True)
+        return rc
+    if rc == 0 and not js:
+        print("[bench] the rank job exited 0 without a JSON line", file=sys.stderr, flush=True)
+        return 1
+    if js:
+        sys.stdout.write(js[-1] + "\n")
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,7 +109,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("GPF_BENCH_LAUNCH_TIMEOUT", "1500")),
+                    help="wall-clock bound (s) of the self-launched multi-rank job")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # BEFORE torch is imported or any GPU call is made
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
 
     import numpy as np
     import torch
@@ -61,8 +125,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or run plain `python bench.py --gpus N`)")
     # functional check of the multi-rank code path on a 1-GPU box: every rank on cuda:0, collectives staged through gloo
     one_device = os.environ.get("GPF_BENCH_ONE_DEVICE") == "1"
     if one_device:
@@ -316,6 +379,14 @@ def main():
         cpu_all = {"value": round(n_cpu * k_cpu / ce, 1), "unit": "particle-steps/sec", "cores": used, "kind": "port",
                    "sample": f"same sample, OpenMP over particles on {used} threads ({ce:.1f} s)"}
 
+    # world size of the RCCL communicator the timed resamples actually ran their exchange on (0: no RCCL in the data path --
+    # one unsharded GPU, or the torch.distributed engine over gloo)
+    if not sharded_mode:
+        rccl_ranks = 0
+    elif getattr(state.backend, "lib_comm", False):
+        rccl_ranks = int(state.backend.comm_world()) if os.environ.get("GPF_RCCL_LIBRARY") is None else 0
+    else:
+        rccl_ranks = world if (dist is not None and dist.is_initialized() and dist.get_backend() == "nccl") else 0
     if rank == 0:
         out = {
             "metric": "particle-steps/sec", "value": round(value, 1), "unit": "particle-steps/sec",
@@ -331,6 +402,7 @@ def main():
                               f"python: sharded.py composes the phases over torch.distributed ({dist.get_backend() if dist is not None and dist.is_initialized() else 'no'} backend, {world} rank(s))"
                               + (f"; {engine_note}" if engine_note else ""))),
             "log_ml_estimate": lml, "log_ml_exact_kalman": lml_exact, "log_ml_abs_error": abs(lml - lml_exact),
+            "rccl_ranks": rccl_ranks,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
             "stratified_variant": strat, "local_resample_variant": island,
         }

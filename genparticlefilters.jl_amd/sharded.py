@@ -161,6 +161,11 @@ class HipShardBackend:
         if not ok:
             raise ErrorException(err)
         self.lib_comm = True
+        self._rccl_world = world if idbuf is not None else 0      # no id: a single shard without any RCCL communicator
+
+    def comm_world(self) -> int:
+        """ranks of the library's RCCL communicator (0: none)"""
+        return getattr(self, "_rccl_world", 0)
 
     def shard_resample(self, method_id: int, check) -> bool:
         """pf_resample!(state, method; check) over all shards, collectives issued by the library; returns `invalid`"""

@@ -107,3 +107,66 @@ def test_bench_main_prints_one_json_line(argv, o, built, monkeypatch):
     assert c is not None and c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["sample"]
     assert set(out["resample_gather_kernel"]) == {"multinomial", "stratified"}
     assert np.isfinite(out["log_ml_estimate"]) and np.isfinite(out["log_ml_abs_error"])
+
+
+# ---- `python bench.py --gpus N` with no WORLD_SIZE: the launcher branch (the driver's scaling command; round 2 exited rc 1 on it)
+def _fake_torchrun(tmp_path, body):
+    """a stand-in for `python -m torch.distributed.run` on sys.path of the child: records its argv, then runs `body`"""
+    pkg = tmp_path / "torch" / "distributed"
+    pkg.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("")
+    (pkg / "run.py").write_text("import sys, json, os, time\nargv = sys.argv[1:]\n" + body)
+    return str(tmp_path)
+
+
+def _run_launcher(tmp_path, body, extra=()):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=_fake_torchrun(tmp_path, body))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", *extra],
+                          capture_output=True, text=True, env=env, timeout=120)
+
+
+def test_launcher_starts_ranks_and_relays_the_json_line(tmp_path):
+    body = ("print('RCCL version banner')\n"
+            "assert '--nproc-per-node' in argv and argv[argv.index('--nproc-per-node') + 1] == '2', argv\n"
+            "assert '--master-addr' in argv and argv[argv.index('--master-addr') + 1] == '127.0.0.1'\n"
+            "assert argv[-6:] == ['--gpus', '2', '--steps', '20', '--warmup', '5'], argv\n"
+            "assert os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'\n"
+            "print(json.dumps({'metric': 'particle-steps/sec', 'value': 1.0, 'n_gpus': 2}))\n"
+            "print('trailing noise')\n")
+    p = _run_launcher(tmp_path, body)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2          # the JSON line is the only (so the last) stdout line
+    assert "RCCL version banner" in p.stderr and "trailing noise" in p.stderr
+
+
+def test_launcher_propagates_a_rank_failure(tmp_path):
+    p = _run_launcher(tmp_path, "print('rank 1 died', file=sys.stderr)\nsys.exit(3)\n")
+    assert p.returncode == 3 and p.stdout.strip() == ""
+
+
+def test_launcher_needs_a_json_line(tmp_path):
+    p = _run_launcher(tmp_path, "print('no result')\n")
+    assert p.returncode != 0 and "without a JSON line" in p.stderr
+
+
+def test_launcher_kills_a_hung_job(tmp_path):
+    import time
+    t0 = time.time()
+    p = _run_launcher(tmp_path, "time.sleep(600)\n", extra=("--launch-timeout", "3"))
+    assert p.returncode == 124 and time.time() - t0 < 60 and "killed" in p.stderr
+
+
+def test_rank_count_mismatch_is_an_error(monkeypatch, built):
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=1" in str(e.value)

@@ -89,3 +89,19 @@ def test_two_ranks_library_engine_over_loopback(built, tmp_path):
     assert p3.returncode == 0, p3.stderr[-3000:]
     out3 = _last_json(p3.stdout)
     assert out3["shard_engine"].startswith("python") and "fell back" in out3["shard_engine"] and out3["log_ml_estimate"] == ref
+
+
+@pytest.mark.gpu
+def test_plain_command_self_launches_two_ranks(built):
+    """the driver's scaling command as the driver types it -- plain `python bench.py --gpus 2 ...`, no torchrun, no WORLD_SIZE:
+    bench.py starts the two ranks itself as a child job (round 2: SystemExit, rc 1).  Both ranks on cuda:0 here."""
+    env = dict(os.environ, GPF_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--particles-per-gpu", "200000"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])                      # the LAST stdout line, nothing after it
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["config"]["particles_total"] == 400000
+    assert out["rccl_ranks"] == 0 and out["shard_engine"].startswith("python")      # gloo staging: no RCCL in this run, and the line says so
+    assert out["value"] > 0 and out["scaling"] == "weak"
