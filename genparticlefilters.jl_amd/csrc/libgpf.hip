@@ -963,6 +963,7 @@ gpf_status gpf_destroy(gpf_handle h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    h->pending_packed = false;                                   // the filter goes away: nothing to scatter a deferred commit into
     gpf_comm_destroy(h);
     hist_clear(h);
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
@@ -2146,6 +2147,11 @@ gpf_status gpf_comm_destroy(gpf_handle h)
 {
     if (!h) return GPF_OK;
     hipSetDevice(h->cfg.device);
+    // a deferred commit (gpf_shard_resample leaves the new population in the exchange buffers: pend_packed / pend_mf / pend_tot
+    // point into sh_recv / sh_send / sh_mf_all / sh_tot_all) is scattered into the filter's own rows BEFORE those buffers go
+    gpf_status ms = GPF_OK;
+    if (h->pending_packed && h->initialized && h->rows[0]) ms = materialize(h);
+    h->pending_packed = false; h->pend_packed = nullptr; h->pend_mf = nullptr; h->pend_tot = nullptr; h->pend_G = 0;
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
@@ -2154,7 +2160,7 @@ gpf_status gpf_comm_destroy(gpf_handle h)
     for (void* b : bufs) if (b) (void)hipFree(b);
     h->sh_mf = h->sh_mf_all = nullptr; h->sh_tot = h->sh_tot_all = h->sh_cr = h->sh_cr_all = nullptr;
     h->sh_send = h->sh_recv = nullptr; h->sh_send_cap = h->sh_recv_cap = 0;
-    return GPF_OK;
+    return ms;
 }
 
 gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid)
@@ -2174,11 +2180,34 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
         if (bounds[me] != h->cfg.gid0 || bounds[me + 1] != h->cfg.gid0 + n)
             return fail(h, GPF_ERR_STATE, "this shard's (gid0, n_particles) is not rank's contiguous share of n_global");
     }
+    // Everything that can fail for reasons of THIS rank alone (allocations) happens before the first collective of the call: a
+    // rank that returned early would leave its peers blocked in a collective it never joins.  The send buffer holds a balanced
+    // exchange with slack -- or, when that is cheap against the HBM at hand (<= 1/16 of the free memory), one entry per GLOBAL slot,
+    // the most any shard can ever serve, so that the overflow re-push below never has to allocate.
+    auto ensure = [&](double*& buf, int64_t& cap, int64_t want) -> gpf_status {
+        if (cap >= want) return GPF_OK;
+        if (buf) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(buf); buf = nullptr; cap = 0; }
+        HIP_TRY(h, hipMalloc(&buf, (size_t)want * E * sizeof(double)));
+        cap = want;
+        return GPF_OK;
+    };
+    int64_t cap = std::min<int64_t>(h->cfg.n_global, 2 * n + 65536);
+    if (h->sh_send_cap < h->cfg.n_global) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)h->cfg.n_global * E * sizeof(double) <= free_b / 16) cap = h->cfg.n_global;
+    } else cap = h->cfg.n_global;
+    if (const char* e = getenv("GPF_PUSH_CAPACITY")) cap = atoll(e);                                  // tests: force the overflow path
+    if ((s = ensure(h->sh_send, h->sh_send_cap, std::max<int64_t>(cap, 1)))) return s;
+    static const bool force = getenv("GPF_SHARD_FORCE_COLLECTIVES") && !strcmp(getenv("GPF_SHARD_FORCE_COLLECTIVES"), "1");
+    const bool exchange = G > 1 || (force && h->comm);            // one shard: what it "sends" is what it "receives"
+    if (exchange && (s = ensure(h->sh_recv, h->sh_recv_cap, n))) return s;
+
     h->want_offsets = method == GPF_RESAMPLE_MULTINOMIAL;         // (the offset levels serve k_push_multi only)
     s = shard_summary(h, 0);                                      // phases 1, 2
     h->want_offsets = true;
     if (s) return s;
     if (check != GPF_CHECK_FALSE || invalid) {                    // safe_softmax validity (utils.jl:117-140): pinned flags, no stream sync
+        // (the flags describe the GLOBAL weights: every rank takes the same branch here)
         int32_t flags = 0;
         if ((s = gpf_shard_flags(h, &flags))) return s;
         if (invalid) *invalid = flags != 0;
@@ -2192,43 +2221,60 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
         cr_all = h->sh_cr_all;
     }
     if ((s = gpf_shard_push_count(h, method, h->sh_tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
-    // phase 4 is enqueued before the host learns the counts, into a send buffer sized for a balanced exchange with slack;
-    // the kernel stops at the capacity and the push is repeated if the counts say it overflowed
-    auto ensure = [&](double*& buf, int64_t& cap, int64_t want) -> gpf_status {
-        if (cap >= want) return GPF_OK;
-        if (buf) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(buf); buf = nullptr; cap = 0; }
-        HIP_TRY(h, hipMalloc(&buf, (size_t)want * E * sizeof(double)));
-        cap = want;
-        return GPF_OK;
-    };
-    int64_t cap = std::min<int64_t>(h->cfg.n_global, 2 * n + 65536);
-    if (const char* e = getenv("GPF_PUSH_CAPACITY")) cap = atoll(e);                                  // tests: force the overflow path
-    if ((s = ensure(h->sh_send, h->sh_send_cap, std::max<int64_t>(cap, 1)))) return s;
-    static const bool force = getenv("GPF_SHARD_FORCE_COLLECTIVES") && !strcmp(getenv("GPF_SHARD_FORCE_COLLECTIVES"), "1");
-    const bool exchange = G > 1 || (force && h->comm);            // one shard: what it "sends" is what it "receives"
-    if (exchange && (s = ensure(h->sh_recv, h->sh_recv_cap, n))) return s;
-    if ((s = gpf_shard_push(h, method, h->sh_tot_all, cr_all, G, me, bounds.data(), cap, h->sh_send))) return s;
+    // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
+    // counts say it overflowed
+    const int64_t pushed_cap = std::min(cap, h->sh_send_cap);
+    if ((s = gpf_shard_push(h, method, h->sh_tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
     std::vector<int64_t> counts(2 * (size_t)G);
     if ((s = gpf_shard_counts(h, G, counts.data()))) return s;   // ONE host wait (the exchange's split sizes), behind phase 4
     int64_t n_send = 0, n_recv = 0;
     for (int g = 0; g < G; ++g) { n_send += counts[g]; n_recv += counts[G + g]; }
-    if (n_recv != n) return fail(h, GPF_ERR_STATE, "exchange counts do not add up to the shard's slots");
-    if (n_send > cap) {                                           // skewed weights: this shard serves more than its buffer held
-        if ((s = ensure(h->sh_send, h->sh_send_cap, n_send))) return s;
-        if ((s = gpf_shard_push(h, method, h->sh_tot_all, cr_all, G, me, bounds.data(), n_send, h->sh_send))) return s;
+    // From here on a local failure is REMEMBERED and the rank still joins the exchange with the counts its peers expect (they
+    // worked out their receive counts themselves and will wait for exactly that many entries): the error is returned after the
+    // group has closed.  A failed gpf_shard_resample leaves the communicator and the filter unusable on every rank that sees
+    // one (the entries a failing rank sends are undefined): the host must tear the job down.
+    gpf_status late = GPF_OK;
+    std::string late_msg;
+    auto remember = [&](gpf_status st) { if (st && !late) { late = st; late_msg = h->err; } };
+    if (n_recv != n) remember(fail(h, GPF_ERR_STATE, "exchange counts do not add up to the shard's slots"));
+    if (n_send > h->sh_send_cap) {                                // skewed weights: this shard serves more than its buffer held
+        gpf_status es = ensure(h->sh_send, h->sh_send_cap, n_send);
+        if (es) {                                                 // cannot hold what the peers expect: nothing sane can be sent
+            if (exchange) remember(fail(h, GPF_ERR_HIP, "send buffer for a skewed exchange could not be allocated; the communicator is poisoned (peers are waiting)"));
+            return es;
+        }
     }
-    // the exchange: [row | slot | ancestor id], grouped point-to-point sends and receives (one pair per peer)
+    if (n_send > pushed_cap)
+        remember(gpf_shard_push(h, method, h->sh_tot_all, cr_all, G, me, bounds.data(), n_send, h->sh_send));
+    // the exchange: [row | slot | ancestor id], grouped point-to-point sends and receives (one pair per PEER; the shard's own
+    // entries never touch RCCL: one device-to-device copy on the same stream)
+    const double* commit_from = h->sh_send;
     if (exchange) {
-        NCCL_TRY(h, g_rccl.GroupStart());
-        int64_t so = 0, ro = 0;
+        commit_from = h->sh_recv;
+        ncclResult_t first = ncclSuccess;
+        const char* where = "";
+        auto note = [&](ncclResult_t r, const char* w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; where = w; } };
+        const bool recv_fits = n_recv <= h->sh_recv_cap;
+        int64_t so = 0, ro = 0, self_so = -1, self_ro = -1;
+        note(g_rccl.GroupStart(), "ncclGroupStart");
         for (int g = 0; g < G; ++g) {
-            if (counts[g]) NCCL_TRY(h, g_rccl.Send(h->sh_send + so * E, (size_t)(counts[g] * E), ncclDouble, g, h->comm, h->stream));
-            if (counts[G + g]) NCCL_TRY(h, g_rccl.Recv(h->sh_recv + ro * E, (size_t)(counts[G + g] * E), ncclDouble, g, h->comm, h->stream));
+            if (g == me && !(force && G == 1)) { self_so = so; self_ro = ro; }
+            else {
+                if (counts[g]) note(g_rccl.Send(h->sh_send + so * E, (size_t)(counts[g] * E), ncclDouble, g, h->comm, h->stream), "ncclSend");
+                if (counts[G + g] && recv_fits) note(g_rccl.Recv(h->sh_recv + ro * E, (size_t)(counts[G + g] * E), ncclDouble, g, h->comm, h->stream), "ncclRecv");
+            }
             so += counts[g]; ro += counts[G + g];
         }
-        NCCL_TRY(h, g_rccl.GroupEnd());
+        note(g_rccl.GroupEnd(), "ncclGroupEnd");                  // ALWAYS closed: librccl is shared with the host (PyTorch); an open group
+                                                                  // would swallow every later RCCL call of this thread
+        if (first != ncclSuccess) remember(fail(h, GPF_ERR_HIP, std::string(where) + ": " + g_rccl.GetErrorString(first)));
+        if (self_so >= 0 && counts[me] && recv_fits) {
+            const hipError_t ce = hipMemcpyAsync(h->sh_recv + self_ro * E, h->sh_send + self_so * E, (size_t)counts[me] * E * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+            if (ce != hipSuccess) remember(fail(h, GPF_ERR_HIP, std::string("self copy: ") + hipGetErrorString(ce)));
+        }
     }
-    return gpf_shard_commit(h, exchange ? h->sh_recv : h->sh_send, n, h->sh_mf_all, h->sh_tot_all, G);                      // phase 5 (deferred)
+    if (late) { h->err = late_msg; return late; }
+    return gpf_shard_commit(h, commit_from, n, h->sh_mf_all, h->sh_tot_all, G);                      // phase 5 (deferred)
 }
 
 gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out)

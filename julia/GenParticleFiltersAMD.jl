@@ -287,9 +287,11 @@ function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multi
     m = method == :multinomial ? 0 : method == :residual ? 1 : method == :stratified ? 2 : error("Resampling method $method not recognized.")
     chk = check === true ? 2 : (check === :warn ? 1 : 0)
     invalid = Ref{Cint}(0)
-    st = local_only ?
-        ccall((:gpf_resample_local, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ref{Cint}), s.handle, m, sort_particles ? 1 : 0, chk, invalid) :
-        ccall((:gpf_shard_resample, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cint}), s.handle, m, chk, invalid)
+    # check = false: NULL for `invalid` keeps the call fully asynchronous (a non-NULL pointer makes the library poll the weight flags)
+    inv_ptr = check === false ? Ptr{Cint}(C_NULL) : Base.unsafe_convert(Ptr{Cint}, invalid)
+    st = GC.@preserve invalid (local_only ?
+        ccall((:gpf_resample_local, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cint}), s.handle, m, sort_particles ? 1 : 0, chk, inv_ptr) :
+        ccall((:gpf_shard_resample, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}), s.handle, m, chk, inv_ptr))
     _status(s, st)                                # (the keyword `check` shadows the status helper of that name in this method)
     check === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
     return s

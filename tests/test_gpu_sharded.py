@@ -217,3 +217,27 @@ def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib,
     for p in parts:
         assert np.array_equal(p["scal"], ref, equal_nan=True)
         assert float(p["lml"]) == f.log_ml_estimate() or (np.isnan(float(p["lml"])) and np.isnan(f.log_ml_estimate()))
+
+
+def test_comm_destroy_after_resample_keeps_the_population(g, o):
+    """resample -> gpf_comm_destroy -> update: the deferred commit points into the communicator's exchange buffers; destroying
+    the communicator must scatter it first (round-2 advisor: use-after-free through the public ABI)"""
+    from gpf_amd import sharded
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 4); N = 50_000
+    a = sharded.pf_initialize(model, (1,), ys[0], N, seed=9)
+    b = g.pf_initialize(model, (1,), ys[0], N, seed=9)
+    assert a.backend.lib_comm
+    for method in ("multinomial", "stratified"):
+        sharded.pf_resample(a, method, check=False)
+        g.pf_resample(b, method, check=False, **({"sort_particles": False} if method == "stratified" else {}))
+        a.backend._ck(a.backend.L.gpf_comm_destroy(a.backend.h))
+        # scribble over freed device memory: a stale pointer would now read garbage
+        import torch
+        junk = [torch.full((N * 3,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(4)]
+        torch.cuda.synchronize()
+        sharded.pf_update(a, (2,), (None,), ys[1]); g.pf_update(b, (2,), (None,), ys[1])
+        assert np.array_equal(a.local.parents, b.parents)
+        assert np.array_equal(a.local.traces, b.traces) and np.array_equal(a.local.log_weights, b.log_weights)
+        del junk
+        a.backend._ck(a.backend.L.gpf_comm_create(a.backend.h, None, 0, 1))
+    assert g.get_lml_est(b) == sharded.get_lml_est(a)

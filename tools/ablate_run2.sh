@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for f in BASE genparticlefilters.jl_amd/abl/*.so; do
   if [ "$f" = BASE ]; then unset GPF_LIB_OVERRIDE; else export GPF_LIB_OVERRIDE=$PWD/$f; fi
   python - "$f" <<'PY' 2>/dev/null

@@ -1,7 +1,7 @@
 # usage: bash tools/gpu_bench.sh [tag]   -- bench + rocprofv3 kernel trace on the GPU box
 set -x
 TAG=${1:-r01}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
 cd $R
 python bench.py --steps 1000 --warmup 20 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err

@@ -1,3 +1,3 @@
 set -x
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; mkdir -p gpurun_out
 GPF_BENCH_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 200 --warmup 10 --no-cpu-baseline 2>&1 | tail -5

@@ -1,6 +1,6 @@
 # PMC passes (separate runs, kernel-trace only): HBM-side bytes per kernel
 TAG=${1:-r01}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do

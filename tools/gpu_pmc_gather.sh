@@ -1,7 +1,7 @@
 # usage: bash tools/gpu_pmc_gather.sh TAG   -- L1->L2 and L2->fabric request counters of the stand-alone resample gather
 # (k_gather<2>: 16-byte rows, N = 1e6) for i.i.d. (multinomial) and monotone (stratified) ancestors; one --pmc pass per group
 TAG=${1:-x}
-R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
 OUT=$R/gpurun_out/gather_$TAG.txt; : > $OUT
 for M in multinomial stratified; do
  i=0

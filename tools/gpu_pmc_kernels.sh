@@ -1,7 +1,7 @@
 # usage: [LOOP=sharded_loop.py] bash tools/gpu_pmc_kernels.sh TAG METHOD [STEPS] [N]   -- SQ counters of every kernel of a resample+update loop
 # (one rocprofv3 --pmc pass per counter group, kernel trace only; summaries -> gpurun_out/pmc_TAG.txt)
 TAG=${1:-x}; METHOD=${2:-multinomial}; STEPS=${3:-30}; NP=${4:-1000000}
-R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_$TAG.txt; : > $OUT
 i=0
 for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" ${PMC_EXTRA:+"$PMC_EXTRA"}; do

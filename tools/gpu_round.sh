@@ -2,7 +2,7 @@
 # rocprofv3 kernel stats of the same command, FETCH_SIZE / WRITE_SIZE passes, per-config times
 set -x
 TAG=${1:-r02}
-R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; cd $R
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; mkdir -p $R/gpurun_out; cd $R
 python bench.py --steps 1000 --warmup 20 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -2 gpurun_out/${TAG}_bench.err
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_cmd.json 2>> gpurun_out/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 # kernel stats of the sorted-stratified loop (N = 1e6)
-R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp; rm -rf $R/gpurun_out/prof_sort
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd /tmp; export TMPDIR=/tmp; rm -rf $R/gpurun_out/prof_sort
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sort -- python3 $R/tools/resample_loop.py stratified_sorted 30 > /dev/null 2>&1
 python3 - <<PY
 import csv,glob
