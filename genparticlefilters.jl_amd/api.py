@@ -102,17 +102,18 @@ class DeviceParticleFilterState:
         if history:                      # trajectory store for `history` time steps (persistent-trace queries)
             self._check(self._L.gpf_history_enable(self._h, int(history)))
 
-    # -- state[idxs] / view(state, idxs): a sub-state over a contiguous range (src/view.jl:35-48)
+    # -- state[idxs] / view(state, idxs): a sub-state over a range start:step:stop (src/view.jl:35-48; the reference's tests use
+    #    contiguous and strided ranges, state[1:50], state[k:5:100]).  0-based half-open Python slices / ranges.
     def __getitem__(self, idx):
         if isinstance(idx, slice):
             start, stop, step = idx.indices(self.n_particles)
         elif isinstance(idx, range):
             start, stop, step = idx.start, idx.stop, idx.step
         else:
-            raise TypeError("device sub-states cover contiguous ranges: use state[a:b]")
-        if step != 1 or stop <= start:
-            raise ErrorException("device sub-states cover contiguous, non-empty ranges")
-        return DeviceParticleFilterSubState(self, start, stop - start)
+            raise TypeError("device sub-states cover ranges: use state[a:b] or state[a:b:step]")
+        if step < 1 or stop <= start:
+            raise ErrorException("device sub-states cover non-empty ranges with a positive step")
+        return DeviceParticleFilterSubState(self, start, (stop - start + step - 1) // step, step)
 
     def view(self, idx):
         return self[idx]
@@ -200,18 +201,18 @@ class DeviceParticleFilterState:
 
 
 class DeviceParticleFilterSubState(DeviceParticleFilterState):
-    """ParticleFilterSubState (src/view.jl:16-22): aliases particles [start, start+count) of `source`; every pf_* function
+    """ParticleFilterSubState (src/view.jl:16-22): aliases particles start, start+step, ... (count of them) of `source`; every pf_* function
     accepts it, with the reference's sub-state semantics (local parents, no log-ML update on resampling, weights reset to
     the block average, log_ml_estimate relative to the source's running estimate)."""
 
-    def __init__(self, source: DeviceParticleFilterState, start: int, count: int):
+    def __init__(self, source: DeviceParticleFilterState, start: int, count: int, step: int = 1):
         self.source = source                     # keeps the parent alive
-        self.start = int(start)
+        self.start, self.step = int(start), int(step)
         self._L = source._L
         self.model, self.seed, self.keep_prev = source.model, source.seed, source.keep_prev
         self.n_particles, self.dim, self.row_width = int(count), source.dim, source.row_width
         self._h = C.c_void_p()
-        st = self._L.gpf_view_create(source._h, int(start), int(count), C.byref(self._h))
+        st = self._L.gpf_view_create_strided(source._h, int(start), int(step), int(count), C.byref(self._h))
         if st != _lib.OK:
             self._h = None
             raise ErrorException(self._L.gpf_last_error(source._h).decode())

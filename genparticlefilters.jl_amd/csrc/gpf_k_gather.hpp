@@ -66,6 +66,29 @@ __global__ void k_sum_partials(const double* __restrict__ partial, int np, doubl
     if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < NWAVES; ++w) t += s[w]; *out = t; }
 }
 
+// ----------------------------------------------------------------------------- strided sub-state views
+// state[start:step:stop] (reference src/view.jl:35-48; test/initialize.jl:60, test/update.jl:33): a strided view works on a
+// compact copy of its particles -- view_enter gathers rows / log-weights / parents of particles start + i*step, view_exit
+// scatters them back (update_refs! for sub-states copies back as well, utils.jl:17-20).  to_view: parent -> compact, else back.
+__global__ __launch_bounds__(BLOCK) void k_view_strided_copy(double* __restrict__ prow, double* __restrict__ plw, int32_t* __restrict__ panc,
+                                                             double* __restrict__ vrow, double* __restrict__ vlw, int32_t* __restrict__ vanc,
+                                                             int W, int64_t step, int64_t n, int to_view)
+{
+    const int C = W / 2;
+    const int64_t total = n * C;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t j = t / C;
+        const int c = (int)(t - j * C);
+        double2* pp = reinterpret_cast<double2*>(prow) + (j * step) * C + c;
+        double2* vp = reinterpret_cast<double2*>(vrow) + t;
+        if (to_view) *vp = *pp; else *pp = *vp;
+        if (c == 0) {
+            if (to_view) { vlw[j] = plw[j * step]; vanc[j] = panc[j * step]; }
+            else { plw[j * step] = vlw[j]; panc[j * step] = vanc[j]; }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- small utilities
 __global__ void k_iota(int32_t* v, int64_t n)
 {

@@ -35,7 +35,7 @@ __device__ __forceinline__ int stratum_of(const ModelArgs& a, uint64_t seed, uin
 {
     const int64_t K = a.n_strata, B = n / K;
     if (i < K * B) return (int)(a.interleaved ? i % K : i / B);
-    const Philox b = rng(seed, (uint32_t)(gid0 + i), (uint32_t)Mo::NBLK, epoch, tag);
+    const Philox b = rng(seed, (uint32_t)(gid0 + i * a.gstride), (uint32_t)Mo::NBLK, epoch, tag);
     return (int)mulhi64(u64(b.w0, b.w1), (uint64_t)K);
 }
 
@@ -53,13 +53,13 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         double x[MAX_DIM];
         double ll;
-        if constexpr (MODE == 1) ll = Mo::propose(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+        if constexpr (MODE == 1) ll = Mo::propose(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
         else if constexpr (MODE == 2) {
             const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
-            const double lp = Mo::sample_stratum(a.P, true, nullptr, a.obs, v, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+            const double lp = Mo::sample_stratum(a.P, true, nullptr, a.obs, v, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
             ll = (lp + Mo::loglik(a.P, x, a.obs)) + a.logK;                      // initialize.jl:103-104
         } else {
-            Mo::sample(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_INIT, x);
+            Mo::sample(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
             ll = Mo::loglik(a.P, x, a.obs);
         }
         double* r = rows + i * W;
@@ -125,13 +125,13 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
         }
         double xn[MAX_DIM];
         double ll;
-        if constexpr (MODE == 1) ll = Mo::propose(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
+        if constexpr (MODE == 1) ll = Mo::propose(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
         else if constexpr (MODE == 2) {
             const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_UPDATE)];
-            const double lp = Mo::sample_stratum(a.P, false, r, a.obs, v, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
+            const double lp = Mo::sample_stratum(a.P, false, r, a.obs, v, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
             ll = (lp + Mo::loglik(a.P, xn, a.obs)) + a.logK;                     // update.jl:201-206
         } else {
-            Mo::sample(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i), 0, epoch, TAG_UPDATE, xn);
+            Mo::sample(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
             ll = Mo::loglik(a.P, xn, a.obs);
         }
         double o[W];
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
         const double* xp = r + D;                    // x_{t-1} (valid when has_prev)
         double llx = Mo::loglik(a.P, x, a.obs);
         double wsum = 0.0;
-        const uint32_t gid = (uint32_t)(gid0 + i);
+        const uint32_t gid = (uint32_t)(gid0 + i * a.gstride);
         for (int it = 0; it < n_iters; ++it) {
             if (REWEIGHT) {
                 Mo::sample(a.P, !has_prev, xp, a.obs, seed, gid, (uint32_t)(it * NB), epoch, TAG_REWEIGHT, xs);

@@ -27,6 +27,9 @@ struct ModelArgs {          // passed by value in the kernarg segment: no device
     double strata[MAX_STRATA];   // value of the model's discrete latent in each stratum
     double logK;                 // log(n_strata)
     int32_t n_strata, interleaved;
+    // strided sub-state views (reference src/view.jl:35-48 with idxs = start:step:stop): local particle i is particle
+    // gid0 + i * gstride of the filter and keeps THAT id as its RNG counter (1 everywhere else)
+    int32_t gstride, pad_;
 };
 
 template <int M> struct Model;

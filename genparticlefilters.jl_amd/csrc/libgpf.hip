@@ -103,6 +103,8 @@ struct gpf_filter {
     // sub-state view (src/view.jl:16-48): this handle aliases particles [view_start, view_start + n) of `parent`
     gpf_filter* parent = nullptr;
     int64_t view_start = 0;
+    int64_t view_step = 1;               // > 1: strided view (state[start:step:stop]); works on the compact copies below
+    double* vrows[2] = {nullptr, nullptr}; double* vlw = nullptr; int32_t* vanc = nullptr;
     uint64_t generation = 0;             // bumped when the per-particle buffers are reallocated (views check it)
     uint64_t parent_generation = 0;
     uint64_t mutations = 0;              // bumped by every change of the rows / log-weights of this filter (through any handle)
@@ -573,11 +575,18 @@ gpf_status view_enter(gpf_filter* v)
     gpf_status s = materialize(p);
     if (s) { v->err = p->err; return s; }
     const int64_t o = v->view_start;
-    v->rows[0] = p->rows[p->cur] + o * v->W;
-    v->rows[1] = p->rows[1 - p->cur] + o * v->W;
+    if (v->view_step == 1) {
+        v->rows[0] = p->rows[p->cur] + o * v->W;
+        v->rows[1] = p->rows[1 - p->cur] + o * v->W;
+        v->lw = p->lw + o;
+        v->anc = p->anc + o;
+    } else {                                                     // strided: a compact copy of particles o + i * step
+        v->rows[0] = v->vrows[0]; v->rows[1] = v->vrows[1]; v->lw = v->vlw; v->anc = v->vanc;
+        GPF_LAUNCH(k_view_strided_copy, dim3(grid_for(v, v->n * (v->W / 2), 8)), dim3(BLOCK), 0, v->stream, p->rows[p->cur] + o * v->W, p->lw + o, p->anc + o,
+                   v->vrows[0], v->vlw, v->vanc, v->W, v->view_step, v->n, 1);
+        HIP_TRY(v, hipGetLastError());
+    }
     v->cur = 0;
-    v->lw = p->lw + o;
-    v->anc = p->anc + o;
     v->epoch = p->epoch;
     v->has_prev = p->has_prev;
     v->initialized = true;
@@ -592,7 +601,13 @@ gpf_status view_exit(gpf_filter* v)
 {
     if (!v->parent) return GPF_OK;
     gpf_filter* p = v->parent;
-    if (v->cur == 1) {
+    if (v->view_step != 1) {                                     // strided: scatter the compact copy back into the source
+        const int64_t o = v->view_start;
+        GPF_LAUNCH(k_view_strided_copy, dim3(grid_for(v, v->n * (v->W / 2), 8)), dim3(BLOCK), 0, v->stream, p->rows[p->cur] + o * v->W, p->lw + o, p->anc + o,
+                   v->rows[v->cur], v->vlw, v->vanc, v->W, v->view_step, v->n, 0);
+        HIP_TRY(v, hipGetLastError());
+        v->cur = 0;
+    } else if (v->cur == 1) {
         HIP_TRY(v, hipMemcpyAsync(v->rows[0], v->rows[1], (size_t)v->n * v->W * sizeof(double), hipMemcpyDeviceToDevice, v->stream));
         v->cur = 0;
     }
@@ -893,6 +908,7 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
     h->cfg = *cfg;
     h->cfg.params = nullptr;
     for (int i = 0; i < cfg->n_params; ++i) h->args.P[i] = cfg->params[i];
+    h->args.gstride = 1;
     h->d = d;
     h->W = row_width(d, cfg->keep_prev != 0);
     h->n = cfg->n_particles;
@@ -967,7 +983,8 @@ gpf_status gpf_destroy(gpf_handle h)
     gpf_comm_destroy(h);
     hist_clear(h);
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
-    if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers
+    if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers (or of the compact copies below)
+    for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc}) if (q) (void)hipFree(q);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
     void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan};
     for (void* b : bufs) if (b) hipFree(b);
@@ -1278,6 +1295,7 @@ gpf_status gpf_set_rows(gpf_handle h, const double* rows, int64_t n_doubles)
     if (h->parent) { gpf_status s = view_enter(h); if (s) return s; }
     { gpf_status s = materialize(h); if (s) return s; }
     HIP_TRY(h, hipMemcpyAsync(h->rows[h->cur], rows, (size_t)n_doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->parent && h->view_step != 1) { gpf_status s = view_exit(h); if (s) return s; }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->initialized = true;
     mutated(h);
@@ -1293,6 +1311,7 @@ gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n)
     { gpf_status s = materialize(h); if (s) return s; }
     h->max_valid = false;
     HIP_TRY(h, hipMemcpyAsync(h->lw, lw, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->parent && h->view_step != 1) { gpf_status s = view_exit(h); if (s) return s; }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->raw_valid = false;
     h->initialized = true;
@@ -1425,13 +1444,19 @@ gpf_status gpf_sample_unweighted(gpf_handle h, int64_t n_samples, double* rows_o
 // =================================================================================== sub-state views (src/view.jl)
 gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_handle* out)
 {
+    return gpf_view_create_strided(parent, start, 1, count, out);
+}
+
+gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t step, int64_t count, gpf_handle* out)
+{
     if (!parent || !out) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
+    if (step < 1 || step >= ((int64_t)1 << 31)) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view step must be >= 1");
     if (parent->parent) return fail(parent, GPF_ERR_STATE, "views of views are not supported");
     // the trajectory store keeps ONE ancestor map and one set of columns per time step for the whole filter: a sub-state that
     // resamples or advances only its own particles would leave it describing something else -- refuse instead of going stale
     if (parent->hist_on) return fail(parent, GPF_ERR_STATE, "a filter with a trajectory store has no sub-state views");
-    if (start < 0 || count < 1 || start + count > parent->n) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view range out of bounds");
+    if (start < 0 || count < 1 || start + (count - 1) * step >= parent->n) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view range out of bounds");
     gpf_filter* v = new gpf_filter();
     v->cfg = parent->cfg;
     v->cfg.n_particles = count; v->cfg.n_global = count;          // a sub-state normalises over its own particles
@@ -1439,7 +1464,8 @@ gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_
     v->args = parent->args;
     v->d = parent->d; v->W = parent->W; v->n = count; v->n_cu = parent->n_cu;
     v->stream = parent->stream; v->own_stream = false;
-    v->parent = parent; v->view_start = start; v->parent_generation = parent->generation;
+    v->parent = parent; v->view_start = start; v->view_step = step; v->parent_generation = parent->generation;
+    v->args.gstride = (int32_t)step;                               // per-particle RNG counters stay the source's particle ids
     auto body = [&]() -> gpf_status {
         HIP_TRY(v, hipSetDevice(v->cfg.device));
         // scratch of its own (weight levels, descriptors, partials, scalars); rows / lw / anc alias the parent
@@ -1447,6 +1473,12 @@ gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_
         v->K = fix_K(count);
         v->logN = log_((double)count);
         const size_t n = (size_t)count;
+        if (step != 1) {
+            HIP_TRY(v, hipMalloc(&v->vrows[0], n * (size_t)v->W * sizeof(double)));
+            HIP_TRY(v, hipMalloc(&v->vrows[1], n * (size_t)v->W * sizeof(double)));
+            HIP_TRY(v, hipMalloc(&v->vlw, n * sizeof(double)));
+            HIP_TRY(v, hipMalloc(&v->vanc, n * sizeof(int32_t)));
+        }
         HIP_TRY(v, hipMalloc(&v->lws, n * sizeof(double)));
         HIP_TRY(v, hipMalloc(&v->lp, n * sizeof(double)));
         HIP_TRY(v, hipMalloc(&v->dtmp, n * sizeof(double)));

@@ -198,6 +198,13 @@ gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const do
  * A filter with a trajectory store (gpf_history_enable) has no views (GPF_ERR_STATE): the store keeps one ancestor map and one
  * set of columns per time step for the WHOLE filter. */
 gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_handle* out);
+/* state[start:step:stop] (src/view.jl:35-48 takes any AbstractVector; the reference's tests use strided ranges, state[k:5:100] and
+ * state[k:2:100], test/initialize.jl:60,85, test/update.jl:33,61, test/resize.jl:138): the view's particle i is particle
+ * start + i * step of `parent` (0-based start, count particles).  Same semantics as gpf_view_create; per-particle RNG counters
+ * stay the parent's particle ids, the view's resample stream is indexed by the slot ids start, start + 1, ... whatever the step.
+ * A strided view works on a compact copy (gathered on entry, scattered back by every mutating call: update_refs! for sub-states
+ * copies back as well, src/utils.jl:17-20). */
+gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t step, int64_t count, gpf_handle* out);
 
 /* ---- resize family (src/resize.jl) --------------------------------------------------
  * The handle stays valid; its per-particle buffers are reallocated for the new count.  Unsharded filters only. */

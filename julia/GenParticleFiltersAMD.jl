@@ -65,6 +65,14 @@ function Base.getindex(s::DeviceParticleFilterState, r::UnitRange{Int})
     return DeviceParticleFilterState(h[], getfield(s, :model), length(r))
 end
 Base.view(s::DeviceParticleFilterState, r::UnitRange{Int}) = s[r]
+# state[k:5:100] (test/initialize.jl:60, test/update.jl:33): a strided sub-state; particle i of the view is particle first(r) + (i-1) step(r)
+function Base.getindex(s::DeviceParticleFilterState, r::StepRange{Int,Int})
+    step(r) >= 1 || error("sub-state ranges need a positive step")
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(s, ccall((:gpf_view_create_strided, libgpf), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ref{Ptr{Cvoid}}), getfield(s, :handle), first(r) - 1, step(r), length(r), h))
+    return DeviceParticleFilterState(h[], getfield(s, :model), length(r))
+end
+Base.view(s::DeviceParticleFilterState, r::StepRange{Int,Int}) = s[r]
 
 check(state, st) = st == 0 ? nothing :
     error(unsafe_string(ccall((:gpf_last_error, libgpf), Cstring, (Ptr{Cvoid},), state.handle)))   # ErrorException

@@ -267,6 +267,13 @@ O_EXPORT void o_loglik_rows(int model, const double *P, const double *rows, int 
 {
     for (int64_t i = 0; i < n; ++i) out[i] = model_loglik(model, P, rows + i * W, obs);
 }
+/* Strided sub-state views (reference src/view.jl:35-48 with idxs = start:step:stop, e.g. state[k:5:100] in test/update.jl:33):
+ * local particle i of the view is particle start + i*step of the source, and its RNG counter stays that GLOBAL id.  The stride
+ * is a property of the call (set by the Python composition around a view's per-particle call, 1 otherwise). */
+static int64_t g_gid_stride = 1;
+O_EXPORT void o_set_gid_stride(int64_t stride) { g_gid_stride = stride; }
+#define O_GID(gid0, i) ((uint32_t)((gid0) + (int64_t)(i) * g_gid_stride))
+
 O_EXPORT void o_init_proposal(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
                               int W, const double *obs, double *rows, double *lw)
 {
@@ -274,7 +281,7 @@ O_EXPORT void o_init_proposal(int model, const double *P, uint64_t seed, uint32_
     for (int64_t i = 0; i < n; ++i) {
         double *r = rows + i * W;
         for (int k = 0; k < W; ++k) r[k] = 0.0;
-        lw[i] = model_propose(model, P, 1, NULL, obs, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_INIT, r);   /* initialize.jl:58 */
+        lw[i] = model_propose(model, P, 1, NULL, obs, seed, O_GID(gid0, i), 0, epoch, O_TAG_INIT, r);   /* initialize.jl:58 */
     }
 }
 O_EXPORT void o_step_proposal(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
@@ -286,7 +293,7 @@ O_EXPORT void o_step_proposal(int model, const double *P, uint64_t seed, uint32_
         const double *ri = rows_in + i * W;
         double *ro = rows_out + i * W;
         double xn[4], xp[4];
-        double w = model_propose(model, P, 0, ri, obs, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_UPDATE, xn);
+        double w = model_propose(model, P, 0, ri, obs, seed, O_GID(gid0, i), 0, epoch, O_TAG_UPDATE, xn);
         for (int k = 0; k < d; ++k) xp[k] = ri[k];
         for (int k = 0; k < W; ++k) ro[k] = 0.0;
         for (int k = 0; k < d; ++k) ro[k] = xn[k];
@@ -331,7 +338,7 @@ static int stratum_of(int model, int K, int interleaved, uint64_t seed, uint32_t
 {
     int64_t B = n / K;
     if (i < (int64_t)K * B) return (int)(interleaved ? i % K : i / B);
-    o_philox_t b = o_rng(seed, (uint32_t)(gid0 + i), (uint32_t)model_nblk(model), epoch, tag);
+    o_philox_t b = o_rng(seed, O_GID(gid0, i), (uint32_t)model_nblk(model), epoch, tag);
     return (int)o_mulhi64(((uint64_t)b.v[0] << 32) | b.v[1], (uint64_t)K);
 }
 O_EXPORT void o_init_strata(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n, int W,
@@ -342,7 +349,7 @@ O_EXPORT void o_init_strata(int model, const double *P, uint64_t seed, uint32_t 
         double *r = rows + i * W;
         for (int k = 0; k < W; ++k) r[k] = 0.0;
         double v = values[stratum_of(model, K, interleaved, seed, epoch, gid0, i, n, O_TAG_INIT)];
-        double lp = model_sample_stratum(model, P, 1, NULL, obs, v, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_INIT, r);
+        double lp = model_sample_stratum(model, P, 1, NULL, obs, v, seed, O_GID(gid0, i), 0, epoch, O_TAG_INIT, r);
         lw[i] = (lp + model_loglik(model, P, r, obs)) + logK;           /* initialize.jl:103-104 */
     }
 }
@@ -357,7 +364,7 @@ O_EXPORT void o_step_strata(int model, const double *P, uint64_t seed, uint32_t 
         double *ro = rows_out + i * W;
         double xn[4], xp[4];
         double v = values[stratum_of(model, K, interleaved, seed, epoch, gid0, i, n, O_TAG_UPDATE)];
-        double lp = model_sample_stratum(model, P, 0, ri, obs, v, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_UPDATE, xn);
+        double lp = model_sample_stratum(model, P, 0, ri, obs, v, seed, O_GID(gid0, i), 0, epoch, O_TAG_UPDATE, xn);
         for (int k = 0; k < d; ++k) xp[k] = ri[k];
         for (int k = 0; k < W; ++k) ro[k] = 0.0;
         for (int k = 0; k < d; ++k) ro[k] = xn[k];
@@ -375,7 +382,7 @@ O_EXPORT void o_init(int model, const double *P, uint64_t seed, uint32_t epoch, 
     for (int64_t i = 0; i < n; ++i) {
         double *r = rows + i * W;
         for (int k = 0; k < W; ++k) r[k] = 0.0;
-        model_sample(model, P, 1, NULL, obs, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_INIT, r);
+        model_sample(model, P, 1, NULL, obs, seed, O_GID(gid0, i), 0, epoch, O_TAG_INIT, r);
         lw[i] = model_loglik(model, P, r, obs);
         (void)d;
     }
@@ -393,7 +400,7 @@ O_EXPORT void o_step(int model, const double *P, uint64_t seed, uint32_t epoch, 
         const double *ri = rows_in + i * W;
         double *ro = rows_out + i * W;
         double xn[4];
-        model_sample(model, P, 0, ri, obs, seed, (uint32_t)(gid0 + i), 0, epoch, O_TAG_UPDATE, xn);
+        model_sample(model, P, 0, ri, obs, seed, O_GID(gid0, i), 0, epoch, O_TAG_UPDATE, xn);
         double ll = model_loglik(model, P, xn, obs);
         double xp[4];
         for (int k = 0; k < d; ++k) xp[k] = ri[k];
@@ -428,7 +435,7 @@ O_EXPORT uint64_t o_move(int model, const double *P, uint64_t seed, uint32_t epo
         for (int it = 0; it < n_iters; ++it) {
             if (reweight) {
                 uint32_t blk0 = (uint32_t)(it * nb);
-                model_sample(model, P, !has_prev, xp, obs, seed, (uint32_t)(gid0 + i), blk0, epoch,
+                model_sample(model, P, !has_prev, xp, obs, seed, O_GID(gid0, i), blk0, epoch,
                              O_TAG_REWEIGHT, xs);
                 double lls = model_loglik(model, P, xs, obs);
                 wsum = wsum + (lls - llx);                 /* rejuvenate.jl:82 */
@@ -437,10 +444,10 @@ O_EXPORT uint64_t o_move(int model, const double *P, uint64_t seed, uint32_t epo
                 nacc++;
             } else {
                 uint32_t blk0 = (uint32_t)(it * (nb + 1));
-                model_sample(model, P, !has_prev, xp, obs, seed, (uint32_t)(gid0 + i), blk0, epoch,
+                model_sample(model, P, !has_prev, xp, obs, seed, O_GID(gid0, i), blk0, epoch,
                              O_TAG_MOVE, xs);
                 double lls = model_loglik(model, P, xs, obs);
-                o_philox_t b = o_rng(seed, (uint32_t)(gid0 + i), blk0 + (uint32_t)nb, epoch, O_TAG_MOVE);
+                o_philox_t b = o_rng(seed, O_GID(gid0, i), blk0 + (uint32_t)nb, epoch, O_TAG_MOVE);
                 double lu = o_log(o_u52(b.v[0], b.v[1]));
                 if (lu < lls - llx) {                     /* Gen.mh: log(rand()) < weight */
                     for (int k = 0; k < d; ++k) x[k] = xs[k];

@@ -84,6 +84,7 @@ def lib():
     sig("o_wsum", f64, _u64p, u64, _f64p, i32, i32, i64, i32, f64)
     sig("o_normals", None, u64, u32, i64, _f64p)
     sig("o_set_threads", i32, i32)
+    sig("o_set_gid_stride", None, i64)
     sig("o_dereplicate_sample", None, _f64p, i64, i64, i32, i32, u64, u32, _i64p, _f64p)
     # literal Float64 restatement (ref_literal.c)
     sig("lit_logsumexp", f64, _f64p, i64); sig("lit_lognorm", None, _f64p, i64, _f64p)
@@ -521,14 +522,23 @@ class OracleFilter:
 
 
 class OracleSubState:
-    """ParticleFilterSubState (view.jl:16-48) over the contiguous range [start, start+count) of an OracleFilter:
-    numpy views alias the source's arrays; semantics of resample.jl:185-187,205-218 and utils.jl:17-20,174-178."""
+    """ParticleFilterSubState (view.jl:16-48) over the range start : step : start + (count-1) step of an OracleFilter
+    (view.jl:35-48 takes any index vector; the reference's tests use contiguous and strided ranges, e.g. state[k:5:100],
+    test/update.jl:33): numpy views alias the source's arrays; semantics of resample.jl:185-187,205-218 and
+    utils.jl:17-20,174-178.  Per-particle RNG counters stay the GLOBAL particle ids start + i*step; the resample stream of a
+    view is indexed by the slot ids start, start + 1, ... (consecutive from the view's first particle), whatever the step."""
 
-    def __init__(self, source: OracleFilter, start: int, count: int):
-        self.source, self.start, self.n = source, int(start), int(count)
-        self.sl = slice(self.start, self.start + self.n)
+    def __init__(self, source: OracleFilter, start: int, count: int, step: int = 1):
+        self.source, self.start, self.n, self.step = source, int(start), int(count), int(step)
+        self.sl = slice(self.start, self.start + (self.n - 1) * self.step + 1, self.step)
         self.last_obs = source.last_obs
         self.n_accepted = 0
+
+    class _Stride:
+        """per-particle oracle calls inside: local particle i carries the RNG counter gid0 + i*step"""
+        def __init__(self, step): self.step = step
+        def __enter__(self): lib().o_set_gid_stride(self.step)
+        def __exit__(self, *a): lib().o_set_gid_stride(1)
 
     # aliases of the source's arrays (the source may swap its row buffer: always re-derive)
     @property
@@ -552,13 +562,14 @@ class OracleSubState:
         obs = np.ascontiguousarray(obs, np.float64)
         rin = np.ascontiguousarray(self.rows); lw = np.ascontiguousarray(self.lw)
         rout = np.empty_like(rin)
-        if strata is not None:
-            v = np.ascontiguousarray(strata, np.float64)
-            lib().o_step_strata(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.keep_prev), obs, v, v.size,
-                                int(layout != "contiguous"), olog(float(v.size)), rin, rout, lw)
-        else:
-            f = lib().o_step_proposal if proposal else lib().o_step
-            f(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.keep_prev), obs, rin, rout, lw)
+        with self._Stride(self.step):
+            if strata is not None:
+                v = np.ascontiguousarray(strata, np.float64)
+                lib().o_step_strata(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.keep_prev), obs, v, v.size,
+                                    int(layout != "contiguous"), olog(float(v.size)), rin, rout, lw)
+            else:
+                f = lib().o_step_proposal if proposal else lib().o_step
+                f(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.keep_prev), obs, rin, rout, lw)
         s.rows[self.sl] = rout; s.lw[self.sl] = lw
         s.epoch += 1; s.has_prev = True; self.last_obs = obs
         return self
@@ -567,8 +578,9 @@ class OracleSubState:
         s = self.source
         rin = np.ascontiguousarray(self.rows); lw = np.ascontiguousarray(self.lw)
         rout = np.empty_like(rin)
-        self.n_accepted = int(lib().o_move(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.has_prev),
-                                           self.last_obs, int(n_iters), int(method == "reweight"), rin, rout, lw))
+        with self._Stride(self.step):
+            self.n_accepted = int(lib().o_move(s.model, s.params, s.seed, s.epoch, self.start, self.n, s.W, int(s.has_prev),
+                                               self.last_obs, int(n_iters), int(method == "reweight"), rin, rout, lw))
         s.rows[self.sl] = rout; s.lw[self.sl] = lw
         s.epoch += 1
         return self
@@ -631,8 +643,8 @@ def _targets_stratified_view(seed, epoch, start, n, S) -> np.ndarray:
 
 def _oracle_getitem(self, idx):
     start, stop, step = idx.indices(self.n)
-    assert step == 1 and stop > start
-    return OracleSubState(self, start, stop - start)
+    assert step >= 1 and stop > start
+    return OracleSubState(self, start, (stop - start + step - 1) // step, step)
 
 
 OracleFilter.__getitem__ = _oracle_getitem

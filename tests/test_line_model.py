@@ -40,6 +40,9 @@ class OracleDriver:
     def rejuvenate(self, method):
         self.f.rejuvenate(method, 1); return self
 
+    def view(self, sl):                                      # state[idxs] (src/view.jl:35-48): traces and weights of a sub-state
+        v = self.f[sl]; return np.array(v.rows), np.array(v.lw)
+
     rows = property(lambda s: s.f.rows)
     lw = property(lambda s: s.f.lw)
     n_accepted = property(lambda s: s.f.n_accepted)
@@ -77,6 +80,9 @@ class DeviceDriver:
     def rejuvenate(self, method):
         self._acc = self.g.pf_rejuvenate(self.st, self.g.mh if method == "move" else self.g.move_reweight, (), 1, method=method, count=True)
         return self
+
+    def view(self, sl):                                      # state[idxs] through gpf_view_create_strided
+        v = self.st[sl]; return v.traces, v.log_weights
 
     rows = property(lambda s: s.st.traces)
     lw = property(lambda s: s.st.log_weights)
@@ -131,9 +137,11 @@ def test_initialize_with_stratification(g, o, D, layout):
     d = D(g, o).init(1, strata=slopes, layout=layout)
     for k, slope in enumerate(slopes):
         sel = slice(20 * k, 20 * k + 20) if layout == "contiguous" else slice(k, N, 5)            # state[(k-20+1):k] / state[k:5:100]
-        assert np.all(d.rows[sel, 0] == slope)                                                     # :49 / :60
-        exp = [logpdf_normal(0.0, slope, 10.0 if out else 1.0) for out in d.rows[sel, 1]]
-        np.testing.assert_allclose(d.lw[sel], exp, rtol=1e-12, atol=1e-12)
+        vrows, vlw = d.view(sel)                                                                   # get_traces(state[...]), :48 / :59
+        assert vrows.shape[0] == 20 and np.array_equal(vrows, d.rows[sel]) and np.array_equal(vlw, d.lw[sel])
+        assert np.all(vrows[:, 0] == slope)                                                        # :49 / :60
+        exp = [logpdf_normal(0.0, slope, 10.0 if out else 1.0) for out in vrows[:, 1]]
+        np.testing.assert_allclose(vlw, exp, rtol=1e-12, atol=1e-12)
 
 
 # ------------------------------------------------------------------------------------------ test/update.jl
@@ -153,11 +161,13 @@ def test_update_with_stratification(g, o, D, layout):
     logpdf(normal, 0.0, tr[:slope], std)."""
     d = D(g, o).init(0).update(1, strata=[0.0, 1.0], layout=layout)
     for k, val in enumerate([False, True]):
-        sel = slice(50 * k, 50 * k + 50) if layout == "contiguous" else slice(k, N, 2)            # :20 / :33
-        assert np.all((d.rows[sel, 1] != 0) == val)                                                # :21 / :34
+        sel = slice(50 * k, 50 * k + 50) if layout == "contiguous" else slice(k, N, 2)            # :20 state[(50k-49):50k] / :33 state[k:2:100]
+        vrows, vlw = d.view(sel)
+        assert vrows.shape[0] == 50 and np.array_equal(vrows, d.rows[sel]) and np.array_equal(vlw, d.lw[sel])
+        assert np.all((vrows[:, 1] != 0) == val)                                                   # :21 / :34
         std = 10.0 if val else 1.0
-        exp = [logpdf_bernoulli(val, 0.1) + math.log(2) + logpdf_normal(0.0, s, std) for s in d.rows[sel, 0]]   # :23-24 / :36-37
-        np.testing.assert_allclose(d.lw[sel], exp, rtol=1e-12, atol=1e-12)                         # :25 / :38
+        exp = [logpdf_bernoulli(val, 0.1) + math.log(2) + logpdf_normal(0.0, s, std) for s in vrows[:, 0]]      # :23-24 / :36-37
+        np.testing.assert_allclose(vlw, exp, rtol=1e-12, atol=1e-12)                               # :25 / :38
 
 
 @pytest.mark.parametrize("D", DRIVERS)

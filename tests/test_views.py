@@ -49,7 +49,95 @@ def test_oracle_per_view_update_and_rejuvenation(g, o):
     assert np.array_equal(f.rows[:50, 2:4], rows1[:50, 2:4])           # x_{t-1} untouched
 
 
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("alpha", [None, 0.5])
+def test_oracle_blockwise_resampling_interleaved(g, o, method, alpha):
+    """the block-wise resampling test of test/resample.jl:130-162 on INTERLEAVED blocks state[k:5:100] (the index sets of
+    test/initialize.jl:60, test/update.jl:33, test/resize.jl:138): per view new == old[parents], its log-ML estimate is
+    unchanged, the other blocks are untouched, and the whole filter's estimate is unchanged."""
+    m, ys, f = lgssm(g, o)
+    lml_full = f.log_ml_estimate()
+    for k in range(5):
+        v = f[k:100:5]
+        assert v.n == 20
+        before = f.rows.copy()
+        old, lml = v.rows.copy(), v.log_ml_estimate()
+        v.resample(method, priority_alpha=alpha)
+        assert np.array_equal(v.rows, old[v.parents - 1]) and abs(v.log_ml_estimate() - lml) < 1e-9
+        others = np.ones(100, bool); others[k::5] = False
+        assert np.array_equal(f.rows[others], before[others])
+        assert np.all((f.parents[k::5] >= 1) & (f.parents[k::5] <= 20))   # local to the view
+    assert abs(f.log_ml_estimate() - lml_full) < 1e-9 and f.lml_est == 0.0
+
+
+def test_oracle_strided_view_keeps_global_rng_ids(g, o):
+    """pf_update!(state[k:5:100]) for every k with the same observation == ... the particles of view k carry the RNG counters
+    k, k+5, ...: two filters updated through different partitions into strided views agree particle by particle when the
+    epochs agree (one view per filter here), and a strided view differs from a contiguous one over other particles"""
+    m, ys, f = lgssm(g, o)
+    h = o.OracleFilter(m.model_id, m.params, 100, 3, keep_prev=True).initialize(ys[0])
+    f[3:100:5].update(ys[1]); h[3:100:5].update(ys[1])
+    assert np.array_equal(f.rows, h.rows) and np.array_equal(f.lw, h.lw)
+    k = o.OracleFilter(m.model_id, m.params, 100, 3, keep_prev=True).initialize(ys[0])
+    k.update(ys[1])                                                       # whole filter, same epoch: same per-particle streams
+    assert np.array_equal(f.rows[3::5], k.rows[3::5]) and np.array_equal(f.lw[3::5], k.lw[3::5])
+    assert not np.array_equal(f.rows[4::5], k.rows[4::5])                 # untouched by the view
+
+
 # ------------------------------------------------------------------------------------------ GPU parity
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("alpha", [None, 0.5])
+@pytest.mark.parametrize("N,step", [(100, 5), (100, 2), (10_007, 3)])
+def test_hip_strided_views_bitexact(g, o, method, alpha, N, step):
+    """state[k:step:N] for every k (src/view.jl:35-48; test/initialize.jl:60, test/update.jl:33): update, getters, resample and
+    rejuvenation through strided views, against the oracle bit for bit, then the source as a whole"""
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 5)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=6, keep_prev=True)
+    orc = o.OracleFilter(model.model_id, model.params, N, 6, keep_prev=True).initialize(ys[0])
+    pf = None if alpha is None else g.Tempering(alpha)
+    kw = dict(sort_particles=True) if method == "stratified" else {}
+    for k in range(step):
+        sv, ov = st[k:N:step], orc[k:N:step]
+        assert sv.n_particles == ov.n == len(range(k, N, step))
+        y = ys[1 + k % 2]
+        g.pf_update(sv, (2,), (None,), y); ov.update(y)
+        assert np.array_equal(sv.traces, ov.rows) and np.array_equal(sv.log_weights, ov.lw)
+        assert g.get_ess(sv) == ov.effective_sample_size()
+        lml_v = g.get_lml_est(sv)
+        assert lml_v == ov.log_ml_estimate()
+        g.pf_resample(sv, method, priority_fn=pf, check=False, **kw); ov.resample(method, priority_alpha=alpha, check=False, **kw)
+        assert np.array_equal(sv.parents, ov.parents)                 # local to the view
+        np.testing.assert_allclose(g.get_lml_est(sv), lml_v, rtol=1e-9)
+        g.pf_rejuvenate(sv, g.mh, (), 1); ov.rejuvenate("move", 1)
+        assert np.array_equal(sv.traces, ov.rows) and np.array_equal(sv.log_weights, ov.lw)
+        assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw)
+    assert np.array_equal(st.parents, orc.parents)
+    assert g.get_lml_est(st) == orc.log_ml_estimate() and g.get_ess(st) == orc.effective_sample_size()
+    g.pf_resample(st, "multinomial", check=False); orc.resample("multinomial", check=False)
+    g.pf_update(st, (3,), (None,), ys[3]); orc.update(ys[3])
+    assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.parents, orc.parents)
+
+
+@pytest.mark.gpu
+def test_hip_strided_view_set_and_strata(g, o):
+    """writes through a strided view land in the source (gpf_set_log_weights / gpf_set_rows), and a stratified update of a
+    strided view of the discrete-latent model equals the oracle"""
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    st = g.pf_initialize(model, (1,), ys[0], 60, seed=2)
+    v = st[1:60:4]
+    lw = np.linspace(-3.0, 0.0, v.n_particles)
+    v.log_weights = lw
+    assert np.array_equal(st.log_weights[1:60:4], lw) and np.array_equal(v.log_weights, lw)
+    m = g.models.line_model()
+    s2 = g.pf_initialize(m, (0,), g.models.line_obs(0, 0.0), 100, seed=4)
+    o2 = o.OracleFilter(m.model_id, m.params, 100, 4).initialize(g.models.line_obs(0, 0.0))
+    for k in range(2):
+        g.pf_update(s2[k:100:2], (1,), (None,), g.models.line_obs(1, 0.0), [{"outlier": 0.0}, {"outlier": 1.0}], layout="interleaved")
+        o2[k:100:2].update(g.models.line_obs(1, 0.0), strata=[0.0, 1.0], layout="interleaved")
+    assert np.array_equal(s2.traces, o2.rows) and np.array_equal(s2.log_weights, o2.lw)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("alpha", [None, 0.5])
