@@ -120,6 +120,72 @@ __device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v)
     return v;
 }
 
+// ----------------------------------------------------------------------------- shard mailboxes (multi-GPU summaries)
+// The summaries a sharded resample exchanges are 16-40 bytes per rank: (max, flags), {S, sum q^2 limbs}, residual {Ctot, Rs}
+// (SURVEY.md §2.3 C1-C4).  As RCCL all-gathers they cost ~24 us of launch + protocol each, more than the kernels between them.
+// Here the PRODUCING kernel stores them straight into every peer's mailbox (device memory mapped through hipIpc; xGMI peer
+// writes) and the CONSUMING kernel waits for the G tagged entries it needs: no collective, no host involvement, no extra launch.
+//   mailbox = MB_KINDS x MB_SLOTS x { payload [G][words(kind)] u64, dense like the gathered arrays ; tags [MAX_SHARDS] u64 }
+//   round `seq` (1, 2, ... per kind, the same on every rank: SPMD call order) uses slot seq & (MB_SLOTS - 1); entry [src] is
+//   written by rank src alone: payload words (system-scope stores), then its tag = seq (system-scope RELEASE).  A reader spins
+//   on tag == seq (system-scope ACQUIRE), then reads the payload with system-scope loads (they bypass the non-coherent L2, so
+//   the memory type of the mailbox does not matter).  Tags only grow: slots are never cleared; a peer can run at most one
+//   round ahead (it needs this rank's entry of round r to finish round r), so four slots never alias.
+constexpr int MB_KINDS = 3, MB_SLOTS = 4;
+enum : int { MB_MF = 0, MB_TOT = 1, MB_CR = 2 };
+__host__ __device__ constexpr int mb_words(int kind) { return kind == MB_TOT ? 5 : 2; }
+// offsets in u64 words inside a mailbox
+__host__ __device__ constexpr int64_t mb_payload_off(int kind, int slot)
+{
+    int64_t o = 0;
+    for (int k = 0; k < kind; ++k) o += (int64_t)MB_SLOTS * (MAX_SHARDS * mb_words(k) + MAX_SHARDS);
+    return o + (int64_t)slot * (MAX_SHARDS * mb_words(kind) + MAX_SHARDS);
+}
+__host__ __device__ constexpr int64_t mb_tag_off(int kind, int slot) { return mb_payload_off(kind, slot) + (int64_t)MAX_SHARDS * mb_words(kind); }
+constexpr int64_t MB_TOTAL_WORDS = mb_payload_off(MB_KINDS, 0);
+
+__device__ __forceinline__ uint64_t ld_sys(const uint64_t* p) { return __hip_atomic_load(const_cast<uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ int64_t ld_sys(const int64_t* p) { return (int64_t)ld_sys(reinterpret_cast<const uint64_t*>(p)); }
+__device__ __forceinline__ double ld_sys(const double* p) { return u2d(ld_sys(reinterpret_cast<const uint64_t*>(p))); }
+
+struct MboxPush {              // where a producer's summary goes (peers == nullptr: nowhere, the caller gathers it with a collective)
+    uint64_t* const* peers;    // device array [G]: base of every rank's mailbox as mapped HERE (peers[me] = the own one)
+    int64_t payload_off, tag_off;   // of (kind, slot), before the [me] index
+    uint64_t tag;              // = seq
+    int G, me, nwords;
+};
+// wave-collective (all 64 lanes call it with the same words): lane l < G stores this rank's entry into rank l's mailbox
+__device__ __forceinline__ void mbox_push_wave(const MboxPush& p, const uint64_t* words)
+{
+    const int l = lane_id();
+    if (p.peers && l < p.G) {
+        uint64_t* base = p.peers[l];
+        uint64_t* dst = base + p.payload_off + (int64_t)p.me * p.nwords;
+        for (int k = 0; k < p.nwords; ++k) __hip_atomic_store(dst + k, words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(base + p.tag_off + p.me, p.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+struct MboxWait {              // what a consumer waits for (tags == nullptr: nothing -- the data came by a collective or is local)
+    const uint64_t* tags;      // own mailbox + tag_off(kind, slot)
+    uint64_t want;             // = seq
+    int n;                     // ranks
+    int32_t* timeout;          // pinned host flag: set to 2 when a peer's entry did not arrive in time
+};
+constexpr unsigned MB_SPIN_LIMIT = 1u << 23;       // x ~1-2 us per probe: a peer may be ~10 s late (host preempted) before the wait gives up and flags the run
+// block-collective: returns when the entries of all a.n ranks have arrived (threads < n poll one tag each)
+__device__ __forceinline__ void mbox_wait_block(const MboxWait& w)
+{
+    if (!w.tags) return;
+    if ((int)threadIdx.x < w.n) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(const_cast<uint64_t*>(w.tags) + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != w.want) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > MB_SPIN_LIMIT) { __hip_atomic_store(w.timeout, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+    }
+    __syncthreads();
+}
+
 // order-preserving key of Julia's isless on Float64 (-0.0 < 0.0); descending sort = ascending on ~key (K10), and its inverse
 __device__ __forceinline__ uint64_t sort_key_desc(double v)
 {

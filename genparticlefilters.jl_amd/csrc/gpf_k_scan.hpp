@@ -188,6 +188,10 @@ struct ScanExtras {            // optional side jobs of a scan launch
     int64_t* host_flags;       // pinned host {flags, ticket}: publish the validity flags of the weights, or nullptr
     int64_t ticket;
     int64_t n_slots;           // > 0: also write ws_out->{sB, srem, sinv}, the strata of the total over n_slots slots
+    // sharded scans (MODE 3 / 4) with shard mailboxes: wait for the ranks' (max, flags) entries before reading `pmax`; the
+    // workgroup that ends up with the shard total S pushes {S, 0, 0, 0, 0} to every peer (MODE 4: k_export_q pushes S with the limbs)
+    MboxWait wait;
+    MboxPush push;
 };
 constexpr int SCAN_ROWS = 4;
 // MODE 0: plain scan of In; 1: fixed-point weights (folds the max partials); 2: as 1, plus sum q^2 for the ESS;
@@ -221,10 +225,22 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
     if constexpr (MODE >= 1) {
         double m; int f;
         if constexpr (MODE >= 3) {
-            m = -__builtin_huge_val(); f = 0;
-            for (int g = 0; g < np; ++g) { const double v = pmax[2 * g]; m = v > m ? v : m; f |= (int)pmax[2 * g + 1]; }
+            // the np <= 64 gathered (max, flags) pairs: one lane of the first wave each (system-scope loads: the pairs may sit in
+            // this rank's mailbox, written by its peers), folded across the wave, broadcast through LDS
+            mbox_wait_block(ex.wait);
+            if (threadIdx.x < WAVE) {
+                const int g = (int)threadIdx.x;
+                m = g < np ? ld_sys(pmax + 2 * g) : -__builtin_huge_val();
+                f = g < np ? (int)ld_sys(pmax + 2 * g + 1) : 0;
+                m = wave_max_f64(m);
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
+                if (threadIdx.x == 0) { sm[0] = m; sf[0] = f; }
+            }
+            __syncthreads();
+            m = sm[0]; f = sf[0];
             if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
-            (void)sm; (void)sf;
+            __syncthreads();
         } else fold_partials(pmax, pflags, np, sm, sf, m, f);
         in.m = m; in.flags = f;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -313,6 +329,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
                         if ((lane & 7) == 7) reinterpret_cast<uint32_t*>(out.coarse)[(idx + 1) >> 4] = part | (o1 << 16);
                     }
                 }
+            }
+        }
+        if constexpr (MODE == 3) {
+            if (tile == ntiles - 1 && wv == NWAVES - 1) {       // the wave that ends up with the shard total tells every peer
+                const uint64_t Sw = shfl_u64(off + p[2 * SCAN_ROWS - 1], WAVE - 1);
+                const uint64_t words[5] = {Sw, 0, 0, 0, 0};
+                mbox_push_wave(ex.push, words);
             }
         }
         if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) {

@@ -10,18 +10,31 @@ namespace gpf {
 constexpr int64_t SPACE_COUNTS = (int64_t)1 << 62;   // residual: target lives in the copy-count CDF
 constexpr uint64_t STAGE_T_MASK = (1ull << 62) - 1;  // a staged target (T_local < S_local <= 2^62) below its space bit
 
-__global__ void k_pack_mflags(const double* __restrict__ pmax, const int32_t* __restrict__ pflags, int np, double* out2)
+__global__ void k_pack_mflags(const double* __restrict__ pmax, const int32_t* __restrict__ pflags, int np, double* out2, MboxPush push)
 {
     __shared__ double sm[NWAVES];
     __shared__ int sf[NWAVES];
     double m; int f;
     fold_partials(pmax, pflags, np, sm, sf, m, f);
     if (threadIdx.x == 0) { out2[0] = m; out2[1] = (double)(f & (FLAG_NAN | FLAG_POSINF)); }
+    if (wave_id() == 0) {                                   // every lane holds (m, f): straight into the peers' mailboxes
+        const uint64_t words[2] = {d2u(m), d2u((double)(f & (FLAG_NAN | FLAG_POSINF)))};
+        mbox_push_wave(push, words);
+    }
+}
+// host getters: wait for two mailbox rounds and copy their gathered arrays (na / nb words) into ordinary device memory
+// (system-scope loads; the host then copies from there)
+__global__ void k_mbox_collect(MboxWait a, const uint64_t* srca, uint64_t* dsta, int na, MboxWait b, const uint64_t* srcb, uint64_t* dstb, int nb)
+{
+    mbox_wait_block(a); mbox_wait_block(b);
+    for (int i = threadIdx.x; i < na; i += blockDim.x) dsta[i] = ld_sys(srca + i);
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) dstb[i] = ld_sys(srcb + i);
 }
 // {Ql0..3} -> out5[1..4]: limb sums of sum q^2 folded over the scan blocks (exact integers); out5[0] = S_local is written by the scan
-__global__ void k_export_q(const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5)
+__global__ void k_export_q(const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5, MboxPush push)
 {
     __shared__ uint64_t s_q[NWAVES][4];
+    __shared__ uint64_t s_tot[4];
     uint64_t ql[4] = {0, 0, 0, 0};
     for (int b = threadIdx.x; b < nblk; b += BLOCK)
         for (int k = 0; k < 4; ++k) ql[k] += blockQ[(int64_t)b * 4 + k];
@@ -32,21 +45,33 @@ __global__ void k_export_q(const uint64_t* __restrict__ blockQ, int nblk, int64_
         uint64_t t = 0;
         for (int w = 0; w < NWAVES; ++w) t += s_q[w][threadIdx.x];
         out5[1 + threadIdx.x] = (int64_t)t;
+        s_tot[threadIdx.x] = t;
+    }
+    if (push.peers) {                                       // {S, Ql0..3} to every peer (S was written by the scan before this kernel)
+        __syncthreads();
+        if (wave_id() == 0) {
+            const uint64_t words[5] = {(uint64_t)out5[0], s_tot[0], s_tot[1], s_tot[2], s_tot[3]};
+            mbox_push_wave(push, words);
+        }
     }
 }
 // global S (and residual shift) into the device scalar block from the gathered shard totals
 // tot_all = the gathered {S_local, Ql0..3} of all G shards -> the global S
-__global__ void k_set_global(const int64_t* __restrict__ tot_all, int G, WSum* ws)
+__global__ void k_set_global(const int64_t* __restrict__ tot_all, int G, WSum* ws, MboxWait wait)
 {
+    mbox_wait_block(wait);
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint64_t S = 0;
-        for (int g = 0; g < G; ++g) S += (uint64_t)tot_all[5 * g];
+        for (int g = 0; g < G; ++g) S += (uint64_t)ld_sys(tot_all + 5 * g);
         ws->S = S;
     }
 }
-__global__ void k_export_residual(const Scalars* sc, int64_t* out2)
+// (one wave)
+__global__ void k_export_residual(const Scalars* sc, int64_t* out2, MboxPush push)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { out2[0] = (int64_t)sc->Ctot; out2[1] = (int64_t)sc->Rs; }
+    const uint64_t words[2] = {sc->Ctot, sc->Rs};
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out2[0] = (int64_t)words[0]; out2[1] = (int64_t)words[1]; }
+    mbox_push_wave(push, words);
 }
 
 // ---- sharded resampling, the PUSH exchange.  RNG counters are keyed by the GLOBAL slot id, so every
@@ -70,6 +95,7 @@ struct PushArgs {
     int64_t* counts;                              // [2G]: entries sent to each shard | received from each shard
     int64_t* host_counts;                         // pinned host mirror [2 * MAX_SHARDS + 1]: k_push publishes the counts + a ticket
     int64_t ticket;
+    MboxWait wait_tot, wait_cr;                   // shard mailboxes: tot_all / cr_all are filled by the peers' kernels -- wait before reading
 };
 struct PushTables {                               // LDS copy of the per-shard tables
     int64_t w_incl[MAX_SHARDS], c_incl[MAX_SHARDS], bounds[MAX_SHARDS + 1], chunk0[MAX_SHARDS + 1];
@@ -79,10 +105,12 @@ __device__ __forceinline__ void push_tables(const PushArgs& a, PushTables& t)
     // inclusive shard totals of the sampled space (weights, or residual weights) and of the residual copy counts: the
     // first wave, one shard per lane (G <= MAX_SHARDS = 64)
     static_assert(MAX_SHARDS <= WAVE, "one lane per shard");
+    mbox_wait_block(a.wait_tot);
+    mbox_wait_block(a.wait_cr);
     if (threadIdx.x < WAVE) {
         const int g = (int)threadIdx.x;
-        uint64_t w = g < a.G ? (uint64_t)(a.cr_all ? a.cr_all[2 * g + 1] : a.tot_all[5 * g]) : 0;
-        uint64_t c = g < a.G && a.cr_all ? (uint64_t)a.cr_all[2 * g] : 0;
+        uint64_t w = g < a.G ? (uint64_t)(a.cr_all ? ld_sys(a.cr_all + 2 * g + 1) : ld_sys(a.tot_all + 5 * g)) : 0;
+        uint64_t c = g < a.G && a.cr_all ? (uint64_t)ld_sys(a.cr_all + 2 * g) : 0;
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) {
             const uint64_t ow = shfl_up_u64(w, d), oc = shfl_up_u64(c, d);
@@ -315,8 +343,9 @@ __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
     const int h = (int)threadIdx.x;
     const uint64_t N = (uint64_t)a.n_global;
     uint64_t S = 0, lo = 0, lo_me = 0;
+    mbox_wait_block(a.wait_tot);
     for (int g = 0; g < a.G; ++g) {
-        const uint64_t v = (uint64_t)a.tot_all[5 * g];
+        const uint64_t v = (uint64_t)ld_sys(a.tot_all + 5 * g);
         if (g < h) lo += v;
         if (g < a.me) lo_me += v;
         S += v;
@@ -383,7 +412,7 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels 
             __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    const MultiTable tb = multi_table_load<LOGG>(lw_, ntiles, (uint64_t)a.tot_all[5 * a.me], reinterpret_cast<uint32_t*>(smem), [] {});
+    const MultiTable tb = multi_table_load<LOGG>(lw_, ntiles, (uint64_t)ld_sys(a.tot_all + 5 * a.me), reinterpret_cast<uint32_t*>(smem), [] {});
     const int64_t total = s_off[a.G] < capacity ? s_off[a.G] : capacity;
     for (int64_t base = (int64_t)blockIdx.x * NE * SBLOCK; base < total; base += (int64_t)gridDim.x * NE * SBLOCK) {
         int64_t e[NE]; bool act[NE]; uint64_t T[NE]; uint32_t slot[NE];
@@ -425,8 +454,8 @@ __global__ __launch_bounds__(BLOCK) void k_commit_packed(const double* __restric
         double mx = -__builtin_huge_val();
         int f = 0;
         for (int g = 0; g < G; ++g) {
-            S += (uint64_t)tot_all[5 * g];
-            const double v = mf_all[2 * g]; mx = v > mx ? v : mx; f |= (int)mf_all[2 * g + 1];
+            S += (uint64_t)ld_sys(tot_all + 5 * g);
+            const double v = ld_sys(mf_all + 2 * g); mx = v > mx ? v : mx; f |= (int)ld_sys(mf_all + 2 * g + 1);
         }
         if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
         sc->lml_est = sc->lml_est + (lse_from(mx, S, K, f) - logN);

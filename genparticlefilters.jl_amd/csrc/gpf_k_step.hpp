@@ -99,9 +99,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
             uint64_t S = 0;
             double mx = -__builtin_huge_val();
             int f = 0;
-            for (int g = 0; g < pc.G; ++g) {
-                S += (uint64_t)pc.tot_all[5 * g];
-                const double v = pc.mf_all[2 * g]; mx = v > mx ? v : mx; f |= (int)pc.mf_all[2 * g + 1];
+            for (int g = 0; g < pc.G; ++g) {                 // (system-scope loads: the gathered summaries may sit in the shard mailbox)
+                S += (uint64_t)ld_sys(pc.tot_all + 5 * g);
+                const double v = ld_sys(pc.mf_all + 2 * g); mx = v > mx ? v : mx; f |= (int)ld_sys(pc.mf_all + 2 * g + 1);
             }
             if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
             pc.sc->lml_est = pc.sc->lml_est + (lse_from(mx, S, pc.K, f) - pc.logN);

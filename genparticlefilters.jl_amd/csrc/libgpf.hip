@@ -11,6 +11,7 @@
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>        // types and enums only: librccl is loaded with dlopen (gpf_comm_create), nothing links against it
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -114,6 +115,16 @@ struct gpf_filter {
     int comm_rank = 0, comm_world = 1;
     double *sh_mf = nullptr, *sh_mf_all = nullptr; int64_t *sh_tot = nullptr, *sh_tot_all = nullptr, *sh_cr = nullptr, *sh_cr_all = nullptr;
     double *sh_send = nullptr, *sh_recv = nullptr; int64_t sh_send_cap = 0, sh_recv_cap = 0;
+    // shard mailboxes (gpf_k_common.hpp): the three small summaries of a sharded resample travel as peer stores from the
+    // producing kernel into every rank's mailbox instead of RCCL all-gathers
+    uint64_t* mbox = nullptr;            // this rank's mailbox (device memory, exported through hipIpc)
+    uint64_t** mb_peers = nullptr;       // device array [world]: every rank's mailbox as mapped in this process
+    std::vector<void*> mb_opened;        // peers' mailboxes opened with hipIpcOpenMemHandle (closed by gpf_comm_destroy)
+    bool mb_active = false;
+    bool mb_engine = false;              // set by the library engine around its phase calls: they push / wait through the mailbox
+    const double* cur_mf_all = nullptr; const int64_t* cur_tot_all = nullptr; const int64_t* cur_cr_all = nullptr;   // the gathered summaries of the current round
+    uint64_t mb_seq[MB_KINDS] = {0, 0, 0};   // rounds so far per kind: the same on every rank (SPMD call order)
+    uint64_t mb_cur[MB_KINDS] = {0, 0, 0};   // the round whose entries the current gathered pointers name
     int32_t* h_timeout = nullptr;        // pinned: set by a scan whose bounded inter-workgroup wait gave up (checked on the host)
     int scan_blocks_per_cu = 2;          // resident scan workgroups per CU the launch may rely on (occupancy query)
     int64_t* shard_counts = nullptr;     // [2 * MAX_SHARDS] exchange counters of the current resample (device) + pinned mirror
@@ -189,6 +200,34 @@ gpf_status timed(gpf_filter* h, int id, F&& launch)
     g_ev_start = g_ev_stop = nullptr;
     t.ev.emplace_back(a, b);
     return GPF_OK;
+}
+
+// ------------------------------------------------------------------ shard mailboxes (host side)
+// begin a new round of `kind` (the producing kernel of this call pushes it); no mailbox / not the library engine: push nowhere
+MboxPush mb_begin(gpf_filter* h, int kind)
+{
+    MboxPush p{};
+    if (!(h->mb_active && h->mb_engine)) return p;
+    const uint64_t seq = ++h->mb_seq[kind];
+    h->mb_cur[kind] = seq;
+    const int slot = (int)(seq & (MB_SLOTS - 1));
+    p.peers = h->mb_peers; p.payload_off = mb_payload_off(kind, slot); p.tag_off = mb_tag_off(kind, slot);
+    p.tag = seq; p.G = h->comm_world; p.me = h->comm_rank; p.nwords = mb_words(kind);
+    return p;
+}
+// what a consumer of the current round of `kind` waits for
+MboxWait mb_wait(const gpf_filter* h, int kind)
+{
+    MboxWait w{};
+    if (!(h->mb_active && h->mb_engine)) return w;
+    const uint64_t seq = h->mb_cur[kind];
+    w.tags = h->mbox + mb_tag_off(kind, (int)(seq & (MB_SLOTS - 1))); w.want = seq; w.n = h->comm_world; w.timeout = h->h_timeout;
+    return w;
+}
+// the gathered array of the current round of `kind` inside the own mailbox ([G][words], dense like the all-gather's output)
+const void* mb_gathered(const gpf_filter* h, int kind)
+{
+    return h->mbox + mb_payload_off(kind, (int)(h->mb_cur[kind] & (MB_SLOTS - 1)));
 }
 
 // ------------------------------------------------------------------ per-N device buffers
@@ -531,6 +570,8 @@ gpf_status wait_ticket(gpf_filter* h, volatile int64_t* tk, int64_t want, const 
 // a scan whose bounded inter-workgroup wait gave up leaves garbage prefixes behind: fail loudly at the next host touch point
 gpf_status check_scan_timeout(gpf_filter* h)
 {
+    if (h->h_timeout && __atomic_load_n(h->h_timeout, __ATOMIC_ACQUIRE) == 2)
+        return fail(h, GPF_ERR_HIP, "sharded resample: a peer's summary did not arrive in its mailbox in time (a rank is down or far behind); results are invalid");
     if (h->h_timeout && __atomic_load_n(h->h_timeout, __ATOMIC_ACQUIRE) != 0)
         return fail(h, GPF_ERR_HIP, "scan kernel: bounded inter-workgroup wait timed out (workgroups not co-resident?); results are invalid");
     return GPF_OK;
@@ -1820,7 +1861,7 @@ gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
         if (s) return s;
     }
     h->max_valid = false;            // gpf_shard_weight_scan overwrites pmax[0] with the global maximum
-    GPF_LAUNCH(k_pack_mflags, dim3(1), dim3(BLOCK), 0, h->stream, h->pmax, h->pflags, gp, out2);
+    GPF_LAUNCH(k_pack_mflags, dim3(1), dim3(BLOCK), 0, h->stream, h->pmax, h->pflags, gp, out2, mb_begin(h, MB_MF));
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
@@ -1842,11 +1883,17 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     // publishes the global validity flags to pinned host memory (gpf_shard_flags)
     if (!h->h_flags) { HIP_TRY(h, hipHostMalloc(&h->h_flags, 2 * sizeof(int64_t))); h->h_flags[0] = h->h_flags[1] = 0; }
     h->flag_ticket += 1;
+    // shard mailboxes: the scan waits for the ranks' (max, flags) entries itself and the kernel that ends up with the shard's
+    // {S, limbs} stores them into every peer's mailbox (the scan's last workgroup, or k_export_q when the limbs are wanted)
+    ScanExtras ex{h->shard_counts, h->h_flags, h->flag_ticket, 0};
+    ex.wait = mb_wait(h, MB_MF);
+    const MboxPush tot_push = mb_begin(h, MB_TOT);
     if (want_q) {
-        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, h->h_flags, h->flag_ticket, 0}))) return s;
-        GPF_LAUNCH(k_export_q, dim3(1), dim3(BLOCK), 0, h->stream, h->blockQ, gs, out5);
+        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ex))) return s;
+        GPF_LAUNCH(k_export_q, dim3(1), dim3(BLOCK), 0, h->stream, h->blockQ, gs, out5, tot_push);
     } else {
-        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ScanExtras{h->shard_counts, h->h_flags, h->flag_ticket, 0}))) return s;
+        ex.push = tot_push;
+        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ex))) return s;
     }
     HIP_TRY(h, hipGetLastError());
     h->raw_valid = false;            // sc->raw holds the GLOBAL max but no sum: not the unsharded summary
@@ -1869,9 +1916,9 @@ gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t
     if (s) return s;
     if (!tot_all || !out2 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     // global S into sc->prio (the local CDF in cdf[0] stays local)
-    GPF_LAUNCH(k_set_global, dim3(1), dim3(64), 0, h->stream, tot_all, (int)G, &h->sc->prio);
+    GPF_LAUNCH(k_set_global, dim3(1), dim3(64), 0, h->stream, tot_all, (int)G, &h->sc->prio, mb_wait(h, MB_TOT));
     if ((s = residual_scans(h, &h->sc->prio, h->cfg.n_global))) return s;
-    GPF_LAUNCH(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2);
+    GPF_LAUNCH(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2, mb_begin(h, MB_CR));
     HIP_TRY(h, hipGetLastError());
     h->residual_scanned = true;
     return GPF_OK;
@@ -1900,6 +1947,8 @@ static gpf_status push_args(gpf_handle h, int32_t method, const int64_t* tot_all
         HIP_TRY(h, hipMalloc(&h->push_stage, (size_t)h->cfg.n_global * sizeof(ulonglong2)));
         h->push_cap = h->cfg.n_global;
     }
+    a.wait_tot = mb_wait(h, MB_TOT);
+    a.wait_cr = method == GPF_RESAMPLE_RESIDUAL ? mb_wait(h, MB_CR) : MboxWait{};
     a.tot_all = tot_all; a.cr_all = method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr; a.stage = h->push_stage; a.counts = h->shard_counts; a.host_counts = h->h_shard_counts; a.ticket = h->push_ticket;
     return GPF_OK;
 }
@@ -2112,21 +2161,34 @@ gpf_status shard_scratch(gpf_filter* h)
     HIP_TRY(h, hipMemsetAsync(h->sh_tot, 0, 5 * sizeof(int64_t), h->stream));
     return GPF_OK;
 }
-// phases 1 + 2 of DESIGN.md §6: (max, flags) and {S, sum q^2 limbs} of every shard, gathered on every rank
+// phases 1 + 2 of DESIGN.md §6: (max, flags) and {S, sum q^2 limbs} of every shard, gathered on every rank -- through the shard
+// mailboxes (peer stores from the producing kernels, waits in the consuming ones: no collective) or two RCCL all-gathers.
+// Leaves h->cur_mf_all / cur_tot_all naming the gathered arrays of this round.
+struct EngineScope { gpf_filter* h; explicit EngineScope(gpf_filter* f) : h(f) { h->mb_engine = true; } ~EngineScope() { h->mb_engine = false; } };
 gpf_status shard_summary(gpf_filter* h, int want_q)
 {
     gpf_status s = shard_scratch(h);
     if (s) return s;
+    const bool mb = h->mb_active;
     if ((s = gpf_shard_weight_max(h, h->sh_mf))) return s;
-    if ((s = shard_all_gather(h, h->sh_mf, h->sh_mf_all, 2, ncclDouble, sizeof(double)))) return s;
-    if ((s = gpf_shard_weight_scan(h, h->sh_mf_all, h->comm_world, want_q, h->sh_tot))) return s;
-    return shard_all_gather(h, h->sh_tot, h->sh_tot_all, 5, ncclInt64, sizeof(int64_t));
+    if (!mb && (s = shard_all_gather(h, h->sh_mf, h->sh_mf_all, 2, ncclDouble, sizeof(double)))) return s;
+    h->cur_mf_all = mb ? static_cast<const double*>(mb_gathered(h, MB_MF)) : h->sh_mf_all;
+    if ((s = gpf_shard_weight_scan(h, h->cur_mf_all, h->comm_world, want_q, h->sh_tot))) return s;
+    if (!mb && (s = shard_all_gather(h, h->sh_tot, h->sh_tot_all, 5, ncclInt64, sizeof(int64_t)))) return s;
+    h->cur_tot_all = mb ? static_cast<const int64_t*>(mb_gathered(h, MB_TOT)) : h->sh_tot_all;
+    return GPF_OK;
 }
 // the gathered summaries on the host: global max, flags, S and sum q^2
 gpf_status shard_scalars(gpf_filter* h, double& m, int& flags, uint64_t& S, uint64_t& Qhi, uint64_t& Qlo)
 {
     const int G = h->comm_world;
     std::vector<double> mf(2 * (size_t)G); std::vector<int64_t> tot(5 * (size_t)G);
+    if (h->mb_active) {                                          // wait for the peers' entries, then out of the mailbox into plain device memory
+        GPF_LAUNCH(k_mbox_collect, dim3(1), dim3(BLOCK), 0, h->stream, mb_wait(h, MB_MF), reinterpret_cast<const uint64_t*>(h->cur_mf_all),
+                   reinterpret_cast<uint64_t*>(h->sh_mf_all), 2 * G, mb_wait(h, MB_TOT), reinterpret_cast<const uint64_t*>(h->cur_tot_all),
+                   reinterpret_cast<uint64_t*>(h->sh_tot_all), 5 * G);
+        HIP_TRY(h, hipGetLastError());
+    }
     HIP_TRY(h, hipMemcpyAsync(mf.data(), h->sh_mf_all, mf.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(tot.data(), h->sh_tot_all, tot.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2140,9 +2202,88 @@ gpf_status shard_scalars(gpf_filter* h, double& m, int& flags, uint64_t& S, uint
     Qhi = (uint64_t)(Q >> 64); Qlo = (uint64_t)Q;
     return check_scan_timeout(h);
 }
+// ---- shard mailboxes: allocation, hipIpc exchange of the handles over the communicator that was just created, peer mapping.
+// Every decision is taken from data all ranks hold identically (the all-gathered packets), so either every rank ends with the
+// mailboxes up or every rank stays on the RCCL all-gathers.  Any failure is soft: the collectives remain.
+void mailbox_teardown(gpf_filter* h)
+{
+    for (void* p : h->mb_opened) (void)hipIpcCloseMemHandle(p);
+    h->mb_opened.clear();
+    if (h->mb_peers) (void)hipFree(h->mb_peers);
+    if (h->mbox) (void)hipFree(h->mbox);
+    h->mb_peers = nullptr; h->mbox = nullptr; h->mb_active = false;
+}
+struct MboxPacket { hipIpcMemHandle_t handle; int64_t ok; int64_t pid; };
+gpf_status mailbox_setup(gpf_filter* h)
+{
+    const char* mode = getenv("GPF_SHARD_SUMMARY");               // "rccl": keep the all-gathers (A/B measurements, fallback drills)
+    if (mode && !strcmp(mode, "rccl")) return GPF_OK;
+    const int G = h->comm_world, me = h->comm_rank;
+    if (!h->comm) return GPF_OK;                                  // a single shard without communicator aliases its own summaries
+    const size_t bytes = (size_t)MB_TOTAL_WORDS * sizeof(uint64_t);
+    int64_t ok = 1;
+    // uncached device memory (peers write it, system-scope loads read it); plain device memory serves as well
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&h->mbox), bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&h->mbox, bytes) != hipSuccess) { (void)hipGetLastError(); h->mbox = nullptr; ok = 0; }
+    }
+    if (h->mbox) { HIP_TRY(h, hipMemsetAsync(h->mbox, 0, bytes, h->stream)); HIP_TRY(h, hipStreamSynchronize(h->stream)); }
+    std::vector<MboxPacket> all((size_t)G);
+    MboxPacket mine{};
+    mine.pid = (int64_t)getpid();
+    if (G > 1 && ok) {
+        if (hipIpcGetMemHandle(&mine.handle, h->mbox) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+    }
+    mine.ok = ok;
+    auto gather = [&](const void* src, void* dst_host, size_t each) -> gpf_status {   // all-gather of `each` bytes per rank, host to host
+        if (G == 1) { memcpy(dst_host, src, each); return GPF_OK; }
+        char *dsrc = nullptr, *ddst = nullptr;
+        HIP_TRY(h, hipMalloc(&dsrc, each)); HIP_TRY(h, hipMalloc(&ddst, each * G));
+        HIP_TRY(h, hipMemcpyAsync(dsrc, src, each, hipMemcpyHostToDevice, h->stream));
+        NCCL_TRY(h, g_rccl.AllGather(dsrc, ddst, each, ncclInt8, h->comm, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(dst_host, ddst, each * G, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(dsrc); (void)hipFree(ddst);
+        return GPF_OK;
+    };
+    gpf_status s = gather(&mine, all.data(), sizeof(MboxPacket));
+    if (s) { mailbox_teardown(h); return s; }                     // (a failed collective is not soft: the communicator is unusable)
+    bool all_ok = true;
+    for (int r = 0; r < G; ++r) {
+        all_ok = all_ok && all[r].ok != 0;
+        if (r != me && all[r].pid == mine.pid) all_ok = false;    // two shards in one process: hipIpc cannot map a handle of its own process
+    }
+    if (!all_ok) { mailbox_teardown(h); return GPF_OK; }
+    std::vector<uint64_t*> peers((size_t)G, nullptr);
+    int64_t opened = 1;
+    for (int r = 0; r < G && opened; ++r) {
+        if (r == me) { peers[r] = h->mbox; continue; }
+        void* ptr = nullptr;
+        if (hipIpcOpenMemHandle(&ptr, all[r].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); opened = 0; break; }
+        h->mb_opened.push_back(ptr);
+        peers[r] = static_cast<uint64_t*>(ptr);
+    }
+    std::vector<int64_t> oks((size_t)G, 0);
+    if ((s = gather(&opened, oks.data(), sizeof(int64_t)))) { mailbox_teardown(h); return s; }
+    for (int r = 0; r < G; ++r) if (!oks[r]) { mailbox_teardown(h); return GPF_OK; }
+    HIP_TRY(h, hipMalloc(&h->mb_peers, (size_t)G * sizeof(uint64_t*)));
+    HIP_TRY(h, hipMemcpy(h->mb_peers, peers.data(), (size_t)G * sizeof(uint64_t*), hipMemcpyHostToDevice));
+    for (int k = 0; k < MB_KINDS; ++k) h->mb_seq[k] = h->mb_cur[k] = 0;
+    h->mb_active = true;
+    return GPF_OK;
+}
 } // namespace
 
 extern "C" {
+
+/* 1: the handle's sharded resamples exchange their summaries through the shard mailboxes (peer stores, no collective);
+ * 0: through RCCL all-gathers (or there is nothing to exchange: one shard) */
+gpf_status gpf_comm_summary_mode(gpf_handle h, int32_t* mailbox)
+{
+    if (!h || !mailbox) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    *mailbox = h->mb_active ? 1 : 0;
+    return GPF_OK;
+}
 
 gpf_status gpf_comm_unique_id(void* id128)
 {
@@ -2172,7 +2313,9 @@ gpf_status gpf_comm_create(gpf_handle h, const void* id128, int32_t rank, int32_
         memcpy(&id, id128, sizeof(id));
         NCCL_TRY(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
     }
-    return shard_scratch(h);
+    gpf_status s = shard_scratch(h);
+    if (s) return s;
+    return mailbox_setup(h);
 }
 
 gpf_status gpf_comm_destroy(gpf_handle h)
@@ -2185,6 +2328,8 @@ gpf_status gpf_comm_destroy(gpf_handle h)
     if (h->pending_packed && h->initialized && h->rows[0]) ms = materialize(h);
     h->pending_packed = false; h->pend_packed = nullptr; h->pend_mf = nullptr; h->pend_tot = nullptr; h->pend_G = 0;
     if (h->stream) hipStreamSynchronize(h->stream);
+    mailbox_teardown(h);
+    h->cur_mf_all = nullptr; h->cur_tot_all = h->cur_cr_all = nullptr;
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
     void* bufs[] = {h->sh_mf, h->sh_mf_all != h->sh_mf ? h->sh_mf_all : nullptr, h->sh_tot, h->sh_tot_all != h->sh_tot ? h->sh_tot_all : nullptr,
@@ -2204,6 +2349,7 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
     if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_shard_resample needs gpf_comm_create first");
     const int G = h->comm_world, me = h->comm_rank;
     const int64_t n = h->n, E = h->W + 1;
+    EngineScope engine(h);                                        // the phases below push / wait through the shard mailboxes when they are up
     // shard bounds from the contiguous-range rule every rank applies to its own gpf_config (ranks ordered by gid0)
     std::vector<int64_t> bounds((size_t)G + 1);
     {
@@ -2247,16 +2393,17 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
         if (check == GPF_CHECK_TRUE && flags) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights.");   // resample.jl:55
     }
     const int64_t* cr_all = nullptr;
+    const int64_t* tot_all = h->cur_tot_all;
     if (method == GPF_RESAMPLE_RESIDUAL) {                        // phase 2b
-        if ((s = gpf_shard_residual_scan(h, h->sh_tot_all, G, h->sh_cr))) return s;
-        if ((s = shard_all_gather(h, h->sh_cr, h->sh_cr_all, 2, ncclInt64, sizeof(int64_t)))) return s;
-        cr_all = h->sh_cr_all;
+        if ((s = gpf_shard_residual_scan(h, tot_all, G, h->sh_cr))) return s;
+        if (!h->mb_active && (s = shard_all_gather(h, h->sh_cr, h->sh_cr_all, 2, ncclInt64, sizeof(int64_t)))) return s;
+        cr_all = h->cur_cr_all = h->mb_active ? static_cast<const int64_t*>(mb_gathered(h, MB_CR)) : h->sh_cr_all;
     }
-    if ((s = gpf_shard_push_count(h, method, h->sh_tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
+    if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
     // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
     // counts say it overflowed
     const int64_t pushed_cap = std::min(cap, h->sh_send_cap);
-    if ((s = gpf_shard_push(h, method, h->sh_tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
+    if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
     std::vector<int64_t> counts(2 * (size_t)G);
     if ((s = gpf_shard_counts(h, G, counts.data()))) return s;   // ONE host wait (the exchange's split sizes), behind phase 4
     int64_t n_send = 0, n_recv = 0;
@@ -2277,7 +2424,7 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
         }
     }
     if (n_send > pushed_cap)
-        remember(gpf_shard_push(h, method, h->sh_tot_all, cr_all, G, me, bounds.data(), n_send, h->sh_send));
+        remember(gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), n_send, h->sh_send));
     // the exchange: [row | slot | ancestor id], grouped point-to-point sends and receives (one pair per PEER; the shard's own
     // entries never touch RCCL: one device-to-device copy on the same stream)
     const double* commit_from = h->sh_send;
@@ -2306,7 +2453,7 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
         }
     }
     if (late) { h->err = late_msg; return late; }
-    return gpf_shard_commit(h, commit_from, n, h->sh_mf_all, h->sh_tot_all, G);                      // phase 5 (deferred)
+    return gpf_shard_commit(h, commit_from, n, h->cur_mf_all, tot_all, G);                           // phase 5 (deferred)
 }
 
 gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out)
@@ -2315,6 +2462,7 @@ gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out)
     if (s) return s;
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
     if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "needs gpf_comm_create first");
+    EngineScope engine(h);
     if ((s = shard_summary(h, 1))) return s;
     double m; int flags; uint64_t S, Qhi, Qlo;
     if ((s = shard_scalars(h, m, flags, S, Qhi, Qlo))) return s;
@@ -2328,6 +2476,7 @@ gpf_status gpf_shard_log_ml_estimate(gpf_handle h, double* out)
     if (s) return s;
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
     if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "needs gpf_comm_create first");
+    EngineScope engine(h);
     if ((s = shard_summary(h, 0))) return s;
     double m; int flags; uint64_t S, Qhi, Qlo;
     if ((s = shard_scalars(h, m, flags, S, Qhi, Qlo))) return s;

@@ -163,6 +163,15 @@ class HipShardBackend:
         self.lib_comm = True
         self._rccl_world = world if idbuf is not None else 0      # no id: a single shard without any RCCL communicator
 
+    def summary_mode(self) -> str:
+        """how the small summaries of a sharded resample travel: "mailbox" (peer stores from the producing kernels, gpf.h
+        gpf_comm_summary_mode), "rccl" (all-gathers issued by the library), "torch.distributed" (python engine), "none" (one shard)"""
+        if not self.lib_comm:
+            return "torch.distributed"
+        mb = C.c_int32(0)
+        self._ck(self.L.gpf_comm_summary_mode(self.h, C.byref(mb)))
+        return "mailbox" if mb.value else ("rccl" if self.comm_world() else "none")
+
     def comm_world(self) -> int:
         """ranks of the library's RCCL communicator (0: none)"""
         return getattr(self, "_rccl_world", 0)

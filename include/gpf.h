@@ -313,6 +313,12 @@ double  gpf_host_ess(uint64_t S, uint64_t Q_hi, uint64_t Q_lo);           /* S^2
 gpf_status gpf_comm_unique_id(void* id128);
 gpf_status gpf_comm_create(gpf_handle h, const void* id128, int32_t rank, int32_t world);
 gpf_status gpf_comm_destroy(gpf_handle h);
+/* How the three small summaries of a sharded resample -- (max, flags), {S, sum q^2 limbs}, the residual counts; 16-40 bytes per rank
+ *  -- travel: *mailbox = 1: the producing kernel stores them straight into every peer's mailbox (device
+ * memory mapped with hipIpc at gpf_comm_create, xGMI peer writes) and the consuming kernel waits for them -- no collective, no
+ * launch, no host; 0: RCCL all-gathers (hipIpc mapping not possible on this system, or GPF_SHARD_SUMMARY=rccl in the environment).
+ * Every rank of a communicator is in the same mode.  The row exchange itself is always grouped ncclSend / ncclRecv. */
+gpf_status gpf_comm_summary_mode(gpf_handle h, int32_t* mailbox);
 gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid);
 gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out);
 gpf_status gpf_shard_log_ml_estimate(gpf_handle h, double* out);

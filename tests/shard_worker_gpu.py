@@ -41,7 +41,7 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
             lml_log.append(sharded.get_lml_est(st))
         loc = st.local
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents,
-                 gid0=st.gid0, ess=np.array(ess_log), lml=np.array(lml_log))
+                 gid0=st.gid0, ess=np.array(ess_log), lml=np.array(lml_log), summaries=st.backend.summary_mode())
     finally:
         dist.destroy_process_group()
 

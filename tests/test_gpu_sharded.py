@@ -125,6 +125,25 @@ def test_library_engine_several_ranks_over_loopback(g, o, tmp_path, monkeypatch,
     test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
 
 
+@pytest.mark.parametrize("mode", ["mailbox", "rccl"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_library_engine_summary_transport(g, o, tmp_path, monkeypatch, loopback_lib, world, mode):
+    """the two ways the (max, flags) / {S, Q} / residual summaries travel between ranks: shard mailboxes (hipIpc-mapped device
+    memory, peer stores from the producing kernels, waits in the consuming ones -- the default) and RCCL all-gathers
+    (GPF_SHARD_SUMMARY=rccl, also the automatic fallback).  Both must be the mode they claim and give the oracle's result for
+    all three resamplers (CASES[0..2]) plus the ESS-triggered bearings run with rejuvenation."""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
+    monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    if mode == "rccl":
+        monkeypatch.setenv("GPF_SHARD_SUMMARY", "rccl")
+    else:
+        monkeypatch.delenv("GPF_SHARD_SUMMARY", raising=False)
+    for case in CASES[:4]:
+        test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
+        for r in range(world):
+            assert str(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["summaries"]) == mode
+
+
 @pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
 @pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
 def test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern):
