@@ -148,6 +148,9 @@ __device__ __forceinline__ uint64_t ld_sys(const uint64_t* p) { return __hip_ato
 __device__ __forceinline__ int64_t ld_sys(const int64_t* p) { return (int64_t)ld_sys(reinterpret_cast<const uint64_t*>(p)); }
 __device__ __forceinline__ double ld_sys(const double* p) { return u2d(ld_sys(reinterpret_cast<const uint64_t*>(p))); }
 
+// gathered summaries that MAY sit in the mailbox: system-scope loads there, ordinary (cached) loads when they came by a collective
+template <class T> __device__ __forceinline__ T ld_gathered(const T* p, bool in_mailbox) { return in_mailbox ? ld_sys(p) : *p; }
+
 struct MboxPush {              // where a producer's summary goes (peers == nullptr: nowhere, the caller gathers it with a collective)
     uint64_t* const* peers;    // device array [G]: base of every rank's mailbox as mapped HERE (peers[me] = the own one)
     int64_t payload_off, tag_off;   // of (kind, slot), before the [me] index

@@ -30,12 +30,14 @@ __global__ __launch_bounds__(BLOCK) void k_max_partial(PrioView pv, int64_t n, d
 }
 
 // fold the partials: every lane of the block ends with (m, flags); needs 2 LDS arrays of NWAVES
+template <int NT = BLOCK>
 __device__ __forceinline__ void fold_partials(const double* __restrict__ pmax, const int32_t* __restrict__ pflags,
                                               int np, double* sm, int* sf, double& m_out, int& f_out)
 {
+    constexpr int NWAVES = NT / WAVE;
     double m = -__builtin_huge_val();
     int f = 0;
-    for (int i = threadIdx.x; i < np; i += BLOCK) { const double v = pmax[i]; m = v > m ? v : m; f |= pflags[i]; }
+    for (int i = threadIdx.x; i < np; i += NT) { const double v = pmax[i]; m = v > m ? v : m; f |= pflags[i]; }
     m = wave_max_f64(m);
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
@@ -164,7 +166,23 @@ struct ScanOut {
     int logg;
     uint32_t* k32s;            // [ntiles*64 >> sample] every (1 << sample)-th key, compact: the LDS table of k_search_multi_s (nullptr: not wanted)
     int sample;
+    // k_search_fine's levels (nullptr: not wanted; they share the buffer space of off16 / coarse / k32s -- one family per scan):
+    uint32_t* k1024;           // [ntiles*2]    4-byte key (prefix >> KEY_SHIFT) at the end of every 1024-cell super-group
+    uint16_t* d16;             // [ntiles*128]  the prefix at the end of every 16-cell group as a 16-bit offset inside its super-group (key_quant_shift)
+    uint8_t*  o8;              // [ntiles*2048] every prefix as an 8-bit offset inside its 16-cell group (fine_quant)
 };
+// ---- the 8-bit level of k_search_fine.  A 16-cell group g lies inside a 1024-cell super-group with end keys (klo, khi), shift
+// sh = key_quant_shift(klo, khi) and base kb = klo << KEY_SHIFT; dprev / dg are the 16-bit offsets of the prefixes at the group's
+// two ends (dprev = 0 for the first group of a super-group).  Both sides -- the scan that writes the level and the search that
+// quantises a target -- derive the SAME (base, shift) from these four numbers alone:
+//     base = kb + (dprev << sh)  (<= every prefix of the group),   span < (dg - dprev + 1) << sh,   x -> (x - base) >> sh8 <= 255.
+struct FineQuant { uint64_t base; int sh8; };
+__device__ __forceinline__ FineQuant fine_quant(uint64_t kb, int sh, uint32_t dprev, uint32_t dg)
+{
+    const uint32_t dd = dg - dprev;                           // (dd + 1) << sh bounds the group's span
+    const int bits = dd ? 32 - (int)__builtin_clz(dd) : 0;    // = ceil(log2(dd + 1))
+    return FineQuant{kb + ((uint64_t)dprev << sh), sh + (bits > 8 ? bits - 8 : 0)};
+}
 constexpr int KEY_SHIFT = 30;  // S <= 2^62: (prefix >> 30) fits 32 bits whatever N is, once the one value 2^62 is saturated
 // S = 2^62 exactly when N >= 1024 is a power of two and EVERY weight equals the maximum (a second resample right after a
 // resample: all log-weights 0).  For the keys and the 16-bit offsets such a prefix counts as 2^62 - 1: the maps stay monotone, no
@@ -193,11 +211,21 @@ struct ScanExtras {            // optional side jobs of a scan launch
     MboxWait wait;
     MboxPush push;
 };
-constexpr int SCAN_ROWS = 4;
+// Workgroup of the scan kernels: SCAN_BLOCK threads over one 2048-element tile, every wave SCAN_ROWS rows of 128.  512 threads
+// (8 waves, 2 rows each; two workgroups per CU = 16 waves per CU) hide the kernel's three dependent round trips -- weights in,
+// aggregates of the earlier tiles, levels out -- twice as well as 256 x 4 rows did (r02: 7.6 waves per CU, 65 % of the wave
+// cycles waiting; profiles/r03_scan_phases.txt).
+#ifndef GPF_SCAN_BLOCK
+#define GPF_SCAN_BLOCK 512
+#endif
+constexpr int SCAN_BLOCK = GPF_SCAN_BLOCK;
+constexpr int SCAN_NWAVES = SCAN_BLOCK / WAVE;
+constexpr int SCAN_ROWS = TILE / (2 * SCAN_BLOCK);
+static_assert(SCAN_ROWS * 2 * SCAN_BLOCK == TILE && SCAN_ROWS >= 2 && SCAN_ROWS % 2 == 0, "a wave owns whole 256-element groups");
 // MODE 0: plain scan of In; 1: fixed-point weights (folds the max partials); 2: as 1, plus sum q^2 for the ESS;
 // 3 / 4: as 1 / 2 with the maximum and flags taken from the np gathered (max, flags) pairs of the shards (pmax = mf_all)
 template <class In, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles,
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t ntiles,
                                                 const double* __restrict__ pmax, const int32_t* __restrict__ pflags,
                                                 int np, WSum* __restrict__ ws_out, ScanOut out,
                                                 uint64_t* __restrict__ dcur, uint64_t* __restrict__ dnext,
@@ -207,13 +235,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
     // (ex.n_slots: the thread that ends up with the total also leaves the stratum width of S over n_slots output slots)
     // sharded resamples: the exchange counters of the push pass that follows are cleared here (no memset node)
     if (ex.zero128 && blockIdx.x == 0 && threadIdx.x < 2 * MAX_SHARDS) ex.zero128[threadIdx.x] = 0;
-    __shared__ double sm[NWAVES];
-    __shared__ int sf[NWAVES];
-    __shared__ uint64_t s_wave[NWAVES];
-    __shared__ uint64_t s_red[NWAVES];
+    __shared__ double sm[SCAN_NWAVES];
+    __shared__ int sf[SCAN_NWAVES];
+    __shared__ uint64_t s_wave[SCAN_NWAVES];
+    __shared__ uint64_t s_red[SCAN_NWAVES];
     uint64_t* const d_agg = dcur;
     uint64_t* const d_pre = dcur + ntiles;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * BLOCK) dnext[i] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * SCAN_BLOCK) dnext[i] = 0;
     constexpr bool WANT_Q = MODE == 2 || MODE == 4;
     // the first tile's log-weights are loaded BEFORE the partial maxima are folded (they need neither m nor the flags)
     double pre[2 * SCAN_ROWS];
@@ -230,8 +258,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
             mbox_wait_block(ex.wait);
             if (threadIdx.x < WAVE) {
                 const int g = (int)threadIdx.x;
-                m = g < np ? ld_sys(pmax + 2 * g) : -__builtin_huge_val();
-                f = g < np ? (int)ld_sys(pmax + 2 * g + 1) : 0;
+                const bool mb = ex.wait.tags != nullptr;
+                m = g < np ? ld_gathered(pmax + 2 * g, mb) : -__builtin_huge_val();
+                f = g < np ? (int)ld_gathered(pmax + 2 * g + 1, mb) : 0;
                 m = wave_max_f64(m);
 #pragma unroll
                 for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
@@ -241,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
             m = sm[0]; f = sf[0];
             if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
             __syncthreads();
-        } else fold_partials(pmax, pflags, np, sm, sf, m, f);
+        } else fold_partials<SCAN_BLOCK>(pmax, pflags, np, sm, sf, m, f);
         in.m = m; in.flags = f;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             ws_out->m = m; ws_out->flags = f;
@@ -284,21 +313,35 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
         __syncthreads();
         uint64_t wexcl = 0, agg = 0;
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) { if (w < wv) wexcl += s_wave[w]; agg += s_wave[w]; }
+        for (int w = 0; w < SCAN_NWAVES; ++w) { if (w < wv) wexcl += s_wave[w]; agg += s_wave[w]; }
         if (threadIdx.x == 0) desc_store(d_agg + tile, DESC_VALID | agg);
         // exclusive prefix of this tile: one parallel read of the round's earlier aggregates
         const int64_t first = (tile / gridDim.x) * gridDim.x;
         uint64_t acc = 0;
-        for (int64_t idx = first + threadIdx.x; idx < tile; idx += BLOCK) acc += desc_wait(d_agg + idx, timeout);
-        if (first > 0 && threadIdx.x == BLOCK - 1) acc += desc_wait(d_pre + first - 1, timeout);
+        for (int64_t idx = first + threadIdx.x; idx < tile; idx += SCAN_BLOCK) acc += desc_wait(d_agg + idx, timeout);
+        if (first > 0 && threadIdx.x == SCAN_BLOCK - 1) acc += desc_wait(d_pre + first - 1, timeout);
         acc = wave_sum_u64(acc);
         if (lane == 0) s_red[wv] = acc;
         __syncthreads();
         uint64_t excl = 0;
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) excl += s_red[w];
+        for (int w = 0; w < SCAN_NWAVES; ++w) excl += s_red[w];
         if (threadIdx.x == 0) desc_store(d_pre + tile, DESC_VALID | (excl + agg));
         const uint64_t off = excl + wexcl;
+        // k_search_fine's levels: this wave owns 256 cells = 16 groups of 16; its 1024-cell super-group is 4 consecutive waves
+        uint32_t f_khi = 0; int f_sh = 0; uint64_t f_kb = 0;
+        if constexpr (SCAN_ROWS == 2) {
+            if (out.o8) {                                       // kernel-uniform
+                uint64_t sg0 = 0, sgt = 0;
+#pragma unroll
+                for (int w = 0; w < SCAN_NWAVES; ++w) { if (w < (wv & ~3)) sg0 += s_wave[w]; if ((w & ~3) == (wv & ~3)) sgt += s_wave[w]; }
+                const uint64_t sg_start = excl + sg0, sg_end = sg_start + sgt;
+                const uint32_t klo = (uint32_t)(key_sat(sg_start) >> KEY_SHIFT);
+                f_khi = (uint32_t)(key_sat(sg_end) >> KEY_SHIFT);
+                f_sh = key_quant_shift(klo, f_khi);
+                f_kb = (uint64_t)klo << KEY_SHIFT;
+            }
+        }
         if (out.cdf) {
 #pragma unroll
             for (int k = 0; k < SCAN_ROWS; ++k) {
@@ -309,6 +352,19 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
                 if ((lane & 15) == 15) out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(v1) >> KEY_SHIFT);   // ... = 31 (mod 32)
                 if (lane == WAVE - 1 && (k & 1)) out.t256[(idx + 1) >> 8] = v1;         // ... = 255 (mod 256)
                 if (out.k32s && lane == WAVE - 1) out.k32s[(idx + 1) >> 7] = (uint32_t)(key_sat(v1) >> KEY_SHIFT);   // (sample == 2) element idx+1 = 127 (mod 128)
+                if constexpr (SCAN_ROWS == 2) {
+                if (out.o8) {                                                           // kernel-uniform
+                    const uint32_t dl = (uint32_t)((key_sat(v1) - f_kb) >> f_sh);         // this lane's second cell, as a group-end candidate
+                    const uint32_t dg = (uint32_t)__shfl((int)dl, lane | 7, WAVE);        // the group's end (its last lane)
+                    uint32_t dprev = (uint32_t)__shfl((int)dl, ((lane & ~7) - 1) & (WAVE - 1), WAVE);   // end of the previous group
+                    if (lane < 8) dprev = ((wv & 3) == 0 && k == 0) ? 0u : (uint32_t)((key_sat(off + cb[k]) - f_kb) >> f_sh);   // the row's first group
+                    const FineQuant fq = fine_quant(f_kb, f_sh, dprev, dg);
+                    const uint32_t o0 = (uint32_t)((key_sat(off + p[2 * k]) - fq.base) >> fq.sh8), o1 = (uint32_t)((key_sat(v1) - fq.base) >> fq.sh8);
+                    reinterpret_cast<uint16_t*>(out.o8)[idx >> 1] = (uint16_t)(o0 | (o1 << 8));
+                    if ((lane & 7) == 7) out.d16[(idx + 1) >> 4] = (uint16_t)dl;
+                    if ((wv & 3) == 3 && k == SCAN_ROWS - 1 && lane == WAVE - 1) out.k1024[(idx + 1) >> 10] = f_khi;
+                }
+                }
                 if (out.off16) {                                                        // kernel-uniform
                     // 16-bit offsets inside the key group (16 << logg lanes of this row): klo = key of the previous group
                     const int GL = 16 << out.logg;
@@ -332,13 +388,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
             }
         }
         if constexpr (MODE == 3) {
-            if (tile == ntiles - 1 && wv == NWAVES - 1) {       // the wave that ends up with the shard total tells every peer
+            if (tile == ntiles - 1 && wv == SCAN_NWAVES - 1) {       // the wave that ends up with the shard total tells every peer
                 const uint64_t Sw = shfl_u64(off + p[2 * SCAN_ROWS - 1], WAVE - 1);
                 const uint64_t words[5] = {Sw, 0, 0, 0, 0};
                 mbox_push_wave(ex.push, words);
             }
         }
-        if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) {
+        if (tile == ntiles - 1 && threadIdx.x == SCAN_BLOCK - 1) {
             const uint64_t Stot = off + p[2 * SCAN_ROWS - 1];
             *total_out = Stot;
             if constexpr (MODE >= 1) {
@@ -353,14 +409,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
     }
     if constexpr (WANT_Q) {
         // block partial of the limb sums of sum q^2 (plain stores, folded on demand by k_publish_scalars)
-        __shared__ uint64_t s_q[NWAVES][4];
+        __shared__ uint64_t s_q[SCAN_NWAVES][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
         if (lane == 0) { for (int k = 0; k < 4; ++k) s_q[wv][k] = ql[k]; }
         __syncthreads();
         if (threadIdx.x < 4) {
             uint64_t t = 0;
-            for (int w = 0; w < NWAVES; ++w) t += s_q[w][threadIdx.x];
+            for (int w = 0; w < SCAN_NWAVES; ++w) t += s_q[w][threadIdx.x];
             blockQ[(int64_t)blockIdx.x * 4 + threadIdx.x] = t;
         }
     }
@@ -371,13 +427,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan(In in, int64_t n, int64_t ntiles
 // ONE 64-bit division per element (quotient and remainder), two descriptor channels polled in the same round trip.
 // Same tile / descriptor protocol as k_scan (channel A = counts, channel B = residual weights).
 struct Scan2Chan { ScanOut out; uint64_t* dcur; uint64_t* dnext; uint64_t* total_out; };
-__global__ __launch_bounds__(BLOCK) void k_scan_residual2(const uint64_t* __restrict__ cdf, const WSum* ws, int64_t Nslots,
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* __restrict__ cdf, const WSum* ws, int64_t Nslots,
                                                           int64_t n, int64_t ntiles, Scan2Chan A, Scan2Chan B,
                                                           int32_t* __restrict__ timeout)
 {
-    __shared__ uint64_t s_wave[2][NWAVES];
-    __shared__ uint64_t s_red[2][NWAVES];
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * BLOCK) { A.dnext[i] = 0; B.dnext[i] = 0; }
+    __shared__ uint64_t s_wave[2][SCAN_NWAVES];
+    __shared__ uint64_t s_red[2][SCAN_NWAVES];
+    for (int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * SCAN_BLOCK) { A.dnext[i] = 0; B.dnext[i] = 0; }
     const uint64_t S = ws->S;
     const int sh = residual_shift(S, Nslots);
     const int lane = lane_id(), wv = wave_id();
@@ -408,18 +464,18 @@ __global__ __launch_bounds__(BLOCK) void k_scan_residual2(const uint64_t* __rest
         __syncthreads();
         uint64_t wexa = 0, agga = 0, wexb = 0, aggb = 0;
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) {
+        for (int w = 0; w < SCAN_NWAVES; ++w) {
             if (w < wv) { wexa += s_wave[0][w]; wexb += s_wave[1][w]; }
             agga += s_wave[0][w]; aggb += s_wave[1][w];
         }
         if (threadIdx.x == 0) { desc_store(A.dcur + tile, DESC_VALID | agga); desc_store(B.dcur + tile, DESC_VALID | aggb); }
         const int64_t first = (tile / gridDim.x) * gridDim.x;
         uint64_t acca = 0, accb = 0;
-        for (int64_t idx = first + threadIdx.x; idx < tile; idx += BLOCK) {
+        for (int64_t idx = first + threadIdx.x; idx < tile; idx += SCAN_BLOCK) {
             acca += desc_wait(A.dcur + idx, timeout);
             accb += desc_wait(B.dcur + idx, timeout);
         }
-        if (first > 0 && threadIdx.x == BLOCK - 1) {
+        if (first > 0 && threadIdx.x == SCAN_BLOCK - 1) {
             acca += desc_wait(A.dcur + ntiles + first - 1, timeout);
             accb += desc_wait(B.dcur + ntiles + first - 1, timeout);
         }
@@ -428,7 +484,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_residual2(const uint64_t* __rest
         __syncthreads();
         uint64_t exa = 0, exb = 0;
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) { exa += s_red[0][w]; exb += s_red[1][w]; }
+        for (int w = 0; w < SCAN_NWAVES; ++w) { exa += s_red[0][w]; exb += s_red[1][w]; }
         if (threadIdx.x == 0) {
             desc_store(A.dcur + ntiles + tile, DESC_VALID | (exa + agga));
             desc_store(B.dcur + ntiles + tile, DESC_VALID | (exb + aggb));
@@ -444,7 +500,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_residual2(const uint64_t* __rest
             if ((lane & 15) == 15) { A.out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(va) >> KEY_SHIFT); B.out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(vb) >> KEY_SHIFT); }
             if (lane == WAVE - 1 && (k & 1)) { A.out.t256[(idx + 1) >> 8] = va; B.out.t256[(idx + 1) >> 8] = vb; }
         }
-        if (tile == ntiles - 1 && threadIdx.x == BLOCK - 1) { *A.total_out = offa + pa[2 * SCAN_ROWS - 1]; *B.total_out = offb + pb[2 * SCAN_ROWS - 1]; }
+        if (tile == ntiles - 1 && threadIdx.x == SCAN_BLOCK - 1) { *A.total_out = offa + pa[2 * SCAN_ROWS - 1]; *B.total_out = offb + pb[2 * SCAN_ROWS - 1]; }
         __syncthreads();                                // s_wave / s_red reuse
     }
 }

@@ -62,7 +62,7 @@ __global__ void k_set_global(const int64_t* __restrict__ tot_all, int G, WSum* w
     mbox_wait_block(wait);
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint64_t S = 0;
-        for (int g = 0; g < G; ++g) S += (uint64_t)ld_sys(tot_all + 5 * g);
+        for (int g = 0; g < G; ++g) S += (uint64_t)ld_gathered(tot_all + 5 * g, wait.tags != nullptr);
         ws->S = S;
     }
 }
@@ -109,8 +109,9 @@ __device__ __forceinline__ void push_tables(const PushArgs& a, PushTables& t)
     mbox_wait_block(a.wait_cr);
     if (threadIdx.x < WAVE) {
         const int g = (int)threadIdx.x;
-        uint64_t w = g < a.G ? (uint64_t)(a.cr_all ? ld_sys(a.cr_all + 2 * g + 1) : ld_sys(a.tot_all + 5 * g)) : 0;
-        uint64_t c = g < a.G && a.cr_all ? (uint64_t)ld_sys(a.cr_all + 2 * g) : 0;
+        const bool mb = a.wait_tot.tags != nullptr;
+        uint64_t w = g < a.G ? (uint64_t)(a.cr_all ? ld_gathered(a.cr_all + 2 * g + 1, mb) : ld_gathered(a.tot_all + 5 * g, mb)) : 0;
+        uint64_t c = g < a.G && a.cr_all ? (uint64_t)ld_gathered(a.cr_all + 2 * g, mb) : 0;
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) {
             const uint64_t ow = shfl_up_u64(w, d), oc = shfl_up_u64(c, d);
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
     uint64_t S = 0, lo = 0, lo_me = 0;
     mbox_wait_block(a.wait_tot);
     for (int g = 0; g < a.G; ++g) {
-        const uint64_t v = (uint64_t)ld_sys(a.tot_all + 5 * g);
+        const uint64_t v = (uint64_t)ld_gathered(a.tot_all + 5 * g, a.wait_tot.tags != nullptr);
         if (g < h) lo += v;
         if (g < a.me) lo_me += v;
         S += v;
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels 
             __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    const MultiTable tb = multi_table_load<LOGG>(lw_, ntiles, (uint64_t)ld_sys(a.tot_all + 5 * a.me), reinterpret_cast<uint32_t*>(smem), [] {});
+    const MultiTable tb = multi_table_load<LOGG>(lw_, ntiles, (uint64_t)ld_gathered(a.tot_all + 5 * a.me, a.wait_tot.tags != nullptr), reinterpret_cast<uint32_t*>(smem), [] {});
     const int64_t total = s_off[a.G] < capacity ? s_off[a.G] : capacity;
     for (int64_t base = (int64_t)blockIdx.x * NE * SBLOCK; base < total; base += (int64_t)gridDim.x * NE * SBLOCK) {
         int64_t e[NE]; bool act[NE]; uint64_t T[NE]; uint32_t slot[NE];
@@ -446,7 +447,7 @@ template <int W>
 __global__ __launch_bounds__(BLOCK) void k_commit_packed(const double* __restrict__ packed, int64_t m, double* __restrict__ rows_new,
                                                          int32_t* __restrict__ anc, double* __restrict__ lw,
                                                          const double* __restrict__ mf_all, const int64_t* __restrict__ tot_all, int G, int K,
-                                                         double logN, Scalars* sc)
+                                                         double logN, Scalars* sc, int in_mailbox)
 {
     // update_lml_est! (resample.jl:178-182) from the gathered global summary: lml += (m + log(S 2^-K)) - log N
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -454,8 +455,8 @@ __global__ __launch_bounds__(BLOCK) void k_commit_packed(const double* __restric
         double mx = -__builtin_huge_val();
         int f = 0;
         for (int g = 0; g < G; ++g) {
-            S += (uint64_t)ld_sys(tot_all + 5 * g);
-            const double v = ld_sys(mf_all + 2 * g); mx = v > mx ? v : mx; f |= (int)ld_sys(mf_all + 2 * g + 1);
+            S += (uint64_t)ld_gathered(tot_all + 5 * g, in_mailbox != 0);
+            const double v = ld_gathered(mf_all + 2 * g, in_mailbox != 0); mx = v > mx ? v : mx; f |= (int)ld_gathered(mf_all + 2 * g + 1, in_mailbox != 0);
         }
         if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
         sc->lml_est = sc->lml_est + (lse_from(mx, S, K, f) - logN);

@@ -83,6 +83,7 @@ struct PackedCommit {
     int32_t* anc;              // parents of the committed population
     const double* mf_all; const int64_t* tot_all; int G, K; double logN; Scalars* sc;   // update_lml_est! from the gathered summaries
     const double* lw_fill;     // GATHER after gpf_resample_local: the incoming log-weights are this constant, not 0 (resample.jl:210)
+    int in_mailbox;            // mf_all / tot_all sit in the shard mailbox (written by peers: system-scope loads)
 };
 template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
             double mx = -__builtin_huge_val();
             int f = 0;
             for (int g = 0; g < pc.G; ++g) {                 // (system-scope loads: the gathered summaries may sit in the shard mailbox)
-                S += (uint64_t)ld_sys(pc.tot_all + 5 * g);
-                const double v = ld_sys(pc.mf_all + 2 * g); mx = v > mx ? v : mx; f |= (int)ld_sys(pc.mf_all + 2 * g + 1);
+                S += (uint64_t)ld_gathered(pc.tot_all + 5 * g, pc.in_mailbox != 0);
+                const double v = ld_gathered(pc.mf_all + 2 * g, pc.in_mailbox != 0); mx = v > mx ? v : mx; f |= (int)ld_gathered(pc.mf_all + 2 * g + 1, pc.in_mailbox != 0);
             }
             if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
             pc.sc->lml_est = pc.sc->lml_est + (lse_from(mx, S, pc.K, f) - pc.logN);
