@@ -50,7 +50,4 @@ def test_fine_levels_match_numpy(g, o, N, weights):
     base = np.repeat(kb, 64) + (dprev.reshape(-1) << np.repeat(sh, 64))
     oexp = (sat.reshape(-1, 16) - base[:, None]) >> sh8[:, None]
     assert oexp.max() <= 255 and np.array_equal(o8.reshape(-1, 16), oexp.astype(np.uint8))
-    orc = o.OracleFilter(model.model_id, model.params, N, 4).initialize(ys[0])
-    if weights != "filter":
-        orc.lw = np.asarray(st.log_weights * 0 + (np.where(np.arange(N) % 9973 == 5, 0.0, -35.0 - 1e-4 * np.arange(N)) if weights == "collapsed" else 0.0))
     st.close()
