@@ -33,37 +33,63 @@ __global__ __launch_bounds__(BLOCK) void k_apply_post(const Scalars* sc, int K, 
 }
 
 // ----------------------------------------------------------------------------- K9: statistics
-// sum_i w_i f(x_i), w_i = q_i / S (statistics.jl:13-14, 48-50); per-block partials in Float64
-__global__ __launch_bounds__(BLOCK) void k_wsum(const double* __restrict__ lw, const WSum* ws, int K,
-                                                const double* __restrict__ rows, int W, int col, int64_t n,
-                                                int pw, const double* center, double* __restrict__ partial)
+// sum_i w_i f(x_i), w_i = q_i / S (statistics.jl:13-14, 48-50, 91-101).  The reference adds the terms one after the other; a
+// parallel machine cannot, and Float64 addition is not associative -- so the ORDER is part of the spec: the
+// terms are summed by the perfect binary tree over their indices (neighbours first: t0 + t1, t2 + t3, then pairs of pairs, ...),
+// evaluated in chunks of 2048 terms (missing terms are +0.0) whose partials are summed by the same tree again.  Every level of
+// it maps onto the machine -- 8 consecutive terms per lane, an xor-butterfly over the 64 lanes (lane l holds terms 8 l .. 8 l + 7),
+// the 4 waves of a workgroup, one workgroup per chunk -- and onto two nested loops in the oracle (o_tree_sum): the same bits on
+// any number of threads, and an error bound of O(log n) ulps instead of the sequential sum's O(n).
+constexpr int TREE_CHUNK = BLOCK * 8;              // terms per workgroup
+static_assert(TREE_CHUNK == 2048, "the oracle's o_tree_sum uses the same chunk");
+__device__ __forceinline__ double tree8(const double (&t)[8]) { return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])); }
+// block-collective: the tree sum of the workgroup's 2048 terms (thread x holds terms 8x .. 8x+7 as their subtree's sum); valid in thread 0
+__device__ __forceinline__ double tree_block_sum(double v)
+{
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) v += u2d(shfl_xor_u64(d2u(v), m));       // neighbours first
+    __shared__ double s_tree[NWAVES];
+    if (lane_id() == 0) s_tree[wave_id()] = v;
+    __syncthreads();
+    static_assert(NWAVES == 4, "two more levels");
+    return (s_tree[0] + s_tree[1]) + (s_tree[2] + s_tree[3]);
+}
+// the terms: values[i * stride + col] (a column of the particle rows, or a plain array with stride 1, col 0)
+// pw = 1: w v;  2: w (v - *center)^2;  3: w [v == match]  (proportionmap)
+__global__ __launch_bounds__(BLOCK) void k_wsum_tree(const double* __restrict__ lw, const WSum* ws, int K,
+                                                     const double* __restrict__ values, int stride, int col, int64_t n,
+                                                     int pw, const double* center, double match, double* __restrict__ partial)
 {
     const double m = ws->m;
     const double Sd = (double)ws->S;
     const bool uniform = (ws->flags & FLAG_ALL_NEGINF) != 0;
     const double c = center ? *center : 0.0;
-    double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-        const uint64_t q = uniform ? 1 : exp_fix(lw[i] - m, K);
-        double v = rows[i * W + col];
-        if (pw == 2) { v = v - c; v = v * v; }
-        acc += ((double)q / Sd) * v;
+    double t[8];
+    const int64_t i0 = (int64_t)blockIdx.x * TREE_CHUNK + (int64_t)threadIdx.x * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = i0 + j;
+        t[j] = 0.0;
+        if (i < n) {
+            const uint64_t q = uniform ? 1 : exp_fix(lw[i] - m, K);
+            double v = values[i * stride + col];
+            if (pw == 2) { v = v - c; v = v * v; }
+            if (pw == 3) v = (v == match) ? 1.0 : 0.0;
+            t[j] = ((double)q / Sd) * v;
+        }
     }
-    acc = wave_sum_f64(acc);
-    __shared__ double s[NWAVES];
-    if (lane_id() == 0) s[wave_id()] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < NWAVES; ++w) t += s[w]; partial[blockIdx.x] = t; }
+    const double r = tree_block_sum(tree8(t));
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
-__global__ void k_sum_partials(const double* __restrict__ partial, int np, double* out)
+// the next level of the tree: np partials -> ceil(np / 2048)
+__global__ __launch_bounds__(BLOCK) void k_tree_partials(const double* __restrict__ in, int64_t np, double* __restrict__ out)
 {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < np; i += BLOCK) acc += partial[i];
-    acc = wave_sum_f64(acc);
-    __shared__ double s[NWAVES];
-    if (lane_id() == 0) s[wave_id()] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < NWAVES; ++w) t += s[w]; *out = t; }
+    double t[8];
+    const int64_t i0 = (int64_t)blockIdx.x * TREE_CHUNK + (int64_t)threadIdx.x * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = i0 + j < np ? in[i0 + j] : 0.0;
+    const double r = tree_block_sum(tree8(t));
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
 // ----------------------------------------------------------------------------- strided sub-state views

@@ -131,31 +131,6 @@ __global__ void k_hist_column(const int32_t* const* __restrict__ maps, int n_map
         out[i] = hx[idx * d + col];
     }
 }
-// sum_i w_i f(v_i) over a plain value array (same weights / reduction as k_wsum)
-__global__ __launch_bounds__(BLOCK) void k_wsum_values(const double* __restrict__ lw, const WSum* ws, int K,
-                                                       const double* __restrict__ values, int64_t n, int pw,
-                                                       const double* center, double match, double* __restrict__ partial)
-{
-    // pw = 1: sum w v;  2: sum w (v - *center)^2;  3: sum w [v == match]  (proportionmap, statistics.jl:91-101)
-    const double m = ws->m;
-    const double Sd = (double)ws->S;
-    const bool uniform = (ws->flags & FLAG_ALL_NEGINF) != 0;
-    const double c = center ? *center : 0.0;
-    double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-        const uint64_t q = uniform ? 1 : exp_fix(lw[i] - m, K);
-        double v = values[i];
-        if (pw == 2) { v = v - c; v = v * v; }
-        if (pw == 3) v = (v == match) ? 1.0 : 0.0;
-        acc += ((double)q / Sd) * v;
-    }
-    acc = wave_sum_f64(acc);
-    __shared__ double s[NWAVES];
-    if (lane_id() == 0) s[wave_id()] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < NWAVES; ++w) t += s[w]; partial[blockIdx.x] = t; }
-}
-
 // ----------------------------------------------------------------------------- sub-state views (src/view.jl, resample.jl:205-218)
 // after resampling a view: every log-weight = logsumexp(view) - log n (the block keeps its total mass, resample.jl:210)
 __global__ void k_fill_from(double* __restrict__ lw, int64_t n, const double* __restrict__ value)

@@ -75,6 +75,7 @@ struct gpf_filter {
     int32_t* pflags = nullptr;
     uint64_t* blockQ = nullptr;
     double *partial = nullptr, *dscal = nullptr;
+    double* tree_buf = nullptr; int64_t tree_cap = 0;   // partials of the weighted tree sums (statistics)
     Scalars* sc = nullptr;
     Scalars* h_sc = nullptr;       // pinned mirror
     long long* h_sc_ticket = nullptr; long long sc_ticket = 0;   // k_publish_scalars -> host polling (fetch_scalars)
@@ -1046,7 +1047,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers (or of the compact copies below)
     for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc}) if (q) (void)hipFree(q);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan};
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
@@ -1379,21 +1380,37 @@ gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n)
     return GPF_OK;
 }
 
+// sum_i w_i f(values[i * stride + col]) by the binary tree of DESIGN.md §3.5 (one workgroup per 2048 terms, then the same tree over
+// the partials) into *out_dev (device)
+static gpf_status weighted_tree_sum(gpf_filter* h, const double* values, int stride, int col, int pw, const double* center, double match, double* out_dev)
+{
+    const int64_t nb = (h->n + TREE_CHUNK - 1) / TREE_CHUNK;
+    const int64_t need = nb + (nb + TREE_CHUNK - 1) / TREE_CHUNK + 1;
+    if (h->tree_cap < need) {
+        if (h->tree_buf) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->tree_buf); h->tree_buf = nullptr; h->tree_cap = 0; }
+        HIP_TRY(h, hipMalloc(&h->tree_buf, (size_t)need * sizeof(double)));
+        h->tree_cap = need;
+    }
+    double *in = h->tree_buf, *out = h->tree_buf + nb;
+    GPF_LAUNCH(k_wsum_tree, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, values, stride, col, h->n, pw, center, match, in);
+    for (int64_t np = nb; np > 1;) {
+        const int64_t g = (np + TREE_CHUNK - 1) / TREE_CHUNK;
+        GPF_LAUNCH(k_tree_partials, dim3((unsigned)g), dim3(BLOCK), 0, h->stream, in, np, out);
+        np = g; std::swap(in, out);
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_dev, in, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return GPF_OK;
+}
+
 static gpf_status wstat(gpf_handle h, int32_t column, double* out, bool variance)
 {
     gpf_status s = check_ready(h);
     if (s) return s;
     if (!out || column < 0 || column >= h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad column/output");
     if ((s = ensure_raw(h))) return s;
-    const int g = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
-    GPF_LAUNCH(k_wsum, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->rows[h->cur], h->W, column, h->n, 1,
-                       nullptr, h->partial);
-    GPF_LAUNCH(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
-    if (variance) {
-        GPF_LAUNCH(k_wsum, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->rows[h->cur], h->W, column, h->n, 2,
-                           h->dscal, h->partial);
-        GPF_LAUNCH(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal + 1);
-    }
+    if ((s = weighted_tree_sum(h, h->rows[h->cur], h->W, column, 1, nullptr, 0.0, h->dscal))) return s;
+    if (variance && (s = weighted_tree_sum(h, h->rows[h->cur], h->W, column, 2, h->dscal, 0.0, h->dscal + 1))) return s;
     double tmp[2];
     if ((s = copy_out(h, h->dscal, tmp, sizeof(tmp)))) return s;
     *out = variance ? tmp[1] : tmp[0];
@@ -1826,13 +1843,8 @@ static gpf_status history_stat(gpf_handle h, int32_t step, int32_t column, doubl
     gpf_status s = history_values(h, step, column);
     if (s) return s;
     if ((s = ensure_raw(h))) return s;
-    const int g = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
-    GPF_LAUNCH(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 1, nullptr, 0.0, h->partial);
-    GPF_LAUNCH(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
-    if (variance) {
-        GPF_LAUNCH(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 2, h->dscal, 0.0, h->partial);
-        GPF_LAUNCH(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal + 1);
-    }
+    if ((s = weighted_tree_sum(h, h->dtmp, 1, 0, 1, nullptr, 0.0, h->dscal))) return s;
+    if (variance && (s = weighted_tree_sum(h, h->dtmp, 1, 0, 2, h->dscal, 0.0, h->dscal + 1))) return s;
     double tmp[2];
     if ((s = copy_out(h, h->dscal, tmp, sizeof(tmp)))) return s;
     *out = variance ? tmp[1] : tmp[0];
@@ -1852,9 +1864,7 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
         GPF_LAUNCH(k_extract_column, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->rows[h->cur], h->W, column, h->n, h->dtmp);
     }
     if ((s = ensure_raw(h))) return s;
-    const int g = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
-    GPF_LAUNCH(k_wsum_values, dim3(g), dim3(BLOCK), 0, h->stream, h->lw, &h->sc->raw, h->K, h->dtmp, h->n, 3, nullptr, value, h->partial);
-    GPF_LAUNCH(k_sum_partials, dim3(1), dim3(BLOCK), 0, h->stream, h->partial, g, h->dscal);
+    if ((s = weighted_tree_sum(h, h->dtmp, 1, 0, 3, nullptr, value, h->dscal))) return s;
     return copy_out(h, h->dscal, out, sizeof(double));
 }
 gpf_status gpf_history_mean(gpf_handle h, int32_t step, int32_t column, double* out) { return history_stat(h, step, column, out, false); }

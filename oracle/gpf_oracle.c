@@ -601,19 +601,43 @@ O_EXPORT void o_argsort_desc(const double *lp, int64_t n, int64_t *order)
     free(kv);
 }
 
-/* sum_i q_i * f(x_i[col]) / S with f = identity (pw=1) or square of (x - c) (pw=2):
- * statistics.jl:13-14 (mean) and :48-50 (var); sequential Float64 accumulation */
+/* The order of a Float64 sum is part of the spec: the terms are added by the perfect binary tree over their
+ * indices (neighbours first), in chunks of 2048 terms (missing terms are +0.0) whose partials are summed by the same tree again.
+ * t is destroyed; n >= 1. */
+#define O_TREE_CHUNK 2048
+static double o_tree_sum(double *t, int64_t n)
+{
+    double buf[O_TREE_CHUNK];
+    while (1) {
+        int64_t nb = (n + O_TREE_CHUNK - 1) / O_TREE_CHUNK;
+        for (int64_t b = 0; b < nb; ++b) {
+            for (int j = 0; j < O_TREE_CHUNK; ++j) buf[j] = b * O_TREE_CHUNK + j < n ? t[b * O_TREE_CHUNK + j] : 0.0;
+            for (int w = 1; w < O_TREE_CHUNK; w *= 2)
+                for (int i = 0; i < O_TREE_CHUNK; i += 2 * w) buf[i] = buf[i] + buf[i + w];
+            t[b] = buf[0];
+        }
+        if (nb == 1) return t[0];
+        n = nb;
+    }
+}
+/* sum_i q_i * f(x_i[col]) / S with f = identity (pw=1), square of (x - c) (pw=2) or [x == c] (pw=3):
+ * statistics.jl:13-14 (mean), :48-50 (var), :91-101 (proportionmap); the reference accumulates sequentially, the spec sums the
+ * same terms by o_tree_sum (a parallel machine cannot add one after the other; the tree also has the smaller error bound) */
 O_EXPORT double o_wsum(const uint64_t *q, uint64_t S, const double *rows, int W, int col, int64_t n,
                        int pw, double c)
 {
-    double acc = 0.0, Sd = (double)S;
+    double Sd = (double)S;
+    double *t = (double *)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
     for (int64_t i = 0; i < n; ++i) {
         double w = (double)q[i] / Sd;
         double v = rows[i * W + col];
         if (pw == 2) { v = v - c; v = v * v; }
-        acc += w * v;
+        if (pw == 3) v = (v == c) ? 1.0 : 0.0;
+        t[i] = w * v;
     }
-    return acc;
+    double r = n > 0 ? o_tree_sum(t, n) : 0.0;
+    free(t);
+    return r;
 }
 
 /* synthetic data generator shared by tests/bench (DATA stream, tag 7): y = truth + noise for the SSMs */

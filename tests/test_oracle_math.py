@@ -61,3 +61,41 @@ def test_fixed_point_weights(o):
     assert L.o_exp_fix_d(-math.log(2.0), 42) in (2**41 - 1, 2**41, 2**41 + 1)
     # weights below half a quantum vanish, the maximum never does
     assert L.o_exp_fix_d(-43 * math.log(2.0), 42) in (0, 1)
+
+
+def test_weighted_sums_follow_the_binary_tree(g, o):
+    """mean / var (src/statistics.jl:13-14, 48-50): the reference adds the terms one after the other; the spec adds the SAME terms
+    by the perfect binary tree over their indices in chunks of 2048.  Checked against a plain-Python restatement of
+    that tree (bit for bit) and against math.fsum / the sequential sum (to rounding error)."""
+    import math
+
+    def tree(t):
+        t = list(t)
+        while True:
+            out = []
+            for b in range(0, len(t), 2048):
+                buf = t[b:b + 2048] + [0.0] * (2048 - len(t[b:b + 2048]))
+                w = 1
+                while w < 2048:
+                    for i in range(0, 2048, 2 * w):
+                        buf[i] = buf[i] + buf[i + w]
+                    w *= 2
+                out.append(buf[0])
+            if len(out) == 1:
+                return out[0]
+            t = out
+
+    m = g.models.lgssm2()
+    for n in (1, 5, 2048, 2049, 5000):
+        f = o.OracleFilter(m.model_id, m.params, n, 3).initialize(g.models.simulate(m, 1)[0])
+        f.lw = -20.0 * np.random.default_rng(n).random(n)
+        s = f.summary()
+        terms = [(float(q) / float(s.S)) * float(v) for q, v in zip(s.q, f.rows[:, 0])]
+        assert f.mean(0) == tree(terms)
+        assert abs(f.mean(0) - math.fsum(terms)) <= 1e-13 * max(1.0, sum(abs(x) for x in terms))
+        seq = 0.0
+        for x in terms:
+            seq += x
+        assert abs(f.mean(0) - seq) <= 1e-12 * max(1.0, sum(abs(x) for x in terms))       # the reference's order, to rounding error
+        mu = f.mean(0)
+        assert f.var(0) == tree([(float(q) / float(s.S)) * ((float(v) - mu) * (float(v) - mu)) for q, v in zip(s.q, f.rows[:, 0])])
