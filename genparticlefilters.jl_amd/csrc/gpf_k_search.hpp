@@ -95,7 +95,9 @@ struct ShardPlan {
     int64_t bounds[MAX_SHARDS + 1];                                   // first global slot of every shard (the packed entries name slots inside their shard)
 };
 // k_search_strat on a shard packs the exchange entries itself: [row | slot inside its shard << 32 | global ancestor id]
-struct PackOut { const double* rows; double* packed; int64_t capacity, gid0; int W; };
+// extra = 1 (a prioritised resample, priority_fn = w -> alpha w, resample.jl:51-52): one more double per entry, log_ws = lw[a] - lp[a]
+// (update_weights!, resample.jl:198) -- the receiver does not hold its ancestors' weights
+struct PackOut { const double* rows; double* packed; int64_t capacity, gid0; int W; int extra; PrioView pv; };
 struct SearchArgs {
     CdfLevels w;                                                      // weights (or residual weights for the tail)
     CdfLevels c;                                                      // residual: copy counts
@@ -1130,7 +1132,8 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
             while (lo < G - 1 && s_bnd[lo + 1] <= jg) ++lo;
             const int64_t i = s_mark[k * MBLOCK + tid];
             const double2* src = reinterpret_cast<const double2*>(a.pack.rows + i * W);
-            double* dst = a.pack.packed + e * (W + 1);
+            double* dst = a.pack.packed + e * (W + 1 + a.pack.extra);
+            if (a.pack.extra) dst[W + 1] = a.pack.pv.lw[i] - a.pack.pv.at(i);
             for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }
             dst[W] = u2d(((uint64_t)(jg - s_bnd[lo]) << 32) | (uint64_t)(a.pack.gid0 + i));
         }

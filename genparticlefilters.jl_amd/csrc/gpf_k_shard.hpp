@@ -96,6 +96,7 @@ struct PushArgs {
     int64_t* host_counts;                         // pinned host mirror [2 * MAX_SHARDS + 1]: k_push publishes the counts + a ticket
     int64_t ticket;
     MboxWait wait_tot, wait_cr;                   // shard mailboxes: tot_all / cr_all are filled by the peers' kernels -- wait before reading
+    int extra; PrioView pv;                       // prioritised resample: packed entries carry one more double, lw[a] - lp[a] (PackOut::extra)
 };
 struct PushTables {                               // LDS copy of the per-shard tables
     int64_t w_incl[MAX_SHARDS], c_incl[MAX_SHARDS], bounds[MAX_SHARDS + 1], chunk0[MAX_SHARDS + 1];
@@ -324,7 +325,8 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
         for (int u = 0; u < 2; ++u) {
             if (!act[u]) continue;
             const double* src = rows + idx[u] * W;
-            double* dst = packed_out + e[u] * (W + 1);
+            double* dst = packed_out + e[u] * (W + 1 + a.extra);
+            if (a.extra) dst[W + 1] = a.pv.lw[idx[u]] - a.pv.at(idx[u]);
 #pragma unroll
             for (int c = 0; c < W; ++c) dst[c] = src[c];
             dst[W] = u2d((slot[u] << 32) | (uint64_t)(gid0 + idx[u]));
@@ -434,7 +436,8 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels 
         for (int u = 0; u < NE; ++u) {
             if (!act[u]) continue;
             const double2* src = reinterpret_cast<const double2*>(rows + (int64_t)idx[u] * W);
-            double* dst = packed_out + e[u] * (W + 1);
+            double* dst = packed_out + e[u] * (W + 1 + a.extra);
+            if (a.extra) dst[W + 1] = a.pv.lw[idx[u]] - a.pv.at(idx[u]);
 #pragma unroll
             for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }
             dst[W] = u2d(((uint64_t)slot[u] << 32) | (uint64_t)(gid0 + idx[u]));
@@ -471,6 +474,56 @@ __global__ __launch_bounds__(BLOCK) void k_commit_packed(const double* __restric
         anc[j] = (int32_t)(meta & 0xffffffffull);
         lw[j] = 0.0;                                   // update_weights!, resample.jl:195
     }
+}
+
+// a prioritised sharded resample: entries are [row | meta | log_ws]; the log-ML estimate moves by the RAW weights' summary
+// (update_lml_est!, resample.jl:57,178-182), the new log-weights wait for the global logsumexp of log_ws (k_shard_apply_post)
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_commit_packed_ws(const double* __restrict__ packed, int64_t m, double* __restrict__ rows_new,
+                                                            int32_t* __restrict__ anc, double* __restrict__ lws,
+                                                            const double* __restrict__ mf_raw, const int64_t* __restrict__ tot_raw, int G, int K,
+                                                            double logN, Scalars* sc, int in_mailbox)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t S = 0;
+        double mx = -__builtin_huge_val();
+        int f = 0;
+        for (int g = 0; g < G; ++g) {
+            S += (uint64_t)ld_gathered(tot_raw + 5 * g, in_mailbox != 0);
+            const double v = ld_gathered(mf_raw + 2 * g, in_mailbox != 0); mx = v > mx ? v : mx; f |= (int)ld_gathered(mf_raw + 2 * g + 1, in_mailbox != 0);
+        }
+        if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+        sc->lml_est = sc->lml_est + (lse_from(mx, S, K, f) - logN);
+    }
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < m; k += (int64_t)gridDim.x * BLOCK) {
+        const double* src = packed + k * (W + 2);
+        const uint64_t meta = d2u(src[W]);
+        const int64_t j = (int64_t)(meta >> 32);
+        double* dst = rows_new + j * W;
+#pragma unroll
+        for (int c = 0; c < W; ++c) dst[c] = src[c];
+        anc[j] = (int32_t)(meta & 0xffffffffull);
+        lws[j] = src[W + 1];                               // log_ws = lw[parents] - lp[parents], resample.jl:198
+    }
+}
+// lw = log_ws + (log N - logsumexp(log_ws)) with the logsumexp over ALL shards (resample.jl:200), from the gathered post summaries
+__global__ __launch_bounds__(BLOCK) void k_shard_apply_post(const double* __restrict__ mf_all, const int64_t* __restrict__ tot_all, int G, int K,
+                                                            double logN, const double* __restrict__ lws, double* __restrict__ lw, int64_t n,
+                                                            MboxWait wait)
+{
+    mbox_wait_block(wait);
+    const bool mb = wait.tags != nullptr;
+    uint64_t S = 0;
+    double mx = -__builtin_huge_val();
+    int f = 0;
+    for (int g = 0; g < G; ++g) {
+        S += (uint64_t)ld_gathered(tot_all + 5 * g, mb);
+        const double v = ld_gathered(mf_all + 2 * g, mb); mx = v > mx ? v : mx; f |= (int)ld_gathered(mf_all + 2 * g + 1, mb);
+    }
+    if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+    const double off = logN - lse_from(mx, S, K, f);
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+        lw[i] = lws[i] + off;
 }
 
 } // namespace gpf

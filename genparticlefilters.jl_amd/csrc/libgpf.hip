@@ -126,6 +126,10 @@ struct gpf_filter {
     std::vector<void*> mb_opened;        // peers' mailboxes opened with hipIpcOpenMemHandle (closed by gpf_comm_destroy)
     bool mb_active = false;
     bool mb_engine = false;              // set by the library engine around its phase calls: they push / wait through the mailbox
+    // what the shard phases summarise / pack on behalf of the engine (defaults: the raw log-weights, no extra field)
+    PrioView sum_pv{nullptr, nullptr, 0.0, 0}; bool sum_pv_set = false; WSum* sum_slot = nullptr; bool sum_no_cdf = false;
+    int push_extra = 0; PrioView push_pv{nullptr, nullptr, 0.0, 0};
+    uint64_t sh_round = 0;               // summary rounds so far: the local / gathered arrays are rings of SH_RING rounds
     const double* cur_mf_all = nullptr; const int64_t* cur_tot_all = nullptr; const int64_t* cur_cr_all = nullptr;   // the gathered summaries of the current round
     uint64_t mb_seq[MB_KINDS] = {0, 0, 0};   // rounds so far per kind: the same on every rank (SPMD call order)
     uint64_t mb_cur[MB_KINDS] = {0, 0, 0};   // the round whose entries the current gathered pointers name
@@ -1885,10 +1889,11 @@ gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
     if (!out2) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
     if ((s = materialize(h))) return s;
     int gp = h->max_np;
-    if (!h->max_valid) {
+    const PrioView pv = h->sum_pv_set ? h->sum_pv : raw_view(h);  // (the engine's prioritised resample summarises alpha lw and log_ws too)
+    if (!h->max_valid || h->sum_pv_set) {
         gp = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
         s = timed(h, GPF_K_MAX, [&] {
-            GPF_LAUNCH(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, raw_view(h), h->n, h->pmax, h->pflags);
+            GPF_LAUNCH(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, pv, h->n, h->pmax, h->pflags);
         });
         if (s) return s;
     }
@@ -1909,7 +1914,9 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
         h->h_shard_counts[2 * MAX_SHARDS] = 0;
     }
     h->max_valid = false;
-    InFixQ in{raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
+    InFixQ in{h->sum_pv_set ? h->sum_pv : raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
+    WSum* const slot = h->sum_slot ? h->sum_slot : &h->sc->raw;
+    const bool want_cdf = !h->sum_no_cdf;
     const int gs = scan_grid(h);
     // the scan folds the gathered (max, flags) pairs itself and writes the shard total straight into out5[0]; it also
     // publishes the global validity flags to pinned host memory (gpf_shard_flags)
@@ -1923,11 +1930,11 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     ex.wait = mb_wait(h, MB_MF);
     const MboxPush tot_push = mb_begin(h, MB_TOT);
     if (want_q) {
-        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ex))) return s;
+        if ((s = scan_launch<InFixQ, 4>(h, 0, in, (int)G, slot, want_cdf, reinterpret_cast<uint64_t*>(out5), mf_all, ex))) return s;
         GPF_LAUNCH(k_export_q, dim3(1), dim3(BLOCK), 0, h->stream, h->blockQ, gs, out5, tot_push);
     } else {
         ex.push = tot_push;
-        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, &h->sc->raw, true, reinterpret_cast<uint64_t*>(out5), mf_all, ex))) return s;
+        if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, slot, want_cdf, reinterpret_cast<uint64_t*>(out5), mf_all, ex))) return s;
     }
     HIP_TRY(h, hipGetLastError());
     h->raw_valid = false;            // sc->raw holds the GLOBAL max but no sum: not the unsharded summary
@@ -1981,6 +1988,7 @@ static gpf_status push_args(gpf_handle h, int32_t method, const int64_t* tot_all
         HIP_TRY(h, hipMalloc(&h->push_stage, (size_t)h->cfg.n_global * sizeof(ulonglong2)));
         h->push_cap = h->cfg.n_global;
     }
+    a.extra = h->push_extra; a.pv = h->push_pv;
     a.wait_tot = mb_wait(h, MB_TOT);
     a.wait_cr = method == GPF_RESAMPLE_RESIDUAL ? mb_wait(h, MB_CR) : MboxWait{};
     a.tot_all = tot_all; a.cr_all = method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr; a.stage = h->push_stage; a.counts = h->shard_counts; a.host_counts = h->h_shard_counts; a.ticket = h->push_ticket;
@@ -2060,7 +2068,7 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
         sa.n = cap; sa.n_cells = h->n; sa.n_global = h->cfg.n_global; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
         sa.K = h->K; sa.logN = h->logN; sa.anc = nullptr; sa.invN = 1.0 / (double)h->cfg.n_global;
         sa.update_lml = 0;                                            // the commit carries the log-ML update
-        sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W};
+        sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W, h->push_extra, h->push_pv};
         s = timed(h, GPF_K_GATHER, [&] {
             GPF_LAUNCH(k_search_strat, dim3((unsigned)((cap + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa);
         });
@@ -2179,21 +2187,24 @@ gpf_status shard_all_gather(gpf_filter* h, const void* src, void* dst, size_t co
     NCCL_TRY(h, g_rccl.AllGather(src, dst, count, dt, h->comm, h->stream));
     return GPF_OK;
 }
+// The local summaries and (for the RCCL all-gathers) the gathered arrays are rings of SH_RING rounds: a prioritised resample runs
+// three summary rounds (raw weights, priorities, log_ws) and its commit still reads the first.
+constexpr int SH_RING = 4;
 gpf_status shard_scratch(gpf_filter* h)
 {
     if (h->sh_mf) return GPF_OK;
     const size_t G = (size_t)h->comm_world;
-    HIP_TRY(h, hipMalloc(&h->sh_mf, 2 * sizeof(double)));
-    HIP_TRY(h, hipMalloc(&h->sh_tot, 5 * sizeof(int64_t)));
+    HIP_TRY(h, hipMalloc(&h->sh_mf, SH_RING * 2 * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->sh_tot, SH_RING * 5 * sizeof(int64_t)));
     HIP_TRY(h, hipMalloc(&h->sh_cr, 2 * sizeof(int64_t)));
     if (h->comm_world == 1 && !h->comm) {                        // one shard, no communicator: the "gathered" arrays ARE the local ones
         h->sh_mf_all = h->sh_mf; h->sh_tot_all = h->sh_tot; h->sh_cr_all = h->sh_cr;
     } else {
-        HIP_TRY(h, hipMalloc(&h->sh_mf_all, 2 * G * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->sh_tot_all, 5 * G * sizeof(int64_t)));
+        HIP_TRY(h, hipMalloc(&h->sh_mf_all, SH_RING * 2 * G * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->sh_tot_all, SH_RING * 5 * G * sizeof(int64_t)));
         HIP_TRY(h, hipMalloc(&h->sh_cr_all, 2 * G * sizeof(int64_t)));
     }
-    HIP_TRY(h, hipMemsetAsync(h->sh_tot, 0, 5 * sizeof(int64_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->sh_tot, 0, SH_RING * 5 * sizeof(int64_t), h->stream));
     return GPF_OK;
 }
 // phases 1 + 2 of DESIGN.md §6: (max, flags) and {S, sum q^2 limbs} of every shard, gathered on every rank -- through the shard
@@ -2205,13 +2216,26 @@ gpf_status shard_summary(gpf_filter* h, int want_q)
     gpf_status s = shard_scratch(h);
     if (s) return s;
     const bool mb = h->mb_active;
-    if ((s = gpf_shard_weight_max(h, h->sh_mf))) return s;
-    if (!mb && (s = shard_all_gather(h, h->sh_mf, h->sh_mf_all, 2, ncclDouble, sizeof(double)))) return s;
-    h->cur_mf_all = mb ? static_cast<const double*>(mb_gathered(h, MB_MF)) : h->sh_mf_all;
-    if ((s = gpf_shard_weight_scan(h, h->cur_mf_all, h->comm_world, want_q, h->sh_tot))) return s;
-    if (!mb && (s = shard_all_gather(h, h->sh_tot, h->sh_tot_all, 5, ncclInt64, sizeof(int64_t)))) return s;
-    h->cur_tot_all = mb ? static_cast<const int64_t*>(mb_gathered(h, MB_TOT)) : h->sh_tot_all;
+    const size_t G = (size_t)h->comm_world;
+    const int r = (int)(h->sh_round++ % SH_RING);
+    const bool alias = h->sh_mf_all == h->sh_mf;                 // one shard without communicator
+    double* mf = h->sh_mf + 2 * r; int64_t* tot = h->sh_tot + 5 * r;
+    double* mf_all = alias ? mf : h->sh_mf_all + 2 * G * r; int64_t* tot_all = alias ? tot : h->sh_tot_all + 5 * G * r;
+    if ((s = gpf_shard_weight_max(h, mf))) return s;
+    if (!mb && !alias && (s = shard_all_gather(h, mf, mf_all, 2, ncclDouble, sizeof(double)))) return s;
+    h->cur_mf_all = mb ? static_cast<const double*>(mb_gathered(h, MB_MF)) : mf_all;
+    if ((s = gpf_shard_weight_scan(h, h->cur_mf_all, h->comm_world, want_q, tot))) return s;
+    if (!mb && !alias && (s = shard_all_gather(h, tot, tot_all, 5, ncclInt64, sizeof(int64_t)))) return s;
+    h->cur_tot_all = mb ? static_cast<const int64_t*>(mb_gathered(h, MB_TOT)) : tot_all;
     return GPF_OK;
+}
+// the same over another view of the weights (a prioritised resample: alpha lw, then log_ws), into summary slot `slot`, with or
+// without the CDF levels
+gpf_status shard_summary_of(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cdf)
+{
+    struct Scope { gpf_filter* h; ~Scope() { h->sum_pv_set = false; h->sum_slot = nullptr; h->sum_no_cdf = false; } } scope{h};
+    h->sum_pv = pv; h->sum_pv_set = true; h->sum_slot = slot; h->sum_no_cdf = !want_cdf;
+    return shard_summary(h, 0);
 }
 // the gathered summaries on the host: global max, flags, S and sum q^2
 gpf_status shard_scalars(gpf_filter* h, double& m, int& flags, uint64_t& S, uint64_t& Qhi, uint64_t& Qlo)
@@ -2224,8 +2248,8 @@ gpf_status shard_scalars(gpf_filter* h, double& m, int& flags, uint64_t& S, uint
                    reinterpret_cast<uint64_t*>(h->sh_tot_all), 5 * G);
         HIP_TRY(h, hipGetLastError());
     }
-    HIP_TRY(h, hipMemcpyAsync(mf.data(), h->sh_mf_all, mf.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(tot.data(), h->sh_tot_all, tot.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(mf.data(), h->mb_active ? h->sh_mf_all : h->cur_mf_all, mf.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(tot.data(), h->mb_active ? h->sh_tot_all : h->cur_tot_all, tot.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     m = -HUGE_VAL; flags = 0; S = 0;
     unsigned __int128 Q = 0;
@@ -2375,7 +2399,7 @@ gpf_status gpf_comm_destroy(gpf_handle h)
     return ms;
 }
 
-gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid)
+static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double priority_alpha, int32_t check, int32_t* invalid)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
@@ -2383,7 +2407,12 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
         return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");             // resample.jl:28
     if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_shard_resample needs gpf_comm_create first");
     const int G = h->comm_world, me = h->comm_rank;
-    const int64_t n = h->n, E = h->W + 1;
+    // priority_fn = w -> alpha w (resample.jl:51-52): ancestors from the priorities' CDF, the log-ML update from the RAW weights
+    // (:57), new log-weights log_ws + (log N - logsumexp(log_ws)) with log_ws = lw[a] - lp[a] (:198-200).  Across shards that is
+    // three summary rounds instead of one (raw weights, priorities, log_ws) and one more double per exchanged entry (log_ws: the
+    // receiver does not hold its ancestors' weights); the commit cannot be deferred (the weights need the third round).
+    const bool prio = priority_alpha == priority_alpha;
+    const int64_t n = h->n, E = h->W + 1 + (prio ? 1 : 0);
     EngineScope engine(h);                                        // the phases below push / wait through the shard mailboxes when they are up
     // shard bounds from the contiguous-range rule every rank applies to its own gpf_config (ranks ordered by gid0)
     std::vector<int64_t> bounds((size_t)G + 1);
@@ -2400,14 +2429,14 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
     auto ensure = [&](double*& buf, int64_t& cap, int64_t want) -> gpf_status {
         if (cap >= want) return GPF_OK;
         if (buf) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(buf); buf = nullptr; cap = 0; }
-        HIP_TRY(h, hipMalloc(&buf, (size_t)want * E * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&buf, (size_t)want * (h->W + 2) * sizeof(double)));   // (room for the widest entry: a prioritised resample's [row | meta | log_ws])
         cap = want;
         return GPF_OK;
     };
     int64_t cap = std::min<int64_t>(h->cfg.n_global, 2 * n + 65536);
     if (h->sh_send_cap < h->cfg.n_global) {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)h->cfg.n_global * E * sizeof(double) <= free_b / 16) cap = h->cfg.n_global;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)h->cfg.n_global * (h->W + 2) * sizeof(double) <= free_b / 16) cap = h->cfg.n_global;
     } else cap = h->cfg.n_global;
     if (const char* e = getenv("GPF_PUSH_CAPACITY")) cap = atoll(e);                                  // tests: force the overflow path
     if ((s = ensure(h->sh_send, h->sh_send_cap, std::max<int64_t>(cap, 1)))) return s;
@@ -2415,8 +2444,19 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
     const bool exchange = G > 1 || (force && h->comm);            // one shard: what it "sends" is what it "receives"
     if (exchange && (s = ensure(h->sh_recv, h->sh_recv_cap, n))) return s;
 
+    const double* raw_mf = nullptr; const int64_t* raw_tot = nullptr;
+    struct PushScope { gpf_filter* h; ~PushScope() { h->push_extra = 0; } } push_scope{h};
+    if (prio) {
+        if ((s = materialize(h))) return s;
+        h->want_offsets = false;
+        s = shard_summary_of(h, raw_view(h), &h->sc->raw, false);  // logsumexp(log_weights), every shard (resample.jl:180)
+        h->want_offsets = true;
+        if (s) return s;
+        raw_mf = h->cur_mf_all; raw_tot = h->cur_tot_all;
+        h->push_extra = 1; h->push_pv = PrioView{h->lw, nullptr, priority_alpha, 1};
+    }
     h->want_offsets = method == GPF_RESAMPLE_MULTINOMIAL;         // (the offset levels serve k_push_multi only)
-    s = shard_summary(h, 0);                                      // phases 1, 2
+    s = prio ? shard_summary_of(h, h->push_pv, &h->sc->prio, true) : shard_summary(h, 0);   // phases 1, 2 (safe_softmax of the priorities, :54)
     h->want_offsets = true;
     if (s) return s;
     if (check != GPF_CHECK_FALSE || invalid) {                    // safe_softmax validity (utils.jl:117-140): pinned flags, no stream sync
@@ -2488,8 +2528,44 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
         }
     }
     if (late) { h->err = late_msg; return late; }
-    return gpf_shard_commit(h, commit_from, n, h->cur_mf_all, tot_all, G);                           // phase 5 (deferred)
+    if (!prio) return gpf_shard_commit(h, commit_from, n, h->cur_mf_all, tot_all, G);                // phase 5 (deferred)
+    // phase 5 of a prioritised resample, at once: scatter rows / parents / log_ws, log-ML from the raw summary ...
+    {
+        const int grid = grid_for(h, n, 8);
+        double* out = h->rows[1 - h->cur];
+        const int mbx = (int)h->mb_active;
+        switch (h->W) {
+            case 2: GPF_LAUNCH((k_commit_packed_ws<2>), dim3(grid), dim3(BLOCK), 0, h->stream, commit_from, n, out, h->anc, h->lws, raw_mf, raw_tot, G, h->K, h->logN, h->sc, mbx); break;
+            case 4: GPF_LAUNCH((k_commit_packed_ws<4>), dim3(grid), dim3(BLOCK), 0, h->stream, commit_from, n, out, h->anc, h->lws, raw_mf, raw_tot, G, h->K, h->logN, h->sc, mbx); break;
+            case 8: GPF_LAUNCH((k_commit_packed_ws<8>), dim3(grid), dim3(BLOCK), 0, h->stream, commit_from, n, out, h->anc, h->lws, raw_mf, raw_tot, G, h->K, h->logN, h->sc, mbx); break;
+        }
+        HIP_TRY(h, hipGetLastError());
+        h->cur ^= 1;
+    }
+    // ... then logsumexp(log_ws) over all shards and lw = log_ws + (log N - logsumexp) (resample.jl:200)
+    h->want_offsets = false;
+    s = shard_summary_of(h, PrioView{h->lws, nullptr, 0.0, 0}, &h->sc->post, false);
+    h->want_offsets = true;
+    if (s) return s;
+    GPF_LAUNCH(k_shard_apply_post, dim3(grid_for(h, n, 8)), dim3(BLOCK), 0, h->stream, h->cur_mf_all, h->cur_tot_all, G, h->K, h->logN, h->lws, h->lw, n,
+               mb_wait(h, MB_TOT));
+    HIP_TRY(h, hipGetLastError());
+    h->epoch += 1;
+    h->raw_valid = false; h->max_valid = false; h->residual_scanned = false; h->push_counted = false;
+    mutated(h);
+    return GPF_OK;
 }
+
+gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid)
+{
+    return shard_resample_impl(h, method, std::nan(""), check, invalid);
+}
+gpf_status gpf_shard_resample_tempered(gpf_handle h, int32_t method, double priority_alpha, int32_t check, int32_t* invalid)
+{
+    if (!(priority_alpha == priority_alpha)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "priority_alpha is NaN: use gpf_shard_resample for priority_fn = nothing");
+    return shard_resample_impl(h, method, priority_alpha, check, invalid);
+}
+
 
 gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out)
 {

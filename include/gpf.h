@@ -320,6 +320,12 @@ gpf_status gpf_comm_destroy(gpf_handle h);
  * Every rank of a communicator is in the same mode.  The row exchange itself is always grouped ncclSend / ncclRecv. */
 gpf_status gpf_comm_summary_mode(gpf_handle h, int32_t* mailbox);
 gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid);
+/* pf_resample!(state, method; priority_fn = w -> priority_alpha * w, check) on a sharded state (src/resample.jl:51-52,57,198-200; the
+ * tempering family of test/resample.jl:15): ancestors from the CDF of the priorities over ALL shards, log_ml_est from the raw
+ * weights, new log-weights log_ws + (log N - logsumexp(log_ws)), log_ws = lw[a] - lp[a], with the logsumexp over all shards.
+ * Three summary rounds instead of one and one more double (log_ws) per exchanged entry; the result is bit-identical to
+ * gpf_resample(h, method, priority_alpha, ...) on the unsharded filter.  sort_particles stays unavailable across shards. */
+gpf_status gpf_shard_resample_tempered(gpf_handle h, int32_t method, double priority_alpha, int32_t check, int32_t* invalid);
 gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out);
 gpf_status gpf_shard_log_ml_estimate(gpf_handle h, double* out);
 

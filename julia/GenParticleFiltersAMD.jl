@@ -291,7 +291,7 @@ end
 # local_only = true: the communication-free "island" resample, pf_resample!(state[shard range], method) on every shard
 # (sub-state semantics, src/resample.jl:185-187,205-218), also one call (gpf_resample_local).
 function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multinomial; check=:warn, sort_particles::Bool=false,
-                      local_only::Bool=false)
+                      local_only::Bool=false, priority_alpha::Union{Nothing,Float64}=nothing)   # priority_fn = w -> priority_alpha * w
     m = method == :multinomial ? 0 : method == :residual ? 1 : method == :stratified ? 2 : error("Resampling method $method not recognized.")
     chk = check === true ? 2 : (check === :warn ? 1 : 0)
     invalid = Ref{Cint}(0)
@@ -299,7 +299,9 @@ function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multi
     inv_ptr = check === false ? Ptr{Cint}(C_NULL) : Base.unsafe_convert(Ptr{Cint}, invalid)
     st = GC.@preserve invalid (local_only ?
         ccall((:gpf_resample_local, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cint}), s.handle, m, sort_particles ? 1 : 0, chk, inv_ptr) :
-        ccall((:gpf_shard_resample, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}), s.handle, m, chk, inv_ptr))
+        (priority_alpha === nothing ?
+            ccall((:gpf_shard_resample, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}), s.handle, m, chk, inv_ptr) :
+            ccall((:gpf_shard_resample_tempered, libgpf), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Cint}), s.handle, m, priority_alpha, chk, inv_ptr)))
     _status(s, st)                                # (the keyword `check` shadows the status helper of that name in this method)
     check === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
     return s

@@ -149,3 +149,29 @@ def run_fuzz(rank, world, port, seed, n_global, T, out_dir):
                  scal=np.array(scal, dtype=np.float64).reshape(-1, 2), lml=sharded.get_lml_est(st))
     finally:
         dist.destroy_process_group()
+
+
+def run_tempered(rank, world, port, method, n_global, T, out_dir):
+    """pf_resample!(state, method; priority_fn = w -> w / 2) across shards (library engine), with updates and the global getters between"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import gpf_amd as g
+    from gpf_amd import sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = g.models.bearings4(); ys = g.models.simulate(model, T + 1)
+        st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, keep_prev=True, device=0)
+        scal = []
+        for t in range(1, T):
+            sharded.pf_resample(st, method, priority_fn=g.Tempering(0.5 if t % 2 else 0.25), check="warn")
+            scal.append((sharded.get_ess(st), sharded.get_lml_est(st)))
+            if t == 2:
+                sharded.pf_rejuvenate(st, None, (), 1, method="move")
+            if t == 3:
+                sharded.pf_resample(st, method, check=False)              # a plain resample right after a tempered one
+            sharded.pf_update(st, (t + 1,), (None,), ys[t])
+        loc = st.local
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents, n=st.n_local,
+                 scal=np.array(scal), lml=sharded.get_lml_est(st), summaries=st.backend.summary_mode())
+    finally:
+        dist.destroy_process_group()

@@ -260,3 +260,60 @@ def test_comm_destroy_after_resample_keeps_the_population(g, o):
         del junk
         a.backend._ck(a.backend.L.gpf_comm_create(a.backend.h, None, 0, 1))
     assert g.get_lml_est(b) == sharded.get_lml_est(a)
+
+
+def _tempered_oracle(g, o, method, n_global, T):
+    model = g.models.bearings4(); ys = g.models.simulate(model, T + 1)
+    f = o.OracleFilter(model.model_id, model.params, n_global, 77, keep_prev=True).initialize(ys[0])
+    kw = {"sort_particles": False} if method == "stratified" else {}
+    scal = []
+    for t in range(1, T):
+        f.resample(method, priority_alpha=0.5 if t % 2 else 0.25, check=False, **kw)
+        scal.append((f.effective_sample_size(), f.log_ml_estimate()))
+        if t == 2:
+            f.rejuvenate("move", 1)
+        if t == 3:
+            f.resample(method, check=False, **kw)
+        f.update(ys[t])
+    return f, np.array(scal)
+
+
+@pytest.mark.parametrize("mode", ["mailbox", "rccl"])
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+def test_sharded_tempered_resample(g, o, tmp_path, monkeypatch, loopback_lib, method, world, mode):
+    """priority_fn = w -> alpha w across shards (src/resample.jl:51-52,57,198-200; test/resample.jl:15): ancestors from the
+    priorities' global CDF, log-ML from the raw weights, weights from the global logsumexp of log_ws -- three summary rounds and
+    one more double per exchanged entry; bit-identical to the unsharded oracle's resample(method, priority_alpha=...)"""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
+    monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    if mode == "rccl":
+        monkeypatch.setenv("GPF_SHARD_SUMMARY", "rccl")
+    n_global, T = 30_011, 6
+    mp.spawn(shard_worker_gpu.run_tempered, args=(world, free_port(), method, n_global, T, str(tmp_path)), nprocs=world, join=True)
+    f, scal = _tempered_oracle(g, o, method, n_global, T)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
+    assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
+    for p in parts:
+        assert np.array_equal(p["scal"], scal) and float(p["lml"]) == f.log_ml_estimate() and str(p["summaries"]) == mode
+
+
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+def test_world1_tempered_equals_unsharded(g, o, method):
+    """one shard, no communicator: the tempered sharded resample against the plain device API"""
+    from gpf_amd import sharded
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 4); N = 40_000
+    a = sharded.pf_initialize(model, (1,), ys[0], N, seed=5)
+    b = g.pf_initialize(model, (1,), ys[0], N, seed=5)
+    kw = {"sort_particles": False} if method == "stratified" else {}
+    for t in range(1, 4):
+        sharded.pf_resample(a, method, priority_fn=g.Tempering(0.5), check=False)
+        g.pf_resample(b, method, priority_fn=g.Tempering(0.5), check=False, **kw)
+        assert np.array_equal(a.local.parents, b.parents) and np.array_equal(a.local.log_weights, b.log_weights)
+        assert sharded.get_lml_est(a) == g.get_lml_est(b)
+        sharded.pf_update(a, (t + 1,), (None,), ys[t]); g.pf_update(b, (t + 1,), (None,), ys[t])
+        assert np.array_equal(a.local.traces, b.traces) and np.array_equal(a.local.log_weights, b.log_weights)
+    with pytest.raises(g.ErrorException):
+        sharded.pf_resample(a, method, priority_fn=lambda w: 0.3 * w)
