@@ -383,10 +383,38 @@ def pf_move_accept(state, kern=mh, kern_args: tuple = (), n_iters: int = 1, *, c
     return _rejuvenate(state, 0, n_iters, count)
 
 
+class MoveProposal:
+    """a native proposal for move_reweight(trace, proposal, proposal_args) (src/rejuvenate.jl:134-148):
+    `locally_optimal_move` (lgssm2: q = p(x_t | x_{t-1}, y_t)), `outlier_propose(q)` (line_model: the current step's outlier ~ bernoulli(q),
+    the proposal of test/rejuvenate.jl:19-27)"""
+
+    def __init__(self, name, proposal_id, params=()):
+        self.name, self.proposal_id, self.params = name, proposal_id, tuple(float(p) for p in params)
+
+    def __repr__(self):
+        return f"<native move proposal {self.name}{self.params}>"
+
+
+locally_optimal_move = MoveProposal("locally_optimal", 1)
+
+
+def outlier_propose(q: float) -> MoveProposal:
+    import math
+    return MoveProposal("outlier_propose", 2, (q, math.log(q) if q > 0 else -math.inf, math.log1p(-q) if q < 1 else -math.inf))
+
+
 def pf_move_reweight(state, kern=move_reweight, kern_args: tuple = (), n_iters: int = 1, *, count: bool = False):
-    """src/rejuvenate.jl:74-90 with the native move_reweight kernel"""
+    """src/rejuvenate.jl:74-90 with the native move_reweight kernel; kern_args = () -> the selection variant (rejuvenate.jl:125-132),
+    kern_args = (proposal[, proposal_args]) with a MoveProposal -> the proposal variant (rejuvenate.jl:134-148)"""
     if kern is not move_reweight:
         raise ErrorException("device states support the native `move_reweight` kernel only")
+    if kern_args and isinstance(kern_args[0], MoveProposal):
+        mp = kern_args[0]
+        q = np.asarray(mp.params, np.float64)
+        st = state._L.gpf_rejuvenate_proposal(state._h, mp.proposal_id, _pd(q) if q.size else None, int(q.size), int(n_iters))
+        state._check(st)
+        state.n_accepted = state.n_particles * int(n_iters)
+        return (state, state.n_accepted) if count else state
     return _rejuvenate(state, 1, n_iters, count)
 
 

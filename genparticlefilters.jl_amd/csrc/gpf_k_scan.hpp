@@ -166,23 +166,7 @@ struct ScanOut {
     int logg;
     uint32_t* k32s;            // [ntiles*64 >> sample] every (1 << sample)-th key, compact: the LDS table of k_search_multi_s (nullptr: not wanted)
     int sample;
-    // k_search_fine's levels (nullptr: not wanted; they share the buffer space of off16 / coarse / k32s -- one family per scan):
-    uint32_t* k1024;           // [ntiles*2]    4-byte key (prefix >> KEY_SHIFT) at the end of every 1024-cell super-group
-    uint16_t* d16;             // [ntiles*128]  the prefix at the end of every 16-cell group as a 16-bit offset inside its super-group (key_quant_shift)
-    uint8_t*  o8;              // [ntiles*2048] every prefix as an 8-bit offset inside its 16-cell group (fine_quant)
 };
-// ---- the 8-bit level of k_search_fine.  A 16-cell group g lies inside a 1024-cell super-group with end keys (klo, khi), shift
-// sh = key_quant_shift(klo, khi) and base kb = klo << KEY_SHIFT; dprev / dg are the 16-bit offsets of the prefixes at the group's
-// two ends (dprev = 0 for the first group of a super-group).  Both sides -- the scan that writes the level and the search that
-// quantises a target -- derive the SAME (base, shift) from these four numbers alone:
-//     base = kb + (dprev << sh)  (<= every prefix of the group),   span < (dg - dprev + 1) << sh,   x -> (x - base) >> sh8 <= 255.
-struct FineQuant { uint64_t base; int sh8; };
-__device__ __forceinline__ FineQuant fine_quant(uint64_t kb, int sh, uint32_t dprev, uint32_t dg)
-{
-    const uint32_t dd = dg - dprev;                           // (dd + 1) << sh bounds the group's span
-    const int bits = dd ? 32 - (int)__builtin_clz(dd) : 0;    // = ceil(log2(dd + 1))
-    return FineQuant{kb + ((uint64_t)dprev << sh), sh + (bits > 8 ? bits - 8 : 0)};
-}
 constexpr int KEY_SHIFT = 30;  // S <= 2^62: (prefix >> 30) fits 32 bits whatever N is, once the one value 2^62 is saturated
 // S = 2^62 exactly when N >= 1024 is a power of two and EVERY weight equals the maximum (a second resample right after a
 // resample: all log-weights 0).  For the keys and the 16-bit offsets such a prefix counts as 2^62 - 1: the maps stay monotone, no
@@ -211,12 +195,12 @@ struct ScanExtras {            // optional side jobs of a scan launch
     MboxWait wait;
     MboxPush push;
 };
-// Workgroup of the scan kernels: SCAN_BLOCK threads over one 2048-element tile, every wave SCAN_ROWS rows of 128.  512 threads
-// (8 waves, 2 rows each; two workgroups per CU = 16 waves per CU) hide the kernel's three dependent round trips -- weights in,
-// aggregates of the earlier tiles, levels out -- twice as well as 256 x 4 rows did (r02: 7.6 waves per CU, 65 % of the wave
-// cycles waiting; profiles/r03_scan_phases.txt).
+// Workgroup of the scan kernels: SCAN_BLOCK threads over one 2048-element tile, every wave SCAN_ROWS rows of 128.  256 threads x 4
+// rows is the measured optimum: 512 x 2 (twice the waves per CU against the kernel's three dependent round trips) ran 1.3-1.5 us
+// SLOWER (13.5 -> 14.9 us with the offset levels, 12.1 -> 13.4 without; profiles/r03_scan_phases.txt) -- the fold of the partial
+// maxima and the two block-wide reductions cost more with eight waves than the extra overlap returns.
 #ifndef GPF_SCAN_BLOCK
-#define GPF_SCAN_BLOCK 512
+#define GPF_SCAN_BLOCK 256
 #endif
 constexpr int SCAN_BLOCK = GPF_SCAN_BLOCK;
 constexpr int SCAN_NWAVES = SCAN_BLOCK / WAVE;
@@ -328,20 +312,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
         for (int w = 0; w < SCAN_NWAVES; ++w) excl += s_red[w];
         if (threadIdx.x == 0) desc_store(d_pre + tile, DESC_VALID | (excl + agg));
         const uint64_t off = excl + wexcl;
-        // k_search_fine's levels: this wave owns 256 cells = 16 groups of 16; its 1024-cell super-group is 4 consecutive waves
-        uint32_t f_khi = 0; int f_sh = 0; uint64_t f_kb = 0;
-        if constexpr (SCAN_ROWS == 2) {
-            if (out.o8) {                                       // kernel-uniform
-                uint64_t sg0 = 0, sgt = 0;
-#pragma unroll
-                for (int w = 0; w < SCAN_NWAVES; ++w) { if (w < (wv & ~3)) sg0 += s_wave[w]; if ((w & ~3) == (wv & ~3)) sgt += s_wave[w]; }
-                const uint64_t sg_start = excl + sg0, sg_end = sg_start + sgt;
-                const uint32_t klo = (uint32_t)(key_sat(sg_start) >> KEY_SHIFT);
-                f_khi = (uint32_t)(key_sat(sg_end) >> KEY_SHIFT);
-                f_sh = key_quant_shift(klo, f_khi);
-                f_kb = (uint64_t)klo << KEY_SHIFT;
-            }
-        }
         if (out.cdf) {
 #pragma unroll
             for (int k = 0; k < SCAN_ROWS; ++k) {
@@ -352,19 +322,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
                 if ((lane & 15) == 15) out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(v1) >> KEY_SHIFT);   // ... = 31 (mod 32)
                 if (lane == WAVE - 1 && (k & 1)) out.t256[(idx + 1) >> 8] = v1;         // ... = 255 (mod 256)
                 if (out.k32s && lane == WAVE - 1) out.k32s[(idx + 1) >> 7] = (uint32_t)(key_sat(v1) >> KEY_SHIFT);   // (sample == 2) element idx+1 = 127 (mod 128)
-                if constexpr (SCAN_ROWS == 2) {
-                if (out.o8) {                                                           // kernel-uniform
-                    const uint32_t dl = (uint32_t)((key_sat(v1) - f_kb) >> f_sh);         // this lane's second cell, as a group-end candidate
-                    const uint32_t dg = (uint32_t)__shfl((int)dl, lane | 7, WAVE);        // the group's end (its last lane)
-                    uint32_t dprev = (uint32_t)__shfl((int)dl, ((lane & ~7) - 1) & (WAVE - 1), WAVE);   // end of the previous group
-                    if (lane < 8) dprev = ((wv & 3) == 0 && k == 0) ? 0u : (uint32_t)((key_sat(off + cb[k]) - f_kb) >> f_sh);   // the row's first group
-                    const FineQuant fq = fine_quant(f_kb, f_sh, dprev, dg);
-                    const uint32_t o0 = (uint32_t)((key_sat(off + p[2 * k]) - fq.base) >> fq.sh8), o1 = (uint32_t)((key_sat(v1) - fq.base) >> fq.sh8);
-                    reinterpret_cast<uint16_t*>(out.o8)[idx >> 1] = (uint16_t)(o0 | (o1 << 8));
-                    if ((lane & 7) == 7) out.d16[(idx + 1) >> 4] = (uint16_t)dl;
-                    if ((wv & 3) == 3 && k == SCAN_ROWS - 1 && lane == WAVE - 1) out.k1024[(idx + 1) >> 10] = f_khi;
-                }
-                }
                 if (out.off16) {                                                        // kernel-uniform
                     // 16-bit offsets inside the key group (16 << logg lanes of this row): klo = key of the previous group
                     const int GL = 16 << out.logg;

@@ -13,7 +13,6 @@ struct CdfLevels {
     const uint32_t* k32;                                                                        // 4-byte keys per 32 cells (ScanOut::k32)
     const uint16_t* off16; const uint16_t* coarse; int logg;                                    // ScanOut::off16 / coarse / logg
     const uint32_t* k32s; int sample;                                                           // ScanOut::k32s / sample (k_search_multi_s)
-    const uint32_t* k1024; const uint16_t* d16; const uint8_t* o8;                              // ScanOut::k1024 / d16 / o8 (k_search_fine)
 };
 // a pointer rebuilt from an integer is generic (flat_load: also counts on lgkmcnt and serialises behind the LDS
 // reads); the lines live in global memory, so say so
@@ -674,160 +673,6 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_search_multi(SearchArgs a)
         const int64_t j0 = base + NS * (int64_t)threadIdx.x;
         uint32_t idx[NS];
         multi_lookup<LOGG, NS>(tb, a.w, a.n_cells, T, idx);
-        int32_t* dst = a.anc + j0;
-        if (j0 + NS <= a.n && (reinterpret_cast<uintptr_t>(dst) & (4 * NS - 1)) == 0) {
-            if (NS == 4) *reinterpret_cast<int4*>(dst) = make_int4((int32_t)idx[0], (int32_t)idx[1], (int32_t)idx[2], (int32_t)idx[3]);
-            else *reinterpret_cast<int2*>(dst) = make_int2((int32_t)idx[0], (int32_t)idx[1]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < NS; ++u) if (j0 + u < a.n) dst[u] = (int32_t)idx[u];
-        }
-        if (base + stride < a.n) targets(base + stride, T);
-    }
-}
-
-// ----------------------------------------------------------------------------- K5a': i.i.d. targets, ONE divergent global load per slot
-// What k_search_multi costs is its two divergent global loads per slot (coarse row, fine run): each occupies the CU's address
-// path for a few cycles per lane whatever level of the hierarchy answers (r02: 3.4 + 4.8 us of its 16.8 at 10^6 slots).  Here the
-// LDS table reaches down to 16-cell groups, so that ONE 16-byte read -- the group's sixteen 8-bit offsets -- names the cell:
-//   level 1, LDS: 4-byte key (prefix >> KEY_SHIFT) at the end of every 1024-cell super-group (ScanOut::k1024; 4 KB at 10^6);
-//   level 2, LDS: the prefix at the end of every 16-cell group as a 16-bit offset inside its super-group (ScanOut::d16; 125 KB),
-//            one pad word per super-group against bank conflicts; 6-step uniform binary search over the super-group's 64 entries;
-//   level 3, one 16-byte global read per slot: the group's 8-bit offsets (ScanOut::o8, fine_quant); cell = number of offsets below
-//            the target's.  Equal offsets (~6 % of the slots: a cell spans ~16 of the 256 levels) are decided by the exact prefixes,
-//            as are equal 16-bit offsets (~1e-3, through the per-16 level t16) and equal keys (through the CDF at super-group ends).
-// Fits LDS up to ~1.2 M cells; larger filters keep k_search_multi.
-constexpr int FINE_GPS = 64;                        // 16-cell groups per super-group
-constexpr int FINE_DPAD = FINE_GPS + 2;             // LDS entries per super-group (one pad dword)
-__host__ __device__ __forceinline__ int64_t fine_supergroups(int64_t ntiles) { return ntiles * (TILE / 1024); }
-__host__ inline size_t fine_lds_bytes(int64_t ntiles)
-{
-    const int64_t nsg = fine_supergroups(ntiles);
-    return (size_t)(kpad((uint32_t)nsg) + 1) * sizeof(uint32_t) + (size_t)nsg * FINE_DPAD * sizeof(uint16_t) + 16;
-}
-__host__ inline bool fine_fits(int64_t ntiles) { return SCAN_ROWS == 2 && fine_lds_bytes(ntiles) <= (size_t)MULTI_LDS_BUDGET; }
-
-// byte-wise counts over a 32-bit word of four 8-bit offsets against q (qq = q | q << 16): number of bytes < q, number != q
-__device__ __forceinline__ uint32_t b4_lt(uint32_t x, uint32_t qq) { return pk_lt(x & 0x00ff00ffu, qq) + pk_lt((x >> 8) & 0x00ff00ffu, qq); }
-__device__ __forceinline__ uint32_t b4_ne(uint32_t x, uint32_t qq) { return pk_ne(x & 0x00ff00ffu, qq) + pk_ne((x >> 8) & 0x00ff00ffu, qq); }
-
-template <int NS>
-__device__ __forceinline__ void fine_lookup(const MultiTable& tb, const uint16_t* __restrict__ dl, const CdfLevels& w, int64_t n_cells,
-                                            const uint64_t (&T)[NS], uint32_t (&idx)[NS])
-{
-    uint32_t pos[NS];
-    multi_find<5, NS>(tb, w, T, pos);                                   // the 1024-cell super-group (32 << 5 cells per key)
-    uint32_t g[NS], qq[NS];
-    uint64_t base[NS]; int sh8[NS];
-    uint4 row[NS];
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        const uint32_t s = pos[u] < tb.ng ? pos[u] : tb.ng - 1;
-        const uint32_t klo = s ? tb.keys[kpad(s - 1)] : 0u, khi = tb.keys[kpad(s)];
-        const int sh = key_quant_shift(klo, khi);
-        const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
-        const uint64_t d = T[u] > kb ? T[u] - kb : 0;
-        uint32_t q = (uint32_t)(d >> sh);
-        q = q < 65535u ? q : 65535u;
-        const uint16_t* ds = dl + (size_t)s * FINE_DPAD;                 // the super-group's 64 group-end offsets
-        uint32_t c = 0;                                                  // number of entries < q (uniform binary search, 64 = 2^6 entries)
-#pragma unroll
-        for (uint32_t h = 32; h >= 1; h >>= 1) c += ds[c + h - 1] < q ? h : 0u;
-        c += ds[c] < q ? 1u : 0u;                                        // c in [0, 64]
-        // equal offsets: the exact prefixes at the group ends decide (rare: one value in ~2^12 per slot)
-        while (c < (uint32_t)FINE_GPS && ds[c] == q && w.t16[(size_t)s * FINE_GPS + c] <= T[u]) ++c;
-        c = c < (uint32_t)FINE_GPS ? c : (uint32_t)FINE_GPS - 1;         // (the super-group holds T: its last group ends above it)
-        const FineQuant fq = fine_quant(kb, sh, c ? (uint32_t)ds[c - 1] : 0u, (uint32_t)ds[c]);
-        g[u] = s * (uint32_t)FINE_GPS + c;
-        base[u] = fq.base; sh8[u] = fq.sh8;
-        row[u] = *reinterpret_cast<const uint4*>(w.o8 + (size_t)g[u] * 16);
-    }
-    bool anytie = false;
-    uint32_t lt[NS], eq[NS];
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        const uint64_t d = T[u] > base[u] ? T[u] - base[u] : 0;
-        uint32_t q = (uint32_t)(d >> sh8[u] < 255u ? d >> sh8[u] : 255u);
-        qq[u] = q | (q << 16);
-        uint32_t a = b4_lt(row[u].x, qq[u]) + b4_lt(row[u].y, qq[u]) + b4_lt(row[u].z, qq[u]) + b4_lt(row[u].w, qq[u]);
-        uint32_t b = b4_ne(row[u].x, qq[u]) + b4_ne(row[u].y, qq[u]) + b4_ne(row[u].z, qq[u]) + b4_ne(row[u].w, qq[u]);
-        lt[u] = (a & 0xffffu) + (a >> 16);
-        eq[u] = 16u - ((b & 0xffffu) + (b >> 16));
-        anytie = anytie || eq[u] != 0;
-        idx[u] = g[u] * 16u + lt[u];
-    }
-    if (__any(anytie)) {
-        // cells lt .. lt + eq - 1 share the target's offset: the exact prefixes decide (every cell before them is below T, every cell
-        // after them above); offsets ascend with the cells, so they are one run
-#pragma unroll
-        for (int u = 0; u < NS; ++u) {
-            if (!eq[u]) continue;
-            uint32_t i = idx[u];
-            const uint32_t end = i + eq[u];
-            while (i < end && w.cdf[i] <= T[u]) ++i;
-            idx[u] = i;
-        }
-    }
-    const uint32_t last = (uint32_t)(n_cells - 1);
-#pragma unroll
-    for (int u = 0; u < NS; ++u) idx[u] = idx[u] < last ? idx[u] : last;
-}
-
-__global__ __launch_bounds__(SBLOCK, 4) void k_search_fine(SearchArgs a)
-{
-    constexpr int NS = GPF_MULTI_NS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (a.update_lml && blockIdx.x == 0 && threadIdx.x == 0) resample_bookkeeping(a);   // update_lml_est! (resample.jl:57,178-182)
-    const uint64_t S = a.ws->S;
-    auto targets = [&](int64_t base, uint64_t* T) {                      // as k_search_multi: one Philox block per aligned slot pair
-        const uint32_t s0 = (uint32_t)(a.gid0 + base + NS * (int64_t)threadIdx.x), sb = s0 >> 1;
-        if (!(s0 & 1u)) {                                                // kernel-uniform
-#pragma unroll
-            for (int q = 0; q < NS / 2; ++q) {
-                const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
-                T[2 * q] = mulhi64(u64(b.w0, b.w1), S); T[2 * q + 1] = mulhi64(u64(b.w2, b.w3), S);     // resample.jl:59
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q <= NS / 2; ++q) {
-                const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
-                if (q > 0) T[2 * q - 1] = mulhi64(u64(b.w0, b.w1), S);
-                if (q < NS / 2) T[2 * q] = mulhi64(u64(b.w2, b.w3), S);
-            }
-        }
-    };
-    // the two LDS levels: keys of the super-groups (padded like k_search_multi's table), then the 16-bit group offsets
-    MultiTable tb;
-    tb.ng = (uint32_t)fine_supergroups(a.ntiles);
-    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
-    uint16_t* dl = reinterpret_cast<uint16_t*>(keys + ((kpad(tb.ng) + 1 + 3) & ~3u));
-    tb.keys = keys;
-    tb.p2 = 1; while (2 * tb.p2 <= tb.ng) tb.p2 *= 2;
-    tb.kscale = (float)tb.ng / (float)((S >> KEY_SHIFT) + 1);
-    constexpr int DT = (MULTI_LDS_BUDGET / FINE_DPAD / 2 * FINE_GPS / 8 + SBLOCK - 1) / SBLOCK;   // 16-byte loads per lane that cover any d16 level within the budget
-    const uint32_t nd8 = tb.ng * (FINE_GPS / 8);                         // 16-byte pieces (8 entries) of the level
-    uint4 dv[DT];
-    const uint4* dsrc = reinterpret_cast<const uint4*>(a.w.d16);
-#pragma unroll
-    for (int r = 0; r < DT; ++r) { const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK; if (q < nd8) dv[r] = dsrc[q]; }
-    for (uint32_t i = threadIdx.x; i < tb.ng; i += SBLOCK) keys[kpad(i)] = a.w.k1024[i];
-    const int64_t stride = (int64_t)gridDim.x * NS * SBLOCK;
-    int64_t base = (int64_t)blockIdx.x * NS * SBLOCK;
-    uint64_t T[NS];
-    targets(base, T);                                                    // while the level's loads are in flight
-#pragma unroll
-    for (int r = 0; r < DT; ++r) {
-        const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK;
-        if (q < nd8) {                                                   // piece q = entries 8 (q % 8) .. + 7 of super-group q / 8: 4 dwords, never across a pad
-            uint32_t* d = reinterpret_cast<uint32_t*>(dl + (size_t)(q >> 3) * FINE_DPAD + (q & 7u) * 8u);
-            d[0] = dv[r].x; d[1] = dv[r].y; d[2] = dv[r].z; d[3] = dv[r].w;
-        }
-    }
-    __syncthreads();
-    for (; base < a.n; base += stride) {
-        const int64_t j0 = base + NS * (int64_t)threadIdx.x;
-        uint32_t idx[NS];
-        fine_lookup<NS>(tb, dl, a.w, a.n_cells, T, idx);
         int32_t* dst = a.anc + j0;
         if (j0 + NS <= a.n && (reinterpret_cast<uintptr_t>(dst) & (4 * NS - 1)) == 0) {
             if (NS == 4) *reinterpret_cast<int4*>(dst) = make_int4((int32_t)idx[0], (int32_t)idx[1], (int32_t)idx[2], (int32_t)idx[3]);

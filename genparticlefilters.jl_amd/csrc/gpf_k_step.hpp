@@ -159,7 +159,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
 // pf_move_reweight! with move_reweight(trace, selection) (rejuvenate.jl:74-90, :125-132)
 // GATHER: a pf_resample! left its ancestor vector pending; the move reads row anc[i] (new_traces .= view(traces, parents),
 // resample.jl:60, fused) and the incoming log-weights are 0 (resample.jl:195), exactly like k_step<GATHER>.
-template <int M, int W, bool REWEIGHT, bool GATHER = false>
+// PROP (with REWEIGHT): move_reweight(trace, proposal, proposal_args) (rejuvenate.jl:134-148) with the model's native move proposal
+// (Model::move_propose): the new latent comes from the proposal, rel_weight = weight - fwd_score + bwd_score.
+template <int M, int W, bool REWEIGHT, bool GATHER = false, bool PROP = false>
 __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, int has_prev, int n_iters, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
@@ -185,7 +187,15 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
         double wsum = 0.0;
         const uint32_t gid = (uint32_t)(gid0 + i * a.gstride);
         for (int it = 0; it < n_iters; ++it) {
-            if (REWEIGHT) {
+            if constexpr (PROP) {
+                if constexpr (Mo::HAS_MOVE_PROPOSAL) {
+                    const double rw = Mo::move_propose(a.P, a.q, !has_prev, xp, x, a.obs, seed, gid, (uint32_t)(it * NB), epoch, TAG_REWEIGHT, xs);
+                    wsum = wsum + rw;                                          // rejuvenate.jl:86
+#pragma unroll
+                    for (int k = 0; k < D; ++k) x[k] = xs[k];
+                    ++acc;
+                }
+            } else if (REWEIGHT) {
                 Mo::sample(a.P, !has_prev, xp, a.obs, seed, gid, (uint32_t)(it * NB), epoch, TAG_REWEIGHT, xs);
                 const double lls = Mo::loglik(a.P, xs, a.obs);
                 wsum = wsum + (lls - llx);

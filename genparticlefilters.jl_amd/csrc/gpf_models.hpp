@@ -30,6 +30,7 @@ struct ModelArgs {          // passed by value in the kernarg segment: no device
     // strided sub-state views (reference src/view.jl:35-48 with idxs = start:step:stop): local particle i is particle
     // gid0 + i * gstride of the filter and keeps THAT id as its RNG counter (1 everywhere else)
     int32_t gstride, pad_;
+    double q[4];                 // parameters of a native MOVE proposal (gpf_rejuvenate_proposal), e.g. {p, log p, log(1 - p)}
 };
 
 template <int M> struct Model;
@@ -55,11 +56,31 @@ template <> struct Model<MODEL_LGSSM2> {
         const double m0 = mu0 + P[o] * (obs[0] - mu0), m1 = mu1 + P[o] * (obs[1] - mu1);
         xn[0] = m0 + P[o + 1] * z0;
         xn[1] = m1 + P[o + 1] * z1;
-        const double a0 = (xn[0] - mu0) * P[o + 4], a1 = (xn[1] - mu1) * P[o + 4];
+        return proposal_weight(P, first, xp, obs, xn);
+    }
+    // [log p(x | x_{t-1}) + log p(y | x)] - log q(x | x_{t-1}, y) for a GIVEN x (the weight of `propose`; the two scores of a move)
+    static GPF_HD double proposal_weight(const double* P, bool first, const double* xp, const double* obs, const double* x)
+    {
+        const double mu0 = first ? 0.0 : P[0] * xp[0] + P[1] * xp[1];
+        const double mu1 = first ? 0.0 : P[2] * xp[0] + P[3] * xp[1];
+        const int o = first ? 14 : 8;
+        const double m0 = mu0 + P[o] * (obs[0] - mu0), m1 = mu1 + P[o] * (obs[1] - mu1);
+        const double a0 = (x[0] - mu0) * P[o + 4], a1 = (x[1] - mu1) * P[o + 4];
         const double lt = -0.5 * (a0 * a0 + a1 * a1) - P[o + 5];
-        const double b0 = (xn[0] - m0) * P[o + 2], b1 = (xn[1] - m1) * P[o + 2];
+        const double b0 = (x[0] - m0) * P[o + 2], b1 = (x[1] - m1) * P[o + 2];
         const double lq = -0.5 * (b0 * b0 + b1 * b1) - P[o + 3];
-        return (lt + loglik(P, xn, obs)) - lq;
+        return (lt + loglik(P, x, obs)) - lq;
+    }
+    // move_reweight(trace, proposal, proposal_args) (src/rejuvenate.jl:134-148) with the locally optimal proposal of x_t:
+    // fwd_choices ~ q(. | x_{t-1}, y_t); update -> weight = model score(new) - model score(old); rel_weight = weight - fwd_score +
+    // bwd_score = W(x') - W(x) with W = proposal_weight.  (q is the exact conditional here, so the relative weight is 0 up to
+    // rounding: a Gibbs move on x_t.)
+    static constexpr bool HAS_MOVE_PROPOSAL = true;
+    static GPF_HD double move_propose(const double* P, const double*, bool first, const double* xp, const double* x, const double* obs,
+                                      uint64_t seed, uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
+    {
+        const double wn = propose(P, first, xp, obs, seed, gid, blk0, epoch, tag, xn);
+        return wn - proposal_weight(P, first, xp, obs, x);
     }
     static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
                               uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
@@ -87,6 +108,7 @@ template <> struct Model<MODEL_BEARINGS4> {
     static constexpr bool HAS_STRATA = false;
     static constexpr int D = 4, NBLK = 2;
     static constexpr bool HAS_PROPOSAL = false;
+    static constexpr bool HAS_MOVE_PROPOSAL = false;
     static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
                               uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
     {
@@ -120,6 +142,7 @@ template <> struct Model<MODEL_SV1> {
     static constexpr bool HAS_STRATA = false;
     static constexpr int D = 1, NBLK = 1;
     static constexpr bool HAS_PROPOSAL = false;
+    static constexpr bool HAS_MOVE_PROPOSAL = false;
     static GPF_HD void sample(const double* P, bool first, const double* xp, const double*, uint64_t seed,
                               uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
     {
@@ -142,6 +165,7 @@ template <> struct Model<MODEL_SV1> {
 template <> struct Model<MODEL_OBJECT_MOTION> {
     static constexpr int D = 2, NBLK = 2;
     static constexpr bool HAS_PROPOSAL = false;
+    static constexpr bool HAS_MOVE_PROPOSAL = false;
     static constexpr bool HAS_STRATA = true;
     // stratified generate / update: `moving` is constrained to the stratum's value (merge(stratum, observations),
     // initialize.jl:102, update.jl:200); y is sampled as usual.  Returns log p(moving = value | moving_{t-1}), the part of
@@ -216,6 +240,23 @@ template <> struct Model<MODEL_LINE> {
         double w = first ? P[7] : 0.0;                                                         // log p(slope = 0) = log(1/5), test/initialize.jl:21
         if (obs[1] != 0.0) w = (w + P[6]) + loglik(P, xn, obs);                                // log p(outlier = false) + log p(y | .)
         return w;
+    }
+    // move_reweight(trace, outlier_propose, (idx,)) with outlier_propose = {:line => idx => :outlier} ~ bernoulli(q) for the current
+    // step (src/rejuvenate.jl:134-148; the reference's test uses q = 0.9, test/rejuvenate.jl:19-27):
+    //   weight = [log p(out') + log p(y | slope, out')] - [log p(out) + log p(y | slope, out)]   (update with the proposed choice)
+    //   rel_weight = weight - log q(out') + log q(out)                                            (:146)
+    // Q = {q, log q, log(1 - q)}
+    static constexpr bool HAS_MOVE_PROPOSAL = true;
+    static GPF_HD double move_propose(const double* P, const double* Q, bool, const double*, const double* x, const double* obs,
+                                      uint64_t seed, uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double* xn)
+    {
+        const Philox b = rng(seed, gid, blk0, epoch, tag);
+        xn[0] = x[0];
+        xn[1] = (obs[1] != 0.0 && u52(b.w2, b.w3) < Q[0]) ? 1.0 : 0.0;
+        if (obs[1] == 0.0) return 0.0;                                                         // model args (0,): no outlier choice to move
+        const bool on = xn[1] != 0.0, oo = x[1] != 0.0;
+        const double wn = (on ? P[5] : P[6]) + loglik(P, xn, obs), wo = (oo ? P[5] : P[6]) + loglik(P, x, obs);
+        return ((wn - wo) - (on ? Q[1] : Q[2])) + (oo ? Q[1] : Q[2]);
     }
     // stratified initialise (strata over `slope`, test/initialize.jl:39-64) / update (strata over the step's `outlier`,
     // test/update.jl:13-40): the stratified choice is constrained, the other one is sampled as usual; returns the log

@@ -92,8 +92,6 @@ struct gpf_filter {
     bool want_offsets = true;      // what the next scan of channel 0 writes
     bool ch0_offsets = false;      // what the last scan of channel 0 wrote
     bool offsets_hint = true;      // was the last resample multinomial?  (scans that run ahead of a resample: the ESS getter)
-    bool want_fine = true;         // offsets wanted: prefer k_search_fine's levels (k1024 / d16 / o8) when its table fits LDS (sharded scans: no, k_push_multi reads off16)
-    bool ch0_fine = false;         // the last scan of channel 0 wrote k_search_fine's levels (instead of off16 / coarse)
     bool pending_packed = false;   // sharded: the resampled population is still the received exchange buffer (gpf_shard_commit)
     const double* pend_packed = nullptr; const double* pend_mf = nullptr; const int64_t* pend_tot = nullptr; int pend_G = 0;
     bool pend_mailbox = false;     // pend_mf / pend_tot sit in the shard mailbox
@@ -179,20 +177,13 @@ uint16_t* off16_of(uint64_t* t256, int64_t ntiles) { return reinterpret_cast<uin
 uint16_t* coarse_of(uint64_t* t256, int64_t ntiles) { return off16_of(t256, ntiles) + ntiles * TILE; }
 uint32_t* k32s_of(uint64_t* t256, int64_t ntiles) { return reinterpret_cast<uint32_t*>(coarse_of(t256, ntiles) + ntiles * (TILE / 4)); }
 // channel 0 (the weights) carries the offset levels when k_search_multi can take the filter (multi_logg >= 0)
-// k_search_fine's levels live where off16 / coarse / k32s would (one family per scan): o8 1 byte per cell, d16 2 bytes per 16 cells,
-// k1024 4 bytes per 1024 cells
-uint8_t* o8_of(uint64_t* t256, int64_t ntiles) { return reinterpret_cast<uint8_t*>(off16_of(t256, ntiles)); }
-uint16_t* d16_of(uint64_t* t256, int64_t ntiles) { return coarse_of(t256, ntiles); }
-uint32_t* k1024_of(uint64_t* t256, int64_t ntiles) { return k32s_of(t256, ntiles); }
-ScanOut scan_out(uint64_t* cdf, uint64_t* t16, uint64_t* t256, int64_t ntiles, bool with_offsets, bool fine = false)
+ScanOut scan_out(uint64_t* cdf, uint64_t* t16, uint64_t* t256, int64_t ntiles, bool with_offsets)
 {
-    if (with_offsets && fine && fine_fits(ntiles))
-        return ScanOut{cdf, t16, t256, k32_of(t256, ntiles), nullptr, nullptr, -1, nullptr, 0, k1024_of(t256, ntiles), d16_of(t256, ntiles), o8_of(t256, ntiles)};
     int logg = with_offsets ? multi_logg(ntiles) : -1;
     const int sample = with_offsets && logg < 0 ? multi_sample(ntiles) : 0;       // beyond 2.5 M particles: 32-cell levels + sampled keys
     if (sample > 0) logg = 0;
     return ScanOut{cdf, t16, t256, k32_of(t256, ntiles), logg >= 0 ? off16_of(t256, ntiles) : nullptr, logg >= 0 ? coarse_of(t256, ntiles) : nullptr, logg,
-                   sample > 0 ? k32s_of(t256, ntiles) : nullptr, sample, nullptr, nullptr, nullptr};
+                   sample > 0 ? k32s_of(t256, ntiles) : nullptr, sample};
 }
 
 int grid_for(const gpf_filter* h, int64_t work_items, int blocks_per_cu)
@@ -372,6 +363,31 @@ bool model_has_strata(int model)
     }
     return false;
 }
+template <int M>
+void launch_move_prop_t(gpf_filter* h, int grid, int n_iters)
+{
+    constexpr int Wc = row_width(Model<M>::D, true);
+    if constexpr (!Model<M>::HAS_MOVE_PROPOSAL) { (void)h; (void)grid; (void)n_iters; return; }
+    else if (h->pending_gather)
+        GPF_LAUNCH((k_move<M, Wc, true, true, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                           h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
+                           reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
+    else
+        GPF_LAUNCH((k_move<M, Wc, true, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                           h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
+                           reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
+}
+bool model_has_move_proposal(int model)
+{
+    switch (model) {
+        case MODEL_LGSSM2: return Model<MODEL_LGSSM2>::HAS_MOVE_PROPOSAL;
+        case MODEL_BEARINGS4: return Model<MODEL_BEARINGS4>::HAS_MOVE_PROPOSAL;
+        case MODEL_SV1: return Model<MODEL_SV1>::HAS_MOVE_PROPOSAL;
+        case MODEL_OBJECT_MOTION: return Model<MODEL_OBJECT_MOTION>::HAS_MOVE_PROPOSAL;
+        case MODEL_LINE: return Model<MODEL_LINE>::HAS_MOVE_PROPOSAL;
+    }
+    return false;
+}
 template <int M, bool RW>
 void launch_move_t(gpf_filter* h, int grid, int n_iters)
 {
@@ -507,8 +523,8 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
     uint64_t* dn = h->desc[ch][1 - h->dcur[ch]];
     const int gs = scan_grid(h);
     const bool offsets = ch == 0 && h->want_offsets && want_cdf;
-    const ScanOut so = scan_out(want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch], h->ntiles, offsets, h->want_fine);
-    if (ch == 0 && want_cdf) { h->ch0_offsets = offsets && (so.off16 != nullptr || so.o8 != nullptr); h->ch0_fine = offsets && so.o8 != nullptr; }
+    const ScanOut so = scan_out(want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch], h->ntiles, offsets);
+    if (ch == 0 && want_cdf) h->ch0_offsets = offsets && so.off16 != nullptr;
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
         GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, in, h->n, h->ntiles, pmax, h->pflags, np, slot,
                            so, dc, dn, total_out, h->blockQ, h->h_timeout, ex);
@@ -745,15 +761,12 @@ gpf_status ensure_residual_buffers(gpf_filter* h)
 
 CdfLevels levels(const gpf_filter* h, int ch)
 {
-    if (ch == 0 && h->ch0_offsets && h->ch0_fine)
-        return CdfLevels{h->cdf[ch], h->t16[ch], h->t256[ch], h->table[ch], k32_of(h->t256[ch], h->ntiles), nullptr, nullptr, -1, nullptr, 0,
-                         k1024_of(h->t256[ch], h->ntiles), d16_of(h->t256[ch], h->ntiles), o8_of(h->t256[ch], h->ntiles)};
     int logg = ch == 0 && h->ch0_offsets ? multi_logg(h->ntiles) : -1;
     const int sample = ch == 0 && h->ch0_offsets && logg < 0 ? multi_sample(h->ntiles) : 0;
     if (sample > 0) logg = 0;
     return CdfLevels{h->cdf[ch], h->t16[ch], h->t256[ch], h->table[ch], k32_of(h->t256[ch], h->ntiles),
                      logg >= 0 ? off16_of(h->t256[ch], h->ntiles) : nullptr, logg >= 0 ? coarse_of(h->t256[ch], h->ntiles) : nullptr, logg,
-                     sample > 0 ? k32s_of(h->t256[ch], h->ntiles) : nullptr, sample, nullptr, nullptr, nullptr};
+                     sample > 0 ? k32s_of(h->t256[ch], h->ntiles) : nullptr, sample};
 }
 
 // residual: copy-count and residual-weight CDFs from the weight CDF (resample.jl:99,109); ws->S must be the GLOBAL sum
@@ -784,11 +797,6 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
 // ancestors of i.i.d. targets: k_search_multi (4-byte keys of every 32 / 64 cells in LDS) while the key table fits, else k_search<0>
 void launch_multinomial_search(gpf_filter* h, const SearchArgs& sa)
 {
-    if (sa.w.o8) {                                               // up to ~1.2 M cells: both LDS levels, ONE divergent global read per slot
-        const int gsf = (int)std::max<int64_t>(1, std::min<int64_t>((sa.n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));
-        GPF_LAUNCH(k_search_fine, dim3(gsf), dim3(SBLOCK), fine_lds_bytes(sa.ntiles), h->stream, sa);
-        return;
-    }
     const int logg = sa.w.off16 && sa.w.sample == 0 ? sa.w.logg : -1;   // the offset levels exist for channel 0 only
     if (sa.w.off16 && sa.w.sample > 0) {                         // 2.5 M .. 5 M particles: sampled key table
         const int gss = (int)std::max<int64_t>(1, std::min<int64_t>((sa.n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu));
@@ -812,7 +820,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     const bool sorted = method == GPF_RESAMPLE_STRATIFIED && sort_particles;
     const bool need_sync = check == GPF_CHECK_TRUE || invalid != nullptr;
     // only the multinomial search reads the offset levels: the scans of this call write them for it alone
-    const bool need_off = method == GPF_RESAMPLE_MULTINOMIAL && (fine_fits(h->ntiles) || multi_logg(h->ntiles) >= 0 || multi_sample(h->ntiles) > 0);
+    const bool need_off = method == GPF_RESAMPLE_MULTINOMIAL && (multi_logg(h->ntiles) >= 0 || multi_sample(h->ntiles) > 0);
     struct OffScope { gpf_filter* h; ~OffScope() { h->want_offsets = true; } } off_scope{h};
     h->want_offsets = need_off;
     h->offsets_hint = need_off;
@@ -1022,7 +1030,6 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_multi<0>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_multi<1>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_multi_s<2>), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_fine), hipFuncAttributeMaxDynamicSharedMemorySize, MULTI_LDS_BUDGET));
 #define GPF_PUSH_ATTR(M, W) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_push<M, W>), hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn))
         GPF_PUSH_ATTR(0, 2); GPF_PUSH_ATTR(0, 4); GPF_PUSH_ATTR(0, 8);
         GPF_PUSH_ATTR(1, 2); GPF_PUSH_ATTR(1, 4); GPF_PUSH_ATTR(1, 8);
@@ -1220,7 +1227,22 @@ gpf_status gpf_resample_with_priorities(gpf_handle h, int32_t method, const doub
     return resample_impl(h, method, pv, sort_particles, check, invalid);
 }
 
+static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters, uint64_t* n_accepted, bool with_proposal);
 gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_t* n_accepted)
+{
+    return rejuvenate_impl(h, method, n_iters, n_accepted, false);
+}
+gpf_status gpf_rejuvenate_proposal(gpf_handle h, int32_t proposal, const double* params, int32_t n_params, int32_t n_iters)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (n_params < 0 || n_params > 4 || (n_params > 0 && !params)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad proposal parameters");
+    const bool ok = (proposal == GPF_MOVE_PROPOSAL_LOCALLY_OPTIMAL && h->cfg.model == MODEL_LGSSM2 && n_params == 0) ||
+                    (proposal == GPF_MOVE_PROPOSAL_LINE_OUTLIER && h->cfg.model == MODEL_LINE && n_params == 3);
+    if (!ok || !model_has_move_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown move proposal for this model (or wrong parameter count)");
+    for (int i = 0; i < 4; ++i) h->args.q[i] = i < n_params ? params[i] : 0.0;
+    return rejuvenate_impl(h, GPF_REJUVENATE_REWEIGHT, n_iters, nullptr, true);
+}
+static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters, uint64_t* n_accepted, bool with_proposal)
 {
     gpf_status s = check_ready(h);
     if (s) return s;
@@ -1234,8 +1256,9 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
     HIP_TRY(h, hipMemsetAsync(&h->sc->n_accept, 0, sizeof(uint64_t), h->stream));
     const int grid = move_grid(h);
     s = timed(h, GPF_K_MOVE, [&] {
-        if (method == GPF_REJUVENATE_REWEIGHT) { DISPATCH_MODEL(h, (launch_move_t<MM, true>(h, grid, n_iters))); }
-        else                                   { DISPATCH_MODEL(h, (launch_move_t<MM, false>(h, grid, n_iters))); }
+        if (with_proposal)                          { DISPATCH_MODEL(h, (launch_move_prop_t<MM>(h, grid, n_iters))); }
+        else if (method == GPF_REJUVENATE_REWEIGHT) { DISPATCH_MODEL(h, (launch_move_t<MM, true>(h, grid, n_iters))); }
+        else                                        { DISPATCH_MODEL(h, (launch_move_t<MM, false>(h, grid, n_iters))); }
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
@@ -1479,11 +1502,8 @@ gpf_status gpf_debug_levels(gpf_handle h, int32_t which, void* out, int64_t* n_b
         case 1: src = h->t16[0]; bytes = nt * (TILE / 16) * 8; break;
         case 2: src = h->t256[0]; bytes = nt * (TILE / 256) * 8; break;
         case 3: src = k32_of(h->t256[0], nt); bytes = nt * (TILE / 32) * 4; break;
-        case 4: src = off16_of(h->t256[0], nt); bytes = logg >= 0 && !h->ch0_fine ? nt * TILE * 2 : 0; break;
-        case 5: src = coarse_of(h->t256[0], nt); bytes = logg >= 0 && !h->ch0_fine ? (nt * TILE / (4 << logg)) * 2 : 0; break;
-        case 6: src = k1024_of(h->t256[0], nt); bytes = h->ch0_fine ? nt * (TILE / 1024) * 4 : 0; break;
-        case 7: src = d16_of(h->t256[0], nt); bytes = h->ch0_fine ? nt * (TILE / 16) * 2 : 0; break;
-        case 8: src = o8_of(h->t256[0], nt); bytes = h->ch0_fine ? nt * TILE : 0; break;
+        case 4: src = off16_of(h->t256[0], nt); bytes = logg >= 0 ? nt * TILE * 2 : 0; break;
+        case 5: src = coarse_of(h->t256[0], nt); bytes = logg >= 0 ? (nt * TILE / (4 << logg)) * 2 : 0; break;
         default: return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad level");
     }
     if (bytes > *n_bytes) return fail(h, GPF_ERR_INVALID_ARGUMENT, "output too small");
@@ -1925,8 +1945,6 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     // shard mailboxes: the scan waits for the ranks' (max, flags) entries itself and the kernel that ends up with the shard's
     // {S, limbs} stores them into every peer's mailbox (the scan's last workgroup, or k_export_q when the limbs are wanted)
     ScanExtras ex{h->shard_counts, h->h_flags, h->flag_ticket, 0};
-    struct FineScope { gpf_filter* h; bool was; ~FineScope() { h->want_fine = was; } } fine_scope{h, h->want_fine};
-    h->want_fine = false;                                         // a shard's multinomial lookups are k_push_multi's: off16 / coarse
     ex.wait = mb_wait(h, MB_MF);
     const MboxPush tot_push = mb_begin(h, MB_TOT);
     if (want_q) {

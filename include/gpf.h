@@ -139,6 +139,16 @@ gpf_status gpf_resample_with_priorities(gpf_handle h, int32_t method, const doub
  * (src/rejuvenate.jl:47). Requires keep_prev = 1. */
 gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_t* n_accepted);
 
+/* pf_move_reweight!(state, move_reweight, (proposal, proposal_args), n_iters)   src/rejuvenate.jl:74-90 with the PROPOSAL variant
+ * of the kernel, move_reweight(trace, proposal, proposal_args) (src/rejuvenate.jl:134-148): the current step's latent is proposed by a
+ * NATIVE proposal q, the trace is updated with it, log_weights[i] += weight - fwd_score + bwd_score.
+ *   GPF_MOVE_PROPOSAL_LOCALLY_OPTIMAL  (GPF_MODEL_LGSSM2, no parameters): q = p(x_t | x_{t-1}, y_t) -- a Gibbs move, relative weight 0 up to rounding
+ *   GPF_MOVE_PROPOSAL_LINE_OUTLIER     (GPF_MODEL_LINE, params = {q, log q, log(1 - q)}): {:line => t => :outlier} ~ bernoulli(q), the
+ *                                      outlier_propose of the reference's test (test/rejuvenate.jl:19-27, q = 0.9)
+ * Requires keep_prev = 1 like gpf_rejuvenate. */
+typedef enum { GPF_MOVE_PROPOSAL_LOCALLY_OPTIMAL = 1, GPF_MOVE_PROPOSAL_LINE_OUTLIER = 2 } gpf_move_proposal;
+gpf_status gpf_rejuvenate_proposal(gpf_handle h, int32_t proposal, const double* params, int32_t n_params, int32_t n_iters);
+
 /* ---- weight summaries ---------------------------------------------------------------------- */
 /* effective_sample_size(state) / get_ess                            src/utils.jl:163-164,171 */
 gpf_status gpf_effective_sample_size(gpf_handle h, double* out);

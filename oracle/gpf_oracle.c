@@ -463,6 +463,65 @@ O_EXPORT uint64_t o_move(int model, const double *P, uint64_t seed, uint32_t epo
     return nacc;
 }
 
+/* move_reweight(trace, proposal, proposal_args) (rejuvenate.jl:134-148) with a native proposal of the current step's latent:
+ *   fwd_choices, fwd_score = propose(proposal, (trace, args...))           :140-141
+ *   new_trace, weight, _, discard = update(trace, ..., fwd_choices)        :142-143   weight = model score(new) - model score(old)
+ *   bwd_score = assess(proposal, (new_trace, args...), discard)            :144-145
+ *   rel_weight = weight - fwd_score + bwd_score                            :147
+ * LGSSM2: the locally optimal proposal q = p(x_t | x_{t-1}, y_t): rel_weight = W(x') - W(x), W = (log p(x|x_prev) + log p(y|x)) - log q(x)
+ * LINE:   outlier ~ bernoulli(Q[0]) for the current step (test/rejuvenate.jl:19-27), Q = {q, log q, log(1 - q)} */
+static double lgssm2_proposal_weight(const double *P, int first, const double *xp, const double *obs, const double *x)
+{
+    double mu0 = first ? 0.0 : P[0] * xp[0] + P[1] * xp[1];
+    double mu1 = first ? 0.0 : P[2] * xp[0] + P[3] * xp[1];
+    int o = first ? 14 : 8;
+    double m0 = mu0 + P[o] * (obs[0] - mu0), m1 = mu1 + P[o] * (obs[1] - mu1);
+    double a0 = (x[0] - mu0) * P[o + 4], a1 = (x[1] - mu1) * P[o + 4];
+    double lt = -0.5 * (a0 * a0 + a1 * a1) - P[o + 5];
+    double b0 = (x[0] - m0) * P[o + 2], b1 = (x[1] - m1) * P[o + 2];
+    double lq = -0.5 * (b0 * b0 + b1 * b1) - P[o + 3];
+    return (lt + model_loglik(O_MODEL_LGSSM2, P, x, obs)) - lq;
+}
+static double model_move_propose(int model, const double *P, const double *Q, int first, const double *xp, const double *x,
+                                 const double *obs, uint64_t seed, uint32_t gid, uint32_t blk0, uint32_t epoch, uint32_t tag, double *xn)
+{
+    if (model == O_MODEL_LINE) {
+        o_philox_t b = o_rng(seed, gid, blk0, epoch, tag);
+        xn[0] = x[0];
+        xn[1] = (obs[1] != 0.0 && o_u52(b.v[2], b.v[3]) < Q[0]) ? 1.0 : 0.0;
+        if (obs[1] == 0.0) return 0.0;
+        int on = xn[1] != 0.0, oo = x[1] != 0.0;
+        double wn = (on ? P[5] : P[6]) + model_loglik(model, P, xn, obs), wo = (oo ? P[5] : P[6]) + model_loglik(model, P, x, obs);
+        return ((wn - wo) - (on ? Q[1] : Q[2])) + (oo ? Q[1] : Q[2]);        /* :147 */
+    }
+    if (model != O_MODEL_LGSSM2) return NAN;
+    double wn = model_propose(model, P, first, xp, obs, seed, gid, blk0, epoch, tag, xn);
+    return wn - lgssm2_proposal_weight(P, first, xp, obs, x);
+}
+/* pf_move_reweight! (rejuvenate.jl:74-90) with the proposal variant of the kernel; every particle moves, log_weights[i] += sum rel_weight */
+O_EXPORT void o_move_proposal(int model, const double *P, const double *Q, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
+                              int W, int has_prev, const double *obs, int n_iters, const double *rows_in, double *rows_out, double *lw)
+{
+    int d = model_dim(model), nb = model_nblk(model);
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double *ri = rows_in + i * W;
+        double *ro = rows_out + i * W;
+        double x[4], xs[4];
+        const double *xp = ri + d;
+        for (int k = 0; k < d; ++k) x[k] = ri[k];
+        double wsum = 0.0;
+        for (int it = 0; it < n_iters; ++it) {
+            double rw = model_move_propose(model, P, Q, !has_prev, xp, x, obs, seed, O_GID(gid0, i), (uint32_t)(it * nb), epoch, O_TAG_REWEIGHT, xs);
+            wsum = wsum + rw;                             /* rejuvenate.jl:86 */
+            for (int k = 0; k < d; ++k) x[k] = xs[k];
+        }
+        for (int k = 0; k < W; ++k) ro[k] = ri[k];
+        for (int k = 0; k < d; ++k) ro[k] = x[k];
+        lw[i] = lw[i] + wsum;
+    }
+}
+
 /* ------------------------------------------------------------------ weight normalisation */
 /* maximum + validity flags of safe_softmax (utils.jl:119-126): any NaN; all == -Inf; (+Inf present
  * makes exp.(vs .- max) contain NaN -> "total weight is NaN" branch, utils.jl:134-137) */

@@ -37,8 +37,9 @@ class OracleDriver:
     def update(self, t, slope=0.0, proposal=False, strata=None, layout="interleaved"):
         self.f.update(self.g.models.line_obs(t, slope), proposal=proposal, strata=strata, layout=layout); return self
 
-    def rejuvenate(self, method):
-        self.f.rejuvenate(method, 1); return self
+    def rejuvenate(self, method, q=None):
+        import math
+        self.f.rejuvenate(method, 1, proposal=None if q is None else (q, math.log(q), math.log1p(-q))); return self
 
     def view(self, sl):                                      # state[idxs] (src/view.jl:35-48): traces and weights of a sub-state
         v = self.f[sl]; return np.array(v.rows), np.array(v.lw)
@@ -77,7 +78,10 @@ class DeviceDriver:
             g.pf_update(self.st, (t,), (None,), obs)
         return self
 
-    def rejuvenate(self, method):
+    def rejuvenate(self, method, q=None):
+        if q is not None:                                    # move_reweight(trace, outlier_propose, (idx,)) with outlier ~ bernoulli(q)
+            self.g.pf_rejuvenate(self.st, self.g.move_reweight, (self.g.outlier_propose(q), (1,)), 1, method="reweight")
+            return self
         self._acc = self.g.pf_rejuvenate(self.st, self.g.mh if method == "move" else self.g.move_reweight, (), 1, method=method, count=True)
         return self
 
@@ -196,6 +200,23 @@ def test_move_reweight_kernel(g, o, D):
     exp = [logpdf_normal(0, s, 10. if n else 1.) - logpdf_normal(0, s, 10. if ol else 1.) for s, ol, n in zip(slope, out_old, out_new)]
     np.testing.assert_allclose(d.lw - lw_old, exp, rtol=1e-9, atol=1e-12)
     assert np.array_equal(d.rows[:, 0], slope) and (out_old != out_new).any()
+
+
+@pytest.mark.parametrize("D", DRIVERS)
+def test_move_reweight_kernel_proposal_variant(g, o, D):
+    """test/rejuvenate.jl:19-27, proposal variant with outlier_propose = {:line => idx => :outlier} ~ bernoulli(0.9):
+        expected_w = logpdf(bernoulli, out_new, 0.1) - logpdf(bernoulli, out_old, 0.1)
+                   + logpdf(normal, 0, slope, out_new ? 10. : 1.) - logpdf(normal, 0, slope, out_old ? 10. : 1.)
+                   + (out_old == out_new ? 0.0 : logpdf(bernoulli, out_old, 0.9) - logpdf(bernoulli, out_old, 0.1))     (:20-25)"""
+    d = D(g, o, keep_prev=True).init(0).update(1)
+    slope, out_old, lw_old = d.rows[:, 0].copy(), d.rows[:, 1] != 0, d.lw.copy()
+    d.rejuvenate("reweight", q=0.9)
+    out_new = d.rows[:, 1] != 0
+    exp = [logpdf_bernoulli(n, 0.1) - logpdf_bernoulli(ol, 0.1) + logpdf_normal(0, s, 10. if n else 1.) - logpdf_normal(0, s, 10. if ol else 1.)
+           + (0.0 if ol == n else logpdf_bernoulli(ol, 0.9) - logpdf_bernoulli(ol, 0.1)) for s, ol, n in zip(slope, out_old, out_new)]
+    np.testing.assert_allclose(d.lw - lw_old, exp, rtol=1e-9, atol=1e-12)                          # :27
+    assert np.array_equal(d.rows[:, 0], slope)
+    assert 0.75 * N < out_new.sum() <= N and (out_old != out_new).any()                            # proposed from bernoulli(0.9)
 
 
 @pytest.mark.parametrize("D", DRIVERS)
