@@ -71,6 +71,8 @@ struct gpf_filter {
     uint64_t *keys = nullptr, *keys_out = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    // sample sort (gpf_k_sort.hpp K10b): splitters, bucket regions, cursors; pinned {overflow, ticket}
+    void* ss_buf = nullptr; int64_t* h_ss_flag = nullptr; int64_t ss_ticket = 0;
     double* pmax = nullptr;
     int32_t* pflags = nullptr;
     uint64_t* blockQ = nullptr;
@@ -722,10 +724,43 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
     return GPF_OK;
 }
 
+gpf_status sort_desc_radix(gpf_filter* h, const PrioView& pv, int64_t n);
+// order = sortperm(log_priorities, rev=true) (resample.jl:156-157) into h->order, the sorted keys into h->keys.  Two data passes
+// (sample sort, gpf_k_sort.hpp K10b) for 2^17 <= n <= 2^20, the eight-pass radix sort otherwise -- and whenever a bucket of the
+// sample sort outgrew its region (the host learns it from pinned memory while the bucket sorts are still running).
+gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
+{
+    static const int mode = [] { const char* e = getenv("GPF_SORT"); return e && !strcmp(e, "radix") ? 1 : (e && !strcmp(e, "overflow") ? 2 : 0); }();
+    if (mode == 1 || n < SS_MIN_N || n > SS_MAX_N) return sort_desc_radix(h, pv, n);
+    gpf_status s = ensure_sort_buffers(h);
+    if (s) return s;
+    constexpr size_t RK = (size_t)SS_BUCKETS * SS_CAP * sizeof(uint64_t), RI = (size_t)SS_BUCKETS * SS_CAP * sizeof(int32_t);
+    constexpr size_t SK = 256 * sizeof(uint64_t), SI = 256 * sizeof(int32_t), CU = 256 * sizeof(uint32_t);
+    if (!h->ss_buf) {
+        HIP_TRY(h, hipMalloc(&h->ss_buf, RK + RI + SK + SI + CU + 64));
+        HIP_TRY(h, hipHostMalloc(&h->h_ss_flag, 2 * sizeof(int64_t)));
+        h->h_ss_flag[0] = h->h_ss_flag[1] = 0;
+    }
+    char* base = static_cast<char*>(h->ss_buf);
+    SSortArgs a;
+    a.rkeys = reinterpret_cast<uint64_t*>(base); a.ridx = reinterpret_cast<int32_t*>(base + RK);
+    a.skeys = reinterpret_cast<uint64_t*>(base + RK + RI); a.sidx = reinterpret_cast<int32_t*>(base + RK + RI + SK);
+    a.cursor = reinterpret_cast<uint32_t*>(base + RK + RI + SK + SI); a.done = a.cursor + 256;
+    a.host_flag = h->h_ss_flag; a.ticket = ++h->ss_ticket;
+    GPF_LAUNCH(k_ssort_splitters, dim3(1), dim3(SS_BLOCK), 0, h->stream, pv, n, h->cfg.seed, h->epoch, a);
+    GPF_LAUNCH(k_ssort_partition, dim3((unsigned)((n + SS_TILE - 1) / SS_TILE)), dim3(SS_BLOCK), 0, h->stream, pv, n, a);
+    GPF_LAUNCH(k_ssort_buckets, dim3(SS_BUCKETS), dim3(SS_BLOCK), 0, h->stream, a, h->keys, h->order);
+    HIP_TRY(h, hipGetLastError());
+    // every bucket inside its region?  (published by the partition's last tile; the bucket sorts keep running meanwhile)
+    if ((s = wait_ticket(h, h->h_ss_flag + 1, h->ss_ticket, "sample sort"))) return s;
+    if (h->h_ss_flag[0] != 0 || mode == 2) return sort_desc_radix(h, pv, n);
+    return GPF_OK;
+}
+
 // order = sortperm(log_priorities, rev=true) (resample.jl:156-157) into h->order: keys + digit histograms in one pass, then
 // eight onesweep digit passes (gpf_kernels.hpp K10).  Key buffers alternate keys -> keys_out -> keys ...; the payload
 // starts as the element index and alternates idx_in -> order, so the eighth pass leaves the permutation in h->order.
-gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
+gpf_status sort_desc_radix(gpf_filter* h, const PrioView& pv, int64_t n)
 {
     gpf_status s = ensure_sort_buffers(h);
     if (s) return s;
@@ -1058,7 +1093,8 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers (or of the compact copies below)
     for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc}) if (q) (void)hipFree(q);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf};
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf, h->ss_buf};
+    if (h->h_ss_flag) hipHostFree(h->h_ss_flag);
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);

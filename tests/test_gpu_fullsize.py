@@ -2,6 +2,8 @@
 DIRECTLY for a few steps (the C oracle does ~6 M particle-steps/s, so N = 1e6 costs < 1 s per step), plus
 size-independent properties of the domain: log-ML invariance across resampling, gather consistency
 new_traces == old_traces[parents], uniform-weights identity, parents in range."""
+import os
+
 import numpy as np
 import pytest
 
@@ -261,3 +263,59 @@ def test_extreme_weight_vectors_at_full_size(g, o, case):
         assert np.array_equal(st.parents, orc.parents), (case, method, kw, alpha)
         assert np.array_equal(st.log_weights, orc.lw, equal_nan=True), (case, method, kw, alpha)
     st.close()
+
+
+def _sorted_case(N, kind, seed=3):
+    rng = np.random.default_rng(seed)
+    i = np.arange(N, dtype=np.float64)
+    return {"filter": None, "all equal": np.zeros(N), "two values": np.where(i % 2 == 0, -0.5, -0.25),
+            "mostly -inf": np.where(rng.random(N) < 0.9, -np.inf, -rng.random(N)), "few distinct": -np.floor(8 * rng.random(N)),
+            "signed zeros": np.where(i % 3 == 0, -0.0, np.where(i % 3 == 1, 0.0, -1.0)), "ramp": -1e-7 * i,
+            "close values": -1.0 - 1e-13 * rng.integers(0, 50, N)}[kind]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1 << 17, (1 << 17) + 1, 300_007, 1_000_000, 1 << 20, (1 << 20) + 1])
+@pytest.mark.parametrize("kind", ["filter", "all equal", "two values", "mostly -inf", "few distinct", "signed zeros", "ramp", "close values"])
+def test_sorted_stratified_sample_sort_sizes(g, o, N, kind):
+    """sort_particles=true (the reference's default, src/resample.jl:145,156-157) through the sample sort (2^17 <= N <= 2^20) and
+    through the radix sort on both sides of its size window: the permutation is the stable descending sort of the oracle (ties by
+    index, -0.0 < 0.0), so the ancestors are equal"""
+    if N > 400_000 and kind not in ("filter", "all equal", "few distinct", "close values"):
+        pytest.skip("the large sizes run four weight patterns")
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=5)
+    orc = o.OracleFilter(model.model_id, model.params, N, 5).initialize(ys[0])
+    lw = _sorted_case(N, kind)
+    if lw is not None:
+        st.log_weights = lw; orc.lw = lw.copy()
+    for t in range(2):
+        g.pf_resample(st, "stratified", sort_particles=True, check=False); orc.resample("stratified", sort_particles=True, check=False)
+        assert np.array_equal(st.parents, orc.parents), (N, kind, t)
+        g.pf_update(st, (t + 2,), (None,), ys[t + 1]); orc.update(ys[t + 1])
+    assert g.get_lml_est(st) == orc.log_ml_estimate() or (np.isnan(g.get_lml_est(st)) and np.isnan(orc.log_ml_estimate()))
+    st.close()
+
+
+@pytest.mark.gpu
+def test_sample_sort_overflow_falls_back_to_the_radix_sort():
+    """GPF_SORT=overflow: the host treats every sample sort as overflowed and re-sorts with the eight-pass radix sort (the path a
+    bucket that outgrew its region takes); GPF_SORT=radix: the radix sort alone.  Same ancestors as the default (separate processes:
+    the switch is read once per process)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); import gpf_amd as g\n"
+            "m = g.models.lgssm2(); ys = g.models.simulate(m, 3); st = g.pf_initialize(m, (1,), ys[0], 400_001, seed=5)\n"
+            "g.pf_update(st, (2,), (None,), ys[1]); g.pf_resample(st, 'stratified', sort_particles=True, check=False)\n"
+            "p = st.parents; print(json.dumps([int(p.sum()), int((p * np.arange(1, p.size + 1) % 1000003).sum()), g.get_lml_est(st)]))\n" % root)
+    outs = []
+    for mode in ("", "overflow", "radix"):
+        env = dict(os.environ); env.pop("GPF_SORT", None)
+        if mode:
+            env["GPF_SORT"] = mode
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] == outs[2]

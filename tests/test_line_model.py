@@ -244,7 +244,7 @@ def test_statistics_on_a_degenerate_state(g, o, D):
 
 # ------------------------------------------------------------------------------------------ device == oracle, bit for bit
 @pytest.mark.gpu
-@pytest.mark.parametrize("scenario", ["default", "proposal", "strata_c", "strata_i", "reweight", "move"])
+@pytest.mark.parametrize("scenario", ["default", "proposal", "strata_c", "strata_i", "reweight", "move", "reweight_proposal"])
 def test_hip_line_model_bitexact(g, o, scenario):
     a, b = OracleDriver(g, o, seed=5, keep_prev=True), DeviceDriver(g, o, seed=5, keep_prev=True)
     for d in (a, b):
@@ -259,6 +259,8 @@ def test_hip_line_model_bitexact(g, o, scenario):
             d.init(0).update(1).update(2, slope=1.0)
             if scenario in ("reweight", "move"):
                 d.rejuvenate(scenario)
+            if scenario == "reweight_proposal":
+                d.rejuvenate("reweight", q=0.9)
     assert np.array_equal(a.rows, b.rows) and np.array_equal(a.lw, b.lw)
     if scenario == "move":
         assert a.n_accepted == b.n_accepted

@@ -55,3 +55,40 @@ def test_hip_proposal_bitexact(g, o, keep_prev):
     assert g.get_lml_est(st) == orc.log_ml_estimate() and g.get_ess(st) == orc.effective_sample_size()
     with pytest.raises(g.ErrorException):
         g.pf_update(g.pf_initialize(g.models.sv1(), (1,), [0.1], 64), (2,), (None,), [0.1], g.locally_optimal, ())
+
+
+def test_oracle_move_reweight_with_the_locally_optimal_proposal(g, o):
+    """move_reweight(trace, proposal, proposal_args) (src/rejuvenate.jl:134-148): rel_weight = weight - fwd_score + bwd_score.  With
+    q = p(x_t | x_{t-1}, y_t) the three terms cancel analytically -- a Gibbs move: every particle gets a fresh x_t from the exact
+    conditional, the log-weights move by rounding error only, and the filter's estimates stay where they were."""
+    m = g.models.lgssm2(); ys = g.models.simulate(m, 4); N = 2000
+    f = o.OracleFilter(m.model_id, m.params, N, 5, keep_prev=True).initialize(ys[0])
+    f.update(ys[1]); f.resample("multinomial", check=False); f.update(ys[2])
+    rows0, lw0, lml0 = f.rows.copy(), f.lw.copy(), f.log_ml_estimate()
+    f.rejuvenate("reweight", 2, proposal=())
+    assert np.all(f.rows[:, :2] != rows0[:, :2]) and np.array_equal(f.rows[:, 2:4], rows0[:, 2:4])     # x_t moved, x_{t-1} kept
+    assert np.abs(f.lw - lw0).max() < 1e-9 and abs(f.log_ml_estimate() - lml0) < 1e-9
+    # the moved x_t follows the conditional: mean = mu + gain (y - mu)
+    A, sq, sr = m.info["A"], m.info["sq"], m.info["sr"]
+    mu = rows0[:, 2:4] @ A.T
+    gain = sq ** 2 / (sq ** 2 + sr ** 2)
+    assert np.abs((f.rows[:, :2] - (mu + gain * (ys[2] - mu))).mean(axis=0)).max() < 0.01
+
+
+@pytest.mark.gpu
+def test_hip_move_reweight_proposal_bitexact(g, o):
+    m = g.models.lgssm2(); ys = g.models.simulate(m, 5); N = 30_000
+    st = g.pf_initialize(m, (1,), ys[0], N, seed=3, keep_prev=True)
+    orc = o.OracleFilter(m.model_id, m.params, N, 3, keep_prev=True).initialize(ys[0])
+    for t in range(1, 4):
+        g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
+        g.pf_resample(st, "multinomial", check=False); orc.resample("multinomial", check=False)
+        # right after a resample: the pending gather rides on the move kernel
+        g.pf_rejuvenate(st, g.move_reweight, (g.locally_optimal_move, ()), t, method="reweight"); orc.rejuvenate("reweight", t, proposal=())
+        assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw)
+    assert g.get_lml_est(st) == orc.log_ml_estimate() and g.get_ess(st) == orc.effective_sample_size()
+    with pytest.raises(g.ErrorException):                                                 # a model without a native move proposal
+        s2 = g.pf_initialize(g.models.sv1(), (1,), [0.1], 64, keep_prev=True)
+        g.pf_rejuvenate(s2, g.move_reweight, (g.locally_optimal_move, ()), 1, method="reweight")
+    with pytest.raises(g.ErrorException):                                                 # the wrong proposal for the model
+        g.pf_rejuvenate(st, g.move_reweight, (g.outlier_propose(0.9), (1,)), 1, method="reweight")
