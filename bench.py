@@ -30,6 +30,17 @@ SEED = 1
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def kernel_sources_sha16() -> str:
+    """fingerprint of the kernel sources of this build (tools/pmc_to_json.py stores the same when it records PMC traffic)"""
+    import hashlib
+    root = os.path.join(ROOT, "genparticlefilters.jl_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hpp", ".hip")):
+            h.update(f.encode()); h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(d: int, W: int):
     """Algorithmic bytes per particle and launch: every input read once,
     every output written once.  d = state columns, rows are W doubles."""
@@ -267,15 +278,24 @@ def main():
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json; FETCH_SIZE +
         # WRITE_SIZE collected in separate runs and corrected as MI355X_MICROARCH.md §HBM prescribes); only valid for
         # the workload they were measured on
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if n_local == N_PER_GPU and dom in pmc["kernels"]:
+            sha = kernel_sources_sha16()
+            if n_local != N_PER_GPU or dom not in pmc["kernels"]:
+                traffic_source = "none: no PMC pass for this kernel / size"
+            elif pmc.get("kernel_sources_sha16") != sha:
+                # the counters were collected on other kernel sources than the ones being timed: do not quote them
+                traffic_source = (f"stale: profiles/pmc_traffic.json (tag {pmc.get('tag')}) was collected on kernel sources "
+                                  f"{pmc.get('kernel_sources_sha16')}, this build is {sha}")
+            else:
                 traffic = pmc["kernels"][dom]["traffic_bytes"]
-        except Exception:
-            traffic = None
+                traffic_source = {"file": "profiles/pmc_traffic.json", "tag": pmc.get("tag"), "kernel_sources_sha16": sha,
+                                  "passes": f"profiles/{pmc.get('tag')}_pmc_FETCH_SIZE.csv, profiles/{pmc.get('tag')}_pmc_WRITE_SIZE.csv"}
+        except Exception as e:                                   # noqa: BLE001
+            traffic, traffic_source = None, f"none: {e!r}"
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": ab[dom] * n_local, "avg_launch_us": round(us, 2),
                     "all_kernels_us": {k: round(v[0], 2) for k, v in per.items()}}
 
@@ -403,6 +423,7 @@ def main():
                               + (f"; {engine_note}" if engine_note else ""))),
             "log_ml_estimate": lml, "log_ml_exact_kalman": lml_exact, "log_ml_abs_error": abs(lml - lml_exact),
             "rccl_ranks": rccl_ranks,
+            "shard_summaries": (state.backend.summary_mode() if sharded_mode and hasattr(state.backend, "summary_mode") else None),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
             "stratified_variant": strat, "local_resample_variant": island,
         }

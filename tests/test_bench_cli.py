@@ -103,6 +103,7 @@ def test_bench_main_prints_one_json_line(argv, o, built, monkeypatch):
     r = out["roofline"]
     assert r is not None and r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and "traffic" in r
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic_source"] is not None and (r["traffic"] is None) == isinstance(r["traffic_source"], str)   # a figure only with its provenance
     c = out["cpu_baseline"]
     assert c is not None and c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["sample"]
     assert set(out["resample_gather_kernel"]) == {"multinomial", "stratified"}
