@@ -227,11 +227,12 @@ __global__ __launch_bounds__(SS_BLOCK) void k_ssort_splitters(PrioView pv, int64
     __syncthreads();
     // bitonic sort of the 8192 composites (4 compare-exchanges per thread and stage)
     for (int size = 2; size <= SS_SAMPLES; size <<= 1) {
-        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+        for (int ls = 31 - __builtin_clz(size >> 1); ls >= 0; --ls) {      // stride = 1 << ls
+            const int stride = 1 << ls;
 #pragma unroll
             for (int r = 0; r < SS_SAMPLES / 2 / SS_BLOCK; ++r) {
                 const int c = tid + r * SS_BLOCK;                          // compare-exchange index
-                const int lo_i = ((c / stride) * (stride << 1)) + (c % stride), hi_i = lo_i + stride;
+                const int lo_i = ((c >> ls) << (ls + 1)) | (c & (stride - 1)), hi_i = lo_i + stride;
                 const bool up = (lo_i & size) == 0;
                 const uint64_t k1 = s_k[lo_i], k2 = s_k[hi_i];
                 const int32_t i1 = s_i[lo_i], i2 = s_i[hi_i];
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(SS_BLOCK) void k_ssort_partition(PrioView pv, int64
     // the last tile to finish tells the host whether every bucket stayed inside its region
     if (__syncthreads_or((int)over) && tid == 0) atomicOr(a.done, 0x80000000u);
     __shared__ uint32_t s_last;
-    if (tid == 0) { __threadfence(); s_last = atomicAdd(a.done, 1u); }
+    if (tid == 0) s_last = atomicAdd(a.done, 1u);                      // (only the flag travels: the regions are read by the NEXT kernel)
     __syncthreads();
     if (tid == 0 && (s_last & 0x7fffffffu) == gridDim.x - 1) {
         const uint32_t v = __hip_atomic_load(a.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -319,10 +320,14 @@ __global__ __launch_bounds__(SS_BLOCK) void k_ssort_partition(PrioView pv, int64
     }
 }
 
+// LDS index of element i: one pad element per 8 -- a thread's 8 consecutive elements (stride 64 B: a 16-way bank conflict for the
+// 64 lanes of a wave) become stride 72 B (2-way), the merge's ~32-byte strides become ~36 bytes (conflict-free)
+__device__ __forceinline__ int ss_pad(int i) { return i + (i >> 3); }
+constexpr int SS_CAP_PAD = SS_CAP + SS_CAP / 8;
 __global__ __launch_bounds__(SS_BLOCK) void k_ssort_buckets(SSortArgs a, uint64_t* __restrict__ keys_out, int32_t* __restrict__ order_out)
 {
-    __shared__ uint64_t s_k[SS_CAP];
-    __shared__ int32_t s_i[SS_CAP];
+    __shared__ uint64_t s_k[SS_CAP_PAD];
+    __shared__ int32_t s_i[SS_CAP_PAD];
     __shared__ uint32_t s_scan[SS_BUCKETS / WAVE];
     __shared__ uint32_t s_base;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
@@ -340,19 +345,21 @@ __global__ __launch_bounds__(SS_BLOCK) void k_ssort_buckets(SSortArgs a, uint64_
     const uint32_t nb_raw = a.cursor[b];
     const int nb = (int)(nb_raw < (uint32_t)SS_CAP ? nb_raw : (uint32_t)SS_CAP);     // (an overflowing bucket: the host re-sorts everything)
     constexpr int E = SS_CAP / SS_BLOCK;                                 // 8 elements per thread
-    // ---- load (coalesced), then every thread sorts its 8 consecutive elements in registers
-    for (int p = tid; p < SS_CAP; p += SS_BLOCK) {
-        const bool v = p < nb;
-        s_k[p] = v ? a.rkeys[(size_t)b * SS_CAP + p] : ~0ull;
-        s_i[p] = v ? a.ridx[(size_t)b * SS_CAP + p] : 0x7fffffff;
-    }
-    __syncthreads();
     int npad = E;                                                        // sorted length needed: smallest E 2^r >= nb
     while (npad < nb) npad <<= 1;
+    // ---- load (coalesced), then every thread sorts its 8 consecutive elements in registers
+    for (int p = tid; p < npad; p += SS_BLOCK) {
+        const bool v = p < nb;
+        s_k[ss_pad(p)] = v ? a.rkeys[(size_t)b * SS_CAP + p] : ~0ull;
+        s_i[ss_pad(p)] = v ? a.ridx[(size_t)b * SS_CAP + p] : 0x7fffffff;
+    }
+    __syncthreads();
     uint64_t k[E]; int32_t ix[E];
-    if (tid * E < npad) {
+    const int o0 = tid * E;
+    const bool act = o0 < npad;
+    if (act) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) { k[e] = s_k[tid * E + e]; ix[e] = s_i[tid * E + e]; }
+        for (int e = 0; e < E; ++e) { k[e] = s_k[tid * (E + 1) + e]; ix[e] = s_i[tid * (E + 1) + e]; }     // ss_pad(8 t + e) = 9 t + e
 #pragma unroll
         for (int e = 1; e < E; ++e) {                                    // insertion sort (fully unrolled: stays in registers)
 #pragma unroll
@@ -361,44 +368,42 @@ __global__ __launch_bounds__(SS_BLOCK) void k_ssort_buckets(SSortArgs a, uint64_
             }
         }
 #pragma unroll
-        for (int e = 0; e < E; ++e) { s_k[tid * E + e] = k[e]; s_i[tid * E + e] = ix[e]; }
+        for (int e = 0; e < E; ++e) { s_k[tid * (E + 1) + e] = k[e]; s_i[tid * (E + 1) + e] = ix[e]; }
     }
     __syncthreads();
     // ---- merge rounds, in place: thread t produces outputs [8t, 8t + 8) of its pair of runs (merge path), everybody reads, barrier,
-    //      everybody writes
+    //      everybody writes.  Runs start at multiples of 8, so ss_pad(base + i) = ss_pad(base) + ss_pad(i).
     for (int L = E; L < npad; L <<= 1) {
-        const int o0 = tid * E;
-        const bool act = o0 < npad;
         if (act) {
             const int pair = o0 / (2 * L), off = o0 - pair * 2 * L;
-            const uint64_t* A = s_k + pair * 2 * L; const int32_t* Ai = s_i + pair * 2 * L;
-            const uint64_t* B = A + L; const int32_t* Bi = Ai + L;
+            const uint64_t* A = s_k + ss_pad(pair * 2 * L); const int32_t* Ai = s_i + ss_pad(pair * 2 * L);
+            const uint64_t* B = s_k + ss_pad(pair * 2 * L + L); const int32_t* Bi = s_i + ss_pad(pair * 2 * L + L);
             // i = number of A elements among the first `off` outputs: the smallest i with A[i] > B[off - i - 1] (composite order, no ties)
             int lo = off > L ? off - L : 0, hi = off < L ? off : L;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 const int j = off - mid - 1;                              // 0 <= j < L
-                if (ss_less(B[j], Bi[j], A[mid], Ai[mid])) hi = mid; else lo = mid + 1;
+                if (ss_less(B[ss_pad(j)], Bi[ss_pad(j)], A[ss_pad(mid)], Ai[ss_pad(mid)])) hi = mid; else lo = mid + 1;
             }
             int i = lo, j = off - lo;
-            uint64_t ka = i < L ? A[i] : ~0ull, kb = j < L ? B[j] : ~0ull;
-            int32_t ia = i < L ? Ai[i] : 0x7fffffff, ib = j < L ? Bi[j] : 0x7fffffff;
+            uint64_t ka = i < L ? A[ss_pad(i)] : ~0ull, kb = j < L ? B[ss_pad(j)] : ~0ull;
+            int32_t ia = i < L ? Ai[ss_pad(i)] : 0x7fffffff, ib = j < L ? Bi[ss_pad(j)] : 0x7fffffff;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const bool takeb = j < L && (i >= L || ss_less(kb, ib, ka, ia));
-                if (takeb) { k[e] = kb; ix[e] = ib; ++j; kb = j < L ? B[j] : ~0ull; ib = j < L ? Bi[j] : 0x7fffffff; }
-                else       { k[e] = ka; ix[e] = ia; ++i; ka = i < L ? A[i] : ~0ull; ia = i < L ? Ai[i] : 0x7fffffff; }
+                if (takeb) { k[e] = kb; ix[e] = ib; ++j; kb = j < L ? B[ss_pad(j)] : ~0ull; ib = j < L ? Bi[ss_pad(j)] : 0x7fffffff; }
+                else       { k[e] = ka; ix[e] = ia; ++i; ka = i < L ? A[ss_pad(i)] : ~0ull; ia = i < L ? Ai[ss_pad(i)] : 0x7fffffff; }
             }
         }
         __syncthreads();
         if (act) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) { s_k[o0 + e] = k[e]; s_i[o0 + e] = ix[e]; }
+            for (int e = 0; e < E; ++e) { s_k[tid * (E + 1) + e] = k[e]; s_i[tid * (E + 1) + e] = ix[e]; }
         }
         __syncthreads();
     }
     const uint32_t base = s_base;
-    for (int p = tid; p < nb; p += SS_BLOCK) { keys_out[base + p] = s_k[p]; order_out[base + p] = s_i[p]; }
+    for (int p = tid; p < nb; p += SS_BLOCK) { keys_out[base + p] = s_k[ss_pad(p)]; order_out[base + p] = s_i[ss_pad(p)]; }
 }
 
 __global__ void k_extract_column(const double* __restrict__ rows, int W, int col, int64_t n, double* __restrict__ out)

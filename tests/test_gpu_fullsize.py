@@ -306,10 +306,10 @@ def test_sample_sort_overflow_falls_back_to_the_radix_sort():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); import gpf_amd as g\n"
+    code = ("import sys, json, numpy as np; sys.path.insert(0, ROOT); import gpf_amd as g\n"
             "m = g.models.lgssm2(); ys = g.models.simulate(m, 3); st = g.pf_initialize(m, (1,), ys[0], 400_001, seed=5)\n"
             "g.pf_update(st, (2,), (None,), ys[1]); g.pf_resample(st, 'stratified', sort_particles=True, check=False)\n"
-            "p = st.parents; print(json.dumps([int(p.sum()), int((p * np.arange(1, p.size + 1) % 1000003).sum()), g.get_lml_est(st)]))\n" % root)
+            "p = st.parents; print(json.dumps([int(p.sum()), int((p * np.arange(1, p.size + 1) % 1000003).sum()), g.get_lml_est(st)]))\n").replace("ROOT", repr(root))
     outs = []
     for mode in ("", "overflow", "radix"):
         env = dict(os.environ); env.pop("GPF_SORT", None)
