@@ -23,6 +23,8 @@ __host__ inline size_t sort_ws_bytes(int64_t n)
     return sort_ws_desc_offset() + (size_t)SORT_PASSES * (nt + (nt + 15) / 16 + (nt + 255) / 256) * SORT_BINS * sizeof(uint64_t);
 }
 // keys of the log-priorities + the histograms of all eight digits in one pass over the weights
+// (FIRST: the lowest digit that will be sorted -- 0: all eight passes, 4: the high 32 bits only, §K10c)
+template <int FIRST>
 __global__ __launch_bounds__(BLOCK) void k_sort_keys_hist(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t s_h[SORT_PASSES][SORT_BINS];
@@ -32,10 +34,10 @@ __global__ __launch_bounds__(BLOCK) void k_sort_keys_hist(PrioView pv, int64_t n
         const uint64_t k = sort_key_desc(pv.at(i));
         keys[i] = k;
 #pragma unroll
-        for (int p = 0; p < SORT_PASSES; ++p) atomicAdd(&s_h[p][(k >> (8 * p)) & 0xff], 1u);
+        for (int p = FIRST; p < SORT_PASSES; ++p) atomicAdd(&s_h[p][(k >> (8 * p)) & 0xff], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SORT_PASSES * SORT_BINS; i += BLOCK) { const uint32_t c = (&s_h[0][0])[i]; if (c) atomicAdd(hist + i, c); }
+    for (int i = FIRST * SORT_BINS + threadIdx.x; i < SORT_PASSES * SORT_BINS; i += BLOCK) { const uint32_t c = (&s_h[0][0])[i]; if (c) atomicAdd(hist + i, c); }
 }
 
 // one digit pass.  vals_in == nullptr: the payload is the element's index (first pass).
@@ -181,229 +183,64 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     }
 }
 
-// ----------------------------------------------------------------------------- K10b: the same order by a sample sort (two data passes)
-// Eight digit passes are eight latency chains (profiles/r02d_sort_phases.txt).  For the sizes a GPU holds per shard in the
-// BASELINE configs (up to 2^20 particles) the same permutation comes from TWO passes over the data:
-//   k_ssort_splitters  one workgroup: 8192 pseudo-random samples (one per stratum of the index range), sorted in LDS (bitonic),
-//                      every 32nd becomes a splitter -> 256 buckets of ~n / 256 elements;
-//   k_ssort_partition  every 4096-element tile classifies its keys against the splitters (LDS, 8 probes), reorders the tile by
-//                      bucket in LDS and appends each bucket's run to the bucket's fixed-capacity region (one atomic per tile and
-//                      bucket; the order inside a region is arbitrary);
-//   k_ssort_buckets    one workgroup per bucket sorts its region in LDS (8 keys per lane in registers, then in-place merge-path
-//                      rounds) and writes it to its final place (the exclusive sum of the bucket counts).
-// Everything compares the COMPOSITE (key, index): a total order, so no pass has to be stable, equal keys split across buckets by
-// index (a million equal weights still give 256 equal buckets), and the result is exactly the stable descending sort of K10.
-// A bucket that outgrows its region (sampling variance: P ~ 1e-7 per sort at 32 samples per bucket) raises a flag in pinned host
-// memory; the host reads it while the bucket sorts run and re-sorts with the eight-pass radix sort.
-constexpr int SS_BUCKETS = 256, SS_OVERSAMPLE = 32, SS_SAMPLES = SS_BUCKETS * SS_OVERSAMPLE;   // 8192
-constexpr int SS_CAP = 8192;                        // elements per bucket region = elements a workgroup sorts in LDS
-constexpr int SS_BLOCK = 1024, SS_TILE = 4096;
-constexpr int64_t SS_MIN_N = 1 << 17, SS_MAX_N = (int64_t)SS_BUCKETS * (SS_CAP / 2);   // mean bucket <= half its region
-struct SSortArgs {
-    uint64_t* skeys; int32_t* sidx;                 // [255] splitters (composite)
-    uint64_t* rkeys; int32_t* ridx;                 // [SS_BUCKETS][SS_CAP] bucket regions
-    uint32_t* cursor;                               // [SS_BUCKETS] elements appended so far (cleared by k_ssort_splitters)
-    uint32_t* done;                                 // tiles finished (cleared by k_ssort_splitters)
-    int64_t* host_flag; int64_t ticket;             // pinned {overflow, ticket}
-};
-__device__ __forceinline__ bool ss_less(uint64_t k1, int32_t i1, uint64_t k2, int32_t i2) { return k1 < k2 || (k1 == k2 && i1 < i2); }
-
-__global__ __launch_bounds__(SS_BLOCK) void k_ssort_splitters(PrioView pv, int64_t n, uint64_t seed, uint32_t epoch, SSortArgs a)
+// ----------------------------------------------------------------------------- K10c: four passes + a finish
+// The log-priorities of a filter are continuous: after FOUR stable passes over the HIGH 32 key bits (sign, exponent, 20 mantissa
+// bits) almost every key already stands where it belongs; what is left are short runs of keys that share their high word (a few
+// per thousand at 10^6 particles), in index order.  k_sort_finish orders each such run by the low word -- every element counts,
+// inside its run, the keys with a smaller low word plus the equal ones before it (stable) -- and copies everything else through:
+// one streaming pass instead of four latency-chain passes.  A run longer than SORT_RUN_MAX (nearly equal weights: they differ
+// only below 2^-20 relative; or equal weights) raises a flag; the last tile publishes it to pinned host memory and the host
+// re-sorts with all eight passes.
+constexpr int SORT_RUN_MAX = 48;                    // elements of a run to either side of an element that the finish looks at
+constexpr int FIN_BLOCK = 1024, FIN_TILE = 4096, FIN_HALO = SORT_RUN_MAX + 1;
+__global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                                                           uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
+                                                           uint32_t* __restrict__ done, int64_t* host_flag, int64_t ticket)
 {
-    __shared__ uint64_t s_k[SS_SAMPLES];
-    __shared__ int32_t s_i[SS_SAMPLES];
-    const int tid = (int)threadIdx.x;
-    if (tid < SS_BUCKETS) a.cursor[tid] = 0;
-    if (tid == 0) *a.done = 0;
-    // sample s: one pseudo-random element of stratum [s n / 8192, (s + 1) n / 8192) of the index range (a counter-based hash of
-    // (s, epoch): periodic patterns in the weights cannot resonate with the sample positions)
-    for (int s = tid; s < SS_SAMPLES; s += SS_BLOCK) {
-        const int64_t lo = (int64_t)(((unsigned __int128)(uint64_t)s * (uint64_t)n) >> 13), hi = (int64_t)(((unsigned __int128)(uint64_t)(s + 1) * (uint64_t)n) >> 13);
-        uint64_t x = ((uint64_t)s << 32 | epoch) * 0x9E3779B97F4A7C15ull + seed;
-        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
-        const int64_t i = lo + (int64_t)(x % (uint64_t)(hi > lo ? hi - lo : 1));
-        s_k[s] = sort_key_desc(pv.at(i)); s_i[s] = (int32_t)i;
-    }
-    __syncthreads();
-    // bitonic sort of the 8192 composites (4 compare-exchanges per thread and stage)
-    for (int size = 2; size <= SS_SAMPLES; size <<= 1) {
-        for (int ls = 31 - __builtin_clz(size >> 1); ls >= 0; --ls) {      // stride = 1 << ls
-            const int stride = 1 << ls;
-#pragma unroll
-            for (int r = 0; r < SS_SAMPLES / 2 / SS_BLOCK; ++r) {
-                const int c = tid + r * SS_BLOCK;                          // compare-exchange index
-                const int lo_i = ((c >> ls) << (ls + 1)) | (c & (stride - 1)), hi_i = lo_i + stride;
-                const bool up = (lo_i & size) == 0;
-                const uint64_t k1 = s_k[lo_i], k2 = s_k[hi_i];
-                const int32_t i1 = s_i[lo_i], i2 = s_i[hi_i];
-                if (ss_less(k2, i2, k1, i1) == up) { s_k[lo_i] = k2; s_k[hi_i] = k1; s_i[lo_i] = i2; s_i[hi_i] = i1; }
-            }
-            __syncthreads();
-        }
-    }
-    if (tid < SS_BUCKETS - 1) { a.skeys[tid] = s_k[SS_OVERSAMPLE * (tid + 1) - 1]; a.sidx[tid] = s_i[SS_OVERSAMPLE * (tid + 1) - 1]; }
-}
-
-__global__ __launch_bounds__(SS_BLOCK) void k_ssort_partition(PrioView pv, int64_t n, SSortArgs a)
-{
-    __shared__ uint64_t s_sk[SS_BUCKETS];
-    __shared__ int32_t s_si[SS_BUCKETS];
-    __shared__ uint32_t s_cnt[SS_BUCKETS], s_start[SS_BUCKETS], s_gbase[SS_BUCKETS], s_scan[SS_BUCKETS / WAVE];
-    __shared__ uint64_t s_k[SS_TILE];
-    __shared__ int32_t s_i[SS_TILE];
-    __shared__ uint16_t s_b[SS_TILE];
-    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
-    if (tid < SS_BUCKETS) {
-        s_sk[tid] = tid < SS_BUCKETS - 1 ? a.skeys[tid] : ~0ull;         // (a sentinel above every key: never read as a splitter)
-        s_si[tid] = tid < SS_BUCKETS - 1 ? a.sidx[tid] : 0x7fffffff;
-        s_cnt[tid] = 0;
-    }
-    __syncthreads();
-    const int64_t t0 = (int64_t)blockIdx.x * SS_TILE;
-    constexpr int IT = SS_TILE / SS_BLOCK;
-    uint64_t key[IT]; int32_t idx[IT]; uint32_t bkt[IT], rnk[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int64_t i = t0 + it * SS_BLOCK + tid;
-        idx[it] = (int32_t)i;
-        bkt[it] = 0; rnk[it] = 0;
-        if (i < n) {
-            key[it] = sort_key_desc(pv.at(i));
-            uint32_t c = 0;                                              // number of splitters below the element (255 = 2^8 - 1 of them)
-#pragma unroll
-            for (uint32_t h = 128; h >= 1; h >>= 1) c += ss_less(s_sk[c + h - 1], s_si[c + h - 1], key[it], idx[it]) ? h : 0u;
-            bkt[it] = c;
-            rnk[it] = atomicAdd(&s_cnt[c], 1u);
-        }
-    }
-    __syncthreads();
-    // where each bucket's run starts inside the tile (exclusive scan of the 256 counts), and in its region (one global atomic)
-    uint32_t cnt = tid < SS_BUCKETS ? s_cnt[tid] : 0u, inc = cnt;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(inc, d, WAVE); if (lane >= d) inc += o; }
-    if (tid < SS_BUCKETS && lane == WAVE - 1) s_scan[wv] = inc;
-    __syncthreads();
-    if (tid < SS_BUCKETS) {
-        uint32_t st = inc - cnt;
-        for (int w = 0; w < wv; ++w) st += s_scan[w];
-        s_start[tid] = st;
-        s_gbase[tid] = cnt ? atomicAdd(a.cursor + tid, cnt) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int64_t i = t0 + it * SS_BLOCK + tid;
-        if (i < n) { const uint32_t p = s_start[bkt[it]] + rnk[it]; s_k[p] = key[it]; s_i[p] = idx[it]; s_b[p] = (uint16_t)bkt[it]; }
-    }
-    __syncthreads();
-    const int64_t nvalid = n - t0 < SS_TILE ? n - t0 : SS_TILE;
-    bool over = false;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int p = it * SS_BLOCK + tid;
-        if (p < nvalid) {
-            const uint32_t b = s_b[p];
-            const uint32_t q = s_gbase[b] + ((uint32_t)p - s_start[b]);  // position inside the bucket's region
-            if (q < (uint32_t)SS_CAP) { a.rkeys[(size_t)b * SS_CAP + q] = s_k[p]; a.ridx[(size_t)b * SS_CAP + q] = s_i[p]; }
-            else over = true;
-        }
-    }
-    // the last tile to finish tells the host whether every bucket stayed inside its region
-    if (__syncthreads_or((int)over) && tid == 0) atomicOr(a.done, 0x80000000u);
+    __shared__ uint64_t s_k[FIN_TILE + 2 * FIN_HALO];
     __shared__ uint32_t s_last;
-    if (tid == 0) s_last = atomicAdd(a.done, 1u);                      // (only the flag travels: the regions are read by the NEXT kernel)
+    const int tid = (int)threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * FIN_TILE;
+    for (int p = tid; p < FIN_TILE + 2 * FIN_HALO; p += FIN_BLOCK) {
+        const int64_t g = t0 - FIN_HALO + p;
+        s_k[p] = (g >= 0 && g < n) ? keys_in[g] : 0ull;
+    }
+    __syncthreads();
+    bool too_long = false;
+#pragma unroll
+    for (int it = 0; it < FIN_TILE / FIN_BLOCK; ++it) {
+        const int li = it * FIN_BLOCK + tid;                               // consecutive lanes, consecutive elements: coalesced copy-through
+        const int64_t g = t0 + li;
+        if (g >= n) continue;
+        const int c = li + FIN_HALO;
+        const uint64_t key = s_k[c];
+        const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+        // the run of equal high words around this element: lc elements to the left, rc to the right (inside the array)
+        int lc = 0, rc = 0;
+        while (lc < SORT_RUN_MAX + 1 && g - lc - 1 >= 0 && (uint32_t)(s_k[c - lc - 1] >> 32) == hi) ++lc;
+        while (rc < SORT_RUN_MAX + 1 && g + rc + 1 < n && (uint32_t)(s_k[c + rc + 1] >> 32) == hi) ++rc;
+        int64_t pos = g;
+        if (lc + rc > 0) {
+            if (lc > SORT_RUN_MAX || rc > SORT_RUN_MAX) too_long = true;   // the run leaves the window: the host re-sorts
+            else {
+                int rank = 0;
+                for (int q = -lc; q <= rc; ++q) {
+                    const uint32_t l2 = (uint32_t)s_k[c + q];
+                    rank += (l2 < lo || (l2 == lo && q < 0)) ? 1 : 0;
+                }
+                pos = g - lc + rank;
+            }
+        }
+        keys_out[pos] = key; vals_out[pos] = vals_in[g];
+    }
+    if (__syncthreads_or((int)too_long) && tid == 0) atomicOr(done, 0x80000000u);
+    if (tid == 0) s_last = atomicAdd(done, 1u);
     __syncthreads();
     if (tid == 0 && (s_last & 0x7fffffffu) == gridDim.x - 1) {
-        const uint32_t v = __hip_atomic_load(a.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.host_flag, (int64_t)(v >> 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(a.host_flag + 1, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(host_flag, (int64_t)(v >> 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_flag + 1, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-}
-
-// LDS index of element i: one pad element per 8 -- a thread's 8 consecutive elements (stride 64 B: a 16-way bank conflict for the
-// 64 lanes of a wave) become stride 72 B (2-way), the merge's ~32-byte strides become ~36 bytes (conflict-free)
-__device__ __forceinline__ int ss_pad(int i) { return i + (i >> 3); }
-constexpr int SS_CAP_PAD = SS_CAP + SS_CAP / 8;
-__global__ __launch_bounds__(SS_BLOCK) void k_ssort_buckets(SSortArgs a, uint64_t* __restrict__ keys_out, int32_t* __restrict__ order_out)
-{
-    __shared__ uint64_t s_k[SS_CAP_PAD];
-    __shared__ int32_t s_i[SS_CAP_PAD];
-    __shared__ uint32_t s_scan[SS_BUCKETS / WAVE];
-    __shared__ uint32_t s_base;
-    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
-    const int b = (int)blockIdx.x;
-    // this bucket's place in the output: the exclusive sum of the bucket counts
-    {
-        const uint32_t c = tid < SS_BUCKETS ? a.cursor[tid] : 0u;
-        uint32_t inc = c;
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(inc, d, WAVE); if (lane >= d) inc += o; }
-        if (tid < SS_BUCKETS && lane == WAVE - 1) s_scan[wv] = inc;
-        __syncthreads();
-        if (tid == b) { uint32_t st = inc - c; for (int w = 0; w < wv; ++w) st += s_scan[w]; s_base = st; }
-    }
-    const uint32_t nb_raw = a.cursor[b];
-    const int nb = (int)(nb_raw < (uint32_t)SS_CAP ? nb_raw : (uint32_t)SS_CAP);     // (an overflowing bucket: the host re-sorts everything)
-    constexpr int E = SS_CAP / SS_BLOCK;                                 // 8 elements per thread
-    int npad = E;                                                        // sorted length needed: smallest E 2^r >= nb
-    while (npad < nb) npad <<= 1;
-    // ---- load (coalesced), then every thread sorts its 8 consecutive elements in registers
-    for (int p = tid; p < npad; p += SS_BLOCK) {
-        const bool v = p < nb;
-        s_k[ss_pad(p)] = v ? a.rkeys[(size_t)b * SS_CAP + p] : ~0ull;
-        s_i[ss_pad(p)] = v ? a.ridx[(size_t)b * SS_CAP + p] : 0x7fffffff;
-    }
-    __syncthreads();
-    uint64_t k[E]; int32_t ix[E];
-    const int o0 = tid * E;
-    const bool act = o0 < npad;
-    if (act) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) { k[e] = s_k[tid * (E + 1) + e]; ix[e] = s_i[tid * (E + 1) + e]; }     // ss_pad(8 t + e) = 9 t + e
-#pragma unroll
-        for (int e = 1; e < E; ++e) {                                    // insertion sort (fully unrolled: stays in registers)
-#pragma unroll
-            for (int f = e; f >= 1; --f) {
-                if (ss_less(k[f], ix[f], k[f - 1], ix[f - 1])) { const uint64_t tk = k[f]; k[f] = k[f - 1]; k[f - 1] = tk; const int32_t ti = ix[f]; ix[f] = ix[f - 1]; ix[f - 1] = ti; }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) { s_k[tid * (E + 1) + e] = k[e]; s_i[tid * (E + 1) + e] = ix[e]; }
-    }
-    __syncthreads();
-    // ---- merge rounds, in place: thread t produces outputs [8t, 8t + 8) of its pair of runs (merge path), everybody reads, barrier,
-    //      everybody writes.  Runs start at multiples of 8, so ss_pad(base + i) = ss_pad(base) + ss_pad(i).
-    for (int L = E; L < npad; L <<= 1) {
-        if (act) {
-            const int pair = o0 / (2 * L), off = o0 - pair * 2 * L;
-            const uint64_t* A = s_k + ss_pad(pair * 2 * L); const int32_t* Ai = s_i + ss_pad(pair * 2 * L);
-            const uint64_t* B = s_k + ss_pad(pair * 2 * L + L); const int32_t* Bi = s_i + ss_pad(pair * 2 * L + L);
-            // i = number of A elements among the first `off` outputs: the smallest i with A[i] > B[off - i - 1] (composite order, no ties)
-            int lo = off > L ? off - L : 0, hi = off < L ? off : L;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const int j = off - mid - 1;                              // 0 <= j < L
-                if (ss_less(B[ss_pad(j)], Bi[ss_pad(j)], A[ss_pad(mid)], Ai[ss_pad(mid)])) hi = mid; else lo = mid + 1;
-            }
-            int i = lo, j = off - lo;
-            uint64_t ka = i < L ? A[ss_pad(i)] : ~0ull, kb = j < L ? B[ss_pad(j)] : ~0ull;
-            int32_t ia = i < L ? Ai[ss_pad(i)] : 0x7fffffff, ib = j < L ? Bi[ss_pad(j)] : 0x7fffffff;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const bool takeb = j < L && (i >= L || ss_less(kb, ib, ka, ia));
-                if (takeb) { k[e] = kb; ix[e] = ib; ++j; kb = j < L ? B[ss_pad(j)] : ~0ull; ib = j < L ? Bi[ss_pad(j)] : 0x7fffffff; }
-                else       { k[e] = ka; ix[e] = ia; ++i; ka = i < L ? A[ss_pad(i)] : ~0ull; ia = i < L ? Ai[ss_pad(i)] : 0x7fffffff; }
-            }
-        }
-        __syncthreads();
-        if (act) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) { s_k[tid * (E + 1) + e] = k[e]; s_i[tid * (E + 1) + e] = ix[e]; }
-        }
-        __syncthreads();
-    }
-    const uint32_t base = s_base;
-    for (int p = tid; p < nb; p += SS_BLOCK) { keys_out[base + p] = s_k[ss_pad(p)]; order_out[base + p] = s_i[ss_pad(p)]; }
 }
 
 __global__ void k_extract_column(const double* __restrict__ rows, int W, int col, int64_t n, double* __restrict__ out)

@@ -71,8 +71,7 @@ struct gpf_filter {
     uint64_t *keys = nullptr, *keys_out = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    // sample sort (gpf_k_sort.hpp K10b): splitters, bucket regions, cursors; pinned {overflow, ticket}
-    void* ss_buf = nullptr; int64_t* h_ss_flag = nullptr; int64_t ss_ticket = 0;
+    int64_t* h_sort_flag = nullptr; int64_t sort_ticket = 0;   // pinned {a run too long for k_sort_finish, ticket}
     double* pmax = nullptr;
     int32_t* pflags = nullptr;
     uint64_t* blockQ = nullptr;
@@ -724,43 +723,11 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
     return GPF_OK;
 }
 
-gpf_status sort_desc_radix(gpf_filter* h, const PrioView& pv, int64_t n);
-// order = sortperm(log_priorities, rev=true) (resample.jl:156-157) into h->order, the sorted keys into h->keys.  Two data passes
-// (sample sort, gpf_k_sort.hpp K10b) for 2^17 <= n <= 2^20, the eight-pass radix sort otherwise -- and whenever a bucket of the
-// sample sort outgrew its region (the host learns it from pinned memory while the bucket sorts are still running).
-gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
-{
-    static const int mode = [] { const char* e = getenv("GPF_SORT"); return e && !strcmp(e, "radix") ? 1 : (e && !strcmp(e, "overflow") ? 2 : 0); }();
-    if (mode == 1 || n < SS_MIN_N || n > SS_MAX_N) return sort_desc_radix(h, pv, n);
-    gpf_status s = ensure_sort_buffers(h);
-    if (s) return s;
-    constexpr size_t RK = (size_t)SS_BUCKETS * SS_CAP * sizeof(uint64_t), RI = (size_t)SS_BUCKETS * SS_CAP * sizeof(int32_t);
-    constexpr size_t SK = 256 * sizeof(uint64_t), SI = 256 * sizeof(int32_t), CU = 256 * sizeof(uint32_t);
-    if (!h->ss_buf) {
-        HIP_TRY(h, hipMalloc(&h->ss_buf, RK + RI + SK + SI + CU + 64));
-        HIP_TRY(h, hipHostMalloc(&h->h_ss_flag, 2 * sizeof(int64_t)));
-        h->h_ss_flag[0] = h->h_ss_flag[1] = 0;
-    }
-    char* base = static_cast<char*>(h->ss_buf);
-    SSortArgs a;
-    a.rkeys = reinterpret_cast<uint64_t*>(base); a.ridx = reinterpret_cast<int32_t*>(base + RK);
-    a.skeys = reinterpret_cast<uint64_t*>(base + RK + RI); a.sidx = reinterpret_cast<int32_t*>(base + RK + RI + SK);
-    a.cursor = reinterpret_cast<uint32_t*>(base + RK + RI + SK + SI); a.done = a.cursor + 256;
-    a.host_flag = h->h_ss_flag; a.ticket = ++h->ss_ticket;
-    GPF_LAUNCH(k_ssort_splitters, dim3(1), dim3(SS_BLOCK), 0, h->stream, pv, n, h->cfg.seed, h->epoch, a);
-    GPF_LAUNCH(k_ssort_partition, dim3((unsigned)((n + SS_TILE - 1) / SS_TILE)), dim3(SS_BLOCK), 0, h->stream, pv, n, a);
-    GPF_LAUNCH(k_ssort_buckets, dim3(SS_BUCKETS), dim3(SS_BLOCK), 0, h->stream, a, h->keys, h->order);
-    HIP_TRY(h, hipGetLastError());
-    // every bucket inside its region?  (published by the partition's last tile; the bucket sorts keep running meanwhile)
-    if ((s = wait_ticket(h, h->h_ss_flag + 1, h->ss_ticket, "sample sort"))) return s;
-    if (h->h_ss_flag[0] != 0 || mode == 2) return sort_desc_radix(h, pv, n);
-    return GPF_OK;
-}
-
 // order = sortperm(log_priorities, rev=true) (resample.jl:156-157) into h->order: keys + digit histograms in one pass, then
 // eight onesweep digit passes (gpf_kernels.hpp K10).  Key buffers alternate keys -> keys_out -> keys ...; the payload
 // starts as the element index and alternates idx_in -> order, so the eighth pass leaves the permutation in h->order.
-gpf_status sort_desc_radix(gpf_filter* h, const PrioView& pv, int64_t n)
+// first_pass = 0: all eight digit passes;  4: the four passes over the high 32 key bits (K10c: the caller finishes the runs)
+gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, int first_pass)
 {
     gpf_status s = ensure_sort_buffers(h);
     if (s) return s;
@@ -771,15 +738,36 @@ gpf_status sort_desc_radix(gpf_filter* h, const PrioView& pv, int64_t n)
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
     HIP_TRY(h, hipMemsetAsync(h->sort_tmp, 0, sort_ws_bytes(n), h->stream));
     // (one workgroup per CU: every workgroup ends with up to 2048 global atomic adds into the same 2048 counters)
-    GPF_LAUNCH(k_sort_keys_hist, dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
-    for (int p = 0; p < SORT_PASSES; ++p) {
+    if (first_pass == 0) GPF_LAUNCH((k_sort_keys_hist<0>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
+    else                 GPF_LAUNCH((k_sort_keys_hist<4>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
+    for (int p = first_pass; p < SORT_PASSES; ++p) {
         const uint64_t* kin = (p & 1) ? h->keys_out : h->keys;
         uint64_t* kout = (p & 1) ? h->keys : h->keys_out;
-        const int32_t* vin = p == 0 ? nullptr : ((p & 1) ? h->idx_in : h->order);
+        const int32_t* vin = p == first_pass ? nullptr : ((p & 1) ? h->idx_in : h->order);
         int32_t* vout = (p & 1) ? h->order : h->idx_in;
         GPF_LAUNCH(k_sort_pass, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout);
     }
     HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+// order = sortperm(log_priorities, rev=true) into h->order, the sorted keys into h->keys: four passes over the high 32 key bits +
+// k_sort_finish (gpf_k_sort.hpp K10c); all eight passes when a run of equal high words was too long for the finish (the host
+// learns it from pinned memory), or with GPF_SORT=radix8 in the environment (A/B measurements)
+gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
+{
+    static const int mode = [] { const char* e = getenv("GPF_SORT"); return e && !strcmp(e, "radix8") ? 1 : (e && !strcmp(e, "fallback") ? 2 : 0); }();
+    if (mode == 1) return sort_passes(h, pv, n, 0);
+    gpf_status s = sort_passes(h, pv, n, 4);                     // (the fourth of them leaves keys / payload in h->keys / h->order)
+    if (s) return s;
+    if (!h->h_sort_flag) { HIP_TRY(h, hipHostMalloc(&h->h_sort_flag, 2 * sizeof(int64_t))); h->h_sort_flag[0] = h->h_sort_flag[1] = 0; }
+    uint32_t* done = reinterpret_cast<uint32_t*>(h->sort_tmp) + SORT_PASSES * SORT_BINS + 32;     // (inside the workspace's cleared ticket block)
+    h->sort_ticket += 1;
+    GPF_LAUNCH(k_sort_finish, dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)), dim3(FIN_BLOCK), 0, h->stream, h->keys, h->order, h->keys_out, h->idx_in, n,
+               done, h->h_sort_flag, h->sort_ticket);
+    HIP_TRY(h, hipGetLastError());
+    std::swap(h->keys, h->keys_out); std::swap(h->order, h->idx_in);
+    if ((s = wait_ticket(h, h->h_sort_flag + 1, h->sort_ticket, "sort finish"))) return s;
+    if (h->h_sort_flag[0] != 0 || mode == 2) return sort_passes(h, pv, n, 0);
     return GPF_OK;
 }
 
@@ -1093,13 +1081,13 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers (or of the compact copies below)
     for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc}) if (q) (void)hipFree(q);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf, h->ss_buf};
-    if (h->h_ss_flag) hipHostFree(h->h_ss_flag);
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
     if (h->h_flags) hipHostFree(h->h_flags);
+    if (h->h_sort_flag) hipHostFree(h->h_sort_flag);
     if (h->h_timeout) hipHostFree(h->h_timeout);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;

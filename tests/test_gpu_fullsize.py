@@ -275,12 +275,13 @@ def _sorted_case(N, kind, seed=3):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N", [1 << 17, (1 << 17) + 1, 300_007, 1_000_000, 1 << 20, (1 << 20) + 1])
+@pytest.mark.parametrize("N", [1, 2, 100, 4096, 4097, (1 << 17) + 1, 300_007, 1_000_000])
 @pytest.mark.parametrize("kind", ["filter", "all equal", "two values", "mostly -inf", "few distinct", "signed zeros", "ramp", "close values"])
-def test_sorted_stratified_sample_sort_sizes(g, o, N, kind):
-    """sort_particles=true (the reference's default, src/resample.jl:145,156-157) through the sample sort (2^17 <= N <= 2^20) and
-    through the radix sort on both sides of its size window: the permutation is the stable descending sort of the oracle (ties by
-    index, -0.0 < 0.0), so the ancestors are equal"""
+def test_sorted_stratified_sizes_and_patterns(g, o, N, kind):
+    """sort_particles=true (the reference's default, src/resample.jl:145,156-157): four digit passes over the high 32 key bits + the
+    finish of the short runs of equal high words, and -- for weights that are equal or differ only far below 2^-20 relative ("all
+    equal", "two values", "few distinct", "close values": runs longer than the finish's window) -- the eight-pass fallback.  The
+    permutation is the stable descending sort of the oracle (ties by index, -0.0 < 0.0), so the ancestors are equal."""
     if N > 400_000 and kind not in ("filter", "all equal", "few distinct", "close values"):
         pytest.skip("the large sizes run four weight patterns")
     model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
@@ -298,10 +299,28 @@ def test_sorted_stratified_sample_sort_sizes(g, o, N, kind):
 
 
 @pytest.mark.gpu
-def test_sample_sort_overflow_falls_back_to_the_radix_sort():
-    """GPF_SORT=overflow: the host treats every sample sort as overflowed and re-sorts with the eight-pass radix sort (the path a
-    bucket that outgrew its region takes); GPF_SORT=radix: the radix sort alone.  Same ancestors as the default (separate processes:
-    the switch is read once per process)."""
+def test_sort_finish_window_boundaries(g, o):
+    """runs of equal high key words of every length around the finish's window (48 to either side): up to 49 elements are ordered by
+    the finish, longer runs take the eight-pass fallback; mixed in one filter with ordinary weights"""
+    N = 50_000
+    rng = np.random.default_rng(2)
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 2)
+    for run_len in (2, 3, 48, 49, 50, 97, 98, 200):
+        lw = -5.0 * rng.random(N)
+        pos = rng.choice(N, size=run_len, replace=False)
+        lw[pos] = -1.0 - 1e-12 * rng.permutation(run_len)               # same high word (they differ below 2^-20 relative), distinct low words
+        st = g.pf_initialize(model, (1,), ys[0], N, seed=5)
+        orc = o.OracleFilter(model.model_id, model.params, N, 5).initialize(ys[0])
+        st.log_weights = lw; orc.lw = lw.copy()
+        g.pf_resample(st, "stratified", sort_particles=True, check=False); orc.resample("stratified", sort_particles=True, check=False)
+        assert np.array_equal(st.parents, orc.parents), run_len
+        st.close()
+
+
+@pytest.mark.gpu
+def test_sort_fallback_and_eight_pass_modes_agree():
+    """GPF_SORT=fallback: the host treats every finish as flagged and re-sorts with all eight passes; GPF_SORT=radix8: the eight
+    passes alone.  Same ancestors as the default (separate processes: the switch is read once per process)."""
     import json
     import subprocess
     import sys
@@ -311,7 +330,7 @@ def test_sample_sort_overflow_falls_back_to_the_radix_sort():
             "g.pf_update(st, (2,), (None,), ys[1]); g.pf_resample(st, 'stratified', sort_particles=True, check=False)\n"
             "p = st.parents; print(json.dumps([int(p.sum()), int((p * np.arange(1, p.size + 1) % 1000003).sum()), g.get_lml_est(st)]))\n").replace("ROOT", repr(root))
     outs = []
-    for mode in ("", "overflow", "radix"):
+    for mode in ("", "fallback", "radix8"):
         env = dict(os.environ); env.pop("GPF_SORT", None)
         if mode:
             env["GPF_SORT"] = mode
