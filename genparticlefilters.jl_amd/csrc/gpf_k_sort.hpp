@@ -192,7 +192,10 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
 // only below 2^-20 relative; or equal weights) raises a flag; the last tile publishes it to pinned host memory and the host
 // re-sorts with all eight passes.
 constexpr int SORT_RUN_MAX = 48;                    // elements of a run to either side of an element that the finish looks at
-constexpr int FIN_BLOCK = 1024, FIN_TILE = 4096, FIN_HALO = SORT_RUN_MAX + 1;
+#ifndef GPF_FIN_BLOCK
+#define GPF_FIN_BLOCK 256
+#endif
+constexpr int FIN_BLOCK = GPF_FIN_BLOCK, FIN_TILE = 4 * FIN_BLOCK, FIN_HALO = SORT_RUN_MAX + 1;   // (many small workgroups: the pass is load -> barrier -> store)
 __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                            uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
                                                            uint32_t* __restrict__ done, int64_t* host_flag, int64_t ticket)

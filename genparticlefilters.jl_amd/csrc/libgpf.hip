@@ -726,6 +726,9 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
 // order = sortperm(log_priorities, rev=true) (resample.jl:156-157) into h->order: keys + digit histograms in one pass, then
 // eight onesweep digit passes (gpf_kernels.hpp K10).  Key buffers alternate keys -> keys_out -> keys ...; the payload
 // starts as the element index and alternates idx_in -> order, so the eighth pass leaves the permutation in h->order.
+#ifndef KEYS_HIST4_BLOCKS_PER_CU
+#define KEYS_HIST4_BLOCKS_PER_CU 2
+#endif
 // first_pass = 0: all eight digit passes;  4: the four passes over the high 32 key bits (K10c: the caller finishes the runs)
 gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, int first_pass)
 {
@@ -736,10 +739,14 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, int first_p
     uint32_t* ticket = hist + SORT_PASSES * SORT_BINS;
     uint64_t* desc = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(h->sort_tmp) + sort_ws_desc_offset());
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
-    HIP_TRY(h, hipMemsetAsync(h->sort_tmp, 0, sort_ws_bytes(n), h->stream));
-    // (one workgroup per CU: every workgroup ends with up to 2048 global atomic adds into the same 2048 counters)
+    // clear the histograms + tickets and the descriptor planes of the passes that will run (they are laid out pass by pass)
+    const size_t per_pass = (size_t)(nt + (nt + 15) / 16 + (nt + 255) / 256) * SORT_BINS * sizeof(uint64_t);
+    HIP_TRY(h, hipMemsetAsync(h->sort_tmp, 0, sort_ws_desc_offset(), h->stream));
+    HIP_TRY(h, hipMemsetAsync(reinterpret_cast<char*>(h->sort_tmp) + sort_ws_desc_offset() + (size_t)first_pass * per_pass, 0,
+                              (size_t)(SORT_PASSES - first_pass) * per_pass, h->stream));
+    // (few workgroups per CU: every workgroup ends with up to 256 global atomic adds per sorted digit into the same counters)
     if (first_pass == 0) GPF_LAUNCH((k_sort_keys_hist<0>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
-    else                 GPF_LAUNCH((k_sort_keys_hist<4>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
+    else                 GPF_LAUNCH((k_sort_keys_hist<4>), dim3(grid_for(h, n, KEYS_HIST4_BLOCKS_PER_CU)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
     for (int p = first_pass; p < SORT_PASSES; ++p) {
         const uint64_t* kin = (p & 1) ? h->keys_out : h->keys;
         uint64_t* kout = (p & 1) ? h->keys : h->keys_out;
