@@ -193,15 +193,16 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
 // re-sorts with all eight passes.
 constexpr int SORT_RUN_MAX = 48;                    // elements of a run to either side of an element that the finish looks at
 #ifndef GPF_FIN_BLOCK
-#define GPF_FIN_BLOCK 256
+#define GPF_FIN_BLOCK 1024
 #endif
-constexpr int FIN_BLOCK = GPF_FIN_BLOCK, FIN_TILE = 4 * FIN_BLOCK, FIN_HALO = SORT_RUN_MAX + 1;   // (many small workgroups: the pass is load -> barrier -> store)
+// (1024 x 4: with 512- / 256-thread workgroups the pass took 16.8 / 22.1 us against 14.8 -- the completion count below is one
+// same-address atomic per workgroup, ~20 ns each; profiles/r03_sort_experiments.txt)
+constexpr int FIN_BLOCK = GPF_FIN_BLOCK, FIN_TILE = 4 * FIN_BLOCK, FIN_HALO = SORT_RUN_MAX + 1;
 __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                            uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
                                                            uint32_t* __restrict__ done, int64_t* host_flag, int64_t ticket)
 {
     __shared__ uint64_t s_k[FIN_TILE + 2 * FIN_HALO];
-    __shared__ uint32_t s_last;
     const int tid = (int)threadIdx.x;
     const int64_t t0 = (int64_t)blockIdx.x * FIN_TILE;
     for (int p = tid; p < FIN_TILE + 2 * FIN_HALO; p += FIN_BLOCK) {
@@ -236,13 +237,16 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __res
         }
         keys_out[pos] = key; vals_out[pos] = vals_in[g];
     }
-    if (__syncthreads_or((int)too_long) && tid == 0) atomicOr(done, 0x80000000u);
-    if (tid == 0) s_last = atomicAdd(done, 1u);
-    __syncthreads();
-    if (tid == 0 && (s_last & 0x7fffffffu) == gridDim.x - 1) {
-        const uint32_t v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(host_flag, (int64_t)(v >> 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(host_flag + 1, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // completion: done[0] = "a run was too long", done[1] = groups finished, done[2 + i] = workgroups of group i (= blockIdx & 15)
+    // finished -- two levels, so that no counter sees more than gridDim / 16 (+ 16) same-address atomics
+    if (__syncthreads_or((int)too_long) && tid == 0) { atomicOr(done, 1u); __threadfence(); }
+    if (tid == 0) {
+        const uint32_t grp = blockIdx.x & 15u, members = (gridDim.x - grp + 15u) / 16u, groups = gridDim.x < 16u ? gridDim.x : 16u;
+        if (atomicAdd(done + 2 + grp, 1u) == members - 1 && atomicAdd(done + 1, 1u) == groups - 1) {
+            const uint32_t v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_flag, (int64_t)(v & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_flag + 1, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -727,7 +727,7 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
 // eight onesweep digit passes (gpf_kernels.hpp K10).  Key buffers alternate keys -> keys_out -> keys ...; the payload
 // starts as the element index and alternates idx_in -> order, so the eighth pass leaves the permutation in h->order.
 #ifndef KEYS_HIST4_BLOCKS_PER_CU
-#define KEYS_HIST4_BLOCKS_PER_CU 2
+#define KEYS_HIST4_BLOCKS_PER_CU 1
 #endif
 // first_pass = 0: all eight digit passes;  4: the four passes over the high 32 key bits (K10c: the caller finishes the runs)
 gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, int first_pass)
@@ -744,7 +744,8 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, int first_p
     HIP_TRY(h, hipMemsetAsync(h->sort_tmp, 0, sort_ws_desc_offset(), h->stream));
     HIP_TRY(h, hipMemsetAsync(reinterpret_cast<char*>(h->sort_tmp) + sort_ws_desc_offset() + (size_t)first_pass * per_pass, 0,
                               (size_t)(SORT_PASSES - first_pass) * per_pass, h->stream));
-    // (few workgroups per CU: every workgroup ends with up to 256 global atomic adds per sorted digit into the same counters)
+    // (ONE workgroup per CU: every workgroup ends with up to 256 global atomic adds per sorted digit into the same counters; with 2 / 4
+    //  workgroups per CU the four-digit kernel took 16.0 / 24.2 us against 13.3)
     if (first_pass == 0) GPF_LAUNCH((k_sort_keys_hist<0>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
     else                 GPF_LAUNCH((k_sort_keys_hist<4>), dim3(grid_for(h, n, KEYS_HIST4_BLOCKS_PER_CU)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
     for (int p = first_pass; p < SORT_PASSES; ++p) {
