@@ -14,4 +14,15 @@ for C in FETCH_SIZE WRITE_SIZE; do
   f=$(find $R/gpurun_out/pmc_${TAG}_$C -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/${TAG}_pmc_$C.csv
 done
 cd $R; python tools/bench_configs.py > gpurun_out/${TAG}_configs.log 2>&1; cut -c1-300 gpurun_out/${TAG}_configs.log
+# the driver's scaling command as the driver types it (no torchrun, no WORLD_SIZE), two ranks on this box's one GPU
+GPF_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --steps 20 --warmup 5 --particles-per-gpu 500000 > gpurun_out/${TAG}_bench_two_ranks_one_device.json 2> gpurun_out/${TAG}_bench2.err; echo "rc $?"; cut -c1-300 gpurun_out/${TAG}_bench_two_ranks_one_device.json
+# the sharded code path on one rank, three transports
+OUT=$R/gpurun_out/${TAG}_sharded_one_rank.txt; : > $OUT
+for M in multinomial stratified residual; do
+  echo "== $M, N = 1e6, 300 steps, library engine (tools/sharded_loop.py)" >> $OUT
+  echo -n "no communicator (gathered arrays alias the local ones):      " >> $OUT; python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
+  echo -n "1-rank RCCL communicator, summaries through the mailbox:     " >> $OUT; GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
+  echo -n "1-rank RCCL communicator, summaries as RCCL all-gathers:     " >> $OUT; GPF_SHARD_FORCE_COLLECTIVES=1 GPF_SHARD_SUMMARY=rccl python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
+done
+cat $OUT
 rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE
