@@ -134,7 +134,9 @@ def run_fuzz(rank, world, port, seed, n_global, T, out_dir):
             if op == "update":
                 sharded.pf_update(st, (t + 1,), (None,), ys[t]); t += 1
             elif op == "resample":
-                sharded.pf_resample(st, method, check=False)
+                # (library engine: every other global resample is tempered, priority_fn = w -> w / 2)
+                tempered = st.backend.lib_comm and bool(salt & 4)
+                sharded.pf_resample(st, method, check=False, priority_fn=g.Tempering(0.5) if tempered else None)
             elif op == "rejuvenate":
                 sharded.pf_rejuvenate(st, None, (), 1, method="move")
             elif op == "getters":

@@ -216,7 +216,8 @@ def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib,
         if op == "update":
             f.update(ys[t]); t += 1
         elif op == "resample":
-            f.resample(method, check=False, **({"sort_particles": False} if method == "stratified" else {}))
+            f.resample(method, check=False, priority_alpha=0.5 if (engine == "library" and salt & 4) else None,
+                       **({"sort_particles": False} if method == "stratified" else {}))
         elif op == "rejuvenate":
             f.rejuvenate("move", 1)
         elif op == "getters":
