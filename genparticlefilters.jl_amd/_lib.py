@@ -40,6 +40,7 @@ SYMBOLS = [
     ("gpf_update_proposal", C.c_int, [_H, _pd, C.c_int32, C.c_int32]),
     ("gpf_initialize_strata", C.c_int, [_H, _pd, C.c_int32, _pd, C.c_int32, C.c_int32]),
     ("gpf_update_strata", C.c_int, [_H, _pd, C.c_int32, _pd, C.c_int32, C.c_int32]),
+    ("gpf_initialize_strata_proposal", C.c_int, [_H, _pd, C.c_int32, _pd, C.c_int32, C.c_int32, C.c_int32]),
     ("gpf_resample", C.c_int, [_H, C.c_int32, C.c_double, C.c_int32, C.c_int32, _pi32]),
     ("gpf_resample_local", C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, _pi32]),
     ("gpf_resample_with_priorities", C.c_int, [_H, C.c_int32, _pd, C.c_int32, C.c_int32, _pi32]),

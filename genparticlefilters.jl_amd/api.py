@@ -244,11 +244,17 @@ def pf_initialize(model: NativeModel, model_args: tuple, observations, *rest, se
     elif len(rest) == 3:
         proposal, n_particles = rest[0], rest[2]
         _proposal_id(proposal)
+    elif len(rest) == 4:                                            # (strata, proposal, proposal_args, n): initialize.jl:111-129
+        strata, proposal, n_particles = _strata_values(model, rest[0], "initialize"), rest[1], rest[3]
+        _proposal_id(proposal)
     else:
-        raise TypeError("pf_initialize(model, model_args, observations, [strata, | proposal, proposal_args,] n_particles)")
+        raise TypeError("pf_initialize(model, model_args, observations, [strata,] [proposal, proposal_args,] n_particles)")
     state = DeviceParticleFilterState(model, n_particles, seed=seed, keep_prev=keep_prev, device=device, **kw)
     obs = _obs_vector(observations)
-    if strata is not None:
+    if strata is not None and proposal is not None:
+        state._check(state._L.gpf_initialize_strata_proposal(state._h, _pd(obs), obs.size, _pd(strata), strata.size, int(_layout_id(layout)),
+                                                             _proposal_id(proposal)))
+    elif strata is not None:
         state._check(state._L.gpf_initialize_strata(state._h, _pd(obs), obs.size, _pd(strata), strata.size, int(_layout_id(layout))))
     elif proposal is None:
         state._check(state._L.gpf_initialize(state._h, _pd(obs), obs.size))

@@ -41,7 +41,8 @@ __device__ __forceinline__ int stratum_of(const ModelArgs& a, uint64_t seed, uin
 
 // pf_initialize (initialize.jl:39-41) / pf_update! (update.jl:15-22): one lane per particle, row in,
 // row out, lw += log p(y|x).  Counter-based RNG: no RNG state in memory.
-// MODE 0: the model's own sampler; 1: native custom proposal; 2: stratified (the discrete latent constrained per stratum)
+// MODE 0: the model's own sampler; 1: native custom proposal; 2: stratified (the discrete latent constrained per stratum);
+// 3 (k_init only): stratified with a native proposal for the other choice
 template <int M, int MODE = 0>
 __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, int W, double* __restrict__ rows,
@@ -58,6 +59,9 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
             const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
             const double lp = Mo::sample_stratum(a.P, true, nullptr, a.obs, v, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
             ll = (lp + Mo::loglik(a.P, x, a.obs)) + a.logK;                      // initialize.jl:103-104
+        } else if constexpr (MODE == 3) {                                        // strata + native proposal, initialize.jl:122-126
+            const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
+            ll = Mo::propose_stratum(a.P, a.obs, v, x) + a.logK;
         } else {
             Mo::sample(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
             ll = Mo::loglik(a.P, x, a.obs);

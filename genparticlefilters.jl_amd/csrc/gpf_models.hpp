@@ -40,6 +40,7 @@ template <int M> struct Model;
 //      locally optimal proposal, transition: gain sv 1/sv 2(log sv + ..) 1/sq 2(log sq + ..) | initial: gain0 sv0 1/sv0 2(log sv0 + ..) 1/s0 2(log s0 + ..)]
 template <> struct Model<MODEL_LGSSM2> {
     static constexpr bool HAS_STRATA = false;
+    static constexpr bool HAS_STRATA_PROPOSAL = false;
     static constexpr int D = 2, NBLK = 1;
     static constexpr bool HAS_PROPOSAL = true;
     // custom-proposal update (reference src/update.jl:79-96, src/translate.jl:86-105 without transform;
@@ -106,6 +107,7 @@ template <> struct Model<MODEL_LGSSM2> {
 // P = [mu0..3 | s0..3 | sp | sv | 1/sb | log sb + log(2 pi)/2]
 template <> struct Model<MODEL_BEARINGS4> {
     static constexpr bool HAS_STRATA = false;
+    static constexpr bool HAS_STRATA_PROPOSAL = false;
     static constexpr int D = 4, NBLK = 2;
     static constexpr bool HAS_PROPOSAL = false;
     static constexpr bool HAS_MOVE_PROPOSAL = false;
@@ -140,6 +142,7 @@ template <> struct Model<MODEL_BEARINGS4> {
 // P = [mu | phi | sigma | sigma/sqrt(1-phi^2) | log(2 pi)/2]
 template <> struct Model<MODEL_SV1> {
     static constexpr bool HAS_STRATA = false;
+    static constexpr bool HAS_STRATA_PROPOSAL = false;
     static constexpr int D = 1, NBLK = 1;
     static constexpr bool HAS_PROPOSAL = false;
     static constexpr bool HAS_MOVE_PROPOSAL = false;
@@ -167,6 +170,7 @@ template <> struct Model<MODEL_OBJECT_MOTION> {
     static constexpr bool HAS_PROPOSAL = false;
     static constexpr bool HAS_MOVE_PROPOSAL = false;
     static constexpr bool HAS_STRATA = true;
+    static constexpr bool HAS_STRATA_PROPOSAL = false;
     // stratified generate / update: `moving` is constrained to the stratum's value (merge(stratum, observations),
     // initialize.jl:102, update.jl:200); y is sampled as usual.  Returns log p(moving = value | moving_{t-1}), the part of
     // the weight increment Gen adds for the constrained latent choice.
@@ -257,6 +261,18 @@ template <> struct Model<MODEL_LINE> {
         const bool on = xn[1] != 0.0, oo = x[1] != 0.0;
         const double wn = (on ? P[5] : P[6]) + loglik(P, xn, obs), wo = (oo ? P[5] : P[6]) + loglik(P, x, obs);
         return ((wn - wo) - (on ? Q[1] : Q[2])) + (oo ? Q[1] : Q[2]);
+    }
+    // pf_initialize(model, args, obs, strata, proposal, proposal_args, n) (src/initialize.jl:111-129) as the reference's test uses it
+    // (test/initialize.jl:66-90): strata over `slope`, outlier_propose = bernoulli(0.0) for the step's outlier:
+    //   model_weight - prop_weight = [log p(slope) + log p(outlier = false) + log p(y | .)] - 0      (the caller adds log n_strata)
+    static constexpr bool HAS_STRATA_PROPOSAL = true;
+    static GPF_HD double propose_stratum(const double* P, const double* obs, double value, double* xn)
+    {
+        xn[0] = value;
+        xn[1] = 0.0;
+        double w = P[7];                                                                       // log p(slope = value) = log(1/5)
+        if (obs[1] != 0.0) w = (w + P[6]) + loglik(P, xn, obs);
+        return w;
     }
     // stratified initialise (strata over `slope`, test/initialize.jl:39-64) / update (strata over the step's `outlier`,
     // test/update.jl:13-40): the stratified choice is constrained, the other one is sampled as usual; returns the log

@@ -337,7 +337,7 @@ void launch_step_t(gpf_filter* h, int grid)
 template <int M, int PROP = 0>
 void launch_init_t(gpf_filter* h, int grid)
 {
-    if constexpr ((PROP == 1 && !Model<M>::HAS_PROPOSAL) || (PROP == 2 && !Model<M>::HAS_STRATA)) { (void)h; (void)grid; return; }
+    if constexpr ((PROP == 1 && !Model<M>::HAS_PROPOSAL) || (PROP == 2 && !Model<M>::HAS_STRATA) || (PROP == 3 && !Model<M>::HAS_STRATA_PROPOSAL)) { (void)h; (void)grid; return; }
     else
         GPF_LAUNCH((k_init<M, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw, h->pmax, h->pflags);
@@ -1114,6 +1114,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (prop == 1 && !model_has_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no native proposal");
     if (prop == 2 && !model_has_strata(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no discrete latent to stratify over");
+    if (prop == 3 && h->cfg.model != MODEL_LINE) return fail(h, GPF_ERR_INVALID_ARGUMENT, "stratified initialisation with a native proposal: line_model only");
     if (h->parent) return fail(h, GPF_ERR_STATE, "gpf_initialize on a sub-state view");
     h->generation += 1;
     gpf_status s = set_obs(h, obs, n_obs);
@@ -1124,6 +1125,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
     s = timed(h, GPF_K_STEP, [&] {
         if (prop == 1)      { DISPATCH_MODEL(h, (launch_init_t<MM, 1>(h, grid))); }
         else if (prop == 2) { DISPATCH_MODEL(h, (launch_init_t<MM, 2>(h, grid))); }
+        else if (prop == 3) { DISPATCH_MODEL(h, (launch_init_t<MM, 3>(h, grid))); }
         else                { DISPATCH_MODEL(h, (launch_init_t<MM, 0>(h, grid))); }
     });
     if (s) return s;
@@ -1213,6 +1215,13 @@ gpf_status gpf_initialize_strata(gpf_handle h, const double* obs, int32_t n_obs,
 {
     gpf_status s = set_strata(h, values, n_strata, interleaved);
     return s ? s : initialize_impl(h, obs, n_obs, 2);
+}
+gpf_status gpf_initialize_strata_proposal(gpf_handle h, const double* obs, int32_t n_obs, const double* values, int32_t n_strata, int32_t interleaved,
+                                          int32_t proposal)
+{
+    if (!proposal_matches(h, proposal) || proposal != GPF_PROPOSAL_LINE_FIXED) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown proposal id for this model");
+    gpf_status s = set_strata(h, values, n_strata, interleaved);
+    return s ? s : initialize_impl(h, obs, n_obs, 3);
 }
 gpf_status gpf_update_strata(gpf_handle h, const double* obs, int32_t n_obs, const double* values, int32_t n_strata, int32_t interleaved)
 {

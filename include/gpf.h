@@ -107,6 +107,12 @@ gpf_status gpf_update_proposal(gpf_handle h, const double* obs, int32_t n_obs, i
  * uniformly.  log_weights[i] (+)= log p(latent = value | parents) + log p(obs | x) + log K. */
 gpf_status gpf_initialize_strata(gpf_handle h, const double* obs, int32_t n_obs, const double* values, int32_t n_strata, int32_t interleaved);
 gpf_status gpf_update_strata(gpf_handle h, const double* obs, int32_t n_obs, const double* values, int32_t n_strata, int32_t interleaved);
+/* pf_initialize(model, args, obs, strata, proposal, proposal_args, n; layout)   src/initialize.jl:111-129: the stratified latent is
+ * constrained per stratum, the model's other choice comes from a native proposal, log_weights[i] = model_weight - prop_weight +
+ * log(n_strata).  GPF_MODEL_LINE with GPF_PROPOSAL_LINE_FIXED: strata over `slope`, outlier ~ bernoulli(0.0) -- the form the reference
+ * tests (test/initialize.jl:66-90: expected_w = logpdf(bernoulli, false, 0.1) + logpdf(normal, 0, slope, 1)). */
+gpf_status gpf_initialize_strata_proposal(gpf_handle h, const double* obs, int32_t n_obs, const double* values, int32_t n_strata, int32_t interleaved,
+                                          int32_t proposal);
 
 /* pf_resample!(state, method; priority_fn, check[, sort_particles])  src/resample.jl:19-175
  *   priority_alpha: NaN -> priority_fn = nothing; otherwise priority_fn = w -> priority_alpha * w

@@ -353,6 +353,21 @@ O_EXPORT void o_init_strata(int model, const double *P, uint64_t seed, uint32_t 
         lw[i] = (lp + model_loglik(model, P, r, obs)) + logK;           /* initialize.jl:103-104 */
     }
 }
+/* pf_initialize(model, args, obs, strata, proposal, proposal_args, n) (initialize.jl:111-129) for line_model as test/initialize.jl:66-90
+ * uses it: strata over slope, outlier_propose = bernoulli(0.0): log_weights[i] = model_weight - prop_weight (= 0) + log(n_strata) */
+O_EXPORT void o_init_strata_proposal(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n, int W,
+                                     const double *obs, const double *values, int K, int interleaved, double logK, double *rows, double *lw)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double *r = rows + i * W;
+        for (int k = 0; k < W; ++k) r[k] = 0.0;
+        double v = values[stratum_of(model, K, interleaved, seed, epoch, gid0, i, n, O_TAG_INIT)];
+        r[0] = v; r[1] = 0.0;                                           /* :122-123: stratum + proposed outlier = false */
+        double w = P[7];                                                /* log p(slope = v) = log(1/5) */
+        if (obs[1] != 0.0) w = (w + P[6]) + model_loglik(model, P, r, obs);   /* generate(model, args, merge(stratum, obs, prop_choices)) :124 */
+        lw[i] = w + logK;                                               /* :125 */
+    }
+}
 O_EXPORT void o_step_strata(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n, int W, int keep_prev,
                             const double *obs, const double *values, int K, int interleaved, double logK,
                             const double *rows_in, double *rows_out, double *lw)

@@ -68,6 +68,7 @@ def lib():
     sig("o_init_proposal", None, i32, _f64p, u64, u32, i64, i64, i32, _f64p, _f64p, _f64p)
     sig("o_step_proposal", None, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, _f64p, _f64p, _f64p)
     sig("o_init_strata", None, i32, _f64p, u64, u32, i64, i64, i32, _f64p, _f64p, i32, i32, f64, _f64p, _f64p)
+    sig("o_init_strata_proposal", None, i32, _f64p, u64, u32, i64, i64, i32, _f64p, _f64p, i32, i32, f64, _f64p, _f64p)
     sig("o_step_strata", None, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, _f64p, i32, i32, f64, _f64p, _f64p, _f64p)
     sig("o_move", u64, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, i32, i32, _f64p, _f64p, _f64p)
     sig("o_move_proposal", None, i32, _f64p, _f64p, u64, u32, i64, i64, i32, i32, _f64p, i32, _f64p, _f64p, _f64p)
@@ -234,8 +235,9 @@ class OracleFilter:
         self.hist_x, self.hist_map = [None], [None]
         if strata is not None:                                           # initialize.jl:92-109 + stratified_map!, utils.jl:29-55
             v = np.ascontiguousarray(strata, np.float64)
-            lib().o_init_strata(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, obs, v, v.size,
-                                int(layout != "contiguous"), olog(float(v.size)), self.rows, self.lw)
+            f = lib().o_init_strata_proposal if proposal else lib().o_init_strata     # initialize.jl:111-129 / :92-109
+            f(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, obs, v, v.size,
+              int(layout != "contiguous"), olog(float(v.size)), self.rows, self.lw)
         else:
             f = lib().o_init_proposal if proposal else lib().o_init      # initialize.jl:46-62 / :31-44
             f(self.model, self.params, self.seed, self.epoch, 0, self.n, self.W, obs, self.rows, self.lw)

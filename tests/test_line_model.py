@@ -60,7 +60,9 @@ class DeviceDriver:
     def init(self, t, slope=0.0, proposal=False, strata=None, layout="contiguous"):
         g, obs = self.g, self.g.models.line_obs(t, slope)
         kw = dict(seed=self.seed, keep_prev=self.keep_prev)
-        if strata is not None:
+        if strata is not None and proposal:
+            self.st = g.pf_initialize(self.m, (t,), obs, [{"slope": v} for v in strata], g.line_fixed, ([1],), N, layout=layout, **kw)
+        elif strata is not None:
             self.st = g.pf_initialize(self.m, (t,), obs, [{"slope": v} for v in strata], N, layout=layout, **kw)
         elif proposal:
             self.st = g.pf_initialize(self.m, (t,), obs, g.line_fixed, (0,), N, **kw)
@@ -146,6 +148,21 @@ def test_initialize_with_stratification(g, o, D, layout):
         assert np.all(vrows[:, 0] == slope)                                                        # :49 / :60
         exp = [logpdf_normal(0.0, slope, 10.0 if out else 1.0) for out in vrows[:, 1]]
         np.testing.assert_allclose(vlw, exp, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("D", DRIVERS)
+@pytest.mark.parametrize("layout", ["contiguous", "interleaved"])
+def test_initialize_with_stratification_and_custom_proposal(g, o, D, layout):
+    """test/initialize.jl:66-90: strata = the five slopes, outlier_propose = bernoulli(0.0): per stratum slope == the stratum's,
+    outlier == false, expected_w = logpdf(bernoulli, false, 0.1) + logpdf(normal, 0.0, slope, 1.0)  (:77-79 / :88-90);
+    contiguous blocks state[(k-20+1):k] (:73) or interleaved state[k:5:100] (:84)"""
+    slopes = [-2., -1., 0., 1., 2.]
+    d = D(g, o).init(1, strata=slopes, proposal=True, layout=layout)
+    for k, slope in enumerate(slopes):
+        sel = slice(20 * k, 20 * k + 20) if layout == "contiguous" else slice(k, N, 5)
+        vrows, vlw = d.view(sel)
+        assert np.all(vrows[:, 0] == slope) and np.all(vrows[:, 1] == 0.0)                         # :74-75 / :85-86
+        np.testing.assert_allclose(vlw, logpdf_bernoulli(False, 0.1) + logpdf_normal(0.0, slope, 1.0), rtol=1e-12, atol=1e-12)
 
 
 # ------------------------------------------------------------------------------------------ test/update.jl
@@ -244,7 +261,7 @@ def test_statistics_on_a_degenerate_state(g, o, D):
 
 # ------------------------------------------------------------------------------------------ device == oracle, bit for bit
 @pytest.mark.gpu
-@pytest.mark.parametrize("scenario", ["default", "proposal", "strata_c", "strata_i", "reweight", "move", "reweight_proposal"])
+@pytest.mark.parametrize("scenario", ["default", "proposal", "strata_c", "strata_i", "reweight", "move", "reweight_proposal", "strata_proposal"])
 def test_hip_line_model_bitexact(g, o, scenario):
     a, b = OracleDriver(g, o, seed=5, keep_prev=True), DeviceDriver(g, o, seed=5, keep_prev=True)
     for d in (a, b):
@@ -252,6 +269,8 @@ def test_hip_line_model_bitexact(g, o, scenario):
             d.init(0, proposal=True)
             for t in range(1, 4):
                 d.update(t, proposal=True)
+        elif scenario == "strata_proposal":
+            d.init(1, strata=[-2., -1., 0., 1., 2.], proposal=True, layout="interleaved").update(2)
         elif scenario.startswith("strata"):
             lay = "contiguous" if scenario.endswith("c") else "interleaved"
             d.init(1, strata=[-2., -1., 0., 1., 2.], layout=lay).update(2, strata=[0.0, 1.0], layout=lay)
