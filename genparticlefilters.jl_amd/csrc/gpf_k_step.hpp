@@ -163,6 +163,17 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
 // pf_move_reweight! with move_reweight(trace, selection) (rejuvenate.jl:74-90, :125-132)
 // GATHER: a pf_resample! left its ancestor vector pending; the move reads row anc[i] (new_traces .= view(traces, parents),
 // resample.jl:60, fused) and the incoming log-weights are 0 (resample.jl:195), exactly like k_step<GATHER>.
+// n_accept: [gridDim.x] per-workgroup counts of accepted moves (move-accept only)
+__global__ void k_sum_accepts(const unsigned long long* __restrict__ part, int np, unsigned long long* __restrict__ out)
+{
+    unsigned long long a = 0;
+    for (int i = threadIdx.x; i < np; i += BLOCK) a += part[i];
+    a = wave_sum_u64(a);
+    __shared__ unsigned long long s_a[NWAVES];
+    if (lane_id() == 0) s_a[wave_id()] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < NWAVES; ++w) t += s_a[w]; *out = t; }
+}
 // PROP (with REWEIGHT): move_reweight(trace, proposal, proposal_args) (rejuvenate.jl:134-148) with the model's native move proposal
 // (Model::move_propose): the new latent comes from the proposal, rel_weight = weight - fwd_score + bwd_score.
 template <int M, int W, bool REWEIGHT, bool GATHER = false, bool PROP = false>
@@ -229,9 +240,16 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
         if (REWEIGHT) { const double nl = (GATHER ? 0.0 : lw[i]) + wsum; lw[i] = nl; track_max(nl, bm, bf); }
         else if (GATHER) lw[i] = 0.0;
     }
-    // one atomic per wave
-    unsigned long long t = wave_sum_u64(acc);
-    if (lane_id() == 0 && t) atomicAdd(n_accept, t);
+    // accepted moves: one plain store per workgroup, summed on demand (k_sum_accepts) when the host asks for the count.  (One
+    // same-address atomic per WAVE, as in rounds 1-2, serialises at ~10 ns each: 20-40 us of this kernel at 2 workgroups per CU and
+    // the reason why fewer workgroups per CU ran faster.)  Move-reweight kernels move every particle: nothing to count.
+    if (!REWEIGHT) {
+        const unsigned long long t = wave_sum_u64(acc);
+        __shared__ unsigned long long s_acc[NWAVES];
+        if (lane_id() == 0) s_acc[wave_id()] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned long long b = 0; for (int w = 0; w < NWAVES; ++w) b += s_acc[w]; n_accept[blockIdx.x] = b; }
+    }
     if (REWEIGHT) block_max_store(bm, bf, pmax, pflags);
 }
 

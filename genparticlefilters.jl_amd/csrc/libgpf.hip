@@ -76,6 +76,7 @@ struct gpf_filter {
     int32_t* pflags = nullptr;
     uint64_t* blockQ = nullptr;
     double *partial = nullptr, *dscal = nullptr;
+    unsigned long long* acc_part = nullptr;   // [MAX_PARTIALS] accepted moves per workgroup of the last move-accept kernel
     double* tree_buf = nullptr; int64_t tree_cap = 0;   // partials of the weighted tree sums (statistics)
     Scalars* sc = nullptr;
     Scalars* h_sc = nullptr;       // pinned mirror
@@ -372,11 +373,11 @@ void launch_move_prop_t(gpf_filter* h, int grid, int n_iters)
     else if (h->pending_gather)
         GPF_LAUNCH((k_move<M, Wc, true, true, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                           reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
+                           h->acc_part, h->pmax, h->pflags);
     else
         GPF_LAUNCH((k_move<M, Wc, true, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                           reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
+                           h->acc_part, h->pmax, h->pflags);
 }
 bool model_has_move_proposal(int model)
 {
@@ -396,11 +397,11 @@ void launch_move_t(gpf_filter* h, int grid, int n_iters)
     if (h->pending_gather)           // the resample gather rides on the move (rows read through anc, incoming weights 0)
         GPF_LAUNCH((k_move<M, Wc, RW, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                           reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
+                           h->acc_part, h->pmax, h->pflags);
     else
         GPF_LAUNCH((k_move<M, Wc, RW, false>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                           reinterpret_cast<unsigned long long*>(&h->sc->n_accept), h->pmax, h->pflags);
+                           h->acc_part, h->pmax, h->pflags);
 }
 
 #define DISPATCH_MODEL(h, CALL)                                                                  \
@@ -1030,6 +1031,7 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         HIP_TRY(h, hipMalloc(&h->blockQ, (size_t)4 * 2 * h->n_cu * sizeof(uint64_t) + 64));
         h->max_np = 0;
         HIP_TRY(h, hipMalloc(&h->partial, MAX_PARTIALS * sizeof(double)));
+        HIP_TRY(h, hipMalloc(&h->acc_part, MAX_PARTIALS * sizeof(unsigned long long)));
         HIP_TRY(h, hipMalloc(&h->dscal, 4 * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->sc, sizeof(Scalars)));
         HIP_TRY(h, hipHostMalloc(&h->h_sc, sizeof(Scalars)));
@@ -1089,7 +1091,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers (or of the compact copies below)
     for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc}) if (q) (void)hipFree(q);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf};
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf, h->acc_part};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
@@ -1294,7 +1296,6 @@ static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters,
     if (h->pending_packed && (s = materialize(h))) return s;     // sharded deferred commit: scatter first
     if (h->pending_fill && (s = materialize(h))) return s;       // (the move kernel's fused gather assumes incoming weights 0)
     const bool fused_gather = h->pending_gather;                 // a pending resample gather rides on the move kernel
-    HIP_TRY(h, hipMemsetAsync(&h->sc->n_accept, 0, sizeof(uint64_t), h->stream));
     const int grid = move_grid(h);
     s = timed(h, GPF_K_MOVE, [&] {
         if (with_proposal)                          { DISPATCH_MODEL(h, (launch_move_prop_t<MM>(h, grid, n_iters))); }
@@ -1310,8 +1311,13 @@ static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters,
     mutated(h);
     if ((s = view_exit(h))) return s;
     if (n_accepted) {
-        if ((s = fetch_scalars(h))) return s;
-        *n_accepted = h->h_sc->n_accept;
+        if (method == GPF_REJUVENATE_REWEIGHT) *n_accepted = (uint64_t)h->n * (uint64_t)n_iters;     // every particle moves (rejuvenate.jl:81-86)
+        else {
+            GPF_LAUNCH(k_sum_accepts, dim3(1), dim3(BLOCK), 0, h->stream, h->acc_part, grid, reinterpret_cast<unsigned long long*>(&h->sc->n_accept));
+            HIP_TRY(h, hipGetLastError());
+            if ((s = fetch_scalars(h))) return s;
+            *n_accepted = h->h_sc->n_accept;
+        }
     }
     return GPF_OK;
 }
@@ -1640,6 +1646,7 @@ gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t ste
         HIP_TRY(v, hipMalloc(&v->pflags, MAX_PARTIALS * sizeof(int32_t)));
         HIP_TRY(v, hipMalloc(&v->blockQ, (size_t)4 * 2 * v->n_cu * sizeof(uint64_t) + 64));
         HIP_TRY(v, hipMalloc(&v->partial, MAX_PARTIALS * sizeof(double)));
+        HIP_TRY(v, hipMalloc(&v->acc_part, MAX_PARTIALS * sizeof(unsigned long long)));
         HIP_TRY(v, hipMalloc(&v->dscal, 4 * sizeof(double)));
         HIP_TRY(v, hipMalloc(&v->sc, sizeof(Scalars)));
         HIP_TRY(v, hipHostMalloc(&v->h_sc, sizeof(Scalars)));

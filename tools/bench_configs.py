@@ -63,5 +63,7 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
 
 
 if __name__ == "__main__":
+    want = sys.argv[1:]                    # e.g. `config4 config5`: only the configs whose name starts with one of these
     for c in CONFIGS:
-        run(*c)
+        if not want or any(c[0].startswith(w) for w in want):
+            run(*c)
