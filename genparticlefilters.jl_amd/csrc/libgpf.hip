@@ -308,10 +308,11 @@ gpf_status alloc_particle_buffers(gpf_filter* h)
 #define STEP_BLOCKS_PER_CU 4
 #endif
 int step_grid(const gpf_filter* h) { return std::min(grid_for(h, h->n, STEP_BLOCKS_PER_CU), MAX_PARTIALS); }
-// the rejuvenation kernels (two likelihoods, three Philox blocks, the fused row gather) run FASTER with fewer workgroups per CU:
-// measured at N = 1e6 / 2e6, 8 per CU 105 / 123 us, 4: 68 / 84, 2: 52 / 61, 1: 55 / 59 (bearings MH / SV move-reweight)
+// the rejuvenation kernels: rounds 1-2 found them FASTER with fewer workgroups per CU (8 per CU 105 / 123 us, 2: 52 / 61, bearings MH / SV
+// move-reweight) -- the reason was one same-address atomic per WAVE for the accept count (~10 ns each, serialised: 20-40 us).  With
+// per-workgroup counts (round 3): 2 per CU 36.7 / 44.2 us, 3: 32.1 / 44.6, 4: 31.3 / 44.6, 6: 31.2 / 47.7, 8: 31.5 / 47.0.
 #ifndef MOVE_BLOCKS_PER_CU
-#define MOVE_BLOCKS_PER_CU 2
+#define MOVE_BLOCKS_PER_CU 4
 #endif
 int move_grid(const gpf_filter* h) { return std::min(grid_for(h, h->n, MOVE_BLOCKS_PER_CU), MAX_PARTIALS); }
 
