@@ -16,7 +16,9 @@ constexpr int SORT_ITEMS = SORT_TILE / SORT_BLOCK;                 // rank -> lo
 constexpr int SORT_PASSES = 8, SORT_BINS = 256;
 constexpr uint64_t SORT_VALID = 1ull << 62, SORT_VAL = (1ull << 62) - 1;   // descriptor = {valid | count}
 // workspace: [8][256] u32 histograms | [8] u32 tile tickets | pad | per pass: [ntiles | ntiles/16 | ntiles/256][256] u64 descriptors
-__host__ __device__ __forceinline__ size_t sort_ws_desc_offset() { return (size_t)(SORT_PASSES * SORT_BINS + 64) * sizeof(uint32_t); }
+// (after the histograms: 64 tile tickets -- 8 per pass -- and 18 completion words of k_sort_finish, inside 128 words)
+constexpr int SORT_TICKET_WAYS = 8;
+__host__ __device__ __forceinline__ size_t sort_ws_desc_offset() { return (size_t)(SORT_PASSES * SORT_BINS + 128) * sizeof(uint32_t); }
 __host__ inline size_t sort_ws_bytes(int64_t n)
 {
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
@@ -55,7 +57,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     __shared__ uint32_t s_tile;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
     const int shift = 8 * pass;
-    if (tid == 0) s_tile = atomicAdd(ticket + pass, 1u);
+    // tiles are taken by ticket (arrival order, not block index: a tile only ever waits for tiles that are already running) -- from
+    // EIGHT counters, way = blockIdx & 7 taking the tiles way, way + 8, ...: one counter would serialise the launch's ~250 same-address
+    // atomics (~10 ns each) in front of every tile's load
+#ifdef GPF_SORT_ONE_TICKET
+    if (tid == 0) s_tile = atomicAdd(ticket + pass * SORT_TICKET_WAYS, 1u);
+#else
+    if (tid == 0) { const uint32_t way = blockIdx.x & (SORT_TICKET_WAYS - 1); s_tile = way + SORT_TICKET_WAYS * atomicAdd(ticket + pass * SORT_TICKET_WAYS + way, 1u); }
+#endif
     for (int i = tid; i < SORT_WAVES * SORT_BINS; i += SORT_BLOCK) (&s_cnt[0][0])[i] = 0;
     // exclusive scan of the digit's histogram: where each bin starts in the output
     const bool binthr = tid < SORT_BINS;               // the first four waves double as "thread = bin"
