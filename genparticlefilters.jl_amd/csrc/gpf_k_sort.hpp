@@ -57,14 +57,11 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     __shared__ uint32_t s_tile;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
     const int shift = 8 * pass;
-    // tiles are taken by ticket (arrival order, not block index: a tile only ever waits for tiles that are already running) -- from
-    // EIGHT counters, way = blockIdx & 7 taking the tiles way, way + 8, ...: one counter would serialise the launch's ~250 same-address
-    // atomics (~10 ns each) in front of every tile's load
-#ifdef GPF_SORT_ONE_TICKET
+    // tiles are taken by ticket (arrival order, not block index: a tile only ever waits for tiles that are already running).  ONE counter:
+    // eight counters (way = blockIdx & 7 taking the tiles way, way + 8, ...), which avoid ~250 serialised same-address atomics in front
+    // of the loads, measured 16.4 us per pass against 15.1 (profiles/r03_sort_experiments.txt) -- the interleaved arrival order costs
+    // more in the look-back than the atomics cost
     if (tid == 0) s_tile = atomicAdd(ticket + pass * SORT_TICKET_WAYS, 1u);
-#else
-    if (tid == 0) { const uint32_t way = blockIdx.x & (SORT_TICKET_WAYS - 1); s_tile = way + SORT_TICKET_WAYS * atomicAdd(ticket + pass * SORT_TICKET_WAYS + way, 1u); }
-#endif
     for (int i = tid; i < SORT_WAVES * SORT_BINS; i += SORT_BLOCK) (&s_cnt[0][0])[i] = 0;
     // exclusive scan of the digit's histogram: where each bin starts in the output
     const bool binthr = tid < SORT_BINS;               // the first four waves double as "thread = bin"
