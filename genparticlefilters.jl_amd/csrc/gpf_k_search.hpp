@@ -327,9 +327,12 @@ __host__ __device__ __forceinline__ int64_t multi_groups(int64_t ntiles, int log
 __host__ __device__ __forceinline__ uint32_t kpad(uint32_t i) { return i + (i >> 5); }
 __host__ inline size_t multi_lds_bytes(int64_t ntiles, int logg) { return (size_t)(kpad((uint32_t)multi_groups(ntiles, logg)) + 1) * sizeof(uint32_t); }
 // smallest LOGG whose key table fits (-1: none; the caller falls back to k_search)
+#ifndef GPF_MULTI_MIN_LOGG
+#define GPF_MULTI_MIN_LOGG 0
+#endif
 __host__ inline int multi_logg(int64_t ntiles)
 {
-    for (int g = 0; g <= 1; ++g) if (multi_lds_bytes(ntiles, g) <= (size_t)MULTI_LDS_BUDGET) return g;
+    for (int g = GPF_MULTI_MIN_LOGG; g <= 1; ++g) if (multi_lds_bytes(ntiles, g) <= (size_t)MULTI_LDS_BUDGET) return g;
     return -1;
 }
 // Beyond that (2.5 M particles) the levels stay those of 32-cell key groups and LDS keeps every (1 << s)-th key (ScanOut::k32s,
