@@ -361,8 +361,10 @@ __device__ __forceinline__ uint32_t pk_ne(uint32_t x, uint32_t qq)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x ^ qq), one));
 }
 
+// slots per lane and iteration of the key-table searches: 2 (two iterations per workgroup at 10^6 slots) measured 16.0 us against 17.1
+// for 4 (one iteration) -- rocprofv3, alternating runs, round 3; 64-cell key groups at this size: 19.2 us
 #ifndef GPF_MULTI_NS
-#define GPF_MULTI_NS 4
+#define GPF_MULTI_NS 2
 #endif
 struct MultiTable { const uint32_t* keys; uint32_t ng, p2; float kscale; };      // the LDS key table of k_search_multi
 constexpr uint32_t MULTI_WIN = 512;                // interpolation window of the key search
