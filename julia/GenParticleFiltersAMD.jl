@@ -147,6 +147,15 @@ function pf_rejuvenate!(s::DeviceParticleFilterState, kern=nothing, kern_args::T
     check(s, ccall((:gpf_rejuvenate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, C_NULL))
     return s
 end
+# move_reweight(trace, proposal, proposal_args) (src/rejuvenate.jl:134-148) with a native proposal:
+#   MoveProposal(1, Float64[])                      the LG-SSM's locally optimal proposal of x_t
+#   MoveProposal(2, [q, log(q), log1p(-q)])         line_model: outlier ~ bernoulli(q), the outlier_propose of test/rejuvenate.jl:19-27
+struct MoveProposal; id::Int; params::Vector{Float64}; end
+function pf_move_reweight!(s::DeviceParticleFilterState, kern, kern_args::Tuple{MoveProposal,Vararg}, n_iters::Int=1)
+    mp = kern_args[1]
+    check(s, ccall((:gpf_rejuvenate_proposal, libgpf), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Cint), s.handle, mp.id, mp.params, length(mp.params), n_iters))
+    return s
+end
 pf_move_accept!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1) = pf_rejuvenate!(s, kern, kern_args, n_iters; method=:move)
 pf_move_reweight!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1) = pf_rejuvenate!(s, kern, kern_args, n_iters; method=:reweight)
 
@@ -231,6 +240,13 @@ function pf_initialize(model::NativeModel, args::Tuple, obs::Vector{Float64}, st
     s = DeviceParticleFilterState(model, n; kwargs...)
     check(s, ccall((:gpf_initialize_strata, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint),
                    s.handle, obs, length(obs), strata, length(strata), layout != :contiguous)); s
+end
+# ... with a native proposal for the model's other choice (src/initialize.jl:111-129; line_model + LineFixed: test/initialize.jl:66-90)
+function pf_initialize(model::NativeModel, args::Tuple, obs::Vector{Float64}, strata::Vector{Float64}, proposal_id::Int, proposal_args::Tuple, n::Int;
+                       layout::Symbol=:contiguous, kwargs...)
+    s = DeviceParticleFilterState(model, n; kwargs...)
+    check(s, ccall((:gpf_initialize_strata_proposal, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint, Cint),
+                   s.handle, obs, length(obs), strata, length(strata), layout != :contiguous, proposal_id)); s
 end
 function pf_update!(s::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, obs::Vector{Float64}, strata::Vector{Float64}; layout::Symbol=:interleaved)
     check(s, ccall((:gpf_update_strata, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint),
