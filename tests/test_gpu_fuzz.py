@@ -95,7 +95,11 @@ def test_random_api_sequences(g, o, seed):
             op = f"resample {m} {alpha} {kw}"
         elif op == "rejuvenate":
             meth = str(rng.choice(["move", "reweight"])); it = int(rng.integers(1, 3))
-            g.pf_rejuvenate(st, g.mh if meth == "move" else g.move_reweight, (), it, method=meth); orc.rejuvenate(meth, it)
+            if name == "lgssm2" and meth == "reweight" and rng.random() < 0.5:       # move_reweight(trace, proposal, args), rejuvenate.jl:134-148
+                g.pf_rejuvenate(st, g.move_reweight, (g.locally_optimal_move, ()), it, method="reweight"); orc.rejuvenate("reweight", it, proposal=())
+                meth = "reweight (locally optimal proposal)"
+            else:
+                g.pf_rejuvenate(st, g.mh if meth == "move" else g.move_reweight, (), it, method=meth); orc.rejuvenate(meth, it)
             op = f"rejuvenate {meth} {it}"
         elif op == "set_weights":
             # ParticleFilterState(trs, ws): weights no filter step would produce -- equal, collapsed, with zeros, far apart
@@ -110,8 +114,7 @@ def test_random_api_sequences(g, o, seed):
             if hist:                                                    # a past choice along the surviving ancestry (README.md:97-104)
                 step_q = int(rng.integers(1, t + 1)); c = int(rng.integers(model.dim))
                 assert np.array_equal(st.history_column(step_q, c), orc.history_column(step_q, c)), (step_q, c, log[-6:])
-            np.testing.assert_allclose(g.mean(st, 0), orc.mean(0), rtol=1e-9, atol=1e-12)
-            np.testing.assert_allclose(g.var(st, 0), orc.var(0), rtol=1e-9, atol=1e-12)
+            assert same(g.mean(st, 0), orc.mean(0)) and same(g.var(st, 0), orc.var(0)), log[-6:]     # (the summation order is part of the spec)
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 np.testing.assert_allclose(g.get_norm_weights(st), orc.norm_weights(), rtol=1e-12, atol=0, equal_nan=True)
@@ -124,7 +127,10 @@ def test_random_api_sequences(g, o, seed):
             a, b = (0, n) if op == "whole_view" else sorted(int(x) for x in rng.choice(n + 1, 2, replace=False))
             if b - a < 2:
                 continue
-            sv, ov = st[a:b], orc[a:b]
+            stride = 1 if (op == "whole_view" or rng.random() < 0.5) else int(rng.integers(2, 8))      # state[a:stride:b] (view.jl:35-48)
+            if len(range(a, b, stride)) < 2:
+                continue
+            sv, ov = st[a:b:stride], orc[a:b:stride]
             sub = rng.choice(["update", "resample", "rejuvenate"])
             if sub == "update":
                 g.pf_update(sv, (t + 1,), (None,), ys[t]); ov.update(ys[t])          # (only the view's particles advance)
@@ -137,7 +143,7 @@ def test_random_api_sequences(g, o, seed):
             else:
                 g.pf_rejuvenate(sv, g.mh, (), 1); ov.rejuvenate("move", 1)
             assert same(g.get_ess(sv), ov.effective_sample_size()) and same(g.get_lml_est(sv), ov.log_ml_estimate())
-            op = f"{op}[{a}:{b}] {sub}"
+            op = f"{op}[{a}:{b}:{stride}] {sub}"
         elif op == "resize":
             kind = rng.choice(["multinomial", "residual", "optimal", "replicate"])
             if kind == "replicate":
@@ -203,15 +209,25 @@ def test_random_api_sequences_discrete_latent_models(g, o, seed):
                 return
             op = f"resample {m} {kw}"
         elif op == "rejuvenate":
-            g.pf_rejuvenate(st, g.mh, (), 1); orc.rejuvenate("move", 1)
+            if name == "line_model" and t > 1 and rng.random() < 0.5:   # outlier_propose = bernoulli(q) on the current step (test/rejuvenate.jl:19-27)
+                import math
+                q = float(rng.choice([0.9, 0.5, 0.1]))
+                g.pf_rejuvenate(st, g.move_reweight, (g.outlier_propose(q), (t - 1,)), 1, method="reweight")
+                orc.rejuvenate("reweight", 1, proposal=(q, math.log(q), math.log1p(-q)))
+                op = f"rejuvenate reweight outlier_propose({q})"
+            else:
+                g.pf_rejuvenate(st, g.mh, (), 1); orc.rejuvenate("move", 1)
         elif op == "view_strata":
             a, b = sorted(int(x) for x in rng.choice(n + 1, 2, replace=False))
             if b - a < 4:
                 continue
-            g.pf_update(st[a:b], (t,), (None,), ys[t], strata_t, layout="contiguous"); orc[a:b].update(ys[t], strata=strata_t, layout="contiguous")
-            op = f"view_strata[{a}:{b}]"
+            stride = int(rng.choice([1, 1, 2, 5]))
+            if len(range(a, b, stride)) < 4:
+                continue
+            g.pf_update(st[a:b:stride], (t,), (None,), ys[t], strata_t, layout="contiguous"); orc[a:b:stride].update(ys[t], strata=strata_t, layout="contiguous")
+            op = f"view_strata[{a}:{b}:{stride}]"
         else:
-            np.testing.assert_allclose(g.mean(st, 0), orc.mean(0), rtol=1e-9, atol=1e-12)
+            assert same(g.mean(st, 0), orc.mean(0)), log[-6:]
         log.append(op)
         check(g, st, orc, f"seed {seed} {name} N={N} after {log[-6:]}")
     st.close()
