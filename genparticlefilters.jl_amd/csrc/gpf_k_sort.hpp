@@ -26,10 +26,14 @@ __host__ inline size_t sort_ws_bytes(int64_t n)
 }
 // keys of the log-priorities + the histograms of all eight digits in one pass over the weights
 // (FIRST: the lowest digit that will be sorted -- 0: all eight passes, 4: the high 32 bits only, §K10c)
+// clear / clear16: the OTHER of the two sort workspaces (16-byte units), zeroed here for the next sort: histograms, tickets and
+// descriptor planes must start at zero, and a hipMemsetAsync in front of every sort costs ~5 us of stream time each
 template <int FIRST>
-__global__ __launch_bounds__(BLOCK) void k_sort_keys_hist(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ hist)
+__global__ __launch_bounds__(BLOCK) void k_sort_keys_hist(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ hist,
+                                                          uint4* __restrict__ clear, int64_t clear16)
 {
     __shared__ uint32_t s_h[SORT_PASSES][SORT_BINS];
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < clear16; i += (int64_t)gridDim.x * BLOCK) clear[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = threadIdx.x; i < SORT_PASSES * SORT_BINS; i += BLOCK) (&s_h[0][0])[i] = 0;
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {

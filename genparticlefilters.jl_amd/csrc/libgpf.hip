@@ -71,6 +71,7 @@ struct gpf_filter {
     uint64_t *keys = nullptr, *keys_out = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    int sort_ws_cur = 0;
     int64_t* h_sort_flag = nullptr; int64_t sort_ticket = 0;   // pinned {a run too long for k_sort_finish, ticket}
     double* pmax = nullptr;
     int32_t* pflags = nullptr;
@@ -720,8 +721,11 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
     HIP_TRY(h, hipMalloc(&h->idx_in, n * sizeof(int32_t)));
     HIP_TRY(h, hipMalloc(&h->keys, n * sizeof(uint64_t)));
     HIP_TRY(h, hipMalloc(&h->keys_out, n * sizeof(uint64_t)));
-    h->sort_tmp_bytes = sort_ws_bytes(h->n);
-    HIP_TRY(h, hipMalloc(&h->sort_tmp, h->sort_tmp_bytes));
+    // TWO workspaces (histograms, tickets, descriptor planes), used in turn: every sort clears the other one for the next sort
+    h->sort_tmp_bytes = (sort_ws_bytes(h->n) + 15) & ~(size_t)15;
+    HIP_TRY(h, hipMalloc(&h->sort_tmp, 2 * h->sort_tmp_bytes));
+    HIP_TRY(h, hipMemsetAsync(h->sort_tmp, 0, 2 * h->sort_tmp_bytes, h->stream));
+    h->sort_ws_cur = 0;
     return GPF_OK;
 }
 
@@ -732,24 +736,25 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
 #define KEYS_HIST4_BLOCKS_PER_CU 1
 #endif
 // first_pass = 0: all eight digit passes;  4: the four passes over the high 32 key bits (K10c: the caller finishes the runs)
-gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, int first_pass)
+gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, int first_pass, uint32_t** ws_used = nullptr)
 {
     gpf_status s = ensure_sort_buffers(h);
     if (s) return s;
     static_assert(SORT_BINS == BLOCK, "one thread per digit bin");
-    uint32_t* hist = reinterpret_cast<uint32_t*>(h->sort_tmp);
+    // this sort's workspace starts zeroed (by the previous sort, or by the allocation); the key pass zeroes the other one
+    char* ws = static_cast<char*>(h->sort_tmp) + (size_t)h->sort_ws_cur * h->sort_tmp_bytes;
+    char* other = static_cast<char*>(h->sort_tmp) + (size_t)(1 - h->sort_ws_cur) * h->sort_tmp_bytes;
+    h->sort_ws_cur ^= 1;
+    if (ws_used) *ws_used = reinterpret_cast<uint32_t*>(ws);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ws);
     uint32_t* ticket = hist + SORT_PASSES * SORT_BINS;
-    uint64_t* desc = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(h->sort_tmp) + sort_ws_desc_offset());
+    uint64_t* desc = reinterpret_cast<uint64_t*>(ws + sort_ws_desc_offset());
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
-    // clear the histograms + tickets and the descriptor planes of the passes that will run (they are laid out pass by pass)
-    const size_t per_pass = (size_t)(nt + (nt + 15) / 16 + (nt + 255) / 256) * SORT_BINS * sizeof(uint64_t);
-    HIP_TRY(h, hipMemsetAsync(h->sort_tmp, 0, sort_ws_desc_offset(), h->stream));
-    HIP_TRY(h, hipMemsetAsync(reinterpret_cast<char*>(h->sort_tmp) + sort_ws_desc_offset() + (size_t)first_pass * per_pass, 0,
-                              (size_t)(SORT_PASSES - first_pass) * per_pass, h->stream));
+    const int64_t clear16 = (int64_t)(h->sort_tmp_bytes / 16);
     // (ONE workgroup per CU: every workgroup ends with up to 256 global atomic adds per sorted digit into the same counters; with 2 / 4
     //  workgroups per CU the four-digit kernel took 16.0 / 24.2 us against 13.3)
-    if (first_pass == 0) GPF_LAUNCH((k_sort_keys_hist<0>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
-    else                 GPF_LAUNCH((k_sort_keys_hist<4>), dim3(grid_for(h, n, KEYS_HIST4_BLOCKS_PER_CU)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist);
+    if (first_pass == 0) GPF_LAUNCH((k_sort_keys_hist<0>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16);
+    else                 GPF_LAUNCH((k_sort_keys_hist<4>), dim3(grid_for(h, n, KEYS_HIST4_BLOCKS_PER_CU)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16);
     for (int p = first_pass; p < SORT_PASSES; ++p) {
         const uint64_t* kin = (p & 1) ? h->keys_out : h->keys;
         uint64_t* kout = (p & 1) ? h->keys : h->keys_out;
@@ -767,10 +772,11 @@ gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
 {
     static const int mode = [] { const char* e = getenv("GPF_SORT"); return e && !strcmp(e, "radix8") ? 1 : (e && !strcmp(e, "fallback") ? 2 : 0); }();
     if (mode == 1) return sort_passes(h, pv, n, 0);
-    gpf_status s = sort_passes(h, pv, n, 4);                     // (the fourth of them leaves keys / payload in h->keys / h->order)
+    uint32_t* ws = nullptr;
+    gpf_status s = sort_passes(h, pv, n, 4, &ws);                // (the fourth of them leaves keys / payload in h->keys / h->order)
     if (s) return s;
     if (!h->h_sort_flag) { HIP_TRY(h, hipHostMalloc(&h->h_sort_flag, 2 * sizeof(int64_t))); h->h_sort_flag[0] = h->h_sort_flag[1] = 0; }
-    uint32_t* done = reinterpret_cast<uint32_t*>(h->sort_tmp) + SORT_PASSES * SORT_BINS + SORT_PASSES * SORT_TICKET_WAYS;   // (inside the workspace's cleared ticket block)
+    uint32_t* done = ws + SORT_PASSES * SORT_BINS + SORT_PASSES * SORT_TICKET_WAYS;      // (inside this sort's zeroed ticket block)
     h->sort_ticket += 1;
     GPF_LAUNCH(k_sort_finish, dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)), dim3(FIN_BLOCK), 0, h->stream, h->keys, h->order, h->keys_out, h->idx_in, n,
                done, h->h_sort_flag, h->sort_ticket);
