@@ -16,9 +16,11 @@ constexpr int SORT_ITEMS = SORT_TILE / SORT_BLOCK;                 // rank -> lo
 constexpr int SORT_PASSES = 8, SORT_BINS = 256;
 constexpr uint64_t SORT_VALID = 1ull << 62, SORT_VAL = (1ull << 62) - 1;   // descriptor = {valid | count}
 // workspace: [8][256] u32 histograms | [8] u32 tile tickets | pad | per pass: [ntiles | ntiles/16 | ntiles/256][256] u64 descriptors
-// (after the histograms: 64 tile tickets -- 8 per pass -- and 18 completion words of k_sort_finish, inside 128 words)
+// (after the histograms: 64 words of tile tickets -- 8 per pass --, then the completion words of k_sort_finish, one per 128-byte line:
+//  same-LINE atomics serialise like same-address ones, ~10 ns each)
 constexpr int SORT_TICKET_WAYS = 8;
-__host__ __device__ __forceinline__ size_t sort_ws_desc_offset() { return (size_t)(SORT_PASSES * SORT_BINS + 128) * sizeof(uint32_t); }
+constexpr int SORT_DONE_STRIDE = 32;               // u32 words between completion counters
+__host__ __device__ __forceinline__ size_t sort_ws_desc_offset() { return (size_t)(SORT_PASSES * SORT_BINS + 64 + 18 * SORT_DONE_STRIDE) * sizeof(uint32_t); }
 __host__ inline size_t sort_ws_bytes(int64_t n)
 {
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
@@ -247,12 +249,12 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __res
         }
         keys_out[pos] = key; vals_out[pos] = vals_in[g];
     }
-    // completion: done[0] = "a run was too long", done[1] = groups finished, done[2 + i] = workgroups of group i (= blockIdx & 15)
-    // finished -- two levels, so that no counter sees more than gridDim / 16 (+ 16) same-address atomics
+    // completion: done[0] = "a run was too long", done[32] = groups finished, done[32 (2 + i)] = workgroups of group i (= blockIdx & 15)
+    // finished -- two levels on separate 128-byte lines, so that no line sees more than gridDim / 16 (+ 16) atomics
     if (__syncthreads_or((int)too_long) && tid == 0) { atomicOr(done, 1u); __threadfence(); }
     if (tid == 0) {
         const uint32_t grp = blockIdx.x & 15u, members = (gridDim.x - grp + 15u) / 16u, groups = gridDim.x < 16u ? gridDim.x : 16u;
-        if (atomicAdd(done + 2 + grp, 1u) == members - 1 && atomicAdd(done + 1, 1u) == groups - 1) {
+        if (atomicAdd(done + (2 + grp) * SORT_DONE_STRIDE, 1u) == members - 1 && atomicAdd(done + SORT_DONE_STRIDE, 1u) == groups - 1) {
             const uint32_t v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(host_flag, (int64_t)(v & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(host_flag + 1, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -776,7 +776,7 @@ gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
     gpf_status s = sort_passes(h, pv, n, 4, &ws);                // (the fourth of them leaves keys / payload in h->keys / h->order)
     if (s) return s;
     if (!h->h_sort_flag) { HIP_TRY(h, hipHostMalloc(&h->h_sort_flag, 2 * sizeof(int64_t))); h->h_sort_flag[0] = h->h_sort_flag[1] = 0; }
-    uint32_t* done = ws + SORT_PASSES * SORT_BINS + SORT_PASSES * SORT_TICKET_WAYS;      // (inside this sort's zeroed ticket block)
+    uint32_t* done = ws + SORT_PASSES * SORT_BINS + 64;                                  // (behind this sort's zeroed tickets)
     h->sort_ticket += 1;
     GPF_LAUNCH(k_sort_finish, dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)), dim3(FIN_BLOCK), 0, h->stream, h->keys, h->order, h->keys_out, h->idx_in, n,
                done, h->h_sort_flag, h->sort_ticket);
