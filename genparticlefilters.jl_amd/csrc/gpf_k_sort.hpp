@@ -221,6 +221,9 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __res
         const int64_t g = t0 - FIN_HALO + p;
         s_k[p] = (g >= 0 && g < n) ? keys_in[g] : 0ull;
     }
+    int32_t val[FIN_TILE / FIN_BLOCK];                                     // the payloads: in flight while the runs are examined
+#pragma unroll
+    for (int it = 0; it < FIN_TILE / FIN_BLOCK; ++it) { const int64_t g = t0 + it * FIN_BLOCK + tid; val[it] = g < n ? vals_in[g] : 0; }
     __syncthreads();
     bool too_long = false;
 #pragma unroll
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __res
                 pos = g - lc + rank;
             }
         }
-        keys_out[pos] = key; vals_out[pos] = vals_in[g];
+        keys_out[pos] = key; vals_out[pos] = val[it];
     }
     // completion: done[0] = "a run was too long", done[32] = groups finished, done[32 (2 + i)] = workgroups of group i (= blockIdx & 15)
     // finished -- two levels on separate 128-byte lines, so that no line sees more than gridDim / 16 (+ 16) atomics
