@@ -207,8 +207,8 @@ constexpr int SORT_RUN_MAX = 48;                    // elements of a run to eith
 #ifndef GPF_FIN_BLOCK
 #define GPF_FIN_BLOCK 1024
 #endif
-// (1024 x 4: with 512- / 256-thread workgroups the pass took 16.8 / 22.1 us against 14.8 -- the completion count below is one
-// same-address atomic per workgroup, ~20 ns each; profiles/r03_sort_experiments.txt)
+// (with the completion counters of the first build on ONE 128-byte line, 512- / 256-thread workgroups took 16.8 / 22.1 us against 14.8:
+// atomics to the same LINE serialise at ~10 ns each; on separate lines every shape takes 14.0-14.3 us, profiles/r03_sort_experiments.txt)
 constexpr int FIN_BLOCK = GPF_FIN_BLOCK, FIN_TILE = 4 * FIN_BLOCK, FIN_HALO = SORT_RUN_MAX + 1;
 __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                            uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
