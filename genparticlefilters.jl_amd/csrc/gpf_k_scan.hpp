@@ -186,7 +186,7 @@ __device__ __forceinline__ int key_quant_shift(uint32_t klo, uint32_t khi)
 // lane l holds elements 2l, 2l+1 of each row, so every global access is 16 B per lane, contiguous
 // across the wave (1 KiB per wave-instruction), for the loads AND the CDF stores.
 struct ScanExtras {            // optional side jobs of a scan launch
-    int64_t* zero128;          // clear 2 * MAX_SHARDS exchange counters (sharded resample), or nullptr
+    int64_t* zero128;          // clear the 2 * MAX_SHARDS exchange counters (sharded resample; zero_stride words apart), or nullptr
     int64_t* host_flags;       // pinned host {flags, ticket}: publish the validity flags of the weights, or nullptr
     int64_t ticket;
     int64_t n_slots;           // > 0: also write ws_out->{sB, srem, sinv}, the strata of the total over n_slots slots
@@ -194,6 +194,7 @@ struct ScanExtras {            // optional side jobs of a scan launch
     // workgroup that ends up with the shard total S pushes {S, 0, 0, 0, 0} to every peer (MODE 4: k_export_q pushes S with the limbs)
     MboxWait wait;
     MboxPush push;
+    int zero_stride;
 };
 // Workgroup of the scan kernels: SCAN_BLOCK threads over one 2048-element tile, every wave SCAN_ROWS rows of 128.  256 threads x 4
 // rows is the measured optimum: 512 x 2 (twice the waves per CU against the kernel's three dependent round trips) ran 1.3-1.5 us
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
 {
     // (ex.n_slots: the thread that ends up with the total also leaves the stratum width of S over n_slots output slots)
     // sharded resamples: the exchange counters of the push pass that follows are cleared here (no memset node)
-    if (ex.zero128 && blockIdx.x == 0 && threadIdx.x < 2 * MAX_SHARDS) ex.zero128[threadIdx.x] = 0;
+    if (ex.zero128 && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 2 * MAX_SHARDS * ex.zero_stride; i += SCAN_BLOCK) ex.zero128[i] = 0;
     __shared__ double sm[SCAN_NWAVES];
     __shared__ int sf[SCAN_NWAVES];
     __shared__ uint64_t s_wave[SCAN_NWAVES];

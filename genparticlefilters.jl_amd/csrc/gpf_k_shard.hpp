@@ -82,6 +82,12 @@ __global__ void k_export_residual(const Scalars* sc, int64_t* out2, MboxPush pus
 // atomic per chunk; the order of chunks inside a list is arbitrary, every entry names its slot); it also counts what
 // this shard will receive from whom.  Pass 2 looks the staged hits up (same core as k_search) and packs the rows.
 constexpr int PUSH_CHUNK = 2048;                  // output slots per chunk
+// the 2G exchange counters sit on separate 128-byte lines: every chunk does one returning atomic add on its destination's counter, and
+// atomics to the same cache LINE serialise (~7-10 ns each: with G = 8 and all 16 counters on one line, ~4000 of them per launch)
+#ifndef GPF_COUNT_STRIDE
+#define GPF_COUNT_STRIDE 16
+#endif
+constexpr int COUNT_STRIDE = GPF_COUNT_STRIDE;     // int64 words between counters
 struct PushArgs {
     uint64_t seed; uint32_t epoch;
     int64_t n_global;
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
                 if (r1 > r0) recv_cnt += (unsigned)(r1 - r0);
             }
             if (total) {                                                              // block-uniform
-                if (threadIdx.x == 0) s_base = atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + g), (unsigned long long)total);
+                if (threadIdx.x == 0) s_base = atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + g * COUNT_STRIDE), (unsigned long long)total);
                 __syncthreads();
                 ulonglong2* dst = a.stage + t.bounds[g] + s_base;
                 for (unsigned k = threadIdx.x; k < total; k += PUSH_SCAN_BLOCK)
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
 #pragma unroll
         for (int w = 0; w < NW; ++w) { const unsigned v = s_wtot[w]; before += w < wv ? v : 0; total += v; }
         if (threadIdx.x == 0 && total)
-            s_base = atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + g), (unsigned long long)total);
+            s_base = atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + g * COUNT_STRIDE), (unsigned long long)total);
         __syncthreads();
         if (cnt) {
             ulonglong2* dst = a.stage + t.bounds[g] + s_base + before + (incl - cnt);
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
     if (recv_cnt) atomicAdd(&s_recv[lane], recv_cnt);
     __syncthreads();
     if (threadIdx.x < a.G && s_recv[threadIdx.x])
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + a.G + threadIdx.x), (unsigned long long)s_recv[threadIdx.x]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + (a.G + threadIdx.x) * COUNT_STRIDE), (unsigned long long)s_recv[threadIdx.x]);
 }
 // pass 2: every staged hit is looked up in this shard's CDF (same core as k_search) and pushed with its row:
 // packed_out[e] = [row (W doubles) | (slot inside its shard) << 32 | global ancestor id], grouped by destination shard
@@ -291,13 +297,13 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
     ulonglong2* const lds_wave = s_coop + wave_id() * (2 * WAVE);
     if (threadIdx.x == 0) {
         int64_t o = 0;
-        for (int g = 0; g < a.G; ++g) { s_off[g] = o; o += a.counts[g]; s_bnd[g] = a.bounds[g]; }
+        for (int g = 0; g < a.G; ++g) { s_off[g] = o; o += a.counts[g * COUNT_STRIDE]; s_bnd[g] = a.bounds[g]; }
         s_off[a.G] = o;
         // the host needs the counts for the all-to-all split sizes: publish them to pinned host memory NOW, so the host
         // reads them while this kernel is still looking ancestors up (system-scope stores, ticket last)
         if (blockIdx.x == 0 && a.host_counts) {
             for (int g = 0; g < 2 * a.G; ++g)
-                __hip_atomic_store(a.host_counts + g, a.counts[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.host_counts + g, a.counts[g * COUNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
         const int64_t s0 = F[a.me] > a.bounds[h] ? F[a.me] : a.bounds[h], s1 = F[a.me + 1] < a.bounds[h + 1] ? F[a.me + 1] : a.bounds[h + 1];
         const int64_t r0 = F[h] > a.bounds[a.me] ? F[h] : a.bounds[a.me], r1 = F[h + 1] < a.bounds[a.me + 1] ? F[h + 1] : a.bounds[a.me + 1];
         const int64_t ns = s1 > s0 ? s1 - s0 : 0, nr = r1 > r0 ? r1 - r0 : 0;
-        a.counts[h] = ns; a.counts[a.G + h] = nr;
+        a.counts[h * COUNT_STRIDE] = ns; a.counts[(a.G + h) * COUNT_STRIDE] = nr;
         if (a.host_counts) {
             __hip_atomic_store(a.host_counts + h, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(a.host_counts + a.G + h, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -407,11 +413,11 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels 
     __shared__ int64_t s_bnd[MAX_SHARDS + 1];
     if (threadIdx.x == 0) {
         int64_t o = 0;
-        for (int g = 0; g < a.G; ++g) { s_off[g] = o; o += a.counts[g]; s_bnd[g] = a.bounds[g]; }
+        for (int g = 0; g < a.G; ++g) { s_off[g] = o; o += a.counts[g * COUNT_STRIDE]; s_bnd[g] = a.bounds[g]; }
         s_off[a.G] = o;
         if (blockIdx.x == 0 && a.host_counts) {   // (as in k_push: the host reads the counts while the look-ups run)
             for (int g = 0; g < 2 * a.G; ++g)
-                __hip_atomic_store(a.host_counts + g, a.counts[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.host_counts + g, a.counts[g * COUNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }

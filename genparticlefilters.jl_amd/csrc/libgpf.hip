@@ -1984,7 +1984,8 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     if (s) return s;
     if (!mf_all || !out5 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     if (!h->shard_counts) {
-        HIP_TRY(h, hipMalloc(&h->shard_counts, (size_t)2 * MAX_SHARDS * sizeof(int64_t)));
+        HIP_TRY(h, hipMalloc(&h->shard_counts, (size_t)2 * MAX_SHARDS * COUNT_STRIDE * sizeof(int64_t)));
+        HIP_TRY(h, hipMemsetAsync(h->shard_counts, 0, (size_t)2 * MAX_SHARDS * COUNT_STRIDE * sizeof(int64_t), h->stream));
         HIP_TRY(h, hipHostMalloc(&h->h_shard_counts, (size_t)(2 * MAX_SHARDS + 1) * sizeof(int64_t)));
         h->h_shard_counts[2 * MAX_SHARDS] = 0;
     }
@@ -2000,6 +2001,7 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     // shard mailboxes: the scan waits for the ranks' (max, flags) entries itself and the kernel that ends up with the shard's
     // {S, limbs} stores them into every peer's mailbox (the scan's last workgroup, or k_export_q when the limbs are wanted)
     ScanExtras ex{h->shard_counts, h->h_flags, h->flag_ticket, 0};
+    ex.zero_stride = COUNT_STRIDE;
     ex.wait = mb_wait(h, MB_MF);
     const MboxPush tot_push = mb_begin(h, MB_TOT);
     if (want_q) {
@@ -2113,7 +2115,8 @@ gpf_status gpf_shard_counts(gpf_handle h, int32_t G, int64_t* host_counts)
         // k_push publishes the counts to pinned host memory when it STARTS: poll the ticket (the kernel keeps running)
         if ((s = wait_ticket(h, h->h_shard_counts + 2 * MAX_SHARDS, h->push_ticket, "push counts"))) return s;
     } else {
-        HIP_TRY(h, hipMemcpyAsync(h->h_shard_counts, h->shard_counts, (size_t)2 * MAX_SHARDS * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        for (int k = 0; k < 2 * G; ++k)                          // (the counters sit COUNT_STRIDE words apart on the device, densely in the mirror)
+            HIP_TRY(h, hipMemcpyAsync(h->h_shard_counts + k, h->shard_counts + (size_t)k * COUNT_STRIDE, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     for (int g = 0; g < G; ++g) { host_counts[g] = h->h_shard_counts[g]; host_counts[G + g] = h->h_shard_counts[G + g]; }
