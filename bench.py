@@ -318,57 +318,54 @@ def main():
             gather[meth] = {"avg_launch_us": round(us, 2), "achieved": round(gbytes / us / 1e3, 1), "unit": "GB/s",
                             "frac": round(gbytes / us / 1e3 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": gbytes}
 
-    # ---- sharded runs: the same filter with STRATIFIED resampling (BASELINE.json configs[2]: monotone targets, almost no
-    #      row leaves its shard), reported beside the headline multinomial workload, same timing protocol
-    strat = None
-    if sharded_mode:
-        ks = min(K, 200)
-
-        def step_s(tq):
-            sharded.pf_resample(state, "stratified", check=False)
-            sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % (n_obs - 1)])
+    # ---- sharded runs: variants of the same filter reported beside the headline workload, same timing protocol
+    def variant(step_fn, k):
+        """k steps of step_fn after 5 untimed ones, barriers on both sides, MAX over ranks -> seconds"""
         for i in range(5):
-            step_s(i)
+            step_fn(i)
         gc.collect(); gc.disable()
         barrier()
-        s0 = time.perf_counter()
-        for i in range(ks):
-            step_s(i)
+        v0 = time.perf_counter()
+        for i in range(k):
+            step_fn(i)
         barrier()
-        se = time.perf_counter() - s0
+        ve = time.perf_counter() - v0
         gc.enable()
         if dist is not None:
-            tt = torch.tensor([se], dtype=torch.float64, device="cpu" if one_device else "cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            se = float(tt.item())
-        strat = {"workload": "same filter, stratified resample every step, sort_particles=false (BASELINE.json configs[2])",
-                 "value": round(n_global * ks / se, 1), "unit": "particle-steps/sec", "steps": ks, "ms_per_step": round(se / ks * 1e3, 5)}
+            tv = torch.tensor([ve], dtype=torch.float64, device="cpu" if one_device else "cuda")
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+            ve = float(tv.item())
+        return ve
 
-    # ---- ... and the communication-free "island" mode (every shard resamples locally with the reference's sub-state
-    #      semantics): a different estimator, reported for comparison only
-    island = None
+    def variant_line(workload, k, seconds):
+        return {"workload": workload, "value": round(n_global * k / seconds, 1), "unit": "particle-steps/sec", "steps": k,
+                "ms_per_step": round(seconds / k * 1e3, 5)}
+
+    strat = island = plans = None
     if sharded_mode:
-        ki = min(K, 200)
+        kv = min(K, 200)
 
-        def step_i(tq):
-            sharded.pf_resample(state, "multinomial", check=False, local=True)
-            sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % (n_obs - 1)])
-        for i in range(5):
-            step_i(i)
-        gc.collect(); gc.disable()
-        barrier()
-        i0 = time.perf_counter()
-        for i in range(ki):
-            step_i(i)
-        barrier()
-        ie = time.perf_counter() - i0
-        gc.enable()
-        if dist is not None:
-            tt = torch.tensor([ie], dtype=torch.float64, device="cpu" if one_device else "cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ie = float(tt.item())
-        island = {"workload": "same filter, every shard resamples its own particles (multinomial, sub-state semantics), no exchange",
-                  "value": round(n_global * ki / ie, 1), "unit": "particle-steps/sec", "steps": ki, "ms_per_step": round(ie / ki * 1e3, 5)}
+        def step_of(method, **kw):
+            def f(tq):
+                sharded.pf_resample(state, method, check=False, **kw)
+                sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % (n_obs - 1)])
+            return f
+        # STRATIFIED resampling (BASELINE.json configs[2]: monotone targets, almost no row leaves its shard)
+        strat = variant_line("same filter, stratified resample every step, sort_particles=false (BASELINE.json configs[2])",
+                             kv, variant(step_of("stratified"), kv))
+        # the communication-free "island" mode (every shard resamples locally with the reference's sub-state semantics,
+        # SURVEY.md 8e): a different estimator, reported for comparison only
+        island = variant_line("same filter, every shard resamples its own particles (multinomial, sub-state semantics), no exchange",
+                              kv, variant(step_of("multinomial", local=True), kv))
+        # the two exchange plans of the i.i.d. resamplers (gpf.h gpf_comm_set_plan; DESIGN.md 6.5): the headline ran the plan
+        # named in "timed"; with >= 100 steps both are timed so that a multi-GPU run can decide between them
+        if getattr(state.backend, "lib_comm", False) and K >= 100:
+            timed_plan = state.backend.plan()
+            plans = {"timed": timed_plan}
+            for pl in ("push", "pull"):
+                state.backend.set_plan(pl)
+                plans[pl] = variant_line(f"headline workload, exchange plan {pl}", kv, variant(step_of("multinomial"), kv))
+            state.backend.set_plan(timed_plan)
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 / N=1 only ----
     cpu = cpu_all = None
@@ -425,7 +422,7 @@ def main():
             "rccl_ranks": rccl_ranks,
             "shard_summaries": (state.backend.summary_mode() if sharded_mode and hasattr(state.backend, "summary_mode") else None),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
-            "stratified_variant": strat, "local_resample_variant": island,
+            "stratified_variant": strat, "local_resample_variant": island, "exchange_plans": plans,
         }
     else:
         out = None

@@ -282,6 +282,94 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
     if (threadIdx.x < a.G && s_recv[threadIdx.x])
         atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + (a.G + threadIdx.x) * COUNT_STRIDE), (unsigned long long)s_recv[threadIdx.x]);
 }
+// ---- the PULL plan of the i.i.d. resamplers (gpf_comm_set_plan / GPF_SHARD_PLAN=pull).  Every shard evaluates only
+// its OWN slots -- n targets instead of the push plan's n_global -- and asks for them: request {T_local | space << 62, slot inside the
+// requester} (the entry format of the push stage) goes to the shard whose range of the sampled space holds the target, grouped by
+// owner.  The owners receive the requests straight into their staging lists and run pass 2 (k_push / k_push_multi) unchanged.  The
+// price is a second exchange (requests out, rows back) and a host wait before it; which plan wins depends on G and on the links.
+// req: [G][req_stride] request lists, req_counts: G counters COUNT_STRIDE words apart (cleared by the caller)
+template <int METHOD>
+__global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_pull_scan(PushArgs a, ulonglong2* __restrict__ req, int64_t req_stride, int64_t* __restrict__ req_counts)
+{
+    constexpr int R = PUSH_CHUNK / PUSH_SCAN_BLOCK, NW = PUSH_SCAN_BLOCK / WAVE;
+    __shared__ PushTables t;
+    __shared__ unsigned int s_wcnt[NW][MAX_SHARDS];                                   // per wave and owner: count, then exclusive prefix over waves
+    __shared__ unsigned long long s_base[MAX_SHARDS];
+    push_tables(a, t);
+    const PushScal sc = push_scalars<METHOD>(a, t);
+    const int lane = lane_id(), wv = (int)threadIdx.x / WAVE;
+    const uint64_t lt = lane ? (~0ull >> (WAVE - lane)) : 0ull;                       // lanes below this one
+    const int64_t lo = t.bounds[a.me], hi = t.bounds[a.me + 1];
+    const int64_t nch = (hi - lo + PUSH_CHUNK - 1) / PUSH_CHUNK;
+    for (int64_t c = blockIdx.x; c < nch; c += gridDim.x) {
+        const int64_t j0 = lo + c * PUSH_CHUNK, j1 = j0 + PUSH_CHUNK < hi ? j0 + PUSH_CHUNK : hi;
+        uint64_t U[R];                                                                // (the slot uniforms: as in k_push_scan)
+        {
+            const uint32_t s0 = (uint32_t)(j0 + (int64_t)threadIdx.x * R), sb = s0 >> 1;
+            if (!(s0 & 1u)) {
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) {
+                    const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
+                    U[2 * q] = u64(b.w0, b.w1); U[2 * q + 1] = u64(b.w2, b.w3);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q <= R / 2; ++q) {
+                    const Philox b = rng(a.seed, sb + (uint32_t)q, 0, a.epoch, TAG_RESAMPLE);
+                    if (q > 0) U[2 * q - 1] = u64(b.w0, b.w1);
+                    if (q < R / 2) U[2 * q] = u64(b.w2, b.w3);
+                }
+            }
+        }
+        uint64_t Tl[R]; int own[R]; unsigned rank[R];
+        unsigned wcnt = 0;                                                            // lane q: this wave's requests to shard q so far
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t j = j0 + (int64_t)threadIdx.x * R + r;
+            own[r] = -1; Tl[r] = 0; rank[r] = 0;
+            if (j < j1) {
+                uint64_t T = 0; int space = 0;
+                push_target<METHOD>(a, sc, (uint64_t)j, U[r], T, space);
+                own[r] = push_owner(t, a.G, space, T, Tl[r]);
+                Tl[r] |= (uint64_t)space << 62;
+            }
+            for (int q = 0; q < a.G; ++q) {
+                const uint64_t m = __ballot(own[r] == q);
+                const unsigned prev = (unsigned)__shfl((int)wcnt, q, WAVE);
+                if (own[r] == q) rank[r] = prev + (unsigned)__popcll(m & lt);
+                if (lane == q) wcnt += (unsigned)__popcll(m);
+            }
+        }
+        if (lane < a.G) s_wcnt[wv][lane] = wcnt;
+        __syncthreads();
+        if ((int)threadIdx.x < a.G) {                                                 // one returning atomic per chunk and owner
+            unsigned run = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const unsigned v = s_wcnt[w][threadIdx.x]; s_wcnt[w][threadIdx.x] = run; run += v; }
+            s_base[threadIdx.x] = run ? atomicAdd(reinterpret_cast<unsigned long long*>(req_counts + threadIdx.x * COUNT_STRIDE), (unsigned long long)run) : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (own[r] >= 0)
+                req[(int64_t)own[r] * req_stride + (int64_t)s_base[own[r]] + s_wcnt[wv][own[r]] + rank[r]] =
+                    make_ulonglong2(Tl[r], (uint64_t)(j0 + (int64_t)threadIdx.x * R + r - lo));
+        __syncthreads();                                                              // s_wcnt / s_base
+    }
+}
+// the request counters, densely: out[q] = requests of this shard to shard q
+__global__ void k_pull_counts(const int64_t* __restrict__ req_counts, int G, int64_t* __restrict__ out)
+{
+    if ((int)threadIdx.x < G) out[threadIdx.x] = req_counts[threadIdx.x * COUNT_STRIDE];
+}
+// after the gathered request matrix M[requester][owner] is known: the exchange counters pass 2 and the row exchange work from --
+// entries this shard serves to g = what g asked of it, entries it receives from g = what it asked of g
+__global__ void k_pull_set_counts(const int64_t* __restrict__ M, int G, int me, int64_t* __restrict__ counts)
+{
+    const int g = (int)threadIdx.x;
+    if (g < G) { counts[g * COUNT_STRIDE] = M[g * G + me]; counts[(G + g) * COUNT_STRIDE] = M[me * G + g]; }
+}
+
 // pass 2: every staged hit is looked up in this shard's CDF (same core as k_search) and pushed with its row:
 // packed_out[e] = [row (W doubles) | (slot inside its shard) << 32 | global ancestor id], grouped by destination shard
 template <int METHOD, int W>

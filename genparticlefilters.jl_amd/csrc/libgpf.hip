@@ -138,6 +138,10 @@ struct gpf_filter {
     int scan_blocks_per_cu = 2;          // resident scan workgroups per CU the launch may rely on (occupancy query)
     int64_t* shard_counts = nullptr;     // [2 * MAX_SHARDS] exchange counters of the current resample (device) + pinned mirror
     int64_t* h_shard_counts = nullptr;
+    // the pull plan (gpf_comm_set_plan): request lists [G][n], their counters, the dense / gathered request matrix and its pinned mirror
+    int shard_plan_kind = 0;
+    ulonglong2* pull_req = nullptr; int64_t pull_req_cap = 0;
+    int64_t* pull_counts = nullptr; int64_t* pull_pc = nullptr; int64_t* pull_pc_all = nullptr; int64_t* h_pull_pc_all = nullptr;
     int64_t* h_flags = nullptr;          // pinned {validity flags, ticket} published by the weight scan of a checked resample
     int64_t flag_ticket = 0;
     int64_t push_ticket = 0;             // bumped by every gpf_shard_push launch; k_push publishes it with the counts
@@ -1098,11 +1102,13 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers (or of the compact copies below)
     for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc}) if (q) (void)hipFree(q);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf, h->acc_part};
+    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf, h->acc_part,
+                    h->pull_req, h->pull_counts, h->pull_pc, h->pull_pc_all};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
+    if (h->h_pull_pc_all) hipHostFree(h->h_pull_pc_all);
     if (h->h_flags) hipHostFree(h->h_flags);
     if (h->h_sort_flag) hipHostFree(h->h_sort_flag);
     if (h->h_timeout) hipHostFree(h->h_timeout);
@@ -2420,6 +2426,22 @@ gpf_status gpf_comm_summary_mode(gpf_handle h, int32_t* mailbox)
     return GPF_OK;
 }
 
+gpf_status gpf_comm_set_plan(gpf_handle h, int32_t plan)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (plan != GPF_SHARD_PLAN_PUSH && plan != GPF_SHARD_PLAN_PULL) return fail(h, GPF_ERR_INVALID_ARGUMENT, "exchange plan: GPF_SHARD_PLAN_PUSH or GPF_SHARD_PLAN_PULL");
+    if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_comm_set_plan needs gpf_comm_create first");
+    h->shard_plan_kind = plan;
+    return GPF_OK;
+}
+gpf_status gpf_comm_plan(gpf_handle h, int32_t* plan)
+{
+    if (!h || !plan) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_comm_plan needs gpf_comm_create first");
+    *plan = h->shard_plan_kind;
+    return GPF_OK;
+}
+
 gpf_status gpf_comm_unique_id(void* id128)
 {
     if (!id128) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null id");
@@ -2450,6 +2472,11 @@ gpf_status gpf_comm_create(gpf_handle h, const void* id128, int32_t rank, int32_
     }
     gpf_status s = shard_scratch(h);
     if (s) return s;
+    h->shard_plan_kind = GPF_SHARD_PLAN_PUSH;
+    if (const char* e = getenv("GPF_SHARD_PLAN")) {
+        if (!strcmp(e, "pull")) h->shard_plan_kind = GPF_SHARD_PLAN_PULL;
+        else if (strcmp(e, "push")) return fail(h, GPF_ERR_INVALID_ARGUMENT, "GPF_SHARD_PLAN: push or pull");
+    }
     return mailbox_setup(h);
 }
 
@@ -2473,6 +2500,77 @@ gpf_status gpf_comm_destroy(gpf_handle h)
     h->sh_mf = h->sh_mf_all = nullptr; h->sh_tot = h->sh_tot_all = h->sh_cr = h->sh_cr_all = nullptr;
     h->sh_send = h->sh_recv = nullptr; h->sh_send_cap = h->sh_recv_cap = 0;
     return ms;
+}
+
+// Phase 3 of the PULL plan (gpf_k_shard.hpp, k_pull_scan): this shard's requests grouped by owner, the request matrix gathered on
+// every rank (one all-gather of G counts + the host wait the split sizes need), the requests exchanged straight into the owners'
+// staging lists, the exchange counters set from the matrix.  Leaves the handle where gpf_shard_push_count leaves it; counts[0..G) =
+// entries to serve per shard, counts[G..2G) = entries to receive.  Buffers are allocated by pull_buffers before any collective.
+static gpf_status pull_buffers(gpf_filter* h, int G)
+{
+    if (!h->pull_counts) {
+        HIP_TRY(h, hipMalloc(&h->pull_counts, (size_t)MAX_SHARDS * COUNT_STRIDE * sizeof(int64_t)));
+        HIP_TRY(h, hipMalloc(&h->pull_pc, (size_t)MAX_SHARDS * sizeof(int64_t)));
+        HIP_TRY(h, hipMalloc(&h->pull_pc_all, (size_t)MAX_SHARDS * MAX_SHARDS * sizeof(int64_t)));
+        HIP_TRY(h, hipHostMalloc(&h->h_pull_pc_all, (size_t)MAX_SHARDS * MAX_SHARDS * sizeof(int64_t)));
+    }
+    const int64_t want = (int64_t)G * std::max<int64_t>(h->n, 1);
+    if (h->pull_req_cap < want) {
+        if (h->pull_req) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->pull_req); h->pull_req = nullptr; h->pull_req_cap = 0; }
+        HIP_TRY(h, hipMalloc(&h->pull_req, (size_t)want * sizeof(ulonglong2)));
+        h->pull_req_cap = want;
+    }
+    return GPF_OK;
+}
+static gpf_status pull_requests(gpf_filter* h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int G, int me, const int64_t* bounds,
+                                bool exchange, bool force_self, std::vector<int64_t>& counts)
+{
+    PushArgs a;
+    gpf_status s = push_args(h, method, tot_all, cr_all, G, me, bounds, a);
+    if (s) return s;
+    const int64_t n = h->n;
+    HIP_TRY(h, hipMemsetAsync(h->pull_counts, 0, (size_t)MAX_SHARDS * COUNT_STRIDE * sizeof(int64_t), h->stream));
+    const int64_t nch = (n + PUSH_CHUNK - 1) / PUSH_CHUNK;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(nch, (int64_t)h->n_cu * PUSH_SCAN_BLOCKS_PER_CU));
+    s = timed(h, GPF_K_SEARCH, [&] {
+        if (method == GPF_RESAMPLE_MULTINOMIAL) GPF_LAUNCH((k_pull_scan<0>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a, h->pull_req, n, h->pull_counts);
+        else                                    GPF_LAUNCH((k_pull_scan<1>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a, h->pull_req, n, h->pull_counts);
+    });
+    if (s) return s;
+    GPF_LAUNCH(k_pull_counts, dim3(1), dim3(WAVE), 0, h->stream, h->pull_counts, G, h->pull_pc);
+    HIP_TRY(h, hipGetLastError());
+    if ((s = shard_all_gather(h, h->pull_pc, h->pull_pc_all, (size_t)G, ncclInt64, sizeof(int64_t)))) return s;
+    HIP_TRY(h, hipMemcpyAsync(h->h_pull_pc_all, h->pull_pc_all, (size_t)G * G * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));                  // the host wait of this plan: the split sizes of BOTH exchanges
+    const int64_t* M = h->h_pull_pc_all;                          // M[requester][owner]
+    int64_t asked = 0;
+    for (int g = 0; g < G; ++g) { counts[g] = M[(size_t)g * G + me]; counts[G + g] = M[(size_t)me * G + g]; asked += counts[G + g]; }
+    // (as in the push plan: from the first exchange on, a local failure is remembered and the rank still joins the exchanges)
+    gpf_status late = GPF_OK; std::string late_msg;
+    auto remember = [&](gpf_status st) { if (st && !late) { late = st; late_msg = h->err; } };
+    if (asked != n) remember(fail(h, GPF_ERR_STATE, "request counts do not add up to the shard's slots"));
+    ncclResult_t first = ncclSuccess; const char* where = "";
+    auto note = [&](ncclResult_t r, const char* w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; where = w; } };
+    if (exchange) note(g_rccl.GroupStart(), "ncclGroupStart");
+    for (int g = 0; g < G; ++g) {
+        ulonglong2* from = h->pull_req + (size_t)g * n;
+        ulonglong2* to = h->push_stage + bounds[g];
+        if (g == me && !force_self) continue;
+        if (counts[G + g]) note(g_rccl.Send(from, (size_t)counts[G + g] * 2, ncclUint64, g, h->comm, h->stream), "ncclSend");
+        if (counts[g] && counts[g] <= bounds[g + 1] - bounds[g]) note(g_rccl.Recv(to, (size_t)counts[g] * 2, ncclUint64, g, h->comm, h->stream), "ncclRecv");
+    }
+    if (exchange) note(g_rccl.GroupEnd(), "ncclGroupEnd");
+    if (first != ncclSuccess) remember(fail(h, GPF_ERR_HIP, std::string(where) + ": " + g_rccl.GetErrorString(first)));
+    if (!force_self && counts[me]) {                              // the shard's own requests never touch RCCL
+        const hipError_t ce = hipMemcpyAsync(h->push_stage + bounds[me], h->pull_req + (size_t)me * n, (size_t)counts[me] * sizeof(ulonglong2), hipMemcpyDeviceToDevice, h->stream);
+        if (ce != hipSuccess) remember(fail(h, GPF_ERR_HIP, std::string("self copy: ") + hipGetErrorString(ce)));
+    }
+    GPF_LAUNCH(k_pull_set_counts, dim3(1), dim3(WAVE), 0, h->stream, h->pull_pc_all, G, me, h->shard_counts);
+    if (hipGetLastError() != hipSuccess) remember(fail(h, GPF_ERR_HIP, "k_pull_set_counts launch"));
+    if (late) { h->err = late_msg; return late; }
+    h->counts_published = false;
+    h->push_counted = true;
+    return GPF_OK;
 }
 
 static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double priority_alpha, int32_t check, int32_t* invalid)
@@ -2519,6 +2617,8 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     static const bool force = getenv("GPF_SHARD_FORCE_COLLECTIVES") && !strcmp(getenv("GPF_SHARD_FORCE_COLLECTIVES"), "1");
     const bool exchange = G > 1 || (force && h->comm);            // one shard: what it "sends" is what it "receives"
     if (exchange && (s = ensure(h->sh_recv, h->sh_recv_cap, n))) return s;
+    const bool pull = h->shard_plan_kind == GPF_SHARD_PLAN_PULL && method != GPF_RESAMPLE_STRATIFIED;
+    if (pull && (s = pull_buffers(h, G))) return s;
 
     const double* raw_mf = nullptr; const int64_t* raw_tot = nullptr;
     struct PushScope { gpf_filter* h; ~PushScope() { h->push_extra = 0; } } push_scope{h};
@@ -2550,15 +2650,23 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         if (!h->mb_active && (s = shard_all_gather(h, h->sh_cr, h->sh_cr_all, 2, ncclInt64, sizeof(int64_t)))) return s;
         cr_all = h->cur_cr_all = h->mb_active ? static_cast<const int64_t*>(mb_gathered(h, MB_CR)) : h->sh_cr_all;
     }
-    if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
-    // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
-    // counts say it overflowed
-    const int64_t pushed_cap = std::min(cap, h->sh_send_cap);
-    if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
     std::vector<int64_t> counts(2 * (size_t)G);
-    if ((s = gpf_shard_counts(h, G, counts.data()))) return s;   // ONE host wait (the exchange's split sizes), behind phase 4
+    int64_t pushed_cap = std::min(cap, h->sh_send_cap);
     int64_t n_send = 0, n_recv = 0;
-    for (int g = 0; g < G; ++g) { n_send += counts[g]; n_recv += counts[G + g]; }
+    if (pull) {
+        // phase 3 of the pull plan: requests out, counts known on the host BEFORE pass 2 is enqueued (no speculative capacity)
+        if ((s = pull_requests(h, method, tot_all, cr_all, G, me, bounds.data(), exchange, force && G == 1, counts))) return s;
+        for (int g = 0; g < G; ++g) { n_send += counts[g]; n_recv += counts[G + g]; }
+        pushed_cap = std::min(n_send, h->sh_send_cap);
+        if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
+    } else {
+        if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
+        // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
+        // counts say it overflowed
+        if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
+        if ((s = gpf_shard_counts(h, G, counts.data()))) return s;   // ONE host wait (the exchange's split sizes), behind phase 4
+        for (int g = 0; g < G; ++g) { n_send += counts[g]; n_recv += counts[G + g]; }
+    }
     // From here on a local failure is REMEMBERED and the rank still joins the exchange with the counts its peers expect (they
     // worked out their receive counts themselves and will wait for exactly that many entries): the error is returned after the
     // group has closed.  A failed gpf_shard_resample leaves the communicator and the filter unusable on every rank that sees

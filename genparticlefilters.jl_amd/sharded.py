@@ -173,6 +173,23 @@ class HipShardBackend:
         self._ck(self.L.gpf_comm_summary_mode(self.h, C.byref(mb)))
         return "mailbox" if mb.value else ("rccl" if self.comm_world() else "none")
 
+    def set_plan(self, plan: str) -> None:
+        """exchange plan of the i.i.d. resamplers in the library engine (gpf.h gpf_comm_set_plan): "push" (every shard evaluates all
+        n_global targets, one row exchange) or "pull" (own targets only, requests out and rows back); the same bits either way.
+        Every rank must choose the same plan."""
+        if not self.lib_comm:
+            raise ErrorException("the exchange plan is selectable in the library engine only (python engine: push)")
+        if plan not in ("push", "pull"):
+            raise ErrorException(f"exchange plan {plan!r}: push or pull")
+        self._ck(self.L.gpf_comm_set_plan(self.h, 1 if plan == "pull" else 0))
+
+    def plan(self) -> str:
+        if not self.lib_comm:
+            return "push"
+        p = C.c_int32(0)
+        self._ck(self.L.gpf_comm_plan(self.h, C.byref(p)))
+        return "pull" if p.value else "push"
+
     def comm_world(self) -> int:
         """ranks of the library's RCCL communicator (0: none)"""
         return getattr(self, "_rccl_world", 0)

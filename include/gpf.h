@@ -335,6 +335,17 @@ gpf_status gpf_comm_destroy(gpf_handle h);
  * launch, no host; 0: RCCL all-gathers (hipIpc mapping not possible on this system, or GPF_SHARD_SUMMARY=rccl in the environment).
  * Every rank of a communicator is in the same mode.  The row exchange itself is always grouped ncclSend / ncclRecv. */
 gpf_status gpf_comm_summary_mode(gpf_handle h, int32_t* mailbox);
+/* The exchange plan of the i.i.d. resamplers (multinomial, and residual's i.i.d. tail) across shards; both give the same bits
+ * (Random.rand(Categorical(weights), n), src/resample.jl:59,108 -- every slot's uniform is keyed by its GLOBAL slot id):
+ *   GPF_SHARD_PLAN_PUSH (default): every shard evaluates the targets of ALL n_global slots, looks up the ones that fall in its own range
+ *     and pushes [row | slot | ancestor] to the slot's shard -- one row exchange, no request message, O(n_global) ALU work per shard;
+ *   GPF_SHARD_PLAN_PULL: every shard evaluates only its own n slots and sends each target to its owner, the owners answer with the
+ *     rows -- O(n) work per shard, two exchanges and one more host wait.
+ * Stratified resampling plans its exchange in closed form and ignores the setting.  Every rank of a communicator must use the same
+ * plan.  gpf_comm_create takes the initial plan from the environment (GPF_SHARD_PLAN=push|pull). */
+typedef enum { GPF_SHARD_PLAN_PUSH = 0, GPF_SHARD_PLAN_PULL = 1 } gpf_shard_plan;
+gpf_status gpf_comm_set_plan(gpf_handle h, int32_t plan);
+gpf_status gpf_comm_plan(gpf_handle h, int32_t* plan);
 gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid);
 /* pf_resample!(state, method; priority_fn = w -> priority_alpha * w, check) on a sharded state (src/resample.jl:51-52,57,198-200; the
  * tempering family of test/resample.jl:15): ancestors from the CDF of the priorities over ALL shards, log_ml_est from the raw

@@ -322,6 +322,16 @@ function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multi
     check === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
     return s
 end
+"""exchange plan of the i.i.d. resamplers across shards: :push (default) or :pull (gpf.h gpf_comm_set_plan); the same on every rank"""
+function shard_plan!(s::ShardedDeviceParticleFilterState, plan::Symbol)
+    plan in (:push, :pull) || error("exchange plan :$plan: :push or :pull")
+    check(s, ccall((:gpf_comm_set_plan, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, plan == :pull ? 1 : 0)); s
+end
+function shard_plan(s::ShardedDeviceParticleFilterState)
+    p = Ref{Cint}(0)
+    check(s, ccall((:gpf_comm_plan, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cint}), s.handle, p))
+    p[] == 1 ? :pull : :push
+end
 effective_sample_size(s::ShardedDeviceParticleFilterState) = _scalar(s, :gpf_shard_effective_sample_size)
 get_ess(s::ShardedDeviceParticleFilterState) = effective_sample_size(s)
 log_ml_estimate(s::ShardedDeviceParticleFilterState) = _scalar(s, :gpf_shard_log_ml_estimate)

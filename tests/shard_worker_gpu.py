@@ -41,7 +41,7 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
             lml_log.append(sharded.get_lml_est(st))
         loc = st.local
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents,
-                 gid0=st.gid0, ess=np.array(ess_log), lml=np.array(lml_log), summaries=st.backend.summary_mode())
+                 gid0=st.gid0, ess=np.array(ess_log), lml=np.array(lml_log), summaries=st.backend.summary_mode(), plan=st.backend.plan())
     finally:
         dist.destroy_process_group()
 
@@ -174,6 +174,6 @@ def run_tempered(rank, world, port, method, n_global, T, out_dir):
             sharded.pf_update(st, (t + 1,), (None,), ys[t])
         loc = st.local
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents, n=st.n_local,
-                 scal=np.array(scal), lml=sharded.get_lml_est(st), summaries=st.backend.summary_mode())
+                 scal=np.array(scal), lml=sharded.get_lml_est(st), summaries=st.backend.summary_mode(), plan=st.backend.plan())
     finally:
         dist.destroy_process_group()

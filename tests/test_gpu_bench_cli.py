@@ -105,3 +105,26 @@ def test_plain_command_self_launches_two_ranks(built):
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["config"]["particles_total"] == 400000
     assert out["rccl_ranks"] == 0 and out["shard_engine"].startswith("python")      # gloo staging: no RCCL in this run, and the line says so
     assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_two_ranks_report_both_exchange_plans(built, tmp_path):
+    """with >= 100 steps a sharded library-engine run times the headline workload under BOTH exchange plans (gpf_comm_set_plan:
+    push / pull) and says which one the headline value used; two ranks on cuda:0 over the loopback transport"""
+    lib = tmp_path / "libloopback_rccl.so"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "loopback_rccl", "loopback_rccl.cpp"),
+                    "-o", str(lib)], check=True)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29739", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100", "--warmup", "2",
+           "--particles-per-gpu", "100000"]
+    ests = {}
+    for plan in ("push", "pull"):
+        env = dict(os.environ, GPF_BENCH_ONE_DEVICE="1", GPF_SHARD_ENGINE="library", GPF_RCCL_LIBRARY=str(lib), GPF_SHARD_PLAN=plan)
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out = _last_json(p.stdout)
+        assert out["shard_engine"].startswith("library") and "fell back" not in out["shard_engine"]
+        ep = out["exchange_plans"]
+        assert ep["timed"] == plan and ep["push"]["value"] > 0 and ep["pull"]["value"] > 0 and ep["push"]["steps"] == 100
+        ests[plan] = out["log_ml_estimate"]
+    assert ests["push"] == ests["pull"]                                       # the same filter, bit for bit

@@ -144,6 +144,71 @@ def test_library_engine_summary_transport(g, o, tmp_path, monkeypatch, loopback_
             assert str(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["summaries"]) == mode
 
 
+@pytest.mark.parametrize("summaries", ["mailbox", "rccl"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_library_engine_pull_plan(g, o, tmp_path, monkeypatch, loopback_lib, world, summaries):
+    """GPF_SHARD_PLAN=pull (gpf.h gpf_comm_set_plan): every shard evaluates its own slots only, requests go to the owners of the
+    targets, rows come back -- two exchanges with their own counts and offsets.  The same bits as the push plan and the oracle for
+    multinomial, residual (deterministic head + i.i.d. tail), stratified (closed-form plan, unaffected) and the ESS-triggered
+    bearings run with rejuvenation; also with a send buffer that is too small (the repeated pass 2)."""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
+    monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    monkeypatch.setenv("GPF_SHARD_PLAN", "pull")
+    if summaries == "rccl":
+        monkeypatch.setenv("GPF_SHARD_SUMMARY", "rccl")
+    for case in CASES[:4]:
+        test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
+        for r in range(world):
+            assert str(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["plan"]) == "pull"
+    monkeypatch.setenv("GPF_PUSH_CAPACITY", "1000")
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[0], world=world)
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[2], world=world)
+
+
+@pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
+@pytest.mark.parametrize("method", ["multinomial", "residual"])
+def test_pull_plan_skewed_weights(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern):
+    """every request to one shard (the others receive no request at all and serve nothing), pull plan"""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
+    monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    monkeypatch.setenv("GPF_SHARD_PLAN", "pull")
+    test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2]], ids=["multinomial", "residual"])
+def test_pull_plan_on_rccl_one_rank(g, o, tmp_path, monkeypatch, case):
+    """the pull plan's collectives on the REAL RCCL (1-rank communicator: the all-gather of the request counts, the request
+    send / receive to itself as ncclUint64)"""
+    monkeypatch.setenv("GPF_SHARD_PLAN", "pull")
+    test_rccl_collectives_one_rank(g, o, tmp_path, case, "library")
+    assert str(np.load(os.path.join(tmp_path, "rank0.npz"))["plan"]) == "pull"
+
+
+def test_plan_switch_between_resamples(g, o):
+    """gpf_comm_set_plan between resamples of one filter (world 1, no communicator): push and pull alternate, all three resamplers,
+    against the unsharded filter; the python engine refuses the setting"""
+    from gpf_amd import sharded
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 8); N = 50_001
+    a = sharded.pf_initialize(model, (1,), ys[0], N, seed=5)
+    b = g.pf_initialize(model, (1,), ys[0], N, seed=5)
+    if not a.backend.lib_comm:
+        with pytest.raises(g.ErrorException):
+            a.backend.set_plan("pull")
+        pytest.skip("python engine")
+    assert a.backend.plan() == "push"
+    with pytest.raises(g.ErrorException):
+        a.backend.set_plan("sideways")
+    for t in range(1, 8):
+        a.backend.set_plan("pull" if t % 2 else "push"); assert a.backend.plan() == ("pull" if t % 2 else "push")
+        method = ("multinomial", "residual", "stratified")[t % 3]
+        sharded.pf_resample(a, method, check=False)
+        g.pf_resample(b, method, check=False, **({"sort_particles": False} if method == "stratified" else {}))
+        assert np.array_equal(a.local.parents, b.parents), (t, method)
+        sharded.pf_update(a, (t + 1,), (None,), ys[t]); g.pf_update(b, (t + 1,), (None,), ys[t])
+        assert np.array_equal(a.local.traces, b.traces) and np.array_equal(a.local.log_weights, b.log_weights)
+    assert sharded.get_lml_est(a) == g.get_lml_est(b)
+
+
 @pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
 @pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
 def test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern):
@@ -193,7 +258,7 @@ def test_hip_sharded_validity_checks(g, o, tmp_path):
     assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
 
 
-@pytest.mark.parametrize("engine", ["library", "python"])
+@pytest.mark.parametrize("engine", ["library", "library-pull", "python"])
 @pytest.mark.parametrize("seed,world,n_global", [(s_, 2 + s_ % 2, [6000, 6001, 40_000, 2048, 1024, 9999][s_ % 6])
                                                  for s_ in range(int(os.environ.get("GPF_FUZZ_SHARD_SEEDS", "4")))])
 def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib, seed, world, n_global, engine):
@@ -201,8 +266,9 @@ def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib,
     weight vectors on a sharded filter (2 - 3 ranks on one GPU; library engine over the loopback transport / python engine over
     gloo) against ONE oracle filter: the global resample is the unsharded one bit for bit, the island resample is the sub-state
     resample of each shard's range"""
-    if engine == "library":
+    if engine.startswith("library"):
         monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+        monkeypatch.setenv("GPF_SHARD_PLAN", "pull" if engine == "library-pull" else "push")
     else:
         monkeypatch.setenv("GPF_SHARD_ENGINE", "python")
     T = 30
@@ -216,7 +282,7 @@ def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib,
         if op == "update":
             f.update(ys[t]); t += 1
         elif op == "resample":
-            f.resample(method, check=False, priority_alpha=0.5 if (engine == "library" and salt & 4) else None,
+            f.resample(method, check=False, priority_alpha=0.5 if (engine.startswith("library") and salt & 4) else None,
                        **({"sort_particles": False} if method == "stratified" else {}))
         elif op == "rejuvenate":
             f.rejuvenate("move", 1)
@@ -299,6 +365,15 @@ def test_sharded_tempered_resample(g, o, tmp_path, monkeypatch, loopback_lib, me
     assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
     for p in parts:
         assert np.array_equal(p["scal"], scal) and float(p["lml"]) == f.log_ml_estimate() and str(p["summaries"]) == mode
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("method", ["multinomial", "residual"])
+def test_sharded_tempered_resample_pull_plan(g, o, tmp_path, monkeypatch, loopback_lib, method, world):
+    """tempering through the pull plan: the answered entries carry log_ws like the pushed ones"""
+    monkeypatch.setenv("GPF_SHARD_PLAN", "pull")
+    test_sharded_tempered_resample(g, o, tmp_path, monkeypatch, loopback_lib, method, world, "mailbox")
+    assert all(str(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["plan"]) == "pull" for r in range(world))
 
 
 @pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
