@@ -8,7 +8,16 @@ constexpr int WAVE = 64;
 constexpr int NWAVES = BLOCK / WAVE;
 constexpr int SCAN_ITEMS = 8;
 constexpr int TILE = BLOCK * SCAN_ITEMS;          // 2048 weights per scan tile
-constexpr int MAX_PARTIALS = 2048;                // partial (max, flags) slots of the reduce kernels
+constexpr int MAX_PARTIALS = 2048;                // most workgroups of a kernel that leaves the maximum of the log-weights behind
+// maximum(vs) / any(isnan) of safe_softmax (utils.jl:119-128), left behind by the kernel that WRITES the log-weights: every workgroup
+// folds its block maximum into one of MAX_SLOTS slots with ONE fire-and-forget integer atomic max on an order-preserving key (and an
+// atomic or of its flags, only when it has any); the consumer reads the 32 slots with one load per lane and a wave reduction -- no
+// LDS, no barrier.  (Before: one partial per workgroup and a fold of <= 1024 of them in every workgroup of the scan, ~3.5 us of its
+// 13.5, profiles/r03_scan_phases.txt.)  A slot is a 128-byte line of its own: atomics to one line serialise (~8 ns each), ~32 per
+// line and launch stay invisible.  Two slot arrays alternate: a producer folds into one and clears the other for the next producer.
+constexpr int MAX_SLOTS = 32;
+constexpr int SLOT_WORDS = 16;                    // 8-byte words per slot: {key, flags, pad}
+struct MaxSlots { unsigned long long* cur; unsigned long long* clear; };
 constexpr int MAX_SHARDS = 64;                    // shards (GPUs) of one filter
 constexpr int LDS_TILE_TABLE = 8192;              // tile-prefix entries kept in LDS by the search kernel (64 KiB)
 
@@ -86,6 +95,30 @@ __device__ __forceinline__ double wave_max_f64(double v)
         v = o > v ? o : v;
     }
     return v;
+}
+// order-preserving key of a non-NaN double: larger value <=> larger key; key 0 is below every value ("no workgroup wrote")
+__device__ __forceinline__ unsigned long long max_key(double v)
+{
+    const uint64_t b = d2u(v);
+    return (b >> 63) ? ~b : (b | (1ull << 63));
+}
+__device__ __forceinline__ double max_unkey(unsigned long long k)
+{
+    if (k == 0) return -__builtin_huge_val();
+    return u2d((k >> 63) ? (k & ~(1ull << 63)) : ~k);
+}
+// every lane of the calling wave ends with (maximum, flags) of the slots; any number of waves may call it, no LDS, no barrier
+__device__ __forceinline__ void fold_slots(const unsigned long long* __restrict__ slots, double& m_out, int& f_out)
+{
+    static_assert(MAX_SLOTS <= WAVE, "one lane per slot");
+    const int l = (int)(threadIdx.x % WAVE);
+    const unsigned long long k = l < MAX_SLOTS ? slots[l * SLOT_WORDS] : 0ull;
+    int f = l < MAX_SLOTS ? (int)slots[l * SLOT_WORDS + 1] : 0;
+    const double m = wave_max_f64(max_unkey(k));
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
+    if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+    m_out = m; f_out = f;
 }
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
@@ -200,6 +233,20 @@ __device__ __forceinline__ double sort_key_value(uint64_t key)
 {
     const uint64_t asc = ~key;
     return u2d((asc >> 63) ? (asc & 0x7fffffffffffffffull) : ~asc);
+}
+// Coarse 24-bit sort key (K10c): the distance d = m - v >= 0 of a log-priority from the maximum m, as {5-bit binade | 19 mantissa
+// bits}: binades 2^-21 .. 2^9 (below: 0, above -- weights that underflow anyway, -inf, NaN --: all ones).  Weakly monotone in the full
+// key (v1 > v2 => d1 <= d2: the subtraction rounds monotonically), so three stable 8-bit passes over it leave the keys sorted up to
+// runs of equal coarse keys, which k_sort_finish orders by the full key.  Against the high 32 bits of the key itself (sign, 11 exponent
+// bits, 20 mantissa bits = four passes) the exponent field shrinks to the binades log-weights actually occupy below their maximum.
+constexpr int COARSE_E0 = 1023 - 21;
+__device__ __forceinline__ uint32_t sort_coarse(uint64_t key, double m)
+{
+    const uint64_t b = d2u(m - sort_key_value(key)) & 0x7fffffffffffffffull;
+    const int e = (int)(b >> 52) - COARSE_E0;
+    if (e < 0) return 0u;
+    if (e > 29) return 0xFFFFFFu;
+    return ((uint32_t)(e + 1) << 19) | (uint32_t)((b >> 33) & 0x7FFFFu);
 }
 
 } // namespace gpf

@@ -3,52 +3,15 @@
 
 namespace gpf {
 // ----------------------------------------------------------------------------- K3: max + flags
-// maximum(vs), any(isnan), all(== -Inf) of safe_softmax (utils.jl:119-128): per-block partials; the
-// consumers (k_scan, k_scalar) fold the <= MAX_PARTIALS partials themselves (no finalize launch).
-__global__ __launch_bounds__(BLOCK) void k_max_partial(PrioView pv, int64_t n, double* __restrict__ pmax,
-                                                       int32_t* __restrict__ pflags)
+// maximum(vs), any(isnan), all(== -Inf) of safe_softmax (utils.jl:119-128) of weights no kernel of ours produced (host-written
+// log-weights, priorities): folded into the maximum slots like the producers do (MaxSlots, gpf_k_common.hpp); the consumers
+// (k_scan, k_pack_mflags) read the slots themselves (no finalize launch).
+__global__ __launch_bounds__(BLOCK) void k_max_partial(PrioView pv, int64_t n, MaxSlots ms)
 {
     double m = -__builtin_huge_val();
     int f = 0;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-        const double v = pv.at(i);
-        if (v != v) f |= FLAG_NAN;
-        else { m = v > m ? v : m; if (v == __builtin_huge_val()) f |= FLAG_POSINF; }
-    }
-    m = wave_max_f64(m);
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
-    __shared__ double sm[NWAVES];
-    __shared__ int sf[NWAVES];
-    if (lane_id() == 0) { sm[wave_id()] = m; sf[wave_id()] = f; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < NWAVES; ++w) { m = sm[w] > m ? sm[w] : m; f |= sf[w]; }
-        pmax[blockIdx.x] = m;
-        pflags[blockIdx.x] = f;
-    }
-}
-
-// fold the partials: every lane of the block ends with (m, flags); needs 2 LDS arrays of NWAVES
-template <int NT = BLOCK>
-__device__ __forceinline__ void fold_partials(const double* __restrict__ pmax, const int32_t* __restrict__ pflags,
-                                              int np, double* sm, int* sf, double& m_out, int& f_out)
-{
-    constexpr int NWAVES = NT / WAVE;
-    double m = -__builtin_huge_val();
-    int f = 0;
-    for (int i = threadIdx.x; i < np; i += NT) { const double v = pmax[i]; m = v > m ? v : m; f |= pflags[i]; }
-    m = wave_max_f64(m);
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
-    if (lane_id() == 0) { sm[wave_id()] = m; sf[wave_id()] = f; }
-    __syncthreads();
-    m = sm[0]; f = sf[0];
-#pragma unroll
-    for (int w = 1; w < NWAVES; ++w) { m = sm[w] > m ? sm[w] : m; f |= sf[w]; }
-    if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
-    m_out = m; f_out = f;
-    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) track_max(pv.at(i), m, f);
+    block_max_store(m, f, ms);
 }
 
 // ----------------------------------------------------------------------------- K4: fixed-point scan
@@ -208,10 +171,10 @@ constexpr int SCAN_NWAVES = SCAN_BLOCK / WAVE;
 constexpr int SCAN_ROWS = TILE / (2 * SCAN_BLOCK);
 static_assert(SCAN_ROWS * 2 * SCAN_BLOCK == TILE && SCAN_ROWS >= 2 && SCAN_ROWS % 2 == 0, "a wave owns whole 256-element groups");
 // MODE 0: plain scan of In; 1: fixed-point weights (folds the max partials); 2: as 1, plus sum q^2 for the ESS;
-// 3 / 4: as 1 / 2 with the maximum and flags taken from the np gathered (max, flags) pairs of the shards (pmax = mf_all)
+// 3 / 4: as 1 / 2 with the maximum and flags taken from the np gathered (max, flags) pairs of the shards (mf_all) instead of the slots
 template <class In, int MODE>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t ntiles,
-                                                const double* __restrict__ pmax, const int32_t* __restrict__ pflags,
+                                                const double* __restrict__ mf_all, const unsigned long long* __restrict__ slots,
                                                 int np, WSum* __restrict__ ws_out, ScanOut out,
                                                 uint64_t* __restrict__ dcur, uint64_t* __restrict__ dnext,
                                                 uint64_t* __restrict__ total_out, uint64_t* __restrict__ blockQ,
@@ -221,8 +184,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
     // sharded resamples: the exchange counters of the push pass that follows are cleared here (no memset node)
     if (ex.zero128 && blockIdx.x == 0)
         for (int i = threadIdx.x; i < 2 * MAX_SHARDS * ex.zero_stride; i += SCAN_BLOCK) ex.zero128[i] = 0;
-    __shared__ double sm[SCAN_NWAVES];
-    __shared__ int sf[SCAN_NWAVES];
     __shared__ uint64_t s_wave[SCAN_NWAVES];
     __shared__ uint64_t s_red[SCAN_NWAVES];
     uint64_t* const d_agg = dcur;
@@ -239,24 +200,18 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
     if constexpr (MODE >= 1) {
         double m; int f;
         if constexpr (MODE >= 3) {
-            // the np <= 64 gathered (max, flags) pairs: one lane of the first wave each (system-scope loads: the pairs may sit in
-            // this rank's mailbox, written by its peers), folded across the wave, broadcast through LDS
+            // the np <= 64 gathered (max, flags) pairs: one lane each, in every wave (system-scope loads: the pairs may sit in this
+            // rank's mailbox, written by its peers), folded across the wave
             mbox_wait_block(ex.wait);
-            if (threadIdx.x < WAVE) {
-                const int g = (int)threadIdx.x;
-                const bool mb = ex.wait.tags != nullptr;
-                m = g < np ? ld_gathered(pmax + 2 * g, mb) : -__builtin_huge_val();
-                f = g < np ? (int)ld_gathered(pmax + 2 * g + 1, mb) : 0;
-                m = wave_max_f64(m);
+            const int g = lane_id();
+            const bool mb = ex.wait.tags != nullptr;
+            m = g < np ? ld_gathered(mf_all + 2 * g, mb) : -__builtin_huge_val();
+            f = g < np ? (int)ld_gathered(mf_all + 2 * g + 1, mb) : 0;
+            m = wave_max_f64(m);
 #pragma unroll
-                for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
-                if (threadIdx.x == 0) { sm[0] = m; sf[0] = f; }
-            }
-            __syncthreads();
-            m = sm[0]; f = sf[0];
+            for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
             if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
-            __syncthreads();
-        } else fold_partials<SCAN_BLOCK>(pmax, pflags, np, sm, sf, m, f);
+        } else fold_slots(slots, m, f);                           // every wave for itself: no LDS, no barrier
         in.m = m; in.flags = f;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             ws_out->m = m; ws_out->flags = f;

@@ -70,6 +70,29 @@ __device__ __forceinline__ void coop_count_le2(const uint64_t* line0, uint64_t T
     }
     __builtin_amdgcn_wave_barrier();
 }
+// NS independent slots per lane at once (8 NS line loads in flight per lane; the targets are re-read from the strip instead of kept):
+// lds_wave holds NS x 64 entries
+template <int NS>
+__device__ __forceinline__ void coop_count_le(const uint64_t* const (&line)[NS], const uint64_t (&T)[NS], ulonglong2* lds_wave, int (&cnt)[NS])
+{
+    const int lane = lane_id(), sub = lane & 7, gbase = lane & ~7;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) lds_wave[q * WAVE + lane] = make_ulonglong2(reinterpret_cast<uint64_t>(line[q]), T[q]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ulonglong2 v[8 * NS];
+#pragma unroll
+    for (int r = 0; r < 8 * NS; ++r) v[r] = load_global_16(lds_wave[(r >> 3) * WAVE + gbase + (r & 7)].x, sub);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) cnt[q] = 0;
+#pragma unroll
+    for (int r = 0; r < 8 * NS; ++r) {
+        const uint64_t t = lds_wave[(r >> 3) * WAVE + gbase + (r & 7)].y;
+        const int c = group8_sum((int)(v[r].x <= t) + (int)(v[r].y <= t));
+        cnt[r >> 3] = sub == (r & 7) ? c : cnt[r >> 3];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 // per-lane variant for coherent targets (stratified, residual head): neighbouring lanes hit the same lines,
 // the loads coalesce by themselves and the cooperation overhead is not worth it
 __device__ __forceinline__ int count_le_line(const uint64_t* __restrict__ line, uint64_t T)
@@ -705,7 +728,18 @@ constexpr int MBLOCK = 256;
 #endif
 constexpr int MSLOTS = GPF_MSLOTS;                 // consecutive slots per lane (16-byte ancestor stores)
 constexpr int MJB = MBLOCK * MSLOTS;               // slots per workgroup
-constexpr int64_t MONO_WIDE = 8 * (int64_t)MJB;    // a cell range wider than this is searched per slot, not streamed
+#ifndef GPF_MONO_WIDE_MULT
+#define GPF_MONO_WIDE_MULT 2
+#endif
+#ifndef GPF_MONO_WIDE2_MULT
+#define GPF_MONO_WIDE2_MULT 64
+#endif
+#ifndef GPF_WIDE_NS
+#define GPF_WIDE_NS 4
+#endif
+constexpr int MONO_WIDE_NS = GPF_WIDE_NS;
+constexpr int64_t MONO_WIDE = GPF_MONO_WIDE_MULT * (int64_t)MJB;     // a cell range wider than this is streamed on the per-16 level ...
+constexpr int64_t MONO_WIDE2 = GPF_MONO_WIDE2_MULT * (int64_t)MJB;   // ... and beyond this searched per slot
 
 // Block-cooperative: A0 / A1 = number of entries of arr[0..cnt) (ascending) that are <= L0 / <= L1 (L0 <= L1).
 // Fast path, ONE global round trip of one coalesced 8-byte load per thread: a 256-entry window around `guess` (for
@@ -720,6 +754,31 @@ __device__ __forceinline__ void block_count_le_pair(const uint64_t* __restrict__
     const int tid = (int)threadIdx.x;
     uint64_t Lq[2];
     int par = 0;
+    if (guess < 0 && cnt <= 16 * MBLOCK) {
+        // no usable guess (a sorted order: the CDF is far from linear) and the level is small: every thread reads 16 entries, the
+        // whole level in ONE round trip of coalesced 16-byte loads, and the counts are exact
+        ulonglong2 v[8];
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(arr);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (int64_t)(2 * (c * MBLOCK + tid)) < cnt ? src[c * MBLOCK + tid] : make_ulonglong2(~0ull, ~0ull);   // (cnt is even)
+        between(Lq[0], Lq[1]);
+        int c0 = 0, c1 = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            c0 += (int)(v[c].x <= Lq[0]) + (int)(v[c].y <= Lq[0]);
+            c1 += (int)(v[c].x <= Lq[1]) + (int)(v[c].y <= Lq[1]);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { c0 += __shfl_xor(c0, m, WAVE); c1 += __shfl_xor(c1, m, WAVE); }
+        if (lane_id() == 0) { s_cnt[0][0][wave_id()] = c0; s_cnt[0][1][wave_id()] = c1; }
+        __syncthreads();
+        int64_t k0 = 0, k1 = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) { k0 += s_cnt[0][0][w]; k1 += s_cnt[0][1][w]; }
+        A0 = k0; A1 = k1;
+        return;
+    }
+    if (guess < 0) guess = cnt / 2;
     {
         int64_t w_lo = guess - MBLOCK / 2;
         w_lo = w_lo + MBLOCK > cnt ? cnt - MBLOCK : w_lo;
@@ -772,14 +831,22 @@ __device__ __forceinline__ void block_count_le_pair(const uint64_t* __restrict__
     A0 = lo[0]; A1 = lo[1];
 }
 
-// (4 waves per SIMD = 4 workgroups per CU: a 10^6-slot launch is ONE resident round of workgroups)
-__global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
+#ifdef GPF_DBG_STRAT
+__device__ unsigned long long g_dbg_strat[8 * 4096];
+#define DBG_STRAT(slot, val) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_dbg_strat[8 * blockIdx.x + (slot)] = (unsigned long long)(val); } while (0)
+#else
+#define DBG_STRAT(slot, val) do {} while (0)
+#endif
+// (2-3 workgroups per CU -- 41 KB of LDS each --: a 10^6-slot launch, 489 workgroups, is ONE resident round)
+__global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
 {
+    DBG_STRAT(0, wall_clock64());
     static_assert(MSLOTS % 4 == 0, "ancestors leave the lane as 16-byte stores");
     __shared__ __attribute__((aligned(16))) uint64_t s_T[MJB + 4];   // targets of the block's slots (+inf beyond n, and as padding)
     __shared__ __attribute__((aligned(16))) uint32_t s_mark[MJB];
     __shared__ int s_cnt[2][2][NWAVES];
     __shared__ uint32_t s_wmax[NWAVES];
+    __shared__ __attribute__((aligned(16))) ulonglong2 s_coop[NWAVES * MONO_WIDE_NS * WAVE];   // the wide path's line-count strips (coop_count_le)
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
     if (a.update_lml && blockIdx.x == 0 && tid == 0)
@@ -808,7 +875,8 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
     uint64_t Lj0, Lj1;                                                 // strata bounds of the block, local, clamped at 0
     int64_t Lj0s;                                                      // ... unclamped
     // (the guess: were the weights equal, slot j0's target would fall into cell j0 n_cells / n_out)
-    const int64_t guess = (int64_t)((double)j0 * (a.plan ? (double)a.n_cells / (double)n_out : (double)a.n_cells * invN)) >> 8;
+    // (under a sorted order the CDF is steep at the front and flat in the tail: no guess, block_count_le_pair reads the whole level)
+    const int64_t guess = a.order ? -1 : (int64_t)((double)j0 * (a.plan ? (double)a.n_cells / (double)n_out : (double)a.n_cells * invN)) >> 8;
     block_count_le_pair(a.w.t256, n256, guess, s_cnt, A0, A1, [&](uint64_t& L0, uint64_t& L1) {
         // S = N B + rem; stratum j is [L(j), L(j+1)), L(j) = j B + floor(j rem / N)   (DESIGN.md §3.3); B, rem and N / S
         // were left beside S by the scan that produced it
@@ -857,14 +925,20 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
     });
     const int64_t g_lo = A0 < n256 ? A0 : n256 - 1, g_hi = A1 < n256 ? A1 : n256 - 1;
     const int64_t i_start = g_lo * 256, i_end = g_hi * 256 + 256;
-    if (tid == 0) s_mark[0] = (uint32_t)i_start;
+    // Three regimes by the width of the block's cell range (all block-uniform):  <= MONO_WIDE cells: stream the cells;  <= MONO_WIDE2
+    // (the light tail of a sorted order: many cells per slot): stream the per-16 level -- a sixteenth of the entries -- for every
+    // slot's 16-cell group, then ONE line count per slot inside it;  beyond: per-slot search from the per-256 level down.
+    const bool two_level = i_end - i_start > MONO_WIDE && i_end - i_start <= MONO_WIDE2;
+    const int64_t n16 = a.ntiles * (TILE / 16);
+    if (tid == 0) s_mark[0] = (uint32_t)(two_level ? i_start / 16 : i_start);
     __syncthreads();
+    DBG_STRAT(1, wall_clock64()); DBG_STRAT(4, i_end - i_start);
     uint32_t res[MSLOTS];
-    if (i_end - i_start <= MONO_WIDE) {
-        // ---- stream the cells; cell i resolves e = #{slots of the block with a target < cdf[i]} slots
+    if (i_end - i_start <= MONO_WIDE2) {
+        // ---- stream the cells (or the per-16 entries); entry i resolves e = #{slots of the block with a target < value[i]} slots
         const double inv_step = a.ws->sinv;
-        const uint64_t* cbase = a.w.cdf + i_start;
-        const uint32_t ncell = (uint32_t)(i_end - i_start), ibase = (uint32_t)i_start + 1u;
+        const uint64_t* cbase = two_level ? a.w.t16 + i_start / 16 : a.w.cdf + i_start;
+        const uint32_t ncell = (uint32_t)(two_level ? (i_end - i_start) / 16 : i_end - i_start), ibase = (uint32_t)(two_level ? i_start / 16 : i_start) + 1u;
         constexpr int CPF = 6;                                            // 16-byte loads in flight per lane: 3072 cells per sweep
         for (uint32_t i0 = 0; i0 < ncell; i0 += 2u * MBLOCK * CPF) {
             ulonglong2 cc[CPF];
@@ -915,12 +989,31 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
         for (int w = 0; w < NWAVES; ++w) if (w < wv) pre = s_wmax[w] > pre ? s_wmax[w] : pre;
 #pragma unroll
         for (int k = 0; k < MSLOTS; ++k) res[k] = res[k] > pre ? res[k] : pre;
+        if (two_level) {
+            // res = number of per-16 entries <= target = the slot's 16-cell group; the cells <= target inside it: one 128-byte line
+            // per slot, 8 lanes to a line, MONO_WIDE_NS slots of the lane in flight (coop_count_le)
+            constexpr int WNS = MONO_WIDE_NS;
+            static_assert(MSLOTS % WNS == 0, "whole rounds");
+            ulonglong2* const strip = s_coop + wv * (WNS * WAVE);
+#pragma unroll
+            for (int k = 0; k < MSLOTS; k += WNS) {
+                uint64_t Tq[WNS]; const uint64_t* ln[WNS]; int cq[WNS];
+#pragma unroll
+                for (int q = 0; q < WNS; ++q) {
+                    Tq[q] = s_T[MSLOTS * tid + k + q];
+                    res[k + q] = (int64_t)res[k + q] < n16 ? res[k + q] : (uint32_t)(n16 - 1);
+                    ln[q] = a.w.cdf + (int64_t)res[k + q] * 16;
+                }
+                coop_count_le<WNS>(ln, Tq, strip, cq);
+#pragma unroll
+                for (int q = 0; q < WNS; ++q) res[k + q] = res[k + q] * 16u + (uint32_t)cq[q];
+            }
+        }
     } else {
-        // ---- a few slots over very many cells (e.g. the light tail of a sorted order): per-slot search of the range.
-        //      The range's per-256 entries are staged in LDS (over s_mark) and searched there; the two line counts below
-        //      them (per-16 level, cells) are dependent global reads, two slots of the lane in flight at a time.  Targets
-        //      are read from and results written to the lane's own s_T entries (rolled loop: the streaming path's registers).
-        const int64_t n16 = a.ntiles * (TILE / 16);
+        // ---- a few slots over a very large part of the CDF: per-slot search of the range.  The range's per-256 entries are
+        //      staged in LDS (over s_mark) and searched there; the two line counts below them (per-16 level, cells) are dependent
+        //      global reads, MONO_WIDE_NS slots of the lane in flight at a time.  Targets are read from and results written to the
+        //      lane's own s_T entries (rolled loop: the streaming path's registers).
         constexpr int WIDE_ENTRIES = MJB / 2;                             // u64 entries that fit s_mark
         uint64_t* const s_w = reinterpret_cast<uint64_t*>(s_mark);
         const int64_t nent = g_hi - g_lo;                                 // entries [g_lo, g_hi) decide the group
@@ -938,21 +1031,29 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
             while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.w.t256[mid] <= Tk) lo = mid + 1; else hi = mid; }
             return lo;
         };
+        constexpr int WNS = MONO_WIDE_NS;                                  // slots of the lane in flight at a time
+        static_assert(MSLOTS % WNS == 0, "whole rounds");
+        ulonglong2* const strip = s_coop + wv * (WNS * WAVE);
 #pragma unroll 1
-        for (int k = 0; k < MSLOTS; k += 2) {
-            const uint64_t Ta = s_T[MSLOTS * tid + k], Tb = s_T[MSLOTS * tid + k + 1];
-            const int64_t ga = group_of(Ta), gb = group_of(Tb);
-            const int ca = count_le_line(a.w.t16 + ga * 16, Ta), cb = count_le_line(a.w.t16 + gb * 16, Tb);
-            int64_t sa = ga * 16 + ca, sb2 = gb * 16 + cb;
-            sa = sa < n16 ? sa : n16 - 1;
-            sb2 = sb2 < n16 ? sb2 : n16 - 1;
-            const int da = count_le_line(a.w.cdf + sa * 16, Ta), db = count_le_line(a.w.cdf + sb2 * 16, Tb);
-            s_T[MSLOTS * tid + k] = (uint64_t)(sa * 16 + da);
-            s_T[MSLOTS * tid + k + 1] = (uint64_t)(sb2 * 16 + db);
+        for (int k = 0; k < MSLOTS; k += WNS) {
+            uint64_t Tq[WNS]; int64_t gq[WNS]; const uint64_t* ln[WNS]; int cq[WNS];
+#pragma unroll
+            for (int q = 0; q < WNS; ++q) { Tq[q] = s_T[MSLOTS * tid + k + q]; gq[q] = group_of(Tq[q]); ln[q] = a.w.t16 + gq[q] * 16; }
+            coop_count_le<WNS>(ln, Tq, strip, cq);
+#pragma unroll
+            for (int q = 0; q < WNS; ++q) {
+                int64_t sq = gq[q] * 16 + cq[q];
+                gq[q] = sq < n16 ? sq : n16 - 1;
+                ln[q] = a.w.cdf + gq[q] * 16;
+            }
+            coop_count_le<WNS>(ln, Tq, strip, cq);
+#pragma unroll
+            for (int q = 0; q < WNS; ++q) s_T[MSLOTS * tid + k + q] = (uint64_t)(gq[q] * 16 + cq[q]);
         }
 #pragma unroll
         for (int k = 0; k < MSLOTS; ++k) res[k] = (uint32_t)s_T[MSLOTS * tid + k];
     }
+    DBG_STRAT(2, wall_clock64());
     const int64_t jb = j0 + MSLOTS * tid;
     const uint32_t last = (uint32_t)(a.n_cells - 1);
     if (a.plan && a.pack.packed) {
@@ -1005,6 +1106,7 @@ __global__ __launch_bounds__(MBLOCK, 4) void k_search_strat(SearchArgs a)
 #pragma unroll
         for (int k = 0; k < MSLOTS; ++k) if (jb + k < n_out) dst[k] = out[k];
     }
+    DBG_STRAT(3, wall_clock64());
 }
 
 } // namespace gpf

@@ -10,12 +10,10 @@ namespace gpf {
 constexpr int64_t SPACE_COUNTS = (int64_t)1 << 62;   // residual: target lives in the copy-count CDF
 constexpr uint64_t STAGE_T_MASK = (1ull << 62) - 1;  // a staged target (T_local < S_local <= 2^62) below its space bit
 
-__global__ void k_pack_mflags(const double* __restrict__ pmax, const int32_t* __restrict__ pflags, int np, double* out2, MboxPush push)
+__global__ void k_pack_mflags(const unsigned long long* __restrict__ slots, double* out2, MboxPush push)
 {
-    __shared__ double sm[NWAVES];
-    __shared__ int sf[NWAVES];
     double m; int f;
-    fold_partials(pmax, pflags, np, sm, sf, m, f);
+    fold_slots(slots, m, f);
     if (threadIdx.x == 0) { out2[0] = m; out2[1] = (double)(f & (FLAG_NAN | FLAG_POSINF)); }
     if (wave_id() == 0) {                                   // every lane holds (m, f): straight into the peers' mailboxes
         const uint64_t words[2] = {d2u(m), d2u((double)(f & (FLAG_NAN | FLAG_POSINF)))};

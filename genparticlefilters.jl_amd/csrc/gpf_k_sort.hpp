@@ -27,33 +27,49 @@ __host__ inline size_t sort_ws_bytes(int64_t n)
     return sort_ws_desc_offset() + (size_t)SORT_PASSES * (nt + (nt + 15) / 16 + (nt + 255) / 256) * SORT_BINS * sizeof(uint64_t);
 }
 // keys of the log-priorities + the histograms of all eight digits in one pass over the weights
-// (FIRST: the lowest digit that will be sorted -- 0: all eight passes, 4: the high 32 bits only, §K10c)
+// (FIRST: the lowest digit that will be sorted -- 0: all eight passes)
 // clear / clear16: the OTHER of the two sort workspaces (16-byte units), zeroed here for the next sort: histograms, tickets and
 // descriptor planes must start at zero, and a hipMemsetAsync in front of every sort costs ~5 us of stream time each
-template <int FIRST>
+// COARSE: the three digits of the coarse key (sort_coarse, gpf_k_common.hpp) instead, histograms 0..2; `slots` hold the maximum of pv
+// (MaxSlots), which workgroup 0 also leaves in *m_out for the passes
+constexpr int SORT_M_WORD = 62;                     // the coarse sort's maximum: a double in ticket words 62, 63 of the workspace
+template <int FIRST, bool COARSE = false>
 __global__ __launch_bounds__(BLOCK) void k_sort_keys_hist(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ hist,
-                                                          uint4* __restrict__ clear, int64_t clear16)
+                                                          uint4* __restrict__ clear, int64_t clear16, const unsigned long long* __restrict__ slots,
+                                                          double* __restrict__ m_out)
 {
+    constexpr int P0 = COARSE ? 0 : FIRST, P1 = COARSE ? 3 : SORT_PASSES;
     __shared__ uint32_t s_h[SORT_PASSES][SORT_BINS];
+    double m = 0.0;
+    if constexpr (COARSE) { int f; fold_slots(slots, m, f); if (blockIdx.x == 0 && threadIdx.x == 0) *m_out = m; }
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < clear16; i += (int64_t)gridDim.x * BLOCK) clear[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = threadIdx.x; i < SORT_PASSES * SORT_BINS; i += BLOCK) (&s_h[0][0])[i] = 0;
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         const uint64_t k = sort_key_desc(pv.at(i));
         keys[i] = k;
+        const uint64_t dk = COARSE ? (uint64_t)sort_coarse(k, m) : k;
 #pragma unroll
-        for (int p = FIRST; p < SORT_PASSES; ++p) atomicAdd(&s_h[p][(k >> (8 * p)) & 0xff], 1u);
+        for (int p = P0; p < P1; ++p) atomicAdd(&s_h[p][(dk >> (8 * p)) & 0xff], 1u);
     }
     __syncthreads();
-    for (int i = FIRST * SORT_BINS + threadIdx.x; i < SORT_PASSES * SORT_BINS; i += BLOCK) { const uint32_t c = (&s_h[0][0])[i]; if (c) atomicAdd(hist + i, c); }
+    for (int i = P0 * SORT_BINS + threadIdx.x; i < P1 * SORT_BINS; i += BLOCK) { const uint32_t c = (&s_h[0][0])[i]; if (c) atomicAdd(hist + i, c); }
 }
 
 // one digit pass.  vals_in == nullptr: the payload is the element's index (first pass).
+// COARSE: the digit is taken from the coarse key (sort_coarse with the maximum *m_ptr) instead of the key itself
+template <bool COARSE>
 __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                      uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
                                                      int pass, const uint32_t* __restrict__ hist, uint32_t* __restrict__ ticket,
-                                                     uint64_t* __restrict__ desc, int32_t* __restrict__ timeout)
+                                                     uint64_t* __restrict__ desc, int32_t* __restrict__ timeout, const double* __restrict__ m_ptr)
 {
+    double cm = 0.0;
+    if constexpr (COARSE) cm = *m_ptr;
+    auto digit_of = [&](uint64_t k) -> uint32_t {
+        if constexpr (COARSE) return (sort_coarse(k, cm) >> (8 * pass)) & 0xffu;
+        else return (uint32_t)(k >> (8 * pass)) & 0xffu;
+    };
     __shared__ uint32_t s_cnt[SORT_WAVES][SORT_BINS];      // per-wave digit counts, then exclusive offsets of the wave inside the tile's bin
     __shared__ uint32_t s_lstart[SORT_BINS];           // first position of the bin in the tile's sorted order
     __shared__ int64_t s_gbase[SORT_BINS];             // global position of the bin's first element of this tile, minus s_lstart
@@ -62,7 +78,6 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     __shared__ int32_t s_vals[SORT_TILE];
     __shared__ uint32_t s_tile;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
-    const int shift = 8 * pass;
     // tiles are taken by ticket (arrival order, not block index: a tile only ever waits for tiles that are already running).  ONE counter:
     // eight counters (way = blockIdx & 7 taking the tiles way, way + 8, ...), which avoid ~250 serialised same-address atomics in front
     // of the loads, measured 16.4 us per pass against 15.1 (profiles/r03_sort_experiments.txt) -- the interleaved arrival order costs
@@ -95,7 +110,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const int64_t i = t0 + wv * (WAVE * SORT_ITEMS) + it * WAVE + lane;
         const bool valid = i < n;
-        const uint32_t d = (uint32_t)(key[it] >> shift) & 0xffu;
+        const uint32_t d = digit_of(key[it]);
         uint64_t peers = __ballot(valid);                 // lanes with the same digit (invalid lanes take no part)
 #pragma unroll
         for (int b = 0; b < 8; ++b) { const uint64_t m = __ballot((d >> b) & 1u); peers &= ((d >> b) & 1u) ? m : ~m; }
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const int64_t i = t0 + wv * (WAVE * SORT_ITEMS) + it * WAVE + lane;
         if (i < n) {
-            const uint32_t d = (uint32_t)(key[it] >> shift) & 0xffu;
+            const uint32_t d = digit_of(key[it]);
             const uint32_t lp = s_lstart[d] + s_cnt[wv][d] + rank[it];
             s_keys[lp] = key[it]; s_vals[lp] = val[it];
         }
@@ -189,20 +204,22 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
         const int lp = k * SORT_BLOCK + tid;
         if (lp < nvalid) {
             const uint64_t kk = s_keys[lp];
-            const int64_t g = s_gbase[(uint32_t)(kk >> shift) & 0xffu] + lp;
+            const int64_t g = s_gbase[digit_of(kk)] + lp;
             keys_out[g] = kk; vals_out[g] = s_vals[lp];
         }
     }
 }
 
-// ----------------------------------------------------------------------------- K10c: four passes + a finish
-// The log-priorities of a filter are continuous: after FOUR stable passes over the HIGH 32 key bits (sign, exponent, 20 mantissa
-// bits) almost every key already stands where it belongs; what is left are short runs of keys that share their high word (a few
-// per thousand at 10^6 particles), in index order.  k_sort_finish orders each such run by the low word -- every element counts,
-// inside its run, the keys with a smaller low word plus the equal ones before it (stable) -- and copies everything else through:
-// one streaming pass instead of four latency-chain passes.  A run longer than SORT_RUN_MAX (nearly equal weights: they differ
-// only below 2^-20 relative; or equal weights) raises a flag; the last tile publishes it to pinned host memory and the host
-// re-sorts with all eight passes.
+// ----------------------------------------------------------------------------- K10c: three coarse passes + a finish
+// The log-priorities of a filter are continuous and live in a few binades below their maximum.  THREE stable passes over the 24-bit
+// coarse key (sort_coarse, gpf_k_common.hpp: the distance from the maximum as {5-bit binade | 19 mantissa bits}) leave almost every
+// key where it belongs; what is left are short runs of keys that share their coarse key (~1 per bucket in the populated binades at
+// 10^6 particles), in index order.  k_sort_finish orders each such run by the full 64-bit key -- every element counts, inside its run,
+// the smaller keys plus the equal ones before it (stable) -- and copies everything else through: one streaming pass instead of five
+// latency-chain passes.  A run of more than SORT_RUN_MAX + 1 elements (equal or nearly equal weights; many weights further than 2^9 below the
+// maximum, e.g. -inf) raises a flag; the last tile publishes it to pinned host memory and the host re-sorts with all eight passes over
+// the key itself.  (Round 3, first form: four passes over the HIGH 32 key bits -- sign, 11 exponent bits, 20 mantissa bits -- + the
+// finish: 4 x 15.2 us of passes; the coarse key spends its exponent bits on the binades that are in use.)
 constexpr int SORT_RUN_MAX = 48;                    // elements of a run to either side of an element that the finish looks at
 #ifndef GPF_FIN_BLOCK
 #define GPF_FIN_BLOCK 1024
@@ -212,14 +229,17 @@ constexpr int SORT_RUN_MAX = 48;                    // elements of a run to eith
 constexpr int FIN_BLOCK = GPF_FIN_BLOCK, FIN_TILE = 4 * FIN_BLOCK, FIN_HALO = SORT_RUN_MAX + 1;
 __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                            uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
-                                                           uint32_t* __restrict__ done, int64_t* host_flag, int64_t ticket)
+                                                           uint32_t* __restrict__ done, int64_t* host_flag, int64_t ticket, const double* __restrict__ m_ptr)
 {
     __shared__ uint64_t s_k[FIN_TILE + 2 * FIN_HALO];
+    __shared__ uint32_t s_c[FIN_TILE + 2 * FIN_HALO];                       // the coarse keys: a run = neighbours with equal coarse keys
     const int tid = (int)threadIdx.x;
     const int64_t t0 = (int64_t)blockIdx.x * FIN_TILE;
+    const double cm = *m_ptr;
     for (int p = tid; p < FIN_TILE + 2 * FIN_HALO; p += FIN_BLOCK) {
         const int64_t g = t0 - FIN_HALO + p;
-        s_k[p] = (g >= 0 && g < n) ? keys_in[g] : 0ull;
+        const uint64_t k = (g >= 0 && g < n) ? keys_in[g] : 0ull;
+        s_k[p] = k; s_c[p] = sort_coarse(k, cm);
     }
     int32_t val[FIN_TILE / FIN_BLOCK];                                     // the payloads: in flight while the runs are examined
 #pragma unroll
@@ -233,19 +253,22 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __res
         if (g >= n) continue;
         const int c = li + FIN_HALO;
         const uint64_t key = s_k[c];
-        const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
-        // the run of equal high words around this element: lc elements to the left, rc to the right (inside the array)
+        const uint32_t hi = s_c[c];
+        // the run of equal coarse keys around this element: lc elements to the left, rc to the right (inside the array)
         int lc = 0, rc = 0;
-        while (lc < SORT_RUN_MAX + 1 && g - lc - 1 >= 0 && (uint32_t)(s_k[c - lc - 1] >> 32) == hi) ++lc;
-        while (rc < SORT_RUN_MAX + 1 && g + rc + 1 < n && (uint32_t)(s_k[c + rc + 1] >> 32) == hi) ++rc;
+        while (lc < SORT_RUN_MAX + 1 && g - lc - 1 >= 0 && s_c[c - lc - 1] == hi) ++lc;
+        while (rc < SORT_RUN_MAX + 1 && g + rc + 1 < n && s_c[c + rc + 1] == hi) ++rc;
         int64_t pos = g;
         if (lc + rc > 0) {
-            if (lc > SORT_RUN_MAX || rc > SORT_RUN_MAX) too_long = true;   // the run leaves the window: the host re-sorts
+            // a run of more than SORT_RUN_MAX + 1 elements is left as it stands and flagged (the host re-sorts).  EVERY element of such
+            // a run sees that (each looks SORT_RUN_MAX + 1 to either side), so the output is a permutation of the input either way:
+            // the weight sums taken over it -- and the log-ML update -- are right even when the order is not
+            if (lc + rc > SORT_RUN_MAX) too_long = true;
             else {
                 int rank = 0;
                 for (int q = -lc; q <= rc; ++q) {
-                    const uint32_t l2 = (uint32_t)s_k[c + q];
-                    rank += (l2 < lo || (l2 == lo && q < 0)) ? 1 : 0;
+                    const uint64_t k2 = s_k[c + q];
+                    rank += (k2 < key || (k2 == key && q < 0)) ? 1 : 0;
                 }
                 pos = g - lc + rank;
             }

@@ -10,7 +10,8 @@ __device__ __forceinline__ void track_max(double v, double& m, int& f)
     if (v != v) f |= FLAG_NAN;
     else { m = v > m ? v : m; if (v == __builtin_huge_val()) f |= FLAG_POSINF; }
 }
-__device__ __forceinline__ void block_max_store(double m, int f, double* __restrict__ pmax, int32_t* __restrict__ pflags)
+// the workgroup's (maximum, flags) into its slot of ms.cur (MaxSlots, gpf_k_common.hpp); workgroup 0 clears ms.clear for the next producer
+__device__ __forceinline__ void block_max_store(double m, int f, MaxSlots ms)
 {
     m = wave_max_f64(m);
 #pragma unroll
@@ -22,9 +23,11 @@ __device__ __forceinline__ void block_max_store(double m, int f, double* __restr
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int w = 1; w < NWAVES; ++w) { m = sm_[w] > m ? sm_[w] : m; f |= sf_[w]; }
-        pmax[blockIdx.x] = m;
-        pflags[blockIdx.x] = f;
+        unsigned long long* slot = ms.cur + (blockIdx.x % MAX_SLOTS) * SLOT_WORDS;
+        atomicMax(slot, max_key(m));                              // (no return value used: fire and forget)
+        if (f) atomicOr(slot + 1, (unsigned long long)f);
     }
+    if (blockIdx.x == 0 && threadIdx.x < MAX_SLOTS) { ms.clear[threadIdx.x * SLOT_WORDS] = 0; ms.clear[threadIdx.x * SLOT_WORDS + 1] = 0; }
 }
 
 // stratified_map! (utils.jl:29-55): K strata, block size B = n div K; particle i < K B belongs to stratum i div B
@@ -46,8 +49,7 @@ __device__ __forceinline__ int stratum_of(const ModelArgs& a, uint64_t seed, uin
 template <int M, int MODE = 0>
 __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, int W, double* __restrict__ rows,
-                                                double* __restrict__ lw, double* __restrict__ pmax,
-                                                int32_t* __restrict__ pflags)
+                                                double* __restrict__ lw, MaxSlots ms)
 {
     using Mo = Model<M>;
     double bm = -__builtin_huge_val(); int bf = 0;
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
         lw[i] = ll;
         track_max(ll, bm, bf);
     }
-    block_max_store(bm, bf, pmax, pflags);
+    block_max_store(bm, bf, ms);
 }
 
 // GATHER: the preceding pf_resample! left its ancestor vector pending; this kernel reads row anc[i]
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
                                                 int64_t n, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
                                                 double* __restrict__ rows_out, double* __restrict__ lw,
-                                                double* __restrict__ pmax, int32_t* __restrict__ pflags, PackedCommit pc)
+                                                MaxSlots ms, PackedCommit pc)
 {
     using Mo = Model<M>;
     constexpr int D = Mo::D;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
         lw[i] = nl;
         track_max(nl, bm, bf);
     }
-    block_max_store(bm, bf, pmax, pflags);
+    block_max_store(bm, bf, ms);
 }
 
 // K7/K8: pf_move_accept! with Gen.mh on the current step's latent (rejuvenate.jl:40-53) and
@@ -181,8 +183,7 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
                                                 int64_t n, int has_prev, int n_iters, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
                                                 double* __restrict__ rows_out, double* __restrict__ lw,
-                                                unsigned long long* __restrict__ n_accept,
-                                                double* __restrict__ pmax, int32_t* __restrict__ pflags)
+                                                unsigned long long* __restrict__ n_accept, MaxSlots ms)
 {
     using Mo = Model<M>;
     constexpr int D = Mo::D, NB = Mo::NBLK;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
         __syncthreads();
         if (threadIdx.x == 0) { unsigned long long b = 0; for (int w = 0; w < NWAVES; ++w) b += s_acc[w]; n_accept[blockIdx.x] = b; }
     }
-    if (REWEIGHT) block_max_store(bm, bf, pmax, pflags);
+    if (REWEIGHT) block_max_store(bm, bf, ms);
 }
 
 } // namespace gpf

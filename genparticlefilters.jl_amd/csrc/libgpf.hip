@@ -73,8 +73,8 @@ struct gpf_filter {
     size_t sort_tmp_bytes = 0;
     int sort_ws_cur = 0;
     int64_t* h_sort_flag = nullptr; int64_t sort_ticket = 0;   // pinned {a run too long for k_sort_finish, ticket}
-    double* pmax = nullptr;
-    int32_t* pflags = nullptr;
+    unsigned long long* mslots[2] = {nullptr, nullptr};   // MaxSlots (gpf_k_common.hpp): maximum + flags of the log-weights, two alternating arrays
+    int mcur = 0;                                         // mslots[mcur]: written by the latest producer
     uint64_t* blockQ = nullptr;
     double *partial = nullptr, *dscal = nullptr;
     unsigned long long* acc_part = nullptr;   // [MAX_PARTIALS] accepted moves per workgroup of the last move-accept kernel
@@ -84,8 +84,7 @@ struct gpf_filter {
     long long* h_sc_ticket = nullptr; long long sc_ticket = 0;   // k_publish_scalars -> host polling (fetch_scalars)
     uint32_t epoch = 0;
     bool initialized = false, has_prev = false, raw_valid = false, residual_scanned = false;
-    bool max_valid = false;        // pmax/pflags hold the block partials of the current log-weights (written by the producer kernel)
-    int max_np = 0;
+    bool max_valid = false;        // mslots[mcur] describes the current log-weights (written by the kernel that produced them)
     bool raw_has_q = false;        // the raw summary's scan also accumulated sum q^2 (blockQ)
     bool raw_q_folded = false;     // sc->raw.Ql folded from blockQ
     bool pending_gather = false;   // a resample left (rows[cur], anc) un-gathered; log-weights are 0
@@ -199,6 +198,9 @@ int grid_for(const gpf_filter* h, int64_t work_items, int blocks_per_cu)
     const int64_t cap = (int64_t)h->n_cu * blocks_per_cu;
     return (int)std::max<int64_t>(1, std::min(need, cap));
 }
+
+// the slots the next producer of log-weights folds its maximum into (and the array it clears for the producer after it)
+MaxSlots next_slots(gpf_filter* h) { h->mcur ^= 1; return MaxSlots{h->mslots[h->mcur], h->mslots[1 - h->mcur]}; }
 
 template <class F>
 gpf_status timed(gpf_filter* h, int id, F&& launch)
@@ -328,18 +330,20 @@ void launch_step_t(gpf_filter* h, int grid)
     constexpr int Wc = row_width(Model<M>::D, KEEP);
     if constexpr ((PROP == 1 && !Model<M>::HAS_PROPOSAL) || (PROP == 2 && !Model<M>::HAS_STRATA)) { (void)h; (void)grid; return; }
     else if (h->pending_packed) {
+        const MaxSlots ms = next_slots(h);
         const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox};
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags, pc);
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pc);
     } else if (h->pending_gather) {
+        const MaxSlots ms = next_slots(h);
         PackedCommit pc{};
         pc.lw_fill = h->pending_fill ? &h->sc->lw_fill : nullptr;
         GPF_LAUNCH((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags, pc);
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pc);
     }
     else
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, h->pmax, h->pflags, PackedCommit{});
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, next_slots(h), PackedCommit{});
 }
 template <int M, int PROP = 0>
 void launch_init_t(gpf_filter* h, int grid)
@@ -347,7 +351,7 @@ void launch_init_t(gpf_filter* h, int grid)
     if constexpr ((PROP == 1 && !Model<M>::HAS_PROPOSAL) || (PROP == 2 && !Model<M>::HAS_STRATA) || (PROP == 3 && !Model<M>::HAS_STRATA_PROPOSAL)) { (void)h; (void)grid; return; }
     else
         GPF_LAUNCH((k_init<M, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                           h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw, h->pmax, h->pflags);
+                           h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw, next_slots(h));
 }
 bool model_has_proposal(int model)
 {
@@ -379,11 +383,11 @@ void launch_move_prop_t(gpf_filter* h, int grid, int n_iters)
     else if (h->pending_gather)
         GPF_LAUNCH((k_move<M, Wc, true, true, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                           h->acc_part, h->pmax, h->pflags);
+                           h->acc_part, next_slots(h));
     else
         GPF_LAUNCH((k_move<M, Wc, true, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                           h->acc_part, h->pmax, h->pflags);
+                           h->acc_part, next_slots(h));
 }
 bool model_has_move_proposal(int model)
 {
@@ -403,11 +407,11 @@ void launch_move_t(gpf_filter* h, int grid, int n_iters)
     if (h->pending_gather)           // the resample gather rides on the move (rows read through anc, incoming weights 0)
         GPF_LAUNCH((k_move<M, Wc, RW, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                           h->acc_part, h->pmax, h->pflags);
+                           h->acc_part, RW ? next_slots(h) : MaxSlots{nullptr, nullptr});
     else
         GPF_LAUNCH((k_move<M, Wc, RW, false>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                           h->acc_part, h->pmax, h->pflags);
+                           h->acc_part, RW ? next_slots(h) : MaxSlots{nullptr, nullptr});
 }
 
 #define DISPATCH_MODEL(h, CALL)                                                                  \
@@ -526,7 +530,6 @@ template <class In, int FIXQ>
 gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, bool want_cdf, uint64_t* total_out,
                        const double* mf_all = nullptr, ScanExtras ex = ScanExtras{nullptr, nullptr, 0, 0})
 {
-    const double* pmax = mf_all ? mf_all : h->pmax;
     uint64_t* dc = h->desc[ch][h->dcur[ch]];
     uint64_t* dn = h->desc[ch][1 - h->dcur[ch]];
     const int gs = scan_grid(h);
@@ -534,7 +537,7 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
     const ScanOut so = scan_out(want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch], h->ntiles, offsets);
     if (ch == 0 && want_cdf) h->ch0_offsets = offsets && so.off16 != nullptr;
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
-        GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, in, h->n, h->ntiles, pmax, h->pflags, np, slot,
+        GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, in, h->n, h->ntiles, mf_all, h->mslots[h->mcur], np, slot,
                            so, dc, dn, total_out, h->blockQ, h->h_timeout, ex);
     });
     if (s) return s;
@@ -543,9 +546,22 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
     return GPF_OK;
 }
 
-// pv: the weights to summarise; use_producer_max: pmax/pflags written by the kernel that produced lw are current
+// the maximum slots (MaxSlots) describe pv: the slots left by the kernel that produced the log-weights when pv is the raw weights and
+// they are current (use_producer_max), else one k_max_partial pass over pv
+gpf_status ensure_max(gpf_filter* h, const PrioView& pv, bool use_producer_max)
+{
+    if (use_producer_max && h->max_valid) return GPF_OK;
+    const int gp = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
+    gpf_status s = timed(h, GPF_K_MAX, [&] {
+        GPF_LAUNCH(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, pv, h->n, next_slots(h));
+    });
+    if (s) return s;
+    h->max_valid = use_producer_max;           // (otherwise the slots describe pv, which may not be the raw log-weights)
+    return GPF_OK;
+}
+// pv: the weights to summarise; max_ready: ensure_max(pv) has run already (the sorted resample needs the maximum for its sort keys)
 gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cdf, const int32_t* order, bool use_producer_max,
-                     bool want_q = false, bool publish_flags = false)
+                     bool want_q = false, bool publish_flags = false, bool max_ready = false)
 {
     ScanExtras ex{nullptr, nullptr, 0, h->cfg.n_global};
     if (publish_flags) {
@@ -553,18 +569,9 @@ gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cd
         h->flag_ticket += 1;
         ex.host_flags = h->h_flags; ex.ticket = h->flag_ticket;
     }
-    int np;
+    const int np = 0;               // (only the sharded scans fold gathered pairs)
     gpf_status s;
-    if (use_producer_max && h->max_valid) np = h->max_np;
-    else {
-        np = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
-        s = timed(h, GPF_K_MAX, [&] {
-            GPF_LAUNCH(k_max_partial, dim3(np), dim3(BLOCK), 0, h->stream, pv, h->n, h->pmax, h->pflags);
-        });
-        if (s) return s;
-        h->max_valid = false;       // pmax now describes pv, which may not be the raw log-weights
-        if (use_producer_max) { h->max_valid = true; h->max_np = np; }
-    }
+    if (!max_ready && (s = ensure_max(h, pv, use_producer_max))) return s;
     InFixQ in{pv, order, order ? h->keys : nullptr, h->K, 0.0, 0};     // (after sort_desc the sorted keys are in h->keys)
     if (want_q) s = scan_launch<InFixQ, 2>(h, 0, in, np, slot, want_cdf, &slot->S, nullptr, ex);
     else        s = scan_launch<InFixQ, 1>(h, 0, in, np, slot, want_cdf, &slot->S, nullptr, ex);
@@ -733,14 +740,13 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
     return GPF_OK;
 }
 
-// order = sortperm(log_priorities, rev=true) (resample.jl:156-157) into h->order: keys + digit histograms in one pass, then
-// eight onesweep digit passes (gpf_kernels.hpp K10).  Key buffers alternate keys -> keys_out -> keys ...; the payload
-// starts as the element index and alternates idx_in -> order, so the eighth pass leaves the permutation in h->order.
-#ifndef KEYS_HIST4_BLOCKS_PER_CU
-#define KEYS_HIST4_BLOCKS_PER_CU 1
-#endif
-// first_pass = 0: all eight digit passes;  4: the four passes over the high 32 key bits (K10c: the caller finishes the runs)
-gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, int first_pass, uint32_t** ws_used = nullptr)
+// order = sortperm(log_priorities, rev=true) (resample.jl:156-157) into h->order, the sorted keys into h->keys (gpf_k_sort.hpp K10):
+// keys + digit histograms in one pass, then one onesweep kernel per 8-bit digit.
+//   coarse = true : three passes over the 24-bit coarse key (sort_coarse: distance from the maximum, which the maximum slots must hold
+//                   -- ensure_max); the caller finishes the runs of equal coarse keys (k_sort_finish).  keys -> keys_out -> keys ->
+//                   keys_out, payload index -> idx_in -> order -> idx_in: the finish brings both back to h->keys / h->order.
+//   coarse = false: all eight passes over the 64-bit key; the eighth leaves keys / permutation in h->keys / h->order.
+gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse, uint32_t** ws_used = nullptr)
 {
     gpf_status s = ensure_sort_buffers(h);
     if (s) return s;
@@ -752,43 +758,64 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, int first_p
     if (ws_used) *ws_used = reinterpret_cast<uint32_t*>(ws);
     uint32_t* hist = reinterpret_cast<uint32_t*>(ws);
     uint32_t* ticket = hist + SORT_PASSES * SORT_BINS;
+    double* m_ptr = reinterpret_cast<double*>(ticket + SORT_M_WORD);
     uint64_t* desc = reinterpret_cast<uint64_t*>(ws + sort_ws_desc_offset());
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
     const int64_t clear16 = (int64_t)(h->sort_tmp_bytes / 16);
     // (ONE workgroup per CU: every workgroup ends with up to 256 global atomic adds per sorted digit into the same counters; with 2 / 4
-    //  workgroups per CU the four-digit kernel took 16.0 / 24.2 us against 13.3)
-    if (first_pass == 0) GPF_LAUNCH((k_sort_keys_hist<0>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16);
-    else                 GPF_LAUNCH((k_sort_keys_hist<4>), dim3(grid_for(h, n, KEYS_HIST4_BLOCKS_PER_CU)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16);
-    for (int p = first_pass; p < SORT_PASSES; ++p) {
+    //  workgroups per CU a four-digit kernel took 16.0 / 24.2 us against 13.3)
+    const unsigned long long* slots = h->mslots[h->mcur];
+    if (coarse) GPF_LAUNCH((k_sort_keys_hist<0, true>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
+    else        GPF_LAUNCH((k_sort_keys_hist<0, false>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
+    for (int p = 0; p < (coarse ? 3 : SORT_PASSES); ++p) {
         const uint64_t* kin = (p & 1) ? h->keys_out : h->keys;
         uint64_t* kout = (p & 1) ? h->keys : h->keys_out;
-        const int32_t* vin = p == first_pass ? nullptr : ((p & 1) ? h->idx_in : h->order);
+        const int32_t* vin = p == 0 ? nullptr : ((p & 1) ? h->idx_in : h->order);
         int32_t* vout = (p & 1) ? h->order : h->idx_in;
-        GPF_LAUNCH(k_sort_pass, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout);
+        if (coarse) GPF_LAUNCH(k_sort_pass<true>, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout, m_ptr);
+        else        GPF_LAUNCH(k_sort_pass<false>, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout, m_ptr);
     }
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
-// order = sortperm(log_priorities, rev=true) into h->order, the sorted keys into h->keys: four passes over the high 32 key bits +
-// k_sort_finish (gpf_k_sort.hpp K10c); all eight passes when a run of equal high words was too long for the finish (the host
-// learns it from pinned memory), or with GPF_SORT=radix8 in the environment (A/B measurements)
-gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
+// three coarse passes + k_sort_finish; all eight passes when a run of equal coarse keys was too long for the finish (the host learns
+// it from pinned memory), or with GPF_SORT=radix8 in the environment (A/B measurements; GPF_SORT=fallback: always both, for the tests).
+// The maximum slots must describe pv (ensure_max).
+//   sort_desc_begin enqueues the sort; *pending = the finish's verdict is still out: the caller may enqueue the work that consumes
+//   the order behind it and asks sort_desc_flagged AFTERWARDS (no host wait between the sort and its consumers) -- when that says
+//   "flagged" the order was wrong: sort_passes(..., false) and the consumers again.
+int sort_mode() { static const int mode = [] { const char* e = getenv("GPF_SORT"); return e && !strcmp(e, "radix8") ? 1 : (e && !strcmp(e, "fallback") ? 2 : 0); }(); return mode; }
+gpf_status sort_desc_begin(gpf_filter* h, const PrioView& pv, int64_t n, bool* pending)
 {
-    static const int mode = [] { const char* e = getenv("GPF_SORT"); return e && !strcmp(e, "radix8") ? 1 : (e && !strcmp(e, "fallback") ? 2 : 0); }();
-    if (mode == 1) return sort_passes(h, pv, n, 0);
+    *pending = false;
+    if (sort_mode() == 1) return sort_passes(h, pv, n, false);
     uint32_t* ws = nullptr;
-    gpf_status s = sort_passes(h, pv, n, 4, &ws);                // (the fourth of them leaves keys / payload in h->keys / h->order)
+    gpf_status s = sort_passes(h, pv, n, true, &ws);             // (the third pass leaves keys / payload in h->keys_out / h->idx_in)
     if (s) return s;
     if (!h->h_sort_flag) { HIP_TRY(h, hipHostMalloc(&h->h_sort_flag, 2 * sizeof(int64_t))); h->h_sort_flag[0] = h->h_sort_flag[1] = 0; }
     uint32_t* done = ws + SORT_PASSES * SORT_BINS + 64;                                  // (behind this sort's zeroed tickets)
+    const double* m_ptr = reinterpret_cast<const double*>(ws + SORT_PASSES * SORT_BINS + SORT_M_WORD);
     h->sort_ticket += 1;
-    GPF_LAUNCH(k_sort_finish, dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)), dim3(FIN_BLOCK), 0, h->stream, h->keys, h->order, h->keys_out, h->idx_in, n,
-               done, h->h_sort_flag, h->sort_ticket);
+    GPF_LAUNCH(k_sort_finish, dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)), dim3(FIN_BLOCK), 0, h->stream, h->keys_out, h->idx_in, h->keys, h->order, n,
+               done, h->h_sort_flag, h->sort_ticket, m_ptr);
     HIP_TRY(h, hipGetLastError());
-    std::swap(h->keys, h->keys_out); std::swap(h->order, h->idx_in);
-    if ((s = wait_ticket(h, h->h_sort_flag + 1, h->sort_ticket, "sort finish"))) return s;
-    if (h->h_sort_flag[0] != 0 || mode == 2) return sort_passes(h, pv, n, 0);
+    *pending = true;
     return GPF_OK;
+}
+gpf_status sort_desc_flagged(gpf_filter* h, bool* flagged)
+{
+    gpf_status s = wait_ticket(h, h->h_sort_flag + 1, h->sort_ticket, "sort finish");
+    if (s) return s;
+    *flagged = h->h_sort_flag[0] != 0 || sort_mode() == 2;
+    return GPF_OK;
+}
+gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
+{
+    bool pending = false, flagged = false;
+    gpf_status s = sort_desc_begin(h, pv, n, &pending);
+    if (s || !pending) return s;
+    if ((s = sort_desc_flagged(h, &flagged))) return s;
+    return flagged ? sort_passes(h, pv, n, false) : GPF_OK;
 }
 
 gpf_status ensure_residual_buffers(gpf_filter* h)
@@ -871,8 +898,10 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     if ((s = check_scan_timeout(h))) return s;                   // an earlier scan gave up: do not build on its CDF
     if ((s = materialize(h))) return s;                          // two resamples in a row: finish the first one
     // sortperm(log_priorities, rev=true)  (resample.jl:156-157)
+    bool sort_pending = false;                                   // the sort's verdict (k_sort_finish) is asked for after the search is enqueued
     if (sorted) {
-        if ((s = sort_desc(h, pv, h->n))) return s;
+        if ((s = ensure_max(h, pv, pv.mode == 0))) return s;     // (the coarse sort keys are distances from the maximum)
+        if ((s = sort_desc_begin(h, pv, h->n, &sort_pending))) return s;
     }
     // safe_softmax(log_priorities) (resample.jl:54) and logsumexp(log_weights) (resample.jl:180)
     WSum* ws;
@@ -880,14 +909,14 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     if (pv.mode == 0) {
         ws = &h->sc->raw;
         if (!h->raw_valid || sorted || (need_off && !h->ch0_offsets)) {
-            if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, true, false, need_sync))) return s;
+            if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, true, false, need_sync, sorted))) return s;
             published = need_sync;
         }
     } else {
         if ((s = ensure_raw(h))) return s;                       // raw summary (cdf[0] is overwritten next; only S, m matter)
         h->want_offsets = need_off;
         ws = &h->sc->prio;
-        if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, false, false, need_sync))) return s;
+        if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, false, false, need_sync, sorted))) return s;
         published = need_sync;
     }
     h->raw_valid = false;                                        // cdf[0] no longer the plain raw CDF / lw about to change
@@ -925,15 +954,31 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     // every block first copies the top level of the CDF into LDS: keep the grid small (persistent blocks)
     // one 1024-thread workgroup per CU, two slots per lane and iteration
     const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + 2 * SBLOCK - 1) / (2 * SBLOCK), (int64_t)h->n_cu * SEARCH_BLOCKS_PER_CU));
-    s = timed(h, GPF_K_SEARCH, [&] {
-        switch (method) {
-            case GPF_RESAMPLE_MULTINOMIAL: launch_multinomial_search(h, sa); break;
-            case GPF_RESAMPLE_RESIDUAL:    GPF_LAUNCH((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
-            default:                       // monotone targets: a streaming merge, MJB slots per workgroup
-                GPF_LAUNCH(k_search_strat, dim3((unsigned)((h->n + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa); break;
+    auto search = [&]() {
+        return timed(h, GPF_K_SEARCH, [&] {
+            switch (method) {
+                case GPF_RESAMPLE_MULTINOMIAL: launch_multinomial_search(h, sa); break;
+                case GPF_RESAMPLE_RESIDUAL:    GPF_LAUNCH((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
+                default:                       // monotone targets: a streaming merge, MJB slots per workgroup
+                    GPF_LAUNCH(k_search_strat, dim3((unsigned)((h->n + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa); break;
+            }
+        });
+    };
+    if ((s = search())) return s;
+    if (sort_pending) {
+        // the scan and the search above ran behind the sort without a host wait; if the finish met a run it could not order (equal
+        // or nearly equal priorities) they worked on a wrong order: eight passes over the full key, then both again.  The weight
+        // sums are order-independent (integers): the log-ML update of the first search stands.
+        bool flagged = false;
+        if ((s = sort_desc_flagged(h, &flagged))) return s;
+        if (flagged) {
+            if ((s = sort_passes(h, pv, h->n, false))) return s;
+            h->want_offsets = need_off;
+            if ((s = summarize(h, pv, ws, true, h->order, pv.mode == 0, false, false, true))) return s;
+            sa.w = levels(h, 0); sa.c = levels(h, 0); sa.update_lml = 0;
+            if ((s = search())) return s;
         }
-    });
-    if (s) return s;
+    }
     if ((s = hist_on_resample(h))) return s;
     if (h->parent) {
         // sub-state (resample.jl:205-218): eager gather; weights keep the block's total mass
@@ -1037,10 +1082,11 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         else { HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
         { gpf_status a_ = alloc_particle_buffers(h); if (a_) return a_; }
         const size_t n = (size_t)h->n, rb = n * (size_t)h->W * sizeof(double);
-        HIP_TRY(h, hipMalloc(&h->pmax, MAX_PARTIALS * sizeof(double)));
-        HIP_TRY(h, hipMalloc(&h->pflags, MAX_PARTIALS * sizeof(int32_t)));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(h, hipMalloc(&h->mslots[b], (size_t)MAX_SLOTS * SLOT_WORDS * sizeof(unsigned long long)));
+            HIP_TRY(h, hipMemsetAsync(h->mslots[b], 0, (size_t)MAX_SLOTS * SLOT_WORDS * sizeof(unsigned long long), h->stream));
+        }
         HIP_TRY(h, hipMalloc(&h->blockQ, (size_t)4 * 2 * h->n_cu * sizeof(uint64_t) + 64));
-        h->max_np = 0;
         HIP_TRY(h, hipMalloc(&h->partial, MAX_PARTIALS * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->acc_part, MAX_PARTIALS * sizeof(unsigned long long)));
         HIP_TRY(h, hipMalloc(&h->dscal, 4 * sizeof(double)));
@@ -1102,7 +1148,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers (or of the compact copies below)
     for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc}) if (q) (void)hipFree(q);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
-    void* bufs[] = {h->pmax, h->pflags, h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf, h->acc_part,
+    void* bufs[] = {h->mslots[0], h->mslots[1], h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf, h->acc_part,
                     h->pull_req, h->pull_counts, h->pull_pc, h->pull_pc_all};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
@@ -1146,7 +1192,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
     if (s) return s;
     h->pending_gather = false; h->pending_fill = false;
     h->pending_packed = false;
-    h->max_valid = true; h->max_np = grid;
+    h->max_valid = true;
     GPF_LAUNCH(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
     HIP_TRY(h, hipMemsetAsync(&h->sc->lml_est, 0, sizeof(double), h->stream));                   // log_ml_est = 0.
     HIP_TRY(h, hipGetLastError());
@@ -1199,7 +1245,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
     HIP_TRY(h, hipGetLastError());
     h->pending_gather = false; h->pending_fill = false;      // a pending resample gather was fused into this step
     h->pending_packed = false;      // ... or a pending sharded commit
-    h->max_valid = true; h->max_np = grid;
+    h->max_valid = true;
     h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
     h->epoch += 1;
     h->has_prev = true;
@@ -1320,7 +1366,7 @@ static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters,
     h->cur ^= 1;
     h->epoch += 1;
     if (fused_gather) { h->pending_gather = false; h->pending_fill = false; h->max_valid = false; }   // log-weights are all 0 now (resample.jl:195)
-    if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; h->max_np = grid; }
+    if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; }
     mutated(h);
     if ((s = view_exit(h))) return s;
     if (n_accepted) {
@@ -1655,8 +1701,10 @@ gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t ste
                 HIP_TRY(v, hipMalloc(&v->desc[i][j], db));
                 HIP_TRY(v, hipMemsetAsync(v->desc[i][j], 0, db, v->stream));
             }
-        HIP_TRY(v, hipMalloc(&v->pmax, MAX_PARTIALS * sizeof(double)));
-        HIP_TRY(v, hipMalloc(&v->pflags, MAX_PARTIALS * sizeof(int32_t)));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(v, hipMalloc(&v->mslots[b], (size_t)MAX_SLOTS * SLOT_WORDS * sizeof(unsigned long long)));
+            HIP_TRY(v, hipMemsetAsync(v->mslots[b], 0, (size_t)MAX_SLOTS * SLOT_WORDS * sizeof(unsigned long long), v->stream));
+        }
         HIP_TRY(v, hipMalloc(&v->blockQ, (size_t)4 * 2 * v->n_cu * sizeof(uint64_t) + 64));
         HIP_TRY(v, hipMalloc(&v->partial, MAX_PARTIALS * sizeof(double)));
         HIP_TRY(v, hipMalloc(&v->acc_part, MAX_PARTIALS * sizeof(unsigned long long)));
@@ -1711,10 +1759,11 @@ static gpf_status resize_optimal(gpf_handle h, int64_t n_new, int32_t check, int
     // sort(weights) (resize.jl:204), descending; safe_softmax + logsumexp (resize.jl:152,190) over that order
     if ((s = ensure_residual_buffers(h))) return s;
     const PrioView pv = raw_view(h);
+    if ((s = ensure_max(h, pv, true))) return s;
     if ((s = sort_desc(h, pv, n_old))) return s;
     WSum* ws = &h->sc->raw;
     h->raw_valid = false;
-    if ((s = summarize(h, pv, ws, true, h->order, true))) return s;
+    if ((s = summarize(h, pv, ws, true, h->order, true, false, false, true))) return s;
     HIP_TRY(h, hipMemsetAsync(&h->sc->opt_d, 0xff, sizeof(long long), h->stream));
     GPF_LAUNCH(k_opt_threshold, dim3(grid_for(h, n_new, 8)), dim3(BLOCK), 0, h->stream, h->cdf[0], ws, n_new, n_old, h->sc);
     GPF_LAUNCH(k_opt_params, dim3(1), dim3(1), 0, h->stream, h->cdf[0], ws, n_new, h->sc);
@@ -1969,17 +2018,16 @@ gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
     if (s) return s;
     if (!out2) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
     if ((s = materialize(h))) return s;
-    int gp = h->max_np;
     const PrioView pv = h->sum_pv_set ? h->sum_pv : raw_view(h);  // (the engine's prioritised resample summarises alpha lw and log_ws too)
     if (!h->max_valid || h->sum_pv_set) {
-        gp = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
+        const int gp = (int)std::min<int64_t>(MAX_PARTIALS, (h->n + BLOCK - 1) / BLOCK);
         s = timed(h, GPF_K_MAX, [&] {
-            GPF_LAUNCH(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, pv, h->n, h->pmax, h->pflags);
+            GPF_LAUNCH(k_max_partial, dim3(gp), dim3(BLOCK), 0, h->stream, pv, h->n, next_slots(h));
         });
         if (s) return s;
+        h->max_valid = !h->sum_pv_set;
     }
-    h->max_valid = false;            // gpf_shard_weight_scan overwrites pmax[0] with the global maximum
-    GPF_LAUNCH(k_pack_mflags, dim3(1), dim3(BLOCK), 0, h->stream, h->pmax, h->pflags, gp, out2, mb_begin(h, MB_MF));
+    GPF_LAUNCH(k_pack_mflags, dim3(1), dim3(BLOCK), 0, h->stream, h->mslots[h->mcur], out2, mb_begin(h, MB_MF));
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
@@ -1995,7 +2043,6 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
         HIP_TRY(h, hipHostMalloc(&h->h_shard_counts, (size_t)(2 * MAX_SHARDS + 1) * sizeof(int64_t)));
         h->h_shard_counts[2 * MAX_SHARDS] = 0;
     }
-    h->max_valid = false;
     InFixQ in{h->sum_pv_set ? h->sum_pv : raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
     WSum* const slot = h->sum_slot ? h->sum_slot : &h->sc->raw;
     const bool want_cdf = !h->sum_no_cdf;
@@ -2810,3 +2857,10 @@ void gpf_host_math(int32_t which, const double* a, const double* b, int64_t n, d
 }
 
 } // extern "C"
+
+#ifdef GPF_DBG_STRAT
+extern "C" int gpf_debug_strat(unsigned long long* out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gpf::g_dbg_strat), (size_t)n_words * sizeof(unsigned long long));
+}
+#endif

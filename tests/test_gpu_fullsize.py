@@ -271,19 +271,24 @@ def _sorted_case(N, kind, seed=3):
     return {"filter": None, "all equal": np.zeros(N), "two values": np.where(i % 2 == 0, -0.5, -0.25),
             "mostly -inf": np.where(rng.random(N) < 0.9, -np.inf, -rng.random(N)), "few distinct": -np.floor(8 * rng.random(N)),
             "signed zeros": np.where(i % 3 == 0, -0.0, np.where(i % 3 == 1, 0.0, -1.0)), "ramp": -1e-7 * i,
-            "close values": -1.0 - 1e-13 * rng.integers(0, 50, N)}[kind]
+            "close values": -1.0 - 1e-13 * rng.integers(0, 50, N),
+            # distances from the maximum over every binade of the coarse sort key and beyond both of its ends (2^-21, 2^9)
+            "wide range": np.concatenate([[3.5], 3.5 - np.exp(rng.uniform(-40.0, 8.0, N - 1))]) if N > 1 else np.array([3.5]),
+            "tiny spread": 7.0 - 1e-9 * rng.random(N)}[kind]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N", [1, 2, 100, 4096, 4097, (1 << 17) + 1, 300_007, 1_000_000])
-@pytest.mark.parametrize("kind", ["filter", "all equal", "two values", "mostly -inf", "few distinct", "signed zeros", "ramp", "close values"])
+@pytest.mark.parametrize("kind", ["filter", "all equal", "two values", "mostly -inf", "few distinct", "signed zeros", "ramp", "close values",
+                                  "wide range", "tiny spread"])
 def test_sorted_stratified_sizes_and_patterns(g, o, N, kind):
-    """sort_particles=true (the reference's default, src/resample.jl:145,156-157): four digit passes over the high 32 key bits + the
-    finish of the short runs of equal high words, and -- for weights that are equal or differ only far below 2^-20 relative ("all
-    equal", "two values", "few distinct", "close values": runs longer than the finish's window) -- the eight-pass fallback.  The
-    permutation is the stable descending sort of the oracle (ties by index, -0.0 < 0.0), so the ancestors are equal."""
-    if N > 400_000 and kind not in ("filter", "all equal", "few distinct", "close values"):
-        pytest.skip("the large sizes run four weight patterns")
+    """sort_particles=true (the reference's default, src/resample.jl:145,156-157): three digit passes over the 24-bit coarse key
+    (distance from the maximum: 5-bit binade, 19 mantissa bits) + the finish of the short runs of equal coarse keys, and -- for weights
+    that are equal, nearly equal or far below the maximum ("all equal", "two values", "few distinct", "close values", "mostly -inf":
+    runs longer than the finish's window) -- the eight-pass fallback.  The permutation is the stable descending sort of the oracle
+    (ties by index, -0.0 < 0.0), so the ancestors are equal."""
+    if N > 400_000 and kind not in ("filter", "all equal", "few distinct", "close values", "wide range", "tiny spread"):
+        pytest.skip("the large sizes run six weight patterns")
     model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
     st = g.pf_initialize(model, (1,), ys[0], N, seed=5)
     orc = o.OracleFilter(model.model_id, model.params, N, 5).initialize(ys[0])
@@ -300,7 +305,7 @@ def test_sorted_stratified_sizes_and_patterns(g, o, N, kind):
 
 @pytest.mark.gpu
 def test_sort_finish_window_boundaries(g, o):
-    """runs of equal high key words of every length around the finish's window (48 to either side): up to 49 elements are ordered by
+    """runs of equal coarse sort keys of every length around the finish's window (48 to either side): up to 49 elements are ordered by
     the finish, longer runs take the eight-pass fallback; mixed in one filter with ordinary weights"""
     N = 50_000
     rng = np.random.default_rng(2)
@@ -308,12 +313,15 @@ def test_sort_finish_window_boundaries(g, o):
     for run_len in (2, 3, 48, 49, 50, 97, 98, 200):
         lw = -5.0 * rng.random(N)
         pos = rng.choice(N, size=run_len, replace=False)
-        lw[pos] = -1.0 - 1e-12 * rng.permutation(run_len)               # same high word (they differ below 2^-20 relative), distinct low words
+        lw[pos] = -1.0 - 1e-12 * rng.permutation(run_len)               # one coarse key (they differ far below 2^-19 of their distance from the maximum), distinct keys
         st = g.pf_initialize(model, (1,), ys[0], N, seed=5)
         orc = o.OracleFilter(model.model_id, model.params, N, 5).initialize(ys[0])
         st.log_weights = lw; orc.lw = lw.copy()
         g.pf_resample(st, "stratified", sort_particles=True, check=False); orc.resample("stratified", sort_particles=True, check=False)
         assert np.array_equal(st.parents, orc.parents), run_len
+        # (the scan and the search run behind the finish before its verdict is known: a flagged finish must still have left a
+        #  permutation, or the weight sums -- and this estimate -- would be off)
+        assert g.get_lml_est(st) == orc.log_ml_estimate(), run_len
         st.close()
 
 
