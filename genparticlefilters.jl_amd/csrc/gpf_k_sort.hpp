@@ -45,18 +45,34 @@ __global__ __launch_bounds__(BLOCK) void k_sort_keys_hist(PrioView pv, int64_t n
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < clear16; i += (int64_t)gridDim.x * BLOCK) clear[i] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = threadIdx.x; i < SORT_PASSES * SORT_BINS; i += BLOCK) (&s_h[0][0])[i] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-        const uint64_t k = sort_key_desc(pv.at(i));
-        keys[i] = k;
-        const uint64_t dk = COARSE ? (uint64_t)sort_coarse(k, m) : k;
+    // (one workgroup per CU -- the flush below is global atomics -- so each lane keeps KH_ILP independent loads in flight)
+    constexpr int KH_ILP = 4;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += KH_ILP * stride) {
+        double v[KH_ILP];
 #pragma unroll
-        for (int p = P0; p < P1; ++p) atomicAdd(&s_h[p][(dk >> (8 * p)) & 0xff], 1u);
+        for (int q = 0; q < KH_ILP; ++q) v[q] = i0 + q * stride < n ? pv.at(i0 + q * stride) : 0.0;
+#pragma unroll
+        for (int q = 0; q < KH_ILP; ++q) {
+            if (i0 + q * stride >= n) break;
+            const uint64_t k = sort_key_desc(v[q]);
+            keys[i0 + q * stride] = k;
+            const uint64_t dk = COARSE ? (uint64_t)sort_coarse(k, m) : k;
+#pragma unroll
+            for (int p = P0; p < P1; ++p) atomicAdd(&s_h[p][(dk >> (8 * p)) & 0xff], 1u);
+        }
     }
     __syncthreads();
     for (int i = P0 * SORT_BINS + threadIdx.x; i < P1 * SORT_BINS; i += BLOCK) { const uint32_t c = (&s_h[0][0])[i]; if (c) atomicAdd(hist + i, c); }
 }
 
 // one digit pass.  vals_in == nullptr: the payload is the element's index (first pass).
+#ifdef GPF_DBG_SORT
+__device__ unsigned long long g_dbg_sort[8 * 4096];
+#define DBG_SORT(slot) do { if (threadIdx.x == 0 && pass == 1 && blockIdx.x < 4096) g_dbg_sort[8 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+#else
+#define DBG_SORT(slot) do {} while (0)
+#endif
 // COARSE: the digit is taken from the coarse key (sort_coarse with the maximum *m_ptr) instead of the key itself
 template <bool COARSE>
 __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
@@ -64,6 +80,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
                                                      int pass, const uint32_t* __restrict__ hist, uint32_t* __restrict__ ticket,
                                                      uint64_t* __restrict__ desc, int32_t* __restrict__ timeout, const double* __restrict__ m_ptr)
 {
+    DBG_SORT(0);
     double cm = 0.0;
     if constexpr (COARSE) cm = *m_ptr;
     auto digit_of = [&](uint64_t k) -> uint32_t {
@@ -82,6 +99,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     // eight counters (way = blockIdx & 7 taking the tiles way, way + 8, ...), which avoid ~250 serialised same-address atomics in front
     // of the loads, measured 16.4 us per pass against 15.1 (profiles/r03_sort_experiments.txt) -- the interleaved arrival order costs
     // more in the look-back than the atomics cost
+    // (tile = workgroup index when the whole launch is resident, without the same-address atomic in front of the loads, was measured too:
+    //  16.8-17.5 us per pass against 15.8 -- arrival order is the better look-back order)
     if (tid == 0) s_tile = atomicAdd(ticket + pass * SORT_TICKET_WAYS, 1u);
     for (int i = tid; i < SORT_WAVES * SORT_BINS; i += SORT_BLOCK) (&s_cnt[0][0])[i] = 0;
     // exclusive scan of the digit's histogram: where each bin starts in the output
@@ -97,6 +116,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     for (int w = 0; w < SORT_BINS / WAVE; ++w) if (w < wv) hbase += s_scan[w];
     const int64_t tile = s_tile;
     const int64_t t0 = tile * SORT_TILE;
+    DBG_SORT(1);
     // ---- load (wave-striped: element = t0 + wave * 1024 + item * 64 + lane), rank inside the wave by digit
     uint64_t key[SORT_ITEMS]; int32_t val[SORT_ITEMS]; uint32_t rank[SORT_ITEMS];
 #pragma unroll
@@ -106,6 +126,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
         val[it] = i < n ? (vals_in ? vals_in[i] : (int32_t)i) : 0;
     }
     const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (key[0] == 1234567ull) DBG_SORT(7);                 // (forces the loads to have landed before the next stamp is meaningful)
+    DBG_SORT(2);
 #pragma unroll
     for (int it = 0; it < SORT_ITEMS; ++it) {
         const int64_t i = t0 + wv * (WAVE * SORT_ITEMS) + it * WAVE + lane;
@@ -122,6 +144,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    DBG_SORT(3);
     // ---- per bin (thread = bin): offsets of the waves inside the bin, the tile's count, the bin's start inside the tile
     uint32_t tcnt = 0;
     if (binthr) {
@@ -155,6 +178,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
             s_keys[lp] = key[it]; s_vals[lp] = val[it];
         }
     }
+    DBG_SORT(4);
     uint64_t excl = 0;
     // ---- global number of this bin's elements in earlier tiles.  Tiles are taken by ticket, so every earlier tile is running
     //      or done, and the tiles of a launch mostly start TOGETHER: a one-word-per-hop look-back would crawl through a chain
@@ -198,6 +222,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     }
     if (binthr) s_gbase[tid] = (int64_t)hbase + (int64_t)excl - (int64_t)lstart;
     __syncthreads();
+    DBG_SORT(5);
     const int64_t nvalid = n - t0 < SORT_TILE ? n - t0 : SORT_TILE;
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; ++k) {
@@ -208,6 +233,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
             keys_out[g] = kk; vals_out[g] = s_vals[lp];
         }
     }
+    DBG_SORT(6);
 }
 
 // ----------------------------------------------------------------------------- K10c: three coarse passes + a finish

@@ -757,10 +757,11 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse
     h->sort_ws_cur ^= 1;
     if (ws_used) *ws_used = reinterpret_cast<uint32_t*>(ws);
     uint32_t* hist = reinterpret_cast<uint32_t*>(ws);
-    uint32_t* ticket = hist + SORT_PASSES * SORT_BINS;
-    double* m_ptr = reinterpret_cast<double*>(ticket + SORT_M_WORD);
+    uint32_t* const ticket_words = hist + SORT_PASSES * SORT_BINS;
+    double* m_ptr = reinterpret_cast<double*>(ticket_words + SORT_M_WORD);
     uint64_t* desc = reinterpret_cast<uint64_t*>(ws + sort_ws_desc_offset());
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
+    uint32_t* const ticket = ticket_words;
     const int64_t clear16 = (int64_t)(h->sort_tmp_bytes / 16);
     // (ONE workgroup per CU: every workgroup ends with up to 256 global atomic adds per sorted digit into the same counters; with 2 / 4
     //  workgroups per CU a four-digit kernel took 16.0 / 24.2 us against 13.3)
@@ -2862,5 +2863,12 @@ void gpf_host_math(int32_t which, const double* a, const double* b, int64_t n, d
 extern "C" int gpf_debug_strat(unsigned long long* out, int n_words)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gpf::g_dbg_strat), (size_t)n_words * sizeof(unsigned long long));
+}
+#endif
+
+#ifdef GPF_DBG_SORT
+extern "C" int gpf_debug_sort(unsigned long long* out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gpf::g_dbg_sort), (size_t)n_words * sizeof(unsigned long long));
 }
 #endif
