@@ -1,6 +1,6 @@
 # usage: [LOOP=sharded_loop.py] bash tools/gpu_pmc_kernels.sh TAG METHOD [STEPS] [N]   -- SQ counters of every kernel of a resample+update loop
 # (one rocprofv3 --pmc pass per counter group, kernel trace only; summaries -> gpurun_out/pmc_TAG.txt)
-TAG=${1:-x}; METHOD=${2:-multinomial}; STEPS=${3:-30}; NP=${4:-1000000}
+TAG=${1:-x}; METHOD=${2:-multinomial}; STEPS=${3:-30}; NP=${4:-}     # (no N: the loop's own size for that config)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_$TAG.txt; : > $OUT
 i=0
