@@ -374,6 +374,49 @@ def pf_resample(state, method: str = "multinomial", **kwargs):
     raise ErrorException(f"Resampling method {method} not recognized.")
 
 
+def pf_resample_blocks(state, block_size: int, method: str = "multinomial", *, ess_frac=None, sort_particles: bool = True, check="warn"):
+    """Many small filters in one state: the batched form of
+
+        for b in blocks:                                   # consecutive blocks of block_size particles (<= 2048)
+            if ess_frac is None or get_ess(state[b]) < ess_frac * len(b):
+                pf_resample(state[b], method, sort_particles=..., check=...)
+
+    (sub-states: src/view.jl:16-48, src/resample.jl:185-187,205-218; the README loop README.md:60-79 per block) in ONE kernel
+    launch (gpf.h gpf_resample_blocks): one workgroup per block, everything out of LDS, the ESS test on the device.  Every block's
+    result is bit-identical to the loop above run through views.  Returns the number of blocks that resampled."""
+    if method not in RESAMPLE_METHODS:
+        raise ErrorException(f"Resampling method {method} not recognized.")
+    if check not in (True, False, "warn"):
+        raise ValueError("check must be True, 'warn' or False")
+    if isinstance(state, DeviceParticleFilterSubState):
+        raise ErrorException("pf_resample_blocks works on the whole filter")
+    check_id = 2 if check is True else (1 if check == "warn" else 0)
+    inv, cnt = C.c_int32(0), C.c_int64(0)
+    st = state._L.gpf_resample_blocks(state._h, RESAMPLE_METHODS[method], int(block_size), int(sort_particles),
+                                      float("nan") if ess_frac is None else float(ess_frac), check_id, C.byref(inv), C.byref(cnt))
+    state._n_blocks_last = (state.n_particles + int(block_size) - 1) // int(block_size) if int(block_size) > 0 else 0
+    if st != _lib.OK:
+        raise ErrorException(state._L.gpf_last_error(state._h).decode())
+    if check == "warn" and inv.value:
+        warnings.warn("Invalid weights (all -Inf or zero) in some block: resampled with uniform weights.")
+    return int(cnt.value)
+
+
+def block_resampled(state) -> np.ndarray:
+    """which blocks the last pf_resample_blocks resampled (bool per block)"""
+    out = np.zeros(getattr(state, "_n_blocks_last", 0), np.int32)
+    state._check(state._L.gpf_block_resampled(state._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out.astype(bool)
+
+
+def block_stats(state, block_size: int):
+    """(effective_sample_size(state[b]), log_ml_estimate(state[b])) of every block, src/utils.jl:163-178, in one launch"""
+    nb = (state.n_particles + int(block_size) - 1) // int(block_size)
+    ess, lml = np.empty(nb), np.empty(nb)
+    state._check(state._L.gpf_block_stats(state._h, int(block_size), _pd(ess), _pd(lml)))
+    return ess, lml
+
+
 def _rejuvenate(state, method_id: int, n_iters: int, want_count: bool):
     acc = C.c_uint64(0)
     st = state._L.gpf_rejuvenate(state._h, method_id, int(n_iters), C.byref(acc) if want_count else None)

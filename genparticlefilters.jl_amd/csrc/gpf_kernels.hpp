@@ -21,3 +21,4 @@
 #include "gpf_k_sort.hpp"
 #include "gpf_k_shard.hpp"
 #include "gpf_k_resize.hpp"
+#include "gpf_k_block.hpp"

@@ -137,6 +137,8 @@ struct gpf_filter {
     int scan_blocks_per_cu = 2;          // resident scan workgroups per CU the launch may rely on (occupancy query)
     int64_t* shard_counts = nullptr;     // [2 * MAX_SHARDS] exchange counters of the current resample (device) + pinned mirror
     int64_t* h_shard_counts = nullptr;
+    // block-wise resampling (gpf_resample_blocks): {flags, count} words, the per-block mask, per-block statistics
+    int32_t* blk_words = nullptr; int32_t* blk_mask = nullptr; double* blk_stats = nullptr; int64_t blk_cap = 0, blk_last = 0;
     // the pull plan (gpf_comm_set_plan): request lists [G][n], their counters, the dense / gathered request matrix and its pinned mirror
     int shard_plan_kind = 0;
     ulonglong2* pull_req = nullptr; int64_t pull_req_cap = 0;
@@ -865,6 +867,24 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
     return GPF_OK;
 }
 
+// a block of <= 128 / <= 512 particles is the work of one wave (2 / 8 particles per lane, four blocks per workgroup), a larger one of a workgroup
+template <int METHOD, int Wc>
+void launch_block_resample_w(gpf_filter* h, const BlockArgs& a)
+{
+    if (a.nb <= 2 * WAVE)      GPF_LAUNCH((k_block_resample<METHOD, Wc, WAVE, 2>), dim3((unsigned)((a.nblocks + 3) / 4)), dim3(BLOCK), 0, h->stream, a);
+    else if (a.nb <= 8 * WAVE) GPF_LAUNCH((k_block_resample<METHOD, Wc, WAVE, 8>), dim3((unsigned)((a.nblocks + 3) / 4)), dim3(BLOCK), 0, h->stream, a);
+    else                       GPF_LAUNCH((k_block_resample<METHOD, Wc, BLOCK, 8>), dim3((unsigned)a.nblocks), dim3(BLOCK), 0, h->stream, a);
+}
+template <int METHOD>
+void launch_block_resample(gpf_filter* h, const BlockArgs& a, int64_t nblocks)
+{
+    (void)nblocks;
+    switch (h->W) {
+        case 2: launch_block_resample_w<METHOD, 2>(h, a); break;
+        case 4: launch_block_resample_w<METHOD, 4>(h, a); break;
+        case 8: launch_block_resample_w<METHOD, 8>(h, a); break;
+    }
+}
 // ancestors of i.i.d. targets: k_search_multi (4-byte keys of every 32 / 64 cells in LDS) while the key table fits, else k_search<0>
 void launch_multinomial_search(gpf_filter* h, const SearchArgs& sa)
 {
@@ -1150,7 +1170,7 @@ gpf_status gpf_destroy(gpf_handle h)
     for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc}) if (q) (void)hipFree(q);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
     void* bufs[] = {h->mslots[0], h->mslots[1], h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf, h->acc_part,
-                    h->pull_req, h->pull_counts, h->pull_pc, h->pull_pc_all};
+                    h->pull_req, h->pull_counts, h->pull_pc, h->pull_pc_all, h->blk_words, h->blk_mask, h->blk_stats};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
@@ -1317,6 +1337,98 @@ gpf_status gpf_resample_local(gpf_handle h, int32_t method, int32_t sort_particl
         ~Scope() { h->K = K; h->logN = logN; h->cfg.n_global = ng; h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; }
     } scope(h);
     return resample_impl(h, method, raw_view(h), sort_particles, check, invalid, true);
+}
+
+// ------------------------------------------------------------------ block-wise resampling: many small filters in one launch (K11)
+static gpf_status block_buffers(gpf_filter* h, int64_t nblocks)
+{
+    if (!h->blk_words) HIP_TRY(h, hipMalloc(&h->blk_words, 2 * sizeof(int32_t)));
+    if (h->blk_cap < nblocks) {
+        if (h->blk_mask) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->blk_mask); (void)hipFree(h->blk_stats); h->blk_mask = nullptr; h->blk_stats = nullptr; h->blk_cap = 0; }
+        HIP_TRY(h, hipMalloc(&h->blk_mask, (size_t)nblocks * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc(&h->blk_stats, (size_t)nblocks * 2 * sizeof(double)));
+        h->blk_cap = nblocks;
+    }
+    return GPF_OK;
+}
+static gpf_status block_checks(gpf_handle h, int64_t block_size, const char* who)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (h->parent) return fail(h, GPF_ERR_STATE, std::string(who) + " on a sub-state view: call it on the filter");
+    if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, std::string(who) + " on a shard of a sharded filter");
+    if (block_size < 1 || block_size > BLK_MAX) return fail(h, GPF_ERR_INVALID_ARGUMENT, "block_size: 1 .. 2048 particles");
+    return GPF_OK;
+}
+gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size, int32_t sort_particles, double ess_frac,
+                               int32_t check, int32_t* invalid, int64_t* n_resampled)
+{
+    gpf_status s = block_checks(h, block_size, "gpf_resample_blocks");
+    if (s) return s;
+    if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED)
+        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");          // resample.jl:28
+    if (h->hist_on) return fail(h, GPF_ERR_STATE, "gpf_resample_blocks on a filter with a trajectory store");
+    if (h->W != 2 && h->W != 4 && h->W != 8) return fail(h, GPF_ERR_STATE, "row width");
+    if ((s = materialize(h))) return s;
+    const int64_t nblocks = (h->n + block_size - 1) / block_size;
+    if ((s = block_buffers(h, nblocks))) return s;
+    BlockArgs a{};
+    a.rows_in = h->rows[h->cur]; a.rows_out = h->rows[1 - h->cur]; a.lw = h->lw; a.anc = h->anc;
+    a.n = h->n; a.nb = block_size; a.nblocks = nblocks; a.gid0 = h->cfg.gid0; a.seed = h->cfg.seed; a.epoch = h->epoch;
+    a.sorted = method == GPF_RESAMPLE_STRATIFIED && sort_particles ? 1 : 0;
+    a.ess_frac = ess_frac == ess_frac ? ess_frac : -1.0;
+    a.check_true = check == GPF_CHECK_TRUE ? 1 : 0;
+    a.resampled = h->blk_mask;
+    s = timed(h, GPF_K_SEARCH, [&] {
+        if (method == GPF_RESAMPLE_MULTINOMIAL)   launch_block_resample<0>(h, a, nblocks);
+        else if (method == GPF_RESAMPLE_RESIDUAL) launch_block_resample<1>(h, a, nblocks);
+        else                                      launch_block_resample<2>(h, a, nblocks);
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->cur ^= 1;
+    h->blk_last = nblocks;
+    h->pending_gather = false; h->pending_fill = false;
+    h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false;
+    h->epoch += 1;
+    mutated(h);
+    if (check != GPF_CHECK_FALSE || invalid || n_resampled) {
+        int32_t words[2] = {0, 0};
+        GPF_LAUNCH(k_block_summary, dim3(1), dim3(BLOCK), 0, h->stream, h->blk_mask, nblocks, h->blk_words);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(words, h->blk_words, sizeof(words), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (invalid) *invalid = words[0] != 0;
+        if (n_resampled) *n_resampled = (int64_t)(uint32_t)words[1];
+        if (words[0] & (FLAG_NAN | FLAG_POSINF)) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights (NaN).");
+        if (check == GPF_CHECK_TRUE && words[0]) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights.");   // resample.jl:55
+    }
+    return GPF_OK;
+}
+gpf_status gpf_block_resampled(gpf_handle h, int32_t* out)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
+    if (!h->blk_mask || h->blk_last < 1) return fail(h, GPF_ERR_STATE, "gpf_block_resampled needs gpf_resample_blocks first");
+    HIP_TRY(h, hipMemcpyAsync(out, h->blk_mask, (size_t)h->blk_last * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < h->blk_last; ++i) out[i] &= 1;       // (the words also carry the blocks' validity flags)
+    return GPF_OK;
+}
+gpf_status gpf_block_stats(gpf_handle h, int64_t block_size, double* ess_out, double* lml_out)
+{
+    gpf_status s = block_checks(h, block_size, "gpf_block_stats");
+    if (s) return s;
+    if ((s = materialize(h))) return s;
+    const int64_t nblocks = (h->n + block_size - 1) / block_size;
+    if ((s = block_buffers(h, nblocks))) return s;
+    GPF_LAUNCH(k_block_stats, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, h->lw, h->n, block_size, &h->sc->lml_est, h->blk_stats, h->blk_stats + nblocks);
+    HIP_TRY(h, hipGetLastError());
+    if (ess_out) HIP_TRY(h, hipMemcpyAsync(ess_out, h->blk_stats, (size_t)nblocks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (lml_out) HIP_TRY(h, hipMemcpyAsync(lml_out, h->blk_stats + nblocks, (size_t)nblocks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return GPF_OK;
 }
 
 gpf_status gpf_resample_with_priorities(gpf_handle h, int32_t method, const double* log_priorities, int32_t sort_particles,

@@ -132,6 +132,27 @@ gpf_status gpf_resample(gpf_handle h, int32_t method, double priority_alpha, int
  * like gpf_resample's.  On a shard of a sharded filter this is the communication-free "island" resample. */
 gpf_status gpf_resample_local(gpf_handle h, int32_t method, int32_t sort_particles, int32_t check, int32_t* invalid);
 
+/* Many small filters in one state -- the batched form of
+ *     for b in blocks; if effective_sample_size(state[b]) < ess_frac * length(b); pf_resample!(state[b], method; sort_particles, check); end; end
+ * (sub-states: src/view.jl:16-48, src/resample.jl:185-187,205-218; the README loop README.md:60-79 per block; the reference's own
+ * tests run N = 100).  The particles are cut into consecutive blocks of block_size (<= 2048; the last block may be shorter); ONE launch
+ * resamples every block out of LDS with the sub-state semantics: normalised over the block, log_ml_est untouched, every particle of
+ * a resampled block carries logsumexp(block weights) - log(block size), parents local to the block.  Block b's result is
+ * bit-identical to the same call on a view of the block (gpf_view_create + gpf_resample), all blocks under the call's one epoch.
+ *   ess_frac:    >= 0: a block resamples only if its effective sample size is below ess_frac x its size (decided on the device;
+ *                an invalid block -- ESS NaN -- does not);  < 0 or NaN: every block resamples.
+ *   check / invalid: as gpf_resample, over all blocks; blocks with NaN / +Inf weights (and, with GPF_CHECK_TRUE, all -Inf blocks)
+ *                are left as they stand, the other blocks resample, and the call returns GPF_ERR_INVALID_WEIGHTS.
+ *   n_resampled: if non-NULL receives the number of blocks that resampled (synchronises).
+ * Not on sharded filters, views or filters with a trajectory store (GPF_ERR_STATE). */
+gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size, int32_t sort_particles, double ess_frac,
+                               int32_t check, int32_t* invalid, int64_t* n_resampled);
+/* which blocks the last gpf_resample_blocks resampled: out[ceil(n / block_size)] (host), 1 / 0 */
+gpf_status gpf_block_resampled(gpf_handle h, int32_t* out);
+/* effective_sample_size(state[b]) and log_ml_estimate(state[b]) = log_ml_est + logsumexp(block weights) - log(block size) of every block
+ * (src/utils.jl:163-178); host arrays of ceil(n / block_size) doubles, either may be NULL */
+gpf_status gpf_block_stats(gpf_handle h, int64_t block_size, double* ess_out, double* lml_out);
+
 /* same, with log_priorities = priority_fn.(log_weights) evaluated by the caller (any closure):
  * log_priorities is a HOST array of n_particles doubles. */
 gpf_status gpf_resample_with_priorities(gpf_handle h, int32_t method, const double* log_priorities,

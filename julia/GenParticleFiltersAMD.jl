@@ -141,6 +141,35 @@ function pf_resample!(s::DeviceParticleFilterState, method::Symbol=:multinomial;
     error("Resampling method $method not recognized.")
 end
 
+# Many small filters in one state: the batched form of
+#     for b in blocks; (ess_frac === nothing || get_ess(state[b]) < ess_frac * length(b)) && pf_resample!(state[b], method; ...); end
+# over consecutive blocks of block_size particles (<= 2048) in ONE launch (gpf.h gpf_resample_blocks; sub-state semantics of
+# src/resample.jl:185-187,205-218, README.md:60-79 per block).  Returns the number of blocks that resampled.
+function pf_resample_blocks!(s::DeviceParticleFilterState, block_size::Int, method::Symbol=:multinomial;
+                             ess_frac=nothing, sort_particles::Bool=true, check=:warn)
+    m = method == :multinomial ? 0 : method == :residual ? 1 : method == :stratified ? 2 : error("Resampling method $method not recognized.")
+    chk = check === true ? 2 : (check === :warn ? 1 : 0)
+    invalid = Ref{Cint}(0); count = Ref{Int64}(0)
+    st = ccall((:gpf_resample_blocks, libgpf), Cint, (Ptr{Cvoid}, Cint, Int64, Cint, Cdouble, Cint, Ptr{Cint}, Ptr{Int64}),
+               s.handle, m, block_size, sort_particles ? 1 : 0, ess_frac === nothing ? NaN : Float64(ess_frac), chk, invalid, count)
+    check(s, st)
+    check === :warn && invalid[] != 0 && @warn("Invalid weights in some block: resampled with uniform weights.")
+    return Int(count[])
+end
+"(effective_sample_size(state[b]), log_ml_estimate(state[b])) of every block of block_size particles (src/utils.jl:163-178), one launch"
+function block_stats(s::DeviceParticleFilterState, block_size::Int)
+    nb = cld(s.n_particles, block_size)
+    ess = Vector{Float64}(undef, nb); lml = Vector{Float64}(undef, nb)
+    check(s, ccall((:gpf_block_stats, libgpf), Cint, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}), s.handle, block_size, ess, lml))
+    return ess, lml
+end
+"which blocks the last pf_resample_blocks! resampled"
+function block_resampled(s::DeviceParticleFilterState, block_size::Int)
+    out = Vector{Cint}(undef, cld(s.n_particles, block_size))
+    check(s, ccall((:gpf_block_resampled, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cint}), s.handle, out))
+    return out .!= 0
+end
+
 # src/rejuvenate.jl:18-90 with the native kernels (Gen.mh / move_reweight on the current step's latent)
 function pf_rejuvenate!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1; method::Symbol=:move)
     m = method == :move ? 0 : method == :reweight ? 1 : error("Method $method not recognized.")

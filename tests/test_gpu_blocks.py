@@ -1,0 +1,216 @@
+"""Many small filters in one state: gpf_resample_blocks / gpf_block_stats (gpf_k_block.hpp K11) -- the batched form of the
+reference's loop over sub-states `for b in blocks; pf_resample!(state[b], method); end` (src/view.jl:16-48,
+src/resample.jl:185-187,205-218; block-wise resampling test/resample.jl:130-162; the README loop README.md:60-79 per block).
+Every block must equal the oracle's sub-state resample of that block bit for bit, all blocks under one epoch."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+METHODS = ["multinomial", "residual", "stratified"]
+
+
+def make(g, o, model_name, N, seed=11, keep_prev=False, T=6):
+    m = g.models.by_name(model_name); ys = g.models.simulate(m, T)
+    st = g.pf_initialize(m, (1,), ys[0], N, seed=seed, keep_prev=keep_prev)
+    f = o.OracleFilter(m.model_id, m.params, N, seed, keep_prev=keep_prev).initialize(ys[0])
+    return m, ys, st, f
+
+
+def oracle_blocks(f, nb, method, ess_frac=None, sort_particles=True, check=False):
+    """the loop over sub-states, every block under the call's one epoch; returns the mask of the blocks that resampled"""
+    e, mask = f.epoch, []
+    for b0 in range(0, f.n, nb):
+        v = f[b0:min(b0 + nb, f.n)]
+        f.epoch = e
+        go = ess_frac is None or v.effective_sample_size() < ess_frac * v.n
+        if go:
+            v.resample(method, sort_particles=sort_particles, check=check)
+        mask.append(bool(go))
+    f.epoch = e + 1
+    return np.array(mask)
+
+
+def same(st, f):
+    return np.array_equal(st.traces, f.rows) and np.array_equal(st.log_weights, f.lw, equal_nan=True) and np.array_equal(st.parents, f.parents)
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("sort_particles", [False, True])
+@pytest.mark.parametrize("N,nb", [(100, 100), (1000, 100), (4096, 2048), (5000, 2048), (777, 64), (37, 1), (2500, 1000), (300, 7),
+                                  (3000, 300), (2100, 512), (1000, 129), (640, 128), (1539, 513)])   # (<= 128: a wave, 2 per lane; <= 512: a wave, 8 per lane; else a workgroup)
+def test_blocks_equal_the_loop_over_substates(g, o, method, sort_particles, N, nb):
+    if sort_particles and method != "stratified":
+        pytest.skip("sort_particles is a stratified option")
+    m, ys, st, f = make(g, o, "lgssm2", N)
+    for t in range(1, 4):
+        g.pf_update(st, (t + 1,), (None,), ys[t]); f.update(ys[t])
+        n_res = g.pf_resample_blocks(st, nb, method, sort_particles=sort_particles, check=False)
+        mask = oracle_blocks(f, nb, method, sort_particles=sort_particles)
+        assert n_res == mask.sum() == (N + nb - 1) // nb
+        assert same(st, f), (method, sort_particles, N, nb, t)
+        ess, lml = g.block_stats(st, nb)
+        for k, b0 in enumerate(range(0, N, nb)):
+            v = f[b0:min(b0 + nb, N)]
+            assert ess[k] == v.effective_sample_size() and lml[k] == v.log_ml_estimate()
+    assert g.get_lml_est(st) == f.log_ml_estimate()                    # the whole filter's estimate: sub-states never touch log_ml_est
+    st.close()
+
+
+@pytest.mark.parametrize("model_name,keep_prev", [("bearings4", True), ("sv1", True), ("bearings4", False), ("object_motion", False)])
+@pytest.mark.parametrize("method", METHODS)
+def test_blocks_other_row_widths(g, o, model_name, keep_prev, method):
+    m, ys, st, f = make(g, o, model_name, 1200, keep_prev=keep_prev)
+    for t in range(1, 4):
+        g.pf_update(st, (t + 1,), (None,), ys[t]); f.update(ys[t])
+        g.pf_resample_blocks(st, 100, method, check=False); oracle_blocks(f, 100, method)
+        assert same(st, f), (model_name, method, t)
+    st.close()
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("ess_frac", [0.5, 0.9, 0.05, 2.0])
+def test_ess_triggered_per_block(g, o, method, ess_frac):
+    """`if effective_sample_size(state[b]) < ess_frac * N; pf_resample!(state[b]); end` decided on the device, block by block"""
+    N, nb = 3000, 100
+    m, ys, st, f = make(g, o, "bearings4", N, keep_prev=True, T=12)
+    seen = set()
+    for t in range(1, 10):
+        g.pf_update(st, (t + 1,), (None,), ys[t]); f.update(ys[t])
+        n_res = g.pf_resample_blocks(st, nb, method, ess_frac=ess_frac, check=False)
+        mask = oracle_blocks(f, nb, method, ess_frac=ess_frac)
+        assert n_res == mask.sum() and np.array_equal(g.block_resampled(st), mask)
+        assert same(st, f), (method, ess_frac, t)
+        seen.add(int(n_res))
+    if ess_frac == 2.0:
+        assert seen == {N // nb}                                         # ESS <= N: every block, every step
+    if ess_frac == 0.05:
+        assert len(seen) > 1                                             # some steps resample some of the blocks only
+    st.close()
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_first_block_equals_a_device_view(g, o, method):
+    """the same resample through the device's own view of block 0 (gpf_view_create + gpf_resample; its epoch is the call's epoch
+    in both forms): identical particles, weights, parents"""
+    N, nb = 600, 100
+    m, ys, st, f = make(g, o, "lgssm2", N)
+    st2 = g.pf_initialize(m, (1,), ys[0], N, seed=11)
+    g.pf_update(st, (2,), (None,), ys[1]); g.pf_update(st2, (2,), (None,), ys[1])
+    g.pf_resample_blocks(st, nb, method, check=False)
+    g.pf_resample(st2[0:nb], method, check=False)
+    assert np.array_equal(st.traces[:nb], st2.traces[:nb]) and np.array_equal(st.log_weights[:nb], st2.log_weights[:nb])
+    assert np.array_equal(st.parents[:nb], st2.parents[:nb])
+    st.close(); st2.close()
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_adversarial_block_weights(g, o, method):
+    """blocks with equal weights, one dominant particle, all -Inf (uniform fallback, flagged invalid), wide ranges, -Inf-heavy"""
+    N, nb = 1000, 100
+    m, ys, st, f = make(g, o, "lgssm2", N)
+    rng = np.random.default_rng(5)
+    lw = np.concatenate([np.zeros(nb), np.where(np.arange(nb) == 17, 0.0, -800.0), np.full(nb, -np.inf), -700.0 * rng.random(nb),
+                         np.where(rng.random(nb) < 0.8, -np.inf, -rng.random(nb)), -1e-9 * rng.random(nb), np.full(nb, -3.25),
+                         -np.arange(nb, dtype=np.float64), np.where(np.arange(nb) % 2 == 0, -0.0, 0.0), -50.0 * rng.random(nb) ** 4])
+    st.log_weights = lw; f.lw = lw.copy()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        g.pf_resample_blocks(st, nb, method, check="warn")
+        assert any("Invalid weights" in str(x.message) for x in w)       # the all -Inf block
+    oracle_blocks(f, nb, method, check="warn")
+    assert same(st, f)
+    g.pf_update(st, (2,), (None,), ys[1]); f.update(ys[1])
+    assert same(st, f)
+    st.close()
+
+
+def test_invalid_blocks_are_reported_and_left_alone(g, o):
+    N, nb = 400, 100
+    m, ys, st, f = make(g, o, "lgssm2", N)
+    g.pf_update(st, (2,), (None,), ys[1]); f.update(ys[1])
+    lw = st.log_weights.copy(); lw[150] = np.nan; lw[300:400] = -np.inf
+    st.log_weights = lw; f.lw = lw.copy()
+    rows0 = st.traces.copy()
+    with pytest.raises(g.ErrorException, match="Invalid weights"):
+        g.pf_resample_blocks(st, nb, "multinomial", check=False)          # NaN always raises (the reference's Categorical rejects it)
+    # blocks 0, 2, 3 resampled (3: uniform fallback), block 1 untouched
+    e = f.epoch
+    for b in (0, 2, 3):
+        f.epoch = e; f[b * nb:(b + 1) * nb].resample("multinomial", check=False)
+    f.epoch = e + 1
+    assert np.array_equal(st.traces, f.rows) and np.array_equal(st.traces[100:200], rows0[100:200])
+    assert np.array_equal(st.log_weights, f.lw, equal_nan=True)
+    assert np.array_equal(g.block_resampled(st), [True, False, True, True])
+    # check = true: the all -Inf block is refused as well
+    lw = st.log_weights.copy(); lw[150] = -1.0; lw[0:100] = -np.inf
+    st.log_weights = lw; f.lw = lw.copy()
+    with pytest.raises(g.ErrorException, match="Invalid weights"):
+        g.pf_resample_blocks(st, nb, "residual", check=True)
+    e = f.epoch
+    for b in (1, 2, 3):
+        f.epoch = e; f[b * nb:(b + 1) * nb].resample("residual", check=False)
+    f.epoch = e + 1
+    assert np.array_equal(st.traces, f.rows) and np.array_equal(st.log_weights, f.lw, equal_nan=True)
+    st.close()
+
+
+def test_readme_loop_per_block(g, o):
+    """README.md:60-79 on 200 filters of 100 particles at once: update, ESS-triggered residual resample per block, MH move"""
+    N, nb = 20_000, 100
+    m, ys, st, f = make(g, o, "object_motion", N, keep_prev=True, T=10)
+    for t in range(1, 9):
+        g.pf_update(st, (t + 1,), (None,), ys[t]); f.update(ys[t])
+        g.pf_resample_blocks(st, nb, "residual", ess_frac=0.5, check=False); oracle_blocks(f, nb, "residual", ess_frac=0.5)
+        g.pf_rejuvenate(st, None, (), 1, method="move"); f.rejuvenate("move", 1)
+        assert same(st, f), t
+    ess, lml = g.block_stats(st, nb)
+    assert all(lml[k] == f[k * nb:(k + 1) * nb].log_ml_estimate() for k in range(0, N // nb, 17))
+    assert np.isfinite(lml).all() and lml.std() > 0                     # 200 independent estimates of the same log p(y)
+    st.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_sequences_with_block_resamples(g, o, seed):
+    rng = np.random.default_rng(100 + seed)
+    N = int(rng.choice([500, 1024, 3001])); nb = int(rng.choice([50, 128, 2048, 999, 300, 512]))
+    m, ys, st, f = make(g, o, "bearings4", N, keep_prev=True, T=40)
+    t = 1
+    for _ in range(25):
+        op = rng.choice(["update", "blocks", "blocks_ess", "whole", "move", "stats"], p=[0.3, 0.25, 0.15, 0.1, 0.1, 0.1])
+        method = str(rng.choice(METHODS)); sp = bool(rng.integers(2))
+        if op == "update":
+            g.pf_update(st, (t + 1,), (None,), ys[t]); f.update(ys[t]); t += 1
+        elif op == "blocks":
+            g.pf_resample_blocks(st, nb, method, sort_particles=sp, check=False); oracle_blocks(f, nb, method, sort_particles=sp)
+        elif op == "blocks_ess":
+            fr = float(rng.choice([0.3, 0.6, 0.95]))
+            assert g.pf_resample_blocks(st, nb, method, ess_frac=fr, sort_particles=sp, check=False) == oracle_blocks(f, nb, method, ess_frac=fr, sort_particles=sp).sum()
+        elif op == "whole":
+            kw = {"sort_particles": sp} if method == "stratified" else {}
+            g.pf_resample(st, method, check=False, **kw); f.resample(method, check=False, **kw)
+        elif op == "move":
+            g.pf_rejuvenate(st, None, (), 1, method="move"); f.rejuvenate("move", 1)
+        else:
+            ess, lml = g.block_stats(st, nb)
+            k = int(rng.integers(len(ess))); v = f[k * nb:min((k + 1) * nb, N)]
+            assert (ess[k] == v.effective_sample_size() or (np.isnan(ess[k]) and np.isnan(v.effective_sample_size()))) and lml[k] == v.log_ml_estimate()
+        assert same(st, f), (seed, op, method)
+    assert g.get_lml_est(st) == f.log_ml_estimate()
+    st.close()
+
+
+def test_argument_errors(g, o):
+    m, ys, st, f = make(g, o, "lgssm2", 300)
+    with pytest.raises(g.ErrorException):
+        g.pf_resample_blocks(st, 4096, "multinomial")
+    with pytest.raises(g.ErrorException):
+        g.pf_resample_blocks(st, 0, "multinomial")
+    with pytest.raises(g.ErrorException, match="not recognized"):
+        g.pf_resample_blocks(st, 100, "systematic")
+    with pytest.raises(g.ErrorException):
+        g.pf_resample_blocks(st[0:100], 50, "multinomial")
+    with pytest.raises(g.ErrorException):
+        g.block_resampled(g.pf_initialize(m, (1,), ys[0], 10, seed=1))
+    st.close()
