@@ -46,6 +46,9 @@ SYMBOLS = [
     ("gpf_resample_blocks", C.c_int, [_H, C.c_int32, C.c_int64, C.c_int32, C.c_double, C.c_int32, _pi32, C.POINTER(C.c_int64)]),
     ("gpf_block_resampled", C.c_int, [_H, _pi32]),
     ("gpf_block_stats", C.c_int, [_H, C.c_int64, _pd, _pd]),
+    ("gpf_initialize_blocks", C.c_int, [_H, _pd, C.c_int32, C.c_int64]),
+    ("gpf_update_blocks", C.c_int, [_H, _pd, C.c_int32, C.c_int64]),
+    ("gpf_rejuvenate_blocks", C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     ("gpf_resample_with_priorities", C.c_int, [_H, C.c_int32, _pd, C.c_int32, C.c_int32, _pi32]),
     ("gpf_rejuvenate", C.c_int, [_H, C.c_int32, C.c_int32, _pu64]),
     ("gpf_rejuvenate_proposal", C.c_int, [_H, C.c_int32, _pd, C.c_int32, C.c_int32]),

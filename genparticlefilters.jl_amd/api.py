@@ -402,6 +402,44 @@ def pf_resample_blocks(state, block_size: int, method: str = "multinomial", *, e
     return int(cnt.value)
 
 
+def _block_obs(state, observations, block_size: int) -> np.ndarray:
+    nb = (state.n_particles + int(block_size) - 1) // int(block_size)
+    obs = np.ascontiguousarray(observations, np.float64)
+    if obs.ndim == 1:
+        obs = obs.reshape(nb, -1)
+    if obs.ndim != 2 or obs.shape[0] != nb:
+        raise ErrorException(f"one observation vector per block expected: {nb} rows, got an array of shape {obs.shape}")
+    return obs
+
+
+def pf_initialize_blocks(model: NativeModel, model_args: tuple, observations, n_particles: int, block_size: int, *, seed: int = 1,
+                         keep_prev: bool = False, device: int = 0):
+    """many small filters in one state, each with its own data: block b (block_size consecutive particles) is initialised with
+    observations[b] -- the batched form of per-view initialisation (gpf.h gpf_initialize_blocks)"""
+    state = DeviceParticleFilterState(model, n_particles, seed=seed, keep_prev=keep_prev, device=device)
+    obs = _block_obs(state, observations, block_size)
+    state._check(state._L.gpf_initialize_blocks(state._h, _pd(obs), obs.shape[1], int(block_size)))
+    return state
+
+
+def pf_update_blocks(state, new_args: tuple, argdiffs: tuple, observations, block_size: int):
+    """for b in blocks: pf_update!(state[b], new_args, argdiffs, observations[b]) (per-view updates, test/update.jl:179-189) in one launch"""
+    obs = _block_obs(state, observations, block_size)
+    state._check(state._L.gpf_update_blocks(state._h, _pd(obs), obs.shape[1], int(block_size)))
+    return state
+
+
+def pf_rejuvenate_blocks(state, kern=None, kern_args: tuple = (), n_iters: int = 1, *, method: str = "move", only_resampled: bool = False,
+                         count: bool = False):
+    """for b in blocks: pf_rejuvenate!(state[b], ...) with the block's own latest observation; only_resampled: only the blocks the last
+    pf_resample_blocks resampled (the README loop rejuvenates inside its `if`)"""
+    if method not in REJUVENATE_METHODS:
+        raise ErrorException(f"Method {method} not recognized.")
+    acc = C.c_uint64(0)
+    state._check(state._L.gpf_rejuvenate_blocks(state._h, REJUVENATE_METHODS[method], int(n_iters), int(only_resampled), C.byref(acc) if count else None))
+    return int(acc.value) if count else state
+
+
 def block_resampled(state) -> np.ndarray:
     """which blocks the last pf_resample_blocks resampled (bool per block)"""
     out = np.zeros(getattr(state, "_n_blocks_last", 0), np.int32)

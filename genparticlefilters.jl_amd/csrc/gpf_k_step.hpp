@@ -46,7 +46,7 @@ __device__ __forceinline__ int stratum_of(const ModelArgs& a, uint64_t seed, uin
 // row out, lw += log p(y|x).  Counter-based RNG: no RNG state in memory.
 // MODE 0: the model's own sampler; 1: native custom proposal; 2: stratified (the discrete latent constrained per stratum);
 // 3 (k_init only): stratified with a native proposal for the other choice
-template <int M, int MODE = 0>
+template <int M, int MODE = 0, bool BLK = false>
 __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, int W, double* __restrict__ rows,
                                                 double* __restrict__ lw, MaxSlots ms)
@@ -56,17 +56,18 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         double x[MAX_DIM];
         double ll;
-        if constexpr (MODE == 1) ll = Mo::propose(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
+        const double* const ob = obs_of<BLK>(a, i);
+        if constexpr (MODE == 1) ll = Mo::propose(a.P, true, nullptr, ob, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
         else if constexpr (MODE == 2) {
             const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
-            const double lp = Mo::sample_stratum(a.P, true, nullptr, a.obs, v, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
-            ll = (lp + Mo::loglik(a.P, x, a.obs)) + a.logK;                      // initialize.jl:103-104
+            const double lp = Mo::sample_stratum(a.P, true, nullptr, ob, v, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
+            ll = (lp + Mo::loglik(a.P, x, ob)) + a.logK;                      // initialize.jl:103-104
         } else if constexpr (MODE == 3) {                                        // strata + native proposal, initialize.jl:122-126
             const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
-            ll = Mo::propose_stratum(a.P, a.obs, v, x) + a.logK;
+            ll = Mo::propose_stratum(a.P, ob, v, x) + a.logK;
         } else {
-            Mo::sample(a.P, true, nullptr, a.obs, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
-            ll = Mo::loglik(a.P, x, a.obs);
+            Mo::sample(a.P, true, nullptr, ob, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
+            ll = Mo::loglik(a.P, x, ob);
         }
         double* r = rows + i * W;
 #pragma unroll
@@ -91,7 +92,7 @@ struct PackedCommit {
     const double* lw_fill;     // GATHER after gpf_resample_local: the incoming log-weights are this constant, not 0 (resample.jl:210)
     int in_mailbox;            // mf_all / tot_all sit in the shard mailbox (written by peers: system-scope loads)
 };
-template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false>
+template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false, bool BLK = false>
 __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
@@ -132,14 +133,15 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
         }
         double xn[MAX_DIM];
         double ll;
-        if constexpr (MODE == 1) ll = Mo::propose(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
+        const double* const ob = obs_of<BLK>(a, i);
+        if constexpr (MODE == 1) ll = Mo::propose(a.P, false, r, ob, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
         else if constexpr (MODE == 2) {
             const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_UPDATE)];
-            const double lp = Mo::sample_stratum(a.P, false, r, a.obs, v, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
-            ll = (lp + Mo::loglik(a.P, xn, a.obs)) + a.logK;                     // update.jl:201-206
+            const double lp = Mo::sample_stratum(a.P, false, r, ob, v, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
+            ll = (lp + Mo::loglik(a.P, xn, ob)) + a.logK;                     // update.jl:201-206
         } else {
-            Mo::sample(a.P, false, r, a.obs, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
-            ll = Mo::loglik(a.P, xn, a.obs);
+            Mo::sample(a.P, false, r, ob, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
+            ll = Mo::loglik(a.P, xn, ob);
         }
         double o[W];
 #pragma unroll
@@ -178,7 +180,8 @@ __global__ void k_sum_accepts(const unsigned long long* __restrict__ part, int n
 }
 // PROP (with REWEIGHT): move_reweight(trace, proposal, proposal_args) (rejuvenate.jl:134-148) with the model's native move proposal
 // (Model::move_propose): the new latent comes from the proposal, rel_weight = weight - fwd_score + bwd_score.
-template <int M, int W, bool REWEIGHT, bool GATHER = false, bool PROP = false>
+// BLK: block-wise (ModelArgs::blk_*): the observation of the particle's block; blocks whose mask bit is clear keep their particles
+template <int M, int W, bool REWEIGHT, bool GATHER = false, bool PROP = false, bool BLK = false>
 __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, int has_prev, int n_iters, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
@@ -199,21 +202,24 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
 #pragma unroll
         for (int k = 0; k < D; ++k) x[k] = r[k];
         const double* xp = r + D;                    // x_{t-1} (valid when has_prev)
-        double llx = Mo::loglik(a.P, x, a.obs);
+        const double* const ob = obs_of<BLK>(a, i);
+        const bool live = !(BLK && a.blk_mask && !(a.blk_mask[(uint32_t)i / (uint32_t)a.blk_size] & 1));
+        const int iters = live ? n_iters : 0;
+        double llx = Mo::loglik(a.P, x, ob);
         double wsum = 0.0;
         const uint32_t gid = (uint32_t)(gid0 + i * a.gstride);
-        for (int it = 0; it < n_iters; ++it) {
+        for (int it = 0; it < iters; ++it) {
             if constexpr (PROP) {
                 if constexpr (Mo::HAS_MOVE_PROPOSAL) {
-                    const double rw = Mo::move_propose(a.P, a.q, !has_prev, xp, x, a.obs, seed, gid, (uint32_t)(it * NB), epoch, TAG_REWEIGHT, xs);
+                    const double rw = Mo::move_propose(a.P, a.q, !has_prev, xp, x, ob, seed, gid, (uint32_t)(it * NB), epoch, TAG_REWEIGHT, xs);
                     wsum = wsum + rw;                                          // rejuvenate.jl:86
 #pragma unroll
                     for (int k = 0; k < D; ++k) x[k] = xs[k];
                     ++acc;
                 }
             } else if (REWEIGHT) {
-                Mo::sample(a.P, !has_prev, xp, a.obs, seed, gid, (uint32_t)(it * NB), epoch, TAG_REWEIGHT, xs);
-                const double lls = Mo::loglik(a.P, xs, a.obs);
+                Mo::sample(a.P, !has_prev, xp, ob, seed, gid, (uint32_t)(it * NB), epoch, TAG_REWEIGHT, xs);
+                const double lls = Mo::loglik(a.P, xs, ob);
                 wsum = wsum + (lls - llx);
 #pragma unroll
                 for (int k = 0; k < D; ++k) x[k] = xs[k];
@@ -221,8 +227,8 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
                 ++acc;
             } else {
                 const uint32_t blk0 = (uint32_t)(it * (NB + 1));
-                Mo::sample(a.P, !has_prev, xp, a.obs, seed, gid, blk0, epoch, TAG_MOVE, xs);
-                const double lls = Mo::loglik(a.P, xs, a.obs);
+                Mo::sample(a.P, !has_prev, xp, ob, seed, gid, blk0, epoch, TAG_MOVE, xs);
+                const double lls = Mo::loglik(a.P, xs, ob);
                 const Philox b = rng(seed, gid, blk0 + NB, epoch, TAG_MOVE);
                 const double lu = log_(u52(b.w0, b.w1));
                 if (lu < lls - llx) {
@@ -238,7 +244,11 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
         double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(r[2 * c], r[2 * c + 1]);
-        if (REWEIGHT) { const double nl = (GATHER ? 0.0 : lw[i]) + wsum; lw[i] = nl; track_max(nl, bm, bf); }
+        if (REWEIGHT) {
+            double nl;
+            if (live) { nl = (GATHER ? 0.0 : lw[i]) + wsum; lw[i] = nl; } else nl = lw[i];       // (a masked block: weights untouched)
+            track_max(nl, bm, bf);
+        }
         else if (GATHER) lw[i] = 0.0;
     }
     // accepted moves: one plain store per workgroup, summed on demand (k_sum_accepts) when the host asks for the count.  (One

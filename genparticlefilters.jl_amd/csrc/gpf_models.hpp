@@ -31,7 +31,17 @@ struct ModelArgs {          // passed by value in the kernarg segment: no device
     // gid0 + i * gstride of the filter and keeps THAT id as its RNG counter (1 everywhere else)
     int32_t gstride, pad_;
     double q[4];                 // parameters of a native MOVE proposal (gpf_rejuvenate_proposal), e.g. {p, log p, log(1 - p)}
+    // block-wise operations (many small filters in one state, gpf_update_blocks & co.): particle i belongs to block i / blk_size and
+    // sees that block's observation blk_obs[block][MAX_OBS]; blk_mask (rejuvenation): bit 0 of word [block] = the block takes part
+    const double* blk_obs; const int32_t* blk_mask; int32_t blk_size, pad2_;
 };
+// the observation particle i conditions on
+template <bool BLK>
+__device__ __forceinline__ const double* obs_of(const ModelArgs& a, int64_t i)
+{
+    if constexpr (BLK) return a.blk_obs + (size_t)((uint32_t)i / (uint32_t)a.blk_size) * MAX_OBS;
+    else return a.obs;
+}
 
 template <int M> struct Model;
 

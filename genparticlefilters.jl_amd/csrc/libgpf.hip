@@ -139,6 +139,8 @@ struct gpf_filter {
     int64_t* h_shard_counts = nullptr;
     // block-wise resampling (gpf_resample_blocks): {flags, count} words, the per-block mask, per-block statistics
     int32_t* blk_words = nullptr; int32_t* blk_mask = nullptr; double* blk_stats = nullptr; int64_t blk_cap = 0, blk_last = 0;
+    double* blk_obs = nullptr; double* h_blk_obs = nullptr; int64_t blk_obs_cap = 0;   // per-block observations [n_blocks][MAX_OBS] (device, pinned staging)
+    int64_t blk_obs_size = 0;                                                          // > 0: the latest observations are per block, blocks of this size
     // the pull plan (gpf_comm_set_plan): request lists [G][n], their counters, the dense / gathered request matrix and its pinned mirror
     int shard_plan_kind = 0;
     ulonglong2* pull_req = nullptr; int64_t pull_req_cap = 0;
@@ -867,6 +869,28 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
     return GPF_OK;
 }
 
+// block-wise propagate / move (ModelArgs::blk_*): the default proposal only, no fused gather (a block resample gathers eagerly)
+template <int M>
+void launch_init_blk(gpf_filter* h, int grid)
+{
+    GPF_LAUNCH((k_init<M, 0, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                       h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw, next_slots(h));
+}
+template <int M, bool KEEP>
+void launch_step_blk(gpf_filter* h, int grid)
+{
+    constexpr int Wc = row_width(Model<M>::D, KEEP);
+    GPF_LAUNCH((k_step<M, Wc, KEEP, false, 0, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                       h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, next_slots(h), PackedCommit{});
+}
+template <int M, bool RW>
+void launch_move_blk(gpf_filter* h, int grid, int n_iters)
+{
+    constexpr int Wc = row_width(Model<M>::D, true);
+    GPF_LAUNCH((k_move<M, Wc, RW, false, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                       h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
+                       h->acc_part, RW ? next_slots(h) : MaxSlots{nullptr, nullptr});
+}
 // a block of <= 128 / <= 512 particles is the work of one wave (2 / 8 particles per lane, four blocks per workgroup), a larger one of a workgroup
 template <int METHOD, int Wc>
 void launch_block_resample_w(gpf_filter* h, const BlockArgs& a)
@@ -1170,12 +1194,13 @@ gpf_status gpf_destroy(gpf_handle h)
     for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc}) if (q) (void)hipFree(q);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
     void* bufs[] = {h->mslots[0], h->mslots[1], h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf, h->acc_part,
-                    h->pull_req, h->pull_counts, h->pull_pc, h->pull_pc_all, h->blk_words, h->blk_mask, h->blk_stats};
+                    h->pull_req, h->pull_counts, h->pull_pc, h->pull_pc_all, h->blk_words, h->blk_mask, h->blk_stats, h->blk_obs};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->h_sc) hipHostFree(h->h_sc);
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
     if (h->h_pull_pc_all) hipHostFree(h->h_pull_pc_all);
+    if (h->h_blk_obs) hipHostFree(h->h_blk_obs);
     if (h->h_flags) hipHostFree(h->h_flags);
     if (h->h_sort_flag) hipHostFree(h->h_sort_flag);
     if (h->h_timeout) hipHostFree(h->h_timeout);
@@ -1201,6 +1226,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
     h->generation += 1;
     gpf_status s = set_obs(h, obs, n_obs);
     if (s) return s;
+    h->blk_obs_size = 0;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if ((s = hist_begin_step(h, true))) return s;
     const int grid = step_grid(h);
@@ -1247,6 +1273,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
     if (prop == 1 && !model_has_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no native proposal");
     if (prop == 2 && !model_has_strata(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no discrete latent to stratify over");
     if ((s = set_obs(h, obs, n_obs))) return s;
+    h->blk_obs_size = 0;                                         // one observation for all particles again
     if ((s = hist_begin_step(h, false))) return s;
     const int grid = step_grid(h);
     const bool keep = h->cfg.keep_prev != 0;
@@ -1431,6 +1458,130 @@ gpf_status gpf_block_stats(gpf_handle h, int64_t block_size, double* ess_out, do
     return GPF_OK;
 }
 
+// the blocks' observation vectors -> device ([n_blocks][MAX_OBS], zero-padded), ModelArgs::blk_* set
+static gpf_status set_block_obs(gpf_filter* h, const double* obs, int32_t n_obs, int64_t block_size)
+{
+    if (!obs || n_obs != model_obs_dim(h->cfg.model))
+        return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model takes " + std::to_string(model_obs_dim(h->cfg.model)) + " observation values per step and block");
+    const int64_t nblocks = (h->n + block_size - 1) / block_size;
+    if (h->blk_obs_cap < nblocks) {
+        if (h->blk_obs) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->blk_obs); (void)hipHostFree(h->h_blk_obs); h->blk_obs = nullptr; h->h_blk_obs = nullptr; h->blk_obs_cap = 0; }
+        HIP_TRY(h, hipMalloc(&h->blk_obs, (size_t)nblocks * MAX_OBS * sizeof(double)));
+        HIP_TRY(h, hipHostMalloc(&h->h_blk_obs, (size_t)nblocks * MAX_OBS * sizeof(double)));
+        h->blk_obs_cap = nblocks;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));                 // (the staging buffer of the previous call is read by an asynchronous copy)
+    for (int64_t b = 0; b < nblocks; ++b)
+        for (int i = 0; i < MAX_OBS; ++i) h->h_blk_obs[b * MAX_OBS + i] = i < n_obs ? obs[b * n_obs + i] : 0.0;
+    HIP_TRY(h, hipMemcpyAsync(h->blk_obs, h->h_blk_obs, (size_t)nblocks * MAX_OBS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->args.blk_obs = h->blk_obs; h->args.blk_mask = nullptr; h->args.blk_size = (int32_t)block_size;
+    h->blk_obs_size = block_size;
+    return GPF_OK;
+}
+static gpf_status block_step_checks(gpf_handle h, int64_t block_size, const char* who)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (h->parent) return fail(h, GPF_ERR_STATE, std::string(who) + " on a sub-state view: call it on the filter");
+    if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, std::string(who) + " on a shard of a sharded filter");
+    if (h->hist_on) return fail(h, GPF_ERR_STATE, std::string(who) + " on a filter with a trajectory store");
+    if (block_size < 1 || block_size > BLK_MAX) return fail(h, GPF_ERR_INVALID_ARGUMENT, "block_size: 1 .. 2048 particles");
+    return GPF_OK;
+}
+gpf_status gpf_initialize_blocks(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size)
+{
+    gpf_status s = block_step_checks(h, block_size, "gpf_initialize_blocks");
+    if (s) return s;
+    h->generation += 1;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if ((s = set_block_obs(h, obs, n_obs, block_size))) return s;
+    const int grid = step_grid(h);
+    s = timed(h, GPF_K_STEP, [&] { DISPATCH_MODEL(h, (launch_init_blk<MM>(h, grid))); });
+    if (s) return s;
+    h->pending_gather = false; h->pending_fill = false; h->pending_packed = false;
+    h->max_valid = true;
+    GPF_LAUNCH(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
+    HIP_TRY(h, hipMemsetAsync(&h->sc->lml_est, 0, sizeof(double), h->stream));
+    HIP_TRY(h, hipGetLastError());
+    h->epoch += 1;
+    h->initialized = true; h->has_prev = false; h->raw_valid = false;
+    mutated(h);
+    return GPF_OK;
+}
+gpf_status gpf_update_blocks(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size)
+{
+    gpf_status s = block_step_checks(h, block_size, "gpf_update_blocks");
+    if (s) return s;
+    if ((s = check_ready(h))) return s;
+    if ((s = materialize(h))) return s;                          // (no fused gather in the block-wise step)
+    if ((s = set_block_obs(h, obs, n_obs, block_size))) return s;
+    const int grid = step_grid(h);
+    const bool keep = h->cfg.keep_prev != 0;
+    s = timed(h, GPF_K_STEP, [&] {
+        if (keep) { DISPATCH_MODEL(h, (launch_step_blk<MM, true>(h, grid))); }
+        else      { DISPATCH_MODEL(h, (launch_step_blk<MM, false>(h, grid))); }
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->max_valid = true;
+    h->cur ^= 1;
+    h->epoch += 1;
+    h->has_prev = true;
+    h->raw_valid = false;
+    mutated(h);
+    return GPF_OK;
+}
+gpf_status gpf_rejuvenate_blocks(gpf_handle h, int32_t method, int32_t n_iters, int32_t only_resampled, uint64_t* n_accepted)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (h->blk_obs_size < 1) return fail(h, GPF_ERR_STATE, "gpf_rejuvenate_blocks needs gpf_initialize_blocks / gpf_update_blocks first (per-block observations)");
+    if ((s = block_step_checks(h, h->blk_obs_size, "gpf_rejuvenate_blocks"))) return s;
+    if (method != GPF_REJUVENATE_MOVE && method != GPF_REJUVENATE_REWEIGHT) return fail(h, GPF_ERR_UNKNOWN_METHOD, "Method not recognized.");   // rejuvenate.jl:25
+    if (!h->cfg.keep_prev) return fail(h, GPF_ERR_STATE, "gpf_rejuvenate needs keep_prev = 1 (x_{t-1} must travel with the particle)");
+    if (n_iters < 0) return fail(h, GPF_ERR_INVALID_ARGUMENT, "n_iters < 0");
+    if (only_resampled) {
+        const int64_t nblocks = (h->n + h->blk_obs_size - 1) / h->blk_obs_size;
+        if (!h->blk_mask || h->blk_last != nblocks) return fail(h, GPF_ERR_STATE, "only_resampled needs a gpf_resample_blocks with the same block size first");
+    }
+    if ((s = materialize(h))) return s;
+    h->args.blk_mask = only_resampled ? h->blk_mask : nullptr;
+    const int grid = move_grid(h);
+    s = timed(h, GPF_K_MOVE, [&] {
+        if (method == GPF_REJUVENATE_REWEIGHT) { DISPATCH_MODEL(h, (launch_move_blk<MM, true>(h, grid, n_iters))); }
+        else                                   { DISPATCH_MODEL(h, (launch_move_blk<MM, false>(h, grid, n_iters))); }
+    });
+    h->args.blk_mask = nullptr;
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->cur ^= 1;
+    h->epoch += 1;
+    if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; }
+    mutated(h);
+    if (n_accepted) {
+        // (move-reweight: every particle of a participating block moves; the per-workgroup counts cover both cases)
+        if (method == GPF_REJUVENATE_REWEIGHT && !only_resampled) *n_accepted = (uint64_t)h->n * (uint64_t)n_iters;
+        else if (method == GPF_REJUVENATE_REWEIGHT) {
+            int64_t nres = 0;
+            GPF_LAUNCH(k_block_summary, dim3(1), dim3(BLOCK), 0, h->stream, h->blk_mask, h->blk_last, h->blk_words);
+            int32_t words[2] = {0, 0};
+            HIP_TRY(h, hipMemcpyAsync(words, h->blk_words, sizeof(words), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            nres = (int64_t)(uint32_t)words[1];
+            // (all blocks have block_size particles except possibly the last)
+            const int64_t bs = h->blk_obs_size, last = h->n - (h->blk_last - 1) * bs;
+            int32_t last_word = 0;
+            HIP_TRY(h, hipMemcpy(&last_word, h->blk_mask + (h->blk_last - 1), sizeof(int32_t), hipMemcpyDeviceToHost));
+            *n_accepted = (uint64_t)((nres - (last_word & 1)) * bs + (last_word & 1) * last) * (uint64_t)n_iters;
+        } else {
+            GPF_LAUNCH(k_sum_accepts, dim3(1), dim3(BLOCK), 0, h->stream, h->acc_part, grid, reinterpret_cast<unsigned long long*>(&h->sc->n_accept));
+            HIP_TRY(h, hipGetLastError());
+            if ((s = fetch_scalars(h))) return s;
+            *n_accepted = h->h_sc->n_accept;
+        }
+    }
+    return GPF_OK;
+}
+
 gpf_status gpf_resample_with_priorities(gpf_handle h, int32_t method, const double* log_priorities, int32_t sort_particles,
                                         int32_t check, int32_t* invalid)
 {
@@ -1461,6 +1612,12 @@ static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters,
 {
     gpf_status s = check_ready(h);
     if (s) return s;
+    if (h->parent && h->parent->blk_obs_size > 0)
+        return fail(h, GPF_ERR_STATE, "rejuvenation of a view after a block-wise update of its filter: use gpf_rejuvenate_blocks on the filter");
+    if (h->blk_obs_size > 0 && !h->parent) {                     // the latest observations are per block (gpf_update_blocks)
+        if (with_proposal) return fail(h, GPF_ERR_STATE, "proposal moves are not available after a block-wise update");
+        return gpf_rejuvenate_blocks(h, method, n_iters, 0, n_accepted);
+    }
     if (method != GPF_REJUVENATE_MOVE && method != GPF_REJUVENATE_REWEIGHT)
         return fail(h, GPF_ERR_UNKNOWN_METHOD, "Method not recognized.");                        // rejuvenate.jl:25
     if (!h->cfg.keep_prev) return fail(h, GPF_ERR_STATE, "gpf_rejuvenate needs keep_prev = 1 (x_{t-1} must travel with the particle)");

@@ -153,6 +153,20 @@ gpf_status gpf_block_resampled(gpf_handle h, int32_t* out);
  * (src/utils.jl:163-178); host arrays of ceil(n / block_size) doubles, either may be NULL */
 gpf_status gpf_block_stats(gpf_handle h, int64_t block_size, double* ess_out, double* lml_out);
 
+/* The other steps of the loop over sub-states, block by block in one launch each (blocks as in gpf_resample_blocks):
+ *   gpf_initialize_blocks / gpf_update_blocks: block b is initialised / extended with ITS OWN observation vector
+ *     (for b in blocks; pf_update!(state[b], new_args, argdiffs, observations[b]); end -- per-view updates, test/update.jl:179-189);
+ *     obs = [n_blocks][n_obs] doubles (host), row b for block b.  Default proposal only.
+ *   gpf_rejuvenate_blocks: pf_rejuvenate!(state[b], ...) with the block's latest observation; only_resampled != 0: only in the blocks
+ *     the last gpf_resample_blocks resampled (the README loop rejuvenates inside its `if`), the others keep particles and weights.
+ *     n_accepted as in gpf_rejuvenate (over the blocks that took part).
+ * After gpf_update_blocks the whole-filter gpf_rejuvenate also uses the per-block observations; gpf_update / gpf_initialize go back
+ * to one observation for all particles.  Each call advances the epoch once; block b's result is bit-identical to the same call on a
+ * view of the block.  Not on sharded filters, views or filters with a trajectory store. */
+gpf_status gpf_initialize_blocks(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size);
+gpf_status gpf_update_blocks(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size);
+gpf_status gpf_rejuvenate_blocks(gpf_handle h, int32_t method, int32_t n_iters, int32_t only_resampled, uint64_t* n_accepted);
+
 /* same, with log_priorities = priority_fn.(log_weights) evaluated by the caller (any closure):
  * log_priorities is a HOST array of n_particles doubles. */
 gpf_status gpf_resample_with_priorities(gpf_handle h, int32_t method, const double* log_priorities,

@@ -163,6 +163,22 @@ function block_stats(s::DeviceParticleFilterState, block_size::Int)
     check(s, ccall((:gpf_block_stats, libgpf), Cint, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}), s.handle, block_size, ess, lml))
     return ess, lml
 end
+# Every block a filter on ITS OWN data: per-block initialisation / update / rejuvenation, one launch each (gpf.h gpf_initialize_blocks,
+# gpf_update_blocks, gpf_rejuvenate_blocks).  observations: a (n_obs, n_blocks) Matrix -- column b for block b.
+function pf_initialize_blocks(model::NativeModel, model_args::Tuple, observations::Matrix{Float64}, n_particles::Int, block_size::Int; kw...)
+    state = DeviceParticleFilterState(model, n_particles; kw...)
+    size(observations, 2) == cld(n_particles, block_size) || error("one observation column per block expected")
+    check(state, ccall((:gpf_initialize_blocks, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64), state.handle, observations, size(observations, 1), block_size))
+    return state
+end
+function pf_update_blocks!(s::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Matrix{Float64}, block_size::Int)
+    size(observations, 2) == cld(s.n_particles, block_size) || error("one observation column per block expected")
+    check(s, ccall((:gpf_update_blocks, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64), s.handle, observations, size(observations, 1), block_size)); s
+end
+function pf_rejuvenate_blocks!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1; method::Symbol=:move, only_resampled::Bool=false)
+    m = method == :move ? 0 : method == :reweight ? 1 : error("Method $method not recognized.")
+    check(s, ccall((:gpf_rejuvenate_blocks, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, only_resampled ? 1 : 0, C_NULL)); s
+end
 "which blocks the last pf_resample_blocks! resampled"
 function block_resampled(s::DeviceParticleFilterState, block_size::Int)
     out = Vector{Cint}(undef, cld(s.n_particles, block_size))

@@ -214,3 +214,94 @@ def test_argument_errors(g, o):
     with pytest.raises(g.ErrorException):
         g.block_resampled(g.pf_initialize(m, (1,), ys[0], 10, seed=1))
     st.close()
+
+
+# ----------------------------------------------------------------------------- per-block observations: many DATASETS in one state
+def oracle_init_blocks(o, f, nb, obs_rows):
+    """per-block initialisation: o_init on every block's slice with the block's observation (initialize.jl:39-41 per sub-state)"""
+    lib = o.lib()
+    for k, b0 in enumerate(range(0, f.n, nb)):
+        cnt = min(nb, f.n - b0)
+        rows = np.zeros((cnt, f.W)); lw = np.zeros(cnt)
+        lib.o_init(f.model, f.params, f.seed, f.epoch, b0, cnt, f.W, np.ascontiguousarray(obs_rows[k], np.float64), rows, lw)
+        f.rows[b0:b0 + cnt] = rows; f.lw[b0:b0 + cnt] = lw
+    f.lml_est = 0.0; f.parents = np.arange(1, f.n + 1, dtype=np.int64)
+    f.epoch += 1; f.has_prev = False
+    return f
+
+
+def oracle_update_blocks(f, nb, obs_rows):
+    e = f.epoch
+    for k, b0 in enumerate(range(0, f.n, nb)):
+        f.epoch = e
+        f[b0:min(b0 + nb, f.n)].update(np.asarray(obs_rows[k], np.float64))
+    f.epoch = e + 1
+
+
+def oracle_rejuvenate_blocks(f, nb, obs_rows, method, mask=None):
+    e, acc = f.epoch, 0
+    for k, b0 in enumerate(range(0, f.n, nb)):
+        if mask is not None and not mask[k]:
+            continue
+        f.epoch = e
+        v = f[b0:min(b0 + nb, f.n)]; v.last_obs = np.asarray(obs_rows[k], np.float64)
+        v.rejuvenate(method, 1); acc += v.n_accepted
+    f.epoch = e + 1
+    return acc
+
+
+@pytest.mark.parametrize("model_name", ["lgssm2", "bearings4", "object_motion", "sv1"])
+@pytest.mark.parametrize("N,nb", [(1000, 100), (1030, 100), (4096, 2048), (600, 7)])
+def test_per_block_observations(g, o, model_name, N, nb):
+    """every block is a filter on ITS OWN data: initialise / update / rejuvenate block by block in one launch each ==
+    the loop over sub-states with per-view observations (test/update.jl:179-189, test/rejuvenate.jl:73-103)"""
+    m = g.models.by_name(model_name)
+    B, T = (N + nb - 1) // nb, 6
+    rng = np.random.default_rng(7)
+    base = np.asarray(g.models.simulate(m, T))
+    ys = base[None, :, :] + 0.3 * rng.standard_normal((B,) + base.shape)           # ys[b][t]: a perturbed copy of one sequence per block
+    st = g.pf_initialize_blocks(m, (1,), ys[:, 0], N, nb, seed=13, keep_prev=True)
+    f = o.OracleFilter(m.model_id, m.params, N, 13, keep_prev=True)
+    oracle_init_blocks(o, f, nb, ys[:, 0])
+    assert same(st, f)
+    for t in range(1, T):
+        g.pf_update_blocks(st, (t + 1,), (None,), ys[:, t], nb); oracle_update_blocks(f, nb, ys[:, t])
+        assert same(st, f), (model_name, "update", t)
+        n_res = g.pf_resample_blocks(st, nb, "residual", ess_frac=0.5, check=False)
+        mask = oracle_blocks(f, nb, "residual", ess_frac=0.5)
+        assert n_res == mask.sum() and same(st, f), (model_name, "resample", t)
+        if t % 2:
+            acc = g.pf_rejuvenate_blocks(st, None, (), 1, method="move", only_resampled=True, count=True)
+            assert acc == oracle_rejuvenate_blocks(f, nb, ys[:, t], "move", mask)
+        else:
+            acc = g.pf_rejuvenate_blocks(st, None, (), 1, method="reweight", only_resampled=bool(t % 4), count=True)
+            assert acc == oracle_rejuvenate_blocks(f, nb, ys[:, t], "reweight", mask if t % 4 else None)
+        assert same(st, f), (model_name, "rejuvenate", t)
+    ess, lml = g.block_stats(st, nb)
+    for k in range(0, B, max(1, B // 7)):
+        v = f[k * nb:min((k + 1) * nb, N)]
+        assert lml[k] == v.log_ml_estimate()
+    # the whole-filter pf_rejuvenate after a block-wise update uses the per-block observations; pf_update goes back to one observation
+    g.pf_rejuvenate(st, None, (), 1, method="move"); oracle_rejuvenate_blocks(f, nb, ys[:, T - 1], "move")
+    assert same(st, f)
+    g.pf_update(st, (T + 1,), (None,), base[0]); f.update(base[0])
+    g.pf_rejuvenate(st, None, (), 1, method="move"); f.rejuvenate("move", 1)
+    assert same(st, f)
+    st.close()
+
+
+def test_block_step_argument_errors(g, o):
+    m = g.models.lgssm2(); ys = np.asarray(g.models.simulate(m, 3))
+    st = g.pf_initialize(m, (1,), ys[0], 300, seed=1, keep_prev=True)
+    with pytest.raises(g.ErrorException):
+        g.pf_update_blocks(st, (2,), (None,), np.zeros((2, 2)), 100)             # 3 blocks, 2 rows
+    with pytest.raises(g.ErrorException):
+        g.pf_update_blocks(st, (2,), (None,), np.zeros((3, 5)), 100)             # wrong observation width
+    with pytest.raises(g.ErrorException):
+        g.pf_rejuvenate_blocks(st, None, (), 1)                                  # no per-block observations yet
+    g.pf_update_blocks(st, (2,), (None,), np.tile(ys[1], (3, 1)), 100)
+    with pytest.raises(g.ErrorException):
+        g.pf_rejuvenate_blocks(st, None, (), 1, only_resampled=True)             # no block resample yet
+    with pytest.raises(g.ErrorException):
+        g.pf_rejuvenate(st[0:100], None, (), 1)                                  # a view after a block-wise update
+    st.close()
