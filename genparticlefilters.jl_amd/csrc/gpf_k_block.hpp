@@ -245,51 +245,53 @@ __global__ __launch_bounds__(BLOCK) void k_block_resample(BlockArgs a)
     }
 }
 
-constexpr int BLK_ITEMS = BLK_MAX / BLOCK;         // (k_block_stats: a workgroup per block, eight consecutive particles per lane)
-// per-block effective sample size and log-ML estimate of a sub-state (utils.jl:163-178): ess[b], lml[b] = lml_est + logsumexp(block) - log(block size)
-__global__ __launch_bounds__(BLOCK) void k_block_stats(const double* __restrict__ lw, int64_t n, int64_t nb, const double* lml_est,
+// per-block effective sample size and log-ML estimate of a sub-state (utils.jl:163-178): ess[b], lml[b] = (lml_est + logsumexp(block)) - log(block size);
+// teams as in k_block_resample
+template <int TEAM, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_block_stats(const double* __restrict__ lw, int64_t n, int64_t nb, int64_t nblocks, const double* lml_est,
                                                        double* __restrict__ ess_out, double* __restrict__ lml_out)
 {
+    constexpr int TEAMS = BLOCK / TEAM;
     __shared__ double s_m[NWAVES];
     __shared__ int s_f[NWAVES];
-    __shared__ uint64_t s_q[NWAVES][4];
-    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
-    const int64_t b0 = (int64_t)blockIdx.x * nb;
+    __shared__ uint64_t s_x[NWAVES][4];
+    const int tm = (int)threadIdx.x / TEAM, tl = (int)threadIdx.x % TEAM, lane = lane_id(), wv = wave_id();
+    const int64_t blk = (int64_t)blockIdx.x * TEAMS + tm;
+    if (TEAM != BLOCK && blk >= nblocks) return;
+    const int64_t b0 = blk * nb;
     const int cnt = (int)(n - b0 < nb ? n - b0 : nb);
     const int K = fix_K(cnt);
-    double lwv[BLK_ITEMS];
+    double lwv[ITEMS];
     double m = -__builtin_huge_val(); int f = 0;
 #pragma unroll
-    for (int k = 0; k < BLK_ITEMS; ++k) {
-        const int i = BLK_ITEMS * tid + k;
+    for (int k = 0; k < ITEMS; ++k) {
+        const int i = ITEMS * tl + k;
         lwv[k] = i < cnt ? lw[b0 + i] : -__builtin_huge_val();
         if (i < cnt) { const double v = lwv[k]; if (v != v) f |= FLAG_NAN; else { m = v > m ? v : m; if (v == __builtin_huge_val()) f |= FLAG_POSINF; } }
     }
     m = wave_max_f64(m);
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
-    if (lane == 0) { s_m[wv] = m; s_f[wv] = f; }
-    __syncthreads();
+    if (TEAM == BLOCK) {
+        if (lane == 0) { s_m[wv] = m; s_f[wv] = f; }
+        __syncthreads();
 #pragma unroll
-    for (int w = 0; w < NWAVES; ++w) { m = s_m[w] > m ? s_m[w] : m; f |= s_f[w]; }
+        for (int w = 0; w < NWAVES; ++w) { m = s_m[w] > m ? s_m[w] : m; f |= s_f[w]; }
+    }
     if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
     const bool uniform = (f & FLAG_ALL_NEGINF) != 0;
     unsigned __int128 Q = 0; uint64_t sl = 0;
 #pragma unroll
-    for (int k = 0; k < BLK_ITEMS; ++k) {
-        const uint64_t q = BLK_ITEMS * tid + k < cnt ? (uniform ? 1ull : exp_fix(lwv[k] - m, K)) : 0ull;
+    for (int k = 0; k < ITEMS; ++k) {
+        const uint64_t q = ITEMS * tl + k < cnt ? (uniform ? 1ull : exp_fix(lwv[k] - m, K)) : 0ull;
         Q += (unsigned __int128)q * q; sl += q;
     }
-    uint64_t lo32 = (uint64_t)Q & 0xffffffffull, hi32 = (uint64_t)Q >> 32, qh = (uint64_t)(Q >> 64);
-    lo32 = wave_sum_u64(lo32); hi32 = wave_sum_u64(hi32); qh = wave_sum_u64(qh); sl = wave_sum_u64(sl);
-    if (lane == 0) { s_q[wv][0] = lo32; s_q[wv][1] = hi32; s_q[wv][2] = qh; s_q[wv][3] = sl; }
-    __syncthreads();
-    if (tid == 0) {
-        uint64_t L = 0, H = 0, HH = 0, S = 0;
-        for (int w = 0; w < NWAVES; ++w) { L += s_q[w][0]; H += s_q[w][1]; HH += s_q[w][2]; S += s_q[w][3]; }
-        const unsigned __int128 Qt = ((unsigned __int128)HH << 64) + ((unsigned __int128)H << 32) + L;
-        ess_out[blockIdx.x] = f ? __builtin_nan("") : ess_from(S, (uint64_t)(Qt >> 64), (uint64_t)Qt);   // (lognorm of invalid weights is NaN)
-        lml_out[blockIdx.x] = (*lml_est + lse_from(m, S, K, f)) - log_((double)cnt);                     // utils.jl:174-178, left to right
+    uint64_t v4[4] = {(uint64_t)Q & 0xffffffffull, (uint64_t)Q >> 32, (uint64_t)(Q >> 64), sl};
+    team_sum4<TEAM>(v4, s_x);
+    if (tl == 0) {
+        const unsigned __int128 Qt = ((unsigned __int128)v4[2] << 64) + ((unsigned __int128)v4[1] << 32) + v4[0];
+        ess_out[blk] = f ? __builtin_nan("") : ess_from(v4[3], (uint64_t)(Qt >> 64), (uint64_t)Qt);     // (lognorm of invalid weights is NaN)
+        lml_out[blk] = (*lml_est + lse_from(m, v4[3], K, f)) - log_((double)cnt);                       // utils.jl:174-178, left to right
     }
 }
 

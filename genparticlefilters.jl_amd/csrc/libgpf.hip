@@ -1450,7 +1450,9 @@ gpf_status gpf_block_stats(gpf_handle h, int64_t block_size, double* ess_out, do
     if ((s = materialize(h))) return s;
     const int64_t nblocks = (h->n + block_size - 1) / block_size;
     if ((s = block_buffers(h, nblocks))) return s;
-    GPF_LAUNCH(k_block_stats, dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, h->lw, h->n, block_size, &h->sc->lml_est, h->blk_stats, h->blk_stats + nblocks);
+    if (block_size <= 2 * WAVE)      GPF_LAUNCH((k_block_stats<WAVE, 2>), dim3((unsigned)((nblocks + 3) / 4)), dim3(BLOCK), 0, h->stream, h->lw, h->n, block_size, nblocks, &h->sc->lml_est, h->blk_stats, h->blk_stats + nblocks);
+    else if (block_size <= 8 * WAVE) GPF_LAUNCH((k_block_stats<WAVE, 8>), dim3((unsigned)((nblocks + 3) / 4)), dim3(BLOCK), 0, h->stream, h->lw, h->n, block_size, nblocks, &h->sc->lml_est, h->blk_stats, h->blk_stats + nblocks);
+    else                             GPF_LAUNCH((k_block_stats<BLOCK, 8>), dim3((unsigned)nblocks), dim3(BLOCK), 0, h->stream, h->lw, h->n, block_size, nblocks, &h->sc->lml_est, h->blk_stats, h->blk_stats + nblocks);
     HIP_TRY(h, hipGetLastError());
     if (ess_out) HIP_TRY(h, hipMemcpyAsync(ess_out, h->blk_stats, (size_t)nblocks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (lml_out) HIP_TRY(h, hipMemcpyAsync(lml_out, h->blk_stats + nblocks, (size_t)nblocks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
