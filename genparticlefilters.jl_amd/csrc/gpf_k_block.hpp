@@ -153,7 +153,8 @@ __global__ __launch_bounds__(BLOCK) void k_block_resample(BlockArgs a)
         // `effective_sample_size(state) < N / 2`, README.md:72; invalid weights: the reference's ESS is NaN and the comparison false
         go = f == 0 && ess < a.ess_frac * (double)cnt;
     }
-    if (tl == 0) a.resampled[blk] = (go ? 1 : 0) | (f << 8);
+    // (with an ESS test an invalid block never gets as far as safe_softmax -- its ESS is NaN, the comparison false --: nothing to report)
+    if (tl == 0) a.resampled[blk] = (go ? 1 : 0) | ((a.ess_frac >= 0.0 ? 0 : f) << 8);
     if (!go) {
         // this block keeps its particles: rows move to the other buffer unchanged, weights and parents stay
         for (int t = tl; t < cnt * (W / 2); t += TEAM)

@@ -1614,8 +1614,10 @@ static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters,
 {
     gpf_status s = check_ready(h);
     if (s) return s;
-    if (h->parent && h->parent->blk_obs_size > 0)
+    if (h->parent && h->parent->blk_obs_size != 0)
         return fail(h, GPF_ERR_STATE, "rejuvenation of a view after a block-wise update of its filter: use gpf_rejuvenate_blocks on the filter");
+    if (h->blk_obs_size < 0)
+        return fail(h, GPF_ERR_STATE, "the filter was resized after a block-wise update: no current observation until the next update");
     if (h->blk_obs_size > 0 && !h->parent) {                     // the latest observations are per block (gpf_update_blocks)
         if (with_proposal) return fail(h, GPF_ERR_STATE, "proposal moves are not available after a block-wise update");
         return gpf_rejuvenate_blocks(h, method, n_iters, 0, n_accepted);
@@ -2010,6 +2012,8 @@ static gpf_status resize_ready(gpf_handle h)
 static void set_count(gpf_filter* h, int64_t n_new)
 {
     h->n = n_new; h->cfg.n_particles = n_new; h->cfg.n_global = n_new; h->cfg.gid0 = 0;
+    if (h->blk_obs_size != 0) h->blk_obs_size = -1;              // per-block observations do not survive a change of the particle count
+    h->blk_last = 0;
     h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false; h->pending_gather = false; h->pending_fill = false;
     h->pending_packed = false;
 }

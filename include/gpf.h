@@ -142,7 +142,8 @@ gpf_status gpf_resample_local(gpf_handle h, int32_t method, int32_t sort_particl
  *   ess_frac:    >= 0: a block resamples only if its effective sample size is below ess_frac x its size (decided on the device;
  *                an invalid block -- ESS NaN -- does not);  < 0 or NaN: every block resamples.
  *   check / invalid: as gpf_resample, over all blocks; blocks with NaN / +Inf weights (and, with GPF_CHECK_TRUE, all -Inf blocks)
- *                are left as they stand, the other blocks resample, and the call returns GPF_ERR_INVALID_WEIGHTS.
+ *                are left as they stand, the other blocks resample, and the call returns GPF_ERR_INVALID_WEIGHTS.  (With ess_frac >= 0 an
+ *                invalid block never reaches the resampler -- its ESS is NaN -- and nothing is reported, as in the loop.)
  *   n_resampled: if non-NULL receives the number of blocks that resampled (synchronises).
  * Not on sharded filters, views or filters with a trajectory store (GPF_ERR_STATE). */
 gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size, int32_t sort_particles, double ess_frac,

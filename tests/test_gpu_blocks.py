@@ -238,14 +238,14 @@ def oracle_update_blocks(f, nb, obs_rows):
     f.epoch = e + 1
 
 
-def oracle_rejuvenate_blocks(f, nb, obs_rows, method, mask=None):
+def oracle_rejuvenate_blocks(f, nb, obs_rows, method, mask=None, n_iters=1):
     e, acc = f.epoch, 0
     for k, b0 in enumerate(range(0, f.n, nb)):
         if mask is not None and not mask[k]:
             continue
         f.epoch = e
         v = f[b0:min(b0 + nb, f.n)]; v.last_obs = np.asarray(obs_rows[k], np.float64)
-        v.rejuvenate(method, 1); acc += v.n_accepted
+        v.rejuvenate(method, n_iters); acc += v.n_accepted
     f.epoch = e + 1
     return acc
 

@@ -3,6 +3,7 @@ resamples of every kind, rejuvenation, getters that force the deferred gather, s
 parents stay bit-identical and the scalar getters equal.  (The deferred gather / deferred constant / cached summaries / live views
 are a state machine; this walks it at random.)"""
 import os
+import sys
 import warnings
 
 import numpy as np
@@ -12,6 +13,8 @@ pytestmark = pytest.mark.gpu
 N_SEEDS = int(os.environ.get("GPF_FUZZ_SEEDS", "12"))           # GPF_FUZZ_SEEDS=300 for a longer hunt
 OFFSET = int(os.environ.get("GPF_FUZZ_OFFSET", "0"))             # ... GPF_FUZZ_OFFSET=100000 for other sequences
 METHODS = ["multinomial", "residual", "stratified"]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_gpu_blocks import oracle_blocks, oracle_rejuvenate_blocks, oracle_update_blocks  # noqa: E402
 
 
 def same(a, b):
@@ -56,10 +59,43 @@ def test_random_api_sequences(g, o, seed):
     orc = o.OracleFilter(model.model_id, model.params, N, seed + 5, keep_prev=True, history=hist).initialize(ys[0])
     t = 1
     log = []
+    blk = None                                                        # (block size, observation rows) while the latest observations are per block
     for step in range(T):
-        op = rng.choice(["update", "resample", "rejuvenate", "getters", "view", "whole_view", "resize", "set_weights"],
-                        p=[0.25, 0.22, 0.12, 0.08, 0.12, 0.07, 0.07, 0.07])
+        op = rng.choice(["update", "resample", "rejuvenate", "getters", "view", "whole_view", "resize", "set_weights", "blocks"],
+                        p=[0.22, 0.20, 0.11, 0.08, 0.11, 0.07, 0.07, 0.07, 0.07])
         n = st.n_particles
+        if op == "blocks" and hist:
+            with pytest.raises(g.ErrorException):                       # (no block-wise steps on a filter with a trajectory store)
+                g.pf_resample_blocks(st, 64, "multinomial", check=False)
+            op = "getters"
+        if op == "blocks":
+            # many small filters in one state (gpf_k_block.hpp): block-wise resample / update with per-block data / rejuvenate
+            nb = int(rng.choice([1, 7, 64, 100, 128, 300, 512, 999, 2048]))
+            nblk = (n + nb - 1) // nb
+            sub = str(rng.choice(["resample", "resample_ess", "update", "rejuvenate"]))
+            m = str(rng.choice(METHODS)); sp = bool(rng.integers(2))
+            if sub in ("resample", "resample_ess"):
+                fr = None if sub == "resample" else float(rng.choice([0.3, 0.7, 1.5]))
+                out = {}
+                if both(lambda: out.update(d=g.pf_resample_blocks(st, nb, m, ess_frac=fr, sort_particles=sp, check=False)),
+                        lambda: out.update(o=oracle_blocks(orc, nb, m, ess_frac=fr, sort_particles=sp)), log[-4:]):
+                    st.close()
+                    return                                              # NaN weights in some block: the run ends
+                assert out["d"] == out["o"].sum()
+            elif sub == "update":
+                obs = np.asarray(ys[t], np.float64)[None, :] + 0.2 * rng.standard_normal((nblk, len(ys[t])))
+                g.pf_update_blocks(st, (t + 1,), (None,), obs, nb); oracle_update_blocks(orc, nb, obs)
+                blk = (nb, obs); t += 1
+            else:
+                if blk is None or blk == "lost":
+                    with pytest.raises(g.ErrorException):
+                        g.pf_rejuvenate_blocks(st, None, (), 1)
+                else:
+                    meth = str(rng.choice(["move", "reweight"]))
+                    g.pf_rejuvenate_blocks(st, None, (), 1, method=meth); oracle_rejuvenate_blocks(orc, blk[0], blk[1], meth)
+            log.append(f"blocks {sub} nb={nb} {m} sort={sp}")
+            check(g, st, orc, f"seed {seed} {name} N={N} after {log[-6:]}")
+            continue
         if hist and op in ("resize", "view", "whole_view"):
             if op != "resize":
                 with pytest.raises(g.ErrorException):                   # one ancestor map per step for the whole filter: no sub-states
@@ -77,6 +113,7 @@ def test_random_api_sequences(g, o, seed):
             else:
                 g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
             t += 1
+            blk = None                                                  # one observation for all particles again
         elif op == "resample":
             m = str(rng.choice(METHODS)); alpha = None if rng.random() < 0.6 else (0.5 if rng.random() < 0.6 else "closure")
             kw = {"sort_particles": bool(rng.random() < 0.5)} if m == "stratified" else {}
@@ -95,7 +132,15 @@ def test_random_api_sequences(g, o, seed):
             op = f"resample {m} {alpha} {kw}"
         elif op == "rejuvenate":
             meth = str(rng.choice(["move", "reweight"])); it = int(rng.integers(1, 3))
-            if name == "lgssm2" and meth == "reweight" and rng.random() < 0.5:       # move_reweight(trace, proposal, args), rejuvenate.jl:134-148
+            if blk == "lost":                                           # resized after a block-wise update: no current observation until the next update
+                with pytest.raises(g.ErrorException):
+                    g.pf_rejuvenate(st, g.mh, (), 1)
+                log.append("rejuvenate refused"); continue
+            if blk is not None:                                         # after a block-wise update the move uses every block's own observation
+                g.pf_rejuvenate(st, g.mh if meth == "move" else g.move_reweight, (), it, method=meth)
+                oracle_rejuvenate_blocks(orc, blk[0], blk[1], meth, n_iters=it)
+                meth = f"{meth} (per-block observations)"
+            elif name == "lgssm2" and meth == "reweight" and rng.random() < 0.5:       # move_reweight(trace, proposal, args), rejuvenate.jl:134-148
                 g.pf_rejuvenate(st, g.move_reweight, (g.locally_optimal_move, ()), it, method="reweight"); orc.rejuvenate("reweight", it, proposal=())
                 meth = "reweight (locally optimal proposal)"
             else:
@@ -132,6 +177,12 @@ def test_random_api_sequences(g, o, seed):
                 continue
             sv, ov = st[a:b:stride], orc[a:b:stride]
             sub = rng.choice(["update", "resample", "rejuvenate"])
+            if sub == "rejuvenate" and blk == "lost":
+                sub = "resample"
+            if sub == "rejuvenate" and blk is not None:
+                with pytest.raises(g.ErrorException):                   # the filter's latest observations are per block: the view cannot know which
+                    g.pf_rejuvenate(sv, g.mh, (), 1)
+                sub = "resample"
             if sub == "update":
                 g.pf_update(sv, (t + 1,), (None,), ys[t]); ov.update(ys[t])          # (only the view's particles advance)
             elif sub == "resample":
@@ -161,6 +212,8 @@ def test_random_api_sequences(g, o, seed):
                 if bad:
                     st.close()
                     return
+            if blk is not None:
+                blk = "lost"                                            # the per-block observations do not survive a change of the particle count
             op = f"resize {kind}"
         log.append(op)
         check(g, st, orc, f"seed {seed} {name} N={N} after {log[-6:]}")
