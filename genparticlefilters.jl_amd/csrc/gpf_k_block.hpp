@@ -296,4 +296,21 @@ __global__ __launch_bounds__(BLOCK) void k_block_stats(const double* __restrict_
     }
 }
 
+// the blocks' observation vectors from a pinned host buffer into device memory, by a KERNEL (coalesced reads over PCIe) rather than a
+// hipMemcpyAsync: the copy stays on the compute queue (an SDMA copy costs a cross-queue dependency of ~10-20 us in front of the step
+// kernel that reads it).  The last workgroup publishes `ticket` to pinned memory: the host may then refill that staging buffer.
+__global__ __launch_bounds__(BLOCK) void k_stage_obs(const double* __restrict__ src_host, double* __restrict__ dst, int64_t n_words,
+                                                     unsigned int* counter, int64_t* host_done, int64_t ticket)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * BLOCK) dst[i] = src_host[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(counter, 1u) == gridDim.x - 1) {
+            *counter = 0;
+            __hip_atomic_store(host_done, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 } // namespace gpf

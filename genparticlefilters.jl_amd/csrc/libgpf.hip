@@ -139,7 +139,11 @@ struct gpf_filter {
     int64_t* h_shard_counts = nullptr;
     // block-wise resampling (gpf_resample_blocks): {flags, count} words, the per-block mask, per-block statistics
     int32_t* blk_words = nullptr; int32_t* blk_mask = nullptr; double* blk_stats = nullptr; int64_t blk_cap = 0, blk_last = 0;
-    double* blk_obs = nullptr; double* h_blk_obs = nullptr; int64_t blk_obs_cap = 0;   // per-block observations [n_blocks][MAX_OBS] (device, pinned staging)
+    double* blk_obs = nullptr; int64_t blk_obs_cap = 0;                                // per-block observations [n_blocks][MAX_OBS] on the device
+    static constexpr int BLK_STAGE = 4;                                                // pinned staging buffers, used in turn (no stream sync per step)
+    double* h_blk_obs[BLK_STAGE] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t blk_stage_next = 0;                                                        // staging copies issued so far (ticket of the next one - 1)
+    int64_t* h_blk_done = nullptr; unsigned int* blk_stage_counter = nullptr;          // pinned: ticket of the last finished staging copy; device: its workgroup counter
     int64_t blk_obs_size = 0;                                                          // > 0: the latest observations are per block, blocks of this size
     // the pull plan (gpf_comm_set_plan): request lists [G][n], their counters, the dense / gathered request matrix and its pinned mirror
     int shard_plan_kind = 0;
@@ -1200,7 +1204,9 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
     if (h->h_pull_pc_all) hipHostFree(h->h_pull_pc_all);
-    if (h->h_blk_obs) hipHostFree(h->h_blk_obs);
+    for (int k = 0; k < gpf_filter::BLK_STAGE; ++k) if (h->h_blk_obs[k]) hipHostFree(h->h_blk_obs[k]);
+    if (h->h_blk_done) hipHostFree(h->h_blk_done);
+    if (h->blk_stage_counter) (void)hipFree(h->blk_stage_counter);
     if (h->h_flags) hipHostFree(h->h_flags);
     if (h->h_sort_flag) hipHostFree(h->h_sort_flag);
     if (h->h_timeout) hipHostFree(h->h_timeout);
@@ -1467,15 +1473,43 @@ static gpf_status set_block_obs(gpf_filter* h, const double* obs, int32_t n_obs,
         return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model takes " + std::to_string(model_obs_dim(h->cfg.model)) + " observation values per step and block");
     const int64_t nblocks = (h->n + block_size - 1) / block_size;
     if (h->blk_obs_cap < nblocks) {
-        if (h->blk_obs) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->blk_obs); (void)hipHostFree(h->h_blk_obs); h->blk_obs = nullptr; h->h_blk_obs = nullptr; h->blk_obs_cap = 0; }
+        if (h->blk_obs) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            (void)hipFree(h->blk_obs); h->blk_obs = nullptr; h->blk_obs_cap = 0;
+            for (int k = 0; k < gpf_filter::BLK_STAGE; ++k) { (void)hipHostFree(h->h_blk_obs[k]); h->h_blk_obs[k] = nullptr; }
+        }
         HIP_TRY(h, hipMalloc(&h->blk_obs, (size_t)nblocks * MAX_OBS * sizeof(double)));
-        HIP_TRY(h, hipHostMalloc(&h->h_blk_obs, (size_t)nblocks * MAX_OBS * sizeof(double)));
+        for (int k = 0; k < gpf_filter::BLK_STAGE; ++k) HIP_TRY(h, hipHostMalloc(&h->h_blk_obs[k], (size_t)nblocks * MAX_OBS * sizeof(double)));
+        if (!h->h_blk_done) {
+            HIP_TRY(h, hipHostMalloc(&h->h_blk_done, sizeof(int64_t))); *h->h_blk_done = 0;
+            HIP_TRY(h, hipMalloc(&h->blk_stage_counter, sizeof(unsigned int)));
+            HIP_TRY(h, hipMemsetAsync(h->blk_stage_counter, 0, sizeof(unsigned int), h->stream));
+        }
         h->blk_obs_cap = nblocks;
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));                 // (the staging buffer of the previous call is read by an asynchronous copy)
+    // the staging buffers are used in turn: wait only until the copy that last read THIS buffer (four calls ago) has finished -- its
+    // kernel publishes a ticket to pinned memory -- not for the stream
+    const int k = (int)(h->blk_stage_next % gpf_filter::BLK_STAGE);
+    if (h->blk_stage_next >= gpf_filter::BLK_STAGE) {
+        const int64_t need = h->blk_stage_next - gpf_filter::BLK_STAGE + 1;
+        uint64_t spins = 0;
+        while (__atomic_load_n(h->h_blk_done, __ATOMIC_ACQUIRE) < need) {
+            cpu_relax();
+            if ((++spins & 0x3fff) != 0) continue;
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipErrorNotReady) continue;
+            if (__atomic_load_n(h->h_blk_done, __ATOMIC_ACQUIRE) >= need) break;
+            return fail(h, GPF_ERR_HIP, q == hipSuccess ? "observation staging: the stream drained without the copy's ticket" : hipGetErrorString(q));
+        }
+    }
+    h->blk_stage_next += 1;
+    double* const stage = h->h_blk_obs[k];
     for (int64_t b = 0; b < nblocks; ++b)
-        for (int i = 0; i < MAX_OBS; ++i) h->h_blk_obs[b * MAX_OBS + i] = i < n_obs ? obs[b * n_obs + i] : 0.0;
-    HIP_TRY(h, hipMemcpyAsync(h->blk_obs, h->h_blk_obs, (size_t)nblocks * MAX_OBS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        for (int i = 0; i < MAX_OBS; ++i) stage[b * MAX_OBS + i] = i < n_obs ? obs[b * n_obs + i] : 0.0;
+    const int64_t n_words = nblocks * MAX_OBS;
+    GPF_LAUNCH(k_stage_obs, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (n_words + BLOCK - 1) / BLOCK))), dim3(BLOCK), 0, h->stream,
+               stage, h->blk_obs, n_words, h->blk_stage_counter, h->h_blk_done, h->blk_stage_next);
+    HIP_TRY(h, hipGetLastError());
     h->args.blk_obs = h->blk_obs; h->args.blk_mask = nullptr; h->args.blk_size = (int32_t)block_size;
     h->blk_obs_size = block_size;
     return GPF_OK;

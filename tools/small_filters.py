@@ -39,8 +39,7 @@ def loop_blocks(B):
     return dt / T * 1e6, float(lml.mean()), float(lml.std())
 
 
-if not os.environ.get("SMALL_B"):
-  def loop_blocks_own_data(B):
+def loop_blocks_own_data(B):
     """every filter on its own observations: per-block initialise / update / rejuvenate (only the blocks that resampled)"""
     import numpy as np
     rng = np.random.default_rng(3)
