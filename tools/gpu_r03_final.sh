@@ -28,3 +28,4 @@ for M in multinomial residual; do
   done
 done
 cat $OUT
+python tools/small_filters.py 300 2>/dev/null > gpurun_out/${TAG}_small_filters.txt; cut -c1-160 gpurun_out/${TAG}_small_filters.txt
