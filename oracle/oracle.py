@@ -655,6 +655,60 @@ def _targets_stratified_view(seed, epoch, start, n, S) -> np.ndarray:
     return T
 
 
+# ---------------------------------------------------------------------- many small filters in one state: loops over sub-states
+# (the batched device forms are gpf_resample_blocks / gpf_update_blocks / gpf_rejuvenate_blocks, gpf_k_block.hpp; every block runs
+#  under the call's one epoch, which then advances once -- like one call on the whole state)
+def blocks_of(f: OracleFilter, nb: int):
+    return [(b0, min(b0 + nb, f.n)) for b0 in range(0, f.n, nb)]
+
+
+def resample_blocks(f: OracleFilter, nb: int, method: str = "multinomial", ess_frac=None, sort_particles: bool = True, check=False) -> np.ndarray:
+    """for b in blocks: if ess_frac is None or ESS(state[b]) < ess_frac * len(b): pf_resample!(state[b], method); returns the mask"""
+    e, mask = f.epoch, []
+    for a, b in blocks_of(f, nb):
+        v = f[a:b]
+        f.epoch = e
+        go = ess_frac is None or v.effective_sample_size() < ess_frac * v.n      # (NaN ESS of invalid weights: False, like the reference's `<`)
+        if go:
+            v.resample(method, sort_particles=sort_particles, check=check)
+        mask.append(bool(go))
+    f.epoch = e + 1
+    return np.array(mask)
+
+
+def update_blocks(f: OracleFilter, nb: int, obs_rows) -> None:
+    """for b in blocks: pf_update!(state[b], ..., observations[b])   (per-view updates, test/update.jl:179-189)"""
+    e = f.epoch
+    for k, (a, b) in enumerate(blocks_of(f, nb)):
+        f.epoch = e
+        f[a:b].update(np.asarray(obs_rows[k], np.float64))
+    f.epoch = e + 1
+
+
+def rejuvenate_blocks(f: OracleFilter, nb: int, obs_rows, method: str = "move", mask=None, n_iters: int = 1) -> int:
+    """for b in blocks (those with mask[b], if given): pf_rejuvenate!(state[b], ...) with the block's observation; returns the accept count"""
+    e, acc = f.epoch, 0
+    for k, (a, b) in enumerate(blocks_of(f, nb)):
+        if mask is not None and not mask[k]:
+            continue
+        f.epoch = e
+        v = f[a:b]; v.last_obs = np.asarray(obs_rows[k], np.float64)
+        v.rejuvenate(method, n_iters); acc += v.n_accepted
+    f.epoch = e + 1
+    return acc
+
+
+def initialize_blocks(f: OracleFilter, nb: int, obs_rows) -> OracleFilter:
+    """per-block initialisation (initialize.jl:39-41 on every sub-state with its own observation)"""
+    for k, (a, b) in enumerate(blocks_of(f, nb)):
+        rows = np.zeros((b - a, f.W)); lw = np.zeros(b - a)
+        lib().o_init(f.model, f.params, f.seed, f.epoch, a, b - a, f.W, np.ascontiguousarray(obs_rows[k], np.float64), rows, lw)
+        f.rows[a:b] = rows; f.lw[a:b] = lw
+    f.lml_est = 0.0; f.parents = np.arange(1, f.n + 1, dtype=np.int64)
+    f.epoch += 1; f.has_prev = False
+    return f
+
+
 def _oracle_getitem(self, idx):
     start, stop, step = idx.indices(self.n)
     assert step >= 1 and stop > start

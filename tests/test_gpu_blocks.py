@@ -19,17 +19,9 @@ def make(g, o, model_name, N, seed=11, keep_prev=False, T=6):
 
 
 def oracle_blocks(f, nb, method, ess_frac=None, sort_particles=True, check=False):
-    """the loop over sub-states, every block under the call's one epoch; returns the mask of the blocks that resampled"""
-    e, mask = f.epoch, []
-    for b0 in range(0, f.n, nb):
-        v = f[b0:min(b0 + nb, f.n)]
-        f.epoch = e
-        go = ess_frac is None or v.effective_sample_size() < ess_frac * v.n
-        if go:
-            v.resample(method, sort_particles=sort_particles, check=check)
-        mask.append(bool(go))
-    f.epoch = e + 1
-    return np.array(mask)
+    """the loop over sub-states, every block under the call's one epoch (oracle/oracle.py resample_blocks); the mask of the blocks that resampled"""
+    from oracle import oracle
+    return oracle.resample_blocks(f, nb, method, ess_frac=ess_frac, sort_particles=sort_particles, check=check)
 
 
 def same(st, f):
@@ -218,36 +210,17 @@ def test_argument_errors(g, o):
 
 # ----------------------------------------------------------------------------- per-block observations: many DATASETS in one state
 def oracle_init_blocks(o, f, nb, obs_rows):
-    """per-block initialisation: o_init on every block's slice with the block's observation (initialize.jl:39-41 per sub-state)"""
-    lib = o.lib()
-    for k, b0 in enumerate(range(0, f.n, nb)):
-        cnt = min(nb, f.n - b0)
-        rows = np.zeros((cnt, f.W)); lw = np.zeros(cnt)
-        lib.o_init(f.model, f.params, f.seed, f.epoch, b0, cnt, f.W, np.ascontiguousarray(obs_rows[k], np.float64), rows, lw)
-        f.rows[b0:b0 + cnt] = rows; f.lw[b0:b0 + cnt] = lw
-    f.lml_est = 0.0; f.parents = np.arange(1, f.n + 1, dtype=np.int64)
-    f.epoch += 1; f.has_prev = False
-    return f
+    return o.initialize_blocks(f, nb, obs_rows)
 
 
 def oracle_update_blocks(f, nb, obs_rows):
-    e = f.epoch
-    for k, b0 in enumerate(range(0, f.n, nb)):
-        f.epoch = e
-        f[b0:min(b0 + nb, f.n)].update(np.asarray(obs_rows[k], np.float64))
-    f.epoch = e + 1
+    from oracle import oracle
+    oracle.update_blocks(f, nb, obs_rows)
 
 
 def oracle_rejuvenate_blocks(f, nb, obs_rows, method, mask=None, n_iters=1):
-    e, acc = f.epoch, 0
-    for k, b0 in enumerate(range(0, f.n, nb)):
-        if mask is not None and not mask[k]:
-            continue
-        f.epoch = e
-        v = f[b0:min(b0 + nb, f.n)]; v.last_obs = np.asarray(obs_rows[k], np.float64)
-        v.rejuvenate(method, n_iters); acc += v.n_accepted
-    f.epoch = e + 1
-    return acc
+    from oracle import oracle
+    return oracle.rejuvenate_blocks(f, nb, obs_rows, method, mask=mask, n_iters=n_iters)
 
 
 @pytest.mark.parametrize("model_name", ["lgssm2", "bearings4", "object_motion", "sv1"])
