@@ -191,14 +191,27 @@ def main():
         else:
             tried_library = False
         ok, err = 1, ""
+        lml2 = float("nan")
         try:
             state = make_state()
+            # a transport that delivers WRONG summaries without failing (the mailboxes have never crossed xGMI) would show here: the
+            # global estimate after the two steps must be finite, within reach of the exact value, and the same on every rank
+            lml2 = sharded.get_lml_est(state)
+            exact2 = g.models.kalman_loglik(model, ys[:3])
+            if not (lml2 == lml2 and abs(lml2 - exact2) < 1.0):
+                ok, err = 0, f"log-ML after two guarded steps {lml2!r} against the exact {exact2!r}"
         except Exception as e:                                       # noqa: BLE001 -- any failure means: use the other engine
             ok, err = 0, repr(e)
         if dist is not None and world > 1:
-            flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if one_device else "cuda")
+            dev_ = "cpu" if one_device else "cuda"
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev_)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok_all = int(flag.item())
+            if ok_all:                                               # every rank computed the GLOBAL estimate: bit-identical or the engine is out
+                lo = torch.tensor([lml2], dtype=torch.float64, device=dev_); hi = lo.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                if float(lo.item()) != float(hi.item()):
+                    ok_all, err = 0, f"ranks disagree on the global log-ML after two steps ({float(lo.item())!r} .. {float(hi.item())!r})"
         else:
             ok_all = ok
         if not ok_all:
