@@ -32,6 +32,17 @@ struct WSum {                  // summary of one weight vector
     uint64_t sB, srem;
     double   sinv;
 };
+// residual resampling, deterministic head: cells with very many copies are not filled by the one workgroup that meets them in
+// k_scan_residual2 but listed here and filled by the whole grid of the search kernel that follows.  No reset between resamples: the word
+// carries the resample's tag (epoch), a list with another tag is empty.
+constexpr int GIANT_MAX = 32;
+constexpr uint32_t GIANT_COPIES = 16384;
+struct HeadGiants {
+    unsigned int word;                    // tag << 8 | entries
+    unsigned int pad;
+    uint64_t start[GIANT_MAX];
+    uint32_t cell[GIANT_MAX], cnt[GIANT_MAX];
+};
 struct Scalars {
     WSum     prio;             // weights the resampler samples from (log_priorities)
     WSum     raw;              // state.log_weights (log-ML estimate, ESS)
@@ -45,6 +56,7 @@ struct Scalars {
     int32_t  pad;
     long long opt_d;           // optimal resize: threshold position in the descending order (-1: none)
     uint64_t opt_a, opt_B;     // optimal resize: inverse weight threshold c = a S / B as the exact pair (a, B)
+    HeadGiants giants;         // residual: cells with >= GIANT_COPIES copies of the current resample
 };
 
 // how the resampler sees the weights: log_priorities = priority_fn.(log_weights) (resample.jl:51-52)

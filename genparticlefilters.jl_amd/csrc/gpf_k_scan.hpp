@@ -341,12 +341,23 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
 // ONE 64-bit division per element (quotient and remainder), two descriptor channels polled in the same round trip.
 // Same tile / descriptor protocol as k_scan (channel A = counts, channel B = residual weights).
 struct Scan2Chan { ScanOut out; uint64_t* dcur; uint64_t* dnext; uint64_t* total_out; };
+// head_anc != nullptr (the plain residual resample): the deterministic head of the resampler -- particle i into the slots
+// [ccdf[i - 1], ccdf[i]) (resample.jl:99-106) -- is written HERE, by the tile that has just learned where its copies start: a lane writes
+// the copies of its own cells when there are few (<= HEAD_SMALL each), cells with more are filled by the whole workgroup (coalesced
+// runs).  The search kernel then looks up the i.i.d. tail only, and the copy-count CDF and its levels (A.out) are not stored at all.
+// A tile with <= HEAD_STAGE copies in all assembles them in LDS first and stores them as one coalesced run.
+constexpr int HEAD_SMALL = 16, HEAD_LIST = 128, HEAD_STAGE = 4096;
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* __restrict__ cdf, const WSum* ws, int64_t Nslots,
                                                           int64_t n, int64_t ntiles, Scan2Chan A, Scan2Chan B,
-                                                          int32_t* __restrict__ timeout)
+                                                          int32_t* __restrict__ timeout, int32_t* __restrict__ head_anc,
+                                                          HeadGiants* __restrict__ giants, uint32_t tag)
 {
     __shared__ uint64_t s_wave[2][SCAN_NWAVES];
     __shared__ uint64_t s_red[2][SCAN_NWAVES];
+    __shared__ unsigned int s_nheavy;
+    __shared__ uint64_t s_hstart[HEAD_LIST];
+    __shared__ uint32_t s_hcell[HEAD_LIST], s_hcnt[HEAD_LIST];
+    __shared__ int32_t s_stage[HEAD_STAGE];
     for (int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * SCAN_BLOCK) { A.dnext[i] = 0; B.dnext[i] = 0; }
     const uint64_t S = ws->S;
     const int sh = residual_shift(S, Nslots);
@@ -354,7 +365,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* _
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t wbase = tile * TILE + (int64_t)wv * (SCAN_ROWS * 2 * WAVE) + 2 * lane;
         uint64_t pa[2 * SCAN_ROWS], pb[2 * SCAN_ROWS];
+        uint32_t cnt[2 * SCAN_ROWS];                                                  // copies of the lane's cells (head_anc)
         uint64_t ca = 0, cb = 0;
+        if (head_anc && threadIdx.x == 0) s_nheavy = 0;
 #pragma unroll
         for (int k = 0; k < SCAN_ROWS; ++k) {
             const int64_t idx = wbase + k * 2 * WAVE;
@@ -368,6 +381,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* _
             }
             if (idx >= n) { a0 = 0; b0 = 0; }
             if (idx + 1 >= n) { a1 = 0; b1 = 0; }
+            cnt[2 * k] = (uint32_t)a0; cnt[2 * k + 1] = (uint32_t)a1;
             const uint64_t paira = a0 + a1, pairb = b0 + b1;
             const uint64_t inca = wave_scan_u64(paira), incb = wave_scan_u64(pairb);
             pa[2 * k] = ca + (inca - paira) + a0; pa[2 * k + 1] = pa[2 * k] + a1;
@@ -404,15 +418,58 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* _
             desc_store(B.dcur + ntiles + tile, DESC_VALID | (exb + aggb));
         }
         const uint64_t offa = exa + wexa, offb = exb + wexb;
+        const bool staged = head_anc && agga <= (uint64_t)HEAD_STAGE;                  // (workgroup-uniform)
 #pragma unroll
         for (int k = 0; k < SCAN_ROWS; ++k) {
             const int64_t idx = wbase + k * 2 * WAVE;
             const uint64_t va = offa + pa[2 * k + 1], vb = offb + pb[2 * k + 1];
-            *reinterpret_cast<ulonglong2*>(A.out.cdf + idx) = make_ulonglong2(offa + pa[2 * k], va);
             *reinterpret_cast<ulonglong2*>(B.out.cdf + idx) = make_ulonglong2(offb + pb[2 * k], vb);
-            if ((lane & 7) == 7) { A.out.t16[(idx + 1) >> 4] = va; B.out.t16[(idx + 1) >> 4] = vb; }
-            if ((lane & 15) == 15) { A.out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(va) >> KEY_SHIFT); B.out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(vb) >> KEY_SHIFT); }
-            if (lane == WAVE - 1 && (k & 1)) { A.out.t256[(idx + 1) >> 8] = va; B.out.t256[(idx + 1) >> 8] = vb; }
+            if ((lane & 7) == 7) B.out.t16[(idx + 1) >> 4] = vb;
+            if ((lane & 15) == 15) B.out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(vb) >> KEY_SHIFT);
+            if (lane == WAVE - 1 && (k & 1)) B.out.t256[(idx + 1) >> 8] = vb;
+            if (!head_anc) {
+                *reinterpret_cast<ulonglong2*>(A.out.cdf + idx) = make_ulonglong2(offa + pa[2 * k], va);
+                if ((lane & 7) == 7) A.out.t16[(idx + 1) >> 4] = va;
+                if ((lane & 15) == 15) A.out.k32[(idx + 1) >> 5] = (uint32_t)(key_sat(va) >> KEY_SHIFT);
+                if (lane == WAVE - 1 && (k & 1)) A.out.t256[(idx + 1) >> 8] = va;
+            } else {
+                // the copies of the lane's two cells start at their exclusive prefixes
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t c_ = cnt[2 * k + u];
+                    const uint64_t start = offa + pa[2 * k + u] - c_;
+                    if (c_ == 0) continue;
+                    unsigned slot = HEAD_LIST;
+                    if (c_ >= GIANT_COPIES) {
+                        // a cell with very many copies: one workgroup would fill them alone (10^6 copies: ~50 us); listed for the search
+                        // kernel's whole grid instead.  The list's word carries this resample's tag: claim an entry, or start the list
+                        unsigned int w = __hip_atomic_load(&giants->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), e = GIANT_MAX;
+                        while (true) {
+                            const unsigned int have = (w >> 8) == tag ? (w & 0xffu) : 0u;
+                            if (have >= (unsigned)GIANT_MAX) break;
+                            const unsigned int nw = (tag << 8) | (have + 1u);
+                            if (__hip_atomic_compare_exchange_strong(&giants->word, &w, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { e = have; break; }
+                        }
+                        if (e < (unsigned)GIANT_MAX) { giants->start[e] = start; giants->cell[e] = (uint32_t)(idx + u); giants->cnt[e] = c_; continue; }
+                    }
+                    if (c_ > HEAD_SMALL) slot = atomicAdd(&s_nheavy, 1u);
+                    if (slot < HEAD_LIST) { s_hstart[slot] = start; s_hcell[slot] = (uint32_t)(idx + u); s_hcnt[slot] = c_; }
+                    else if (staged) for (uint32_t q = 0; q < c_; ++q) s_stage[(start - exa) + q] = (int32_t)(idx + u);
+                    else for (uint32_t q = 0; q < c_; ++q) head_anc[start + q] = (int32_t)(idx + u);      // few copies (or the list is full)
+                }
+            }
+        }
+        if (head_anc) {
+            __syncthreads();
+            if (staged) {                                                              // the tile's copies as one coalesced run (the listed cells' ranges
+                for (uint32_t q = threadIdx.x; q < (uint32_t)agga; q += SCAN_BLOCK) head_anc[exa + q] = s_stage[q];   // hold leftovers: filled next)
+                __syncthreads();
+            }
+            const unsigned nh = s_nheavy < HEAD_LIST ? s_nheavy : HEAD_LIST;
+            for (unsigned hh = 0; hh < nh; ++hh) {
+                const uint64_t start = s_hstart[hh]; const uint32_t c_ = s_hcnt[hh]; const int32_t cell = (int32_t)s_hcell[hh];
+                for (uint32_t q = threadIdx.x; q < c_; q += SCAN_BLOCK) head_anc[start + q] = cell;
+            }
         }
         if (tile == ntiles - 1 && threadIdx.x == SCAN_BLOCK - 1) { *A.total_out = offa + pa[2 * SCAN_ROWS - 1]; *B.total_out = offb + pb[2 * SCAN_ROWS - 1]; }
         __syncthreads();                                // s_wave / s_red reuse

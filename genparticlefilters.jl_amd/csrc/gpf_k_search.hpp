@@ -138,6 +138,7 @@ struct SearchArgs {
     int update_lml;                                                   // 0 for sub-state views (resample.jl:185-187); 2: whole-shard
                                                                       // sub-state, the kept mass goes to sc->lw_fill (resample.jl:210)
     int32_t* anc;
+    int head_done;                                                    // residual: the deterministic head is written already (k_scan_residual2): tail slots only
 };
 
 // LDS copy of the top level: one pad word per 64 entries.  The branch-free search probes at power-of-two strides;
@@ -281,7 +282,7 @@ template <int METHOD>
 __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(SearchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SearchTop st = search_prologue(a.w, a.c, METHOD == 1, a.ntiles, reinterpret_cast<uint64_t*>(smem));
+    const SearchTop st = search_prologue(a.w, a.c, METHOD == 1 && !a.head_done, a.ntiles, reinterpret_cast<uint64_t*>(smem));
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
     if (a.update_lml && blockIdx.x == 0 && threadIdx.x == 0)
         resample_bookkeeping(a);
@@ -296,8 +297,20 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search(Search
         __syncthreads();
     }
     const uint64_t Ctot = (METHOD == 1) ? a.sc->Ctot : 0;
+    // (residual with the head already written by the scan: the slots [Ctot, n) only)
+    const int64_t jfirst = (METHOD == 1 && a.head_done) ? (int64_t)Ctot : 0;
+    if (METHOD == 1 && a.head_done) {
+        // ... except the copies of the cells the scan listed as too many for one workgroup (HeadGiants): filled here, by the whole grid
+        const HeadGiants& gi = a.sc->giants;
+        const unsigned int w = gi.word;
+        const unsigned int ng = (w >> 8) == (a.epoch & 0xffffffu) ? (w & 0xffu) : 0u;
+        for (unsigned int e = 0; e < ng; ++e) {
+            const uint64_t start = gi.start[e]; const uint32_t c_ = gi.cnt[e]; const int32_t cell = (int32_t)gi.cell[e];
+            for (uint64_t q = (uint64_t)blockIdx.x * SBLOCK + threadIdx.x; q < c_; q += (uint64_t)gridDim.x * SBLOCK) a.anc[start + q] = cell;
+        }
+    }
     // two slots per lane and iteration (independent dependency chains); the loop is wave-uniform
-    for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < a.n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
+    for (int64_t base = jfirst + (int64_t)blockIdx.x * 2 * SBLOCK; base < a.n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
         int64_t j[2]; bool act[2], head[2]; uint64_t T[2]; const uint64_t* top[2]; const CdfLevels* L[2];
         // the lane's two CONSECUTIVE slots share one Philox block when their ids form an aligned pair (gfp_math.hpp
         // resample_u64); RNG keyed by the global id; systematic sampling (METHOD 3) draws ONE uniform for all slots

@@ -849,7 +849,9 @@ CdfLevels levels(const gpf_filter* h, int ch)
 }
 
 // residual: copy-count and residual-weight CDFs from the weight CDF (resample.jl:99,109); ws->S must be the GLOBAL sum
-gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
+// head_anc: the plain resample hands over its ancestor array -- the scan writes the deterministic head into it (k_scan_residual2), the
+// search then covers the tail only (SearchArgs::head_done) and the copy-count CDF is not stored
+gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global, int32_t* head_anc = nullptr)
 {
     gpf_status s = ensure_residual_buffers(h);
     if (s) return s;
@@ -866,7 +868,7 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global)
     }
     const int gs = scan_grid(h);
     s = timed(h, GPF_K_SCAN, [&] {
-        GPF_LAUNCH(k_scan_residual2, dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, h->cdf[0], ws, n_slots_global, h->n, h->ntiles, ch[0], ch[1], h->h_timeout);
+        GPF_LAUNCH(k_scan_residual2, dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, h->cdf[0], ws, n_slots_global, h->n, h->ntiles, ch[0], ch[1], h->h_timeout, head_anc, &h->sc->giants, h->epoch & 0xffffffu);
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
@@ -995,10 +997,12 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     sa.update_lml = local ? 2 : (h->parent ? 0 : 1);             // sub-states do not track the estimate (resample.jl:185-187)
 
     if (method == GPF_RESAMPLE_RESIDUAL) {
-        if ((s = residual_scans(h, ws, h->cfg.n_global))) return s;
+        static const bool head_in_search = getenv("GPF_RESIDUAL_HEAD") && !strcmp(getenv("GPF_RESIDUAL_HEAD"), "search");   // (A/B measurements)
+        if ((s = residual_scans(h, ws, h->cfg.n_global, head_in_search ? nullptr : h->anc))) return s;
         sa.w = levels(h, 2); sa.c = levels(h, 1);
+        sa.head_done = head_in_search ? 0 : 1;
     }
-    const int64_t nt = method == GPF_RESAMPLE_RESIDUAL ? 2 : 1;
+    const int64_t nt = method == GPF_RESAMPLE_RESIDUAL && !sa.head_done ? 2 : 1;   // (top tables the search keeps in LDS: its shape depends on their number)
     const size_t lds = search_lds_bytes(h->ntiles, (int)nt);
     // every block first copies the top level of the CDF into LDS: keep the grid small (persistent blocks)
     // one 1024-thread workgroup per CU, two slots per lane and iteration
