@@ -949,6 +949,9 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     if ((s = check_scan_timeout(h))) return s;                   // an earlier scan gave up: do not build on its CDF
     if ((s = materialize(h))) return s;                          // two resamples in a row: finish the first one
     // sortperm(log_priorities, rev=true)  (resample.jl:156-157)
+    // with priorities the log-ML update needs the summary of the RAW weights (cdf[0] is overwritten later; only S, m matter).  First:
+    // it may recompute the maximum slots for the raw weights, and from here on they must describe the priorities (sort keys, scan)
+    if (pv.mode != 0 && (s = ensure_raw(h))) return s;
     bool sort_pending = false;                                   // the sort's verdict (k_sort_finish) is asked for after the search is enqueued
     if (sorted) {
         if ((s = ensure_max(h, pv, pv.mode == 0))) return s;     // (the coarse sort keys are distances from the maximum)
@@ -964,7 +967,6 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
             published = need_sync;
         }
     } else {
-        if ((s = ensure_raw(h))) return s;                       // raw summary (cdf[0] is overwritten next; only S, m matter)
         h->want_offsets = need_off;
         ws = &h->sc->prio;
         if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, false, false, need_sync, sorted))) return s;

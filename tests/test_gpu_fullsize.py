@@ -346,3 +346,26 @@ def test_sort_fallback_and_eight_pass_modes_agree():
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1] == outs[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [5, 37, 1000, 70_001])
+@pytest.mark.parametrize("alpha", [0.5, 2.0])
+def test_sorted_stratified_with_priorities_right_after_a_weight_change(g, o, N, alpha):
+    """sort_particles=true with priority_fn = w -> alpha w when neither the raw summary nor a maximum is current (fresh filter, host-set
+    weights): the sort keys and the scan need the maximum of the PRIORITIES, the log-ML update the summary of the raw weights -- in
+    that order of dependence (found by the random sequences: the raw summary, computed in between, had replaced the priorities' maximum)"""
+    model = g.models.bearings4(); ys = g.models.simulate(model, 3)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=279)
+    orc = o.OracleFilter(model.model_id, model.params, N, 279).initialize(ys[0])
+    for t in range(2):
+        g.pf_resample(st, "stratified", priority_fn=g.Tempering(alpha), sort_particles=True, check=False)
+        orc.resample("stratified", priority_alpha=alpha, sort_particles=True, check=False)
+        assert np.array_equal(st.parents, orc.parents) and np.array_equal(st.log_weights, orc.lw), (N, alpha, t)
+        lw = -3.0 * np.random.default_rng(t).random(N)
+        st.log_weights = lw; orc.lw = lw.copy()
+    g.pf_resample(st, "stratified", priority_fn=g.Tempering(alpha), sort_particles=True, check=False)
+    orc.resample("stratified", priority_alpha=alpha, sort_particles=True, check=False)
+    assert np.array_equal(st.parents, orc.parents) and np.array_equal(st.traces, orc.rows)
+    assert g.get_lml_est(st) == orc.log_ml_estimate()
+    st.close()
