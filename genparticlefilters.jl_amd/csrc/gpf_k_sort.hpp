@@ -308,8 +308,9 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __res
         const uint32_t grp = blockIdx.x & 15u, members = (gridDim.x - grp + 15u) / 16u, groups = gridDim.x < 16u ? gridDim.x : 16u;
         if (atomicAdd(done + (2 + grp) * SORT_DONE_STRIDE, 1u) == members - 1 && atomicAdd(done + SORT_DONE_STRIDE, 1u) == groups - 1) {
             const uint32_t v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(host_flag, (int64_t)(v & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(host_flag + 1, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // verdict and ticket in ONE word (ticket << 1 | flag): a relaxed store needs no release -- a system-scope release at the end of a
+            // kernel that has just written 12 MB would first write this XCD's L2 back
+            __hip_atomic_store(host_flag + 1, (ticket << 1) | (int64_t)(v & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

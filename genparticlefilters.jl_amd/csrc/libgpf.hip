@@ -813,9 +813,19 @@ gpf_status sort_desc_begin(gpf_filter* h, const PrioView& pv, int64_t n, bool* p
 }
 gpf_status sort_desc_flagged(gpf_filter* h, bool* flagged)
 {
-    gpf_status s = wait_ticket(h, h->h_sort_flag + 1, h->sort_ticket, "sort finish");
-    if (s) return s;
-    *flagged = h->h_sort_flag[0] != 0 || sort_mode() == 2;
+    // (the finish publishes ticket << 1 | verdict as one word)
+    volatile int64_t* tk = h->h_sort_flag + 1;
+    uint64_t spins = 0;
+    int64_t v;
+    while (((v = __atomic_load_n(tk, __ATOMIC_ACQUIRE)) >> 1) != h->sort_ticket) {
+        cpu_relax();
+        if ((++spins & 0x3fff) != 0) continue;
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipErrorNotReady) continue;
+        if ((__atomic_load_n(tk, __ATOMIC_ACQUIRE) >> 1) == h->sort_ticket) continue;
+        return fail(h, GPF_ERR_HIP, q == hipSuccess ? "sort finish: the stream drained without the ticket being published" : hipGetErrorString(q));
+    }
+    *flagged = (v & 1) != 0 || sort_mode() == 2;
     return GPF_OK;
 }
 gpf_status sort_desc(gpf_filter* h, const PrioView& pv, int64_t n)
