@@ -135,6 +135,7 @@ struct gpf_filter {
     uint64_t mb_cur[MB_KINDS] = {0, 0, 0};   // the round whose entries the current gathered pointers name
     int32_t* h_timeout = nullptr;        // pinned: set by a scan whose bounded inter-workgroup wait gave up (checked on the host)
     int scan_blocks_per_cu = 2;          // resident scan workgroups per CU the launch may rely on (occupancy query)
+    int wscan_blocks_per_cu = 2;         // ... of the weight scans k_scan<InFixQ, *> alone (fewer registers than the residual scan)
     int64_t* shard_counts = nullptr;     // [2 * MAX_SHARDS] exchange counters of the current resample (device) + pinned mirror
     int64_t* h_shard_counts = nullptr;
     // block-wise resampling (gpf_resample_blocks): {flags, count} words, the per-block mask, per-block statistics
@@ -532,6 +533,8 @@ gpf_status hist_begin_step(gpf_filter* h, bool first)
 // The scan's inter-workgroup protocol needs every workgroup of the launch resident at once (block b owns tiles b, b + G, ...
 // and waits for lower tiles of its round): at most scan_blocks_per_cu per CU, from the occupancy query at gpf_create.
 int scan_grid(const gpf_filter* h) { return (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, (int64_t)h->scan_blocks_per_cu * h->n_cu)); }
+// the weight scans (k_scan<InFixQ, *>): up to WSCAN_MAX workgroups per CU, so that filters of up to WSCAN_MAX x 0.52 M particles scan in ONE round
+int wscan_grid(const gpf_filter* h) { return (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, (int64_t)h->wscan_blocks_per_cu * h->n_cu)); }
 
 // one scan launch on descriptor channel `ch` (0 weights, 1 residual counts, 2 residual weights)
 template <class In, int FIXQ>
@@ -540,7 +543,7 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
 {
     uint64_t* dc = h->desc[ch][h->dcur[ch]];
     uint64_t* dn = h->desc[ch][1 - h->dcur[ch]];
-    const int gs = scan_grid(h);
+    const int gs = std::is_same<In, InFixQ>::value ? wscan_grid(h) : scan_grid(h);
     const bool offsets = ch == 0 && h->want_offsets && want_cdf;
     const ScanOut so = scan_out(want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch], h->ntiles, offsets);
     if (ch == 0 && want_cdf) h->ch0_offsets = offsets && so.off16 != nullptr;
@@ -636,7 +639,7 @@ gpf_status fetch_scalars(gpf_filter* h, bool fold_raw_q = false)
     if (!h->h_sc_ticket) { HIP_TRY(h, hipHostMalloc(&h->h_sc_ticket, sizeof(long long))); *h->h_sc_ticket = 0; }
     h->sc_ticket += 1;
     GPF_LAUNCH(k_publish_scalars, dim3(1), dim3(WAVE), 0, h->stream, h->sc, h->h_sc, h->h_sc_ticket, h->sc_ticket,
-               fold_raw_q ? h->blockQ : nullptr, fold_raw_q ? scan_grid(h) : 0);
+               fold_raw_q ? h->blockQ : nullptr, fold_raw_q ? wscan_grid(h) : 0);
     HIP_TRY(h, hipGetLastError());
     { gpf_status w = wait_ticket(h, reinterpret_cast<volatile int64_t*>(h->h_sc_ticket), (int64_t)h->sc_ticket, "scalar block"); if (w) return w; }
     return check_scan_timeout(h);
@@ -1151,7 +1154,7 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
             HIP_TRY(h, hipMalloc(&h->mslots[b], (size_t)MAX_SLOTS * SLOT_WORDS * sizeof(unsigned long long)));
             HIP_TRY(h, hipMemsetAsync(h->mslots[b], 0, (size_t)MAX_SLOTS * SLOT_WORDS * sizeof(unsigned long long), h->stream));
         }
-        HIP_TRY(h, hipMalloc(&h->blockQ, (size_t)4 * 2 * h->n_cu * sizeof(uint64_t) + 64));
+        HIP_TRY(h, hipMalloc(&h->blockQ, (size_t)4 * 8 * h->n_cu * sizeof(uint64_t) + 64));   // (4 limbs per scan workgroup, <= 8 workgroups per CU)
         HIP_TRY(h, hipMalloc(&h->partial, MAX_PARTIALS * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->acc_part, MAX_PARTIALS * sizeof(unsigned long long)));
         HIP_TRY(h, hipMalloc(&h->dscal, 4 * sizeof(double)));
@@ -1172,6 +1175,15 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
                 nb = std::min(nb, q > 2 ? q - 1 : q);
             }
             h->scan_blocks_per_cu = std::max(1, std::min(nb, 2));
+            int wb = 64;
+            for (int k = 0; k < 4; ++k) {
+                int q = 0;
+                HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scans[k], SCAN_BLOCK, 0));
+                wb = std::min(wb, q > 2 ? q - 1 : q);
+            }
+            // (measured at 2 x 10^6 particles, 977 tiles: 2 per CU = two rounds 23.2 us, 4 per CU = one round 21.3 us; GPF_WSCAN_BLOCKS for A/B)
+            static const int wscan_max = getenv("GPF_WSCAN_BLOCKS") ? atoi(getenv("GPF_WSCAN_BLOCKS")) : 4;
+            h->wscan_blocks_per_cu = std::max(1, std::min(std::min(wb, wscan_max), 8));
         }
         HIP_TRY(h, hipMemsetAsync(h->sc, 0, sizeof(Scalars), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->lw, 0, n * sizeof(double), h->stream));
@@ -2029,7 +2041,7 @@ gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t ste
             HIP_TRY(v, hipMalloc(&v->mslots[b], (size_t)MAX_SLOTS * SLOT_WORDS * sizeof(unsigned long long)));
             HIP_TRY(v, hipMemsetAsync(v->mslots[b], 0, (size_t)MAX_SLOTS * SLOT_WORDS * sizeof(unsigned long long), v->stream));
         }
-        HIP_TRY(v, hipMalloc(&v->blockQ, (size_t)4 * 2 * v->n_cu * sizeof(uint64_t) + 64));
+        HIP_TRY(v, hipMalloc(&v->blockQ, (size_t)4 * 8 * v->n_cu * sizeof(uint64_t) + 64));
         HIP_TRY(v, hipMalloc(&v->partial, MAX_PARTIALS * sizeof(double)));
         HIP_TRY(v, hipMalloc(&v->acc_part, MAX_PARTIALS * sizeof(unsigned long long)));
         HIP_TRY(v, hipMalloc(&v->dscal, 4 * sizeof(double)));
@@ -2037,7 +2049,7 @@ gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t ste
         HIP_TRY(v, hipHostMalloc(&v->h_sc, sizeof(Scalars)));
         HIP_TRY(v, hipHostMalloc(&v->h_timeout, sizeof(int32_t)));
         *v->h_timeout = 0;
-        v->scan_blocks_per_cu = parent->scan_blocks_per_cu;
+        v->scan_blocks_per_cu = parent->scan_blocks_per_cu; v->wscan_blocks_per_cu = parent->wscan_blocks_per_cu;
         HIP_TRY(v, hipMemsetAsync(v->sc, 0, sizeof(Scalars), v->stream));
         return GPF_OK;
     };
@@ -2372,7 +2384,7 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     InFixQ in{h->sum_pv_set ? h->sum_pv : raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
     WSum* const slot = h->sum_slot ? h->sum_slot : &h->sc->raw;
     const bool want_cdf = !h->sum_no_cdf;
-    const int gs = scan_grid(h);
+    const int gs = wscan_grid(h);
     // the scan folds the gathered (max, flags) pairs itself and writes the shard total straight into out5[0]; it also
     // publishes the global validity flags to pinned host memory (gpf_shard_flags)
     if (!h->h_flags) { HIP_TRY(h, hipHostMalloc(&h->h_flags, 2 * sizeof(int64_t))); h->h_flags[0] = h->h_flags[1] = 0; }
