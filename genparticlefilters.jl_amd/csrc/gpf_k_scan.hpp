@@ -158,6 +158,13 @@ struct ScanExtras {            // optional side jobs of a scan launch
     MboxWait wait;
     MboxPush push;
     int zero_stride;
+    // MODE 2 (the ESS getter): the scan publishes {flags, S, limbs of sum q^2} + a ticket to pinned host memory itself -- no publish launch
+    // behind it (~5 us per ESS read; BASELINE config 4 and the README loop read the ESS every step).  Fence-free, like every other
+    // protocol here (an agent-scope fence at the end of a kernel that has written 10 MB writes the XCD's L2 back: measured, +30 us):
+    // every workgroup leaves its limb partials as TAGGED words (tag << 48 | sum, relaxed agent-scope stores), the workgroup that
+    // held the last tile -- it owns S -- waits for the words of this launch's tag, folds them and stores the summary.
+    int64_t* q_host;           // pinned [7]: flags, S, Ql0..3, ticket; nullptr: untagged partials, folded later (k_publish_scalars / k_export_q)
+    int64_t q_ticket;
 };
 // Workgroup of the scan kernels: SCAN_BLOCK threads over one 2048-element tile, every wave SCAN_ROWS rows of 128.  256 threads x 4
 // rows is the measured optimum: 512 x 2 (twice the waves per CU against the kernel's three dependent round trips) ran 1.3-1.5 us
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
         for (int i = threadIdx.x; i < 2 * MAX_SHARDS * ex.zero_stride; i += SCAN_BLOCK) ex.zero128[i] = 0;
     __shared__ uint64_t s_wave[SCAN_NWAVES];
     __shared__ uint64_t s_red[SCAN_NWAVES];
+    __shared__ uint64_t s_Stot;
     uint64_t* const d_agg = dcur;
     uint64_t* const d_pre = dcur + ntiles;
     for (int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * SCAN_BLOCK) dnext[i] = 0;
@@ -311,6 +319,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
         if (tile == ntiles - 1 && threadIdx.x == SCAN_BLOCK - 1) {
             const uint64_t Stot = off + p[2 * SCAN_ROWS - 1];
             *total_out = Stot;
+            if constexpr (WANT_Q) s_Stot = Stot;
             if constexpr (MODE >= 1) {
                 if (ex.n_slots > 0) {                   // one thread per launch: a true 64-bit division is fine here
                     const uint64_t Bq = Stot / (uint64_t)ex.n_slots;
@@ -328,10 +337,43 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
         for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
         if (lane == 0) { for (int k = 0; k < 4; ++k) s_q[wv][k] = ql[k]; }
         __syncthreads();
+        const uint64_t qtag = ex.q_host ? (uint64_t)((ex.q_ticket & 0x7fff) + 1) << 48 : 0;       // (limb sums of a workgroup stay below 2^47)
         if (threadIdx.x < 4) {
             uint64_t t = 0;
             for (int w = 0; w < SCAN_NWAVES; ++w) t += s_q[w][threadIdx.x];
-            blockQ[(int64_t)blockIdx.x * 4 + threadIdx.x] = t;
+            if (ex.q_host) __hip_atomic_store(blockQ + (int64_t)blockIdx.x * 4 + threadIdx.x, qtag | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else blockQ[(int64_t)blockIdx.x * 4 + threadIdx.x] = t;
+        }
+        if (ex.q_host && (int64_t)blockIdx.x == (ntiles - 1) % (int64_t)gridDim.x) {          // the workgroup that held the last tile (workgroup-uniform)
+            uint64_t q[4] = {0, 0, 0, 0};
+            for (int b = threadIdx.x; b < (int)gridDim.x; b += SCAN_BLOCK) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint64_t v = __hip_atomic_load(blockQ + (int64_t)b * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned spins = 0;
+                    while ((v >> 48) != (qtag >> 48)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        v = __hip_atomic_load(blockQ + (int64_t)b * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++spins > SPIN_LIMIT) { *timeout = 1; break; }
+                    }
+                    q[k] += v & 0xffffffffffffull;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = wave_sum_u64(q[k]);
+            __syncthreads();                                                                  // s_q: read above by threads 0..3
+            if (lane == 0) { for (int k = 0; k < 4; ++k) s_q[wv][k] = q[k]; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint64_t t[4] = {0, 0, 0, 0};
+                for (int w = 0; w < SCAN_NWAVES; ++w) for (int k = 0; k < 4; ++k) t[k] += s_q[w][k];
+                for (int k = 0; k < 4; ++k) ws_out->Ql[k] = t[k];                              // (the device copy: later getters find the limbs folded)
+                __hip_atomic_store(ex.q_host + 0, (int64_t)in.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(ex.q_host + 1, (int64_t)s_Stot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int k = 0; k < 4; ++k) __hip_atomic_store(ex.q_host + 2 + k, (int64_t)t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                         // (the six stores have left this wave: no cache write-back)
+                __hip_atomic_store(ex.q_host + 6, ex.q_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

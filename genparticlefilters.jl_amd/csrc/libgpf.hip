@@ -139,6 +139,8 @@ struct gpf_filter {
     int64_t* shard_counts = nullptr;     // [2 * MAX_SHARDS] exchange counters of the current resample (device) + pinned mirror
     int64_t* h_shard_counts = nullptr;
     // block-wise resampling (gpf_resample_blocks): {flags, count} words, the per-block mask, per-block statistics
+    int64_t* h_qpub = nullptr; int64_t q_ticket = 0;   // the ESS getter's scan publishes {flags, S, limbs of sum q^2} itself (ScanExtras::q_host)
+    bool q_published = false;                          // ... and the scan of THIS call did
     int32_t* blk_words = nullptr; int32_t* blk_mask = nullptr; double* blk_stats = nullptr; int64_t blk_cap = 0, blk_last = 0;
     double* blk_obs = nullptr; int64_t blk_obs_cap = 0;                                // per-block observations [n_blocks][MAX_OBS] on the device
     static constexpr int BLK_STAGE = 4;                                                // pinned staging buffers, used in turn (no stream sync per step)
@@ -582,6 +584,15 @@ gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cd
     }
     const int np = 0;               // (only the sharded scans fold gathered pairs)
     gpf_status s;
+    h->q_published = false;
+    static const bool q_publish_off = getenv("GPF_ESS_PUBLISH") && !strcmp(getenv("GPF_ESS_PUBLISH"), "kernel");   // (A/B: the separate publish launch)
+    if (want_q && slot == &h->sc->raw && !q_publish_off) {
+        // the ESS getter's scan: the workgroup of its last tile folds sum q^2 and publishes {flags, S, limbs} to pinned memory itself
+        if (!h->h_qpub) { HIP_TRY(h, hipHostMalloc(&h->h_qpub, 7 * sizeof(int64_t))); for (int i = 0; i < 7; ++i) h->h_qpub[i] = 0; }
+        h->q_ticket += 1;
+        ex.q_host = h->h_qpub; ex.q_ticket = h->q_ticket;
+        h->q_published = true;
+    }
     if (!max_ready && (s = ensure_max(h, pv, use_producer_max))) return s;
     InFixQ in{pv, order, order ? h->keys : nullptr, h->K, 0.0, 0};     // (after sort_desc the sorted keys are in h->keys)
     if (want_q) s = scan_launch<InFixQ, 2>(h, 0, in, np, slot, want_cdf, &slot->S, nullptr, ex);
@@ -603,7 +614,7 @@ gpf_status ensure_raw(gpf_filter* h, bool want_q = false)
     if (s) return s;
     h->raw_valid = true;
     h->raw_has_q = want_q;
-    h->raw_q_folded = false;
+    h->raw_q_folded = h->q_published;                            // (a publishing scan folds the limbs itself; its partials are tagged words)
     return GPF_OK;
 }
 
@@ -1232,6 +1243,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->h_sc_ticket) hipHostFree(h->h_sc_ticket);
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
     if (h->h_pull_pc_all) hipHostFree(h->h_pull_pc_all);
+    if (h->h_qpub) hipHostFree(h->h_qpub);
     for (int k = 0; k < gpf_filter::BLK_STAGE; ++k) if (h->h_blk_obs[k]) hipHostFree(h->h_blk_obs[k]);
     if (h->h_blk_done) hipHostFree(h->h_blk_done);
     if (h->blk_stage_counter) (void)hipFree(h->blk_stage_counter);
@@ -1722,11 +1734,22 @@ gpf_status gpf_effective_sample_size(gpf_handle h, double* out)
     gpf_status s = check_ready(h);
     if (s) return s;
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
+    h->q_published = false;
     if ((s = ensure_raw(h, true))) return s;
-    const bool fold = !h->raw_q_folded;                          // the scan blocks' limb partials of sum q^2: folded by the publish kernel
-    if ((s = fetch_scalars(h, fold))) return s;
-    h->raw_q_folded = true;
-    const WSum& w = h->h_sc->raw;
+    WSum w{};
+    if (h->q_published) {
+        // the scan of this call publishes {flags, S, limbs of sum q^2} itself: wait for its ticket, no publish launch
+        h->q_published = false;
+        if ((s = wait_ticket(h, h->h_qpub + 6, h->q_ticket, "ESS summary"))) return s;
+        if ((s = check_scan_timeout(h))) return s;
+        w.flags = (int32_t)h->h_qpub[0]; w.S = (uint64_t)h->h_qpub[1];
+        for (int k = 0; k < 4; ++k) w.Ql[k] = (uint64_t)h->h_qpub[2 + k];
+    } else {
+        const bool fold = !h->raw_q_folded;                      // the scan blocks' limb partials of sum q^2: folded by the publish kernel
+        if ((s = fetch_scalars(h, fold))) return s;
+        h->raw_q_folded = true;
+        w = h->h_sc->raw;
+    }
     if (w.flags) { *out = std::nan(""); return GPF_OK; }
     uint64_t hi, lo;
     normalise_Q(w, hi, lo);
