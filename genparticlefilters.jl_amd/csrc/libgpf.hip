@@ -1166,6 +1166,8 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
             HIP_TRY(h, hipMemsetAsync(h->mslots[b], 0, (size_t)MAX_SLOTS * SLOT_WORDS * sizeof(unsigned long long), h->stream));
         }
         HIP_TRY(h, hipMalloc(&h->blockQ, (size_t)4 * 8 * h->n_cu * sizeof(uint64_t) + 64));   // (4 limbs per scan workgroup, <= 8 workgroups per CU)
+        // (zeroed: the ESS scan recognises this launch's partials by a tag in their top bits -- recycled memory may hold another filter's)
+        HIP_TRY(h, hipMemsetAsync(h->blockQ, 0, (size_t)4 * 8 * h->n_cu * sizeof(uint64_t) + 64, h->stream));
         HIP_TRY(h, hipMalloc(&h->partial, MAX_PARTIALS * sizeof(double)));
         HIP_TRY(h, hipMalloc(&h->acc_part, MAX_PARTIALS * sizeof(unsigned long long)));
         HIP_TRY(h, hipMalloc(&h->dscal, 4 * sizeof(double)));
@@ -2065,6 +2067,7 @@ gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t ste
             HIP_TRY(v, hipMemsetAsync(v->mslots[b], 0, (size_t)MAX_SLOTS * SLOT_WORDS * sizeof(unsigned long long), v->stream));
         }
         HIP_TRY(v, hipMalloc(&v->blockQ, (size_t)4 * 8 * v->n_cu * sizeof(uint64_t) + 64));
+        HIP_TRY(v, hipMemsetAsync(v->blockQ, 0, (size_t)4 * 8 * v->n_cu * sizeof(uint64_t) + 64, v->stream));
         HIP_TRY(v, hipMalloc(&v->partial, MAX_PARTIALS * sizeof(double)));
         HIP_TRY(v, hipMalloc(&v->acc_part, MAX_PARTIALS * sizeof(unsigned long long)));
         HIP_TRY(v, hipMalloc(&v->dscal, 4 * sizeof(double)));
