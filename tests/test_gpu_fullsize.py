@@ -220,8 +220,8 @@ def test_search_time_does_not_depend_on_how_the_weights_are_spread(g, method):
 @pytest.mark.gpu
 @pytest.mark.parametrize("ntiles,extra", [(594, 3), (595, 0), (612, 0), (612, 1), (1024, 1), (1224, 1), (1225, 5), (2451, 0), (2452, 3)])
 def test_sizes_where_the_search_changes_its_tables(g, o, ntiles, extra):
-    """the ancestor searches pick their LDS tables by size: both levels of k_search_fine up to 594 scan tiles (1.216 M particles),
-    32-cell key groups up to 612 scan tiles (1.25 M particles), 64-cell
+    """the ancestor searches pick their LDS tables by size: 32-cell key groups up to 612 scan tiles (1.25 M particles; 594 / 595 tiles
+    were the boundary of a search variant that was measured and removed -- kept as ordinary sizes), 64-cell
     groups up to 1224 tiles, every fourth key of the 32-cell level up to 2451 tiles (5 M particles), the two-line search beyond; the
     per-256 level as top table up to 1024 tiles, tile descriptors beyond; one filter on each side of every boundary, all three
     resamplers against the oracle"""
