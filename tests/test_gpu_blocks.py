@@ -278,3 +278,27 @@ def test_block_step_argument_errors(g, o):
     with pytest.raises(g.ErrorException):
         g.pf_rejuvenate(st[0:100], None, (), 1)                                  # a view after a block-wise update
     st.close()
+
+
+@pytest.mark.parametrize("nb", [100, 512, 2048])
+def test_many_blocks_at_once(g, o, nb):
+    """a grid of thousands of teams (more than one workgroup round per CU): 200 000 particles in blocks of 100 / 512 / 2048, per-block data,
+    ESS-gated residual resample, masked MH move -- against the loop over sub-states"""
+    N = 200_000
+    m = g.models.bearings4(); base = np.asarray(g.models.simulate(m, 4))
+    B = (N + nb - 1) // nb
+    rng = np.random.default_rng(nb)
+    ys = base[None, :, :] + 0.3 * rng.standard_normal((B,) + base.shape)
+    st = g.pf_initialize_blocks(m, (1,), ys[:, 0], N, nb, seed=21, keep_prev=True)
+    f = oracle_init_blocks(o, o.OracleFilter(m.model_id, m.params, N, 21, keep_prev=True), nb, ys[:, 0])
+    for t in range(1, 3):
+        g.pf_update_blocks(st, (t + 1,), (None,), ys[:, t], nb); oracle_update_blocks(f, nb, ys[:, t])
+        n_res = g.pf_resample_blocks(st, nb, "residual", ess_frac=0.6, check=False)
+        mask = oracle_blocks(f, nb, "residual", ess_frac=0.6)
+        assert n_res == mask.sum() and np.array_equal(g.block_resampled(st), mask)
+        g.pf_rejuvenate_blocks(st, None, (), 1, method="move", only_resampled=True); oracle_rejuvenate_blocks(f, nb, ys[:, t], "move", mask)
+        assert same(st, f), (nb, t)
+    ess, lml = g.block_stats(st, nb)
+    ks = rng.choice(B, size=min(B, 25), replace=False)
+    assert all(lml[k] == f[int(k) * nb:min((int(k) + 1) * nb, N)].log_ml_estimate() for k in ks)
+    st.close()
