@@ -43,7 +43,7 @@ SYMBOLS = [
     ("gpf_initialize_strata_proposal", C.c_int, [_H, _pd, C.c_int32, _pd, C.c_int32, C.c_int32, C.c_int32]),
     ("gpf_resample", C.c_int, [_H, C.c_int32, C.c_double, C.c_int32, C.c_int32, _pi32]),
     ("gpf_resample_local", C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, _pi32]),
-    ("gpf_resample_blocks", C.c_int, [_H, C.c_int32, C.c_int64, C.c_int32, C.c_double, C.c_int32, _pi32, C.POINTER(C.c_int64)]),
+    ("gpf_resample_blocks", C.c_int, [_H, C.c_int32, C.c_int64, C.c_double, C.c_int32, C.c_double, C.c_int32, _pi32, C.POINTER(C.c_int64)]),
     ("gpf_block_resampled", C.c_int, [_H, _pi32]),
     ("gpf_block_stats", C.c_int, [_H, C.c_int64, _pd, _pd]),
     ("gpf_initialize_blocks", C.c_int, [_H, _pd, C.c_int32, C.c_int64]),

@@ -374,7 +374,7 @@ def pf_resample(state, method: str = "multinomial", **kwargs):
     raise ErrorException(f"Resampling method {method} not recognized.")
 
 
-def pf_resample_blocks(state, block_size: int, method: str = "multinomial", *, ess_frac=None, sort_particles: bool = True, check="warn"):
+def pf_resample_blocks(state, block_size: int, method: str = "multinomial", *, priority_fn=None, ess_frac=None, sort_particles: bool = True, check="warn"):
     """Many small filters in one state: the batched form of
 
         for b in blocks:                                   # consecutive blocks of block_size particles (<= 2048)
@@ -390,9 +390,12 @@ def pf_resample_blocks(state, block_size: int, method: str = "multinomial", *, e
         raise ValueError("check must be True, 'warn' or False")
     if isinstance(state, DeviceParticleFilterSubState):
         raise ErrorException("pf_resample_blocks works on the whole filter")
+    if priority_fn is not None and not isinstance(priority_fn, Tempering):
+        raise ErrorException("block-wise resampling takes priority_fn = None or Tempering(alpha) (w -> alpha w)")
     check_id = 2 if check is True else (1 if check == "warn" else 0)
     inv, cnt = C.c_int32(0), C.c_int64(0)
-    st = state._L.gpf_resample_blocks(state._h, RESAMPLE_METHODS[method], int(block_size), int(sort_particles),
+    st = state._L.gpf_resample_blocks(state._h, RESAMPLE_METHODS[method], int(block_size),
+                                      float("nan") if priority_fn is None else float(priority_fn.alpha), int(sort_particles),
                                       float("nan") if ess_frac is None else float(ess_frac), check_id, C.byref(inv), C.byref(cnt))
     state._n_blocks_last = (state.n_particles + int(block_size) - 1) // int(block_size) if int(block_size) > 0 else 0
     if st != _lib.OK:

@@ -28,6 +28,7 @@ struct BlockArgs {
     int64_t gid0;                                  // global id of particle 0 (RNG counters)
     uint64_t seed; uint32_t epoch;
     int sorted;                                    // stratified: sort_particles
+    double alpha;                                  // PRIO kernels: priority_fn = w -> alpha w (resample.jl:51-52)
     double ess_frac;                               // < 0: every block resamples
     int check_true;                                // check = true: blocks with invalid (all -Inf) weights are left alone as well
     int32_t* resampled;                            // [n_blocks] bit 0: the block resampled; bits 8..: its validity flags (no shared counter:
@@ -94,7 +95,31 @@ __device__ __forceinline__ int lds_upper_bound(const uint64_t* cdf, int cnt, uin
     return lo < cnt ? lo : cnt - 1;
 }
 
-template <int METHOD, int W, int TEAM, int ITEMS>     // METHOD 0 multinomial, 1 residual, 2 stratified
+// maximum and validity flags of the team's values (safe_softmax, utils.jl:119-126); s_m / s_f: NWAVES words each (TEAM = BLOCK only)
+template <int TEAM, int ITEMS>
+__device__ __forceinline__ void team_max_flags(const double (&v)[ITEMS], int tl, int cnt, double* s_m, int* s_f, double& m_out, int& f_out)
+{
+    double m = -__builtin_huge_val(); int f = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+        if (ITEMS * tl + k < cnt) { const double x = v[k]; if (x != x) f |= FLAG_NAN; else { m = x > m ? x : m; if (x == __builtin_huge_val()) f |= FLAG_POSINF; } }
+    m = wave_max_f64(m);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
+    if (TEAM == BLOCK) {
+        __syncthreads();                                           // (s_m / s_f may still be read from a previous call)
+        if (lane_id() == 0) { s_m[wave_id()] = m; s_f[wave_id()] = f; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) { m = s_m[w] > m ? s_m[w] : m; f |= s_f[w]; }
+    }
+    if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+    m_out = m; f_out = f;
+}
+
+// PRIO: priority_fn = w -> alpha w (resample.jl:51-52): ancestors from the priorities' CDF, the ESS gate on the raw weights, new weights
+// log_ws + (logsumexp(block weights) - logsumexp(log_ws)) with log_ws = lw[a] - lp[a] (the sub-state form, resample.jl:213-216)
+template <int METHOD, int W, int TEAM, int ITEMS, bool PRIO = false>     // METHOD 0 multinomial, 1 residual, 2 stratified
 __global__ __launch_bounds__(BLOCK) void k_block_resample(BlockArgs a)
 {
     constexpr int TEAMS = BLOCK / TEAM, CAP = TEAM * ITEMS;        // blocks per workgroup, particles a team holds
@@ -105,56 +130,61 @@ __global__ __launch_bounds__(BLOCK) void k_block_resample(BlockArgs a)
     __shared__ uint64_t s_x[NWAVES][4];
     __shared__ double s_m[NWAVES];
     __shared__ int s_f[NWAVES];
+    __shared__ double s_lw_[PRIO ? BLOCK * ITEMS : 1];             // PRIO: the block's incoming log-weights, then log_ws of its slots
+    __shared__ double s_lws_[PRIO ? BLOCK * ITEMS : 1];
     const int tm = (int)threadIdx.x / TEAM, tl = (int)threadIdx.x % TEAM, lane = lane_id(), wv = wave_id();
     const int64_t blk = (int64_t)blockIdx.x * TEAMS + tm;
     if (TEAM != BLOCK && blk >= a.nblocks) return;                 // (an idle wave: the wave-team path has no workgroup barrier)
+    double* const s_lw = s_lw_ + (PRIO ? tm * CAP : 0);
+    double* const s_lws = s_lws_ + (PRIO ? tm * CAP : 0);
+    (void)lane; (void)wv;
     uint64_t* const s_cdf = s_cdf_ + tm * CAP;
     uint64_t* const s_aux = s_aux_ + (METHOD == 0 ? 0 : tm * CAP);
     uint16_t* const s_idx = s_idx_ + (METHOD == 2 ? tm * CAP : 0);
     const int64_t b0 = blk * a.nb;
     const int cnt = (int)(a.n - b0 < a.nb ? a.n - b0 : a.nb);      // particles of this block
     const int K = fix_K(cnt);
-    // ---- maximum + flags (utils.jl:119-126)
+    // ---- the raw weights: maximum + flags (utils.jl:119-126), fixed-point weights, their sum (and sum of squares for the ESS gate)
     double lwv[ITEMS];
-    double m = -__builtin_huge_val(); int f = 0;
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-        const int i = ITEMS * tl + k;
-        lwv[k] = i < cnt ? a.lw[b0 + i] : -__builtin_huge_val();
-        if (i < cnt) { const double v = lwv[k]; if (v != v) f |= FLAG_NAN; else { m = v > m ? v : m; if (v == __builtin_huge_val()) f |= FLAG_POSINF; } }
-    }
-    m = wave_max_f64(m);
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
-    if (TEAM == BLOCK) {
-        if (lane == 0) { s_m[wv] = m; s_f[wv] = f; }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < NWAVES; ++w) { m = s_m[w] > m ? s_m[w] : m; f |= s_f[w]; }
-    }
-    if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
-    // NaN / +Inf weights: Categorical rejects them in the reference; with check = true any invalid block: left as it stands
-    const bool skip = (f & (FLAG_NAN | FLAG_POSINF)) != 0 || (a.check_true && f != 0);
-    // ---- fixed-point weights, their sum (and sum of squares for the ESS)
-    const bool uniform = (f & FLAG_ALL_NEGINF) != 0;
+    for (int k = 0; k < ITEMS; ++k) { const int i = ITEMS * tl + k; lwv[k] = i < cnt ? a.lw[b0 + i] : -__builtin_huge_val(); }
+    double m_r; int f_r;
+    team_max_flags<TEAM, ITEMS>(lwv, tl, cnt, s_m, s_f, m_r, f_r);
     uint64_t q[ITEMS];
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) q[k] = ITEMS * tl + k < cnt ? (uniform ? 1ull : exp_fix(lwv[k] - m, K)) : 0ull;
-    bool go = !skip;
-    if (go && a.ess_frac >= 0.0) {                                 // (team-uniform)
+    for (int k = 0; k < ITEMS; ++k) q[k] = ITEMS * tl + k < cnt ? ((f_r & FLAG_ALL_NEGINF) ? 1ull : exp_fix(lwv[k] - m_r, K)) : 0ull;
+    bool gate = true;                                              // the block passes the ESS test (or there is none)
+    uint64_t S_r = 0;
+    if (PRIO || a.ess_frac >= 0.0) {                               // (team-uniform)
         unsigned __int128 Q = 0; uint64_t sl = 0;
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) { Q += (unsigned __int128)q[k] * q[k]; sl += q[k]; }
         // 128-bit team sum by limbs: the low word in two 32-bit halves (their carries just add up)
         uint64_t v4[4] = {(uint64_t)Q & 0xffffffffull, (uint64_t)Q >> 32, (uint64_t)(Q >> 64), sl};
         team_sum4<TEAM>(v4, s_x);
-        const unsigned __int128 Qt = ((unsigned __int128)v4[2] << 64) + ((unsigned __int128)v4[1] << 32) + v4[0];
-        const double ess = ess_from(v4[3], (uint64_t)(Qt >> 64), (uint64_t)Qt);
-        // `effective_sample_size(state) < N / 2`, README.md:72; invalid weights: the reference's ESS is NaN and the comparison false
-        go = f == 0 && ess < a.ess_frac * (double)cnt;
+        S_r = v4[3];
+        if (a.ess_frac >= 0.0) {
+            const unsigned __int128 Qt = ((unsigned __int128)v4[2] << 64) + ((unsigned __int128)v4[1] << 32) + v4[0];
+            const double ess = ess_from(S_r, (uint64_t)(Qt >> 64), (uint64_t)Qt);
+            // `effective_sample_size(state) < N / 2`, README.md:72; invalid weights: the reference's ESS is NaN and the comparison false
+            gate = f_r == 0 && ess < a.ess_frac * (double)cnt;
+        }
     }
-    // (with an ESS test an invalid block never gets as far as safe_softmax -- its ESS is NaN, the comparison false --: nothing to report)
-    if (tl == 0) a.resampled[blk] = (go ? 1 : 0) | ((a.ess_frac >= 0.0 ? 0 : f) << 8);
+    // ---- what the resampler samples from: the raw weights, or the priorities alpha * lw (their own maximum, flags, fixed-point weights)
+    double m = m_r; int f = f_r;
+    if (PRIO) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) { const int i = ITEMS * tl + k; if (i < cnt) s_lw[i] = lwv[k]; lwv[k] = i < cnt ? a.alpha * lwv[k] : -__builtin_huge_val(); }
+        team_max_flags<TEAM, ITEMS>(lwv, tl, cnt, s_m, s_f, m, f);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) q[k] = ITEMS * tl + k < cnt ? ((f & FLAG_ALL_NEGINF) ? 1ull : exp_fix(lwv[k] - m, K)) : 0ull;
+    }
+    // NaN / +Inf: Categorical rejects them in the reference; with check = true any invalid block: left as it stands
+    const bool skip = (f & (FLAG_NAN | FLAG_POSINF)) != 0 || (a.check_true && f != 0);
+    const bool uniform = (f & FLAG_ALL_NEGINF) != 0;
+    const bool go = gate && !skip;
+    // (a block that does not pass its ESS test never gets as far as safe_softmax: nothing to report for it)
+    if (tl == 0) a.resampled[blk] = (go ? 1 : 0) | ((gate ? f : 0) << 8);
     if (!go) {
         // this block keeps its particles: rows move to the other buffer unchanged, weights and parents stay
         for (int t = tl; t < cnt * (W / 2); t += TEAM)
@@ -166,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_resample(BlockArgs a)
     if (METHOD == 2 && a.sorted) {
         int p2 = 2;                                                // the network's size: the next power of two >= cnt
         while (p2 < cnt) p2 <<= 1;
-        for (int i = tl; i < p2; i += TEAM) { s_aux[i] = i < cnt ? sort_key_desc(a.lw[b0 + i]) : ~0ull; s_idx[i] = (uint16_t)i; }
+        for (int i = tl; i < p2; i += TEAM) { s_aux[i] = i < cnt ? sort_key_desc(PRIO ? a.alpha * a.lw[b0 + i] : a.lw[b0 + i]) : ~0ull; s_idx[i] = (uint16_t)i; }
         team_sync<TEAM>();
         for (int size = 2; size <= p2; size <<= 1) {
             for (int stride = size >> 1; stride >= 1; stride >>= 1) {
@@ -221,7 +251,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_resample(BlockArgs a)
     }
     team_sync<TEAM>();
     // ---- ancestors, gather, sub-state weights (resample.jl:205-211: every particle carries the block's average weight)
-    const double new_lw = lse_from(m, S, K, f) - log_((double)cnt);
+    const double new_lw = PRIO ? 0.0 : lse_from(m, S, K, f) - log_((double)cnt);
     const uint64_t sB = METHOD == 2 ? S / (uint64_t)cnt : 0, srem = METHOD == 2 ? S % (uint64_t)cnt : 0;
     for (int j = tl; j < cnt; j += TEAM) {                         // consecutive lanes, consecutive slots: coalesced stores
         const uint32_t slot = (uint32_t)(a.gid0 + b0 + j);
@@ -242,7 +272,24 @@ __global__ __launch_bounds__(BLOCK) void k_block_resample(BlockArgs a)
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) dst[c] = src[c];
         a.anc[b0 + j] = anc;
-        a.lw[b0 + j] = new_lw;
+        if (PRIO) { const double w0 = s_lw[anc]; s_lws[j] = w0 - a.alpha * w0; }               // log_ws = lw[a] - lp[a]  (:213)
+        else a.lw[b0 + j] = new_lw;
+    }
+    if (PRIO) {
+        // lw = log_ws + (logsumexp(block's incoming weights) - logsumexp(log_ws))   (resample.jl:213-216)
+        team_sync<TEAM>();
+        double wv2[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) { const int i = ITEMS * tl + k; wv2[k] = i < cnt ? s_lws[i] : -__builtin_huge_val(); }
+        double m2; int f2;
+        team_max_flags<TEAM, ITEMS>(wv2, tl, cnt, s_m, s_f, m2, f2);
+        uint64_t v4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) v4[3] += ITEMS * tl + k < cnt ? ((f2 & FLAG_ALL_NEGINF) ? 1ull : exp_fix(wv2[k] - m2, K)) : 0ull;
+        team_sum4<TEAM>(v4, s_x);
+        const double off = lse_from(m_r, S_r, K, f_r) - lse_from(m2, v4[3], K, f2);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) { const int i = ITEMS * tl + k; if (i < cnt) a.lw[b0 + i] = wv2[k] + off; }
     }
 }
 

@@ -922,21 +922,20 @@ void launch_move_blk(gpf_filter* h, int grid, int n_iters)
                        h->acc_part, RW ? next_slots(h) : MaxSlots{nullptr, nullptr});
 }
 // a block of <= 128 / <= 512 particles is the work of one wave (2 / 8 particles per lane, four blocks per workgroup), a larger one of a workgroup
-template <int METHOD, int Wc>
+template <int METHOD, int Wc, bool PRIO>
 void launch_block_resample_w(gpf_filter* h, const BlockArgs& a)
 {
-    if (a.nb <= 2 * WAVE)      GPF_LAUNCH((k_block_resample<METHOD, Wc, WAVE, 2>), dim3((unsigned)((a.nblocks + 3) / 4)), dim3(BLOCK), 0, h->stream, a);
-    else if (a.nb <= 8 * WAVE) GPF_LAUNCH((k_block_resample<METHOD, Wc, WAVE, 8>), dim3((unsigned)((a.nblocks + 3) / 4)), dim3(BLOCK), 0, h->stream, a);
-    else                       GPF_LAUNCH((k_block_resample<METHOD, Wc, BLOCK, 8>), dim3((unsigned)a.nblocks), dim3(BLOCK), 0, h->stream, a);
+    if (a.nb <= 2 * WAVE)      GPF_LAUNCH((k_block_resample<METHOD, Wc, WAVE, 2, PRIO>), dim3((unsigned)((a.nblocks + 3) / 4)), dim3(BLOCK), 0, h->stream, a);
+    else if (a.nb <= 8 * WAVE) GPF_LAUNCH((k_block_resample<METHOD, Wc, WAVE, 8, PRIO>), dim3((unsigned)((a.nblocks + 3) / 4)), dim3(BLOCK), 0, h->stream, a);
+    else                       GPF_LAUNCH((k_block_resample<METHOD, Wc, BLOCK, 8, PRIO>), dim3((unsigned)a.nblocks), dim3(BLOCK), 0, h->stream, a);
 }
 template <int METHOD>
-void launch_block_resample(gpf_filter* h, const BlockArgs& a, int64_t nblocks)
+void launch_block_resample(gpf_filter* h, const BlockArgs& a, bool prio)
 {
-    (void)nblocks;
     switch (h->W) {
-        case 2: launch_block_resample_w<METHOD, 2>(h, a); break;
-        case 4: launch_block_resample_w<METHOD, 4>(h, a); break;
-        case 8: launch_block_resample_w<METHOD, 8>(h, a); break;
+        case 2: if (prio) launch_block_resample_w<METHOD, 2, true>(h, a); else launch_block_resample_w<METHOD, 2, false>(h, a); break;
+        case 4: if (prio) launch_block_resample_w<METHOD, 4, true>(h, a); else launch_block_resample_w<METHOD, 4, false>(h, a); break;
+        case 8: if (prio) launch_block_resample_w<METHOD, 8, true>(h, a); else launch_block_resample_w<METHOD, 8, false>(h, a); break;
     }
 }
 // ancestors of i.i.d. targets: k_search_multi (4-byte keys of every 32 / 64 cells in LDS) while the key table fits, else k_search<0>
@@ -1435,8 +1434,8 @@ static gpf_status block_checks(gpf_handle h, int64_t block_size, const char* who
     if (block_size < 1 || block_size > BLK_MAX) return fail(h, GPF_ERR_INVALID_ARGUMENT, "block_size: 1 .. 2048 particles");
     return GPF_OK;
 }
-gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size, int32_t sort_particles, double ess_frac,
-                               int32_t check, int32_t* invalid, int64_t* n_resampled)
+gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size, double priority_alpha, int32_t sort_particles,
+                               double ess_frac, int32_t check, int32_t* invalid, int64_t* n_resampled)
 {
     gpf_status s = block_checks(h, block_size, "gpf_resample_blocks");
     if (s) return s;
@@ -1451,13 +1450,15 @@ gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size,
     a.rows_in = h->rows[h->cur]; a.rows_out = h->rows[1 - h->cur]; a.lw = h->lw; a.anc = h->anc;
     a.n = h->n; a.nb = block_size; a.nblocks = nblocks; a.gid0 = h->cfg.gid0; a.seed = h->cfg.seed; a.epoch = h->epoch;
     a.sorted = method == GPF_RESAMPLE_STRATIFIED && sort_particles ? 1 : 0;
+    const bool prio = priority_alpha == priority_alpha;
+    a.alpha = prio ? priority_alpha : 1.0;
     a.ess_frac = ess_frac == ess_frac ? ess_frac : -1.0;
     a.check_true = check == GPF_CHECK_TRUE ? 1 : 0;
     a.resampled = h->blk_mask;
     s = timed(h, GPF_K_SEARCH, [&] {
-        if (method == GPF_RESAMPLE_MULTINOMIAL)   launch_block_resample<0>(h, a, nblocks);
-        else if (method == GPF_RESAMPLE_RESIDUAL) launch_block_resample<1>(h, a, nblocks);
-        else                                      launch_block_resample<2>(h, a, nblocks);
+        if (method == GPF_RESAMPLE_MULTINOMIAL)   launch_block_resample<0>(h, a, prio);
+        else if (method == GPF_RESAMPLE_RESIDUAL) launch_block_resample<1>(h, a, prio);
+        else                                      launch_block_resample<2>(h, a, prio);
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());

@@ -139,6 +139,8 @@ gpf_status gpf_resample_local(gpf_handle h, int32_t method, int32_t sort_particl
  * resamples every block out of LDS with the sub-state semantics: normalised over the block, log_ml_est untouched, every particle of
  * a resampled block carries logsumexp(block weights) - log(block size), parents local to the block.  Block b's result is
  * bit-identical to the same call on a view of the block (gpf_view_create + gpf_resample), all blocks under the call's one epoch.
+ *   priority_alpha: NaN = priority_fn nothing; else priority_fn = w -> priority_alpha * w per block (src/resample.jl:51-52): ancestors from
+ *                the priorities, new weights log_ws + (logsumexp(block weights) - logsumexp(log_ws)), log_ws = lw[a] - lp[a] (:213-216).
  *   ess_frac:    >= 0: a block resamples only if its effective sample size is below ess_frac x its size (decided on the device;
  *                an invalid block -- ESS NaN -- does not);  < 0 or NaN: every block resamples.
  *   check / invalid: as gpf_resample, over all blocks; blocks with NaN / +Inf weights (and, with GPF_CHECK_TRUE, all -Inf blocks)
@@ -146,8 +148,8 @@ gpf_status gpf_resample_local(gpf_handle h, int32_t method, int32_t sort_particl
  *                invalid block never reaches the resampler -- its ESS is NaN -- and nothing is reported, as in the loop.)
  *   n_resampled: if non-NULL receives the number of blocks that resampled (synchronises).
  * Not on sharded filters, views or filters with a trajectory store (GPF_ERR_STATE). */
-gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size, int32_t sort_particles, double ess_frac,
-                               int32_t check, int32_t* invalid, int64_t* n_resampled);
+gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size, double priority_alpha, int32_t sort_particles,
+                               double ess_frac, int32_t check, int32_t* invalid, int64_t* n_resampled);
 /* which blocks the last gpf_resample_blocks resampled: out[ceil(n / block_size)] (host), 1 / 0 */
 gpf_status gpf_block_resampled(gpf_handle h, int32_t* out);
 /* effective_sample_size(state[b]) and log_ml_estimate(state[b]) = log_ml_est + logsumexp(block weights) - log(block size) of every block

@@ -146,12 +146,13 @@ end
 # over consecutive blocks of block_size particles (<= 2048) in ONE launch (gpf.h gpf_resample_blocks; sub-state semantics of
 # src/resample.jl:185-187,205-218, README.md:60-79 per block).  Returns the number of blocks that resampled.
 function pf_resample_blocks!(s::DeviceParticleFilterState, block_size::Int, method::Symbol=:multinomial;
-                             ess_frac=nothing, sort_particles::Bool=true, check=:warn)
+                             priority_fn::Union{Nothing,Tempering}=nothing, ess_frac=nothing, sort_particles::Bool=true, check=:warn)
     m = method == :multinomial ? 0 : method == :residual ? 1 : method == :stratified ? 2 : error("Resampling method $method not recognized.")
     chk = check === true ? 2 : (check === :warn ? 1 : 0)
     invalid = Ref{Cint}(0); count = Ref{Int64}(0)
-    st = ccall((:gpf_resample_blocks, libgpf), Cint, (Ptr{Cvoid}, Cint, Int64, Cint, Cdouble, Cint, Ptr{Cint}, Ptr{Int64}),
-               s.handle, m, block_size, sort_particles ? 1 : 0, ess_frac === nothing ? NaN : Float64(ess_frac), chk, invalid, count)
+    st = ccall((:gpf_resample_blocks, libgpf), Cint, (Ptr{Cvoid}, Cint, Int64, Cdouble, Cint, Cdouble, Cint, Ptr{Cint}, Ptr{Int64}),
+               s.handle, m, block_size, priority_fn === nothing ? NaN : priority_fn.alpha, sort_particles ? 1 : 0,
+               ess_frac === nothing ? NaN : Float64(ess_frac), chk, invalid, count)
     check(s, st)
     check === :warn && invalid[] != 0 && @warn("Invalid weights in some block: resampled with uniform weights.")
     return Int(count[])

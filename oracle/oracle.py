@@ -662,7 +662,8 @@ def blocks_of(f: OracleFilter, nb: int):
     return [(b0, min(b0 + nb, f.n)) for b0 in range(0, f.n, nb)]
 
 
-def resample_blocks(f: OracleFilter, nb: int, method: str = "multinomial", ess_frac=None, sort_particles: bool = True, check=False) -> np.ndarray:
+def resample_blocks(f: OracleFilter, nb: int, method: str = "multinomial", ess_frac=None, sort_particles: bool = True, check=False,
+                    priority_alpha=None) -> np.ndarray:
     """for b in blocks: if ess_frac is None or ESS(state[b]) < ess_frac * len(b): pf_resample!(state[b], method); returns the mask"""
     e, mask = f.epoch, []
     for a, b in blocks_of(f, nb):
@@ -670,7 +671,7 @@ def resample_blocks(f: OracleFilter, nb: int, method: str = "multinomial", ess_f
         f.epoch = e
         go = ess_frac is None or v.effective_sample_size() < ess_frac * v.n      # (NaN ESS of invalid weights: False, like the reference's `<`)
         if go:
-            v.resample(method, sort_particles=sort_particles, check=check)
+            v.resample(method, priority_alpha=priority_alpha, sort_particles=sort_particles, check=check)
         mask.append(bool(go))
     f.epoch = e + 1
     return np.array(mask)

@@ -18,10 +18,10 @@ def make(g, o, model_name, N, seed=11, keep_prev=False, T=6):
     return m, ys, st, f
 
 
-def oracle_blocks(f, nb, method, ess_frac=None, sort_particles=True, check=False):
+def oracle_blocks(f, nb, method, ess_frac=None, sort_particles=True, check=False, priority_alpha=None):
     """the loop over sub-states, every block under the call's one epoch (oracle/oracle.py resample_blocks); the mask of the blocks that resampled"""
     from oracle import oracle
-    return oracle.resample_blocks(f, nb, method, ess_frac=ess_frac, sort_particles=sort_particles, check=check)
+    return oracle.resample_blocks(f, nb, method, ess_frac=ess_frac, sort_particles=sort_particles, check=check, priority_alpha=priority_alpha)
 
 
 def same(st, f):
@@ -301,4 +301,25 @@ def test_many_blocks_at_once(g, o, nb):
     ess, lml = g.block_stats(st, nb)
     ks = rng.choice(B, size=min(B, 25), replace=False)
     assert all(lml[k] == f[int(k) * nb:min((int(k) + 1) * nb, N)].log_ml_estimate() for k in ks)
+    st.close()
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("alpha", [0.5, 2.0])
+@pytest.mark.parametrize("N,nb", [(1000, 100), (4100, 2048), (900, 300), (260, 64)])
+def test_blocks_with_tempering(g, o, method, alpha, N, nb):
+    """priority_fn = w -> alpha w per block (src/resample.jl:51-52, the tempering family of test/resample.jl:15 on sub-states,
+    test/resample.jl:130-162): ancestors from the priorities, weights log_ws + (logsumexp(block) - logsumexp(log_ws)) -- with and
+    without sort_particles and the ESS gate (which tests the RAW weights), against the loop over sub-states"""
+    m, ys, st, f = make(g, o, "bearings4", N, keep_prev=True, T=8)
+    for t in range(1, 6):
+        g.pf_update(st, (t + 1,), (None,), ys[t]); f.update(ys[t])
+        fr = None if t % 2 else 0.7
+        sp = bool(t % 3 == 0)
+        n_res = g.pf_resample_blocks(st, nb, method, priority_fn=g.Tempering(alpha), ess_frac=fr, sort_particles=sp, check=False)
+        mask = oracle_blocks(f, nb, method, ess_frac=fr, sort_particles=sp, priority_alpha=alpha)
+        assert n_res == mask.sum() and same(st, f), (method, alpha, N, nb, t)
+        ess, lml = g.block_stats(st, nb)
+        k = t % len(ess); v = f[k * nb:min((k + 1) * nb, N)]
+        assert lml[k] == v.log_ml_estimate()                            # the block's estimate is kept by the weight update (:215-216)
     st.close()

@@ -76,9 +76,10 @@ def test_random_api_sequences(g, o, seed):
             m = str(rng.choice(METHODS)); sp = bool(rng.integers(2))
             if sub in ("resample", "resample_ess"):
                 fr = None if sub == "resample" else float(rng.choice([0.3, 0.7, 1.5]))
+                al = None if rng.random() < 0.6 else float(rng.choice([0.5, 2.0]))
                 out = {}
-                if both(lambda: out.update(d=g.pf_resample_blocks(st, nb, m, ess_frac=fr, sort_particles=sp, check=False)),
-                        lambda: out.update(o=oracle_blocks(orc, nb, m, ess_frac=fr, sort_particles=sp)), log[-4:]):
+                if both(lambda: out.update(d=g.pf_resample_blocks(st, nb, m, priority_fn=None if al is None else g.Tempering(al), ess_frac=fr, sort_particles=sp, check=False)),
+                        lambda: out.update(o=oracle_blocks(orc, nb, m, ess_frac=fr, sort_particles=sp, priority_alpha=al)), log[-4:]):
                     st.close()
                     return                                              # NaN weights in some block: the run ends
                 assert out["d"] == out["o"].sum()

@@ -31,7 +31,7 @@ def loop_blocks(B):
         st.synchronize(); t0 = time.perf_counter()
         for t in range(1, steps + 1):
             g.pf_update(st, (t + 1,), (None,), ys[t])
-            st._L.gpf_resample_blocks(st._h, 1, N, 1, 0.5, 0, None, None)     # (check = false, no counts asked for: fully asynchronous)
+            st._L.gpf_resample_blocks(st._h, 1, N, float("nan"), 1, 0.5, 0, None, None)     # (check = false, no counts asked for: fully asynchronous)
             g.pf_rejuvenate(st, None, (), 1, method="move")
         st.synchronize(); dt = time.perf_counter() - t0
     ess, lml = g.block_stats(st, N)
@@ -50,7 +50,7 @@ def loop_blocks_own_data(B):
         st.synchronize(); t0 = time.perf_counter()
         for t in range(1, steps + 1):
             g.pf_update_blocks(st, (t + 1,), (None,), obs[t % 11], N)
-            st._L.gpf_resample_blocks(st._h, 1, N, 1, 0.5, 0, None, None)
+            st._L.gpf_resample_blocks(st._h, 1, N, float("nan"), 1, 0.5, 0, None, None)
             st._L.gpf_rejuvenate_blocks(st._h, 0, 1, 1, None)
         st.synchronize(); dt = time.perf_counter() - t0
     st.close()
