@@ -348,3 +348,21 @@ def test_three_filters_on_three_streams_nothing_synchronises(g, o):
         assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw) and np.array_equal(st.parents, orc.parents)
         assert g.get_lml_est(st) == orc.log_ml_estimate()
         st.close()
+
+
+@pytest.mark.gpu
+def test_norm_weights_with_a_nan_among_finite_weights(g, o):
+    """softmax of a weight vector with ONE NaN (or +Inf) is NaN everywhere (utils.jl:103-107: logsumexp is NaN), also where the weight
+    itself is finite (found by the random sequences: a block-wise tempered resample leaves NaN weights in all -Inf blocks only)"""
+    m = g.models.lgssm2(); ys = g.models.simulate(m, 2); N = 5000
+    st = g.pf_initialize(m, (1,), ys[0], N, seed=2)
+    orc = o.OracleFilter(m.model_id, m.params, N, 2).initialize(ys[0])
+    for bad in (np.nan, np.inf):
+        lw = st.log_weights.copy(); lw[17] = bad
+        st.log_weights = lw; orc.lw = lw.copy()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            nw, lnw = g.get_norm_weights(st), g.get_log_norm_weights(st)
+            assert np.isnan(nw).all() and np.array_equal(nw, orc.norm_weights(), equal_nan=True)
+            assert np.isnan(lnw).all() and np.array_equal(lnw, orc.log_norm_weights(), equal_nan=True)
+        assert np.isnan(g.get_ess(st)) and np.isnan(g.get_lml_est(st))
+    st.close()
