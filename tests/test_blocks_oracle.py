@@ -80,3 +80,21 @@ def test_block_initialisation_uses_each_blocks_data(g, o):
     assert np.array_equal(f.rows[100:200], g1.rows[100:200]) and np.array_equal(f.lw[100:200], g1.lw[100:200])    # same RNG counters (global ids), block 1's data
     assert not np.array_equal(f.lw[0:100], g1.lw[0:100])
     assert f.epoch == 1 and np.array_equal(f.parents, np.arange(1, 301))
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("alpha", [0.5, 2.0])
+def test_blockwise_tempered_resampling_invariants(g, o, method, alpha):
+    """test/resample.jl:130-162 with priority_fn = w -> alpha w on every block: new == old[parents] inside the block and the block's
+    log-ML estimate is kept by the weight update log_ws + (logsumexp(block) - logsumexp(log_ws)) (resample.jl:213-216)"""
+    m, ys, f = make(g, o, 300)
+    f.update(ys[1])
+    old, lml_full = f.rows.copy(), f.log_ml_estimate()
+    lml_b = [f[a:b].log_ml_estimate() for a, b in o.blocks_of(f, 100)]
+    o.resample_blocks(f, 100, method, priority_alpha=alpha)
+    for k, (a, b) in enumerate(o.blocks_of(f, 100)):
+        v = f[a:b]
+        assert np.array_equal(v.rows, old[a:b][v.parents - 1])
+        assert abs(v.log_ml_estimate() - lml_b[k]) < 1e-9
+        assert len(np.unique(v.lw)) > 1                                          # weights over priorities: no longer all equal
+    assert abs(f.log_ml_estimate() - lml_full) < 1e-9 and f.lml_est == 0.0
