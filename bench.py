@@ -319,7 +319,7 @@ def main():
         gather = {}
         W = state.row_width
         gbytes = (4 + 8 * W + 8 * W + 8) * n_local                # R anc, R row (random), W row, W lw = 16d + 12
-        for meth, kw in (("multinomial", {}), ("stratified", {"sort_particles": False})):
+        for meth, kw in (("multinomial", {}), ("multinomial_sorted", {}), ("stratified", {"sort_particles": False})):
             state.kernel_timing(g._lib.K_GATHER, True)
             for i in range(AUX_STEPS):
                 g.pf_resample(state, meth, check=False, **kw)
@@ -354,7 +354,34 @@ def main():
         return {"workload": workload, "value": round(n_global * k / seconds, 1), "unit": "particle-steps/sec", "steps": k,
                 "ms_per_step": round(seconds / k * 1e3, 5)}
 
-    strat = island = plans = None
+    strat = island = plans = sorted_variant = None
+    if not sharded_mode:
+        # the OPT-IN sorted form of the multinomial resampler (gpf.h GPF_RESAMPLE_MULTINOMIAL_SORTED): same offspring-count
+        # law, ancestors in non-decreasing order -- NOT the reference's slot order, so a named variant beside the unchanged headline
+        kv = min(K, 200)
+
+        def sorted_step(tq):
+            g.pf_resample(state, "multinomial_sorted")
+            g.pf_update(state, (tq + 1,), (None,), ys[1 + tq % (n_obs - 1)])
+        sorted_variant = variant_line("same filter, opt-in multinomial_sorted resample every step (sorted uniforms: monotone ancestors)",
+                                      kv, variant(sorted_step, kv))
+        for kid in kids:                                           # per-kernel HIP-event times of the variant, in a loop of their own
+            local.kernel_timing(kid, True)
+        for i in range(min(kv, 50)):
+            sorted_step(i)
+        sk = {}
+        for kid in kids:
+            ms, cnt = local.kernel_time(kid)
+            local.kernel_timing(kid, False)
+            if cnt:
+                sk[kid_names[kid]] = round(ms / cnt * 1e3, 2)
+        sorted_variant["all_kernels_us"] = sk
+        if "k_step" in sk and rank == 0:
+            # the fused gather + propagate of this variant against the same algorithmic bytes as the headline's dominant kernel
+            abk = algorithmic_bytes(model.dim, local.row_width)["k_step"]
+            sorted_variant["k_step_roofline"] = {"achieved": round(abk * n_local / (sk["k_step"] * 1e-6) / 1e9, 1), "unit": "GB/s",
+                                                 "frac": round(abk * n_local / (sk["k_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                 "algorithmic_bytes_per_launch": abk * n_local}
     if sharded_mode:
         kv = min(K, 200)
 
@@ -436,6 +463,7 @@ def main():
             "shard_summaries": (state.backend.summary_mode() if sharded_mode and hasattr(state.backend, "summary_mode") else None),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
             "stratified_variant": strat, "local_resample_variant": island, "exchange_plans": plans,
+            "multinomial_sorted_variant": sorted_variant,
         }
     else:
         out = None

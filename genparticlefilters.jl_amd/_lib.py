@@ -104,6 +104,10 @@ SYMBOLS = [
     ("gpf_shard_log_ml_estimate", C.c_int, [_H, _pd]),
     # host-side scalar spec
     ("gpf_host_fix_K", C.c_int32, [C.c_int64]),
+    ("gpf_host_gamma_E", C.c_int32, [C.c_int64]),
+    ("gpf_host_div128", C.c_uint64, [C.c_uint64, C.c_uint64]),
+    ("gpf_host_muldiv128", C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64]),
+    ("gpf_host_gamma_tile", C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int32]),
     ("gpf_host_log", C.c_double, [C.c_double]),
     ("gpf_host_lse", C.c_double, [C.c_double, C.c_uint64, C.c_int32, C.c_int32]),
     ("gpf_host_ess", C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64]),

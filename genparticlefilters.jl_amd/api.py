@@ -25,7 +25,8 @@ import numpy as np
 from . import _lib
 from .models import NativeModel
 
-RESAMPLE_METHODS = {"multinomial": 0, "residual": 1, "stratified": 2}
+RESAMPLE_METHODS = {"multinomial": 0, "residual": 1, "stratified": 2,
+                    "multinomial_sorted": 4}   # opt-in extension (gpf.h GPF_RESAMPLE_MULTINOMIAL_SORTED): ancestors come out non-decreasing
 REJUVENATE_METHODS = {"move": 0, "reweight": 1}
 
 
@@ -363,8 +364,18 @@ def pf_stratified_resample(state, *, priority_fn=None, check="warn", sort_partic
     return _resample(state, 2, priority_fn, check, sort_particles)
 
 
+def pf_multinomial_sorted_resample(state, *, priority_fn=None, check="warn"):
+    """OPT-IN extension, not a reference method: pf_multinomial_resample! (src/resample.jl:48-65) with the N uniforms drawn already sorted
+    (uniform spacings in exact integers): offspring counts ~ Multinomial(N, w) as for "multinomial", `state.parents`
+    non-decreasing instead of an i.i.d. sequence (src/resample.jl:59) -- the ancestor search is a streaming merge, the row gather reads
+    ascending rows."""
+    return _resample(state, RESAMPLE_METHODS["multinomial_sorted"], priority_fn, check, True)
+
+
 def pf_resample(state, method: str = "multinomial", **kwargs):
-    """src/resample.jl:19-30"""
+    """src/resample.jl:19-30 (+ the opt-in "multinomial_sorted")"""
+    if method == "multinomial_sorted":
+        return pf_multinomial_sorted_resample(state, **kwargs)
     if method == "multinomial":
         return pf_multinomial_resample(state, **kwargs)
     if method == "residual":

@@ -261,4 +261,16 @@ __device__ __forceinline__ uint32_t sort_coarse(uint64_t key, double m)
     return ((uint32_t)(e + 1) << 19) | (uint32_t)((b >> 33) & 0x7FFFFu);
 }
 
+
+// GPF_RESAMPLE_MULTINOMIAL_SORTED (gpf_math.hpp): g[t] = the gamma total of tile t of SP_TILE slots (shape = the tile's
+// slots, + 1 in the last tile: the (N + 1)-th spacing), one lane per tile.  Depends on (seed, epoch, n) alone -- not on the weights: it
+// runs as extra workgroups of the weight scan's launch when there is one (k_scan, ScanExtras::sp), else on its own (k_sorted_gammas).
+struct SortedGammaJob { uint64_t seed; uint64_t* g; int64_t gid0, n, ntl; uint32_t epoch; int Eg; int blocks; };
+__device__ __forceinline__ void sorted_gamma_tile(const SortedGammaJob& j, int64_t t)
+{
+    if (t >= j.ntl) return;
+    const int64_t first = t * SP_TILE, cnt = first + SP_TILE <= j.n ? SP_TILE : j.n - first;
+    j.g[t] = gamma_tile(j.seed, (uint32_t)(j.gid0 + first), j.epoch, cnt + (t == j.ntl - 1 ? 1 : 0), j.Eg);
+}
+
 } // namespace gpf

@@ -163,7 +163,8 @@ struct ScanExtras {            // optional side jobs of a scan launch
     // protocol here (an agent-scope fence at the end of a kernel that has written 10 MB writes the XCD's L2 back: measured, +30 us):
     // every workgroup leaves its limb partials as TAGGED words (tag << 48 | sum, relaxed agent-scope stores), the workgroup that
     // held the last tile -- it owns S -- waits for the words of this launch's tag, folds them and stores the summary.
-    int64_t* q_host;           // pinned [7]: flags, S, Ql0..3, ticket; nullptr: untagged partials, folded later (k_publish_scalars / k_export_q)
+    SortedGammaJob sp;         // sp.blocks > 0: the LAST sp.blocks workgroups of the launch compute the tile totals of a sorted multinomial resample
+    int64_t* q_host;           // pinned [8]: flags, S, Ql0..3, ticket, check word; nullptr: untagged partials, folded later (k_publish_scalars / k_export_q)
     int64_t q_ticket;
 };
 // Workgroup of the scan kernels: SCAN_BLOCK threads over one 2048-element tile, every wave SCAN_ROWS rows of 128.  256 threads x 4
@@ -187,6 +188,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
                                                 uint64_t* __restrict__ total_out, uint64_t* __restrict__ blockQ,
                                                 int32_t* __restrict__ timeout, ScanExtras ex)
 {
+    // the launch's last ex.sp.blocks workgroups are not part of the scan: they draw the tile totals of a sorted multinomial resample
+    // (independent of the weights; hidden behind the scan's latency chain instead of a launch of their own)
+    const unsigned G = gridDim.x - (unsigned)ex.sp.blocks;
+    if (blockIdx.x >= G) { sorted_gamma_tile(ex.sp, (int64_t)(blockIdx.x - G) * SCAN_BLOCK + threadIdx.x); return; }
     // (ex.n_slots: the thread that ends up with the total also leaves the stratum width of S over n_slots output slots)
     // sharded resamples: the exchange counters of the push pass that follows are cleared here (no memset node)
     if (ex.zero128 && blockIdx.x == 0)
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
     __shared__ uint64_t s_Stot;
     uint64_t* const d_agg = dcur;
     uint64_t* const d_pre = dcur + ntiles;
-    for (int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * SCAN_BLOCK) dnext[i] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)G * SCAN_BLOCK) dnext[i] = 0;
     constexpr bool WANT_Q = MODE == 2 || MODE == 4;
     // the first tile's log-weights are loaded BEFORE the partial maxima are folded (they need neither m nor the flags)
     double pre[2 * SCAN_ROWS];
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
     }
     uint64_t ql[4] = {0, 0, 0, 0};
     const int lane = lane_id(), wv = wave_id();
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += G) {
         const int64_t wbase = tile * TILE + (int64_t)wv * (SCAN_ROWS * 2 * WAVE) + 2 * lane;
         uint64_t p[2 * SCAN_ROWS];                     // inclusive prefixes inside the wave's 512-element chunk
         uint64_t cb[SCAN_ROWS];                        // the chunk's total before each row
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
         for (int w = 0; w < SCAN_NWAVES; ++w) { if (w < wv) wexcl += s_wave[w]; agg += s_wave[w]; }
         if (threadIdx.x == 0) desc_store(d_agg + tile, DESC_VALID | agg);
         // exclusive prefix of this tile: one parallel read of the round's earlier aggregates
-        const int64_t first = (tile / gridDim.x) * gridDim.x;
+        const int64_t first = (tile / G) * G;
         uint64_t acc = 0;
         for (int64_t idx = first + threadIdx.x; idx < tile; idx += SCAN_BLOCK) acc += desc_wait(d_agg + idx, timeout);
         if (first > 0 && threadIdx.x == SCAN_BLOCK - 1) acc += desc_wait(d_pre + first - 1, timeout);
@@ -337,16 +342,16 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
         for (int k = 0; k < 4; ++k) ql[k] = wave_sum_u64(ql[k]);
         if (lane == 0) { for (int k = 0; k < 4; ++k) s_q[wv][k] = ql[k]; }
         __syncthreads();
-        const uint64_t qtag = ex.q_host ? (uint64_t)((ex.q_ticket & 0x7fff) + 1) << 48 : 0;       // (limb sums of a workgroup stay below 2^47)
+        const uint64_t qtag = ex.q_host ? (uint64_t)((ex.q_ticket & 0x7fff) + 1) << 48 : 0;       // (a workgroup scans <= Q_TAG_MAX_TILES tiles: its limb sums stay below 2^48 -- summarize() guards it)
         if (threadIdx.x < 4) {
             uint64_t t = 0;
             for (int w = 0; w < SCAN_NWAVES; ++w) t += s_q[w][threadIdx.x];
             if (ex.q_host) __hip_atomic_store(blockQ + (int64_t)blockIdx.x * 4 + threadIdx.x, qtag | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else blockQ[(int64_t)blockIdx.x * 4 + threadIdx.x] = t;
         }
-        if (ex.q_host && (int64_t)blockIdx.x == (ntiles - 1) % (int64_t)gridDim.x) {          // the workgroup that held the last tile (workgroup-uniform)
+        if (ex.q_host && (int64_t)blockIdx.x == (ntiles - 1) % (int64_t)G) {          // the workgroup that held the last tile (workgroup-uniform)
             uint64_t q[4] = {0, 0, 0, 0};
-            for (int b = threadIdx.x; b < (int)gridDim.x; b += SCAN_BLOCK) {
+            for (int b = threadIdx.x; b < (int)G; b += SCAN_BLOCK) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     uint64_t v = __hip_atomic_load(blockQ + (int64_t)b * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -371,7 +376,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
                 __hip_atomic_store(ex.q_host + 0, (int64_t)in.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(ex.q_host + 1, (int64_t)s_Stot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 for (int k = 0; k < 4; ++k) __hip_atomic_store(ex.q_host + 2 + k, (int64_t)t[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                         // (the six stores have left this wave: no cache write-back)
+                // No fence orders the seven words on their way to pinned memory (a system-scope release here would write the XCD's L2
+                // back: +30 us).  The payload validates itself instead: word 7 = ticket ^ flags ^ S ^ limbs; the host re-reads until the
+                // ticket AND the check word agree with what it sees (a stale word among fresh ones breaks the xor).
+                uint64_t chk = (uint64_t)ex.q_ticket ^ (uint64_t)(int64_t)in.flags ^ s_Stot;
+                for (int k = 0; k < 4; ++k) chk ^= t[k];
+                __hip_atomic_store(ex.q_host + 7, (int64_t)chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(ex.q_host + 6, ex.q_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -388,6 +398,9 @@ struct Scan2Chan { ScanOut out; uint64_t* dcur; uint64_t* dnext; uint64_t* total
 // the copies of its own cells when there are few (<= HEAD_SMALL each), cells with more are filled by the whole workgroup (coalesced
 // runs).  The search kernel then looks up the i.i.d. tail only, and the copy-count CDF and its levels (A.out) are not stored at all.
 // A tile with <= HEAD_STAGE copies in all assembles them in LDS first and stores them as one coalesced run.
+// tagged limb partials (ScanExtras::q_host): tag << 48 | sum needs sum < 2^48; a limb is < 2^32, so a workgroup may fold at most 2^16
+// elements = 32 tiles
+constexpr int Q_TAG_MAX_TILES = 32;
 constexpr int HEAD_SMALL = 16, HEAD_LIST = 128, HEAD_STAGE = 4096;
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* __restrict__ cdf, const WSum* ws, int64_t Nslots,
                                                           int64_t n, int64_t ntiles, Scan2Chan A, Scan2Chan B,

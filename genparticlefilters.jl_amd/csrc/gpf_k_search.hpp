@@ -139,6 +139,10 @@ struct SearchArgs {
                                                                       // sub-state, the kept mass goes to sc->lw_fill (resample.jl:210)
     int32_t* anc;
     int head_done;                                                    // residual: the deterministic head is written already (k_scan_residual2): tail slots only
+    // GPF_RESAMPLE_MULTINOMIAL_SORTED (k_search_strat<true>): sp_g[t] = the gamma total of tile t of SP_TILE slots (k_sorted_gammas; the
+    // merge kernel places its own tile: prefix and total of the <= SP_DIRECT_TILES entries in its prologue), or, for more tiles,
+    // sp_vlo[t] = where tile t starts among the sorted 64-bit uniforms (k_sorted_tiles), [tiles + 1] entries
+    const uint64_t* sp_g; const uint64_t* sp_vlo;
 };
 
 // LDS copy of the top level: one pad word per 64 entries.  The branch-free search probes at power-of-two strides;
@@ -844,6 +848,54 @@ __device__ __forceinline__ void block_count_le_pair(const uint64_t* __restrict__
     A0 = lo[0]; A1 = lo[1];
 }
 
+// ---- GPF_RESAMPLE_MULTINOMIAL_SORTED: the sorted uniforms (gpf_math.hpp)
+// the lane's MSLOTS consecutive spacings from resample slot s0 on (one Philox block per aligned slot pair, like the targets below)
+__device__ __forceinline__ void lane_spacings(uint64_t seed, uint32_t epoch, uint32_t s0, uint64_t (&e)[MSLOTS])
+{
+    constexpr int NPB = MSLOTS / 2;
+    const uint32_t sb = s0 >> 1;
+    if (!(s0 & 1u)) {                                                 // kernel-uniform
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) {
+            const Philox b = rng(seed, sb + (uint32_t)q, 0, epoch, TAG_RESAMPLE);
+            e[2 * q] = spacing_of(u64(b.w0, b.w1)); e[2 * q + 1] = spacing_of(u64(b.w2, b.w3));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q <= NPB; ++q) {
+            const Philox b = rng(seed, sb + (uint32_t)q, 0, epoch, TAG_RESAMPLE);
+            if (q > 0) e[2 * q - 1] = spacing_of(u64(b.w0, b.w1));
+            if (q < NPB) e[2 * q] = spacing_of(u64(b.w2, b.w3));
+        }
+    }
+}
+// (SortedGammaJob / sorted_gamma_tile: gpf_k_common.hpp -- the weight scan runs the same job as extra workgroups of its launch)
+__global__ __launch_bounds__(BLOCK) void k_sorted_gammas(SortedGammaJob job)
+{
+    sorted_gamma_tile(job, (int64_t)blockIdx.x * BLOCK + threadIdx.x);
+}
+constexpr int SP_DIRECT_TILES = 1024;              // up to 2.1 M slots the merge kernel sums the tile totals itself (4 loads per lane)
+// beyond: vlo[t] = floor((g_0 + ... + g_{t-1}) 2^64 / (sum g + 1)), t = 0 .. ntl, by ONE workgroup (a block-wide scan, a division per tile)
+constexpr int STILES_BLOCK = 1024;
+__global__ __launch_bounds__(STILES_BLOCK) void k_sorted_tiles(const uint64_t* __restrict__ g, int64_t ntl, uint64_t* __restrict__ vlo)
+{
+    __shared__ uint64_t s_w[STILES_BLOCK / WAVE];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int64_t per = (ntl + STILES_BLOCK - 1) / STILES_BLOCK;       // thread i owns the consecutive tiles [i per, (i + 1) per)
+    const int64_t t0 = (int64_t)tid * per, t1 = t0 + per < ntl ? t0 + per : ntl;
+    uint64_t mine = 0;
+    for (int64_t t = t0; t < t1; ++t) mine += g[t];
+    const uint64_t inc = wave_scan_u64(mine);
+    if (lane == WAVE - 1) s_w[wv] = inc;
+    __syncthreads();
+    uint64_t run = inc - mine, tot = 0;
+#pragma unroll
+    for (int w = 0; w < STILES_BLOCK / WAVE; ++w) { run += w < wv ? s_w[w] : 0; tot += s_w[w]; }
+    const Div128 dv = div128_setup(tot + 1);
+    for (int64_t t = t0; t < t1; ++t) { vlo[t] = div128(run, dv); run += g[t]; }
+    if (tid == 0) vlo[ntl] = div128(tot, dv);
+}
+
 #ifdef GPF_DBG_STRAT
 __device__ unsigned long long g_dbg_strat[8 * 4096];
 #define DBG_STRAT(slot, val) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_dbg_strat[8 * blockIdx.x + (slot)] = (unsigned long long)(val); } while (0)
@@ -851,6 +903,9 @@ __device__ unsigned long long g_dbg_strat[8 * 4096];
 #define DBG_STRAT(slot, val) do {} while (0)
 #endif
 // (2-3 workgroups per CU -- 41 KB of LDS each --: a 10^6-slot launch, 489 workgroups, is ONE resident round)
+// SORTED: the targets are the sorted uniforms of GPF_RESAMPLE_MULTINOMIAL_SORTED instead of one uniform per stratum: the same merge from
+// the cell side, with the number of targets below a prefix found by a binary search of the block's targets in LDS (no closed form)
+template <bool SORTED>
 __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
 {
     DBG_STRAT(0, wall_clock64());
@@ -860,6 +915,9 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
     __shared__ int s_cnt[2][2][NWAVES];
     __shared__ uint32_t s_wmax[NWAVES];
     __shared__ __attribute__((aligned(16))) ulonglong2 s_coop[NWAVES * MONO_WIDE_NS * WAVE];   // the wide path's line-count strips (coop_count_le)
+    __shared__ uint64_t s_sp[NWAVES];                  // SORTED: wave totals of the tile's spacings
+    __shared__ uint64_t s_gs[3][NWAVES];               // ... and of the tile totals (before this tile, all, this tile)
+    __shared__ uint64_t s_e0, s_eN;
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
     // update_lml_est! (resample.jl:57,178-182): log_ml_est += logsumexp(log_weights) - log N, once per resample
     if (a.update_lml && blockIdx.x == 0 && tid == 0)
@@ -891,6 +949,66 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
     // (under a sorted order the CDF is steep at the front and flat in the tail: no guess, block_count_le_pair reads the whole level)
     const int64_t guess = a.order ? -1 : (int64_t)((double)j0 * (a.plan ? (double)a.n_cells / (double)n_out : (double)a.n_cells * invN)) >> 8;
     block_count_le_pair(a.w.t256, n256, guess, s_cnt, A0, A1, [&](uint64_t& L0, uint64_t& L1) {
+        if constexpr (SORTED) {
+            // ---- sorted uniforms (gpf_math.hpp): the tile's range [vlo, vlo + W) of the 64-bit uniforms from k_sorted_tiles,
+            //      the slots inside it by the tile's own exponential spacings, normalised by their sum
+            static_assert(MJB == SP_TILE, "one workgroup = one tile of the sorted uniforms");
+            uint64_t gpre = 0, gtot = 0, gown = 0;
+            if (!a.sp_vlo) {                                                            // kernel-uniform: <= SP_DIRECT_TILES tile totals
+                const int64_t ntl = (n_out + MJB - 1) / MJB;
+                for (int64_t t = tid; t < ntl; t += MBLOCK) {
+                    const uint64_t v = a.sp_g[t];
+                    gtot += v; gpre += t < (int64_t)blockIdx.x ? v : 0; gown = t == (int64_t)blockIdx.x ? v : gown;
+                }
+            }
+            uint64_t e[MSLOTS];
+            lane_spacings(a.seed, a.epoch, s0, e);
+            uint64_t run = 0;
+#pragma unroll
+            for (int k = 0; k < MSLOTS; ++k) { run += j0 + (int64_t)t0 + k < n_out ? e[k] : 0; e[k] = run; }   // inclusive inside the lane
+            const uint64_t inc = wave_scan_u64(run);
+            if (lane == WAVE - 1) s_sp[wv] = inc;
+            if (!a.sp_vlo) {
+                gpre = wave_sum_u64(gpre); gtot = wave_sum_u64(gtot); gown = wave_sum_u64(gown);
+                if (lane == 0) { s_gs[0][wv] = gpre; s_gs[1][wv] = gtot; s_gs[2][wv] = gown; }
+            }
+            if (tid == 0) {
+                s_e0 = e[0];
+                // the (N + 1)-th spacing belongs to the last tile
+                s_eN = j0 + MJB >= n_out ? spacing_of(resample_u64(a.seed, (uint32_t)(pbase + n_out), a.epoch)) : 0;
+            }
+            __syncthreads();
+            uint64_t st = 1 + s_eN, wex = 0;                                           // s_t = the tile's sum + 1 (+ e_N)
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) { st += s_sp[w]; wex += w < wv ? s_sp[w] : 0; }
+            uint64_t vlo, Wt;
+            if (a.sp_vlo) { vlo = a.sp_vlo[blockIdx.x]; Wt = a.sp_vlo[blockIdx.x + 1] - vlo; }
+            else {
+                gpre = 0; gtot = 0; gown = 0;
+#pragma unroll
+                for (int w = 0; w < NWAVES; ++w) { gpre += s_gs[0][w]; gtot += s_gs[1][w]; gown += s_gs[2][w]; }
+                const Div128 dg = div128_setup(gtot + 1);                               // (as k_sorted_tiles)
+                vlo = div128(gpre, dg); Wt = div128(gpre + gown, dg) - vlo;
+            }
+            const uint64_t S = a.ws->S;
+            const uint64_t Tlo = mulhi64(vlo, S), Tw = mulhi64(vlo + Wt, S) - Tlo;     // the tile's targets lie in [Tlo, Tlo + Tw]
+            const double inv_s = 1.0 / (double)st, dTw = (double)Tw;
+            const uint64_t off = wex + (inc - run);
+            uint64_t T[MSLOTS];
+#pragma unroll
+            for (int k = 0; k < MSLOTS; ++k)
+                T[k] = j0 + (int64_t)t0 + k < n_out ? sorted_target(off + e[k], inv_s, Tlo, Tw, dTw) : ~0ull;   // resample.jl:59 on the sorted uniform
+            Lj0 = sorted_target(s_e0, inv_s, Tlo, Tw, dTw);                             // the block's first target ...
+            Lj1 = sorted_target(st - 1 - s_eN, inv_s, Tlo, Tw, dTw) + 1;                // ... and one past its last (real) one
+            Lj0s = (int64_t)Lj0;
+            L0 = Lj0; L1 = Lj1 - 1;
+#pragma unroll
+            for (int k = 0; k < MSLOTS; k += 2) *reinterpret_cast<ulonglong2*>(s_T + MSLOTS * tid + k) = make_ulonglong2(T[k], T[k + 1]);
+            if (tid < 4) s_T[MJB + tid] = ~0ull;
+#pragma unroll
+            for (int k = 0; k < MSLOTS; k += 4) *reinterpret_cast<uint4*>(s_mark + MSLOTS * tid + k) = make_uint4(0u, 0u, 0u, 0u);
+            return;
+        }
         // S = N B + rem; stratum j is [L(j), L(j+1)), L(j) = j B + floor(j rem / N)   (DESIGN.md §3.3); B, rem and N / S
         // were left beside S by the scan that produced it
         const uint64_t B = a.ws->sB, rem = a.ws->srem;
@@ -960,6 +1078,37 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
                 const uint32_t i = i0 + 2u * MBLOCK * r + 2u * (uint32_t)tid;
                 cc[r] = i < ncell ? *reinterpret_cast<const ulonglong2*>(cbase + i) : make_ulonglong2(~0ull, ~0ull);
             }
+            if constexpr (SORTED) {
+                // e = number of the block's targets below the prefix, for the lane's 2 CPF prefixes at once: branch-free binary searches
+                // of the (ascending) targets in LDS, interleaved -- 12 independent chains of 12 dependent reads
+                uint64_t cv[2 * CPF]; uint32_t ee[2 * CPF];
+#pragma unroll
+                for (int r = 0; r < CPF; ++r) {
+                    // a prefix at or above Lj1 resolves nothing (every slot is resolved by then); padding reads as ~0
+                    cv[2 * r] = cc[r].x < Lj1 ? cc[r].x : 0; cv[2 * r + 1] = cc[r].y < Lj1 ? cc[r].y : 0;
+                    ee[2 * r] = 0; ee[2 * r + 1] = 0;
+                }
+#pragma unroll
+                for (uint32_t hh = MJB / 2; hh >= 1; hh >>= 1) {
+#pragma unroll
+                    for (int q = 0; q < 2 * CPF; ++q) ee[q] += s_T[ee[q] + hh - 1] < cv[q] ? hh : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 2 * CPF; ++q) ee[q] += s_T[ee[q]] < cv[q] ? 1u : 0u;      // (cv <= the last target: ee <= MJB - 1)
+#pragma unroll
+                for (int r = 0; r < CPF; ++r) {
+                    const uint32_t i = i0 + 2u * MBLOCK * r + 2u * (uint32_t)tid;
+                    if (i0 + 2u * MBLOCK * r >= ncell) break;             // block-uniform
+                    // prefixes at or below the first target resolve nothing: only the LAST of them (they ascend) bounds slot 0
+                    const uint64_t below = __ballot(cc[r].y <= Lj0);
+                    if (cc[r].y <= Lj0) {
+                        if (lane == (int)__popcll(below) - 1) atomicMax(&s_mark[0], ibase + i + 1u);
+                        continue;
+                    }
+                    if (cc[r].x < Lj1) atomicMax(&s_mark[ee[2 * r]], ibase + i);
+                    if (cc[r].y < Lj1) atomicMax(&s_mark[ee[2 * r + 1]], ibase + i + 1u);
+                }
+            } else
 #pragma unroll
             for (int r = 0; r < CPF; ++r) {
                 const uint32_t i = i0 + 2u * MBLOCK * r + 2u * (uint32_t)tid;

@@ -330,12 +330,13 @@ __global__ void k_norm_weights(const double* __restrict__ lw, const WSum* ws, in
     const double m = ws->m;
     const double lse = lse_from(m, ws->S, K, ws->flags);
     const double Sd = (double)ws->S;
-    const bool uniform = (ws->flags & FLAG_ALL_NEGINF) != 0;
-    // a NaN (or +Inf) among the weights: softmax is NaN everywhere (utils.jl:103-107 over logsumexp = NaN), not only where the weight is
-    const bool bad = (ws->flags & (FLAG_NAN | FLAG_POSINF)) != 0;
+    // a NaN (or +Inf) among the weights: softmax is NaN everywhere (utils.jl:103-107 over logsumexp = NaN), not only where the weight is;
+    // all -Inf: maximum = -Inf, vs .- maximum = NaN, NaN everywhere as well -- get_norm_weights is the PLAIN softmax; the uniform
+    // fallback belongs to safe_softmax inside the resamplers (utils.jl:123-126)
+    const bool bad = (ws->flags & (FLAG_NAN | FLAG_POSINF | FLAG_ALL_NEGINF)) != 0;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
         if (want_log) out[i] = lw[i] - lse;
-        else out[i] = bad ? __builtin_nan("") : (double)(uniform ? 1 : exp_fix(lw[i] - m, K)) / Sd;
+        else out[i] = bad ? __builtin_nan("") : (double)exp_fix(lw[i] - m, K) / Sd;
     }
 }
 __global__ void k_debug_math(int which, const double* a, const double* b, int64_t n, uint64_t seed, uint32_t epoch,

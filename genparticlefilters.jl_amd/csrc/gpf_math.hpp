@@ -249,6 +249,96 @@ GPF_HD int fix_K(int64_t n_global)
     const int K = 62 - ceil_log2(n_global);
     return K > 52 ? 52 : K;
 }
+// ------------------------------------------------------------------ uniform spacings ("multinomial_sorted")
+// The opt-in sorted form of the multinomial resampler (resample.jl:59) draws its N uniforms ALREADY SORTED.  With e_0..e_N i.i.d. Exp(1)
+// and P_j = e_0 + ... + e_j, the ratios P_j / P_N are the order statistics of N uniforms.  The sum over a tile of SP_TILE consecutive
+// slots is Gamma(tile size), independent of the tile's normalised partial sums: the tile totals are drawn directly (gamma_tile), the
+// spacings place the slots inside their tile.  All in exact integers:
+//     G_t = trunc(gamma(c_t [+ 1: last tile]) 2^Eg), Gtot = sum G_t + 1, Vlo_t = floor((G_0 + .. + G_{t-1}) 2^64 / Gtot)
+//     e_i = trunc(-log(u_i) 2^SP_E), p_j = the tile's e_i up to slot j, s_t = the tile's sum + 1 (last tile: + e_N)
+//     Tlo_t = mulhi64(Vlo_t, S), Tw_t = Tlo_{t+1} - Tlo_t,  T_j = Tlo_t + min(Tw_t, trunc(((double)p_j (1.0 / (double)s_t)) (double)Tw_t))
+// (the slot's place inside its tile in Float64: monotone in p_j, four roundings, the same on host and device; an exact integer
+// division here cost ~36 quarter-rate 32-bit multiplications per slot)
+constexpr int SP_TILE = 2048;                          // slots per tile (== the search kernel's slots per workgroup)
+constexpr int SP_E = 44;                               // 2049 spacings below 2^6 each: a tile's sum stays below 2^62
+GPF_HD int gamma_E(int64_t ntl) { const int E = 50 - ceil_log2(ntl); return E > 48 ? 48 : E; }   // a tile total is < 2^12
+GPF_HD uint64_t spacing_of(uint64_t U) { return (uint64_t)(-log_(u52((uint32_t)(U >> 32), (uint32_t)U)) * pow2i(SP_E)); }
+// Gamma(shape, 1), integer shape >= 1 (Marsaglia & Tsang 2000): attempt k reads blocks 1 + 2k (normal) and 2 + 2k (uniform) of counter
+// gid on the resample stream; 8 attempts, then d.  |x| <= 8.6 bounds the variate below 1.2 shape + 60 < 2^12.
+GPF_HD uint64_t gamma_tile(uint64_t seed, uint32_t gid, uint32_t epoch, int64_t shape, int Eg)
+{
+    const double d = (double)shape - 1.0 / 3.0;
+    const double c = 1.0 / sqrt_(9.0 * d);
+    const double sc = pow2i(Eg);
+    for (int k = 0; k < 8; ++k) {
+        double x, x1;
+        normal2(rng(seed, gid, (uint32_t)(1 + 2 * k), epoch, TAG_RESAMPLE), x, x1);
+        const Philox b = rng(seed, gid, (uint32_t)(2 + 2 * k), epoch, TAG_RESAMPLE);
+        const double u = u52(b.w0, b.w1);
+        const double v1 = 1.0 + c * x;
+        if (!(v1 > 0.0)) continue;
+        const double v = (v1 * v1) * v1;
+        if (log_(u) < ((0.5 * (x * x) + d) - d * v) + d * log_(v)) return (uint64_t)((d * v) * sc);
+    }
+    return (uint64_t)(d * sc);
+}
+// floor((u1 2^64 + u0) / den) for u1 2^64 + u0 < den 2^64 by one multiplication with a precomputed reciprocal (Moeller & Granlund,
+// "Improved division by invariant integers", algorithm 4: exact): d = den << sh (top bit set), v = floor((2^128 - 1) / d) - 2^64.
+struct Div128 { uint64_t d, v; int sh; };
+GPF_HD Div128 div128_setup(uint64_t den)
+{
+    Div128 c;
+    c.sh = (int)__builtin_clzll(den);
+    c.d = den << c.sh;
+    // v = floor(((2^64 - 1 - d) 2^64 + 2^64 - 1) / d).  A Float64 estimate (off by < 2^13: 53 significant bits of a 64-bit quotient), then
+    // the exact 128-bit remainder corrects it -- twice by a Float64 quotient of the remainder, then by single steps.  The result is the
+    // exact integer whatever the rounding of the estimates (a 64-step long division cost 1.7 us of a lone wave's time).
+    const double dd = (double)c.d;
+    const uint64_t nh = ~c.d, nl = ~0ull;                // numerator, high and low word (nh < d)
+    double est = ((double)nh * 0x1p64 + 0x1p64) / dd;    // ~ v, in [0, 2^64]
+    uint64_t q = est >= 0x1p64 ? ~0ull : (uint64_t)est;
+    // remainder r = n - q d as a signed 128-bit number (|r| < 2^78), kept as (rh: signed high, rl: low)
+    for (int it = 0; it < 3; ++it) {
+        const uint64_t pl = q * c.d, ph = mulhi64(q, c.d);
+        const uint64_t rl = nl - pl;
+        const int64_t rh = (int64_t)(nh - ph - (nl < pl ? 1u : 0u));
+        // |r| small: r as a double (exact enough: the correction only has to shrink |r| below d within the iterations)
+        const double rd = (double)rh * 0x1p64 + (double)rl;
+        if (rh == 0 && rl < c.d) break;                    // 0 <= r < d: q is the quotient
+        if (it < 2) {
+            const double adj = rd / dd;                      // quotient of the remainder (floor / ceil settled by the next round)
+            const int64_t a = (int64_t)adj;
+            q += (uint64_t)(a != 0 ? a : (rh < 0 ? -1 : 1));
+        } else {
+            // last resort: single steps (at most a few)
+            uint64_t l = rl; int64_t hgh = rh;
+            while (hgh < 0) { const uint64_t nl2 = l + c.d; hgh += (nl2 < l) ? 1 : 0; l = nl2; --q; }
+            while (hgh > 0 || l >= c.d) { const uint64_t nl2 = l - c.d; hgh -= (l < c.d) ? 1 : 0; l = nl2; ++q; }
+        }
+    }
+    c.v = q;
+    return c;
+}
+GPF_HD uint64_t div128_2(uint64_t n1, uint64_t n0, const Div128& c)       // floor((n1 2^64 + n0) / den), n1 < den
+{
+    const uint64_t u1 = c.sh ? (n1 << c.sh) | (n0 >> (64 - c.sh)) : n1, u0 = n0 << c.sh;
+    uint64_t q0 = c.v * u1, q1 = mulhi64(c.v, u1);
+    q0 += u0;
+    q1 += u1 + (q0 < u0 ? 1u : 0u) + 1;                // (q1, q0) += (u1, u0); q1 += 1   (mod 2^64, as in the algorithm)
+    uint64_t r = u0 - q1 * c.d;
+    if (r > q0) { q1 -= 1; r += c.d; }
+    if (r >= c.d) { q1 += 1; }
+    return q1;
+}
+GPF_HD uint64_t div128(uint64_t P, const Div128& c) { return div128_2(P, 0, c); }       // floor(P 2^64 / den), P < den
+GPF_HD uint64_t muldiv128(uint64_t p, uint64_t W, const Div128& c) { return div128_2(mulhi64(p, W), p * W, c); }   // floor(p W / den), p < den
+// a slot's target inside its tile: Tlo + min(Tw, trunc(((double)p inv_s) dTw))
+GPF_HD uint64_t sorted_target(uint64_t p, double inv_s, uint64_t Tlo, uint64_t Tw, double dTw)
+{
+    const uint64_t tt = (uint64_t)(((double)p * inv_s) * dTw);
+    return Tlo + (tt > Tw ? Tw : tt);
+}
+
 // logsumexp = m + log(S 2^-K)   (resample.jl:180 / utils.jl:100 on the exact integer sum)
 GPF_HD double lse_from(double m, uint64_t S, int K, int flags)
 {

@@ -156,6 +156,9 @@ struct gpf_filter {
     int64_t flag_ticket = 0;
     int64_t push_ticket = 0;             // bumped by every gpf_shard_push launch; k_push publishes it with the counts
     bool counts_published = false;
+    // GPF_RESAMPLE_MULTINOMIAL_SORTED: gamma totals of the tiles of SP_TILE slots (k_sorted_gammas) and, for many tiles, their starting points (k_sorted_tiles)
+    uint64_t* sp_g = nullptr; uint64_t* sp_vlo = nullptr; int64_t sp_cap = 0;
+    SortedGammaJob sp_job{}; bool sp_job_set = false;    // tile totals wanted: the next weight scan of this call carries them (scan_launch), else k_sorted_gammas
     ulonglong2* push_stage = nullptr;    // push exchange: staged hits, one 16-byte entry per global output slot at most
     ShardPlan* shard_plan = nullptr;     // sharded stratified resampling: the slot range this shard serves (k_strat_plan)
     int64_t push_cap = 0;
@@ -545,12 +548,15 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
 {
     uint64_t* dc = h->desc[ch][h->dcur[ch]];
     uint64_t* dn = h->desc[ch][1 - h->dcur[ch]];
-    const int gs = std::is_same<In, InFixQ>::value ? wscan_grid(h) : scan_grid(h);
+    int gs = std::is_same<In, InFixQ>::value ? wscan_grid(h) : scan_grid(h);
+    // a sorted multinomial resample is waiting for its tile totals: they ride in this launch as extra workgroups behind the scan's own
+    if (h->sp_job_set && std::is_same<In, InFixQ>::value) { ex.sp = h->sp_job; ex.sp.blocks = (int)((h->sp_job.ntl + SCAN_BLOCK - 1) / SCAN_BLOCK); h->sp_job_set = false; }
+    const int g_launch = gs + ex.sp.blocks;
     const bool offsets = ch == 0 && h->want_offsets && want_cdf;
     const ScanOut so = scan_out(want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch], h->ntiles, offsets);
     if (ch == 0 && want_cdf) h->ch0_offsets = offsets && so.off16 != nullptr;
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
-        GPF_LAUNCH((k_scan<In, FIXQ>), dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, in, h->n, h->ntiles, mf_all, h->mslots[h->mcur], np, slot,
+        GPF_LAUNCH((k_scan<In, FIXQ>), dim3(g_launch), dim3(SCAN_BLOCK), 0, h->stream, in, h->n, h->ntiles, mf_all, h->mslots[h->mcur], np, slot,
                            so, dc, dn, total_out, h->blockQ, h->h_timeout, ex);
     });
     if (s) return s;
@@ -586,9 +592,12 @@ gpf_status summarize(gpf_filter* h, const PrioView& pv, WSum* slot, bool want_cd
     gpf_status s;
     h->q_published = false;
     static const bool q_publish_off = getenv("GPF_ESS_PUBLISH") && !strcmp(getenv("GPF_ESS_PUBLISH"), "kernel");   // (A/B: the separate publish launch)
-    if (want_q && slot == &h->sc->raw && !q_publish_off) {
+    // (tag << 48 | limb sum: only while a workgroup folds <= Q_TAG_MAX_TILES tiles -- beyond, e.g. N > 2^26 at 4 x 256 workgroups, the
+    // untagged partials + k_publish_scalars)
+    const int64_t tiles_per_wg = (h->ntiles + wscan_grid(h) - 1) / wscan_grid(h);
+    if (want_q && slot == &h->sc->raw && !q_publish_off && tiles_per_wg <= Q_TAG_MAX_TILES) {
         // the ESS getter's scan: the workgroup of its last tile folds sum q^2 and publishes {flags, S, limbs} to pinned memory itself
-        if (!h->h_qpub) { HIP_TRY(h, hipHostMalloc(&h->h_qpub, 7 * sizeof(int64_t))); for (int i = 0; i < 7; ++i) h->h_qpub[i] = 0; }
+        if (!h->h_qpub) { HIP_TRY(h, hipHostMalloc(&h->h_qpub, 8 * sizeof(int64_t))); for (int i = 0; i < 8; ++i) h->h_qpub[i] = 0; }
         h->q_ticket += 1;
         ex.q_host = h->h_qpub; ex.q_ticket = h->q_ticket;
         h->q_published = true;
@@ -957,7 +966,7 @@ void launch_multinomial_search(gpf_filter* h, const SearchArgs& sa)
 
 gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_particles, int check, int32_t* invalid, bool local = false)
 {
-    if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED)
+    if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED && method != GPF_RESAMPLE_MULTINOMIAL_SORTED)
         return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");          // resample.jl:28
     if (h->cfg.n_global != h->n)
         return fail(h, GPF_ERR_STATE, "sharded filters resample through the shard-level API (sharded.py)");
@@ -980,6 +989,21 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         if ((s = ensure_max(h, pv, pv.mode == 0))) return s;     // (the coarse sort keys are distances from the maximum)
         if ((s = sort_desc_begin(h, pv, h->n, &sort_pending))) return s;
     }
+    if (method == GPF_RESAMPLE_MULTINOMIAL_SORTED) {
+        // the gamma total of every tile of SP_TILE slots: one lane per tile, as extra workgroups of the weight scan below;
+        // beyond SP_DIRECT_TILES tiles one more small launch turns them into the tiles' starting points, else the merge kernel does
+        // that for its own tile
+        const int64_t ntl = (h->n + SP_TILE - 1) / SP_TILE;
+        if (h->sp_cap < ntl + 1) {
+            if (h->sp_g) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->sp_g); (void)hipFree(h->sp_vlo); h->sp_g = h->sp_vlo = nullptr; h->sp_cap = 0; }
+            HIP_TRY(h, hipMalloc(&h->sp_g, (size_t)(ntl + 1) * sizeof(uint64_t)));
+            HIP_TRY(h, hipMalloc(&h->sp_vlo, (size_t)(ntl + 1) * sizeof(uint64_t)));
+            h->sp_cap = ntl + 1;
+        }
+        h->sp_job = SortedGammaJob{h->cfg.seed, h->sp_g, h->cfg.gid0, h->n, ntl, h->epoch, gamma_E(ntl), 0};
+        h->sp_job_set = true;
+    }
+    struct SpScope { gpf_filter* h; ~SpScope() { h->sp_job_set = false; } } sp_scope{h};
     // safe_softmax(log_priorities) (resample.jl:54) and logsumexp(log_weights) (resample.jl:180)
     WSum* ws;
     bool published = false;                                      // the scan of THIS call publishes the flags to pinned memory
@@ -1027,6 +1051,18 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         sa.w = levels(h, 2); sa.c = levels(h, 1);
         sa.head_done = head_in_search ? 0 : 1;
     }
+    if (method == GPF_RESAMPLE_MULTINOMIAL_SORTED) {
+        const int64_t ntl = (h->n + SP_TILE - 1) / SP_TILE;
+        if (h->sp_job_set) {                                     // no weight scan ran in this call (the CDF of an earlier getter is reused): a launch of its own
+            h->sp_job_set = false;
+            GPF_LAUNCH(k_sorted_gammas, dim3((unsigned)((ntl + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->sp_job);
+        }
+        sa.sp_g = h->sp_g; sa.sp_vlo = nullptr;
+        if (ntl > SP_DIRECT_TILES) {
+            GPF_LAUNCH(k_sorted_tiles, dim3(1), dim3(STILES_BLOCK), 0, h->stream, h->sp_g, ntl, h->sp_vlo);
+            sa.sp_vlo = h->sp_vlo;
+        }
+    }
     const int64_t nt = method == GPF_RESAMPLE_RESIDUAL && !sa.head_done ? 2 : 1;   // (top tables the search keeps in LDS: its shape depends on their number)
     const size_t lds = search_lds_bytes(h->ntiles, (int)nt);
     // every block first copies the top level of the CDF into LDS: keep the grid small (persistent blocks)
@@ -1037,8 +1073,10 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
             switch (method) {
                 case GPF_RESAMPLE_MULTINOMIAL: launch_multinomial_search(h, sa); break;
                 case GPF_RESAMPLE_RESIDUAL:    GPF_LAUNCH((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
+                case GPF_RESAMPLE_MULTINOMIAL_SORTED:   // sorted uniforms: the same streaming merge (the spacing sums were enqueued above)
+                    GPF_LAUNCH((k_search_strat<true>), dim3((unsigned)((h->n + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa); break;
                 default:                       // monotone targets: a streaming merge, MJB slots per workgroup
-                    GPF_LAUNCH(k_search_strat, dim3((unsigned)((h->n + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa); break;
+                    GPF_LAUNCH((k_search_strat<false>), dim3((unsigned)((h->n + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa); break;
             }
         });
     };
@@ -1245,6 +1283,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
     if (h->h_pull_pc_all) hipHostFree(h->h_pull_pc_all);
     if (h->h_qpub) hipHostFree(h->h_qpub);
+    if (h->sp_g) { (void)hipFree(h->sp_g); (void)hipFree(h->sp_vlo); }
     for (int k = 0; k < gpf_filter::BLK_STAGE; ++k) if (h->h_blk_obs[k]) hipHostFree(h->h_blk_obs[k]);
     if (h->h_blk_done) hipHostFree(h->h_blk_done);
     if (h->blk_stage_counter) (void)hipFree(h->blk_stage_counter);
@@ -1419,6 +1458,7 @@ static gpf_status block_buffers(gpf_filter* h, int64_t nblocks)
     if (!h->blk_words) HIP_TRY(h, hipMalloc(&h->blk_words, 2 * sizeof(int32_t)));
     if (h->blk_cap < nblocks) {
         if (h->blk_mask) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->blk_mask); (void)hipFree(h->blk_stats); h->blk_mask = nullptr; h->blk_stats = nullptr; h->blk_cap = 0; }
+        h->blk_last = 0;                                         // the new mask is uninitialised: no block resample to refer to
         HIP_TRY(h, hipMalloc(&h->blk_mask, (size_t)nblocks * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc(&h->blk_stats, (size_t)nblocks * 2 * sizeof(double)));
         h->blk_cap = nblocks;
@@ -1583,6 +1623,7 @@ gpf_status gpf_initialize_blocks(gpf_handle h, const double* obs, int32_t n_obs,
     HIP_TRY(h, hipGetLastError());
     h->epoch += 1;
     h->initialized = true; h->has_prev = false; h->raw_valid = false;
+    h->blk_last = 0;                                             // only_resampled refers to a gpf_resample_blocks of the CURRENT step
     mutated(h);
     return GPF_OK;
 }
@@ -1606,6 +1647,7 @@ gpf_status gpf_update_blocks(gpf_handle h, const double* obs, int32_t n_obs, int
     h->epoch += 1;
     h->has_prev = true;
     h->raw_valid = false;
+    h->blk_last = 0;                                             // (as in gpf_initialize_blocks)
     mutated(h);
     return GPF_OK;
 }
@@ -1745,8 +1787,20 @@ gpf_status gpf_effective_sample_size(gpf_handle h, double* out)
         h->q_published = false;
         if ((s = wait_ticket(h, h->h_qpub + 6, h->q_ticket, "ESS summary"))) return s;
         if ((s = check_scan_timeout(h))) return s;
-        w.flags = (int32_t)h->h_qpub[0]; w.S = (uint64_t)h->h_qpub[1];
-        for (int k = 0; k < 4; ++k) w.Ql[k] = (uint64_t)h->h_qpub[2 + k];
+        // the seven words are unordered on their way to pinned memory: re-read until the check word (ticket ^ payload) agrees
+        for (uint64_t spins = 0;; ++spins) {
+            int64_t v[8];
+            for (int k = 0; k < 8; ++k) v[k] = __atomic_load_n(h->h_qpub + k, __ATOMIC_ACQUIRE);
+            uint64_t chk = (uint64_t)v[6];
+            for (int k = 0; k < 6; ++k) chk ^= (uint64_t)v[k];
+            if (v[6] == h->q_ticket && chk == (uint64_t)v[7]) {
+                w.flags = (int32_t)v[0]; w.S = (uint64_t)v[1];
+                for (int k = 0; k < 4; ++k) w.Ql[k] = (uint64_t)v[2 + k];
+                break;
+            }
+            cpu_relax();
+            if (spins > (1ull << 26)) return fail(h, GPF_ERR_HIP, "ESS summary: the published words never became consistent");
+        }
     } else {
         const bool fold = !h->raw_q_folded;                      // the scan blocks' limb partials of sum q^2: folded by the publish kernel
         if ((s = fetch_scalars(h, fold))) return s;
@@ -2564,7 +2618,7 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
         sa.update_lml = 0;                                            // the commit carries the log-ML update
         sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W, h->push_extra, h->push_pv};
         s = timed(h, GPF_K_GATHER, [&] {
-            GPF_LAUNCH(k_search_strat, dim3((unsigned)((cap + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa);
+            GPF_LAUNCH((k_search_strat<false>), dim3((unsigned)((cap + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa);
         });
         if (s) return s;
         HIP_TRY(h, hipGetLastError());
@@ -3198,6 +3252,10 @@ gpf_status gpf_shard_log_ml_estimate(gpf_handle h, double* out)
 // =================================================================================== host scalar spec
 extern "C" {
 int32_t gpf_host_fix_K(int64_t n_global) { return fix_K(n_global); }
+int32_t gpf_host_gamma_E(int64_t n_tiles) { return gamma_E(n_tiles); }
+uint64_t gpf_host_div128(uint64_t P, uint64_t den) { return div128(P, div128_setup(den)); }
+uint64_t gpf_host_muldiv128(uint64_t p, uint64_t W, uint64_t den) { return muldiv128(p, W, div128_setup(den)); }
+uint64_t gpf_host_gamma_tile(uint64_t seed, uint32_t gid, uint32_t epoch, int64_t shape, int32_t Eg) { return gamma_tile(seed, gid, epoch, shape, Eg); }
 double gpf_host_log(double x) { return log_(x); }
 double gpf_host_lse(double m, uint64_t S, int32_t K, int32_t flags)
 {

@@ -53,7 +53,14 @@ typedef enum {
 
 /* method::Symbol of pf_resample! (src/resample.jl:19-30) */
 typedef enum { GPF_RESAMPLE_MULTINOMIAL = 0, GPF_RESAMPLE_RESIDUAL = 1, GPF_RESAMPLE_STRATIFIED = 2,
-               GPF_RESAMPLE_OPTIMAL = 3 /* gpf_resize only: pf_optimal_resize!, src/resize.jl:149-219 */ } gpf_resample_method;
+               GPF_RESAMPLE_OPTIMAL = 3 /* gpf_resize only: pf_optimal_resize!, src/resize.jl:149-219 */,
+               /* OPT-IN extension, not a reference method: pf_multinomial_resample! (src/resample.jl:48-65) with the N uniforms drawn
+                * ALREADY SORTED (uniform spacings in exact integers).  Offspring counts ~ Multinomial(N, w) as for :multinomial;
+                * state.parents comes out non-decreasing instead of as an i.i.d. sequence (src/resample.jl:59), so slot k of the new
+                * population is NOT exchangeable with slot k' any more -- harmless for a filter that treats its particles as a set, visible
+                * to code that cuts the population into views by position.  The ancestor search becomes a streaming merge and the row
+                * gather reads ascending rows.  gpf_resample (and views) only. */
+               GPF_RESAMPLE_MULTINOMIAL_SORTED = 4 } gpf_resample_method;
 /* method::Symbol of pf_rejuvenate! (src/rejuvenate.jl:18-27) */
 typedef enum { GPF_REJUVENATE_MOVE = 0, GPF_REJUVENATE_REWEIGHT = 1 } gpf_rejuvenate_method;
 /* check keyword of the resamplers: true | :warn | false (src/resample.jl:43-46) */
@@ -348,6 +355,12 @@ gpf_status gpf_shard_lml_est(gpf_handle h, double* out);
 
 /* ---- host-side scalar spec (no GPU needed): the same deterministic functions the kernels use ---------- */
 int32_t gpf_host_fix_K(int64_t n_global);
+/* GPF_RESAMPLE_MULTINOMIAL_SORTED: fixed-point scale of the tile totals; the kernels' reciprocal divisions
+ * floor(P 2^64 / den) (P < den < 2^63) and floor(p W / den) (p < den); one tile's gamma variate */
+int32_t gpf_host_gamma_E(int64_t n_tiles);
+uint64_t gpf_host_div128(uint64_t P, uint64_t den);
+uint64_t gpf_host_muldiv128(uint64_t p, uint64_t W, uint64_t den);
+uint64_t gpf_host_gamma_tile(uint64_t seed, uint32_t gid, uint32_t epoch, int64_t shape, int32_t Eg);
 double  gpf_host_log(double x);
 double  gpf_host_lse(double m, uint64_t S, int32_t K, int32_t flags);     /* m + log(S 2^-K) */
 double  gpf_host_ess(uint64_t S, uint64_t Q_hi, uint64_t Q_lo);           /* S^2 / Q */

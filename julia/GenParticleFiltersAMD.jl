@@ -61,7 +61,7 @@ end
 # file accepts the returned object (it is a DeviceParticleFilterState whose handle aliases the source's particles)
 function Base.getindex(s::DeviceParticleFilterState, r::UnitRange{Int})
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(s, ccall((:gpf_view_create, libgpf), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), getfield(s, :handle), first(r) - 1, length(r), h))
+    _status(s, ccall((:gpf_view_create, libgpf), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), getfield(s, :handle), first(r) - 1, length(r), h))
     return DeviceParticleFilterState(h[], getfield(s, :model), length(r))
 end
 Base.view(s::DeviceParticleFilterState, r::UnitRange{Int}) = s[r]
@@ -69,26 +69,26 @@ Base.view(s::DeviceParticleFilterState, r::UnitRange{Int}) = s[r]
 function Base.getindex(s::DeviceParticleFilterState, r::StepRange{Int,Int})
     step(r) >= 1 || error("sub-state ranges need a positive step")
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(s, ccall((:gpf_view_create_strided, libgpf), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ref{Ptr{Cvoid}}), getfield(s, :handle), first(r) - 1, step(r), length(r), h))
+    _status(s, ccall((:gpf_view_create_strided, libgpf), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ref{Ptr{Cvoid}}), getfield(s, :handle), first(r) - 1, step(r), length(r), h))
     return DeviceParticleFilterState(h[], getfield(s, :model), length(r))
 end
 Base.view(s::DeviceParticleFilterState, r::StepRange{Int,Int}) = s[r]
 
-check(state, st) = st == 0 ? nothing :
+# status helper; NOT called `check`: the resamplers take a keyword of that name (src/resample.jl:43-46) which would shadow it
+_status(state, st) = st == 0 ? nothing :
     error(unsafe_string(ccall((:gpf_last_error, libgpf), Cstring, (Ptr{Cvoid},), state.handle)))   # ErrorException
-const _status = check        # for methods whose keyword argument is called `check`, like the reference's pf_resample!
 
 # src/initialize.jl:31-44
 function pf_initialize(model::NativeModel, model_args::Tuple, observations::Vector{Float64}, n_particles::Int; kw...)
     state = DeviceParticleFilterState(model, n_particles; kw...)
-    check(state, ccall((:gpf_initialize, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint),
+    _status(state, ccall((:gpf_initialize, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint),
                        state.handle, observations, length(observations)))
     return state
 end
 
 # src/update.jl:12-25
 function pf_update!(state::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Vector{Float64})
-    check(state, ccall((:gpf_update, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint),
+    _status(state, ccall((:gpf_update, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint),
                        state.handle, observations, length(observations)))
     return state
 end
@@ -97,11 +97,11 @@ end
 struct LocallyOptimal end
 function pf_initialize(model::NativeModel, model_args::Tuple, observations::Vector{Float64}, proposal::LocallyOptimal, proposal_args::Tuple, n_particles::Int; kw...)
     state = DeviceParticleFilterState(model, n_particles; kw...)
-    check(state, ccall((:gpf_initialize_proposal, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), state.handle, observations, length(observations), 1))
+    _status(state, ccall((:gpf_initialize_proposal, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), state.handle, observations, length(observations), 1))
     return state
 end
 function pf_update!(state::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Vector{Float64}, proposal::LocallyOptimal, proposal_args::Tuple)
-    check(state, ccall((:gpf_update_proposal, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), state.handle, observations, length(observations), 1))
+    _status(state, ccall((:gpf_update_proposal, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cint), state.handle, observations, length(observations), 1))
     return state
 end
 
@@ -124,7 +124,7 @@ function _resample!(state, method::Int, priority_fn, check_kw, sort_particles::B
                        state.handle, method, lp, sort_particles, chk, inv_ptr)
         end
     end
-    check(state, st)                                            # error("Invalid weights."), src/resample.jl:55
+    _status(state, st)                                            # error("Invalid weights."), src/resample.jl:55
     check_kw === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")   # utils.jl:120-135
     return state
 end
@@ -153,7 +153,7 @@ function pf_resample_blocks!(s::DeviceParticleFilterState, block_size::Int, meth
     st = ccall((:gpf_resample_blocks, libgpf), Cint, (Ptr{Cvoid}, Cint, Int64, Cdouble, Cint, Cdouble, Cint, Ptr{Cint}, Ptr{Int64}),
                s.handle, m, block_size, priority_fn === nothing ? NaN : priority_fn.alpha, sort_particles ? 1 : 0,
                ess_frac === nothing ? NaN : Float64(ess_frac), chk, invalid, count)
-    check(s, st)
+    _status(s, st)
     check === :warn && invalid[] != 0 && @warn("Invalid weights in some block: resampled with uniform weights.")
     return Int(count[])
 end
@@ -161,7 +161,7 @@ end
 function block_stats(s::DeviceParticleFilterState, block_size::Int)
     nb = cld(s.n_particles, block_size)
     ess = Vector{Float64}(undef, nb); lml = Vector{Float64}(undef, nb)
-    check(s, ccall((:gpf_block_stats, libgpf), Cint, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}), s.handle, block_size, ess, lml))
+    _status(s, ccall((:gpf_block_stats, libgpf), Cint, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}), s.handle, block_size, ess, lml))
     return ess, lml
 end
 # Every block a filter on ITS OWN data: per-block initialisation / update / rejuvenation, one launch each (gpf.h gpf_initialize_blocks,
@@ -169,28 +169,28 @@ end
 function pf_initialize_blocks(model::NativeModel, model_args::Tuple, observations::Matrix{Float64}, n_particles::Int, block_size::Int; kw...)
     state = DeviceParticleFilterState(model, n_particles; kw...)
     size(observations, 2) == cld(n_particles, block_size) || error("one observation column per block expected")
-    check(state, ccall((:gpf_initialize_blocks, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64), state.handle, observations, size(observations, 1), block_size))
+    _status(state, ccall((:gpf_initialize_blocks, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64), state.handle, observations, size(observations, 1), block_size))
     return state
 end
 function pf_update_blocks!(s::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Matrix{Float64}, block_size::Int)
     size(observations, 2) == cld(s.n_particles, block_size) || error("one observation column per block expected")
-    check(s, ccall((:gpf_update_blocks, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64), s.handle, observations, size(observations, 1), block_size)); s
+    _status(s, ccall((:gpf_update_blocks, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64), s.handle, observations, size(observations, 1), block_size)); s
 end
 function pf_rejuvenate_blocks!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1; method::Symbol=:move, only_resampled::Bool=false)
     m = method == :move ? 0 : method == :reweight ? 1 : error("Method $method not recognized.")
-    check(s, ccall((:gpf_rejuvenate_blocks, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, only_resampled ? 1 : 0, C_NULL)); s
+    _status(s, ccall((:gpf_rejuvenate_blocks, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, only_resampled ? 1 : 0, C_NULL)); s
 end
 "which blocks the last pf_resample_blocks! resampled"
 function block_resampled(s::DeviceParticleFilterState, block_size::Int)
     out = Vector{Cint}(undef, cld(s.n_particles, block_size))
-    check(s, ccall((:gpf_block_resampled, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cint}), s.handle, out))
+    _status(s, ccall((:gpf_block_resampled, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cint}), s.handle, out))
     return out .!= 0
 end
 
 # src/rejuvenate.jl:18-90 with the native kernels (Gen.mh / move_reweight on the current step's latent)
 function pf_rejuvenate!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1; method::Symbol=:move)
     m = method == :move ? 0 : method == :reweight ? 1 : error("Method $method not recognized.")
-    check(s, ccall((:gpf_rejuvenate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, C_NULL))
+    _status(s, ccall((:gpf_rejuvenate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, C_NULL))
     return s
 end
 # move_reweight(trace, proposal, proposal_args) (src/rejuvenate.jl:134-148) with a native proposal:
@@ -199,7 +199,7 @@ end
 struct MoveProposal; id::Int; params::Vector{Float64}; end
 function pf_move_reweight!(s::DeviceParticleFilterState, kern, kern_args::Tuple{MoveProposal,Vararg}, n_iters::Int=1)
     mp = kern_args[1]
-    check(s, ccall((:gpf_rejuvenate_proposal, libgpf), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Cint), s.handle, mp.id, mp.params, length(mp.params), n_iters))
+    _status(s, ccall((:gpf_rejuvenate_proposal, libgpf), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Cint), s.handle, mp.id, mp.params, length(mp.params), n_iters))
     return s
 end
 pf_move_accept!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1) = pf_rejuvenate!(s, kern, kern_args, n_iters; method=:move)
@@ -207,13 +207,13 @@ pf_move_reweight!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(
 
 # src/resize.jl:16-124, 236-297 -- the handle stays valid, its buffers are reallocated
 function _refresh!(s)
-    n = Ref{Int64}(0); check(s, ccall((:gpf_n_particles, libgpf), Cint, (Ptr{Cvoid}, Ref{Int64}), s.handle, n)); s.n_particles = n[]; s
+    n = Ref{Int64}(0); _status(s, ccall((:gpf_n_particles, libgpf), Cint, (Ptr{Cvoid}, Ref{Int64}), s.handle, n)); s.n_particles = n[]; s
 end
 function _resize!(s, n::Int, method::Int, priority_fn, check_kw)
     chk = check_kw === true ? 2 : (check_kw === :warn ? 1 : 0)
     alpha = priority_fn === nothing ? NaN : (priority_fn::Tempering).alpha
     invalid = Ref{Cint}(0)
-    check(s, ccall((:gpf_resize, libgpf), Cint, (Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ref{Cint}), s.handle, n, method, alpha, chk, invalid))
+    _status(s, ccall((:gpf_resize, libgpf), Cint, (Ptr{Cvoid}, Int64, Cint, Cdouble, Cint, Ref{Cint}), s.handle, n, method, alpha, chk, invalid))
     check_kw === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
     _refresh!(s)
 end
@@ -227,21 +227,21 @@ function pf_resize!(s::DeviceParticleFilterState, n::Int, method::Symbol=:multin
     error("Resampling method $method not recognized.")
 end
 function pf_replicate!(s::DeviceParticleFilterState, k::Int; layout::Symbol=:contiguous)
-    check(s, ccall((:gpf_replicate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint), s.handle, k, layout != :contiguous)); _refresh!(s)
+    _status(s, ccall((:gpf_replicate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint), s.handle, k, layout != :contiguous)); _refresh!(s)
 end
 function pf_dereplicate!(s::DeviceParticleFilterState, k::Int; layout::Symbol=:contiguous, method::Symbol=:keepfirst)
-    check(s, ccall((:gpf_dereplicate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint), s.handle, k, layout != :contiguous, method == :sample)); _refresh!(s)
+    _status(s, ccall((:gpf_dereplicate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint), s.handle, k, layout != :contiguous, method == :sample)); _refresh!(s)
 end
 
 # src/utils.jl:148-186
 function _scalar(s, sym)
     out = Ref{Cdouble}(0)
-    check(s, ccall((sym, libgpf), Cint, (Ptr{Cvoid}, Ref{Cdouble}), s.handle, out))
+    _status(s, ccall((sym, libgpf), Cint, (Ptr{Cvoid}, Ref{Cdouble}), s.handle, out))
     return out[]
 end
 function _vector(s, sym)
     out = Vector{Float64}(undef, s.n_particles)
-    check(s, ccall((sym, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64), s.handle, out, length(out)))
+    _status(s, ccall((sym, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64), s.handle, out, length(out)))
     return out
 end
 effective_sample_size(s::DeviceParticleFilterState) = _scalar(s, :gpf_effective_sample_size)
@@ -256,7 +256,7 @@ get_norm_weights(s::DeviceParticleFilterState) = _vector(s, :gpf_get_norm_weight
 function Base.getproperty(s::DeviceParticleFilterState, name::Symbol)
     if name === :parents
         out = Vector{Int64}(undef, getfield(s, :n_particles))
-        check(s, ccall((:gpf_get_parents, libgpf), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64), getfield(s, :handle), out, length(out)))
+        _status(s, ccall((:gpf_get_parents, libgpf), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64), getfield(s, :handle), out, length(out)))
         return out
     elseif name === :log_weights
         return get_log_weights(s)
@@ -266,45 +266,45 @@ end
 
 # src/statistics.jl:13-14, 48-50 -- addr = column of the current-step latent (0-based)
 function mean(s::DeviceParticleFilterState, addr::Integer)
-    out = Ref{Cdouble}(0); check(s, ccall((:gpf_mean, libgpf), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), s.handle, addr, out)); out[]
+    out = Ref{Cdouble}(0); _status(s, ccall((:gpf_mean, libgpf), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), s.handle, addr, out)); out[]
 end
 function var(s::DeviceParticleFilterState, addr::Integer)
-    out = Ref{Cdouble}(0); check(s, ccall((:gpf_var, libgpf), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), s.handle, addr, out)); out[]
+    out = Ref{Cdouble}(0); _status(s, ccall((:gpf_var, libgpf), Cint, (Ptr{Cvoid}, Cint, Ref{Cdouble}), s.handle, addr, out)); out[]
 end
 
 # past choices along the surviving ancestry, README.md:97-104: mean(state, 5 => 0) == mean(state, 5 => :moving)
 # (needs the trajectory store: gpf_history_enable before pf_initialize)
 function mean(s::DeviceParticleFilterState, addr::Pair{<:Integer,<:Integer})
-    out = Ref{Cdouble}(0); check(s, ccall((:gpf_history_mean, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cdouble}), s.handle, addr.first, addr.second, out)); out[]
+    out = Ref{Cdouble}(0); _status(s, ccall((:gpf_history_mean, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cdouble}), s.handle, addr.first, addr.second, out)); out[]
 end
 function var(s::DeviceParticleFilterState, addr::Pair{<:Integer,<:Integer})
-    out = Ref{Cdouble}(0); check(s, ccall((:gpf_history_var, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cdouble}), s.handle, addr.first, addr.second, out)); out[]
+    out = Ref{Cdouble}(0); _status(s, ccall((:gpf_history_var, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{Cdouble}), s.handle, addr.first, addr.second, out)); out[]
 end
 
 # stratified initialisation / update (src/initialize.jl:92-109, src/update.jl:193-210): strata = values of the model's discrete latent
 function pf_initialize(model::NativeModel, args::Tuple, obs::Vector{Float64}, strata::Vector{Float64}, n::Int; layout::Symbol=:contiguous, kwargs...)
     s = DeviceParticleFilterState(model, n; kwargs...)
-    check(s, ccall((:gpf_initialize_strata, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint),
+    _status(s, ccall((:gpf_initialize_strata, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint),
                    s.handle, obs, length(obs), strata, length(strata), layout != :contiguous)); s
 end
 # ... with a native proposal for the model's other choice (src/initialize.jl:111-129; line_model + LineFixed: test/initialize.jl:66-90)
 function pf_initialize(model::NativeModel, args::Tuple, obs::Vector{Float64}, strata::Vector{Float64}, proposal_id::Int, proposal_args::Tuple, n::Int;
                        layout::Symbol=:contiguous, kwargs...)
     s = DeviceParticleFilterState(model, n; kwargs...)
-    check(s, ccall((:gpf_initialize_strata_proposal, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint, Cint),
+    _status(s, ccall((:gpf_initialize_strata_proposal, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint, Cint),
                    s.handle, obs, length(obs), strata, length(strata), layout != :contiguous, proposal_id)); s
 end
 function pf_update!(s::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, obs::Vector{Float64}, strata::Vector{Float64}; layout::Symbol=:interleaved)
-    check(s, ccall((:gpf_update_strata, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint),
+    _status(s, ccall((:gpf_update_strata, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cint, Cint),
                    s.handle, obs, length(obs), strata, length(strata), layout != :contiguous)); s
 end
 
 # Gen.sample_unweighted_traces(state, n) (src/utils.jl:189-194): rows of the drawn particles (n x row_width) and their indices
 function sample_unweighted_traces(s::DeviceParticleFilterState, n::Int)
     dim = Ref{Cint}(0); w = Ref{Cint}(0)
-    check(s, ccall((:gpf_state_dim, libgpf), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), s.handle, dim, w))
+    _status(s, ccall((:gpf_state_dim, libgpf), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), s.handle, dim, w))
     rows = Matrix{Float64}(undef, w[], n); idx = Vector{Int64}(undef, n)
-    check(s, ccall((:gpf_sample_unweighted, libgpf), Cint, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Int64}), s.handle, n, rows, idx))
+    _status(s, ccall((:gpf_sample_unweighted, libgpf), Cint, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Int64}), s.handle, n, rows, idx))
     permutedims(rows)[:, 1:dim[]], idx
 end
 
@@ -338,16 +338,16 @@ function pf_initialize(model::NativeModel, model_args::Tuple, observations::Vect
     end
     s = ShardedDeviceParticleFilterState(h[], model, n, n_global, rank, world)
     finalizer(x -> ccall((:gpf_destroy, libgpf), Cint, (Ptr{Cvoid},), x.handle), s)
-    check(s, ccall((:gpf_comm_create, libgpf), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), s.handle, id, rank, world))
-    check(s, ccall((:gpf_initialize, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), s.handle, observations, length(observations)))
+    _status(s, ccall((:gpf_comm_create, libgpf), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), s.handle, id, rank, world))
+    _status(s, ccall((:gpf_initialize, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), s.handle, observations, length(observations)))
     return s
 end
 function pf_update!(s::ShardedDeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Vector{Float64})
-    check(s, ccall((:gpf_update, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), s.handle, observations, length(observations))); s
+    _status(s, ccall((:gpf_update, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), s.handle, observations, length(observations))); s
 end
 function pf_rejuvenate!(s::ShardedDeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1; method::Symbol=:move)
     m = method == :move ? 0 : method == :reweight ? 1 : error("Method $method not recognized.")
-    check(s, ccall((:gpf_rejuvenate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, C_NULL)); s
+    _status(s, ccall((:gpf_rejuvenate, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, C_NULL)); s
 end
 # src/resample.jl:19-30 over all shards: ONE call, every collective issued by the library.
 # local_only = true: the communication-free "island" resample, pf_resample!(state[shard range], method) on every shard
@@ -364,18 +364,18 @@ function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multi
         (priority_alpha === nothing ?
             ccall((:gpf_shard_resample, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}), s.handle, m, chk, inv_ptr) :
             ccall((:gpf_shard_resample_tempered, libgpf), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Cint}), s.handle, m, priority_alpha, chk, inv_ptr)))
-    _status(s, st)                                # (the keyword `check` shadows the status helper of that name in this method)
+    _status(s, st)
     check === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
     return s
 end
 """exchange plan of the i.i.d. resamplers across shards: :push (default) or :pull (gpf.h gpf_comm_set_plan); the same on every rank"""
 function shard_plan!(s::ShardedDeviceParticleFilterState, plan::Symbol)
     plan in (:push, :pull) || error("exchange plan :$plan: :push or :pull")
-    check(s, ccall((:gpf_comm_set_plan, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, plan == :pull ? 1 : 0)); s
+    _status(s, ccall((:gpf_comm_set_plan, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, plan == :pull ? 1 : 0)); s
 end
 function shard_plan(s::ShardedDeviceParticleFilterState)
     p = Ref{Cint}(0)
-    check(s, ccall((:gpf_comm_plan, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cint}), s.handle, p))
+    _status(s, ccall((:gpf_comm_plan, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cint}), s.handle, p))
     p[] == 1 ? :pull : :push
 end
 effective_sample_size(s::ShardedDeviceParticleFilterState) = _scalar(s, :gpf_shard_effective_sample_size)

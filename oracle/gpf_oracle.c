@@ -600,6 +600,91 @@ O_EXPORT void o_targets_stratified(uint64_t seed, uint32_t epoch, int64_t j0, in
         T[j] = L0 + o_mulhi64(o_resample_u64(seed, (uint32_t)jg, epoch), L1 - L0);
     }
 }
+/* "multinomial_sorted" -- an OPT-IN variant of the multinomial resampler (resample.jl:59: N i.i.d. categorical draws) whose ancestors
+ * come out in NON-DECREASING order: the N uniforms are drawn already sorted.  NOT the reference's slot order (an i.i.d. sequence); the
+ * multiset of ancestors has the same law (offspring counts ~ Multinomial(N, w)), which is all a filter step that treats the particles
+ * exchangeably can see.  Construction: uniform spacings.  With e_0..e_N i.i.d. Exp(1) and P_j = e_0 + ... + e_j, the
+ * ratios P_j / P_N (j < N) are the order statistics of N uniforms.  The sum over a TILE of O_SP_TILE consecutive slots is Gamma(tile
+ * size) and independent of the tile's normalised partial sums, so the tile totals are drawn DIRECTLY (one Marsaglia-Tsang gamma variate
+ * per tile: no pass over all spacings is needed to place a tile, on one GPU or across shards) and the spacings only place the slots
+ * inside their tile:
+ *     G_t   = trunc(gamma(c_t [+ 1 for the last tile: the (N+1)-th spacing]) 2^Eg),  Gtot = sum G_t + 1
+ *     Vlo_t = floor((G_0 + ... + G_{t-1}) 2^64 / Gtot)
+ *     e_i   = trunc(-log(u_i) 2^44),  u_i the 52-bit uniform of resample slot j0 + i;  p_j = sum of the e_i of the tile up to slot j;
+ *     s_t   = the tile's sum + 1 (the last tile: + e_N)
+ *     Tlo_t = floor(Vlo_t S / 2^64)  (the multinomial target formula on the tile's first uniform),  Tw_t = Tlo_{t+1} - Tlo_t
+ *     T_j   = Tlo_t + min(Tw_t, trunc(fl(fl(p_j) fl(1 / fl(s_t))) fl(Tw_t)))      (fl: round to Float64)  */
+#define O_SP_TILE 2048
+#define O_SP_E 44
+O_EXPORT int32_t o_gamma_E(int64_t ntl)
+{
+    int c = 0;
+    while (((int64_t)1 << c) < ntl) ++c;
+    return 50 - c > 48 ? 48 : 50 - c;                 /* a tile total is < 2^12 (see o_gamma_tile): the sum of ntl of them < 2^62 */
+}
+/* Gamma(shape, 1), shape >= 1 an integer, by Marsaglia & Tsang (2000): d = shape - 1/3, c = 1 / sqrt(9 d); x ~ N(0,1), v = (1 + c x)^3,
+ * accept when v > 0 and log u < x^2 / 2 + d - d v + d log v.  Attempt k reads Philox blocks 1 + 2k (the normal) and 2 + 2k (the uniform)
+ * of counter `gid` on the resample stream (block 0 belongs to the slots' own uniforms); 8 attempts, then d (never in practice: the
+ * acceptance rate is > 0.95 for shape >= 1 and > 0.999 for a full tile).  |x| <= 8.6 bounds the variate below 1.2 shape + 60 < 2^12. */
+static uint64_t o_gamma_tile(uint64_t seed, uint32_t gid, uint32_t epoch, int64_t shape, int Eg)
+{
+    const double d = (double)shape - 1.0 / 3.0;
+    const double c = 1.0 / sqrt(9.0 * d);
+    const double sc = o_u2d((uint64_t)(Eg + 1023) << 52);
+    for (int k = 0; k < 8; ++k) {
+        double x, x1;
+        o_normal2(o_rng(seed, gid, (uint32_t)(1 + 2 * k), epoch, O_TAG_RESAMPLE), &x, &x1);
+        const o_philox_t b = o_rng(seed, gid, (uint32_t)(2 + 2 * k), epoch, O_TAG_RESAMPLE);
+        const double u = o_u52(b.v[0], b.v[1]);
+        const double v1 = 1.0 + c * x;
+        if (!(v1 > 0.0)) continue;
+        const double v = (v1 * v1) * v1;
+        if (o_log(u) < ((0.5 * (x * x) + d) - d * v) + d * o_log(v)) return (uint64_t)((d * v) * sc);
+    }
+    return (uint64_t)(d * sc);
+}
+static inline uint64_t o_spacing(uint64_t seed, uint32_t slot, uint32_t epoch)
+{
+    const uint64_t U = o_resample_u64(seed, slot, epoch);
+    const double u = o_u52((uint32_t)(U >> 32), (uint32_t)U);
+    return (uint64_t)(-o_log(u) * o_u2d((uint64_t)(O_SP_E + 1023) << 52));      /* exact scaling by 2^E; truncation = floor */
+}
+O_EXPORT uint64_t o_spacing_d(uint64_t seed, uint32_t slot, uint32_t epoch) { return o_spacing(seed, slot, epoch); }
+O_EXPORT uint64_t o_gamma_tile_d(uint64_t seed, uint32_t gid, uint32_t epoch, int64_t shape, int32_t Eg) { return o_gamma_tile(seed, gid, epoch, shape, Eg); }
+O_EXPORT void o_targets_sorted(uint64_t seed, uint32_t epoch, int64_t j0, int64_t n, uint64_t S, uint64_t *T)
+{
+    const int64_t ntl = (n + O_SP_TILE - 1) / O_SP_TILE;
+    const int Eg = o_gamma_E(ntl);
+    uint64_t *G = (uint64_t *)malloc((size_t)(ntl + 1) * sizeof(uint64_t));      /* exclusive prefix of the tile totals */
+    uint64_t acc = 0;
+    for (int64_t t = 0; t < ntl; ++t) {
+        const int64_t first = t * O_SP_TILE, cnt = (first + O_SP_TILE <= n ? O_SP_TILE : n - first);
+        G[t] = acc;
+        acc += o_gamma_tile(seed, (uint32_t)(j0 + first), epoch, cnt + (t == ntl - 1 ? 1 : 0), Eg);
+    }
+    G[ntl] = acc;
+    const uint64_t Gtot = acc + 1;
+    #pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < ntl; ++t) {
+        const int64_t first = t * O_SP_TILE, cnt = (first + O_SP_TILE <= n ? O_SP_TILE : n - first);
+        const uint64_t Vlo = (uint64_t)((((o_u128)G[t]) << 64) / Gtot), Vhi = (uint64_t)((((o_u128)G[t + 1]) << 64) / Gtot);
+        uint64_t s = 0;
+        for (int64_t k = 0; k < cnt; ++k) { s += o_spacing(seed, (uint32_t)(j0 + first + k), epoch); T[first + k] = s; }   /* p_j for now */
+        s += 1;                                                   /* p_j < s_t strictly (and s_t > 0) */
+        if (t == ntl - 1) s += o_spacing(seed, (uint32_t)(j0 + n), epoch);       /* the (N+1)-th spacing */
+        /* the tile covers the targets [Tlo, Thi]; a slot sits at the fraction p_j / s_t of it -- in Float64 (one rounding each for the
+         * conversions, the product with 1 / s_t and the product with the width: monotone in p_j; the integer division this replaces
+         * cost the GPU ~36 32-bit multiplications per slot) */
+        const uint64_t Tlo = o_mulhi64(Vlo, S), Tw = o_mulhi64(Vhi, S) - Tlo;
+        const double inv_s = 1.0 / (double)s, dTw = (double)Tw;
+        for (int64_t k = 0; k < cnt; ++k) {
+            uint64_t tt = (uint64_t)(((double)T[first + k] * inv_s) * dTw);
+            if (tt > Tw) tt = Tw;
+            T[first + k] = Tlo + tt;
+        }
+    }
+    free(G);
+}
 /* sub-state views: strata are LOCAL to the view (index j of n), the RNG counter keeps the global particle id gid0 + j */
 O_EXPORT void o_targets_stratified_view(uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n, uint64_t S, uint64_t *T)
 {

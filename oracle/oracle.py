@@ -22,7 +22,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 
 MODEL_LGSSM2, MODEL_BEARINGS4, MODEL_SV1, MODEL_OBJECT_MOTION, MODEL_LINE = 1, 2, 3, 4, 5
 FLAG_NAN, FLAG_POSINF, FLAG_ALL_NEGINF = 1, 2, 4
-METHODS = ("multinomial", "residual", "stratified")
+METHODS = ("multinomial", "residual", "stratified", "multinomial_sorted")
 
 
 def build(force: bool = False) -> str:
@@ -76,6 +76,10 @@ def lib():
     sig("o_fixq", None, _f64p, i64, f64, i32, i32, _u64p)
     sig("o_scan", u64, _u64p, i64, _u64p, pu64, pu64)
     sig("o_targets_multinomial", None, u64, u32, i64, i64, u64, _u64p)
+    sig("o_targets_sorted", None, u64, u32, i64, i64, u64, _u64p)
+    sig("o_gamma_E", C.c_int32, i64)
+    sig("o_spacing_d", u64, u64, u32, u32)
+    sig("o_gamma_tile_d", u64, u64, u32, u32, i64, C.c_int32)
     sig("o_targets_stratified", None, u64, u32, i64, i64, i64, u64, _u64p)
     sig("o_targets_stratified_view", None, u64, u32, i64, i64, u64, _u64p)
     sig("o_upper_bound", None, _u64p, i64, _u64p, i64, _i64p)
@@ -151,6 +155,13 @@ def upper_bound(cdf: np.ndarray, T: np.ndarray) -> np.ndarray:
 def targets_multinomial(seed, epoch, j0, n, S) -> np.ndarray:
     T = np.empty(n, np.uint64)
     lib().o_targets_multinomial(seed, epoch, j0, n, S, T)
+    return T
+
+
+def targets_sorted(seed, epoch, j0, n, S) -> np.ndarray:
+    """the n targets of the opt-in "multinomial_sorted" resampler (gpf_oracle.c o_targets_sorted): non-decreasing"""
+    T = np.empty(n, np.uint64)
+    lib().o_targets_sorted(seed, epoch, j0, n, S, T)
     return T
 
 
@@ -284,7 +295,10 @@ class OracleFilter:
 
     def norm_weights(self) -> np.ndarray:
         s = self.summary()
-        return s.q.astype(np.float64) / float(s.S)                  # softmax, utils.jl:103-107
+        if s.uniform:                                               # all -Inf: maximum = -Inf, vs .- maximum = NaN -- the PLAIN softmax
+            return np.full(self.n, np.nan)                          # (utils.jl:103-107); the uniform fallback is safe_softmax's (:123-126)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return s.q.astype(np.float64) / float(s.S)              # softmax, utils.jl:103-107
 
     # -- resample.jl:19-30 dispatcher + :48-175
     def resample(self, method: str = "multinomial", priority_alpha=None, log_priorities=None,
@@ -313,6 +327,9 @@ class OracleFilter:
         epoch = self.epoch
         if method == "multinomial":                                 # :59
             T = targets_multinomial(self.seed, epoch, 0, N, sp.S)
+            anc = upper_bound(sp.cdf, T)
+        elif method == "multinomial_sorted":                        # :59 with the uniforms drawn in sorted order (opt-in)
+            T = targets_sorted(self.seed, epoch, 0, N, sp.S)
             anc = upper_bound(sp.cdf, T)
         elif method == "stratified":                                # :155-170
             if sort_particles:
@@ -613,6 +630,8 @@ class OracleSubState:
         epoch = s.epoch
         if method == "multinomial":
             anc = upper_bound(sp.cdf, targets_multinomial(s.seed, epoch, self.start, N, sp.S))
+        elif method == "multinomial_sorted":                            # (slot ids start, start + 1, ... like the other streams of a view)
+            anc = upper_bound(sp.cdf, targets_sorted(s.seed, epoch, self.start, N, sp.S))
         elif method == "stratified":
             if sort_particles:
                 order = argsort_desc(lp); cdf, S, _, _ = scan(sp.q[order])

@@ -61,3 +61,19 @@ def test_julia_glue_matches_header():
         ja = [a for a in m.group(1).split(",") if a.strip()]
         ha = [a for a in h.group(1).split(",") if a.strip() and a.strip() != "void"]
         assert len(ja) == len(ha), f"{n}: {len(ja)} ccall argument types, {len(ha)} parameters in the header"
+
+
+def test_julia_glue_has_no_shadowed_status_helper():
+    """The resamplers take a keyword called `check` (src/resample.jl:43-46).  A status helper of the same name is shadowed inside those
+    methods (`:warn(s, st)` -> MethodError after the ccall has already mutated the state): the helper is `_status`, no bare `check(`
+    call may remain, and every method with a `check` keyword reports its status through `_status`."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jl = open(os.path.join(root, "julia", "GenParticleFiltersAMD.jl")).read()
+    assert not re.search(r"(?<![\w.:])check\(", jl), "a call of `check(...)`: shadowed wherever a `check=` keyword is in scope"
+    assert "_status(state, st) = st == 0" in jl
+    # every `function ...; check=...)` body that makes a ccall checks its status with _status
+    for m in re.finditer(r"^function (\w+!?)\(([^\n]*(?:\n[^\n]*)?check=[^\n]*)\n(.*?)^end", jl, re.S | re.M):
+        body = m.group(3)
+        if "ccall" in body:
+            assert "_status(" in body, m.group(1)

@@ -365,4 +365,15 @@ def test_norm_weights_with_a_nan_among_finite_weights(g, o):
             assert np.isnan(nw).all() and np.array_equal(nw, orc.norm_weights(), equal_nan=True)
             assert np.isnan(lnw).all() and np.array_equal(lnw, orc.log_norm_weights(), equal_nan=True)
         assert np.isnan(g.get_ess(st)) and np.isnan(g.get_lml_est(st))
+    # all -Inf: get_norm_weights is the PLAIN softmax (utils.jl:103-107): maximum = -Inf, vs .- maximum = NaN -> NaN everywhere; only
+    # safe_softmax inside the resamplers falls back to uniform weights (utils.jl:123-126)
+    lw = np.full(N, -np.inf)
+    st.log_weights = lw; orc.lw = lw.copy()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        nw, lnw = g.get_norm_weights(st), g.get_log_norm_weights(st)
+        assert np.isnan(nw).all() and np.array_equal(nw, orc.norm_weights(), equal_nan=True)
+        assert np.isnan(lnw).all() and np.array_equal(lnw, orc.log_norm_weights(), equal_nan=True)
+    assert np.isnan(g.get_ess(st))
+    g.pf_resample(st, "multinomial", check=False); orc.resample("multinomial", check=False)   # the resampler: uniform fallback
+    assert np.array_equal(st.parents, orc.parents) and (st.log_weights == 0).all()
     st.close()

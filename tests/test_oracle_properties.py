@@ -72,7 +72,8 @@ def test_spec_equals_literal_float64(g, o, lw, seed):
     L.lit_stratified(w, np.arange(N, dtype=np.int64), N, u, par)
     agree = np.mean(f.parents - 1 == par)
     assert agree == 1.0 or agree > 0.98
-    assert abs(f.summary().lse - 0.0) < 1e-300 or True
+    # update_weights! without priorities (resample.jl:195): every log-weight 0.0, so logsumexp = log N
+    assert (f.lw == 0.0).all() and abs(f.summary().lse - np.log(N)) < 1e-12
     np.testing.assert_allclose(make(g, o, lw).summary().lse, L.lit_logsumexp(lw, N), rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(make(g, o, lw).effective_sample_size(), L.lit_ess(lw, N), rtol=1e-6)
 

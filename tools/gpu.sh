@@ -1,0 +1,64 @@
+# tools/gpu.sh -- the ONE script behind this repository's gpurun calls (replaces the per-call gpu_r03*.sh files of round 3).
+#
+#   gpurun --timeout S -- 'bash tools/gpu.sh STEP [STEP ...]'      steps run in order; every output lands under gpurun_out/
+#
+# steps (TAG = $GPF_TAG, default r04):
+#   smoke                 __graft_entry__.smoke()
+#   tests[:EXPR]          pytest -m gpu (optionally -k EXPR) -> gpurun_out/TAG_pytest.log
+#   file:PATH[:EXPR]      pytest -m gpu on one test file
+#   bench[:STEPS]         python bench.py --steps STEPS (default 1000) --warmup 20 -> TAG_bench.json
+#   driver                the driver's own command: python bench.py --gpus 1 --steps 20 --warmup 5 -> TAG_bench_driver_cmd.json
+#   prof                  rocprofv3 --kernel-trace --stats of bench.py (200 steps) -> TAG_kernel_stats.csv
+#   pmc                   FETCH_SIZE / WRITE_SIZE passes of bench.py (one counter per pass) -> TAG_pmc_*.csv (+ tools/pmc_to_json.py TAG)
+#   configs               tools/bench_configs.py (the other BASELINE configs at their per-GPU sizes) -> TAG_configs.jsonl
+#   loop:NAME:ARGS        rocprofv3 kernel stats of `python3 tools/NAME.py ARGS` (ARGS comma-separated) -> TAG_NAME_ARGS_kernel_stats.csv
+#   sq:NAME:ARGS          SQ wait / VALU / LDS counters of the same loop (tools/gpu_pmc_kernels.sh) -> TAG_sq_NAME_ARGS
+#   sharded               one-rank sharded table (tools/sharded_loop.py; no communicator / 1-rank RCCL) -> TAG_sharded_one_rank.txt
+#   variant:OUT:METHOD:DEFS   tools/variant_stats.sh OUT METHOD DEFS (DEFS: comma-separated -D sets, alternating A/B rocprofv3 runs)
+#   py:SCRIPT:ARGS        python3 tools/SCRIPT.py ARGS -> TAG_SCRIPT.txt
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${GPF_TAG:-r04}
+mkdir -p $R/gpurun_out
+export TMPDIR=/tmp
+stats_of() {   # stats_of DIR OUT: copy the kernel-stats csv of a rocprofv3 output directory
+  f=$(find "$1" -name "*kernel_stats.csv" | head -1)
+  if [ -n "$f" ]; then cp "$f" "$2"; head -12 "$f" | cut -c1-170; else echo "no kernel stats under $1"; fi
+}
+for STEP in "$@"; do
+  IFS=: read -r S A1 A2 A3 <<< "$STEP"
+  echo "=== $STEP"
+  cd $R
+  case $S in
+    smoke)   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
+    tests)   timeout 3000 python -m pytest tests -m gpu -q ${A1:+-k "$A1"} > gpurun_out/${TAG}_pytest.log 2>&1; tail -15 gpurun_out/${TAG}_pytest.log | cut -c1-220 ;;
+    file)    timeout 3000 python -m pytest "$A1" -m gpu -x -q ${A2:+-k "$A2"} > gpurun_out/${TAG}_pytest_$(basename $A1 .py).log 2>&1; tail -25 gpurun_out/${TAG}_pytest_$(basename $A1 .py).log | cut -c1-220 ;;
+    bench)   python bench.py --steps ${A1:-1000} --warmup 20 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-3000 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err ;;
+    driver)  python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_cmd.json 2> gpurun_out/${TAG}_bench_driver_cmd.err; cut -c1-600 gpurun_out/${TAG}_bench_driver_cmd.json ;;
+    prof)    cd /tmp; rm -rf $R/gpurun_out/prof_$TAG
+             rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 200 --warmup 10 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof_$TAG.err
+             stats_of $R/gpurun_out/prof_$TAG $R/gpurun_out/${TAG}_kernel_stats.csv; rm -rf $R/gpurun_out/prof_$TAG ;;
+    pmc)     cd /tmp
+             for C in FETCH_SIZE WRITE_SIZE; do
+               rm -rf $R/gpurun_out/pmc_${TAG}_$C
+               rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_${TAG}_$C -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$C.log 2>&1
+               f=$(find $R/gpurun_out/pmc_${TAG}_$C -name "*counter_collection.csv" | head -1)
+               [ -n "$f" ] && cp "$f" $R/gpurun_out/${TAG}_pmc_$C.csv
+               rm -rf $R/gpurun_out/pmc_${TAG}_$C
+             done
+             ls -la $R/gpurun_out/${TAG}_pmc_*.csv ;;   # (then, locally: cp gpurun_out/TAG_pmc_*.csv profiles/ && python tools/pmc_to_json.py TAG)
+    configs) python tools/bench_configs.py > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err; cut -c1-400 gpurun_out/${TAG}_configs.jsonl ;;
+    loop)    cd /tmp; D=$R/gpurun_out/prof_${A1}_${A2//,/_}; rm -rf $D
+             rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/tools/$A1.py ${A2//,/ } > $D.log 2>&1; tail -2 $D.log | cut -c1-200
+             stats_of $D $R/gpurun_out/${TAG}_${A1}_${A2//,/_}_kernel_stats.csv; rm -rf $D ;;
+    sq)      LOOP=$A1.py bash $R/tools/gpu_pmc_kernels.sh ${TAG}_sq_${A1}_${A2//,/_} ${A2//,/ } 2>&1 | tail -40 | cut -c1-200 ;;
+    sharded) OUT=gpurun_out/${TAG}_sharded_one_rank.txt; : > $OUT
+             for M in multinomial stratified residual; do
+               echo -n "$M, no communicator:      " >> $OUT; python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
+               echo -n "$M, 1-rank RCCL, mailbox: " >> $OUT; GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
+             done
+             cat $OUT ;;
+    variant) bash tools/variant_stats.sh gpurun_out/${TAG}_$A1 $A2 ${A3//,/ } 2>&1 | tail -30 | cut -c1-200 ;;
+    py)      python3 tools/$A1.py ${A2//,/ } > gpurun_out/${TAG}_$A1.txt 2> gpurun_out/${TAG}_$A1.err; cut -c1-220 gpurun_out/${TAG}_$A1.txt | tail -40; tail -3 gpurun_out/${TAG}_$A1.err ;;
+    *)       echo "unknown step $S" ;;
+  esac
+done

@@ -4,14 +4,20 @@ import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import gpf_amd as g
-sorted_ = (sys.argv[1] if len(sys.argv) > 1 else "sorted") == "sorted"
+mode = sys.argv[1] if len(sys.argv) > 1 else "sorted"          # sorted | unsorted (stratified) | multinomial_sorted
+sorted_ = mode == "sorted"
 N = 1_000_000
 model = g.models.lgssm2(); ys = g.models.simulate(model, 12)
 st = g.pf_initialize(model, (1,), ys[0], N, seed=1)
+def resample():
+    if mode == "multinomial_sorted":
+        g.pf_resample(st, "multinomial_sorted", check=False)
+    else:
+        g.pf_resample(st, "stratified", check=False, sort_particles=sorted_)
 for t in range(1, 10):
-    g.pf_resample(st, "stratified", check=False, sort_particles=sorted_)
+    resample()
     g.pf_update(st, (t + 1,), (None,), ys[t])
-g.pf_resample(st, "stratified", check=False, sort_particles=sorted_)
+resample()
 st.synchronize()
 lib = C.CDLL(os.environ["GPF_LIB_OVERRIDE"])
 nb = (N + 2047) // 2048
@@ -20,7 +26,7 @@ assert lib.gpf_debug_strat(buf, 8 * 4096) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8)[:nb].astype(np.int64)
 t0 = a[:, 0].min()
 start, pro, sea, end, ncell = (a[:, 0] - t0) / 100.0, (a[:, 1] - a[:, 0]) / 100.0, (a[:, 2] - a[:, 1]) / 100.0, (a[:, 3] - a[:, 2]) / 100.0, a[:, 4]
-print("sorted" if sorted_ else "unsorted", "blocks", nb, "kernel span us", ((a[:, 3] - t0) / 100.0).max())
+print(mode, "blocks", nb, "kernel span us", ((a[:, 3] - t0) / 100.0).max())
 print("start us: max %.2f" % start.max(), " prologue: mean %.2f max %.2f" % (pro.mean(), pro.max()), " search: mean %.2f max %.2f" % (sea.mean(), sea.max()),
       " epilogue: mean %.2f max %.2f" % (end.mean(), end.max()))
 wide = ncell > 8 * 2048
