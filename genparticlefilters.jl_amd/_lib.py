@@ -103,6 +103,7 @@ SYMBOLS = [
     ("gpf_shard_effective_sample_size", C.c_int, [_H, _pd]),
     ("gpf_shard_log_ml_estimate", C.c_int, [_H, _pd]),
     # host-side scalar spec
+    ("gpf_set_lazy_search", C.c_int, [_H, C.c_int32]),
     ("gpf_host_fix_K", C.c_int32, [C.c_int64]),
     ("gpf_host_gamma_E", C.c_int32, [C.c_int64]),
     ("gpf_host_div128", C.c_uint64, [C.c_uint64, C.c_uint64]),

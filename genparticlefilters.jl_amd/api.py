@@ -138,6 +138,12 @@ class DeviceParticleFilterState:
     def synchronize(self):
         self._check(self._L.gpf_synchronize(self._h))
 
+    def set_lazy_search(self, enable: bool = True):
+        """gpf.h gpf_set_lazy_search: pf_resample(state, "multinomial") leaves its ancestor search to the pf_update that follows (one fused
+        kernel); same results, off by default"""
+        self._check(self._L.gpf_set_lazy_search(self._h, int(bool(enable))))
+        return self
+
     # -- fields of ParticleFilterState
     @property
     def log_weights(self) -> np.ndarray:

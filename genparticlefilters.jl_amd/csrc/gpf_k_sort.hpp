@@ -351,6 +351,7 @@ __global__ void k_debug_math(int which, const double* a, const double* b, int64_
             case 4: out[i] = sqrt_(a[i]); break;
             case 5: out[i] = a[i] / b[i]; break;
             case 6: normal2(rng(seed, (uint32_t)a[i], (uint32_t)b[i], epoch, tag), out[i], out2[i]); break;
+            case 7: out[i] = neglog_u52(d2u(a[i])); break;                     // (the argument's BITS are the slot's 64-bit uniform)
             default: out[i] = 0.0;
         }
     }

@@ -17,6 +17,7 @@
 #include "gpf_k_step.hpp"
 #include "gpf_k_scan.hpp"
 #include "gpf_k_search.hpp"
+#include "gpf_k_fused.hpp"
 #include "gpf_k_gather.hpp"
 #include "gpf_k_sort.hpp"
 #include "gpf_k_shard.hpp"

@@ -89,6 +89,11 @@ struct gpf_filter {
     bool raw_q_folded = false;     // sc->raw.Ql folded from blockQ
     bool pending_gather = false;   // a resample left (rows[cur], anc) un-gathered; log-weights are 0
     bool pending_fill = false;     // ... or, after gpf_resample_local, the constant sc->lw_fill
+    // "lazy search" (gpf_k_fused.hpp): pf_resample!(:multinomial) enqueued only the weight scan; the ancestors (h->anc) and the log-ML
+    // update are still to come -- from k_step_search when a plain pf_update! follows, else from finish_search().  Implies pending_gather.
+    bool pending_search = false;
+    SearchArgs pend_sa{};
+    bool lazy_search = false;      // gpf_set_lazy_search (default: GPF_LAZY_SEARCH=1 in the environment, else off)
     // the 16-bit offset levels of the weight channel (k_search_multi / k_push_multi) cost the scan ~1.4 us: only written when a
     // multinomial search will read them
     bool want_offsets = true;      // what the next scan of channel 0 writes
@@ -179,6 +184,7 @@ namespace {
     } while (0)
 
 gpf_status materialize(gpf_filter* h);
+gpf_status finish_search(gpf_filter* h);
 
 gpf_status fail(gpf_handle h, gpf_status s, const std::string& msg)
 {
@@ -348,6 +354,19 @@ void launch_step_t(gpf_filter* h, int grid)
         const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox};
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pc);
+    } else if (h->pending_gather && h->pending_search && PROP == 0) {
+        // the pending multinomial search rides in the propagate (gpf_k_fused.hpp): one 1024-thread workgroup per CU like k_search_multi
+        const MaxSlots ms = next_slots(h);
+        const SearchArgs& sa = h->pend_sa;
+        const int gsr = (int)std::max<int64_t>(1, std::min<int64_t>((sa.n + FCH - 1) / FCH, (int64_t)h->n_cu));
+        const size_t tbytes = (multi_lds_bytes(sa.ntiles, sa.w.logg) + 15) & ~(size_t)15;
+        if (sa.w.logg == 0)
+            GPF_LAUNCH((k_step_search<M, Wc, KEEP, 0>), dim3(gsr), dim3(SBLOCK), tbytes + FUSED_LDS_EXTRA, h->stream, h->args, h->cfg.seed, h->epoch, sa,
+                       h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, (uint32_t)(tbytes / 4));
+        else
+            GPF_LAUNCH((k_step_search<M, Wc, KEEP, 1>), dim3(gsr), dim3(SBLOCK), tbytes + FUSED_LDS_EXTRA, h->stream, h->args, h->cfg.seed, h->epoch, sa,
+                       h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, (uint32_t)(tbytes / 4));
+        h->pending_search = false;
     } else if (h->pending_gather) {
         const MaxSlots ms = next_slots(h);
         PackedCommit pc{};
@@ -481,6 +500,7 @@ gpf_status materialize(gpf_filter* h)
         return GPF_OK;
     }
     if (!h->pending_gather) return GPF_OK;
+    { gpf_status fs = finish_search(h); if (fs) return fs; }         // (a lazy multinomial resample: its ancestors first)
     gpf_status s = timed(h, GPF_K_GATHER, [&] { launch_gather(h, raw_view(h), h->lw); });
     if (s) return s;
     if (h->pending_fill) GPF_LAUNCH(k_fill_from, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->lw, h->n, &h->sc->lw_fill);
@@ -964,6 +984,27 @@ void launch_multinomial_search(gpf_filter* h, const SearchArgs& sa)
     else                GPF_LAUNCH((k_search<0>), dim3(gsr), dim3(SBLOCK), search_lds_bytes(sa.ntiles, 1), h->stream, sa);
 }
 
+// the ancestors of a pending multinomial resample are wanted as an array after all (getters, views, rejuvenation, a second resample,
+// an update that is not the plain propagate): the stand-alone search, as the resample itself would have run it
+gpf_status finish_search(gpf_filter* h)
+{
+    if (!h->pending_search) return GPF_OK;
+    h->pending_search = false;
+    gpf_status s = timed(h, GPF_K_SEARCH, [&] { launch_multinomial_search(h, h->pend_sa); });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+// which models / sizes k_step_search covers: the key-table regime of the search (up to 2.5 M particles)
+bool lazy_search_ok(const gpf_filter* h)
+{
+    const bool off = !h->lazy_search;                            // off by default: no faster than the two kernels (gpf_k_fused.hpp), gpf_set_lazy_search
+    const int logg = multi_logg(h->ntiles);
+    // (the ancestor ring sits behind the key table: both must fit the CU's LDS with the kernel's static words)
+    return !off && !h->parent && !h->hist_on && h->cfg.n_global == h->n && logg >= 0 &&
+           multi_lds_bytes(h->ntiles, logg) + 16 + FUSED_LDS_EXTRA + 1024 <= (size_t)160 * 1024;
+}
+
 gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_particles, int check, int32_t* invalid, bool local = false)
 {
     if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED && method != GPF_RESAMPLE_MULTINOMIAL_SORTED)
@@ -1080,7 +1121,10 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
             }
         });
     };
-    if ((s = search())) return s;
+    // lazy search: a plain multinomial resample of a whole filter leaves its search to the pf_update! that follows (k_step_search)
+    const bool lazy = method == GPF_RESAMPLE_MULTINOMIAL && pv.mode == 0 && !local && lazy_search_ok(h) && sa.w.off16 && sa.w.sample == 0;
+    if (lazy) { h->pend_sa = sa; h->pending_search = true; }
+    else if ((s = search())) return s;
     if (sort_pending) {
         // the scan and the search above ran behind the sort without a host wait; if the finish met a run it could not order (equal
         // or nearly equal priorities) they worked on a wrong order: eight passes over the full key, then both again.  The weight
@@ -1181,6 +1225,7 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "bad device ordinal");
 
     gpf_filter* h = new gpf_filter();
+    h->lazy_search = getenv("GPF_LAZY_SEARCH") && !strcmp(getenv("GPF_LAZY_SEARCH"), "1");
     h->cfg = *cfg;
     h->cfg.params = nullptr;
     for (int i = 0; i < cfg->n_params; ++i) h->args.P[i] = cfg->params[i];
@@ -1295,6 +1340,14 @@ gpf_status gpf_destroy(gpf_handle h)
     return GPF_OK;
 }
 
+gpf_status gpf_set_lazy_search(gpf_handle h, int32_t enable)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (!enable) { gpf_status s = finish_search(h); if (s) return s; }
+    h->lazy_search = enable != 0;
+    return GPF_OK;
+}
+
 gpf_status gpf_synchronize(gpf_handle h)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
@@ -1323,7 +1376,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
         else                { DISPATCH_MODEL(h, (launch_init_t<MM, 0>(h, grid))); }
     });
     if (s) return s;
-    h->pending_gather = false; h->pending_fill = false;
+    h->pending_gather = false; h->pending_fill = false; h->pending_search = false;
     h->pending_packed = false;
     h->max_valid = true;
     GPF_LAUNCH(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
@@ -1361,6 +1414,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
     if ((s = set_obs(h, obs, n_obs))) return s;
     h->blk_obs_size = 0;                                         // one observation for all particles again
     if ((s = hist_begin_step(h, false))) return s;
+    if (prop != 0 && (s = finish_search(h))) return s;           // (only the plain propagate carries a pending search)
     const int grid = step_grid(h);
     const bool keep = h->cfg.keep_prev != 0;
     s = timed(h, GPF_K_STEP, [&] {
@@ -1616,7 +1670,7 @@ gpf_status gpf_initialize_blocks(gpf_handle h, const double* obs, int32_t n_obs,
     const int grid = step_grid(h);
     s = timed(h, GPF_K_STEP, [&] { DISPATCH_MODEL(h, (launch_init_blk<MM>(h, grid))); });
     if (s) return s;
-    h->pending_gather = false; h->pending_fill = false; h->pending_packed = false;
+    h->pending_gather = false; h->pending_fill = false; h->pending_packed = false; h->pending_search = false;
     h->max_valid = true;
     GPF_LAUNCH(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
     HIP_TRY(h, hipMemsetAsync(&h->sc->lml_est, 0, sizeof(double), h->stream));
@@ -1747,6 +1801,7 @@ static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters,
     if (n_iters < 0) return fail(h, GPF_ERR_INVALID_ARGUMENT, "n_iters < 0");
     if (h->pending_packed && (s = materialize(h))) return s;     // sharded deferred commit: scatter first
     if (h->pending_fill && (s = materialize(h))) return s;       // (the move kernel's fused gather assumes incoming weights 0)
+    if ((s = finish_search(h))) return s;                        // (a lazy multinomial resample: the move kernel reads the ancestor array)
     const bool fused_gather = h->pending_gather;                 // a pending resample gather rides on the move kernel
     const int grid = move_grid(h);
     s = timed(h, GPF_K_MOVE, [&] {
@@ -1866,6 +1921,7 @@ gpf_status gpf_get_parents(gpf_handle h, int64_t* out, int64_t n)
     if (s0) return s0;
     if (!out || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad output array");
     if (h->pending_packed) { gpf_status s = materialize(h); if (s) return s; }   // a deferred sharded commit also carries the parents
+    { gpf_status s = finish_search(h); if (s) return s; }                         // a lazy multinomial resample: its ancestors now
     GPF_LAUNCH(k_parents, dim3(grid_for(h, h->n, 8)), dim3(BLOCK), 0, h->stream, h->anc, h->n, reinterpret_cast<int64_t*>(h->dtmp));
     return copy_out(h, h->dtmp, out, (size_t)n * sizeof(int64_t));
 }
@@ -2158,7 +2214,7 @@ static void set_count(gpf_filter* h, int64_t n_new)
     if (h->blk_obs_size != 0) h->blk_obs_size = -1;              // per-block observations do not survive a change of the particle count
     h->blk_last = 0;
     h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false; h->pending_gather = false; h->pending_fill = false;
-    h->pending_packed = false;
+    h->pending_packed = false; h->pending_search = false;
 }
 
 gpf_status gpf_n_particles(gpf_handle h, int64_t* out)
@@ -3274,6 +3330,7 @@ void gpf_host_math(int32_t which, const double* a, const double* b, int64_t n, d
             case 3: out[i] = atan2_(a[i], b[i]); break;
             case 4: out[i] = sqrt_(a[i]); break;
             case 5: out[i] = a[i] / b[i]; break;
+            case 7: out[i] = neglog_u52(d2u(a[i])); break;
             default: out[i] = 0.0;
         }
     }

@@ -200,6 +200,12 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
 typedef enum { GPF_MOVE_PROPOSAL_LOCALLY_OPTIMAL = 1, GPF_MOVE_PROPOSAL_LINE_OUTLIER = 2 } gpf_move_proposal;
 gpf_status gpf_rejuvenate_proposal(gpf_handle h, int32_t proposal, const double* params, int32_t n_params, int32_t n_iters);
 
+/* "Lazy search" (csrc/gpf_k_fused.hpp): with enable != 0 a plain pf_resample!(state, :multinomial) enqueues the weight scan
+ * only and the pf_update! that follows finds the ancestors, gathers, propagates and writes state.parents in ONE kernel; any other consumer
+ * runs the stand-alone search first.  Same results bit for bit.  OFF by default (GPF_LAZY_SEARCH=1 in the environment turns it on for new
+ * handles): measured on MI355X it is no faster than the two kernels (profiles/r04_lazy_search.txt). */
+gpf_status gpf_set_lazy_search(gpf_handle h, int32_t enable);
+
 /* ---- weight summaries ---------------------------------------------------------------------- */
 /* effective_sample_size(state) / get_ess                            src/utils.jl:163-164,171 */
 gpf_status gpf_effective_sample_size(gpf_handle h, double* out);
@@ -243,7 +249,8 @@ gpf_status gpf_kernel_time(gpf_handle h, int32_t id, double* total_ms, int64_t* 
 
 /* device-side math spec, for the bitwise host/device parity tests (tests/test_math_parity.py):
  * which: 0 exp, 1 log, 2 sincos2pi (out=sin,out2=cos), 3 atan2(a,b), 4 sqrt, 5 a/b,
- *        6 normal2 from counters (a=gid as double, b=blk as double; seed/epoch/tag via the handle) */
+ *        6 normal2 from counters (a=gid as double, b=blk as double; seed/epoch/tag via the handle),
+ *        7 the spacing logarithm of GPF_RESAMPLE_MULTINOMIAL_SORTED: -log((k + 1/2) 2^-52), k = the top 52 bits of a's BIT PATTERN */
 gpf_status gpf_debug_math(gpf_handle h, int32_t which, const double* a, const double* b, int64_t n,
                           double* out, double* out2);
 
@@ -412,7 +419,7 @@ gpf_status gpf_shard_log_ml_estimate(gpf_handle h, double* out);
  * 4 16-bit in-group offsets (u16 per padded cell), 5 coarse offset rows (u16).  *n_bytes: capacity in, bytes written out. */
 gpf_status gpf_debug_levels(gpf_handle h, int32_t which, void* out, int64_t* n_bytes);
 
-/* host twin of gpf_debug_math (which = 0..5) */
+/* host twin of gpf_debug_math (which = 0..5, 7) */
 void    gpf_host_math(int32_t which, const double* a, const double* b, int64_t n, double* out, double* out2);
 
 #ifdef __cplusplus

@@ -129,6 +129,12 @@ function _resample!(state, method::Int, priority_fn, check_kw, sort_particles::B
     return state
 end
 
+"opt-in: pf_resample!(state, :multinomial) leaves its ancestor search to the pf_update! that follows (one fused kernel; gpf.h gpf_set_lazy_search)"
+set_lazy_search!(s::DeviceParticleFilterState, enable::Bool=true) =
+    (_status(s, ccall((:gpf_set_lazy_search, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, enable ? 1 : 0)); s)
+"opt-in extension (gpf.h GPF_RESAMPLE_MULTINOMIAL_SORTED): multinomial resampling with the uniforms drawn already sorted -- state.parents non-decreasing"
+pf_multinomial_sorted_resample!(s::DeviceParticleFilterState; priority_fn=nothing, check=:warn) = _resample!(s, 4, priority_fn, check, true)
+
 # src/resample.jl:48-65, 85-120, 143-175, 19-30
 pf_multinomial_resample!(s::DeviceParticleFilterState; priority_fn=nothing, check=:warn) = _resample!(s, 0, priority_fn, check, true)
 pf_residual_resample!(s::DeviceParticleFilterState; priority_fn=nothing, check=:warn) = _resample!(s, 1, priority_fn, check, true)
@@ -138,6 +144,7 @@ function pf_resample!(s::DeviceParticleFilterState, method::Symbol=:multinomial;
     method == :multinomial && return pf_multinomial_resample!(s; kwargs...)
     method == :residual && return pf_residual_resample!(s; kwargs...)
     method == :stratified && return pf_stratified_resample!(s; kwargs...)
+    method == :multinomial_sorted && return pf_multinomial_sorted_resample!(s; kwargs...)      # (extension)
     error("Resampling method $method not recognized.")
 end
 

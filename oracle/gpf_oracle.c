@@ -89,6 +89,7 @@ O_EXPORT void o_math_vec(int which, const double *a, const double *b, int64_t n,
             case 3: out[i] = o_atan2(a[i], b[i]); break;
             case 4: out[i] = sqrt(a[i]); break;
             case 5: out[i] = a[i] / b[i]; break;
+            case 7: out[i] = o_neglog_u52(o_d2u(a[i])); break;            /* the argument's BITS are the slot's 64-bit uniform */
             default: out[i] = 0.0;
         }
     }
@@ -610,7 +611,7 @@ O_EXPORT void o_targets_stratified(uint64_t seed, uint32_t epoch, int64_t j0, in
  * inside their tile:
  *     G_t   = trunc(gamma(c_t [+ 1 for the last tile: the (N+1)-th spacing]) 2^Eg),  Gtot = sum G_t + 1
  *     Vlo_t = floor((G_0 + ... + G_{t-1}) 2^64 / Gtot)
- *     e_i   = trunc(-log(u_i) 2^44),  u_i the 52-bit uniform of resample slot j0 + i;  p_j = sum of the e_i of the tile up to slot j;
+ *     e_i   = trunc(neglog(u_i) 2^44),  u_i the 52-bit uniform of resample slot j0 + i, neglog = -log to ~6e-12 (o_neglog_u52);  p_j = sum of the e_i of the tile up to slot j;
  *     s_t   = the tile's sum + 1 (the last tile: + e_N)
  *     Tlo_t = floor(Vlo_t S / 2^64)  (the multinomial target formula on the tile's first uniform),  Tw_t = Tlo_{t+1} - Tlo_t
  *     T_j   = Tlo_t + min(Tw_t, trunc(fl(fl(p_j) fl(1 / fl(s_t))) fl(Tw_t)))      (fl: round to Float64)  */
@@ -646,8 +647,7 @@ static uint64_t o_gamma_tile(uint64_t seed, uint32_t gid, uint32_t epoch, int64_
 static inline uint64_t o_spacing(uint64_t seed, uint32_t slot, uint32_t epoch)
 {
     const uint64_t U = o_resample_u64(seed, slot, epoch);
-    const double u = o_u52((uint32_t)(U >> 32), (uint32_t)U);
-    return (uint64_t)(-o_log(u) * o_u2d((uint64_t)(O_SP_E + 1023) << 52));      /* exact scaling by 2^E; truncation = floor */
+    return (uint64_t)(o_neglog_u52(U) * o_u2d((uint64_t)(O_SP_E + 1023) << 52));      /* exact scaling by 2^E; truncation = floor */
 }
 O_EXPORT uint64_t o_spacing_d(uint64_t seed, uint32_t slot, uint32_t epoch) { return o_spacing(seed, slot, epoch); }
 O_EXPORT uint64_t o_gamma_tile_d(uint64_t seed, uint32_t gid, uint32_t epoch, int64_t shape, int32_t Eg) { return o_gamma_tile(seed, gid, epoch, shape, Eg); }

@@ -215,6 +215,59 @@ static inline void o_normal2(o_philox_t b, double *z0, double *z1)
     *z0 = r * c; *z1 = r * s;
 }
 
+/* ---------------------------------------------------------------- spacing logarithm (multinomial_sorted) */
+/* -log of the slot's 52-bit uniform u = (k + 1/2) 2^-52, to ~6e-12 absolute (tools/derive_splog.py): (2k + 1) = m 2^e, m in [1, 2);
+ * i = the mantissa's top 6 bits; ln m = O_SP_LN[i] + log1p(r), r = m O_SP_INV[i] - 1 (|r| < 2^-7: four terms of the series);
+ * -ln u = (53 - e) ln 2 - ln m, clamped at 0. */
+static const double O_SP_INV[64] = {
+    0x1.fc07f01fc07f0p-1, 0x1.f44659e4a4271p-1, 0x1.ecc07b301ecc0p-1, 0x1.e573ac901e574p-1,
+    0x1.de5d6e3f8868ap-1, 0x1.d77b654b82c34p-1, 0x1.d0cb58f6ec074p-1, 0x1.ca4b3055ee191p-1,
+    0x1.c3f8f01c3f8f0p-1, 0x1.bdd2b899406f7p-1, 0x1.b7d6c3dda338bp-1, 0x1.b2036406c80d9p-1,
+    0x1.ac5701ac5701bp-1, 0x1.a6d01a6d01a6dp-1, 0x1.a16d3f97a4b02p-1, 0x1.9c2d14ee4a102p-1,
+    0x1.970e4f80cb872p-1, 0x1.920fb49d0e229p-1, 0x1.8d3018d3018d3p-1, 0x1.886e5f0abb04ap-1,
+    0x1.83c977ab2beddp-1, 0x1.7f405fd017f40p-1, 0x1.7ad2208e0ecc3p-1, 0x1.767dce434a9b1p-1,
+    0x1.724287f46debcp-1, 0x1.6e1f76b4337c7p-1, 0x1.6a13cd1537290p-1, 0x1.661ec6a5122f9p-1,
+    0x1.623fa77016240p-1, 0x1.5e75bb8d015e7p-1, 0x1.5ac056b015ac0p-1, 0x1.571ed3c506b3ap-1,
+    0x1.5390948f40febp-1, 0x1.5015015015015p-1, 0x1.4cab88725af6ep-1, 0x1.49539e3b2d067p-1,
+    0x1.460cbc7f5cf9ap-1, 0x1.42d6625d51f87p-1, 0x1.3fb013fb013fbp-1, 0x1.3c995a47babe7p-1,
+    0x1.3991c2c187f63p-1, 0x1.3698df3de0748p-1, 0x1.33ae45b57bcb2p-1, 0x1.30d190130d190p-1,
+    0x1.2e025c04b8097p-1, 0x1.2b404ad012b40p-1, 0x1.288b01288b013p-1, 0x1.25e22708092f1p-1,
+    0x1.23456789abcdfp-1, 0x1.20b470c67c0d9p-1, 0x1.1e2ef3b3fb874p-1, 0x1.1bb4a4046ed29p-1,
+    0x1.19453808ca29cp-1, 0x1.16e0689427379p-1, 0x1.1485f0e0acd3bp-1, 0x1.12358e75d3033p-1,
+    0x1.0fef010fef011p-1, 0x1.0db20a88f4696p-1, 0x1.0b7e6ec259dc8p-1, 0x1.0953f39010954p-1,
+    0x1.073260a47f7c6p-1, 0x1.05197f7d73404p-1, 0x1.03091b51f5e1ap-1, 0x1.0101010101010p-1,
+};
+static const double O_SP_LN[64] = {
+    0x1.fe02a6b106799p-8, 0x1.7b91b07d5b126p-6, 0x1.39e87b9febd68p-5, 0x1.b42dd711971b9p-5,
+    0x1.16536eea37ae3p-4, 0x1.51b073f06183cp-4, 0x1.8c345d6319b23p-4, 0x1.c5e548f5bc743p-4,
+    0x1.fec9131dbeabcp-4, 0x1.1b72ad52f67a2p-3, 0x1.371fc201e8f75p-3, 0x1.526e5e3a1b438p-3,
+    0x1.6d60fe719d21bp-3, 0x1.87fa06520c911p-3, 0x1.a23bc1fe2b561p-3, 0x1.bc286742d8cd4p-3,
+    0x1.d5c216b4fbb94p-3, 0x1.ef0adcbdc5935p-3, 0x1.0402594b4d041p-2, 0x1.1058bf9ae4ad4p-2,
+    0x1.1c898c16999fbp-2, 0x1.2895a13de86a4p-2, 0x1.347dd9a987d56p-2, 0x1.404308686a7e4p-2,
+    0x1.4be5f957778a1p-2, 0x1.5767717455a6cp-2, 0x1.62c82f2b9c796p-2, 0x1.6e08eaa2ba1e4p-2,
+    0x1.792a55fdd47a1p-2, 0x1.842d1da1e8b18p-2, 0x1.8f11e873662c8p-2, 0x1.99d958117e08ap-2,
+    0x1.a484090e5bb09p-2, 0x1.af1293247786bp-2, 0x1.b9858969310fdp-2, 0x1.c3dd7a7cdad4dp-2,
+    0x1.ce1af0b85f3ecp-2, 0x1.d83e7258a2f3ep-2, 0x1.e24881a7c6c26p-2, 0x1.ec399d2468cc1p-2,
+    0x1.f6123fa7028adp-2, 0x1.ffd2e0857f497p-2, 0x1.04bdf9da926d2p-1, 0x1.0986f4f573521p-1,
+    0x1.0e44985d1cc8cp-1, 0x1.12f719593efbdp-1, 0x1.179eabbd899a0p-1, 0x1.1c3b81f713c25p-1,
+    0x1.20cdcd192ab6ep-1, 0x1.2555bce98f7cap-1, 0x1.29d37fec2b08bp-1, 0x1.2e47436e40268p-1,
+    0x1.32b1339121d71p-1, 0x1.37117b54747b6p-1, 0x1.3b68449fffc23p-1, 0x1.3fb5b84d16f43p-1,
+    0x1.43f9fe2f9ce67p-1, 0x1.48353d1ea88dfp-1, 0x1.4c679afccee39p-1, 0x1.50913cc01686bp-1,
+    0x1.54b2467999498p-1, 0x1.58cadb5cd7989p-1, 0x1.5cdb1dc6c1765p-1, 0x1.60e32f44788d9p-1,
+};
+static inline double o_neglog_u52(uint64_t U)
+{
+    const uint64_t bits = o_d2u((double)(((U >> 12) << 1) | 1ull));
+    const int e = (int)(bits >> 52) - 1023;
+    const uint64_t mb = bits & 0x000FFFFFFFFFFFFFull;
+    const double m = o_u2d(mb | 0x3FF0000000000000ull);
+    const int i = (int)(mb >> 46);
+    const double r = m * O_SP_INV[i] - 1.0;
+    const double p = r * (1.0 - r * (0.5 - r * (1.0 / 3.0 - r * 0.25)));
+    const double v = (double)(53 - e) * 0x1.62e42fefa39efp-1 - (O_SP_LN[i] + p);
+    return v > 0.0 ? v : 0.0;
+}
+
 /* ---------------------------------------------------------------- atan2 */
 static inline double o_atan_small(double x)  /* |x| <= tan(pi/8)(1+1e-4) */
 {

@@ -106,7 +106,9 @@ def test_bench_main_prints_one_json_line(argv, o, built, monkeypatch):
     assert r["traffic_source"] is not None and (r["traffic"] is None) == isinstance(r["traffic_source"], str)   # a figure only with its provenance
     c = out["cpu_baseline"]
     assert c is not None and c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["sample"]
-    assert set(out["resample_gather_kernel"]) == {"multinomial", "stratified"}
+    assert set(out["resample_gather_kernel"]) == {"multinomial", "multinomial_sorted", "stratified"}
+    sv = out["multinomial_sorted_variant"]                          # the opt-in sorted multinomial as a named variant beside the unchanged headline
+    assert sv is not None and sv["value"] > 0 and "multinomial_sorted" in sv["workload"] and "configs[1]" in out["config"]["workload"]
     assert np.isfinite(out["log_ml_estimate"]) and np.isfinite(out["log_ml_abs_error"])
 
 
