@@ -72,6 +72,7 @@ SYMBOLS = [
     ("gpf_debug_levels", C.c_int, [_H, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]),
     ("gpf_view_create", C.c_int, [_H, C.c_int64, C.c_int64, C.POINTER(_H)]),
     ("gpf_view_create_strided", C.c_int, [_H, C.c_int64, C.c_int64, C.c_int64, C.POINTER(_H)]),
+    ("gpf_view_create_indexed", C.c_int, [_H, C.POINTER(C.c_int64), C.c_int64, C.POINTER(_H)]),
     ("gpf_n_particles", C.c_int, [_H, _pi64]),
     ("gpf_resize", C.c_int, [_H, C.c_int64, C.c_int32, C.c_double, C.c_int32, _pi32]),
     ("gpf_replicate", C.c_int, [_H, C.c_int32, C.c_int32]),

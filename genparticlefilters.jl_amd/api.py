@@ -103,15 +103,25 @@ class DeviceParticleFilterState:
         if history:                      # trajectory store for `history` time steps (persistent-trace queries)
             self._check(self._L.gpf_history_enable(self._h, int(history)))
 
-    # -- state[idxs] / view(state, idxs): a sub-state over a range start:step:stop (src/view.jl:35-48; the reference's tests use
-    #    contiguous and strided ranges, state[1:50], state[k:5:100]).  0-based half-open Python slices / ranges.
+    # -- state[idxs] / view(state, idxs): a sub-state over a range start:step:stop or over ANY vector of distinct indices
+    #    (src/view.jl:35-48 takes `idxs::AbstractVector`; the reference's tests use contiguous and strided ranges, state[1:50],
+    #    state[k:5:100]).  0-based half-open Python slices / ranges, or a list / NumPy array of 0-based indices.
     def __getitem__(self, idx):
         if isinstance(idx, slice):
             start, stop, step = idx.indices(self.n_particles)
         elif isinstance(idx, range):
             start, stop, step = idx.start, idx.stop, idx.step
+        elif isinstance(idx, (list, tuple, np.ndarray)):
+            ix = np.asarray(idx)
+            if ix.dtype == bool:                                    # state[mask], like Julia's logical indexing
+                if ix.shape != (self.n_particles,):
+                    raise ErrorException("a boolean index must have one entry per particle")
+                ix = np.flatnonzero(ix)
+            if ix.ndim != 1 or ix.size == 0 or not np.issubdtype(ix.dtype, np.integer):
+                raise ErrorException("device sub-states over an index vector need a non-empty 1-D integer array")
+            return DeviceParticleFilterSubState(self, int(ix[0]), ix.size, 0, index=np.ascontiguousarray(ix, np.int64))
         else:
-            raise TypeError("device sub-states cover ranges: use state[a:b] or state[a:b:step]")
+            raise TypeError("device sub-states: use state[a:b], state[a:b:step] or state[index_vector]")
         if step < 1 or stop <= start:
             raise ErrorException("device sub-states cover non-empty ranges with a positive step")
         return DeviceParticleFilterSubState(self, start, (stop - start + step - 1) // step, step)
@@ -212,14 +222,18 @@ class DeviceParticleFilterSubState(DeviceParticleFilterState):
     accepts it, with the reference's sub-state semantics (local parents, no log-ML update on resampling, weights reset to
     the block average, log_ml_estimate relative to the source's running estimate)."""
 
-    def __init__(self, source: DeviceParticleFilterState, start: int, count: int, step: int = 1):
+    def __init__(self, source: DeviceParticleFilterState, start: int, count: int, step: int = 1, index=None):
         self.source = source                     # keeps the parent alive
         self.start, self.step = int(start), int(step)
+        self.index = index                       # state[idxs] over an arbitrary index vector (step == 0)
         self._L = source._L
         self.model, self.seed, self.keep_prev = source.model, source.seed, source.keep_prev
         self.n_particles, self.dim, self.row_width = int(count), source.dim, source.row_width
         self._h = C.c_void_p()
-        st = self._L.gpf_view_create_strided(source._h, int(start), int(step), int(count), C.byref(self._h))
+        if index is not None:
+            st = self._L.gpf_view_create_indexed(source._h, index.ctypes.data_as(C.POINTER(C.c_int64)), int(count), C.byref(self._h))
+        else:
+            st = self._L.gpf_view_create_strided(source._h, int(start), int(step), int(count), C.byref(self._h))
         if st != _lib.OK:
             self._h = None
             raise ErrorException(self._L.gpf_last_error(source._h).decode())
@@ -330,7 +344,7 @@ def _resample(state, method_id: int, priority_fn, check, sort_particles: bool):
     inv = C.c_int32(0)
     inv_ptr = C.byref(inv) if check_id != 0 else None          # check=false: fully asynchronous
     err_handle = state._h
-    if (priority_fn is None and isinstance(state, DeviceParticleFilterSubState) and state.start == 0
+    if (priority_fn is None and isinstance(state, DeviceParticleFilterSubState) and state.start == 0 and state.index is None
             and state.n_particles == state.source.n_particles and os.environ.get("GPF_VIEW_RESAMPLE") != "eager"):
         # pf_resample!(state[1:end], ...): the library resamples the whole filter with the sub-state semantics itself
         # (gpf_resample_local: same result, no eager gather, no copies through the view handle)

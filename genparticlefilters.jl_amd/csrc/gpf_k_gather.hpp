@@ -115,6 +115,27 @@ __global__ __launch_bounds__(BLOCK) void k_view_strided_copy(double* __restrict_
     }
 }
 
+// state[idxs] for an arbitrary vector of distinct indices (src/view.jl:35-48): the same compact-copy mechanism with an index array
+__global__ __launch_bounds__(BLOCK) void k_view_index_copy(double* __restrict__ prow, double* __restrict__ plw, int32_t* __restrict__ panc,
+                                                           double* __restrict__ vrow, double* __restrict__ vlw, int32_t* __restrict__ vanc,
+                                                           int W, const int32_t* __restrict__ idx, int64_t n, int to_view)
+{
+    const int C = W / 2;
+    const int64_t total = n * C;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t j = t / C;
+        const int c = (int)(t - j * C);
+        const int64_t pj = idx[j];
+        double2* pp = reinterpret_cast<double2*>(prow) + pj * C + c;
+        double2* vp = reinterpret_cast<double2*>(vrow) + t;
+        if (to_view) *vp = *pp; else *pp = *vp;
+        if (c == 0) {
+            if (to_view) { vlw[j] = plw[pj]; vanc[j] = panc[pj]; }
+            else { plw[pj] = vlw[j]; panc[pj] = vanc[j]; }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- small utilities
 __global__ void k_iota(int32_t* v, int64_t n)
 {

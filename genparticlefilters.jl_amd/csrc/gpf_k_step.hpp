@@ -38,7 +38,7 @@ __device__ __forceinline__ int stratum_of(const ModelArgs& a, uint64_t seed, uin
 {
     const int64_t K = a.n_strata, B = n / K;
     if (i < K * B) return (int)(a.interleaved ? i % K : i / B);
-    const Philox b = rng(seed, (uint32_t)(gid0 + i * a.gstride), (uint32_t)Mo::NBLK, epoch, tag);
+    const Philox b = rng(seed, particle_gid(a, gid0, i), (uint32_t)Mo::NBLK, epoch, tag);
     return (int)mulhi64(u64(b.w0, b.w1), (uint64_t)K);
 }
 
@@ -57,16 +57,16 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
         double x[MAX_DIM];
         double ll;
         const double* const ob = obs_of<BLK>(a, i);
-        if constexpr (MODE == 1) ll = Mo::propose(a.P, true, nullptr, ob, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
+        if constexpr (MODE == 1) ll = Mo::propose(a.P, true, nullptr, ob, seed, particle_gid(a, gid0, i), 0, epoch, TAG_INIT, x);
         else if constexpr (MODE == 2) {
             const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
-            const double lp = Mo::sample_stratum(a.P, true, nullptr, ob, v, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
+            const double lp = Mo::sample_stratum(a.P, true, nullptr, ob, v, seed, particle_gid(a, gid0, i), 0, epoch, TAG_INIT, x);
             ll = (lp + Mo::loglik(a.P, x, ob)) + a.logK;                      // initialize.jl:103-104
         } else if constexpr (MODE == 3) {                                        // strata + native proposal, initialize.jl:122-126
             const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
             ll = Mo::propose_stratum(a.P, ob, v, x) + a.logK;
         } else {
-            Mo::sample(a.P, true, nullptr, ob, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_INIT, x);
+            Mo::sample(a.P, true, nullptr, ob, seed, particle_gid(a, gid0, i), 0, epoch, TAG_INIT, x);
             ll = Mo::loglik(a.P, x, ob);
         }
         double* r = rows + i * W;
@@ -134,13 +134,13 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
         double xn[MAX_DIM];
         double ll;
         const double* const ob = obs_of<BLK>(a, i);
-        if constexpr (MODE == 1) ll = Mo::propose(a.P, false, r, ob, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
+        if constexpr (MODE == 1) ll = Mo::propose(a.P, false, r, ob, seed, particle_gid(a, gid0, i), 0, epoch, TAG_UPDATE, xn);
         else if constexpr (MODE == 2) {
             const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_UPDATE)];
-            const double lp = Mo::sample_stratum(a.P, false, r, ob, v, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
+            const double lp = Mo::sample_stratum(a.P, false, r, ob, v, seed, particle_gid(a, gid0, i), 0, epoch, TAG_UPDATE, xn);
             ll = (lp + Mo::loglik(a.P, xn, ob)) + a.logK;                     // update.jl:201-206
         } else {
-            Mo::sample(a.P, false, r, ob, seed, (uint32_t)(gid0 + i * a.gstride), 0, epoch, TAG_UPDATE, xn);
+            Mo::sample(a.P, false, r, ob, seed, particle_gid(a, gid0, i), 0, epoch, TAG_UPDATE, xn);
             ll = Mo::loglik(a.P, xn, ob);
         }
         double o[W];
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
         const int iters = live ? n_iters : 0;
         double llx = Mo::loglik(a.P, x, ob);
         double wsum = 0.0;
-        const uint32_t gid = (uint32_t)(gid0 + i * a.gstride);
+        const uint32_t gid = particle_gid(a, gid0, i);
         for (int it = 0; it < iters; ++it) {
             if constexpr (PROP) {
                 if constexpr (Mo::HAS_MOVE_PROPOSAL) {

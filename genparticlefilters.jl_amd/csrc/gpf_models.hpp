@@ -30,6 +30,9 @@ struct ModelArgs {          // passed by value in the kernarg segment: no device
     // strided sub-state views (reference src/view.jl:35-48 with idxs = start:step:stop): local particle i is particle
     // gid0 + i * gstride of the filter and keeps THAT id as its RNG counter (1 everywhere else)
     int32_t gstride, pad_;
+    // views over an arbitrary index vector (state[idxs], src/view.jl:35-48): local particle i is particle gid0 + gid_map[i] (gid_map[i] =
+    // idxs[i] - idxs[0], device array), nullptr everywhere else
+    const int32_t* gid_map;
     double q[4];                 // parameters of a native MOVE proposal (gpf_rejuvenate_proposal), e.g. {p, log p, log(1 - p)}
     // block-wise operations (many small filters in one state, gpf_update_blocks & co.): particle i belongs to block i / blk_size and
     // sees that block's observation blk_obs[block][MAX_OBS]; blk_mask (rejuvenation): bit 0 of word [block] = the block takes part
@@ -41,6 +44,12 @@ __device__ __forceinline__ const double* obs_of(const ModelArgs& a, int64_t i)
 {
     if constexpr (BLK) return a.blk_obs + (size_t)((uint32_t)i / (uint32_t)a.blk_size) * MAX_OBS;
     else return a.obs;
+}
+
+// the RNG counter of local particle i: its id in the whole filter
+__device__ __forceinline__ uint32_t particle_gid(const ModelArgs& a, int64_t gid0, int64_t i)
+{
+    return a.gid_map ? (uint32_t)(gid0 + (int64_t)a.gid_map[i]) : (uint32_t)(gid0 + i * a.gstride);
 }
 
 template <int M> struct Model;

@@ -115,6 +115,7 @@ struct gpf_filter {
     int64_t view_start = 0;
     int64_t view_step = 1;               // > 1: strided view (state[start:step:stop]); works on the compact copies below
     double* vrows[2] = {nullptr, nullptr}; double* vlw = nullptr; int32_t* vanc = nullptr;
+    int32_t* vidx = nullptr; int32_t* vgid = nullptr;   // view over an index vector (view_step == 0): the particles' indices in the parent, and idx - idx[0] (ModelArgs::gid_map)
     uint64_t generation = 0;             // bumped when the per-particle buffers are reallocated (views check it)
     uint64_t parent_generation = 0;
     uint64_t mutations = 0;              // bumped by every change of the rows / log-weights of this filter (through any handle)
@@ -720,6 +721,10 @@ gpf_status view_enter(gpf_filter* v)
         v->anc = p->anc + o;
     } else {                                                     // strided: a compact copy of particles o + i * step
         v->rows[0] = v->vrows[0]; v->rows[1] = v->vrows[1]; v->lw = v->vlw; v->anc = v->vanc;
+        if (v->view_step == 0)                                   // state[idxs]: an arbitrary index vector
+            GPF_LAUNCH(k_view_index_copy, dim3(grid_for(v, v->n * (v->W / 2), 8)), dim3(BLOCK), 0, v->stream, p->rows[p->cur], p->lw, p->anc,
+                       v->vrows[0], v->vlw, v->vanc, v->W, v->vidx, v->n, 1);
+        else
         GPF_LAUNCH(k_view_strided_copy, dim3(grid_for(v, v->n * (v->W / 2), 8)), dim3(BLOCK), 0, v->stream, p->rows[p->cur] + o * v->W, p->lw + o, p->anc + o,
                    v->vrows[0], v->vlw, v->vanc, v->W, v->view_step, v->n, 1);
         HIP_TRY(v, hipGetLastError());
@@ -741,6 +746,10 @@ gpf_status view_exit(gpf_filter* v)
     gpf_filter* p = v->parent;
     if (v->view_step != 1) {                                     // strided: scatter the compact copy back into the source
         const int64_t o = v->view_start;
+        if (v->view_step == 0)
+            GPF_LAUNCH(k_view_index_copy, dim3(grid_for(v, v->n * (v->W / 2), 8)), dim3(BLOCK), 0, v->stream, p->rows[p->cur], p->lw, p->anc,
+                       v->rows[v->cur], v->vlw, v->vanc, v->W, v->vidx, v->n, 0);
+        else
         GPF_LAUNCH(k_view_strided_copy, dim3(grid_for(v, v->n * (v->W / 2), 8)), dim3(BLOCK), 0, v->stream, p->rows[p->cur] + o * v->W, p->lw + o, p->anc + o,
                    v->rows[v->cur], v->vlw, v->vanc, v->W, v->view_step, v->n, 0);
         HIP_TRY(v, hipGetLastError());
@@ -1318,7 +1327,7 @@ gpf_status gpf_destroy(gpf_handle h)
     hist_clear(h);
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
     if (h->parent) { h->rows[0] = h->rows[1] = nullptr; h->lw = nullptr; h->anc = nullptr; }   // aliases of the parent's buffers (or of the compact copies below)
-    for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc}) if (q) (void)hipFree(q);
+    for (void* q : {(void*)h->vrows[0], (void*)h->vrows[1], (void*)h->vlw, (void*)h->vanc, (void*)h->vidx, (void*)h->vgid}) if (q) (void)hipFree(q);
     { Bufs b = take_particle_buffers(h); free_bufs(b); }
     void* bufs[] = {h->mslots[0], h->mslots[1], h->blockQ, h->partial, h->dscal, h->sc, h->push_stage, h->shard_counts, h->shard_plan, h->tree_buf, h->acc_part,
                     h->pull_req, h->pull_counts, h->pull_pc, h->pull_pc_all, h->blk_words, h->blk_mask, h->blk_stats, h->blk_obs};
@@ -2129,16 +2138,35 @@ gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_
     return gpf_view_create_strided(parent, start, 1, count, out);
 }
 
+static gpf_status view_create_impl(gpf_handle parent, int64_t start, int64_t step, int64_t count, const int64_t* index, gpf_handle* out);
 gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t step, int64_t count, gpf_handle* out)
 {
     if (!parent || !out) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (step < 1 || step >= ((int64_t)1 << 31)) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view step must be >= 1");
+    return view_create_impl(parent, start, step, count, nullptr, out);
+}
+// state[idxs] / view(state, idxs) for any vector of DISTINCT indices (src/view.jl:35-48): the strided view's compact-copy mechanism with
+// an index array.  index: HOST, 0-based, count entries.
+gpf_status gpf_view_create_indexed(gpf_handle parent, const int64_t* index, int64_t count, gpf_handle* out)
+{
+    if (!parent || !out || !index) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (count < 1) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "empty index vector");
+    std::vector<int64_t> sorted(index, index + count);
+    std::sort(sorted.begin(), sorted.end());
+    if (sorted.front() < 0 || sorted.back() >= parent->n) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view index out of bounds");
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+        return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view indices must be distinct (a particle written through two slots of a view has no defined value)");
+    return view_create_impl(parent, index[0], 0, count, index, out);
+}
+static gpf_status view_create_impl(gpf_handle parent, int64_t start, int64_t step, int64_t count, const int64_t* index, gpf_handle* out)
+{
     if (parent->parent) return fail(parent, GPF_ERR_STATE, "views of views are not supported");
     // the trajectory store keeps ONE ancestor map and one set of columns per time step for the whole filter: a sub-state that
     // resamples or advances only its own particles would leave it describing something else -- refuse instead of going stale
     if (parent->hist_on) return fail(parent, GPF_ERR_STATE, "a filter with a trajectory store has no sub-state views");
-    if (start < 0 || count < 1 || start + (count - 1) * step >= parent->n) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view range out of bounds");
+    if (!index && (start < 0 || count < 1 || start + (count - 1) * step >= parent->n)) return fail(parent, GPF_ERR_INVALID_ARGUMENT, "view range out of bounds");
     gpf_filter* v = new gpf_filter();
     v->cfg = parent->cfg;
     v->cfg.n_particles = count; v->cfg.n_global = count;          // a sub-state normalises over its own particles
@@ -2147,7 +2175,7 @@ gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t ste
     v->d = parent->d; v->W = parent->W; v->n = count; v->n_cu = parent->n_cu;
     v->stream = parent->stream; v->own_stream = false;
     v->parent = parent; v->view_start = start; v->view_step = step; v->parent_generation = parent->generation;
-    v->args.gstride = (int32_t)step;                               // per-particle RNG counters stay the source's particle ids
+    v->args.gstride = (int32_t)(step ? step : 1);                  // per-particle RNG counters stay the source's particle ids (index views: ModelArgs::gid_map)
     auto body = [&]() -> gpf_status {
         HIP_TRY(v, hipSetDevice(v->cfg.device));
         // scratch of its own (weight levels, descriptors, partials, scalars); rows / lw / anc alias the parent
@@ -2155,6 +2183,15 @@ gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t ste
         v->K = fix_K(count);
         v->logN = log_((double)count);
         const size_t n = (size_t)count;
+        if (index) {                                             // the particles' indices in the parent; their ids relative to the first
+            std::vector<int32_t> ix((size_t)count), rel((size_t)count);
+            for (int64_t i = 0; i < count; ++i) { ix[i] = (int32_t)index[i]; rel[i] = (int32_t)(index[i] - index[0]); }
+            HIP_TRY(v, hipMalloc(&v->vidx, n * sizeof(int32_t)));
+            HIP_TRY(v, hipMalloc(&v->vgid, n * sizeof(int32_t)));
+            HIP_TRY(v, hipMemcpy(v->vidx, ix.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(v, hipMemcpy(v->vgid, rel.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+            v->args.gid_map = v->vgid;
+        }
         if (step != 1) {
             HIP_TRY(v, hipMalloc(&v->vrows[0], n * (size_t)v->W * sizeof(double)));
             HIP_TRY(v, hipMalloc(&v->vrows[1], n * (size_t)v->W * sizeof(double)));

@@ -273,6 +273,11 @@ gpf_status gpf_view_create(gpf_handle parent, int64_t start, int64_t count, gpf_
  * A strided view works on a compact copy (gathered on entry, scattered back by every mutating call: update_refs! for sub-states
  * copies back as well, src/utils.jl:17-20). */
 gpf_status gpf_view_create_strided(gpf_handle parent, int64_t start, int64_t step, int64_t count, gpf_handle* out);
+/* state[idxs] / view(state, idxs) for ANY vector of distinct indices (src/view.jl:35-48: `idxs::AbstractVector`): index = HOST array of
+ * count 0-based particle indices of `parent`, in the order the view presents them.  Same semantics and the same compact-copy mechanism as
+ * the strided view; a particle keeps its own id as its RNG counter, the view's resample stream is indexed by the slot ids index[0],
+ * index[0] + 1, ...  Repeated indices are refused (GPF_ERR_INVALID_ARGUMENT): a particle written through two slots has no defined value. */
+gpf_status gpf_view_create_indexed(gpf_handle parent, const int64_t* index, int64_t count, gpf_handle* out);
 
 /* ---- resize family (src/resize.jl) --------------------------------------------------
  * The handle stays valid; its per-particle buffers are reallocated for the new count.  Unsharded filters only. */

@@ -73,6 +73,15 @@ function Base.getindex(s::DeviceParticleFilterState, r::StepRange{Int,Int})
     return DeviceParticleFilterState(h[], getfield(s, :model), length(r))
 end
 Base.view(s::DeviceParticleFilterState, r::StepRange{Int,Int}) = s[r]
+# state[idxs] for ANY vector of distinct indices (src/view.jl:35-48 takes idxs::AbstractVector): the same compact-copy view over an index array
+function Base.getindex(s::DeviceParticleFilterState, idxs::AbstractVector{<:Integer})
+    ix = Int64.(idxs) .- 1
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    _status(s, ccall((:gpf_view_create_indexed, libgpf), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64, Ref{Ptr{Cvoid}}), getfield(s, :handle), ix, length(ix), h))
+    return DeviceParticleFilterState(h[], getfield(s, :model), length(ix))
+end
+Base.getindex(s::DeviceParticleFilterState, mask::AbstractVector{Bool}) = s[findall(mask)]
+Base.view(s::DeviceParticleFilterState, idxs::AbstractVector{<:Integer}) = s[idxs]
 
 # status helper; NOT called `check`: the resamplers take a keyword of that name (src/resample.jl:43-46) which would shadow it
 _status(state, st) = st == 0 ? nothing :

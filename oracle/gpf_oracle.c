@@ -273,7 +273,11 @@ O_EXPORT void o_loglik_rows(int model, const double *P, const double *rows, int 
  * is a property of the call (set by the Python composition around a view's per-particle call, 1 otherwise). */
 static int64_t g_gid_stride = 1;
 O_EXPORT void o_set_gid_stride(int64_t stride) { g_gid_stride = stride; }
-#define O_GID(gid0, i) ((uint32_t)((gid0) + (int64_t)(i) * g_gid_stride))
+/* Views over an arbitrary index vector (src/view.jl:35-48, state[idxs]): local particle i is particle idxs[i] of the source; the map
+ * holds idxs[i] - idxs[0] (gid0 = the first index), NULL otherwise. */
+static const int32_t *g_gid_map = NULL;
+O_EXPORT void o_set_gid_map(const int32_t *map) { g_gid_map = map; }
+#define O_GID(gid0, i) ((uint32_t)(g_gid_map ? (gid0) + (int64_t)g_gid_map[i] : (gid0) + (int64_t)(i) * g_gid_stride))
 
 O_EXPORT void o_init_proposal(int model, const double *P, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
                               int W, const double *obs, double *rows, double *lw)

@@ -75,6 +75,7 @@ def lib():
     sig("o_max_flags", None, _f64p, i64, pf64, pi32)
     sig("o_fixq", None, _f64p, i64, f64, i32, i32, _u64p)
     sig("o_scan", u64, _u64p, i64, _u64p, pu64, pu64)
+    sig("o_set_gid_map", None, C.POINTER(C.c_int32))
     sig("o_targets_multinomial", None, u64, u32, i64, i64, u64, _u64p)
     sig("o_targets_sorted", None, u64, u32, i64, i64, u64, _u64p)
     sig("o_gamma_E", C.c_int32, i64)
@@ -559,17 +560,34 @@ class OracleSubState:
     utils.jl:17-20,174-178.  Per-particle RNG counters stay the GLOBAL particle ids start + i*step; the resample stream of a
     view is indexed by the slot ids start, start + 1, ... (consecutive from the view's first particle), whatever the step."""
 
-    def __init__(self, source: OracleFilter, start: int, count: int, step: int = 1):
+    def __init__(self, source: OracleFilter, start: int, count: int, step: int = 1, index=None):
+        """index: an arbitrary vector of distinct particle indices (state[idxs], view.jl:35-48) -- then start = index[0], the per-particle
+        RNG counters are the particles' own ids index[i], the resample stream the slot ids index[0], index[0] + 1, ..."""
         self.source, self.start, self.n, self.step = source, int(start), int(count), int(step)
-        self.sl = slice(self.start, self.start + (self.n - 1) * self.step + 1, self.step)
+        if index is None:
+            self.sl = slice(self.start, self.start + (self.n - 1) * self.step + 1, self.step)
+            self.gid_map = None
+        else:
+            self.sl = np.ascontiguousarray(index, np.int64)
+            assert self.sl.size == np.unique(self.sl).size == self.n and self.start == int(self.sl[0])
+            self.gid_map = np.ascontiguousarray(self.sl - self.sl[0], np.int32)
         self.last_obs = source.last_obs
         self.n_accepted = 0
 
-    class _Stride:
-        """per-particle oracle calls inside: local particle i carries the RNG counter gid0 + i*step"""
-        def __init__(self, step): self.step = step
-        def __enter__(self): lib().o_set_gid_stride(self.step)
-        def __exit__(self, *a): lib().o_set_gid_stride(1)
+    def _Stride(self, step):
+        """per-particle oracle calls inside: local particle i carries the RNG counter gid0 + i*step (or gid0 + gid_map[i])"""
+        view = self
+
+        class _Ctx:
+            def __enter__(self_):
+                lib().o_set_gid_stride(step)
+                if view.gid_map is not None:
+                    lib().o_set_gid_map(view.gid_map.ctypes.data_as(C.POINTER(C.c_int32)))
+
+            def __exit__(self_, *a):
+                lib().o_set_gid_stride(1)
+                lib().o_set_gid_map(None)
+        return _Ctx()
 
     # aliases of the source's arrays (the source may swap its row buffer: always re-derive)
     @property
@@ -730,6 +748,9 @@ def initialize_blocks(f: OracleFilter, nb: int, obs_rows) -> OracleFilter:
 
 
 def _oracle_getitem(self, idx):
+    if not isinstance(idx, slice):                                       # state[idxs] with any vector of distinct indices (view.jl:35-48)
+        ix = np.asarray(idx, np.int64)
+        return OracleSubState(self, int(ix[0]), ix.size, 1, index=ix)
     start, stop, step = idx.indices(self.n)
     assert step >= 1 and stop > start
     return OracleSubState(self, start, (stop - start + step - 1) // step, step)

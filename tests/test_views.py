@@ -257,3 +257,95 @@ def test_hip_whole_view_resample_is_the_library_local_resample(g, o, monkeypatch
         orc.resample("multinomial", check=False); orc.update(ys[2])
     assert np.array_equal(b[0], orc.parents) and np.array_equal(b[1], orc.rows) and np.array_equal(b[2], orc.lw)
     assert b[3] == orc.log_ml_estimate() and b[4] == orc.effective_sample_size()
+
+
+# ----------------------------------------------------------------------------------------------- state[idxs], any index vector
+def _index_sets(N, rng):
+    """a random partition of 0..N-1 into three index vectors (unsorted), plus a sorted non-contiguous one"""
+    perm = rng.permutation(N)
+    a, b = N // 3, (2 * N) // 3
+    return [perm[:a], perm[a:b], perm[b:]], np.sort(rng.choice(N, N // 2, replace=False))
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("alpha", [None, 0.5])
+def test_oracle_index_vector_views(g, o, method, alpha):
+    """src/view.jl:35-48 takes ANY index vector.  The block-wise resampling invariants of test/resample.jl:130-162 on a random partition
+    of the particles into three unsorted index sets: per view new == old[parents] and an unchanged estimate; the other particles
+    untouched; the whole filter's estimate unchanged."""
+    m, ys, f = lgssm(g, o, N=120)
+    parts, _ = _index_sets(120, np.random.default_rng(5))
+    lml_full = f.log_ml_estimate()
+    for ix in parts:
+        v = f[ix]
+        old, lml, rest = v.rows.copy(), v.log_ml_estimate(), np.setdiff1d(np.arange(120), ix)
+        rows_rest, lw_rest = f.rows[rest].copy(), f.lw[rest].copy()
+        v.resample(method, priority_alpha=alpha)
+        assert np.array_equal(v.rows, old[v.parents - 1])
+        assert abs(v.log_ml_estimate() - lml) < 1e-9
+        assert np.array_equal(f.rows[rest], rows_rest) and np.array_equal(f.lw[rest], lw_rest)
+    assert abs(f.log_ml_estimate() - lml_full) < 1e-9 and f.lml_est == 0.0
+
+
+def test_oracle_index_view_keeps_the_particles_own_rng_ids(g, o):
+    """a particle updated through state[idxs] draws what it would draw through the whole filter: its RNG counter is its own index"""
+    m, ys, f = lgssm(g, o, N=200)
+    whole = o.OracleFilter(m.model_id, m.params, 200, 3, keep_prev=True).initialize(ys[0])
+    whole.update(ys[1])
+    ix = np.random.default_rng(1).permutation(200)[:77]
+    f[ix].update(ys[1])
+    assert np.array_equal(f.rows[ix], whole.rows[ix]) and np.array_equal(f.lw[ix], whole.lw[ix])
+    rest = np.setdiff1d(np.arange(200), ix)
+    assert not np.array_equal(f.rows[rest], whole.rows[rest])            # the others were not updated
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", METHODS + ["multinomial_sorted"])
+@pytest.mark.parametrize("N", [97, 5000])
+def test_hip_index_vector_views_bitexact(g, o, method, N):
+    """every pf_* operation through state[idxs] over permuted / sorted / boolean index sets == the oracle's sub-state over the same indices"""
+    rng = np.random.default_rng(N)
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 6)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=7, keep_prev=True)
+    orc = o.OracleFilter(model.model_id, model.params, N, 7, keep_prev=True).initialize(ys[0])
+    parts, half = _index_sets(N, rng)
+    kw = dict(sort_particles=True) if method == "stratified" else {}
+    for k, ix in enumerate(parts + [half]):
+        sv, ov = st[ix], orc[ix]
+        assert sv.n_particles == ix.size
+        g.pf_update(sv, (2,), (None,), ys[1 + k % 3]); ov.update(ys[1 + k % 3])
+        assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw), (k, "update")
+        assert g.get_ess(sv) == ov.effective_sample_size() and g.get_lml_est(sv) == ov.log_ml_estimate()
+        alpha = 0.5 if k == 1 else None
+        g.pf_resample(sv, method, priority_fn=g.Tempering(alpha) if alpha else None, check=False, **kw)
+        ov.resample(method, priority_alpha=alpha, check=False, **kw)
+        assert np.array_equal(sv.parents, ov.parents), (k, "parents")
+        g.pf_rejuvenate(sv, None, (), 1, method="move" if k % 2 else "reweight"); ov.rejuvenate("move" if k % 2 else "reweight", 1)
+        assert np.array_equal(sv.traces, ov.rows), (k, "rows")
+        np.testing.assert_allclose(sv.log_weights, ov.lw, rtol=1e-12, atol=1e-12)
+        orc.lw[ix] = sv.log_weights                                   # (tempered weights: 1e-6 bar; keep the two in lockstep)
+        assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.parents, orc.parents), (k, "source")
+    # a boolean mask is an index vector too
+    mask = rng.random(N) < 0.4
+    sv, ov = st[mask], orc[np.flatnonzero(mask)]
+    g.pf_resample(sv, method, check=False, **kw); ov.resample(method, check=False, **kw)
+    assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.parents, orc.parents)
+    # the filter keeps working as a whole
+    g.pf_resample(st, "residual", check=False); orc.resample("residual", check=False)
+    g.pf_update(st, (5,), (None,), ys[5]); orc.update(ys[5])
+    assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.parents, orc.parents)
+    st.close()
+
+
+@pytest.mark.gpu
+def test_hip_index_view_errors(g, o):
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    st = g.pf_initialize(model, (1,), ys[0], 100, seed=1)
+    for bad in ([3, 5, 3], [0, 100], [-1, 2], []):                    # repeated / out of bounds / empty
+        with pytest.raises(g.ErrorException):
+            st[bad]
+    with pytest.raises(g.ErrorException):
+        st[np.zeros(7, bool)]                                         # a mask of the wrong length
+    v = st[[5, 1, 99]]
+    assert np.array_equal(v.traces, st.traces[[5, 1, 99]]) and np.array_equal(v.log_weights, st.log_weights[[5, 1, 99]])
+    st.close()

@@ -12,11 +12,14 @@ import gpf_amd as g  # noqa: E402
 
 CONFIGS = [
     ("config2 lgssm2 multinomial", "lgssm2", 1_000_000, "multinomial", {}, None, None),
+    ("config2s lgssm2 multinomial_sorted (opt-in: sorted uniforms)", "lgssm2", 1_000_000, "multinomial_sorted", {}, None, None),
+    ("config2l lgssm2 multinomial, lazy search (k_step_search)", "lgssm2", 1_000_000, "multinomial", {"_lazy": True}, None, None),
     ("config3 lgssm2 stratified(unsorted) [1 of 8 shards' worth]", "lgssm2", 1_000_000, "stratified", {"sort_particles": False}, None, None),
     ("lgssm2 stratified(sorted)", "lgssm2", 1_000_000, "stratified", {"sort_particles": True}, None, None),
     ("lgssm2 residual", "lgssm2", 1_000_000, "residual", {}, None, None),
     ("config4 bearings4 ESS<N/2 residual + MH [1 of 4 shards' worth]", "bearings4", 1_000_000, "residual", {}, "move", 0.5),
     ("config5 sv1 multinomial + move-reweight", "sv1", 2_000_000, "multinomial", {}, "reweight", None),
+    ("config5s sv1 multinomial_sorted + move-reweight", "sv1", 2_000_000, "multinomial_sorted", {}, "reweight", None),
 ]
 
 
@@ -24,6 +27,9 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
     model = g.models.by_name(model_name)
     ys = g.models.simulate(model, steps + warm + 1)
     st = g.pf_initialize(model, (1,), ys[0], N, seed=1, keep_prev=rejuv is not None)
+    kw = dict(kw)
+    if kw.pop("_lazy", False):
+        st.set_lazy_search(True)
     n_res = 0
 
     def step(t):
