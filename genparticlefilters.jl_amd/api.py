@@ -408,7 +408,7 @@ def pf_resample(state, method: str = "multinomial", **kwargs):
 def pf_resample_blocks(state, block_size: int, method: str = "multinomial", *, priority_fn=None, ess_frac=None, sort_particles: bool = True, check="warn"):
     """Many small filters in one state: the batched form of
 
-        for b in blocks:                                   # consecutive blocks of block_size particles (<= 2048)
+        for b in blocks:                                   # consecutive blocks of block_size particles
             if ess_frac is None or get_ess(state[b]) < ess_frac * len(b):
                 pf_resample(state[b], method, sort_particles=..., check=...)
 

@@ -148,6 +148,9 @@ struct gpf_filter {
     int64_t* h_qpub = nullptr; int64_t q_ticket = 0;   // the ESS getter's scan publishes {flags, S, limbs of sum q^2} itself (ScanExtras::q_host)
     bool q_published = false;                          // ... and the scan of THIS call did
     int32_t* blk_words = nullptr; int32_t* blk_mask = nullptr; double* blk_stats = nullptr; int64_t blk_cap = 0, blk_last = 0;
+    // blocks of more than BLK_MAX particles: gpf_resample_blocks / gpf_block_stats run the loop over sub-states themselves, through view
+    // handles kept on the filter (one per block; rebuilt when the block size or the particle buffers change)
+    std::vector<gpf_filter*> blk_views; int64_t blk_views_size = 0; uint64_t blk_views_gen = 0;
     double* blk_obs = nullptr; int64_t blk_obs_cap = 0;                                // per-block observations [n_blocks][MAX_OBS] on the device
     static constexpr int BLK_STAGE = 4;                                                // pinned staging buffers, used in turn (no stream sync per step)
     double* h_blk_obs[BLK_STAGE] = {nullptr, nullptr, nullptr, nullptr};
@@ -1323,6 +1326,8 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     h->pending_packed = false;                                   // the filter goes away: nothing to scatter a deferred commit into
+    for (gpf_filter* v : h->blk_views) gpf_destroy(v);
+    h->blk_views.clear();
     gpf_comm_destroy(h);
     hist_clear(h);
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);
@@ -1534,7 +1539,75 @@ static gpf_status block_checks(gpf_handle h, int64_t block_size, const char* who
     if (s) return s;
     if (h->parent) return fail(h, GPF_ERR_STATE, std::string(who) + " on a sub-state view: call it on the filter");
     if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, std::string(who) + " on a shard of a sharded filter");
-    if (block_size < 1 || block_size > BLK_MAX) return fail(h, GPF_ERR_INVALID_ARGUMENT, "block_size: 1 .. 2048 particles");
+    if (block_size < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "block_size < 1");
+    return GPF_OK;
+}
+// Blocks of more than BLK_MAX = 2048 particles do not fit the one-workgroup-per-block kernels (gpf_k_block.hpp keeps a block's weights, CDF
+// and order in LDS).  Their loop over sub-states (for b in blocks; pf_resample!(state[b], ...); end -- test/resample.jl:130-162 has no
+// size limit) runs on the host over view handles of the blocks, with the full-size kernels: the same results as the views give, the
+// same single epoch for all blocks, no size cliff.  At these sizes a block fills the chip by itself.
+static gpf_status big_block_views(gpf_filter* h, int64_t block_size)
+{
+    const int64_t nblocks = (h->n + block_size - 1) / block_size;
+    if (h->blk_views_size == block_size && h->blk_views_gen == h->generation && (int64_t)h->blk_views.size() == nblocks) return GPF_OK;
+    for (gpf_filter* v : h->blk_views) gpf_destroy(v);
+    h->blk_views.clear();
+    for (int64_t b = 0; b < nblocks; ++b) {
+        gpf_handle v = nullptr;
+        const int64_t start = b * block_size, cnt = std::min(block_size, h->n - start);
+        gpf_status s = gpf_view_create(h, start, cnt, &v);
+        if (s) return s;
+        h->blk_views.push_back(v);
+    }
+    h->blk_views_size = block_size; h->blk_views_gen = h->generation;
+    return GPF_OK;
+}
+static gpf_status resample_big_blocks(gpf_handle h, int32_t method, int64_t block_size, double priority_alpha, int32_t sort_particles,
+                                      double ess_frac, int32_t check, int32_t* invalid, int64_t* n_resampled)
+{
+    gpf_status s = big_block_views(h, block_size);
+    if (s) return s;
+    const int64_t nblocks = (int64_t)h->blk_views.size();
+    if ((s = block_buffers(h, nblocks))) return s;
+    const uint32_t E = h->epoch;                                 // every block resamples under the call's ONE epoch (like the batched kernel)
+    std::vector<int32_t> words((size_t)nblocks, 0);
+    bool any_invalid = false, any_nan = false, any_neginf_err = false;
+    int64_t count = 0;
+    const bool gate = ess_frac == ess_frac && ess_frac >= 0.0;
+    for (int64_t b = 0; b < nblocks; ++b) {
+        gpf_filter* v = h->blk_views[(size_t)b];
+        h->epoch = E;
+        if (gate) {
+            double ess = 0.0;
+            if ((s = gpf_effective_sample_size(v, &ess))) { h->err = v->err; h->epoch = E; return s; }
+            if (!(ess < ess_frac * (double)v->n)) continue;      // (an invalid block: ESS NaN -- it does not resample, nothing is reported)
+        }
+        int32_t inv = 0;
+        s = gpf_resample(v, method, priority_alpha, sort_particles, check == GPF_CHECK_TRUE ? GPF_CHECK_TRUE : GPF_CHECK_WARN, &inv);
+        if (s == GPF_ERR_INVALID_WEIGHTS) {                      // the block is left as it stands; the others go on
+            any_invalid = true;
+            const bool nan_block = v->err.find("NaN") != std::string::npos;
+            if (nan_block) any_nan = true; else any_neginf_err = true;
+            words[(size_t)b] = (nan_block ? FLAG_NAN : FLAG_ALL_NEGINF) << 8;      // (the word layout of the batched kernel: flags << 8 | resampled)
+            continue;
+        }
+        if (s) { h->err = v->err; h->epoch = E; return s; }
+        if (inv) { any_invalid = true; words[(size_t)b] |= FLAG_ALL_NEGINF << 8; }
+        words[(size_t)b] |= 1;
+        ++count;
+    }
+    h->epoch = E + 1;
+    HIP_TRY(h, hipMemcpyAsync(h->blk_mask, words.data(), (size_t)nblocks * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));                // (the host vector goes out of scope)
+    h->blk_last = nblocks;
+    h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false;
+    mutated(h);
+    if (invalid) *invalid = any_invalid ? 1 : 0;
+    if (n_resampled) *n_resampled = count;
+    if (check != GPF_CHECK_FALSE || invalid || n_resampled) {
+        if (any_nan) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights (NaN).");
+        if (check == GPF_CHECK_TRUE && (any_neginf_err || any_invalid)) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights.");   // resample.jl:55
+    }
     return GPF_OK;
 }
 gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size, double priority_alpha, int32_t sort_particles,
@@ -1547,6 +1620,7 @@ gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size,
     if (h->hist_on) return fail(h, GPF_ERR_STATE, "gpf_resample_blocks on a filter with a trajectory store");
     if (h->W != 2 && h->W != 4 && h->W != 8) return fail(h, GPF_ERR_STATE, "row width");
     if ((s = materialize(h))) return s;
+    if (block_size > BLK_MAX) return resample_big_blocks(h, method, block_size, priority_alpha, sort_particles, ess_frac, check, invalid, n_resampled);
     const int64_t nblocks = (h->n + block_size - 1) / block_size;
     if ((s = block_buffers(h, nblocks))) return s;
     BlockArgs a{};
@@ -1601,6 +1675,15 @@ gpf_status gpf_block_stats(gpf_handle h, int64_t block_size, double* ess_out, do
     if (s) return s;
     if ((s = materialize(h))) return s;
     const int64_t nblocks = (h->n + block_size - 1) / block_size;
+    if (block_size > BLK_MAX) {                                  // the loop over sub-states (big_block_views)
+        if ((s = big_block_views(h, block_size))) return s;
+        for (int64_t b = 0; b < nblocks; ++b) {
+            gpf_filter* v = h->blk_views[(size_t)b];
+            if (ess_out && (s = gpf_effective_sample_size(v, ess_out + b))) { h->err = v->err; return s; }
+            if (lml_out && (s = gpf_log_ml_estimate(v, lml_out + b))) { h->err = v->err; return s; }
+        }
+        return GPF_OK;
+    }
     if ((s = block_buffers(h, nblocks))) return s;
     if (block_size <= 2 * WAVE)      GPF_LAUNCH((k_block_stats<WAVE, 2>), dim3((unsigned)((nblocks + 3) / 4)), dim3(BLOCK), 0, h->stream, h->lw, h->n, block_size, nblocks, &h->sc->lml_est, h->blk_stats, h->blk_stats + nblocks);
     else if (block_size <= 8 * WAVE) GPF_LAUNCH((k_block_stats<WAVE, 8>), dim3((unsigned)((nblocks + 3) / 4)), dim3(BLOCK), 0, h->stream, h->lw, h->n, block_size, nblocks, &h->sc->lml_est, h->blk_stats, h->blk_stats + nblocks);
@@ -1666,7 +1749,7 @@ static gpf_status block_step_checks(gpf_handle h, int64_t block_size, const char
     if (h->parent) return fail(h, GPF_ERR_STATE, std::string(who) + " on a sub-state view: call it on the filter");
     if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, std::string(who) + " on a shard of a sharded filter");
     if (h->hist_on) return fail(h, GPF_ERR_STATE, std::string(who) + " on a filter with a trajectory store");
-    if (block_size < 1 || block_size > BLK_MAX) return fail(h, GPF_ERR_INVALID_ARGUMENT, "block_size: 1 .. 2048 particles");
+    if (block_size < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "block_size < 1");      // (the per-block steps index observations by i / block_size: any size)
     return GPF_OK;
 }
 gpf_status gpf_initialize_blocks(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size)

@@ -142,7 +142,8 @@ gpf_status gpf_resample_local(gpf_handle h, int32_t method, int32_t sort_particl
 /* Many small filters in one state -- the batched form of
  *     for b in blocks; if effective_sample_size(state[b]) < ess_frac * length(b); pf_resample!(state[b], method; sort_particles, check); end; end
  * (sub-states: src/view.jl:16-48, src/resample.jl:185-187,205-218; the README loop README.md:60-79 per block; the reference's own
- * tests run N = 100).  The particles are cut into consecutive blocks of block_size (<= 2048; the last block may be shorter); ONE launch
+ * tests run N = 100).  The particles are cut into consecutive blocks of block_size (the last block may be shorter).  Up to 2048 particles per
+ * block ONE launch
  * resamples every block out of LDS with the sub-state semantics: normalised over the block, log_ml_est untouched, every particle of
  * a resampled block carries logsumexp(block weights) - log(block size), parents local to the block.  Block b's result is
  * bit-identical to the same call on a view of the block (gpf_view_create + gpf_resample), all blocks under the call's one epoch.
@@ -154,6 +155,8 @@ gpf_status gpf_resample_local(gpf_handle h, int32_t method, int32_t sort_particl
  *                are left as they stand, the other blocks resample, and the call returns GPF_ERR_INVALID_WEIGHTS.  (With ess_frac >= 0 an
  *                invalid block never reaches the resampler -- its ESS is NaN -- and nothing is reported, as in the loop.)
  *   n_resampled: if non-NULL receives the number of blocks that resampled (synchronises).
+ * Blocks of more than 2048 particles (no size limit in the reference's loop, test/resample.jl:130-162) are resampled one after the other with the
+ * full-size kernels through view handles the filter keeps -- the same results, the same single epoch, one set of launches per block.
  * Not on sharded filters, views or filters with a trajectory store (GPF_ERR_STATE). */
 gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size, double priority_alpha, int32_t sort_particles,
                                double ess_frac, int32_t check, int32_t* invalid, int64_t* n_resampled);

@@ -196,8 +196,6 @@ def test_random_sequences_with_block_resamples(g, o, seed):
 def test_argument_errors(g, o):
     m, ys, st, f = make(g, o, "lgssm2", 300)
     with pytest.raises(g.ErrorException):
-        g.pf_resample_blocks(st, 4096, "multinomial")
-    with pytest.raises(g.ErrorException):
         g.pf_resample_blocks(st, 0, "multinomial")
     with pytest.raises(g.ErrorException, match="not recognized"):
         g.pf_resample_blocks(st, 100, "systematic")
@@ -322,4 +320,61 @@ def test_blocks_with_tempering(g, o, method, alpha, N, nb):
         ess, lml = g.block_stats(st, nb)
         k = t % len(ess); v = f[k * nb:min((k + 1) * nb, N)]
         assert lml[k] == v.log_ml_estimate()                            # the block's estimate is kept by the weight update (:215-216)
+    st.close()
+
+
+# ----------------------------------------------------------------------------------------------- blocks of more than 2048 particles
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("N,nb", [(10_000, 4096), (8192, 4096), (120_000, 50_000), (5000, 2049), (300, 4096)])
+def test_big_blocks_equal_the_loop_over_substates(g, o, method, N, nb):
+    """test/resample.jl:130-162 puts no limit on the size of a sub-state: blocks beyond the one-workgroup kernels' 2048 particles go through
+    the full-size kernels block by block -- same results as the loop over views, one epoch for all blocks, ESS gate, priorities, statistics"""
+    m, ys, st, f = make(g, o, "lgssm2", N, keep_prev=True)
+    B = (N + nb - 1) // nb
+    for t in range(1, 4):
+        g.pf_update(st, (t + 1,), (None,), ys[t]); f.update(ys[t])
+        if t == 1:
+            n_res = g.pf_resample_blocks(st, nb, method, sort_particles=(method == "stratified"), check=False)
+            mask = oracle_blocks(f, nb, method, sort_particles=(method == "stratified"))
+        elif t == 2:
+            n_res = g.pf_resample_blocks(st, nb, method, ess_frac=0.7, sort_particles=False, check=False)
+            mask = oracle_blocks(f, nb, method, ess_frac=0.7, sort_particles=False)
+        else:
+            n_res = g.pf_resample_blocks(st, nb, method, priority_fn=g.Tempering(0.5), sort_particles=False, check=False)
+            mask = oracle_blocks(f, nb, method, priority_alpha=0.5, sort_particles=False)
+        assert n_res == mask.sum() and np.array_equal(g.block_resampled(st), mask), (method, N, nb, t)
+        assert np.array_equal(st.traces, f.rows) and np.array_equal(st.parents, f.parents), (method, N, nb, t)
+        np.testing.assert_allclose(st.log_weights, f.lw, rtol=1e-12, atol=1e-12)
+        f.lw = st.log_weights.copy()                                   # (tempered weights: keep the two in lockstep)
+        ess, lml = g.block_stats(st, nb)
+        for k in range(B):
+            v = f[k * nb:min((k + 1) * nb, N)]
+            assert ess[k] == v.effective_sample_size() and lml[k] == v.log_ml_estimate()
+    assert g.get_lml_est(st) == f.log_ml_estimate()
+    st.close()
+
+
+def test_big_blocks_steps_and_invalid_blocks(g, o):
+    """per-block observations and masked rejuvenation at block sizes beyond 2048; a NaN block is left as it stands and reported"""
+    N, nb = 9000, 4000
+    m = g.models.bearings4(); base = np.asarray(g.models.simulate(m, 4))
+    B = (N + nb - 1) // nb
+    rng = np.random.default_rng(3)
+    ys = base[None, :, :] + 0.3 * rng.standard_normal((B,) + base.shape)
+    st = g.pf_initialize_blocks(m, (1,), ys[:, 0], N, nb, seed=21, keep_prev=True)
+    f = oracle_init_blocks(o, o.OracleFilter(m.model_id, m.params, N, 21, keep_prev=True), nb, ys[:, 0])
+    for t in range(1, 3):
+        g.pf_update_blocks(st, (t + 1,), (None,), ys[:, t], nb); oracle_update_blocks(f, nb, ys[:, t])
+        n_res = g.pf_resample_blocks(st, nb, "residual", ess_frac=0.6, check=False)
+        mask = oracle_blocks(f, nb, "residual", ess_frac=0.6)
+        assert n_res == mask.sum() and np.array_equal(g.block_resampled(st), mask)
+        g.pf_rejuvenate_blocks(st, None, (), 1, method="move", only_resampled=True); oracle_rejuvenate_blocks(f, nb, ys[:, t], "move", mask)
+        assert same(st, f), t
+    lw = st.log_weights.copy(); lw[nb + 5] = np.nan                    # block 1 is invalid
+    st.log_weights = lw; f.lw = lw.copy()
+    rows0 = st.traces.copy()
+    with pytest.raises(g.ErrorException, match="NaN"):
+        g.pf_resample_blocks(st, nb, "multinomial", check="warn")
+    assert np.array_equal(st.traces[nb:2 * nb], rows0[nb:2 * nb])       # left as it stands
+    assert not np.array_equal(st.traces[:nb], rows0[:nb])               # the others resampled
     st.close()
