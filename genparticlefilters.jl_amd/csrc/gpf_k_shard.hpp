@@ -101,6 +101,7 @@ struct PushArgs {
     int64_t ticket;
     MboxWait wait_tot, wait_cr;                   // shard mailboxes: tot_all / cr_all are filled by the peers' kernels -- wait before reading
     int extra; PrioView pv;                       // prioritised resample: packed entries carry one more double, lw[a] - lp[a] (PackOut::extra)
+    int skip_own;                                 // the shard's OWN slots are resolved by k_search_own (ancestors in place, no packed entry): pass 1 skips their chunks
 };
 struct PushTables {                               // LDS copy of the per-shard tables
     int64_t w_incl[MAX_SHARDS], c_incl[MAX_SHARDS], bounds[MAX_SHARDS + 1], chunk0[MAX_SHARDS + 1];
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
     for (int64_t c = blockIdx.x; c < a.nchunks; c += gridDim.x) {
         int64_t j0, j1;
         const int g = push_chunk(a, t, c, j0, j1);
+        if (a.skip_own && g == a.me) continue;                                        // block-uniform: k_search_own takes this shard's slots
         if (METHOD == 1 && (uint64_t)j1 <= sc.Ctot) {                                 // block-uniform
             // the chunk lies in the residual resampler's deterministic head (resample.jl:96-106): slot j is the j-th copy, its
             // target is j itself in the copy-count space -- no uniform to draw, and the hits are ONE range of slots
@@ -280,6 +282,68 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
     if (threadIdx.x < a.G && s_recv[threadIdx.x])
         atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + (a.G + threadIdx.x) * COUNT_STRIDE), (unsigned long long)s_recv[threadIdx.x]);
 }
+// ---- the shard's OWN slots (multinomial).  A slot of this shard whose target falls into this shard's part of the CDF needs no exchange
+// entry at all: its ancestor is a local particle, exactly the unsharded case.  This kernel is k_search_multi over the shard's own slots
+// with the GLOBAL target arithmetic: own hits get anc[j] = global id of the ancestor (the next propagate gathers the row through it,
+// k_step<GATHER> with PackedCommit::masked), slots whose target another shard owns get anc[j] = -1 (their rows arrive packed) and are
+// counted per owner (the receive counts of the exchange; counts[G + me] = own hits).  Pass 1 (k_push_scan) then walks the OTHER shards'
+// slots only, and nothing is staged, packed or copied for what never leaves the GPU: on one rank the sharded resample is the unsharded one.
+template <int LOGG>
+__global__ __launch_bounds__(SBLOCK, 4) void k_search_own(PushArgs a, CdfLevels lw_, int64_t n, int64_t ntiles, int64_t gid0, int32_t* __restrict__ anc)
+{
+    constexpr int NS = GPF_MULTI_NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ PushTables t;
+    __shared__ unsigned int s_recv[MAX_SHARDS];
+    if (threadIdx.x < MAX_SHARDS) s_recv[threadIdx.x] = 0;
+    push_tables(a, t);
+    const uint64_t Sw = (uint64_t)t.w_incl[a.G - 1];
+    const uint64_t w_lo = a.me ? (uint64_t)t.w_incl[a.me - 1] : 0;
+    const MultiTable tb = multi_table_load<LOGG>(lw_, ntiles, (uint64_t)t.w_incl[a.me] - w_lo, reinterpret_cast<uint32_t*>(smem), [] {});
+    const int lane = lane_id();
+    unsigned recv_cnt = 0;                                                           // lane q: this wave's slots served by shard q
+    const int64_t stride = (int64_t)gridDim.x * NS * SBLOCK;
+    for (int64_t base = (int64_t)blockIdx.x * NS * SBLOCK; base < n; base += stride) {
+        const int64_t j0 = base + NS * (int64_t)threadIdx.x;
+        uint64_t T[NS]; int own[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const uint64_t Tg = mulhi64(resample_u64(a.seed, (uint32_t)(gid0 + j0 + u), a.epoch), Sw);     // resample.jl:59, global coordinates
+            uint64_t Tl;
+            own[u] = j0 + u < n ? push_owner(t, a.G, 0, Tg, Tl) : -1;
+            T[u] = own[u] == a.me ? Tl : 0;                                          // (another shard's target: the lane rides along with a dummy)
+            for (int q = 0; q < a.G; ++q) {
+                const unsigned c = (unsigned)__popcll(__ballot(own[u] == q));
+                if (lane == q) recv_cnt += c;
+            }
+        }
+        uint32_t idx[NS];
+        multi_lookup<LOGG, NS>(tb, lw_, n, T, idx);
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+            if (j0 + u < n) anc[j0 + u] = own[u] == a.me ? (int32_t)(gid0 + (int64_t)idx[u]) : -1;
+    }
+    if (recv_cnt) atomicAdd(&s_recv[lane], recv_cnt);
+    __syncthreads();
+    if (threadIdx.x < (unsigned)a.G && s_recv[threadIdx.x])
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + (a.G + threadIdx.x) * COUNT_STRIDE), (unsigned long long)s_recv[threadIdx.x]);
+}
+// materialize() of a commit with own hits: rows_out[j] = rows_in[anc[j] - gid0], lw[j] = 0 for the slots with anc[j] >= 0
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_gather_own(const int32_t* __restrict__ anc, int64_t gid0, const double* __restrict__ rows_in,
+                                                      double* __restrict__ rows_out, double* __restrict__ lw, int64_t n)
+{
+    constexpr int C = W / 2;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t j = t / C;
+        const int c = (int)(t - j * C);
+        const int32_t a = anc[j];
+        if (a < 0) continue;
+        reinterpret_cast<double2*>(rows_out)[t] = reinterpret_cast<const double2*>(rows_in)[((int64_t)a - gid0) * C + c];
+        if (c == 0) lw[j] = 0.0;                                                     // update_weights!, resample.jl:195
+    }
+}
+
 // ---- the PULL plan of the i.i.d. resamplers (gpf_comm_set_plan / GPF_SHARD_PLAN=pull).  Every shard evaluates only
 // its OWN slots -- n targets instead of the push plan's n_global -- and asks for them: request {T_local | space << 62, slot inside the
 // requester} (the entry format of the push stage) goes to the shard whose range of the sampled space holds the target, grouped by

@@ -91,6 +91,10 @@ struct PackedCommit {
     const double* mf_all; const int64_t* tot_all; int G, K; double logN; Scalars* sc;   // update_lml_est! from the gathered summaries
     const double* lw_fill;     // GATHER after gpf_resample_local: the incoming log-weights are this constant, not 0 (resample.jl:210)
     int in_mailbox;            // mf_all / tot_all sit in the shard mailbox (written by peers: system-scope loads)
+    // GATHER on a shard whose own slots were resolved in place (k_search_own): anc holds GLOBAL ancestor ids (row anc - anc_off) for the
+    // slots this shard serves itself and -1 for the slots whose rows arrive packed (skipped here); sc != nullptr: this launch carries
+    // the log-ML update from the gathered summaries
+    int masked; int64_t anc_off;
 };
 template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false, bool BLK = false>
 __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
     using Mo = Model<M>;
     constexpr int D = Mo::D;
     double bm = -__builtin_huge_val(); int bf = 0;
-    if constexpr (PACKED) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if constexpr (PACKED || GATHER) {
+        if (pc.sc && pc.mf_all && blockIdx.x == 0 && threadIdx.x == 0) {
             uint64_t S = 0;
             double mx = -__builtin_huge_val();
             int f = 0;
@@ -126,7 +130,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
             i = (int64_t)(meta >> 32);
             pc.anc[i] = (int32_t)(meta & 0xffffffffull);
         } else {
-        const int64_t srow = GATHER ? (int64_t)anc[i] : i;
+        int64_t srow = GATHER ? (int64_t)anc[i] : i;
+        if (GATHER && pc.masked) { if (srow < 0) continue; srow -= pc.anc_off; }     // (kernel-uniform flag; the slot's row arrives packed)
         const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
 #pragma unroll
         for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }

@@ -102,6 +102,10 @@ struct gpf_filter {
     bool pending_packed = false;   // sharded: the resampled population is still the received exchange buffer (gpf_shard_commit)
     const double* pend_packed = nullptr; const double* pend_mf = nullptr; const int64_t* pend_tot = nullptr; int pend_G = 0;
     bool pend_mailbox = false;     // pend_mf / pend_tot sit in the shard mailbox
+    // own-direct commit (k_search_own): the packed buffer holds pend_m < n entries (the slots other shards serve), the shard's own hits
+    // sit in h->anc as global ancestor ids (-1 elsewhere) and are gathered through it
+    bool pend_own = false; int64_t pend_m = 0;
+    bool own_direct = false;       // set by the library engine around its phase calls: gpf_shard_push_count resolves the own slots in place
     // trajectory store (gpf_history_enable): per recorded step the d latent columns in the step's final particle
     // order, and the composed ancestor map of the resamples that happened during that step (nullptr = identity)
     bool hist_on = false;
@@ -353,9 +357,23 @@ void launch_step_t(gpf_filter* h, int grid)
 {
     constexpr int Wc = row_width(Model<M>::D, KEEP);
     if constexpr ((PROP == 1 && !Model<M>::HAS_PROPOSAL) || (PROP == 2 && !Model<M>::HAS_STRATA)) { (void)h; (void)grid; return; }
+    else if (h->pending_packed && h->pend_own) {
+        // own-direct commit: the shard's own hits through the ancestor array FIRST (it reads anc[j] >= 0 / -1; the packed entries'
+        // launch behind it overwrites the -1 with the received ancestors), then the received entries; one weight vector, one slot array
+        const MaxSlots ms = next_slots(h);
+        PackedCommit pg{nullptr, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox, 1, h->cfg.gid0};
+        GPF_LAUNCH((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pg);
+        if (h->pend_m > 0) {
+            const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, nullptr, nullptr, (int)h->pend_mailbox, 0, 0};
+            g_ev_start = g_ev_stop = nullptr;                    // (timed(): the event pair belongs to the first launch)
+            GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP, true>), dim3(grid_for(h, h->pend_m, STEP_BLOCKS_PER_CU)), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                               h->cfg.gid0, h->pend_m, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pc);
+        }
+    }
     else if (h->pending_packed) {
         const MaxSlots ms = next_slots(h);
-        const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox};
+        const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox, 0, 0};
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pc);
     } else if (h->pending_gather && h->pending_search && PROP == 0) {
@@ -490,16 +508,25 @@ PrioView raw_view(const gpf_filter* h) { return PrioView{h->lw, nullptr, 0.0, 0}
 gpf_status materialize(gpf_filter* h)
 {
     if (h->pending_packed) {                                     // scatter the received exchange buffer by slot (+ log-ML update)
-        const int grid = grid_for(h, h->n, 8);
         double* out = h->rows[1 - h->cur];
+        const int64_t m = h->pend_own ? h->pend_m : h->n;
+        if (h->pend_own) {                                       // the shard's own hits first (anc[j] >= 0; the scatter below overwrites the -1 of the others)
+            const int go = grid_for(h, h->n * (h->W / 2), 8);
+            switch (h->W) {
+                case 2: GPF_LAUNCH((k_gather_own<2>), dim3(go), dim3(BLOCK), 0, h->stream, h->anc, h->cfg.gid0, h->rows[h->cur], out, h->lw, h->n); break;
+                case 4: GPF_LAUNCH((k_gather_own<4>), dim3(go), dim3(BLOCK), 0, h->stream, h->anc, h->cfg.gid0, h->rows[h->cur], out, h->lw, h->n); break;
+                case 8: GPF_LAUNCH((k_gather_own<8>), dim3(go), dim3(BLOCK), 0, h->stream, h->anc, h->cfg.gid0, h->rows[h->cur], out, h->lw, h->n); break;
+            }
+        }
+        const int grid = grid_for(h, std::max<int64_t>(m, 1), 8);
         switch (h->W) {
-            case 2: GPF_LAUNCH((k_commit_packed<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, h->n, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
-            case 4: GPF_LAUNCH((k_commit_packed<4>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, h->n, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
-            case 8: GPF_LAUNCH((k_commit_packed<8>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, h->n, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
+            case 2: GPF_LAUNCH((k_commit_packed<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, m, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
+            case 4: GPF_LAUNCH((k_commit_packed<4>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, m, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
+            case 8: GPF_LAUNCH((k_commit_packed<8>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, m, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
         }
         HIP_TRY(h, hipGetLastError());
         h->cur ^= 1;
-        h->pending_packed = false;
+        h->pending_packed = false; h->pend_own = false;
         h->max_valid = false;
         return GPF_OK;
     }
@@ -1446,7 +1473,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
     h->pending_gather = false; h->pending_fill = false;      // a pending resample gather was fused into this step
-    h->pending_packed = false;      // ... or a pending sharded commit
+    h->pending_packed = false; h->pend_own = false;      // ... or a pending sharded commit
     h->max_valid = true;
     h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
     h->epoch += 1;
@@ -2711,7 +2738,7 @@ static gpf_status push_args(gpf_handle h, int32_t method, const int64_t* tot_all
         HIP_TRY(h, hipMalloc(&h->push_stage, (size_t)h->cfg.n_global * sizeof(ulonglong2)));
         h->push_cap = h->cfg.n_global;
     }
-    a.extra = h->push_extra; a.pv = h->push_pv;
+    a.extra = h->push_extra; a.pv = h->push_pv; a.skip_own = 0;
     a.wait_tot = mb_wait(h, MB_TOT);
     a.wait_cr = method == GPF_RESAMPLE_RESIDUAL ? mb_wait(h, MB_CR) : MboxWait{};
     a.tot_all = tot_all; a.cr_all = method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr; a.stage = h->push_stage; a.counts = h->shard_counts; a.host_counts = h->h_shard_counts; a.ticket = h->push_ticket;
@@ -2744,6 +2771,23 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
 #define PUSH_SCAN_BLOCKS_PER_CU 8
 #endif
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.nchunks, (int64_t)h->n_cu * PUSH_SCAN_BLOCKS_PER_CU));
+    a.skip_own = h->own_direct ? 1 : 0;
+    if (h->own_direct) {
+        // the shard's own slots: ancestors in place (k_search_own), nothing staged or packed for them; pass 1 walks the other shards' slots
+        // only -- with one shard there are none
+        const CdfLevels lw_ = levels(h, 0);
+        const int gso = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + GPF_MULTI_NS * SBLOCK - 1) / (GPF_MULTI_NS * SBLOCK), (int64_t)h->n_cu));
+        const size_t lds = multi_lds_bytes(h->ntiles, lw_.logg);
+        s = timed(h, GPF_K_SEARCH, [&] {
+            if (lw_.logg == 0) GPF_LAUNCH((k_search_own<0>), dim3(gso), dim3(SBLOCK), lds, h->stream, a, lw_, h->n, h->ntiles, h->cfg.gid0, h->anc);
+            else               GPF_LAUNCH((k_search_own<1>), dim3(gso), dim3(SBLOCK), lds, h->stream, a, lw_, h->n, h->ntiles, h->cfg.gid0, h->anc);
+        });
+        if (s) return s;
+        if (G > 1) GPF_LAUNCH((k_push_scan<0>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a);
+        HIP_TRY(h, hipGetLastError());
+        h->push_counted = true;
+        return GPF_OK;
+    }
     s = timed(h, GPF_K_SEARCH, [&] {
         if (method == GPF_RESAMPLE_MULTINOMIAL) GPF_LAUNCH((k_push_scan<0>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a);
         else                                    GPF_LAUNCH((k_push_scan<1>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a);
@@ -2828,7 +2872,8 @@ gpf_status gpf_shard_commit(gpf_handle h, const double* packed, int64_t m, const
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!packed || !mf_all || !tot_all || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
-    if (m != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "a shard must receive exactly one entry per output slot");
+    if (m != h->n && !(h->own_direct && m >= 0 && m <= h->n)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "a shard must receive exactly one entry per output slot");
+    h->pend_own = h->own_direct; h->pend_m = m;                  // (own-direct engine: m entries from the other shards, the rest through h->anc)
     // Deferred like the single-GPU gather: the next gpf_update propagates the entries straight out of
     // the exchange buffer into their slots (k_step<PACKED>); any other consumer scatters first (materialize()).
     // packed / mf_all / tot_all must stay alive and unchanged until then (the caller keeps them until the next commit).
@@ -3261,6 +3306,14 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     if (exchange && (s = ensure(h->sh_recv, h->sh_recv_cap, n))) return s;
     const bool pull = h->shard_plan_kind == GPF_SHARD_PLAN_PULL && method != GPF_RESAMPLE_STRATIFIED;
     if (pull && (s = pull_buffers(h, G))) return s;
+    // Own-direct (multinomial, push plan, no priorities): a slot of this shard whose target falls into this shard's own part of the CDF is
+    // resolved in place -- its ancestor goes into h->anc and the next propagate gathers the row through it, as on an unsharded filter;
+    // only the slots other shards serve travel as packed entries.  On one rank nothing is staged, packed, counted or waited for.
+    static const bool own_off = getenv("GPF_SHARD_OWN") && !strcmp(getenv("GPF_SHARD_OWN"), "0");        // (A/B measurements; tests of the packed path)
+    const bool own = !own_off && method == GPF_RESAMPLE_MULTINOMIAL && !prio && !pull && multi_logg(h->ntiles) >= 0 &&
+                     multi_lds_bytes(h->ntiles, multi_logg(h->ntiles)) + 4096 <= (size_t)160 * 1024;
+    struct OwnScope { gpf_filter* h; ~OwnScope() { h->own_direct = false; } } own_scope{h};
+    h->own_direct = own;
 
     const double* raw_mf = nullptr; const int64_t* raw_tot = nullptr;
     struct PushScope { gpf_filter* h; ~PushScope() { h->push_extra = 0; } } push_scope{h};
@@ -3303,10 +3356,13 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
     } else {
         if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
+        if (own && G == 1) { counts[0] = 0; counts[1] = n; }     // one shard, own-direct: every slot is an own hit, nothing to push or to wait for
+        else {
         // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
         // counts say it overflowed
         if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
         if ((s = gpf_shard_counts(h, G, counts.data()))) return s;   // ONE host wait (the exchange's split sizes), behind phase 4
+        }
         for (int g = 0; g < G; ++g) { n_send += counts[g]; n_recv += counts[G + g]; }
     }
     // From here on a local failure is REMEMBERED and the rank still joins the exchange with the counts its peers expect (they
@@ -3338,6 +3394,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         int64_t so = 0, ro = 0, self_so = -1, self_ro = -1;
         note(g_rccl.GroupStart(), "ncclGroupStart");
         for (int g = 0; g < G; ++g) {
+            if (g == me && own) continue;                         // own hits never enter the buffers (counts[me] = 0; counts[G + me] of them sit in h->anc)
             if (g == me && !(force && G == 1)) { self_so = so; self_ro = ro; }
             else {
                 if (counts[g]) note(g_rccl.Send(h->sh_send + so * E, (size_t)(counts[g] * E), ncclDouble, g, h->comm, h->stream), "ncclSend");
@@ -3354,7 +3411,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         }
     }
     if (late) { h->err = late_msg; return late; }
-    if (!prio) return gpf_shard_commit(h, commit_from, n, h->cur_mf_all, tot_all, G);                // phase 5 (deferred)
+    if (!prio) return gpf_shard_commit(h, commit_from, own ? n - counts[(size_t)G + me] : n, h->cur_mf_all, tot_all, G);   // phase 5 (deferred)
     // phase 5 of a prioritised resample, at once: scatter rows / parents / log_ws, log-ML from the raw summary ...
     {
         const int grid = grid_for(h, n, 8);
