@@ -163,6 +163,10 @@ struct ScanExtras {            // optional side jobs of a scan launch
     // protocol here (an agent-scope fence at the end of a kernel that has written 10 MB writes the XCD's L2 back: measured, +30 us):
     // every workgroup leaves its limb partials as TAGGED words (tag << 48 | sum, relaxed agent-scope stores), the workgroup that
     // held the last tile -- it owns S -- waits for the words of this launch's tag, folds them and stores the summary.
+    // sharded scans (MODE 3 / 4), fused first summary: the launch folds the maximum slots itself, workgroup 0 leaves (max, flags) in mf_out
+    // and pushes it to the peers' mailboxes, every workgroup then waits for the peers' pairs -- the separate k_pack_mflags launch (4.5 us)
+    // is gone.  mf_me = this shard's index among the gathered pairs (its own pair is the fold, never read back).
+    int fuse_mf; int mf_me; double* mf_out; MboxPush mf_push;
     SortedGammaJob sp;         // sp.blocks > 0: the LAST sp.blocks workgroups of the launch compute the tile totals of a sorted multinomial resample
     int64_t* q_host;           // pinned [8]: flags, S, Ql0..3, ticket, check word; nullptr: untagged partials, folded later (k_publish_scalars / k_export_q)
     int64_t q_ticket;
@@ -215,11 +219,22 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
         if constexpr (MODE >= 3) {
             // the np <= 64 gathered (max, flags) pairs: one lane each, in every wave (system-scope loads: the pairs may sit in this
             // rank's mailbox, written by its peers), folded across the wave
+            double m0 = 0.0; int f0 = 0;
+            if (ex.fuse_mf) {                                         // kernel-uniform
+                fold_slots(slots, m0, f0);
+                f0 &= FLAG_NAN | FLAG_POSINF;
+                if (blockIdx.x == 0 && wave_id() == 0) {
+                    if (lane_id() == 0) { ex.mf_out[0] = m0; ex.mf_out[1] = (double)f0; }
+                    const uint64_t words[2] = {d2u(m0), d2u((double)f0)};
+                    mbox_push_wave(ex.mf_push, words);
+                }
+            }
             mbox_wait_block(ex.wait);
             const int g = lane_id();
             const bool mb = ex.wait.tags != nullptr;
-            m = g < np ? ld_gathered(mf_all + 2 * g, mb) : -__builtin_huge_val();
-            f = g < np ? (int)ld_gathered(mf_all + 2 * g + 1, mb) : 0;
+            const bool self = ex.fuse_mf && g == ex.mf_me;            // (the own pair: the fold above, not the array another workgroup is writing)
+            m = g < np ? (self ? m0 : ld_gathered(mf_all + 2 * g, mb)) : -__builtin_huge_val();
+            f = g < np ? (self ? f0 : (int)ld_gathered(mf_all + 2 * g + 1, mb)) : 0;
             m = wave_max_f64(m);
 #pragma unroll
             for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);

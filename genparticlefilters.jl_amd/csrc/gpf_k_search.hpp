@@ -115,11 +115,13 @@ struct ShardPlan {
     uint64_t t_off;                                                   // where this shard's CDF starts in the global one
     int32_t n_shards, pad;
     int64_t bounds[MAX_SHARDS + 1];                                   // first global slot of every shard (the packed entries name slots inside their shard)
+    int64_t own_range[2];                                             // the slots of THIS shard (local indices) that it serves itself: [lo, hi)
 };
 // k_search_strat on a shard packs the exchange entries itself: [row | slot inside its shard << 32 | global ancestor id]
 // extra = 1 (a prioritised resample, priority_fn = w -> alpha w, resample.jl:51-52): one more double per entry, log_ws = lw[a] - lp[a]
 // (update_weights!, resample.jl:198) -- the receiver does not hold its ancestors' weights
-struct PackOut { const double* rows; double* packed; int64_t capacity, gid0; int W; int extra; PrioView pv; };
+struct PackOut { const double* rows; double* packed; int64_t capacity, gid0; int W; int extra; PrioView pv;
+                 int32_t* own_anc; int me; };   // own_anc != nullptr: entries for shard `me` itself are not packed -- their GLOBAL ancestor id goes to own_anc[slot inside the shard]
 struct SearchArgs {
     CdfLevels w;                                                      // weights (or residual weights for the tail)
     CdfLevels c;                                                      // residual: copy counts
@@ -1244,6 +1246,10 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
             const int64_t jg = sbase + e;
             while (lo < G - 1 && s_bnd[lo + 1] <= jg) ++lo;
             const int64_t i = s_mark[k * MBLOCK + tid];
+            if (a.pack.own_anc && lo == a.pack.me) {                  // this shard's own slot: no packed entry, the ancestor in place
+                a.pack.own_anc[jg - s_bnd[lo]] = (int32_t)(a.pack.gid0 + i);
+                continue;
+            }
             const double2* src = reinterpret_cast<const double2*>(a.pack.rows + i * W);
             double* dst = a.pack.packed + e * (W + 1 + a.pack.extra);
             if (a.pack.extra) dst[W + 1] = a.pack.pv.lw[i] - a.pack.pv.at(i);

@@ -329,16 +329,19 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_search_own(PushArgs a, CdfLevels 
         atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + (a.G + threadIdx.x) * COUNT_STRIDE), (unsigned long long)s_recv[threadIdx.x]);
 }
 // materialize() of a commit with own hits: rows_out[j] = rows_in[anc[j] - gid0], lw[j] = 0 for the slots with anc[j] >= 0
+// (own_range != nullptr: the own hits are the slots [own_range[0], own_range[1]) -- stratified resampling; else the slots with anc >= 0)
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_gather_own(const int32_t* __restrict__ anc, int64_t gid0, const double* __restrict__ rows_in,
-                                                      double* __restrict__ rows_out, double* __restrict__ lw, int64_t n)
+                                                      double* __restrict__ rows_out, double* __restrict__ lw, int64_t n, const int64_t* __restrict__ own_range)
 {
     constexpr int C = W / 2;
+    const int64_t lo = own_range ? own_range[0] : 0, hi = own_range ? own_range[1] : n;
     for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * BLOCK) {
         const int64_t j = t / C;
         const int c = (int)(t - j * C);
+        if (j < lo || j >= hi) continue;
         const int32_t a = anc[j];
-        if (a < 0) continue;
+        if (!own_range && a < 0) continue;
         reinterpret_cast<double2*>(rows_out)[t] = reinterpret_cast<const double2*>(rows_in)[((int64_t)a - gid0) * C + c];
         if (c == 0) lw[j] = 0.0;                                                     // update_weights!, resample.jl:195
     }
@@ -533,6 +536,7 @@ __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
         const int64_t r0 = F[h] > a.bounds[a.me] ? F[h] : a.bounds[a.me], r1 = F[h + 1] < a.bounds[a.me + 1] ? F[h + 1] : a.bounds[a.me + 1];
         const int64_t ns = s1 > s0 ? s1 - s0 : 0, nr = r1 > r0 ? r1 - r0 : 0;
         a.counts[h * COUNT_STRIDE] = ns; a.counts[(a.G + h) * COUNT_STRIDE] = nr;
+        if (h == a.me) { plan->own_range[0] = nr > 0 ? r0 - a.bounds[a.me] : 0; plan->own_range[1] = nr > 0 ? r1 - a.bounds[a.me] : 0; }
         if (a.host_counts) {
             __hip_atomic_store(a.host_counts + h, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(a.host_counts + a.G + h, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

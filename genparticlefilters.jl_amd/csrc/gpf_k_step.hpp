@@ -95,6 +95,7 @@ struct PackedCommit {
     // slots this shard serves itself and -1 for the slots whose rows arrive packed (skipped here); sc != nullptr: this launch carries
     // the log-ML update from the gathered summaries
     int masked; int64_t anc_off;
+    const int64_t* own_range;  // masked == 2 (stratified): the own hits are the slots [own_range[0], own_range[1]) instead of the slots with anc >= 0
 };
 template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false, bool BLK = false>
 __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
@@ -131,7 +132,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
             pc.anc[i] = (int32_t)(meta & 0xffffffffull);
         } else {
         int64_t srow = GATHER ? (int64_t)anc[i] : i;
-        if (GATHER && pc.masked) { if (srow < 0) continue; srow -= pc.anc_off; }     // (kernel-uniform flag; the slot's row arrives packed)
+        if (GATHER && pc.masked) {                                                   // (kernel-uniform flag; the other slots' rows arrive packed)
+            if (pc.masked == 2 ? (i < pc.own_range[0] || i >= pc.own_range[1]) : srow < 0) continue;
+            srow -= pc.anc_off;
+        }
         const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
 #pragma unroll
         for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }

@@ -104,8 +104,10 @@ struct gpf_filter {
     bool pend_mailbox = false;     // pend_mf / pend_tot sit in the shard mailbox
     // own-direct commit (k_search_own): the packed buffer holds pend_m < n entries (the slots other shards serve), the shard's own hits
     // sit in h->anc as global ancestor ids (-1 elsewhere) and are gathered through it
-    bool pend_own = false; int64_t pend_m = 0;
+    bool pend_own = false; int64_t pend_m = 0; bool pend_own_range = false;   // (own hits named by ShardPlan::own_range: stratified)
+    double* fuse_mf_out = nullptr; // set by shard_summary around gpf_shard_weight_scan: the scan produces / pushes the (max, flags) summary itself
     bool own_direct = false;       // set by the library engine around its phase calls: gpf_shard_push_count resolves the own slots in place
+    bool own_direct_range = false; // ... stratified: the own hits are one slot range (ShardPlan::own_range), written by k_search_strat's pack loop
     // trajectory store (gpf_history_enable): per recorded step the d latent columns in the step's final particle
     // order, and the composed ancestor map of the resamples that happened during that step (nullptr = identity)
     bool hist_on = false;
@@ -361,11 +363,12 @@ void launch_step_t(gpf_filter* h, int grid)
         // own-direct commit: the shard's own hits through the ancestor array FIRST (it reads anc[j] >= 0 / -1; the packed entries'
         // launch behind it overwrites the -1 with the received ancestors), then the received entries; one weight vector, one slot array
         const MaxSlots ms = next_slots(h);
-        PackedCommit pg{nullptr, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox, 1, h->cfg.gid0};
+        PackedCommit pg{nullptr, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox, h->pend_own_range ? 2 : 1, h->cfg.gid0,
+                        h->pend_own_range ? h->shard_plan->own_range : nullptr};
         GPF_LAUNCH((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pg);
         if (h->pend_m > 0) {
-            const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, nullptr, nullptr, (int)h->pend_mailbox, 0, 0};
+            const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, nullptr, nullptr, (int)h->pend_mailbox, 0, 0, nullptr};
             g_ev_start = g_ev_stop = nullptr;                    // (timed(): the event pair belongs to the first launch)
             GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP, true>), dim3(grid_for(h, h->pend_m, STEP_BLOCKS_PER_CU)), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                                h->cfg.gid0, h->pend_m, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pc);
@@ -373,7 +376,7 @@ void launch_step_t(gpf_filter* h, int grid)
     }
     else if (h->pending_packed) {
         const MaxSlots ms = next_slots(h);
-        const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox, 0, 0};
+        const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox, 0, 0, nullptr};
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pc);
     } else if (h->pending_gather && h->pending_search && PROP == 0) {
@@ -512,10 +515,11 @@ gpf_status materialize(gpf_filter* h)
         const int64_t m = h->pend_own ? h->pend_m : h->n;
         if (h->pend_own) {                                       // the shard's own hits first (anc[j] >= 0; the scatter below overwrites the -1 of the others)
             const int go = grid_for(h, h->n * (h->W / 2), 8);
+            const int64_t* own_rng = h->pend_own_range ? h->shard_plan->own_range : nullptr;
             switch (h->W) {
-                case 2: GPF_LAUNCH((k_gather_own<2>), dim3(go), dim3(BLOCK), 0, h->stream, h->anc, h->cfg.gid0, h->rows[h->cur], out, h->lw, h->n); break;
-                case 4: GPF_LAUNCH((k_gather_own<4>), dim3(go), dim3(BLOCK), 0, h->stream, h->anc, h->cfg.gid0, h->rows[h->cur], out, h->lw, h->n); break;
-                case 8: GPF_LAUNCH((k_gather_own<8>), dim3(go), dim3(BLOCK), 0, h->stream, h->anc, h->cfg.gid0, h->rows[h->cur], out, h->lw, h->n); break;
+                case 2: GPF_LAUNCH((k_gather_own<2>), dim3(go), dim3(BLOCK), 0, h->stream, h->anc, h->cfg.gid0, h->rows[h->cur], out, h->lw, h->n, own_rng); break;
+                case 4: GPF_LAUNCH((k_gather_own<4>), dim3(go), dim3(BLOCK), 0, h->stream, h->anc, h->cfg.gid0, h->rows[h->cur], out, h->lw, h->n, own_rng); break;
+                case 8: GPF_LAUNCH((k_gather_own<8>), dim3(go), dim3(BLOCK), 0, h->stream, h->anc, h->cfg.gid0, h->rows[h->cur], out, h->lw, h->n, own_rng); break;
             }
         }
         const int grid = grid_for(h, std::max<int64_t>(m, 1), 8);
@@ -2634,11 +2638,21 @@ static gpf_status shard_ready(gpf_handle h)
     return GPF_OK;
 }
 
+static gpf_status shard_max_slots(gpf_handle h);
 gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!out2) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
+    if ((s = shard_max_slots(h))) return s;
+    GPF_LAUNCH(k_pack_mflags, dim3(1), dim3(BLOCK), 0, h->stream, h->mslots[h->mcur], out2, mb_begin(h, MB_MF));
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+// the maximum slots describe the weights to summarise (the producer's slots, or one k_max_partial pass)
+static gpf_status shard_max_slots(gpf_handle h)
+{
+    gpf_status s;
     if ((s = materialize(h))) return s;
     const PrioView pv = h->sum_pv_set ? h->sum_pv : raw_view(h);  // (the engine's prioritised resample summarises alpha lw and log_ws too)
     if (!h->max_valid || h->sum_pv_set) {
@@ -2649,8 +2663,6 @@ gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
         if (s) return s;
         h->max_valid = !h->sum_pv_set;
     }
-    GPF_LAUNCH(k_pack_mflags, dim3(1), dim3(BLOCK), 0, h->stream, h->mslots[h->mcur], out2, mb_begin(h, MB_MF));
-    HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
 
@@ -2677,6 +2689,10 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     // {S, limbs} stores them into every peer's mailbox (the scan's last workgroup, or k_export_q when the limbs are wanted)
     ScanExtras ex{h->shard_counts, h->h_flags, h->flag_ticket, 0};
     ex.zero_stride = COUNT_STRIDE;
+    if (h->fuse_mf_out) {                                        // (library engine: the scan produces and pushes the first summary itself)
+        ex.fuse_mf = 1; ex.mf_me = h->comm_rank; ex.mf_out = h->fuse_mf_out; ex.mf_push = mb_begin(h, MB_MF);
+        if (h->mb_active && h->mb_engine) mf_all = static_cast<const double*>(mb_gathered(h, MB_MF));   // the round that has just begun
+    }
     ex.wait = mb_wait(h, MB_MF);
     const MboxPush tot_push = mb_begin(h, MB_TOT);
     if (want_q) {
@@ -2836,7 +2852,7 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
         sa.n = cap; sa.n_cells = h->n; sa.n_global = h->cfg.n_global; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
         sa.K = h->K; sa.logN = h->logN; sa.anc = nullptr; sa.invN = 1.0 / (double)h->cfg.n_global;
         sa.update_lml = 0;                                            // the commit carries the log-ML update
-        sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W, h->push_extra, h->push_pv};
+        sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W, h->push_extra, h->push_pv, h->own_direct ? h->anc : nullptr, (int)me};
         s = timed(h, GPF_K_GATHER, [&] {
             GPF_LAUNCH((k_search_strat<false>), dim3((unsigned)((cap + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa);
         });
@@ -2874,6 +2890,7 @@ gpf_status gpf_shard_commit(gpf_handle h, const double* packed, int64_t m, const
     if (!packed || !mf_all || !tot_all || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     if (m != h->n && !(h->own_direct && m >= 0 && m <= h->n)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "a shard must receive exactly one entry per output slot");
     h->pend_own = h->own_direct; h->pend_m = m;                  // (own-direct engine: m entries from the other shards, the rest through h->anc)
+    h->pend_own_range = h->own_direct && h->own_direct_range;
     // Deferred like the single-GPU gather: the next gpf_update propagates the entries straight out of
     // the exchange buffer into their slots (k_step<PACKED>); any other consumer scatters first (materialize()).
     // packed / mf_all / tot_all must stay alive and unchanged until then (the caller keeps them until the next commit).
@@ -2990,10 +3007,21 @@ gpf_status shard_summary(gpf_filter* h, int want_q)
     const bool alias = h->sh_mf_all == h->sh_mf;                 // one shard without communicator
     double* mf = h->sh_mf + 2 * r; int64_t* tot = h->sh_tot + 5 * r;
     double* mf_all = alias ? mf : h->sh_mf_all + 2 * G * r; int64_t* tot_all = alias ? tot : h->sh_tot_all + 5 * G * r;
-    if ((s = gpf_shard_weight_max(h, mf))) return s;
+    // One shard without a communicator: the first summary -- (max, flags) -- is folded inside the scan's launch (no k_pack_mflags launch).
+    // With the mailboxes the same fusion is possible (GPF_SHARD_FUSE_MF=1: the scan's workgroup 0 pushes, every workgroup waits) and was
+    // measured SLOWER on one rank (+6 us per step: the push's system-scope stores land on the critical path of every scan workgroup instead
+    // of in an earlier launch), so the separate launch stays; as an RCCL all-gather the summary needs its own launch ahead of the collective.
+    static const bool fuse_mb = getenv("GPF_SHARD_FUSE_MF") && !strcmp(getenv("GPF_SHARD_FUSE_MF"), "1");
+    const bool fuse = alias || (mb && fuse_mb);
+    if (fuse) { if ((s = shard_ready(h)) || (s = shard_max_slots(h))) return s; }
+    else if ((s = gpf_shard_weight_max(h, mf))) return s;
     if (!mb && !alias && (s = shard_all_gather(h, mf, mf_all, 2, ncclDouble, sizeof(double)))) return s;
-    h->cur_mf_all = mb ? static_cast<const double*>(mb_gathered(h, MB_MF)) : mf_all;
-    if ((s = gpf_shard_weight_scan(h, h->cur_mf_all, h->comm_world, want_q, tot))) return s;
+    struct FuseScope { gpf_filter* h; ~FuseScope() { h->fuse_mf_out = nullptr; } } fuse_scope{h};
+    h->fuse_mf_out = fuse ? mf : nullptr;
+    // (fused: MB_MF's round begins inside gpf_shard_weight_scan -- name the gathered array after it)
+    if (!fuse) h->cur_mf_all = mb ? static_cast<const double*>(mb_gathered(h, MB_MF)) : mf_all;
+    if ((s = gpf_shard_weight_scan(h, fuse ? mf_all : h->cur_mf_all, h->comm_world, want_q, tot))) return s;      // (fused + mailboxes: the callee names the gathered array)
+    if (fuse) h->cur_mf_all = mb ? static_cast<const double*>(mb_gathered(h, MB_MF)) : mf_all;
     if (!mb && !alias && (s = shard_all_gather(h, tot, tot_all, 5, ncclInt64, sizeof(int64_t)))) return s;
     h->cur_tot_all = mb ? static_cast<const int64_t*>(mb_gathered(h, MB_TOT)) : tot_all;
     return GPF_OK;
@@ -3310,10 +3338,11 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     // resolved in place -- its ancestor goes into h->anc and the next propagate gathers the row through it, as on an unsharded filter;
     // only the slots other shards serve travel as packed entries.  On one rank nothing is staged, packed, counted or waited for.
     static const bool own_off = getenv("GPF_SHARD_OWN") && !strcmp(getenv("GPF_SHARD_OWN"), "0");        // (A/B measurements; tests of the packed path)
-    const bool own = !own_off && method == GPF_RESAMPLE_MULTINOMIAL && !prio && !pull && multi_logg(h->ntiles) >= 0 &&
-                     multi_lds_bytes(h->ntiles, multi_logg(h->ntiles)) + 4096 <= (size_t)160 * 1024;
-    struct OwnScope { gpf_filter* h; ~OwnScope() { h->own_direct = false; } } own_scope{h};
-    h->own_direct = own;
+    const bool own = !own_off && !prio && ((method == GPF_RESAMPLE_MULTINOMIAL && !pull && multi_logg(h->ntiles) >= 0 &&
+                                            multi_lds_bytes(h->ntiles, multi_logg(h->ntiles)) + 4096 <= (size_t)160 * 1024) ||
+                                           method == GPF_RESAMPLE_STRATIFIED);
+    struct OwnScope { gpf_filter* h; ~OwnScope() { h->own_direct = false; h->own_direct_range = false; } } own_scope{h};
+    h->own_direct = own; h->own_direct_range = own && method == GPF_RESAMPLE_STRATIFIED;
 
     const double* raw_mf = nullptr; const int64_t* raw_tot = nullptr;
     struct PushScope { gpf_filter* h; ~PushScope() { h->push_extra = 0; } } push_scope{h};
@@ -3356,7 +3385,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
     } else {
         if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
-        if (own && G == 1) { counts[0] = 0; counts[1] = n; }     // one shard, own-direct: every slot is an own hit, nothing to push or to wait for
+        if (own && G == 1 && method == GPF_RESAMPLE_MULTINOMIAL) { counts[0] = 0; counts[1] = n; }     // one shard, own-direct: every slot is an own hit, nothing to push or to wait for
         else {
         // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
         // counts say it overflowed
@@ -3394,7 +3423,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         int64_t so = 0, ro = 0, self_so = -1, self_ro = -1;
         note(g_rccl.GroupStart(), "ncclGroupStart");
         for (int g = 0; g < G; ++g) {
-            if (g == me && own) continue;                         // own hits never enter the buffers (counts[me] = 0; counts[G + me] of them sit in h->anc)
+            if (g == me && own) { so += counts[g]; continue; }    // own hits never enter the exchange (their places in the send buffer stay unused; counts[G + me] of them sit in h->anc)
             if (g == me && !(force && G == 1)) { self_so = so; self_ro = ro; }
             else {
                 if (counts[g]) note(g_rccl.Send(h->sh_send + so * E, (size_t)(counts[g] * E), ncclDouble, g, h->comm, h->stream), "ncclSend");
