@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 N_SEEDS = int(os.environ.get("GPF_FUZZ_SEEDS", "12"))           # GPF_FUZZ_SEEDS=300 for a longer hunt
 OFFSET = int(os.environ.get("GPF_FUZZ_OFFSET", "0"))             # ... GPF_FUZZ_OFFSET=100000 for other sequences
 METHODS = ["multinomial", "residual", "stratified"]
+RES_METHODS = METHODS + ["multinomial_sorted"]              # whole-filter and view resamples also draw the opt-in sorted multinomial
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from test_gpu_blocks import oracle_blocks, oracle_rejuvenate_blocks, oracle_update_blocks  # noqa: E402
 
@@ -57,6 +58,7 @@ def test_random_api_sequences(g, o, seed):
     hist = seed % 4 == 3                                              # every fourth run keeps the trajectory store
     st = g.pf_initialize(model, (1,), ys[0], N, seed=seed + 5, keep_prev=True, history=T + 2 if hist else 0)
     orc = o.OracleFilter(model.model_id, model.params, N, seed + 5, keep_prev=True, history=hist).initialize(ys[0])
+    st.set_lazy_search(bool(seed % 2))                                # every other run leaves the multinomial search to the update that follows
     t = 1
     log = []
     blk = None                                                        # (block size, observation rows) while the latest observations are per block
@@ -116,7 +118,7 @@ def test_random_api_sequences(g, o, seed):
             t += 1
             blk = None                                                  # one observation for all particles again
         elif op == "resample":
-            m = str(rng.choice(METHODS)); alpha = None if rng.random() < 0.6 else (0.5 if rng.random() < 0.6 else "closure")
+            m = str(rng.choice(RES_METHODS)); alpha = None if rng.random() < 0.6 else (0.5 if rng.random() < 0.6 else "closure")
             kw = {"sort_particles": bool(rng.random() < 0.5)} if m == "stratified" else {}
             closure = lambda w: 0.25 * w - 0.125 * np.abs(w) ** 0.5      # an arbitrary priority_fn: evaluated by the host (resample.jl:51-52)
             if alpha == "closure":
@@ -176,7 +178,12 @@ def test_random_api_sequences(g, o, seed):
             stride = 1 if (op == "whole_view" or rng.random() < 0.5) else int(rng.integers(2, 8))      # state[a:stride:b] (view.jl:35-48)
             if len(range(a, b, stride)) < 2:
                 continue
-            sv, ov = st[a:b:stride], orc[a:b:stride]
+            if op == "view" and rng.random() < 0.3:                    # state[idxs] over an arbitrary vector of distinct indices (view.jl:35-48)
+                ix = rng.permutation(n)[:max(2, int(rng.integers(2, min(n, 5000) + 1)))]
+                sv, ov = st[ix], orc[ix]
+                stride = f"index vector of {ix.size}"
+            else:
+                sv, ov = st[a:b:stride], orc[a:b:stride]
             sub = rng.choice(["update", "resample", "rejuvenate"])
             if sub == "rejuvenate" and blk == "lost":
                 sub = "resample"
@@ -187,7 +194,7 @@ def test_random_api_sequences(g, o, seed):
             if sub == "update":
                 g.pf_update(sv, (t + 1,), (None,), ys[t]); ov.update(ys[t])          # (only the view's particles advance)
             elif sub == "resample":
-                m = str(rng.choice(METHODS)); kw = {"sort_particles": bool(rng.random() < 0.5)} if m == "stratified" else {}
+                m = str(rng.choice(RES_METHODS)); kw = {"sort_particles": bool(rng.random() < 0.5)} if m == "stratified" else {}
                 if both(lambda: g.pf_resample(sv, m, check="warn", **kw), lambda: ov.resample(m, check="warn", **kw), log[-4:]):
                     st.close()
                     return
