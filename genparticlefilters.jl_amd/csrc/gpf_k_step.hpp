@@ -42,6 +42,59 @@ __device__ __forceinline__ int stratum_of(const ModelArgs& a, uint64_t seed, uin
     return (int)mulhi64(u64(b.w0, b.w1), (uint64_t)K);
 }
 
+// ---- wide rows (W = 8: 64 bytes, the bearings model with x_{t-1}): a lane that reads its own row issues W / 2 16-byte loads 64 bytes
+// apart from its neighbours' -- every wave-instruction touches 32-64 different 128-byte lines and uses a quarter of each.  Here the wave
+// moves its 64 rows COOPERATIVELY: W / 2 adjacent lanes fetch one row (64 contiguous bytes per row, whole kilobytes per instruction
+// when the rows are consecutive) into the wave's LDS strip, then every lane reads its own row from LDS (pitch W / 2 + 1 sixteen-byte
+// words: no bank conflicts); the stores go the other way.  All 64 lanes take part (callers loop wave-uniformly).
+template <int W> struct RowStage {
+    static constexpr int C = W / 2, PITCH = C + 1, RPI = WAVE / C;        // 16-byte parts per row, LDS pitch, rows per wave-instruction
+    static constexpr int WORDS = WAVE * PITCH;                            // double2 words per wave
+};
+// r[0..W) = row `srow` of rows_in for the calling lane (srow >= 0; any valid row for lanes that have no particle)
+template <int W>
+__device__ __forceinline__ void wave_rows_load(const double* __restrict__ rows_in, int64_t srow, double2* lds_wave, double (&r)[W])
+{
+    using RS = RowStage<W>;
+    const int lane = lane_id(), part = lane % RS::C, sub = lane / RS::C;
+    const int lo = (int)(uint32_t)srow, hi = (int)(uint32_t)((uint64_t)srow >> 32);
+    double2 v[RS::C];
+#pragma unroll
+    for (int c = 0; c < RS::C; ++c) {
+        const int rr = c * RS::RPI + sub;                                 // the row this lane helps to fetch
+        const int64_t src = (int64_t)(((uint64_t)(uint32_t)__shfl(hi, rr, WAVE) << 32) | (uint32_t)__shfl(lo, rr, WAVE));
+        v[c] = reinterpret_cast<const double2*>(rows_in + src * W)[part];
+    }
+#pragma unroll
+    for (int c = 0; c < RS::C; ++c) lds_wave[(c * RS::RPI + sub) * RS::PITCH + part] = v[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < RS::C; ++q) { const double2 t = lds_wave[lane * RS::PITCH + q]; r[2 * q] = t.x; r[2 * q + 1] = t.y; }
+    __builtin_amdgcn_wave_barrier();
+}
+// rows_out[i0 + lane] = o for the lanes with i0 + lane < n
+template <int W>
+__device__ __forceinline__ void wave_rows_store(double* __restrict__ rows_out, int64_t i0, int64_t n, double2* lds_wave, const double (&o)[W])
+{
+    using RS = RowStage<W>;
+    const int lane = lane_id(), part = lane % RS::C, sub = lane / RS::C;
+#pragma unroll
+    for (int q = 0; q < RS::C; ++q) lds_wave[lane * RS::PITCH + q] = make_double2(o[2 * q], o[2 * q + 1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < RS::C; ++c) {
+        const int rr = c * RS::RPI + sub;
+        const double2 t = lds_wave[rr * RS::PITCH + part];
+        if (i0 + rr < n) reinterpret_cast<double2*>(rows_out + (i0 + rr) * W)[part] = t;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+#ifndef GPF_STAGE_ROWS
+#define GPF_STAGE_ROWS 1
+#endif
+
 // pf_initialize (initialize.jl:39-41) / pf_update! (update.jl:15-22): one lane per particle, row in,
 // row out, lw += log p(y|x).  Counter-based RNG: no RNG state in memory.
 // MODE 0: the model's own sampler; 1: native custom proposal; 2: stratified (the discrete latent constrained per stratum);
@@ -120,9 +173,25 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
             pc.sc->lml_est = pc.sc->lml_est + (lse_from(mx, S, pc.K, f) - pc.logN);
         }
     }
-    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < n; e += (int64_t)gridDim.x * BLOCK) {
+    constexpr bool STAGE = GPF_STAGE_ROWS && W >= 8 && !PACKED;          // wide rows travel through the wave's LDS strip (wave_rows_load / _store)
+    __shared__ double2 s_stage[STAGE ? NWAVES * RowStage<W>::WORDS : 1];
+    double2* const lds_wave = s_stage + (STAGE ? wave_id() * RowStage<W>::WORDS : 0);
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; STAGE ? e - lane_id() < n : e < n; e += (int64_t)gridDim.x * BLOCK) {
         int64_t i = e;                                  // the slot this lane fills
+        const bool live = !STAGE || e < n;              // (STAGE: the whole wave stays in the loop; lanes beyond n help to move rows)
+        if (!live) i = 0;
+        bool act = true;
         double r[W];
+        if constexpr (STAGE) {
+            int64_t srow = live ? (GATHER ? (int64_t)anc[i] : i) : 0;
+            bool skip = false;
+            if (GATHER && pc.masked) {
+                skip = live && (pc.masked == 2 ? (i < pc.own_range[0] || i >= pc.own_range[1]) : srow < 0);
+                srow = skip ? 0 : srow - (live ? pc.anc_off : 0);
+            }
+            wave_rows_load<W>(rows_in, srow, lds_wave, r);
+            act = live && !skip;                        // (a lane without a particle -- or whose row arrives packed -- computes on row 0 and writes nothing)
+        } else
         if constexpr (PACKED) {
             const double* src = pc.packed + e * (W + 1);
 #pragma unroll
@@ -161,9 +230,13 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
 #pragma unroll
             for (int k = 0; k < D; ++k) o[D + k] = r[k];
         }
-        double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
+        if (STAGE && !(GATHER && pc.masked)) wave_rows_store<W>(rows_out, e - lane_id(), n, lds_wave, o);     // (kernel-uniform condition)
+        else if (act) {
+            double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
 #pragma unroll
-        for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(o[2 * c], o[2 * c + 1]);
+            for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(o[2 * c], o[2 * c + 1]);
+        }
+        if (!act) continue;
         const double nl = (GATHER || PACKED) ? ((GATHER && pc.lw_fill) ? *pc.lw_fill + ll : ll)   // after a resample the incoming
                                              : lw[i] + ll;                                    // log-weights are 0 (or one constant)
         lw[i] = nl;
@@ -201,18 +274,31 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
     constexpr int D = Mo::D, NB = Mo::NBLK;
     unsigned long long acc = 0;
     double bm = -__builtin_huge_val(); int bf = 0;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    // (wide rows through the wave's LDS strip as in k_step: measured SLOWER here -- k_move<bearings> 31.8 -> 34.3 us, the kernel is bound by its
+    // two likelihoods and the staging adds LDS latency to every iteration; k_step<2,8> gained 28.7 -> 26.5 us.  GPF_STAGE_MOVE=1 builds it.)
+#ifndef GPF_STAGE_MOVE
+#define GPF_STAGE_MOVE 0
+#endif
+    constexpr bool STAGE = GPF_STAGE_MOVE && W >= 8;
+    __shared__ double2 s_stage[STAGE ? NWAVES * RowStage<W>::WORDS : 1];
+    double2* const lds_wave = s_stage + (STAGE ? wave_id() * RowStage<W>::WORDS : 0);
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; STAGE ? e - lane_id() < n : e < n; e += (int64_t)gridDim.x * BLOCK) {
+        const bool alive = !STAGE || e < n;             // (STAGE: the whole wave stays in the loop; lanes beyond n help to move rows and write nothing)
+        const int64_t i = alive ? e : 0;
         double r[W];
         const int64_t srow = GATHER ? (int64_t)anc[i] : i;
+        if constexpr (STAGE) wave_rows_load<W>(rows_in, srow, lds_wave, r);
+        else {
         const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
+        }
         double x[MAX_DIM], xs[MAX_DIM];
 #pragma unroll
         for (int k = 0; k < D; ++k) x[k] = r[k];
         const double* xp = r + D;                    // x_{t-1} (valid when has_prev)
         const double* const ob = obs_of<BLK>(a, i);
-        const bool live = !(BLK && a.blk_mask && !(a.blk_mask[(uint32_t)i / (uint32_t)a.blk_size] & 1));
+        const bool live = alive && !(BLK && a.blk_mask && !(a.blk_mask[(uint32_t)i / (uint32_t)a.blk_size] & 1));
         const int iters = live ? n_iters : 0;
         double llx = Mo::loglik(a.P, x, ob);
         double wsum = 0.0;
@@ -250,9 +336,13 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) r[k] = x[k];
+        if constexpr (STAGE) wave_rows_store<W>(rows_out, e - lane_id(), n, lds_wave, r);
+        else {
         double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
 #pragma unroll
         for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(r[2 * c], r[2 * c + 1]);
+        }
+        if (!alive) continue;
         if (REWEIGHT) {
             double nl;
             if (live) { nl = (GATHER ? 0.0 : lw[i]) + wsum; lw[i] = nl; } else nl = lw[i];       // (a masked block: weights untouched)
