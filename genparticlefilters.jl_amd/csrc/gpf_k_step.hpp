@@ -363,4 +363,89 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
     if (REWEIGHT) block_max_store(bm, bf, ms);
 }
 
+// K7/K8 + K2 in one launch ("lazy move"): pf_rejuvenate!(state, kern, args, n_iters; method) followed by pf_update! -- the README loop's order
+// (README.md:69-76) and BASELINE configs 4 and 5.  The move is not enqueued by gpf_rejuvenate; the plain pf_update! that follows runs
+// gather (if a resample is pending) -> move (rejuvenate.jl:40-90 with Gen.mh / move_reweight on the current step's latent, under the OLD
+// observation `obs_move` and the move's epoch) -> propagate (update.jl:15-22, new observation, the update's epoch) -> one row store.
+// Against k_move + k_step: the moved rows are not written and read back (16 W bytes per particle: 128 B at W = 8) and one launch is
+// gone.  Any other consumer of the state runs the stand-alone k_move first (libgpf.hip finish_move).  Same arithmetic, same order:
+// lw = ((GATHER ? 0 : lw) + sum of relative weights) + log-likelihood.
+struct ObsVec { double v[MAX_OBS]; };
+template <int M, int W, bool REWEIGHT, bool GATHER>
+__global__ __launch_bounds__(BLOCK) void k_move_step(ModelArgs a, ObsVec obs_move, uint64_t seed, uint32_t epoch_move, uint32_t epoch, int64_t gid0,
+                                                     int64_t n, int has_prev, int n_iters, const int32_t* __restrict__ anc,
+                                                     const double* __restrict__ rows_in, double* __restrict__ rows_out, double* __restrict__ lw,
+                                                     MaxSlots ms)
+{
+    using Mo = Model<M>;
+    constexpr int D = Mo::D, NB = Mo::NBLK;
+    constexpr bool STAGE = GPF_STAGE_ROWS && W >= 8;                      // wide rows through the wave's LDS strip (as k_step)
+    __shared__ double2 s_stage[STAGE ? NWAVES * RowStage<W>::WORDS : 1];
+    double2* const lds_wave = s_stage + (STAGE ? wave_id() * RowStage<W>::WORDS : 0);
+    double bm = -__builtin_huge_val(); int bf = 0;
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; STAGE ? e - lane_id() < n : e < n; e += (int64_t)gridDim.x * BLOCK) {
+        const bool alive = !STAGE || e < n;
+        const int64_t i = alive ? e : 0;
+        double r[W];
+        const int64_t srow = GATHER ? (int64_t)anc[i] : i;
+        if constexpr (STAGE) wave_rows_load<W>(rows_in, srow, lds_wave, r);
+        else {
+            const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
+#pragma unroll
+            for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
+        }
+        // ---- the move (k_move's loop), under the observation and the epoch of the pf_rejuvenate! call
+        double x[MAX_DIM], xs[MAX_DIM];
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = r[k];
+        const double* xp = r + D;                       // x_{t-1} (valid when has_prev)
+        double llx = Mo::loglik(a.P, x, obs_move.v);
+        double wsum = 0.0;
+        const uint32_t gid = particle_gid(a, gid0, i);
+        const int iters = alive ? n_iters : 0;
+        for (int it = 0; it < iters; ++it) {
+            if (REWEIGHT) {
+                Mo::sample(a.P, !has_prev, xp, obs_move.v, seed, gid, (uint32_t)(it * NB), epoch_move, TAG_REWEIGHT, xs);
+                const double lls = Mo::loglik(a.P, xs, obs_move.v);
+                wsum = wsum + (lls - llx);                                     // rejuvenate.jl:86
+#pragma unroll
+                for (int k = 0; k < D; ++k) x[k] = xs[k];
+                llx = lls;
+            } else {
+                const uint32_t blk0 = (uint32_t)(it * (NB + 1));
+                Mo::sample(a.P, !has_prev, xp, obs_move.v, seed, gid, blk0, epoch_move, TAG_MOVE, xs);
+                const double lls = Mo::loglik(a.P, xs, obs_move.v);
+                const Philox b = rng(seed, gid, blk0 + NB, epoch_move, TAG_MOVE);
+                const double lu = log_(u52(b.w0, b.w1));
+                if (lu < lls - llx) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) x[k] = xs[k];
+                    llx = lls;
+                }
+            }
+        }
+        // ---- the propagate (k_step), from the moved latent, under the new observation and the update's epoch
+        double xn[MAX_DIM];
+        Mo::sample(a.P, false, x, a.obs, seed, gid, 0, epoch, TAG_UPDATE, xn);
+        const double ll = Mo::loglik(a.P, xn, a.obs);
+        double o[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) o[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { o[k] = xn[k]; o[D + k] = x[k]; }
+        if constexpr (STAGE) wave_rows_store<W>(rows_out, e - lane_id(), n, lds_wave, o);
+        else {
+            double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
+#pragma unroll
+            for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(o[2 * c], o[2 * c + 1]);
+        }
+        if (!alive) continue;
+        const double base = GATHER ? 0.0 : lw[i];                             // resample.jl:195 when a gather was pending
+        const double nl = REWEIGHT ? (base + wsum) + ll : base + ll;
+        lw[i] = nl;
+        track_max(nl, bm, bf);
+    }
+    block_max_store(bm, bf, ms);
+}
+
 } // namespace gpf

@@ -93,6 +93,11 @@ struct gpf_filter {
     // update are still to come -- from k_step_search when a plain pf_update! follows, else from finish_search().  Implies pending_gather.
     bool pending_search = false;
     SearchArgs pend_sa{};
+    // "lazy move" (gpf_k_step.hpp k_move_step): pf_rejuvenate! enqueued nothing; the move runs inside the plain pf_update! that follows
+    // (gather -> move -> propagate -> one row store), or on its own (finish_move) as soon as anything else looks at the state.  The move's
+    // epoch is consumed at the call (pm_epoch = the epoch the stand-alone k_move would have used).
+    bool pending_move = false; int pm_method = 0, pm_iters = 0; uint32_t pm_epoch = 0; ModelArgs pm_args{};
+    bool lazy_move = true;         // GPF_LAZY_MOVE=0 in the environment: every pf_rejuvenate! launches its kernel at once
     bool lazy_search = false;      // gpf_set_lazy_search (default: GPF_LAZY_SEARCH=1 in the environment, else off)
     // the 16-bit offset levels of the weight channel (k_search_multi / k_push_multi) cost the scan ~1.4 us: only written when a
     // multinomial search will read them
@@ -195,6 +200,7 @@ namespace {
 
 gpf_status materialize(gpf_filter* h);
 gpf_status finish_search(gpf_filter* h);
+gpf_status finish_move(gpf_filter* h);
 
 gpf_status fail(gpf_handle h, gpf_status s, const std::string& msg)
 {
@@ -459,17 +465,32 @@ bool model_has_move_proposal(int model)
     return false;
 }
 template <int M, bool RW>
-void launch_move_t(gpf_filter* h, int grid, int n_iters)
+void launch_move_t(gpf_filter* h, int grid, int n_iters, const ModelArgs& args, uint32_t epoch)
 {
     constexpr int Wc = row_width(Model<M>::D, true);
     if (h->pending_gather)           // the resample gather rides on the move (rows read through anc, incoming weights 0)
-        GPF_LAUNCH((k_move<M, Wc, RW, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+        GPF_LAUNCH((k_move<M, Wc, RW, true>), dim3(grid), dim3(BLOCK), 0, h->stream, args, h->cfg.seed, epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
                            h->acc_part, RW ? next_slots(h) : MaxSlots{nullptr, nullptr});
     else
-        GPF_LAUNCH((k_move<M, Wc, RW, false>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+        GPF_LAUNCH((k_move<M, Wc, RW, false>), dim3(grid), dim3(BLOCK), 0, h->stream, args, h->cfg.seed, epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
                            h->acc_part, RW ? next_slots(h) : MaxSlots{nullptr, nullptr});
+}
+// the pending move inside the propagate (k_move_step): old observation + the move's epoch, new observation (h->args) + the update's epoch
+template <int M, bool RW>
+void launch_move_step_t(gpf_filter* h, int grid)
+{
+    constexpr int Wc = row_width(Model<M>::D, true);
+    ObsVec om;
+    for (int i = 0; i < MAX_OBS; ++i) om.v[i] = h->pm_args.obs[i];
+    const MaxSlots ms = next_slots(h);
+    if (h->pending_gather)
+        GPF_LAUNCH((k_move_step<M, Wc, RW, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, om, h->cfg.seed, h->pm_epoch, h->epoch,
+                   h->cfg.gid0, h->n, (int)h->has_prev, h->pm_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms);
+    else
+        GPF_LAUNCH((k_move_step<M, Wc, RW, false>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, om, h->cfg.seed, h->pm_epoch, h->epoch,
+                   h->cfg.gid0, h->n, (int)h->has_prev, h->pm_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms);
 }
 
 #define DISPATCH_MODEL(h, CALL)                                                                  \
@@ -745,6 +766,7 @@ gpf_status view_enter(gpf_filter* v)
     gpf_filter* p = v->parent;
     if (p->generation != v->parent_generation) return fail(v, GPF_ERR_STATE, "stale view: the parent filter was resized or re-created");
     if (!p->initialized) return fail(v, GPF_ERR_STATE, "parent filter not initialised");
+    if (p->pending_move) { gpf_status ms = finish_move(p); if (ms) { v->err = p->err; return ms; } }
     gpf_status s = materialize(p);
     if (s) { v->err = p->err; return s; }
     const int64_t o = v->view_start;
@@ -798,9 +820,10 @@ gpf_status view_exit(gpf_filter* v)
     return GPF_OK;
 }
 
-gpf_status check_ready(gpf_handle h)
+gpf_status check_ready(gpf_handle h, bool keep_pending_move = false)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (h->pending_move && !keep_pending_move) { gpf_status ms = finish_move(h); if (ms) return ms; }   // (a lazy move: only the plain pf_update! carries it)
     if (h->parent) { gpf_status vs = view_enter(h); if (vs) return vs; }
     if (!h->initialized) return fail(h, GPF_ERR_STATE, "filter not initialised: call gpf_initialize (pf_initialize) first");
     HIP_TRY(h, hipSetDevice(h->cfg.device));       // launches go to the calling thread's current device
@@ -1038,6 +1061,26 @@ gpf_status finish_search(gpf_filter* h)
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
 }
+// a pending lazy move is wanted as a state after all: the stand-alone k_move with the arguments and the epoch of its pf_rejuvenate! call
+gpf_status finish_move(gpf_filter* h)
+{
+    if (!h->pending_move) return GPF_OK;
+    h->pending_move = false;
+    const bool fused_gather = h->pending_gather;
+    const int grid = move_grid(h);
+    const int n_iters = h->pm_iters;
+    gpf_status s = timed(h, GPF_K_MOVE, [&] {
+        if (h->pm_method == GPF_REJUVENATE_REWEIGHT) { DISPATCH_MODEL(h, (launch_move_t<MM, true>(h, grid, n_iters, h->pm_args, h->pm_epoch))); }
+        else                                         { DISPATCH_MODEL(h, (launch_move_t<MM, false>(h, grid, n_iters, h->pm_args, h->pm_epoch))); }
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->cur ^= 1;                                                 // (the epoch was consumed at the call)
+    if (fused_gather) { h->pending_gather = false; h->pending_fill = false; h->max_valid = false; }
+    if (h->pm_method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; }
+    mutated(h);
+    return GPF_OK;
+}
 // which models / sizes k_step_search covers: the key-table regime of the search (up to 2.5 M particles)
 bool lazy_search_ok(const gpf_filter* h)
 {
@@ -1269,6 +1312,7 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
 
     gpf_filter* h = new gpf_filter();
     h->lazy_search = getenv("GPF_LAZY_SEARCH") && !strcmp(getenv("GPF_LAZY_SEARCH"), "1");
+    h->lazy_move = !(getenv("GPF_LAZY_MOVE") && !strcmp(getenv("GPF_LAZY_MOVE"), "0"));
     h->cfg = *cfg;
     h->cfg.params = nullptr;
     for (int i = 0; i < cfg->n_params; ++i) h->args.P[i] = cfg->params[i];
@@ -1395,6 +1439,8 @@ gpf_status gpf_set_lazy_search(gpf_handle h, int32_t enable)
 
 gpf_status gpf_synchronize(gpf_handle h)
 {
+    // (work that was left for a later call to pick up is enqueued now: a timed loop that ends in pf_rejuvenate! pays for its move)
+    if (h && h->pending_move) { gpf_status ms = finish_move(h); if (ms) return ms; }
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return check_scan_timeout(h);
@@ -1421,7 +1467,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
         else                { DISPATCH_MODEL(h, (launch_init_t<MM, 0>(h, grid))); }
     });
     if (s) return s;
-    h->pending_gather = false; h->pending_fill = false; h->pending_search = false;
+    h->pending_gather = false; h->pending_fill = false; h->pending_search = false; h->pending_move = false;
     h->pending_packed = false;
     h->max_valid = true;
     GPF_LAUNCH(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
@@ -1452,7 +1498,7 @@ gpf_status gpf_initialize_proposal(gpf_handle h, const double* obs, int32_t n_ob
 
 static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, int prop)
 {
-    gpf_status s = check_ready(h);
+    gpf_status s = check_ready(h, prop == 0);                    // (the plain propagate carries a pending lazy move)
     if (s) return s;
     if (prop == 1 && !model_has_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no native proposal");
     if (prop == 2 && !model_has_strata(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no discrete latent to stratify over");
@@ -1462,6 +1508,25 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
     if (prop != 0 && (s = finish_search(h))) return s;           // (only the plain propagate carries a pending search)
     const int grid = step_grid(h);
     const bool keep = h->cfg.keep_prev != 0;
+    if (h->pending_move) {
+        // gather (if pending) -> move -> propagate in one launch (k_move_step): the old observation and epoch travel with the move
+        const bool rw = h->pm_method == GPF_REJUVENATE_REWEIGHT;
+        s = timed(h, GPF_K_STEP, [&] {
+            if (rw) { DISPATCH_MODEL(h, (launch_move_step_t<MM, true>(h, grid))); }
+            else    { DISPATCH_MODEL(h, (launch_move_step_t<MM, false>(h, grid))); }
+        });
+        if (s) return s;
+        HIP_TRY(h, hipGetLastError());
+        h->pending_move = false;
+        h->pending_gather = false; h->pending_fill = false;
+        h->max_valid = true;
+        h->cur ^= 1;                // (read rows[cur], wrote the other buffer once: the move's and the update's swaps cancel to one)
+        h->epoch += 1;
+        h->has_prev = true;
+        h->raw_valid = false;
+        mutated(h);
+        return GPF_OK;
+    }
     s = timed(h, GPF_K_STEP, [&] {
         if (prop == 1) {
             if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true, 1>(h, grid))); }
@@ -1793,7 +1858,7 @@ gpf_status gpf_initialize_blocks(gpf_handle h, const double* obs, int32_t n_obs,
     const int grid = step_grid(h);
     s = timed(h, GPF_K_STEP, [&] { DISPATCH_MODEL(h, (launch_init_blk<MM>(h, grid))); });
     if (s) return s;
-    h->pending_gather = false; h->pending_fill = false; h->pending_packed = false; h->pending_search = false;
+    h->pending_gather = false; h->pending_fill = false; h->pending_packed = false; h->pending_search = false; h->pending_move = false;
     h->max_valid = true;
     GPF_LAUNCH(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
     HIP_TRY(h, hipMemsetAsync(&h->sc->lml_est, 0, sizeof(double), h->stream));
@@ -1925,12 +1990,19 @@ static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters,
     if (h->pending_packed && (s = materialize(h))) return s;     // sharded deferred commit: scatter first
     if (h->pending_fill && (s = materialize(h))) return s;       // (the move kernel's fused gather assumes incoming weights 0)
     if ((s = finish_search(h))) return s;                        // (a lazy multinomial resample: the move kernel reads the ancestor array)
+    // lazy move: a plain selection move of a whole, unsharded filter whose acceptance count nobody asked for waits for the pf_update! that
+    // follows (k_move_step); its epoch is consumed now
+    if (h->lazy_move && !with_proposal && !n_accepted && !h->parent && !h->hist_on && h->cfg.n_global == h->n && !h->pending_packed) {
+        h->pending_move = true; h->pm_method = method; h->pm_iters = n_iters; h->pm_epoch = h->epoch; h->pm_args = h->args;
+        h->epoch += 1;
+        return GPF_OK;
+    }
     const bool fused_gather = h->pending_gather;                 // a pending resample gather rides on the move kernel
     const int grid = move_grid(h);
     s = timed(h, GPF_K_MOVE, [&] {
         if (with_proposal)                          { DISPATCH_MODEL(h, (launch_move_prop_t<MM>(h, grid, n_iters))); }
-        else if (method == GPF_REJUVENATE_REWEIGHT) { DISPATCH_MODEL(h, (launch_move_t<MM, true>(h, grid, n_iters))); }
-        else                                        { DISPATCH_MODEL(h, (launch_move_t<MM, false>(h, grid, n_iters))); }
+        else if (method == GPF_REJUVENATE_REWEIGHT) { DISPATCH_MODEL(h, (launch_move_t<MM, true>(h, grid, n_iters, h->args, h->epoch))); }
+        else                                        { DISPATCH_MODEL(h, (launch_move_t<MM, false>(h, grid, n_iters, h->args, h->epoch))); }
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());

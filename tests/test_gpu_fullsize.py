@@ -369,3 +369,34 @@ def test_sorted_stratified_with_priorities_right_after_a_weight_change(g, o, N, 
     assert np.array_equal(st.parents, orc.parents) and np.array_equal(st.traces, orc.rows)
     assert g.get_lml_est(st) == orc.log_ml_estimate()
     st.close()
+
+
+def test_ess_publish_beyond_32_tiles_per_workgroup():
+    """The ESS scan's tagged limb partials (tag << 48 | sum) hold a workgroup's limb sums only while it folds <= 32 tiles (2^16 elements of
+    < 2^32 each).  With ONE scan workgroup per CU (GPF_WSCAN_BLOCKS=1, read once per process) N = 2^25 is 64 tiles per workgroup: the scan
+    must fall back to the untagged partials + k_publish_scalars and the ESS must still be (sum w)^2 / sum w^2 (test/utils.jl:10)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import gpf_amd as g
+N = 1 << 25
+m = g.models.lgssm2(); ys = g.models.simulate(m, 2)
+st = g.pf_initialize(m, (1,), ys[0], N, seed=4)
+lw = st.log_weights
+w = np.exp(lw - lw.max())
+want = w.sum() ** 2 / (w * w).sum()
+for rep in range(3):
+    ess = g.get_ess(st)
+    assert abs(ess - want) <= 1e-9 * want, (ess, want)
+    g.pf_update(st, (2,), (None,), ys[1])
+    lw = st.log_weights; w = np.exp(lw - lw.max()); want = w.sum() ** 2 / (w * w).sum()
+print("ok")
+""" % root
+    for blocks in ("1", "4"):
+        env = dict(os.environ, GPF_WSCAN_BLOCKS=blocks)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (blocks, out.stdout[-500:], out.stderr[-1500:])
