@@ -2153,6 +2153,7 @@ gpf_status gpf_set_rows(gpf_handle h, const double* rows, int64_t n_doubles)
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!rows || n_doubles != h->n * h->W) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (h->pending_move) { gpf_status s = finish_move(h); if (s) return s; }
     if (h->parent) { gpf_status s = view_enter(h); if (s) return s; }
     { gpf_status s = materialize(h); if (s) return s; }
     HIP_TRY(h, hipMemcpyAsync(h->rows[h->cur], rows, (size_t)n_doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -2168,6 +2169,7 @@ gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n)
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!lw || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (h->pending_move) { gpf_status s = finish_move(h); if (s) return s; }
     if (h->parent) { gpf_status s = view_enter(h); if (s) return s; h->parent->raw_valid = false; h->parent->max_valid = false; }
     { gpf_status s = materialize(h); if (s) return s; }
     h->max_valid = false;

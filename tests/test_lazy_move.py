@@ -81,7 +81,12 @@ def test_every_other_consumer_runs_the_move_first(g, o):
     # a move, then synchronize (enqueues it), then the state
     mv(); st.synchronize(); assert _same(st, orc)
     # set_log_weights / set rows behind a pending move
-    mv("reweight"); lw = st.log_weights * 0.5; st.log_weights = lw; orc.lw = lw.copy(); upd(); assert _same(st, orc)
+    lw = np.linspace(-3.0, 0.0, st.n_particles)
+    mv("reweight"); st.log_weights = lw; orc.lw = lw.copy(); upd(); assert _same(st, orc)              # (no getter in between: the setter runs the move)
+    rows = orc.rows.copy(); rows[:, 0] += 0.25
+    mv("move")
+    # set rows behind a pending move: the move runs first, then the rows are replaced
+    st.traces = rows; orc.rows = rows.copy(); upd(); assert _same(st, orc)
     st.close()
 
 
