@@ -403,6 +403,91 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
     }
 }
 
+// ----------------------------------------------------------------------------- weight summary WITHOUT a prefix sum (the ESS / log-ML getters)
+// effective_sample_size(state) and log_ml_estimate(state) (utils.jl:163-178) need S = sum q and Q = sum q^2 only -- not the CDF.  An
+// ESS-triggered filter (README.md:68, BASELINE config 4) reads the ESS every step and resamples on a minority of them: the scan's
+// inter-workgroup chain and its 10 MB of CDF stores were paid on every step for a CDF most steps never used.  This is the reduction:
+// same fixed-point weights (InFixQ), exact integer sums (order-free, identical to the scan's), no chain.  Workgroups leave
+// {S low 31 bits, S high bits, limb sums of Q} as TAGGED words (tag << 48 | sum, relaxed agent-scope stores, as the scan's ESS
+// partials: a workgroup folds <= Q_TAG_MAX_TILES tiles); workgroup 0 waits for this launch's tags, folds, fills ws_out and publishes
+// {flags, S, limbs, ticket, check word} to pinned host memory (the scan's format: gpf_effective_sample_size reads either).
+__global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int64_t n, int64_t ntiles, const unsigned long long* __restrict__ slots,
+                                                           WSum* __restrict__ ws_out, uint64_t* __restrict__ part, int64_t* __restrict__ q_host,
+                                                           int64_t q_ticket, int32_t* __restrict__ timeout)
+{
+    double m; int f;
+    fold_slots(slots, m, f);
+    in.m = m; in.flags = f;
+    const int lane = lane_id(), wv = wave_id();
+    uint64_t acc[6] = {0, 0, 0, 0, 0, 0};             // S, (unused), Ql0..3
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t wbase = tile * TILE + (int64_t)wv * (SCAN_ROWS * 2 * WAVE) + 2 * lane;
+#pragma unroll
+        for (int k = 0; k < SCAN_ROWS; ++k) {
+            uint64_t q0, q1;
+            in.load2(wbase + k * 2 * WAVE, n, q0, q1);
+            acc[0] += q0 + q1;
+            uint64_t lo = q0 * q0, hi = __umul64hi(q0, q0);
+            acc[2] += lo & 0xffffffffull; acc[3] += lo >> 32; acc[4] += hi & 0xffffffffull; acc[5] += hi >> 32;
+            lo = q1 * q1; hi = __umul64hi(q1, q1);
+            acc[2] += lo & 0xffffffffull; acc[3] += lo >> 32; acc[4] += hi & 0xffffffffull; acc[5] += hi >> 32;
+        }
+    }
+    __shared__ uint64_t s_p[SCAN_NWAVES][6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = wave_sum_u64(acc[k]);
+    if (lane == 0) { for (int k = 0; k < 6; ++k) s_p[wv][k] = acc[k]; }
+    __syncthreads();
+    const uint64_t tag = (uint64_t)((q_ticket & 0x7fff) + 1) << 48;
+    if (threadIdx.x < 6) {
+        uint64_t t = 0;
+        for (int w = 0; w < SCAN_NWAVES; ++w) t += s_p[w][threadIdx.x];
+        if (threadIdx.x == 0) { s_p[0][0] = t & 0x7fffffffull; s_p[0][1] = t >> 31; }      // S in two tagged halves (S < 2^62)
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        uint64_t t = 0;
+        if (threadIdx.x < 2) t = s_p[0][threadIdx.x];
+        else for (int w = 0; w < SCAN_NWAVES; ++w) t += s_p[w][threadIdx.x];
+        __hip_atomic_store(part + (int64_t)blockIdx.x * 6 + threadIdx.x, tag | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (blockIdx.x != 0) return;
+    uint64_t q[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += SCAN_BLOCK) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            uint64_t v = __hip_atomic_load(part + (int64_t)b * 6 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while ((v >> 48) != (tag >> 48)) {
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(part + (int64_t)b * 6 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > SPIN_LIMIT) { *timeout = 1; break; }
+            }
+            q[k] += v & 0xffffffffffffull;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q[k] = wave_sum_u64(q[k]);
+    __syncthreads();
+    if (lane == 0) { for (int k = 0; k < 6; ++k) s_p[wv][k] = q[k]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < SCAN_NWAVES; ++w) for (int k = 0; k < 6; ++k) t[k] += s_p[w][k];
+        const uint64_t S = t[0] + (t[1] << 31);
+        ws_out->m = m; ws_out->flags = f; ws_out->S = S;
+        for (int k = 0; k < 4; ++k) ws_out->Ql[k] = t[2 + k];
+        if (q_host) {
+            __hip_atomic_store(q_host + 0, (int64_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(q_host + 1, (int64_t)S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            uint64_t chk = (uint64_t)q_ticket ^ (uint64_t)(int64_t)f ^ S;
+            for (int k = 0; k < 4; ++k) { __hip_atomic_store(q_host + 2 + k, (int64_t)t[2 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); chk ^= t[2 + k]; }
+            __hip_atomic_store(q_host + 7, (int64_t)chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(q_host + 6, q_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // Residual resampling needs TWO prefix sums over the same elements: the copy counts c_i = (N q_i) div S and the
 // residual weights r_i = ((N q_i) mod S) >> sh (resample.jl:99,109).  One pass computes both: one read of the weight CDF,
 // ONE 64-bit division per element (quotient and remainder), two descriptor channels polled in the same round trip.

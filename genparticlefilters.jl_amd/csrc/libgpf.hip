@@ -85,6 +85,9 @@ struct gpf_filter {
     uint32_t epoch = 0;
     bool initialized = false, has_prev = false, raw_valid = false, residual_scanned = false;
     bool max_valid = false;        // mslots[mcur] describes the current log-weights (written by the kernel that produced them)
+    bool raw_sum_valid = false;    // sc->raw holds {m, flags, S, Ql} of the current log-weights WITHOUT a CDF (k_sum_reduce: the ESS / log-ML getters)
+    WSum sum_cache{};              // ... and the host's copy of it
+    uint64_t* sum_part = nullptr;  // [6][workgroups] tagged partials of k_sum_reduce
     bool raw_has_q = false;        // the raw summary's scan also accumulated sum q^2 (blockQ)
     bool raw_q_folded = false;     // sc->raw.Ql folded from blockQ
     bool pending_gather = false;   // a resample left (rows[cur], anc) un-gathered; log-weights are 0
@@ -703,6 +706,64 @@ gpf_status ensure_raw(gpf_filter* h, bool want_q = false)
     return GPF_OK;
 }
 
+gpf_status wait_ticket(gpf_filter* h, volatile int64_t* tk, int64_t want, const char* what);
+gpf_status check_scan_timeout(gpf_filter* h);
+// {flags, S, limbs} as published by the ESS scan or by k_sum_reduce (8 words, unordered on their way to pinned memory: re-read until the
+// check word -- ticket ^ payload -- agrees)
+gpf_status read_published_summary(gpf_filter* h, WSum& w)
+{
+    gpf_status s;
+    if ((s = wait_ticket(h, h->h_qpub + 6, h->q_ticket, "weight summary"))) return s;
+    if ((s = check_scan_timeout(h))) return s;
+    for (uint64_t spins = 0;; ++spins) {
+        int64_t v[8];
+        for (int k = 0; k < 8; ++k) v[k] = __atomic_load_n(h->h_qpub + k, __ATOMIC_ACQUIRE);
+        uint64_t chk = (uint64_t)v[6];
+        for (int k = 0; k < 6; ++k) chk ^= (uint64_t)v[k];
+        if (v[6] == h->q_ticket && chk == (uint64_t)v[7]) {
+            w.flags = (int32_t)v[0]; w.S = (uint64_t)v[1];
+            for (int k = 0; k < 4; ++k) w.Ql[k] = (uint64_t)v[2 + k];
+            return GPF_OK;
+        }
+        cpu_relax();
+        if (spins > (1ull << 26)) return fail(h, GPF_ERR_HIP, "weight summary: the published words never became consistent");
+    }
+}
+// The summary of the raw log-weights WITHOUT the CDF (the ESS and log-ML getters): reuses a valid scan, else ONE reduction launch
+// (k_sum_reduce) instead of the scan -- no inter-workgroup chain, no 10 MB of CDF and levels.  false in *done: the filter is too large
+// for the tagged partials (a workgroup would fold more than Q_TAG_MAX_TILES tiles): the caller takes the scan.
+gpf_status ensure_raw_summary(gpf_filter* h, bool want_q, bool* done)
+{
+    *done = false;
+    gpf_status s = materialize(h);
+    if (s) return s;
+    static const bool off = getenv("GPF_SUM_REDUCE") && !strcmp(getenv("GPF_SUM_REDUCE"), "0");          // (A/B: always the scan)
+    if (off || (h->raw_valid && (!want_q || h->raw_has_q))) return GPF_OK;                              // (a scan's summary is there: use it)
+    if (h->raw_sum_valid) { *done = true; return GPF_OK; }
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, (int64_t)h->n_cu * 4));
+    if ((h->ntiles + grid - 1) / grid > Q_TAG_MAX_TILES) return GPF_OK;
+    if (!h->sum_part) {
+        HIP_TRY(h, hipMalloc(&h->sum_part, (size_t)6 * 4 * h->n_cu * sizeof(uint64_t)));
+        HIP_TRY(h, hipMemsetAsync(h->sum_part, 0, (size_t)6 * 4 * h->n_cu * sizeof(uint64_t), h->stream));
+    }
+    if (!h->h_qpub) { HIP_TRY(h, hipHostMalloc(&h->h_qpub, 8 * sizeof(int64_t))); for (int i = 0; i < 8; ++i) h->h_qpub[i] = 0; }
+    if ((s = ensure_max(h, raw_view(h), true))) return s;
+    h->q_ticket += 1;
+    InFixQ in{raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
+    s = timed(h, GPF_K_SCAN, [&] {
+        GPF_LAUNCH(k_sum_reduce, dim3(grid), dim3(SCAN_BLOCK), 0, h->stream, in, h->n, h->ntiles, h->mslots[h->mcur], &h->sc->raw, h->sum_part, h->h_qpub,
+                   h->q_ticket, h->h_timeout);
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    WSum w{};
+    if ((s = read_published_summary(h, w))) return s;
+    h->sum_cache = w;                                            // (m is not published: the log-ML getter reads it from the device block)
+    h->raw_sum_valid = true;
+    *done = true;
+    return GPF_OK;
+}
+
 // Poll a pinned ticket that a kernel on h->stream publishes.  A failed kernel never writes it: any stream status other than
 // "not ready" is terminal (re-read once, then report), so a faulting kernel cannot hang the host -- or, in a multi-rank job,
 // its peers in the next collective.
@@ -790,7 +851,7 @@ gpf_status view_enter(gpf_filter* v)
     v->has_prev = p->has_prev;
     v->initialized = true;
     if (v->seen_mutations != p->mutations) {                     // the aliased weights changed behind this view's back
-        v->raw_valid = false; v->raw_has_q = false; v->raw_q_folded = false; v->max_valid = false;
+        v->raw_valid = false; v->raw_sum_valid = false; v->raw_has_q = false; v->raw_q_folded = false; v->max_valid = false;
         v->seen_mutations = p->mutations;
     }
     return GPF_OK;
@@ -816,7 +877,7 @@ gpf_status view_exit(gpf_filter* v)
     }
     p->epoch = v->epoch;
     p->has_prev = p->has_prev || v->has_prev;
-    p->raw_valid = false; p->max_valid = false; p->raw_has_q = false; p->raw_q_folded = false;
+    p->raw_valid = false; p->raw_sum_valid = false; p->max_valid = false; p->raw_has_q = false; p->raw_q_folded = false;
     return GPF_OK;
 }
 
@@ -1077,7 +1138,7 @@ gpf_status finish_move(gpf_filter* h)
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;                                                 // (the epoch was consumed at the call)
     if (fused_gather) { h->pending_gather = false; h->pending_fill = false; h->max_valid = false; }
-    if (h->pm_method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; }
+    if (h->pm_method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->raw_sum_valid = false; h->max_valid = true; }
     mutated(h);
     return GPF_OK;
 }
@@ -1146,7 +1207,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         if ((s = summarize(h, pv, ws, true, sorted ? h->order : nullptr, false, false, need_sync, sorted))) return s;
         published = need_sync;
     }
-    h->raw_valid = false;                                        // cdf[0] no longer the plain raw CDF / lw about to change
+    h->raw_valid = false; h->raw_sum_valid = false;                                        // cdf[0] no longer the plain raw CDF / lw about to change
     h->raw_q_folded = false;
     if (need_sync) {
         int flags;
@@ -1418,6 +1479,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->h_pull_pc_all) hipHostFree(h->h_pull_pc_all);
     if (h->h_qpub) hipHostFree(h->h_qpub);
     if (h->sp_g) { (void)hipFree(h->sp_g); (void)hipFree(h->sp_vlo); }
+    if (h->sum_part) (void)hipFree(h->sum_part);
     for (int k = 0; k < gpf_filter::BLK_STAGE; ++k) if (h->h_blk_obs[k]) hipHostFree(h->h_blk_obs[k]);
     if (h->h_blk_done) hipHostFree(h->h_blk_done);
     if (h->blk_stage_counter) (void)hipFree(h->blk_stage_counter);
@@ -1476,7 +1538,7 @@ static gpf_status initialize_impl(gpf_handle h, const double* obs, int32_t n_obs
     h->epoch += 1;
     h->initialized = true;
     h->has_prev = false;
-    h->raw_valid = false;
+    h->raw_valid = false; h->raw_sum_valid = false;
     mutated(h);
     return GPF_OK;
 }
@@ -1523,7 +1585,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
         h->cur ^= 1;                // (read rows[cur], wrote the other buffer once: the move's and the update's swaps cancel to one)
         h->epoch += 1;
         h->has_prev = true;
-        h->raw_valid = false;
+        h->raw_valid = false; h->raw_sum_valid = false;
         mutated(h);
         return GPF_OK;
     }
@@ -1547,7 +1609,7 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
     h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
     h->epoch += 1;
     h->has_prev = true;
-    h->raw_valid = false;
+    h->raw_valid = false; h->raw_sum_valid = false;
     mutated(h);
     return view_exit(h);            // sub-state: copy back (utils.jl:17-20)
 }
@@ -1610,8 +1672,8 @@ gpf_status gpf_resample_local(gpf_handle h, int32_t method, int32_t sort_particl
     struct Scope {                                               // the filter as its own population for the duration of the call
         gpf_filter* h; int K; double logN; int64_t ng;
         explicit Scope(gpf_filter* f) : h(f), K(f->K), logN(f->logN), ng(f->cfg.n_global)
-        { h->K = fix_K(h->n); h->logN = log_((double)h->n); h->cfg.n_global = h->n; h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; }
-        ~Scope() { h->K = K; h->logN = logN; h->cfg.n_global = ng; h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; }
+        { h->K = fix_K(h->n); h->logN = log_((double)h->n); h->cfg.n_global = h->n; h->raw_valid = false; h->raw_sum_valid = false; h->raw_has_q = false; h->raw_q_folded = false; }
+        ~Scope() { h->K = K; h->logN = logN; h->cfg.n_global = ng; h->raw_valid = false; h->raw_sum_valid = false; h->raw_has_q = false; h->raw_q_folded = false; }
     } scope(h);
     return resample_impl(h, method, raw_view(h), sort_particles, check, invalid, true);
 }
@@ -1696,7 +1758,7 @@ static gpf_status resample_big_blocks(gpf_handle h, int32_t method, int64_t bloc
     HIP_TRY(h, hipMemcpyAsync(h->blk_mask, words.data(), (size_t)nblocks * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));                // (the host vector goes out of scope)
     h->blk_last = nblocks;
-    h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false;
+    h->raw_valid = false; h->raw_sum_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false;
     mutated(h);
     if (invalid) *invalid = any_invalid ? 1 : 0;
     if (n_resampled) *n_resampled = count;
@@ -1738,7 +1800,7 @@ gpf_status gpf_resample_blocks(gpf_handle h, int32_t method, int64_t block_size,
     h->cur ^= 1;
     h->blk_last = nblocks;
     h->pending_gather = false; h->pending_fill = false;
-    h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false;
+    h->raw_valid = false; h->raw_sum_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false;
     h->epoch += 1;
     mutated(h);
     if (check != GPF_CHECK_FALSE || invalid || n_resampled) {
@@ -1864,7 +1926,7 @@ gpf_status gpf_initialize_blocks(gpf_handle h, const double* obs, int32_t n_obs,
     HIP_TRY(h, hipMemsetAsync(&h->sc->lml_est, 0, sizeof(double), h->stream));
     HIP_TRY(h, hipGetLastError());
     h->epoch += 1;
-    h->initialized = true; h->has_prev = false; h->raw_valid = false;
+    h->initialized = true; h->has_prev = false; h->raw_valid = false; h->raw_sum_valid = false;
     h->blk_last = 0;                                             // only_resampled refers to a gpf_resample_blocks of the CURRENT step
     mutated(h);
     return GPF_OK;
@@ -1888,7 +1950,7 @@ gpf_status gpf_update_blocks(gpf_handle h, const double* obs, int32_t n_obs, int
     h->cur ^= 1;
     h->epoch += 1;
     h->has_prev = true;
-    h->raw_valid = false;
+    h->raw_valid = false; h->raw_sum_valid = false;
     h->blk_last = 0;                                             // (as in gpf_initialize_blocks)
     mutated(h);
     return GPF_OK;
@@ -1918,7 +1980,7 @@ gpf_status gpf_rejuvenate_blocks(gpf_handle h, int32_t method, int32_t n_iters, 
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;
     h->epoch += 1;
-    if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; }
+    if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->raw_sum_valid = false; h->max_valid = true; }
     mutated(h);
     if (n_accepted) {
         // (move-reweight: every particle of a participating block moves; the per-workgroup counts cover both cases)
@@ -2009,7 +2071,7 @@ static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters,
     h->cur ^= 1;
     h->epoch += 1;
     if (fused_gather) { h->pending_gather = false; h->pending_fill = false; h->max_valid = false; }   // log-weights are all 0 now (resample.jl:195)
-    if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->max_valid = true; }
+    if (method == GPF_REJUVENATE_REWEIGHT) { h->raw_valid = false; h->raw_sum_valid = false; h->max_valid = true; }
     mutated(h);
     if ((s = view_exit(h))) return s;
     if (n_accepted) {
@@ -2029,33 +2091,23 @@ gpf_status gpf_effective_sample_size(gpf_handle h, double* out)
     gpf_status s = check_ready(h);
     if (s) return s;
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
-    h->q_published = false;
-    if ((s = ensure_raw(h, true))) return s;
     WSum w{};
-    if (h->q_published) {
-        // the scan of this call publishes {flags, S, limbs of sum q^2} itself: wait for its ticket, no publish launch
+    bool reduced = false;
+    if ((s = ensure_raw_summary(h, true, &reduced))) return s;
+    if (reduced) w = h->sum_cache;                                // S and sum q^2 from the reduction: no CDF was written
+    else {
         h->q_published = false;
-        if ((s = wait_ticket(h, h->h_qpub + 6, h->q_ticket, "ESS summary"))) return s;
-        if ((s = check_scan_timeout(h))) return s;
-        // the seven words are unordered on their way to pinned memory: re-read until the check word (ticket ^ payload) agrees
-        for (uint64_t spins = 0;; ++spins) {
-            int64_t v[8];
-            for (int k = 0; k < 8; ++k) v[k] = __atomic_load_n(h->h_qpub + k, __ATOMIC_ACQUIRE);
-            uint64_t chk = (uint64_t)v[6];
-            for (int k = 0; k < 6; ++k) chk ^= (uint64_t)v[k];
-            if (v[6] == h->q_ticket && chk == (uint64_t)v[7]) {
-                w.flags = (int32_t)v[0]; w.S = (uint64_t)v[1];
-                for (int k = 0; k < 4; ++k) w.Ql[k] = (uint64_t)v[2 + k];
-                break;
-            }
-            cpu_relax();
-            if (spins > (1ull << 26)) return fail(h, GPF_ERR_HIP, "ESS summary: the published words never became consistent");
+        if ((s = ensure_raw(h, true))) return s;
+        if (h->q_published) {
+            // the scan of this call publishes {flags, S, limbs of sum q^2} itself: wait for its ticket, no publish launch
+            h->q_published = false;
+            if ((s = read_published_summary(h, w))) return s;
+        } else {
+            const bool fold = !h->raw_q_folded;                      // the scan blocks' limb partials of sum q^2: folded by the publish kernel
+            if ((s = fetch_scalars(h, fold))) return s;
+            h->raw_q_folded = true;
+            w = h->h_sc->raw;
         }
-    } else {
-        const bool fold = !h->raw_q_folded;                      // the scan blocks' limb partials of sum q^2: folded by the publish kernel
-        if ((s = fetch_scalars(h, fold))) return s;
-        h->raw_q_folded = true;
-        w = h->h_sc->raw;
     }
     if (w.flags) { *out = std::nan(""); return GPF_OK; }
     uint64_t hi, lo;
@@ -2069,7 +2121,9 @@ gpf_status gpf_log_ml_estimate(gpf_handle h, double* out)
     gpf_status s = check_ready(h);
     if (s) return s;
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
-    if ((s = ensure_raw(h))) return s;
+    bool reduced = false;
+    if ((s = ensure_raw_summary(h, false, &reduced))) return s;  // (S and the maximum are all it needs: no CDF)
+    if (!reduced && (s = ensure_raw(h))) return s;
     if ((s = fetch_scalars(h))) return s;
     const WSum& w = h->h_sc->raw;
     double base = h->h_sc->lml_est;
@@ -2170,13 +2224,13 @@ gpf_status gpf_set_log_weights(gpf_handle h, const double* lw, int64_t n)
     if (!lw || n != h->n) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad input array");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (h->pending_move) { gpf_status s = finish_move(h); if (s) return s; }
-    if (h->parent) { gpf_status s = view_enter(h); if (s) return s; h->parent->raw_valid = false; h->parent->max_valid = false; }
+    if (h->parent) { gpf_status s = view_enter(h); if (s) return s; h->parent->raw_valid = false; h->parent->raw_sum_valid = false; h->parent->max_valid = false; }
     { gpf_status s = materialize(h); if (s) return s; }
     h->max_valid = false;
     HIP_TRY(h, hipMemcpyAsync(h->lw, lw, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (h->parent && h->view_step != 1) { gpf_status s = view_exit(h); if (s) return s; }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->raw_valid = false;
+    h->raw_valid = false; h->raw_sum_valid = false;
     h->initialized = true;
     mutated(h);
     return GPF_OK;
@@ -2438,7 +2492,7 @@ static void set_count(gpf_filter* h, int64_t n_new)
     h->n = n_new; h->cfg.n_particles = n_new; h->cfg.n_global = n_new; h->cfg.gid0 = 0;
     if (h->blk_obs_size != 0) h->blk_obs_size = -1;              // per-block observations do not survive a change of the particle count
     h->blk_last = 0;
-    h->raw_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false; h->pending_gather = false; h->pending_fill = false;
+    h->raw_valid = false; h->raw_sum_valid = false; h->raw_has_q = false; h->raw_q_folded = false; h->max_valid = false; h->pending_gather = false; h->pending_fill = false;
     h->pending_packed = false; h->pending_search = false;
 }
 
@@ -2462,7 +2516,7 @@ static gpf_status resize_optimal(gpf_handle h, int64_t n_new, int32_t check, int
     if ((s = ensure_max(h, pv, true))) return s;
     if ((s = sort_desc(h, pv, n_old))) return s;
     WSum* ws = &h->sc->raw;
-    h->raw_valid = false;
+    h->raw_valid = false; h->raw_sum_valid = false;
     if ((s = summarize(h, pv, ws, true, h->order, true, false, false, true))) return s;
     HIP_TRY(h, hipMemsetAsync(&h->sc->opt_d, 0xff, sizeof(long long), h->stream));
     GPF_LAUNCH(k_opt_threshold, dim3(grid_for(h, n_new, 8)), dim3(BLOCK), 0, h->stream, h->cdf[0], ws, n_new, n_old, h->sc);
@@ -2528,7 +2582,7 @@ gpf_status gpf_resize(gpf_handle h, int64_t n_new, int32_t method, double priori
     if (priority_alpha == priority_alpha) { pv.alpha = priority_alpha; pv.mode = 1; }
     // fixed-point scale for max(n_old, n_new): both N_old 2^K and n_new 2^K must stay below 2^62
     h->K = fix_K(std::max(n_old, n_new));
-    h->raw_valid = false;
+    h->raw_valid = false; h->raw_sum_valid = false;
     WSum* ws = &h->sc->raw;
     if ((s = summarize(h, raw_view(h), &h->sc->raw, true, nullptr, true))) return s;          // logsumexp(log_weights), resize.jl:58
     if (pv.mode != 0) { ws = &h->sc->prio; if ((s = summarize(h, pv, ws, true, nullptr, false))) return s; }
@@ -2777,7 +2831,7 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
         if ((s = scan_launch<InFixQ, 3>(h, 0, in, (int)G, slot, want_cdf, reinterpret_cast<uint64_t*>(out5), mf_all, ex))) return s;
     }
     HIP_TRY(h, hipGetLastError());
-    h->raw_valid = false;            // sc->raw holds the GLOBAL max but no sum: not the unsharded summary
+    h->raw_valid = false; h->raw_sum_valid = false;            // sc->raw holds the GLOBAL max but no sum: not the unsharded summary
     return GPF_OK;
 }
 
@@ -2972,7 +3026,7 @@ gpf_status gpf_shard_commit(gpf_handle h, const double* packed, int64_t m, const
     h->pend_packed = packed; h->pend_mf = mf_all; h->pend_tot = tot_all; h->pend_G = G;
     h->pend_mailbox = h->mb_active && h->mb_engine;
     h->epoch += 1;
-    h->raw_valid = false;
+    h->raw_valid = false; h->raw_sum_valid = false;
     h->max_valid = false;
     h->residual_scanned = false;
     h->push_counted = false;
@@ -3537,7 +3591,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
                mb_wait(h, MB_TOT));
     HIP_TRY(h, hipGetLastError());
     h->epoch += 1;
-    h->raw_valid = false; h->max_valid = false; h->residual_scanned = false; h->push_counted = false;
+    h->raw_valid = false; h->raw_sum_valid = false; h->max_valid = false; h->residual_scanned = false; h->push_counted = false;
     mutated(h);
     return GPF_OK;
 }
