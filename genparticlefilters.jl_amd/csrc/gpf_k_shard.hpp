@@ -328,6 +328,53 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_search_own(PushArgs a, CdfLevels 
     if (threadIdx.x < (unsigned)a.G && s_recv[threadIdx.x])
         atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + (a.G + threadIdx.x) * COUNT_STRIDE), (unsigned long long)s_recv[threadIdx.x]);
 }
+// ... and for RESIDUAL resampling (resample.jl:96-115): an own slot below the global copy total is the jg-th deterministic copy (target jg in
+// the copy-count space, owner by the shards' inclusive copy totals), the others draw from the residual weights; own hits are looked up
+// in this shard's copy-count / residual-weight CDF (k_search's two-line core, both top tables in LDS), the rest get -1 and a count per owner.
+__global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search_own_res(PushArgs a, CdfLevels lw_, CdfLevels lc_, int64_t n, int64_t ntiles,
+                                                                                   int64_t gid0, int32_t* __restrict__ anc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SearchTop st = search_prologue(lw_, lc_, true, ntiles, reinterpret_cast<uint64_t*>(smem));
+    __shared__ PushTables t;
+    __shared__ unsigned int s_recv[MAX_SHARDS];
+    __shared__ ulonglong2 s_coop[2 * SBLOCK];
+    ulonglong2* const lds_wave = s_coop + wave_id() * (2 * WAVE);
+    if (threadIdx.x < MAX_SHARDS) s_recv[threadIdx.x] = 0;
+    push_tables(a, t);
+    const PushScal sc = push_scalars<1>(a, t);
+    const int lane = lane_id();
+    unsigned recv_cnt = 0;
+    for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
+        uint64_t T[2]; int own[2]; const uint64_t* top[2]; const CdfLevels* L[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t j = base + 2 * (int64_t)threadIdx.x + u;
+            const uint64_t jg = (uint64_t)(gid0 + j);
+            uint64_t Tg = 0, Tl = 0; int space = 0;
+            push_target<1>(a, sc, jg, resample_u64(a.seed, (uint32_t)jg, a.epoch), Tg, space);
+            own[u] = j < n ? push_owner(t, a.G, space, Tg, Tl) : -1;
+            const bool mine = own[u] == a.me;
+            T[u] = mine ? Tl : 0;                                                    // (another shard's target: the lane rides along with a dummy)
+            top[u] = (mine && space) ? st.topc : st.topw; L[u] = (mine && space) ? &lc_ : &lw_;
+            for (int q = 0; q < a.G; ++q) {
+                const unsigned c = (unsigned)__popcll(__ballot(own[u] == q));
+                if (lane == q) recv_cnt += c;
+            }
+        }
+        int64_t idx[2];
+        search_pair(st, L, top, T, true, lds_wave, n, ntiles, idx);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t j = base + 2 * (int64_t)threadIdx.x + u;
+            if (j < n) anc[j] = own[u] == a.me ? (int32_t)(gid0 + idx[u]) : -1;
+        }
+    }
+    if (recv_cnt) atomicAdd(&s_recv[lane], recv_cnt);
+    __syncthreads();
+    if (threadIdx.x < (unsigned)a.G && s_recv[threadIdx.x])
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + (a.G + threadIdx.x) * COUNT_STRIDE), (unsigned long long)s_recv[threadIdx.x]);
+}
 // materialize() of a commit with own hits: rows_out[j] = rows_in[anc[j] - gid0], lw[j] = 0 for the slots with anc[j] >= 0
 // (own_range != nullptr: the own hits are the slots [own_range[0], own_range[1]) -- stratified resampling; else the slots with anc >= 0)
 template <int W>

@@ -2919,8 +2919,21 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
     if (h->own_direct) {
         // the shard's own slots: ancestors in place (k_search_own), nothing staged or packed for them; pass 1 walks the other shards' slots
         // only -- with one shard there are none
-        const CdfLevels lw_ = levels(h, 0);
         const int gso = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + GPF_MULTI_NS * SBLOCK - 1) / (GPF_MULTI_NS * SBLOCK), (int64_t)h->n_cu));
+        if (method == GPF_RESAMPLE_RESIDUAL) {
+            if (!h->residual_scanned) return fail(h, GPF_ERR_STATE, "residual push needs gpf_shard_residual_scan first");
+            const CdfLevels lw_ = levels(h, 2), lc_ = levels(h, 1);
+            const size_t lds = search_lds_bytes(h->ntiles, 2);
+            s = timed(h, GPF_K_SEARCH, [&] {
+                GPF_LAUNCH(k_search_own_res, dim3(gso), dim3(SBLOCK), lds, h->stream, a, lw_, lc_, h->n, h->ntiles, h->cfg.gid0, h->anc);
+            });
+            if (s) return s;
+            if (G > 1) GPF_LAUNCH((k_push_scan<1>), dim3(grid), dim3(PUSH_SCAN_BLOCK), 0, h->stream, a);
+            HIP_TRY(h, hipGetLastError());
+            h->push_counted = true;
+            return GPF_OK;
+        }
+        const CdfLevels lw_ = levels(h, 0);
         const size_t lds = multi_lds_bytes(h->ntiles, lw_.logg);
         s = timed(h, GPF_K_SEARCH, [&] {
             if (lw_.logg == 0) GPF_LAUNCH((k_search_own<0>), dim3(gso), dim3(SBLOCK), lds, h->stream, a, lw_, h->n, h->ntiles, h->cfg.gid0, h->anc);
@@ -3468,6 +3481,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     static const bool own_off = getenv("GPF_SHARD_OWN") && !strcmp(getenv("GPF_SHARD_OWN"), "0");        // (A/B measurements; tests of the packed path)
     const bool own = !own_off && !prio && ((method == GPF_RESAMPLE_MULTINOMIAL && !pull && multi_logg(h->ntiles) >= 0 &&
                                             multi_lds_bytes(h->ntiles, multi_logg(h->ntiles)) + 4096 <= (size_t)160 * 1024) ||
+                                           (method == GPF_RESAMPLE_RESIDUAL && !pull && search_lds_bytes(h->ntiles, 2) + 40 * 1024 <= (size_t)160 * 1024) ||
                                            method == GPF_RESAMPLE_STRATIFIED);
     struct OwnScope { gpf_filter* h; ~OwnScope() { h->own_direct = false; h->own_direct_range = false; } } own_scope{h};
     h->own_direct = own; h->own_direct_range = own && method == GPF_RESAMPLE_STRATIFIED;
@@ -3513,7 +3527,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
     } else {
         if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
-        if (own && G == 1 && method == GPF_RESAMPLE_MULTINOMIAL) { counts[0] = 0; counts[1] = n; }     // one shard, own-direct: every slot is an own hit, nothing to push or to wait for
+        if (own && G == 1 && method != GPF_RESAMPLE_STRATIFIED) { counts[0] = 0; counts[1] = n; }     // one shard, own-direct: every slot is an own hit, nothing to push or to wait for
         else {
         // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
         // counts say it overflowed
