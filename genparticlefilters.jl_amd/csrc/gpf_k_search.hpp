@@ -1224,6 +1224,26 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
         // ---- a shard: the served slots leave as exchange entries in slot order (which is grouped by destination shard).  The
         //      ancestors go through LDS so that neighbouring LANES take neighbouring entries: the packed stores are contiguous
         //      and the row reads (ascending ancestors) coalesce
+        if (a.pack.own_anc) {
+            // own-direct: a workgroup whose slots ALL belong to this shard itself (on one rank: every workgroup) writes the ancestors in
+            // place from its registers, like the unsharded kernel -- no LDS round trip, no packed entries
+            const int64_t b0 = a.plan->bounds[a.pack.me], b1 = a.plan->bounds[a.pack.me + 1];
+            const int64_t g0 = sbase + j0, g1 = sbase + (j0 + MJB < n_out ? j0 + MJB : n_out);
+            if (g0 >= b0 && g1 <= b1 && n_out <= a.pack.capacity) {     // block-uniform
+                int32_t* dst = a.pack.own_anc + (sbase + jb - b0);
+                int32_t out[MSLOTS];
+#pragma unroll
+                for (int k = 0; k < MSLOTS; ++k) out[k] = (int32_t)(a.pack.gid0 + (int64_t)(res[k] < last ? res[k] : last));
+                if (jb + MSLOTS <= n_out && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+#pragma unroll
+                    for (int k = 0; k < MSLOTS; k += 4) *reinterpret_cast<int4*>(dst + k) = make_int4(out[k], out[k + 1], out[k + 2], out[k + 3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < MSLOTS; ++k) if (jb + k < n_out) dst[k] = out[k];
+                }
+                return;
+            }
+        }
         int64_t* const s_bnd = reinterpret_cast<int64_t*>(s_T);        // the targets are spent
         __syncthreads();
 #pragma unroll

@@ -3527,8 +3527,13 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
     } else {
         if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
-        if (own && G == 1 && method != GPF_RESAMPLE_STRATIFIED) { counts[0] = 0; counts[1] = n; }     // one shard, own-direct: every slot is an own hit, nothing to push or to wait for
-        else {
+        if (own && G == 1) {
+            // one shard, own-direct: every slot is an own hit -- nothing to exchange, so no split sizes to wait for (the host wait left a
+            // gap in the queue on every resample); the i.i.d. methods have nothing to push either, stratified writes its ancestors in
+            // place from the merge kernel
+            counts[0] = method == GPF_RESAMPLE_STRATIFIED ? n : 0; counts[1] = n;
+            if (method == GPF_RESAMPLE_STRATIFIED && (s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
+        } else {
         // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
         // counts say it overflowed
         if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
