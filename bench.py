@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline loop (no stand-alone gather leg, no named variants, no CPU baseline): what the PMC passes profile, so that "
+                         "a kernel's mean counters are not mixed with the variants' launches of the same kernel")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("GPF_BENCH_LAUNCH_TIMEOUT", "1500")),
                     help="wall-clock bound (s) of the self-launched multi-rank job")
     args = ap.parse_args()
@@ -315,7 +318,7 @@ def main():
     # ---- the stand-alone resample gather (BASELINE.json names it): the hot loop above fuses the gather into the next
     #      propagate, so time k_gather itself on the same state by asking for the ESS between resample and update
     gather = None
-    if not sharded_mode and rank == 0:
+    if not sharded_mode and rank == 0 and not args.headline_only:
         gather = {}
         W = state.row_width
         gbytes = (4 + 8 * W + 8 * W + 8) * n_local                # R anc, R row (random), W row, W lw = 16d + 12
@@ -355,7 +358,7 @@ def main():
                 "ms_per_step": round(seconds / k * 1e3, 5)}
 
     strat = island = plans = sorted_variant = None
-    if not sharded_mode:
+    if not sharded_mode and not args.headline_only:
         # the OPT-IN sorted form of the multinomial resampler (gpf.h GPF_RESAMPLE_MULTINOMIAL_SORTED): same offspring-count
         # law, ancestors in non-decreasing order -- NOT the reference's slot order, so a named variant beside the unchanged headline
         kv = min(K, 200)
@@ -409,7 +412,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 / N=1 only ----
     cpu = cpu_all = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.headline_only:
         from oracle import oracle as o          # cpu_baseline leg: the only place bench.py touches oracle/
         o.lib()
         n_cpu, k_cpu = n_local, CPU_STEPS

@@ -40,7 +40,7 @@ for STEP in "$@"; do
     pmc)     cd /tmp
              for C in FETCH_SIZE WRITE_SIZE; do
                rm -rf $R/gpurun_out/pmc_${TAG}_$C
-               rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_${TAG}_$C -- python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$C.log 2>&1
+               rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_${TAG}_$C -- python3 $R/bench.py --steps 40 --warmup 5 --headline-only > $R/gpurun_out/pmc_${TAG}_$C.log 2>&1
                f=$(find $R/gpurun_out/pmc_${TAG}_$C -name "*counter_collection.csv" | head -1)
                [ -n "$f" ] && cp "$f" $R/gpurun_out/${TAG}_pmc_$C.csv
                rm -rf $R/gpurun_out/pmc_${TAG}_$C

@@ -27,7 +27,7 @@ out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (s
                 "against FETCH_SIZE = 52.3 MB.  WRITE_SIZE is exact.  traffic_bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024.",
        "tag": tag, "kernel_sources_sha16": kernel_sources_sha16(), "kernels": {}}
 PATTERNS = (("k_step", "k_step<1, 2, false, true"), ("k_scan", "k_scan<gpf::InFixQ, 1>"), ("k_search", "k_search_multi<0>"),
-            ("k_search_strat", "k_search_strat"), ("k_gather", "k_gather<2>"))
+            ("k_search_sorted", "k_search_strat<true>"), ("k_search_strat", "k_search_strat<false>"), ("k_gather", "k_gather<2>"))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f"profiles/{tag}_pmc_{c}.csv")):
