@@ -262,6 +262,12 @@ def test_priorities_views_and_invalid_weights(g, o):
         g.pf_resample(v, "multinomial_sorted", check=False); ov.resample("multinomial_sorted", check=False)
         assert np.array_equal(v.parents, ov.parents), sl
         assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw), sl
+    # the whole filter as a sub-state (pf_resample!(state[1:end], ...): the library's local resample, deferred gather with the kept mass)
+    v, ov = st[0:N], orc[0:N]
+    g.pf_resample(v, "multinomial_sorted", check=False); ov.resample("multinomial_sorted", check=False)
+    assert np.array_equal(st.parents, orc.parents)
+    g.pf_update(st, (3,), (None,), ys[2]); orc.update(ys[2])
+    assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw)
     # invalid weights (test/resample.jl:26-31)
     lw = np.full(N, -np.inf)
     st.log_weights = lw; orc.lw = lw.copy()
