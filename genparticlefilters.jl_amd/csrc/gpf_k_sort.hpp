@@ -20,7 +20,10 @@ constexpr uint64_t SORT_VALID = 1ull << 62, SORT_VAL = (1ull << 62) - 1;   // de
 //  same-LINE atomics serialise like same-address ones, ~10 ns each)
 constexpr int SORT_TICKET_WAYS = 8;
 constexpr int SORT_DONE_STRIDE = 32;               // u32 words between completion counters
-__host__ __device__ __forceinline__ size_t sort_ws_desc_offset() { return (size_t)(SORT_PASSES * SORT_BINS + 64 + 18 * SORT_DONE_STRIDE) * sizeof(uint32_t); }
+// (K10d, below: behind the completion words the histogram of the SORT_FINE fine bins and the SORT_BINS + 1 bucket boundaries)
+constexpr int SORT_FINE_BITS = 13, SORT_FINE = 1 << SORT_FINE_BITS, SORT_COARSE_BITS = 24;
+__host__ __device__ __forceinline__ size_t sort_ws_fine_offset() { return (size_t)(SORT_PASSES * SORT_BINS + 64 + 18 * SORT_DONE_STRIDE) * sizeof(uint32_t); }
+__host__ __device__ __forceinline__ size_t sort_ws_desc_offset() { return sort_ws_fine_offset() + (size_t)(SORT_FINE + 2 * SORT_BINS) * sizeof(uint32_t); }
 __host__ inline size_t sort_ws_bytes(int64_t n)
 {
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
@@ -66,6 +69,36 @@ __global__ __launch_bounds__(BLOCK) void k_sort_keys_hist(PrioView pv, int64_t n
     for (int i = P0 * SORT_BINS + threadIdx.x; i < P1 * SORT_BINS; i += BLOCK) { const uint32_t c = (&s_h[0][0])[i]; if (c) atomicAdd(hist + i, c); }
 }
 
+// K10d key pass: the keys + the histogram of the coarse key's top SORT_FINE_BITS bits (the "fine bins": 128 per binade of the
+// distance from the maximum) -- what k_sort_pass<2> cuts into SORT_BINS buckets of (nearly) equal counts.
+__global__ __launch_bounds__(BLOCK) void k_sort_keys_fine(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ fine,
+                                                          uint4* __restrict__ clear, int64_t clear16, const unsigned long long* __restrict__ slots,
+                                                          double* __restrict__ m_out)
+{
+    __shared__ uint32_t s_h[SORT_FINE];
+    double m; int f; fold_slots(slots, m, f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *m_out = m;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < clear16; i += (int64_t)gridDim.x * BLOCK) clear[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = threadIdx.x; i < SORT_FINE; i += BLOCK) s_h[i] = 0;
+    __syncthreads();
+    constexpr int KH_ILP = 4;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += KH_ILP * stride) {
+        double v[KH_ILP];
+#pragma unroll
+        for (int q = 0; q < KH_ILP; ++q) v[q] = i0 + q * stride < n ? pv.at(i0 + q * stride) : 0.0;
+#pragma unroll
+        for (int q = 0; q < KH_ILP; ++q) {
+            if (i0 + q * stride >= n) break;
+            const uint64_t k = sort_key_desc(v[q]);
+            keys[i0 + q * stride] = k;
+            atomicAdd(&s_h[sort_coarse(k, m) >> (SORT_COARSE_BITS - SORT_FINE_BITS)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SORT_FINE; i += BLOCK) { const uint32_t c = s_h[i]; if (c) atomicAdd(fine + i, c); }
+}
+
 // one digit pass.  vals_in == nullptr: the payload is the element's index (first pass).
 #ifdef GPF_DBG_SORT
 __device__ unsigned long long g_dbg_sort[8 * 4096];
@@ -73,18 +106,28 @@ __device__ unsigned long long g_dbg_sort[8 * 4096];
 #else
 #define DBG_SORT(slot) do {} while (0)
 #endif
-// COARSE: the digit is taken from the coarse key (sort_coarse with the maximum *m_ptr) instead of the key itself
-template <bool COARSE>
+// MODE 1: the digit is taken from the coarse key (sort_coarse with the maximum *m_ptr) instead of the key itself
+// MODE 2 (K10d): ONE most-significant "digit" -- the bucket of the key's fine bin.  The fine bins (the coarse key's top SORT_FINE_BITS
+//         bits, histogram `fine` from k_sort_keys_fine) are cut into SORT_BINS buckets of nearly equal counts: bucket(f) = the fine bins
+//         whose exclusive count prefix lies in [b n / 256, (b + 1) n / 256) -- monotone in the key, at most n / 256 + (the fullest fine bin)
+//         elements each.  Every workgroup derives the same table from the same histogram (integers); the first tile leaves the bucket
+//         boundaries in bbase[0 .. SORT_BINS] for k_sort_buckets.
+template <int MODE>
 __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                      uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
                                                      int pass, const uint32_t* __restrict__ hist, uint32_t* __restrict__ ticket,
-                                                     uint64_t* __restrict__ desc, int32_t* __restrict__ timeout, const double* __restrict__ m_ptr)
+                                                     uint64_t* __restrict__ desc, int32_t* __restrict__ timeout, const double* __restrict__ m_ptr,
+                                                     const uint32_t* __restrict__ fine, uint32_t* __restrict__ bbase)
 {
     DBG_SORT(0);
+    constexpr bool COARSE = MODE == 1, PART = MODE == 2;
+    __shared__ uint8_t s_tab[PART ? SORT_FINE : 4];
+    __shared__ uint32_t s_bcnt[SORT_BINS];
     double cm = 0.0;
-    if constexpr (COARSE) cm = *m_ptr;
+    if constexpr (MODE != 0) cm = *m_ptr;
     auto digit_of = [&](uint64_t k) -> uint32_t {
-        if constexpr (COARSE) return (sort_coarse(k, cm) >> (8 * pass)) & 0xffu;
+        if constexpr (PART) return s_tab[sort_coarse(k, cm) >> (SORT_COARSE_BITS - SORT_FINE_BITS)];
+        else if constexpr (COARSE) return (sort_coarse(k, cm) >> (8 * pass)) & 0xffu;
         else return (uint32_t)(k >> (8 * pass)) & 0xffu;
     };
     __shared__ uint32_t s_cnt[SORT_WAVES][SORT_BINS];      // per-wave digit counts, then exclusive offsets of the wave inside the tile's bin
@@ -103,9 +146,40 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     //  16.8-17.5 us per pass against 15.8 -- arrival order is the better look-back order)
     if (tid == 0) s_tile = atomicAdd(ticket + pass * SORT_TICKET_WAYS, 1u);
     for (int i = tid; i < SORT_WAVES * SORT_BINS; i += SORT_BLOCK) (&s_cnt[0][0])[i] = 0;
-    // exclusive scan of the digit's histogram: where each bin starts in the output
     const bool binthr = tid < SORT_BINS;               // the first four waves double as "thread = bin"
-    const uint32_t hv = binthr ? hist[pass * SORT_BINS + tid] : 0u;
+    if constexpr (PART) {
+        // fine bins -> buckets: thread t holds bins FPT t .. FPT t + FPT - 1
+        constexpr int FPT = SORT_FINE / SORT_BLOCK;
+        static_assert(FPT % 4 == 0, "whole uint4 loads");
+        uint32_t hq[FPT], hs = 0;
+#pragma unroll
+        for (int q = 0; q < FPT / 4; ++q) {
+            const uint4 h4 = reinterpret_cast<const uint4*>(fine)[tid * (FPT / 4) + q];
+            hq[4 * q] = h4.x; hq[4 * q + 1] = h4.y; hq[4 * q + 2] = h4.z; hq[4 * q + 3] = h4.w;
+            hs += h4.x + h4.y + h4.z + h4.w;
+        }
+        uint32_t inc = hs;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(inc, d, WAVE); if (lane >= d) inc += o; }
+        if (lane == WAVE - 1) s_scan[wv] = inc;
+        if (binthr) s_bcnt[tid] = 0;
+        __syncthreads();
+        uint32_t c = inc - hs;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) if (w < wv) c += s_scan[w];
+        const double scale = (double)SORT_BINS / (double)n;
+#pragma unroll
+        for (int q = 0; q < FPT; ++q) {
+            const uint32_t bq = (uint32_t)((double)c * scale);            // (monotone in c, the same in every workgroup: that is all it takes)
+            const uint32_t bk = bq > SORT_BINS - 1 ? SORT_BINS - 1 : bq;
+            s_tab[FPT * tid + q] = (uint8_t)bk;
+            if (hq[q]) atomicAdd(&s_bcnt[bk], hq[q]);
+            c += hq[q];
+        }
+        __syncthreads();
+    }
+    // exclusive scan of the digit's histogram: where each bin starts in the output
+    const uint32_t hv = binthr ? (PART ? s_bcnt[tid] : hist[pass * SORT_BINS + tid]) : 0u;
     uint32_t hinc = hv;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(hinc, d, WAVE); if (lane >= d) hinc += o; }
@@ -116,6 +190,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     for (int w = 0; w < SORT_BINS / WAVE; ++w) if (w < wv) hbase += s_scan[w];
     const int64_t tile = s_tile;
     const int64_t t0 = tile * SORT_TILE;
+    if constexpr (PART) {
+        if (tile == 0 && binthr) { bbase[tid] = hbase; if (tid == 0) bbase[SORT_BINS] = (uint32_t)n; }
+    }
     DBG_SORT(1);
     // ---- load (wave-striped: element = t0 + wave * 1024 + item * 64 + lane), rank inside the wave by digit
     uint64_t key[SORT_ITEMS]; int32_t val[SORT_ITEMS]; uint32_t rank[SORT_ITEMS];
@@ -310,6 +387,173 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __res
             const uint32_t v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // verdict and ticket in ONE word (ticket << 1 | flag): a relaxed store needs no release -- a system-scope release at the end of a
             // kernel that has just written 12 MB would first write this XCD's L2 back
+            __hip_atomic_store(host_flag + 1, (ticket << 1) | (int64_t)(v & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- K10d: key pass + ONE partition pass + a sort per bucket in LDS
+// sort_particles=true for filters of up to BK_MAX_N particles.  k_sort_keys_fine (keys + the fine-bin histogram), k_sort_pass<2> (one
+// stable onesweep partition into SORT_BINS buckets of nearly equal counts: every bucket is a contiguous range of positions AND of
+// keys), then this kernel: one workgroup per bucket orders its <= BK_CAP keys inside LDS and writes them to their final places.
+//   sub-key : the bucket's coarse keys, minus their minimum, shifted down to BK_SUB_BITS bits (a few thousand keys over 8192 values);
+//   count   : one LDS atomic per key on the histogram of the sub-keys (its return value = the key's arrival number in its bin), an
+//             exclusive scan of the histogram, ord[bin start + arrival number] = the key's position in the bucket;
+//   rank    : a key alone in its bin stands at the bin's start; the others count, among their bin's members, the smaller full 64-bit keys
+//             + the equal ones that stood before them in the bucket (the partition is stable, so that is index order: the sort is stable
+//             although the arrival numbers are not ordered);
+//   output  : keys and payloads go to their positions in LDS, then leave as coalesced stores.
+// A bin of more than BK_RUN_MAX keys (many equal or nearly equal weights) or a bucket of more than BK_CAP keys (a fine bin fuller than
+// the slack) stays in SOME order -- still a permutation of the input: the weight sums taken over it are right -- and raises the
+// flag of k_sort_finish (pinned host word; the host then sorts with all eight passes over the full key).
+// Three launches against five for the three coarse passes + finish: the two lower coarse passes and the finish's pass over global
+// memory happen inside LDS, without ballots or per-wave counters (every key is independent of the others until the scan).
+#ifdef GPF_DBG_SORT
+__device__ unsigned long long g_dbg_bk[8 * 256];
+#define DBG_BK(slot) do { if (threadIdx.x == 0) g_dbg_bk[8 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+#else
+#define DBG_BK(slot) do {} while (0)
+#endif
+constexpr int BK_BLOCK = 1024, BK_WAVES = BK_BLOCK / WAVE, BK_ITEMS = 8, BK_CAP = BK_BLOCK * BK_ITEMS;
+constexpr int BK_SUB_BITS = 14, BK_SUB = 1 << BK_SUB_BITS, BK_SUB_PER = BK_SUB / BK_BLOCK;   // (16-bit counters, two to a word: 32 KB)
+constexpr int BK_RUN_MAX = 1024;                              // keys of one bin that are still ranked (quadratic work inside the bin)
+constexpr int64_t BK_MAX_N = (int64_t)SORT_BINS * 4608;      // mean bucket <= 4608 keys: BK_CAP - 4608 left for the fullest fine bin
+__global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                                                           uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
+                                                           const uint32_t* __restrict__ bbase, uint32_t* __restrict__ done, int64_t* host_flag,
+                                                           int64_t ticket, const double* __restrict__ m_ptr)
+{
+    __shared__ uint64_t s_key[BK_CAP];                   // by position in the bucket; at the end by final position
+    __shared__ int32_t s_val[BK_CAP];                    // by final position
+    __shared__ uint32_t s_binw[BK_SUB / 2 + 1];          // 16-bit counts (<= BK_CAP) two to a word, then exclusive starts (+ the total)
+    uint16_t* const s_bin = reinterpret_cast<uint16_t*>(s_binw);
+    __shared__ uint16_t s_ord[BK_CAP];                   // bin start + arrival number -> position in the bucket
+    __shared__ uint32_t s_scan[BK_WAVES];
+    __shared__ uint32_t s_mn[BK_WAVES], s_mx[BK_WAVES];
+    const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
+    DBG_BK(0);
+    const int64_t b0 = bbase[blockIdx.x];
+    const int64_t Lg = (int64_t)bbase[blockIdx.x + 1] - b0;
+    const double cm = *m_ptr;
+    bool too_long = false;
+    if (Lg > BK_CAP) {
+        for (int64_t i = tid; i < Lg; i += BK_BLOCK) { keys_out[b0 + i] = keys_in[b0 + i]; vals_out[b0 + i] = vals_in[b0 + i]; }
+        too_long = true;
+    } else if (Lg > 0) {
+        const int L = (int)Lg;
+        uint64_t key[BK_ITEMS]; int32_t val[BK_ITEMS]; uint32_t co[BK_ITEMS];
+        uint32_t cmin = 0xffffffffu, cmax = 0u;
+#pragma unroll
+        for (int it = 0; it < BK_ITEMS; ++it) {
+            const int i = it * BK_BLOCK + tid;
+            key[it] = 0ull; val[it] = 0;
+            if (i < L) { key[it] = keys_in[b0 + i]; val[it] = vals_in[b0 + i]; }
+        }
+#pragma unroll
+        for (int q = 0; q < BK_SUB_PER / 2; ++q) s_binw[q * BK_BLOCK + tid] = 0u;
+#pragma unroll
+        for (int it = 0; it < BK_ITEMS; ++it) {
+            const int i = it * BK_BLOCK + tid;
+            co[it] = 0u;
+            if (i < L) {
+                s_key[i] = key[it];
+                co[it] = sort_coarse(key[it], cm);
+                cmin = co[it] < cmin ? co[it] : cmin; cmax = co[it] > cmax ? co[it] : cmax;
+            }
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const uint32_t a = (uint32_t)__shfl_xor((int)cmin, s, WAVE), c = (uint32_t)__shfl_xor((int)cmax, s, WAVE);
+            cmin = a < cmin ? a : cmin; cmax = c > cmax ? c : cmax;
+        }
+        DBG_BK(1);
+        if (lane == 0) { s_mn[wv] = cmin; s_mx[wv] = cmax; }
+        __syncthreads();
+        DBG_BK(2);
+#pragma unroll
+        for (int w = 0; w < BK_WAVES; ++w) { cmin = s_mn[w] < cmin ? s_mn[w] : cmin; cmax = s_mx[w] > cmax ? s_mx[w] : cmax; }
+        const uint32_t span = cmax - cmin;
+        const int shift = (span >> BK_SUB_BITS) ? (32 - __clz((int)span)) - BK_SUB_BITS : 0;
+        uint32_t arr[BK_ITEMS];
+#pragma unroll
+        for (int it = 0; it < BK_ITEMS; ++it) {
+            const int i = it * BK_BLOCK + tid;
+            co[it] = (co[it] - cmin) >> shift;                                     // the sub-key from here on
+            const int hsh = 16 * (int)(co[it] & 1u);
+            arr[it] = i < L ? (atomicAdd(&s_binw[co[it] >> 1], 1u << hsh) >> hsh) & 0xffffu : 0u;
+        }
+        __syncthreads();
+        // exclusive scan of the BK_SUB counts: thread t owns bins BK_SUB_PER t .. BK_SUB_PER t + BK_SUB_PER - 1
+        uint32_t cnt[BK_SUB_PER], tsum = 0;
+#pragma unroll
+        for (int q = 0; q < BK_SUB_PER; ++q) { cnt[q] = s_bin[BK_SUB_PER * tid + q]; tsum += cnt[q]; }
+        uint32_t inc = tsum;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(inc, d, WAVE); if (lane >= d) inc += o; }
+        if (lane == WAVE - 1) s_scan[wv] = inc;
+        __syncthreads();
+        uint32_t ex = inc - tsum;
+#pragma unroll
+        for (int w = 0; w < BK_WAVES; ++w) if (w < wv) ex += s_scan[w];
+#pragma unroll
+        for (int q = 0; q < BK_SUB_PER; ++q) { s_bin[BK_SUB_PER * tid + q] = (uint16_t)ex; ex += cnt[q]; }
+        if (tid == BK_BLOCK - 1) s_bin[BK_SUB] = (uint16_t)ex;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < BK_ITEMS; ++it) {
+            const int i = it * BK_BLOCK + tid;
+            if (i < L) s_ord[s_bin[co[it]] + arr[it]] = (uint16_t)i;
+        }
+        __syncthreads();
+        DBG_BK(3);
+        uint32_t pos[BK_ITEMS];
+#pragma unroll
+        for (int it = 0; it < BK_ITEMS; ++it) {
+            const int i = it * BK_BLOCK + tid;
+            pos[it] = 0u;
+            if (i >= L) continue;
+            const uint32_t st = s_bin[co[it]], c = s_bin[co[it] + 1] - st;
+            uint32_t rank = arr[it];                      // (a bin that is too full keeps its arrival order: distinct positions all the same)
+            if (c > (uint32_t)BK_RUN_MAX) too_long = true;
+            else if (c > 1) {
+                rank = 0;
+                for (uint32_t q = 0; q < c; q += 4) {    // (four independent member reads in flight; past the bin's end: the element itself, which counts 0)
+                    uint32_t i2[4]; uint64_t k2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) i2[u] = q + u < c ? (uint32_t)s_ord[st + q + u] : (uint32_t)i;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) k2[u] = s_key[i2[u]];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rank += (k2[u] < key[it] || (k2[u] == key[it] && i2[u] < (uint32_t)i)) ? 1u : 0u;
+                }
+            }
+            pos[it] = st + rank;
+        }
+        DBG_BK(4);
+        __syncthreads();                                  // (every read of s_key by bucket position is done)
+        DBG_BK(5);
+#pragma unroll
+        for (int it = 0; it < BK_ITEMS; ++it) {
+            const int i = it * BK_BLOCK + tid;
+            if (i < L) { s_key[pos[it]] = key[it]; s_val[pos[it]] = val[it]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < BK_ITEMS; ++it) {
+            const int j = it * BK_BLOCK + tid;
+            if (j < L) { keys_out[b0 + j] = s_key[j]; vals_out[b0 + j] = s_val[j]; }
+        }
+        DBG_BK(6);
+#ifdef GPF_DBG_SORT
+        if (tid == 0) g_dbg_bk[8 * blockIdx.x + 7] = (unsigned long long)L;
+#endif
+    }
+    // completion and verdict: as k_sort_finish
+    if (__syncthreads_or((int)too_long) && tid == 0) { atomicOr(done, 1u); __threadfence(); }
+    if (tid == 0) {
+        const uint32_t grp = blockIdx.x & 15u, members = (gridDim.x - grp + 15u) / 16u, groups = gridDim.x < 16u ? gridDim.x : 16u;
+        if (atomicAdd(done + (2 + grp) * SORT_DONE_STRIDE, 1u) == members - 1 && atomicAdd(done + SORT_DONE_STRIDE, 1u) == groups - 1) {
+            const uint32_t v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(host_flag + 1, (ticket << 1) | (int64_t)(v & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }

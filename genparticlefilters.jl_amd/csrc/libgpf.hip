@@ -924,7 +924,7 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
 //                   -- ensure_max); the caller finishes the runs of equal coarse keys (k_sort_finish).  keys -> keys_out -> keys ->
 //                   keys_out, payload index -> idx_in -> order -> idx_in: the finish brings both back to h->keys / h->order.
 //   coarse = false: all eight passes over the 64-bit key; the eighth leaves keys / permutation in h->keys / h->order.
-gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse, uint32_t** ws_used = nullptr)
+gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse, uint32_t** ws_used = nullptr, bool buckets = false)
 {
     gpf_status s = ensure_sort_buffers(h);
     if (s) return s;
@@ -937,6 +937,8 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse
     uint32_t* hist = reinterpret_cast<uint32_t*>(ws);
     uint32_t* const ticket_words = hist + SORT_PASSES * SORT_BINS;
     double* m_ptr = reinterpret_cast<double*>(ticket_words + SORT_M_WORD);
+    uint32_t* fine = reinterpret_cast<uint32_t*>(ws + sort_ws_fine_offset());
+    uint32_t* bbase = fine + SORT_FINE;
     uint64_t* desc = reinterpret_cast<uint64_t*>(ws + sort_ws_desc_offset());
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
     uint32_t* const ticket = ticket_words;
@@ -944,6 +946,13 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse
     // (ONE workgroup per CU: every workgroup ends with up to 256 global atomic adds per sorted digit into the same counters; with 2 / 4
     //  workgroups per CU a four-digit kernel took 16.0 / 24.2 us against 13.3)
     const unsigned long long* slots = h->mslots[h->mcur];
+    if (buckets) {
+        // K10d: keys + fine-bin histogram, ONE partition pass (keys -> keys_out, payload index -> idx_in); the caller runs k_sort_buckets
+        GPF_LAUNCH(k_sort_keys_fine, dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, fine, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
+        GPF_LAUNCH(k_sort_pass<2>, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, h->keys, nullptr, h->keys_out, h->idx_in, n, 0, hist, ticket, desc, h->h_timeout, m_ptr, fine, bbase);
+        HIP_TRY(h, hipGetLastError());
+        return GPF_OK;
+    }
     if (coarse) GPF_LAUNCH((k_sort_keys_hist<0, true>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
     else        GPF_LAUNCH((k_sort_keys_hist<0, false>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
     for (int p = 0; p < (coarse ? 3 : SORT_PASSES); ++p) {
@@ -951,8 +960,8 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse
         uint64_t* kout = (p & 1) ? h->keys : h->keys_out;
         const int32_t* vin = p == 0 ? nullptr : ((p & 1) ? h->idx_in : h->order);
         int32_t* vout = (p & 1) ? h->order : h->idx_in;
-        if (coarse) GPF_LAUNCH(k_sort_pass<true>, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout, m_ptr);
-        else        GPF_LAUNCH(k_sort_pass<false>, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout, m_ptr);
+        if (coarse) GPF_LAUNCH(k_sort_pass<1>, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout, m_ptr, nullptr, nullptr);
+        else        GPF_LAUNCH(k_sort_pass<0>, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, kin, vin, kout, vout, n, p, hist, ticket, desc, h->h_timeout, m_ptr, nullptr, nullptr);
     }
     HIP_TRY(h, hipGetLastError());
     return GPF_OK;
@@ -963,20 +972,30 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse
 //   sort_desc_begin enqueues the sort; *pending = the finish's verdict is still out: the caller may enqueue the work that consumes
 //   the order behind it and asks sort_desc_flagged AFTERWARDS (no host wait between the sort and its consumers) -- when that says
 //   "flagged" the order was wrong: sort_passes(..., false) and the consumers again.
-int sort_mode() { static const int mode = [] { const char* e = getenv("GPF_SORT"); return e && !strcmp(e, "radix8") ? 1 : (e && !strcmp(e, "fallback") ? 2 : 0); }(); return mode; }
+// GPF_SORT: radix8 = always the eight passes; fallback = the fast path AND the eight passes (tests); coarse3 = the three coarse passes +
+// k_sort_finish also where the bucket sort (K10d, n <= BK_MAX_N) would run (A/B measurements, tests of that path at small n)
+int sort_mode() { static const int mode = [] { const char* e = getenv("GPF_SORT"); return e && strstr(e, "radix8") ? 1 : (e && strstr(e, "fallback") ? 2 : 0); }(); return mode; }
+bool sort_buckets_ok(int64_t n) { static const bool off = getenv("GPF_SORT") && strstr(getenv("GPF_SORT"), "coarse3"); return !off && n <= BK_MAX_N; }
 gpf_status sort_desc_begin(gpf_filter* h, const PrioView& pv, int64_t n, bool* pending)
 {
     *pending = false;
     if (sort_mode() == 1) return sort_passes(h, pv, n, false);
+    const bool buckets = sort_buckets_ok(n);
     uint32_t* ws = nullptr;
-    gpf_status s = sort_passes(h, pv, n, true, &ws);             // (the third pass leaves keys / payload in h->keys_out / h->idx_in)
+    gpf_status s = sort_passes(h, pv, n, true, &ws, buckets);    // (either form leaves keys / payload in h->keys_out / h->idx_in)
     if (s) return s;
     if (!h->h_sort_flag) { HIP_TRY(h, hipHostMalloc(&h->h_sort_flag, 2 * sizeof(int64_t))); h->h_sort_flag[0] = h->h_sort_flag[1] = 0; }
     uint32_t* done = ws + SORT_PASSES * SORT_BINS + 64;                                  // (behind this sort's zeroed tickets)
     const double* m_ptr = reinterpret_cast<const double*>(ws + SORT_PASSES * SORT_BINS + SORT_M_WORD);
     h->sort_ticket += 1;
-    GPF_LAUNCH(k_sort_finish, dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)), dim3(FIN_BLOCK), 0, h->stream, h->keys_out, h->idx_in, h->keys, h->order, n,
-               done, h->h_sort_flag, h->sort_ticket, m_ptr);
+    if (buckets) {
+        const uint32_t* bbase = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ws) + sort_ws_fine_offset()) + SORT_FINE;
+        GPF_LAUNCH(k_sort_buckets, dim3(SORT_BINS), dim3(BK_BLOCK), 0, h->stream, h->keys_out, h->idx_in, h->keys, h->order, n, bbase,
+                   done, h->h_sort_flag, h->sort_ticket, m_ptr);
+    } else {
+        GPF_LAUNCH(k_sort_finish, dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)), dim3(FIN_BLOCK), 0, h->stream, h->keys_out, h->idx_in, h->keys, h->order, n,
+                   done, h->h_sort_flag, h->sort_ticket, m_ptr);
+    }
     HIP_TRY(h, hipGetLastError());
     *pending = true;
     return GPF_OK;
@@ -3699,6 +3718,10 @@ extern "C" int gpf_debug_strat(unsigned long long* out, int n_words)
 #endif
 
 #ifdef GPF_DBG_SORT
+extern "C" int gpf_debug_sort_buckets(unsigned long long* out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gpf::g_dbg_bk), (size_t)n_words * sizeof(unsigned long long));
+}
 extern "C" int gpf_debug_sort(unsigned long long* out, int n_words)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gpf::g_dbg_sort), (size_t)n_words * sizeof(unsigned long long));

@@ -328,7 +328,9 @@ def test_sort_finish_window_boundaries(g, o):
 @pytest.mark.gpu
 def test_sort_fallback_and_eight_pass_modes_agree():
     """GPF_SORT=fallback: the host treats every finish as flagged and re-sorts with all eight passes; GPF_SORT=radix8: the eight
-    passes alone.  Same ancestors as the default (separate processes: the switch is read once per process)."""
+    passes alone; GPF_SORT=coarse3: the three coarse passes + k_sort_finish where the default is the bucket sort (key pass, one partition
+    pass, one workgroup per bucket in LDS; n <= 1 179 648).  Same ancestors as the default (separate processes: the switch is read once
+    per process)."""
     import json
     import subprocess
     import sys
@@ -338,14 +340,14 @@ def test_sort_fallback_and_eight_pass_modes_agree():
             "g.pf_update(st, (2,), (None,), ys[1]); g.pf_resample(st, 'stratified', sort_particles=True, check=False)\n"
             "p = st.parents; print(json.dumps([int(p.sum()), int((p * np.arange(1, p.size + 1) % 1000003).sum()), g.get_lml_est(st)]))\n").replace("ROOT", repr(root))
     outs = []
-    for mode in ("", "fallback", "radix8"):
+    for mode in ("", "fallback", "radix8", "coarse3", "coarse3,fallback"):
         env = dict(os.environ); env.pop("GPF_SORT", None)
         if mode:
             env["GPF_SORT"] = mode
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1] == outs[2]
+    assert all(x == outs[0] for x in outs[1:]), outs
 
 
 @pytest.mark.gpu
