@@ -71,19 +71,23 @@ __global__ __launch_bounds__(BLOCK) void k_sort_keys_hist(PrioView pv, int64_t n
 
 // K10d key pass: the keys + the histogram of the coarse key's top SORT_FINE_BITS bits (the "fine bins": 128 per binade of the
 // distance from the maximum) -- what k_sort_pass<2> cuts into SORT_BINS buckets of (nearly) equal counts.
-__global__ __launch_bounds__(BLOCK) void k_sort_keys_fine(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ fine,
+#ifndef GPF_KF_BLOCK
+#define GPF_KF_BLOCK 1024
+#endif
+constexpr int KF_BLOCK = GPF_KF_BLOCK;             // one workgroup per CU (the flush is global atomics), many waves: every lane has all its loads in flight at once
+__global__ __launch_bounds__(KF_BLOCK) void k_sort_keys_fine(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ fine,
                                                           uint4* __restrict__ clear, int64_t clear16, const unsigned long long* __restrict__ slots,
                                                           double* __restrict__ m_out)
 {
     __shared__ uint32_t s_h[SORT_FINE];
     double m; int f; fold_slots(slots, m, f);
     if (blockIdx.x == 0 && threadIdx.x == 0) *m_out = m;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < clear16; i += (int64_t)gridDim.x * BLOCK) clear[i] = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = threadIdx.x; i < SORT_FINE; i += BLOCK) s_h[i] = 0;
+    for (int64_t i = (int64_t)blockIdx.x * KF_BLOCK + threadIdx.x; i < clear16; i += (int64_t)gridDim.x * KF_BLOCK) clear[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = threadIdx.x; i < SORT_FINE; i += KF_BLOCK) s_h[i] = 0;
     __syncthreads();
     constexpr int KH_ILP = 4;
-    const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    for (int64_t i0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += KH_ILP * stride) {
+    const int64_t stride = (int64_t)gridDim.x * KF_BLOCK;
+    for (int64_t i0 = (int64_t)blockIdx.x * KF_BLOCK + threadIdx.x; i0 < n; i0 += KH_ILP * stride) {
         double v[KH_ILP];
 #pragma unroll
         for (int q = 0; q < KH_ILP; ++q) v[q] = i0 + q * stride < n ? pv.at(i0 + q * stride) : 0.0;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_keys_fine(PrioView pv, int64_t n
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SORT_FINE; i += BLOCK) { const uint32_t c = s_h[i]; if (c) atomicAdd(fine + i, c); }
+    for (int i = threadIdx.x; i < SORT_FINE; i += KF_BLOCK) { const uint32_t c = s_h[i]; if (c) atomicAdd(fine + i, c); }
 }
 
 // one digit pass.  vals_in == nullptr: the payload is the element's index (first pass).
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     constexpr bool COARSE = MODE == 1, PART = MODE == 2;
     __shared__ uint8_t s_tab[PART ? SORT_FINE : 4];
     __shared__ uint32_t s_bcnt[SORT_BINS];
+    __shared__ uint32_t s_last[SORT_WAVES];
     double cm = 0.0;
     if constexpr (MODE != 0) cm = *m_ptr;
     auto digit_of = [&](uint64_t k) -> uint32_t {
@@ -161,33 +166,43 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
         uint32_t inc = hs;
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(inc, d, WAVE); if (lane >= d) inc += o; }
-        if (lane == WAVE - 1) s_scan[wv] = inc;
-        if (binthr) s_bcnt[tid] = 0;
+        if (lane == WAVE - 1) { s_scan[wv] = inc; s_last[wv] = hq[FPT - 1]; }
+        if (binthr) s_bcnt[tid] = (uint32_t)n;             // s_bcnt: where each bucket STARTS (a bucket no fine bin opens starts at the end)
         __syncthreads();
         uint32_t c = inc - hs;
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) if (w < wv) c += s_scan[w];
         const double scale = (double)SORT_BINS / (double)n;
+        auto bucket_at = [&](uint32_t cc) { const uint32_t bq = (uint32_t)((double)cc * scale); return bq > SORT_BINS - 1 ? (uint32_t)(SORT_BINS - 1) : bq; };   // (monotone in cc, the same in every workgroup: that is all it takes)
+        // the bucket of the bin before this thread's first one (-1 in front of bin 0): a bin whose bucket differs from its
+        // predecessor's opens every bucket in between at its own exclusive count
+        uint32_t hprev = (uint32_t)__shfl_up((int)hq[FPT - 1], 1, WAVE);
+        if (lane == 0 && wv > 0) hprev = s_last[wv - 1];
+        int pb = tid == 0 ? -1 : (int)bucket_at(c - hprev);
 #pragma unroll
         for (int q = 0; q < FPT; ++q) {
-            const uint32_t bq = (uint32_t)((double)c * scale);            // (monotone in c, the same in every workgroup: that is all it takes)
-            const uint32_t bk = bq > SORT_BINS - 1 ? SORT_BINS - 1 : bq;
+            const int bk = (int)bucket_at(c);
             s_tab[FPT * tid + q] = (uint8_t)bk;
-            if (hq[q]) atomicAdd(&s_bcnt[bk], hq[q]);
+            for (int b_ = pb + 1; b_ <= bk; ++b_) s_bcnt[b_] = c;
+            pb = bk;
             c += hq[q];
         }
         __syncthreads();
     }
     // exclusive scan of the digit's histogram: where each bin starts in the output
-    const uint32_t hv = binthr ? (PART ? s_bcnt[tid] : hist[pass * SORT_BINS + tid]) : 0u;
-    uint32_t hinc = hv;
+    uint32_t hbase = 0;
+    if constexpr (PART) hbase = binthr ? s_bcnt[tid] : 0u;
+    else {
+        const uint32_t hv = binthr ? hist[pass * SORT_BINS + tid] : 0u;
+        uint32_t hinc = hv;
 #pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(hinc, d, WAVE); if (lane >= d) hinc += o; }
-    if (binthr && lane == WAVE - 1) s_scan[wv] = hinc;
-    __syncthreads();
-    uint32_t hbase = hinc - hv;
+        for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(hinc, d, WAVE); if (lane >= d) hinc += o; }
+        if (binthr && lane == WAVE - 1) s_scan[wv] = hinc;
+        __syncthreads();
+        hbase = hinc - hv;
 #pragma unroll
-    for (int w = 0; w < SORT_BINS / WAVE; ++w) if (w < wv) hbase += s_scan[w];
+        for (int w = 0; w < SORT_BINS / WAVE; ++w) if (w < wv) hbase += s_scan[w];
+    }
     const int64_t tile = s_tile;
     const int64_t t0 = tile * SORT_TILE;
     if constexpr (PART) {
@@ -396,7 +411,8 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __res
 // sort_particles=true for filters of up to BK_MAX_N particles.  k_sort_keys_fine (keys + the fine-bin histogram), k_sort_pass<2> (one
 // stable onesweep partition into SORT_BINS buckets of nearly equal counts: every bucket is a contiguous range of positions AND of
 // keys), then this kernel: one workgroup per bucket orders its <= BK_CAP keys inside LDS and writes them to their final places.
-//   sub-key : the bucket's coarse keys, minus their minimum, shifted down to BK_SUB_BITS bits (a few thousand keys over 8192 values);
+//   sub-key : the bucket's keys, minus their minimum, shifted down to BK_SUB_BITS bits (a few thousand keys over 16 384 values; keys beyond
+//             the coarse key's range -- -inf, weights that underflow -- in the last one);
 //   count   : one LDS atomic per key on the histogram of the sub-keys (its return value = the key's arrival number in its bin), an
 //             exclusive scan of the histogram, ord[bin start + arrival number] = the key's position in the bucket;
 //   rank    : a key alone in its bin stands at the bin's start; the others count, among their bin's members, the smaller full 64-bit keys
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(const uint64_t* __res
     uint16_t* const s_bin = reinterpret_cast<uint16_t*>(s_binw);
     __shared__ uint16_t s_ord[BK_CAP];                   // bin start + arrival number -> position in the bucket
     __shared__ uint32_t s_scan[BK_WAVES];
-    __shared__ uint32_t s_mn[BK_WAVES], s_mx[BK_WAVES];
+    __shared__ uint64_t s_mn[BK_WAVES], s_mx[BK_WAVES];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
     DBG_BK(0);
     const int64_t b0 = bbase[blockIdx.x];
@@ -442,7 +458,8 @@ __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(const uint64_t* __res
     } else if (Lg > 0) {
         const int L = (int)Lg;
         uint64_t key[BK_ITEMS]; int32_t val[BK_ITEMS]; uint32_t co[BK_ITEMS];
-        uint32_t cmin = 0xffffffffu, cmax = 0u;
+        bool far[BK_ITEMS];                              // beyond the coarse key's range (more than 2^9 below the maximum, -inf): the last bin
+        uint64_t kmin = ~0ull, kmax = 0ull;              // (kmax: over the keys inside the range)
 #pragma unroll
         for (int it = 0; it < BK_ITEMS; ++it) {
             const int i = it * BK_BLOCK + tid;
@@ -454,31 +471,36 @@ __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(const uint64_t* __res
 #pragma unroll
         for (int it = 0; it < BK_ITEMS; ++it) {
             const int i = it * BK_BLOCK + tid;
-            co[it] = 0u;
+            far[it] = false;
             if (i < L) {
                 s_key[i] = key[it];
-                co[it] = sort_coarse(key[it], cm);
-                cmin = co[it] < cmin ? co[it] : cmin; cmax = co[it] > cmax ? co[it] : cmax;
+                far[it] = sort_coarse(key[it], cm) == 0xFFFFFFu;
+                kmin = key[it] < kmin ? key[it] : kmin;
+                if (!far[it]) kmax = key[it] > kmax ? key[it] : kmax;
             }
         }
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) {
-            const uint32_t a = (uint32_t)__shfl_xor((int)cmin, s, WAVE), c = (uint32_t)__shfl_xor((int)cmax, s, WAVE);
-            cmin = a < cmin ? a : cmin; cmax = c > cmax ? c : cmax;
+            const uint64_t a = shfl_xor_u64(kmin, s), c = shfl_xor_u64(kmax, s);
+            kmin = a < kmin ? a : kmin; kmax = c > kmax ? c : kmax;
         }
         DBG_BK(1);
-        if (lane == 0) { s_mn[wv] = cmin; s_mx[wv] = cmax; }
+        if (lane == 0) { s_mn[wv] = kmin; s_mx[wv] = kmax; }
         __syncthreads();
         DBG_BK(2);
 #pragma unroll
-        for (int w = 0; w < BK_WAVES; ++w) { cmin = s_mn[w] < cmin ? s_mn[w] : cmin; cmax = s_mx[w] > cmax ? s_mx[w] : cmax; }
-        const uint32_t span = cmax - cmin;
-        const int shift = (span >> BK_SUB_BITS) ? (32 - __clz((int)span)) - BK_SUB_BITS : 0;
+        for (int w = 0; w < BK_WAVES; ++w) { kmin = s_mn[w] < kmin ? s_mn[w] : kmin; kmax = s_mx[w] > kmax ? s_mx[w] : kmax; }
+        // the sub-key: the key itself (linear in the weight inside a binade: the keys of a bucket are a narrow range of weights), from the
+        // bucket's smallest key, shifted down to BK_SUB_BITS bits; weakly monotone in the key, which is all the ranking below needs
+        const uint64_t span = kmax > kmin ? kmax - kmin : 0ull;
+        const int bits = span ? 64 - __clzll((long long)span) : 0;
+        const int shift = bits > BK_SUB_BITS ? bits - BK_SUB_BITS : 0;
         uint32_t arr[BK_ITEMS];
 #pragma unroll
         for (int it = 0; it < BK_ITEMS; ++it) {
             const int i = it * BK_BLOCK + tid;
-            co[it] = (co[it] - cmin) >> shift;                                     // the sub-key from here on
+            const uint64_t sk = (key[it] - kmin) >> shift;
+            co[it] = far[it] ? (uint32_t)(BK_SUB - 1) : (sk > (uint64_t)(BK_SUB - 2) ? (uint32_t)(BK_SUB - 2) : (uint32_t)sk);
             const int hsh = 16 * (int)(co[it] & 1u);
             arr[it] = i < L ? (atomicAdd(&s_binw[co[it] >> 1], 1u << hsh) >> hsh) & 0xffffu : 0u;
         }
