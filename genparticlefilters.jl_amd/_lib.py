@@ -35,7 +35,7 @@ SYMBOLS = [
     ("gpf_last_error", C.c_char_p, [_H]),
     ("gpf_synchronize", C.c_int, [_H]),
     ("gpf_initialize", C.c_int, [_H, _pd, C.c_int32]),
-    ("gpf_update", C.c_int, [_H, _pd, C.c_int32]),
+    ("gpf_update", C.c_int, [_H, C.c_void_p, C.c_int32]),          # (const double*: api.py passes the address as an integer)
     ("gpf_initialize_proposal", C.c_int, [_H, _pd, C.c_int32, C.c_int32]),
     ("gpf_update_proposal", C.c_int, [_H, _pd, C.c_int32, C.c_int32]),
     ("gpf_initialize_strata", C.c_int, [_H, _pd, C.c_int32, _pd, C.c_int32, C.c_int32]),

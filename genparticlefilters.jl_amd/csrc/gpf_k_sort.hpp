@@ -441,7 +441,7 @@ __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(const uint64_t* __res
 {
     __shared__ uint64_t s_key[BK_CAP];                   // by position in the bucket; at the end by final position
     __shared__ int32_t s_val[BK_CAP];                    // by final position
-    __shared__ uint32_t s_binw[BK_SUB / 2 + 1];          // 16-bit counts (<= BK_CAP) two to a word, then exclusive starts (+ the total)
+    __shared__ __attribute__((aligned(16))) uint32_t s_binw[BK_SUB / 2 + 4];          // 16-bit counts (<= BK_CAP) two to a word, then exclusive starts (+ the total)
     uint16_t* const s_bin = reinterpret_cast<uint16_t*>(s_binw);
     __shared__ uint16_t s_ord[BK_CAP];                   // bin start + arrival number -> position in the bucket
     __shared__ uint32_t s_scan[BK_WAVES];
@@ -505,10 +505,16 @@ __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(const uint64_t* __res
             arr[it] = i < L ? (atomicAdd(&s_binw[co[it] >> 1], 1u << hsh) >> hsh) & 0xffffu : 0u;
         }
         __syncthreads();
-        // exclusive scan of the BK_SUB counts: thread t owns bins BK_SUB_PER t .. BK_SUB_PER t + BK_SUB_PER - 1
+        // exclusive scan of the BK_SUB counts: thread t owns bins BK_SUB_PER t .. BK_SUB_PER t + BK_SUB_PER - 1 (BK_SUB_PER / 2 packed words)
+        static_assert(BK_SUB_PER % 8 == 0, "whole uint4 words");
         uint32_t cnt[BK_SUB_PER], tsum = 0;
 #pragma unroll
-        for (int q = 0; q < BK_SUB_PER; ++q) { cnt[q] = s_bin[BK_SUB_PER * tid + q]; tsum += cnt[q]; }
+        for (int q = 0; q < BK_SUB_PER / 8; ++q) {
+            const uint4 w4 = reinterpret_cast<const uint4*>(s_binw)[(BK_SUB_PER / 8) * tid + q];
+            const uint32_t ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { cnt[8 * q + 2 * u] = ww[u] & 0xffffu; cnt[8 * q + 2 * u + 1] = ww[u] >> 16; tsum += (ww[u] & 0xffffu) + (ww[u] >> 16); }
+        }
         uint32_t inc = tsum;
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(inc, d, WAVE); if (lane >= d) inc += o; }
@@ -518,7 +524,12 @@ __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(const uint64_t* __res
 #pragma unroll
         for (int w = 0; w < BK_WAVES; ++w) if (w < wv) ex += s_scan[w];
 #pragma unroll
-        for (int q = 0; q < BK_SUB_PER; ++q) { s_bin[BK_SUB_PER * tid + q] = (uint16_t)ex; ex += cnt[q]; }
+        for (int q = 0; q < BK_SUB_PER / 8; ++q) {
+            uint32_t ww[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t lo = ex; ex += cnt[8 * q + 2 * u]; ww[u] = lo | (ex << 16); ex += cnt[8 * q + 2 * u + 1]; }
+            reinterpret_cast<uint4*>(s_binw)[(BK_SUB_PER / 8) * tid + q] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+        }
         if (tid == BK_BLOCK - 1) s_bin[BK_SUB] = (uint16_t)ex;
         __syncthreads();
 #pragma unroll

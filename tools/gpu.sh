@@ -12,6 +12,7 @@
 #   pmc                   FETCH_SIZE / WRITE_SIZE passes of bench.py (one counter per pass) -> TAG_pmc_*.csv (+ tools/pmc_to_json.py TAG)
 #   configs               tools/bench_configs.py (the other BASELINE configs at their per-GPU sizes) -> TAG_configs.jsonl
 #   loop:NAME:ARGS        rocprofv3 kernel stats of `python3 tools/NAME.py ARGS` (ARGS comma-separated) -> TAG_NAME_ARGS_kernel_stats.csv
+#   gaps:NAME:ARGS        kernel trace of the same loop; a window of it with the idle gap in front of every kernel (tools/trace_gaps.py) -> TAG_NAME_ARGS_gaps.txt
 #   sq:NAME:ARGS          SQ wait / VALU / LDS counters of the same loop (tools/gpu_pmc_kernels.sh) -> TAG_sq_NAME_ARGS
 #   sharded               one-rank sharded table (tools/sharded_loop.py; no communicator / 1-rank RCCL) -> TAG_sharded_one_rank.txt
 #   variant:OUT:METHOD:DEFS   tools/variant_stats.sh OUT METHOD DEFS (DEFS: comma-separated -D sets, alternating A/B rocprofv3 runs)
@@ -50,6 +51,9 @@ for STEP in "$@"; do
     loop)    cd /tmp; D=$R/gpurun_out/prof_${A1}_${A2//,/_}; rm -rf $D
              rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/tools/$A1.py ${A2//,/ } > $D.log 2>&1; tail -2 $D.log | cut -c1-200
              stats_of $D $R/gpurun_out/${TAG}_${A1}_${A2//,/_}_kernel_stats.csv; rm -rf $D ;;
+    gaps)    cd /tmp; D=$R/gpurun_out/gaps_${A1}_${A2//,/_}; rm -rf $D
+             rocprofv3 --kernel-trace --output-format csv -d $D -- python3 $R/tools/$A1.py ${A2//,/ } > $D.log 2>&1; tail -1 $D.log | cut -c1-200
+             python3 $R/tools/trace_gaps.py $D 0.6 ${A3:-40} > $R/gpurun_out/${TAG}_${A1}_${A2//,/_}_gaps.txt; cat $R/gpurun_out/${TAG}_${A1}_${A2//,/_}_gaps.txt; rm -rf $D ;;
     sq)      LOOP=$A1.py bash $R/tools/gpu_pmc_kernels.sh ${TAG}_sq_${A1}_${A2//,/_} ${A2//,/ } 2>&1 | tail -40 | cut -c1-200 ;;
     sharded) OUT=gpurun_out/${TAG}_sharded_one_rank.txt; : > $OUT
              for M in multinomial stratified residual; do
