@@ -25,8 +25,11 @@ def test_c_example_builds_and_links(g, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,method,ess_fraction", [("lgssm2", 0, 2.0), ("sv1", 2, 0.5), ("object_motion", 1, 0.5)])
-def test_c_example_equals_python_host(g, tmp_path, name, method, ess_fraction):
+@pytest.mark.parametrize("name,method,ess_fraction,rejuv", [("lgssm2", 0, 2.0, 0), ("sv1", 2, 0.5, 0), ("object_motion", 1, 0.5, 0),
+                                                            ("bearings4", 1, 0.5, 1), ("sv1", 0, 2.0, 2)])
+def test_c_example_equals_python_host(g, tmp_path, name, method, ess_fraction, rejuv):
+    """rejuv 1 / 2: one MH / move-reweight sweep after every resample (the README loop's `if` body); with a timing request the host
+    prints a second line, the first stays the same"""
     exe = build(str(tmp_path))
     model = g.models.by_name(name); T, N, seed = 12, 20_000, 31
     ys = g.models.simulate(model, T)
@@ -34,13 +37,17 @@ def test_c_example_equals_python_host(g, tmp_path, name, method, ess_fraction):
     with open(inp, "w") as f:
         f.write(f"{model.model_id} {model.params.size}\n" + " ".join(repr(float(v)) for v in model.params) + "\n")
         f.write(f"{ys.shape[1]} {T}\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in ys) + "\n")
-    out = subprocess.check_output([exe, inp, str(N), str(seed), str(method), str(ess_fraction)], text=True).split()
+    lines = subprocess.check_output([exe, inp, str(N), str(seed), str(method), str(ess_fraction), str(rejuv), "3"], text=True).splitlines()
+    out = lines[0].split()
+    assert lines[1].split()[0] == "us_per_step" and float(lines[1].split()[1]) > 0.0
     lml, ess, mean0, var0, n_res = float(out[0]), float(out[1]), float(out[2]), float(out[3]), int(out[4])
-    st = g.pf_initialize(model, (1,), ys[0], N, seed=seed)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=seed, keep_prev=rejuv != 0)
     mname = ["multinomial", "residual", "stratified"][method]
     k = 0
     for t in range(1, T):
         if g.get_ess(st) < ess_fraction * N:
             g.pf_resample(st, mname, check=False, **({"sort_particles": False} if method == 2 else {})); k += 1
+            if rejuv:
+                g.pf_rejuvenate(st, None, (), 1, method="move" if rejuv == 1 else "reweight")
         g.pf_update(st, (t + 1,), (None,), ys[t])
     assert (lml, ess, mean0, var0, n_res) == (g.get_lml_est(st), g.get_ess(st), g.mean(st, 0), g.var(st, 0), k)

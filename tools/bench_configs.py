@@ -52,6 +52,7 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
     st.synchronize()
     el = time.perf_counter() - t0
     gc.enable()
+    n_res_timed = n_res                    # (the per-kernel timing steps below replay early observations and resample almost every time)
     kids = list(g._lib.KERNEL_NAMES)
     for k in kids:
         st.kernel_timing(k, True)
@@ -63,9 +64,30 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
         if cnt:
             per[g._lib.KERNEL_NAMES[k]] = round(ms / cnt * 1e3, 2)
     out = dict(config=name, N=N, steps=steps, us_per_step=round(el / steps * 1e6, 2), particle_steps_per_s=round(N * steps / el, 1),
-               resampled_steps=n_res, kernels_us=per, log_ml=g.get_lml_est(st))
+               resampled_steps=n_res_timed, kernels_us=per, log_ml=g.get_lml_est(st))
     print(json.dumps(out), flush=True)
     st.close()
+
+
+def run_c_host(name, model_name, N, method_id, rejuvenate, ess_frac, steps=200, warm=10):
+    """the same ESS-triggered loop from the compiled host (examples/lgssm_filter.c over the C ABI): what the loop costs without the
+    Python wrappers on the critical path between the ESS read and the next launch -- the drop-in's host is Julia (ccall), not Python"""
+    import subprocess
+    import tempfile
+    model = g.models.by_name(model_name)
+    ys = g.models.simulate(model, steps + warm + 1)
+    tmp = tempfile.mkdtemp()
+    exe, inp = os.path.join(tmp, "host"), os.path.join(tmp, "input.txt")
+    libdir = os.path.join(ROOT, "genparticlefilters.jl_amd")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "lgssm_filter.c"), "-o", exe,
+                           os.path.join(libdir, "libgpf_hip.so"), "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
+    with open(inp, "w") as f:
+        f.write(f"{model.model_id} {model.params.size}\n" + " ".join(repr(float(v)) for v in model.params) + "\n")
+        f.write(f"{ys.shape[1]} {ys.shape[0]}\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in ys) + "\n")
+    out = subprocess.check_output([exe, inp, str(N), "1", str(method_id), str(ess_frac), str(rejuvenate), str(warm + 1)], text=True).splitlines()
+    first = out[0].split(); us = float(out[1].split()[1])
+    print(json.dumps(dict(config=name, N=N, steps=steps, us_per_step=round(us, 2), particle_steps_per_s=round(N / us * 1e6, 1),
+                          resampled_steps_incl_warmup=int(first[4]), warmup=warm, log_ml=float(first[0]))), flush=True)
 
 
 if __name__ == "__main__":
@@ -73,3 +95,5 @@ if __name__ == "__main__":
     for c in CONFIGS:
         if not want or any(c[0].startswith(w) for w in want):
             run(*c)
+            if c[0].startswith("config4"):
+                run_c_host("config4, the same loop from a compiled host (examples/lgssm_filter.c)", "bearings4", c[2], 1, 1, 0.5)
