@@ -16,6 +16,7 @@ CONFIGS = [
     ("config2l lgssm2 multinomial, lazy search (k_step_search)", "lgssm2", 1_000_000, "multinomial", {"_lazy": True}, None, None),
     ("config3 lgssm2 stratified(unsorted) [1 of 8 shards' worth]", "lgssm2", 1_000_000, "stratified", {"sort_particles": False}, None, None),
     ("lgssm2 stratified(sorted)", "lgssm2", 1_000_000, "stratified", {"sort_particles": True}, None, None),
+    ("bearings4 stratified(sorted) (weights beyond the coarse key's range every step)", "bearings4", 1_000_000, "stratified", {"sort_particles": True}, None, None),
     ("lgssm2 residual", "lgssm2", 1_000_000, "residual", {}, None, None),
     ("config4 bearings4 ESS<N/2 residual + MH [1 of 4 shards' worth]", "bearings4", 1_000_000, "residual", {}, "move", 0.5),
     ("config5 sv1 multinomial + move-reweight", "sv1", 2_000_000, "multinomial", {}, "reweight", None),
