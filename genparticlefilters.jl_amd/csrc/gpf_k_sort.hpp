@@ -22,6 +22,14 @@ constexpr int SORT_TICKET_WAYS = 8;
 constexpr int SORT_DONE_STRIDE = 32;               // u32 words between completion counters
 // (K10d, below: behind the completion words the histogram of the SORT_FINE fine bins and the SORT_BINS + 1 bucket boundaries)
 constexpr int SORT_FINE_BITS = 13, SORT_FINE = 1 << SORT_FINE_BITS, SORT_COARSE_BITS = 24;
+// "dead" keys: more than 2^6 = 64 below the maximum (incl. -inf and everything beyond the coarse key's range).  Their fixed-point weight
+// is exactly 0 (exp(-64) 2^52 < 1/2): no slot can ever choose them, so their order among themselves cannot be observed
+// through pf_resample! -- they only have to stand behind every live key.  K10d sends them all to the last bucket, which k_sort_buckets
+// (it orders every bucket IN PLACE) leaves as the partition wrote it, in the partition's (stable) order: -inf-heavy and sharply peaked weight vectors (a bearings filter: half the particles) sort without ranking
+// their dead half and without the eight-pass fall-back.  (All weights -inf: every key is dead, the order is the identity -- which is the
+// stable sort of equal keys that the uniform fall-back of safe_softmax needs.)
+constexpr uint32_t SORT_COARSE_DEAD = 28u << 19;             // sort_coarse of 2^6: binade index 6 + 21, + 1
+constexpr int SORT_FINE_DEAD = (int)(SORT_COARSE_DEAD >> (SORT_COARSE_BITS - SORT_FINE_BITS));
 __host__ __device__ __forceinline__ size_t sort_ws_fine_offset() { return (size_t)(SORT_PASSES * SORT_BINS + 64 + 18 * SORT_DONE_STRIDE) * sizeof(uint32_t); }
 __host__ __device__ __forceinline__ size_t sort_ws_desc_offset() { return sort_ws_fine_offset() + (size_t)(SORT_FINE + 2 * SORT_BINS) * sizeof(uint32_t); }
 __host__ inline size_t sort_ws_bytes(int64_t n)
@@ -172,16 +180,19 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
         uint32_t c = inc - hs;
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) if (w < wv) c += s_scan[w];
-        const double scale = (double)SORT_BINS / (double)n;
-        auto bucket_at = [&](uint32_t cc) { const uint32_t bq = (uint32_t)((double)cc * scale); return bq > SORT_BINS - 1 ? (uint32_t)(SORT_BINS - 1) : bq; };   // (monotone in cc, the same in every workgroup: that is all it takes)
+        // live keys: buckets 0 .. 254 by their exclusive count; dead keys (fine bins from SORT_FINE_DEAD on): bucket 255
+        const double scale = (double)(SORT_BINS - 1) / (double)n;
+        auto bucket_at = [&](uint32_t cc) { const uint32_t bq = (uint32_t)((double)cc * scale); return bq > SORT_BINS - 2 ? (uint32_t)(SORT_BINS - 2) : bq; };   // (monotone in cc, the same in every workgroup: that is all it takes)
         // the bucket of the bin before this thread's first one (-1 in front of bin 0): a bin whose bucket differs from its
         // predecessor's opens every bucket in between at its own exclusive count
         uint32_t hprev = (uint32_t)__shfl_up((int)hq[FPT - 1], 1, WAVE);
         if (lane == 0 && wv > 0) hprev = s_last[wv - 1];
-        int pb = tid == 0 ? -1 : (int)bucket_at(c - hprev);
+        static_assert(SORT_FINE_DEAD % FPT == 0, "a thread's fine bins are all live or all dead");
+        const bool dead = FPT * tid >= SORT_FINE_DEAD;
+        int pb = tid == 0 ? -1 : (FPT * tid - 1 >= SORT_FINE_DEAD ? SORT_BINS - 1 : (int)bucket_at(c - hprev));
 #pragma unroll
         for (int q = 0; q < FPT; ++q) {
-            const int bk = (int)bucket_at(c);
+            const int bk = dead ? SORT_BINS - 1 : (int)bucket_at(c);
             s_tab[FPT * tid + q] = (uint8_t)bk;
             for (int b_ = pb + 1; b_ <= bk; ++b_) s_bcnt[b_] = c;
             pb = bk;
@@ -411,8 +422,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __res
 // sort_particles=true for filters of up to BK_MAX_N particles.  k_sort_keys_fine (keys + the fine-bin histogram), k_sort_pass<2> (one
 // stable onesweep partition into SORT_BINS buckets of nearly equal counts: every bucket is a contiguous range of positions AND of
 // keys), then this kernel: one workgroup per bucket orders its <= BK_CAP keys inside LDS and writes them to their final places.
-//   sub-key : the bucket's keys, minus their minimum, shifted down to BK_SUB_BITS bits (a few thousand keys over 16 384 values; keys beyond
-//             the coarse key's range -- -inf, weights that underflow -- in the last one);
+//   sub-key : the distance from the maximum, linear between the bucket's smallest and largest, 14 bits (a few thousand keys over 16 384 values);
 //   count   : one LDS atomic per key on the histogram of the sub-keys (its return value = the key's arrival number in its bin), an
 //             exclusive scan of the histogram, ord[bin start + arrival number] = the key's position in the bucket;
 //   rank    : a key alone in its bin stands at the bin's start; the others count, among their bin's members, the smaller full 64-bit keys
@@ -434,32 +444,32 @@ constexpr int BK_BLOCK = 1024, BK_WAVES = BK_BLOCK / WAVE, BK_ITEMS = 8, BK_CAP 
 constexpr int BK_SUB_BITS = 14, BK_SUB = 1 << BK_SUB_BITS, BK_SUB_PER = BK_SUB / BK_BLOCK;   // (16-bit counters, two to a word: 32 KB)
 constexpr int BK_RUN_MAX = 1024;                              // keys of one bin that are still ranked (quadratic work inside the bin)
 constexpr int64_t BK_MAX_N = (int64_t)SORT_BINS * 4608;      // mean bucket <= 4608 keys: BK_CAP - 4608 left for the fullest fine bin
-__global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
-                                                           uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
+__global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(uint64_t* keys, int32_t* vals, int64_t n,
                                                            const uint32_t* __restrict__ bbase, uint32_t* __restrict__ done, int64_t* host_flag,
                                                            int64_t ticket, const double* __restrict__ m_ptr)
 {
+    // in place: a workgroup has its whole bucket in registers / LDS before it stores anything, and buckets are disjoint ranges
+    const uint64_t* const keys_in = keys; const int32_t* const vals_in = vals;
+    uint64_t* const keys_out = keys; int32_t* const vals_out = vals;
     __shared__ uint64_t s_key[BK_CAP];                   // by position in the bucket; at the end by final position
     __shared__ int32_t s_val[BK_CAP];                    // by final position
     __shared__ __attribute__((aligned(16))) uint32_t s_binw[BK_SUB / 2 + 4];          // 16-bit counts (<= BK_CAP) two to a word, then exclusive starts (+ the total)
     uint16_t* const s_bin = reinterpret_cast<uint16_t*>(s_binw);
     __shared__ uint16_t s_ord[BK_CAP];                   // bin start + arrival number -> position in the bucket
     __shared__ uint32_t s_scan[BK_WAVES];
-    __shared__ uint64_t s_mn[BK_WAVES], s_mx[BK_WAVES];
+    __shared__ double s_mn[BK_WAVES], s_mx[BK_WAVES];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
     DBG_BK(0);
     const int64_t b0 = bbase[blockIdx.x];
-    const int64_t Lg = (int64_t)bbase[blockIdx.x + 1] - b0;
+    const int64_t Lg = blockIdx.x == SORT_BINS - 1 ? 0 : (int64_t)bbase[blockIdx.x + 1] - b0;     // (the last bucket: the dead keys, already in place)
     const double cm = *m_ptr;
     bool too_long = false;
-    if (Lg > BK_CAP) {
-        for (int64_t i = tid; i < Lg; i += BK_BLOCK) { keys_out[b0 + i] = keys_in[b0 + i]; vals_out[b0 + i] = vals_in[b0 + i]; }
-        too_long = true;
-    } else if (Lg > 0) {
+    if (Lg > BK_CAP) too_long = true;                   // (stays as the partition left it)
+    else if (Lg > 0) {
         const int L = (int)Lg;
         uint64_t key[BK_ITEMS]; int32_t val[BK_ITEMS]; uint32_t co[BK_ITEMS];
-        bool far[BK_ITEMS];                              // beyond the coarse key's range (more than 2^9 below the maximum, -inf): the last bin
-        uint64_t kmin = ~0ull, kmax = 0ull;              // (kmax: over the keys inside the range)
+        double dist[BK_ITEMS];                           // the distance from the maximum (< 64: live keys only in these buckets)
+        double dmin = __builtin_huge_val(), dmax = -__builtin_huge_val();
 #pragma unroll
         for (int it = 0; it < BK_ITEMS; ++it) {
             const int i = it * BK_BLOCK + tid;
@@ -471,36 +481,32 @@ __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(const uint64_t* __res
 #pragma unroll
         for (int it = 0; it < BK_ITEMS; ++it) {
             const int i = it * BK_BLOCK + tid;
-            far[it] = false;
+            dist[it] = 0.0;
             if (i < L) {
                 s_key[i] = key[it];
-                far[it] = sort_coarse(key[it], cm) == 0xFFFFFFu;
-                kmin = key[it] < kmin ? key[it] : kmin;
-                if (!far[it]) kmax = key[it] > kmax ? key[it] : kmax;
+                dist[it] = cm - sort_key_value(key[it]);
+                dmin = dist[it] < dmin ? dist[it] : dmin;
+                dmax = dist[it] > dmax ? dist[it] : dmax;
             }
         }
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) {
-            const uint64_t a = shfl_xor_u64(kmin, s), c = shfl_xor_u64(kmax, s);
-            kmin = a < kmin ? a : kmin; kmax = c > kmax ? c : kmax;
-        }
+        dmax = wave_max_f64(dmax); dmin = -wave_max_f64(-dmin);
         DBG_BK(1);
-        if (lane == 0) { s_mn[wv] = kmin; s_mx[wv] = kmax; }
+        if (lane == 0) { s_mn[wv] = dmin; s_mx[wv] = dmax; }
         __syncthreads();
         DBG_BK(2);
 #pragma unroll
-        for (int w = 0; w < BK_WAVES; ++w) { kmin = s_mn[w] < kmin ? s_mn[w] : kmin; kmax = s_mx[w] > kmax ? s_mx[w] : kmax; }
-        // the sub-key: the key itself (linear in the weight inside a binade: the keys of a bucket are a narrow range of weights), from the
-        // bucket's smallest key, shifted down to BK_SUB_BITS bits; weakly monotone in the key, which is all the ranking below needs
-        const uint64_t span = kmax > kmin ? kmax - kmin : 0ull;
-        const int bits = span ? 64 - __clzll((long long)span) : 0;
-        const int shift = bits > BK_SUB_BITS ? bits - BK_SUB_BITS : 0;
+        for (int w = 0; w < BK_WAVES; ++w) { dmin = s_mn[w] < dmin ? s_mn[w] : dmin; dmax = s_mx[w] > dmax ? s_mx[w] : dmax; }
+        // the sub-key: the distance from the maximum, LINEAR between the bucket's extremes (a bucket is a narrow quantile slice of the
+        // weights: their density is nearly flat across it), BK_SUB bins.  Weakly monotone in the key (m - v rounds monotonically, so do the
+        // subtraction, the product and the truncation), which is all the ranking below needs.  (First form: the key's own bits, shifted --
+        // linear in the weight inside a binade, but a bucket whose weights straddle 0 spans 2^62 key values and collapses into two bins.)
+        const double scale = dmax > dmin ? (double)(BK_SUB - 1) / (dmax - dmin) : 0.0;
         uint32_t arr[BK_ITEMS];
 #pragma unroll
         for (int it = 0; it < BK_ITEMS; ++it) {
             const int i = it * BK_BLOCK + tid;
-            const uint64_t sk = (key[it] - kmin) >> shift;
-            co[it] = far[it] ? (uint32_t)(BK_SUB - 1) : (sk > (uint64_t)(BK_SUB - 2) ? (uint32_t)(BK_SUB - 2) : (uint32_t)sk);
+            const uint32_t sk = i < L ? (uint32_t)((dist[it] - dmin) * scale) : 0u;
+            co[it] = sk > (uint32_t)(BK_SUB - 1) ? (uint32_t)(BK_SUB - 1) : sk;
             const int hsh = 16 * (int)(co[it] & 1u);
             arr[it] = i < L ? (atomicAdd(&s_binw[co[it] >> 1], 1u << hsh) >> hsh) & 0xffffu : 0u;
         }

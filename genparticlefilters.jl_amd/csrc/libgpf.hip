@@ -991,8 +991,12 @@ gpf_status sort_desc_begin(gpf_filter* h, const PrioView& pv, int64_t n, bool* p
     h->sort_ticket += 1;
     if (buckets) {
         const uint32_t* bbase = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ws) + sort_ws_fine_offset()) + SORT_FINE;
-        GPF_LAUNCH(k_sort_buckets, dim3(SORT_BINS), dim3(BK_BLOCK), 0, h->stream, h->keys_out, h->idx_in, h->keys, h->order, n, bbase,
+        // every bucket is ordered in place (the dead keys' bucket is left as the partition wrote it): the partition's output buffers
+        // become the sorted keys / the permutation
+        GPF_LAUNCH(k_sort_buckets, dim3(SORT_BINS), dim3(BK_BLOCK), 0, h->stream, h->keys_out, h->idx_in, n, bbase,
                    done, h->h_sort_flag, h->sort_ticket, m_ptr);
+        std::swap(h->keys, h->keys_out);
+        std::swap(h->order, h->idx_in);
     } else {
         GPF_LAUNCH(k_sort_finish, dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)), dim3(FIN_BLOCK), 0, h->stream, h->keys_out, h->idx_in, h->keys, h->order, n,
                    done, h->h_sort_flag, h->sort_ticket, m_ptr);

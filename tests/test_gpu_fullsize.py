@@ -304,6 +304,34 @@ def test_sorted_stratified_sizes_and_patterns(g, o, N, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [2000, 300_007, 1_000_000])
+def test_sorted_stratified_with_dead_weights(g, o, N):
+    """weights more than 2^6 below the maximum have the fixed-point weight 0: the bucket sort leaves them unranked in its last bucket
+    (gpf_k_sort.hpp SORT_COARSE_DEAD) -- a bearings filter (half its particles after every update), 60 % -inf, one live particle among
+    dead ones, live weights right at the threshold.  The ancestors are the oracle's: no slot can choose a dead particle."""
+    model = g.models.bearings4(); ys = g.models.simulate(model, 6)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=8)
+    orc = o.OracleFilter(model.model_id, model.params, N, 8).initialize(ys[0])
+    for t in range(1, 4):
+        g.pf_resample(st, "stratified", sort_particles=True, check=False); orc.resample("stratified", sort_particles=True, check=False)
+        assert np.array_equal(st.parents, orc.parents), (N, t)
+        g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
+    rng = np.random.default_rng(3)
+    pats = [np.where(rng.random(N) < 0.6, -np.inf, -40.0 * rng.random(N)),
+            np.concatenate([[-1.0], -1.0 - 64.0 - 500.0 * rng.random(N - 1)]),
+            -1.0 - np.where(rng.random(N) < 0.5, 63.9999 + 2e-4 * rng.random(N), 30.0 * rng.random(N)),
+            np.where(rng.random(N) < 0.999, -1e300, -rng.random(N))]
+    for k, lw in enumerate(pats):
+        lw[rng.integers(N)] = 0.0                                          # the maximum
+        st.log_weights = lw; orc.lw = lw.copy()
+        g.pf_resample(st, "stratified", sort_particles=True, check=False); orc.resample("stratified", sort_particles=True, check=False)
+        assert np.array_equal(st.parents, orc.parents), (N, "pattern", k)
+        assert g.get_lml_est(st) == orc.log_ml_estimate()
+        g.pf_update(st, (5,), (None,), ys[4]); orc.update(ys[4])
+    st.close()
+
+
+@pytest.mark.gpu
 def test_sort_finish_window_boundaries(g, o):
     """runs of equal coarse sort keys of every length around the finish's window (48 to either side): up to 49 elements are ordered by
     the finish, longer runs take the eight-pass fallback; mixed in one filter with ordinary weights"""
