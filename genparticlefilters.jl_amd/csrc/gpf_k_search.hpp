@@ -907,10 +907,22 @@ __device__ unsigned long long g_dbg_strat[8 * 4096];
 // (2-3 workgroups per CU -- 41 KB of LDS each --: a 10^6-slot launch, 489 workgroups, is ONE resident round)
 // SORTED: the targets are the sorted uniforms of GPF_RESAMPLE_MULTINOMIAL_SORTED instead of one uniform per stratum: the same merge from
 // the cell side, with the number of targets below a prefix found by a binary search of the block's targets in LDS (no closed form)
+// Slots per lane: 8 for the sorted uniforms (a workgroup = one tile of SP_TILE slots: the spec), 4 for the strata -- on a CDF in sorted order
+// (sort_particles=true) the kernel lasts as long as its widest workgroups, the light tail's, whose cell ranges halve with the slots:
+// 15.0 -> 12.9 us at 10^6 (unsorted CDF: 10.2 -> 10.1; profiles/r04_sort_buckets.txt).
+#ifndef GPF_MSLOTS_STRAT
+#define GPF_MSLOTS_STRAT 4
+#endif
+constexpr int MJB_STRAT = MBLOCK * GPF_MSLOTS_STRAT;
+template <bool SORTED> constexpr int strat_slots_per_block() { return SORTED ? MBLOCK * GPF_MSLOTS : MJB_STRAT; }
 template <bool SORTED>
 __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
 {
     DBG_STRAT(0, wall_clock64());
+    // (these shadow the namespace-scope constants of the same names for the whole kernel)
+    constexpr int MSLOTS = SORTED ? GPF_MSLOTS : GPF_MSLOTS_STRAT;
+    constexpr int MJB = MBLOCK * MSLOTS;
+    constexpr int64_t MONO_WIDE = GPF_MONO_WIDE_MULT * (int64_t)MJB, MONO_WIDE2 = GPF_MONO_WIDE2_MULT * (int64_t)MJB;
     static_assert(MSLOTS % 4 == 0, "ancestors leave the lane as 16-byte stores");
     __shared__ __attribute__((aligned(16))) uint64_t s_T[MJB + 4];   // targets of the block's slots (+inf beyond n, and as padding)
     __shared__ __attribute__((aligned(16))) uint32_t s_mark[MJB];

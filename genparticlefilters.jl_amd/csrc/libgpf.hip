@@ -1287,8 +1287,8 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
                 case GPF_RESAMPLE_RESIDUAL:    GPF_LAUNCH((k_search<1>), dim3(gsr), dim3(SBLOCK), lds, h->stream, sa); break;
                 case GPF_RESAMPLE_MULTINOMIAL_SORTED:   // sorted uniforms: the same streaming merge (the spacing sums were enqueued above)
                     GPF_LAUNCH((k_search_strat<true>), dim3((unsigned)((h->n + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa); break;
-                default:                       // monotone targets: a streaming merge, MJB slots per workgroup
-                    GPF_LAUNCH((k_search_strat<false>), dim3((unsigned)((h->n + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa); break;
+                default:                       // monotone targets: a streaming merge, MJB_STRAT slots per workgroup
+                    GPF_LAUNCH((k_search_strat<false>), dim3((unsigned)((h->n + MJB_STRAT - 1) / MJB_STRAT)), dim3(MBLOCK), 0, h->stream, sa); break;
             }
         });
     };
@@ -3019,7 +3019,7 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
         sa.update_lml = 0;                                            // the commit carries the log-ML update
         sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W, h->push_extra, h->push_pv, h->own_direct ? h->anc : nullptr, (int)me};
         s = timed(h, GPF_K_GATHER, [&] {
-            GPF_LAUNCH((k_search_strat<false>), dim3((unsigned)((cap + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa);
+            GPF_LAUNCH((k_search_strat<false>), dim3((unsigned)((cap + MJB_STRAT - 1) / MJB_STRAT)), dim3(MBLOCK), 0, h->stream, sa);
         });
         if (s) return s;
         HIP_TRY(h, hipGetLastError());

@@ -61,7 +61,7 @@ for STEP in "$@"; do
                echo -n "$M, 1-rank RCCL, mailbox: " >> $OUT; GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
              done
              cat $OUT ;;
-    variant) bash tools/variant_stats.sh gpurun_out/${TAG}_$A1 $A2 ${A3//,/ } 2>&1 | tail -30 | cut -c1-200 ;;
+    variant) bash tools/variant_stats.sh $R/gpurun_out/${TAG}_$A1 $A2 ${A3//,/ } 2>&1 | tail -30 | cut -c1-200 ;;
     py)      python3 tools/$A1.py ${A2//,/ } > gpurun_out/${TAG}_$A1.txt 2> gpurun_out/${TAG}_$A1.err; cut -c1-220 gpurun_out/${TAG}_$A1.txt | tail -40; tail -3 gpurun_out/${TAG}_$A1.err ;;
     *)       echo "unknown step $S" ;;
   esac

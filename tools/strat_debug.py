@@ -20,7 +20,8 @@ for t in range(1, 10):
 resample()
 st.synchronize()
 lib = C.CDLL(os.environ["GPF_LIB_OVERRIDE"])
-nb = (N + 2047) // 2048
+spb = 2048 if mode == "multinomial_sorted" else 1024            # slots per workgroup (gpf_k_search.hpp: SP_TILE / MJB_STRAT)
+nb = (N + spb - 1) // spb
 buf = (C.c_ulonglong * (8 * 4096))()
 assert lib.gpf_debug_strat(buf, 8 * 4096) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8)[:nb].astype(np.int64)
@@ -29,7 +30,7 @@ start, pro, sea, end, ncell = (a[:, 0] - t0) / 100.0, (a[:, 1] - a[:, 0]) / 100.
 print(mode, "blocks", nb, "kernel span us", ((a[:, 3] - t0) / 100.0).max())
 print("start us: max %.2f" % start.max(), " prologue: mean %.2f max %.2f" % (pro.mean(), pro.max()), " search: mean %.2f max %.2f" % (sea.mean(), sea.max()),
       " epilogue: mean %.2f max %.2f" % (end.mean(), end.max()))
-wide = ncell > 8 * 2048
+wide = ncell > 8 * spb
 print("wide blocks", int(wide.sum()), "search us wide mean %.2f max %.2f" % (sea[wide].mean() if wide.any() else 0, sea[wide].max() if wide.any() else 0),
       " streamed mean %.2f max %.2f" % (sea[~wide].mean(), sea[~wide].max()))
 for lo, hi in ((0, 2048), (2048, 4096), (4096, 8192), (8192, 16385), (16385, 1 << 40)):
