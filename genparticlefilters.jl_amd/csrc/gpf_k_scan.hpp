@@ -488,6 +488,54 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int64_t n,
     }
 }
 
+// The same summary with the HOST as the folder (the ESS / log-ML getters block on the result anyway): every workgroup leaves its partial
+// sums as eight tagged words in ONE 64-byte line of pinned host memory and is done -- no dependency between workgroups, no collecting
+// workgroup (k_sum_reduce: two cross-XCD hops of ~2 us between the partial stores and the publish).  The host waits for the tags of this
+// launch and adds <= n_cu lines up.  1024-thread workgroups, 8 weights per lane, every load in flight at once.
+//   line b: {S low 31 bits, S high bits | flags << 40, Q limb 0..3, maximum low / high 32 bits}, each (tag << 48) | value
+constexpr int SH_BLOCK = 1024, SH_NWAVES = SH_BLOCK / WAVE, SH_ROWS = 4, SH_TILE = SH_BLOCK * 2 * SH_ROWS;      // 8192 weights per workgroup and trip
+__global__ __launch_bounds__(SH_BLOCK) void k_sum_host(InFixQ in, int64_t n, const unsigned long long* __restrict__ slots, int64_t* __restrict__ h_part, int64_t q_ticket)
+{
+    double m; int f;
+    fold_slots(slots, m, f);
+    in.m = m; in.flags = f;
+    const int lane = lane_id(), wv = wave_id();
+    uint64_t acc[5] = {0, 0, 0, 0, 0};                // S, Ql0..3
+    for (int64_t base = (int64_t)blockIdx.x * SH_TILE; base < n; base += (int64_t)gridDim.x * SH_TILE) {
+        double v0[SH_ROWS], v1[SH_ROWS];
+#pragma unroll
+        for (int k = 0; k < SH_ROWS; ++k) in.raw2(base + (int64_t)k * (2 * SH_BLOCK) + 2 * (int64_t)threadIdx.x, n, v0[k], v1[k]);
+#pragma unroll
+        for (int k = 0; k < SH_ROWS; ++k) {
+            uint64_t q0, q1;
+            in.conv2(base + (int64_t)k * (2 * SH_BLOCK) + 2 * (int64_t)threadIdx.x, n, v0[k], v1[k], q0, q1);
+            acc[0] += q0 + q1;
+            uint64_t lo = q0 * q0, hi = __umul64hi(q0, q0);
+            acc[1] += lo & 0xffffffffull; acc[2] += lo >> 32; acc[3] += hi & 0xffffffffull; acc[4] += hi >> 32;
+            lo = q1 * q1; hi = __umul64hi(q1, q1);
+            acc[1] += lo & 0xffffffffull; acc[2] += lo >> 32; acc[3] += hi & 0xffffffffull; acc[4] += hi >> 32;
+        }
+    }
+    __shared__ uint64_t s_p[SH_NWAVES][5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] = wave_sum_u64(acc[k]);
+    if (lane == 0) { for (int k = 0; k < 5; ++k) s_p[wv][k] = acc[k]; }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const uint64_t tag = (uint64_t)((q_ticket & 0x7fff) + 1) << 48;
+        const int t = (int)threadIdx.x;
+        uint64_t v = 0;
+        if (t < 2) {
+            uint64_t S = 0;
+            for (int w = 0; w < SH_NWAVES; ++w) S += s_p[w][0];
+            v = t == 0 ? (S & 0x7fffffffull) : ((S >> 31) | ((uint64_t)(uint32_t)f << 40));       // (S < 2^62: the high part < 2^31)
+        } else if (t < 6) {
+            for (int w = 0; w < SH_NWAVES; ++w) v += s_p[w][t - 1];
+        } else v = t == 6 ? (d2u(m) & 0xffffffffull) : (d2u(m) >> 32);
+        __hip_atomic_store(h_part + (int64_t)blockIdx.x * 8 + t, (int64_t)(tag | v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Residual resampling needs TWO prefix sums over the same elements: the copy counts c_i = (N q_i) div S and the
 // residual weights r_i = ((N q_i) mod S) >> sh (resample.jl:99,109).  One pass computes both: one read of the weight CDF,
 // ONE 64-bit division per element (quotient and remainder), two descriptor channels polled in the same round trip.

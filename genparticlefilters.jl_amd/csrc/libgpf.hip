@@ -88,6 +88,8 @@ struct gpf_filter {
     bool raw_sum_valid = false;    // sc->raw holds {m, flags, S, Ql} of the current log-weights WITHOUT a CDF (k_sum_reduce: the ESS / log-ML getters)
     WSum sum_cache{};              // ... and the host's copy of it
     uint64_t* sum_part = nullptr;  // [6][workgroups] tagged partials of k_sum_reduce
+    int64_t* h_spart = nullptr;    // pinned: [n_cu][8] tagged partials of k_sum_host, folded by the host
+    bool sum_on_host = false;      // sum_cache came from k_sum_host: it holds m too, and sc->raw on the device was NOT updated
     bool raw_has_q = false;        // the raw summary's scan also accumulated sum q^2 (blockQ)
     bool raw_q_folded = false;     // sc->raw.Ql folded from blockQ
     bool pending_gather = false;   // a resample left (rows[cur], anc) un-gathered; log-weights are 0
@@ -740,6 +742,57 @@ gpf_status ensure_raw_summary(gpf_filter* h, bool want_q, bool* done)
     static const bool off = getenv("GPF_SUM_REDUCE") && !strcmp(getenv("GPF_SUM_REDUCE"), "0");          // (A/B: always the scan)
     if (off || (h->raw_valid && (!want_q || h->raw_has_q))) return GPF_OK;                              // (a scan's summary is there: use it)
     if (h->raw_sum_valid) { *done = true; return GPF_OK; }
+    // GPF_SUM_REDUCE=device: the reduction whose workgroup 0 folds the partials on the device (k_sum_reduce) instead of the host (k_sum_host)
+    static const bool device_fold = getenv("GPF_SUM_REDUCE") && !strcmp(getenv("GPF_SUM_REDUCE"), "device");
+    const int hgrid = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + SH_TILE - 1) / SH_TILE, (int64_t)h->n_cu));
+    if (!device_fold && (h->n + hgrid - 1) / hgrid <= (int64_t)Q_TAG_MAX_TILES * TILE) {
+        // every workgroup's partial sums go straight to pinned memory; this thread adds them up
+        if (!h->h_spart) {
+            HIP_TRY(h, hipHostMalloc(&h->h_spart, (size_t)8 * h->n_cu * sizeof(int64_t)));
+            memset(h->h_spart, 0, (size_t)8 * h->n_cu * sizeof(int64_t));
+        }
+        if ((s = ensure_max(h, raw_view(h), true))) return s;
+        h->q_ticket += 1;
+        InFixQ in{raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
+        s = timed(h, GPF_K_SCAN, [&] {
+            GPF_LAUNCH(k_sum_host, dim3(hgrid), dim3(SH_BLOCK), 0, h->stream, in, h->n, h->mslots[h->mcur], h->h_spart, h->q_ticket);
+        });
+        if (s) return s;
+        HIP_TRY(h, hipGetLastError());
+        const uint64_t tag = (uint64_t)((h->q_ticket & 0x7fff) + 1);
+        uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t flags_m[3] = {0, 0, 0};
+        for (int b = 0; b < hgrid; ++b) {
+            volatile int64_t* line = h->h_spart + (size_t)b * 8;
+            uint64_t v[8];
+            for (int k = 0; k < 8; ++k) {
+                uint64_t spins = 0;
+                while (((v[k] = (uint64_t)__atomic_load_n(line + k, __ATOMIC_ACQUIRE)) >> 48) != tag) {
+                    cpu_relax();
+                    if ((++spins & 0x3fff) != 0) continue;
+                    const hipError_t q = hipStreamQuery(h->stream);
+                    if (q == hipErrorNotReady) continue;
+                    if (((uint64_t)__atomic_load_n(line + k, __ATOMIC_ACQUIRE) >> 48) == tag) continue;
+                    return fail(h, GPF_ERR_HIP, q == hipSuccess ? "weight summary: the stream drained without the partial sums being published" : hipGetErrorString(q));
+                }
+                v[k] &= 0xffffffffffffull;
+            }
+            t[0] += v[0]; t[1] += v[1] & 0xffffffffffull;             // (S can be 2^62 itself: the high part takes 32 bits; the flags sit above bit 40)
+            for (int k = 2; k < 6; ++k) t[k] += v[k];
+            if (b == 0) { flags_m[0] = v[1] >> 40; flags_m[1] = v[6]; flags_m[2] = v[7]; }
+        }
+        WSum w{};
+        w.flags = (int32_t)flags_m[0];
+        w.S = t[0] + (t[1] << 31);
+        for (int k = 0; k < 4; ++k) w.Ql[k] = t[2 + k];
+        const uint64_t mb = flags_m[1] | (flags_m[2] << 32);
+        memcpy(&w.m, &mb, sizeof(double));
+        h->sum_cache = w;                                        // (sc->raw on the device is NOT updated: the getters read this copy)
+        h->sum_on_host = true;
+        h->raw_sum_valid = true;
+        *done = true;
+        return GPF_OK;
+    }
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, (int64_t)h->n_cu * 4));
     if ((h->ntiles + grid - 1) / grid > Q_TAG_MAX_TILES) return GPF_OK;
     if (!h->sum_part) {
@@ -758,7 +811,8 @@ gpf_status ensure_raw_summary(gpf_filter* h, bool want_q, bool* done)
     HIP_TRY(h, hipGetLastError());
     WSum w{};
     if ((s = read_published_summary(h, w))) return s;
-    h->sum_cache = w;                                            // (m is not published: the log-ML getter reads it from the device block)
+    h->sum_cache = w;                                            // (m is not published by this kernel: the log-ML getter reads the device block)
+    h->sum_on_host = false;
     h->raw_sum_valid = true;
     *done = true;
     return GPF_OK;
@@ -1502,6 +1556,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->h_shard_counts) hipHostFree(h->h_shard_counts);
     if (h->h_pull_pc_all) hipHostFree(h->h_pull_pc_all);
     if (h->h_qpub) hipHostFree(h->h_qpub);
+    if (h->h_spart) hipHostFree(h->h_spart);
     if (h->sp_g) { (void)hipFree(h->sp_g); (void)hipFree(h->sp_vlo); }
     if (h->sum_part) (void)hipFree(h->sum_part);
     for (int k = 0; k < gpf_filter::BLK_STAGE; ++k) if (h->h_blk_obs[k]) hipHostFree(h->h_blk_obs[k]);
@@ -2149,7 +2204,7 @@ gpf_status gpf_log_ml_estimate(gpf_handle h, double* out)
     if ((s = ensure_raw_summary(h, false, &reduced))) return s;  // (S and the maximum are all it needs: no CDF)
     if (!reduced && (s = ensure_raw(h))) return s;
     if ((s = fetch_scalars(h))) return s;
-    const WSum& w = h->h_sc->raw;
+    const WSum& w = reduced && h->sum_on_host ? h->sum_cache : h->h_sc->raw;   // (k_sum_host leaves {m, flags, S} with the host, not in the device block)
     double base = h->h_sc->lml_est;
     if (h->parent) {                                             // source.log_ml_est (utils.jl:174-178)
         if ((s = fetch_scalars(h->parent))) { h->err = h->parent->err; return s; }
