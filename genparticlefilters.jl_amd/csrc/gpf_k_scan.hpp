@@ -493,18 +493,21 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int64_t n,
 // workgroup (k_sum_reduce: two cross-XCD hops of ~2 us between the partial stores and the publish).  The host waits for the tags of this
 // launch and adds <= n_cu lines up.  1024-thread workgroups, 8 weights per lane, every load in flight at once.
 //   line b: {S low 31 bits, S high bits | flags << 40, Q limb 0..3, maximum low / high 32 bits}, each (tag << 48) | value
-constexpr int SH_BLOCK = 1024, SH_NWAVES = SH_BLOCK / WAVE, SH_ROWS = 4, SH_TILE = SH_BLOCK * 2 * SH_ROWS;      // 8192 weights per workgroup and trip
+constexpr int SH_BLOCK = 1024, SH_NWAVES = SH_BLOCK / WAVE, SH_ROWS = 2, SH_TILE = SH_BLOCK * 2 * SH_ROWS;      // 4096 weights per workgroup and trip: 245 workgroups at 10^6, every CU busy
 __global__ __launch_bounds__(SH_BLOCK) void k_sum_host(InFixQ in, int64_t n, const unsigned long long* __restrict__ slots, int64_t* __restrict__ h_part, int64_t q_ticket)
 {
+    const int lane = lane_id(), wv = wave_id();
+    uint64_t acc[5] = {0, 0, 0, 0, 0};                // S, Ql0..3
+    // the first trip's weights are requested BEFORE the maximum slots are folded (raw2 needs neither the maximum nor the flags): one
+    // memory round trip instead of two in a kernel that is nothing but a chain of them
+    double v0[SH_ROWS], v1[SH_ROWS];
+    int64_t base = (int64_t)blockIdx.x * SH_TILE;
+#pragma unroll
+    for (int k = 0; k < SH_ROWS; ++k) in.raw2(base + (int64_t)k * (2 * SH_BLOCK) + 2 * (int64_t)threadIdx.x, n, v0[k], v1[k]);
     double m; int f;
     fold_slots(slots, m, f);
     in.m = m; in.flags = f;
-    const int lane = lane_id(), wv = wave_id();
-    uint64_t acc[5] = {0, 0, 0, 0, 0};                // S, Ql0..3
-    for (int64_t base = (int64_t)blockIdx.x * SH_TILE; base < n; base += (int64_t)gridDim.x * SH_TILE) {
-        double v0[SH_ROWS], v1[SH_ROWS];
-#pragma unroll
-        for (int k = 0; k < SH_ROWS; ++k) in.raw2(base + (int64_t)k * (2 * SH_BLOCK) + 2 * (int64_t)threadIdx.x, n, v0[k], v1[k]);
+    for (; base < n; base += (int64_t)gridDim.x * SH_TILE) {
 #pragma unroll
         for (int k = 0; k < SH_ROWS; ++k) {
             uint64_t q0, q1;
@@ -514,6 +517,11 @@ __global__ __launch_bounds__(SH_BLOCK) void k_sum_host(InFixQ in, int64_t n, con
             acc[1] += lo & 0xffffffffull; acc[2] += lo >> 32; acc[3] += hi & 0xffffffffull; acc[4] += hi >> 32;
             lo = q1 * q1; hi = __umul64hi(q1, q1);
             acc[1] += lo & 0xffffffffull; acc[2] += lo >> 32; acc[3] += hi & 0xffffffffull; acc[4] += hi >> 32;
+        }
+        const int64_t nb = base + (int64_t)gridDim.x * SH_TILE;
+        if (nb < n) {
+#pragma unroll
+            for (int k = 0; k < SH_ROWS; ++k) in.raw2(nb + (int64_t)k * (2 * SH_BLOCK) + 2 * (int64_t)threadIdx.x, n, v0[k], v1[k]);
         }
     }
     __shared__ uint64_t s_p[SH_NWAVES][5];
