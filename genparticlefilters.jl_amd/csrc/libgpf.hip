@@ -1008,8 +1008,9 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse
         HIP_TRY(h, hipGetLastError());
         return GPF_OK;
     }
-    if (coarse) GPF_LAUNCH((k_sort_keys_hist<0, true>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
-    else        GPF_LAUNCH((k_sort_keys_hist<0, false>), dim3(grid_for(h, n, 1)), dim3(BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
+    const int64_t kh_grid = std::max<int64_t>(1, std::min<int64_t>((n + 4 * KF_BLOCK - 1) / (4 * KF_BLOCK), h->n_cu));
+    if (coarse) GPF_LAUNCH((k_sort_keys_hist<0, true>), dim3((unsigned)kh_grid), dim3(KF_BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
+    else        GPF_LAUNCH((k_sort_keys_hist<0, false>), dim3((unsigned)kh_grid), dim3(KF_BLOCK), 0, h->stream, pv, n, h->keys, hist, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
     for (int p = 0; p < (coarse ? 3 : SORT_PASSES); ++p) {
         const uint64_t* kin = (p & 1) ? h->keys_out : h->keys;
         uint64_t* kout = (p & 1) ? h->keys : h->keys_out;
