@@ -558,10 +558,16 @@ struct Scan2Chan { ScanOut out; uint64_t* dcur; uint64_t* dnext; uint64_t* total
 // elements = 32 tiles
 constexpr int Q_TAG_MAX_TILES = 32;
 constexpr int HEAD_SMALL = 16, HEAD_LIST = 128, HEAD_STAGE = 4096;
+// DIRECT (an ESS read came before the resample -- README.md:68-70 -- and left {maximum, flags, S} with the host, k_sum_host): the weights
+// are converted here (the same exp_fix as the weight scan's) and the summary arrives as kernel arguments, so the weight scan -- whose only
+// product this kernel would read is q_i = cdf[i] - cdf[i - 1] -- is not run at all; workgroup 0 leaves the summary in the device block for
+// the search kernel's log-ML update.
+struct ResidDirect { const double* lw; double m; int32_t flags; int32_t K; uint64_t S; WSum* ws_out; };
+template <bool DIRECT>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* __restrict__ cdf, const WSum* ws, int64_t Nslots,
                                                           int64_t n, int64_t ntiles, Scan2Chan A, Scan2Chan B,
                                                           int32_t* __restrict__ timeout, int32_t* __restrict__ head_anc,
-                                                          HeadGiants* __restrict__ giants, uint32_t tag)
+                                                          HeadGiants* __restrict__ giants, uint32_t tag, ResidDirect rd)
 {
     __shared__ uint64_t s_wave[2][SCAN_NWAVES];
     __shared__ uint64_t s_red[2][SCAN_NWAVES];
@@ -570,7 +576,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* _
     __shared__ uint32_t s_hcell[HEAD_LIST], s_hcnt[HEAD_LIST];
     __shared__ int32_t s_stage[HEAD_STAGE];
     for (int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x; i < 2 * ntiles; i += (int64_t)gridDim.x * SCAN_BLOCK) { A.dnext[i] = 0; B.dnext[i] = 0; }
-    const uint64_t S = ws->S;
+    uint64_t S;
+    InFixQ in{PrioView{rd.lw, nullptr, 0.0, 0}, nullptr, nullptr, rd.K, rd.m, rd.flags};
+    if constexpr (DIRECT) {
+        S = rd.S;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { rd.ws_out->m = rd.m; rd.ws_out->flags = rd.flags; rd.ws_out->S = rd.S; }
+    } else S = ws->S;
     const int sh = residual_shift(S, Nslots);
     const int lane = lane_id(), wv = wave_id();
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -582,11 +593,16 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* _
 #pragma unroll
         for (int k = 0; k < SCAN_ROWS; ++k) {
             const int64_t idx = wbase + k * 2 * WAVE;
-            const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(cdf + idx);      // padded to whole tiles, flat beyond n
-            const uint64_t prev = idx > 0 ? cdf[idx - 1] : 0;
+            uint64_t q0, q1;
+            if constexpr (DIRECT) in.load2(idx, n, q0, q1);
+            else {
+                const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(cdf + idx);      // padded to whole tiles, flat beyond n
+                const uint64_t prev = idx > 0 ? cdf[idx - 1] : 0;
+                q0 = c.x - prev; q1 = c.y - c.x;
+            }
             uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
             if (S != 0) {
-                const uint64_t n0 = (uint64_t)Nslots * (c.x - prev), n1 = (uint64_t)Nslots * (c.y - c.x);
+                const uint64_t n0 = (uint64_t)Nslots * q0, n1 = (uint64_t)Nslots * q1;
                 a0 = n0 / S; b0 = (n0 - a0 * S) >> sh;
                 a1 = n1 / S; b1 = (n1 - a1 * S) >> sh;
             }

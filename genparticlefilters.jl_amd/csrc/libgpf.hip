@@ -1110,7 +1110,7 @@ CdfLevels levels(const gpf_filter* h, int ch)
 // residual: copy-count and residual-weight CDFs from the weight CDF (resample.jl:99,109); ws->S must be the GLOBAL sum
 // head_anc: the plain resample hands over its ancestor array -- the scan writes the deterministic head into it (k_scan_residual2), the
 // search then covers the tail only (SearchArgs::head_done) and the copy-count CDF is not stored
-gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global, int32_t* head_anc = nullptr)
+gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global, int32_t* head_anc = nullptr, const ResidDirect* direct = nullptr)
 {
     gpf_status s = ensure_residual_buffers(h);
     if (s) return s;
@@ -1127,7 +1127,8 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global,
     }
     const int gs = scan_grid(h);
     s = timed(h, GPF_K_SCAN, [&] {
-        GPF_LAUNCH(k_scan_residual2, dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, h->cdf[0], ws, n_slots_global, h->n, h->ntiles, ch[0], ch[1], h->h_timeout, head_anc, &h->sc->giants, h->epoch & 0xffffffu);
+        if (direct) GPF_LAUNCH(k_scan_residual2<true>, dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, h->cdf[0], ws, n_slots_global, h->n, h->ntiles, ch[0], ch[1], h->h_timeout, head_anc, &h->sc->giants, h->epoch & 0xffffffu, *direct);
+        else        GPF_LAUNCH(k_scan_residual2<false>, dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, h->cdf[0], ws, n_slots_global, h->n, h->ntiles, ch[0], ch[1], h->h_timeout, head_anc, &h->sc->giants, h->epoch & 0xffffffu, ResidDirect{});
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
@@ -1274,6 +1275,17 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     // safe_softmax(log_priorities) (resample.jl:54) and logsumexp(log_weights) (resample.jl:180)
     WSum* ws;
     bool published = false;                                      // the scan of THIS call publishes the flags to pinned memory
+    // :residual right after an ESS / log-ML read (README.md:68-70): the summary is with the host (k_sum_host) and the residual scan needs
+    // nothing else of the weight scan -- it converts the weights itself (k_scan_residual2<DIRECT>) and the weight scan is not run
+    static const bool no_direct = getenv("GPF_RESIDUAL_DIRECT") && !strcmp(getenv("GPF_RESIDUAL_DIRECT"), "0");
+    ResidDirect rdirect{};
+    const bool resid_direct = !no_direct && method == GPF_RESAMPLE_RESIDUAL && pv.mode == 0 && !h->raw_valid && h->raw_sum_valid && h->sum_on_host;
+    int direct_flags = 0;
+    if (resid_direct) {
+        rdirect = ResidDirect{h->lw, h->sum_cache.m, h->sum_cache.flags, h->K, h->sum_cache.S, &h->sc->raw};
+        direct_flags = h->sum_cache.flags;
+        ws = &h->sc->raw;
+    } else
     if (pv.mode == 0) {
         ws = &h->sc->raw;
         if (!h->raw_valid || sorted || (need_off && !h->ch0_offsets)) {
@@ -1295,7 +1307,8 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
             // scan keeps running and the search below is enqueued behind it without a gap
             if ((s = wait_ticket(h, h->h_flags + 1, h->flag_ticket, "weight scan flags"))) return s;
             flags = (int)h->h_flags[0];
-        } else {
+        } else if (resid_direct) flags = direct_flags;           // (known since the getter)
+        else {
             if ((s = fetch_scalars(h))) return s;
             flags = (pv.mode == 0 ? h->h_sc->raw : h->h_sc->prio).flags;
         }
@@ -1314,7 +1327,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
 
     if (method == GPF_RESAMPLE_RESIDUAL) {
         static const bool head_in_search = getenv("GPF_RESIDUAL_HEAD") && !strcmp(getenv("GPF_RESIDUAL_HEAD"), "search");   // (A/B measurements)
-        if ((s = residual_scans(h, ws, h->cfg.n_global, head_in_search ? nullptr : h->anc))) return s;
+        if ((s = residual_scans(h, ws, h->cfg.n_global, head_in_search ? nullptr : h->anc, resid_direct ? &rdirect : nullptr))) return s;
         sa.w = levels(h, 2); sa.c = levels(h, 1);
         sa.head_done = head_in_search ? 0 : 1;
     }
@@ -1489,7 +1502,8 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
             int nb = 2;
             const void* scans[] = {reinterpret_cast<const void*>(&k_scan<InFixQ, 1>), reinterpret_cast<const void*>(&k_scan<InFixQ, 2>),
                                    reinterpret_cast<const void*>(&k_scan<InFixQ, 3>), reinterpret_cast<const void*>(&k_scan<InFixQ, 4>),
-                                   reinterpret_cast<const void*>(&k_scan<InOptimal, 0>), reinterpret_cast<const void*>(&k_scan_residual2)};
+                                   reinterpret_cast<const void*>(&k_scan<InOptimal, 0>), reinterpret_cast<const void*>(&k_scan_residual2<false>),
+                                   reinterpret_cast<const void*>(&k_scan_residual2<true>)};
             for (const void* f : scans) {
                 int q = 0;
                 HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, f, SCAN_BLOCK, 0));
