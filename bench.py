@@ -357,7 +357,7 @@ def main():
         return {"workload": workload, "value": round(n_global * k / seconds, 1), "unit": "particle-steps/sec", "steps": k,
                 "ms_per_step": round(seconds / k * 1e3, 5)}
 
-    strat = island = plans = sorted_variant = None
+    strat = island = plans = sorted_variant = strat_sorted = None
     if not sharded_mode and not args.headline_only:
         # the OPT-IN sorted form of the multinomial resampler (gpf.h GPF_RESAMPLE_MULTINOMIAL_SORTED): same offspring-count
         # law, ancestors in non-decreasing order -- NOT the reference's slot order, so a named variant beside the unchanged headline
@@ -385,6 +385,13 @@ def main():
             sorted_variant["k_step_roofline"] = {"achieved": round(abk * n_local / (sk["k_step"] * 1e-6) / 1e9, 1), "unit": "GB/s",
                                                  "frac": round(abk * n_local / (sk["k_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                                  "algorithmic_bytes_per_launch": abk * n_local}
+        # :stratified with the reference's DEFAULT sort_particles=true (src/resample.jl:145,156-157): sortperm of the weights in front of
+        # every resample (key pass, one equal-count partition pass, one workgroup per bucket in LDS: DESIGN.md 4.5)
+        def strat_sorted_step(tq):
+            g.pf_resample(state, "stratified", sort_particles=True, check=False)
+            g.pf_update(state, (tq + 1,), (None,), ys[1 + tq % (n_obs - 1)])
+        strat_sorted = variant_line("same filter, stratified resample every step with the reference's default sort_particles=true",
+                                    kv, variant(strat_sorted_step, kv))
     if sharded_mode:
         kv = min(K, 200)
 
@@ -466,7 +473,7 @@ def main():
             "shard_summaries": (state.backend.summary_mode() if sharded_mode and hasattr(state.backend, "summary_mode") else None),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
             "stratified_variant": strat, "local_resample_variant": island, "exchange_plans": plans,
-            "multinomial_sorted_variant": sorted_variant,
+            "multinomial_sorted_variant": sorted_variant, "stratified_sort_particles_variant": strat_sorted,
         }
     else:
         out = None

@@ -109,6 +109,8 @@ def test_bench_main_prints_one_json_line(argv, o, built, monkeypatch):
     assert set(out["resample_gather_kernel"]) == {"multinomial", "multinomial_sorted", "stratified"}
     sv = out["multinomial_sorted_variant"]                          # the opt-in sorted multinomial as a named variant beside the unchanged headline
     assert sv is not None and sv["value"] > 0 and "multinomial_sorted" in sv["workload"] and "configs[1]" in out["config"]["workload"]
+    ss = out["stratified_sort_particles_variant"]                   # :stratified with the reference's default sort_particles=true
+    assert ss is not None and ss["value"] > 0 and "sort_particles=true" in ss["workload"]
     assert np.isfinite(out["log_ml_estimate"]) and np.isfinite(out["log_ml_abs_error"])
 
 
