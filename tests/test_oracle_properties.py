@@ -88,3 +88,14 @@ def test_resize_properties(g, o, lw, n_new, method):
     assert f.n == n_new and f.rows.shape[0] == n_new
     assert np.array_equal(f.rows, rows0[f.parents - 1])               # test/resize.jl:13
     assert abs(f.log_ml_estimate() - lml0) <= 1e-9 * max(1.0, abs(lml0))   # test/resize.jl:14
+
+
+def test_weights_64_below_the_maximum_have_fixed_point_weight_zero(o):
+    """the bucket sort behind sort_particles=true leaves keys more than 2^6 below the maximum unranked ("dead" keys, gpf_k_sort.hpp
+    SORT_COARSE_DEAD): that is only right if their fixed-point weight q = trunc(exp(d) 2^K + 1/2) is 0 for every
+    admissible K <= 52 -- and it leaves a margin: the last nonzero weight is 53 ln 2 = 36.7 below the maximum"""
+    L = o.lib()
+    for K in range(1, 53):
+        for d in (-64.0, -64.0 - 2.0 ** -40, -100.0, -512.0, -707.9, -1e300, -np.inf):
+            assert L.o_exp_fix_d(d, K) == 0, (K, d)
+    assert L.o_exp_fix_d(-36.0, 52) > 0 and L.o_exp_fix_d(-37.5, 52) == 0
