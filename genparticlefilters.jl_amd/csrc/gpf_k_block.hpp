@@ -35,7 +35,7 @@ struct BlockArgs {
                                                    // 10^4 same-address atomics would cost ~100 us; k_block_summary folds the words on request)
 };
 // OR of the blocks' flags and the number of blocks that resampled -> out2 = {flags, count}
-__global__ __launch_bounds__(BLOCK) void k_block_summary(const int32_t* __restrict__ words, int64_t nblocks, int32_t* __restrict__ out2)
+static __global__ __launch_bounds__(BLOCK) void k_block_summary(const int32_t* __restrict__ words, int64_t nblocks, int32_t* __restrict__ out2)
 {
     int f = 0; unsigned c = 0;
     for (int64_t i = threadIdx.x; i < nblocks; i += BLOCK) { const int w = words[i]; f |= w >> 8; c += (unsigned)(w & 1); }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_stats(const double* __restrict_
 // the blocks' observation vectors from a pinned host buffer into device memory, by a KERNEL (coalesced reads over PCIe) rather than a
 // hipMemcpyAsync: the copy stays on the compute queue (an SDMA copy costs a cross-queue dependency of ~10-20 us in front of the step
 // kernel that reads it).  The last workgroup publishes `ticket` to pinned memory: the host may then refill that staging buffer.
-__global__ __launch_bounds__(BLOCK) void k_stage_obs(const double* __restrict__ src_host, double* __restrict__ dst, int64_t n_words,
+static __global__ __launch_bounds__(BLOCK) void k_stage_obs(const double* __restrict__ src_host, double* __restrict__ dst, int64_t n_words,
                                                      unsigned int* counter, int64_t* host_done, int64_t ticket)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * BLOCK) dst[i] = src_host[i];

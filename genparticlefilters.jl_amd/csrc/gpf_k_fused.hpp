@@ -9,7 +9,7 @@ namespace gpf {
 // parents[j] = a.  Against k_search_multi + k_step<GATHER>: one launch boundary and the 4-byte ancestor round trip are gone, and the
 // Philox / Box-Muller work of a slot -- which does not depend on its ancestor -- overlaps the search's dependent round trips.
 // Any other consumer of the resampled population (getters, views, rejuvenation, a second resample) runs the stand-alone search first
-// (libgpf.hip finish_search), exactly as materialize() runs the stand-alone gather.
+// (libgpf_resample.hip finish_search), exactly as materialize() runs the stand-alone gather.
 //
 // One 1024-thread workgroup per CU (the key table is copied into LDS once per CU), NS slots per lane and iteration.
 template <int NW>

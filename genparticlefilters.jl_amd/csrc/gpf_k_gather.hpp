@@ -24,7 +24,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(const int32_t* __restrict__ an
 }
 
 // lw = log_ws + (log N - logsumexp(log_ws))   (resample.jl:200)
-__global__ __launch_bounds__(BLOCK) void k_apply_post(const Scalars* sc, int K, double logN, const double* __restrict__ lws,
+static __global__ __launch_bounds__(BLOCK) void k_apply_post(const Scalars* sc, int K, double logN, const double* __restrict__ lws,
                                                       double* __restrict__ lw, int64_t n)
 {
     const double off = logN - lse_from(sc->post.m, sc->post.S, K, sc->post.flags);
@@ -56,7 +56,7 @@ __device__ __forceinline__ double tree_block_sum(double v)
 }
 // the terms: values[i * stride + col] (a column of the particle rows, or a plain array with stride 1, col 0)
 // pw = 1: w v;  2: w (v - *center)^2;  3: w [v == match]  (proportionmap)
-__global__ __launch_bounds__(BLOCK) void k_wsum_tree(const double* __restrict__ lw, const WSum* ws, int K,
+static __global__ __launch_bounds__(BLOCK) void k_wsum_tree(const double* __restrict__ lw, const WSum* ws, int K,
                                                      const double* __restrict__ values, int stride, int col, int64_t n,
                                                      int pw, const double* center, double match, double* __restrict__ partial)
 {
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BLOCK) void k_wsum_tree(const double* __restrict__ 
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 // the next level of the tree: np partials -> ceil(np / 2048)
-__global__ __launch_bounds__(BLOCK) void k_tree_partials(const double* __restrict__ in, int64_t np, double* __restrict__ out)
+static __global__ __launch_bounds__(BLOCK) void k_tree_partials(const double* __restrict__ in, int64_t np, double* __restrict__ out)
 {
     double t[8];
     const int64_t i0 = (int64_t)blockIdx.x * TREE_CHUNK + (int64_t)threadIdx.x * 8;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(BLOCK) void k_tree_partials(const double* __restric
 // state[start:step:stop] (reference src/view.jl:35-48; test/initialize.jl:60, test/update.jl:33): a strided view works on a
 // compact copy of its particles -- view_enter gathers rows / log-weights / parents of particles start + i*step, view_exit
 // scatters them back (update_refs! for sub-states copies back as well, utils.jl:17-20).  to_view: parent -> compact, else back.
-__global__ __launch_bounds__(BLOCK) void k_view_strided_copy(double* __restrict__ prow, double* __restrict__ plw, int32_t* __restrict__ panc,
+static __global__ __launch_bounds__(BLOCK) void k_view_strided_copy(double* __restrict__ prow, double* __restrict__ plw, int32_t* __restrict__ panc,
                                                              double* __restrict__ vrow, double* __restrict__ vlw, int32_t* __restrict__ vanc,
                                                              int W, int64_t step, int64_t n, int to_view)
 {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(BLOCK) void k_view_strided_copy(double* __restrict_
 }
 
 // state[idxs] for an arbitrary vector of distinct indices (src/view.jl:35-48): the same compact-copy mechanism with an index array
-__global__ __launch_bounds__(BLOCK) void k_view_index_copy(double* __restrict__ prow, double* __restrict__ plw, int32_t* __restrict__ panc,
+static __global__ __launch_bounds__(BLOCK) void k_view_index_copy(double* __restrict__ prow, double* __restrict__ plw, int32_t* __restrict__ panc,
                                                            double* __restrict__ vrow, double* __restrict__ vlw, int32_t* __restrict__ vanc,
                                                            int W, const int32_t* __restrict__ idx, int64_t n, int to_view)
 {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(BLOCK) void k_view_index_copy(double* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------- small utilities
-__global__ void k_iota(int32_t* v, int64_t n)
+static __global__ void k_iota(int32_t* v, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) v[i] = (int32_t)i;
 }

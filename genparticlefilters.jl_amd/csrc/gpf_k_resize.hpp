@@ -5,7 +5,7 @@ namespace gpf {
 // ----------------------------------------------------------------------------- resize family (reference src/resize.jl)
 // pf_replicate! (resize.jl:236-244): parents = repeat(1:N, inner=k) (contiguous) or repeat(1:N, k) (interleaved);
 // pf_dereplicate! :keepfirst (resize.jl:267-280): parents = 1:k:N (contiguous) or 1:N/k (interleaved)
-__global__ void k_replicate_anc(int64_t n_new, int64_t n_old, int k, int interleaved, int shrink, int32_t* __restrict__ anc)
+static __global__ void k_replicate_anc(int64_t n_new, int64_t n_old, int k, int interleaved, int shrink, int32_t* __restrict__ anc)
 {
     for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n_new; j += (int64_t)gridDim.x * BLOCK) {
         int64_t a;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows_lw(const int32_t* __restr
 // find_inv_w_threshold (resize.jl:203-219) on the DESCENDING order: position d holds kappa = q_(d), A = d weights
 // before it and B = S - C[d-1] from it on; the reference's first kappa (ascending) with B / kappa + A <= n is the
 // LARGEST such d.  The condition is constant over ties, and d < n is necessary.
-__global__ __launch_bounds__(BLOCK) void k_opt_threshold(const uint64_t* __restrict__ cdf_desc, const WSum* ws, int64_t n_new,
+static __global__ __launch_bounds__(BLOCK) void k_opt_threshold(const uint64_t* __restrict__ cdf_desc, const WSum* ws, int64_t n_new,
                                                          int64_t n_old, Scalars* sc)
 {
     const uint64_t S = ws->S;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(BLOCK) void k_opt_threshold(const uint64_t* __restr
     if (lane_id() == 0 && best >= 0) atomicMax(&sc->opt_d, best);
 }
 // c = (n - A) / B, or float(n) when no kappa qualifies (resize.jl:215,218), as the pair (a, B): c w_i >= 1 <=> a q_i >= B
-__global__ void k_opt_params(const uint64_t* __restrict__ cdf_desc, const WSum* ws, int64_t n_new, Scalars* sc)
+static __global__ void k_opt_params(const uint64_t* __restrict__ cdf_desc, const WSum* ws, int64_t n_new, Scalars* sc)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long d = sc->opt_d;
@@ -58,7 +58,7 @@ __global__ void k_opt_params(const uint64_t* __restrict__ cdf_desc, const WSum* 
     sc->opt_B = d <= 0 ? ws->S : ws->S - cdf_desc[d - 1];
 }
 // parents[1:n_keep] .= findall(keep_idxs) (resize.jl:159,180) from the inclusive scan of the keep flags
-__global__ __launch_bounds__(BLOCK) void k_opt_keep_scatter(const uint64_t* __restrict__ keepcdf, int64_t n_old, int32_t* __restrict__ anc)
+static __global__ __launch_bounds__(BLOCK) void k_opt_keep_scatter(const uint64_t* __restrict__ keepcdf, int64_t n_old, int32_t* __restrict__ anc)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_old; i += (int64_t)gridDim.x * BLOCK) {
         const uint64_t c = keepcdf[i], p = i > 0 ? keepcdf[i - 1] : 0;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(BLOCK) void k_opt_keep_scatter(const uint64_t* __re
     }
 }
 // log_weights (resize.jl:189-195): kept particles keep theirs, the others get logsumexp - log c; all + log(n / n_old)
-__global__ __launch_bounds__(BLOCK) void k_opt_weights(double* __restrict__ lw, int64_t n, const Scalars* sc, const WSum* ws, int K,
+static __global__ __launch_bounds__(BLOCK) void k_opt_weights(double* __restrict__ lw, int64_t n, const Scalars* sc, const WSum* ws, int K,
                                                        double log_n_ratio)
 {
     const int64_t n_keep = (int64_t)sc->Ctot;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void k_opt_weights(double* __restrict__ lw, 
 
 // pf_dereplicate! method = :sample (resize.jl:281-293): one categorical draw per block of k replicates, with the
 // block's softmax in K_b-bit fixed point (same spec as §3.3 of DESIGN.md, N = k); new weight = logsumexp(block) - log k
-__global__ void k_dereplicate_sample(const double* __restrict__ lw, int64_t n_new, int64_t n_old, int k, int interleaved,
+static __global__ void k_dereplicate_sample(const double* __restrict__ lw, int64_t n_new, int64_t n_old, int k, int interleaved,
                                      uint64_t seed, uint32_t epoch, int Kb, double logk, int32_t* __restrict__ anc,
                                      double* __restrict__ lw_out)
 {
@@ -108,7 +108,7 @@ __global__ void k_dereplicate_sample(const double* __restrict__ lw, int64_t n_ne
 // Gen traces are persistent: mean(state, 5 => :moving) (reference README.md:97) reads a PAST choice of every
 // surviving particle.  The device keeps, per time step, the step's latent columns (final particle order of that
 // step) and the composed ancestor map of the resamples that happened during the step.
-__global__ void k_hist_snapshot(const double* __restrict__ rows, int W, int d, int64_t n, double* __restrict__ out)
+static __global__ void k_hist_snapshot(const double* __restrict__ rows, int W, int d, int64_t n, double* __restrict__ out)
 {
     for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < n * d; t += (int64_t)gridDim.x * BLOCK) {
         const int64_t i = t / d;
@@ -116,13 +116,13 @@ __global__ void k_hist_snapshot(const double* __restrict__ rows, int W, int d, i
     }
 }
 // B[j] = first resample of the step ? anc[j] : B_old[anc[j]]
-__global__ void k_hist_compose(const int32_t* __restrict__ anc, const int32_t* __restrict__ b_old, int64_t n, int32_t* __restrict__ b_new)
+static __global__ void k_hist_compose(const int32_t* __restrict__ anc, const int32_t* __restrict__ b_old, int64_t n, int32_t* __restrict__ b_new)
 {
     for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (int64_t)gridDim.x * BLOCK)
         b_new[j] = b_old ? b_old[anc[j]] : anc[j];
 }
 // value of column `col` of step `t` along the ancestry of every current particle: follow B_T, B_{T-1}, ..., B_{t+1}
-__global__ void k_hist_column(const int32_t* const* __restrict__ maps, int n_maps, const double* __restrict__ hx, int d, int col,
+static __global__ void k_hist_column(const int32_t* const* __restrict__ maps, int n_maps, const double* __restrict__ hx, int d, int col,
                               int64_t n, double* __restrict__ out)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
@@ -133,18 +133,18 @@ __global__ void k_hist_column(const int32_t* const* __restrict__ maps, int n_map
 }
 // ----------------------------------------------------------------------------- sub-state views (src/view.jl, resample.jl:205-218)
 // after resampling a view: every log-weight = logsumexp(view) - log n (the block keeps its total mass, resample.jl:210)
-__global__ void k_fill_from(double* __restrict__ lw, int64_t n, const double* __restrict__ value)
+static __global__ void k_fill_from(double* __restrict__ lw, int64_t n, const double* __restrict__ value)
 {
     const double v = *value;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) lw[i] = v;
 }
-__global__ void k_view_fill_weights(double* __restrict__ lw, int64_t n, const WSum* ws, int K, double logN)
+static __global__ void k_view_fill_weights(double* __restrict__ lw, int64_t n, const WSum* ws, int K, double logN)
 {
     const double v = lse_from(ws->m, ws->S, K, ws->flags) - logN;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) lw[i] = v;
 }
 // with priorities: lw = log_ws + (logsumexp(view weights) - logsumexp(log_ws))   (resample.jl:213-216)
-__global__ void k_view_apply_post(const Scalars* sc, int K, const double* __restrict__ lws, double* __restrict__ lw, int64_t n)
+static __global__ void k_view_apply_post(const Scalars* sc, int K, const double* __restrict__ lws, double* __restrict__ lw, int64_t n)
 {
     const double off = lse_from(sc->raw.m, sc->raw.S, K, sc->raw.flags) - lse_from(sc->post.m, sc->post.S, K, sc->post.flags);
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) lw[i] = lws[i] + off;

@@ -6,7 +6,7 @@ namespace gpf {
 // maximum(vs), any(isnan), all(== -Inf) of safe_softmax (utils.jl:119-128) of weights no kernel of ours produced (host-written
 // log-weights, priorities): folded into the maximum slots like the producers do (MaxSlots, gpf_k_common.hpp); the consumers
 // (k_scan, k_pack_mflags) read the slots themselves (no finalize launch).
-__global__ __launch_bounds__(BLOCK) void k_max_partial(PrioView pv, int64_t n, MaxSlots ms)
+static __global__ __launch_bounds__(BLOCK) void k_max_partial(PrioView pv, int64_t n, MaxSlots ms)
 {
     double m = -__builtin_huge_val();
     int f = 0;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
 // {S low 31 bits, S high bits, limb sums of Q} as TAGGED words (tag << 48 | sum, relaxed agent-scope stores, as the scan's ESS
 // partials: a workgroup folds <= Q_TAG_MAX_TILES tiles); workgroup 0 waits for this launch's tags, folds, fills ws_out and publishes
 // {flags, S, limbs, ticket, check word} to pinned host memory (the scan's format: gpf_effective_sample_size reads either).
-__global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int64_t n, int64_t ntiles, const unsigned long long* __restrict__ slots,
+static __global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int64_t n, int64_t ntiles, const unsigned long long* __restrict__ slots,
                                                            WSum* __restrict__ ws_out, uint64_t* __restrict__ part, int64_t* __restrict__ q_host,
                                                            int64_t q_ticket, int32_t* __restrict__ timeout)
 {
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int64_t n,
 // launch and adds <= n_cu lines up.  1024-thread workgroups, 8 weights per lane, every load in flight at once.
 //   line b: {S low 31 bits, S high bits | flags << 40, Q limb 0..3, maximum low / high 32 bits}, each (tag << 48) | value
 constexpr int SH_BLOCK = 1024, SH_NWAVES = SH_BLOCK / WAVE, SH_ROWS = 2, SH_TILE = SH_BLOCK * 2 * SH_ROWS;      // 4096 weights per workgroup and trip: 245 workgroups at 10^6, every CU busy
-__global__ __launch_bounds__(SH_BLOCK) void k_sum_host(InFixQ in, int64_t n, const unsigned long long* __restrict__ slots, int64_t* __restrict__ h_part, int64_t q_ticket)
+static __global__ __launch_bounds__(SH_BLOCK) void k_sum_host(InFixQ in, int64_t n, const unsigned long long* __restrict__ slots, int64_t* __restrict__ h_part, int64_t q_ticket)
 {
     const int lane = lane_id(), wv = wave_id();
     uint64_t acc[5] = {0, 0, 0, 0, 0};                // S, Ql0..3
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* _
 // blockQ != nullptr: the limb partials of sum q^2 that the scan blocks left (only the ESS needs them) are folded into sc->raw.Ql
 // on the way -- one launch for "fold + publish" (the ESS-triggered loop of BASELINE config 4 asks for the ESS every step).
 // Launched with ONE wave.
-__global__ void k_publish_scalars(Scalars* sc, Scalars* host, long long* host_ticket, long long ticket,
+static __global__ void k_publish_scalars(Scalars* sc, Scalars* host, long long* host_ticket, long long ticket,
                                   const uint64_t* __restrict__ blockQ, int nblk)
 {
     constexpr int NW = (int)(sizeof(Scalars) / sizeof(unsigned long long));

@@ -872,14 +872,14 @@ __device__ __forceinline__ void lane_spacings(uint64_t seed, uint32_t epoch, uin
     }
 }
 // (SortedGammaJob / sorted_gamma_tile: gpf_k_common.hpp -- the weight scan runs the same job as extra workgroups of its launch)
-__global__ __launch_bounds__(BLOCK) void k_sorted_gammas(SortedGammaJob job)
+static __global__ __launch_bounds__(BLOCK) void k_sorted_gammas(SortedGammaJob job)
 {
     sorted_gamma_tile(job, (int64_t)blockIdx.x * BLOCK + threadIdx.x);
 }
 constexpr int SP_DIRECT_TILES = 1024;              // up to 2.1 M slots the merge kernel sums the tile totals itself (4 loads per lane)
 // beyond: vlo[t] = floor((g_0 + ... + g_{t-1}) 2^64 / (sum g + 1)), t = 0 .. ntl, by ONE workgroup (a block-wide scan, a division per tile)
 constexpr int STILES_BLOCK = 1024;
-__global__ __launch_bounds__(STILES_BLOCK) void k_sorted_tiles(const uint64_t* __restrict__ g, int64_t ntl, uint64_t* __restrict__ vlo)
+static __global__ __launch_bounds__(STILES_BLOCK) void k_sorted_tiles(const uint64_t* __restrict__ g, int64_t ntl, uint64_t* __restrict__ vlo)
 {
     __shared__ uint64_t s_w[STILES_BLOCK / WAVE];
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();

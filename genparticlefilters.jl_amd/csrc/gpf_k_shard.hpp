@@ -10,7 +10,7 @@ namespace gpf {
 constexpr int64_t SPACE_COUNTS = (int64_t)1 << 62;   // residual: target lives in the copy-count CDF
 constexpr uint64_t STAGE_T_MASK = (1ull << 62) - 1;  // a staged target (T_local < S_local <= 2^62) below its space bit
 
-__global__ void k_pack_mflags(const unsigned long long* __restrict__ slots, double* out2, MboxPush push)
+static __global__ void k_pack_mflags(const unsigned long long* __restrict__ slots, double* out2, MboxPush push)
 {
     double m; int f;
     fold_slots(slots, m, f);
@@ -22,14 +22,14 @@ __global__ void k_pack_mflags(const unsigned long long* __restrict__ slots, doub
 }
 // host getters: wait for two mailbox rounds and copy their gathered arrays (na / nb words) into ordinary device memory
 // (system-scope loads; the host then copies from there)
-__global__ void k_mbox_collect(MboxWait a, const uint64_t* srca, uint64_t* dsta, int na, MboxWait b, const uint64_t* srcb, uint64_t* dstb, int nb)
+static __global__ void k_mbox_collect(MboxWait a, const uint64_t* srca, uint64_t* dsta, int na, MboxWait b, const uint64_t* srcb, uint64_t* dstb, int nb)
 {
     mbox_wait_block(a); mbox_wait_block(b);
     for (int i = threadIdx.x; i < na; i += blockDim.x) dsta[i] = ld_sys(srca + i);
     for (int i = threadIdx.x; i < nb; i += blockDim.x) dstb[i] = ld_sys(srcb + i);
 }
 // {Ql0..3} -> out5[1..4]: limb sums of sum q^2 folded over the scan blocks (exact integers); out5[0] = S_local is written by the scan
-__global__ void k_export_q(const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5, MboxPush push)
+static __global__ void k_export_q(const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5, MboxPush push)
 {
     __shared__ uint64_t s_q[NWAVES][4];
     __shared__ uint64_t s_tot[4];
@@ -55,7 +55,7 @@ __global__ void k_export_q(const uint64_t* __restrict__ blockQ, int nblk, int64_
 }
 // global S (and residual shift) into the device scalar block from the gathered shard totals
 // tot_all = the gathered {S_local, Ql0..3} of all G shards -> the global S
-__global__ void k_set_global(const int64_t* __restrict__ tot_all, int G, WSum* ws, MboxWait wait)
+static __global__ void k_set_global(const int64_t* __restrict__ tot_all, int G, WSum* ws, MboxWait wait)
 {
     mbox_wait_block(wait);
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -65,7 +65,7 @@ __global__ void k_set_global(const int64_t* __restrict__ tot_all, int G, WSum* w
     }
 }
 // (one wave)
-__global__ void k_export_residual(const Scalars* sc, int64_t* out2, MboxPush push)
+static __global__ void k_export_residual(const Scalars* sc, int64_t* out2, MboxPush push)
 {
     const uint64_t words[2] = {sc->Ctot, sc->Rs};
     if (threadIdx.x == 0 && blockIdx.x == 0) { out2[0] = (int64_t)words[0]; out2[1] = (int64_t)words[1]; }
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_search_own(PushArgs a, CdfLevels 
 // ... and for RESIDUAL resampling (resample.jl:96-115): an own slot below the global copy total is the jg-th deterministic copy (target jg in
 // the copy-count space, owner by the shards' inclusive copy totals), the others draw from the residual weights; own hits are looked up
 // in this shard's copy-count / residual-weight CDF (k_search's two-line core, both top tables in LDS), the rest get -1 and a count per owner.
-__global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search_own_res(PushArgs a, CdfLevels lw_, CdfLevels lc_, int64_t n, int64_t ntiles,
+static __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search_own_res(PushArgs a, CdfLevels lw_, CdfLevels lc_, int64_t n, int64_t ntiles,
                                                                                    int64_t gid0, int32_t* __restrict__ anc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -470,13 +470,13 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_pull_scan(PushArgs a, ulong
     }
 }
 // the request counters, densely: out[q] = requests of this shard to shard q
-__global__ void k_pull_counts(const int64_t* __restrict__ req_counts, int G, int64_t* __restrict__ out)
+static __global__ void k_pull_counts(const int64_t* __restrict__ req_counts, int G, int64_t* __restrict__ out)
 {
     if ((int)threadIdx.x < G) out[threadIdx.x] = req_counts[threadIdx.x * COUNT_STRIDE];
 }
 // after the gathered request matrix M[requester][owner] is known: the exchange counters pass 2 and the row exchange work from --
 // entries this shard serves to g = what g asked of it, entries it receives from g = what it asked of g
-__global__ void k_pull_set_counts(const int64_t* __restrict__ M, int G, int me, int64_t* __restrict__ counts)
+static __global__ void k_pull_set_counts(const int64_t* __restrict__ M, int G, int me, int64_t* __restrict__ counts)
 {
     const int g = (int)threadIdx.x;
     if (g < G) { counts[g * COUNT_STRIDE] = M[g * G + me]; counts[(G + g) * COUNT_STRIDE] = M[me * G + g]; }
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
 // that one slot's target.  One small workgroup derives F from the gathered totals (every shard the same), the exchange
 // counts follow by intersecting slot ranges, and the served slots' ancestors AND their packed rows come from k_search_strat
 // (streaming merge over the shard's own CDF, SearchArgs::pack) -- no pass over the global slots, no staging list.
-__global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
+static __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
 {
     __shared__ int64_t F[MAX_SHARDS + 1];
     const int h = (int)threadIdx.x;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(BLOCK) void k_commit_packed_ws(const double* __rest
     }
 }
 // lw = log_ws + (log N - logsumexp(log_ws)) with the logsumexp over ALL shards (resample.jl:200), from the gathered post summaries
-__global__ __launch_bounds__(BLOCK) void k_shard_apply_post(const double* __restrict__ mf_all, const int64_t* __restrict__ tot_all, int G, int K,
+static __global__ __launch_bounds__(BLOCK) void k_shard_apply_post(const double* __restrict__ mf_all, const int64_t* __restrict__ tot_all, int G, int K,
                                                             double logN, const double* __restrict__ lws, double* __restrict__ lw, int64_t n,
                                                             MboxWait wait)
 {

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(KF_BLOCK) void k_sort_keys_hist(PrioView pv, int64_
 
 // K10d key pass: the keys + the histogram of the coarse key's top SORT_FINE_BITS bits (the "fine bins": 128 per binade of the
 // distance from the maximum) -- what k_sort_pass<2> cuts into SORT_BINS buckets of (nearly) equal counts.
-__global__ __launch_bounds__(KF_BLOCK) void k_sort_keys_fine(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ fine,
+static __global__ __launch_bounds__(KF_BLOCK) void k_sort_keys_fine(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ fine,
                                                           uint4* __restrict__ clear, int64_t clear16, const unsigned long long* __restrict__ slots,
                                                           double* __restrict__ m_out)
 {
@@ -356,7 +356,7 @@ constexpr int SORT_RUN_MAX = 48;                    // elements of a run to eith
 // (with the completion counters of the first build on ONE 128-byte line, 512- / 256-thread workgroups took 16.8 / 22.1 us against 14.8:
 // atomics to the same LINE serialise at ~10 ns each; on separate lines every shape takes 14.0-14.3 us, profiles/r03_sort_experiments.txt)
 constexpr int FIN_BLOCK = GPF_FIN_BLOCK, FIN_TILE = 4 * FIN_BLOCK, FIN_HALO = SORT_RUN_MAX + 1;
-__global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+static __global__ __launch_bounds__(FIN_BLOCK) void k_sort_finish(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                            uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
                                                            uint32_t* __restrict__ done, int64_t* host_flag, int64_t ticket, const double* __restrict__ m_ptr)
 {
@@ -444,7 +444,7 @@ constexpr int BK_BLOCK = 1024, BK_WAVES = BK_BLOCK / WAVE, BK_ITEMS = 8, BK_CAP 
 constexpr int BK_SUB_BITS = 14, BK_SUB = 1 << BK_SUB_BITS, BK_SUB_PER = BK_SUB / BK_BLOCK;   // (16-bit counters, two to a word: 32 KB)
 constexpr int BK_RUN_MAX = 1024;                              // keys of one bin that are still ranked (quadratic work inside the bin)
 constexpr int64_t BK_MAX_N = (int64_t)SORT_BINS * 4608;      // mean bucket <= 4608 keys: BK_CAP - 4608 left for the fullest fine bin
-__global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(uint64_t* keys, int32_t* vals, int64_t n,
+static __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(uint64_t* keys, int32_t* vals, int64_t n,
                                                            const uint32_t* __restrict__ bbase, uint32_t* __restrict__ done, int64_t* host_flag,
                                                            int64_t ticket, const double* __restrict__ m_ptr)
 {
@@ -598,16 +598,16 @@ __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(uint64_t* keys, int32
     }
 }
 
-__global__ void k_extract_column(const double* __restrict__ rows, int W, int col, int64_t n, double* __restrict__ out)
+static __global__ void k_extract_column(const double* __restrict__ rows, int W, int col, int64_t n, double* __restrict__ out)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = rows[i * W + col];
 }
-__global__ void k_parents(const int32_t* __restrict__ anc, int64_t n, int64_t* __restrict__ out)
+static __global__ void k_parents(const int32_t* __restrict__ anc, int64_t n, int64_t* __restrict__ out)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) out[i] = (int64_t)anc[i] + 1;
 }
 // get_log_norm_weights / get_norm_weights (utils.jl:100,103-107,148,156)
-__global__ void k_norm_weights(const double* __restrict__ lw, const WSum* ws, int K, int64_t n, int want_log,
+static __global__ void k_norm_weights(const double* __restrict__ lw, const WSum* ws, int K, int64_t n, int want_log,
                                double* __restrict__ out)
 {
     const double m = ws->m;
@@ -622,7 +622,7 @@ __global__ void k_norm_weights(const double* __restrict__ lw, const WSum* ws, in
         else out[i] = bad ? __builtin_nan("") : (double)exp_fix(lw[i] - m, K) / Sd;
     }
 }
-__global__ void k_debug_math(int which, const double* a, const double* b, int64_t n, uint64_t seed, uint32_t epoch,
+static __global__ void k_debug_math(int which, const double* a, const double* b, int64_t n, uint64_t seed, uint32_t epoch,
                              uint32_t tag, double* out, double* out2)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {

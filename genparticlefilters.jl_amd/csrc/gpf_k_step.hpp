@@ -250,7 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
 // GATHER: a pf_resample! left its ancestor vector pending; the move reads row anc[i] (new_traces .= view(traces, parents),
 // resample.jl:60, fused) and the incoming log-weights are 0 (resample.jl:195), exactly like k_step<GATHER>.
 // n_accept: [gridDim.x] per-workgroup counts of accepted moves (move-accept only)
-__global__ void k_sum_accepts(const unsigned long long* __restrict__ part, int np, unsigned long long* __restrict__ out)
+static __global__ void k_sum_accepts(const unsigned long long* __restrict__ part, int np, unsigned long long* __restrict__ out)
 {
     unsigned long long a = 0;
     for (int i = threadIdx.x; i < np; i += BLOCK) a += part[i];
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
 // gather (if a resample is pending) -> move (rejuvenate.jl:40-90 with Gen.mh / move_reweight on the current step's latent, under the OLD
 // observation `obs_move` and the move's epoch) -> propagate (update.jl:15-22, new observation, the update's epoch) -> one row store.
 // Against k_move + k_step: the moved rows are not written and read back (16 W bytes per particle: 128 B at W = 8) and one launch is
-// gone.  Any other consumer of the state runs the stand-alone k_move first (libgpf.hip finish_move).  Same arithmetic, same order:
+// gone.  Any other consumer of the state runs the stand-alone k_move first (libgpf_core.hip finish_move).  Same arithmetic, same order:
 // lw = ((GATHER ? 0 : lw) + sum of relative weights) + log-likelihood.
 struct ObsVec { double v[MAX_OBS]; };
 template <int M, int W, bool REWEIGHT, bool GATHER>

@@ -27,10 +27,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-
 #define GPF_ABI_VERSION 1
 
 typedef struct gpf_filter* gpf_handle;
+
+/* the library is built with -fvisibility=hidden: the functions this header declares are what it exports */
+#pragma GCC visibility push(default)
 
 typedef enum {
     GPF_OK = 0,
@@ -430,6 +432,7 @@ gpf_status gpf_debug_levels(gpf_handle h, int32_t which, void* out, int64_t* n_b
 /* host twin of gpf_debug_math (which = 0..5, 7) */
 void    gpf_host_math(int32_t which, const double* a, const double* b, int64_t n, double* out, double* out2);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,6 @@
 """Register / scratch / LDS / occupancy table of every kernel of libgpf (compile-time, no GPU):
     python3 tools/kernel_resources.py > profiles/rNN_kernel_resources.txt
-Compiles csrc/libgpf.hip with -Rpass-analysis=kernel-resource-usage and prints one line per kernel."""
+Compiles the four translation units with -Rpass-analysis=kernel-resource-usage and prints one line per kernel."""
 import os
 import re
 import subprocess
@@ -8,11 +8,17 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "genparticlefilters.jl_amd", "csrc", "libgpf.hip")
+csrc = os.path.join(ROOT, "genparticlefilters.jl_amd", "csrc")
+err = ""
 with tempfile.TemporaryDirectory() as td:
-    p = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-                        "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-Rpass-analysis=kernel-resource-usage", *sys.argv[1:],
-                        src, "-o", os.path.join(td, "x.so")], capture_output=True, text=True)
+    procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
+                               "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-Rpass-analysis=kernel-resource-usage", *sys.argv[1:],
+                               "-c", os.path.join(csrc, u), "-o", os.path.join(td, u + ".o")], stderr=subprocess.PIPE, text=True)
+             for u in ("libgpf_core.hip", "libgpf_resample.hip", "libgpf_aux.hip", "libgpf_shard.hip")]
+    for q in procs:
+        err += q.communicate()[1]
+class _P: stderr = err
+p = _P()
 rows, cur = [], None
 for ln in p.stderr.splitlines():
     m = re.search(r"remark: (?:\s*)([A-Za-z ]+?)(?: \[bytes/lane\]| \[waves/SIMD\]| \[bytes/block\])?: (\S+) \[-Rpass", ln)
