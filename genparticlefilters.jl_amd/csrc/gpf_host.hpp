@@ -182,7 +182,8 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     uint64_t* sp_g = nullptr; uint64_t* sp_vlo = nullptr; int64_t sp_cap = 0;
     SortedGammaJob sp_job{}; bool sp_job_set = false;    // tile totals wanted: the next weight scan of this call carries them (scan_launch), else k_sorted_gammas
     ulonglong2* push_stage = nullptr;    // push exchange: staged hits, one 16-byte entry per global output slot at most
-    ShardPlan* shard_plan = nullptr;     // sharded stratified resampling: the slot range this shard serves (k_strat_plan)
+    ShardPlan* shard_plan = nullptr;     // sharded stratified / sorted multinomial resampling: the slot range this shard serves (k_strat_plan, k_sorted_plan)
+    int64_t* splan_F = nullptr; unsigned int* splan_arrive = nullptr;   // k_sorted_plan: boundary scratch [MAX_SHARDS + 1], arrival counter (zero between launches)
     int64_t push_cap = 0;
     bool push_counted = false;
     int last_flags = 0;                  // safe_softmax flags (FLAG_*) of the latest resample that read them on the host (resample_impl)
@@ -371,7 +372,9 @@ CdfLevels levels(const gpf_filter* h, int ch);
 gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global, int32_t* head_anc = nullptr, const ResidDirect* direct = nullptr);
 void launch_multinomial_search(gpf_filter* h, const SearchArgs& sa);
 void launch_search_plain(gpf_filter* h, int which, int grid, size_t lds, const SearchArgs& sa);   // k_search<which>, which = 1 (residual) | 3 (systematic)
-void launch_search_strat(gpf_filter* h, const SearchArgs& sa, int64_t n_slots);                     // k_search_strat<false>
+void launch_search_strat(gpf_filter* h, const SearchArgs& sa, int64_t n_slots, bool sorted_uniforms);   // k_search_strat<sorted_uniforms>
+gpf_status sorted_job_prepare(gpf_filter* h, int64_t gid0, int64_t n_slots);
+gpf_status sorted_gammas_finish(gpf_filter* h, bool with_tiles);
 gpf_status finish_search(gpf_filter* h);
 gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_particles, int check, int32_t* invalid, bool local = false);
 // ---- defined in libgpf_aux.hip

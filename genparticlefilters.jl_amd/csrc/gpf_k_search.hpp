@@ -942,11 +942,17 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
     // a shard serves the global slots [first, first + count) out of its own CDF, which starts at t_off in the global one:
     // strata and RNG counters by GLOBAL slot, targets and strata bounds shifted into local coordinates (signed: the first
     // served stratum may start below the shard's range)
-    const int64_t n_out = a.plan ? (a.plan->count < a.n ? a.plan->count : a.n) : a.n;
-    if (j0 >= n_out) return;                                          // (the grid of a shard is sized for the send buffer)
-    const int64_t sbase = a.plan ? a.plan->first : 0;                 // strata: global slot of the launch's slot 0
-    const int64_t pbase = a.plan ? a.plan->first : a.gid0;            // RNG counters
+    // SORTED on a shard: the spec's tiles are tiles of GLOBAL slots, so the launch's slot 0 is the first slot of the tile that holds the
+    // first served slot; the `skip` launch slots below plan->first belong to a lower shard (their spacings still count in the tile's sum)
+    const int64_t skip = SORTED && a.plan ? a.plan->first % MJB : 0;
+    const int64_t n_out = a.plan ? skip + (a.plan->count < a.n ? a.plan->count : a.n) : a.n;
+    if (j0 >= n_out || (a.plan && a.plan->count == 0)) return;        // (the grid of a shard is sized for the send buffer)
+    const int64_t sbase = a.plan ? a.plan->first - skip : 0;          // strata / tiles: global slot of the launch's slot 0
+    const int64_t pbase = a.plan ? a.plan->first - skip : a.gid0;     // RNG counters
     const int64_t t_off = a.plan ? (int64_t)a.plan->t_off : 0;
+    // launch slots that exist at all: a tile's spacings are summed over ALL its slots, whoever serves them
+    const int64_t n_all = SORTED && a.plan ? a.n_global - sbase : n_out;
+    const int64_t tile = (SORTED && a.plan ? sbase / MJB : 0) + (int64_t)blockIdx.x;   // SORTED: the workgroup's tile of the sorted uniforms
     // ---- the CDF cells the block's targets can fall into, at per-256 granularity (block_count_le_pair on the per-256
     //      level), with the block's targets computed while the probes are in flight: MSLOTS consecutive slots per lane,
     //      one Philox block per aligned slot pair (gpf_math.hpp resample_u64; one more block when the run starts odd),
@@ -961,7 +967,7 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
     int64_t Lj0s;                                                      // ... unclamped
     // (the guess: were the weights equal, slot j0's target would fall into cell j0 n_cells / n_out)
     // (under a sorted order the CDF is steep at the front and flat in the tail: no guess, block_count_le_pair reads the whole level)
-    const int64_t guess = a.order ? -1 : (int64_t)((double)j0 * (a.plan ? (double)a.n_cells / (double)n_out : (double)a.n_cells * invN)) >> 8;
+    const int64_t guess = a.order ? -1 : (int64_t)((double)(j0 > skip ? j0 - skip : 0) * (a.plan ? (double)a.n_cells / (double)(n_out - skip) : (double)a.n_cells * invN)) >> 8;
     block_count_le_pair(a.w.t256, n256, guess, s_cnt, A0, A1, [&](uint64_t& L0, uint64_t& L1) {
         if constexpr (SORTED) {
             // ---- sorted uniforms (gpf_math.hpp): the tile's range [vlo, vlo + W) of the 64-bit uniforms from k_sorted_tiles,
@@ -969,17 +975,17 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
             static_assert(MJB == SP_TILE, "one workgroup = one tile of the sorted uniforms");
             uint64_t gpre = 0, gtot = 0, gown = 0;
             if (!a.sp_vlo) {                                                            // kernel-uniform: <= SP_DIRECT_TILES tile totals
-                const int64_t ntl = (n_out + MJB - 1) / MJB;
+                const int64_t ntl = (sbase + n_all + MJB - 1) / MJB;
                 for (int64_t t = tid; t < ntl; t += MBLOCK) {
                     const uint64_t v = a.sp_g[t];
-                    gtot += v; gpre += t < (int64_t)blockIdx.x ? v : 0; gown = t == (int64_t)blockIdx.x ? v : gown;
+                    gtot += v; gpre += t < tile ? v : 0; gown = t == tile ? v : gown;
                 }
             }
             uint64_t e[MSLOTS];
             lane_spacings(a.seed, a.epoch, s0, e);
             uint64_t run = 0;
 #pragma unroll
-            for (int k = 0; k < MSLOTS; ++k) { run += j0 + (int64_t)t0 + k < n_out ? e[k] : 0; e[k] = run; }   // inclusive inside the lane
+            for (int k = 0; k < MSLOTS; ++k) { run += j0 + (int64_t)t0 + k < n_all ? e[k] : 0; e[k] = run; }   // inclusive inside the lane
             const uint64_t inc = wave_scan_u64(run);
             if (lane == WAVE - 1) s_sp[wv] = inc;
             if (!a.sp_vlo) {
@@ -989,14 +995,14 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
             if (tid == 0) {
                 s_e0 = e[0];
                 // the (N + 1)-th spacing belongs to the last tile
-                s_eN = j0 + MJB >= n_out ? spacing_of(resample_u64(a.seed, (uint32_t)(pbase + n_out), a.epoch)) : 0;
+                s_eN = j0 + MJB >= n_all ? spacing_of(resample_u64(a.seed, (uint32_t)(pbase + n_all), a.epoch)) : 0;
             }
             __syncthreads();
             uint64_t st = 1 + s_eN, wex = 0;                                           // s_t = the tile's sum + 1 (+ e_N)
 #pragma unroll
             for (int w = 0; w < NWAVES; ++w) { st += s_sp[w]; wex += w < wv ? s_sp[w] : 0; }
             uint64_t vlo, Wt;
-            if (a.sp_vlo) { vlo = a.sp_vlo[blockIdx.x]; Wt = a.sp_vlo[blockIdx.x + 1] - vlo; }
+            if (a.sp_vlo) { vlo = a.sp_vlo[tile]; Wt = a.sp_vlo[tile + 1] - vlo; }
             else {
                 gpre = 0; gtot = 0; gown = 0;
 #pragma unroll
@@ -1010,10 +1016,17 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
             const uint64_t off = wex + (inc - run);
             uint64_t T[MSLOTS];
 #pragma unroll
-            for (int k = 0; k < MSLOTS; ++k)
-                T[k] = j0 + (int64_t)t0 + k < n_out ? sorted_target(off + e[k], inv_s, Tlo, Tw, dTw) : ~0ull;   // resample.jl:59 on the sorted uniform
+            for (int k = 0; k < MSLOTS; ++k) {
+                const int64_t j = j0 + (int64_t)t0 + k;
+                // (a shard: slots above its served range -- a higher shard's, targets beyond its CDF -- read as padding; the `skip` slots below
+                //  it -- targets below its CDF -- as 0: the targets stay ascending, neither kind is written out)
+                const uint64_t Tg = j < n_out ? sorted_target(off + e[k], inv_s, Tlo, Tw, dTw) : ~0ull;     // resample.jl:59 on the sorted uniform
+                T[k] = j < n_out ? (j >= skip ? Tg - (uint64_t)t_off : 0) : ~0ull;
+            }
             Lj0 = sorted_target(s_e0, inv_s, Tlo, Tw, dTw);                             // the block's first target ...
             Lj1 = sorted_target(st - 1 - s_eN, inv_s, Tlo, Tw, dTw) + 1;                // ... and one past its last (real) one
+            Lj0 = Lj0 > (uint64_t)t_off ? Lj0 - (uint64_t)t_off : 0;                    // (local; the tile may start below the shard's CDF
+            Lj1 -= (uint64_t)t_off;                                                     //  and end above it: a block with a served slot has Lj1 > t_off)
             Lj0s = (int64_t)Lj0;
             L0 = Lj0; L1 = Lj1 - 1;
 #pragma unroll
@@ -1240,18 +1253,18 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
             // own-direct: a workgroup whose slots ALL belong to this shard itself (on one rank: every workgroup) writes the ancestors in
             // place from its registers, like the unsharded kernel -- no LDS round trip, no packed entries
             const int64_t b0 = a.plan->bounds[a.pack.me], b1 = a.plan->bounds[a.pack.me + 1];
-            const int64_t g0 = sbase + j0, g1 = sbase + (j0 + MJB < n_out ? j0 + MJB : n_out);
-            if (g0 >= b0 && g1 <= b1 && n_out <= a.pack.capacity) {     // block-uniform
+            const int64_t g0 = sbase + (j0 > skip ? j0 : skip), g1 = sbase + (j0 + MJB < n_out ? j0 + MJB : n_out);
+            if (g0 >= b0 && g1 <= b1 && n_out - skip <= a.pack.capacity) {     // block-uniform
                 int32_t* dst = a.pack.own_anc + (sbase + jb - b0);
                 int32_t out[MSLOTS];
 #pragma unroll
                 for (int k = 0; k < MSLOTS; ++k) out[k] = (int32_t)(a.pack.gid0 + (int64_t)(res[k] < last ? res[k] : last));
-                if (jb + MSLOTS <= n_out && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                if (jb >= skip && jb + MSLOTS <= n_out && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
 #pragma unroll
                     for (int k = 0; k < MSLOTS; k += 4) *reinterpret_cast<int4*>(dst + k) = make_int4(out[k], out[k + 1], out[k + 2], out[k + 3]);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < MSLOTS; ++k) if (jb + k < n_out) dst[k] = out[k];
+                    for (int k = 0; k < MSLOTS; ++k) if (jb + k >= skip && jb + k < n_out) dst[k] = out[k];
                 }
                 return;
             }
@@ -1263,7 +1276,7 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
         const int G = a.plan->n_shards;
         for (int g = tid; g <= G; g += MBLOCK) s_bnd[g] = a.plan->bounds[g];
         __syncthreads();
-        const int64_t lim = n_out < a.pack.capacity ? n_out : a.pack.capacity;
+        const int64_t lim = n_out - skip < a.pack.capacity ? n_out : skip + a.pack.capacity;
         int lo = 0;
         {
             const int64_t jg = sbase + j0 + tid;                         // the shard that holds the lane's first entry
@@ -1275,6 +1288,7 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
         for (int k = 0; k < MSLOTS; ++k) {
             const int64_t e = j0 + k * MBLOCK + tid;
             if (e >= lim) break;
+            if (e < skip) continue;
             const int64_t jg = sbase + e;
             while (lo < G - 1 && s_bnd[lo + 1] <= jg) ++lo;
             const int64_t i = s_mark[k * MBLOCK + tid];
@@ -1283,7 +1297,7 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
                 continue;
             }
             const double2* src = reinterpret_cast<const double2*>(a.pack.rows + i * W);
-            double* dst = a.pack.packed + e * (W + 1 + a.pack.extra);
+            double* dst = a.pack.packed + (e - skip) * (W + 1 + a.pack.extra);
             if (a.pack.extra) dst[W + 1] = a.pack.pv.lw[i] - a.pack.pv.at(i);
             for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }
             dst[W] = u2d(((uint64_t)(jg - s_bnd[lo]) << 32) | (uint64_t)(a.pack.gid0 + i));

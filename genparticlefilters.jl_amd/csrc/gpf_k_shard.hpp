@@ -601,6 +601,178 @@ static __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan
         __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// ---- sharded SORTED MULTINOMIAL (GPF_RESAMPLE_MULTINOMIAL_SORTED): the targets of the N slots are non-decreasing in
+// the slot index, like the strata, so the slots shard h serves are again ONE range [F[h], F[h+1]), F[h] = the first slot whose target is
+// >= lo_h.  The tile totals depend on (seed, epoch, N) alone: every shard draws all of them (k_sorted_gammas over the GLOBAL tiles, as extra
+// workgroups of its weight scan), so every shard can place every tile -- mulhi(vlo[t], S) ascends in t -- and, with the spacings of ONE
+// tile, every slot of it.  Workgroup h of this kernel finds F[h]: the first tile whose END reaches lo_h (the tiles below it lie entirely
+// below lo_h), then that tile's 2048 targets exactly as k_search_strat<true> forms them, and the number of them below lo_h.  The workgroup
+// that arrives last turns F into the plan and the exchange counts (as k_strat_plan).  Up to SP_DIRECT_TILES tiles every workgroup scans the
+// tile totals itself (workgroup 0 leaves vlo[] behind for the merge kernel); beyond, k_sorted_tiles has run and vlo[] is searched in place.
+struct SortedPlanJob {
+    const uint64_t* g;            // [ntl] gamma totals of the GLOBAL tiles
+    uint64_t* vlo;                // [ntl + 1] where every tile starts among the sorted 64-bit uniforms: read (have_vlo) or written by workgroup 0
+    int64_t ntl; int have_vlo;
+    int64_t* F;                   // [MAX_SHARDS + 1] first slot served by every shard (scratch between the workgroups)
+    unsigned int* arrive;         // arrival counter, zero between launches
+};
+// number of t in [0, cnt) with pred(t), pred monotone (true ... true false ... false); block-cooperative: one 256-entry window around `guess`
+// (one round trip when it brackets the answer), else 256-ary rounds over the whole range
+template <class P>
+__device__ __forceinline__ int64_t block_partition_point(int64_t cnt, int64_t guess, int (*s_cnt)[NWAVES], P&& pred)
+{
+    const int tid = (int)threadIdx.x;
+    int par = 0;
+    auto count = [&](bool p) {
+        const int c = (int)__popcll(__ballot(p));
+        if (lane_id() == 0) s_cnt[par][wave_id()] = c;
+        __syncthreads();
+        int64_t k = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) k += s_cnt[par][w];
+        par ^= 1;
+        return k;
+    };
+    {
+        int64_t w_lo = guess - MBLOCK / 2;
+        w_lo = w_lo + MBLOCK > cnt ? cnt - MBLOCK : w_lo;
+        w_lo = w_lo < 0 ? 0 : w_lo;
+        const int64_t w_hi = w_lo + MBLOCK < cnt ? w_lo + MBLOCK : cnt;
+        const int64_t k = count(w_lo + tid < w_hi ? pred(w_lo + tid) : false);
+        if ((k > 0 || w_lo == 0) && (k < w_hi - w_lo || w_hi == cnt)) return w_lo + k;                       // block-uniform
+    }
+    int64_t lo = 0, hi = cnt;                      // invariant: lo <= answer <= hi
+    while (hi > lo) {                              // block-uniform
+        const int64_t len = hi - lo, step = len <= MBLOCK ? 1 : (len + MBLOCK - 1) / MBLOCK;
+        const int64_t p = lo + (int64_t)(tid + 1) * step - 1;
+        const int64_t k = count(p < hi ? pred(p) : false);
+        const int64_t nlo = lo + k * step, cap = step == 1 ? nlo : nlo + step - 1;                          // the first probe that failed bounds the answer
+        hi = cap < hi ? cap : hi;
+        lo = nlo;
+    }
+    return lo;
+}
+static __global__ __launch_bounds__(MBLOCK) void k_sorted_plan(PushArgs a, ShardPlan* plan, SortedPlanJob jb)
+{
+    static_assert(MJB == SP_TILE && MAX_SHARDS + 1 <= MBLOCK, "one workgroup = one tile; one thread per shard boundary in the tail");
+    __shared__ uint64_t s_v[SP_DIRECT_TILES + 1];
+    __shared__ uint64_t s_w[NWAVES], s_sp[NWAVES];
+    __shared__ int s_cnt[2][NWAVES];
+    __shared__ int64_t s_F[MAX_SHARDS + 1];
+    __shared__ uint64_t s_eN;
+    __shared__ int s_last;
+    const int h = (int)blockIdx.x, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
+    const uint64_t N = (uint64_t)a.n_global;
+    uint64_t S = 0, lo = 0, lo_me = 0;
+    mbox_wait_block(a.wait_tot);
+    for (int g = 0; g < a.G; ++g) {
+        const uint64_t v = (uint64_t)ld_gathered(a.tot_all + 5 * g, a.wait_tot.tags != nullptr);
+        if (g < h) lo += v;
+        if (g < a.me) lo_me += v;
+        S += v;
+    }
+    const int64_t ntl = jb.ntl;
+    if (!jb.have_vlo) {
+        // vlo[t] = floor((g_0 + ... + g_{t-1}) 2^64 / (sum g + 1)) for every tile (k_sorted_tiles' arithmetic): thread i owns consecutive tiles
+        const int64_t per = (ntl + MBLOCK - 1) / MBLOCK;
+        const int64_t t0 = (int64_t)tid * per, t1 = t0 + per < ntl ? t0 + per : ntl;
+        uint64_t mine = 0;
+        for (int64_t t = t0; t < t1; ++t) mine += jb.g[t];
+        const uint64_t inc = wave_scan_u64(mine);
+        if (lane == WAVE - 1) s_w[wv] = inc;
+        __syncthreads();
+        uint64_t run = inc - mine, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) { run += w < wv ? s_w[w] : 0; tot += s_w[w]; }
+        const Div128 dv = div128_setup(tot + 1);
+        for (int64_t t = t0; t < t1; ++t) {
+            const uint64_t v = div128(run, dv);
+            s_v[t] = v;
+            if (h == 0) jb.vlo[t] = v;
+            run += jb.g[t];
+        }
+        if (tid == 0) { const uint64_t v = div128(tot, dv); s_v[ntl] = v; if (h == 0) jb.vlo[ntl] = v; }
+        __syncthreads();
+    }
+    const uint64_t* const V = jb.have_vlo ? jb.vlo : s_v;
+    int64_t f;
+    if (h == 0) f = 0;
+    else if (h >= a.G || lo >= S) f = (int64_t)N;                     // (block-uniform branches)
+    else {
+        // tiles whose targets all lie below lo: the tile's targets are <= mulhi(vlo[t + 1], S); the sorted uniforms spread evenly over the
+        // tiles whatever the weights, so lo / S names the tile up to a few
+        const int64_t guess = (int64_t)((double)lo / (double)S * (double)ntl);
+        const int64_t ts = block_partition_point(ntl, guess, s_cnt, [&](int64_t t) { return mulhi64(V[t + 1], S) < lo; });
+        if (ts >= ntl) f = (int64_t)N;
+        else {
+            // the targets of tile ts, as k_search_strat<true> forms them (global coordinates), and how many of them lie below lo
+            const int64_t base = ts * MJB, n_all = (int64_t)N - base;
+            uint64_t e[MSLOTS];
+            lane_spacings(a.seed, a.epoch, (uint32_t)(base + MSLOTS * tid), e);
+            uint64_t run = 0;
+#pragma unroll
+            for (int k = 0; k < MSLOTS; ++k) { run += MSLOTS * tid + k < n_all ? e[k] : 0; e[k] = run; }
+            const uint64_t inc = wave_scan_u64(run);
+            if (lane == WAVE - 1) s_sp[wv] = inc;
+            if (tid == 0) s_eN = MJB >= n_all ? spacing_of(resample_u64(a.seed, (uint32_t)N, a.epoch)) : 0;   // the (N + 1)-th spacing belongs to the last tile
+            __syncthreads();
+            uint64_t st = 1 + s_eN, wex = 0;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) { st += s_sp[w]; wex += w < wv ? s_sp[w] : 0; }
+            const uint64_t vlo = V[ts], Wt = V[ts + 1] - vlo;
+            const uint64_t Tlo = mulhi64(vlo, S), Tw = mulhi64(vlo + Wt, S) - Tlo;
+            const double inv_s = 1.0 / (double)st, dTw = (double)Tw;
+            const uint64_t off = wex + (inc - run);
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < MSLOTS; ++k)
+                c += MSLOTS * tid + k < n_all && sorted_target(off + e[k], inv_s, Tlo, Tw, dTw) < lo ? 1 : 0;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, WAVE);
+            if (lane == 0) s_cnt[0][wv] = c;                          // (the partition point's last round used the other parity or is behind a barrier)
+            __syncthreads();
+            int64_t cb = 0;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) cb += s_cnt[0][w];
+            f = base + cb;
+        }
+    }
+    // ---- the last workgroup to arrive turns the boundaries into the plan
+    if (tid == 0) {
+        __hip_atomic_store(jb.F + h, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int old = __hip_atomic_fetch_add(jb.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid <= a.G) s_F[tid] = __hip_atomic_load(jb.F + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int q = tid;
+    if (q < a.G) {
+        // sent to shard q: the served slots that lie in q's slot range; received from shard q: q's served slots in this shard's range
+        const int64_t s0 = s_F[a.me] > a.bounds[q] ? s_F[a.me] : a.bounds[q], s1 = s_F[a.me + 1] < a.bounds[q + 1] ? s_F[a.me + 1] : a.bounds[q + 1];
+        const int64_t r0 = s_F[q] > a.bounds[a.me] ? s_F[q] : a.bounds[a.me], r1 = s_F[q + 1] < a.bounds[a.me + 1] ? s_F[q + 1] : a.bounds[a.me + 1];
+        const int64_t ns = s1 > s0 ? s1 - s0 : 0, nr = r1 > r0 ? r1 - r0 : 0;
+        a.counts[q * COUNT_STRIDE] = ns; a.counts[(a.G + q) * COUNT_STRIDE] = nr;
+        if (q == a.me) { plan->own_range[0] = nr > 0 ? r0 - a.bounds[a.me] : 0; plan->own_range[1] = nr > 0 ? r1 - a.bounds[a.me] : 0; }
+        if (a.host_counts) {
+            __hip_atomic_store(a.host_counts + q, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.host_counts + a.G + q, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (q == 0) {
+        plan->ws.S = S; plan->ws.sB = S / N; plan->ws.srem = S % N; plan->ws.sinv = (double)N / (double)S;
+        plan->first = s_F[a.me]; plan->count = s_F[a.me + 1] - s_F[a.me]; plan->t_off = lo_me;
+        plan->n_shards = a.G;
+        __hip_atomic_store(jb.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (q <= a.G) plan->bounds[q] = a.bounds[q];
+    __syncthreads();
+    if (q == 0 && a.host_counts) {
+        __threadfence_system();
+        __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 // k_push for multinomial shards whose CDF carries the offset levels of k_search_multi: the 4-byte key table in LDS, four staged
 // hits per lane in flight.  What bounds these kernels is the number of DIVERGENT global loads per entry (each costs the CU's L1
 // about four cycles per lane): here the coarse row, the fine run and the particle's row -- the keys never leave LDS.

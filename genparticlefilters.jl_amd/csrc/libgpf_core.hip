@@ -531,6 +531,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->h_qpub) hipHostFree(h->h_qpub);
     if (h->h_spart) hipHostFree(h->h_spart);
     if (h->sp_g) { (void)hipFree(h->sp_g); (void)hipFree(h->sp_vlo); }
+    if (h->splan_F) { (void)hipFree(h->splan_F); (void)hipFree(h->splan_arrive); }
     if (h->sum_part) (void)hipFree(h->sum_part);
     for (int k = 0; k < gpf_filter::BLK_STAGE; ++k) if (h->h_blk_obs[k]) hipHostFree(h->h_blk_obs[k]);
     if (h->h_blk_done) hipHostFree(h->h_blk_done);

@@ -493,9 +493,37 @@ void launch_search_plain(gpf_filter* h, int which, int grid, size_t lds, const S
     if (which == 1) GPF_LAUNCH((k_search<1>), dim3(grid), dim3(SBLOCK), lds, h->stream, sa);
     else            GPF_LAUNCH((k_search<3>), dim3(grid), dim3(SBLOCK), lds, h->stream, sa);
 }
-void launch_search_strat(gpf_filter* h, const SearchArgs& sa, int64_t n_slots)
+void launch_search_strat(gpf_filter* h, const SearchArgs& sa, int64_t n_slots, bool sorted_uniforms)
 {
-    GPF_LAUNCH((k_search_strat<false>), dim3((unsigned)((n_slots + MJB_STRAT - 1) / MJB_STRAT)), dim3(MBLOCK), 0, h->stream, sa);
+    if (sorted_uniforms) GPF_LAUNCH((k_search_strat<true>), dim3((unsigned)((n_slots + MJB - 1) / MJB)), dim3(MBLOCK), 0, h->stream, sa);
+    else                 GPF_LAUNCH((k_search_strat<false>), dim3((unsigned)((n_slots + MJB_STRAT - 1) / MJB_STRAT)), dim3(MBLOCK), 0, h->stream, sa);
+}
+// GPF_RESAMPLE_MULTINOMIAL_SORTED: buffers for the tile totals of n_slots slots whose first slot has the RNG id gid0, and the job that draws them
+// (left pending: the next weight scan of the call carries it as extra workgroups -- scan_launch --, else sorted_gammas_finish launches it)
+gpf_status sorted_job_prepare(gpf_filter* h, int64_t gid0, int64_t n_slots)
+{
+    const int64_t ntl = (n_slots + SP_TILE - 1) / SP_TILE;
+    if (h->sp_cap < ntl + 1) {
+        if (h->sp_g) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->sp_g); (void)hipFree(h->sp_vlo); h->sp_g = h->sp_vlo = nullptr; h->sp_cap = 0; }
+        HIP_TRY(h, hipMalloc(&h->sp_g, (size_t)(ntl + 1) * sizeof(uint64_t)));
+        HIP_TRY(h, hipMalloc(&h->sp_vlo, (size_t)(ntl + 1) * sizeof(uint64_t)));
+        h->sp_cap = ntl + 1;
+    }
+    h->sp_job = SortedGammaJob{h->cfg.seed, h->sp_g, gid0, n_slots, ntl, h->epoch, gamma_E(ntl), 0};
+    h->sp_job_set = true;
+    return GPF_OK;
+}
+// the pending tile totals now, if no weight scan has carried them; with_tiles: also where every tile starts (k_sorted_tiles)
+gpf_status sorted_gammas_finish(gpf_filter* h, bool with_tiles)
+{
+    const int64_t ntl = h->sp_job.ntl;
+    if (h->sp_job_set) {
+        h->sp_job_set = false;
+        GPF_LAUNCH(k_sorted_gammas, dim3((unsigned)((ntl + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->sp_job);
+    }
+    if (with_tiles) GPF_LAUNCH(k_sorted_tiles, dim3(1), dim3(STILES_BLOCK), 0, h->stream, h->sp_g, ntl, h->sp_vlo);
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
 }
 
 // the ancestors of a pending multinomial resample are wanted as an array after all (getters, views, rejuvenation, a second resample,
@@ -548,15 +576,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
         // the gamma total of every tile of SP_TILE slots: one lane per tile, as extra workgroups of the weight scan below;
         // beyond SP_DIRECT_TILES tiles one more small launch turns them into the tiles' starting points, else the merge kernel does
         // that for its own tile
-        const int64_t ntl = (h->n + SP_TILE - 1) / SP_TILE;
-        if (h->sp_cap < ntl + 1) {
-            if (h->sp_g) { HIP_TRY(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->sp_g); (void)hipFree(h->sp_vlo); h->sp_g = h->sp_vlo = nullptr; h->sp_cap = 0; }
-            HIP_TRY(h, hipMalloc(&h->sp_g, (size_t)(ntl + 1) * sizeof(uint64_t)));
-            HIP_TRY(h, hipMalloc(&h->sp_vlo, (size_t)(ntl + 1) * sizeof(uint64_t)));
-            h->sp_cap = ntl + 1;
-        }
-        h->sp_job = SortedGammaJob{h->cfg.seed, h->sp_g, h->cfg.gid0, h->n, ntl, h->epoch, gamma_E(ntl), 0};
-        h->sp_job_set = true;
+        if ((s = sorted_job_prepare(h, h->cfg.gid0, h->n))) return s;
     }
     struct SpScope { gpf_filter* h; ~SpScope() { h->sp_job_set = false; } } sp_scope{h};
     // safe_softmax(log_priorities) (resample.jl:54) and logsumexp(log_weights) (resample.jl:180)
@@ -621,15 +641,9 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     }
     if (method == GPF_RESAMPLE_MULTINOMIAL_SORTED) {
         const int64_t ntl = (h->n + SP_TILE - 1) / SP_TILE;
-        if (h->sp_job_set) {                                     // no weight scan ran in this call (the CDF of an earlier getter is reused): a launch of its own
-            h->sp_job_set = false;
-            GPF_LAUNCH(k_sorted_gammas, dim3((unsigned)((ntl + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->sp_job);
-        }
-        sa.sp_g = h->sp_g; sa.sp_vlo = nullptr;
-        if (ntl > SP_DIRECT_TILES) {
-            GPF_LAUNCH(k_sorted_tiles, dim3(1), dim3(STILES_BLOCK), 0, h->stream, h->sp_g, ntl, h->sp_vlo);
-            sa.sp_vlo = h->sp_vlo;
-        }
+        // (the tile totals in a launch of their own if no weight scan ran in this call -- the CDF of an earlier getter is reused)
+        if ((s = sorted_gammas_finish(h, ntl > SP_DIRECT_TILES))) return s;
+        sa.sp_g = h->sp_g; sa.sp_vlo = ntl > SP_DIRECT_TILES ? h->sp_vlo : nullptr;
     }
     const int64_t nt = method == GPF_RESAMPLE_RESIDUAL && !sa.head_done ? 2 : 1;   // (top tables the search keeps in LDS: its shape depends on their number)
     const size_t lds = search_lds_bytes(h->ntiles, (int)nt);

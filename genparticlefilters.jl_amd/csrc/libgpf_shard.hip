@@ -147,7 +147,7 @@ gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t
 static gpf_status push_args(gpf_handle h, int32_t method, const int64_t* tot_all, const int64_t* cr_all, int32_t G, int32_t me,
                             const int64_t* bounds, PushArgs& a)
 {
-    if (method < 0 || method > 2) return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");
+    if ((method < 0 || method > 2) && method != GPF_RESAMPLE_MULTINOMIAL_SORTED) return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");
     if (!tot_all || !bounds || G < 1 || G > MAX_SHARDS || me < 0 || me >= G || (method == GPF_RESAMPLE_RESIDUAL && !cr_all))
         return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     if (bounds[0] != 0 || bounds[G] != h->cfg.n_global || bounds[me] != h->cfg.gid0 || bounds[me + 1] != h->cfg.gid0 + h->n)
@@ -182,6 +182,29 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
     PushArgs a;
     if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, a))) return s;    // the counters were cleared by the weight scan
     h->counts_published = false;
+    if (method == GPF_RESAMPLE_MULTINOMIAL_SORTED) {
+        // sorted uniforms: ascending targets, so the plan is again ONE served slot range per shard (k_sorted_plan); every shard draws ALL tile
+        // totals itself -- with its weight scan when the library engine prepared the job, else now
+        if (!h->shard_plan) HIP_TRY(h, hipMalloc(&h->shard_plan, sizeof(ShardPlan)));
+        if (!h->splan_F) {
+            HIP_TRY(h, hipMalloc(&h->splan_F, (MAX_SHARDS + 1) * sizeof(int64_t)));
+            HIP_TRY(h, hipMalloc(&h->splan_arrive, sizeof(unsigned int)));
+            HIP_TRY(h, hipMemsetAsync(h->splan_arrive, 0, sizeof(unsigned int), h->stream));
+        }
+        const int64_t ntl = (h->cfg.n_global + SP_TILE - 1) / SP_TILE;
+        if (!(h->sp_cap >= ntl + 1 && h->sp_job.g == h->sp_g && h->sp_job.epoch == h->epoch && h->sp_job.n == h->cfg.n_global && h->sp_job.gid0 == 0 && h->sp_job.ntl == ntl)
+            && (s = sorted_job_prepare(h, 0, h->cfg.n_global))) return s;
+        if ((s = sorted_gammas_finish(h, ntl > SP_DIRECT_TILES))) return s;
+        h->push_ticket += 1;
+        a.ticket = h->push_ticket;
+        const SortedPlanJob job{h->sp_g, h->sp_vlo, ntl, ntl > SP_DIRECT_TILES ? 1 : 0, h->splan_F, h->splan_arrive};
+        s = timed(h, GPF_K_SEARCH, [&] { GPF_LAUNCH(k_sorted_plan, dim3((unsigned)(G + 1)), dim3(MBLOCK), 0, h->stream, a, h->shard_plan, job); });
+        if (s) return s;
+        HIP_TRY(h, hipGetLastError());
+        h->counts_published = true;
+        h->push_counted = true;
+        return GPF_OK;
+    }
     if (method == GPF_RESAMPLE_STRATIFIED) {
         // contiguous strata x contiguous shard ranges: the plan (served slot range, exchange counts) is closed-form; the
         // counts go to the host right away
@@ -264,7 +287,8 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
     if (!h->push_counted) return fail(h, GPF_ERR_STATE, "gpf_shard_push needs gpf_shard_push_count of the same resample first");
     if (capacity < 0 || (capacity > 0 && !packed_out)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     PushArgs a;
-    if (method == GPF_RESAMPLE_STRATIFIED) {
+    if (method == GPF_RESAMPLE_STRATIFIED || method == GPF_RESAMPLE_MULTINOMIAL_SORTED) {
+        const bool su = method == GPF_RESAMPLE_MULTINOMIAL_SORTED;
         if (!h->shard_plan) return fail(h, GPF_ERR_STATE, "gpf_shard_push needs gpf_shard_push_count of the same resample first");
         if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, a))) return s;
         if (capacity == 0) return GPF_OK;
@@ -278,8 +302,10 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
         sa.K = h->K; sa.logN = h->logN; sa.anc = nullptr; sa.invN = 1.0 / (double)h->cfg.n_global;
         sa.update_lml = 0;                                            // the commit carries the log-ML update
         sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W, h->push_extra, h->push_pv, h->own_direct ? h->anc : nullptr, (int)me};
+        if (su) { sa.sp_g = nullptr; sa.sp_vlo = h->sp_vlo; }         // (k_sorted_plan / k_sorted_tiles left every GLOBAL tile's start there)
         s = timed(h, GPF_K_GATHER, [&] {
-            launch_search_strat(h, sa, cap);
+            // (sorted uniforms: the launch starts at the tile boundary below the first served slot -- up to one tile of slots more)
+            launch_search_strat(h, sa, su ? cap + SP_TILE : cap, su);
         });
         if (s) return s;
         HIP_TRY(h, hipGetLastError());
@@ -717,9 +743,10 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
-    if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED)
+    if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED && method != GPF_RESAMPLE_MULTINOMIAL_SORTED)
         return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");             // resample.jl:28
     if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_shard_resample needs gpf_comm_create first");
+    const bool ranged = method == GPF_RESAMPLE_STRATIFIED || method == GPF_RESAMPLE_MULTINOMIAL_SORTED;   // ascending targets: every shard serves ONE slot range
     const int G = h->comm_world, me = h->comm_rank;
     // priority_fn = w -> alpha w (resample.jl:51-52): ancestors from the priorities' CDF, the log-ML update from the RAW weights
     // (:57), new log-weights log_ws + (log N - logsumexp(log_ws)) with log_ws = lw[a] - lp[a] (:198-200).  Across shards that is
@@ -757,7 +784,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     static const bool force = getenv("GPF_SHARD_FORCE_COLLECTIVES") && !strcmp(getenv("GPF_SHARD_FORCE_COLLECTIVES"), "1");
     const bool exchange = G > 1 || (force && h->comm);            // one shard: what it "sends" is what it "receives"
     if (exchange && (s = ensure(h->sh_recv, h->sh_recv_cap, n))) return s;
-    const bool pull = h->shard_plan_kind == GPF_SHARD_PLAN_PULL && method != GPF_RESAMPLE_STRATIFIED;
+    const bool pull = h->shard_plan_kind == GPF_SHARD_PLAN_PULL && !ranged;
     if (pull && (s = pull_buffers(h, G))) return s;
     // Own-direct (multinomial, push plan, no priorities): a slot of this shard whose target falls into this shard's own part of the CDF is
     // resolved in place -- its ancestor goes into h->anc and the next propagate gathers the row through it, as on an unsharded filter;
@@ -767,9 +794,21 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     const bool own = !own_off && !prio && h->cfg.n_global < ((int64_t)1 << 31) && ((method == GPF_RESAMPLE_MULTINOMIAL && !pull && multi_logg(h->ntiles) >= 0 &&
                                             multi_lds_bytes(h->ntiles, multi_logg(h->ntiles)) + 4096 <= (size_t)160 * 1024) ||
                                            (method == GPF_RESAMPLE_RESIDUAL && !pull && search_lds_bytes(h->ntiles, 2) + 40 * 1024 <= (size_t)160 * 1024) ||
-                                           method == GPF_RESAMPLE_STRATIFIED);
+                                           ranged);
     struct OwnScope { gpf_filter* h; ~OwnScope() { h->own_direct = false; h->own_direct_range = false; } } own_scope{h};
-    h->own_direct = own; h->own_direct_range = own && method == GPF_RESAMPLE_STRATIFIED;
+    h->own_direct = own; h->own_direct_range = own && ranged;
+    // sorted multinomial: the tile totals of ALL global slots (they depend on seed, epoch and N alone) -- the job rides in the weight scan below
+    struct SpScope { gpf_filter* h; ~SpScope() { h->sp_job_set = false; } } sp_scope{h};
+    if (method == GPF_RESAMPLE_MULTINOMIAL_SORTED) {
+        if ((s = materialize(h))) return s;
+        if ((s = sorted_job_prepare(h, 0, h->cfg.n_global))) return s;
+        if (!h->shard_plan) HIP_TRY(h, hipMalloc(&h->shard_plan, sizeof(ShardPlan)));
+        if (!h->splan_F) {
+            HIP_TRY(h, hipMalloc(&h->splan_F, (MAX_SHARDS + 1) * sizeof(int64_t)));
+            HIP_TRY(h, hipMalloc(&h->splan_arrive, sizeof(unsigned int)));
+            HIP_TRY(h, hipMemsetAsync(h->splan_arrive, 0, sizeof(unsigned int), h->stream));
+        }
+    }
 
     const double* raw_mf = nullptr; const int64_t* raw_tot = nullptr;
     struct PushScope { gpf_filter* h; ~PushScope() { h->push_extra = 0; } } push_scope{h};
@@ -816,8 +855,8 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
             // one shard, own-direct: every slot is an own hit -- nothing to exchange, so no split sizes to wait for (the host wait left a
             // gap in the queue on every resample); the i.i.d. methods have nothing to push either, stratified writes its ancestors in
             // place from the merge kernel
-            counts[0] = method == GPF_RESAMPLE_STRATIFIED ? n : 0; counts[1] = n;
-            if (method == GPF_RESAMPLE_STRATIFIED && (s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
+            counts[0] = ranged ? n : 0; counts[1] = n;
+            if (ranged && (s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
         } else {
         // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
         // counts say it overflowed

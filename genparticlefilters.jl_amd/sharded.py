@@ -39,7 +39,10 @@ import torch.distributed as dist
 from . import _lib
 from .api import DeviceParticleFilterState, ErrorException, _obs_vector, _pd
 
-RESAMPLE_METHODS = {"multinomial": 0, "residual": 1, "stratified": 2}
+RESAMPLE_METHODS = {"multinomial": 0, "residual": 1, "stratified": 2,
+                    # the opt-in sorted form of the multinomial resampler (gpf.h GPF_RESAMPLE_MULTINOMIAL_SORTED): ascending
+                    # targets like the strata's, so every shard serves ONE slot range and the exchange is boundary slabs
+                    "multinomial_sorted": 4}
 # tests: issue the real collectives even in a 1-rank process group (exercises the RCCL call path on a 1-GPU box)
 _FORCE_COLLECTIVES = os.environ.get("GPF_SHARD_FORCE_COLLECTIVES") == "1"
 SPACE_COUNTS = 1 << 62

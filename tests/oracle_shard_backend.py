@@ -81,6 +81,8 @@ class OracleShardBackend:
             T = o.targets_multinomial(self.seed, self.epoch, 0, self.N, S).astype(np.int64)
         elif method_id == 2:
             T = o.targets_stratified(self.seed, self.epoch, 0, self.N, self.N, S).astype(np.int64)
+        elif method_id == 4:                                   # sorted uniforms (opt-in multinomial_sorted): the unsharded spec over the GLOBAL slots
+            T = o.targets_sorted(self.seed, self.epoch, 0, self.N, S).astype(np.int64)
         else:
             cr = cr_all.numpy()
             Ctot, Rs = int(cr[:, 0].sum()), int(cr[:, 1].sum())

@@ -108,7 +108,7 @@ def fuzz_ops(seed, T):
     ops = []
     for _ in range(T):
         op = str(rng.choice(["update", "resample", "rejuvenate", "getters", "local", "set_weights"], p=[0.3, 0.3, 0.1, 0.1, 0.1, 0.1]))
-        ops.append((op, str(rng.choice(["multinomial", "stratified", "residual"])), str(rng.choice(["equal", "one heavy", "some -inf", "wide"])),
+        ops.append((op, str(rng.choice(["multinomial", "stratified", "residual", "multinomial_sorted"])), str(rng.choice(["equal", "one heavy", "some -inf", "wide"])),
                     int(rng.integers(1 << 30))))
     return ops
 

@@ -31,7 +31,7 @@ def test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=2):
         assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
 
 
-@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
 @pytest.mark.parametrize("n_global,world", [(10, 3), (3, 3), (257, 2)])
 def test_hip_tiny_shards(g, o, tmp_path, method, n_global, world):
     """shards of 1 to a few particles (fewer slots than a workgroup handles, shard totals that differ a lot)"""
@@ -52,7 +52,7 @@ def test_world1_sharded_equals_unsharded(g, o):
     a = sharded.pf_initialize(model, (1,), ys[0], N, seed=5)
     b = g.pf_initialize(model, (1,), ys[0], N, seed=5)
     for t in range(1, 5):
-        for method in ("multinomial", "stratified", "residual")[(t - 1) % 3:(t - 1) % 3 + 1]:
+        for method in ("multinomial", "stratified", "residual", "multinomial_sorted")[(t - 1) % 4:(t - 1) % 4 + 1]:
             sharded.pf_resample(a, method, check=False)
             kw = dict(sort_particles=False) if method == "stratified" else {}
             g.pf_resample(b, method, check=False, **kw)
@@ -70,7 +70,7 @@ def test_world1_uniform_weights_power_of_two(g, o, N):
     model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
     a = sharded.pf_initialize(model, (1,), ys[0], N, seed=5)
     b = g.pf_initialize(model, (1,), ys[0], N, seed=5)
-    for method in ("multinomial", "multinomial", "stratified", "residual", "multinomial"):
+    for method in ("multinomial", "multinomial", "stratified", "residual", "multinomial_sorted", "multinomial"):
         sharded.pf_resample(a, method, check=False)
         g.pf_resample(b, method, check=False, **({"sort_particles": False} if method == "stratified" else {}))
         assert np.array_equal(a.local.parents, b.parents), method
@@ -83,6 +83,7 @@ def test_hip_push_overflow_path(g, o, tmp_path, monkeypatch):
     monkeypatch.setenv("GPF_PUSH_CAPACITY", "1000")
     test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[0])
     test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[1])    # stratified: the served slot range is cut at the capacity
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[7])    # sorted multinomial: the same, from a tile boundary below the range
     test_world1_sharded_equals_unsharded(g, o)
 
 
@@ -101,6 +102,18 @@ def test_rccl_collectives_one_rank(g, o, tmp_path, case, engine):
     p = np.load(os.path.join(tmp_path, "rank0.npz"))
     assert np.array_equal(p["parents"], f.parents) and np.array_equal(p["rows"], f.rows) and np.array_equal(p["lw"], f.lw)
     assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
+
+
+@pytest.mark.parametrize("engine", ["library", "python"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sorted_multinomial_many_tiles(g, o, tmp_path, monkeypatch, loopback_lib, world, engine):
+    """more than SP_DIRECT_TILES = 1024 tiles of 2048 global slots (the shape of 8 shards of 10^6): the tiles' starting points come from
+    k_sorted_tiles and k_sorted_plan searches them in place (window around lo / S, 256-ary rounds behind it) instead of scanning the tile
+    totals in LDS; the shard boundaries fall inside tiles"""
+    if engine == "library":
+        monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
+    monkeypatch.setenv("GPF_SHARD_ENGINE", engine)
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, ("lgssm2", "multinomial_sorted", 115_001, 3, None, None), world=world)   # (x 20 inside)
 
 
 @pytest.fixture(scope="module")
@@ -210,7 +223,7 @@ def test_plan_switch_between_resamples(g, o):
 
 
 @pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
-@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
 def test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern):
     """zero-length sends, one shard serving everything (send-buffer overflow and the repeated push) through the library engine"""
     monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
@@ -219,7 +232,7 @@ def test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch
 
 
 @pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
-@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
 def test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern):
     """one shard owns every target (its push exceeds the balanced-size send buffer: the overflow path runs for real),
     the others own none (zero-length sends)"""
@@ -347,7 +360,7 @@ def _tempered_oracle(g, o, method, n_global, T):
 
 @pytest.mark.parametrize("mode", ["mailbox", "rccl"])
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
 def test_sharded_tempered_resample(g, o, tmp_path, monkeypatch, loopback_lib, method, world, mode):
     """priority_fn = w -> alpha w across shards (src/resample.jl:51-52,57,198-200; test/resample.jl:15): ancestors from the
     priorities' global CDF, log-ML from the raw weights, weights from the global logsumexp of log_ws -- three summary rounds and
@@ -376,7 +389,7 @@ def test_sharded_tempered_resample_pull_plan(g, o, tmp_path, monkeypatch, loopba
     assert all(str(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["plan"]) == "pull" for r in range(world))
 
 
-@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
 def test_world1_tempered_equals_unsharded(g, o, method):
     """one shard, no communicator: the tempered sharded resample against the plain device API"""
     from gpf_amd import sharded

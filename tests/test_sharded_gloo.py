@@ -43,6 +43,8 @@ CASES = [
     ("bearings4", "stratified", 1600, 5, 0.6, "move"),       # ESS-triggered stratified + MH: the deferred packed commit is scattered by the move
     ("bearings4", "multinomial", 1200, 4, None, "keep"),     # rows carry x_{t-1} (keep_prev) but nothing rejuvenates: the
                                                              # resampled population goes straight into the next propagate
+    ("lgssm2", "multinomial_sorted", 9001, 5, None, None),   # sorted uniforms across shards: 5 tiles of 2048 global slots, ragged last tile
+    ("sv1", "multinomial_sorted", 2500, 5, None, "reweight"),  # BASELINE config 5 shape with the sorted resampler; shard boundaries inside tiles
 ]
 
 
@@ -80,7 +82,7 @@ def single_skew(g, o, method, n_global, pattern):
 
 
 @pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
-@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual"])
+@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
 def test_sharded_skewed_weights(g, o, tmp_path, method, pattern):
     """shards that own every target (their push overflows the balanced-size send buffer) next to shards that own none"""
     world, n_global = 3, 5000

@@ -1,5 +1,7 @@
-"""Single-GPU timing of the BASELINE.json configs other than the headline one (per-GPU sizes), with per-kernel
-HIP-event times.  Not the driver's bench; numbers go to DESIGN.md / BASELINE table."""
+"""Single-GPU timing of the BASELINE.json configs (per-GPU sizes) with per-kernel HIP-event times, and -- SURVEY 8(d) / BASELINE.md 3 --
+the CPU path timed beside every config: the C oracle (a port of the reference algorithm; the Julia reference cannot run here) on a bounded
+sample of the same loop, single-threaded (the reference is) and on up to 16 OpenMP threads.  Not the driver's bench; numbers go to
+DESIGN.md 7.  `--no-cpu` skips the CPU legs; `--cpu-seconds S` bounds each single-thread leg (default 6 s)."""
 import gc
 import json
 import os
@@ -10,7 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import gpf_amd as g  # noqa: E402
 
+CPU_SECONDS = 6.0          # bound of every single-thread CPU leg (the sample = as many steps of the same loop as fit, at least 3)
+
 CONFIGS = [
+    ("config1 object_motion N=100, ESS<N/2 residual + MH (the README loop, the reference's own CPU-sized case; timed over 200 steps, not T=10)", "object_motion", 100, "residual", {}, "move", 0.5),
     ("config2 lgssm2 multinomial", "lgssm2", 1_000_000, "multinomial", {}, None, None),
     ("config2s lgssm2 multinomial_sorted (opt-in: sorted uniforms)", "lgssm2", 1_000_000, "multinomial_sorted", {}, None, None),
     ("config2l lgssm2 multinomial, lazy search (k_step_search)", "lgssm2", 1_000_000, "multinomial", {"_lazy": True}, None, None),
@@ -22,6 +27,42 @@ CONFIGS = [
     ("config5 sv1 multinomial + move-reweight", "sv1", 2_000_000, "multinomial", {}, "reweight", None),
     ("config5s sv1 multinomial_sorted + move-reweight", "sv1", 2_000_000, "multinomial_sorted", {}, "reweight", None),
 ]
+
+
+def cpu_baseline(model, ys, N, method, kw, rejuv, ess_frac, seconds):
+    """the oracle on the same loop: single thread, then OpenMP; returns the two cpu_baseline objects (bench.py's format)"""
+    from oracle import oracle as o          # the checker as the timed CPU comparator: tools/ only, never the product
+    o.lib()
+    okw = {k: v for k, v in kw.items() if not k.startswith("_")}
+    om = {"multinomial_sorted": "multinomial_sorted"}.get(method, method)
+
+    def loop(threads, budget, max_steps):
+        used = o.set_threads(threads)
+        orc = o.OracleFilter(model.model_id, model.params, N, 1, keep_prev=rejuv is not None).initialize(ys[0])
+        k, c0 = 0, time.perf_counter()
+        while k < max_steps and (k < 3 or time.perf_counter() - c0 < budget):
+            if ess_frac is None or orc.effective_sample_size() < ess_frac * N:
+                orc.resample(om, check=False, **okw)
+                if rejuv:
+                    orc.rejuvenate(rejuv, 1)
+            orc.update(ys[1 + k % (len(ys) - 1)])
+            k += 1
+        ce = time.perf_counter() - c0
+        o.set_threads(1)
+        return used, k, ce
+    u1, k1, c1 = loop(1, seconds, 10_000)
+    if N < 100_000:                      # (a fork-join per primitive at N = 100 measures OpenMP, not the filter)
+        un, kn, cn = u1, k1, c1
+    else:
+        un, kn, cn = loop(min(os.cpu_count() or 1, 16), seconds / 2, k1)
+    one = {"value": round(N * k1 / c1, 1), "unit": "particle-steps/sec", "cores": 1, "kind": "port",
+           "sample": f"same loop, N={N}, first {k1} steps, single-thread C oracle ({c1:.1f} s); reference (Julia) not runnable on this box"}
+    many = {"value": round(N * kn / cn, 1), "unit": "particle-steps/sec", "cores": un, "kind": "port",
+            "sample": f"same loop, first {kn} steps, OpenMP over particles on {un} threads ({cn:.1f} s)"}
+    return one, many
+
+
+NO_CPU = False
 
 
 def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
@@ -66,8 +107,11 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
             per[g._lib.KERNEL_NAMES[k]] = round(ms / cnt * 1e3, 2)
     out = dict(config=name, N=N, steps=steps, us_per_step=round(el / steps * 1e6, 2), particle_steps_per_s=round(N * steps / el, 1),
                resampled_steps=n_res_timed, kernels_us=per, log_ml=g.get_lml_est(st))
-    print(json.dumps(out), flush=True)
     st.close()
+    if not NO_CPU and not kw.get("_lazy"):
+        out["cpu_baseline"], out["cpu_baseline_multithread"] = cpu_baseline(model, ys, N, method, kw, rejuv, ess_frac, CPU_SECONDS)
+        out["gpu_over_cpu_1core"] = round(out["particle_steps_per_s"] / out["cpu_baseline"]["value"], 1)
+    print(json.dumps(out), flush=True)
 
 
 def run_c_host(name, model_name, N, method_id, rejuvenate, ess_frac, steps=200, warm=10):
@@ -92,7 +136,12 @@ def run_c_host(name, model_name, N, method_id, rejuvenate, ess_frac, steps=200, 
 
 
 if __name__ == "__main__":
-    want = sys.argv[1:]                    # e.g. `config4 config5`: only the configs whose name starts with one of these
+    argv = sys.argv[1:]
+    if "--no-cpu" in argv:
+        NO_CPU = True; argv.remove("--no-cpu")
+    if "--cpu-seconds" in argv:
+        i = argv.index("--cpu-seconds"); CPU_SECONDS = float(argv[i + 1]); del argv[i:i + 2]
+    want = argv                            # e.g. `config4 config5`: only the configs whose name starts with one of these
     for c in CONFIGS:
         if not want or any(c[0].startswith(w) for w in want):
             run(*c)

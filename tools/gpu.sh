@@ -2,13 +2,14 @@
 #
 #   gpurun --timeout S -- 'bash tools/gpu.sh STEP [STEP ...]'      steps run in order; every output lands under gpurun_out/
 #
-# steps (TAG = $GPF_TAG, default r04):
+# steps (TAG = $GPF_TAG, default r05):
 #   smoke                 __graft_entry__.smoke()
 #   tests[:EXPR]          pytest -m gpu (optionally -k EXPR) -> gpurun_out/TAG_pytest.log
 #   file:PATH[:EXPR]      pytest -m gpu on one test file
 #   bench[:STEPS]         python bench.py --steps STEPS (default 1000) --warmup 20 -> TAG_bench.json
 #   driver                the driver's own command: python bench.py --gpus 1 --steps 20 --warmup 5 -> TAG_bench_driver_cmd.json
-#   prof                  rocprofv3 --kernel-trace --stats of bench.py (200 steps) -> TAG_kernel_stats.csv
+#   prof                  rocprofv3 --kernel-trace --stats of bench.py --headline-only (200 steps) -> TAG_kernel_stats.csv, and of
+#                         tools/resample_loop.py for every named variant -> TAG_<variant>_kernel_stats.csv
 #   pmc                   FETCH_SIZE / WRITE_SIZE passes of bench.py (one counter per pass) -> TAG_pmc_*.csv (+ tools/pmc_to_json.py TAG)
 #   configs               tools/bench_configs.py (the other BASELINE configs at their per-GPU sizes) -> TAG_configs.jsonl
 #   loop:NAME:ARGS        rocprofv3 kernel stats of `python3 tools/NAME.py ARGS` (ARGS comma-separated) -> TAG_NAME_ARGS_kernel_stats.csv
@@ -18,7 +19,7 @@
 #   variant:OUT:METHOD:DEFS   tools/variant_stats.sh OUT METHOD DEFS (DEFS: comma-separated -D sets, alternating A/B rocprofv3 runs)
 #   py:SCRIPT:ARGS        python3 tools/SCRIPT.py ARGS -> TAG_SCRIPT.txt
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${GPF_TAG:-r04}
+TAG=${GPF_TAG:-r05}
 mkdir -p $R/gpurun_out
 export TMPDIR=/tmp
 stats_of() {   # stats_of DIR OUT: copy the kernel-stats csv of a rocprofv3 output directory
@@ -35,9 +36,16 @@ for STEP in "$@"; do
     file)    timeout 3000 python -m pytest "$A1" -m gpu -x -q ${A2:+-k "$A2"} > gpurun_out/${TAG}_pytest_$(basename $A1 .py).log 2>&1; tail -25 gpurun_out/${TAG}_pytest_$(basename $A1 .py).log | cut -c1-220 ;;
     bench)   python bench.py --steps ${A1:-1000} --warmup 20 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-3000 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err ;;
     driver)  python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_cmd.json 2> gpurun_out/${TAG}_bench_driver_cmd.err; cut -c1-600 gpurun_out/${TAG}_bench_driver_cmd.json ;;
-    prof)    cd /tmp; rm -rf $R/gpurun_out/prof_$TAG
-             rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 200 --warmup 10 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof_$TAG.err
-             stats_of $R/gpurun_out/prof_$TAG $R/gpurun_out/${TAG}_kernel_stats.csv; rm -rf $R/gpurun_out/prof_$TAG ;;
+    prof)    # the headline loop ALONE (k_step<...GATHER> is also launched by the sorted variants: a mixed file misstates its average), then one
+             # stats file per named variant
+             cd /tmp; rm -rf $R/gpurun_out/prof_$TAG
+             rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 200 --warmup 10 --headline-only > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof_$TAG.err
+             stats_of $R/gpurun_out/prof_$TAG $R/gpurun_out/${TAG}_kernel_stats.csv; rm -rf $R/gpurun_out/prof_$TAG
+             for V in multinomial_sorted stratified stratified_sorted residual; do
+               D=$R/gpurun_out/prof_${TAG}_$V; rm -rf $D
+               rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/tools/resample_loop.py $V 200 > $D.log 2>&1
+               stats_of $D $R/gpurun_out/${TAG}_${V}_kernel_stats.csv | head -6; rm -rf $D
+             done ;;
     pmc)     cd /tmp
              for C in FETCH_SIZE WRITE_SIZE; do
                rm -rf $R/gpurun_out/pmc_${TAG}_$C
@@ -56,7 +64,7 @@ for STEP in "$@"; do
              python3 $R/tools/trace_gaps.py $D 0.6 ${A3:-40} > $R/gpurun_out/${TAG}_${A1}_${A2//,/_}_gaps.txt; cat $R/gpurun_out/${TAG}_${A1}_${A2//,/_}_gaps.txt; rm -rf $D ;;
     sq)      LOOP=$A1.py bash $R/tools/gpu_pmc_kernels.sh ${TAG}_sq_${A1}_${A2//,/_} ${A2//,/ } 2>&1 | tail -40 | cut -c1-200 ;;
     sharded) OUT=gpurun_out/${TAG}_sharded_one_rank.txt; : > $OUT
-             for M in multinomial stratified residual; do
+             for M in multinomial stratified residual multinomial_sorted; do
                echo -n "$M, no communicator:      " >> $OUT; python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
                echo -n "$M, 1-rank RCCL, mailbox: " >> $OUT; GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
              done
