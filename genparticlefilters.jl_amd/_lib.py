@@ -38,6 +38,8 @@ SYMBOLS = [
     ("gpf_update", C.c_int, [_H, C.c_void_p, C.c_int32]),          # (const double*: api.py passes the address as an integer)
     ("gpf_initialize_proposal", C.c_int, [_H, _pd, C.c_int32, C.c_int32]),
     ("gpf_update_proposal", C.c_int, [_H, _pd, C.c_int32, C.c_int32]),
+    ("gpf_step_ess", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                               C.POINTER(C.c_int32), C.POINTER(C.c_int32), _pd]),
     ("gpf_initialize_strata", C.c_int, [_H, _pd, C.c_int32, _pd, C.c_int32, C.c_int32]),
     ("gpf_update_strata", C.c_int, [_H, _pd, C.c_int32, _pd, C.c_int32, C.c_int32]),
     ("gpf_initialize_strata_proposal", C.c_int, [_H, _pd, C.c_int32, _pd, C.c_int32, C.c_int32, C.c_int32]),

@@ -344,6 +344,37 @@ def pf_update(state: DeviceParticleFilterState, new_args: tuple, argdiffs: tuple
     return state
 
 
+def pf_step_ess(state: DeviceParticleFilterState, new_args: tuple, argdiffs: tuple, observations, *, ess_threshold: float = 0.5,
+                method: str = "multinomial", rejuvenate=None, n_iters: int = 1, check="warn", sort_particles: bool = True) -> bool:
+    """One iteration of the reference's README loop (README.md:66-77) in ONE call (gpf.h gpf_step_ess):
+
+        if effective_sample_size(state) < ess_threshold * n_particles
+            pf_resample!(state, method; check, sort_particles)
+            pf_rejuvenate!(state, kern, (), n_iters; method = rejuvenate)      # rejuvenate: None | "move" | "reweight"
+        end
+        pf_update!(state, new_args, argdiffs, observations)
+
+    The results are those of the separate calls, bit for bit; the steps that do not resample do not wait for the host's ESS decision
+    (the propagate is enqueued speculatively behind the reduction, which leaves its verdict on the device).  Returns whether it resampled."""
+    if method not in RESAMPLE_METHODS:
+        raise ErrorException(f"Resampling method {method} not recognized.")
+    if rejuvenate is not None and rejuvenate not in REJUVENATE_METHODS:
+        raise ErrorException(f"Method {rejuvenate} not recognized.")
+    if check not in (True, False, "warn"):
+        raise ValueError("check must be True, 'warn' or False")
+    check_id = 2 if check is True else (1 if check == "warn" else 0)
+    obs = _obs_vector(observations)
+    res, inv = C.c_int32(0), C.c_int32(0)
+    st = state._L.gpf_step_ess(state._h, obs.ctypes.data, obs.size, float(ess_threshold), RESAMPLE_METHODS[method], int(sort_particles), check_id,
+                               -1 if rejuvenate is None else REJUVENATE_METHODS[rejuvenate], int(n_iters), C.byref(res),
+                               C.byref(inv) if check_id != 0 else None, None)
+    if st != _lib.OK:
+        raise ErrorException(state._L.gpf_last_error(state._h).decode())
+    if check == "warn" and inv.value:
+        warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")   # utils.jl:120-135
+    return bool(res.value)
+
+
 def _resample(state, method_id: int, priority_fn, check, sort_particles: bool):
     if check not in (True, False, "warn"):
         raise ValueError("check must be True, 'warn' or False")

@@ -53,7 +53,7 @@ struct Scalars {
     uint64_t Rs;               // residual: sum of residual weights
     uint64_t n_accept;         // accepted MH moves of the last gpf_rejuvenate
     int32_t  timeout;          // set if a bounded inter-workgroup spin gave up (never expected)
-    int32_t  pad;
+    int32_t  gate_go;          // gpf_step_ess: 1 = the ESS fell below the threshold (k_sum_host<GATE>); the speculative propagate behind it returns at once
     long long opt_d;           // optimal resize: threshold position in the descending order (-1: none)
     uint64_t opt_a, opt_B;     // optimal resize: inverse weight threshold c = a S / B as the exact pair (a, B)
     HeadGiants giants;         // residual: cells with >= GIANT_COPIES copies of the current resample

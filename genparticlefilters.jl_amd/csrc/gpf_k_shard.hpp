@@ -607,11 +607,12 @@ static __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan
 // workgroups of its weight scan), so every shard can place every tile -- mulhi(vlo[t], S) ascends in t -- and, with the spacings of ONE
 // tile, every slot of it.  Workgroup h of this kernel finds F[h]: the first tile whose END reaches lo_h (the tiles below it lie entirely
 // below lo_h), then that tile's 2048 targets exactly as k_search_strat<true> forms them, and the number of them below lo_h.  The workgroup
-// that arrives last turns F into the plan and the exchange counts (as k_strat_plan).  Up to SP_DIRECT_TILES tiles every workgroup scans the
-// tile totals itself (workgroup 0 leaves vlo[] behind for the merge kernel); beyond, k_sorted_tiles has run and vlo[] is searched in place.
+// that arrives last turns F into the plan and the exchange counts (as k_strat_plan).  One workgroup per INTERIOR boundary (F[0] = 0 and
+// F[G] = N need no search; one shard: one workgroup, no search, no arrival).  Up to SP_DIRECT_TILES tiles every workgroup scans the tile
+// totals itself (the merge kernel does the same for its own tile); beyond, k_sorted_tiles has run and vlo[] is searched in place.
 struct SortedPlanJob {
     const uint64_t* g;            // [ntl] gamma totals of the GLOBAL tiles
-    uint64_t* vlo;                // [ntl + 1] where every tile starts among the sorted 64-bit uniforms: read (have_vlo) or written by workgroup 0
+    const uint64_t* vlo;          // have_vlo: [ntl + 1] where every tile starts among the sorted 64-bit uniforms (k_sorted_tiles)
     int64_t ntl; int have_vlo;
     int64_t* F;                   // [MAX_SHARDS + 1] first slot served by every shard (scratch between the workgroups)
     unsigned int* arrive;         // arrival counter, zero between launches
@@ -661,7 +662,7 @@ static __global__ __launch_bounds__(MBLOCK) void k_sorted_plan(PushArgs a, Shard
     __shared__ int64_t s_F[MAX_SHARDS + 1];
     __shared__ uint64_t s_eN;
     __shared__ int s_last;
-    const int h = (int)blockIdx.x, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int h = a.G > 1 ? (int)blockIdx.x + 1 : 0, tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();   // the workgroup's boundary (interior; one shard: none)
     const uint64_t N = (uint64_t)a.n_global;
     uint64_t S = 0, lo = 0, lo_me = 0;
     mbox_wait_block(a.wait_tot);
@@ -672,7 +673,7 @@ static __global__ __launch_bounds__(MBLOCK) void k_sorted_plan(PushArgs a, Shard
         S += v;
     }
     const int64_t ntl = jb.ntl;
-    if (!jb.have_vlo) {
+    if (!jb.have_vlo && a.G > 1) {
         // vlo[t] = floor((g_0 + ... + g_{t-1}) 2^64 / (sum g + 1)) for every tile (k_sorted_tiles' arithmetic): thread i owns consecutive tiles
         const int64_t per = (ntl + MBLOCK - 1) / MBLOCK;
         const int64_t t0 = (int64_t)tid * per, t1 = t0 + per < ntl ? t0 + per : ntl;
@@ -686,12 +687,10 @@ static __global__ __launch_bounds__(MBLOCK) void k_sorted_plan(PushArgs a, Shard
         for (int w = 0; w < NWAVES; ++w) { run += w < wv ? s_w[w] : 0; tot += s_w[w]; }
         const Div128 dv = div128_setup(tot + 1);
         for (int64_t t = t0; t < t1; ++t) {
-            const uint64_t v = div128(run, dv);
-            s_v[t] = v;
-            if (h == 0) jb.vlo[t] = v;
+            s_v[t] = div128(run, dv);
             run += jb.g[t];
         }
-        if (tid == 0) { const uint64_t v = div128(tot, dv); s_v[ntl] = v; if (h == 0) jb.vlo[ntl] = v; }
+        if (tid == 0) s_v[ntl] = div128(tot, dv);
         __syncthreads();
     }
     const uint64_t* const V = jb.have_vlo ? jb.vlo : s_v;
@@ -738,14 +737,16 @@ static __global__ __launch_bounds__(MBLOCK) void k_sorted_plan(PushArgs a, Shard
         }
     }
     // ---- the last workgroup to arrive turns the boundaries into the plan
-    if (tid == 0) {
-        __hip_atomic_store(jb.F + h, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned int old = __hip_atomic_fetch_add(jb.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == gridDim.x - 1 ? 1 : 0;
+    if (gridDim.x > 1) {
+        if (tid == 0) {
+            __hip_atomic_store(jb.F + h, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int old = __hip_atomic_fetch_add(jb.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == gridDim.x - 1 ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_last) return;
     }
-    __syncthreads();
-    if (!s_last) return;
-    if (tid <= a.G) s_F[tid] = __hip_atomic_load(jb.F + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid <= a.G) s_F[tid] = tid == 0 ? 0 : (tid == a.G ? (int64_t)N : (gridDim.x > 1 ? __hip_atomic_load(jb.F + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : f));
     __syncthreads();
     const int q = tid;
     if (q < a.G) {
@@ -764,7 +765,7 @@ static __global__ __launch_bounds__(MBLOCK) void k_sorted_plan(PushArgs a, Shard
         plan->ws.S = S; plan->ws.sB = S / N; plan->ws.srem = S % N; plan->ws.sinv = (double)N / (double)S;
         plan->first = s_F[a.me]; plan->count = s_F[a.me + 1] - s_F[a.me]; plan->t_off = lo_me;
         plan->n_shards = a.G;
-        __hip_atomic_store(jb.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gridDim.x > 1) __hip_atomic_store(jb.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (q <= a.G) plan->bounds[q] = a.bounds[q];
     __syncthreads();

@@ -149,6 +149,9 @@ struct PackedCommit {
     // the log-ML update from the gathered summaries
     int masked; int64_t anc_off;
     const int64_t* own_range;  // masked == 2 (stratified): the own hits are the slots [own_range[0], own_range[1]) instead of the slots with anc >= 0
+    // a propagate enqueued SPECULATIVELY behind the ESS gate (gpf_step_ess, k_sum_host<GATE>): set = the filter resamples first, this launch
+    // must not touch the state -- it returns before its first store
+    const int32_t* abort_if;
 };
 template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false, bool BLK = false>
 __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
 {
     using Mo = Model<M>;
     constexpr int D = Mo::D;
+    if (pc.abort_if && *pc.abort_if) return;                // (kernel-uniform: a scalar load)
     double bm = -__builtin_huge_val(); int bf = 0;
     if constexpr (PACKED || GATHER) {
         if (pc.sc && pc.mf_all && blockIdx.x == 0 && threadIdx.x == 0) {

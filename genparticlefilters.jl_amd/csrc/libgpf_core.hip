@@ -67,7 +67,7 @@ gpf_status alloc_particle_buffers(gpf_filter* h)
 
 // PROP 0: the model's own sampler; 1: native custom proposal; 2: stratified
 template <int M, bool KEEP, int PROP = 0>
-void launch_step_t(gpf_filter* h, int grid)
+void launch_step_t(gpf_filter* h, int grid, const int32_t* abort_if = nullptr)
 {
     constexpr int Wc = row_width(Model<M>::D, KEEP);
     if constexpr ((PROP == 1 && !Model<M>::HAS_PROPOSAL) || (PROP == 2 && !Model<M>::HAS_STRATA)) { (void)h; (void)grid; return; }
@@ -111,9 +111,12 @@ void launch_step_t(gpf_filter* h, int grid)
         GPF_LAUNCH((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pc);
     }
-    else
+    else {
+        PackedCommit pc{};
+        pc.abort_if = abort_if;                                      // (gpf_step_ess: a speculative propagate behind the ESS gate)
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
-                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, next_slots(h), PackedCommit{});
+                           h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, next_slots(h), pc);
+    }
 }
 template <int M, int PROP = 0>
 void launch_init_t(gpf_filter* h, int grid)
@@ -532,6 +535,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->h_spart) hipHostFree(h->h_spart);
     if (h->sp_g) { (void)hipFree(h->sp_g); (void)hipFree(h->sp_vlo); }
     if (h->splan_F) { (void)hipFree(h->splan_F); (void)hipFree(h->splan_arrive); }
+    if (h->gate_part) { (void)hipFree(h->gate_part); (void)hipFree(h->gate_arrive); hipHostFree(h->h_gate); }
     if (h->sum_part) (void)hipFree(h->sum_part);
     for (int k = 0; k < gpf_filter::BLK_STAGE; ++k) if (h->h_blk_obs[k]) hipHostFree(h->h_blk_obs[k]);
     if (h->h_blk_done) hipHostFree(h->h_blk_done);
@@ -674,6 +678,84 @@ gpf_status gpf_update_proposal(gpf_handle h, const double* obs, int32_t n_obs, i
 {
     if (!proposal_matches(h, proposal)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown proposal id for this model");
     return update_impl(h, obs, n_obs, 1);
+}
+
+// One iteration of the reference's README loop (README.md:66-77) in one call:
+//     if effective_sample_size(state) < ess_frac * N;  pf_resample!(state, method);  pf_rejuvenate!(state, kern, ...);  end
+//     pf_update!(state, new_args, argdiffs, observations)
+// The results are those of the four calls in that order, bit for bit (the fall-back below IS that sequence).  What the single call buys is
+// the host's round trip: the ESS reduction leaves its verdict on the device as well (k_sum_host<GATE>), the propagate is enqueued
+// SPECULATIVELY right behind it and returns at once if the verdict says "resample first" -- so on the steps that do not resample (the
+// majority of an ESS-triggered filter's) the GPU never waits for the host's decision; on the others the host, which folds the same sums,
+// enqueues resample -> move -> propagate as before.
+gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double ess_frac, int32_t resample_method, int32_t sort_particles,
+                        int32_t check, int32_t rejuvenate_method, int32_t n_iters, int32_t* resampled, int32_t* invalid, double* ess_out)
+{
+    gpf_status s = check_ready(h);
+    if (s) return s;
+    if (!(ess_frac == ess_frac) || ess_frac < 0.0) return fail(h, GPF_ERR_INVALID_ARGUMENT, "ess_frac must be >= 0");
+    if (rejuvenate_method >= 0 && rejuvenate_method != GPF_REJUVENATE_MOVE && rejuvenate_method != GPF_REJUVENATE_REWEIGHT)
+        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Method not recognized.");                        // rejuvenate.jl:25
+    if (resample_method != GPF_RESAMPLE_MULTINOMIAL && resample_method != GPF_RESAMPLE_RESIDUAL && resample_method != GPF_RESAMPLE_STRATIFIED &&
+        resample_method != GPF_RESAMPLE_MULTINOMIAL_SORTED)
+        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");             // resample.jl:28
+    if (rejuvenate_method >= 0 && !h->cfg.keep_prev) return fail(h, GPF_ERR_STATE, "gpf_rejuvenate needs keep_prev = 1 (x_{t-1} must travel with the particle)");
+    if (resampled) *resampled = 0;
+    if (invalid) *invalid = 0;
+    const double thr = ess_frac * (double)h->n;
+    static const bool spec_off = getenv("GPF_STEP_SPECULATE") && !strcmp(getenv("GPF_STEP_SPECULATE"), "0");   // (A/B measurements, tests: the plain sequence)
+    const bool fast = !spec_off && !h->parent && !h->hist_on && h->cfg.n_global == h->n && !h->pending_packed && !h->pending_gather && !h->pending_fill &&
+                      !h->pending_search && !h->raw_valid && !h->raw_sum_valid && h->blk_obs_size == 0 && sum_host_ok(h) &&
+                      n_obs == model_obs_dim(h->cfg.model) && obs != nullptr;
+    if (!fast) {
+        // the host-decided sequence (sub-states, shards, trajectory stores, a resample still pending, summaries already at hand, ...)
+        double ess = 0.0;
+        if ((s = gpf_effective_sample_size(h, &ess))) return s;
+        if (ess_out) *ess_out = ess;
+        if (ess < thr) {
+            if ((s = gpf_resample(h, resample_method, std::nan(""), sort_particles, check, invalid))) return s;
+            if (resampled) *resampled = 1;
+            if (rejuvenate_method >= 0 && (s = gpf_rejuvenate(h, rejuvenate_method, n_iters, nullptr))) return s;
+        }
+        return gpf_update(h, obs, n_obs);
+    }
+    // ---- ESS reduction with the verdict on the device, the propagate speculatively behind it
+    const ModelArgs old_args = h->args;                          // (a rejuvenation moves under the CURRENT step's observation)
+    if ((s = sum_host_launch(h, &thr))) return s;
+    if ((s = set_obs(h, obs, n_obs))) { h->args = old_args; return s; }
+    const int grid = step_grid(h);
+    const bool keep = h->cfg.keep_prev != 0;
+    s = timed(h, GPF_K_STEP, [&] {
+        if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true>(h, grid, &h->sc->gate_go))); }
+        else      { DISPATCH_MODEL(h, (launch_step_t<MM, false>(h, grid, &h->sc->gate_go))); }
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    int go = 0;
+    if ((s = sum_host_fold(h, &thr, &go))) return s;
+    if (ess_out) {
+        uint64_t hi, lo;
+        normalise_Q(h->sum_cache, hi, lo);
+        *ess_out = h->sum_cache.flags ? std::nan("") : ess_from(h->sum_cache.S, hi, lo);
+    }
+    if (!go) {
+        // the speculative propagate WAS the step's pf_update! (update_impl's bookkeeping)
+        h->max_valid = true;
+        h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
+        h->epoch += 1;
+        h->has_prev = true;
+        h->raw_valid = false; h->raw_sum_valid = false;
+        mutated(h);
+        return GPF_OK;
+    }
+    // the propagate returned without touching anything: take its maximum slots back, restore the step's observation, and run the sequence
+    // from the resample on -- the summary is with the host as after effective_sample_size(state) (a :residual resample skips its weight scan)
+    h->mcur ^= 1;
+    h->args = old_args;
+    if ((s = gpf_resample(h, resample_method, std::nan(""), sort_particles, check, invalid))) return s;
+    if (resampled) *resampled = 1;
+    if (rejuvenate_method >= 0 && (s = gpf_rejuvenate(h, rejuvenate_method, n_iters, nullptr))) return s;
+    return gpf_update(h, obs, n_obs);
 }
 
 // stratified initialisation / update: the strata are values of the model's discrete latent

@@ -179,53 +179,10 @@ gpf_status ensure_raw_summary(gpf_filter* h, bool want_q, bool* done)
     static const bool device_fold = getenv("GPF_SUM_REDUCE") && !strcmp(getenv("GPF_SUM_REDUCE"), "device");
     const int hgrid = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + SH_TILE - 1) / SH_TILE, (int64_t)h->n_cu));
     if (!device_fold && (h->n + hgrid - 1) / hgrid <= (int64_t)Q_TAG_MAX_TILES * TILE) {
+        (void)hgrid;
         // every workgroup's partial sums go straight to pinned memory; this thread adds them up
-        if (!h->h_spart) {
-            HIP_TRY(h, hipHostMalloc(&h->h_spart, (size_t)8 * h->n_cu * sizeof(int64_t)));
-            memset(h->h_spart, 0, (size_t)8 * h->n_cu * sizeof(int64_t));
-        }
-        if ((s = ensure_max(h, raw_view(h), true))) return s;
-        h->q_ticket += 1;
-        InFixQ in{raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
-        s = timed(h, GPF_K_SCAN, [&] {
-            GPF_LAUNCH(k_sum_host, dim3(hgrid), dim3(SH_BLOCK), 0, h->stream, in, h->n, h->mslots[h->mcur], h->h_spart, h->q_ticket);
-        });
-        if (s) return s;
-        HIP_TRY(h, hipGetLastError());
-        const uint64_t tag = (uint64_t)((h->q_ticket & 0x7fff) + 1);
-        uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint64_t flags_m[3] = {0, 0, 0};
-        for (int b = 0; b < hgrid; ++b) {
-            volatile int64_t* line = h->h_spart + (size_t)b * 8;
-            uint64_t v[8];
-            for (int k = 0; k < 8; ++k) {
-                uint64_t spins = 0;
-                while (((v[k] = (uint64_t)__atomic_load_n(line + k, __ATOMIC_ACQUIRE)) >> 48) != tag) {
-                    cpu_relax();
-                    if ((++spins & 0x3fff) != 0) continue;
-                    const hipError_t q = hipStreamQuery(h->stream);
-                    if (q == hipErrorNotReady) continue;
-                    if (((uint64_t)__atomic_load_n(line + k, __ATOMIC_ACQUIRE) >> 48) == tag) continue;
-                    return fail(h, GPF_ERR_HIP, q == hipSuccess ? "weight summary: the stream drained without the partial sums being published" : hipGetErrorString(q));
-                }
-                v[k] &= 0xffffffffffffull;
-            }
-            // the consumed line goes back to zero (tag 0 is never valid): the 15-bit tag alone cannot tell this launch's words from those of a
-            // launch 32768 tickets earlier (q_ticket is shared with the ESS scan and k_sum_reduce; the grid changes with a resize)
-            for (int k = 0; k < 8; ++k) __atomic_store_n(const_cast<int64_t*>(line + k), (int64_t)0, __ATOMIC_RELAXED);
-            t[0] += v[0]; t[1] += v[1] & 0xffffffffffull;             // (S can be 2^62 itself: the high part takes 32 bits; the flags sit above bit 40)
-            for (int k = 2; k < 6; ++k) t[k] += v[k];
-            if (b == 0) { flags_m[0] = v[1] >> 40; flags_m[1] = v[6]; flags_m[2] = v[7]; }
-        }
-        WSum w{};
-        w.flags = (int32_t)flags_m[0];
-        w.S = t[0] + (t[1] << 31);
-        for (int k = 0; k < 4; ++k) w.Ql[k] = t[2 + k];
-        const uint64_t mb = flags_m[1] | (flags_m[2] << 32);
-        memcpy(&w.m, &mb, sizeof(double));
-        h->sum_cache = w;                                        // (sc->raw on the device is NOT updated: the getters read this copy)
-        h->sum_on_host = true;
-        h->raw_sum_valid = true;
+        if ((s = sum_host_launch(h, nullptr))) return s;
+        if ((s = sum_host_fold(h, nullptr))) return s;
         *done = true;
         return GPF_OK;
     }
@@ -251,6 +208,104 @@ gpf_status ensure_raw_summary(gpf_filter* h, bool want_q, bool* done)
     h->sum_on_host = false;
     h->raw_sum_valid = true;
     *done = true;
+    return GPF_OK;
+}
+
+// k_sum_host: the raw weights' {maximum, flags, S, sum q^2} with the HOST as the folder.  sum_host_launch enqueues it, sum_host_fold waits for
+// this launch's lines and leaves the summary in h->sum_cache (sum_on_host, raw_sum_valid).  thr != nullptr (gpf_step_ess): the gated
+// form -- the last workgroup also folds on the device and leaves the verdict ESS < *thr in sc->gate_go for the launch behind it; the fold
+// then returns that verdict too (after cross-checking it against the host's own).
+bool sum_host_ok(const gpf_filter* h)
+{
+    static const bool off = getenv("GPF_SUM_REDUCE") && (!strcmp(getenv("GPF_SUM_REDUCE"), "0") || !strcmp(getenv("GPF_SUM_REDUCE"), "device"));
+    const int hgrid = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + SH_TILE - 1) / SH_TILE, (int64_t)h->n_cu));
+    return !off && (h->n + hgrid - 1) / hgrid <= (int64_t)Q_TAG_MAX_TILES * TILE && h->n_cu <= SH_BLOCK;
+}
+gpf_status sum_host_launch(gpf_filter* h, const double* thr)
+{
+    gpf_status s;
+    const int hgrid = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + SH_TILE - 1) / SH_TILE, (int64_t)h->n_cu));
+    if (!h->h_spart) {
+        HIP_TRY(h, hipHostMalloc(&h->h_spart, (size_t)8 * h->n_cu * sizeof(int64_t)));
+        memset(h->h_spart, 0, (size_t)8 * h->n_cu * sizeof(int64_t));
+    }
+    if (thr && !h->gate_part) {
+        HIP_TRY(h, hipMalloc(&h->gate_part, (size_t)8 * h->n_cu * sizeof(uint64_t)));
+        HIP_TRY(h, hipMemsetAsync(h->gate_part, 0, (size_t)8 * h->n_cu * sizeof(uint64_t), h->stream));
+        HIP_TRY(h, hipMalloc(&h->gate_arrive, sizeof(unsigned int)));
+        HIP_TRY(h, hipMemsetAsync(h->gate_arrive, 0, sizeof(unsigned int), h->stream));
+        HIP_TRY(h, hipHostMalloc(&h->h_gate, sizeof(int64_t)));
+        *h->h_gate = 0;
+    }
+    if ((s = ensure_max(h, raw_view(h), true))) return s;
+    h->q_ticket += 1;
+    InFixQ in{raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
+    s = timed(h, GPF_K_SCAN, [&] {
+        if (thr) GPF_LAUNCH(k_sum_host<true>, dim3(hgrid), dim3(SH_BLOCK), 0, h->stream, in, h->n, h->mslots[h->mcur], h->h_spart, h->q_ticket,
+                            SumGate{h->gate_part, h->gate_arrive, &h->sc->gate_go, h->h_gate, *thr, h->h_timeout});
+        else     GPF_LAUNCH(k_sum_host<false>, dim3(hgrid), dim3(SH_BLOCK), 0, h->stream, in, h->n, h->mslots[h->mcur], h->h_spart, h->q_ticket, SumGate{});
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+gpf_status sum_host_fold(gpf_filter* h, const double* thr, int* go_out)
+{
+    const int hgrid = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + SH_TILE - 1) / SH_TILE, (int64_t)h->n_cu));
+    const uint64_t tag = (uint64_t)((h->q_ticket & 0x7fff) + 1);
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t flags_m[3] = {0, 0, 0};
+    for (int b = 0; b < hgrid; ++b) {
+        volatile int64_t* line = h->h_spart + (size_t)b * 8;
+        uint64_t v[8];
+        for (int k = 0; k < 8; ++k) {
+            uint64_t spins = 0;
+            while (((v[k] = (uint64_t)__atomic_load_n(line + k, __ATOMIC_ACQUIRE)) >> 48) != tag) {
+                cpu_relax();
+                if ((++spins & 0x3fff) != 0) continue;
+                const hipError_t q = hipStreamQuery(h->stream);
+                if (q == hipErrorNotReady) continue;
+                if (((uint64_t)__atomic_load_n(line + k, __ATOMIC_ACQUIRE) >> 48) == tag) continue;
+                return fail(h, GPF_ERR_HIP, q == hipSuccess ? "weight summary: the stream drained without the partial sums being published" : hipGetErrorString(q));
+            }
+            v[k] &= 0xffffffffffffull;
+        }
+        // the consumed line goes back to zero (tag 0 is never valid): the 15-bit tag alone cannot tell this launch's words from those of a
+        // launch 32768 tickets earlier (q_ticket is shared with the ESS scan and k_sum_reduce; the grid changes with a resize)
+        for (int k = 0; k < 8; ++k) __atomic_store_n(line + k, (int64_t)0, __ATOMIC_RELAXED);
+        t[0] += v[0]; t[1] += v[1] & 0xffffffffffull;             // (S can be 2^62 itself: the high part takes 32 bits; the flags sit above bit 40)
+        for (int k = 2; k < 6; ++k) t[k] += v[k];
+        if (b == 0) { flags_m[0] = v[1] >> 40; flags_m[1] = v[6]; flags_m[2] = v[7]; }
+    }
+    WSum w{};
+    w.flags = (int32_t)flags_m[0];
+    w.S = t[0] + (t[1] << 31);
+    for (int k = 0; k < 4; ++k) w.Ql[k] = t[2 + k];
+    const uint64_t mb = flags_m[1] | (flags_m[2] << 32);
+    memcpy(&w.m, &mb, sizeof(double));
+    h->sum_cache = w;                                        // (sc->raw on the device is NOT updated: the getters read this copy)
+    h->sum_on_host = true;
+    h->raw_sum_valid = true;
+    if (thr) {
+        // the device's verdict (the launch behind the gate acts on THAT one): ticket << 1 | go in pinned memory, a few microseconds behind the lines
+        gpf_status s;
+        uint64_t spins = 0;
+        int64_t gv;
+        while (((gv = __atomic_load_n(h->h_gate, __ATOMIC_ACQUIRE)) >> 1) != h->q_ticket) {
+            cpu_relax();
+            if ((++spins & 0x3fff) != 0) continue;
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipErrorNotReady) continue;
+            if ((__atomic_load_n(h->h_gate, __ATOMIC_ACQUIRE) >> 1) == h->q_ticket) continue;
+            return fail(h, GPF_ERR_HIP, q == hipSuccess ? "ESS gate: the stream drained without the verdict being published" : hipGetErrorString(q));
+        }
+        if ((s = check_scan_timeout(h))) return s;
+        uint64_t hi, lo;
+        normalise_Q(w, hi, lo);
+        const int host_go = !w.flags && ess_from(w.S, hi, lo) < *thr ? 1 : 0;
+        if (host_go != (int)(gv & 1)) return fail(h, GPF_ERR_HIP, "ESS gate: the device's verdict differs from the host's (state may be inconsistent)");
+        if (go_out) *go_out = host_go;
+    }
     return GPF_OK;
 }
 

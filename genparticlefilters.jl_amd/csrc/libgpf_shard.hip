@@ -198,7 +198,7 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
         h->push_ticket += 1;
         a.ticket = h->push_ticket;
         const SortedPlanJob job{h->sp_g, h->sp_vlo, ntl, ntl > SP_DIRECT_TILES ? 1 : 0, h->splan_F, h->splan_arrive};
-        s = timed(h, GPF_K_SEARCH, [&] { GPF_LAUNCH(k_sorted_plan, dim3((unsigned)(G + 1)), dim3(MBLOCK), 0, h->stream, a, h->shard_plan, job); });
+        s = timed(h, GPF_K_SEARCH, [&] { GPF_LAUNCH(k_sorted_plan, dim3((unsigned)(G > 1 ? G - 1 : 1)), dim3(MBLOCK), 0, h->stream, a, h->shard_plan, job); });
         if (s) return s;
         HIP_TRY(h, hipGetLastError());
         h->counts_published = true;
@@ -302,7 +302,10 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
         sa.K = h->K; sa.logN = h->logN; sa.anc = nullptr; sa.invN = 1.0 / (double)h->cfg.n_global;
         sa.update_lml = 0;                                            // the commit carries the log-ML update
         sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W, h->push_extra, h->push_pv, h->own_direct ? h->anc : nullptr, (int)me};
-        if (su) { sa.sp_g = nullptr; sa.sp_vlo = h->sp_vlo; }         // (k_sorted_plan / k_sorted_tiles left every GLOBAL tile's start there)
+        if (su) {                                                     // the GLOBAL tiles: their totals, or (many tiles) their starting points from k_sorted_tiles
+            const bool many = (h->cfg.n_global + SP_TILE - 1) / SP_TILE > SP_DIRECT_TILES;
+            sa.sp_g = many ? nullptr : h->sp_g; sa.sp_vlo = many ? h->sp_vlo : nullptr;
+        }
         s = timed(h, GPF_K_GATHER, [&] {
             // (sorted uniforms: the launch starts at the tile boundary below the first served slot -- up to one tile of slots more)
             launch_search_strat(h, sa, su ? cap + SP_TILE : cap, su);

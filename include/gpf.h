@@ -99,6 +99,18 @@ gpf_status gpf_initialize(gpf_handle h, const double* obs, int32_t n_obs);
  * x_t ~ p(. | x_{t-1}), log_weights[i] += log p(obs | x_t); buffers swap (update_refs!, src/utils.jl:10-15). */
 gpf_status gpf_update(gpf_handle h, const double* obs, int32_t n_obs);
 
+/* One iteration of the reference's README loop (README.md:66-77) in one call:
+ *     if effective_sample_size(state) < ess_frac * N   (src/utils.jl:163-164)
+ *         pf_resample!(state, resample_method; check, sort_particles)          (src/resample.jl:19-30)
+ *         pf_rejuvenate!(state, kern, (), n_iters; method = rejuvenate_method)  (src/rejuvenate.jl:18-27; rejuvenate_method < 0: none)
+ *     end
+ *     pf_update!(state, new_args, argdiffs, observations)                       (src/update.jl:12-25)
+ * Same results as the four calls in that order, bit for bit.  The ESS verdict is also formed on the device and the propagate is
+ * enqueued speculatively behind it, so the steps that do not resample never wait for the host's decision.
+ * resampled / invalid / ess_out may be NULL. */
+gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double ess_frac, int32_t resample_method, int32_t sort_particles,
+                        int32_t check, int32_t rejuvenate_method, int32_t n_iters, int32_t* resampled, int32_t* invalid, double* ess_out);
+
 /* pf_initialize(model, args, obs, proposal, proposal_args, n)        src/initialize.jl:46-62
  * pf_update!(state, new_args, argdiffs, obs, proposal, proposal_args) src/update.jl:79-96 (+ src/translate.jl:86-105)
  * with a NATIVE proposal: new latents x ~ q(. | x_{t-1}, y_t); log_weights[i] += [log p(x | x_{t-1}) + log p(y | x)] - log q(x).

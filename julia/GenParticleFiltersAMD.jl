@@ -138,6 +138,29 @@ function _resample!(state, method::Int, priority_fn, check_kw, sort_particles::B
     return state
 end
 
+"""
+    pf_step_ess!(state, new_args, argdiffs, observations; ess_threshold=0.5, method=:multinomial, rejuvenate=nothing, n_iters=1, check=:warn, sort_particles=true)
+
+One iteration of the README loop (README.md:66-77) in one ccall (gpf.h gpf_step_ess): `if effective_sample_size(state) < ess_threshold * N;
+pf_resample!(state, method); pf_rejuvenate!(state, ...; method=rejuvenate); end; pf_update!(state, new_args, argdiffs, observations)` -- the
+same results, without the host's round trip on the steps that do not resample.  Returns whether it resampled.
+"""
+function pf_step_ess!(s::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Vector{Float64}; ess_threshold::Real=0.5,
+                      method::Symbol=:multinomial, rejuvenate::Union{Nothing,Symbol}=nothing, n_iters::Int=1, check=:warn, sort_particles::Bool=true)
+    mid = method == :multinomial ? 0 : method == :residual ? 1 : method == :stratified ? 2 : method == :multinomial_sorted ? 4 : error("Resampling method $method not recognized.")
+    rid = rejuvenate === nothing ? -1 : rejuvenate == :move ? 0 : rejuvenate == :reweight ? 1 : error("Method $rejuvenate not recognized.")
+    chk = check === true ? 2 : (check === :warn ? 1 : 0)
+    resampled = Ref{Cint}(0); invalid = Ref{Cint}(0)
+    GC.@preserve resampled invalid begin
+        st = ccall((:gpf_step_ess, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Cint, Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}),
+                   s.handle, observations, length(observations), Float64(ess_threshold), mid, sort_particles, chk, rid, n_iters,
+                   Base.unsafe_convert(Ptr{Cint}, resampled), chk == 0 ? Ptr{Cint}(C_NULL) : Base.unsafe_convert(Ptr{Cint}, invalid), Ptr{Cdouble}(C_NULL))
+    end
+    _status(s, st)
+    check === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
+    return resampled[] != 0
+end
+
 "opt-in: pf_resample!(state, :multinomial) leaves its ancestor search to the pf_update! that follows (one fused kernel; gpf.h gpf_set_lazy_search)"
 set_lazy_search!(s::DeviceParticleFilterState, enable::Bool=true) =
     (_status(s, ccall((:gpf_set_lazy_search, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, enable ? 1 : 0)); s)

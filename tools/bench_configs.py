@@ -24,6 +24,7 @@ CONFIGS = [
     ("bearings4 stratified(sorted) (weights beyond the coarse key's range every step)", "bearings4", 1_000_000, "stratified", {"sort_particles": True}, None, None),
     ("lgssm2 residual", "lgssm2", 1_000_000, "residual", {}, None, None),
     ("config4 bearings4 ESS<N/2 residual + MH [1 of 4 shards' worth]", "bearings4", 1_000_000, "residual", {}, "move", 0.5),
+    ("config4g the same loop, one pf_step_ess call per step (gpf_step_ess: verdict on the device, speculative propagate)", "bearings4", 1_000_000, "residual", {"_step_ess": True}, "move", 0.5),
     ("config5 sv1 multinomial + move-reweight", "sv1", 2_000_000, "multinomial", {}, "reweight", None),
     ("config5s sv1 multinomial_sorted + move-reweight", "sv1", 2_000_000, "multinomial_sorted", {}, "reweight", None),
 ]
@@ -70,12 +71,17 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
     ys = g.models.simulate(model, steps + warm + 1)
     st = g.pf_initialize(model, (1,), ys[0], N, seed=1, keep_prev=rejuv is not None)
     kw = dict(kw)
-    if kw.pop("_lazy", False):
+    lazy = kw.pop("_lazy", False)
+    if lazy:
         st.set_lazy_search(True)
     n_res = 0
+    gated = kw.pop("_step_ess", False)
 
     def step(t):
         nonlocal n_res
+        if gated:
+            n_res += g.pf_step_ess(st, (t + 1,), (None,), ys[t], ess_threshold=ess_frac, method=method, rejuvenate=rejuv, check=False, **kw)
+            return
         if ess_frac is None or g.get_ess(st) < ess_frac * N:
             n_res += 1
             g.pf_resample(st, method, check=False, **kw)
@@ -108,7 +114,7 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
     out = dict(config=name, N=N, steps=steps, us_per_step=round(el / steps * 1e6, 2), particle_steps_per_s=round(N * steps / el, 1),
                resampled_steps=n_res_timed, kernels_us=per, log_ml=g.get_lml_est(st))
     st.close()
-    if not NO_CPU and not kw.get("_lazy"):
+    if not NO_CPU and not lazy and not gated:
         out["cpu_baseline"], out["cpu_baseline_multithread"] = cpu_baseline(model, ys, N, method, kw, rejuv, ess_frac, CPU_SECONDS)
         out["gpu_over_cpu_1core"] = round(out["particle_steps_per_s"] / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out), flush=True)
