@@ -32,7 +32,7 @@
 int main(int argc, char** argv)
 {
     gpf_handle h = NULL;
-    if (argc < 6) { fprintf(stderr, "usage: %s input.txt n_particles seed method ess_fraction\n", argv[0]); return 2; }
+    if (argc < 6) { fprintf(stderr, "usage: %s input.txt n_particles seed method ess_fraction [rejuvenate [timed_from [one_call]]]\n", argv[0]); return 2; }
     FILE* f = fopen(argv[1], "r");
     if (!f) { perror(argv[1]); return 2; }
     int model, n_params, obs_dim, T;
@@ -49,6 +49,7 @@ int main(int argc, char** argv)
     const double ess_fraction = atof(argv[5]);
     const int rejuvenate = argc > 6 ? atoi(argv[6]) : 0;
     const int timed_from = argc > 7 ? atoi(argv[7]) : 0;
+    const int one_call = argc > 8 ? atoi(argv[8]) : 0;     /* 1: the loop body as ONE call (gpf_step_ess) instead of the four below -- same results */
 
     gpf_config cfg = {0};
     cfg.abi_version = GPF_ABI_VERSION;
@@ -64,6 +65,14 @@ int main(int argc, char** argv)
     for (int t = 1; t < T; ++t) {
         double ess;
         if (t == timed_from) { CHECK(gpf_synchronize(h)); clock_gettime(CLOCK_MONOTONIC, &t0); }
+        if (one_call) {
+            /* if effective_sample_size(state) < tau N; pf_resample!; pf_rejuvenate!; end; pf_update!  (README.md:66-77) */
+            int32_t res = 0;
+            CHECK(gpf_step_ess(h, ys + (size_t)t * obs_dim, obs_dim, ess_fraction, method, 0, GPF_CHECK_FALSE,
+                               rejuvenate ? (rejuvenate == 2 ? GPF_REJUVENATE_REWEIGHT : GPF_REJUVENATE_MOVE) : -1, 1, &res, NULL, NULL));
+            n_resamples += res;
+            continue;
+        }
         CHECK(gpf_effective_sample_size(h, &ess));                           /* get_ess, src/utils.jl:171 */
         if (ess < ess_fraction * (double)n) {
             /* pf_resample!(state, method), src/resample.jl:19-30; sort_particles = false, check = :warn without the print */

@@ -87,7 +87,7 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     uint64_t* sum_part = nullptr;  // [6][workgroups] tagged partials of k_sum_reduce
     int64_t* h_spart = nullptr;    // pinned: [n_cu][8] tagged partials of k_sum_host, folded by the host
     bool sum_on_host = false;      // sum_cache came from k_sum_host: it holds m too, and sc->raw on the device was NOT updated
-    uint64_t* gate_part = nullptr; unsigned int* gate_arrive = nullptr; int64_t* h_gate = nullptr;   // gpf_step_ess: device partials + arrival counter of k_sum_host<GATE>, pinned {ticket << 1 | verdict}
+    uint64_t* gate_part = nullptr; int gate_cur = 0; int64_t* h_gate = nullptr;   // gpf_step_ess: two sets of k_sum_host<GATE>'s accumulator lines (gate_verdict), pinned {ticket << 1 | verdict} of the launch that read them
     bool raw_has_q = false;        // the raw summary's scan also accumulated sum q^2 (blockQ)
     bool raw_q_folded = false;     // sc->raw.Ql folded from blockQ
     bool pending_gather = false;   // a resample left (rows[cur], anc) un-gathered; log-weights are 0
@@ -367,6 +367,7 @@ gpf_status read_published_summary(gpf_filter* h, WSum& w);
 bool sum_host_ok(const gpf_filter* h);
 gpf_status sum_host_launch(gpf_filter* h, const double* thr);
 gpf_status sum_host_fold(gpf_filter* h, const double* thr, int* go_out = nullptr);
+gpf_status sum_gate_check(gpf_filter* h, int host_go);
 gpf_status wait_ticket(gpf_filter* h, volatile int64_t* tk, int64_t want, const char* what);
 gpf_status check_scan_timeout(gpf_filter* h);
 gpf_status fetch_scalars(gpf_filter* h, bool fold_raw_q = false);

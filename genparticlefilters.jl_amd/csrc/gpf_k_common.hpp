@@ -273,4 +273,29 @@ __device__ __forceinline__ void sorted_gamma_tile(const SortedGammaJob& j, int64
     j.g[t] = gamma_tile(j.seed, (uint32_t)(j.gid0 + first), j.epoch, cnt + (t == j.ntl - 1 ? 1 : 0), j.Eg);
 }
 
+// gpf_step_ess: k_sum_host<GATE> adds every workgroup's partial sums into one of GATE_SLOTS accumulator lines (fire-and-forget device
+// atomics: slot = workgroup & 7, words {S, flags, Q limb 0..3, -, -}); the propagate enqueued speculatively behind it reads the 64 words
+// with ONE load per lane (lane = slot * 8 + word), adds the slots up with three butterfly steps and forms the verdict ESS = S^2 / Q < thr
+// with the host's own arithmetic (normalise_Q + ess_from: the same IEEE operations, the same result; invalid weights: the ESS is NaN, NaN <
+// thr is false).  Every wave for itself, all lanes converged, no LDS, no barrier.  Measured alternatives (profiles/r05_step_ess.txt): a fold
+// by k_sum_host's last-arriving workgroup (+6 us on the reduction), a fold of per-workgroup lines by every workgroup of the propagate
+// through LDS (+3.5 us on the propagate), by every wave (12 loads per lane: +10 us).
+constexpr int GATE_SLOTS = 8, GATE_WORDS = GATE_SLOTS * 8;
+struct GateIn { const uint64_t* acc; double thr; int32_t* go_dev; int64_t* h_gate; int64_t ticket; };
+__device__ __forceinline__ bool gate_verdict(const GateIn& g)
+{
+    static_assert(GATE_WORDS == WAVE, "one accumulator word per lane");
+    uint64_t v = g.acc[lane_id()];
+    v += shfl_xor_u64(v, 8); v += shfl_xor_u64(v, 16); v += shfl_xor_u64(v, 32);      // (flags: a sum of ORs -- zero iff no flag anywhere)
+    const uint64_t S = shfl_u64(v, 0), fl = shfl_u64(v, 1), q0 = shfl_u64(v, 2), q1 = shfl_u64(v, 3), q2 = shfl_u64(v, 4), q3 = shfl_u64(v, 5);
+    const uint64_t lo = q0 + (q1 << 32);                                        // Q = sum of the limb sums << 32 k (Q <= S^2 < 2^124)
+    const uint64_t hi = (q1 >> 32) + q2 + (q3 << 32) + (lo < q0 ? 1u : 0u);
+    const bool go = fl == 0 && ess_from(S, hi, lo) < g.thr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *g.go_dev = go ? 1 : 0;
+        __hip_atomic_store(g.h_gate, (int64_t)((g.ticket << 1) | (go ? 1 : 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return go;
+}
+
 } // namespace gpf

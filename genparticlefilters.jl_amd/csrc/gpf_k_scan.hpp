@@ -495,11 +495,9 @@ static __global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int
 //   line b: {S low 31 bits, S high bits | flags << 40, Q limb 0..3, maximum low / high 32 bits}, each (tag << 48) | value
 constexpr int SH_BLOCK = 1024, SH_NWAVES = SH_BLOCK / WAVE, SH_ROWS = 2, SH_TILE = SH_BLOCK * 2 * SH_ROWS;      // 4096 weights per workgroup and trip: 245 workgroups at 10^6, every CU busy
 // GATE (gpf_step_ess: the README loop's `if effective_sample_size(state) < threshold`, README.md:68, decided where the next launch can see
-// it): the same tagged words also go to device memory, the workgroup that arrives LAST folds them (no waiting workgroup: whoever finds the
-// arrival counter at grid - 1 is the folder; a word whose tag is not this launch's yet is re-read), evaluates ESS = S^2 / Q < thr with the
-// host's own arithmetic (ess_from) and leaves the verdict in *go -- the propagate launched speculatively behind this kernel returns at once
-// if it is set -- and, ticketed, in pinned memory.  The host folds its lines as before and does not wait for the device's fold.
-struct SumGate { uint64_t* part; unsigned int* arrive; int32_t* go; int64_t* h_gate; double thr; int32_t* timeout; };
+// it): every workgroup also adds its partial sums into one of GATE_SLOTS accumulator lines in device memory (gate_verdict, gpf_k_common.hpp);
+// the launch's first workgroup clears the accumulators of the NEXT gated reduction (two sets alternate).
+struct SumGate { uint64_t* acc; uint64_t* acc_next; };
 template <bool GATE>
 __global__ __launch_bounds__(SH_BLOCK) void k_sum_host(InFixQ in, int64_t n, const unsigned long long* __restrict__ slots, int64_t* __restrict__ h_part, int64_t q_ticket, SumGate gt)
 {
@@ -548,49 +546,18 @@ __global__ __launch_bounds__(SH_BLOCK) void k_sum_host(InFixQ in, int64_t n, con
             for (int w = 0; w < SH_NWAVES; ++w) v += s_p[w][t - 1];
         } else v = t == 6 ? (d2u(m) & 0xffffffffull) : (d2u(m) >> 32);
         __hip_atomic_store(h_part + (int64_t)blockIdx.x * 8 + t, (int64_t)(tag | v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if constexpr (GATE) { if (t < 6) __hip_atomic_store(gt.part + (int64_t)blockIdx.x * 8 + t, tag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    }
-    if constexpr (GATE) {
-        __shared__ int s_last;
-        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(gt.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
-        __syncthreads();
-        if (!s_last) return;
-        const uint64_t tag = (uint64_t)((q_ticket & 0x7fff) + 1);
-        uint64_t q[6] = {0, 0, 0, 0, 0, 0};
-        if (threadIdx.x < gridDim.x) {                              // (grid <= n_cu <= SH_BLOCK workgroups: one line per thread)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                uint64_t v = __hip_atomic_load(gt.part + (int64_t)threadIdx.x * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                while ((v >> 48) != tag) {                         // (the stores and the arrival are unordered: a line may trail its workgroup's arrival)
-                    __builtin_amdgcn_s_sleep(1);
-                    v = __hip_atomic_load(gt.part + (int64_t)threadIdx.x * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (++spins > SPIN_LIMIT) { *gt.timeout = 1; break; }
-                }
-                q[k] = v & 0xffffffffffffull;
-            }
-            q[1] &= 0xffffffffffull;                                // (the flags sit above bit 40 of the high half of S)
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) q[k] = wave_sum_u64(q[k]);
-        __shared__ uint64_t s_g[SH_NWAVES][6];
-        if (lane == 0) { for (int k = 0; k < 6; ++k) s_g[wv][k] = q[k]; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-            for (int w = 0; w < SH_NWAVES; ++w) for (int k = 0; k < 6; ++k) t[k] += s_g[w][k];
-            const uint64_t S = t[0] + (t[1] << 31);
-            // Q = sum of the limb sums << 32 k (as normalise_Q on the host; Q <= S^2 < 2^124)
-            const uint64_t lo = t[2] + (t[3] << 32);
-            const uint64_t hi = (t[3] >> 32) + t[4] + (t[5] << 32) + (lo < t[2] ? 1u : 0u);
-            const int go = !f && ess_from(S, hi, lo) < gt.thr ? 1 : 0;      // (invalid weights: the ESS is NaN, NaN < thr is false)
-            *gt.go = go;
-            __hip_atomic_store(gt.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(gt.h_gate, (int64_t)((q_ticket << 1) | go), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if constexpr (GATE) {
+            uint64_t* const slot = gt.acc + (blockIdx.x & (GATE_SLOTS - 1)) * 8;
+            if (t == 0) {
+                uint64_t S = 0;
+                for (int w = 0; w < SH_NWAVES; ++w) S += s_p[w][0];
+                (void)__hip_atomic_fetch_add(slot + 0, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (t == 1) { if (f) (void)__hip_atomic_fetch_or(slot + 1, (uint64_t)(uint32_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else if (t < 6) (void)__hip_atomic_fetch_add(slot + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if constexpr (GATE) { if (blockIdx.x == 0 && threadIdx.x >= WAVE && threadIdx.x < WAVE + GATE_WORDS) gt.acc_next[threadIdx.x - WAVE] = 0; }
 }
-
 // Residual resampling needs TWO prefix sums over the same elements: the copy counts c_i = (N q_i) div S and the
 // residual weights r_i = ((N q_i) mod S) >> sh (resample.jl:99,109).  One pass computes both: one read of the weight CDF,
 // ONE 64-bit division per element (quotient and remainder), two descriptor channels polled in the same round trip.

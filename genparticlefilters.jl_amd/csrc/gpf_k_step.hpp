@@ -149,12 +149,12 @@ struct PackedCommit {
     // the log-ML update from the gathered summaries
     int masked; int64_t anc_off;
     const int64_t* own_range;  // masked == 2 (stratified): the own hits are the slots [own_range[0], own_range[1]) instead of the slots with anc >= 0
-    // a propagate enqueued SPECULATIVELY behind the ESS gate (gpf_step_ess, k_sum_host<GATE>): set = the filter resamples first, this launch
-    // must not touch the state -- it returns before its first store
-    const int32_t* abort_if;
+    // a propagate enqueued SPECULATIVELY behind the ESS reduction (gpf_step_ess, k_sum_host<GATE>): it forms the verdict from the reduction's
+    // accumulators itself (gate_verdict) and, if the ESS is below the threshold -- the filter resamples first --, returns before its first store
+    GateIn gate;
 };
 template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false, bool BLK = false>
-__global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
+__global__ __launch_bounds__(BLOCK, 4) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
                                                 double* __restrict__ rows_out, double* __restrict__ lw,
@@ -162,7 +162,11 @@ __global__ __launch_bounds__(BLOCK) void k_step(ModelArgs a, uint64_t seed, uint
 {
     using Mo = Model<M>;
     constexpr int D = Mo::D;
-    if (pc.abort_if && *pc.abort_if) return;                // (kernel-uniform: a scalar load)
+    // a speculative propagate behind the ESS reduction (gpf_step_ess): every wave forms the verdict from the reduction's accumulators and
+    // returns before its first store if the filter resamples first (kernel-uniform)
+#ifndef GPF_NO_GATE
+    if constexpr (!GATHER && !PACKED) { if (pc.gate.acc && gate_verdict(pc.gate)) return; }
+#endif
     double bm = -__builtin_huge_val(); int bf = 0;
     if constexpr (PACKED || GATHER) {
         if (pc.sc && pc.mf_all && blockIdx.x == 0 && threadIdx.x == 0) {

@@ -67,7 +67,7 @@ gpf_status alloc_particle_buffers(gpf_filter* h)
 
 // PROP 0: the model's own sampler; 1: native custom proposal; 2: stratified
 template <int M, bool KEEP, int PROP = 0>
-void launch_step_t(gpf_filter* h, int grid, const int32_t* abort_if = nullptr)
+void launch_step_t(gpf_filter* h, int grid, const GateIn* gate = nullptr)
 {
     constexpr int Wc = row_width(Model<M>::D, KEEP);
     if constexpr ((PROP == 1 && !Model<M>::HAS_PROPOSAL) || (PROP == 2 && !Model<M>::HAS_STRATA)) { (void)h; (void)grid; return; }
@@ -113,7 +113,7 @@ void launch_step_t(gpf_filter* h, int grid, const int32_t* abort_if = nullptr)
     }
     else {
         PackedCommit pc{};
-        pc.abort_if = abort_if;                                      // (gpf_step_ess: a speculative propagate behind the ESS gate)
+        if (gate) pc.gate = *gate;                                   // (gpf_step_ess: a speculative propagate behind the ESS reduction)
         GPF_LAUNCH((k_step<M, Wc, KEEP, false, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, next_slots(h), pc);
     }
@@ -535,7 +535,7 @@ gpf_status gpf_destroy(gpf_handle h)
     if (h->h_spart) hipHostFree(h->h_spart);
     if (h->sp_g) { (void)hipFree(h->sp_g); (void)hipFree(h->sp_vlo); }
     if (h->splan_F) { (void)hipFree(h->splan_F); (void)hipFree(h->splan_arrive); }
-    if (h->gate_part) { (void)hipFree(h->gate_part); (void)hipFree(h->gate_arrive); hipHostFree(h->h_gate); }
+    if (h->gate_part) { (void)hipFree(h->gate_part); hipHostFree(h->h_gate); }
     if (h->sum_part) (void)hipFree(h->sum_part);
     for (int k = 0; k < gpf_filter::BLK_STAGE; ++k) if (h->h_blk_obs[k]) hipHostFree(h->h_blk_obs[k]);
     if (h->h_blk_done) hipHostFree(h->h_blk_done);
@@ -725,9 +725,10 @@ gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double e
     if ((s = set_obs(h, obs, n_obs))) { h->args = old_args; return s; }
     const int grid = step_grid(h);
     const bool keep = h->cfg.keep_prev != 0;
+    const GateIn gate{h->gate_part + h->gate_cur * GATE_WORDS, thr, &h->sc->gate_go, h->h_gate, h->q_ticket};
     s = timed(h, GPF_K_STEP, [&] {
-        if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true>(h, grid, &h->sc->gate_go))); }
-        else      { DISPATCH_MODEL(h, (launch_step_t<MM, false>(h, grid, &h->sc->gate_go))); }
+        if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true>(h, grid, &gate))); }
+        else      { DISPATCH_MODEL(h, (launch_step_t<MM, false>(h, grid, &gate))); }
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
@@ -746,7 +747,7 @@ gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double e
         h->has_prev = true;
         h->raw_valid = false; h->raw_sum_valid = false;
         mutated(h);
-        return GPF_OK;
+        return sum_gate_check(h, go);
     }
     // the propagate returned without touching anything: take its maximum slots back, restore the step's observation, and run the sequence
     // from the resample on -- the summary is with the host as after effective_sample_size(state) (a :residual resample skips its weight scan)
@@ -755,7 +756,8 @@ gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double e
     if ((s = gpf_resample(h, resample_method, std::nan(""), sort_particles, check, invalid))) return s;
     if (resampled) *resampled = 1;
     if (rejuvenate_method >= 0 && (s = gpf_rejuvenate(h, rejuvenate_method, n_iters, nullptr))) return s;
-    return gpf_update(h, obs, n_obs);
+    if ((s = gpf_update(h, obs, n_obs))) return s;
+    return sum_gate_check(h, go);                                // (after the sequence is enqueued: the check is a safety net, not a dependency)
 }
 
 // stratified initialisation / update: the strata are values of the model's discrete latent

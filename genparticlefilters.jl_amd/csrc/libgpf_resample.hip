@@ -219,7 +219,7 @@ bool sum_host_ok(const gpf_filter* h)
 {
     static const bool off = getenv("GPF_SUM_REDUCE") && (!strcmp(getenv("GPF_SUM_REDUCE"), "0") || !strcmp(getenv("GPF_SUM_REDUCE"), "device"));
     const int hgrid = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + SH_TILE - 1) / SH_TILE, (int64_t)h->n_cu));
-    return !off && (h->n + hgrid - 1) / hgrid <= (int64_t)Q_TAG_MAX_TILES * TILE && h->n_cu <= SH_BLOCK;
+    return !off && (h->n + hgrid - 1) / hgrid <= (int64_t)Q_TAG_MAX_TILES * TILE && true;
 }
 gpf_status sum_host_launch(gpf_filter* h, const double* thr)
 {
@@ -229,21 +229,20 @@ gpf_status sum_host_launch(gpf_filter* h, const double* thr)
         HIP_TRY(h, hipHostMalloc(&h->h_spart, (size_t)8 * h->n_cu * sizeof(int64_t)));
         memset(h->h_spart, 0, (size_t)8 * h->n_cu * sizeof(int64_t));
     }
-    if (thr && !h->gate_part) {
-        HIP_TRY(h, hipMalloc(&h->gate_part, (size_t)8 * h->n_cu * sizeof(uint64_t)));
-        HIP_TRY(h, hipMemsetAsync(h->gate_part, 0, (size_t)8 * h->n_cu * sizeof(uint64_t), h->stream));
-        HIP_TRY(h, hipMalloc(&h->gate_arrive, sizeof(unsigned int)));
-        HIP_TRY(h, hipMemsetAsync(h->gate_arrive, 0, sizeof(unsigned int), h->stream));
+    if (thr && !h->gate_part) {                                  // two sets of accumulators, used in turn: every gated reduction clears the other set
+        HIP_TRY(h, hipMalloc(&h->gate_part, (size_t)2 * GATE_WORDS * sizeof(uint64_t)));
+        HIP_TRY(h, hipMemsetAsync(h->gate_part, 0, (size_t)2 * GATE_WORDS * sizeof(uint64_t), h->stream));
         HIP_TRY(h, hipHostMalloc(&h->h_gate, sizeof(int64_t)));
         *h->h_gate = 0;
+        h->gate_cur = 0;
     }
+    if (thr) h->gate_cur ^= 1;
     if ((s = ensure_max(h, raw_view(h), true))) return s;
     h->q_ticket += 1;
     InFixQ in{raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
     s = timed(h, GPF_K_SCAN, [&] {
-        if (thr) GPF_LAUNCH(k_sum_host<true>, dim3(hgrid), dim3(SH_BLOCK), 0, h->stream, in, h->n, h->mslots[h->mcur], h->h_spart, h->q_ticket,
-                            SumGate{h->gate_part, h->gate_arrive, &h->sc->gate_go, h->h_gate, *thr, h->h_timeout});
-        else     GPF_LAUNCH(k_sum_host<false>, dim3(hgrid), dim3(SH_BLOCK), 0, h->stream, in, h->n, h->mslots[h->mcur], h->h_spart, h->q_ticket, SumGate{});
+        if (thr) GPF_LAUNCH(k_sum_host<true>, dim3(hgrid), dim3(SH_BLOCK), 0, h->stream, in, h->n, h->mslots[h->mcur], h->h_spart, h->q_ticket, SumGate{h->gate_part + h->gate_cur * GATE_WORDS, h->gate_part + (1 - h->gate_cur) * GATE_WORDS});
+        else     GPF_LAUNCH(k_sum_host<false>, dim3(hgrid), dim3(SH_BLOCK), 0, h->stream, in, h->n, h->mslots[h->mcur], h->h_spart, h->q_ticket, SumGate{nullptr, nullptr});
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
@@ -287,7 +286,17 @@ gpf_status sum_host_fold(gpf_filter* h, const double* thr, int* go_out)
     h->sum_on_host = true;
     h->raw_sum_valid = true;
     if (thr) {
-        // the device's verdict (the launch behind the gate acts on THAT one): ticket << 1 | go in pinned memory, a few microseconds behind the lines
+        uint64_t hi, lo;
+        normalise_Q(w, hi, lo);
+        if (go_out) *go_out = !w.flags && ess_from(w.S, hi, lo) < *thr ? 1 : 0;
+    }
+    return GPF_OK;
+}
+// the verdict the speculative propagate acted on (gate_verdict: ticket << 1 | go in pinned memory, published by its first workgroup) against
+// the host's: the same sums through the same operations -- a difference means the two sides of the call went different ways
+gpf_status sum_gate_check(gpf_filter* h, int host_go)
+{
+    {
         gpf_status s;
         uint64_t spins = 0;
         int64_t gv;
@@ -300,11 +309,7 @@ gpf_status sum_host_fold(gpf_filter* h, const double* thr, int* go_out)
             return fail(h, GPF_ERR_HIP, q == hipSuccess ? "ESS gate: the stream drained without the verdict being published" : hipGetErrorString(q));
         }
         if ((s = check_scan_timeout(h))) return s;
-        uint64_t hi, lo;
-        normalise_Q(w, hi, lo);
-        const int host_go = !w.flags && ess_from(w.S, hi, lo) < *thr ? 1 : 0;
         if (host_go != (int)(gv & 1)) return fail(h, GPF_ERR_HIP, "ESS gate: the device's verdict differs from the host's (state may be inconsistent)");
-        if (go_out) *go_out = host_go;
     }
     return GPF_OK;
 }

@@ -38,6 +38,9 @@ def test_c_example_equals_python_host(g, tmp_path, name, method, ess_fraction, r
         f.write(f"{model.model_id} {model.params.size}\n" + " ".join(repr(float(v)) for v in model.params) + "\n")
         f.write(f"{ys.shape[1]} {T}\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in ys) + "\n")
     lines = subprocess.check_output([exe, inp, str(N), str(seed), str(method), str(ess_fraction), str(rejuv), "3"], text=True).splitlines()
+    # the loop body as ONE gpf_step_ess call per step (README.md:66-77): the same numbers
+    one = subprocess.check_output([exe, inp, str(N), str(seed), str(method), str(ess_fraction), str(rejuv), "3", "1"], text=True).splitlines()
+    assert one[0] == lines[0]
     out = lines[0].split()
     assert lines[1].split()[0] == "us_per_step" and float(lines[1].split()[1]) > 0.0
     lml, ess, mean0, var0, n_res = float(out[0]), float(out[1]), float(out[2]), float(out[3]), int(out[4])

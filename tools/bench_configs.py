@@ -120,7 +120,7 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
     print(json.dumps(out), flush=True)
 
 
-def run_c_host(name, model_name, N, method_id, rejuvenate, ess_frac, steps=200, warm=10):
+def run_c_host(name, model_name, N, method_id, rejuvenate, ess_frac, steps=200, warm=10, one_call=0):
     """the same ESS-triggered loop from the compiled host (examples/lgssm_filter.c over the C ABI): what the loop costs without the
     Python wrappers on the critical path between the ESS read and the next launch -- the drop-in's host is Julia (ccall), not Python"""
     import subprocess
@@ -135,7 +135,7 @@ def run_c_host(name, model_name, N, method_id, rejuvenate, ess_frac, steps=200, 
     with open(inp, "w") as f:
         f.write(f"{model.model_id} {model.params.size}\n" + " ".join(repr(float(v)) for v in model.params) + "\n")
         f.write(f"{ys.shape[1]} {ys.shape[0]}\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in ys) + "\n")
-    out = subprocess.check_output([exe, inp, str(N), "1", str(method_id), str(ess_frac), str(rejuvenate), str(warm + 1)], text=True).splitlines()
+    out = subprocess.check_output([exe, inp, str(N), "1", str(method_id), str(ess_frac), str(rejuvenate), str(warm + 1), str(one_call)], text=True).splitlines()
     first = out[0].split(); us = float(out[1].split()[1])
     print(json.dumps(dict(config=name, N=N, steps=steps, us_per_step=round(us, 2), particle_steps_per_s=round(N / us * 1e6, 1),
                           resampled_steps_incl_warmup=int(first[4]), warmup=warm, log_ml=float(first[0]))), flush=True)
@@ -151,5 +151,7 @@ if __name__ == "__main__":
     for c in CONFIGS:
         if not want or any(c[0].startswith(w) for w in want):
             run(*c)
-            if c[0].startswith("config4"):
+            if c[0].startswith("config4 "):
                 run_c_host("config4, the same loop from a compiled host (examples/lgssm_filter.c)", "bearings4", c[2], 1, 1, 0.5)
+            if c[0].startswith("config4g"):
+                run_c_host("config4g from the compiled host: one gpf_step_ess call per step", "bearings4", c[2], 1, 1, 0.5, one_call=1)
