@@ -54,6 +54,7 @@ SYMBOLS = [
     ("gpf_resample_with_priorities", C.c_int, [_H, C.c_int32, _pd, C.c_int32, C.c_int32, _pi32]),
     ("gpf_rejuvenate", C.c_int, [_H, C.c_int32, C.c_int32, _pu64]),
     ("gpf_rejuvenate_proposal", C.c_int, [_H, C.c_int32, _pd, C.c_int32, C.c_int32]),
+    ("gpf_rejuvenate_with_proposal", C.c_int, [_H, C.c_int32, C.c_int32, _pd, C.c_int32, C.c_int32, _pu64]),
     ("gpf_effective_sample_size", C.c_int, [_H, _pd]),
     ("gpf_log_ml_estimate", C.c_int, [_H, _pd]),
     ("gpf_get_log_weights", C.c_int, [_H, _pd, C.c_int64]),

@@ -536,9 +536,20 @@ def _rejuvenate(state, method_id: int, n_iters: int, want_count: bool):
 
 
 def pf_move_accept(state, kern=mh, kern_args: tuple = (), n_iters: int = 1, *, count: bool = False):
-    """src/rejuvenate.jl:40-53 with the native mh kernel"""
+    """src/rejuvenate.jl:40-53 with the native mh kernel; kern_args = () -> Gen.mh(trace, selection) on the current step's latent,
+    kern_args = (proposal[, proposal_args]) with a MoveProposal -> Gen.mh(trace, proposal, proposal_args): accept iff
+    log(rand()) < weight - fwd_score + bwd_score"""
     if kern is not mh:
         raise ErrorException("device states support the native `mh` kernel only (arbitrary Julia/Python callables are out of scope)")
+    if kern_args and isinstance(kern_args[0], MoveProposal):
+        mp = kern_args[0]
+        q = np.asarray(mp.params, np.float64)
+        acc = C.c_uint64(0)
+        st = state._L.gpf_rejuvenate_with_proposal(state._h, 0, mp.proposal_id, _pd(q) if q.size else None, int(q.size), int(n_iters),
+                                                   C.byref(acc) if count else None)
+        state._check(st)
+        state.n_accepted = acc.value if count else None
+        return state
     return _rejuvenate(state, 0, n_iters, count)
 
 

@@ -268,8 +268,10 @@ static __global__ void k_sum_accepts(const unsigned long long* __restrict__ part
     __syncthreads();
     if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < NWAVES; ++w) t += s_a[w]; *out = t; }
 }
-// PROP (with REWEIGHT): move_reweight(trace, proposal, proposal_args) (rejuvenate.jl:134-148) with the model's native move proposal
-// (Model::move_propose): the new latent comes from the proposal, rel_weight = weight - fwd_score + bwd_score.
+// PROP: the model's native move proposal (Model::move_propose): the new latent comes from the proposal, alpha = weight - fwd_score +
+// bwd_score.  With REWEIGHT: move_reweight(trace, proposal, proposal_args) (rejuvenate.jl:134-148), every proposal is taken and alpha is the
+// relative weight; without: Gen.mh(trace, proposal, proposal_args) under pf_move_accept! (rejuvenate.jl:40-53) -- accept iff log(rand()) <
+// alpha, the weights stay (the uniform: block NBLK behind the proposal's, tag MOVE, as in the selection variant).
 // BLK: block-wise (ModelArgs::blk_*): the observation of the particle's block; blocks whose mask bit is clear keep their particles
 template <int M, int W, bool REWEIGHT, bool GATHER = false, bool PROP = false, bool BLK = false>
 __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
@@ -313,12 +315,21 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
         const uint32_t gid = particle_gid(a, gid0, i);
         for (int it = 0; it < iters; ++it) {
             if constexpr (PROP) {
-                if constexpr (Mo::HAS_MOVE_PROPOSAL) {
+                if constexpr (Mo::HAS_MOVE_PROPOSAL && REWEIGHT) {
                     const double rw = Mo::move_propose(a.P, a.q, !has_prev, xp, x, ob, seed, gid, (uint32_t)(it * NB), epoch, TAG_REWEIGHT, xs);
                     wsum = wsum + rw;                                          // rejuvenate.jl:86
 #pragma unroll
                     for (int k = 0; k < D; ++k) x[k] = xs[k];
                     ++acc;
+                } else if constexpr (Mo::HAS_MOVE_PROPOSAL) {
+                    const uint32_t blk0 = (uint32_t)(it * (NB + 1));
+                    const double alpha = Mo::move_propose(a.P, a.q, !has_prev, xp, x, ob, seed, gid, blk0, epoch, TAG_MOVE, xs);
+                    const Philox b = rng(seed, gid, blk0 + NB, epoch, TAG_MOVE);
+                    if (log_(u52(b.w0, b.w1)) < alpha) {                       // Gen.mh: accept iff log(rand()) < weight - fwd_score + bwd_score
+#pragma unroll
+                        for (int k = 0; k < D; ++k) x[k] = xs[k];
+                        ++acc;
+                    }
                 }
             } else if (REWEIGHT) {
                 Mo::sample(a.P, !has_prev, xp, ob, seed, gid, (uint32_t)(it * NB), epoch, TAG_REWEIGHT, xs);

@@ -148,19 +148,19 @@ bool model_has_strata(int model)
     }
     return false;
 }
-template <int M>
+template <int M, bool RW>
 void launch_move_prop_t(gpf_filter* h, int grid, int n_iters)
 {
     constexpr int Wc = row_width(Model<M>::D, true);
     if constexpr (!Model<M>::HAS_MOVE_PROPOSAL) { (void)h; (void)grid; (void)n_iters; return; }
     else if (h->pending_gather)
-        GPF_LAUNCH((k_move<M, Wc, true, true, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+        GPF_LAUNCH((k_move<M, Wc, RW, true, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                           h->acc_part, next_slots(h));
+                           h->acc_part, RW ? next_slots(h) : MaxSlots{nullptr, nullptr});
     else
-        GPF_LAUNCH((k_move<M, Wc, true, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+        GPF_LAUNCH((k_move<M, Wc, RW, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, (int)h->has_prev, n_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw,
-                           h->acc_part, next_slots(h));
+                           h->acc_part, RW ? next_slots(h) : MaxSlots{nullptr, nullptr});
 }
 bool model_has_move_proposal(int model)
 {
@@ -796,13 +796,17 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
 }
 gpf_status gpf_rejuvenate_proposal(gpf_handle h, int32_t proposal, const double* params, int32_t n_params, int32_t n_iters)
 {
+    return gpf_rejuvenate_with_proposal(h, GPF_REJUVENATE_REWEIGHT, proposal, params, n_params, n_iters, nullptr);
+}
+gpf_status gpf_rejuvenate_with_proposal(gpf_handle h, int32_t method, int32_t proposal, const double* params, int32_t n_params, int32_t n_iters, uint64_t* n_accepted)
+{
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (n_params < 0 || n_params > 4 || (n_params > 0 && !params)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad proposal parameters");
     const bool ok = (proposal == GPF_MOVE_PROPOSAL_LOCALLY_OPTIMAL && h->cfg.model == MODEL_LGSSM2 && n_params == 0) ||
                     (proposal == GPF_MOVE_PROPOSAL_LINE_OUTLIER && h->cfg.model == MODEL_LINE && n_params == 3);
     if (!ok || !model_has_move_proposal(h->cfg.model)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "unknown move proposal for this model (or wrong parameter count)");
     for (int i = 0; i < 4; ++i) h->args.q[i] = i < n_params ? params[i] : 0.0;
-    return rejuvenate_impl(h, GPF_REJUVENATE_REWEIGHT, n_iters, nullptr, true);
+    return rejuvenate_impl(h, method, n_iters, n_accepted, true);
 }
 static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters, uint64_t* n_accepted, bool with_proposal)
 {
@@ -833,7 +837,8 @@ static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters,
     const bool fused_gather = h->pending_gather;                 // a pending resample gather rides on the move kernel
     const int grid = move_grid(h);
     s = timed(h, GPF_K_MOVE, [&] {
-        if (with_proposal)                          { DISPATCH_MODEL(h, (launch_move_prop_t<MM>(h, grid, n_iters))); }
+        if (with_proposal && method == GPF_REJUVENATE_REWEIGHT) { DISPATCH_MODEL(h, (launch_move_prop_t<MM, true>(h, grid, n_iters))); }
+        else if (with_proposal)                     { DISPATCH_MODEL(h, (launch_move_prop_t<MM, false>(h, grid, n_iters))); }
         else if (method == GPF_REJUVENATE_REWEIGHT) { DISPATCH_MODEL(h, (launch_move_t<MM, true>(h, grid, n_iters, h->args, h->epoch))); }
         else                                        { DISPATCH_MODEL(h, (launch_move_t<MM, false>(h, grid, n_iters, h->args, h->epoch))); }
     });

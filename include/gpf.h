@@ -216,6 +216,12 @@ gpf_status gpf_rejuvenate(gpf_handle h, int32_t method, int32_t n_iters, uint64_
  * Requires keep_prev = 1 like gpf_rejuvenate. */
 typedef enum { GPF_MOVE_PROPOSAL_LOCALLY_OPTIMAL = 1, GPF_MOVE_PROPOSAL_LINE_OUTLIER = 2 } gpf_move_proposal;
 gpf_status gpf_rejuvenate_proposal(gpf_handle h, int32_t proposal, const double* params, int32_t n_params, int32_t n_iters);
+/* the same native proposals under either rejuvenation method (method::Symbol of pf_rejuvenate!, src/rejuvenate.jl:18-27):
+ * GPF_REJUVENATE_REWEIGHT = gpf_rejuvenate_proposal above; GPF_REJUVENATE_MOVE = pf_move_accept!(state, mh, (proposal, proposal_args), n_iters)
+ * (src/rejuvenate.jl:40-53 with Gen.mh(trace, proposal, proposal_args)): propose, update, assess the reverse move, accept iff
+ * log(rand()) < weight - fwd_score + bwd_score; the weights stay.  n_accepted (may be NULL): accepted proposals over all particles and sweeps. */
+gpf_status gpf_rejuvenate_with_proposal(gpf_handle h, int32_t method, int32_t proposal, const double* params, int32_t n_params, int32_t n_iters,
+                                        uint64_t* n_accepted);
 
 /* "Lazy search" (csrc/gpf_k_fused.hpp): with enable != 0 a plain pf_resample!(state, :multinomial) enqueues the weight scan
  * only and the pf_update! that follows finds the ancestors, gathers, propagates and writes state.parents in ONE kernel; any other consumer

@@ -241,6 +241,14 @@ function pf_move_reweight!(s::DeviceParticleFilterState, kern, kern_args::Tuple{
     _status(s, ccall((:gpf_rejuvenate_proposal, libgpf), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint, Cint), s.handle, mp.id, mp.params, length(mp.params), n_iters))
     return s
 end
+# pf_move_accept!(state, mh, (proposal, proposal_args...), n_iters) (src/rejuvenate.jl:40-53 with Gen.mh(trace, proposal, proposal_args)): the same
+# native proposals, accepted iff log(rand()) < weight - fwd_score + bwd_score
+function pf_move_accept!(s::DeviceParticleFilterState, kern, kern_args::Tuple{MoveProposal,Vararg}, n_iters::Int=1)
+    mp = kern_args[1]
+    _status(s, ccall((:gpf_rejuvenate_with_proposal, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cint, Cint, Ptr{UInt64}),
+                     s.handle, 0, mp.id, mp.params, length(mp.params), n_iters, Ptr{UInt64}(C_NULL)))
+    return s
+end
 pf_move_accept!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1) = pf_rejuvenate!(s, kern, kern_args, n_iters; method=:move)
 pf_move_reweight!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1) = pf_rejuvenate!(s, kern, kern_args, n_iters; method=:reweight)
 

@@ -542,6 +542,33 @@ O_EXPORT void o_move_proposal(int model, const double *P, const double *Q, uint6
     }
 }
 
+/* pf_move_accept! (rejuvenate.jl:40-53) with Gen.mh(trace, proposal, proposal_args): propose -> update -> assess the reverse move;
+ * alpha = weight - fwd_score + bwd_score (the quantity move_reweight calls rel_weight, :146); accept iff log(rand()) < alpha; the
+ * weights are untouched.  RNG: proposal blocks blk0 .. blk0 + nb - 1, the uniform in block blk0 + nb, tag MOVE (as o_move's selection variant). */
+O_EXPORT uint64_t o_move_proposal_accept(int model, const double *P, const double *Q, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t n,
+                                         int W, int has_prev, const double *obs, int n_iters, const double *rows_in, double *rows_out)
+{
+    int d = model_dim(model), nb = model_nblk(model);
+    uint64_t acc = 0;
+    #pragma omp parallel for schedule(static) reduction(+:acc)
+    for (int64_t i = 0; i < n; ++i) {
+        const double *ri = rows_in + i * W;
+        double *ro = rows_out + i * W;
+        double x[4], xs[4];
+        const double *xp = ri + d;
+        for (int k = 0; k < d; ++k) x[k] = ri[k];
+        for (int it = 0; it < n_iters; ++it) {
+            uint32_t blk0 = (uint32_t)(it * (nb + 1));
+            double alpha = model_move_propose(model, P, Q, !has_prev, xp, x, obs, seed, O_GID(gid0, i), blk0, epoch, O_TAG_MOVE, xs);
+            o_philox_t b = o_rng(seed, O_GID(gid0, i), blk0 + (uint32_t)nb, epoch, O_TAG_MOVE);
+            if (o_log(o_u52(b.v[0], b.v[1])) < alpha) { for (int k = 0; k < d; ++k) x[k] = xs[k]; ++acc; }
+        }
+        for (int k = 0; k < W; ++k) ro[k] = ri[k];
+        for (int k = 0; k < d; ++k) ro[k] = x[k];
+    }
+    return acc;
+}
+
 /* ------------------------------------------------------------------ weight normalisation */
 /* maximum + validity flags of safe_softmax (utils.jl:119-126): any NaN; all == -Inf; (+Inf present
  * makes exp.(vs .- max) contain NaN -> "total weight is NaN" branch, utils.jl:134-137) */

@@ -72,6 +72,7 @@ def lib():
     sig("o_step_strata", None, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, _f64p, i32, i32, f64, _f64p, _f64p, _f64p)
     sig("o_move", u64, i32, _f64p, u64, u32, i64, i64, i32, i32, _f64p, i32, i32, _f64p, _f64p, _f64p)
     sig("o_move_proposal", None, i32, _f64p, _f64p, u64, u32, i64, i64, i32, i32, _f64p, i32, _f64p, _f64p, _f64p)
+    sig("o_move_proposal_accept", u64, i32, _f64p, _f64p, u64, u32, i64, i64, i32, i32, _f64p, i32, _f64p, _f64p)
     sig("o_max_flags", None, _f64p, i64, pf64, pi32)
     sig("o_fixq", None, _f64p, i64, f64, i32, i32, _u64p)
     sig("o_scan", u64, _u64p, i64, _u64p, pu64, pu64)
@@ -371,12 +372,19 @@ class OracleFilter:
     # -- rejuvenate.jl:18-27 dispatcher, :40-53 move-accept, :74-90 move-reweight
     def rejuvenate(self, method: str = "move", n_iters: int = 1, proposal=None):
         """proposal: the parameter vector of the model's native move proposal -> move_reweight(trace, proposal, proposal_args),
-        rejuvenate.jl:134-148 (() for the LG-SSM's locally optimal proposal, (q, log q, log(1-q)) for line_model's outlier proposal)"""
+        rejuvenate.jl:134-148, or (method "move") Gen.mh(trace, proposal, proposal_args) (() for the LG-SSM's locally optimal proposal,
+        (q, log q, log(1-q)) for line_model's outlier proposal)"""
         if method not in ("move", "reweight"):
             raise OracleError(f"Method {method} not recognized.")   # :25
         new_rows = np.empty_like(self.rows)
+        if proposal is not None and method == "move":                   # Gen.mh(trace, proposal, proposal_args) under pf_move_accept! (:40-53)
+            q = np.zeros(4); q[:len(proposal)] = proposal
+            self.n_accepted = int(lib().o_move_proposal_accept(self.model, self.params, q, self.seed, self.epoch, 0, self.n, self.W,
+                                                               int(self.has_prev), self.last_obs, int(n_iters), self.rows, new_rows))
+            self.rows = new_rows
+            self.epoch += 1
+            return self
         if proposal is not None:
-            assert method == "reweight"
             q = np.zeros(4); q[:len(proposal)] = proposal
             lib().o_move_proposal(self.model, self.params, q, self.seed, self.epoch, 0, self.n, self.W, int(self.has_prev),
                                   self.last_obs, int(n_iters), self.rows, new_rows, self.lw)

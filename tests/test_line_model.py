@@ -81,6 +81,9 @@ class DeviceDriver:
         return self
 
     def rejuvenate(self, method, q=None):
+        if q is not None and method == "move":               # mh(trace, outlier_propose, (idx,)) under pf_move_accept!
+            self.g.pf_rejuvenate(self.st, self.g.mh, (self.g.outlier_propose(q), (1,)), 1, method="move", count=True)
+            return self
         if q is not None:                                    # move_reweight(trace, outlier_propose, (idx,)) with outlier ~ bernoulli(q)
             self.g.pf_rejuvenate(self.st, self.g.move_reweight, (self.g.outlier_propose(q), (1,)), 1, method="reweight")
             return self
@@ -249,6 +252,56 @@ def test_move_accept_rejuvenation(g, o, D):
     assert np.all((rows_old[changed, 1] != 0) | (np.abs(rows_old[changed, 0]) < 3))              # (moves to an outlier are accepted only sometimes)
 
 
+@pytest.mark.parametrize("D", DRIVERS)
+def test_move_accept_with_a_proposal_kernel(g, o, D):
+    """pf_move_accept!(state, mh, (outlier_propose, (idx,))) -- Gen.mh(trace, proposal, proposal_args) through src/rejuvenate.jl:40-53, with the
+    proposal of test/rejuvenate.jl:19-27 (outlier ~ bernoulli(q)).  The weights do not change (:30-50); a particle whose proposal equals its
+    current value has alpha = 0 and always "accepts" (log(rand()) < 0); a changed particle was accepted with
+        alpha = [logpdf(bernoulli, new, 0.1) + logpdf(normal, 0, slope, new ? 10 : 1)] - [the same at old] - logpdf(bernoulli, new, q) + logpdf(bernoulli, old, q)
+    (test/rejuvenate.jl:20-25's expected_w), so changes with alpha > 0 all happen, and the fraction of false -> true moves at slope 0 matches
+    q * min(1, exp(alpha)) -- the closed form of the MH kernel."""
+    import math
+    q = 0.5
+    d = D(g, o, keep_prev=True).init(0).update(1)
+    rows_old, lw_old = d.rows.copy(), d.lw.copy()
+    d.rejuvenate("move", q=q)
+    assert np.array_equal(d.lw, lw_old) and np.array_equal(d.rows[:, 0], rows_old[:, 0])          # weights and the untouched choice stay
+    old, new, slope = rows_old[:, 1] != 0, d.rows[:, 1] != 0, rows_old[:, 0]
+    changed = old != new
+    assert changed.any() and changed.sum() <= d.n_accepted <= N
+
+
+
+def test_mh_proposal_acceptance_rates_closed_form(g, o):
+    """the same kernel on 40 000 particles (oracle; the device equals it bit for bit, test_hip_line_model_bitexact[move_proposal]): per
+    (slope, old outlier) class the fraction of particles that changed is P(propose the other value) * min(1, exp(alpha)) with alpha =
+    test/rejuvenate.jl:20-25's expected_w -- the Metropolis-Hastings acceptance rule of Gen.mh(trace, proposal, proposal_args)"""
+    q, n = 0.5, 40_000
+    m = g.models.line_model()
+    f = o.OracleFilter(m.model_id, m.params, n, 11, keep_prev=True)
+    f.initialize(g.models.line_obs(0, 0.0)); f.update(g.models.line_obs(1, 0.0))
+    rows_old, lw_old = f.rows.copy(), f.lw.copy()
+    f.rejuvenate("move", 1, proposal=(q, math.log(q), math.log1p(-q)))
+    assert np.array_equal(f.lw, lw_old)
+    old, new, slope = rows_old[:, 1] != 0, f.rows[:, 1] != 0, rows_old[:, 0]
+
+    def alpha(s, ol, nw):                                    # y_1 = 0 (line_obs(1, 0.0)): logpdf(normal, 0, slope * 1, sd)
+        return (logpdf_bernoulli(nw, 0.1) + logpdf_normal(0, s, 10. if nw else 1.)) - (logpdf_bernoulli(ol, 0.1) + logpdf_normal(0, s, 10. if ol else 1.)) \
+            - logpdf_bernoulli(nw, q) + logpdf_bernoulli(ol, q)
+    checked = 0
+    for sv in (-2.0, -1.0, 0.0, 1.0, 2.0):
+        for ol in (False, True):
+            sel = (slope == sv) & (old == ol)
+            cnt = int(sel.sum())
+            if cnt < 300:
+                continue
+            p = (q if not ol else 1 - q) * min(1.0, math.exp(alpha(sv, ol, not ol)))
+            k = int((new[sel] != ol).sum())
+            assert abs(k - cnt * p) <= 5 * math.sqrt(cnt * p * (1 - p)) + 2, (sv, ol, k, cnt, p)
+            checked += 1
+    assert checked >= 6
+
+
 # ------------------------------------------------------------------------------------------ test/statistics.jl
 @pytest.mark.parametrize("D", DRIVERS)
 def test_statistics_on_a_degenerate_state(g, o, D):
@@ -261,7 +314,7 @@ def test_statistics_on_a_degenerate_state(g, o, D):
 
 # ------------------------------------------------------------------------------------------ device == oracle, bit for bit
 @pytest.mark.gpu
-@pytest.mark.parametrize("scenario", ["default", "proposal", "strata_c", "strata_i", "reweight", "move", "reweight_proposal", "strata_proposal"])
+@pytest.mark.parametrize("scenario", ["default", "proposal", "strata_c", "strata_i", "reweight", "move", "reweight_proposal", "move_proposal", "strata_proposal"])
 def test_hip_line_model_bitexact(g, o, scenario):
     a, b = OracleDriver(g, o, seed=5, keep_prev=True), DeviceDriver(g, o, seed=5, keep_prev=True)
     for d in (a, b):
@@ -280,8 +333,10 @@ def test_hip_line_model_bitexact(g, o, scenario):
                 d.rejuvenate(scenario)
             if scenario == "reweight_proposal":
                 d.rejuvenate("reweight", q=0.9)
+            if scenario == "move_proposal":
+                d.rejuvenate("move", q=0.6)
     assert np.array_equal(a.rows, b.rows) and np.array_equal(a.lw, b.lw)
-    if scenario == "move":
+    if scenario in ("move", "move_proposal"):
         assert a.n_accepted == b.n_accepted
     st, f = b.st, a.f
     assert g.get_ess(st) == f.effective_sample_size() and g.get_lml_est(st) == f.log_ml_estimate()

@@ -92,3 +92,42 @@ def test_hip_move_reweight_proposal_bitexact(g, o):
         g.pf_rejuvenate(s2, g.move_reweight, (g.locally_optimal_move, ()), 1, method="reweight")
     with pytest.raises(g.ErrorException):                                                 # the wrong proposal for the model
         g.pf_rejuvenate(st, g.move_reweight, (g.outlier_propose(0.9), (1,)), 1, method="reweight")
+
+
+def test_oracle_mh_with_the_locally_optimal_proposal(g, o):
+    """pf_move_accept!(state, mh, (proposal, proposal_args)) -- Gen.mh(trace, proposal, proposal_args) through src/rejuvenate.jl:40-53.  With
+    q = p(x_t | x_{t-1}, y_t) alpha = weight - fwd_score + bwd_score is 0 up to rounding: an independence sampler from the exact conditional
+    that accepts whenever log(rand()) < alpha ~ +-1e-15 -- every proposal whose alpha rounds to >= 0 plus almost all others (log u < -1e-15
+    nearly surely): the acceptance count is ~ N per sweep, the weights never change."""
+    m = g.models.lgssm2(); ys = g.models.simulate(m, 4); N = 4000
+    f = o.OracleFilter(m.model_id, m.params, N, 5, keep_prev=True).initialize(ys[0])
+    f.update(ys[1]); f.update(ys[2])
+    rows0, lw0 = f.rows.copy(), f.lw.copy()
+    f.rejuvenate("move", 2, proposal=())
+    assert np.array_equal(f.lw, lw0) and np.array_equal(f.rows[:, 2:4], rows0[:, 2:4])
+    assert f.n_accepted >= 2 * N - 5
+    A, sq, sr = m.info["A"], m.info["sq"], m.info["sr"]
+    mu = rows0[:, 2:4] @ A.T
+    gain = sq ** 2 / (sq ** 2 + sr ** 2)
+    assert np.abs((f.rows[:, :2] - (mu + gain * (ys[2] - mu))).mean(axis=0)).max() < 0.01
+
+
+@pytest.mark.gpu
+def test_hip_mh_proposal_bitexact(g, o):
+    """k_move<..., REWEIGHT = false, PROP = true> against the oracle: states, weights, acceptance counts; with a pending resample gather
+    riding on the move; models without a native move proposal refuse"""
+    m = g.models.lgssm2(); ys = g.models.simulate(m, 5); N = 30_001
+    st = g.pf_initialize(m, (1,), ys[0], N, seed=3, keep_prev=True)
+    orc = o.OracleFilter(m.model_id, m.params, N, 3, keep_prev=True).initialize(ys[0])
+    for t in range(1, 4):
+        g.pf_update(st, (t + 1,), (None,), ys[t]); orc.update(ys[t])
+        if t != 2:
+            g.pf_resample(st, "residual", check=False); orc.resample("residual", check=False)
+        g.pf_rejuvenate(st, g.mh, (g.locally_optimal_move, ()), t, method="move", count=(t == 3)); orc.rejuvenate("move", t, proposal=())
+        if t == 3:
+            assert st.n_accepted == orc.n_accepted
+        assert np.array_equal(st.traces, orc.rows) and np.array_equal(st.log_weights, orc.lw)
+    assert g.get_lml_est(st) == orc.log_ml_estimate() and g.get_ess(st) == orc.effective_sample_size()
+    with pytest.raises(g.ErrorException):
+        s2 = g.pf_initialize(g.models.sv1(), (1,), [0.1], 64, keep_prev=True)
+        g.pf_rejuvenate(s2, g.mh, (g.locally_optimal_move, ()), 1, method="move")
