@@ -183,7 +183,7 @@ def main():
         def make_state():
             st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=SEED, device=local_rank)
             for tp in (1, 2):                                        # two steps before the counted warm-up
-                sharded.pf_resample(st, "multinomial", check=False)
+                sharded.pf_resample(st, "multinomial")
                 sharded.pf_update(st, (tp + 1,), (None,), ys[tp])
             st.synchronize()
             return st
@@ -227,7 +227,7 @@ def main():
         t_first = 3
 
         def step(t):
-            sharded.pf_resample(state, "multinomial", check=False)   # (check = :warn polls one more pinned flag per resample: +6 us)
+            sharded.pf_resample(state, "multinomial")                # the reference's defaults as in the one-GPU loop above: priority_fn = nothing, check = :warn
             sharded.pf_update(state, (t + 1,), (None,), ys[t])
 
     def barrier():
@@ -246,12 +246,17 @@ def main():
     for _ in range(Wm):
         step(t); t += 1
     barrier()
+    headline_traffic = None
+    if sharded_mode and getattr(state.backend, "lib_comm", False):
+        state.backend.traffic(reset=True)
     t0 = time.perf_counter()
     for _ in range(K):
         step(t); t += 1
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if sharded_mode and getattr(state.backend, "lib_comm", False):
+        headline_traffic = state.backend.traffic(reset=True)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -357,7 +362,7 @@ def main():
         return {"workload": workload, "value": round(n_global * k / seconds, 1), "unit": "particle-steps/sec", "steps": k,
                 "ms_per_step": round(seconds / k * 1e3, 5)}
 
-    strat = island = plans = sorted_variant = strat_sorted = None
+    strat = island = plans = sorted_variant = strat_sorted = links = None
     if not sharded_mode and not args.headline_only:
         # the OPT-IN sorted form of the multinomial resampler (gpf.h GPF_RESAMPLE_MULTINOMIAL_SORTED): same offspring-count
         # law, ancestors in non-decreasing order -- NOT the reference's slot order, so a named variant beside the unchanged headline
@@ -397,12 +402,48 @@ def main():
 
         def step_of(method, **kw):
             def f(tq):
-                sharded.pf_resample(state, method, check=False, **kw)
+                sharded.pf_resample(state, method, **kw)                 # (check = :warn like the headline loop)
                 sharded.pf_update(state, (tq + 1,), (None,), ys[1 + tq % (n_obs - 1)])
             return f
+        lib_engine = getattr(state.backend, "lib_comm", False)
+        links = {}
+        if headline_traffic is not None:                             # the timed headline loop itself (i.i.d. multinomial, the plan named in exchange_plans.timed)
+            calls, sent, recv, eb = headline_traffic
+            peers = max(world - 1, 1)
+            links["multinomial_headline"] = {"entry_bytes": eb, "observed_entries_out_per_step": round(sent / max(calls, 1), 1),
+                                             "observed_bytes_per_link_per_step": round(sent * eb / max(calls, 1) / peers, 1),
+                                             "predicted_entries_out_per_step": round(n_local * (world - 1) / world, 1),
+                                             "predicted_bytes_per_link_per_step": round(n_local / world * eb, 1),
+                                             "prediction": "i.i.d. ancestors: (G-1)/G of a shard's rows leave it every step, n / G entries per link (DESIGN.md 6.7)",
+                                             "rank": rank}
+
+        def link_bytes(name, run, predicted_entries_out, note):
+            """bytes this rank put on each of its G - 1 links per step (gpf_comm_traffic: what the library's exchange really sent) beside the
+            scaling worksheet's prediction"""
+            if not lib_engine:
+                return run()
+            state.backend.traffic(reset=True)
+            out = run()
+            calls, sent, recv, eb = state.backend.traffic(reset=True)
+            peers = max(world - 1, 1)
+            links[name] = {"entry_bytes": eb, "observed_entries_out_per_step": round(sent / max(calls, 1), 1),
+                           "observed_bytes_per_link_per_step": round(sent * eb / max(calls, 1) / peers, 1),
+                           "predicted_entries_out_per_step": predicted_entries_out,
+                           "predicted_bytes_per_link_per_step": (None if predicted_entries_out is None else round(predicted_entries_out * eb / peers, 1)),
+                           "prediction": note, "rank": rank}
+            return out
         # STRATIFIED resampling (BASELINE.json configs[2]: monotone targets, almost no row leaves its shard)
         strat = variant_line("same filter, stratified resample every step, sort_particles=false (BASELINE.json configs[2])",
-                             kv, variant(step_of("stratified"), kv))
+                             kv, link_bytes("stratified", lambda: variant(step_of("stratified"), kv), None,
+                                            "boundary slabs: ~ cv sqrt(h n) slots per shard boundary (DESIGN.md 6.7: 2-4e3 at n = 1e6), not (G-1)/G of the rows"))
+        # the opt-in sorted form of the HEADLINE's resampler across shards (DESIGN.md 3.6, 6.9): the same offspring-count law as :multinomial,
+        # ascending targets -> every shard serves one slot range, the exchange is boundary slabs like the stratified one
+        try:
+            sorted_variant = variant_line("same filter, opt-in multinomial_sorted resample every step across the shards (sorted uniforms: one served slot range per shard)",
+                                          kv, link_bytes("multinomial_sorted", lambda: variant(step_of("multinomial_sorted"), kv), None,
+                                                         "boundary slabs: the sorted uniforms' spread ~ sqrt(N) slots per shard boundary plus the shards' weight imbalance"))
+        except Exception as e:                                       # noqa: BLE001 -- a variant must not take the headline line down
+            sorted_variant = {"error": repr(e)}
         # the communication-free "island" mode (every shard resamples locally with the reference's sub-state semantics,
         # SURVEY.md 8e): a different estimator, reported for comparison only
         island = variant_line("same filter, every shard resamples its own particles (multinomial, sub-state semantics), no exchange",
@@ -414,7 +455,9 @@ def main():
             plans = {"timed": timed_plan}
             for pl in ("push", "pull"):
                 state.backend.set_plan(pl)
-                plans[pl] = variant_line(f"headline workload, exchange plan {pl}", kv, variant(step_of("multinomial"), kv))
+                plans[pl] = variant_line(f"headline workload, exchange plan {pl}", kv,
+                                         link_bytes(f"multinomial_{pl}", lambda: variant(step_of("multinomial"), kv), round(n_local * (world - 1) / world, 1),
+                                                    "i.i.d. ancestors: (G-1)/G of a shard's rows leave it every step, n / G entries per link"))
             state.backend.set_plan(timed_plan)
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 / N=1 only ----
@@ -474,6 +517,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_multithread": cpu_all, "resample_gather_kernel": gather,
             "stratified_variant": strat, "local_resample_variant": island, "exchange_plans": plans,
             "multinomial_sorted_variant": sorted_variant, "stratified_sort_particles_variant": strat_sorted,
+            "exchange_bytes_per_link": links,
         }
     else:
         out = None

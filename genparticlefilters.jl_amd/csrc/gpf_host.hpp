@@ -187,6 +187,8 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     int64_t* splan_F = nullptr; unsigned int* splan_arrive = nullptr;   // k_sorted_plan: boundary scratch [MAX_SHARDS + 1], arrival counter (zero between launches)
     int64_t push_cap = 0;
     bool push_counted = false;
+    // exchange volume of the sharded resamples so far (gpf_comm_traffic): calls, entries sent to / received from OTHER ranks, bytes of one entry of the latest call
+    int64_t tr_calls = 0, tr_sent = 0, tr_recv = 0, tr_entry_bytes = 0;
     int last_flags = 0;                  // safe_softmax flags (FLAG_*) of the latest resample that read them on the host (resample_impl)
     gpfh::Timer timers[GPF_K_COUNT];
     std::string err;

@@ -595,6 +595,16 @@ gpf_status gpf_comm_summary_mode(gpf_handle h, int32_t* mailbox)
     return GPF_OK;
 }
 
+/* exchange volume of this handle's gpf_shard_resample calls so far: out4 = {calls, entries sent to other ranks, entries received from other
+ * ranks, bytes of one exchanged entry in the latest call}; reset = 1 clears the counters after reading */
+gpf_status gpf_comm_traffic(gpf_handle h, int64_t* out4, int32_t reset)
+{
+    if (!h || !out4) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    out4[0] = h->tr_calls; out4[1] = h->tr_sent; out4[2] = h->tr_recv; out4[3] = h->tr_entry_bytes;
+    if (reset) h->tr_calls = h->tr_sent = h->tr_recv = 0;
+    return GPF_OK;
+}
+
 gpf_status gpf_comm_set_plan(gpf_handle h, int32_t plan)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
@@ -872,6 +882,8 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     // worked out their receive counts themselves and will wait for exactly that many entries): the error is returned after the
     // group has closed.  A failed gpf_shard_resample leaves the communicator and the filter unusable on every rank that sees
     // one (the entries a failing rank sends are undefined): the host must tear the job down.
+    h->tr_calls += 1; h->tr_entry_bytes = E * (int64_t)sizeof(double);
+    for (int g = 0; g < G; ++g) if (g != me) { h->tr_sent += counts[g]; h->tr_recv += counts[(size_t)G + g]; }
     gpf_status late = GPF_OK;
     std::string late_msg;
     auto remember = [&](gpf_status st) { if (st && !late) { late = st; late_msg = h->err; } };

@@ -193,6 +193,12 @@ class HipShardBackend:
         self._ck(self.L.gpf_comm_plan(self.h, C.byref(p)))
         return "pull" if p.value else "push"
 
+    def traffic(self, reset: bool = False):
+        """(calls, entries sent to other ranks, entries received from other ranks, bytes per entry) of the library engine's resamples so far"""
+        out = (C.c_int64 * 4)()
+        self._ck(self.L.gpf_comm_traffic(self.h, out, int(reset)))
+        return tuple(int(x) for x in out)
+
     def comm_world(self) -> int:
         """ranks of the library's RCCL communicator (0: none)"""
         return getattr(self, "_rccl_world", 0)

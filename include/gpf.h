@@ -421,6 +421,11 @@ gpf_status gpf_comm_destroy(gpf_handle h);
  * launch, no host; 0: RCCL all-gathers (hipIpc mapping not possible on this system, or GPF_SHARD_SUMMARY=rccl in the environment).
  * Every rank of a communicator is in the same mode.  The row exchange itself is always grouped ncclSend / ncclRecv. */
 gpf_status gpf_comm_summary_mode(gpf_handle h, int32_t* mailbox);
+/* exchange volume of this handle's gpf_shard_resample calls so far (what a scaling run compares with the worksheet of DESIGN.md 6.7):
+ * out4 = {calls, entries sent to OTHER ranks, entries received from other ranks, bytes of one exchanged entry in the latest call};
+ * reset = 1 clears the counters after reading */
+gpf_status gpf_comm_traffic(gpf_handle h, int64_t* out4, int32_t reset);
+
 /* The exchange plan of the i.i.d. resamplers (multinomial, and residual's i.i.d. tail) across shards; both give the same bits
  * (Random.rand(Categorical(weights), n), src/resample.jl:59,108 -- every slot's uniform is keyed by its GLOBAL slot id):
  *   GPF_SHARD_PLAN_PUSH (default): every shard evaluates the targets of ALL n_global slots, looks up the ones that fall in its own range

@@ -401,7 +401,8 @@ end
 # (sub-state semantics, src/resample.jl:185-187,205-218), also one call (gpf_resample_local).
 function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multinomial; check=:warn, sort_particles::Bool=false,
                       local_only::Bool=false, priority_alpha::Union{Nothing,Float64}=nothing)   # priority_fn = w -> priority_alpha * w
-    m = method == :multinomial ? 0 : method == :residual ? 1 : method == :stratified ? 2 : error("Resampling method $method not recognized.")
+    m = method == :multinomial ? 0 : method == :residual ? 1 : method == :stratified ? 2 :
+        method == :multinomial_sorted ? 4 : error("Resampling method $method not recognized.")    # (:multinomial_sorted: the opt-in extension, boundary slabs instead of (G-1)/G of all rows)
     chk = check === true ? 2 : (check === :warn ? 1 : 0)
     invalid = Ref{Cint}(0)
     # check = false: NULL for `invalid` keeps the call fully asynchronous (a non-NULL pointer makes the library poll the weight flags)
@@ -419,6 +420,12 @@ end
 function shard_plan!(s::ShardedDeviceParticleFilterState, plan::Symbol)
     plan in (:push, :pull) || error("exchange plan :$plan: :push or :pull")
     _status(s, ccall((:gpf_comm_set_plan, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, plan == :pull ? 1 : 0)); s
+end
+"(calls, entries sent to other ranks, entries received from other ranks, bytes per entry) of this rank's sharded resamples so far (gpf.h gpf_comm_traffic)"
+function shard_traffic(s::ShardedDeviceParticleFilterState; reset::Bool=false)
+    out = zeros(Int64, 4)
+    _status(s, ccall((:gpf_comm_traffic, libgpf), Cint, (Ptr{Cvoid}, Ptr{Int64}, Cint), s.handle, out, reset ? 1 : 0))
+    (out[1], out[2], out[3], out[4])
 end
 function shard_plan(s::ShardedDeviceParticleFilterState)
     p = Ref{Cint}(0)
