@@ -153,33 +153,6 @@ struct PackedCommit {
     // accumulators itself (gate_verdict) and, if the ESS is below the threshold -- the filter resamples first --, returns before its first store
     GateIn gate;
 };
-// ---- experiment switches of the i.i.d. row gather (profiles/r05_gather_policy.txt; product build: all off)
-//   GPF_GATHER_POLICY 1 / 2 / 3: the gathered row's 16-byte loads carry nt / sc1 / sc0 sc1 (does any cache policy make the L2 fetch less than a
-//                                128-byte line per 16-byte row?)
-//   GPF_GATHER_PIPE   1:         the next grid-stride iteration's ancestor and row are requested before the current one is propagated (two
-//                                rows in flight per lane)
-#ifndef GPF_GATHER_POLICY
-#define GPF_GATHER_POLICY 0
-#endif
-#ifndef GPF_GATHER_PIPE
-#define GPF_GATHER_PIPE 0
-#endif
-__device__ __forceinline__ double2 gather_load16(const double2* p)
-{
-#if GPF_GATHER_POLICY == 0
-    return *p;
-#else
-    double2 v;
-#if GPF_GATHER_POLICY == 1
-    asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-#elif GPF_GATHER_POLICY == 2
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-#else
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-#endif
-    return v;
-#endif
-}
 template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false, bool BLK = false>
 __global__ __launch_bounds__(BLOCK, 4) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, const int32_t* __restrict__ anc,
@@ -211,34 +184,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step(ModelArgs a, uint64_t seed, u
     constexpr bool STAGE = GPF_STAGE_ROWS && W >= 8 && !PACKED;          // wide rows travel through the wave's LDS strip (wave_rows_load / _store)
     __shared__ double2 s_stage[STAGE ? NWAVES * RowStage<W>::WORDS : 1];
     double2* const lds_wave = s_stage + (STAGE ? wave_id() * RowStage<W>::WORDS : 0);
-    constexpr bool PIPE = GPF_GATHER_PIPE && GATHER && !STAGE && !PACKED;      // (experiment: two rows in flight per lane)
-    double2 pipe_rows[PIPE ? (D + 1) / 2 : 1];
-    if constexpr (PIPE) {
-        const int64_t e0 = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-        if (e0 < n && !pc.masked) {
-            const double2* src = reinterpret_cast<const double2*>(rows_in + (int64_t)anc[e0] * W);
-#pragma unroll
-            for (int c = 0; c < (D + 1) / 2; ++c) pipe_rows[c] = src[c];
-        }
-    }
     for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; STAGE ? e - lane_id() < n : e < n; e += (int64_t)gridDim.x * BLOCK) {
         int64_t i = e;                                  // the slot this lane fills
         const bool live = !STAGE || e < n;              // (STAGE: the whole wave stays in the loop; lanes beyond n help to move rows)
         if (!live) i = 0;
         bool act = true;
         double r[W];
-        if constexpr (PIPE) {
-            if (!pc.masked) {
-#pragma unroll
-                for (int c = 0; c < (D + 1) / 2; ++c) { r[2 * c] = pipe_rows[c].x; r[2 * c + 1] = pipe_rows[c].y; }
-                const int64_t en = e + (int64_t)gridDim.x * BLOCK;
-                if (en < n) {
-                    const double2* src = reinterpret_cast<const double2*>(rows_in + (int64_t)anc[en] * W);
-#pragma unroll
-                    for (int c = 0; c < (D + 1) / 2; ++c) pipe_rows[c] = src[c];
-                }
-            }
-        }
         if constexpr (STAGE) {
             int64_t srow = live ? (GATHER ? (int64_t)anc[i] : i) : 0;
             bool skip = false;
@@ -262,11 +213,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step(ModelArgs a, uint64_t seed, u
             if (pc.masked == 2 ? (i < pc.own_range[0] || i >= pc.own_range[1]) : srow < 0) continue;
             srow -= pc.anc_off;
         }
-        if (!(PIPE && !pc.masked)) {
         const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
 #pragma unroll
-        for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = GATHER ? gather_load16(src + c) : src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
-        }
+        for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
         }
         double xn[MAX_DIM];
         double ll;
