@@ -197,11 +197,12 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
         if ((s = sorted_gammas_finish(h, ntl > SP_DIRECT_TILES))) return s;
         h->push_ticket += 1;
         a.ticket = h->push_ticket;
+        if (h->own_direct && G == 1) a.host_counts = nullptr;      // (one shard, own-direct: nobody waits for the counts -- no system-scope publish)
         const SortedPlanJob job{h->sp_g, h->sp_vlo, ntl, ntl > SP_DIRECT_TILES ? 1 : 0, h->splan_F, h->splan_arrive};
         s = timed(h, GPF_K_SEARCH, [&] { GPF_LAUNCH(k_sorted_plan, dim3((unsigned)(G > 1 ? G - 1 : 1)), dim3(MBLOCK), 0, h->stream, a, h->shard_plan, job); });
         if (s) return s;
         HIP_TRY(h, hipGetLastError());
-        h->counts_published = true;
+        h->counts_published = a.host_counts != nullptr;         // (else gpf_shard_counts copies them from the device)
         h->push_counted = true;
         return GPF_OK;
     }
@@ -211,10 +212,11 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
         if (!h->shard_plan) HIP_TRY(h, hipMalloc(&h->shard_plan, sizeof(ShardPlan)));
         h->push_ticket += 1;
         a.ticket = h->push_ticket;
+        if (h->own_direct && G == 1) a.host_counts = nullptr;      // (as above)
         s = timed(h, GPF_K_SEARCH, [&] { GPF_LAUNCH(k_strat_plan, dim3(1), dim3(128), 0, h->stream, a, h->shard_plan); });
         if (s) return s;
         HIP_TRY(h, hipGetLastError());
-        h->counts_published = true;
+        h->counts_published = a.host_counts != nullptr;         // (else gpf_shard_counts copies them from the device)
         h->push_counted = true;
         return GPF_OK;
     }
