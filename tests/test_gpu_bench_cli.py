@@ -127,4 +127,13 @@ def test_two_ranks_report_both_exchange_plans(built, tmp_path):
         ep = out["exchange_plans"]
         assert ep["timed"] == plan and ep["push"]["value"] > 0 and ep["pull"]["value"] > 0 and ep["push"]["steps"] == 100
         ests[plan] = out["log_ml_estimate"]
+        # what the exchanges really sent (gpf_comm_traffic) beside the worksheet: the i.i.d. multinomial moves (G-1)/G of a shard's rows, the
+        # sorted multinomial and the stratified resampler boundary slabs
+        links = out["exchange_bytes_per_link"]
+        head = links["multinomial_headline"]
+        assert head["entry_bytes"] == 24 and abs(head["observed_entries_out_per_step"] - 50_000) < 2_000       # n (G-1)/G = 50 000 at G = 2
+        assert abs(head["observed_bytes_per_link_per_step"] - head["predicted_bytes_per_link_per_step"]) < 0.05 * head["predicted_bytes_per_link_per_step"]
+        for name in ("stratified", "multinomial_sorted"):
+            assert 0 <= links[name]["observed_entries_out_per_step"] < 5_000, (name, links[name])
+        assert out["multinomial_sorted_variant"]["value"] > 0 and out["stratified_variant"]["value"] > 0
     assert ests["push"] == ests["pull"]                                       # the same filter, bit for bit
