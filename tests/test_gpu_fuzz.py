@@ -63,8 +63,8 @@ def test_random_api_sequences(g, o, seed):
     log = []
     blk = None                                                        # (block size, observation rows) while the latest observations are per block
     for step in range(T):
-        op = rng.choice(["update", "resample", "rejuvenate", "getters", "view", "whole_view", "resize", "set_weights", "blocks"],
-                        p=[0.22, 0.20, 0.11, 0.08, 0.11, 0.07, 0.07, 0.07, 0.07])
+        op = rng.choice(["update", "resample", "rejuvenate", "getters", "view", "whole_view", "resize", "set_weights", "blocks", "step_ess"],
+                        p=[0.17, 0.17, 0.11, 0.08, 0.11, 0.07, 0.07, 0.07, 0.07, 0.08])
         n = st.n_particles
         if op == "blocks" and hist:
             with pytest.raises(g.ErrorException):                       # (no block-wise steps on a filter with a trajectory store)
@@ -104,7 +104,31 @@ def test_random_api_sequences(g, o, seed):
                 with pytest.raises(g.ErrorException):                   # one ancestor map per step for the whole filter: no sub-states
                     st[0:max(1, n // 2)]
             op = "getters"                                              # (nor can such a filter be resized)
-        if op == "update":
+        if op == "step_ess" and blk is not None:
+            op = "update"                                               # (per-block observations: the one-call step takes one observation for all)
+        if op == "step_ess":
+            # one iteration of the README loop in ONE call (gpf_step_ess: the verdict on the device, the propagate speculatively behind it --
+            # or the plain sequence when a resample / move is pending, a summary is cached, the filter keeps a trajectory store)
+            thr = float(rng.choice([0.0, 0.3, 0.7, 1.1])); m = str(rng.choice(RES_METHODS)); rj = [None, "move", "reweight"][int(rng.integers(3))]
+            kw = {"sort_particles": bool(rng.random() < 0.5)} if m == "stratified" else {}
+            out = {}
+
+            def oracle_step():
+                go = orc.effective_sample_size() < thr * n
+                if go:
+                    orc.resample(m, check="warn", **kw)
+                    if rj:
+                        orc.rejuvenate(rj, 1)
+                orc.update(ys[t])
+                out["o"] = bool(go)
+            if both(lambda: out.update(d=g.pf_step_ess(st, (t + 1,), (None,), ys[t], ess_threshold=thr, method=m, rejuvenate=rj, check="warn", **kw)),
+                    oracle_step, log[-4:]):
+                st.close()
+                return
+            assert out["d"] == out["o"], (thr, m, rj, log[-4:])
+            t += 1
+            op = f"step_ess {thr} {m} {rj} -> {out['d']}"
+        elif op == "update":
             if name == "lgssm2" and rng.random() < 0.3:               # the native locally optimal proposal (update.jl:79-96)
                 g.pf_update(st, (t + 1,), (None,), ys[t], g.locally_optimal, ()); orc.update(ys[t], proposal=True)
                 op = "update (proposal)"
@@ -146,6 +170,10 @@ def test_random_api_sequences(g, o, seed):
             elif name == "lgssm2" and meth == "reweight" and rng.random() < 0.5:       # move_reweight(trace, proposal, args), rejuvenate.jl:134-148
                 g.pf_rejuvenate(st, g.move_reweight, (g.locally_optimal_move, ()), it, method="reweight"); orc.rejuvenate("reweight", it, proposal=())
                 meth = "reweight (locally optimal proposal)"
+            elif name == "lgssm2" and meth == "move" and rng.random() < 0.5:           # mh(trace, proposal, args) under pf_move_accept!, rejuvenate.jl:40-53
+                g.pf_rejuvenate(st, g.mh, (g.locally_optimal_move, ()), it, method="move", count=True); orc.rejuvenate("move", it, proposal=())
+                assert st.n_accepted == orc.n_accepted
+                meth = "move (locally optimal proposal)"
             else:
                 g.pf_rejuvenate(st, g.mh if meth == "move" else g.move_reweight, (), it, method=meth); orc.rejuvenate(meth, it)
             op = f"rejuvenate {meth} {it}"
