@@ -494,10 +494,22 @@ def pf_initialize_blocks(model: NativeModel, model_args: tuple, observations, n_
     return state
 
 
-def pf_update_blocks(state, new_args: tuple, argdiffs: tuple, observations, block_size: int):
-    """for b in blocks: pf_update!(state[b], new_args, argdiffs, observations[b]) (per-view updates, test/update.jl:179-189) in one launch"""
+def pf_update_blocks(state, new_args: tuple, argdiffs: tuple, observations, block_size: int, proposals=None):
+    """for b in blocks: pf_update!(state[b], new_args, argdiffs, observations[b]) (per-view updates, test/update.jl:179-189) in one launch.
+    proposals: one entry per block, None (default proposal, update.jl:12-25) or the model's native proposal (update.jl:79-96) -- "Update with
+    different proposals per view" in one launch (gpf.h gpf_update_blocks_proposal)"""
     obs = _block_obs(state, observations, block_size)
-    state._check(state._L.gpf_update_blocks(state._h, _pd(obs), obs.shape[1], int(block_size)))
+    if proposals is None:
+        state._check(state._L.gpf_update_blocks(state._h, _pd(obs), obs.shape[1], int(block_size)))
+        return state
+    if len(proposals) != obs.shape[0]:
+        raise ErrorException(f"one proposal (or None) per block expected: {obs.shape[0]}, got {len(proposals)}")
+    native = [q for q in proposals if q is not None]
+    pid = _proposal_id(native[0]) if native else 1
+    if any(_proposal_id(q) != pid for q in native):
+        raise ErrorException("the blocks' native proposals must be the same one")
+    flags = np.ascontiguousarray([0 if q is None else 1 for q in proposals], np.int32)
+    state._check(state._L.gpf_update_blocks_proposal(state._h, _pd(obs), obs.shape[1], int(block_size), flags.ctypes.data_as(C.POINTER(C.c_int32)), pid))
     return state
 
 

@@ -221,6 +221,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step(ModelArgs a, uint64_t seed, u
         double ll;
         const double* const ob = obs_of<BLK>(a, i);
         if constexpr (MODE == 1) ll = Mo::propose(a.P, false, r, ob, seed, particle_gid(a, gid0, i), 0, epoch, TAG_UPDATE, xn);
+        else if constexpr (MODE == 4) {
+            // block-wise update with a proposal PER BLOCK (the per-view updates of test/update.jl:179-189 in one launch): the block's flag
+            // selects update.jl:79-96 (native proposal) or update.jl:12-25 (default) for its particles -- the same counters either way
+            if (a.blk_prop[(uint32_t)i / (uint32_t)a.blk_size]) ll = Mo::propose(a.P, false, r, ob, seed, particle_gid(a, gid0, i), 0, epoch, TAG_UPDATE, xn);
+            else { Mo::sample(a.P, false, r, ob, seed, particle_gid(a, gid0, i), 0, epoch, TAG_UPDATE, xn); ll = Mo::loglik(a.P, xn, ob); }
+        }
         else if constexpr (MODE == 2) {
             const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_UPDATE)];
             const double lp = Mo::sample_stratum(a.P, false, r, ob, v, seed, particle_gid(a, gid0, i), 0, epoch, TAG_UPDATE, xn);

@@ -37,6 +37,8 @@ struct ModelArgs {          // passed by value in the kernarg segment: no device
     // block-wise operations (many small filters in one state, gpf_update_blocks & co.): particle i belongs to block i / blk_size and
     // sees that block's observation blk_obs[block][MAX_OBS]; blk_mask (rejuvenation): bit 0 of word [block] = the block takes part
     const double* blk_obs; const int32_t* blk_mask; int32_t blk_size, pad2_;
+    // gpf_update_blocks_proposal: word [block] != 0 = the block's particles are extended with the model's native proposal (MODE 4 of k_step)
+    const int32_t* blk_prop;
 };
 // the observation particle i conditions on
 template <bool BLK>

@@ -21,6 +21,14 @@ void launch_step_blk(gpf_filter* h, int grid)
     GPF_LAUNCH((k_step<M, Wc, KEEP, false, 0, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                        h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, next_slots(h), PackedCommit{});
 }
+template <int M, bool KEEP>
+void launch_step_blk_prop(gpf_filter* h, int grid)
+{
+    constexpr int Wc = row_width(Model<M>::D, KEEP);
+    if constexpr (!Model<M>::HAS_PROPOSAL) { (void)h; (void)grid; return; }
+    else GPF_LAUNCH((k_step<M, Wc, KEEP, false, 4, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                    h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, next_slots(h), PackedCommit{});
+}
 template <int M, bool RW>
 void launch_move_blk(gpf_filter* h, int grid, int n_iters)
 {
@@ -332,6 +340,44 @@ gpf_status gpf_update_blocks(gpf_handle h, const double* obs, int32_t n_obs, int
     h->has_prev = true;
     h->raw_valid = false; h->raw_sum_valid = false;
     h->blk_last = 0;                                             // (as in gpf_initialize_blocks)
+    mutated(h);
+    return GPF_OK;
+}
+// for b in blocks: pf_update!(state[b], new_args, argdiffs, observations[b][, proposal, proposal_args]) -- the per-view updates with DIFFERENT
+// proposals per view (test/update.jl:179-189) in one launch: use_proposal[b] != 0 -> block b is extended with the model's native proposal
+// (src/update.jl:79-96), else with the default one (src/update.jl:12-25).  One epoch for all blocks, like gpf_update_blocks.
+gpf_status gpf_update_blocks_proposal(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size, const int32_t* use_proposal, int32_t proposal)
+{
+    gpf_status s = block_step_checks(h, block_size, "gpf_update_blocks_proposal");
+    if (s) return s;
+    if ((s = check_ready(h))) return s;
+    if (!use_proposal) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null use_proposal");
+    const bool ok = (proposal == GPF_PROPOSAL_LOCALLY_OPTIMAL && h->cfg.model != MODEL_LINE) || (proposal == GPF_PROPOSAL_LINE_FIXED && h->cfg.model == MODEL_LINE);
+    bool has = false;
+    DISPATCH_MODEL(h, (has = Model<MM>::HAS_PROPOSAL));
+    if (!ok || !has) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no such native proposal");
+    if ((s = materialize(h))) return s;                          // (no fused gather in the block-wise step)
+    if ((s = set_block_obs(h, obs, n_obs, block_size))) return s;
+    const int64_t nblocks = (h->n + block_size - 1) / block_size;
+    if ((s = block_buffers(h, nblocks))) return s;               // (blk_mask doubles as the flag array: no block resample refers to it after this call)
+    HIP_TRY(h, hipMemcpyAsync(h->blk_mask, use_proposal, (size_t)nblocks * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));                 // (the caller's array may go away)
+    h->args.blk_prop = h->blk_mask;
+    const int grid = step_grid(h);
+    const bool keep = h->cfg.keep_prev != 0;
+    s = timed(h, GPF_K_STEP, [&] {
+        if (keep) { DISPATCH_MODEL(h, (launch_step_blk_prop<MM, true>(h, grid))); }
+        else      { DISPATCH_MODEL(h, (launch_step_blk_prop<MM, false>(h, grid))); }
+    });
+    h->args.blk_prop = nullptr;
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->max_valid = true;
+    h->cur ^= 1;
+    h->epoch += 1;
+    h->has_prev = true;
+    h->raw_valid = false; h->raw_sum_valid = false;
+    h->blk_last = 0;
     mutated(h);
     return GPF_OK;
 }

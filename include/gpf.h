@@ -192,6 +192,10 @@ gpf_status gpf_block_stats(gpf_handle h, int64_t block_size, double* ess_out, do
  * view of the block.  Not on sharded filters, views or filters with a trajectory store. */
 gpf_status gpf_initialize_blocks(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size);
 gpf_status gpf_update_blocks(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size);
+/* the same with a proposal PER BLOCK -- "Update with different proposals per view", test/update.jl:179-189, in one launch:
+ * use_proposal[b] != 0 extends block b with the model's native proposal (src/update.jl:79-96, gpf_update_proposal's), 0 with the default
+ * one (src/update.jl:12-25).  use_proposal: HOST int32[n_blocks]. */
+gpf_status gpf_update_blocks_proposal(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size, const int32_t* use_proposal, int32_t proposal);
 gpf_status gpf_rejuvenate_blocks(gpf_handle h, int32_t method, int32_t n_iters, int32_t only_resampled, uint64_t* n_accepted);
 
 /* same, with log_priorities = priority_fn.(log_weights) evaluated by the caller (any closure):

@@ -215,6 +215,13 @@ function pf_update_blocks!(s::DeviceParticleFilterState, new_args::Tuple, argdif
     size(observations, 2) == cld(s.n_particles, block_size) || error("one observation column per block expected")
     _status(s, ccall((:gpf_update_blocks, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64), s.handle, observations, size(observations, 1), block_size)); s
 end
+# "Update with different proposals per view" (test/update.jl:179-189) in one launch: use_proposal[b] = true extends block b with the model's native
+# proposal (LocallyOptimal for the LG-SSM: id 1; line_model's fixed proposals: id 2), false with the default one
+function pf_update_blocks!(s::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Matrix{Float64}, block_size::Int, use_proposal::Vector{Bool}, proposal_id::Int=1)
+    size(observations, 2) == cld(s.n_particles, block_size) == length(use_proposal) || error("one observation column and one flag per block expected")
+    flags = Int32.(use_proposal)
+    _status(s, ccall((:gpf_update_blocks_proposal, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64, Ptr{Int32}, Cint), s.handle, observations, size(observations, 1), block_size, flags, proposal_id)); s
+end
 function pf_rejuvenate_blocks!(s::DeviceParticleFilterState, kern=nothing, kern_args::Tuple=(), n_iters::Int=1; method::Symbol=:move, only_resampled::Bool=false)
     m = method == :move ? 0 : method == :reweight ? 1 : error("Method $method not recognized.")
     _status(s, ccall((:gpf_rejuvenate_blocks, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{UInt64}), s.handle, m, n_iters, only_resampled ? 1 : 0, C_NULL)); s

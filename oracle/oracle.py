@@ -722,12 +722,13 @@ def resample_blocks(f: OracleFilter, nb: int, method: str = "multinomial", ess_f
     return np.array(mask)
 
 
-def update_blocks(f: OracleFilter, nb: int, obs_rows) -> None:
-    """for b in blocks: pf_update!(state[b], ..., observations[b])   (per-view updates, test/update.jl:179-189)"""
+def update_blocks(f: OracleFilter, nb: int, obs_rows, proposals=None) -> None:
+    """for b in blocks: pf_update!(state[b], ..., observations[b][, proposal, proposal_args])   (per-view updates, also with different
+    proposals per view, test/update.jl:179-189); proposals: one bool per block"""
     e = f.epoch
     for k, (a, b) in enumerate(blocks_of(f, nb)):
         f.epoch = e
-        f[a:b].update(np.asarray(obs_rows[k], np.float64))
+        f[a:b].update(np.asarray(obs_rows[k], np.float64), proposal=bool(proposals[k]) if proposals is not None else False)
     f.epoch = e + 1
 
 

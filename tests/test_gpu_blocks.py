@@ -378,3 +378,49 @@ def test_big_blocks_steps_and_invalid_blocks(g, o):
     assert np.array_equal(st.traces[nb:2 * nb], rows0[nb:2 * nb])       # left as it stands
     assert not np.array_equal(st.traces[:nb], rows0[:nb])               # the others resampled
     st.close()
+
+
+@pytest.mark.parametrize("N,nb", [(1000, 100), (1030, 100), (6000, 2500), (600, 7)])
+def test_per_block_proposals(g, o, N, nb):
+    """"Update with different proposals per view" (test/update.jl:179-189) in ONE launch: every block with its own observation AND its own
+    choice of proposal -- the model's native one (update.jl:79-96) or the default (update.jl:12-25) -- equals the loop over sub-states bit for bit"""
+    m = g.models.lgssm2()
+    B, T = (N + nb - 1) // nb, 5
+    rng = np.random.default_rng(11)
+    base = np.asarray(g.models.simulate(m, T))
+    ys = base[None, :, :] + 0.3 * rng.standard_normal((B,) + base.shape)
+    st = g.pf_initialize_blocks(m, (1,), ys[:, 0], N, nb, seed=13, keep_prev=True)
+    f = o.OracleFilter(m.model_id, m.params, N, 13, keep_prev=True)
+    oracle_init_blocks(o, f, nb, ys[:, 0])
+    for t in range(1, T):
+        flags = rng.random(B) < 0.5 if t < T - 1 else np.ones(B, bool)
+        g.pf_update_blocks(st, (t + 1,), (None,), ys[:, t], nb, proposals=[g.locally_optimal if fl else None for fl in flags])
+        from oracle import oracle
+        oracle.update_blocks(f, nb, ys[:, t], proposals=flags)
+        assert same(st, f), ("update with per-block proposals", t)
+        n_res = g.pf_resample_blocks(st, nb, "stratified", ess_frac=0.7, check=False)
+        assert n_res == oracle_blocks(f, nb, "stratified", ess_frac=0.7).sum() and same(st, f)
+    with pytest.raises(g.ErrorException):                                     # one entry per block
+        g.pf_update_blocks(st, (T + 1,), (None,), ys[:, 0], nb, proposals=[None])
+    sv = g.pf_initialize_blocks(g.models.sv1(), (1,), np.zeros((2, 1)), 100, 50)
+    with pytest.raises(g.ErrorException):                                     # a model without a native proposal
+        g.pf_update_blocks(sv, (2,), (None,), np.zeros((2, 1)), 50, proposals=[g.locally_optimal, None])
+    st.close(); sv.close()
+
+
+def test_reference_update_with_different_proposals_per_view_in_one_launch(g, o):
+    """test/update.jl:179-189 restated on the batched call: line_model, 100 particles, state[1:50] extended to step 10 with the default proposal,
+    state[51:end] with outlier_propose (outlier ~ bernoulli(0.0)): y_10 == 0 everywhere (the observation), outlier == false in the second half,
+    no weight is 0"""
+    m = g.models.line_model()
+    st = g.pf_initialize(m, (0,), g.models.line_obs(0), 100, seed=5)
+    obs = np.stack([g.models.line_obs(10), g.models.line_obs(10)])
+    g.pf_update_blocks(st, (10,), (None,), obs, 50, proposals=[None, g.line_fixed])
+    rows, lw = st.traces, st.log_weights
+    assert np.all(rows[50:, 1] == 0.0)                                       # :line => 10 => :outlier == false under outlier_propose
+    assert np.all(lw != 0.0) and np.all(np.isfinite(lw))
+    f = o.OracleFilter(m.model_id, m.params, 100, 5).initialize(g.models.line_obs(0))
+    from oracle import oracle
+    oracle.update_blocks(f, 50, obs, proposals=[False, True])
+    assert np.array_equal(rows, f.rows) and np.array_equal(lw, f.lw)
+    st.close()

@@ -88,7 +88,7 @@ def test_hip_push_overflow_path(g, o, tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("engine", ["library", "python"])
-@pytest.mark.parametrize("case", CASES[:3], ids=[f"{c[0]}-{c[1]}" for c in CASES[:3]])
+@pytest.mark.parametrize("case", CASES[:3] + [CASES[7]], ids=[f"{c[0]}-{c[1]}" for c in CASES[:3] + [CASES[7]]])
 def test_rccl_collectives_one_rank(g, o, tmp_path, case, engine):
     """the REAL collectives on RCCL in a 1-rank group: the call path the multi-GPU runs take, as far as a 1-GPU box can
     exercise it.  engine = library: gpf_shard_resample -- ncclAllGather and the grouped ncclSend / ncclRecv exchange issued by
