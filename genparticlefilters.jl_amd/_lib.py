@@ -50,6 +50,8 @@ SYMBOLS = [
     ("gpf_block_stats", C.c_int, [_H, C.c_int64, _pd, _pd]),
     ("gpf_initialize_blocks", C.c_int, [_H, _pd, C.c_int32, C.c_int64]),
     ("gpf_update_blocks", C.c_int, [_H, _pd, C.c_int32, C.c_int64]),
+    ("gpf_initialize_blocks_strata", C.c_int, [_H, _pd, C.c_int32, C.c_int64, _pd, C.c_int32, C.c_int32]),
+    ("gpf_update_blocks_strata", C.c_int, [_H, _pd, C.c_int32, C.c_int64, _pd, C.c_int32, C.c_int32]),
     ("gpf_update_blocks_proposal", C.c_int, [_H, _pd, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.c_int32]),
     ("gpf_rejuvenate_blocks", C.c_int, [_H, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     ("gpf_resample_with_priorities", C.c_int, [_H, C.c_int32, _pd, C.c_int32, C.c_int32, _pi32]),

@@ -485,20 +485,31 @@ def _block_obs(state, observations, block_size: int) -> np.ndarray:
 
 
 def pf_initialize_blocks(model: NativeModel, model_args: tuple, observations, n_particles: int, block_size: int, *, seed: int = 1,
-                         keep_prev: bool = False, device: int = 0):
+                         keep_prev: bool = False, device: int = 0, strata=None, layout: str = "contiguous"):
     """many small filters in one state, each with its own data: block b (block_size consecutive particles) is initialised with
-    observations[b] -- the batched form of per-view initialisation (gpf.h gpf_initialize_blocks)"""
+    observations[b] -- the batched form of per-view initialisation (gpf.h gpf_initialize_blocks).  strata: every block is initialised
+    stratified by itself (src/initialize.jl:92-109 per sub-state, gpf.h gpf_initialize_blocks_strata), the same strata for all blocks"""
     state = DeviceParticleFilterState(model, n_particles, seed=seed, keep_prev=keep_prev, device=device)
     obs = _block_obs(state, observations, block_size)
+    if strata is not None:
+        v = _strata_values(model, strata, "initialize")
+        state._check(state._L.gpf_initialize_blocks_strata(state._h, _pd(obs), obs.shape[1], int(block_size), _pd(v), v.size, int(_layout_id(layout))))
+        return state
     state._check(state._L.gpf_initialize_blocks(state._h, _pd(obs), obs.shape[1], int(block_size)))
     return state
 
 
-def pf_update_blocks(state, new_args: tuple, argdiffs: tuple, observations, block_size: int, proposals=None):
+def pf_update_blocks(state, new_args: tuple, argdiffs: tuple, observations, block_size: int, proposals=None, *, strata=None, layout: str = "interleaved"):
     """for b in blocks: pf_update!(state[b], new_args, argdiffs, observations[b]) (per-view updates, test/update.jl:179-189) in one launch.
     proposals: one entry per block, None (default proposal, update.jl:12-25) or the model's native proposal (update.jl:79-96) -- "Update with
     different proposals per view" in one launch (gpf.h gpf_update_blocks_proposal)"""
     obs = _block_obs(state, observations, block_size)
+    if strata is not None:                                       # every block stratified by itself (src/update.jl:193-210 per sub-state)
+        if proposals is not None:
+            raise ErrorException("block-wise updates take strata or per-block proposals, not both")
+        v = _strata_values(state.model, strata)
+        state._check(state._L.gpf_update_blocks_strata(state._h, _pd(obs), obs.shape[1], int(block_size), _pd(v), v.size, int(_layout_id(layout))))
+        return state
     if proposals is None:
         state._check(state._L.gpf_update_blocks(state._h, _pd(obs), obs.shape[1], int(block_size)))
         return state

@@ -354,6 +354,7 @@ gpf_status view_exit(gpf_filter* v);
 gpf_status check_ready(gpf_handle h, bool keep_pending_move = false);
 gpf_status set_obs(gpf_filter* h, const double* obs, int n_obs);
 gpf_status copy_out(gpf_handle h, const void* dsrc, void* out, size_t bytes);
+gpf_status set_strata(gpf_handle h, const double* values, int32_t n_strata, int32_t interleaved);
 // ---- defined in libgpf_resample.hip
 // one scan launch on descriptor channel `ch` (0 weights, 1 residual counts, 2 residual weights): the sharded weight scans (MODE 3: pushes
 // the shard's total itself; 4: also the limbs of sum q^2) and the scans of pf_optimal_resize!

@@ -33,12 +33,20 @@ __device__ __forceinline__ void block_max_store(double m, int f, MaxSlots ms)
 // stratified_map! (utils.jl:29-55): K strata, block size B = n div K; particle i < K B belongs to stratum i div B
 // (:contiguous) or i mod K (:interleaved); the n - K B remaining particles draw a stratum uniformly (sample(strata, R)),
 // here from one more Philox block of the particle (block index NBLK, behind the model's own blocks)
-template <class Mo>
-__device__ __forceinline__ int stratum_of(const ModelArgs& a, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t i, int64_t n, uint32_t tag)
+// BLK (gpf_initialize_blocks_strata / gpf_update_blocks_strata): every block of blk_size particles is stratified by itself, as the sub-state
+// state[b] would be -- the index inside the block and the block's own particle count take the place of (i, n); the RNG counter stays the particle's
+template <class Mo, bool BLK = false>
+__device__ __forceinline__ int stratum_of(const ModelArgs& a, uint64_t seed, uint32_t epoch, int64_t gid0, int64_t ig, int64_t ng, uint32_t tag)
 {
+    int64_t i = ig, n = ng;
+    if constexpr (BLK) {
+        i = ig % a.blk_size;
+        const int64_t b0 = ig - i;
+        n = b0 + a.blk_size <= ng ? (int64_t)a.blk_size : ng - b0;
+    }
     const int64_t K = a.n_strata, B = n / K;
     if (i < K * B) return (int)(a.interleaved ? i % K : i / B);
-    const Philox b = rng(seed, particle_gid(a, gid0, i), (uint32_t)Mo::NBLK, epoch, tag);
+    const Philox b = rng(seed, particle_gid(a, gid0, ig), (uint32_t)Mo::NBLK, epoch, tag);
     return (int)mulhi64(u64(b.w0, b.w1), (uint64_t)K);
 }
 
@@ -112,11 +120,11 @@ __global__ __launch_bounds__(BLOCK) void k_init(ModelArgs a, uint64_t seed, uint
         const double* const ob = obs_of<BLK>(a, i);
         if constexpr (MODE == 1) ll = Mo::propose(a.P, true, nullptr, ob, seed, particle_gid(a, gid0, i), 0, epoch, TAG_INIT, x);
         else if constexpr (MODE == 2) {
-            const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
+            const double v = a.strata[stratum_of<Mo, BLK>(a, seed, epoch, gid0, i, n, TAG_INIT)];
             const double lp = Mo::sample_stratum(a.P, true, nullptr, ob, v, seed, particle_gid(a, gid0, i), 0, epoch, TAG_INIT, x);
             ll = (lp + Mo::loglik(a.P, x, ob)) + a.logK;                      // initialize.jl:103-104
         } else if constexpr (MODE == 3) {                                        // strata + native proposal, initialize.jl:122-126
-            const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_INIT)];
+            const double v = a.strata[stratum_of<Mo, BLK>(a, seed, epoch, gid0, i, n, TAG_INIT)];
             ll = Mo::propose_stratum(a.P, ob, v, x) + a.logK;
         } else {
             Mo::sample(a.P, true, nullptr, ob, seed, particle_gid(a, gid0, i), 0, epoch, TAG_INIT, x);
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step(ModelArgs a, uint64_t seed, u
             else { Mo::sample(a.P, false, r, ob, seed, particle_gid(a, gid0, i), 0, epoch, TAG_UPDATE, xn); ll = Mo::loglik(a.P, xn, ob); }
         }
         else if constexpr (MODE == 2) {
-            const double v = a.strata[stratum_of<Mo>(a, seed, epoch, gid0, i, n, TAG_UPDATE)];
+            const double v = a.strata[stratum_of<Mo, BLK>(a, seed, epoch, gid0, i, n, TAG_UPDATE)];
             const double lp = Mo::sample_stratum(a.P, false, r, ob, v, seed, particle_gid(a, gid0, i), 0, epoch, TAG_UPDATE, xn);
             ll = (lp + Mo::loglik(a.P, xn, ob)) + a.logK;                     // update.jl:201-206
         } else {

@@ -21,6 +21,21 @@ void launch_step_blk(gpf_filter* h, int grid)
     GPF_LAUNCH((k_step<M, Wc, KEEP, false, 0, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                        h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, next_slots(h), PackedCommit{});
 }
+template <int M>
+void launch_init_blk_strata(gpf_filter* h, int grid)
+{
+    if constexpr (!Model<M>::HAS_STRATA) { (void)h; (void)grid; return; }
+    else GPF_LAUNCH((k_init<M, 2, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                    h->cfg.gid0, h->n, h->W, h->rows[h->cur], h->lw, next_slots(h));
+}
+template <int M, bool KEEP>
+void launch_step_blk_strata(gpf_filter* h, int grid)
+{
+    constexpr int Wc = row_width(Model<M>::D, KEEP);
+    if constexpr (!Model<M>::HAS_STRATA) { (void)h; (void)grid; return; }
+    else GPF_LAUNCH((k_step<M, Wc, KEEP, false, 2, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
+                    h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, next_slots(h), PackedCommit{});
+}
 template <int M, bool KEEP>
 void launch_step_blk_prop(gpf_filter* h, int grid)
 {
@@ -340,6 +355,59 @@ gpf_status gpf_update_blocks(gpf_handle h, const double* obs, int32_t n_obs, int
     h->has_prev = true;
     h->raw_valid = false; h->raw_sum_valid = false;
     h->blk_last = 0;                                             // (as in gpf_initialize_blocks)
+    mutated(h);
+    return GPF_OK;
+}
+// for b in blocks: pf_initialize(model, args, observations[b], strata, n_b) / pf_update!(state[b], ..., observations[b], strata) -- stratified
+// initialisation / update (src/initialize.jl:92-109, src/update.jl:193-210) of every block by itself, one launch: the stratum of a particle
+// follows from its index INSIDE its block and the block's own size (stratified_map!, src/utils.jl:29-55, on the sub-state), the same strata for all blocks
+static bool has_strata(gpf_filter* h) { bool v = false; DISPATCH_MODEL(h, (v = Model<MM>::HAS_STRATA)); return v; }
+gpf_status gpf_initialize_blocks_strata(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size, const double* values, int32_t n_strata, int32_t interleaved)
+{
+    gpf_status s = block_step_checks(h, block_size, "gpf_initialize_blocks_strata");
+    if (s) return s;
+    if (!has_strata(h)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no discrete latent to stratify over");
+    if ((s = set_strata(h, values, n_strata, interleaved))) return s;
+    h->generation += 1;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if ((s = set_block_obs(h, obs, n_obs, block_size))) return s;
+    const int grid = step_grid(h);
+    s = timed(h, GPF_K_STEP, [&] { DISPATCH_MODEL(h, (launch_init_blk_strata<MM>(h, grid))); });
+    if (s) return s;
+    h->pending_gather = false; h->pending_fill = false; h->pending_packed = false; h->pending_search = false; h->pending_move = false;
+    h->max_valid = true;
+    GPF_LAUNCH(k_iota, dim3(grid), dim3(BLOCK), 0, h->stream, h->anc, h->n);            // parents = 1:N (initialize.jl:43)
+    HIP_TRY(h, hipMemsetAsync(&h->sc->lml_est, 0, sizeof(double), h->stream));
+    HIP_TRY(h, hipGetLastError());
+    h->epoch += 1;
+    h->initialized = true; h->has_prev = false; h->raw_valid = false; h->raw_sum_valid = false;
+    h->blk_last = 0;
+    mutated(h);
+    return GPF_OK;
+}
+gpf_status gpf_update_blocks_strata(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size, const double* values, int32_t n_strata, int32_t interleaved)
+{
+    gpf_status s = block_step_checks(h, block_size, "gpf_update_blocks_strata");
+    if (s) return s;
+    if ((s = check_ready(h))) return s;
+    if (!has_strata(h)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no discrete latent to stratify over");
+    if ((s = set_strata(h, values, n_strata, interleaved))) return s;
+    if ((s = materialize(h))) return s;
+    if ((s = set_block_obs(h, obs, n_obs, block_size))) return s;
+    const int grid = step_grid(h);
+    const bool keep = h->cfg.keep_prev != 0;
+    s = timed(h, GPF_K_STEP, [&] {
+        if (keep) { DISPATCH_MODEL(h, (launch_step_blk_strata<MM, true>(h, grid))); }
+        else      { DISPATCH_MODEL(h, (launch_step_blk_strata<MM, false>(h, grid))); }
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->max_valid = true;
+    h->cur ^= 1;
+    h->epoch += 1;
+    h->has_prev = true;
+    h->raw_valid = false; h->raw_sum_valid = false;
+    h->blk_last = 0;
     mutated(h);
     return GPF_OK;
 }

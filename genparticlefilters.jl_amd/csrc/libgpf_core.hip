@@ -761,7 +761,9 @@ gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double e
 }
 
 // stratified initialisation / update: the strata are values of the model's discrete latent
-static gpf_status set_strata(gpf_handle h, const double* values, int32_t n_strata, int32_t interleaved)
+} // extern "C"
+namespace gpfh {
+gpf_status set_strata(gpf_handle h, const double* values, int32_t n_strata, int32_t interleaved)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (!values || n_strata < 1 || n_strata > MAX_STRATA) return fail(h, GPF_ERR_INVALID_ARGUMENT, "need 1..8 strata");
@@ -771,6 +773,8 @@ static gpf_status set_strata(gpf_handle h, const double* values, int32_t n_strat
     h->args.logK = log_((double)n_strata);
     return GPF_OK;
 }
+} // namespace gpfh
+extern "C" {
 gpf_status gpf_initialize_strata(gpf_handle h, const double* obs, int32_t n_obs, const double* values, int32_t n_strata, int32_t interleaved)
 {
     gpf_status s = set_strata(h, values, n_strata, interleaved);

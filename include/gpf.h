@@ -196,6 +196,11 @@ gpf_status gpf_update_blocks(gpf_handle h, const double* obs, int32_t n_obs, int
  * use_proposal[b] != 0 extends block b with the model's native proposal (src/update.jl:79-96, gpf_update_proposal's), 0 with the default
  * one (src/update.jl:12-25).  use_proposal: HOST int32[n_blocks]. */
 gpf_status gpf_update_blocks_proposal(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size, const int32_t* use_proposal, int32_t proposal);
+/* stratified initialisation / update of every block by itself (src/initialize.jl:92-109, src/update.jl:193-210 on each sub-state, one launch):
+ * a particle's stratum follows from its index INSIDE its block and the block's own particle count (stratified_map!, src/utils.jl:29-55);
+ * values / n_strata / interleaved as in gpf_initialize_strata, the same strata for all blocks */
+gpf_status gpf_initialize_blocks_strata(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size, const double* values, int32_t n_strata, int32_t interleaved);
+gpf_status gpf_update_blocks_strata(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size, const double* values, int32_t n_strata, int32_t interleaved);
 gpf_status gpf_rejuvenate_blocks(gpf_handle h, int32_t method, int32_t n_iters, int32_t only_resampled, uint64_t* n_accepted);
 
 /* same, with log_priorities = priority_fn.(log_weights) evaluated by the caller (any closure):

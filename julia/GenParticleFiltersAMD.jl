@@ -215,6 +215,19 @@ function pf_update_blocks!(s::DeviceParticleFilterState, new_args::Tuple, argdif
     size(observations, 2) == cld(s.n_particles, block_size) || error("one observation column per block expected")
     _status(s, ccall((:gpf_update_blocks, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64), s.handle, observations, size(observations, 1), block_size)); s
 end
+# every block stratified by itself (src/initialize.jl:92-109 / src/update.jl:193-210 on each sub-state), one launch; strata: the values of the model's discrete latent
+function pf_initialize_blocks(model::NativeModel, model_args::Tuple, observations::Matrix{Float64}, strata::Vector{Float64}, n_particles::Int, block_size::Int; layout::Symbol=:contiguous, kw...)
+    state = DeviceParticleFilterState(model, n_particles; kw...)
+    size(observations, 2) == cld(n_particles, block_size) || error("one observation column per block expected")
+    _status(state, ccall((:gpf_initialize_blocks_strata, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64, Ptr{Cdouble}, Cint, Cint),
+                         state.handle, observations, size(observations, 1), block_size, strata, length(strata), layout == :interleaved ? 1 : 0))
+    return state
+end
+function pf_update_blocks!(s::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Matrix{Float64}, strata::Vector{Float64}, block_size::Int; layout::Symbol=:interleaved)
+    size(observations, 2) == cld(s.n_particles, block_size) || error("one observation column per block expected")
+    _status(s, ccall((:gpf_update_blocks_strata, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Int64, Ptr{Cdouble}, Cint, Cint),
+                     s.handle, observations, size(observations, 1), block_size, strata, length(strata), layout == :interleaved ? 1 : 0)); s
+end
 # "Update with different proposals per view" (test/update.jl:179-189) in one launch: use_proposal[b] = true extends block b with the model's native
 # proposal (LocallyOptimal for the LG-SSM: id 1; line_model's fixed proposals: id 2), false with the default one
 function pf_update_blocks!(s::DeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Matrix{Float64}, block_size::Int, use_proposal::Vector{Bool}, proposal_id::Int=1)

@@ -722,13 +722,16 @@ def resample_blocks(f: OracleFilter, nb: int, method: str = "multinomial", ess_f
     return np.array(mask)
 
 
-def update_blocks(f: OracleFilter, nb: int, obs_rows, proposals=None) -> None:
+def update_blocks(f: OracleFilter, nb: int, obs_rows, proposals=None, strata=None, layout: str = "interleaved") -> None:
     """for b in blocks: pf_update!(state[b], ..., observations[b][, proposal, proposal_args])   (per-view updates, also with different
     proposals per view, test/update.jl:179-189); proposals: one bool per block"""
     e = f.epoch
     for k, (a, b) in enumerate(blocks_of(f, nb)):
         f.epoch = e
-        f[a:b].update(np.asarray(obs_rows[k], np.float64), proposal=bool(proposals[k]) if proposals is not None else False)
+        if strata is not None:                                              # every block stratified by itself (update.jl:193-210 on the sub-state)
+            f[a:b].update(np.asarray(obs_rows[k], np.float64), strata=strata, layout=layout)
+        else:
+            f[a:b].update(np.asarray(obs_rows[k], np.float64), proposal=bool(proposals[k]) if proposals is not None else False)
     f.epoch = e + 1
 
 
@@ -745,11 +748,16 @@ def rejuvenate_blocks(f: OracleFilter, nb: int, obs_rows, method: str = "move", 
     return acc
 
 
-def initialize_blocks(f: OracleFilter, nb: int, obs_rows) -> OracleFilter:
-    """per-block initialisation (initialize.jl:39-41 on every sub-state with its own observation)"""
+def initialize_blocks(f: OracleFilter, nb: int, obs_rows, strata=None, layout: str = "contiguous") -> OracleFilter:
+    """per-block initialisation (initialize.jl:39-41 on every sub-state with its own observation; with strata: initialize.jl:92-109)"""
     for k, (a, b) in enumerate(blocks_of(f, nb)):
         rows = np.zeros((b - a, f.W)); lw = np.zeros(b - a)
-        lib().o_init(f.model, f.params, f.seed, f.epoch, a, b - a, f.W, np.ascontiguousarray(obs_rows[k], np.float64), rows, lw)
+        if strata is not None:
+            v = np.ascontiguousarray(strata, np.float64)
+            lib().o_init_strata(f.model, f.params, f.seed, f.epoch, a, b - a, f.W, np.ascontiguousarray(obs_rows[k], np.float64), v, v.size,
+                                int(layout != "contiguous"), olog(float(v.size)), rows, lw)
+        else:
+            lib().o_init(f.model, f.params, f.seed, f.epoch, a, b - a, f.W, np.ascontiguousarray(obs_rows[k], np.float64), rows, lw)
         f.rows[a:b] = rows; f.lw[a:b] = lw
     f.lml_est = 0.0; f.parents = np.arange(1, f.n + 1, dtype=np.int64)
     f.epoch += 1; f.has_prev = False

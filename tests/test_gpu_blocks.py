@@ -424,3 +424,38 @@ def test_reference_update_with_different_proposals_per_view_in_one_launch(g, o):
     oracle.update_blocks(f, 50, obs, proposals=[False, True])
     assert np.array_equal(rows, f.rows) and np.array_equal(lw, f.lw)
     st.close()
+
+
+@pytest.mark.parametrize("model_name,init_strata,upd_strata", [("object_motion", [0.0, 1.0], [0.0, 1.0]), ("line_model", [-2.0, -1.0, 0.0, 1.0, 2.0], [0.0, 1.0])])
+@pytest.mark.parametrize("N,nb", [(1000, 100), (1030, 100), (5000, 2300), (600, 7)])
+@pytest.mark.parametrize("layout", ["contiguous", "interleaved"])
+def test_per_block_strata(g, o, model_name, init_strata, upd_strata, N, nb, layout):
+    """stratified initialisation / update of every block by itself (src/initialize.jl:92-109, src/update.jl:193-210 on each sub-state, with
+    stratified_map! of src/utils.jl:29-55 over the block's own particles -- ragged last block, more strata than particles, both layouts) in one launch
+    each == the loop over sub-states, bit for bit"""
+    m = g.models.by_name(model_name)
+    B, T = (N + nb - 1) // nb, 4
+    rng = np.random.default_rng(3)
+    if model_name == "line_model":
+        ys = np.stack([[g.models.line_obs(t + 1, float(rng.integers(-2, 3))) for t in range(T)] for _ in range(B)])
+    else:
+        base = np.asarray(g.models.simulate(m, T))
+        ys = base[None, :, :] + 0.2 * rng.standard_normal((B,) + base.shape)
+    st = g.pf_initialize_blocks(m, (1,), ys[:, 0], N, nb, seed=13, keep_prev=True, strata=init_strata, layout=layout)
+    f = o.OracleFilter(m.model_id, m.params, N, 13, keep_prev=True)
+    o.initialize_blocks(f, nb, ys[:, 0], strata=init_strata, layout=layout)
+    assert same(st, f), "stratified initialisation per block"
+    for t in range(1, T):
+        g.pf_update_blocks(st, (t + 1,), (None,), ys[:, t], nb, strata=upd_strata, layout=layout)
+        o.update_blocks(f, nb, ys[:, t], strata=upd_strata, layout=layout)
+        assert same(st, f), ("stratified update per block", t)
+        n_res = g.pf_resample_blocks(st, nb, "residual", ess_frac=0.9, check=False)
+        assert n_res == oracle_blocks(f, nb, "residual", ess_frac=0.9).sum() and same(st, f)
+    with pytest.raises(g.ErrorException):
+        g.pf_update_blocks(st, (T + 1,), (None,), ys[:, 0], nb, strata=upd_strata, proposals=[None] * B)
+    st.close()
+    sv = g.pf_initialize_blocks(g.models.sv1(), (1,), np.zeros((2, 1)), 100, 50)
+    with pytest.raises(g.ErrorException):                                     # a model without a discrete latent
+        sv._check(sv._L.gpf_update_blocks_strata(sv._h, np.zeros(2).ctypes.data_as(g._lib.C.POINTER(g._lib.C.c_double)), 1, 50,
+                                                 np.zeros(2).ctypes.data_as(g._lib.C.POINTER(g._lib.C.c_double)), 2, 1))
+    sv.close()
