@@ -103,6 +103,8 @@ SYMBOLS = [
     ("gpf_comm_create", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
     ("gpf_comm_destroy", C.c_int, [_H]),
     ("gpf_comm_summary_mode", C.c_int, [_H, _pi32]),
+    ("gpf_shard_step_ess", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("gpf_comm_traffic", C.c_int, [_H, C.POINTER(C.c_int64), C.c_int32]),
     ("gpf_comm_set_plan", C.c_int, [_H, C.c_int32]),
     ("gpf_comm_plan", C.c_int, [_H, _pi32]),

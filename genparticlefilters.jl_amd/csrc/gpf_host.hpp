@@ -355,6 +355,8 @@ gpf_status check_ready(gpf_handle h, bool keep_pending_move = false);
 gpf_status set_obs(gpf_filter* h, const double* obs, int n_obs);
 gpf_status copy_out(gpf_handle h, const void* dsrc, void* out, size_t bytes);
 gpf_status set_strata(gpf_handle h, const double* values, int32_t n_strata, int32_t interleaved);
+gpf_status speculative_step(gpf_filter* h, const GateIn& gate);
+void speculative_step_done(gpf_filter* h, bool ran);
 // ---- defined in libgpf_resample.hip
 // one scan launch on descriptor channel `ch` (0 weights, 1 residual counts, 2 residual weights): the sharded weight scans (MODE 3: pushes
 // the shard's total itself; 4: also the limbs of sum q^2) and the scans of pf_optimal_resize!
@@ -371,6 +373,7 @@ bool sum_host_ok(const gpf_filter* h);
 gpf_status sum_host_launch(gpf_filter* h, const double* thr);
 gpf_status sum_host_fold(gpf_filter* h, const double* thr, int* go_out = nullptr);
 gpf_status sum_gate_check(gpf_filter* h, int host_go);
+gpf_status shard_sum_launch(gpf_filter* h, const ShardSum& ss, bool* ok);
 gpf_status wait_ticket(gpf_filter* h, volatile int64_t* tk, int64_t want, const char* what);
 gpf_status check_scan_timeout(gpf_filter* h);
 gpf_status fetch_scalars(gpf_filter* h, bool fold_raw_q = false);

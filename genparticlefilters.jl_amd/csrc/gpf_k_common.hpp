@@ -281,7 +281,8 @@ __device__ __forceinline__ void sorted_gamma_tile(const SortedGammaJob& j, int64
 // by k_sum_host's last-arriving workgroup (+6 us on the reduction), a fold of per-workgroup lines by every workgroup of the propagate
 // through LDS (+3.5 us on the propagate), by every wave (12 loads per lane: +10 us).
 constexpr int GATE_SLOTS = 8, GATE_WORDS = GATE_SLOTS * 8;
-struct GateIn { const uint64_t* acc; double thr; int32_t* go_dev; int64_t* h_gate; int64_t ticket; };
+struct GateIn { const uint64_t* acc; double thr; int32_t* go_dev; int64_t* h_gate; int64_t ticket;
+                const int32_t* flag; };     // flag != nullptr (sharded filters: the verdict needs the GLOBAL sums, k_sum_reduce<SHARD> formed it): just read it
 __device__ __forceinline__ bool gate_verdict(const GateIn& g)
 {
     static_assert(GATE_WORDS == WAVE, "one accumulator word per lane");

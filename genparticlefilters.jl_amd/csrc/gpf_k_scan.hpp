@@ -411,12 +411,33 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
 // {S low 31 bits, S high bits, limb sums of Q} as TAGGED words (tag << 48 | sum, relaxed agent-scope stores, as the scan's ESS
 // partials: a workgroup folds <= Q_TAG_MAX_TILES tiles); workgroup 0 waits for this launch's tags, folds, fills ws_out and publishes
 // {flags, S, limbs, ticket, check word} to pinned host memory (the scan's format: gpf_effective_sample_size reads either).
-static __global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int64_t n, int64_t ntiles, const unsigned long long* __restrict__ slots,
+// SHARD (round 5: the ESS / log-ML getters of a sharded filter, gpf_shard_effective_sample_size, and the verdict of gpf_shard_step_ess): the
+// maximum and the flags come from the np gathered (max, flags) pairs of the shards (as k_scan MODE 3 / 4), the sums are taken under that GLOBAL
+// maximum; workgroup 0, once it has folded this shard's {S, limbs of sum q^2}, pushes them to every peer's mailbox, waits for the peers' entries,
+// folds the GLOBAL summary and publishes THAT to pinned memory ({flags, S, limbs, ticket, check word}: the host polls, no copy, no stream
+// synchronisation) -- and leaves the verdict ESS < thr in *go for a propagate enqueued speculatively behind this launch (thr < 0: none).
+struct ShardSum {
+    const double* mf_all; int np; MboxWait wait_mf;                // the gathered (max, flags) pairs (in the own mailbox)
+    MboxPush push_tot; MboxWait wait_tot; const int64_t* tot_all;  // this round's {S, Ql0..3} entries: pushed to the peers / gathered in the own mailbox
+    int G, me; double thr; int32_t* go;
+};
+template <bool SHARD>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int64_t n, int64_t ntiles, const unsigned long long* __restrict__ slots,
                                                            WSum* __restrict__ ws_out, uint64_t* __restrict__ part, int64_t* __restrict__ q_host,
-                                                           int64_t q_ticket, int32_t* __restrict__ timeout)
+                                                           int64_t q_ticket, int32_t* __restrict__ timeout, ShardSum ss)
 {
     double m; int f;
-    fold_slots(slots, m, f);
+    if constexpr (SHARD) {
+        mbox_wait_block(ss.wait_mf);
+        const int g = lane_id();
+        const bool mb = ss.wait_mf.tags != nullptr;
+        m = g < ss.np ? ld_gathered(ss.mf_all + 2 * g, mb) : -__builtin_huge_val();
+        f = g < ss.np ? (int)ld_gathered(ss.mf_all + 2 * g + 1, mb) : 0;
+        m = wave_max_f64(m);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
+        if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+    } else fold_slots(slots, m, f);
     in.m = m; in.flags = f;
     const int lane = lane_id(), wv = wave_id();
     uint64_t acc[6] = {0, 0, 0, 0, 0, 0};             // S, (unused), Ql0..3
@@ -477,13 +498,45 @@ static __global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int
         const uint64_t S = t[0] + (t[1] << 31);
         ws_out->m = m; ws_out->flags = f; ws_out->S = S;
         for (int k = 0; k < 4; ++k) ws_out->Ql[k] = t[2 + k];
-        if (q_host) {
+        if constexpr (SHARD) { s_p[0][0] = S; for (int k = 0; k < 4; ++k) s_p[0][1 + k] = t[2 + k]; }
+        else if (q_host) {
             __hip_atomic_store(q_host + 0, (int64_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(q_host + 1, (int64_t)S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             uint64_t chk = (uint64_t)q_ticket ^ (uint64_t)(int64_t)f ^ S;
             for (int k = 0; k < 4; ++k) { __hip_atomic_store(q_host + 2 + k, (int64_t)t[2 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); chk ^= t[2 + k]; }
             __hip_atomic_store(q_host + 7, (int64_t)chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(q_host + 6, q_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if constexpr (SHARD) {
+        // ---- this shard's {S, limbs} to every peer; the peers' entries back; the GLOBAL summary to the host (and the verdict to the device)
+        __syncthreads();
+        if (wv == 0) {
+            const uint64_t words[5] = {s_p[0][0], s_p[0][1], s_p[0][2], s_p[0][3], s_p[0][4]};
+            mbox_push_wave(ss.push_tot, words);
+        }
+        mbox_wait_block(ss.wait_tot);
+        if (wv == 0) {
+            const bool mb = ss.wait_tot.tags != nullptr;
+            uint64_t g5[5] = {0, 0, 0, 0, 0};
+            if (lane < ss.G) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) g5[k] = lane == ss.me ? s_p[0][k] : (uint64_t)ld_gathered(ss.tot_all + 5 * lane + k, mb);   // (the own entry: what was just pushed)
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) g5[k] = wave_sum_u64(g5[k]);
+            if (lane == 0) {
+                const uint64_t Sg = g5[0];
+                const uint64_t lo = g5[1] + (g5[2] << 32);
+                const uint64_t hi = (g5[2] >> 32) + g5[3] + (g5[4] << 32) + (lo < g5[1] ? 1u : 0u);
+                if (ss.go) *ss.go = ss.thr >= 0.0 && !f && ess_from(Sg, hi, lo) < ss.thr ? 1 : 0;
+                __hip_atomic_store(q_host + 0, (int64_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(q_host + 1, (int64_t)Sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                uint64_t chk = (uint64_t)q_ticket ^ (uint64_t)(int64_t)f ^ Sg;
+                for (int k = 0; k < 4; ++k) { __hip_atomic_store(q_host + 2 + k, (int64_t)g5[1 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); chk ^= g5[1 + k]; }
+                __hip_atomic_store(q_host + 7, (int64_t)chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(q_host + 6, q_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

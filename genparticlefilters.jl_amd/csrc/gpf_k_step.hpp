@@ -173,7 +173,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step(ModelArgs a, uint64_t seed, u
     // a speculative propagate behind the ESS reduction (gpf_step_ess): every wave forms the verdict from the reduction's accumulators and
     // returns before its first store if the filter resamples first (kernel-uniform)
 #ifndef GPF_NO_GATE
-    if constexpr (!GATHER && !PACKED) { if (pc.gate.acc && gate_verdict(pc.gate)) return; }
+    if constexpr (!GATHER && !PACKED) {
+        if (pc.gate.flag) { if (*pc.gate.flag) return; }
+        else if (pc.gate.acc && gate_verdict(pc.gate)) return;
+    }
 #endif
     double bm = -__builtin_huge_val(); int bf = 0;
     if constexpr (PACKED || GATHER) {

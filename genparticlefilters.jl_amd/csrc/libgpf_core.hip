@@ -680,6 +680,36 @@ gpf_status gpf_update_proposal(gpf_handle h, const double* obs, int32_t n_obs, i
     return update_impl(h, obs, n_obs, 1);
 }
 
+} // extern "C"
+namespace gpfh {
+// the plain propagate of the current observation (h->args), enqueued behind a launch that leaves an ESS verdict on the device: it returns
+// before its first store when the verdict says "resample first" (gpf_step_ess, gpf_shard_step_ess)
+gpf_status speculative_step(gpf_filter* h, const GateIn& gate)
+{
+    const int grid = step_grid(h);
+    const bool keep = h->cfg.keep_prev != 0;
+    gpf_status s = timed(h, GPF_K_STEP, [&] {
+        if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true>(h, grid, &gate))); }
+        else      { DISPATCH_MODEL(h, (launch_step_t<MM, false>(h, grid, &gate))); }
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+// ran = true: it was the step's pf_update! (update_impl's bookkeeping); false: it returned without touching anything -- its maximum slots go back
+void speculative_step_done(gpf_filter* h, bool ran)
+{
+    if (!ran) { h->mcur ^= 1; return; }
+    h->max_valid = true;
+    h->cur ^= 1;                        // update_refs! (utils.jl:10-15)
+    h->epoch += 1;
+    h->has_prev = true;
+    h->raw_valid = false; h->raw_sum_valid = false;
+    mutated(h);
+}
+} // namespace gpfh
+extern "C" {
+
 // One iteration of the reference's README loop (README.md:66-77) in one call:
 //     if effective_sample_size(state) < ess_frac * N;  pf_resample!(state, method);  pf_rejuvenate!(state, kern, ...);  end
 //     pf_update!(state, new_args, argdiffs, observations)
@@ -723,15 +753,8 @@ gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double e
     const ModelArgs old_args = h->args;                          // (a rejuvenation moves under the CURRENT step's observation)
     if ((s = sum_host_launch(h, &thr))) return s;
     if ((s = set_obs(h, obs, n_obs))) { h->args = old_args; return s; }
-    const int grid = step_grid(h);
-    const bool keep = h->cfg.keep_prev != 0;
-    const GateIn gate{h->gate_part + h->gate_cur * GATE_WORDS, thr, &h->sc->gate_go, h->h_gate, h->q_ticket};
-    s = timed(h, GPF_K_STEP, [&] {
-        if (keep) { DISPATCH_MODEL(h, (launch_step_t<MM, true>(h, grid, &gate))); }
-        else      { DISPATCH_MODEL(h, (launch_step_t<MM, false>(h, grid, &gate))); }
-    });
-    if (s) return s;
-    HIP_TRY(h, hipGetLastError());
+    const GateIn gate{h->gate_part + h->gate_cur * GATE_WORDS, thr, &h->sc->gate_go, h->h_gate, h->q_ticket, nullptr};
+    if ((s = speculative_step(h, gate))) return s;
     int go = 0;
     if ((s = sum_host_fold(h, &thr, &go))) return s;
     if (ess_out) {
@@ -740,18 +763,12 @@ gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double e
         *ess_out = h->sum_cache.flags ? std::nan("") : ess_from(h->sum_cache.S, hi, lo);
     }
     if (!go) {
-        // the speculative propagate WAS the step's pf_update! (update_impl's bookkeeping)
-        h->max_valid = true;
-        h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
-        h->epoch += 1;
-        h->has_prev = true;
-        h->raw_valid = false; h->raw_sum_valid = false;
-        mutated(h);
+        speculative_step_done(h, true);                          // the speculative propagate WAS the step's pf_update!
         return sum_gate_check(h, go);
     }
     // the propagate returned without touching anything: take its maximum slots back, restore the step's observation, and run the sequence
     // from the resample on -- the summary is with the host as after effective_sample_size(state) (a :residual resample skips its weight scan)
-    h->mcur ^= 1;
+    speculative_step_done(h, false);
     h->args = old_args;
     if ((s = gpf_resample(h, resample_method, std::nan(""), sort_particles, check, invalid))) return s;
     if (resampled) *resampled = 1;

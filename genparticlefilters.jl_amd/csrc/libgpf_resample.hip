@@ -197,8 +197,8 @@ gpf_status ensure_raw_summary(gpf_filter* h, bool want_q, bool* done)
     h->q_ticket += 1;
     InFixQ in{raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
     s = timed(h, GPF_K_SCAN, [&] {
-        GPF_LAUNCH(k_sum_reduce, dim3(grid), dim3(SCAN_BLOCK), 0, h->stream, in, h->n, h->ntiles, h->mslots[h->mcur], &h->sc->raw, h->sum_part, h->h_qpub,
-                   h->q_ticket, h->h_timeout);
+        GPF_LAUNCH(k_sum_reduce<false>, dim3(grid), dim3(SCAN_BLOCK), 0, h->stream, in, h->n, h->ntiles, h->mslots[h->mcur], &h->sc->raw, h->sum_part, h->h_qpub,
+                   h->q_ticket, h->h_timeout, ShardSum{});
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
@@ -311,6 +311,30 @@ gpf_status sum_gate_check(gpf_filter* h, int host_go)
         if ((s = check_scan_timeout(h))) return s;
         if (host_go != (int)(gv & 1)) return fail(h, GPF_ERR_HIP, "ESS gate: the device's verdict differs from the host's (state may be inconsistent)");
     }
+    return GPF_OK;
+}
+
+// the sharded getters' reduction (k_sum_reduce<SHARD>): launched on behalf of libgpf_shard.hip, which fills the mailbox rounds; false in *ok:
+// the filter is too large for the tagged partials (the caller takes the scan + copies)
+gpf_status shard_sum_launch(gpf_filter* h, const ShardSum& ss, bool* ok)
+{
+    *ok = false;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, (int64_t)h->n_cu * 4));
+    if ((h->ntiles + grid - 1) / grid > Q_TAG_MAX_TILES) return GPF_OK;
+    if (!h->sum_part) {
+        HIP_TRY(h, hipMalloc(&h->sum_part, (size_t)6 * 4 * h->n_cu * sizeof(uint64_t)));
+        HIP_TRY(h, hipMemsetAsync(h->sum_part, 0, (size_t)6 * 4 * h->n_cu * sizeof(uint64_t), h->stream));
+    }
+    if (!h->h_qpub) { HIP_TRY(h, hipHostMalloc(&h->h_qpub, 8 * sizeof(int64_t))); for (int i = 0; i < 8; ++i) h->h_qpub[i] = 0; }
+    h->q_ticket += 1;
+    InFixQ in{raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
+    gpf_status s = timed(h, GPF_K_SCAN, [&] {
+        GPF_LAUNCH(k_sum_reduce<true>, dim3(grid), dim3(SCAN_BLOCK), 0, h->stream, in, h->n, h->ntiles, h->mslots[h->mcur], &h->sc->raw, h->sum_part, h->h_qpub,
+                   h->q_ticket, h->h_timeout, ss);
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    *ok = true;
     return GPF_OK;
 }
 

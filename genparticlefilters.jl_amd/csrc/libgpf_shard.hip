@@ -956,6 +956,70 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     return GPF_OK;
 }
 
+
+} // extern "C"
+namespace {
+gpf_status shard_global_summary_launch(gpf_filter* h, double thr, bool* done);
+bool shard_sum_fits(const gpf_filter* h);
+} // namespace
+extern "C" {
+// One iteration of the README loop (README.md:66-77) on a sharded filter, one call per rank (every rank calls it, like gpf_shard_resample):
+//     if effective_sample_size(state) < ess_frac * N_global;  pf_resample!(state, method);  pf_rejuvenate!(state, ...);  end;  pf_update!(state, ...)
+// The verdict needs the GLOBAL sums: the summary reduction (k_sum_reduce<SHARD>) exchanges the shard totals through the mailboxes, leaves the
+// verdict on the device and the global summary in pinned memory; the propagate runs speculatively behind it (as gpf_step_ess).
+// Every rank folds the same global integers: all ranks take the same branch.  Without mailboxes / with pending work: the plain sequence.
+gpf_status gpf_shard_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double ess_frac, int32_t method, int32_t check,
+                              int32_t rejuvenate_method, int32_t n_iters, int32_t* resampled, int32_t* invalid)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_shard_step_ess needs gpf_comm_create first");
+    if (!(ess_frac == ess_frac) || ess_frac < 0.0) return fail(h, GPF_ERR_INVALID_ARGUMENT, "ess_frac must be >= 0");
+    if (rejuvenate_method >= 0 && rejuvenate_method != GPF_REJUVENATE_MOVE && rejuvenate_method != GPF_REJUVENATE_REWEIGHT)
+        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Method not recognized.");                        // rejuvenate.jl:25
+    if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED && method != GPF_RESAMPLE_MULTINOMIAL_SORTED)
+        return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");             // resample.jl:28
+    if (rejuvenate_method >= 0 && !h->cfg.keep_prev) return fail(h, GPF_ERR_STATE, "gpf_rejuvenate needs keep_prev = 1 (x_{t-1} must travel with the particle)");
+    if (resampled) *resampled = 0;
+    if (invalid) *invalid = 0;
+    static const bool spec_off = getenv("GPF_STEP_SPECULATE") && !strcmp(getenv("GPF_STEP_SPECULATE"), "0");
+    // one shard without a communicator IS the unsharded filter (n_global == n): the unsharded call, sort_particles = false
+    if (!spec_off && h->comm_world == 1 && !h->comm && !h->pending_packed)
+        return gpf_step_ess(h, obs, n_obs, ess_frac, method, 0, check, rejuvenate_method, n_iters, resampled, invalid, nullptr);
+    const double thr = ess_frac * (double)h->cfg.n_global;
+    const bool fast = !spec_off && h->mb_active && shard_sum_fits(h) && !h->pending_packed && !h->pending_gather && !h->pending_fill && !h->pending_move &&
+                      !h->hist_on && h->blk_obs_size == 0 && obs != nullptr && n_obs == model_obs_dim(h->cfg.model);
+    if (!fast) {
+        double ess = 0.0;
+        if ((s = gpf_shard_effective_sample_size(h, &ess))) return s;
+        if (ess < thr) {
+            if ((s = shard_resample_impl(h, method, std::nan(""), check, invalid))) return s;
+            if (resampled) *resampled = 1;
+            if (rejuvenate_method >= 0 && (s = gpf_rejuvenate(h, rejuvenate_method, n_iters, nullptr))) return s;
+        }
+        return gpf_update(h, obs, n_obs);
+    }
+    const ModelArgs old_args = h->args;                          // (a rejuvenation moves under the CURRENT step's observation)
+    bool done = false;
+    if ((s = shard_global_summary_launch(h, thr, &done))) return s;
+    if (!done) return fail(h, GPF_ERR_STATE, "sharded summary not available");
+    if ((s = set_obs(h, obs, n_obs))) { h->args = old_args; return s; }
+    GateIn gate{}; gate.flag = &h->sc->gate_go;
+    if ((s = speculative_step(h, gate))) return s;
+    WSum w{};
+    if ((s = read_published_summary(h, w))) return s;
+    uint64_t hi, lo;
+    normalise_Q(w, hi, lo);
+    const bool go = !w.flags && ess_from(w.S, hi, lo) < thr;     // (the device's verdict: the same integers through the same operations)
+    if (!go) { speculative_step_done(h, true); return GPF_OK; }
+    speculative_step_done(h, false);
+    h->args = old_args;
+    if ((s = shard_resample_impl(h, method, std::nan(""), check, invalid))) return s;
+    if (resampled) *resampled = 1;
+    if (rejuvenate_method >= 0 && (s = gpf_rejuvenate(h, rejuvenate_method, n_iters, nullptr))) return s;
+    return gpf_update(h, obs, n_obs);
+}
+
 gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid)
 {
     return shard_resample_impl(h, method, std::nan(""), check, invalid);
@@ -967,12 +1031,70 @@ gpf_status gpf_shard_resample_tempered(gpf_handle h, int32_t method, double prio
 }
 
 
+} // extern "C"
+namespace {
+// The GLOBAL weight summary {flags, S, sum q^2} on the host without a scan, a copy or a stream synchronisation (the getters of an
+// ESS-triggered sharded filter run on every step: through shard_summary + shard_scalars one read cost ~85 us of kernels, copies and idle GPU
+// on one rank).  One shard without a communicator IS the unsharded filter: its own reduction (k_sum_host).  With the mailboxes up: (max,
+// flags) to the peers (k_pack_mflags), then ONE reduction launch whose workgroup 0 exchanges the shard totals through the mailboxes, folds
+// the global summary and publishes it to pinned memory (k_sum_reduce<SHARD>); thr >= 0: it also leaves the verdict ESS < thr on the device.
+// *done = false: not available (RCCL all-gathers carry the summaries, or the filter is too large): the caller takes shard_summary.
+gpf_status shard_global_summary_launch(gpf_filter* h, double thr, bool* done);
+gpf_status shard_global_summary(gpf_filter* h, double thr, WSum& w, bool* done)
+{
+    gpf_status s = shard_global_summary_launch(h, thr, done);
+    if (s || !*done) return s;
+    if ((s = read_published_summary(h, w))) return s;
+    return GPF_OK;
+}
+gpf_status shard_global_summary_launch(gpf_filter* h, double thr, bool* done)
+{
+    *done = false;
+    gpf_status s;
+    if (!h->mb_active || !h->h_timeout) return GPF_OK;
+    EngineScope engine(h);
+    if ((s = shard_scratch(h))) return s;
+    const int r = (int)(h->sh_round++ % SH_RING);
+    double* mf = h->sh_mf + 2 * r;
+    if ((s = gpf_shard_weight_max(h, mf))) return s;             // maximum slots -> (max, flags) -> every peer's mailbox (MB_MF round)
+    ShardSum ss{};
+    ss.mf_all = static_cast<const double*>(mb_gathered(h, MB_MF)); ss.np = h->comm_world; ss.wait_mf = mb_wait(h, MB_MF);
+    ss.push_tot = mb_begin(h, MB_TOT); ss.wait_tot = mb_wait(h, MB_TOT); ss.tot_all = static_cast<const int64_t*>(mb_gathered(h, MB_TOT));
+    ss.G = h->comm_world; ss.me = h->comm_rank; ss.thr = thr; ss.go = &h->sc->gate_go;
+    bool ok = false;
+    if ((s = shard_sum_launch(h, ss, &ok))) return s;
+    if (!ok) return fail(h, GPF_ERR_STATE, "sharded summary: the filter is too large for the reduction's tagged partials");   // (the rounds are begun: no way back to the scan)
+    h->cur_mf_all = ss.mf_all; h->cur_tot_all = ss.tot_all;
+    h->raw_valid = false; h->raw_sum_valid = false;              // (sc->raw holds this shard's sums under the GLOBAL maximum: not the unsharded summary)
+    *done = true;
+    return GPF_OK;
+}
+bool shard_sum_fits(const gpf_filter* h)
+{
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, (int64_t)h->n_cu * 4));
+    return (h->ntiles + grid - 1) / grid <= Q_TAG_MAX_TILES;
+}
+} // namespace
+extern "C" {
 gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
     if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "needs gpf_comm_create first");
+    static const bool fast_off = getenv("GPF_SHARD_GETTERS") && !strcmp(getenv("GPF_SHARD_GETTERS"), "scan");      // (A/B measurements, tests of the scan + copy path)
+    if (!fast_off && h->comm_world == 1 && !h->comm && !h->pending_packed) return gpf_effective_sample_size(h, out);   // one shard IS the unsharded filter
+    if (!fast_off && h->mb_active && shard_sum_fits(h)) {
+        if ((s = materialize(h))) return s;
+        WSum w{}; bool done = false;
+        if ((s = shard_global_summary(h, -1.0, w, &done))) return s;
+        if (done) {
+            uint64_t hi, lo;
+            normalise_Q(w, hi, lo);
+            *out = w.flags ? std::nan("") : ess_from(w.S, hi, lo);
+            return GPF_OK;
+        }
+    }
     EngineScope engine(h);
     if ((s = shard_summary(h, 1))) return s;
     double m; int flags; uint64_t S, Qhi, Qlo;
@@ -987,6 +1109,8 @@ gpf_status gpf_shard_log_ml_estimate(gpf_handle h, double* out)
     if (s) return s;
     if (!out) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null out");
     if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "needs gpf_comm_create first");
+    static const bool fast_off = getenv("GPF_SHARD_GETTERS") && !strcmp(getenv("GPF_SHARD_GETTERS"), "scan");
+    if (!fast_off && h->comm_world == 1 && !h->comm && !h->pending_packed) return gpf_log_ml_estimate(h, out);   // one shard IS the unsharded filter
     EngineScope engine(h);
     if ((s = shard_summary(h, 0))) return s;
     double m; int flags; uint64_t S, Qhi, Qlo;

@@ -214,6 +214,14 @@ class HipShardBackend:
             self._ck(self.L.gpf_shard_resample_tempered(self.h, method_id, float(alpha), chk, C.byref(inv) if chk else None))
         return bool(inv.value)
 
+    def shard_step_ess(self, obs, ess_frac: float, method_id: int, check, rejuv_id: int, n_iters: int):
+        """gpf_shard_step_ess: one README-loop iteration on this rank's shard; returns (resampled, invalid)"""
+        chk = 2 if check is True else (1 if check == "warn" else 0)
+        res, inv = C.c_int32(0), C.c_int32(0)
+        self._ck(self.L.gpf_shard_step_ess(self.h, obs.ctypes.data, obs.size, float(ess_frac), method_id, chk, rejuv_id, int(n_iters),
+                                           C.byref(res), C.byref(inv) if chk else None))
+        return bool(res.value), bool(inv.value)
+
     def shard_ess(self) -> float:
         out = C.c_double()
         self._ck(self.L.gpf_shard_effective_sample_size(self.h, C.byref(out)))
@@ -421,6 +429,39 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
     back = state._all_to_all(buf[:sum(sc)], sc, rc)                   # the exchange: [row | slot | ancestor id]
     b.commit(back, mf_all, tot_all)                                   # phase 5: scatter by slot, weights, log-ML
     return state
+
+
+def pf_step_ess(state: ShardedParticleFilterState, new_args, argdiffs, observations, *, ess_threshold: float = 0.5, method: str = "multinomial",
+                rejuvenate=None, n_iters: int = 1, check="warn") -> bool:
+    """One iteration of the reference's README loop (README.md:66-77) on the sharded filter, called on every rank:
+
+        if effective_sample_size(state) < ess_threshold * n_global;  pf_resample!(state, method);  pf_rejuvenate!(state, ...; method = rejuvenate);  end
+        pf_update!(state, new_args, argdiffs, observations)
+
+    Library engine: ONE C-ABI call (gpf_shard_step_ess: the summary reduction exchanges the shard totals through the mailboxes and leaves the
+    verdict on the device, the propagate runs speculatively behind it); python engine: the separate calls.  Returns whether it resampled."""
+    if method not in RESAMPLE_METHODS:
+        raise ErrorException(f"Resampling method {method} not recognized.")
+    if rejuvenate is not None and rejuvenate not in ("move", "reweight"):
+        raise ErrorException(f"Method {rejuvenate} not recognized.")
+    b = state.backend
+    if getattr(b, "lib_comm", False):
+        try:
+            res, invalid = b.shard_step_ess(_obs_vector(observations), ess_threshold, RESAMPLE_METHODS[method], check,
+                                            -1 if rejuvenate is None else (0 if rejuvenate == "move" else 1), n_iters)
+        except ErrorException as e:
+            raise ErrorException("Invalid weights.") if "Invalid weights" in str(e) else e
+        if invalid and check == "warn":
+            import warnings
+            warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")
+        return res
+    go = effective_sample_size(state) < ess_threshold * state.n_global
+    if go:
+        pf_resample(state, method, check=check)
+        if rejuvenate is not None:
+            pf_rejuvenate(state, None, (), n_iters, method=rejuvenate)
+    pf_update(state, new_args, argdiffs, observations)
+    return bool(go)
 
 
 def effective_sample_size(state: ShardedParticleFilterState) -> float:

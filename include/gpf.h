@@ -453,6 +453,13 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
  * Three summary rounds instead of one and one more double (log_ws) per exchanged entry; the result is bit-identical to
  * gpf_resample(h, method, priority_alpha, ...) on the unsharded filter.  sort_particles stays unavailable across shards. */
 gpf_status gpf_shard_resample_tempered(gpf_handle h, int32_t method, double priority_alpha, int32_t check, int32_t* invalid);
+/* gpf_step_ess on a sharded filter -- one iteration of the README loop (README.md:66-77), called on every rank like gpf_shard_resample:
+ *     if effective_sample_size(state) < ess_frac * N_global;  pf_resample!(state, method);  pf_rejuvenate!(state, ...; method);  end;  pf_update!(state, ...)
+ * with the GLOBAL effective sample size; the same results as the separate calls (gpf_shard_effective_sample_size, gpf_shard_resample,
+ * gpf_rejuvenate, gpf_update) on every rank.  With the shard mailboxes up, the summary is ONE reduction launch that exchanges the shard totals
+ * itself and leaves the verdict on the device, the propagate runs speculatively behind it.  rejuvenate_method < 0: none. */
+gpf_status gpf_shard_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double ess_frac, int32_t method, int32_t check,
+                              int32_t rejuvenate_method, int32_t n_iters, int32_t* resampled, int32_t* invalid);
 gpf_status gpf_shard_effective_sample_size(gpf_handle h, double* out);
 gpf_status gpf_shard_log_ml_estimate(gpf_handle h, double* out);
 

@@ -436,6 +436,22 @@ function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multi
     check === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
     return s
 end
+"one iteration of the README loop on the sharded filter, every rank calls it (gpf.h gpf_shard_step_ess; the unsharded pf_step_ess! with the GLOBAL effective sample size)"
+function pf_step_ess!(s::ShardedDeviceParticleFilterState, new_args::Tuple, argdiffs::Tuple, observations::Vector{Float64}; ess_threshold::Real=0.5,
+                      method::Symbol=:multinomial, rejuvenate::Union{Nothing,Symbol}=nothing, n_iters::Int=1, check=:warn)
+    mid = method == :multinomial ? 0 : method == :residual ? 1 : method == :stratified ? 2 : method == :multinomial_sorted ? 4 : error("Resampling method $method not recognized.")
+    rid = rejuvenate === nothing ? -1 : rejuvenate == :move ? 0 : rejuvenate == :reweight ? 1 : error("Method $rejuvenate not recognized.")
+    chk = check === true ? 2 : (check === :warn ? 1 : 0)
+    resampled = Ref{Cint}(0); invalid = Ref{Cint}(0)
+    GC.@preserve resampled invalid begin
+        st = ccall((:gpf_shard_step_ess, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{Cint}),
+                   s.handle, observations, length(observations), Float64(ess_threshold), mid, chk, rid, n_iters,
+                   Base.unsafe_convert(Ptr{Cint}, resampled), chk == 0 ? Ptr{Cint}(C_NULL) : Base.unsafe_convert(Ptr{Cint}, invalid))
+    end
+    _status(s, st)
+    check === :warn && invalid[] != 0 && @warn("Invalid weights: resampled with uniform weights.")
+    return resampled[] != 0
+end
 """exchange plan of the i.i.d. resamplers across shards: :push (default) or :pull (gpf.h gpf_comm_set_plan); the same on every rank"""
 function shard_plan!(s::ShardedDeviceParticleFilterState, plan::Symbol)
     plan in (:push, :pull) || error("exchange plan :$plan: :push or :pull")

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out_dir):
+def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out_dir, one_call=False):
     import torch.distributed as dist
     import gpf_amd as g
     from gpf_amd import sharded
@@ -24,6 +24,12 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
                                    backend_factory=OracleShardBackend)
         ess_log, lml_log = [], []
         for t in range(1, T):
+            if one_call:                                     # sharded.pf_step_ess: the loop body as one call (python engine: the same sequence)
+                ess_log.append(float("nan"))
+                sharded.pf_step_ess(st, (t + 1,), (None,), ys[t], ess_threshold=1.1 if ess_frac is None else ess_frac, method=method,
+                                    rejuvenate=None if rejuv in (None, "keep") else rejuv, check=False)
+                lml_log.append(sharded.get_lml_est(st))
+                continue
             ess = sharded.get_ess(st)
             ess_log.append(ess)
             if ess_frac is None or ess < ess_frac * n_global:

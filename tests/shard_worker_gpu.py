@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out_dir, backend="gloo", engine=None):
+def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out_dir, backend="gloo", engine=None, one_call=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     if engine:
         os.environ["GPF_SHARD_ENGINE"] = engine            # "library": gpf_shard_resample (libgpf's own RCCL communicator); "python": sharded.py composes the phases
@@ -32,6 +32,12 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
         assert st.backend.lib_comm == (os.environ.get("GPF_SHARD_ENGINE", "python" if backend == "gloo" else "library") == "library")
         ess_log, lml_log = [], []
         for t in range(1, T):
+            if one_call:                                         # the loop body as ONE call per rank (gpf_shard_step_ess): no separate ESS read
+                ess_log.append(float("nan"))
+                sharded.pf_step_ess(st, (t + 1,), (None,), ys[t], ess_threshold=1.1 if ess_frac is None else ess_frac, method=method,
+                                    rejuvenate=None if rejuv in (None, "keep") else rejuv, check=False)
+                lml_log.append(sharded.get_lml_est(st))
+                continue
             ess = sharded.get_ess(st); ess_log.append(ess)
             if ess_frac is None or ess < ess_frac * n_global:
                 sharded.pf_resample(st, method, check=False)

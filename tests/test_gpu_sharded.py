@@ -16,10 +16,10 @@ import shard_worker  # noqa: E402
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
-def test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=2):
+def test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=2, one_call=False):
     model_name, method, n_global, T, ess_frac, rejuv = case
     n_global *= 20                       # a few scan tiles per shard
-    mp.spawn(shard_worker_gpu.run, args=(world, free_port(), model_name, method, n_global, T, ess_frac, rejuv, str(tmp_path)),
+    mp.spawn(shard_worker_gpu.run, args=(world, free_port(), model_name, method, n_global, T, ess_frac, rejuv, str(tmp_path), "gloo", None, one_call),
              nprocs=world, join=True)
     f, ess_log, lml_log = single(g, o, model_name, method, n_global, T, ess_frac, rejuv)
     parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
@@ -28,7 +28,46 @@ def test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=2):
     assert np.array_equal(parents, f.parents)
     assert np.array_equal(rows, f.rows) and np.array_equal(lw, f.lw)
     for p in parts:
-        assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
+        assert (one_call or np.array_equal(p["ess"], ess_log)) and np.array_equal(p["lml"], lml_log)
+
+
+@pytest.mark.parametrize("mode", ["mailbox", "rccl", "python"])
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", [CASES[3], CASES[5], CASES[4], CASES[0], CASES[7]], ids=lambda c: f"{c[0]}-{c[1]}-{c[4]}-{c[5]}")
+def test_sharded_step_ess_equals_single_oracle(g, o, tmp_path, monkeypatch, loopback_lib, case, world, mode):
+    """gpf_shard_step_ess / sharded.pf_step_ess -- one README-loop iteration per call on every rank, the GLOBAL ESS verdict formed by the summary
+    reduction after it has exchanged the shard totals through the mailboxes (k_sum_reduce<SHARD>), the propagate speculatively behind it: ESS-triggered
+    residual / stratified + MH on the bearings model (BASELINE configs[3]'s loop), resample-every-step cases (threshold 1.1), 2 - 3 ranks on one GPU.
+    mailbox: the fast path; rccl: summaries through all-gathers -> the plain sequence inside the call; python: the python engine's sequence.
+    Bit-identical to the single-shard oracle run of the same loop."""
+    if mode != "python":
+        monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+        if mode == "rccl":
+            monkeypatch.setenv("GPF_SHARD_SUMMARY", "rccl")
+    else:
+        monkeypatch.setenv("GPF_SHARD_ENGINE", "python")
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world, one_call=True)
+    if mode != "python":
+        assert all(str(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["summaries"]) == mode for r in range(world))
+
+
+def test_world1_sharded_step_ess_and_getters_equal_unsharded(g, o):
+    """one shard without a communicator IS the unsharded filter: its getters and its step_ess take the unsharded kernels (k_sum_host, gpf_step_ess);
+    with a real 1-rank RCCL communicator (GPF_SHARD_FORCE_COLLECTIVES) the mailbox path runs -- covered by test_rccl_collectives_one_rank's getters"""
+    from gpf_amd import sharded
+    model = g.models.bearings4(); ys = g.models.simulate(model, 30); N = 40_000
+    a = sharded.pf_initialize(model, (1,), ys[0], N, seed=5, keep_prev=True)
+    b = g.pf_initialize(model, (1,), ys[0], N, seed=5, keep_prev=True)
+    res = []
+    for t in range(1, 30):
+        ra = sharded.pf_step_ess(a, (t + 1,), (None,), ys[t], ess_threshold=0.5, method="residual", rejuvenate="move", check=False)
+        rb = g.pf_step_ess(b, (t + 1,), (None,), ys[t], ess_threshold=0.5, method="residual", rejuvenate="move", check=False, sort_particles=False)
+        assert ra == rb
+        res.append(ra)
+        if t % 5 == 0:
+            assert sharded.get_ess(a) == g.get_ess(b) and sharded.get_lml_est(a) == g.get_lml_est(b)
+    assert any(res) and not all(res)
+    assert np.array_equal(a.local.traces, b.traces) and np.array_equal(a.local.log_weights, b.log_weights) and np.array_equal(a.local.parents, b.parents)
 
 
 @pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
@@ -136,6 +175,14 @@ def test_library_engine_several_ranks_over_loopback(g, o, tmp_path, monkeypatch,
     monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
     monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
     test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
+
+
+@pytest.mark.parametrize("case", [CASES[3], CASES[5]], ids=lambda c: f"{c[0]}-{c[1]}")
+def test_library_engine_getters_through_the_scan(g, o, tmp_path, monkeypatch, loopback_lib, case):
+    """GPF_SHARD_GETTERS=scan: the sharded ESS / log-ML getters through the weight scan, copies and a stream synchronisation (the round-4 form)
+    instead of the one-launch reduction that exchanges the totals through the mailboxes (k_sum_reduce<SHARD>) -- the same values"""
+    monkeypatch.setenv("GPF_SHARD_GETTERS", "scan")
+    test_library_engine_several_ranks_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, case, 2)
 
 
 @pytest.mark.parametrize("mode", ["mailbox", "rccl"])

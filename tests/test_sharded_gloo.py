@@ -50,10 +50,10 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_single(g, o, tmp_path, case, world):
+def test_sharded_equals_single(g, o, tmp_path, case, world, one_call=False):
     model_name, method, n_global, T, ess_frac, rejuv = case
     port = free_port()
-    mp.spawn(shard_worker.run, args=(world, port, model_name, method, n_global, T, ess_frac, rejuv, str(tmp_path)),
+    mp.spawn(shard_worker.run, args=(world, port, model_name, method, n_global, T, ess_frac, rejuv, str(tmp_path), one_call),
              nprocs=world, join=True)
     f, ess_log, lml_log = single(g, o, model_name, method, n_global, T, ess_frac, rejuv)
     parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
@@ -63,7 +63,14 @@ def test_sharded_equals_single(g, o, tmp_path, case, world):
     assert np.array_equal(parents, f.parents), "sharded ancestors differ from the single-shard run"
     assert np.array_equal(rows, f.rows) and np.array_equal(lw, f.lw)
     for p in parts:                                     # every rank sees the same global summaries
-        assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
+        assert (one_call or np.array_equal(p["ess"], ess_log)) and np.array_equal(p["lml"], lml_log)
+
+
+@pytest.mark.parametrize("case", [CASES[3], CASES[5]], ids=lambda c: f"{c[0]}-{c[1]}")
+def test_sharded_step_ess_equals_single(g, o, tmp_path, case):
+    """sharded.pf_step_ess (the README loop's body, README.md:66-77, as one call per rank) through the python engine: the same bits as the
+    separate calls and as the single-shard oracle"""
+    test_sharded_equals_single(g, o, tmp_path, case, 2, one_call=True)
 
 
 def test_sharded_push_overflow_path(g, o, tmp_path, monkeypatch):
