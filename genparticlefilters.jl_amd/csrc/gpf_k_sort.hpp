@@ -22,6 +22,9 @@ constexpr int SORT_TICKET_WAYS = 8;
 constexpr int SORT_DONE_STRIDE = 32;               // u32 words between completion counters
 // (K10d, below: behind the completion words the histogram of the SORT_FINE fine bins and the SORT_BINS + 1 bucket boundaries)
 constexpr int SORT_FINE_BITS = 13, SORT_FINE = 1 << SORT_FINE_BITS, SORT_COARSE_BITS = 24;
+// (the wide form of K10d for filters above SORT_BINS * 4608 particles: twice the buckets and twice the fine bins -- the mean bucket and the
+//  fullest fine bin stay what they are at half the size; the workspace is laid out for the wide form)
+constexpr int SORT_BINS_WIDE = 512, SORT_FINE_BITS_WIDE = 14, SORT_FINE_MAX = 1 << SORT_FINE_BITS_WIDE;
 // "dead" keys: more than 2^6 = 64 below the maximum (incl. -inf and everything beyond the coarse key's range).  Their fixed-point weight
 // is exactly 0 (exp(-64) 2^52 < 1/2): no slot can ever choose them, so their order among themselves cannot be observed
 // through pf_resample! -- they only have to stand behind every live key.  K10d sends them all to the last bucket, which k_sort_buckets
@@ -29,9 +32,9 @@ constexpr int SORT_FINE_BITS = 13, SORT_FINE = 1 << SORT_FINE_BITS, SORT_COARSE_
 // their dead half and without the eight-pass fall-back.  (All weights -inf: every key is dead, the order is the identity -- which is the
 // stable sort of equal keys that the uniform fall-back of safe_softmax needs.)
 constexpr uint32_t SORT_COARSE_DEAD = 28u << 19;             // sort_coarse of 2^6: binade index 6 + 21, + 1
-constexpr int SORT_FINE_DEAD = (int)(SORT_COARSE_DEAD >> (SORT_COARSE_BITS - SORT_FINE_BITS));
+__host__ __device__ constexpr int sort_fine_dead(int fb) { return (int)(SORT_COARSE_DEAD >> (SORT_COARSE_BITS - fb)); }
 __host__ __device__ __forceinline__ size_t sort_ws_fine_offset() { return (size_t)(SORT_PASSES * SORT_BINS + 64 + 18 * SORT_DONE_STRIDE) * sizeof(uint32_t); }
-__host__ __device__ __forceinline__ size_t sort_ws_desc_offset() { return sort_ws_fine_offset() + (size_t)(SORT_FINE + 2 * SORT_BINS) * sizeof(uint32_t); }
+__host__ __device__ __forceinline__ size_t sort_ws_desc_offset() { return sort_ws_fine_offset() + (size_t)(SORT_FINE_MAX + 2 * SORT_BINS_WIDE) * sizeof(uint32_t); }
 __host__ inline size_t sort_ws_bytes(int64_t n)
 {
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
@@ -83,15 +86,16 @@ __global__ __launch_bounds__(KF_BLOCK) void k_sort_keys_hist(PrioView pv, int64_
 
 // K10d key pass: the keys + the histogram of the coarse key's top SORT_FINE_BITS bits (the "fine bins": 128 per binade of the
 // distance from the maximum) -- what k_sort_pass<2> cuts into SORT_BINS buckets of (nearly) equal counts.
-static __global__ __launch_bounds__(KF_BLOCK) void k_sort_keys_fine(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ fine,
+template <int FB>
+__global__ __launch_bounds__(KF_BLOCK) void k_sort_keys_fine(PrioView pv, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ fine,
                                                           uint4* __restrict__ clear, int64_t clear16, const unsigned long long* __restrict__ slots,
                                                           double* __restrict__ m_out)
 {
-    __shared__ uint32_t s_h[SORT_FINE];
+    __shared__ uint32_t s_h[1 << FB];
     double m; int f; fold_slots(slots, m, f);
     if (blockIdx.x == 0 && threadIdx.x == 0) *m_out = m;
     for (int64_t i = (int64_t)blockIdx.x * KF_BLOCK + threadIdx.x; i < clear16; i += (int64_t)gridDim.x * KF_BLOCK) clear[i] = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = threadIdx.x; i < SORT_FINE; i += KF_BLOCK) s_h[i] = 0;
+    for (int i = threadIdx.x; i < (1 << FB); i += KF_BLOCK) s_h[i] = 0;
     __syncthreads();
     constexpr int KH_ILP = 4;
     const int64_t stride = (int64_t)gridDim.x * KF_BLOCK;
@@ -104,11 +108,11 @@ static __global__ __launch_bounds__(KF_BLOCK) void k_sort_keys_fine(PrioView pv,
             if (i0 + q * stride >= n) break;
             const uint64_t k = sort_key_desc(v[q]);
             keys[i0 + q * stride] = k;
-            atomicAdd(&s_h[sort_coarse(k, m) >> (SORT_COARSE_BITS - SORT_FINE_BITS)], 1u);
+            atomicAdd(&s_h[sort_coarse(k, m) >> (SORT_COARSE_BITS - FB)], 1u);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SORT_FINE; i += KF_BLOCK) { const uint32_t c = s_h[i]; if (c) atomicAdd(fine + i, c); }
+    for (int i = threadIdx.x; i < (1 << FB); i += KF_BLOCK) { const uint32_t c = s_h[i]; if (c) atomicAdd(fine + i, c); }
 }
 
 // one digit pass.  vals_in == nullptr: the payload is the element's index (first pass).
@@ -124,7 +128,7 @@ __device__ unsigned long long g_dbg_sort[8 * 4096];
 //         whose exclusive count prefix lies in [b n / 256, (b + 1) n / 256) -- monotone in the key, at most n / 256 + (the fullest fine bin)
 //         elements each.  Every workgroup derives the same table from the same histogram (integers); the first tile leaves the bucket
 //         boundaries in bbase[0 .. SORT_BINS] for k_sort_buckets.
-template <int MODE>
+template <int MODE, int NB = SORT_BINS, int FB = SORT_FINE_BITS>
 __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                                                      uint64_t* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
                                                      int pass, const uint32_t* __restrict__ hist, uint32_t* __restrict__ ticket,
@@ -133,19 +137,22 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
 {
     DBG_SORT(0);
     constexpr bool COARSE = MODE == 1, PART = MODE == 2;
-    __shared__ uint8_t s_tab[PART ? SORT_FINE : 4];
-    __shared__ uint32_t s_bcnt[SORT_BINS];
+    using tab_t = typename std::conditional<(NB > 256), uint16_t, uint8_t>::type;
+    constexpr int NFINE = 1 << FB, FINE_DEAD = sort_fine_dead(FB), NB_BITS = NB == 256 ? 8 : 9;
+    static_assert(NB == (1 << NB_BITS) && NB <= SORT_BLOCK, "one thread per bucket");
+    __shared__ tab_t s_tab[PART ? NFINE : 4];
+    __shared__ uint32_t s_bcnt[NB];
     __shared__ uint32_t s_last[SORT_WAVES];
     double cm = 0.0;
     if constexpr (MODE != 0) cm = *m_ptr;
     auto digit_of = [&](uint64_t k) -> uint32_t {
-        if constexpr (PART) return s_tab[sort_coarse(k, cm) >> (SORT_COARSE_BITS - SORT_FINE_BITS)];
+        if constexpr (PART) return s_tab[sort_coarse(k, cm) >> (SORT_COARSE_BITS - FB)];
         else if constexpr (COARSE) return (sort_coarse(k, cm) >> (8 * pass)) & 0xffu;
         else return (uint32_t)(k >> (8 * pass)) & 0xffu;
     };
-    __shared__ uint32_t s_cnt[SORT_WAVES][SORT_BINS];      // per-wave digit counts, then exclusive offsets of the wave inside the tile's bin
-    __shared__ uint32_t s_lstart[SORT_BINS];           // first position of the bin in the tile's sorted order
-    __shared__ int64_t s_gbase[SORT_BINS];             // global position of the bin's first element of this tile, minus s_lstart
+    __shared__ uint32_t s_cnt[SORT_WAVES][NB];      // per-wave digit counts, then exclusive offsets of the wave inside the tile's bin
+    __shared__ uint32_t s_lstart[NB];           // first position of the bin in the tile's sorted order
+    __shared__ int64_t s_gbase[NB];             // global position of the bin's first element of this tile, minus s_lstart
     __shared__ uint32_t s_scan[SORT_WAVES];
     __shared__ uint64_t s_keys[SORT_TILE];
     __shared__ int32_t s_vals[SORT_TILE];
@@ -158,11 +165,11 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     // (tile = workgroup index when the whole launch is resident, without the same-address atomic in front of the loads, was measured too:
     //  16.8-17.5 us per pass against 15.8 -- arrival order is the better look-back order)
     if (tid == 0) s_tile = atomicAdd(ticket + pass * SORT_TICKET_WAYS, 1u);
-    for (int i = tid; i < SORT_WAVES * SORT_BINS; i += SORT_BLOCK) (&s_cnt[0][0])[i] = 0;
-    const bool binthr = tid < SORT_BINS;               // the first four waves double as "thread = bin"
+    for (int i = tid; i < SORT_WAVES * NB; i += SORT_BLOCK) (&s_cnt[0][0])[i] = 0;
+    const bool binthr = tid < NB;               // the first four waves double as "thread = bin"
     if constexpr (PART) {
         // fine bins -> buckets: thread t holds bins FPT t .. FPT t + FPT - 1
-        constexpr int FPT = SORT_FINE / SORT_BLOCK;
+        constexpr int FPT = NFINE / SORT_BLOCK;
         static_assert(FPT % 4 == 0, "whole uint4 loads");
         uint32_t hq[FPT], hs = 0;
 #pragma unroll
@@ -180,20 +187,20 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
         uint32_t c = inc - hs;
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) if (w < wv) c += s_scan[w];
-        // live keys: buckets 0 .. 254 by their exclusive count; dead keys (fine bins from SORT_FINE_DEAD on): bucket 255
-        const double scale = (double)(SORT_BINS - 1) / (double)n;
-        auto bucket_at = [&](uint32_t cc) { const uint32_t bq = (uint32_t)((double)cc * scale); return bq > SORT_BINS - 2 ? (uint32_t)(SORT_BINS - 2) : bq; };   // (monotone in cc, the same in every workgroup: that is all it takes)
+        // live keys: buckets 0 .. 254 by their exclusive count; dead keys (fine bins from FINE_DEAD on): the last bucket
+        const double scale = (double)(NB - 1) / (double)n;
+        auto bucket_at = [&](uint32_t cc) { const uint32_t bq = (uint32_t)((double)cc * scale); return bq > NB - 2 ? (uint32_t)(NB - 2) : bq; };   // (monotone in cc, the same in every workgroup: that is all it takes)
         // the bucket of the bin before this thread's first one (-1 in front of bin 0): a bin whose bucket differs from its
         // predecessor's opens every bucket in between at its own exclusive count
         uint32_t hprev = (uint32_t)__shfl_up((int)hq[FPT - 1], 1, WAVE);
         if (lane == 0 && wv > 0) hprev = s_last[wv - 1];
-        static_assert(SORT_FINE_DEAD % FPT == 0, "a thread's fine bins are all live or all dead");
-        const bool dead = FPT * tid >= SORT_FINE_DEAD;
-        int pb = tid == 0 ? -1 : (FPT * tid - 1 >= SORT_FINE_DEAD ? SORT_BINS - 1 : (int)bucket_at(c - hprev));
+        static_assert(FINE_DEAD % FPT == 0, "a thread's fine bins are all live or all dead");
+        const bool dead = FPT * tid >= FINE_DEAD;
+        int pb = tid == 0 ? -1 : (FPT * tid - 1 >= FINE_DEAD ? NB - 1 : (int)bucket_at(c - hprev));
 #pragma unroll
         for (int q = 0; q < FPT; ++q) {
-            const int bk = dead ? SORT_BINS - 1 : (int)bucket_at(c);
-            s_tab[FPT * tid + q] = (uint8_t)bk;
+            const int bk = dead ? NB - 1 : (int)bucket_at(c);
+            s_tab[FPT * tid + q] = (tab_t)bk;
             for (int b_ = pb + 1; b_ <= bk; ++b_) s_bcnt[b_] = c;
             pb = bk;
             c += hq[q];
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     uint32_t hbase = 0;
     if constexpr (PART) hbase = binthr ? s_bcnt[tid] : 0u;
     else {
-        const uint32_t hv = binthr ? hist[pass * SORT_BINS + tid] : 0u;
+        const uint32_t hv = binthr ? hist[pass * NB + tid] : 0u;
         uint32_t hinc = hv;
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) { const uint32_t o = __shfl_up(hinc, d, WAVE); if (lane >= d) hinc += o; }
@@ -212,12 +219,12 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
         __syncthreads();
         hbase = hinc - hv;
 #pragma unroll
-        for (int w = 0; w < SORT_BINS / WAVE; ++w) if (w < wv) hbase += s_scan[w];
+        for (int w = 0; w < NB / WAVE; ++w) if (w < wv) hbase += s_scan[w];
     }
     const int64_t tile = s_tile;
     const int64_t t0 = tile * SORT_TILE;
     if constexpr (PART) {
-        if (tile == 0 && binthr) { bbase[tid] = hbase; if (tid == 0) bbase[SORT_BINS] = (uint32_t)n; }
+        if (tile == 0 && binthr) { bbase[tid] = hbase; if (tid == 0) bbase[NB] = (uint32_t)n; }
     }
     DBG_SORT(1);
     // ---- load (wave-striped: element = t0 + wave * 1024 + item * 64 + lane), rank inside the wave by digit
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
         const uint32_t d = digit_of(key[it]);
         uint64_t peers = __ballot(valid);                 // lanes with the same digit (invalid lanes take no part)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) { const uint64_t m = __ballot((d >> b) & 1u); peers &= ((d >> b) & 1u) ? m : ~m; }
+        for (int b = 0; b < NB_BITS; ++b) { const uint64_t m = __ballot((d >> b) & 1u); peers &= ((d >> b) & 1u) ? m : ~m; }
         const uint32_t prev = s_cnt[wv][d];
         rank[it] = prev + (uint32_t)__popcll(peers & lt_mask);
         __builtin_amdgcn_wave_barrier();
@@ -263,12 +270,12 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     // tiles publish theirs, and only then are the earlier tiles' words read
     {
         const size_t nt_ = gridDim.x, ng_ = (nt_ + 15) / 16, nsg_ = (nt_ + 255) / 256;
-        if (binthr) __hip_atomic_store(desc + ((size_t)pass * (nt_ + ng_ + nsg_) + (size_t)tile) * SORT_BINS + tid, SORT_VALID | tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (binthr) __hip_atomic_store(desc + ((size_t)pass * (nt_ + ng_ + nsg_) + (size_t)tile) * NB + tid, SORT_VALID | tcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     uint32_t lstart = linc - tcnt;
 #pragma unroll
-    for (int w = 0; w < SORT_BINS / WAVE; ++w) if (w < wv) lstart += s_scan[w];
+    for (int w = 0; w < NB / WAVE; ++w) if (w < wv) lstart += s_scan[w];
     if (binthr) s_lstart[tid] = lstart;
     __syncthreads();
     // ---- reorder inside the tile: afterwards every digit's run leaves as contiguous stores
@@ -293,9 +300,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
     //      tiles of this group: at most 1 + 15 + 15 words, two or three round trips whatever the number of tiles.
     if (binthr) {
         const size_t nt = gridDim.x, ng = (nt + 15) / 16, nsg = (nt + 255) / 256;
-        uint64_t* const agg = desc + ((size_t)pass * (nt + ng + nsg)) * SORT_BINS + tid;      // this pass, this bin
-        uint64_t* const gt = agg + nt * SORT_BINS;
-        uint64_t* const pre = gt + ng * SORT_BINS;
+        uint64_t* const agg = desc + ((size_t)pass * (nt + ng + nsg)) * NB + tid;      // this pass, this bin
+        uint64_t* const gt = agg + nt * NB;
+        uint64_t* const pre = gt + ng * NB;
         auto wait_word = [&](const uint64_t* p) {
             uint64_t v = __hip_atomic_load(const_cast<uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
@@ -310,17 +317,17 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_sort_pass(const uint64_t* __rest
         auto sum_words = [&](const uint64_t* p, int cnt) {
             uint64_t v[15], acc = 0;
 #pragma unroll
-            for (int e = 0; e < 15; ++e) v[e] = e < cnt ? __hip_atomic_load(const_cast<uint64_t*>(p + (size_t)e * SORT_BINS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SORT_VALID;
+            for (int e = 0; e < 15; ++e) v[e] = e < cnt ? __hip_atomic_load(const_cast<uint64_t*>(p + (size_t)e * NB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SORT_VALID;
 #pragma unroll
-            for (int e = 0; e < 15; ++e) acc += (v[e] & SORT_VALID) ? (v[e] & SORT_VAL) : wait_word(p + (size_t)e * SORT_BINS);
+            for (int e = 0; e < 15; ++e) acc += (v[e] & SORT_VALID) ? (v[e] & SORT_VAL) : wait_word(p + (size_t)e * NB);
             return acc;
         };
         const int64_t k = tile & 15, g = tile >> 4, gk = g & 15, sg = tile >> 8;
-        const uint64_t in_group = sum_words(agg + (size_t)(tile - k) * SORT_BINS, (int)k);
-        if (k == 15) __hip_atomic_store(gt + (size_t)g * SORT_BINS, SORT_VALID | (in_group + tcnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t e_ = in_group + sum_words(gt + (size_t)(g - gk) * SORT_BINS, (int)gk);
-        if (sg > 0) e_ += wait_word(pre + (size_t)(sg - 1) * SORT_BINS);
-        if ((tile & 255) == 255) __hip_atomic_store(pre + (size_t)sg * SORT_BINS, SORT_VALID | (e_ + tcnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t in_group = sum_words(agg + (size_t)(tile - k) * NB, (int)k);
+        if (k == 15) __hip_atomic_store(gt + (size_t)g * NB, SORT_VALID | (in_group + tcnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t e_ = in_group + sum_words(gt + (size_t)(g - gk) * NB, (int)gk);
+        if (sg > 0) e_ += wait_word(pre + (size_t)(sg - 1) * NB);
+        if ((tile & 255) == 255) __hip_atomic_store(pre + (size_t)sg * NB, SORT_VALID | (e_ + tcnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         excl = e_;
     }
     if (binthr) s_gbase[tid] = (int64_t)hbase + (int64_t)excl - (int64_t)lstart;
@@ -443,7 +450,8 @@ __device__ unsigned long long g_dbg_bk[8 * 256];
 constexpr int BK_BLOCK = 1024, BK_WAVES = BK_BLOCK / WAVE, BK_ITEMS = 8, BK_CAP = BK_BLOCK * BK_ITEMS;
 constexpr int BK_SUB_BITS = 14, BK_SUB = 1 << BK_SUB_BITS, BK_SUB_PER = BK_SUB / BK_BLOCK;   // (16-bit counters, two to a word: 32 KB)
 constexpr int BK_RUN_MAX = 1024;                              // keys of one bin that are still ranked (quadratic work inside the bin)
-constexpr int64_t BK_MAX_N = (int64_t)SORT_BINS * 4608;      // mean bucket <= 4608 keys: BK_CAP - 4608 left for the fullest fine bin
+constexpr int64_t BK_MEAN_MAX = 4608;                          // mean bucket <= 4608 keys: BK_CAP - 4608 left for the fullest fine bin
+constexpr int64_t BK_NARROW_N = (int64_t)SORT_BINS * BK_MEAN_MAX, BK_MAX_N = (int64_t)SORT_BINS_WIDE * BK_MEAN_MAX;   // 1 179 648 / 2 359 296 particles
 static __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(uint64_t* keys, int32_t* vals, int64_t n,
                                                            const uint32_t* __restrict__ bbase, uint32_t* __restrict__ done, int64_t* host_flag,
                                                            int64_t ticket, const double* __restrict__ m_ptr)
@@ -461,7 +469,7 @@ static __global__ __launch_bounds__(BK_BLOCK) void k_sort_buckets(uint64_t* keys
     const int tid = (int)threadIdx.x, lane = lane_id(), wv = wave_id();
     DBG_BK(0);
     const int64_t b0 = bbase[blockIdx.x];
-    const int64_t Lg = blockIdx.x == SORT_BINS - 1 ? 0 : (int64_t)bbase[blockIdx.x + 1] - b0;     // (the last bucket: the dead keys, already in place)
+    const int64_t Lg = blockIdx.x == gridDim.x - 1 ? 0 : (int64_t)bbase[blockIdx.x + 1] - b0;     // (the last bucket: the dead keys, already in place)
     const double cm = *m_ptr;
     bool too_long = false;
     if (Lg > BK_CAP) too_long = true;                   // (stays as the partition left it)

@@ -398,6 +398,8 @@ gpf_status ensure_sort_buffers(gpf_filter* h)
 //                   -- ensure_max); the caller finishes the runs of equal coarse keys (k_sort_finish).  keys -> keys_out -> keys ->
 //                   keys_out, payload index -> idx_in -> order -> idx_in: the finish brings both back to h->keys / h->order.
 //   coarse = false: all eight passes over the 64-bit key; the eighth leaves keys / permutation in h->keys / h->order.
+// K10d in its wide form (512 buckets, 16 384 fine bins): above BK_NARROW_N particles, or everywhere with GPF_SORT=wide (tests at small n)
+bool sort_buckets_wide(int64_t n) { static const bool force = getenv("GPF_SORT") && strstr(getenv("GPF_SORT"), "wide"); return force || n > BK_NARROW_N; }
 gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse, uint32_t** ws_used = nullptr, bool buckets = false)
 {
     gpf_status s = ensure_sort_buffers(h);
@@ -412,7 +414,7 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse
     uint32_t* const ticket_words = hist + SORT_PASSES * SORT_BINS;
     double* m_ptr = reinterpret_cast<double*>(ticket_words + SORT_M_WORD);
     uint32_t* fine = reinterpret_cast<uint32_t*>(ws + sort_ws_fine_offset());
-    uint32_t* bbase = fine + SORT_FINE;
+    uint32_t* bbase = fine + SORT_FINE_MAX;
     uint64_t* desc = reinterpret_cast<uint64_t*>(ws + sort_ws_desc_offset());
     const int64_t nt = (n + SORT_TILE - 1) / SORT_TILE;
     uint32_t* const ticket = ticket_words;
@@ -423,8 +425,13 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse
     if (buckets) {
         // K10d: keys + fine-bin histogram, ONE partition pass (keys -> keys_out, payload index -> idx_in); the caller runs k_sort_buckets
         const int64_t kf_grid = std::max<int64_t>(1, std::min<int64_t>((n + 4 * KF_BLOCK - 1) / (4 * KF_BLOCK), h->n_cu));
-        GPF_LAUNCH(k_sort_keys_fine, dim3((unsigned)kf_grid), dim3(KF_BLOCK), 0, h->stream, pv, n, h->keys, fine, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
-        GPF_LAUNCH(k_sort_pass<2>, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, h->keys, nullptr, h->keys_out, h->idx_in, n, 0, hist, ticket, desc, h->h_timeout, m_ptr, fine, bbase);
+        if (sort_buckets_wide(n)) {
+            GPF_LAUNCH(k_sort_keys_fine<SORT_FINE_BITS_WIDE>, dim3((unsigned)kf_grid), dim3(KF_BLOCK), 0, h->stream, pv, n, h->keys, fine, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
+            GPF_LAUNCH((k_sort_pass<2, SORT_BINS_WIDE, SORT_FINE_BITS_WIDE>), dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, h->keys, nullptr, h->keys_out, h->idx_in, n, 0, hist, ticket, desc, h->h_timeout, m_ptr, fine, bbase);
+        } else {
+            GPF_LAUNCH(k_sort_keys_fine<SORT_FINE_BITS>, dim3((unsigned)kf_grid), dim3(KF_BLOCK), 0, h->stream, pv, n, h->keys, fine, reinterpret_cast<uint4*>(other), clear16, slots, m_ptr);
+            GPF_LAUNCH(k_sort_pass<2>, dim3((unsigned)nt), dim3(SORT_BLOCK), 0, h->stream, h->keys, nullptr, h->keys_out, h->idx_in, n, 0, hist, ticket, desc, h->h_timeout, m_ptr, fine, bbase);
+        }
         HIP_TRY(h, hipGetLastError());
         return GPF_OK;
     }
@@ -465,10 +472,10 @@ gpf_status sort_desc_begin(gpf_filter* h, const PrioView& pv, int64_t n, bool* p
     const double* m_ptr = reinterpret_cast<const double*>(ws + SORT_PASSES * SORT_BINS + SORT_M_WORD);
     h->sort_ticket += 1;
     if (buckets) {
-        const uint32_t* bbase = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ws) + sort_ws_fine_offset()) + SORT_FINE;
+        const uint32_t* bbase = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ws) + sort_ws_fine_offset()) + SORT_FINE_MAX;
         // every bucket is ordered in place (the dead keys' bucket is left as the partition wrote it): the partition's output buffers
         // become the sorted keys / the permutation
-        GPF_LAUNCH(k_sort_buckets, dim3(SORT_BINS), dim3(BK_BLOCK), 0, h->stream, h->keys_out, h->idx_in, n, bbase,
+        GPF_LAUNCH(k_sort_buckets, dim3(sort_buckets_wide(n) ? SORT_BINS_WIDE : SORT_BINS), dim3(BK_BLOCK), 0, h->stream, h->keys_out, h->idx_in, n, bbase,
                    done, h->h_sort_flag, h->sort_ticket, m_ptr);
         std::swap(h->keys, h->keys_out);
         std::swap(h->order, h->idx_in);

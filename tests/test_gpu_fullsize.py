@@ -278,7 +278,7 @@ def _sorted_case(N, kind, seed=3):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N", [1, 2, 100, 4096, 4097, (1 << 17) + 1, 300_007, 1_000_000])
+@pytest.mark.parametrize("N", [1, 2, 100, 4096, 4097, (1 << 17) + 1, 300_007, 1_000_000, 2_000_003, 2_400_000])
 @pytest.mark.parametrize("kind", ["filter", "all equal", "two values", "mostly -inf", "few distinct", "signed zeros", "ramp", "close values",
                                   "wide range", "tiny spread"])
 def test_sorted_stratified_sizes_and_patterns(g, o, N, kind):
@@ -286,7 +286,10 @@ def test_sorted_stratified_sizes_and_patterns(g, o, N, kind):
     (distance from the maximum: 5-bit binade, 19 mantissa bits) + the finish of the short runs of equal coarse keys, and -- for weights
     that are equal, nearly equal or far below the maximum ("all equal", "two values", "few distinct", "close values", "mostly -inf":
     runs longer than the finish's window) -- the eight-pass fallback.  The permutation is the stable descending sort of the oracle
-    (ties by index, -0.0 < 0.0), so the ancestors are equal."""
+    (ties by index, -0.0 < 0.0), so the ancestors are equal.  2 000 003: the bucket sort's wide form (512 buckets, 16 384 fine bins, up to
+    2 359 296 particles); 2 400 000: beyond it (three coarse passes + finish)."""
+    if N > 1_500_000 and kind not in ("filter", "few distinct", "wide range", "tiny spread"):
+        pytest.skip("the largest sizes run four weight patterns")
     if N > 400_000 and kind not in ("filter", "all equal", "few distinct", "close values", "wide range", "tiny spread"):
         pytest.skip("the large sizes run six weight patterns")
     model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
@@ -304,7 +307,7 @@ def test_sorted_stratified_sizes_and_patterns(g, o, N, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N", [2000, 300_007, 1_000_000])
+@pytest.mark.parametrize("N", [2000, 300_007, 1_000_000, 2_000_000])
 def test_sorted_stratified_with_dead_weights(g, o, N):
     """weights more than 2^6 below the maximum have the fixed-point weight 0: the bucket sort leaves them unranked in its last bucket
     (gpf_k_sort.hpp SORT_COARSE_DEAD) -- a bearings filter (half its particles after every update), 60 % -inf, one live particle among
@@ -357,7 +360,8 @@ def test_sort_finish_window_boundaries(g, o):
 def test_sort_fallback_and_eight_pass_modes_agree():
     """GPF_SORT=fallback: the host treats every finish as flagged and re-sorts with all eight passes; GPF_SORT=radix8: the eight
     passes alone; GPF_SORT=coarse3: the three coarse passes + k_sort_finish where the default is the bucket sort (key pass, one partition
-    pass, one workgroup per bucket in LDS; n <= 1 179 648).  Same ancestors as the default (separate processes: the switch is read once
+    pass, one workgroup per bucket in LDS; n <= 2 359 296); GPF_SORT=wide: the bucket sort's wide form (512 buckets, above 1 179 648 particles)
+    at this size.  Same ancestors as the default (separate processes: the switch is read once
     per process)."""
     import json
     import subprocess
@@ -368,7 +372,7 @@ def test_sort_fallback_and_eight_pass_modes_agree():
             "g.pf_update(st, (2,), (None,), ys[1]); g.pf_resample(st, 'stratified', sort_particles=True, check=False)\n"
             "p = st.parents; print(json.dumps([int(p.sum()), int((p * np.arange(1, p.size + 1) % 1000003).sum()), g.get_lml_est(st)]))\n").replace("ROOT", repr(root))
     outs = []
-    for mode in ("", "fallback", "radix8", "coarse3", "coarse3,fallback"):
+    for mode in ("", "fallback", "radix8", "coarse3", "coarse3,fallback", "wide", "wide,fallback"):
         env = dict(os.environ); env.pop("GPF_SORT", None)
         if mode:
             env["GPF_SORT"] = mode
@@ -376,6 +380,22 @@ def test_sort_fallback_and_eight_pass_modes_agree():
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
     assert all(x == outs[0] for x in outs[1:]), outs
+
+
+@pytest.mark.gpu
+def test_sort_patterns_through_the_wide_bucket_sort():
+    """the weight patterns, dead weights and window boundaries of the tests above (sizes up to 300 007) with GPF_SORT=wide: every sort takes
+    the 512-bucket form that filters of 1.18 - 2.36 million particles use (a separate pytest process: the switch is read once per process)"""
+    import subprocess
+    import sys
+    if os.environ.get("GPF_SORT"):
+        pytest.skip("already inside a GPF_SORT run")
+    env = dict(os.environ); env["GPF_SORT"] = "wide"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "((sorted_stratified_sizes_and_patterns or dead_weights) and not 1000000 and not 2000003 and not 2400000 and not 2000000) or window_boundaries or priorities_right_after"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
+    assert " passed" in p.stdout
 
 
 @pytest.mark.gpu

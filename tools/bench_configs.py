@@ -22,6 +22,9 @@ CONFIGS = [
     ("config3 lgssm2 stratified(unsorted) [1 of 8 shards' worth]", "lgssm2", 1_000_000, "stratified", {"sort_particles": False}, None, None),
     ("lgssm2 stratified(sorted)", "lgssm2", 1_000_000, "stratified", {"sort_particles": True}, None, None),
     ("bearings4 stratified(sorted) (weights beyond the coarse key's range every step)", "bearings4", 1_000_000, "stratified", {"sort_particles": True}, None, None),
+    ("big lgssm2 stratified(sorted), N = 2 x 10^6 (the bucket sort's wide form)", "lgssm2", 2_000_000, "stratified", {"sort_particles": True}, None, None),
+    ("big bearings4 stratified(sorted), N = 2 x 10^6", "bearings4", 2_000_000, "stratified", {"sort_particles": True}, None, None),
+    ("big lgssm2 stratified(sorted), N = 2.4 x 10^6 (beyond the bucket sort: three coarse passes + finish)", "lgssm2", 2_400_000, "stratified", {"sort_particles": True}, None, None),
     ("lgssm2 residual", "lgssm2", 1_000_000, "residual", {}, None, None),
     ("config4 bearings4 ESS<N/2 residual + MH [1 of 4 shards' worth]", "bearings4", 1_000_000, "residual", {}, "move", 0.5),
     ("config4g the same loop, one pf_step_ess call per step (gpf_step_ess: verdict on the device, speculative propagate)", "bearings4", 1_000_000, "residual", {"_step_ess": True}, "move", 0.5),
