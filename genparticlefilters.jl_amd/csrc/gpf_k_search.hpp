@@ -408,6 +408,9 @@ __device__ __forceinline__ uint32_t pk_ne(uint32_t x, uint32_t qq)
 #ifndef GPF_MULTI_NS
 #define GPF_MULTI_NS 2
 #endif
+#ifndef GPF_MULTI_ROW
+#define GPF_MULTI_ROW 0
+#endif
 struct MultiTable { const uint32_t* keys; uint32_t ng, p2; float kscale; };      // the LDS key table of k_search_multi
 constexpr uint32_t MULTI_WIN = 512;                // interpolation window of the key search
 
@@ -435,6 +438,40 @@ __device__ __forceinline__ void multi_inside_k(const uint32_t (&g)[NS], const ui
 {
     constexpr int G = 32 << LOGG, CS = G / 8;
     uint32_t qq[NS], run[NS];
+#if GPF_MULTI_ROW
+    // (experiment: the group's G offsets as ONE G*2-byte read -- one line fill and one round trip instead of coarse row + run)
+    bool tie[NS]; bool anytie = false;
+    {
+        uint4 rw[NS][G / 8];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const uint32_t klo = klo_[u], khi = khi_[u];
+            const uint64_t kb = (uint64_t)klo << KEY_SHIFT;
+            const uint64_t d = T[u] > kb ? T[u] - kb : 0;
+            uint32_t q = (uint32_t)(d >> key_quant_shift(klo, khi));
+            q = q < 65535u ? q : 65535u;
+            qq[u] = q | (q << 16);
+            const uint4* fp = reinterpret_cast<const uint4*>(w.off16 + (size_t)g[u] * (uint32_t)G);
+#pragma unroll
+            for (int e = 0; e < G / 8; ++e) rw[u][e] = fp[e];
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            uint32_t lt = 0, ne = 0;
+#pragma unroll
+            for (int e = 0; e < G / 8; ++e) {
+                lt += pk_lt(rw[u][e].x, qq[u]) + pk_lt(rw[u][e].y, qq[u]) + pk_lt(rw[u][e].z, qq[u]) + pk_lt(rw[u][e].w, qq[u]);
+                ne += pk_ne(rw[u][e].x, qq[u]) + pk_ne(rw[u][e].y, qq[u]) + pk_ne(rw[u][e].z, qq[u]) + pk_ne(rw[u][e].w, qq[u]);
+            }
+            lt = (lt & 0xffffu) + (lt >> 16); ne = (ne & 0xffffu) + (ne >> 16);
+            lt = lt < (uint32_t)G ? lt : (uint32_t)G - 1;
+            tie[u] = ne != (uint32_t)G;
+            anytie = anytie || tie[u];
+            run[u] = lt / (uint32_t)CS;
+            idx[u] = g[u] * (uint32_t)G + lt;
+        }
+    }
+#else
     uint4 row[NS];
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
@@ -475,6 +512,7 @@ __device__ __forceinline__ void multi_inside_k(const uint32_t (&g)[NS], const ui
         anytie = anytie || tie[u];
         idx[u] = g[u] * (uint32_t)G + run[u] * (uint32_t)CS + lt;
     }
+#endif
     if (__any(anytie)) {
         // a cell of the run shares the target's offset: the exact prefixes decide.  Every cell before the run is below T
         // (its run's coarse offset is < q); walk from the run's first cell -- equal offsets may continue into later runs
