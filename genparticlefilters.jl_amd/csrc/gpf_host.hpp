@@ -275,7 +275,7 @@ inline MboxWait mb_wait(const gpf_filter* h, int kind)
     MboxWait w{};
     if (!(h->mb_active && h->mb_engine)) return w;
     const uint64_t seq = h->mb_cur[kind];
-    w.tags = h->mbox + mb_tag_off(kind, (int)(seq & (MB_SLOTS - 1))); w.want = seq; w.n = h->comm_world; w.timeout = h->h_timeout;
+    w.tags = h->mbox + mb_tag_off(kind, (int)(seq & (MB_SLOTS - 1))); w.want = seq; w.n = h->comm_world; w.nwords = mb_words(kind); w.timeout = h->h_timeout;
     return w;
 }
 // the gathered array of the current round of `kind` inside the own mailbox ([G][words], dense like the all-gather's output)

@@ -196,6 +196,25 @@ __device__ __forceinline__ double ld_sys(const double* p) { return u2d(ld_sys(re
 // gathered summaries that MAY sit in the mailbox: system-scope loads there, ordinary (cached) loads when they came by a collective
 template <class T> __device__ __forceinline__ T ld_gathered(const T* p, bool in_mailbox) { return in_mailbox ? ld_sys(p) : *p; }
 
+// A ticket / seal published BEHIND payload words that the same thread stored with system-scope atomic stores.  Those stores are write-through
+// (sc0 sc1): all that "behind" needs is their acknowledgement, s_waitcnt vmcnt(0).  A system-scope RELEASE store puts `buffer_wbl2 sc0 sc1` in
+// front instead -- a write-back of the whole L2, i.e. of the tens of MB of rows the propagate has just written: 3 - 5 us in kernels that are
+// otherwise one wave (k_pack_mflags 5.5 us, k_set_global / k_export_residual 4.8, +3 us on the weight scan behind a mailbox wait).
+__device__ __forceinline__ void sys_stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <class T> __device__ __forceinline__ void publish_behind_sys_stores(T* p, T v)
+{
+    sys_stores_acknowledged();
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the seal of a mailbox entry: the round's sequence number folded with the entry's words (odd multiplier: every step a bijection; never 0 for
+// seq != 0 over the zeroed mailbox).  The consumer recomputes it from the words IT reads: an entry whose words and seal did not arrive together
+// (in whatever order the fabric delivered them) does not match and is polled again -- the protocol needs no ordering between the stores.
+__device__ __forceinline__ uint64_t mbox_seal(uint64_t seq, const uint64_t* words, int n)
+{
+    uint64_t x = seq;
+    for (int k = 0; k < n; ++k) x = (x ^ words[k]) * 0x9E3779B97F4A7C15ull;
+    return x;
+}
 struct MboxPush {              // where a producer's summary goes (peers == nullptr: nowhere, the caller gathers it with a collective)
     uint64_t* const* peers;    // device array [G]: base of every rank's mailbox as mapped HERE (peers[me] = the own one)
     int64_t payload_off, tag_off;   // of (kind, slot), before the [me] index
@@ -210,13 +229,13 @@ __device__ __forceinline__ void mbox_push_wave(const MboxPush& p, const uint64_t
         uint64_t* base = p.peers[l];
         uint64_t* dst = base + p.payload_off + (int64_t)p.me * p.nwords;
         for (int k = 0; k < p.nwords; ++k) __hip_atomic_store(dst + k, words[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(base + p.tag_off + p.me, p.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        publish_behind_sys_stores(base + p.tag_off + p.me, mbox_seal(p.tag, words, p.nwords));
     }
 }
 struct MboxWait {              // what a consumer waits for (tags == nullptr: nothing -- the data came by a collective or is local)
-    const uint64_t* tags;      // own mailbox + tag_off(kind, slot)
+    const uint64_t* tags;      // own mailbox + tag_off(kind, slot): the seals; the entries ([MAX_SHARDS][nwords]) stand right in front of them
     uint64_t want;             // = seq
-    int n;                     // ranks
+    int n, nwords;             // ranks; words per entry
     int32_t* timeout;          // pinned host flag: set to 2 when a peer's entry did not arrive in time
 };
 constexpr unsigned MB_SPIN_LIMIT = 1u << 23;       // x ~1-2 us per probe: a peer may be ~10 s late (host preempted) before the wait gives up and flags the run
@@ -225,8 +244,14 @@ __device__ __forceinline__ void mbox_wait_block(const MboxWait& w)
 {
     if (!w.tags) return;
     if ((int)threadIdx.x < w.n) {
+        const uint64_t* entry = w.tags - (int64_t)MAX_SHARDS * w.nwords + (int64_t)threadIdx.x * w.nwords;
         unsigned spins = 0;
-        while (__hip_atomic_load(const_cast<uint64_t*>(w.tags) + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != w.want) {
+        for (;;) {
+            // seal and words in one round trip (independent system-scope loads: they bypass the caches, as the consumers' ld_gathered will)
+            const uint64_t seal = ld_sys(w.tags + threadIdx.x);
+            uint64_t x = w.want;
+            for (int k = 0; k < w.nwords; ++k) x = (x ^ ld_sys(entry + k)) * 0x9E3779B97F4A7C15ull;
+            if (seal == x) break;
             __builtin_amdgcn_s_sleep(8);
             if (++spins > MB_SPIN_LIMIT) { __hip_atomic_store(w.timeout, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
         }

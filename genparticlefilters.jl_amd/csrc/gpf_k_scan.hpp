@@ -247,7 +247,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
             // while this kernel and the ancestor search behind it keep running (no stream synchronisation, no idle gap)
             if (ex.host_flags) {
                 __hip_atomic_store(ex.host_flags, (int64_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(ex.host_flags + 1, ex.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                publish_behind_sys_stores(ex.host_flags + 1, ex.ticket);      // (NOT a system-scope release: that is a write-back of the whole L2)
             }
         }
     }

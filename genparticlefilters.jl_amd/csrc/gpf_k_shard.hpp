@@ -504,7 +504,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
         if (blockIdx.x == 0 && a.host_counts) {
             for (int g = 0; g < 2 * a.G; ++g)
                 __hip_atomic_store(a.host_counts + g, a.counts[g * COUNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            publish_behind_sys_stores(a.host_counts + 2 * MAX_SHARDS, a.ticket);
         }
     }
     __syncthreads();
@@ -587,6 +587,7 @@ static __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan
         if (a.host_counts) {
             __hip_atomic_store(a.host_counts + h, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(a.host_counts + a.G + h, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            sys_stores_acknowledged();                       // (before the barrier in front of the ticket)
         }
     }
     if (h == 0) {
@@ -596,10 +597,7 @@ static __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan
     }
     if (h <= a.G) plan->bounds[h] = a.bounds[h];
     __syncthreads();
-    if (h == 0 && a.host_counts) {
-        __threadfence_system();
-        __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (h == 0 && a.host_counts) publish_behind_sys_stores(a.host_counts + 2 * MAX_SHARDS, a.ticket);   // (the counts: acknowledged before the barrier)
 }
 // ---- sharded SORTED MULTINOMIAL (GPF_RESAMPLE_MULTINOMIAL_SORTED): the targets of the N slots are non-decreasing in
 // the slot index, like the strata, so the slots shard h serves are again ONE range [F[h], F[h+1]), F[h] = the first slot whose target is
@@ -740,7 +738,8 @@ static __global__ __launch_bounds__(MBLOCK) void k_sorted_plan(PushArgs a, Shard
     if (gridDim.x > 1) {
         if (tid == 0) {
             __hip_atomic_store(jb.F + h, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int old = __hip_atomic_fetch_add(jb.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            sys_stores_acknowledged();                   // (F[h] is an agent-scope atomic store, read back with agent-scope atomic loads: no L2 write-back needed)
+            const unsigned int old = __hip_atomic_fetch_add(jb.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == gridDim.x - 1 ? 1 : 0;
         }
         __syncthreads();
@@ -759,6 +758,7 @@ static __global__ __launch_bounds__(MBLOCK) void k_sorted_plan(PushArgs a, Shard
         if (a.host_counts) {
             __hip_atomic_store(a.host_counts + q, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(a.host_counts + a.G + q, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            sys_stores_acknowledged();                       // (before the barrier in front of the ticket)
         }
     }
     if (q == 0) {
@@ -769,10 +769,7 @@ static __global__ __launch_bounds__(MBLOCK) void k_sorted_plan(PushArgs a, Shard
     }
     if (q <= a.G) plan->bounds[q] = a.bounds[q];
     __syncthreads();
-    if (q == 0 && a.host_counts) {
-        __threadfence_system();
-        __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (q == 0 && a.host_counts) publish_behind_sys_stores(a.host_counts + 2 * MAX_SHARDS, a.ticket);   // (the counts: acknowledged before the barrier)
 }
 // k_push for multinomial shards whose CDF carries the offset levels of k_search_multi: the 4-byte key table in LDS, four staged
 // hits per lane in flight.  What bounds these kernels is the number of DIVERGENT global loads per entry (each costs the CU's L1
@@ -792,7 +789,7 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels 
         if (blockIdx.x == 0 && a.host_counts) {   // (as in k_push: the host reads the counts while the look-ups run)
             for (int g = 0; g < 2 * a.G; ++g)
                 __hip_atomic_store(a.host_counts + g, a.counts[g * COUNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(a.host_counts + 2 * MAX_SHARDS, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            publish_behind_sys_stores(a.host_counts + 2 * MAX_SHARDS, a.ticket);
         }
     }
     const MultiTable tb = multi_table_load<LOGG>(lw_, ntiles, (uint64_t)ld_gathered(a.tot_all + 5 * a.me, a.wait_tot.tags != nullptr), reinterpret_cast<uint32_t*>(smem), [] {});

@@ -108,12 +108,15 @@ def run_local(rank, world, port, method, n_global, out_dir):
         dist.destroy_process_group()
 
 
+STEP_ESS_THRESHOLDS = (0.0, 0.5, 1.1)
+
+
 def fuzz_ops(seed, T):
     """the operation list of one sharded fuzz run (the same on every rank and in the parent's oracle run)"""
     rng = np.random.default_rng(7000 + seed)
     ops = []
     for _ in range(T):
-        op = str(rng.choice(["update", "resample", "rejuvenate", "getters", "local", "set_weights"], p=[0.3, 0.3, 0.1, 0.1, 0.1, 0.1]))
+        op = str(rng.choice(["update", "resample", "rejuvenate", "getters", "local", "set_weights", "step_ess"], p=[0.25, 0.25, 0.1, 0.1, 0.1, 0.1, 0.1]))
         ops.append((op, str(rng.choice(["multinomial", "stratified", "residual", "multinomial_sorted"])), str(rng.choice(["equal", "one heavy", "some -inf", "wide"])),
                     int(rng.integers(1 << 30))))
     return ops
@@ -147,6 +150,9 @@ def run_fuzz(rank, world, port, seed, n_global, T, out_dir):
                 sharded.pf_rejuvenate(st, None, (), 1, method="move")
             elif op == "getters":
                 scal.append((sharded.get_ess(st), sharded.get_lml_est(st)))
+            elif op == "step_ess":                           # the README loop's body as one call: never / ESS < N/2 / always resampling, with or without the MH sweep
+                sharded.pf_step_ess(st, (t + 1,), (None,), ys[t], ess_threshold=STEP_ESS_THRESHOLDS[salt % 3], method=method,
+                                    rejuvenate="move" if salt & 8 else None, check=False); t += 1
             elif op == "local":
                 sharded.pf_resample(st, method, check=False, local=True, sort_particles=bool(salt & 1),
                                     priority_fn=g.Tempering(0.5) if salt & 2 else None)        # (with a priority: through a view of the shard)

@@ -322,7 +322,7 @@ def test_hip_sharded_validity_checks(g, o, tmp_path):
 @pytest.mark.parametrize("seed,world,n_global", [(s_, 2 + s_ % 2, [6000, 6001, 40_000, 2048, 1024, 9999][s_ % 6])
                                                  for s_ in range(int(os.environ.get("GPF_FUZZ_SHARD_SEEDS", "4")))])
 def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib, seed, world, n_global, engine):
-    """random sequences of updates, global resamples (all three), rejuvenation, global getters, island resamples and adversarial
+    """random sequences of updates, global resamples (all four), rejuvenation, global getters, one-call loop iterations (pf_step_ess), island resamples and adversarial
     weight vectors on a sharded filter (2 - 3 ranks on one GPU; library engine over the loopback transport / python engine over
     gloo) against ONE oracle filter: the global resample is the unsharded one bit for bit, the island resample is the sub-state
     resample of each shard's range"""
@@ -348,6 +348,12 @@ def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib,
             f.rejuvenate("move", 1)
         elif op == "getters":
             scal.append((f.effective_sample_size(), f.log_ml_estimate()))
+        elif op == "step_ess":
+            if f.effective_sample_size() < shard_worker_gpu.STEP_ESS_THRESHOLDS[salt % 3] * n_global:
+                f.resample(method, check=False, **({"sort_particles": False} if method == "stratified" else {}))
+                if salt & 8:
+                    f.rejuvenate("move", 1)
+            f.update(ys[t]); t += 1
         elif op == "local":
             epoch = f.epoch
             for r in range(world):
