@@ -374,6 +374,7 @@ gpf_status sum_host_launch(gpf_filter* h, const double* thr);
 gpf_status sum_host_fold(gpf_filter* h, const double* thr, int* go_out = nullptr);
 gpf_status sum_gate_check(gpf_filter* h, int host_go);
 gpf_status shard_sum_launch(gpf_filter* h, const ShardSum& ss, bool* ok);
+bool shard_sum_collect();                                        // GPF_SHARD_SUM=collect: k_sum_reduce<SHARD> instead of k_sum_shard
 gpf_status wait_ticket(gpf_filter* h, volatile int64_t* tk, int64_t want, const char* what);
 gpf_status check_scan_timeout(gpf_filter* h);
 gpf_status fetch_scalars(gpf_filter* h, bool fold_raw_q = false);

@@ -351,11 +351,12 @@ static __global__ __launch_bounds__(BLOCK) void k_stage_obs(const double* __rest
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * BLOCK) dst[i] = src_host[i];
     __syncthreads();
+    // (the ticket says "the staging buffer has been READ": every load of this workgroup has returned -- its value went into a store that has
+    //  been issued -- before the barrier; nothing the host reads is published, so no fence: an agent / system release is an L2 write-back)
     if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(counter, 1u) == gridDim.x - 1) {
-            *counter = 0;
-            __hip_atomic_store(host_done, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_done, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

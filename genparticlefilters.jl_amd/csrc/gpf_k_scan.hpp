@@ -420,6 +420,9 @@ struct ShardSum {
     const double* mf_all; int np; MboxWait wait_mf;                // the gathered (max, flags) pairs (in the own mailbox)
     MboxPush push_tot; MboxWait wait_tot; const int64_t* tot_all;  // this round's {S, Ql0..3} entries: pushed to the peers / gathered in the own mailbox
     int G, me; double thr; int32_t* go;
+    // k_sum_shard only -- the (max, flags) round inside the same launch (slots != nullptr): workgroup 0 folds this shard's maximum slots and sends
+    // the pair to every peer before anybody waits for the gathered pairs (no k_pack_mflags launch in front: 4.6 us on one rank)
+    const unsigned long long* slots; double* mf_out; MboxPush push_mf;
 };
 template <bool SHARD>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_sum_reduce(InFixQ in, int64_t n, int64_t ntiles, const unsigned long long* __restrict__ slots,
@@ -611,6 +614,115 @@ __global__ __launch_bounds__(SH_BLOCK) void k_sum_host(InFixQ in, int64_t n, con
     }
     if constexpr (GATE) { if (blockIdx.x == 0 && threadIdx.x >= WAVE && threadIdx.x < WAVE + GATE_WORDS) gt.acc_next[threadIdx.x - WAVE] = 0; }
 }
+// The sharded GLOBAL summary (ShardSum, above) in k_sum_host's shape: 1024-thread workgroups, one per CU, the first trip's weights requested
+// BEFORE the gathered maxima are waited for; every workgroup adds its five partial sums into one of GATE_SLOTS accumulator lines (k_sum_host<GATE>'s,
+// the two sets alternating) and the LAST workgroup to arrive -- not a collecting workgroup that spins on tagged partials, k_sum_reduce<SHARD>: 17.8 us
+// per launch at 10^6 against k_sum_host's 9.1 -- folds the lines (one load per lane, three butterfly steps), exchanges the shard's {S, limbs} through the
+// mailboxes, publishes the global summary to pinned memory and leaves the verdict ESS < thr on the device.
+struct ShardAcc { uint64_t* acc; uint64_t* acc_next; unsigned int* arrive; };
+static __global__ __launch_bounds__(SH_BLOCK) void k_sum_shard(InFixQ in, int64_t n, WSum* __restrict__ ws_out, int64_t* __restrict__ q_host, int64_t q_ticket, ShardAcc sa, ShardSum ss)
+{
+    const int lane = lane_id(), wv = wave_id();
+    uint64_t acc[5] = {0, 0, 0, 0, 0};                // S, Ql0..3
+    double v0[SH_ROWS], v1[SH_ROWS];
+    int64_t base = (int64_t)blockIdx.x * SH_TILE;
+#pragma unroll
+    for (int k = 0; k < SH_ROWS; ++k) in.raw2(base + (int64_t)k * (2 * SH_BLOCK) + 2 * (int64_t)threadIdx.x, n, v0[k], v1[k]);
+    __shared__ double s_m; __shared__ int s_f; __shared__ int s_last;
+    __shared__ uint64_t s_p[SH_NWAVES][5];
+    if (blockIdx.x == 0 && threadIdx.x >= WAVE && threadIdx.x < WAVE + GATE_WORDS) sa.acc_next[threadIdx.x - WAVE] = 0;    // (the next launch's set)
+    if (ss.slots && blockIdx.x == 0 && wv == 0) {              // this shard's (max, flags) to every peer (k_pack_mflags)
+        double m0; int f0;
+        fold_slots(ss.slots, m0, f0);
+        const uint64_t words[2] = {d2u(m0), d2u((double)(f0 & (FLAG_NAN | FLAG_POSINF)))};
+        if (lane == 0) { ss.mf_out[0] = m0; ss.mf_out[1] = u2d(words[1]); }
+        mbox_push_wave(ss.push_mf, words);
+    }
+    mbox_wait_block(ss.wait_mf);
+    if (wv == 0) {
+        const bool mb = ss.wait_mf.tags != nullptr;
+        double m = lane < ss.np ? ld_gathered(ss.mf_all + 2 * lane, mb) : -__builtin_huge_val();
+        int f = lane < ss.np ? (int)ld_gathered(ss.mf_all + 2 * lane + 1, mb) : 0;
+        m = wave_max_f64(m);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) f |= __shfl_xor(f, s, WAVE);
+        if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+        if (lane == 0) { s_m = m; s_f = f; }
+    }
+    __syncthreads();
+    const double m = s_m; const int f = s_f;
+    in.m = m; in.flags = f;
+    for (; base < n; base += (int64_t)gridDim.x * SH_TILE) {
+#pragma unroll
+        for (int k = 0; k < SH_ROWS; ++k) {
+            uint64_t q0, q1;
+            in.conv2(base + (int64_t)k * (2 * SH_BLOCK) + 2 * (int64_t)threadIdx.x, n, v0[k], v1[k], q0, q1);
+            acc[0] += q0 + q1;
+            uint64_t lo = q0 * q0, hi = __umul64hi(q0, q0);
+            acc[1] += lo & 0xffffffffull; acc[2] += lo >> 32; acc[3] += hi & 0xffffffffull; acc[4] += hi >> 32;
+            lo = q1 * q1; hi = __umul64hi(q1, q1);
+            acc[1] += lo & 0xffffffffull; acc[2] += lo >> 32; acc[3] += hi & 0xffffffffull; acc[4] += hi >> 32;
+        }
+        const int64_t nb = base + (int64_t)gridDim.x * SH_TILE;
+        if (nb < n) {
+#pragma unroll
+            for (int k = 0; k < SH_ROWS; ++k) in.raw2(nb + (int64_t)k * (2 * SH_BLOCK) + 2 * (int64_t)threadIdx.x, n, v0[k], v1[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] = wave_sum_u64(acc[k]);
+    if (lane == 0) { for (int k = 0; k < 5; ++k) s_p[wv][k] = acc[k]; }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        uint64_t v = 0;
+        for (int w = 0; w < SH_NWAVES; ++w) v += s_p[w][threadIdx.x];
+        uint64_t* const slot = sa.acc + (blockIdx.x & (GATE_SLOTS - 1)) * 8;
+        (void)__hip_atomic_fetch_add(slot + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sys_stores_acknowledged();                     // (the adds have been performed before this workgroup counts as arrived)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(sa.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last workgroup: this shard's sums, the exchange, the publish
+    uint64_t mine[5] = {0, 0, 0, 0, 0};
+    if (wv == 0) {
+        static_assert(GATE_WORDS == WAVE, "one accumulator word per lane");
+        uint64_t v = __hip_atomic_load(sa.acc + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v += shfl_xor_u64(v, 8); v += shfl_xor_u64(v, 16); v += shfl_xor_u64(v, 32);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) mine[k] = shfl_u64(v, k);
+        if (lane == 0) {
+            __hip_atomic_store(sa.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ws_out->m = m; ws_out->flags = f; ws_out->S = mine[0];
+            for (int k = 0; k < 4; ++k) ws_out->Ql[k] = mine[1 + k];
+        }
+        mbox_push_wave(ss.push_tot, mine);
+    }
+    mbox_wait_block(ss.wait_tot);
+    if (wv == 0) {
+        const bool mb = ss.wait_tot.tags != nullptr;
+        uint64_t g5[5] = {0, 0, 0, 0, 0};
+        if (lane < ss.G) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) g5[k] = lane == ss.me ? mine[k] : (uint64_t)ld_gathered(ss.tot_all + 5 * lane + k, mb);   // (the own entry: what was just pushed)
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) g5[k] = wave_sum_u64(g5[k]);
+        if (lane == 0) {
+            const uint64_t Sg = g5[0];
+            const uint64_t lo = g5[1] + (g5[2] << 32);
+            const uint64_t hi = (g5[2] >> 32) + g5[3] + (g5[4] << 32) + (lo < g5[1] ? 1u : 0u);
+            if (ss.go) *ss.go = ss.thr >= 0.0 && !f && ess_from(Sg, hi, lo) < ss.thr ? 1 : 0;
+            __hip_atomic_store(q_host + 0, (int64_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(q_host + 1, (int64_t)Sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            uint64_t chk = (uint64_t)q_ticket ^ (uint64_t)(int64_t)f ^ Sg;
+            for (int k = 0; k < 4; ++k) { __hip_atomic_store(q_host + 2 + k, (int64_t)g5[1 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); chk ^= g5[1 + k]; }
+            __hip_atomic_store(q_host + 7, (int64_t)chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(q_host + 6, q_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 // Residual resampling needs TWO prefix sums over the same elements: the copy counts c_i = (N q_i) div S and the
 // residual weights r_i = ((N q_i) mod S) >> sh (resample.jl:99,109).  One pass computes both: one read of the weight CDF,
 // ONE 64-bit division per element (quotient and remainder), two descriptor channels polled in the same round trip.
@@ -798,9 +910,9 @@ static __global__ void k_publish_scalars(Scalars* sc, Scalars* host, long long* 
         if (fold && i >= QW && i < QW + 4) v = i == QW ? q[0] : i == QW + 1 ? q[1] : i == QW + 2 ? q[2] : q[3];   // (not read back: just written)
         __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
+    sys_stores_acknowledged();                                   // (every thread's words, before the barrier in front of the ticket: gpf_k_common.hpp)
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 } // namespace gpf

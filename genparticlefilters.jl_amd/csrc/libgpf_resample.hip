@@ -221,6 +221,18 @@ bool sum_host_ok(const gpf_filter* h)
     const int hgrid = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + SH_TILE - 1) / SH_TILE, (int64_t)h->n_cu));
     return !off && (h->n + hgrid - 1) / hgrid <= (int64_t)Q_TAG_MAX_TILES * TILE && true;
 }
+// two sets of accumulator lines, used in turn: every gated reduction (k_sum_host<GATE>, k_sum_shard) clears the other set; behind them the
+// arrival counter of k_sum_shard
+gpf_status ensure_gate_buffers(gpf_filter* h)
+{
+    if (h->gate_part) return GPF_OK;
+    HIP_TRY(h, hipMalloc(&h->gate_part, (size_t)(2 * GATE_WORDS + 8) * sizeof(uint64_t)));
+    HIP_TRY(h, hipMemsetAsync(h->gate_part, 0, (size_t)(2 * GATE_WORDS + 8) * sizeof(uint64_t), h->stream));
+    HIP_TRY(h, hipHostMalloc(&h->h_gate, sizeof(int64_t)));
+    *h->h_gate = 0;
+    h->gate_cur = 0;
+    return GPF_OK;
+}
 gpf_status sum_host_launch(gpf_filter* h, const double* thr)
 {
     gpf_status s;
@@ -229,13 +241,7 @@ gpf_status sum_host_launch(gpf_filter* h, const double* thr)
         HIP_TRY(h, hipHostMalloc(&h->h_spart, (size_t)8 * h->n_cu * sizeof(int64_t)));
         memset(h->h_spart, 0, (size_t)8 * h->n_cu * sizeof(int64_t));
     }
-    if (thr && !h->gate_part) {                                  // two sets of accumulators, used in turn: every gated reduction clears the other set
-        HIP_TRY(h, hipMalloc(&h->gate_part, (size_t)2 * GATE_WORDS * sizeof(uint64_t)));
-        HIP_TRY(h, hipMemsetAsync(h->gate_part, 0, (size_t)2 * GATE_WORDS * sizeof(uint64_t), h->stream));
-        HIP_TRY(h, hipHostMalloc(&h->h_gate, sizeof(int64_t)));
-        *h->h_gate = 0;
-        h->gate_cur = 0;
-    }
+    if (thr && (s = ensure_gate_buffers(h))) return s;
     if (thr) h->gate_cur ^= 1;
     if ((s = ensure_max(h, raw_view(h), true))) return s;
     h->q_ticket += 1;
@@ -316,9 +322,26 @@ gpf_status sum_gate_check(gpf_filter* h, int host_go)
 
 // the sharded getters' reduction (k_sum_reduce<SHARD>): launched on behalf of libgpf_shard.hip, which fills the mailbox rounds; false in *ok:
 // the filter is too large for the tagged partials (the caller takes the scan + copies)
+bool shard_sum_collect() { static const bool collect = getenv("GPF_SHARD_SUM") && !strcmp(getenv("GPF_SHARD_SUM"), "collect"); return collect; }
 gpf_status shard_sum_launch(gpf_filter* h, const ShardSum& ss, bool* ok)
 {
     *ok = false;
+    // GPF_SHARD_SUM=collect: the first form (k_sum_reduce<SHARD>: 256-thread workgroups, workgroup 0 collects tagged partials) -- A/B, tests
+    if (!shard_sum_collect()) {
+        gpf_status s0 = ensure_gate_buffers(h);
+        if (s0) return s0;
+        if (!h->h_qpub) { HIP_TRY(h, hipHostMalloc(&h->h_qpub, 8 * sizeof(int64_t))); for (int i = 0; i < 8; ++i) h->h_qpub[i] = 0; }
+        h->gate_cur ^= 1;
+        h->q_ticket += 1;
+        const int hgrid = (int)std::max<int64_t>(1, std::min<int64_t>((h->n + SH_TILE - 1) / SH_TILE, (int64_t)h->n_cu));
+        InFixQ in0{raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
+        const ShardAcc sa{h->gate_part + h->gate_cur * GATE_WORDS, h->gate_part + (1 - h->gate_cur) * GATE_WORDS, reinterpret_cast<unsigned int*>(h->gate_part + 2 * GATE_WORDS)};
+        s0 = timed(h, GPF_K_SCAN, [&] { GPF_LAUNCH(k_sum_shard, dim3(hgrid), dim3(SH_BLOCK), 0, h->stream, in0, h->n, &h->sc->raw, h->h_qpub, h->q_ticket, sa, ss); });
+        if (s0) return s0;
+        HIP_TRY(h, hipGetLastError());
+        *ok = true;
+        return GPF_OK;
+    }
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, (int64_t)h->n_cu * 4));
     if ((h->ntiles + grid - 1) / grid > Q_TAG_MAX_TILES) return GPF_OK;
     if (!h->sum_part) {

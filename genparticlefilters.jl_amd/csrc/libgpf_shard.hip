@@ -1056,8 +1056,12 @@ gpf_status shard_global_summary_launch(gpf_filter* h, double thr, bool* done)
     if ((s = shard_scratch(h))) return s;
     const int r = (int)(h->sh_round++ % SH_RING);
     double* mf = h->sh_mf + 2 * r;
-    if ((s = gpf_shard_weight_max(h, mf))) return s;             // maximum slots -> (max, flags) -> every peer's mailbox (MB_MF round)
     ShardSum ss{};
+    if (shard_sum_collect()) { if ((s = gpf_shard_weight_max(h, mf))) return s; }   // maximum slots -> (max, flags) -> every peer's mailbox (MB_MF round)
+    else {                                                       // ... the same round from inside the reduction's launch (k_sum_shard)
+        if ((s = shard_max_slots(h))) return s;
+        ss.slots = h->mslots[h->mcur]; ss.mf_out = mf; ss.push_mf = mb_begin(h, MB_MF);
+    }
     ss.mf_all = static_cast<const double*>(mb_gathered(h, MB_MF)); ss.np = h->comm_world; ss.wait_mf = mb_wait(h, MB_MF);
     ss.push_tot = mb_begin(h, MB_TOT); ss.wait_tot = mb_wait(h, MB_TOT); ss.tot_all = static_cast<const int64_t*>(mb_gathered(h, MB_TOT));
     ss.G = h->comm_world; ss.me = h->comm_rank; ss.thr = thr; ss.go = &h->sc->gate_go;
@@ -1071,6 +1075,7 @@ gpf_status shard_global_summary_launch(gpf_filter* h, double thr, bool* done)
 }
 bool shard_sum_fits(const gpf_filter* h)
 {
+    if (!shard_sum_collect()) return true;                       // k_sum_shard: 64-bit accumulators, any size
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(h->ntiles, (int64_t)h->n_cu * 4));
     return (h->ntiles + grid - 1) / grid <= Q_TAG_MAX_TILES;
 }

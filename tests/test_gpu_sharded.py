@@ -51,6 +51,14 @@ def test_sharded_step_ess_equals_single_oracle(g, o, tmp_path, monkeypatch, loop
         assert all(str(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["summaries"]) == mode for r in range(world))
 
 
+@pytest.mark.parametrize("case", [CASES[3], CASES[5]], ids=lambda c: f"{c[0]}-{c[1]}")
+def test_sharded_step_ess_collecting_reduction(g, o, tmp_path, monkeypatch, loopback_lib, case):
+    """GPF_SHARD_SUM=collect: the global summary through k_sum_reduce<SHARD> (workgroup 0 collects tagged partials) instead of k_sum_shard (accumulator
+    lines, the last workgroup to arrive exchanges and publishes) -- the same verdicts, the same bits"""
+    monkeypatch.setenv("GPF_SHARD_SUM", "collect")
+    test_sharded_step_ess_equals_single_oracle(g, o, tmp_path, monkeypatch, loopback_lib, case, 3, "mailbox")
+
+
 def test_world1_sharded_step_ess_and_getters_equal_unsharded(g, o):
     """one shard without a communicator IS the unsharded filter: its getters and its step_ess take the unsharded kernels (k_sum_host, gpf_step_ess);
     with a real 1-rank RCCL communicator (GPF_SHARD_FORCE_COLLECTIVES) the mailbox path runs -- covered by test_rccl_collectives_one_rank's getters"""
