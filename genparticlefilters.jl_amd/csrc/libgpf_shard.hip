@@ -1057,8 +1057,14 @@ gpf_status shard_global_summary_launch(gpf_filter* h, double thr, bool* done)
     const int r = (int)(h->sh_round++ % SH_RING);
     double* mf = h->sh_mf + 2 * r;
     ShardSum ss{};
-    if (shard_sum_collect()) { if ((s = gpf_shard_weight_max(h, mf))) return s; }   // maximum slots -> (max, flags) -> every peer's mailbox (MB_MF round)
-    else {                                                       // ... the same round from inside the reduction's launch (k_sum_shard)
+    // maximum slots -> (max, flags) -> every peer's mailbox (MB_MF round): its own small launch.  GPF_SHARD_FUSE_MF=1: from inside the reduction's
+    // launch (k_sum_shard's workgroup 0 pushes, every workgroup waits) -- 0.7 us faster on one rank, but then EVERY workgroup of a launch that can fill
+    // the GPU waits for a push that only the peers' launches of the same kind make: ranks that share one GPU (the loopback tests: 2 - 3 processes on
+    // one device, 256 workgroups of 1024 threads each) starve each other until the mailbox wait gives up.  Behind a separate launch the push needs
+    // 256 free thread slots somewhere, which a waiting reduction always leaves.
+    static const bool fuse_mb = getenv("GPF_SHARD_FUSE_MF") && !strcmp(getenv("GPF_SHARD_FUSE_MF"), "1");
+    if (shard_sum_collect() || !fuse_mb) { if ((s = gpf_shard_weight_max(h, mf))) return s; }
+    else {
         if ((s = shard_max_slots(h))) return s;
         ss.slots = h->mslots[h->mcur]; ss.mf_out = mf; ss.push_mf = mb_begin(h, MB_MF);
     }
