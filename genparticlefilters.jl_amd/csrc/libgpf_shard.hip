@@ -989,7 +989,10 @@ gpf_status gpf_shard_step_ess(gpf_handle h, const double* obs, int32_t n_obs, do
     const double thr = ess_frac * (double)h->cfg.n_global;
     const bool fast = !spec_off && h->mb_active && shard_sum_fits(h) && !h->pending_packed && !h->pending_gather && !h->pending_fill && !h->pending_move &&
                       !h->hist_on && h->blk_obs_size == 0 && obs != nullptr && n_obs == model_obs_dim(h->cfg.model);
-    if (!fast) {
+    // (the launch says "not available" before it has begun any mailbox round: the plain sequence is still open then)
+    bool done = false;
+    if (fast && (s = shard_global_summary_launch(h, thr, &done))) return s;
+    if (!done) {
         double ess = 0.0;
         if ((s = gpf_shard_effective_sample_size(h, &ess))) return s;
         if (ess < thr) {
@@ -1000,9 +1003,6 @@ gpf_status gpf_shard_step_ess(gpf_handle h, const double* obs, int32_t n_obs, do
         return gpf_update(h, obs, n_obs);
     }
     const ModelArgs old_args = h->args;                          // (a rejuvenation moves under the CURRENT step's observation)
-    bool done = false;
-    if ((s = shard_global_summary_launch(h, thr, &done))) return s;
-    if (!done) return fail(h, GPF_ERR_STATE, "sharded summary not available");
     if ((s = set_obs(h, obs, n_obs))) { h->args = old_args; return s; }
     GateIn gate{}; gate.flag = &h->sc->gate_go;
     if ((s = speculative_step(h, gate))) return s;
