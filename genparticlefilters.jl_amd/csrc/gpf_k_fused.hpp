@@ -56,9 +56,16 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_step_search(ModelArgs a, uint64_t
     // update_lml_est! (resample.jl:57,178-182) of the pending resample, once
     if (sa.update_lml && blockIdx.x == 0 && threadIdx.x == 0) resample_bookkeeping(sa);
     const uint64_t S = sa.ws->S;
-    auto targets = [&](int64_t base, uint64_t* T) {                    // one Philox block per aligned slot pair (gpf_math.hpp resample_u64)
+    auto targets = [&](int64_t base, uint64_t (&T)[FNS]) {             // one Philox block per aligned slot pair (gpf_math.hpp resample_u64_run)
+        if constexpr (FNS % 2 == 0) {
+            uint64_t U[FNS];
+            resample_u64_run<FNS>(sa.seed, (uint32_t)(sa.gid0 + base + FNS * (int64_t)threadIdx.x), sa.epoch, U);
 #pragma unroll
-        for (int u = 0; u < FNS; ++u) T[u] = mulhi64(resample_u64(sa.seed, (uint32_t)(sa.gid0 + base + FNS * (int64_t)threadIdx.x + u), sa.epoch), S);   // resample.jl:59
+            for (int u = 0; u < FNS; ++u) T[u] = mulhi64(U[u], S);   // resample.jl:59
+        } else {
+#pragma unroll
+            for (int u = 0; u < FNS; ++u) T[u] = mulhi64(resample_u64(sa.seed, (uint32_t)(sa.gid0 + base + FNS * (int64_t)threadIdx.x + u), sa.epoch), S);   // resample.jl:59
+        }
     };
     auto fetch = [&](const uint32_t (&idx)[FNS], double (&r)[FNS][W]) {   // new_traces .= view(traces, parents): issue, do not wait
 #pragma unroll

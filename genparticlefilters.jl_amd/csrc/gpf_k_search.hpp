@@ -614,8 +614,17 @@ __device__ __forceinline__ void multi_lookup(const MultiTable& tb, const CdfLeve
 
 // block-collective: the key table into LDS, 16 B per lane from the scan's key level (every (1 << LOGG)-th key).  The loads are
 // issued first, `between()` runs while they are in flight (the caller's first targets), then the table is written.
+// multi_table_load_s: the shard's total S is itself the result of work that waits on memory (k_search_own: the gathered shard totals, a
+// barrier) -- between() returns it, so that work runs behind the table's loads too instead of in front of them
+template <int LOGG, class Between>
+__device__ __forceinline__ MultiTable multi_table_load_s(const CdfLevels& w, int64_t ntiles, uint32_t* keys, Between&& between);
 template <int LOGG, class Between>
 __device__ __forceinline__ MultiTable multi_table_load(const CdfLevels& w, int64_t ntiles, uint64_t S, uint32_t* keys, Between&& between)
+{
+    return multi_table_load_s<LOGG>(w, ntiles, keys, [&]() -> uint64_t { between(); return S; });
+}
+template <int LOGG, class Between>
+__device__ __forceinline__ MultiTable multi_table_load_s(const CdfLevels& w, int64_t ntiles, uint32_t* keys, Between&& between)
 {
     constexpr int KT = (MULTI_LDS_BUDGET / 4 / (LOGG == 0 ? 4 : 2) + SBLOCK - 1) / SBLOCK;   // 16-byte source loads per lane that cover any table within the budget
     MultiTable tb;
@@ -628,8 +637,8 @@ __device__ __forceinline__ MultiTable multi_table_load(const CdfLevels& w, int64
     for (int r = 0; r < KT; ++r) { const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK; if (q < nq) kv[r] = src[q]; }
     tb.p2 = 1;                                                           // largest power of two <= ng
     while (2 * tb.p2 <= tb.ng) tb.p2 *= 2;
+    const uint64_t S = between();
     tb.kscale = (float)tb.ng / (float)((S >> KEY_SHIFT) + 1);            // groups per key unit: where a key would sit were the CDF linear
-    between();
 #pragma unroll
     for (int r = 0; r < KT; ++r) {
         const uint32_t q = threadIdx.x + (uint32_t)r * SBLOCK;

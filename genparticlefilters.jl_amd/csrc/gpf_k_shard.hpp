@@ -86,6 +86,21 @@ constexpr int PUSH_CHUNK = 2048;                  // output slots per chunk
 #define GPF_COUNT_STRIDE 16
 #endif
 constexpr int COUNT_STRIDE = GPF_COUNT_STRIDE;     // int64 words between counters
+// The RECEIVE counters (who serves this shard's slots) take one atomic add per workgroup and owner at the END of the kernels that count them
+// (k_search_own, k_search_own_res, k_push_scan): 256 adds on one address, ~5 ns each in a row = 1.3 us of tail per launch.  On one node (G <= 8) they
+// are striped: stripe 0 is the counter itself (index G + q), stripes 1 .. 7 use the lines of counters no shard owns (from index 2 G on; the scan
+// clears all 2 MAX_SHARDS lines every round), a workgroup adds to stripe blockIdx & 7, the reader sums.  Kernels that SET the counters (the plan
+// kernels, the pull plan) write stripe 0 and find the others zero.
+constexpr int RECV_STRIPES = 8;
+__host__ __device__ inline int recv_stripes(int G) { return G <= 8 ? RECV_STRIPES : 1; }
+__host__ __device__ inline int recv_counter_index(int G, int q, int stripe) { return (G <= 8 && stripe) ? 2 * G + (stripe - 1) * G + q : G + q; }
+static_assert(2 * 8 + (RECV_STRIPES - 1) * 8 <= 2 * MAX_SHARDS, "the stripes fit behind the counters of a node");
+__device__ __forceinline__ int64_t recv_count(const int64_t* counts, int G, int q)
+{
+    int64_t v = 0;
+    for (int s = 0; s < recv_stripes(G); ++s) v += counts[recv_counter_index(G, q, s) * COUNT_STRIDE];
+    return v;
+}
 struct PushArgs {
     uint64_t seed; uint32_t epoch;
     int64_t n_global;
@@ -167,6 +182,31 @@ __device__ __forceinline__ int push_owner(const PushTables& t, int G, int space,
         while (h < G - 1 && (uint64_t)incl[h] <= T) ++h;
     }
     T_local = T - (h ? (uint64_t)incl[h - 1] : 0);
+    return h;
+}
+// ... with the inclusive totals of shards 0 .. 6 in REGISTERS (they are the same for every lane: readfirstlane makes them scalars), one node
+// (G <= 8): seven compares against scalars and a select chain for the owner's lower end -- no LDS read, no dependent read indexed by the owner.
+// (push_owner per slot: 7 LDS broadcasts + 1 dependent LDS read, SQ_WAIT_INST_LDS 505 K cycles per launch of k_search_own against 70 K in
+//  k_search_multi, + 90 VALU instructions per slot.)  Totals of the shards from G - 1 on read as ~0: never <= T.
+struct OwnerBounds { uint64_t b[7]; };
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+__device__ __forceinline__ OwnerBounds owner_bounds(const PushTables& t, int G, int space)
+{
+    OwnerBounds ob;
+    const int64_t* incl = space ? t.c_incl : t.w_incl;
+#pragma unroll
+    for (int g = 0; g < 7; ++g) ob.b[g] = uniform_u64(g < G - 1 ? (uint64_t)incl[g] : ~0ull);
+    return ob;
+}
+__device__ __forceinline__ int push_owner(const OwnerBounds& ob, uint64_t T, uint64_t& T_local)
+{
+    int h = 0; uint64_t lo = 0;
+#pragma unroll
+    for (int g = 0; g < 7; ++g) { const bool le = ob.b[g] <= T; h += le ? 1 : 0; lo = le ? ob.b[g] : lo; }
+    T_local = T - lo;
     return h;
 }
 // pass 1: stage the hits (slots whose target this shard owns), count them per destination, and count who owns the
@@ -280,7 +320,8 @@ __global__ __launch_bounds__(PUSH_SCAN_BLOCK) void k_push_scan(PushArgs a)
     if (recv_cnt) atomicAdd(&s_recv[lane], recv_cnt);
     __syncthreads();
     if (threadIdx.x < a.G && s_recv[threadIdx.x])
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + (a.G + threadIdx.x) * COUNT_STRIDE), (unsigned long long)s_recv[threadIdx.x]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + recv_counter_index(a.G, (int)threadIdx.x, (int)(blockIdx.x & (RECV_STRIPES - 1))) * COUNT_STRIDE),
+                  (unsigned long long)s_recv[threadIdx.x]);
 }
 // ---- the shard's OWN slots (multinomial).  A slot of this shard whose target falls into this shard's part of the CDF needs no exchange
 // entry at all: its ancestor is a local particle, exactly the unsharded case.  This kernel is k_search_multi over the shard's own slots
@@ -296,37 +337,67 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_search_own(PushArgs a, CdfLevels 
     __shared__ PushTables t;
     __shared__ unsigned int s_recv[MAX_SHARDS];
     if (threadIdx.x < MAX_SHARDS) s_recv[threadIdx.x] = 0;
-    push_tables(a, t);
-    const uint64_t Sw = (uint64_t)t.w_incl[a.G - 1];
-    const uint64_t w_lo = a.me ? (uint64_t)t.w_incl[a.me - 1] : 0;
-    const MultiTable tb = multi_table_load<LOGG>(lw_, ntiles, (uint64_t)t.w_incl[a.me] - w_lo, reinterpret_cast<uint32_t*>(smem), [] {});
+    uint64_t Sw = 0;
+    // the lane's NS consecutive slots: one Philox block per aligned slot pair, the first trip's while the key table is on its way, the next trip's
+    // behind this trip's stores (as k_search_multi).  What the 4 us between this kernel and k_search_multi were (one rank, 19.4 against 15.2 us;
+    // profiles/r05d_sharded_one_rank.txt): the barrier of push_tables in front of the Philox blocks 1.4, the owner logic 1.1, 256 same-address
+    // atomics on the receive counter at the end of the workgroups 1.3 -- not the doubled Philox work, not the order of the prologue
+    const int64_t stride = (int64_t)gridDim.x * NS * SBLOCK;
+    int64_t base = (int64_t)blockIdx.x * NS * SBLOCK;
+    uint64_t Tgl[NS], U[NS];
+    auto draw = [&](int64_t b0) { resample_u64_run<NS>(a.seed, (uint32_t)(gid0 + b0 + NS * (int64_t)threadIdx.x), a.epoch, U); };
+    auto scale = [&]() {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) Tgl[u] = mulhi64(U[u], Sw);                     // resample.jl:59, global coordinates
+    };
+    // (the shard totals -- a mailbox wait, a load, a barrier -- and the first targets behind the key table's loads, not in front of them)
+    const MultiTable tb = multi_table_load_s<LOGG>(lw_, ntiles, reinterpret_cast<uint32_t*>(smem), [&]() -> uint64_t {
+        draw(base);                                                                  // (Philox needs no total: in front of the barrier of push_tables, not behind it)
+        push_tables(a, t);
+        Sw = (uint64_t)t.w_incl[a.G - 1];
+        scale();
+        return (uint64_t)t.w_incl[a.me] - (a.me ? (uint64_t)t.w_incl[a.me - 1] : 0);
+    });
     const int lane = lane_id();
     unsigned recv_cnt = 0;                                                           // lane q: this wave's slots served by shard q
-    const int64_t stride = (int64_t)gridDim.x * NS * SBLOCK;
-    for (int64_t base = (int64_t)blockIdx.x * NS * SBLOCK; base < n; base += stride) {
+    const bool node = a.G <= 8;                                                      // kernel-uniform
+    const OwnerBounds ob = owner_bounds(t, node ? a.G : 1, 0);
+    for (; base < n; base += stride) {
         const int64_t j0 = base + NS * (int64_t)threadIdx.x;
         uint64_t T[NS]; int own[NS];
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
-            const uint64_t Tg = mulhi64(resample_u64(a.seed, (uint32_t)(gid0 + j0 + u), a.epoch), Sw);     // resample.jl:59, global coordinates
+            const uint64_t Tg = Tgl[u];
             uint64_t Tl;
-            own[u] = j0 + u < n ? push_owner(t, a.G, 0, Tg, Tl) : -1;
-            T[u] = own[u] == a.me ? Tl : 0;                                          // (another shard's target: the lane rides along with a dummy)
-            for (int q = 0; q < a.G; ++q) {
-                const unsigned c = (unsigned)__popcll(__ballot(own[u] == q));
-                if (lane == q) recv_cnt += c;
+            if (a.G == 1) { own[u] = j0 + u < n ? 0 : -1; T[u] = Tg; }               // kernel-uniform: one shard owns every target (the own count: n)
+            else {
+                own[u] = node ? push_owner(ob, Tg, Tl) : push_owner(t, a.G, 0, Tg, Tl);
+                if (j0 + u >= n) own[u] = -1;
+                T[u] = own[u] == a.me ? Tl : 0;                                      // (another shard's target: the lane rides along with a dummy)
+                for (int q = 0; q < a.G; ++q) {
+                    const unsigned c = (unsigned)__popcll(__ballot(own[u] == q));
+                    if (lane == q) recv_cnt += c;
+                }
             }
         }
         uint32_t idx[NS];
         multi_lookup<LOGG, NS>(tb, lw_, n, T, idx);
 #pragma unroll
-        for (int u = 0; u < NS; ++u)
-            if (j0 + u < n) anc[j0 + u] = own[u] == a.me ? (int32_t)(gid0 + (int64_t)idx[u]) : -1;
+        for (int u = 0; u < NS; ++u) idx[u] = own[u] == a.me ? (uint32_t)(int32_t)(gid0 + (int64_t)idx[u]) : 0xffffffffu;      // (-1: another shard serves the slot)
+        int32_t* dst = anc + j0;
+        if (NS == 2 && j0 + NS <= n && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) *reinterpret_cast<int2*>(dst) = make_int2((int32_t)idx[0], (int32_t)idx[1]);
+        else {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) if (j0 + u < n) dst[u] = (int32_t)idx[u];
+        }
+        if (base + stride < n) { draw(base + stride); scale(); }
     }
     if (recv_cnt) atomicAdd(&s_recv[lane], recv_cnt);
     __syncthreads();
-    if (threadIdx.x < (unsigned)a.G && s_recv[threadIdx.x])
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + (a.G + threadIdx.x) * COUNT_STRIDE), (unsigned long long)s_recv[threadIdx.x]);
+    if (a.G == 1) { if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[(a.G + a.me) * COUNT_STRIDE] = n; }    // (every slot is an own hit)
+    else if (threadIdx.x < (unsigned)a.G && s_recv[threadIdx.x])
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + recv_counter_index(a.G, (int)threadIdx.x, (int)(blockIdx.x & (RECV_STRIPES - 1))) * COUNT_STRIDE),
+                  (unsigned long long)s_recv[threadIdx.x]);
 }
 // ... and for RESIDUAL resampling (resample.jl:96-115): an own slot below the global copy total is the jg-th deterministic copy (target jg in
 // the copy-count space, owner by the shards' inclusive copy totals), the others draw from the residual weights; own hits are looked up
@@ -347,12 +418,14 @@ static __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search
     unsigned recv_cnt = 0;
     for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
         uint64_t T[2]; int own[2]; const uint64_t* top[2]; const CdfLevels* L[2];
+        uint64_t U[2];
+        resample_u64_run<2>(a.seed, (uint32_t)(gid0 + base + 2 * (int64_t)threadIdx.x), a.epoch, U);      // (one Philox block for the lane's slot pair)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t j = base + 2 * (int64_t)threadIdx.x + u;
             const uint64_t jg = (uint64_t)(gid0 + j);
             uint64_t Tg = 0, Tl = 0; int space = 0;
-            push_target<1>(a, sc, jg, resample_u64(a.seed, (uint32_t)jg, a.epoch), Tg, space);
+            push_target<1>(a, sc, jg, U[u], Tg, space);
             own[u] = j < n ? push_owner(t, a.G, space, Tg, Tl) : -1;
             const bool mine = own[u] == a.me;
             T[u] = mine ? Tl : 0;                                                    // (another shard's target: the lane rides along with a dummy)
@@ -373,7 +446,8 @@ static __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search
     if (recv_cnt) atomicAdd(&s_recv[lane], recv_cnt);
     __syncthreads();
     if (threadIdx.x < (unsigned)a.G && s_recv[threadIdx.x])
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + (a.G + threadIdx.x) * COUNT_STRIDE), (unsigned long long)s_recv[threadIdx.x]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.counts + recv_counter_index(a.G, (int)threadIdx.x, (int)(blockIdx.x & (RECV_STRIPES - 1))) * COUNT_STRIDE),
+                  (unsigned long long)s_recv[threadIdx.x]);
 }
 // materialize() of a commit with own hits: rows_out[j] = rows_in[anc[j] - gid0], lw[j] = 0 for the slots with anc[j] >= 0
 // (own_range != nullptr: the own hits are the slots [own_range[0], own_range[1]) -- stratified resampling; else the slots with anc >= 0)
@@ -503,7 +577,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
         // reads them while this kernel is still looking ancestors up (system-scope stores, ticket last)
         if (blockIdx.x == 0 && a.host_counts) {
             for (int g = 0; g < 2 * a.G; ++g)
-                __hip_atomic_store(a.host_counts + g, a.counts[g * COUNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.host_counts + g, g < a.G ? a.counts[g * COUNT_STRIDE] : recv_count(a.counts, a.G, g - a.G), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             publish_behind_sys_stores(a.host_counts + 2 * MAX_SHARDS, a.ticket);
         }
     }
@@ -788,7 +862,7 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels 
         s_off[a.G] = o;
         if (blockIdx.x == 0 && a.host_counts) {   // (as in k_push: the host reads the counts while the look-ups run)
             for (int g = 0; g < 2 * a.G; ++g)
-                __hip_atomic_store(a.host_counts + g, a.counts[g * COUNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.host_counts + g, g < a.G ? a.counts[g * COUNT_STRIDE] : recv_count(a.counts, a.G, g - a.G), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             publish_behind_sys_stores(a.host_counts + 2 * MAX_SHARDS, a.ticket);
         }
     }

@@ -87,6 +87,28 @@ GPF_HD uint64_t resample_u64(uint64_t seed, uint32_t slot, uint32_t epoch)
 {
     return resample_pick(rng(seed, slot >> 1, 0, epoch, TAG_RESAMPLE), slot);
 }
+// ... of NS consecutive slots from s0 on (NS even): one block per ALIGNED slot pair, one more when the run starts odd.  (resample_u64 once per
+// slot computes every block twice: the parity of a run's first slot is uniform over a kernel -- one branch -- but not known to the compiler.)
+template <int NS>
+GPF_HD void resample_u64_run(uint64_t seed, uint32_t s0, uint32_t epoch, uint64_t (&U)[NS])
+{
+    static_assert(NS % 2 == 0, "whole slot pairs");
+    const uint32_t sb = s0 >> 1;
+    if (!(s0 & 1u)) {
+#pragma unroll
+        for (int q = 0; q < NS / 2; ++q) {
+            const Philox b = rng(seed, sb + (uint32_t)q, 0, epoch, TAG_RESAMPLE);
+            U[2 * q] = u64(b.w0, b.w1); U[2 * q + 1] = u64(b.w2, b.w3);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q <= NS / 2; ++q) {
+            const Philox b = rng(seed, sb + (uint32_t)q, 0, epoch, TAG_RESAMPLE);
+            if (q > 0) U[2 * q - 1] = u64(b.w0, b.w1);
+            if (q < NS / 2) U[2 * q] = u64(b.w2, b.w3);
+        }
+    }
+}
 
 // ------------------------------------------------------------------ log (positive normal x)
 GPF_HD double log_(double x)

@@ -273,9 +273,16 @@ gpf_status gpf_shard_counts(gpf_handle h, int32_t G, int64_t* host_counts)
         // k_push publishes the counts to pinned host memory when it STARTS: poll the ticket (the kernel keeps running)
         if ((s = wait_ticket(h, h->h_shard_counts + 2 * MAX_SHARDS, h->push_ticket, "push counts"))) return s;
     } else {
-        for (int k = 0; k < 2 * G; ++k)                          // (the counters sit COUNT_STRIDE words apart on the device, densely in the mirror)
-            HIP_TRY(h, hipMemcpyAsync(h->h_shard_counts + k, h->shard_counts + (size_t)k * COUNT_STRIDE, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        // (the counters sit COUNT_STRIDE words apart on the device, densely in the mirror; the receive counters' stripes behind them)
+        std::vector<int64_t> all((size_t)2 * MAX_SHARDS * COUNT_STRIDE);
+        HIP_TRY(h, hipMemcpyAsync(all.data(), h->shard_counts, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int g = 0; g < G; ++g) {
+            h->h_shard_counts[g] = all[(size_t)g * COUNT_STRIDE];
+            int64_t v = 0;
+            for (int st = 0; st < recv_stripes(G); ++st) v += all[(size_t)recv_counter_index(G, g, st) * COUNT_STRIDE];
+            h->h_shard_counts[G + g] = v;
+        }
     }
     for (int g = 0; g < G; ++g) { host_counts[g] = h->h_shard_counts[g]; host_counts[G + g] = h->h_shard_counts[G + g]; }
     return GPF_OK;
