@@ -471,9 +471,12 @@ gpf_status shard_summary(gpf_filter* h, int want_q)
     double* mf = h->sh_mf + 2 * r; int64_t* tot = h->sh_tot + 5 * r;
     double* mf_all = alias ? mf : h->sh_mf_all + 2 * G * r; int64_t* tot_all = alias ? tot : h->sh_tot_all + 5 * G * r;
     // One shard without a communicator: the first summary -- (max, flags) -- is folded inside the scan's launch (no k_pack_mflags launch).
-    // With the mailboxes the same fusion is possible (GPF_SHARD_FUSE_MF=1: the scan's workgroup 0 pushes, every workgroup waits) and was
-    // measured SLOWER on one rank (+6 us per step: the push's system-scope stores land on the critical path of every scan workgroup instead
-    // of in an earlier launch), so the separate launch stays; as an RCCL all-gather the summary needs its own launch ahead of the collective.
+    // With the mailboxes the same fusion is possible (GPF_SHARD_FUSE_MF=1: the scan's workgroup 0 pushes, every workgroup waits).  Round 4 measured
+    // it SLOWER on one rank (+6 us per step) -- that was the push's system-scope RELEASE store, an L2 write-back on the critical path of every scan
+    // workgroup; with sealed entries (gpf_k_common.hpp mbox_seal) it is 1 - 2 us FASTER (58.6 / 47.5 / 52.2 -> 57.8 / 45.9 / 50.5 us per step,
+    // multinomial / stratified / sorted).  Still opt-in: every workgroup of the launch waits for pushes that only the peers' launches of the same
+    // kind make, so ranks that SHARE a GPU can starve each other (shard_global_summary_launch); for ranks with a GPU each.  As an RCCL all-gather
+    // the summary needs its own launch ahead of the collective.
     static const bool fuse_mb = getenv("GPF_SHARD_FUSE_MF") && !strcmp(getenv("GPF_SHARD_FUSE_MF"), "1");
     const bool fuse = alias || (mb && fuse_mb);
     if (fuse) { if ((s = shard_ready(h)) || (s = shard_max_slots(h))) return s; }

@@ -185,6 +185,17 @@ def test_library_engine_several_ranks_over_loopback(g, o, tmp_path, monkeypatch,
     test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
 
 
+@pytest.mark.parametrize("one_call", [False, True])
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[7]], ids=lambda c: f"{c[0]}-{c[1]}")
+def test_library_engine_fused_max_round(g, o, tmp_path, monkeypatch, loopback_lib, case, one_call):
+    """GPF_SHARD_FUSE_MF=1: the (max, flags) mailbox round rides in its consumer's launch (workgroup 0 of the weight scan / of k_sum_shard pushes, every
+    workgroup waits) instead of k_pack_mflags' own launch -- the form for ranks that have a GPU each (faster by 1 - 2 us per step on one rank); here 2 ranks
+    on one GPU at sizes whose launches fit side by side.  The same bits."""
+    monkeypatch.setenv("GPF_SHARD_FUSE_MF", "1")
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=2, one_call=one_call)
+
+
 @pytest.mark.parametrize("case", [CASES[3], CASES[5]], ids=lambda c: f"{c[0]}-{c[1]}")
 def test_library_engine_getters_through_the_scan(g, o, tmp_path, monkeypatch, loopback_lib, case):
     """GPF_SHARD_GETTERS=scan: the sharded ESS / log-ML getters through the weight scan, copies and a stream synchronisation (the round-4 form)
