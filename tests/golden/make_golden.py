@@ -29,6 +29,11 @@ CASES = [
     ("bearings4_residual_mh_ess", "bearings4", "residual", True, None, ("move", 1), True),
     ("sv1_multinomial_reweight", "sv1", "multinomial", True, None, ("reweight", 1), False),
     ("object_motion_residual_mh_ess", "object_motion", "residual", True, None, ("move", 1), True),
+    # round 5: the sorted-uniforms multinomial (opt-in), mh with a native proposal (Gen.mh(trace, proposal, args): the LG-SSM's locally optimal
+    # proposal, 2 sweeps), and the README loop's iteration as ONE call (pf_step_ess on the device against the oracle's separate calls)
+    ("lgssm2_multinomial_sorted", "lgssm2", "multinomial_sorted", True, None, None, False),
+    ("lgssm2_stratified_mh_proposal", "lgssm2", "stratified", False, None, ("move_proposal", 2), False),
+    ("bearings4_residual_mh_step_ess", "bearings4", "residual", False, None, ("move", 1), "one_call"),
 ]
 
 
@@ -43,7 +48,7 @@ def run_case(model_name, method, sort, alpha, rejuv, ess_trig, backend):
         snap = lambda: (f.rows.copy(), f.lw.copy(), f.parents.copy(), f.effective_sample_size(), f.log_ml_estimate())
         ess = f.effective_sample_size
         res = lambda: f.resample(method, priority_alpha=alpha, sort_particles=sort, check=False)
-        rej = lambda: f.rejuvenate(*rejuv)
+        rej = (lambda: f.rejuvenate("move", rejuv[1], proposal=())) if rejuv and rejuv[0] == "move_proposal" else (lambda: f.rejuvenate(*rejuv))
         upd = lambda y: f.update(y)
     else:
         st = g.pf_initialize(model, (1,), ys[0], N, seed=SEED, keep_prev=keep)
@@ -52,11 +57,24 @@ def run_case(model_name, method, sort, alpha, rejuv, ess_trig, backend):
         pf = None if alpha is None else g.Tempering(alpha)
         kw = dict(sort_particles=sort) if method == "stratified" else {}
         res = lambda: g.pf_resample(st, method, priority_fn=pf, check=False, **kw)
-        rej = lambda: g.pf_rejuvenate(st, None, (), rejuv[1], method=rejuv[0])
+        if rejuv and rejuv[0] == "move_proposal":
+            rej = lambda: g.pf_move_accept(st, g.mh, (g.locally_optimal_move,), rejuv[1])
+        else:
+            rej = lambda: g.pf_rejuvenate(st, None, (), rejuv[1], method=rejuv[0])
         upd = lambda y: g.pf_update(st, (0,), (None,), y)
     steps = []
     steps.append(snap())
     for t in range(1, T):
+        if ess_trig == "one_call":                   # one snapshot per iteration: the device runs the whole iteration inside one call
+            if backend == "hip":
+                g.pf_step_ess(st, (0,), (None,), ys[t], ess_threshold=0.5, method=method, rejuvenate=rejuv[0], n_iters=rejuv[1],
+                              check=False, sort_particles=sort)
+            else:
+                if ess() < 0.5 * N:
+                    res(); rej()
+                upd(ys[t])
+            steps.append(snap())
+            continue
         if (not ess_trig) or ess() < 0.5 * N:
             res()
             if rejuv:
