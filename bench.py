@@ -362,7 +362,7 @@ def main():
         return {"workload": workload, "value": round(n_global * k / seconds, 1), "unit": "particle-steps/sec", "steps": k,
                 "ms_per_step": round(seconds / k * 1e3, 5)}
 
-    strat = island = plans = sorted_variant = strat_sorted = links = None
+    strat = island = plans = sorted_variant = strat_sorted = links = exchange_modes = calibration = headline_phases = None
     if not sharded_mode and not args.headline_only:
         # the OPT-IN sorted form of the multinomial resampler (gpf.h GPF_RESAMPLE_MULTINOMIAL_SORTED): same offspring-count
         # law, ancestors in non-decreasing order -- NOT the reference's slot order, so a named variant beside the unchanged headline
@@ -407,6 +407,24 @@ def main():
             return f
         lib_engine = getattr(state.backend, "lib_comm", False)
         links = {}
+
+        def phases_of(step_fn, k=30):
+            """`phases_us`: where a step of this variant spends its time on THIS rank (rank 0 prints its own), microseconds per step from events at
+            the phase boundaries on the handle's stream + one host timer around the wait for the exchange's split sizes (gpf.h gpf_phase_times).
+            A pass of its own behind the timed loop: the marks cost an event each."""
+            if not lib_engine:
+                return None
+            for i in range(3):
+                step_fn(i)
+            barrier()
+            state.backend.phase_timing(True)
+            for i in range(k):
+                step_fn(i)
+            ph = state.backend.phase_times()
+            state.backend.phase_timing(False)
+            barrier()
+            return ph
+        headline_phases = phases_of(step_of("multinomial"))
         if headline_traffic is not None:                             # the timed headline loop itself (i.i.d. multinomial, the plan named in exchange_plans.timed)
             calls, sent, recv, eb = headline_traffic
             peers = max(world - 1, 1)
@@ -436,29 +454,58 @@ def main():
         strat = variant_line("same filter, stratified resample every step, sort_particles=false (BASELINE.json configs[2])",
                              kv, link_bytes("stratified", lambda: variant(step_of("stratified"), kv), None,
                                             "boundary slabs: ~ cv sqrt(h n) slots per shard boundary (DESIGN.md 6.7: 2-4e3 at n = 1e6), not (G-1)/G of the rows"))
+        strat["phases_us"] = phases_of(step_of("stratified"))
+        # how the slabs travel (gpf.h gpf_comm_set_exchange): peer stores into the destination ranks' receive windows ("p2p": no host wait, no
+        # ncclGroup) against packed entries through grouped ncclSend / ncclRecv ("rccl").  The line above ran the mode named in "timed"; both are timed here
+        if lib_engine:
+            timed_mode = state.backend.exchange()
+            strat["exchange"] = timed_mode
+            exchange_modes = {"timed": timed_mode}
+            for md in ("p2p", "rccl"):
+                try:
+                    state.backend.set_exchange(md)
+                except Exception as e:                               # noqa: BLE001 -- no windows on this communicator: the line says so
+                    exchange_modes[md] = {"unavailable": str(e)}
+                    continue
+                exchange_modes[md] = {}
+                for meth in ("stratified", "multinomial_sorted"):
+                    ln = variant_line(f"{meth} resample every step, slabs through {md}", kv, variant(step_of(meth), kv))
+                    ln["phases_us"] = phases_of(step_of(meth))
+                    exchange_modes[md][meth] = ln
+            state.backend.set_exchange(timed_mode)
         # the opt-in sorted form of the HEADLINE's resampler across shards: the same offspring-count law as :multinomial,
         # ascending targets -> every shard serves one slot range, the exchange is boundary slabs like the stratified one
         try:
             sorted_variant = variant_line("same filter, opt-in multinomial_sorted resample every step across the shards (sorted uniforms: one served slot range per shard)",
                                           kv, link_bytes("multinomial_sorted", lambda: variant(step_of("multinomial_sorted"), kv), None,
                                                          "boundary slabs: the sorted uniforms' spread ~ sqrt(N) slots per shard boundary plus the shards' weight imbalance"))
+            sorted_variant["phases_us"] = phases_of(step_of("multinomial_sorted"))
         except Exception as e:                                       # noqa: BLE001 -- a variant must not take the headline line down
             sorted_variant = {"error": repr(e)}
         # the communication-free "island" mode (every shard resamples locally with the reference's sub-state semantics,
         # SURVEY.md 8e): a different estimator, reported for comparison only
         island = variant_line("same filter, every shard resamples its own particles (multinomial, sub-state semantics), no exchange",
                               kv, variant(step_of("multinomial", local=True), kv))
-        # the two exchange plans of the i.i.d. resamplers (gpf.h gpf_comm_set_plan): the headline ran the plan
-        # named in "timed"; with >= 100 steps both are timed so that a multi-GPU run can decide between them
-        if getattr(state.backend, "lib_comm", False) and K >= 100:
+        # the two exchange plans of the i.i.d. resamplers (gpf.h gpf_comm_set_plan): the headline ran the plan named in "timed"; both
+        # are timed over a FIXED 100 steps whatever --steps says (the driver's scaling command runs 20), so that the first multi-GPU run can decide
+        if lib_engine:
             timed_plan = state.backend.plan()
             plans = {"timed": timed_plan}
+            kp = 100
             for pl in ("push", "pull"):
                 state.backend.set_plan(pl)
-                plans[pl] = variant_line(f"headline workload, exchange plan {pl}", kv,
-                                         link_bytes(f"multinomial_{pl}", lambda: variant(step_of("multinomial"), kv), round(n_local * (world - 1) / world, 1),
+                plans[pl] = variant_line(f"headline workload, exchange plan {pl}", kp,
+                                         link_bytes(f"multinomial_{pl}", lambda: variant(step_of("multinomial"), kp), round(n_local * (world - 1) / world, 1),
                                                     "i.i.d. ancestors: (G-1)/G of a shard's rows leave it every step, n / G entries per link"))
+                plans[pl]["phases_us"] = phases_of(step_of("multinomial"))
             state.backend.set_plan(timed_plan)
+            # what the transports cost on this machine (gpf.h gpf_comm_calibrate): the headline's exchange shape -- n / G packed entries to and from every
+            # peer, grouped ncclSend / ncclRecv -- as a measured per-link rate (the scaling worksheet of DESIGN.md 6.7 ASSUMES 76 GB/s), and one mailbox round
+            try:
+                calibration = state.backend.calibrate(max(n_local // world, 1), 20)
+                calibration["slab_exchange"] = state.backend.calibrate(4096, 20)       # ... and a boundary slab's size: the group's latency floor
+            except Exception as e:                                   # noqa: BLE001
+                calibration = {"error": repr(e)}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), bounded sample, rank 0 / N=1 only ----
     cpu = cpu_all = None
@@ -518,6 +565,8 @@ def main():
             "stratified_variant": strat, "local_resample_variant": island, "exchange_plans": plans,
             "multinomial_sorted_variant": sorted_variant, "stratified_sort_particles_variant": strat_sorted,
             "exchange_bytes_per_link": links,
+            # N > 1, library engine: where a step's time goes (rank 0's own phases), both slab transports, what the links and mailboxes measure here
+            "phases_us": headline_phases, "slab_exchange_modes": exchange_modes, "transport_calibration": calibration,
         }
     else:
         out = None

@@ -108,6 +108,11 @@ SYMBOLS = [
     ("gpf_comm_traffic", C.c_int, [_H, C.POINTER(C.c_int64), C.c_int32]),
     ("gpf_comm_set_plan", C.c_int, [_H, C.c_int32]),
     ("gpf_comm_plan", C.c_int, [_H, _pi32]),
+    ("gpf_comm_calibrate", C.c_int, [_H, C.c_int64, C.c_int32, _pd]),
+    ("gpf_comm_set_exchange", C.c_int, [_H, C.c_int32]),
+    ("gpf_comm_exchange", C.c_int, [_H, _pi32]),
+    ("gpf_phase_timing", C.c_int, [_H, C.c_int32]),
+    ("gpf_phase_times", C.c_int, [_H, _pd, _pi64]),
     ("gpf_shard_resample", C.c_int, [_H, C.c_int32, C.c_int32, _pi32]),
     ("gpf_shard_resample_tempered", C.c_int, [_H, C.c_int32, C.c_double, C.c_int32, _pi32]),
     ("gpf_shard_effective_sample_size", C.c_int, [_H, _pd]),

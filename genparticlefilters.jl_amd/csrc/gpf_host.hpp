@@ -43,6 +43,14 @@ struct Timer {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
+// gpf_phase_timing: events on the handle's stream at the phase boundaries of a sharded resample and of the propagate that commits it.  A mark names the
+// phase that ENDS there (-1: a sequence begins); the time of a phase = from the mark in front of it, idle gaps included (GPU timeline, not kernel time).
+struct PhaseTimer {
+    bool on = false;
+    std::vector<std::pair<int, hipEvent_t>> marks;
+    double host_wait_us = 0.0;          // wall clock the host spent blocked on the exchange's split sizes
+    int64_t resamples = 0;
+};
 
 } // namespace gpfh
 
@@ -146,13 +154,24 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     std::vector<void*> mb_opened;        // peers' mailboxes opened with hipIpcOpenMemHandle (closed by gpf_comm_destroy)
     bool mb_active = false;
     bool mb_engine = false;              // set by the library engine around its phase calls: they push / wait through the mailbox
+    // the slot-addressed receive window (gpf_k_common.hpp RingOut / RingIn): one entry of W + 2 words per local slot and parity, mapped by every peer
+    uint64_t* ring = nullptr;            // this rank's window (device memory, exported through hipIpc)
+    uint64_t** ring_peers = nullptr;     // device array [world]: every rank's window as mapped in this process
+    std::vector<void*> ring_opened;
+    bool ring_active = false;
+    int64_t ring_parity_words = 0;       // words of one parity: (slots of the largest shard) x (W + 2)
+    uint64_t ring_seq = 0;               // window exchanges so far: the same on every rank (SPMD call order)
+    int exchange_mode = 0;               // gpf_comm_set_exchange: GPF_SHARD_EXCHANGE_RCCL | _P2P (the resamplers with ascending targets)
+    bool ring_now = false;               // set by the library engine around its phase calls: this resample exchanges through the windows
+    bool pend_ring = false; uint64_t pend_ring_seq = 0;   // the pending commit's entries sit in the window (exchange pend_ring_seq)
+    int64_t* tr_dev = nullptr;           // device {entries sent, received} of the window exchanges (the host never learns their counts: gpf_comm_traffic reads these)
     // what the shard phases summarise / pack on behalf of the engine (defaults: the raw log-weights, no extra field)
     PrioView sum_pv{nullptr, nullptr, 0.0, 0}; bool sum_pv_set = false; WSum* sum_slot = nullptr; bool sum_no_cdf = false;
     int push_extra = 0; PrioView push_pv{nullptr, nullptr, 0.0, 0};
     uint64_t sh_round = 0;               // summary rounds so far: the local / gathered arrays are rings of SH_RING rounds
     const double* cur_mf_all = nullptr; const int64_t* cur_tot_all = nullptr; const int64_t* cur_cr_all = nullptr;   // the gathered summaries of the current round
-    uint64_t mb_seq[MB_KINDS] = {0, 0, 0};   // rounds so far per kind: the same on every rank (SPMD call order)
-    uint64_t mb_cur[MB_KINDS] = {0, 0, 0};   // the round whose entries the current gathered pointers name
+    uint64_t mb_seq[MB_KINDS] = {0, 0, 0, 0};   // rounds so far per kind: the same on every rank (SPMD call order)
+    uint64_t mb_cur[MB_KINDS] = {0, 0, 0, 0};   // the round whose entries the current gathered pointers name
     int32_t* h_timeout = nullptr;        // pinned: set by a scan whose bounded inter-workgroup wait gave up (checked on the host)
     int scan_blocks_per_cu = 2;          // resident scan workgroups per CU the launch may rely on (occupancy query)
     int wscan_blocks_per_cu = 2;         // ... of the weight scans k_scan<InFixQ, *> alone (fewer registers than the residual scan)
@@ -191,6 +210,7 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     int64_t tr_calls = 0, tr_sent = 0, tr_recv = 0, tr_entry_bytes = 0;
     int last_flags = 0;                  // safe_softmax flags (FLAG_*) of the latest resample that read them on the host (resample_impl)
     gpfh::Timer timers[GPF_K_COUNT];
+    gpfh::PhaseTimer phases;
     std::string err;
 };
 
@@ -254,6 +274,15 @@ gpf_status timed(gpf_filter* h, int id, F&& launch)
     g_ev_start = g_ev_stop = nullptr;
     t.ev.emplace_back(a, b);
     return GPF_OK;
+}
+
+inline void phase_mark(gpf_filter* h, int id)
+{
+    if (!h->phases.on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, h->stream);
+    h->phases.marks.emplace_back(id, e);
 }
 
 // ------------------------------------------------------------------ shard mailboxes (host side)

@@ -176,8 +176,8 @@ __device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v)
 //   on tag == seq (system-scope ACQUIRE), then reads the payload with system-scope loads (they bypass the non-coherent L2, so
 //   the memory type of the mailbox does not matter).  Tags only grow: slots are never cleared; a peer can run at most one
 //   round ahead (it needs this rank's entry of round r to finish round r), so four slots never alias.
-constexpr int MB_KINDS = 3, MB_SLOTS = 4;
-enum : int { MB_MF = 0, MB_TOT = 1, MB_CR = 2 };
+constexpr int MB_KINDS = 4, MB_SLOTS = 4;
+enum : int { MB_MF = 0, MB_TOT = 1, MB_CR = 2, MB_CAL = 3 /* gpf_comm_calibrate's rounds */ };
 __host__ __device__ constexpr int mb_words(int kind) { return kind == MB_TOT ? 5 : 2; }
 // offsets in u64 words inside a mailbox
 __host__ __device__ constexpr int64_t mb_payload_off(int kind, int slot)
@@ -200,6 +200,15 @@ template <class T> __device__ __forceinline__ T ld_gathered(const T* p, bool in_
 // (sc0 sc1): all that "behind" needs is their acknowledgement, s_waitcnt vmcnt(0).  A system-scope RELEASE store puts `buffer_wbl2 sc0 sc1` in
 // front instead -- a write-back of the whole L2, i.e. of the tens of MB of rows the propagate has just written: 3 - 5 us in kernels that are
 // otherwise one wave (k_pack_mflags 5.5 us, k_set_global / k_export_residual 4.8, +3 us on the weight scan behind a mailbox wait).
+// ISA DEPENDENCY (checked at compile time below): on the gfx9 family (gfx90a / gfx942 / gfx950) stores and non-returning atomics are counted by vmcnt;
+// gfx10+ counts them in vscnt, where this wait would order nothing.  What stands behind this wait must be (a) atomic stores / non-returning atomics
+// of the SAME thread -- write-through at their scope, so "acknowledged" means "performed at that scope" --, never plain stores (those may still sit
+// in the L2 of this XCD), and (b) read back with atomic loads of at least the same scope.  The mailbox entries and window entries do not even rely
+// on this: their seals validate the words whatever order they arrive in; the accumulator lines + arrival counters of k_sum_shard / k_sorted_plan
+// and the pinned tickets do (agent- / system-scope atomics on both sides).
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx90a__) || defined(__gfx942__) || defined(__gfx950__))
+#error "sys_stores_acknowledged() relies on vmcnt counting stores (gfx90a / gfx942 / gfx950); on another ISA use __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"agent\")"
+#endif
 __device__ __forceinline__ void sys_stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <class T> __device__ __forceinline__ void publish_behind_sys_stores(T* p, T v)
 {
@@ -259,6 +268,60 @@ __device__ __forceinline__ void mbox_wait_block(const MboxWait& w)
         }
     }
     __syncthreads();
+}
+
+// ----------------------------------------------------------------------------- slot-addressed receive window (multi-GPU slab exchange)
+// The resamplers with ascending targets (stratified, sorted multinomial) exchange boundary slabs: a few thousand rows per shard boundary
+// (DESIGN.md 6.7).  As a grouped ncclSend / ncclRecv that costs a host wait for the split sizes and the group's latency -- all of the
+// predicted weak-scaling loss of BASELINE configs[2].  Instead every rank exports a WINDOW of one entry per local slot (device memory mapped
+// by its peers through hipIpc, like the mailboxes); the merge kernel of the shard that SERVES slot j of rank g (k_search_strat's pack loop)
+// stores the entry [row (W words) | global ancestor id | seal] straight into window_g[j] (xGMI peer stores), and rank g's next propagate
+// (k_step<GATHER>, PackedCommit::ring) reads window[j] for the slots outside its own range.  Every slot is served by exactly one shard and
+// the window is addressed by the DESTINATION slot: no counts, no offsets, no capacity to overflow, nothing for the host to wait for.
+// seal = the exchange's sequence number folded with the entry's words (mbox_seal): the consumer recomputes it from the words it reads and
+// polls until it matches, so the protocol needs no ordering between the stores, and an entry of an earlier exchange (another seq) never
+// validates.  Two parities alternate (a peer cannot start exchange r + 1 before this rank has sent it the summaries of r + 1, which this
+// rank's stream only does behind the propagate that consumed r: one parity would do; the second is slack).
+constexpr int RING_PARITIES = 2;
+struct RingOut { uint64_t* const* peers; int64_t off; uint64_t seq; };     // producer: peers[g] = rank g's window as mapped HERE (nullptr: no window), off = the parity's word offset
+struct RingIn  { const uint64_t* base; uint64_t seq; int32_t* timeout; };  // consumer: own window + the parity's offset (nullptr: no window)
+constexpr unsigned RING_SPIN_LIMIT = 1u << 22;     // x ~2 us per probe: as the mailbox wait, a peer may be ~10 s late before the wait gives up and flags the run
+// one entry, W row words: every lane for itself (system-scope write-through stores; no ordering needed)
+__device__ __forceinline__ void ring_store(uint64_t* dst, const double* row, int W, uint64_t anc, uint64_t seq)
+{
+    uint64_t x = seq;
+    for (int c = 0; c < W; ++c) {
+        const uint64_t w = d2u(row[c]);
+        x = (x ^ w) * 0x9E3779B97F4A7C15ull;
+        __hip_atomic_store(dst + c, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    x = (x ^ anc) * 0x9E3779B97F4A7C15ull;
+    __hip_atomic_store(dst + W, anc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + W + 1, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the entry of local slot `slot`: polls until the words it reads carry the seal of exchange in.seq (system-scope loads: the peers wrote them)
+template <int W>
+__device__ __forceinline__ uint64_t ring_load(const RingIn& in, int64_t slot, double (&r)[W])
+{
+    const uint64_t* e = in.base + slot * (W + 2);
+    uint64_t w[W + 2];
+    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+        for (int k = 0; k < W + 2; ++k) w[k] = ld_sys(e + k);
+        uint64_t x = in.seq;
+#pragma unroll
+        for (int k = 0; k < W + 1; ++k) x = (x ^ w[k]) * 0x9E3779B97F4A7C15ull;
+        if (x == w[W + 1]) break;
+        __builtin_amdgcn_s_sleep(8);
+        // (a lane that gave up has flagged the run: the others follow at their next look instead of waiting the limit out one by one)
+        if (spins > RING_SPIN_LIMIT || ((spins & 1023u) == 1023u && __hip_atomic_load(in.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+            __hip_atomic_store(in.timeout, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < W; ++c) r[c] = u2d(w[c]);
+    return w[W];
 }
 
 // order-preserving key of Julia's isless on Float64 (-0.0 < 0.0); descending sort = ascending on ~key (K10), and its inverse

@@ -121,7 +121,10 @@ struct ShardPlan {
 // extra = 1 (a prioritised resample, priority_fn = w -> alpha w, resample.jl:51-52): one more double per entry, log_ws = lw[a] - lp[a]
 // (update_weights!, resample.jl:198) -- the receiver does not hold its ancestors' weights
 struct PackOut { const double* rows; double* packed; int64_t capacity, gid0; int W; int extra; PrioView pv;
-                 int32_t* own_anc; int me; };   // own_anc != nullptr: entries for shard `me` itself are not packed -- their GLOBAL ancestor id goes to own_anc[slot inside the shard]
+                 int32_t* own_anc; int me;      // own_anc != nullptr: entries for shard `me` itself are not packed -- their GLOBAL ancestor id goes to own_anc[slot inside the shard]
+                 // ring.peers != nullptr (the slot-addressed receive windows, gpf_k_common.hpp): the entries for the OTHER shards are not packed either --
+                 // [row | global ancestor id | seal] goes straight into the destination rank's window at the slot's local index (needs own_anc)
+                 RingOut ring; };
 struct SearchArgs {
     CdfLevels w;                                                      // weights (or residual weights for the tail)
     CdfLevels c;                                                      // residual: copy counts
@@ -1292,7 +1295,7 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
     DBG_STRAT(2, wall_clock64());
     const int64_t jb = j0 + MSLOTS * tid;
     const uint32_t last = (uint32_t)(a.n_cells - 1);
-    if (a.plan && a.pack.packed) {
+    if (a.plan && (a.pack.packed || a.pack.ring.peers)) {
         // ---- a shard: the served slots leave as exchange entries in slot order (which is grouped by destination shard).  The
         //      ancestors go through LDS so that neighbouring LANES take neighbouring entries: the packed stores are contiguous
         //      and the row reads (ascending ancestors) coalesce
@@ -1344,6 +1347,12 @@ __global__ __launch_bounds__(MBLOCK, 2) void k_search_strat(SearchArgs a)
                 continue;
             }
             const double2* src = reinterpret_cast<const double2*>(a.pack.rows + i * W);
+            if (a.pack.ring.peers) {                                  // straight into the window of the rank that holds the slot (peer stores)
+                double row[8];
+                for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; row[2 * c] = v.x; row[2 * c + 1] = v.y; }
+                ring_store(a.pack.ring.peers[lo] + a.pack.ring.off + (jg - s_bnd[lo]) * (W + 2), row, W, (uint64_t)(a.pack.gid0 + i), a.pack.ring.seq);
+                continue;
+            }
             double* dst = a.pack.packed + (e - skip) * (W + 1 + a.pack.extra);
             if (a.pack.extra) dst[W + 1] = a.pack.pv.lw[i] - a.pack.pv.at(i);
             for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; dst[2 * c] = v.x; dst[2 * c + 1] = v.y; }

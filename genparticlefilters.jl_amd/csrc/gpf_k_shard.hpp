@@ -28,6 +28,21 @@ static __global__ void k_mbox_collect(MboxWait a, const uint64_t* srca, uint64_t
     for (int i = threadIdx.x; i < na; i += blockDim.x) dsta[i] = ld_sys(srca + i);
     for (int i = threadIdx.x; i < nb; i += blockDim.x) dstb[i] = ld_sys(srcb + i);
 }
+// gpf_comm_calibrate: `reps` DEPENDENT mailbox rounds inside one launch -- every rank stores its entry into every peer's mailbox, then waits for all
+// G entries of the round; nobody can begin round r + 1 before it holds everybody's entry of round r.  Launch time / reps = what one summary round
+// costs between real GPUs (the store's way over xGMI + the poll that sees it).  One wave.
+static __global__ void k_mbox_rounds(uint64_t* const* peers, const uint64_t* own, int G, int me, uint64_t seq0, int reps, int32_t* timeout)
+{
+    for (int r = 0; r < reps; ++r) {
+        const uint64_t seq = seq0 + 1 + (uint64_t)r;
+        const int slot = (int)(seq & (MB_SLOTS - 1));
+        const MboxPush p{peers, mb_payload_off(MB_CAL, slot), mb_tag_off(MB_CAL, slot), seq, G, me, 2};
+        const uint64_t words[2] = {seq, (uint64_t)me};
+        mbox_push_wave(p, words);
+        const MboxWait w{own + mb_tag_off(MB_CAL, slot), seq, G, 2, timeout};
+        mbox_wait_block(w);
+    }
+}
 // {Ql0..3} -> out5[1..4]: limb sums of sum q^2 folded over the scan blocks (exact integers); out5[0] = S_local is written by the scan
 static __global__ void k_export_q(const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5, MboxPush push)
 {
@@ -117,6 +132,7 @@ struct PushArgs {
     MboxWait wait_tot, wait_cr;                   // shard mailboxes: tot_all / cr_all are filled by the peers' kernels -- wait before reading
     int extra; PrioView pv;                       // prioritised resample: packed entries carry one more double, lw[a] - lp[a] (PackOut::extra)
     int skip_own;                                 // the shard's OWN slots are resolved by k_search_own (ancestors in place, no packed entry): pass 1 skips their chunks
+    int64_t* traffic;                             // the plan kernels (window exchange: the host never learns the counts): {entries sent to, received from OTHER shards} so far, or nullptr
 };
 struct PushTables {                               // LDS copy of the per-shard tables
     int64_t w_incl[MAX_SHARDS], c_incl[MAX_SHARDS], bounds[MAX_SHARDS + 1], chunk0[MAX_SHARDS + 1];
@@ -657,6 +673,10 @@ static __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan
         const int64_t r0 = F[h] > a.bounds[a.me] ? F[h] : a.bounds[a.me], r1 = F[h + 1] < a.bounds[a.me + 1] ? F[h + 1] : a.bounds[a.me + 1];
         const int64_t ns = s1 > s0 ? s1 - s0 : 0, nr = r1 > r0 ? r1 - r0 : 0;
         a.counts[h * COUNT_STRIDE] = ns; a.counts[(a.G + h) * COUNT_STRIDE] = nr;
+        if (a.traffic && h != a.me) {
+            if (ns) atomicAdd(reinterpret_cast<unsigned long long*>(a.traffic), (unsigned long long)ns);
+            if (nr) atomicAdd(reinterpret_cast<unsigned long long*>(a.traffic + 1), (unsigned long long)nr);
+        }
         if (h == a.me) { plan->own_range[0] = nr > 0 ? r0 - a.bounds[a.me] : 0; plan->own_range[1] = nr > 0 ? r1 - a.bounds[a.me] : 0; }
         if (a.host_counts) {
             __hip_atomic_store(a.host_counts + h, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -828,6 +848,10 @@ static __global__ __launch_bounds__(MBLOCK) void k_sorted_plan(PushArgs a, Shard
         const int64_t r0 = s_F[q] > a.bounds[a.me] ? s_F[q] : a.bounds[a.me], r1 = s_F[q + 1] < a.bounds[a.me + 1] ? s_F[q + 1] : a.bounds[a.me + 1];
         const int64_t ns = s1 > s0 ? s1 - s0 : 0, nr = r1 > r0 ? r1 - r0 : 0;
         a.counts[q * COUNT_STRIDE] = ns; a.counts[(a.G + q) * COUNT_STRIDE] = nr;
+        if (a.traffic && q != a.me) {
+            if (ns) atomicAdd(reinterpret_cast<unsigned long long*>(a.traffic), (unsigned long long)ns);
+            if (nr) atomicAdd(reinterpret_cast<unsigned long long*>(a.traffic + 1), (unsigned long long)nr);
+        }
         if (q == a.me) { plan->own_range[0] = nr > 0 ? r0 - a.bounds[a.me] : 0; plan->own_range[1] = nr > 0 ? r1 - a.bounds[a.me] : 0; }
         if (a.host_counts) {
             __hip_atomic_store(a.host_counts + q, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -923,6 +947,38 @@ __global__ __launch_bounds__(BLOCK) void k_commit_packed(const double* __restric
 #pragma unroll
         for (int c = 0; c < W; ++c) dst[c] = src[c];
         anc[j] = (int32_t)(meta & 0xffffffffull);
+        lw[j] = 0.0;                                   // update_weights!, resample.jl:195
+    }
+}
+
+// ... the same out of the slot-addressed receive window (gpf_k_common.hpp): the slots outside the shard's own range [own_range[0], own_range[1])
+// were written by the peers that serve them -- entry j = [row | global ancestor id | seal], waited for per entry
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_commit_ring(RingIn ring, int64_t n, const int64_t* __restrict__ own_range, double* __restrict__ rows_new,
+                                                       int32_t* __restrict__ anc, double* __restrict__ lw,
+                                                       const double* __restrict__ mf_all, const int64_t* __restrict__ tot_all, int G, int K,
+                                                       double logN, Scalars* sc, int in_mailbox)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {             // update_lml_est! (resample.jl:178-182), as k_commit_packed
+        uint64_t S = 0;
+        double mx = -__builtin_huge_val();
+        int f = 0;
+        for (int g = 0; g < G; ++g) {
+            S += (uint64_t)ld_gathered(tot_all + 5 * g, in_mailbox != 0);
+            const double v = ld_gathered(mf_all + 2 * g, in_mailbox != 0); mx = v > mx ? v : mx; f |= (int)ld_gathered(mf_all + 2 * g + 1, in_mailbox != 0);
+        }
+        if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+        sc->lml_est = sc->lml_est + (lse_from(mx, S, K, f) - logN);
+    }
+    const int64_t olo = own_range[0], cnt = own_range[1] - own_range[0];
+    for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < n - cnt; k += (int64_t)gridDim.x * BLOCK) {
+        const int64_t j = k < olo ? k : k + cnt;
+        double r[W];
+        const uint64_t ga = ring_load<W>(ring, j, r);
+        double* dst = rows_new + j * W;
+#pragma unroll
+        for (int c = 0; c < W; ++c) dst[c] = r[c];
+        anc[j] = (int32_t)ga;
         lw[j] = 0.0;                                   // update_weights!, resample.jl:195
     }
 }

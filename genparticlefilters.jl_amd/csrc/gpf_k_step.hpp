@@ -157,6 +157,9 @@ struct PackedCommit {
     // the log-ML update from the gathered summaries
     int masked; int64_t anc_off;
     const int64_t* own_range;  // masked == 2 (stratified): the own hits are the slots [own_range[0], own_range[1]) instead of the slots with anc >= 0
+    // masked == 2 && ring.base: the slots OUTSIDE the own range are not skipped -- their entries [row | global ancestor id | seal] were stored into this
+    // rank's slot-addressed receive window by the peers that serve them (gpf_k_common.hpp): ONE launch commits the whole exchange
+    RingIn ring;
     // a propagate enqueued SPECULATIVELY behind the ESS reduction (gpf_step_ess, k_sum_host<GATE>): it forms the verdict from the reduction's
     // accumulators itself (gate_verdict) and, if the ESS is below the threshold -- the filter resamples first --, returns before its first store
     GateIn gate;
@@ -210,6 +213,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step(ModelArgs a, uint64_t seed, u
             }
             wave_rows_load<W>(rows_in, srow, lds_wave, r);
             act = live && !skip;                        // (a lane without a particle -- or whose row arrives packed -- computes on row 0 and writes nothing)
+            if (GATHER && skip && pc.ring.base) {       // ... or arrives in the receive window: the lane's own wait and load
+                pc.anc[i] = (int32_t)ring_load<W>(pc.ring, i, r);
+                act = true;
+            }
         } else
         if constexpr (PACKED) {
             const double* src = pc.packed + e * (W + 1);
@@ -220,13 +227,20 @@ __global__ __launch_bounds__(BLOCK, 4) void k_step(ModelArgs a, uint64_t seed, u
             pc.anc[i] = (int32_t)(meta & 0xffffffffull);
         } else {
         int64_t srow = GATHER ? (int64_t)anc[i] : i;
+        bool windowed = false;
         if (GATHER && pc.masked) {                                                   // (kernel-uniform flag; the other slots' rows arrive packed)
-            if (pc.masked == 2 ? (i < pc.own_range[0] || i >= pc.own_range[1]) : srow < 0) continue;
+            if (pc.masked == 2 ? (i < pc.own_range[0] || i >= pc.own_range[1]) : srow < 0) {
+                if (!pc.ring.base) continue;
+                windowed = true;                                                     // ... or sit in the receive window
+            }
             srow -= pc.anc_off;
         }
+        if (GATHER && windowed) pc.anc[i] = (int32_t)ring_load<W>(pc.ring, i, r);
+        else {
         const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
 #pragma unroll
         for (int c = 0; c < (D + 1) / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
+        }
         }
         double xn[MAX_DIM];
         double ll;

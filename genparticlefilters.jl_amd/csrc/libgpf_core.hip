@@ -77,6 +77,8 @@ void launch_step_t(gpf_filter* h, int grid, const GateIn* gate = nullptr)
         const MaxSlots ms = next_slots(h);
         PackedCommit pg{nullptr, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox, h->pend_own_range ? 2 : 1, h->cfg.gid0,
                         h->pend_own_range ? h->shard_plan->own_range : nullptr};
+        // (a window exchange: the slots outside the own range are read from this rank's receive window in the same launch -- no packed entries)
+        if (h->pend_ring) pg.ring = RingIn{h->ring + (int64_t)(h->pend_ring_seq & (RING_PARITIES - 1)) * h->ring_parity_words, h->pend_ring_seq, h->h_timeout};
         GPF_LAUNCH((k_step<M, Wc, KEEP, true, PROP>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, h->cfg.seed, h->epoch,
                            h->cfg.gid0, h->n, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pg);
         if (h->pend_m > 0) {
@@ -242,6 +244,15 @@ gpf_status materialize(gpf_filter* h)
             }
         }
         const int grid = grid_for(h, std::max<int64_t>(m, 1), 8);
+        if (h->pend_ring) {                                      // a window exchange: the other slots' entries out of the receive window (+ log-ML update)
+            const RingIn rin{h->ring + (int64_t)(h->pend_ring_seq & (RING_PARITIES - 1)) * h->ring_parity_words, h->pend_ring_seq, h->h_timeout};
+            const int gr = grid_for(h, std::min<int64_t>(h->n, (int64_t)1 << 16), 8);
+            switch (h->W) {
+                case 2: GPF_LAUNCH((k_commit_ring<2>), dim3(gr), dim3(BLOCK), 0, h->stream, rin, h->n, h->shard_plan->own_range, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
+                case 4: GPF_LAUNCH((k_commit_ring<4>), dim3(gr), dim3(BLOCK), 0, h->stream, rin, h->n, h->shard_plan->own_range, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
+                case 8: GPF_LAUNCH((k_commit_ring<8>), dim3(gr), dim3(BLOCK), 0, h->stream, rin, h->n, h->shard_plan->own_range, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
+            }
+        } else
         switch (h->W) {
             case 2: GPF_LAUNCH((k_commit_packed<2>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, m, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
             case 4: GPF_LAUNCH((k_commit_packed<4>), dim3(grid), dim3(BLOCK), 0, h->stream, h->pend_packed, m, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
@@ -249,7 +260,7 @@ gpf_status materialize(gpf_filter* h)
         }
         HIP_TRY(h, hipGetLastError());
         h->cur ^= 1;
-        h->pending_packed = false; h->pend_own = false;
+        h->pending_packed = false; h->pend_own = false; h->pend_ring = false;
         h->max_valid = false;
         return GPF_OK;
     }
@@ -515,6 +526,8 @@ gpf_status gpf_destroy(gpf_handle h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& m : h->phases.marks) (void)hipEventDestroy(m.second);
+    h->phases.marks.clear();
     h->pending_packed = false;                                   // the filter goes away: nothing to scatter a deferred commit into
     for (gpf_filter* v : h->blk_views) gpf_destroy(v);
     h->blk_views.clear();
@@ -662,8 +675,9 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
     });
     if (s) return s;
     HIP_TRY(h, hipGetLastError());
+    phase_mark(h, GPF_PHASE_COMMIT);                         // (gpf_phase_timing: the propagate that committed a sharded resample)
     h->pending_gather = false; h->pending_fill = false;      // a pending resample gather was fused into this step
-    h->pending_packed = false; h->pend_own = false;      // ... or a pending sharded commit
+    h->pending_packed = false; h->pend_own = false; h->pend_ring = false;     // ... or a pending sharded commit
     h->max_valid = true;
     h->cur ^= 1;                    // update_refs! (utils.jl:10-15)
     h->epoch += 1;

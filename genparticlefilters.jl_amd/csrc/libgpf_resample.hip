@@ -383,6 +383,8 @@ gpf_status check_scan_timeout(gpf_filter* h)
 {
     if (h->h_timeout && __atomic_load_n(h->h_timeout, __ATOMIC_ACQUIRE) == 2)
         return fail(h, GPF_ERR_HIP, "sharded resample: a peer's summary did not arrive in its mailbox in time (a rank is down or far behind); results are invalid");
+    if (h->h_timeout && __atomic_load_n(h->h_timeout, __ATOMIC_ACQUIRE) == 3)
+        return fail(h, GPF_ERR_HIP, "sharded resample: a peer's rows did not arrive in the receive window in time (a rank is down or far behind); results are invalid");
     if (h->h_timeout && __atomic_load_n(h->h_timeout, __ATOMIC_ACQUIRE) != 0)
         return fail(h, GPF_ERR_HIP, "scan kernel: bounded inter-workgroup wait timed out (workgroups not co-resident?); results are invalid");
     return GPF_OK;

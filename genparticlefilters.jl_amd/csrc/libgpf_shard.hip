@@ -1,6 +1,7 @@
 // libgpf_shard.hip -- multi-GPU: the shard-level phases of a sharded pf_resample!, the library's own RCCL communicator,
 // the shard mailboxes, gpf_shard_resample in one call.
 #include "gpf_host.hpp"
+#include <chrono>
 
 using namespace gpf;
 using namespace gpfh;
@@ -170,6 +171,7 @@ static gpf_status push_args(gpf_handle h, int32_t method, const int64_t* tot_all
     a.wait_tot = mb_wait(h, MB_TOT);
     a.wait_cr = method == GPF_RESAMPLE_RESIDUAL ? mb_wait(h, MB_CR) : MboxWait{};
     a.tot_all = tot_all; a.cr_all = method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr; a.stage = h->push_stage; a.counts = h->shard_counts; a.host_counts = h->h_shard_counts; a.ticket = h->push_ticket;
+    a.traffic = h->ring_now ? h->tr_dev : nullptr;                // (window exchange: nobody on the host reads the counts; the plan kernel keeps the traffic statistics)
     return GPF_OK;
 }
 
@@ -197,7 +199,7 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
         if ((s = sorted_gammas_finish(h, ntl > SP_DIRECT_TILES))) return s;
         h->push_ticket += 1;
         a.ticket = h->push_ticket;
-        if (h->own_direct && G == 1) a.host_counts = nullptr;      // (one shard, own-direct: nobody waits for the counts -- no system-scope publish)
+        if ((h->own_direct && G == 1) || h->ring_now) a.host_counts = nullptr;      // (one shard, own-direct -- or the window exchange --: nobody waits for the counts, no system-scope publish)
         const SortedPlanJob job{h->sp_g, h->sp_vlo, ntl, ntl > SP_DIRECT_TILES ? 1 : 0, h->splan_F, h->splan_arrive};
         s = timed(h, GPF_K_SEARCH, [&] { GPF_LAUNCH(k_sorted_plan, dim3((unsigned)(G > 1 ? G - 1 : 1)), dim3(MBLOCK), 0, h->stream, a, h->shard_plan, job); });
         if (s) return s;
@@ -212,7 +214,7 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
         if (!h->shard_plan) HIP_TRY(h, hipMalloc(&h->shard_plan, sizeof(ShardPlan)));
         h->push_ticket += 1;
         a.ticket = h->push_ticket;
-        if (h->own_direct && G == 1) a.host_counts = nullptr;      // (as above)
+        if ((h->own_direct && G == 1) || h->ring_now) a.host_counts = nullptr;      // (as above)
         s = timed(h, GPF_K_SEARCH, [&] { GPF_LAUNCH(k_strat_plan, dim3(1), dim3(128), 0, h->stream, a, h->shard_plan); });
         if (s) return s;
         HIP_TRY(h, hipGetLastError());
@@ -294,7 +296,7 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!h->push_counted) return fail(h, GPF_ERR_STATE, "gpf_shard_push needs gpf_shard_push_count of the same resample first");
-    if (capacity < 0 || (capacity > 0 && !packed_out)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (capacity < 0 || (capacity > 0 && !packed_out && !h->ring_now)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     PushArgs a;
     if (method == GPF_RESAMPLE_STRATIFIED || method == GPF_RESAMPLE_MULTINOMIAL_SORTED) {
         const bool su = method == GPF_RESAMPLE_MULTINOMIAL_SORTED;
@@ -310,7 +312,12 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
         sa.n = cap; sa.n_cells = h->n; sa.n_global = h->cfg.n_global; sa.gid0 = h->cfg.gid0; sa.seed = h->cfg.seed; sa.epoch = h->epoch;
         sa.K = h->K; sa.logN = h->logN; sa.anc = nullptr; sa.invN = 1.0 / (double)h->cfg.n_global;
         sa.update_lml = 0;                                            // the commit carries the log-ML update
-        sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W, h->push_extra, h->push_pv, h->own_direct ? h->anc : nullptr, (int)me};
+        sa.pack = PackOut{h->rows[h->cur], packed_out, capacity, h->cfg.gid0, h->W, h->push_extra, h->push_pv, h->own_direct ? h->anc : nullptr, (int)me, RingOut{nullptr, 0, 0}};
+        if (h->ring_now) {
+            // the window exchange: own slots in place (own-direct), every other served slot straight into the window of the rank that holds it
+            if (!h->own_direct || !h->ring_active) return fail(h, GPF_ERR_STATE, "window exchange without own-direct resolution / without windows");
+            sa.pack.ring = RingOut{h->ring_peers, (int64_t)(h->ring_seq & (RING_PARITIES - 1)) * h->ring_parity_words, h->ring_seq};
+        }
         if (su) {                                                     // the GLOBAL tiles: their totals, or (many tiles) their starting points from k_sorted_tiles
             const bool many = (h->cfg.n_global + SP_TILE - 1) / SP_TILE > SP_DIRECT_TILES;
             sa.sp_g = many ? nullptr : h->sp_g; sa.sp_vlo = many ? h->sp_vlo : nullptr;
@@ -352,6 +359,7 @@ gpf_status gpf_shard_commit(gpf_handle h, const double* packed, int64_t m, const
     if (s) return s;
     if (!packed || !mf_all || !tot_all || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
     if (m != h->n && !(h->own_direct && m >= 0 && m <= h->n)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "a shard must receive exactly one entry per output slot");
+    h->pend_ring = false;
     h->pend_own = h->own_direct; h->pend_m = m;                  // (own-direct engine: m entries from the other shards, the rest through h->anc)
     h->pend_own_range = h->own_direct && h->own_direct_range;
     // Deferred like the single-GPU gather: the next gpf_update propagates the entries straight out of
@@ -527,8 +535,18 @@ gpf_status shard_scalars(gpf_filter* h, double& m, int& flags, uint64_t& S, uint
 // ---- shard mailboxes: allocation, hipIpc exchange of the handles over the communicator that was just created, peer mapping.
 // Every decision is taken from data all ranks hold identically (the all-gathered packets), so either every rank ends with the
 // mailboxes up or every rank stays on the RCCL all-gathers.  Any failure is soft: the collectives remain.
+void ring_teardown(gpf_filter* h)
+{
+    for (void* p : h->ring_opened) (void)hipIpcCloseMemHandle(p);
+    h->ring_opened.clear();
+    if (h->ring_peers) (void)hipFree(h->ring_peers);
+    if (h->ring) (void)hipFree(h->ring);
+    if (h->tr_dev) (void)hipFree(h->tr_dev);
+    h->ring_peers = nullptr; h->ring = nullptr; h->tr_dev = nullptr; h->ring_active = false; h->pend_ring = false;
+}
 void mailbox_teardown(gpf_filter* h)
 {
+    ring_teardown(h);
     for (void* p : h->mb_opened) (void)hipIpcCloseMemHandle(p);
     h->mb_opened.clear();
     if (h->mb_peers) (void)hipFree(h->mb_peers);
@@ -536,6 +554,69 @@ void mailbox_teardown(gpf_filter* h)
     h->mb_peers = nullptr; h->mbox = nullptr; h->mb_active = false;
 }
 struct MboxPacket { hipIpcMemHandle_t handle; int64_t ok; int64_t pid; };
+// all-gather of `each` bytes per rank, host to host, over the handle's communicator (setup only)
+gpf_status host_all_gather(gpf_filter* h, const void* src, void* dst_host, size_t each)
+{
+    const int G = h->comm_world;
+    if (G == 1) { memcpy(dst_host, src, each); return GPF_OK; }
+    char *dsrc = nullptr, *ddst = nullptr;
+    HIP_TRY(h, hipMalloc(&dsrc, each)); HIP_TRY(h, hipMalloc(&ddst, each * G));
+    HIP_TRY(h, hipMemcpyAsync(dsrc, src, each, hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(h, g_rccl.AllGather(dsrc, ddst, each, ncclInt8, h->comm, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dst_host, ddst, each * G, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(dsrc); (void)hipFree(ddst);
+    return GPF_OK;
+}
+// ---- slot-addressed receive windows (gpf_k_common.hpp): allocated, exported and mapped exactly like the mailboxes, behind them (a rank without
+// mailboxes has no windows); every decision again from all-gathered data, any failure soft -- then every rank keeps the grouped ncclSend / ncclRecv.
+gpf_status ring_setup(gpf_filter* h)
+{
+    const char* mode = getenv("GPF_SHARD_EXCHANGE");              // "rccl": no windows at all (A/B measurements, fallback drills)
+    if (!h->mb_active || (mode && !strcmp(mode, "rccl"))) return GPF_OK;
+    if (mode && strcmp(mode, "p2p")) return fail(h, GPF_ERR_INVALID_ARGUMENT, "GPF_SHARD_EXCHANGE: p2p or rccl");
+    const int G = h->comm_world, me = h->comm_rank;
+    // one entry per local slot of the LARGEST shard (the first n_global % G shards hold one particle more), two parities
+    const int64_t n_max = (h->cfg.n_global + G - 1) / G;
+    h->ring_parity_words = n_max * (h->W + 2);
+    const size_t bytes = (size_t)RING_PARITIES * (size_t)h->ring_parity_words * sizeof(uint64_t);
+    int64_t ok = 1;
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&h->ring), bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&h->ring, bytes) != hipSuccess) { (void)hipGetLastError(); h->ring = nullptr; ok = 0; }
+    }
+    if (ok && hipMalloc(&h->tr_dev, 2 * sizeof(int64_t)) != hipSuccess) { (void)hipGetLastError(); h->tr_dev = nullptr; ok = 0; }
+    if (ok) {
+        HIP_TRY(h, hipMemsetAsync(h->ring, 0, bytes, h->stream)); HIP_TRY(h, hipMemsetAsync(h->tr_dev, 0, 2 * sizeof(int64_t), h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    std::vector<MboxPacket> all((size_t)G);
+    MboxPacket mine{};
+    mine.pid = (int64_t)getpid();
+    if (G > 1 && ok && hipIpcGetMemHandle(&mine.handle, h->ring) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+    mine.ok = ok;
+    gpf_status s = host_all_gather(h, &mine, all.data(), sizeof(MboxPacket));
+    if (s) { ring_teardown(h); return s; }
+    for (int r = 0; r < G; ++r) if (!all[r].ok) { ring_teardown(h); return GPF_OK; }
+    std::vector<uint64_t*> peers((size_t)G, nullptr);
+    int64_t opened = 1;
+    for (int r = 0; r < G && opened; ++r) {
+        if (r == me) { peers[r] = h->ring; continue; }
+        void* ptr = nullptr;
+        if (hipIpcOpenMemHandle(&ptr, all[r].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); opened = 0; break; }
+        h->ring_opened.push_back(ptr);
+        peers[r] = static_cast<uint64_t*>(ptr);
+    }
+    std::vector<int64_t> oks((size_t)G, 0);
+    if ((s = host_all_gather(h, &opened, oks.data(), sizeof(int64_t)))) { ring_teardown(h); return s; }
+    for (int r = 0; r < G; ++r) if (!oks[r]) { ring_teardown(h); return GPF_OK; }
+    HIP_TRY(h, hipMalloc(&h->ring_peers, (size_t)G * sizeof(uint64_t*)));
+    HIP_TRY(h, hipMemcpy(h->ring_peers, peers.data(), (size_t)G * sizeof(uint64_t*), hipMemcpyHostToDevice));
+    h->ring_seq = 0;
+    h->ring_active = true;
+    h->exchange_mode = GPF_SHARD_EXCHANGE_P2P;
+    return GPF_OK;
+}
 gpf_status mailbox_setup(gpf_filter* h)
 {
     const char* mode = getenv("GPF_SHARD_SUMMARY");               // "rccl": keep the all-gathers (A/B measurements, fallback drills)
@@ -557,17 +638,7 @@ gpf_status mailbox_setup(gpf_filter* h)
         if (hipIpcGetMemHandle(&mine.handle, h->mbox) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
     }
     mine.ok = ok;
-    auto gather = [&](const void* src, void* dst_host, size_t each) -> gpf_status {   // all-gather of `each` bytes per rank, host to host
-        if (G == 1) { memcpy(dst_host, src, each); return GPF_OK; }
-        char *dsrc = nullptr, *ddst = nullptr;
-        HIP_TRY(h, hipMalloc(&dsrc, each)); HIP_TRY(h, hipMalloc(&ddst, each * G));
-        HIP_TRY(h, hipMemcpyAsync(dsrc, src, each, hipMemcpyHostToDevice, h->stream));
-        NCCL_TRY(h, g_rccl.AllGather(dsrc, ddst, each, ncclInt8, h->comm, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(dst_host, ddst, each * G, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        (void)hipFree(dsrc); (void)hipFree(ddst);
-        return GPF_OK;
-    };
+    auto gather = [&](const void* src, void* dst_host, size_t each) -> gpf_status { return host_all_gather(h, src, dst_host, each); };
     gpf_status s = gather(&mine, all.data(), sizeof(MboxPacket));
     if (s) { mailbox_teardown(h); return s; }                     // (a failed collective is not soft: the communicator is unusable)
     bool all_ok = true;
@@ -612,8 +683,106 @@ gpf_status gpf_comm_summary_mode(gpf_handle h, int32_t* mailbox)
 gpf_status gpf_comm_traffic(gpf_handle h, int64_t* out4, int32_t reset)
 {
     if (!h || !out4) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (h->tr_dev) {                                              // the window exchanges' counts never reach the host: their plan kernels kept them on the device
+        HIP_TRY(h, hipSetDevice(h->cfg.device));
+        int64_t dv[2] = {0, 0};
+        HIP_TRY(h, hipMemcpyAsync(dv, h->tr_dev, sizeof(dv), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->tr_dev, 0, sizeof(dv), h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->tr_sent += dv[0]; h->tr_recv += dv[1];
+    }
     out4[0] = h->tr_calls; out4[1] = h->tr_sent; out4[2] = h->tr_recv; out4[3] = h->tr_entry_bytes;
     if (reset) h->tr_calls = h->tr_sent = h->tr_recv = 0;
+    return GPF_OK;
+}
+
+/* what the transports under a sharded resample cost on THIS machine (a scaling run prints it beside its step times):
+ *   out4[0] us per grouped ncclSend / ncclRecv exchange of `entries` packed entries ((W + 1) doubles each) with EVERY peer, mean of `reps`
+ *   out4[1] the per-link rate of that exchange in GB/s: bytes one rank put on ONE link / out4[0]
+ *   out4[2] us per mailbox round: every rank stores its entry into every peer's mailbox and waits for all of theirs (`reps` dependent rounds in one launch)
+ *   out4[3] us of the launch that ran the mailbox rounds with reps = 0 (the floor under out4[2] x reps: launch + event overhead)
+ * Collective: every rank calls it with the same arguments.  0 where there is nothing to measure (one rank; no mailboxes). */
+gpf_status gpf_comm_calibrate(gpf_handle h, int64_t entries, int32_t reps, double* out4)
+{
+    if (!h || !out4) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_comm_calibrate needs gpf_comm_create first");
+    if (entries < 1 || reps < 1 || reps > 10000) return fail(h, GPF_ERR_INVALID_ARGUMENT, "entries >= 1, 1 <= reps <= 10000");
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    for (int k = 0; k < 4; ++k) out4[k] = 0.0;
+    const int G = h->comm_world, me = h->comm_rank;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(h, hipEventCreate(&e0)); HIP_TRY(h, hipEventCreate(&e1));
+    struct Ev { hipEvent_t a, b; ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evs{e0, e1};
+    if (G > 1 && h->comm) {
+        const int64_t E = h->W + 1;
+        double *sb = nullptr, *rb = nullptr;
+        const size_t bytes = (size_t)entries * E * G * sizeof(double);
+        // (allocation failures are local: decide together before the first collective)
+        int64_t ok = hipMalloc(&sb, bytes) == hipSuccess && hipMalloc(&rb, bytes) == hipSuccess ? 1 : 0;
+        if (!ok) (void)hipGetLastError();
+        std::vector<int64_t> oks((size_t)G, 0);
+        if ((s = host_all_gather(h, &ok, oks.data(), sizeof(int64_t)))) { if (sb) (void)hipFree(sb); if (rb) (void)hipFree(rb); return s; }
+        bool all_ok = true;
+        for (int r = 0; r < G; ++r) all_ok = all_ok && oks[r] != 0;
+        if (all_ok) {
+            HIP_TRY(h, hipMemsetAsync(sb, 0, bytes, h->stream));
+            ncclResult_t first = ncclSuccess;
+            auto note = [&](ncclResult_t r) { if (r != ncclSuccess && first == ncclSuccess) first = r; };
+            for (int it = 0; it < reps + 2; ++it) {               // (two untimed exchanges first: connection set-up)
+                if (it == 2) HIP_TRY(h, hipEventRecord(e0, h->stream));
+                note(g_rccl.GroupStart());
+                for (int g = 0; g < G; ++g) {
+                    if (g == me) continue;
+                    note(g_rccl.Send(sb + (size_t)g * entries * E, (size_t)(entries * E), ncclDouble, g, h->comm, h->stream));
+                    note(g_rccl.Recv(rb + (size_t)g * entries * E, (size_t)(entries * E), ncclDouble, g, h->comm, h->stream));
+                }
+                note(g_rccl.GroupEnd());
+            }
+            HIP_TRY(h, hipEventRecord(e1, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (first != ncclSuccess) { (void)hipFree(sb); (void)hipFree(rb); return fail(h, GPF_ERR_HIP, std::string("calibration exchange: ") + g_rccl.GetErrorString(first)); }
+            float ms = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+            out4[0] = 1e3 * (double)ms / reps;
+            out4[1] = out4[0] > 0.0 ? (double)(entries * E * (int64_t)sizeof(double)) / (out4[0] * 1e-6) / 1e9 : 0.0;
+        }
+        if (sb) (void)hipFree(sb);
+        if (rb) (void)hipFree(rb);
+    }
+    if (h->mb_active && h->h_timeout) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const int n = pass == 0 ? reps : 0;
+            HIP_TRY(h, hipEventRecord(e0, h->stream));
+            GPF_LAUNCH(k_mbox_rounds, dim3(1), dim3(WAVE), 0, h->stream, h->mb_peers, h->mbox, G, me, h->mb_seq[MB_CAL], n, h->h_timeout);
+            HIP_TRY(h, hipEventRecord(e1, h->stream));
+            HIP_TRY(h, hipGetLastError());
+            h->mb_seq[MB_CAL] += (uint64_t)n;
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            float ms = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+            if (pass == 0) out4[2] = 1e3 * (double)ms; else out4[3] = 1e3 * (double)ms;
+        }
+        out4[2] = (out4[2] - out4[3] > 0.0 ? out4[2] - out4[3] : 0.0) / reps;
+        if ((s = check_scan_timeout(h))) return s;
+    }
+    return GPF_OK;
+}
+
+gpf_status gpf_comm_set_exchange(gpf_handle h, int32_t mode)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (mode != GPF_SHARD_EXCHANGE_RCCL && mode != GPF_SHARD_EXCHANGE_P2P) return fail(h, GPF_ERR_INVALID_ARGUMENT, "exchange mode: GPF_SHARD_EXCHANGE_RCCL or GPF_SHARD_EXCHANGE_P2P");
+    if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_comm_set_exchange needs gpf_comm_create first");
+    if (mode == GPF_SHARD_EXCHANGE_P2P && !h->ring_active) return fail(h, GPF_ERR_STATE, "no receive windows on this communicator (hipIpc mapping not possible, or GPF_SHARD_EXCHANGE / GPF_SHARD_SUMMARY = rccl)");
+    h->exchange_mode = mode;
+    return GPF_OK;
+}
+gpf_status gpf_comm_exchange(gpf_handle h, int32_t* mode)
+{
+    if (!h || !mode) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_comm_exchange needs gpf_comm_create first");
+    *mode = h->exchange_mode;
     return GPF_OK;
 }
 
@@ -668,7 +837,9 @@ gpf_status gpf_comm_create(gpf_handle h, const void* id128, int32_t rank, int32_
         if (!strcmp(e, "pull")) h->shard_plan_kind = GPF_SHARD_PLAN_PULL;
         else if (strcmp(e, "push")) return fail(h, GPF_ERR_INVALID_ARGUMENT, "GPF_SHARD_PLAN: push or pull");
     }
-    return mailbox_setup(h);
+    h->exchange_mode = GPF_SHARD_EXCHANGE_RCCL;
+    if ((s = mailbox_setup(h))) return s;
+    return ring_setup(h);
 }
 
 gpf_status gpf_comm_destroy(gpf_handle h)
@@ -732,7 +903,11 @@ static gpf_status pull_requests(gpf_filter* h, int32_t method, const int64_t* to
     HIP_TRY(h, hipGetLastError());
     if ((s = shard_all_gather(h, h->pull_pc, h->pull_pc_all, (size_t)G, ncclInt64, sizeof(int64_t)))) return s;
     HIP_TRY(h, hipMemcpyAsync(h->h_pull_pc_all, h->pull_pc_all, (size_t)G * G * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));                  // the host wait of this plan: the split sizes of BOTH exchanges
+    {
+        const auto w0 = std::chrono::steady_clock::now();
+        HIP_TRY(h, hipStreamSynchronize(h->stream));              // the host wait of this plan: the split sizes of BOTH exchanges
+        if (h->phases.on) h->phases.host_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+    }
     const int64_t* M = h->h_pull_pc_all;                          // M[requester][owner]
     int64_t asked = 0;
     for (int g = 0; g < G; ++g) { counts[g] = M[(size_t)g * G + me]; counts[G + g] = M[(size_t)me * G + g]; asked += counts[G + g]; }
@@ -764,6 +939,23 @@ static gpf_status pull_requests(gpf_filter* h, int32_t method, const int64_t* to
     return GPF_OK;
 }
 
+// phase 5 of a window exchange: the new population = the shard's own range through the ancestor array + the window entries of the other slots
+static gpf_status shard_commit_ring(gpf_handle h, const double* mf_all, const int64_t* tot_all, int G)
+{
+    h->pend_own = true; h->pend_m = 0; h->pend_own_range = true;
+    h->pending_packed = true;
+    h->pend_packed = nullptr; h->pend_mf = mf_all; h->pend_tot = tot_all; h->pend_G = G;
+    h->pend_mailbox = h->mb_active && h->mb_engine;
+    h->pend_ring = true; h->pend_ring_seq = h->ring_seq;
+    h->epoch += 1;
+    h->raw_valid = false; h->raw_sum_valid = false;
+    h->max_valid = false;
+    h->residual_scanned = false;
+    h->push_counted = false;
+    mutated(h);
+    return GPF_OK;
+}
+
 static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double priority_alpha, int32_t check, int32_t* invalid)
 {
     gpf_status s = shard_ready(h);
@@ -780,6 +972,8 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     const bool prio = priority_alpha == priority_alpha;
     const int64_t n = h->n, E = h->W + 1 + (prio ? 1 : 0);
     EngineScope engine(h);                                        // the phases below push / wait through the shard mailboxes when they are up
+    phase_mark(h, -1);
+    if (h->phases.on) h->phases.resamples += 1;
     // shard bounds from the contiguous-range rule every rank applies to its own gpf_config (ranks ordered by gid0)
     std::vector<int64_t> bounds((size_t)G + 1);
     {
@@ -820,8 +1014,13 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
                                             multi_lds_bytes(h->ntiles, multi_logg(h->ntiles)) + 4096 <= (size_t)160 * 1024) ||
                                            (method == GPF_RESAMPLE_RESIDUAL && !pull && search_lds_bytes(h->ntiles, 2) + 40 * 1024 <= (size_t)160 * 1024) ||
                                            ranged);
-    struct OwnScope { gpf_filter* h; ~OwnScope() { h->own_direct = false; h->own_direct_range = false; } } own_scope{h};
+    struct OwnScope { gpf_filter* h; ~OwnScope() { h->own_direct = false; h->own_direct_range = false; h->ring_now = false; } } own_scope{h};
     h->own_direct = own; h->own_direct_range = own && ranged;
+    // The window exchange (gpf_k_common.hpp RingOut / RingIn; gpf_comm_set_exchange): the resamplers with ascending targets exchange boundary slabs -- the
+    // merge kernel stores them straight into the destination ranks' slot-addressed receive windows, the next propagate reads them there.  No split
+    // sizes for the host to wait for, no ncclGroup, no send / receive buffer, no overflow; the call returns as soon as its kernels are enqueued.
+    const bool p2p = ranged && own && h->ring_active && h->exchange_mode == GPF_SHARD_EXCHANGE_P2P;
+    h->ring_now = p2p;
     // sorted multinomial: the tile totals of ALL global slots (they depend on seed, epoch and N alone) -- the job rides in the weight scan below
     struct SpScope { gpf_filter* h; ~SpScope() { h->sp_job_set = false; } } sp_scope{h};
     if (method == GPF_RESAMPLE_MULTINOMIAL_SORTED) {
@@ -865,28 +1064,45 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         if (!h->mb_active && (s = shard_all_gather(h, h->sh_cr, h->sh_cr_all, 2, ncclInt64, sizeof(int64_t)))) return s;
         cr_all = h->cur_cr_all = h->mb_active ? static_cast<const int64_t*>(mb_gathered(h, MB_CR)) : h->sh_cr_all;
     }
+    phase_mark(h, GPF_PHASE_SUMMARIES);
+    if (p2p) {
+        h->ring_seq += 1;                                         // (the same on every rank: SPMD call order)
+        if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;             // the plan: served range, own range (device only)
+        phase_mark(h, GPF_PHASE_PLAN);
+        if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), h->cfg.n_global, nullptr))) return s;   // own slots in place, the others into their ranks' windows
+        phase_mark(h, GPF_PHASE_PACK);
+        h->tr_calls += 1; h->tr_entry_bytes = (int64_t)(h->W + 2) * (int64_t)sizeof(double);
+        return shard_commit_ring(h, h->cur_mf_all, tot_all, G);   // deferred: the next propagate reads window and own range in ONE launch
+    }
     std::vector<int64_t> counts(2 * (size_t)G);
     int64_t pushed_cap = std::min(cap, h->sh_send_cap);
     int64_t n_send = 0, n_recv = 0;
     if (pull) {
         // phase 3 of the pull plan: requests out, counts known on the host BEFORE pass 2 is enqueued (no speculative capacity)
         if ((s = pull_requests(h, method, tot_all, cr_all, G, me, bounds.data(), exchange, force && G == 1, counts))) return s;
+        phase_mark(h, GPF_PHASE_PLAN);
         for (int g = 0; g < G; ++g) { n_send += counts[g]; n_recv += counts[G + g]; }
         pushed_cap = std::min(n_send, h->sh_send_cap);
         if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
+        phase_mark(h, GPF_PHASE_PACK);
     } else {
         if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
+        phase_mark(h, GPF_PHASE_PLAN);
         if (own && G == 1) {
             // one shard, own-direct: every slot is an own hit -- nothing to exchange, so no split sizes to wait for (the host wait left a
             // gap in the queue on every resample); the i.i.d. methods have nothing to push either, stratified writes its ancestors in
             // place from the merge kernel
             counts[0] = ranged ? n : 0; counts[1] = n;
             if (ranged && (s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
+            phase_mark(h, GPF_PHASE_PACK);
         } else {
         // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
         // counts say it overflowed
         if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
+        phase_mark(h, GPF_PHASE_PACK);
+        const auto w0 = std::chrono::steady_clock::now();
         if ((s = gpf_shard_counts(h, G, counts.data()))) return s;   // ONE host wait (the exchange's split sizes), behind phase 4
+        if (h->phases.on) h->phases.host_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
         }
         for (int g = 0; g < G; ++g) { n_send += counts[g]; n_recv += counts[G + g]; }
     }
@@ -937,6 +1153,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
             if (ce != hipSuccess) remember(fail(h, GPF_ERR_HIP, std::string("self copy: ") + hipGetErrorString(ce)));
         }
     }
+    phase_mark(h, GPF_PHASE_EXCHANGE);
     if (late) { h->err = late_msg; return late; }
     if (!prio) return gpf_shard_commit(h, commit_from, own ? n - counts[(size_t)G + me] : n, h->cur_mf_all, tot_all, G);   // phase 5 (deferred)
     // phase 5 of a prioritised resample, at once: scatter rows / parents / log_ws, log-ML from the raw summary ...
@@ -1030,6 +1247,32 @@ gpf_status gpf_shard_step_ess(gpf_handle h, const double* obs, int32_t n_obs, do
     return gpf_update(h, obs, n_obs);
 }
 
+gpf_status gpf_phase_timing(gpf_handle h, int32_t enable)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    for (auto& m : h->phases.marks) (void)hipEventDestroy(m.second);
+    h->phases.marks.clear();
+    h->phases.host_wait_us = 0.0; h->phases.resamples = 0;
+    h->phases.on = enable != 0;
+    return GPF_OK;
+}
+gpf_status gpf_phase_times(gpf_handle h, double* us6, int64_t* resamples)
+{
+    if (!h || !us6) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < GPF_PHASE_COUNT; ++k) us6[k] = 0.0;
+    const auto& mk = h->phases.marks;
+    for (size_t i = 1; i < mk.size(); ++i) {
+        if (mk[i].first < 0 || mk[i].first >= GPF_PHASE_COUNT) continue;
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, mk[i - 1].second, mk[i].second));
+        us6[mk[i].first] += 1e3 * (double)ms;
+    }
+    us6[GPF_PHASE_HOST_WAIT] = h->phases.host_wait_us;
+    if (resamples) *resamples = h->phases.resamples;
+    return GPF_OK;
+}
 gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid)
 {
     return shard_resample_impl(h, method, std::nan(""), check, invalid);

@@ -193,6 +193,46 @@ class HipShardBackend:
         self._ck(self.L.gpf_comm_plan(self.h, C.byref(p)))
         return "pull" if p.value else "push"
 
+    def set_exchange(self, mode: str) -> None:
+        """how the rows of the resamplers with ascending targets (stratified, multinomial_sorted) cross shards (gpf.h gpf_comm_set_exchange): "p2p" = peer
+        stores into the destination ranks' slot-addressed receive windows, no host wait and no ncclGroup; "rccl" = packed entries through grouped
+        ncclSend / ncclRecv.  The same bits either way; every rank must choose the same mode."""
+        if not self.lib_comm:
+            raise ErrorException("the exchange mode is selectable in the library engine only")
+        if mode not in ("p2p", "rccl"):
+            raise ErrorException(f"exchange mode {mode!r}: p2p or rccl")
+        self._ck(self.L.gpf_comm_set_exchange(self.h, 1 if mode == "p2p" else 0))
+
+    def exchange(self) -> str:
+        if not self.lib_comm:
+            return "torch.distributed"
+        m = C.c_int32(0)
+        self._ck(self.L.gpf_comm_exchange(self.h, C.byref(m)))
+        return "p2p" if m.value else "rccl"
+
+    PHASES = ("summaries", "plan", "pack", "host_wait_counts", "exchange", "commit_propagate")
+
+    def phase_timing(self, on: bool) -> None:
+        """gpf_phase_timing: events at the phase boundaries of gpf_shard_resample and of the gpf_update that commits it (library engine)"""
+        self._ck(self.L.gpf_phase_timing(self.h, int(bool(on))))
+
+    def phase_times(self) -> dict:
+        """microseconds PER RESAMPLE of every phase since phase_timing(True) (gpf.h gpf_phase_times; GPU timeline except host_wait_counts)"""
+        us = (C.c_double * 6)()
+        n = C.c_int64(0)
+        self._ck(self.L.gpf_phase_times(self.h, us, C.byref(n)))
+        k = max(int(n.value), 1)
+        out = {name: round(float(us[i]) / k, 2) for i, name in enumerate(self.PHASES)}
+        out["resamples"] = int(n.value)
+        return out
+
+    def calibrate(self, entries: int, reps: int = 20) -> dict:
+        """gpf_comm_calibrate (collective): the grouped send / receive of `entries` packed entries with every peer and the mailbox round, timed on this machine"""
+        out = (C.c_double * 4)()
+        self._ck(self.L.gpf_comm_calibrate(self.h, int(entries), int(reps), out))
+        return {"entries_per_peer": int(entries), "reps": int(reps), "exchange_us": round(out[0], 2), "link_GBps_measured": round(out[1], 2),
+                "mailbox_round_us": round(out[2], 3), "mailbox_rtt_us": round(2 * out[2], 3), "empty_launch_us": round(out[3], 2)}
+
     def traffic(self, reset: bool = False):
         """(calls, entries sent to other ranks, entries received from other ranks, bytes per entry) of the library engine's resamples so far"""
         out = (C.c_int64 * 4)()

@@ -446,6 +446,38 @@ gpf_status gpf_comm_traffic(gpf_handle h, int64_t* out4, int32_t reset);
 typedef enum { GPF_SHARD_PLAN_PUSH = 0, GPF_SHARD_PLAN_PULL = 1 } gpf_shard_plan;
 gpf_status gpf_comm_set_plan(gpf_handle h, int32_t plan);
 gpf_status gpf_comm_plan(gpf_handle h, int32_t* plan);
+/* How the ROWS of the resamplers with ascending targets travel across shards (stratified with sort_particles = false, src/resample.jl:143-175, and the
+ * opt-in sorted multinomial): their exchange is boundary slabs -- a few thousand rows per shard boundary --, i.e. pure latency.
+ *   GPF_SHARD_EXCHANGE_P2P (the default wherever the shard mailboxes are up): every rank exports a slot-addressed receive window (one entry per local
+ *     slot, hipIpc-mapped by its peers); the merge kernel of the shard that SERVES a slot stores [row | ancestor | seal] straight into the window of the
+ *     rank that HOLDS it (xGMI peer stores) and that rank's next gpf_update reads it there, in the same launch as its own slots.  No split sizes for the
+ *     host to wait for, no ncclGroup, no send / receive buffers, no capacity to overflow; gpf_shard_resample returns when its kernels are enqueued.
+ *   GPF_SHARD_EXCHANGE_RCCL: packed entries, one host wait for the split sizes, grouped ncclSend / ncclRecv (what the i.i.d. resamplers -- a
+ *     bandwidth-bound exchange of (G-1)/G of all rows -- and tempered resamples always use).
+ * The same bits either way.  Every rank of a communicator must use the same mode.  Environment at gpf_comm_create: GPF_SHARD_EXCHANGE=p2p|rccl. */
+/* What the transports under a sharded resample cost on THIS machine -- a scaling run prints it beside its step times (nobody can attach a profiler to it):
+ *   out4[0] us per grouped ncclSend / ncclRecv exchange of `entries` packed entries ((W + 1) doubles each) with EVERY peer, mean of `reps` (2 untimed first)
+ *   out4[1] the per-link rate of that exchange in GB/s: bytes one rank put on ONE link / out4[0]   (the scaling worksheet of DESIGN.md 6.7 assumes 76)
+ *   out4[2] us per mailbox round: every rank stores its entry into every peer's mailbox and waits for all of theirs (`reps` dependent rounds in ONE launch,
+ *           the launch's floor out4[3] taken off) -- what each of the 2 - 3 summary rounds of a sharded resample costs between real GPUs
+ *   out4[3] us of that launch with no rounds in it
+ * Collective: every rank calls it with the same arguments, between resamples.  0 where there is nothing to measure (one rank; no mailboxes). */
+gpf_status gpf_comm_calibrate(gpf_handle h, int64_t entries, int32_t reps, double* out4);
+typedef enum { GPF_SHARD_EXCHANGE_RCCL = 0, GPF_SHARD_EXCHANGE_P2P = 1 } gpf_shard_exchange;
+gpf_status gpf_comm_set_exchange(gpf_handle h, int32_t mode);
+gpf_status gpf_comm_exchange(gpf_handle h, int32_t* mode);
+/* Where the time of a sharded step goes (what a multi-GPU run cannot attach a profiler to): with phase timing on, gpf_shard_resample and the gpf_update that
+ * commits it record events on the handle's stream at their phase boundaries.  gpf_phase_times (synchronises): us6 = total microseconds of
+ *   [0] summaries   weight maximum -> (max, flags) round -> fixed-point scan -> {S} round (-> residual scans + their round), waits for the peers included
+ *   [1] plan        push count: the own-slot search and the pass over the other shards' slots (i.i.d. methods) / the closed-form plan (ascending targets)
+ *   [2] pack        look-ups + packing of the served slots (i.i.d.) / merge + own ancestors + window stores or packing (ascending targets)
+ *   [3] host wait   WALL CLOCK the host spent blocked on the exchange's split sizes (overlaps [2] on the GPU; 0 for the window exchange)
+ *   [4] exchange    grouped ncclSend / ncclRecv + the self copy (0 for the window exchange: its rows travel inside [2])
+ *   [5] commit      from the end of the exchange to the end of the next gpf_update's propagate (the host's way back included)
+ * over *resamples calls; [0], [1], [2], [4], [5] on the GPU's timeline, idle gaps included.  enable = 1 clears the record. */
+enum { GPF_PHASE_SUMMARIES = 0, GPF_PHASE_PLAN = 1, GPF_PHASE_PACK = 2, GPF_PHASE_HOST_WAIT = 3, GPF_PHASE_EXCHANGE = 4, GPF_PHASE_COMMIT = 5, GPF_PHASE_COUNT = 6 };
+gpf_status gpf_phase_timing(gpf_handle h, int32_t enable);
+gpf_status gpf_phase_times(gpf_handle h, double* us6, int64_t* resamples);
 gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid);
 /* pf_resample!(state, method; priority_fn = w -> priority_alpha * w, check) on a sharded state (src/resample.jl:51-52,57,198-200; the
  * tempering family of test/resample.jl:15): ancestors from the CDF of the priorities over ALL shards, log_ml_est from the raw

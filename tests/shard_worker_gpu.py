@@ -47,7 +47,36 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
             lml_log.append(sharded.get_lml_est(st))
         loc = st.local
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents,
-                 gid0=st.gid0, ess=np.array(ess_log), lml=np.array(lml_log), summaries=st.backend.summary_mode(), plan=st.backend.plan())
+                 gid0=st.gid0, ess=np.array(ess_log), lml=np.array(lml_log), summaries=st.backend.summary_mode(), plan=st.backend.plan(),
+                 exchange=st.backend.exchange(), traffic=np.array(st.backend.traffic() if st.backend.lib_comm else (0, 0, 0, 0)))
+    finally:
+        dist.destroy_process_group()
+
+
+def run_exchange_switch(rank, world, port, model_name, n_global, T, out_dir):
+    """gpf_comm_set_exchange between the resamples of one sharded filter (library engine): the receive windows and the grouped send / receive
+    alternate, stratified and sorted multinomial alternate, a getter or a rejuvenation now and then forces the materialised commit"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import gpf_amd as g
+    from gpf_amd import sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = g.models.by_name(model_name); ys = g.models.simulate(model, T + 1)
+        st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, keep_prev=True, device=0)
+        assert st.backend.lib_comm and st.backend.exchange() == "p2p"
+        lml = []
+        for t in range(1, T):
+            st.backend.set_exchange(("p2p", "p2p", "rccl")[t % 3])
+            sharded.pf_resample(st, ("stratified", "multinomial_sorted")[t % 2], check=False)
+            if t % 4 == 0:
+                lml.append(sharded.get_lml_est(st))                   # (materialises the deferred commit out of the window / the receive buffer)
+            if t % 5 == 0:
+                sharded.pf_rejuvenate(st, None, (), 1, method="move")
+            sharded.pf_update(st, (t + 1,), (None,), ys[t])
+        loc = st.local
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents, gid0=st.gid0,
+                 lml=np.array(lml), lml_end=sharded.get_lml_est(st), traffic=np.array(st.backend.traffic()))
     finally:
         dist.destroy_process_group()
 

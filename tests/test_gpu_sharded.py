@@ -13,6 +13,11 @@ sys.path.insert(0, HERE)
 import shard_worker_gpu  # noqa: E402
 from test_sharded_gloo import CASES, _check_single, free_port, single, single_local, single_skew  # noqa: E402
 import shard_worker  # noqa: E402
+from conftest import soak_grid  # noqa: E402
+
+# The driver's `pytest -m gpu` keeps ONE representative of every code path below; the rest of each matrix (more worlds / transports / patterns / seeds
+# of the same path) carries gpu_soak and runs with `-m "gpu or gpu_soak"` (tools/gpu.sh soak).  Every multi-process case costs ~2 s of process start-up.
+_cid = lambda v: (f"{v[0]}-{v[1]}-{v[4]}-{v[5]}" if isinstance(v, tuple) else str(v))  # noqa: E731
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
@@ -31,9 +36,8 @@ def test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=2, one_call=
         assert (one_call or np.array_equal(p["ess"], ess_log)) and np.array_equal(p["lml"], lml_log)
 
 
-@pytest.mark.parametrize("mode", ["mailbox", "rccl", "python"])
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("case", [CASES[3], CASES[5], CASES[4], CASES[0], CASES[7]], ids=lambda c: f"{c[0]}-{c[1]}-{c[4]}-{c[5]}")
+@pytest.mark.parametrize("case,world,mode", soak_grid([CASES[3], CASES[5], CASES[4], CASES[0], CASES[7]], [2, 3], ["mailbox", "rccl", "python"],
+                                                    keep=lambda c, w, m: (m == "mailbox" and (w == 2 or c in (CASES[3], CASES[7]))) or (w == 2 and c == CASES[3])), ids=_cid)
 def test_sharded_step_ess_equals_single_oracle(g, o, tmp_path, monkeypatch, loopback_lib, case, world, mode):
     """gpf_shard_step_ess / sharded.pf_step_ess -- one README-loop iteration per call on every rank, the GLOBAL ESS verdict formed by the summary
     reduction after it has exchanged the shard totals through the mailboxes (k_sum_reduce<SHARD>), the propagate speculatively behind it: ESS-triggered
@@ -78,8 +82,8 @@ def test_world1_sharded_step_ess_and_getters_equal_unsharded(g, o):
     assert np.array_equal(a.local.traces, b.traces) and np.array_equal(a.local.log_weights, b.log_weights) and np.array_equal(a.local.parents, b.parents)
 
 
-@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
-@pytest.mark.parametrize("n_global,world", [(10, 3), (3, 3), (257, 2)])
+@pytest.mark.parametrize("method,n_global,world", [pytest.param(m_, n_, w_, marks=() if (n_ == 10 or (n_ == 3 and m_ == "stratified")) else (pytest.mark.gpu_soak,))
+                                                   for m_ in ("multinomial", "stratified", "residual", "multinomial_sorted") for n_, w_ in ((10, 3), (3, 3), (257, 2))])
 def test_hip_tiny_shards(g, o, tmp_path, method, n_global, world):
     """shards of 1 to a few particles (fewer slots than a workgroup handles, shard totals that differ a lot)"""
     mp.spawn(shard_worker_gpu.run, args=(world, free_port(), "lgssm2", method, n_global, 5, None, None, str(tmp_path)), nprocs=world, join=True)
@@ -134,8 +138,7 @@ def test_hip_push_overflow_path(g, o, tmp_path, monkeypatch):
     test_world1_sharded_equals_unsharded(g, o)
 
 
-@pytest.mark.parametrize("engine", ["library", "python"])
-@pytest.mark.parametrize("case", CASES[:3] + [CASES[7]], ids=[f"{c[0]}-{c[1]}" for c in CASES[:3] + [CASES[7]]])
+@pytest.mark.parametrize("case,engine", soak_grid(CASES[:3] + [CASES[7]], ["library", "python"], keep=lambda c, e: e == "library" or c == CASES[0]), ids=_cid)
 def test_rccl_collectives_one_rank(g, o, tmp_path, case, engine):
     """the REAL collectives on RCCL in a 1-rank group: the call path the multi-GPU runs take, as far as a 1-GPU box can
     exercise it.  engine = library: gpf_shard_resample -- ncclAllGather and the grouped ncclSend / ncclRecv exchange issued by
@@ -151,8 +154,7 @@ def test_rccl_collectives_one_rank(g, o, tmp_path, case, engine):
     assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
 
 
-@pytest.mark.parametrize("engine", ["library", "python"])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,engine", soak_grid([2, 3], ["library", "python"], keep=lambda w, e: (w, e) in ((2, "library"), (3, "python"))))
 def test_sorted_multinomial_many_tiles(g, o, tmp_path, monkeypatch, loopback_lib, world, engine):
     """more than SP_DIRECT_TILES = 1024 tiles of 2048 global slots (the shape of 8 shards of 10^6): the tiles' starting points come from
     k_sorted_tiles and k_sorted_plan searches them in place (window around lo / S, 256-ary rounds behind it) instead of scanning the tile
@@ -173,8 +175,7 @@ def loopback_lib(tmp_path_factory):
     return str(out)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}" for c in CASES])
+@pytest.mark.parametrize("case,world", soak_grid(CASES, [2, 3], keep=lambda c, w: w == 2 or c in (CASES[0], CASES[2], CASES[3])), ids=_cid)
 def test_library_engine_several_ranks_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, case, world):
     """gpf_shard_resample / gpf_shard_effective_sample_size / gpf_shard_log_ml_estimate -- the library engine, its all-gathers and
     its grouped send / receive exchange with real counts and offsets -- with 2 and 3 ranks.  Real RCCL refuses two ranks on one
@@ -185,8 +186,8 @@ def test_library_engine_several_ranks_over_loopback(g, o, tmp_path, monkeypatch,
     test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
 
 
-@pytest.mark.parametrize("one_call", [False, True])
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[7]], ids=lambda c: f"{c[0]}-{c[1]}")
+@pytest.mark.parametrize("case,one_call", soak_grid([CASES[0], CASES[1], CASES[3], CASES[7]], [False, True],
+                                                  keep=lambda c, oc: (c, oc) in ((CASES[0], False), (CASES[1], False), (CASES[3], True))), ids=_cid)
 def test_library_engine_fused_max_round(g, o, tmp_path, monkeypatch, loopback_lib, case, one_call):
     """GPF_SHARD_FUSE_MF=1: the (max, flags) mailbox round rides in its consumer's launch (workgroup 0 of the weight scan / of k_sum_shard pushes, every
     workgroup waits) instead of k_pack_mflags' own launch -- the form for ranks that have a GPU each (faster by 1 - 2 us per step on one rank); here 2 ranks
@@ -204,8 +205,7 @@ def test_library_engine_getters_through_the_scan(g, o, tmp_path, monkeypatch, lo
     test_library_engine_several_ranks_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, case, 2)
 
 
-@pytest.mark.parametrize("mode", ["mailbox", "rccl"])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,mode", soak_grid([2, 3], ["mailbox", "rccl"], keep=lambda w, m: w == 2))
 def test_library_engine_summary_transport(g, o, tmp_path, monkeypatch, loopback_lib, world, mode):
     """the two ways the (max, flags) / {S, Q} / residual summaries travel between ranks: shard mailboxes (hipIpc-mapped device
     memory, peer stores from the producing kernels, waits in the consuming ones -- the default) and RCCL all-gathers
@@ -223,8 +223,7 @@ def test_library_engine_summary_transport(g, o, tmp_path, monkeypatch, loopback_
             assert str(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["summaries"]) == mode
 
 
-@pytest.mark.parametrize("summaries", ["mailbox", "rccl"])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,summaries", soak_grid([2, 3], ["mailbox", "rccl"], keep=lambda w, m: (w, m) == (2, "mailbox")))
 def test_library_engine_pull_plan(g, o, tmp_path, monkeypatch, loopback_lib, world, summaries):
     """GPF_SHARD_PLAN=pull (gpf.h gpf_comm_set_plan): every shard evaluates its own slots only, requests go to the owners of the
     targets, rows come back -- two exchanges with their own counts and offsets.  The same bits as the push plan and the oracle for
@@ -244,8 +243,8 @@ def test_library_engine_pull_plan(g, o, tmp_path, monkeypatch, loopback_lib, wor
     test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[2], world=world)
 
 
-@pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
-@pytest.mark.parametrize("method", ["multinomial", "residual"])
+@pytest.mark.parametrize("method,pattern", soak_grid(["multinomial", "residual"], ["all_on_first_shard", "single_particle", "middle_band"],
+                                                    keep=lambda m, p: (m, p) in (("multinomial", "all_on_first_shard"), ("residual", "single_particle"))))
 def test_pull_plan_skewed_weights(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern):
     """every request to one shard (the others receive no request at all and serve nothing), pull plan"""
     monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
@@ -288,8 +287,12 @@ def test_plan_switch_between_resamples(g, o):
     assert sharded.get_lml_est(a) == g.get_lml_est(b)
 
 
-@pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
-@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
+_SKEW_KEPT = (("multinomial", "all_on_first_shard"), ("stratified", "all_on_first_shard"), ("residual", "single_particle"),
+              ("multinomial_sorted", "all_on_first_shard"), ("stratified", "middle_band"), ("multinomial_sorted", "single_particle"))
+
+
+@pytest.mark.parametrize("method,pattern", soak_grid(["multinomial", "stratified", "residual", "multinomial_sorted"], ["all_on_first_shard", "single_particle", "middle_band"],
+                                                    keep=lambda m, p: (m, p) in _SKEW_KEPT))
 def test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern):
     """zero-length sends, one shard serving everything (send-buffer overflow and the repeated push) through the library engine"""
     monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
@@ -297,8 +300,8 @@ def test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch
     test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern)
 
 
-@pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", "middle_band"])
-@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
+@pytest.mark.parametrize("method,pattern", soak_grid(["multinomial", "stratified", "residual", "multinomial_sorted"], ["all_on_first_shard", "single_particle", "middle_band"],
+                                                    keep=lambda m, p: (m, p) in _SKEW_KEPT[:4]))
 def test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern):
     """one shard owns every target (its push exceeds the balanced-size send buffer: the overflow path runs for real),
     the others own none (zero-length sends)"""
@@ -337,9 +340,9 @@ def test_hip_sharded_validity_checks(g, o, tmp_path):
     assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
 
 
-@pytest.mark.parametrize("engine", ["library", "library-pull", "python"])
-@pytest.mark.parametrize("seed,world,n_global", [(s_, 2 + s_ % 2, [6000, 6001, 40_000, 2048, 1024, 9999][s_ % 6])
-                                                 for s_ in range(int(os.environ.get("GPF_FUZZ_SHARD_SEEDS", "4")))])
+@pytest.mark.parametrize("seed,world,n_global,engine", [pytest.param(s_, 2 + s_ % 2, [6000, 6001, 40_000, 2048, 1024, 9999][s_ % 6], e_,
+                                                                     marks=() if (s_ < 2 or (s_ < 4 and e_ == "library")) else (pytest.mark.gpu_soak,))
+                                                        for s_ in range(int(os.environ.get("GPF_FUZZ_SHARD_SEEDS", "4"))) for e_ in ("library", "library-pull", "python")])
 def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib, seed, world, n_global, engine):
     """random sequences of updates, global resamples (all four), rejuvenation, global getters, one-call loop iterations (pf_step_ess), island resamples and adversarial
     weight vectors on a sharded filter (2 - 3 ranks on one GPU; library engine over the loopback transport / python engine over
@@ -430,9 +433,8 @@ def _tempered_oracle(g, o, method, n_global, T):
     return f, np.array(scal)
 
 
-@pytest.mark.parametrize("mode", ["mailbox", "rccl"])
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("method", ["multinomial", "stratified", "residual", "multinomial_sorted"])
+@pytest.mark.parametrize("method,world,mode", soak_grid(["multinomial", "stratified", "residual", "multinomial_sorted"], [2, 3], ["mailbox", "rccl"],
+                                                       keep=lambda m, w, md: (w, md) == (2, "mailbox") or (w, md, m) in ((3, "rccl", "multinomial"), (3, "rccl", "stratified"))))
 def test_sharded_tempered_resample(g, o, tmp_path, monkeypatch, loopback_lib, method, world, mode):
     """priority_fn = w -> alpha w across shards (src/resample.jl:51-52,57,198-200; test/resample.jl:15): ancestors from the
     priorities' global CDF, log-ML from the raw weights, weights from the global logsumexp of log_ws -- three summary rounds and
@@ -452,8 +454,7 @@ def test_sharded_tempered_resample(g, o, tmp_path, monkeypatch, loopback_lib, me
         assert np.array_equal(p["scal"], scal) and float(p["lml"]) == f.log_ml_estimate() and str(p["summaries"]) == mode
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("method", ["multinomial", "residual"])
+@pytest.mark.parametrize("method,world", soak_grid(["multinomial", "residual"], [2, 3], keep=lambda m, w: (m, w) == ("residual", 3)))
 def test_sharded_tempered_resample_pull_plan(g, o, tmp_path, monkeypatch, loopback_lib, method, world):
     """tempering through the pull plan: the answered entries carry log_ws like the pushed ones"""
     monkeypatch.setenv("GPF_SHARD_PLAN", "pull")
@@ -478,3 +479,107 @@ def test_world1_tempered_equals_unsharded(g, o, method):
         assert np.array_equal(a.local.traces, b.traces) and np.array_equal(a.local.log_weights, b.log_weights)
     with pytest.raises(g.ErrorException):
         sharded.pf_resample(a, method, priority_fn=lambda w: 0.3 * w)
+
+
+# ---- the window exchange (gpf.h gpf_comm_set_exchange): boundary slabs of the resamplers with ascending targets as peer stores into
+#      the destination ranks' slot-addressed receive windows -- no host wait, no ncclGroup
+WINDOW_CASES = [CASES[1], CASES[7], CASES[8], CASES[5],
+                ("bearings4", "stratified", 1600, 5, None, "keep"),          # rows of 8 doubles (x_t and x_{t-1}) straight from the window into the next propagate
+                ("bearings4", "multinomial_sorted", 2100, 5, 0.7, "move")]
+
+
+@pytest.mark.parametrize("case,world,mode", soak_grid(WINDOW_CASES, [2, 3], ["p2p", "rccl"],
+                                                    keep=lambda c, w, m: (m == "p2p" and (w == 2 or c in (WINDOW_CASES[0], WINDOW_CASES[1], WINDOW_CASES[4]))) or
+                                                                         (m == "rccl" and w == 2 and c in (WINDOW_CASES[0], WINDOW_CASES[1], WINDOW_CASES[3]))), ids=_cid)
+def test_window_exchange_equals_single_oracle(g, o, tmp_path, monkeypatch, loopback_lib, case, world, mode):
+    """stratified / sorted multinomial across 2 - 3 ranks on one GPU through the library engine, the rows of the boundary slabs stored by the serving
+    rank's merge kernel straight into the holding rank's receive window (hipIpc-mapped, sealed entries) and read there by that rank's next propagate
+    (k_step<GATHER> with PackedCommit::ring) or materialised commit (k_commit_ring) -- against the grouped send / receive (GPF_SHARD_EXCHANGE=rccl) and
+    the single-shard oracle: the same bits, and each run is in the mode it claims"""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    monkeypatch.setenv("GPF_SHARD_EXCHANGE", mode)
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert all(str(p["exchange"]) == mode for p in parts)
+    # what crossed the shard boundaries is the same either way, and every entry sent was received by somebody
+    sent, recv = sum(int(p["traffic"][1]) for p in parts), sum(int(p["traffic"][2]) for p in parts)
+    assert sent == recv and int(parts[0]["traffic"][0]) > 0
+    D = {"lgssm2": 2, "sv1": 1, "bearings4": 4}[case[0]]
+    W = ((2 * D if case[5] is not None else D) + 1) & ~1                          # (rows carry x_{t-1} whenever the run could rejuvenate)
+    assert all(int(p["traffic"][3]) == 8 * (W + (2 if mode == "p2p" else 1)) for p in parts)       # [row | ancestor | seal] against [row | slot, ancestor]
+
+
+@pytest.mark.parametrize("case,one_call", soak_grid([CASES[5], WINDOW_CASES[-1]], [False, True], keep=lambda c, oc: oc), ids=_cid)
+def test_window_exchange_in_the_one_call_loop(g, o, tmp_path, monkeypatch, loopback_lib, case, one_call):
+    """BASELINE configs[3]'s loop shape with a resampler whose exchange goes through the windows: gpf_shard_step_ess (verdict on the device, speculative
+    propagate) around gpf_shard_resample's window exchange and the MH sweep that materialises it"""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=3, one_call=one_call)
+    assert all(str(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["exchange"]) == "p2p" for r in range(3))
+
+
+@pytest.mark.parametrize("method,n_global,world", [pytest.param(m_, n_, w_, marks=() if (n_ in (10, 4099) or (n_ == 3 and m_ == "stratified")) else (pytest.mark.gpu_soak,))
+                                                   for m_ in ("stratified", "multinomial_sorted") for n_, w_ in ((10, 3), (3, 3), (257, 2), (4099, 3))])
+def test_window_exchange_tiny_shards(g, o, tmp_path, monkeypatch, loopback_lib, method, n_global, world):
+    """shards of 1 to a few particles: own ranges that are empty, a shard served entirely by its neighbours"""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
+    mp.spawn(shard_worker_gpu.run, args=(world, free_port(), "lgssm2", method, n_global, 5, None, None, str(tmp_path), "gloo", "library"), nprocs=world, join=True)
+    f, ess_log, lml_log = single(g, o, "lgssm2", method, n_global, 5, None, None)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert all(str(p["exchange"]) == "p2p" for p in parts)
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
+    assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
+    for p in parts:
+        assert np.array_equal(p["ess"], ess_log) and np.array_equal(p["lml"], lml_log)
+
+
+@pytest.mark.parametrize("method,pattern", soak_grid(["stratified", "multinomial_sorted"], ["all_on_first_shard", "single_particle", "middle_band"],
+                                                    keep=lambda m, p: (m, p) in (("stratified", "all_on_first_shard"), ("multinomial_sorted", "middle_band"))))
+def test_grouped_exchange_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern):
+    """the skew cases of test_library_engine_skewed_weights_over_loopback (which now run through the windows: a slab as large as a whole shard needs no
+    capacity there) through the grouped send / receive with its overflowing send buffer and repeated push"""
+    monkeypatch.setenv("GPF_SHARD_EXCHANGE", "rccl")
+    test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_mode_switch_between_resamples(g, o, tmp_path, monkeypatch, loopback_lib, world):
+    """gpf_comm_set_exchange between the resamples of one filter: windows and grouped send / receive alternate (the window's sequence numbers skip
+    the grouped rounds), deferred and materialised commits alternate; against one oracle filter"""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    n_global, T = 50_003, 13
+    mp.spawn(shard_worker_gpu.run_exchange_switch, args=(world, free_port(), "bearings4", n_global, T, str(tmp_path)), nprocs=world, join=True)
+    model = g.models.bearings4(); ys = g.models.simulate(model, T + 1)
+    f = o.OracleFilter(model.model_id, model.params, n_global, 77, keep_prev=True).initialize(ys[0])
+    lml = []
+    for t in range(1, T):
+        f.resample(("stratified", "multinomial_sorted")[t % 2], check=False, **({"sort_particles": False} if t % 2 == 0 else {}))
+        if t % 4 == 0:
+            lml.append(f.log_ml_estimate())
+        if t % 5 == 0:
+            f.rejuvenate("move", 1)
+        f.update(ys[t])
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
+    assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
+    assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
+    for p in parts:
+        assert np.array_equal(p["lml"], np.array(lml)) and float(p["lml_end"]) == f.log_ml_estimate()
+
+
+def test_exchange_mode_api(g, o):
+    """one shard: without a communicator there are no windows (and nothing to exchange) -- the mode reads rccl and p2p is refused; the python engine has no switch"""
+    from gpf_amd import sharded
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    a = sharded.pf_initialize(model, (1,), ys[0], 10_000, seed=5)
+    if not a.backend.lib_comm:
+        with pytest.raises(g.ErrorException):
+            a.backend.set_exchange("p2p")
+        return
+    assert a.backend.exchange() == "rccl"
+    with pytest.raises(g.ErrorException):
+        a.backend.set_exchange("p2p")
+    with pytest.raises(g.ErrorException):
+        a.backend.set_exchange("carrier pigeon")
+    a.backend.set_exchange("rccl")
