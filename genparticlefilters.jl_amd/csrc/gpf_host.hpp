@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -153,6 +154,11 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     uint64_t** mb_peers = nullptr;       // device array [world]: every rank's mailbox as mapped in this process
     std::vector<void*> mb_opened;        // peers' mailboxes opened with hipIpcOpenMemHandle (closed by gpf_comm_destroy)
     bool mb_active = false;
+    // the GLOBAL weight summary of the latest one-launch reduction (k_sum_shard: the sharded ESS getter / gpf_shard_step_ess), as the host read it, and what
+    // it describes: a gpf_shard_resample that finds it still valid (same weights, no newer mailbox round) does not repeat the (max, flags) round, and a
+    // residual one runs no weight scan at all (shard_resample_impl)
+    bool gsum_ok = false; uint64_t gsum_mut = 0, gsum_mf_seq = 0, gsum_tot_seq = 0; WSum gsum{};
+    bool comm_poisoned = false;          // a sharded call failed on THIS rank after its mailbox rounds / collectives had begun: the peers are out of step with it
     bool mb_engine = false;              // set by the library engine around its phase calls: they push / wait through the mailbox
     // the slot-addressed receive window (gpf_k_common.hpp RingOut / RingIn): one entry of W + 2 words per local slot and parity, mapped by every peer
     uint64_t* ring = nullptr;            // this rank's window (device memory, exported through hipIpc)
@@ -209,6 +215,8 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     // exchange volume of the sharded resamples so far (gpf_comm_traffic): calls, entries sent to / received from OTHER ranks, bytes of one entry of the latest call
     int64_t tr_calls = 0, tr_sent = 0, tr_recv = 0, tr_entry_bytes = 0;
     int last_flags = 0;                  // safe_softmax flags (FLAG_*) of the latest resample that read them on the host (resample_impl)
+    hipEvent_t chain_ev = nullptr;       // ChainGate: recorded behind this filter's chained kernels while other filters live on the device
+    bool chain_counted = false;
     gpfh::Timer timers[GPF_K_COUNT];
     gpfh::PhaseTimer phases;
     std::string err;
@@ -276,6 +284,28 @@ gpf_status timed(gpf_filter* h, int id, F&& launch)
     return GPF_OK;
 }
 
+// ------------------------------------------------------------------ chained kernels of SEVERAL filters on one device
+// The scans (k_scan, k_scan_residual2) and the sort's partition passes (k_sort_pass) chain their workgroups: a workgroup waits for the prefix of the tiles
+// below its own.  With ONE such kernel on the device that is safe -- its grid is sized to be resident at once (resample_device_setup), and a workgroup
+// only ever waits for workgroups dispatched before it.  TWO of them in flight on different streams (independent filters stepped from one process:
+// tools/replicas.py, R = 4 filters of 2 x 10^6 particles) can each hold the slots the other's not-yet-dispatched workgroups need: every resident
+// workgroup waits, nothing retires -- the bounded spins give up after seconds and the run fails loudly ("bounded inter-workgroup wait timed out").
+// So: while a process holds MORE THAN ONE filter on a device, its chained kernels run one after the other -- each such launch waits for the event
+// behind the previous one (of whichever stream) and records its own.  Everything else (propagate, search, gather, reductions) still overlaps across
+// the streams, and a process with one filter per device -- the headline, every sharded rank -- never touches the gate.
+struct ChainGate {
+    std::mutex mu;
+    int live = 0;                        // filters (not views) alive on the device
+    hipEvent_t last = nullptr;           // behind the latest chained launch ...
+    hipStream_t last_stream = nullptr;   // ... which went to this stream
+};
+inline ChainGate g_chain[16];
+struct ChainScope {                      // around the launch (or the launches, same stream) of chained kernels
+    gpf_filter* h; ChainGate* g; bool on;
+    explicit ChainScope(gpf_filter* f);
+    ~ChainScope();
+};
+
 inline void phase_mark(gpf_filter* h, int id)
 {
     if (!h->phases.on) return;
@@ -283,6 +313,26 @@ inline void phase_mark(gpf_filter* h, int id)
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, h->stream);
     h->phases.marks.emplace_back(id, e);
+}
+
+inline ChainScope::ChainScope(gpf_filter* f) : h(f), g(nullptr), on(false)
+{
+    const int dev = h->cfg.device;
+    if (dev < 0 || dev >= 16) return;
+    g = &g_chain[dev];
+    g->mu.lock();
+    on = g->live > 1;
+    if (on && g->last && g->last_stream != h->stream) (void)hipStreamWaitEvent(h->stream, g->last, 0);
+}
+inline ChainScope::~ChainScope()
+{
+    if (!g) return;
+    if (on) {
+        gpf_filter* owner = h->parent ? h->parent : h;            // (a view launches on its filter's stream; the event lives with the filter)
+        if (!owner->chain_ev && hipEventCreateWithFlags(&owner->chain_ev, hipEventDisableTiming) != hipSuccess) owner->chain_ev = nullptr;
+        if (owner->chain_ev && hipEventRecord(owner->chain_ev, h->stream) == hipSuccess) { g->last = owner->chain_ev; g->last_stream = h->stream; }
+    }
+    g->mu.unlock();
 }
 
 // ------------------------------------------------------------------ shard mailboxes (host side)
@@ -401,7 +451,7 @@ gpf_status read_published_summary(gpf_filter* h, WSum& w);
 bool sum_host_ok(const gpf_filter* h);
 gpf_status sum_host_launch(gpf_filter* h, const double* thr);
 gpf_status sum_host_fold(gpf_filter* h, const double* thr, int* go_out = nullptr);
-gpf_status sum_gate_check(gpf_filter* h, int host_go);
+gpf_status sum_gate_check(gpf_filter* h, int host_go, int64_t ticket);
 gpf_status shard_sum_launch(gpf_filter* h, const ShardSum& ss, bool* ok);
 bool shard_sum_collect();                                        // GPF_SHARD_SUM=collect: k_sum_reduce<SHARD> instead of k_sum_shard
 gpf_status wait_ticket(gpf_filter* h, volatile int64_t* tk, int64_t want, const char* what);

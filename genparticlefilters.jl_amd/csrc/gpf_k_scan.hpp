@@ -741,7 +741,10 @@ constexpr int HEAD_SMALL = 16, HEAD_LIST = 128, HEAD_STAGE = 4096;
 // are converted here (the same exp_fix as the weight scan's) and the summary arrives as kernel arguments, so the weight scan -- whose only
 // product this kernel would read is q_i = cdf[i] - cdf[i - 1] -- is not run at all; workgroup 0 leaves the summary in the device block for
 // the search kernel's log-ML update.
-struct ResidDirect { const double* lw; double m; int32_t flags; int32_t K; uint64_t S; WSum* ws_out; };
+// ... on a SHARD (mf_all != nullptr): S is the GLOBAL total the host read from the summary reduction's publish (k_sum_shard), the maximum and the flags are
+// folded here from the ranks' gathered (max, flags) pairs of that reduction's round -- m / flags above are ignored.
+struct ResidDirect { const double* lw; double m; int32_t flags; int32_t K; uint64_t S; WSum* ws_out;
+                     const double* mf_all; int32_t G; int32_t in_mailbox; };
 template <bool DIRECT>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* __restrict__ cdf, const WSum* ws, int64_t Nslots,
                                                           int64_t n, int64_t ntiles, Scan2Chan A, Scan2Chan B,
@@ -759,7 +762,22 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_residual2(const uint64_t* _
     InFixQ in{PrioView{rd.lw, nullptr, 0.0, 0}, nullptr, nullptr, rd.K, rd.m, rd.flags};
     if constexpr (DIRECT) {
         S = rd.S;
-        if (blockIdx.x == 0 && threadIdx.x == 0) { rd.ws_out->m = rd.m; rd.ws_out->flags = rd.flags; rd.ws_out->S = rd.S; }
+        if (rd.mf_all) {                                    // a shard: the global (max, flags) from the gathered pairs (one lane per rank; kernel-uniform branch)
+            __shared__ double s_gm; __shared__ int s_gf;
+            if (wave_id() == 0) {
+                const int l = lane_id();
+                double m = l < rd.G ? ld_gathered(rd.mf_all + 2 * l, rd.in_mailbox != 0) : -__builtin_huge_val();
+                int f = l < rd.G ? (int)ld_gathered(rd.mf_all + 2 * l + 1, rd.in_mailbox != 0) : 0;
+                m = wave_max_f64(m);
+#pragma unroll
+                for (int q = 32; q >= 1; q >>= 1) f |= __shfl_xor(f, q, WAVE);
+                if (!(f & FLAG_NAN) && m == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+                if (l == 0) { s_gm = m; s_gf = f; }
+            }
+            __syncthreads();
+            in.m = s_gm; in.flags = s_gf;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { rd.ws_out->m = in.m; rd.ws_out->flags = in.flags; rd.ws_out->S = rd.S; }
     } else S = ws->S;
     const int sh = residual_shift(S, Nslots);
     const int lane = lane_id(), wv = wave_id();

@@ -79,9 +79,10 @@ static __global__ void k_set_global(const int64_t* __restrict__ tot_all, int G, 
         ws->S = S;
     }
 }
-// (one wave)
-static __global__ void k_export_residual(const Scalars* sc, int64_t* out2, MboxPush push)
+// (one wave)  zero: the exchange counters of the resample, cleared here when no weight scan runs in front (the direct residual scans of a shard)
+static __global__ void k_export_residual(const Scalars* sc, int64_t* out2, MboxPush push, int64_t* zero, int zero_words)
 {
+    if (zero) for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zero[i] = 0;
     const uint64_t words[2] = {sc->Ctot, sc->Rs};
     if (threadIdx.x == 0 && blockIdx.x == 0) { out2[0] = (int64_t)words[0]; out2[1] = (int64_t)words[1]; }
     mbox_push_wave(push, words);
@@ -428,14 +429,18 @@ static __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search
     __shared__ ulonglong2 s_coop[2 * SBLOCK];
     ulonglong2* const lds_wave = s_coop + wave_id() * (2 * WAVE);
     if (threadIdx.x < MAX_SHARDS) s_recv[threadIdx.x] = 0;
+    // (the first trip's uniforms need no total: drawn in front of the mailbox wait + barrier of push_tables, the next trip's behind this trip's stores --
+    //  as k_search_own, where the barrier in front of the Philox blocks cost 1.4 us)
+    uint64_t U[2];
+    const int64_t stride = (int64_t)gridDim.x * 2 * SBLOCK;
+    int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK;
+    resample_u64_run<2>(a.seed, (uint32_t)(gid0 + base + 2 * (int64_t)threadIdx.x), a.epoch, U);      // (one Philox block for the lane's slot pair)
     push_tables(a, t);
     const PushScal sc = push_scalars<1>(a, t);
     const int lane = lane_id();
     unsigned recv_cnt = 0;
-    for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < n; base += (int64_t)gridDim.x * 2 * SBLOCK) {
+    for (; base < n; base += stride) {
         uint64_t T[2]; int own[2]; const uint64_t* top[2]; const CdfLevels* L[2];
-        uint64_t U[2];
-        resample_u64_run<2>(a.seed, (uint32_t)(gid0 + base + 2 * (int64_t)threadIdx.x), a.epoch, U);      // (one Philox block for the lane's slot pair)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t j = base + 2 * (int64_t)threadIdx.x + u;
@@ -458,6 +463,7 @@ static __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_search
             const int64_t j = base + 2 * (int64_t)threadIdx.x + u;
             if (j < n) anc[j] = own[u] == a.me ? (int32_t)(gid0 + idx[u]) : -1;
         }
+        if (base + stride < n) resample_u64_run<2>(a.seed, (uint32_t)(gid0 + base + stride + 2 * (int64_t)threadIdx.x), a.epoch, U);
     }
     if (recv_cnt) atomicAdd(&s_recv[lane], recv_cnt);
     __syncthreads();

@@ -164,8 +164,15 @@ struct PackedCommit {
     // accumulators itself (gate_verdict) and, if the ESS is below the threshold -- the filter resamples first --, returns before its first store
     GateIn gate;
 };
+// Minimum waves per SIMD the compiler plans for (its VGPR budget = 512 / that).  4 was measured on the LG-SSM headline (rows of 2 doubles: 28 - 80 VGPRs,
+// nothing near the 128 it allows).  Rows of 8 doubles (bearings with x_{t-1}) reach the cap -- k_step<2, 8, true, false> (config 4's plain propagate) and its
+// block-wise form spill 12 / 20 bytes per lane to scratch under it (profiles/r06_kernel_resources.txt): GPF_STEP_WAVES_WIDE is their bound.
+#ifndef GPF_STEP_WAVES_WIDE
+#define GPF_STEP_WAVES_WIDE 4
+#endif
+template <int W> constexpr int step_min_waves() { return W >= 8 ? GPF_STEP_WAVES_WIDE : 4; }
 template <int M, int W, bool KEEP_PREV, bool GATHER, int MODE = 0, bool PACKED = false, bool BLK = false>
-__global__ __launch_bounds__(BLOCK, 4) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
+__global__ __launch_bounds__(BLOCK, step_min_waves<W>()) void k_step(ModelArgs a, uint64_t seed, uint32_t epoch, int64_t gid0,
                                                 int64_t n, const int32_t* __restrict__ anc,
                                                 const double* __restrict__ rows_in,
                                                 double* __restrict__ rows_out, double* __restrict__ lw,
@@ -421,28 +428,65 @@ __global__ __launch_bounds__(BLOCK) void k_move(ModelArgs a, uint64_t seed, uint
 // gone.  Any other consumer of the state runs the stand-alone k_move first (libgpf_core.hip finish_move).  Same arithmetic, same order:
 // lw = ((GATHER ? 0 : lw) + sum of relative weights) + log-likelihood.
 struct ObsVec { double v[MAX_OBS]; };
-template <int M, int W, bool REWEIGHT, bool GATHER>
+// On a sharded filter the resample in front of the move left a pending COMMIT instead of a pending gather (gpf_shard_commit): the same three sources
+// as k_step's -- GATHER with pc.masked: the shard's own hits through the ancestor array (global ids; the other slots skipped, or read from the receive
+// window when pc.ring is set), PACKED: the received exchange entries [row | slot, ancestor] -- and the launch that carries pc.sc also carries the log-ML
+// update.  (Before: materialize() ahead of the move -- k_gather_own 27 us + k_commit_packed 4.8 us at n = 10^6, W = 8 on every resampling step of
+// BASELINE configs[3]'s loop, where the unsharded filter pays nothing.)
+template <int M, int W, bool REWEIGHT, bool GATHER, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK) void k_move_step(ModelArgs a, ObsVec obs_move, uint64_t seed, uint32_t epoch_move, uint32_t epoch, int64_t gid0,
                                                      int64_t n, int has_prev, int n_iters, const int32_t* __restrict__ anc,
                                                      const double* __restrict__ rows_in, double* __restrict__ rows_out, double* __restrict__ lw,
-                                                     MaxSlots ms)
+                                                     MaxSlots ms, PackedCommit pc)
 {
     using Mo = Model<M>;
     constexpr int D = Mo::D, NB = Mo::NBLK;
-    constexpr bool STAGE = GPF_STAGE_ROWS && W >= 8;                      // wide rows through the wave's LDS strip (as k_step)
+    constexpr bool STAGE = GPF_STAGE_ROWS && W >= 8 && !PACKED;           // wide rows through the wave's LDS strip (as k_step)
     __shared__ double2 s_stage[STAGE ? NWAVES * RowStage<W>::WORDS : 1];
     double2* const lds_wave = s_stage + (STAGE ? wave_id() * RowStage<W>::WORDS : 0);
     double bm = -__builtin_huge_val(); int bf = 0;
+    if constexpr (PACKED || GATHER) {
+        if (pc.sc && pc.mf_all && blockIdx.x == 0 && threadIdx.x == 0) {    // update_lml_est! from the gathered summaries (as k_step)
+            uint64_t S = 0;
+            double mx = -__builtin_huge_val();
+            int f = 0;
+            for (int g = 0; g < pc.G; ++g) {
+                S += (uint64_t)ld_gathered(pc.tot_all + 5 * g, pc.in_mailbox != 0);
+                const double v = ld_gathered(pc.mf_all + 2 * g, pc.in_mailbox != 0); mx = v > mx ? v : mx; f |= (int)ld_gathered(pc.mf_all + 2 * g + 1, pc.in_mailbox != 0);
+            }
+            if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
+            pc.sc->lml_est = pc.sc->lml_est + (lse_from(mx, S, pc.K, f) - pc.logN);
+        }
+    }
+    const bool masked = GATHER && pc.masked != 0;                         // kernel-uniform
     for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; STAGE ? e - lane_id() < n : e < n; e += (int64_t)gridDim.x * BLOCK) {
-        const bool alive = !STAGE || e < n;
-        const int64_t i = alive ? e : 0;
+        bool alive = !STAGE || e < n;
+        int64_t i = alive ? e : 0;
         double r[W];
-        const int64_t srow = GATHER ? (int64_t)anc[i] : i;
-        if constexpr (STAGE) wave_rows_load<W>(rows_in, srow, lds_wave, r);
-        else {
-            const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
+        if constexpr (PACKED) {
+            const double* src = pc.packed + e * (W + 1);
 #pragma unroll
-            for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
+            for (int c = 0; c < W; ++c) r[c] = src[c];
+            const uint64_t meta = d2u(src[W]);
+            i = (int64_t)(meta >> 32);
+            pc.anc[i] = (int32_t)(meta & 0xffffffffull);
+        } else {
+            int64_t srow = GATHER ? (int64_t)anc[i] : i;
+            bool windowed = false;
+            if (masked) {
+                const bool outside = alive && (pc.masked == 2 ? (i < pc.own_range[0] || i >= pc.own_range[1]) : srow < 0);
+                windowed = outside && pc.ring.base != nullptr;
+                if (outside && !windowed) alive = false;                     // the slot's row arrives packed: the PACKED launch behind this one moves it
+                srow = (outside || !alive) ? 0 : srow - pc.anc_off;
+            }
+            if constexpr (STAGE) wave_rows_load<W>(rows_in, srow, lds_wave, r);
+            else {
+                const double2* src = reinterpret_cast<const double2*>(rows_in + srow * W);
+#pragma unroll
+                for (int c = 0; c < W / 2; ++c) { const double2 v = src[c]; r[2 * c] = v.x; r[2 * c + 1] = v.y; }
+            }
+            if (GATHER && windowed) pc.anc[i] = (int32_t)ring_load<W>(pc.ring, i, r);
+            if (!STAGE && !alive) continue;                                  // (the staged form keeps the whole wave in the loop: its loads and stores are wave-collective)
         }
         // ---- the move (k_move's loop), under the observation and the epoch of the pf_rejuvenate! call
         double x[MAX_DIM], xs[MAX_DIM];
@@ -483,14 +527,14 @@ __global__ __launch_bounds__(BLOCK) void k_move_step(ModelArgs a, ObsVec obs_mov
         for (int k = 0; k < W; ++k) o[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) { o[k] = xn[k]; o[D + k] = x[k]; }
-        if constexpr (STAGE) wave_rows_store<W>(rows_out, e - lane_id(), n, lds_wave, o);
-        else {
+        if (STAGE && !masked) wave_rows_store<W>(rows_out, e - lane_id(), n, lds_wave, o);      // (kernel-uniform condition)
+        else if (alive) {
             double2* dst = reinterpret_cast<double2*>(rows_out + i * W);
 #pragma unroll
             for (int c = 0; c < W / 2; ++c) dst[c] = make_double2(o[2 * c], o[2 * c + 1]);
         }
         if (!alive) continue;
-        const double base = GATHER ? 0.0 : lw[i];                             // resample.jl:195 when a gather was pending
+        const double base = (GATHER || PACKED) ? 0.0 : lw[i];                 // resample.jl:195 when a gather / a commit was pending
         const double nl = REWEIGHT ? (base + wsum) + ll : base + ll;
         lw[i] = nl;
         track_max(nl, bm, bf);

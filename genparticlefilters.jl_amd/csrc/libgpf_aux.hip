@@ -304,13 +304,19 @@ static gpf_status set_block_obs(gpf_filter* h, const double* obs, int32_t n_obs,
     h->blk_obs_size = block_size;
     return GPF_OK;
 }
-static gpf_status block_step_checks(gpf_handle h, int64_t block_size, const char* who)
+// block_size comes back clamped to the particle count ("one block" may be asked for as any size >= n, 2^32 included): the kernels divide by it as a
+// 32-bit number (ModelArgs::blk_size), and n < 2^31
+static gpf_status block_step_checks(gpf_handle h, int64_t& block_size, const char* who, const double* obs = nullptr, int32_t n_obs = 0, bool with_obs = false)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
     if (h->parent) return fail(h, GPF_ERR_STATE, std::string(who) + " on a sub-state view: call it on the filter");
     if (h->cfg.n_global != h->n) return fail(h, GPF_ERR_STATE, std::string(who) + " on a shard of a sharded filter");
     if (h->hist_on) return fail(h, GPF_ERR_STATE, std::string(who) + " on a filter with a trajectory store");
     if (block_size < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "block_size < 1");      // (the per-block steps index observations by i / block_size: any size)
+    block_size = std::min<int64_t>(block_size, std::max<int64_t>(h->n, 1));
+    // (callers that change the handle's arguments before set_block_obs -- the strata -- validate the observations first, so that a bad call changes nothing)
+    if (with_obs && (!obs || n_obs != model_obs_dim(h->cfg.model)))
+        return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model takes " + std::to_string(model_obs_dim(h->cfg.model)) + " observation values per step and block");
     return GPF_OK;
 }
 gpf_status gpf_initialize_blocks(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size)
@@ -364,7 +370,7 @@ gpf_status gpf_update_blocks(gpf_handle h, const double* obs, int32_t n_obs, int
 static bool has_strata(gpf_filter* h) { bool v = false; DISPATCH_MODEL(h, (v = Model<MM>::HAS_STRATA)); return v; }
 gpf_status gpf_initialize_blocks_strata(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size, const double* values, int32_t n_strata, int32_t interleaved)
 {
-    gpf_status s = block_step_checks(h, block_size, "gpf_initialize_blocks_strata");
+    gpf_status s = block_step_checks(h, block_size, "gpf_initialize_blocks_strata", obs, n_obs, true);
     if (s) return s;
     if (!has_strata(h)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no discrete latent to stratify over");
     if ((s = set_strata(h, values, n_strata, interleaved))) return s;
@@ -387,7 +393,7 @@ gpf_status gpf_initialize_blocks_strata(gpf_handle h, const double* obs, int32_t
 }
 gpf_status gpf_update_blocks_strata(gpf_handle h, const double* obs, int32_t n_obs, int64_t block_size, const double* values, int32_t n_strata, int32_t interleaved)
 {
-    gpf_status s = block_step_checks(h, block_size, "gpf_update_blocks_strata");
+    gpf_status s = block_step_checks(h, block_size, "gpf_update_blocks_strata", obs, n_obs, true);
     if (s) return s;
     if ((s = check_ready(h))) return s;
     if (!has_strata(h)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "this model has no discrete latent to stratify over");

@@ -196,12 +196,30 @@ void launch_move_step_t(gpf_filter* h, int grid)
     ObsVec om;
     for (int i = 0; i < MAX_OBS; ++i) om.v[i] = h->pm_args.obs[i];
     const MaxSlots ms = next_slots(h);
-    if (h->pending_gather)
+    if (h->pending_packed && h->pend_own) {
+        // a sharded commit is pending (gpf_shard_commit, own-direct): the shard's own hits through the ancestor array -- and, after a window exchange, the
+        // other slots out of the receive window -- in the first launch, the received packed entries in a second one (as launch_step_t)
+        PackedCommit pg{nullptr, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox, h->pend_own_range ? 2 : 1, h->cfg.gid0,
+                        h->pend_own_range ? h->shard_plan->own_range : nullptr};
+        if (h->pend_ring) pg.ring = RingIn{h->ring + (int64_t)(h->pend_ring_seq & (RING_PARITIES - 1)) * h->ring_parity_words, h->pend_ring_seq, h->h_timeout};
         GPF_LAUNCH((k_move_step<M, Wc, RW, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, om, h->cfg.seed, h->pm_epoch, h->epoch,
-                   h->cfg.gid0, h->n, (int)h->has_prev, h->pm_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms);
+                   h->cfg.gid0, h->n, (int)h->has_prev, h->pm_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pg);
+        if (h->pend_m > 0) {
+            const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, nullptr, nullptr, (int)h->pend_mailbox, 0, 0, nullptr};
+            g_ev_start = g_ev_stop = nullptr;                    // (timed(): the event pair belongs to the first launch)
+            GPF_LAUNCH((k_move_step<M, Wc, RW, false, true>), dim3(grid_for(h, h->pend_m, MOVE_BLOCKS_PER_CU)), dim3(BLOCK), 0, h->stream, h->args, om, h->cfg.seed, h->pm_epoch, h->epoch,
+                       h->cfg.gid0, h->pend_m, (int)h->has_prev, h->pm_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pc);
+        }
+    } else if (h->pending_packed) {
+        const PackedCommit pc{h->pend_packed, h->anc, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, nullptr, (int)h->pend_mailbox, 0, 0, nullptr};
+        GPF_LAUNCH((k_move_step<M, Wc, RW, false, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, om, h->cfg.seed, h->pm_epoch, h->epoch,
+                   h->cfg.gid0, h->n, (int)h->has_prev, h->pm_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, pc);
+    } else if (h->pending_gather)
+        GPF_LAUNCH((k_move_step<M, Wc, RW, true>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, om, h->cfg.seed, h->pm_epoch, h->epoch,
+                   h->cfg.gid0, h->n, (int)h->has_prev, h->pm_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, PackedCommit{});
     else
         GPF_LAUNCH((k_move_step<M, Wc, RW, false>), dim3(grid), dim3(BLOCK), 0, h->stream, h->args, om, h->cfg.seed, h->pm_epoch, h->epoch,
-                   h->cfg.gid0, h->n, (int)h->has_prev, h->pm_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms);
+                   h->cfg.gid0, h->n, (int)h->has_prev, h->pm_iters, h->anc, h->rows[h->cur], h->rows[1 - h->cur], h->lw, ms, PackedCommit{});
 }
 
 void launch_gather_ex(gpf_filter* h, const int32_t* anc, const double* in, double* out, const PrioView& pv, double* lw_out, int64_t n)
@@ -416,6 +434,7 @@ gpf_status finish_move(gpf_filter* h)
 {
     if (!h->pending_move) return GPF_OK;
     h->pending_move = false;
+    if (h->pending_packed) { gpf_status ms = materialize(h); if (ms) return ms; }   // (a sharded commit waited with the move: scatter it, then the stand-alone move)
     const bool fused_gather = h->pending_gather;
     const int grid = move_grid(h);
     const int n_iters = h->pm_iters;
@@ -489,6 +508,10 @@ gpf_status gpf_create(const gpf_config* cfg, gpf_handle* out)
         }
         if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
         else { HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+        if (cfg->device < 16) {                                  // one more filter on this device (gpf_host.hpp ChainGate)
+            std::lock_guard<std::mutex> lk(g_chain[cfg->device].mu);
+            g_chain[cfg->device].live += 1; h->chain_counted = true;
+        }
         { gpf_status a_ = alloc_particle_buffers(h); if (a_) return a_; }
         const size_t n = (size_t)h->n, rb = n * (size_t)h->W * sizeof(double);
         for (int b = 0; b < 2; ++b) {
@@ -528,6 +551,15 @@ gpf_status gpf_destroy(gpf_handle h)
     for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& m : h->phases.marks) (void)hipEventDestroy(m.second);
     h->phases.marks.clear();
+    if (h->chain_counted || h->chain_ev) {                       // (gpf_host.hpp ChainGate; the stream is drained: nothing waits for this filter's event any more)
+        ChainGate& cg = g_chain[h->cfg.device < 16 ? h->cfg.device : 0];
+        std::lock_guard<std::mutex> lk(cg.mu);
+        if (h->chain_counted) { cg.live -= 1; h->chain_counted = false; }
+        if (h->chain_ev) {
+            if (cg.last == h->chain_ev) { cg.last = nullptr; cg.last_stream = nullptr; }
+            (void)hipEventDestroy(h->chain_ev); h->chain_ev = nullptr;
+        }
+    }
     h->pending_packed = false;                                   // the filter goes away: nothing to scatter a deferred commit into
     for (gpf_filter* v : h->blk_views) gpf_destroy(v);
     h->blk_views.clear();
@@ -651,8 +683,10 @@ static gpf_status update_impl(gpf_handle h, const double* obs, int32_t n_obs, in
         });
         if (s) return s;
         HIP_TRY(h, hipGetLastError());
+        phase_mark(h, GPF_PHASE_COMMIT);
         h->pending_move = false;
         h->pending_gather = false; h->pending_fill = false;
+        h->pending_packed = false; h->pend_own = false; h->pend_ring = false;   // (a sharded commit rode in the launch)
         h->max_valid = true;
         h->cur ^= 1;                // (read rows[cur], wrote the other buffer once: the move's and the update's swaps cancel to one)
         h->epoch += 1;
@@ -765,12 +799,17 @@ gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double e
     }
     // ---- ESS reduction with the verdict on the device, the propagate speculatively behind it
     const ModelArgs old_args = h->args;                          // (a rejuvenation moves under the CURRENT step's observation)
+    const int mcur0 = h->mcur;
+    // (an error behind this point leaves the step's observation and the maximum slots as they were: a later call on the handle -- a rejuvenation, say --
+    //  must not work under the NEXT step's observation.  The particle buffers of a failed call are undefined either way.)
+    auto undo = [&](gpf_status st) { h->args = old_args; h->mcur = mcur0; return st; };
     if ((s = sum_host_launch(h, &thr))) return s;
-    if ((s = set_obs(h, obs, n_obs))) { h->args = old_args; return s; }
-    const GateIn gate{h->gate_part + h->gate_cur * GATE_WORDS, thr, &h->sc->gate_go, h->h_gate, h->q_ticket, nullptr};
-    if ((s = speculative_step(h, gate))) return s;
+    const int64_t gate_ticket = h->q_ticket;                     // (this launch's: the live counter moves on with the calls below)
+    if ((s = set_obs(h, obs, n_obs))) return undo(s);
+    const GateIn gate{h->gate_part + h->gate_cur * GATE_WORDS, thr, &h->sc->gate_go, h->h_gate, gate_ticket, nullptr};
+    if ((s = speculative_step(h, gate))) return undo(s);
     int go = 0;
-    if ((s = sum_host_fold(h, &thr, &go))) return s;
+    if ((s = sum_host_fold(h, &thr, &go))) return undo(s);
     if (ess_out) {
         uint64_t hi, lo;
         normalise_Q(h->sum_cache, hi, lo);
@@ -778,7 +817,7 @@ gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double e
     }
     if (!go) {
         speculative_step_done(h, true);                          // the speculative propagate WAS the step's pf_update!
-        return sum_gate_check(h, go);
+        return sum_gate_check(h, go, gate_ticket);
     }
     // the propagate returned without touching anything: take its maximum slots back, restore the step's observation, and run the sequence
     // from the resample on -- the summary is with the host as after effective_sample_size(state) (a :residual resample skips its weight scan)
@@ -788,7 +827,7 @@ gpf_status gpf_step_ess(gpf_handle h, const double* obs, int32_t n_obs, double e
     if (resampled) *resampled = 1;
     if (rejuvenate_method >= 0 && (s = gpf_rejuvenate(h, rejuvenate_method, n_iters, nullptr))) return s;
     if ((s = gpf_update(h, obs, n_obs))) return s;
-    return sum_gate_check(h, go);                                // (after the sequence is enqueued: the check is a safety net, not a dependency)
+    return sum_gate_check(h, go, gate_ticket);                   // (after the sequence is enqueued: the check is a safety net, not a dependency)
 }
 
 // stratified initialisation / update: the strata are values of the model's discrete latent
@@ -859,12 +898,14 @@ static gpf_status rejuvenate_impl(gpf_handle h, int32_t method, int32_t n_iters,
         return fail(h, GPF_ERR_UNKNOWN_METHOD, "Method not recognized.");                        // rejuvenate.jl:25
     if (!h->cfg.keep_prev) return fail(h, GPF_ERR_STATE, "gpf_rejuvenate needs keep_prev = 1 (x_{t-1} must travel with the particle)");
     if (n_iters < 0) return fail(h, GPF_ERR_INVALID_ARGUMENT, "n_iters < 0");
-    if (h->pending_packed && (s = materialize(h))) return s;     // sharded deferred commit: scatter first
+    // lazy move: a plain selection move of a whole filter (or of a whole shard) whose acceptance count nobody asked for waits for the pf_update! that
+    // follows (k_move_step); its epoch is consumed now.  A pending sharded commit waits with it: k_move_step reads the own hits through the
+    // ancestor array, the receive window and the packed entries itself (no k_gather_own + k_commit_packed in front of the move)
+    const bool lazy = h->lazy_move && !with_proposal && !n_accepted && !h->parent && !h->hist_on;
+    if (h->pending_packed && !lazy && (s = materialize(h))) return s;     // sharded deferred commit: scatter first
     if (h->pending_fill && (s = materialize(h))) return s;       // (the move kernel's fused gather assumes incoming weights 0)
     if ((s = finish_search(h))) return s;                        // (a lazy multinomial resample: the move kernel reads the ancestor array)
-    // lazy move: a plain selection move of a whole, unsharded filter whose acceptance count nobody asked for waits for the pf_update! that
-    // follows (k_move_step); its epoch is consumed now
-    if (h->lazy_move && !with_proposal && !n_accepted && !h->parent && !h->hist_on && h->cfg.n_global == h->n && !h->pending_packed) {
+    if (lazy) {
         h->pending_move = true; h->pm_method = method; h->pm_iters = n_iters; h->pm_epoch = h->epoch; h->pm_args = h->args;
         h->epoch += 1;
         return GPF_OK;

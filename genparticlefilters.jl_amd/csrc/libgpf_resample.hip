@@ -21,6 +21,7 @@ gpf_status scan_launch(gpf_filter* h, int ch, const In& in, int np, WSum* slot, 
     const bool offsets = ch == 0 && h->want_offsets && want_cdf;
     const ScanOut so = scan_out(want_cdf ? h->cdf[ch] : nullptr, h->t16[ch], h->t256[ch], h->ntiles, offsets);
     if (ch == 0 && want_cdf) h->ch0_offsets = offsets && so.off16 != nullptr;
+    const ChainScope chain(h);                                   // (several filters on this device: their chained kernels take turns, gpf_host.hpp)
     gpf_status s = timed(h, GPF_K_SCAN, [&] {
         GPF_LAUNCH((k_scan<In, FIXQ>), dim3(g_launch), dim3(SCAN_BLOCK), 0, h->stream, in, h->n, h->ntiles, mf_all, h->mslots[h->mcur], np, slot,
                            so, dc, dn, total_out, h->blockQ, h->h_timeout, ex);
@@ -300,18 +301,20 @@ gpf_status sum_host_fold(gpf_filter* h, const double* thr, int* go_out)
 }
 // the verdict the speculative propagate acted on (gate_verdict: ticket << 1 | go in pinned memory, published by its first workgroup) against
 // the host's: the same sums through the same operations -- a difference means the two sides of the call went different ways
-gpf_status sum_gate_check(gpf_filter* h, int host_go)
+// ticket: the ticket of the reduction launch whose verdict is checked, captured when it was launched (the handle's live q_ticket may have moved on: a
+// resample, an update or a getter between the launch and this check may summarise again)
+gpf_status sum_gate_check(gpf_filter* h, int host_go, int64_t ticket)
 {
     {
         gpf_status s;
         uint64_t spins = 0;
         int64_t gv;
-        while (((gv = __atomic_load_n(h->h_gate, __ATOMIC_ACQUIRE)) >> 1) != h->q_ticket) {
+        while (((gv = __atomic_load_n(h->h_gate, __ATOMIC_ACQUIRE)) >> 1) != ticket) {
             cpu_relax();
             if ((++spins & 0x3fff) != 0) continue;
             const hipError_t q = hipStreamQuery(h->stream);
             if (q == hipErrorNotReady) continue;
-            if ((__atomic_load_n(h->h_gate, __ATOMIC_ACQUIRE) >> 1) == h->q_ticket) continue;
+            if ((__atomic_load_n(h->h_gate, __ATOMIC_ACQUIRE) >> 1) == ticket) continue;
             return fail(h, GPF_ERR_HIP, q == hipSuccess ? "ESS gate: the stream drained without the verdict being published" : hipGetErrorString(q));
         }
         if ((s = check_scan_timeout(h))) return s;
@@ -447,6 +450,7 @@ gpf_status sort_passes(gpf_filter* h, const PrioView& pv, int64_t n, bool coarse
     // (ONE workgroup per CU: every workgroup ends with up to 256 global atomic adds per sorted digit into the same counters; with 2 / 4
     //  workgroups per CU a four-digit kernel took 16.0 / 24.2 us against 13.3)
     const unsigned long long* slots = h->mslots[h->mcur];
+    const ChainScope chain(h);                                   // (k_sort_pass chains its workgroups: gpf_host.hpp ChainGate)
     if (buckets) {
         // K10d: keys + fine-bin histogram, ONE partition pass (keys -> keys_out, payload index -> idx_in); the caller runs k_sort_buckets
         const int64_t kf_grid = std::max<int64_t>(1, std::min<int64_t>((n + 4 * KF_BLOCK - 1) / (4 * KF_BLOCK), h->n_cu));
@@ -578,6 +582,7 @@ gpf_status residual_scans(gpf_filter* h, const WSum* ws, int64_t n_slots_global,
         h->dcur[id] ^= 1;
     }
     const int gs = scan_grid(h);
+    const ChainScope chain(h);
     s = timed(h, GPF_K_SCAN, [&] {
         if (direct) GPF_LAUNCH(k_scan_residual2<true>, dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, h->cdf[0], ws, n_slots_global, h->n, h->ntiles, ch[0], ch[1], h->h_timeout, head_anc, &h->sc->giants, h->epoch & 0xffffffu, *direct);
         else        GPF_LAUNCH(k_scan_residual2<false>, dim3(gs), dim3(SCAN_BLOCK), 0, h->stream, h->cdf[0], ws, n_slots_global, h->n, h->ntiles, ch[0], ch[1], h->h_timeout, head_anc, &h->sc->giants, h->epoch & 0xffffffu, ResidDirect{});
@@ -705,7 +710,7 @@ gpf_status resample_impl(gpf_filter* h, int method, PrioView pv, int sort_partic
     const bool resid_direct = !no_direct && method == GPF_RESAMPLE_RESIDUAL && pv.mode == 0 && !h->raw_valid && h->raw_sum_valid && h->sum_on_host;
     int direct_flags = 0;
     if (resid_direct) {
-        rdirect = ResidDirect{h->lw, h->sum_cache.m, h->sum_cache.flags, h->K, h->sum_cache.S, &h->sc->raw};
+        rdirect = ResidDirect{h->lw, h->sum_cache.m, h->sum_cache.flags, h->K, h->sum_cache.S, &h->sc->raw, nullptr, 0, 0};
         direct_flags = h->sum_cache.flags;
         ws = &h->sc->raw;
     } else

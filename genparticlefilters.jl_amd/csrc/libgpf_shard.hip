@@ -48,10 +48,21 @@ static gpf_status shard_ready(gpf_handle h)
 {
     gpf_status s = check_ready(h);
     if (s) return s;
+    if (h->comm_poisoned)
+        return fail(h, GPF_ERR_STATE, "an earlier sharded call failed on this rank after its exchange rounds had begun: the communicator is out of step with its peers (tear the job down)");
     return GPF_OK;
 }
 
 static gpf_status shard_max_slots(gpf_handle h);
+static gpf_status ensure_shard_counts(gpf_handle h)
+{
+    if (h->shard_counts) return GPF_OK;
+    HIP_TRY(h, hipMalloc(&h->shard_counts, (size_t)2 * MAX_SHARDS * COUNT_STRIDE * sizeof(int64_t)));
+    HIP_TRY(h, hipMemsetAsync(h->shard_counts, 0, (size_t)2 * MAX_SHARDS * COUNT_STRIDE * sizeof(int64_t), h->stream));
+    HIP_TRY(h, hipHostMalloc(&h->h_shard_counts, (size_t)(2 * MAX_SHARDS + 1) * sizeof(int64_t)));
+    h->h_shard_counts[2 * MAX_SHARDS] = 0;
+    return GPF_OK;
+}
 gpf_status gpf_shard_weight_max(gpf_handle h, double* out2)
 {
     gpf_status s = shard_ready(h);
@@ -84,12 +95,7 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (!mf_all || !out5 || G < 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
-    if (!h->shard_counts) {
-        HIP_TRY(h, hipMalloc(&h->shard_counts, (size_t)2 * MAX_SHARDS * COUNT_STRIDE * sizeof(int64_t)));
-        HIP_TRY(h, hipMemsetAsync(h->shard_counts, 0, (size_t)2 * MAX_SHARDS * COUNT_STRIDE * sizeof(int64_t), h->stream));
-        HIP_TRY(h, hipHostMalloc(&h->h_shard_counts, (size_t)(2 * MAX_SHARDS + 1) * sizeof(int64_t)));
-        h->h_shard_counts[2 * MAX_SHARDS] = 0;
-    }
+    if ((s = ensure_shard_counts(h))) return s;
     InFixQ in{h->sum_pv_set ? h->sum_pv : raw_view(h), nullptr, nullptr, h->K, 0.0, 0};
     WSum* const slot = h->sum_slot ? h->sum_slot : &h->sc->raw;
     const bool want_cdf = !h->sum_no_cdf;
@@ -138,9 +144,25 @@ gpf_status gpf_shard_residual_scan(gpf_handle h, const int64_t* tot_all, int32_t
     // global S into sc->prio (the local CDF in cdf[0] stays local)
     GPF_LAUNCH(k_set_global, dim3(1), dim3(64), 0, h->stream, tot_all, (int)G, &h->sc->prio, mb_wait(h, MB_TOT));
     if ((s = residual_scans(h, &h->sc->prio, h->cfg.n_global))) return s;
-    GPF_LAUNCH(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2, mb_begin(h, MB_CR));
+    GPF_LAUNCH(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2, mb_begin(h, MB_CR), nullptr, 0);
     HIP_TRY(h, hipGetLastError());
     h->residual_scanned = true;
+    return GPF_OK;
+}
+// ... the same WITHOUT a weight scan in front (shard_resample_impl: the one-launch summary reduction of the ESS read has left the global S with the
+// host and the gathered (max, flags) in the mailbox -- the unsharded filter's direct form, k_scan_residual2<DIRECT>): the weights are converted in the
+// residual scan itself, the exchange counters the weight scan would have cleared are cleared by k_export_residual
+static gpf_status shard_residual_scan_direct(gpf_handle h, const double* mf_all, uint64_t S_global, int32_t G, int64_t* out2)
+{
+    gpf_status s = ensure_shard_counts(h);
+    if (s) return s;
+    if ((s = materialize(h))) return s;
+    const ResidDirect rd{h->lw, 0.0, 0, h->K, S_global, &h->sc->prio, mf_all, G, (int32_t)(h->mb_active && h->mb_engine)};
+    if ((s = residual_scans(h, &h->sc->prio, h->cfg.n_global, nullptr, &rd))) return s;
+    GPF_LAUNCH(k_export_residual, dim3(1), dim3(64), 0, h->stream, h->sc, out2, mb_begin(h, MB_CR), h->shard_counts, (int)(2 * MAX_SHARDS * COUNT_STRIDE));
+    HIP_TRY(h, hipGetLastError());
+    h->residual_scanned = true;
+    h->raw_valid = false; h->raw_sum_valid = false;
     return GPF_OK;
 }
 
@@ -468,11 +490,25 @@ gpf_status shard_scratch(gpf_filter* h)
 // mailboxes (peer stores from the producing kernels, waits in the consuming ones: no collective) or two RCCL all-gathers.
 // Leaves h->cur_mf_all / cur_tot_all naming the gathered arrays of this round.
 struct EngineScope { gpf_filter* h; explicit EngineScope(gpf_filter* f) : h(f) { h->mb_engine = true; } ~EngineScope() { h->mb_engine = false; } };
-gpf_status shard_summary(gpf_filter* h, int want_q)
+// is the global summary of the latest one-launch reduction (k_sum_shard) still a description of the current weights and of the mailbox's current rounds?
+bool gsum_valid(const gpf_filter* h)
+{
+    return h->gsum_ok && h->mb_active && h->gsum_mut == h->mutations && h->gsum_mf_seq == h->mb_cur[MB_MF] && h->gsum_tot_seq == h->mb_cur[MB_TOT] &&
+           !h->pending_packed && !h->pending_gather && !h->pending_fill && !h->pending_move && !h->sum_pv_set;
+}
+gpf_status shard_summary(gpf_filter* h, int want_q, bool reuse_mf = false)
 {
     gpf_status s = shard_scratch(h);
     if (s) return s;
     const bool mb = h->mb_active;
+    if (reuse_mf) {
+        // the ESS read in front of this resample has exchanged (max, flags) already (its MB_MF round is the mailbox's current one): only the scan + its {S} round
+        h->sh_round++;
+        int64_t* tot = h->sh_tot + 5 * (int)((h->sh_round - 1) % SH_RING);
+        if ((s = gpf_shard_weight_scan(h, h->cur_mf_all, h->comm_world, want_q, tot))) return s;
+        h->cur_tot_all = static_cast<const int64_t*>(mb_gathered(h, MB_TOT));
+        return GPF_OK;
+    }
     const size_t G = (size_t)h->comm_world;
     const int r = (int)(h->sh_round++ % SH_RING);
     const bool alias = h->sh_mf_all == h->sh_mf;                 // one shard without communicator
@@ -853,6 +889,7 @@ gpf_status gpf_comm_destroy(gpf_handle h)
     h->pending_packed = false; h->pend_packed = nullptr; h->pend_mf = nullptr; h->pend_tot = nullptr; h->pend_G = 0;
     if (h->stream) hipStreamSynchronize(h->stream);
     mailbox_teardown(h);
+    h->comm_poisoned = false;
     h->cur_mf_all = nullptr; h->cur_tot_all = h->cur_cr_all = nullptr;
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
@@ -1045,14 +1082,25 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         raw_mf = h->cur_mf_all; raw_tot = h->cur_tot_all;
         h->push_extra = 1; h->push_pv = PrioView{h->lw, nullptr, priority_alpha, 1};
     }
-    h->want_offsets = method == GPF_RESAMPLE_MULTINOMIAL;         // (the offset levels serve k_push_multi only)
-    s = prio ? shard_summary_of(h, h->push_pv, &h->sc->prio, true) : shard_summary(h, 0);   // phases 1, 2 (safe_softmax of the priorities, :54)
-    h->want_offsets = true;
-    if (s) return s;
+    // An ESS read stands in front of this resample (README.md:68-70; gpf_shard_step_ess, or the getter) and its one-launch reduction (k_sum_shard) has
+    // exchanged (max, flags) and {S, limbs} already -- the weights and the mailbox's rounds are still those: the (max, flags) round is not repeated, and a
+    // RESIDUAL resample, which samples from copy counts and residual weights, never from the weight CDF, runs no weight scan at all (the unsharded
+    // filter's direct form).  Every rank holds the same summary, so every rank takes the same branch.
+    static const bool reuse_off = getenv("GPF_SHARD_REUSE_SUMMARY") && !strcmp(getenv("GPF_SHARD_REUSE_SUMMARY"), "0");    // (A/B measurements, tests of the plain path)
+    const bool reuse = !reuse_off && !prio && gsum_valid(h);
+    const bool resid_direct = reuse && method == GPF_RESAMPLE_RESIDUAL;
+    const WSum gsum = h->gsum;
+    h->gsum_ok = false;                                           // (whatever follows starts new rounds or changes the weights)
+    if (!resid_direct) {
+        h->want_offsets = method == GPF_RESAMPLE_MULTINOMIAL;     // (the offset levels serve k_push_multi only)
+        s = prio ? shard_summary_of(h, h->push_pv, &h->sc->prio, true) : shard_summary(h, 0, reuse);   // phases 1, 2 (safe_softmax of the priorities, :54)
+        h->want_offsets = true;
+        if (s) return s;
+    }
     if (check != GPF_CHECK_FALSE || invalid) {                    // safe_softmax validity (utils.jl:117-140): pinned flags, no stream sync
         // (the flags describe the GLOBAL weights: every rank takes the same branch here)
-        int32_t flags = 0;
-        if ((s = gpf_shard_flags(h, &flags))) return s;
+        int32_t flags = resid_direct ? gsum.flags : 0;
+        if (!resid_direct && (s = gpf_shard_flags(h, &flags))) return s;
         if (invalid) *invalid = flags != 0;
         if (flags & (FLAG_NAN | FLAG_POSINF)) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights (NaN).");
         if (check == GPF_CHECK_TRUE && flags) return fail(h, GPF_ERR_INVALID_WEIGHTS, "Invalid weights.");   // resample.jl:55
@@ -1060,7 +1108,8 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     const int64_t* cr_all = nullptr;
     const int64_t* tot_all = h->cur_tot_all;
     if (method == GPF_RESAMPLE_RESIDUAL) {                        // phase 2b
-        if ((s = gpf_shard_residual_scan(h, tot_all, G, h->sh_cr))) return s;
+        if (resid_direct) { if ((s = shard_residual_scan_direct(h, h->cur_mf_all, gsum.S, G, h->sh_cr))) return s; }
+        else if ((s = gpf_shard_residual_scan(h, tot_all, G, h->sh_cr))) return s;
         if (!h->mb_active && (s = shard_all_gather(h, h->sh_cr, h->sh_cr_all, 2, ncclInt64, sizeof(int64_t)))) return s;
         cr_all = h->cur_cr_all = h->mb_active ? static_cast<const int64_t*>(mb_gathered(h, MB_CR)) : h->sh_cr_all;
     }
@@ -1154,7 +1203,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         }
     }
     phase_mark(h, GPF_PHASE_EXCHANGE);
-    if (late) { h->err = late_msg; return late; }
+    if (late) { h->err = late_msg; h->comm_poisoned = true; return late; }
     if (!prio) return gpf_shard_commit(h, commit_from, own ? n - counts[(size_t)G + me] : n, h->cur_mf_all, tot_all, G);   // phase 5 (deferred)
     // phase 5 of a prioritised resample, at once: scatter rows / parents / log_ws, log-ML from the raw summary ...
     {
@@ -1230,11 +1279,16 @@ gpf_status gpf_shard_step_ess(gpf_handle h, const double* obs, int32_t n_obs, do
         return gpf_update(h, obs, n_obs);
     }
     const ModelArgs old_args = h->args;                          // (a rejuvenation moves under the CURRENT step's observation)
-    if ((s = set_obs(h, obs, n_obs))) { h->args = old_args; return s; }
+    const int mcur0 = h->mcur;
+    // (the mailbox rounds of this step have begun: a failure of THIS rank from here on leaves its peers a step ahead of it -- they will wait for its next
+    //  round until the mailbox wait gives up; the handle remembers, and every later sharded call on it fails at once instead of joining out of step)
+    auto undo = [&](gpf_status st) { h->args = old_args; h->mcur = mcur0; h->comm_poisoned = true; return st; };
+    if ((s = set_obs(h, obs, n_obs))) return undo(s);
     GateIn gate{}; gate.flag = &h->sc->gate_go;
-    if ((s = speculative_step(h, gate))) return s;
+    if ((s = speculative_step(h, gate))) return undo(s);
     WSum w{};
-    if ((s = read_published_summary(h, w))) return s;
+    if ((s = read_published_summary(h, w))) return undo(s);
+    h->gsum = w; h->gsum_ok = true;                              // (a resample behind this verdict reuses the exchanged summary: shard_resample_impl)
     uint64_t hi, lo;
     normalise_Q(w, hi, lo);
     const bool go = !w.flags && ess_from(w.S, hi, lo) < thr;     // (the device's verdict: the same integers through the same operations)
@@ -1298,6 +1352,7 @@ gpf_status shard_global_summary(gpf_filter* h, double thr, WSum& w, bool* done)
     gpf_status s = shard_global_summary_launch(h, thr, done);
     if (s || !*done) return s;
     if ((s = read_published_summary(h, w))) return s;
+    h->gsum = w; h->gsum_ok = true;
     return GPF_OK;
 }
 gpf_status shard_global_summary_launch(gpf_filter* h, double thr, bool* done)
@@ -1329,6 +1384,7 @@ gpf_status shard_global_summary_launch(gpf_filter* h, double thr, bool* done)
     if (!ok) return fail(h, GPF_ERR_STATE, "sharded summary: the filter is too large for the reduction's tagged partials");   // (the rounds are begun: no way back to the scan)
     h->cur_mf_all = ss.mf_all; h->cur_tot_all = ss.tot_all;
     h->raw_valid = false; h->raw_sum_valid = false;              // (sc->raw holds this shard's sums under the GLOBAL maximum: not the unsharded summary)
+    h->gsum_ok = false; h->gsum_mut = h->mutations; h->gsum_mf_seq = h->mb_cur[MB_MF]; h->gsum_tot_seq = h->mb_cur[MB_TOT];   // (valid once the host has read it)
     *done = true;
     return GPF_OK;
 }

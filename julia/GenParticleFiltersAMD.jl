@@ -468,6 +468,31 @@ function shard_plan(s::ShardedDeviceParticleFilterState)
     _status(s, ccall((:gpf_comm_plan, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cint}), s.handle, p))
     p[] == 1 ? :pull : :push
 end
+"""how the rows of the resamplers with ascending targets (:stratified with sort_particles = false, the opt-in sorted multinomial) cross shards: :p2p = peer
+stores into the destination ranks' slot-addressed receive windows (no host wait, no ncclGroup; the default where the mailboxes are up), :rccl = packed
+entries through grouped ncclSend / ncclRecv (gpf.h gpf_comm_set_exchange); the same on every rank"""
+function shard_exchange!(s::ShardedDeviceParticleFilterState, mode::Symbol)
+    mode in (:p2p, :rccl) || error("exchange mode :$mode: :p2p or :rccl")
+    _status(s, ccall((:gpf_comm_set_exchange, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, mode == :p2p ? 1 : 0)); s
+end
+function shard_exchange(s::ShardedDeviceParticleFilterState)
+    m = Ref{Cint}(0)
+    _status(s, ccall((:gpf_comm_exchange, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cint}), s.handle, m))
+    m[] == 1 ? :p2p : :rccl
+end
+"(us per grouped exchange of `entries` packed entries with every peer, GB/s per link, us per mailbox round, us of an empty launch) on this machine (gpf.h gpf_comm_calibrate; collective)"
+function shard_calibrate(s::ShardedDeviceParticleFilterState, entries::Integer; reps::Integer=20)
+    out = zeros(Float64, 4)
+    _status(s, ccall((:gpf_comm_calibrate, libgpf), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Cdouble}), s.handle, entries, reps, out))
+    (out[1], out[2], out[3], out[4])
+end
+"per-phase microseconds of the sharded resamples since `shard_phase_timing!(s, true)` (gpf.h gpf_phase_times): summaries, plan, pack, host wait, exchange, commit + propagate"
+shard_phase_timing!(s::ShardedDeviceParticleFilterState, on::Bool) = (_status(s, ccall((:gpf_phase_timing, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, on ? 1 : 0)); s)
+function shard_phase_times(s::ShardedDeviceParticleFilterState)
+    us = zeros(Float64, 6); n = Ref{Int64}(0)
+    _status(s, ccall((:gpf_phase_times, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ref{Int64}), s.handle, us, n))
+    (us, n[])
+end
 effective_sample_size(s::ShardedDeviceParticleFilterState) = _scalar(s, :gpf_shard_effective_sample_size)
 get_ess(s::ShardedDeviceParticleFilterState) = effective_sample_size(s)
 log_ml_estimate(s::ShardedDeviceParticleFilterState) = _scalar(s, :gpf_shard_log_ml_estimate)

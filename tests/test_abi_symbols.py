@@ -63,6 +63,107 @@ def test_julia_glue_matches_header():
         assert len(ja) == len(ha), f"{n}: {len(ja)} ccall argument types, {len(ha)} parameters in the header"
 
 
+# what a ccall argument type may be for a C parameter type of include/gpf.h (Julia's C interface: Cint = Int32, Clonglong = Int64, Cdouble = Float64;
+# Ref{T} and Ptr{T} both pass a T*; a gpf_handle is an opaque pointer)
+_JULIA_FOR_C = {
+    "gpf_handle": {"Ptr{Cvoid}"},
+    "gpf_handle*": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
+    "gpf_config*": {"Ref{GpfConfig}", "Ptr{GpfConfig}"},
+    "int32_t": {"Cint", "Int32"}, "int": {"Cint", "Int32"},
+    "int64_t": {"Int64", "Clonglong"},
+    "uint32_t": {"UInt32", "Cuint"}, "uint64_t": {"UInt64", "Culonglong"},
+    "double": {"Cdouble", "Float64"},
+    "double*": {"Ptr{Cdouble}", "Ref{Cdouble}", "Ptr{Float64}", "Ref{Float64}"},
+    "int32_t*": {"Ptr{Cint}", "Ref{Cint}", "Ptr{Int32}", "Ref{Int32}"},
+    "int64_t*": {"Ptr{Int64}", "Ref{Int64}", "Ptr{Clonglong}"},
+    "uint64_t*": {"Ptr{UInt64}", "Ref{UInt64}"},
+    "void*": {"Ptr{Cvoid}", "Ptr{UInt8}"},
+}
+_JULIA_RETURN = {"gpf_status": {"Cint"}, "int": {"Cint"}, "char*": {"Cstring", "Ptr{UInt8}"}, "void": {"Cvoid"}, "int32_t": {"Cint", "Int32"},
+                 "uint64_t": {"UInt64"}, "double": {"Cdouble", "Float64"}}
+
+
+def _c_prototypes():
+    """name -> (return type, [parameter types]) of every function include/gpf.h declares; `const` dropped, pointers glued to the type"""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "gpf.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9 ]*?[ *]+)\b(gpf_[A-Za-z_0-9]+)\s*\(([^;{}]*?)\)\s*;", hdr):
+        ret = m.group(1).replace("const", "").strip().replace(" *", "*").replace(" ", "")
+        params = []
+        for a in [x.strip() for x in m.group(3).split(",")]:
+            if not a or a == "void":
+                continue
+            a = re.sub(r"\bconst\b", "", a).strip()
+            t = re.sub(r"\s*[A-Za-z_][A-Za-z_0-9]*$", "", a) if re.search(r"[ *][A-Za-z_][A-Za-z_0-9]*$", a) else a      # drop the parameter's name
+            params.append(t.replace(" ", ""))
+        protos[m.group(2)] = (ret, params)
+    return protos
+
+
+def _split_types(tup):
+    """'Ptr{Cvoid}, Ref{Ptr{Cvoid}}' -> the top-level comma-separated types"""
+    out, depth, cur = [], 0, ""
+    for ch in tup:
+        if ch == "{":
+            depth += 1
+        elif ch == "}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def test_julia_glue_argument_types_match_header():
+    """The glue has never run (no Julia in the image), and an arity check passes a `Cint` where the header wants an `int64_t`: map EVERY ccall's return and
+    argument types onto the C prototype (Cint <-> int32_t, Int64 / Clonglong <-> int64_t, Cdouble <-> double, Ptr{T} / Ref{T} <-> T*, UInt64 <-> uint64_t,
+    Ptr{Cvoid} <-> gpf_handle / void*); the calls through a symbol variable (`_scalar`, `_vector`) against every symbol they are given; and the field
+    order and types of `struct GpfConfig` against the header's gpf_config."""
+    import re
+    jl = open(os.path.join(ROOT, "julia", "GenParticleFiltersAMD.jl")).read()
+    protos = _c_prototypes()
+    assert len(protos) >= 90 and protos["gpf_resize"] == ("gpf_status", ["gpf_handle", "int64_t", "int32_t", "double", "int32_t", "int32_t*"])
+
+    def check(name, ret, types, where):
+        assert name in protos, f"{where}: {name} is not declared in include/gpf.h"
+        cret, cparams = protos[name]
+        assert ret in _JULIA_RETURN[cret], f"{where}: {name} returns {cret}, the ccall says {ret}"
+        assert len(types) == len(cparams), f"{where}: {name} takes {len(cparams)} arguments, the ccall passes {len(types)}"
+        for k, (jt, ct) in enumerate(zip(types, cparams)):
+            assert jt in _JULIA_FOR_C[ct], f"{where}: argument {k + 1} of {name} is `{ct}`, the ccall passes `{jt}`"
+
+    n_checked = 0
+    for m in re.finditer(r"ccall\(\(:([a-z_A-Z0-9]+), libgpf\), ([A-Za-z]+), \(", jl):
+        # the argument-type tuple: up to its matching parenthesis
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(jl[i], 0); i += 1
+        check(m.group(1), m.group(2), _split_types(jl[m.end():i - 1]), f"line {jl.count(chr(10), 0, m.start()) + 1}")
+        n_checked += 1
+    assert n_checked >= 60
+    # the two helpers that take the entry point as a symbol
+    helpers = {"_scalar": ["Ptr{Cvoid}", "Ref{Cdouble}"], "_vector": ["Ptr{Cvoid}", "Ptr{Cdouble}", "Int64"]}
+    for hname, types in helpers.items():
+        body = re.search(r"function %s\(s, sym\)(.*?)^end" % hname, jl, re.S | re.M).group(1)
+        assert "(%s)" % ", ".join(types) in body, f"{hname}: its ccall no longer passes {types}"
+        syms = re.findall(r"%s\(s, :([a-z_A-Z0-9]+)\)" % hname, jl)
+        assert syms, hname
+        for sym in syms:
+            check(sym, "Cint", types, hname)
+    # struct GpfConfig: same fields, same order, matching types
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gpf.h")).read(), flags=re.S)
+    cfields = re.findall(r"^\s*(?:const\s+)?([A-Za-z_0-9]+\s*\*?)\s*([a-z_]+);", re.search(r"typedef struct \{(.*?)\} gpf_config;", hdr, re.S).group(1), re.M)
+    jfields = re.findall(r"([a-z_]+)::([A-Za-z0-9{}]+)", re.search(r"struct GpfConfig\n(.*?)\nend", jl, re.S).group(1))
+    assert [f for _, f in cfields] == [f for f, _ in jfields], "GpfConfig: field names / order differ from gpf_config"
+    for (ct, name), (_, jt) in zip(cfields, jfields):
+        assert jt in _JULIA_FOR_C[ct.replace(" ", "")], f"GpfConfig.{name}: `{ct.strip()}` in the header, `{jt}` in the glue"
+
+
 def test_julia_glue_has_no_shadowed_status_helper():
     """The resamplers take a keyword called `check` (src/resample.jl:43-46).  A status helper of the same name is shadowed inside those
     methods (`:warn(s, st)` -> MethodError after the ccall has already mutated the state): the helper is `_status`, no bare `check(`

@@ -54,3 +54,21 @@ def test_c_example_equals_python_host(g, tmp_path, name, method, ess_fraction, r
                 g.pf_rejuvenate(st, None, (), 1, method="move" if rejuv == 1 else "reweight")
         g.pf_update(st, (t + 1,), (None,), ys[t])
     assert (lml, ess, mean0, var0, n_res) == (g.get_lml_est(st), g.get_ess(st), g.mean(st, 0), g.var(st, 0), k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("one_call", [0, 1])
+def test_bench_configs_python_and_compiled_host_lines_agree(g, one_call):
+    """tools/bench_configs.py prints config 4 twice -- the loop driven from Python and from the compiled host (examples/lgssm_filter.c) --: the two
+    lines describe the SAME filter run (same seed, same observations, warm-up + timed steps), so their log_ml must agree to the last digit (round 5:
+    the Python line read its estimate after the kernel-timing replay: -88 582 against 773.43)"""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+    bc = importlib.util.module_from_spec(spec); sys.modules["bench_configs"] = bc; spec.loader.exec_module(bc)
+    bc.NO_CPU = True
+    N, steps, warm = 30_000, 40, 5
+    py = bc.run("config4 at test size", "bearings4", N, "residual", {"_step_ess": True} if one_call else {}, "move", 0.5, steps=steps, warm=warm)
+    c = bc.run_c_host("config4 at test size, compiled host", "bearings4", N, 1, 1, 0.5, steps=steps, warm=warm, one_call=one_call)
+    assert py["log_ml"] == c["log_ml"], (py["log_ml"], c["log_ml"])
+    assert py["resampled_steps"] <= c["resampled_steps_incl_warmup"] <= py["resampled_steps"] + warm

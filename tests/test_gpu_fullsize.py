@@ -450,3 +450,44 @@ print("ok")
         env = dict(os.environ, GPF_WSCAN_BLOCKS=blocks)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (blocks, out.stdout[-500:], out.stderr[-1500:])
+
+
+@pytest.mark.gpu
+def test_four_full_size_filters_in_flight_take_turns_at_the_chained_kernels(g, o):
+    """R = 4 independent filters of BASELINE config 5's size (SV, N = 2 x 10^6, multinomial + move-reweight: SURVEY 8(d)'s "R independent seeds"), one
+    handle and one stream each, stepped round-robin from one host thread with nothing ever waiting.  Round 6 found this shape DEADLOCKING: the weight
+    scans of two filters each held the CU slots the other's not-yet-dispatched workgroups needed, every resident workgroup waited for a lower tile, and
+    after seconds the bounded waits gave up ("bounded inter-workgroup wait timed out").  With more than one filter alive on a device the chained kernels
+    (scans, the sort's partition passes) now take turns (gpf_host.hpp ChainGate); everything else still overlaps.  Checked: no error, and every filter
+    equals the same filter run ALONE, bit for bit; one of them also against the oracle."""
+    model = g.models.sv1(); T = 25; ys = g.models.simulate(model, T + 1); N, R = 2_000_000, 4
+
+    def step(st, t, method):
+        g.pf_resample(st, method, check=False, **({"sort_particles": True} if method == "stratified" else {}))
+        g.pf_rejuvenate(st, None, (), 1, method="reweight")
+        g.pf_update(st, (t + 1,), (None,), ys[t])
+    methods = ["multinomial", "multinomial", "residual", "stratified"]        # (stratified with the reference's default sort: the partition passes chain too)
+    sts = [g.pf_initialize(model, (1,), ys[0], N, seed=1 + r, keep_prev=True) for r in range(R)]
+    for t in range(1, T):
+        for r, st in enumerate(sts):
+            step(st, t, methods[r])
+    together = []
+    for st in sts:
+        together.append((g.get_lml_est(st), g.get_ess(st), st.log_weights, st.parents))
+        st.close()
+    for r in range(R):
+        st = g.pf_initialize(model, (1,), ys[0], N, seed=1 + r, keep_prev=True)
+        for t in range(1, T):
+            step(st, t, methods[r])
+        lml, ess, lw, par = together[r]
+        assert g.get_lml_est(st) == lml and g.get_ess(st) == ess and np.array_equal(st.log_weights, lw) and np.array_equal(st.parents, par), r
+        st.close()
+    orc = o.OracleFilter(model.model_id, model.params, N, 1, keep_prev=True).initialize(ys[0])
+    for t in range(1, 6):
+        orc.resample("multinomial", check=False); orc.rejuvenate("reweight", 1); orc.update(ys[t])
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=1, keep_prev=True)
+    other = g.pf_initialize(model, (1,), ys[0], N, seed=9, keep_prev=True)     # (a second filter alive: the gate is on)
+    for t in range(1, 6):
+        step(st, t, "multinomial"); step(other, t, "multinomial")
+    assert np.array_equal(st.log_weights, orc.lw) and np.array_equal(st.parents, orc.parents) and g.get_lml_est(st) == orc.log_ml_estimate()
+    st.close(); other.close()

@@ -583,3 +583,15 @@ def test_exchange_mode_api(g, o):
     with pytest.raises(g.ErrorException):
         a.backend.set_exchange("carrier pigeon")
     a.backend.set_exchange("rccl")
+
+
+@pytest.mark.parametrize("case,one_call", soak_grid([CASES[3], CASES[5], CASES[0]], [False, True], keep=lambda c, oc: c == CASES[3] or (c == CASES[5] and oc)), ids=_cid)
+def test_resample_behind_an_ess_read_with_and_without_summary_reuse(g, o, tmp_path, monkeypatch, loopback_lib, case, one_call):
+    """An ESS read in front of a resample (README.md:68-70) has exchanged (max, flags) and {S, limbs} already (k_sum_shard): gpf_shard_resample reuses that
+    round -- no second (max, flags) exchange, and for :residual no weight scan at all (k_scan_residual2<DIRECT> with the global S from the host and the
+    maximum folded from the gathered pairs).  GPF_SHARD_REUSE_SUMMARY=0 keeps the plain sequence: both equal the single-shard oracle bit for bit, through
+    the separate calls (get_ess; pf_resample!; ...) and through the one call (gpf_shard_step_ess), 3 ranks on one GPU."""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    for reuse in ("1", "0"):
+        monkeypatch.setenv("GPF_SHARD_REUSE_SUMMARY", reuse)
+        test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=3, one_call=one_call)

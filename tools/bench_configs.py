@@ -104,10 +104,12 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
     el = time.perf_counter() - t0
     gc.enable()
     n_res_timed = n_res                    # (the per-kernel timing steps below replay early observations and resample almost every time)
+    # the estimate of the TIMED run (steps 1 .. warm + steps, what the compiled host's line reports too) -- read before the replay below moves it
+    log_ml = g.get_lml_est(st)
     kids = list(g._lib.KERNEL_NAMES)
     for k in kids:
         st.kernel_timing(k, True)
-    for i in range(50):
+    for i in range(min(50, steps)):
         step(1 + i)
     per = {}
     for k in kids:
@@ -115,12 +117,13 @@ def run(name, model_name, N, method, kw, rejuv, ess_frac, steps=200, warm=10):
         if cnt:
             per[g._lib.KERNEL_NAMES[k]] = round(ms / cnt * 1e3, 2)
     out = dict(config=name, N=N, steps=steps, us_per_step=round(el / steps * 1e6, 2), particle_steps_per_s=round(N * steps / el, 1),
-               resampled_steps=n_res_timed, kernels_us=per, log_ml=g.get_lml_est(st))
+               resampled_steps=n_res_timed, kernels_us=per, log_ml=log_ml)
     st.close()
     if not NO_CPU and not lazy and not gated:
         out["cpu_baseline"], out["cpu_baseline_multithread"] = cpu_baseline(model, ys, N, method, kw, rejuv, ess_frac, CPU_SECONDS)
         out["gpu_over_cpu_1core"] = round(out["particle_steps_per_s"] / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out), flush=True)
+    return out
 
 
 def run_c_host(name, model_name, N, method_id, rejuvenate, ess_frac, steps=200, warm=10, one_call=0):
@@ -140,8 +143,10 @@ def run_c_host(name, model_name, N, method_id, rejuvenate, ess_frac, steps=200, 
         f.write(f"{ys.shape[1]} {ys.shape[0]}\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in ys) + "\n")
     out = subprocess.check_output([exe, inp, str(N), "1", str(method_id), str(ess_frac), str(rejuvenate), str(warm + 1), str(one_call)], text=True).splitlines()
     first = out[0].split(); us = float(out[1].split()[1])
-    print(json.dumps(dict(config=name, N=N, steps=steps, us_per_step=round(us, 2), particle_steps_per_s=round(N / us * 1e6, 1),
-                          resampled_steps_incl_warmup=int(first[4]), warmup=warm, log_ml=float(first[0]))), flush=True)
+    res = dict(config=name, N=N, steps=steps, us_per_step=round(us, 2), particle_steps_per_s=round(N / us * 1e6, 1),
+               resampled_steps_incl_warmup=int(first[4]), warmup=warm, log_ml=float(first[0]))
+    print(json.dumps(res), flush=True)
+    return res
 
 
 if __name__ == "__main__":

@@ -2,9 +2,10 @@
 #
 #   gpurun --timeout S -- 'bash tools/gpu.sh STEP [STEP ...]'      steps run in order; every output lands under gpurun_out/
 #
-# steps (TAG = $GPF_TAG, default r05):
+# steps (TAG = $GPF_TAG, default r06):
 #   smoke                 __graft_entry__.smoke()
 #   tests[:EXPR]          pytest -m gpu (optionally -k EXPR) -> gpurun_out/TAG_pytest.log
+#   soak                  pytest -m "gpu or gpu_soak": the driver's set PLUS the wide multi-process matrices (tests/conftest.py soak_grid) -> TAG_pytest_soak.log
 #   file:PATH[:EXPR]      pytest -m gpu on one test file
 #   bench[:STEPS]         python bench.py --steps STEPS (default 1000) --warmup 20 -> TAG_bench.json
 #   driver                the driver's own command: python bench.py --gpus 1 --steps 20 --warmup 5 -> TAG_bench_driver_cmd.json
@@ -19,7 +20,7 @@
 #   variant:OUT:METHOD:DEFS   tools/variant_stats.sh OUT METHOD DEFS (DEFS: comma-separated -D sets, alternating A/B rocprofv3 runs)
 #   py:SCRIPT:ARGS        python3 tools/SCRIPT.py ARGS -> TAG_SCRIPT.txt
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${GPF_TAG:-r05}
+TAG=${GPF_TAG:-r06}
 mkdir -p $R/gpurun_out
 export TMPDIR=/tmp
 stats_of() {   # stats_of DIR OUT: copy the kernel-stats csv of a rocprofv3 output directory
@@ -33,6 +34,7 @@ for STEP in "$@"; do
   case $S in
     smoke)   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
     tests)   timeout 3000 python -m pytest tests -m gpu -q ${A1:+-k "$A1"} > gpurun_out/${TAG}_pytest.log 2>&1; tail -15 gpurun_out/${TAG}_pytest.log | cut -c1-220 ;;
+    soak)    timeout 3000 python -m pytest tests -m "gpu or gpu_soak" -q > gpurun_out/${TAG}_pytest_soak.log 2>&1; tail -8 gpurun_out/${TAG}_pytest_soak.log | cut -c1-220 ;;
     file)    timeout 3000 python -m pytest "$A1" -m gpu -x -q ${A2:+-k "$A2"} > gpurun_out/${TAG}_pytest_$(basename $A1 .py).log 2>&1; tail -25 gpurun_out/${TAG}_pytest_$(basename $A1 .py).log | cut -c1-220 ;;
     bench)   python bench.py --steps ${A1:-1000} --warmup 20 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-3000 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err ;;
     driver)  python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_cmd.json 2> gpurun_out/${TAG}_bench_driver_cmd.err; cut -c1-600 gpurun_out/${TAG}_bench_driver_cmd.json ;;
@@ -67,6 +69,10 @@ for STEP in "$@"; do
              for M in multinomial stratified residual multinomial_sorted; do
                echo -n "$M, no communicator:      " >> $OUT; python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
                echo -n "$M, 1-rank RCCL, mailbox: " >> $OUT; GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
+               case $M in stratified|multinomial_sorted)   # (the line above ran the window exchange; this one the grouped send / receive and the fused (max, flags) round)
+                 echo -n "$M, 1-rank RCCL, mailbox, GPF_SHARD_EXCHANGE=rccl: " >> $OUT; GPF_SHARD_EXCHANGE=rccl GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
+                 echo -n "$M, 1-rank RCCL, mailbox, GPF_SHARD_FUSE_MF=1:     " >> $OUT; GPF_SHARD_FUSE_MF=1 GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT ;;
+               esac
              done
              cat $OUT ;;
     variant) bash tools/variant_stats.sh $R/gpurun_out/${TAG}_$A1 $A2 ${A3//,/ } 2>&1 | tail -30 | cut -c1-200 ;;
