@@ -159,7 +159,7 @@ def main():
     K, Wm = args.steps, args.warmup
     # every leg below indexes observations by its own loop counter: never fewer rows than any leg touches
     # (the gather and cpu_baseline legs run a fixed 30 steps whatever --steps says)
-    n_obs = max(K + Wm + 3, AUX_STEPS + 2, CPU_STEPS + 2)       # (+2: the guarded first steps of the sharded engine)
+    n_obs = max(K + Wm + 6, AUX_STEPS + 2, CPU_STEPS + 2)       # (+4: the guarded first steps of the sharded engine)
     ys = g.models.simulate(model, n_obs)
     n_local = args.particles_per_gpu
     n_global = n_local * world
@@ -180,51 +180,63 @@ def main():
         # communicator or to run them, ALL ranks fall back to the phase-by-phase engine over torch.distributed.
         engine_note = None
 
+        GUARD_STEPS = (("multinomial",), ("multinomial",), ("stratified",), ("multinomial_sorted",))
+
         def make_state():
             st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=SEED, device=local_rank)
-            for tp in (1, 2):                                        # two steps before the counted warm-up
-                sharded.pf_resample(st, "multinomial")
+            for tp, (meth,) in enumerate(GUARD_STEPS, start=1):     # four steps before the counted warm-up: the headline's resampler twice, then the two
+                sharded.pf_resample(st, meth)                        # resamplers whose slabs travel through the receive windows (never yet over xGMI)
                 sharded.pf_update(st, (tp + 1,), (None,), ys[tp])
             st.synchronize()
             return st
+
+        def attempt():
+            """one engine configuration under the guard: the state after the guard steps, or why not.  A transport that delivers WRONG data without
+            failing (mailboxes and windows have never crossed xGMI) would show in the global estimate: it must be finite, within reach of the exact
+            value, and the same on every rank; the verdict is all-reduced, so all ranks move on together"""
+            ok, err, st, lml_g = 1, "", None, float("nan")
+            try:
+                st = make_state()
+                lml_g = sharded.get_lml_est(st)
+                exact_g = g.models.kalman_loglik(model, ys[:len(GUARD_STEPS) + 1])
+                if not (lml_g == lml_g and abs(lml_g - exact_g) < 1.0):
+                    ok, err = 0, f"log-ML after the guarded steps {lml_g!r} against the exact {exact_g!r}"
+            except Exception as e:                                   # noqa: BLE001 -- any failure means: the next configuration
+                ok, err = 0, repr(e)
+            if dist is not None and world > 1:
+                dev_ = "cpu" if one_device else "cuda"
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev_)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok_all = int(flag.item())
+                if ok_all:                                           # every rank computed the GLOBAL estimate: bit-identical or the configuration is out
+                    lo = torch.tensor([lml_g], dtype=torch.float64, device=dev_); hi = lo.clone()
+                    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                    if float(lo.item()) != float(hi.item()):
+                        ok_all, err = 0, f"ranks disagree on the global log-ML after the guarded steps ({float(lo.item())!r} .. {float(hi.item())!r})"
+            else:
+                ok_all = ok
+            return ok_all, (err or "another rank failed"), st
 
         if os.environ.get("GPF_BENCH_TRY_LIBRARY") == "1" and "GPF_SHARD_ENGINE" not in os.environ:
             os.environ["GPF_SHARD_ENGINE"] = "library"               # tests: start like a multi-GPU box does, whatever the process group
             tried_library = True
         else:
             tried_library = False
-        ok, err = 1, ""
-        lml2 = float("nan")
-        try:
-            state = make_state()
-            # a transport that delivers WRONG summaries without failing (the mailboxes have never crossed xGMI) would show here: the
-            # global estimate after the two steps must be finite, within reach of the exact value, and the same on every rank
-            lml2 = sharded.get_lml_est(state)
-            exact2 = g.models.kalman_loglik(model, ys[:3])
-            if not (lml2 == lml2 and abs(lml2 - exact2) < 1.0):
-                ok, err = 0, f"log-ML after two guarded steps {lml2!r} against the exact {exact2!r}"
-        except Exception as e:                                       # noqa: BLE001 -- any failure means: use the other engine
-            ok, err = 0, repr(e)
-        if dist is not None and world > 1:
-            dev_ = "cpu" if one_device else "cuda"
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev_)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok_all = int(flag.item())
-            if ok_all:                                               # every rank computed the GLOBAL estimate: bit-identical or the engine is out
-                lo = torch.tensor([lml2], dtype=torch.float64, device=dev_); hi = lo.clone()
-                dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-                if float(lo.item()) != float(hi.item()):
-                    ok_all, err = 0, f"ranks disagree on the global log-ML after two steps ({float(lo.item())!r} .. {float(hi.item())!r})"
-        else:
-            ok_all = ok
+        ok_all, err, state = attempt()
+        if not ok_all and os.environ.get("GPF_SHARD_ENGINE") != "python" and os.environ.get("GPF_SHARD_EXCHANGE") != "rccl":
+            # the library engine with the slabs through grouped ncclSend / ncclRecv instead of the receive windows
+            engine_note = f"receive windows off, slabs through RCCL ({err})"
+            print(f"[bench rank {rank}] {engine_note}", file=sys.stderr)
+            os.environ["GPF_SHARD_EXCHANGE"] = "rccl"
+            ok_all, err, state = attempt()
         if not ok_all:
             if os.environ.get("GPF_SHARD_ENGINE") == "python" and not tried_library:
                 raise SystemExit(f"sharded engine failed: {err}")
-            engine_note = f"fell back from the library engine ({err or 'another rank failed'})"
+            engine_note = f"fell back from the library engine ({err})"
             print(f"[bench rank {rank}] {engine_note}", file=sys.stderr)
             os.environ["GPF_SHARD_ENGINE"] = "python"
             state = make_state()
-        t_first = 3
+        t_first = len(GUARD_STEPS) + 1
 
         def step(t):
             sharded.pf_resample(state, "multinomial")                # the reference's defaults as in the one-GPU loop above: priority_fn = nothing, check = :warn
@@ -424,7 +436,10 @@ def main():
             state.backend.phase_timing(False)
             barrier()
             return ph
-        headline_phases = phases_of(step_of("multinomial"))
+        try:
+            headline_phases = phases_of(step_of("multinomial"))
+        except Exception as e:                                       # noqa: BLE001
+            headline_phases = {"error": repr(e)}
         if headline_traffic is not None:                             # the timed headline loop itself (i.i.d. multinomial, the plan named in exchange_plans.timed)
             calls, sent, recv, eb = headline_traffic
             peers = max(world - 1, 1)
@@ -451,10 +466,13 @@ def main():
                            "prediction": note, "rank": rank}
             return out
         # STRATIFIED resampling (BASELINE.json configs[2]: monotone targets, almost no row leaves its shard)
-        strat = variant_line("same filter, stratified resample every step, sort_particles=false (BASELINE.json configs[2])",
-                             kv, link_bytes("stratified", lambda: variant(step_of("stratified"), kv), None,
-                                            "boundary slabs: ~ cv sqrt(h n) slots per shard boundary (DESIGN.md 6.7: 2-4e3 at n = 1e6), not (G-1)/G of the rows"))
-        strat["phases_us"] = phases_of(step_of("stratified"))
+        try:
+            strat = variant_line("same filter, stratified resample every step, sort_particles=false (BASELINE.json configs[2])",
+                                 kv, link_bytes("stratified", lambda: variant(step_of("stratified"), kv), None,
+                                                "boundary slabs: ~ cv sqrt(h n) slots per shard boundary (DESIGN.md 6.9: 2-4e3 at n = 1e6), not (G-1)/G of the rows"))
+            strat["phases_us"] = phases_of(step_of("stratified"))
+        except Exception as e:                                       # noqa: BLE001 -- a variant must not take the headline line down
+            strat = {"error": repr(e)}
         # how the slabs travel (gpf.h gpf_comm_set_exchange): peer stores into the destination ranks' receive windows ("p2p": no host wait, no
         # ncclGroup) against packed entries through grouped ncclSend / ncclRecv ("rccl").  The line above ran the mode named in "timed"; both are timed here
         if lib_engine:
@@ -469,10 +487,16 @@ def main():
                     continue
                 exchange_modes[md] = {}
                 for meth in ("stratified", "multinomial_sorted"):
-                    ln = variant_line(f"{meth} resample every step, slabs through {md}", kv, variant(step_of(meth), kv))
-                    ln["phases_us"] = phases_of(step_of(meth))
+                    try:
+                        ln = variant_line(f"{meth} resample every step, slabs through {md}", kv, variant(step_of(meth), kv))
+                        ln["phases_us"] = phases_of(step_of(meth))
+                    except Exception as e:                           # noqa: BLE001
+                        ln = {"error": repr(e)}
                     exchange_modes[md][meth] = ln
-            state.backend.set_exchange(timed_mode)
+            try:
+                state.backend.set_exchange(timed_mode)
+            except Exception:                                        # noqa: BLE001
+                pass
         # the opt-in sorted form of the HEADLINE's resampler across shards: the same offspring-count law as :multinomial,
         # ascending targets -> every shard serves one slot range, the exchange is boundary slabs like the stratified one
         try:
@@ -484,8 +508,11 @@ def main():
             sorted_variant = {"error": repr(e)}
         # the communication-free "island" mode (every shard resamples locally with the reference's sub-state semantics,
         # SURVEY.md 8e): a different estimator, reported for comparison only
-        island = variant_line("same filter, every shard resamples its own particles (multinomial, sub-state semantics), no exchange",
-                              kv, variant(step_of("multinomial", local=True), kv))
+        try:
+            island = variant_line("same filter, every shard resamples its own particles (multinomial, sub-state semantics), no exchange",
+                                  kv, variant(step_of("multinomial", local=True), kv))
+        except Exception as e:                                       # noqa: BLE001
+            island = {"error": repr(e)}
         # the two exchange plans of the i.i.d. resamplers (gpf.h gpf_comm_set_plan): the headline ran the plan named in "timed"; both
         # are timed over a FIXED 100 steps whatever --steps says (the driver's scaling command runs 20), so that the first multi-GPU run can decide
         if lib_engine:
@@ -493,12 +520,18 @@ def main():
             plans = {"timed": timed_plan}
             kp = 100
             for pl in ("push", "pull"):
-                state.backend.set_plan(pl)
-                plans[pl] = variant_line(f"headline workload, exchange plan {pl}", kp,
-                                         link_bytes(f"multinomial_{pl}", lambda: variant(step_of("multinomial"), kp), round(n_local * (world - 1) / world, 1),
-                                                    "i.i.d. ancestors: (G-1)/G of a shard's rows leave it every step, n / G entries per link"))
-                plans[pl]["phases_us"] = phases_of(step_of("multinomial"))
-            state.backend.set_plan(timed_plan)
+                try:
+                    state.backend.set_plan(pl)
+                    plans[pl] = variant_line(f"headline workload, exchange plan {pl}", kp,
+                                             link_bytes(f"multinomial_{pl}", lambda: variant(step_of("multinomial"), kp), round(n_local * (world - 1) / world, 1),
+                                                        "i.i.d. ancestors: (G-1)/G of a shard's rows leave it every step, n / G entries per link"))
+                    plans[pl]["phases_us"] = phases_of(step_of("multinomial"))
+                except Exception as e:                               # noqa: BLE001
+                    plans[pl] = {"error": repr(e)}
+            try:
+                state.backend.set_plan(timed_plan)
+            except Exception:                                        # noqa: BLE001
+                pass
             # what the transports cost on this machine (gpf.h gpf_comm_calibrate): the headline's exchange shape -- n / G packed entries to and from every
             # peer, grouped ncclSend / ncclRecv -- as a measured per-link rate (the scaling worksheet of DESIGN.md 6.7 ASSUMES 76 GB/s), and one mailbox round
             try:
@@ -554,7 +587,7 @@ def main():
                        "particles_per_gpu": n_local, "particles_total": n_global, "T": K,
                        "state_dim": model.dim, "parallelism": f"particle-shard x{world}"},
             "shard_engine": (None if not sharded_mode else
-                             (f"library: gpf_shard_resample on libgpf's own RCCL communicator of {world} rank(s)"
+                             (f"library: gpf_shard_resample on libgpf's own RCCL communicator of {world} rank(s)" + (f"; {engine_note}" if engine_note else "")
                               if getattr(state.backend, "lib_comm", False) else
                               f"python: sharded.py composes the phases over torch.distributed ({dist.get_backend() if dist is not None and dist.is_initialized() else 'no'} backend, {world} rank(s))"
                               + (f"; {engine_note}" if engine_note else ""))),
