@@ -528,6 +528,18 @@ def main():
                     plans[pl]["phases_us"] = phases_of(step_of("multinomial"))
                 except Exception as e:                               # noqa: BLE001
                     plans[pl] = {"error": repr(e)}
+            # ... and the push plan with its rows through the receive windows (gpf.h GPF_SHARD_EXCHANGE_P2P_ALL): the same look-ups, no host wait for the
+            # split sizes, no ncclGroup -- scattered 8 (W + 2)-byte peer stores against RCCL's bulk copies on a bandwidth-bound exchange
+            try:
+                mode0 = state.backend.exchange()
+                state.backend.set_plan("push"); state.backend.set_exchange("p2p_all")
+                plans["push_windows"] = variant_line("headline workload, push plan, rows through the receive windows (p2p_all)", kp,
+                                                     link_bytes("multinomial_push_windows", lambda: variant(step_of("multinomial"), kp), round(n_local * (world - 1) / world, 1),
+                                                                "i.i.d. ancestors: (G-1)/G of a shard's rows leave it every step, as 8 (W + 2)-byte window entries"))
+                plans["push_windows"]["phases_us"] = phases_of(step_of("multinomial"))
+                state.backend.set_exchange(mode0)
+            except Exception as e:                                   # noqa: BLE001
+                plans["push_windows"] = {"error": repr(e)}
             try:
                 state.backend.set_plan(timed_plan)
             except Exception:                                        # noqa: BLE001

@@ -134,7 +134,17 @@ struct PushArgs {
     int extra; PrioView pv;                       // prioritised resample: packed entries carry one more double, lw[a] - lp[a] (PackOut::extra)
     int skip_own;                                 // the shard's OWN slots are resolved by k_search_own (ancestors in place, no packed entry): pass 1 skips their chunks
     int64_t* traffic;                             // the plan kernels (window exchange: the host never learns the counts): {entries sent to, received from OTHER shards} so far, or nullptr
+    RingOut ring;                                 // k_push / k_push_multi: ring.peers != nullptr -- the entries go straight into the destination ranks' receive windows (GPF_SHARD_EXCHANGE_P2P_ALL)
 };
+// (k_push / k_push_multi, window exchange: what this shard serves to and is served by the OTHER shards, for gpf_comm_traffic)
+__device__ __forceinline__ void push_traffic(const PushArgs& a)
+{
+    if (!a.traffic) return;
+    unsigned long long sent = 0, recv = 0;
+    for (int g = 0; g < a.G; ++g) if (g != a.me) { sent += (unsigned long long)a.counts[g * COUNT_STRIDE]; recv += (unsigned long long)recv_count(a.counts, a.G, g); }
+    if (sent) atomicAdd(reinterpret_cast<unsigned long long*>(a.traffic), sent);
+    if (recv) atomicAdd(reinterpret_cast<unsigned long long*>(a.traffic + 1), recv);
+}
 struct PushTables {                               // LDS copy of the per-shard tables
     int64_t w_incl[MAX_SHARDS], c_incl[MAX_SHARDS], bounds[MAX_SHARDS + 1], chunk0[MAX_SHARDS + 1];
 };
@@ -602,11 +612,12 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
                 __hip_atomic_store(a.host_counts + g, g < a.G ? a.counts[g * COUNT_STRIDE] : recv_count(a.counts, a.G, g - a.G), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             publish_behind_sys_stores(a.host_counts + 2 * MAX_SHARDS, a.ticket);
         }
+        if (blockIdx.x == 0) push_traffic(a);
     }
     __syncthreads();
     const int64_t total = s_off[a.G] < capacity ? s_off[a.G] : capacity;
     for (int64_t base = (int64_t)blockIdx.x * 2 * SBLOCK; base < total; base += (int64_t)gridDim.x * 2 * SBLOCK) {
-        int64_t e[2]; bool act[2]; uint64_t T[2], slot[2]; const uint64_t* top[2]; const CdfLevels* L[2];
+        int64_t e[2]; bool act[2]; uint64_t T[2], slot[2]; const uint64_t* top[2]; const CdfLevels* L[2]; int gdst[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             e[u] = base + u * SBLOCK + threadIdx.x;
@@ -614,6 +625,7 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
             const int64_t ee = act[u] ? e[u] : total - 1;
             int g = 0;
             while (g < a.G - 1 && ee >= s_off[g + 1]) ++g;
+            gdst[u] = g;
             const ulonglong2 q = a.stage[s_bnd[g] + (ee - s_off[g])];
             const bool incounts = (q.x >> 62) != 0;
             T[u] = q.x & STAGE_T_MASK;
@@ -627,6 +639,10 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
         for (int u = 0; u < 2; ++u) {
             if (!act[u]) continue;
             const double* src = rows + idx[u] * W;
+            if (a.ring.peers) {                                   // the window exchange: straight into the slot of the rank that holds it
+                ring_store(a.ring.peers[gdst[u]] + a.ring.off + (int64_t)slot[u] * (W + 2), src, W, (uint64_t)(gid0 + idx[u]), a.ring.seq);
+                continue;
+            }
             double* dst = packed_out + e[u] * (W + 1 + a.extra);
             if (a.extra) dst[W + 1] = a.pv.lw[idx[u]] - a.pv.at(idx[u]);
 #pragma unroll
@@ -895,11 +911,12 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels 
                 __hip_atomic_store(a.host_counts + g, g < a.G ? a.counts[g * COUNT_STRIDE] : recv_count(a.counts, a.G, g - a.G), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             publish_behind_sys_stores(a.host_counts + 2 * MAX_SHARDS, a.ticket);
         }
+        if (blockIdx.x == 0) push_traffic(a);
     }
     const MultiTable tb = multi_table_load<LOGG>(lw_, ntiles, (uint64_t)ld_gathered(a.tot_all + 5 * a.me, a.wait_tot.tags != nullptr), reinterpret_cast<uint32_t*>(smem), [] {});
     const int64_t total = s_off[a.G] < capacity ? s_off[a.G] : capacity;
     for (int64_t base = (int64_t)blockIdx.x * NE * SBLOCK; base < total; base += (int64_t)gridDim.x * NE * SBLOCK) {
-        int64_t e[NE]; bool act[NE]; uint64_t T[NE]; uint32_t slot[NE];
+        int64_t e[NE]; bool act[NE]; uint64_t T[NE]; uint32_t slot[NE]; int gdst[NE];
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
             e[u] = base + u * SBLOCK + threadIdx.x;
@@ -907,6 +924,7 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels 
             const int64_t ee = act[u] ? e[u] : total - 1;
             int g = 0;
             while (g < a.G - 1 && ee >= s_off[g + 1]) ++g;
+            gdst[u] = g;
             const ulonglong2 q = a.stage[s_bnd[g] + (ee - s_off[g])];
             T[u] = q.x & STAGE_T_MASK;
             slot[u] = (uint32_t)q.y;
@@ -917,6 +935,10 @@ __global__ __launch_bounds__(SBLOCK, 4) void k_push_multi(PushArgs a, CdfLevels 
         for (int u = 0; u < NE; ++u) {
             if (!act[u]) continue;
             const double2* src = reinterpret_cast<const double2*>(rows + (int64_t)idx[u] * W);
+            if (a.ring.peers) {                                   // the window exchange (as k_push)
+                ring_store(a.ring.peers[gdst[u]] + a.ring.off + (int64_t)slot[u] * (W + 2), rows + (int64_t)idx[u] * W, W, (uint64_t)(gid0 + idx[u]), a.ring.seq);
+                continue;
+            }
             double* dst = packed_out + e[u] * (W + 1 + a.extra);
             if (a.extra) dst[W + 1] = a.pv.lw[idx[u]] - a.pv.at(idx[u]);
 #pragma unroll
@@ -976,9 +998,12 @@ __global__ __launch_bounds__(BLOCK) void k_commit_ring(RingIn ring, int64_t n, c
         if (!(f & FLAG_NAN) && mx == -__builtin_huge_val()) f |= FLAG_ALL_NEGINF;
         sc->lml_est = sc->lml_est + (lse_from(mx, S, K, f) - logN);
     }
-    const int64_t olo = own_range[0], cnt = own_range[1] - own_range[0];
+    // own_range: the shard's own hits are one slot range (ascending targets); nullptr: they are the slots with anc >= 0 (k_search_own: i.i.d. targets),
+    // every slot with anc < 0 sits in the window
+    const int64_t olo = own_range ? own_range[0] : 0, cnt = own_range ? own_range[1] - own_range[0] : 0;
     for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < n - cnt; k += (int64_t)gridDim.x * BLOCK) {
         const int64_t j = k < olo ? k : k + cnt;
+        if (!own_range && anc[j] >= 0) continue;
         double r[W];
         const uint64_t ga = ring_load<W>(ring, j, r);
         double* dst = rows_new + j * W;

@@ -264,11 +264,13 @@ gpf_status materialize(gpf_filter* h)
         const int grid = grid_for(h, std::max<int64_t>(m, 1), 8);
         if (h->pend_ring) {                                      // a window exchange: the other slots' entries out of the receive window (+ log-ML update)
             const RingIn rin{h->ring + (int64_t)(h->pend_ring_seq & (RING_PARITIES - 1)) * h->ring_parity_words, h->pend_ring_seq, h->h_timeout};
-            const int gr = grid_for(h, std::min<int64_t>(h->n, (int64_t)1 << 16), 8);
+            // (ascending targets: few slots outside the own range -- a small grid; i.i.d. targets: (G-1)/G of all slots sit in the window)
+            const int gr = h->pend_own_range ? grid_for(h, std::min<int64_t>(h->n, (int64_t)1 << 16), 8) : grid_for(h, h->n, 8);
+            const int64_t* own_rng_ring = h->pend_own_range ? h->shard_plan->own_range : nullptr;
             switch (h->W) {
-                case 2: GPF_LAUNCH((k_commit_ring<2>), dim3(gr), dim3(BLOCK), 0, h->stream, rin, h->n, h->shard_plan->own_range, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
-                case 4: GPF_LAUNCH((k_commit_ring<4>), dim3(gr), dim3(BLOCK), 0, h->stream, rin, h->n, h->shard_plan->own_range, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
-                case 8: GPF_LAUNCH((k_commit_ring<8>), dim3(gr), dim3(BLOCK), 0, h->stream, rin, h->n, h->shard_plan->own_range, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
+                case 2: GPF_LAUNCH((k_commit_ring<2>), dim3(gr), dim3(BLOCK), 0, h->stream, rin, h->n, own_rng_ring, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
+                case 4: GPF_LAUNCH((k_commit_ring<4>), dim3(gr), dim3(BLOCK), 0, h->stream, rin, h->n, own_rng_ring, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
+                case 8: GPF_LAUNCH((k_commit_ring<8>), dim3(gr), dim3(BLOCK), 0, h->stream, rin, h->n, own_rng_ring, out, h->anc, h->lw, h->pend_mf, h->pend_tot, h->pend_G, h->K, h->logN, h->sc, (int)h->pend_mailbox); break;
             }
         } else
         switch (h->W) {

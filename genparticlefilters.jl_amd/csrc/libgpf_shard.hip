@@ -194,6 +194,7 @@ static gpf_status push_args(gpf_handle h, int32_t method, const int64_t* tot_all
     a.wait_cr = method == GPF_RESAMPLE_RESIDUAL ? mb_wait(h, MB_CR) : MboxWait{};
     a.tot_all = tot_all; a.cr_all = method == GPF_RESAMPLE_RESIDUAL ? cr_all : nullptr; a.stage = h->push_stage; a.counts = h->shard_counts; a.host_counts = h->h_shard_counts; a.ticket = h->push_ticket;
     a.traffic = h->ring_now ? h->tr_dev : nullptr;                // (window exchange: nobody on the host reads the counts; the plan kernel keeps the traffic statistics)
+    a.ring = RingOut{nullptr, 0, 0};
     return GPF_OK;
 }
 
@@ -356,6 +357,13 @@ gpf_status gpf_shard_push(gpf_handle h, int32_t method, const int64_t* tot_all, 
     if ((s = push_args(h, method, tot_all, cr_all, G, me, bounds, a))) return s;
     if (capacity == 0) return GPF_OK;
     h->counts_published = true;
+    if (h->ring_now) {
+        // the window exchange of the i.i.d. resamplers (GPF_SHARD_EXCHANGE_P2P_ALL): every looked-up row goes straight into the window slot of the rank
+        // that holds it; the traffic statistic is kept by the kernel, nobody publishes or waits for counts
+        if (!h->own_direct || !h->ring_active) return fail(h, GPF_ERR_STATE, "window exchange without own-direct resolution / without windows");
+        a.ring = RingOut{h->ring_peers, (int64_t)(h->ring_seq & (RING_PARITIES - 1)) * h->ring_parity_words, h->ring_seq};
+        a.host_counts = nullptr; h->counts_published = false;
+    }
     const bool two = method == GPF_RESAMPLE_RESIDUAL;
     if (two && !h->residual_scanned) return fail(h, GPF_ERR_STATE, "residual push needs gpf_shard_residual_scan first");
     const int64_t nt = two ? 2 : 1;
@@ -610,7 +618,7 @@ gpf_status ring_setup(gpf_filter* h)
 {
     const char* mode = getenv("GPF_SHARD_EXCHANGE");              // "rccl": no windows at all (A/B measurements, fallback drills)
     if (!h->mb_active || (mode && !strcmp(mode, "rccl"))) return GPF_OK;
-    if (mode && strcmp(mode, "p2p")) return fail(h, GPF_ERR_INVALID_ARGUMENT, "GPF_SHARD_EXCHANGE: p2p or rccl");
+    if (mode && strcmp(mode, "p2p") && strcmp(mode, "p2p_all")) return fail(h, GPF_ERR_INVALID_ARGUMENT, "GPF_SHARD_EXCHANGE: p2p, p2p_all or rccl");
     const int G = h->comm_world, me = h->comm_rank;
     // one entry per local slot of the LARGEST shard (the first n_global % G shards hold one particle more), two parities
     const int64_t n_max = (h->cfg.n_global + G - 1) / G;
@@ -650,7 +658,7 @@ gpf_status ring_setup(gpf_filter* h)
     HIP_TRY(h, hipMemcpy(h->ring_peers, peers.data(), (size_t)G * sizeof(uint64_t*), hipMemcpyHostToDevice));
     h->ring_seq = 0;
     h->ring_active = true;
-    h->exchange_mode = GPF_SHARD_EXCHANGE_P2P;
+    h->exchange_mode = (mode && !strcmp(mode, "p2p_all")) ? GPF_SHARD_EXCHANGE_P2P_ALL : GPF_SHARD_EXCHANGE_P2P;
     return GPF_OK;
 }
 gpf_status mailbox_setup(gpf_filter* h)
@@ -808,9 +816,10 @@ gpf_status gpf_comm_calibrate(gpf_handle h, int64_t entries, int32_t reps, doubl
 gpf_status gpf_comm_set_exchange(gpf_handle h, int32_t mode)
 {
     if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
-    if (mode != GPF_SHARD_EXCHANGE_RCCL && mode != GPF_SHARD_EXCHANGE_P2P) return fail(h, GPF_ERR_INVALID_ARGUMENT, "exchange mode: GPF_SHARD_EXCHANGE_RCCL or GPF_SHARD_EXCHANGE_P2P");
+    if (mode != GPF_SHARD_EXCHANGE_RCCL && mode != GPF_SHARD_EXCHANGE_P2P && mode != GPF_SHARD_EXCHANGE_P2P_ALL)
+        return fail(h, GPF_ERR_INVALID_ARGUMENT, "exchange mode: GPF_SHARD_EXCHANGE_RCCL, GPF_SHARD_EXCHANGE_P2P or GPF_SHARD_EXCHANGE_P2P_ALL");
     if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_comm_set_exchange needs gpf_comm_create first");
-    if (mode == GPF_SHARD_EXCHANGE_P2P && !h->ring_active) return fail(h, GPF_ERR_STATE, "no receive windows on this communicator (hipIpc mapping not possible, or GPF_SHARD_EXCHANGE / GPF_SHARD_SUMMARY = rccl)");
+    if (mode != GPF_SHARD_EXCHANGE_RCCL && !h->ring_active) return fail(h, GPF_ERR_STATE, "no receive windows on this communicator (hipIpc mapping not possible, or GPF_SHARD_EXCHANGE / GPF_SHARD_SUMMARY = rccl)");
     h->exchange_mode = mode;
     return GPF_OK;
 }
@@ -977,9 +986,9 @@ static gpf_status pull_requests(gpf_filter* h, int32_t method, const int64_t* to
 }
 
 // phase 5 of a window exchange: the new population = the shard's own range through the ancestor array + the window entries of the other slots
-static gpf_status shard_commit_ring(gpf_handle h, const double* mf_all, const int64_t* tot_all, int G)
+static gpf_status shard_commit_ring(gpf_handle h, const double* mf_all, const int64_t* tot_all, int G, bool own_is_a_range)
 {
-    h->pend_own = true; h->pend_m = 0; h->pend_own_range = true;
+    h->pend_own = true; h->pend_m = 0; h->pend_own_range = own_is_a_range;   // (else: the own hits are the slots with anc >= 0, k_search_own)
     h->pending_packed = true;
     h->pend_packed = nullptr; h->pend_mf = mf_all; h->pend_tot = tot_all; h->pend_G = G;
     h->pend_mailbox = h->mb_active && h->mb_engine;
@@ -1056,7 +1065,9 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     // The window exchange (gpf_k_common.hpp RingOut / RingIn; gpf_comm_set_exchange): the resamplers with ascending targets exchange boundary slabs -- the
     // merge kernel stores them straight into the destination ranks' slot-addressed receive windows, the next propagate reads them there.  No split
     // sizes for the host to wait for, no ncclGroup, no send / receive buffer, no overflow; the call returns as soon as its kernels are enqueued.
-    const bool p2p = ranged && own && h->ring_active && h->exchange_mode == GPF_SHARD_EXCHANGE_P2P;
+    // (GPF_SHARD_EXCHANGE_P2P_ALL: the i.i.d. resamplers' rows too -- every entry names its slot, so the window takes them as it takes the slabs; that
+    //  exchange is bandwidth-bound, (G-1)/G of all rows as scattered 8 (W + 2)-byte peer stores: opt-in until a multi-GPU run has timed it against RCCL)
+    const bool p2p = own && h->ring_active && ((ranged && h->exchange_mode >= GPF_SHARD_EXCHANGE_P2P) || (!ranged && !pull && h->exchange_mode == GPF_SHARD_EXCHANGE_P2P_ALL));
     h->ring_now = p2p;
     // sorted multinomial: the tile totals of ALL global slots (they depend on seed, epoch and N alone) -- the job rides in the weight scan below
     struct SpScope { gpf_filter* h; ~SpScope() { h->sp_job_set = false; } } sp_scope{h};
@@ -1118,10 +1129,11 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         h->ring_seq += 1;                                         // (the same on every rank: SPMD call order)
         if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;             // the plan: served range, own range (device only)
         phase_mark(h, GPF_PHASE_PLAN);
-        if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), h->cfg.n_global, nullptr))) return s;   // own slots in place, the others into their ranks' windows
+        // own slots in place, the others into their ranks' windows (one rank, i.i.d. targets: every slot is an own hit, nothing to look up for anybody else)
+        if ((ranged || G > 1) && (s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), h->cfg.n_global, nullptr))) return s;
         phase_mark(h, GPF_PHASE_PACK);
         h->tr_calls += 1; h->tr_entry_bytes = (int64_t)(h->W + 2) * (int64_t)sizeof(double);
-        return shard_commit_ring(h, h->cur_mf_all, tot_all, G);   // deferred: the next propagate reads window and own range in ONE launch
+        return shard_commit_ring(h, h->cur_mf_all, tot_all, G, ranged);   // deferred: the next propagate reads window and own hits in ONE launch
     }
     std::vector<int64_t> counts(2 * (size_t)G);
     int64_t pushed_cap = std::min(cap, h->sh_send_cap);

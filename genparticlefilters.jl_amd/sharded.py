@@ -196,19 +196,20 @@ class HipShardBackend:
     def set_exchange(self, mode: str) -> None:
         """how the rows of the resamplers with ascending targets (stratified, multinomial_sorted) cross shards (gpf.h gpf_comm_set_exchange): "p2p" = peer
         stores into the destination ranks' slot-addressed receive windows, no host wait and no ncclGroup; "rccl" = packed entries through grouped
-        ncclSend / ncclRecv.  The same bits either way; every rank must choose the same mode."""
+        ncclSend / ncclRecv; "p2p_all" = the i.i.d. resamplers' rows through the windows too (opt-in, bandwidth-bound).  The same bits either way; every rank
+        must choose the same mode."""
         if not self.lib_comm:
             raise ErrorException("the exchange mode is selectable in the library engine only")
-        if mode not in ("p2p", "rccl"):
-            raise ErrorException(f"exchange mode {mode!r}: p2p or rccl")
-        self._ck(self.L.gpf_comm_set_exchange(self.h, 1 if mode == "p2p" else 0))
+        if mode not in ("p2p", "rccl", "p2p_all"):
+            raise ErrorException(f"exchange mode {mode!r}: p2p, p2p_all or rccl")
+        self._ck(self.L.gpf_comm_set_exchange(self.h, {"rccl": 0, "p2p": 1, "p2p_all": 2}[mode]))
 
     def exchange(self) -> str:
         if not self.lib_comm:
             return "torch.distributed"
         m = C.c_int32(0)
         self._ck(self.L.gpf_comm_exchange(self.h, C.byref(m)))
-        return "p2p" if m.value else "rccl"
+        return {0: "rccl", 1: "p2p", 2: "p2p_all"}[m.value]
 
     PHASES = ("summaries", "plan", "pack", "host_wait_counts", "exchange", "commit_propagate")
 

@@ -454,7 +454,7 @@ gpf_status gpf_comm_plan(gpf_handle h, int32_t* plan);
  *     host to wait for, no ncclGroup, no send / receive buffers, no capacity to overflow; gpf_shard_resample returns when its kernels are enqueued.
  *   GPF_SHARD_EXCHANGE_RCCL: packed entries, one host wait for the split sizes, grouped ncclSend / ncclRecv (what the i.i.d. resamplers -- a
  *     bandwidth-bound exchange of (G-1)/G of all rows -- and tempered resamples always use).
- * The same bits either way.  Every rank of a communicator must use the same mode.  Environment at gpf_comm_create: GPF_SHARD_EXCHANGE=p2p|rccl. */
+ * The same bits either way.  Every rank of a communicator must use the same mode.  Environment at gpf_comm_create: GPF_SHARD_EXCHANGE=p2p|p2p_all|rccl. */
 /* What the transports under a sharded resample cost on THIS machine -- a scaling run prints it beside its step times (nobody can attach a profiler to it):
  *   out4[0] us per grouped ncclSend / ncclRecv exchange of `entries` packed entries ((W + 1) doubles each) with EVERY peer, mean of `reps` (2 untimed first)
  *   out4[1] the per-link rate of that exchange in GB/s: bytes one rank put on ONE link / out4[0]   (the scaling worksheet of DESIGN.md 6.7 assumes 76)
@@ -463,7 +463,11 @@ gpf_status gpf_comm_plan(gpf_handle h, int32_t* plan);
  *   out4[3] us of that launch with no rounds in it
  * Collective: every rank calls it with the same arguments, between resamples.  0 where there is nothing to measure (one rank; no mailboxes). */
 gpf_status gpf_comm_calibrate(gpf_handle h, int64_t entries, int32_t reps, double* out4);
-typedef enum { GPF_SHARD_EXCHANGE_RCCL = 0, GPF_SHARD_EXCHANGE_P2P = 1 } gpf_shard_exchange;
+typedef enum { GPF_SHARD_EXCHANGE_RCCL = 0, GPF_SHARD_EXCHANGE_P2P = 1,
+               /* opt-in: the i.i.d. resamplers' rows (:multinomial, :residual under the push plan; src/resample.jl:59,108) through the windows too -- every entry
+                * names its slot, so nothing else changes: no host wait, no ncclGroup for them either.  Their exchange is bandwidth-bound ((G-1)/G of all rows
+                * as scattered 8 (W + 2)-byte peer stores against RCCL's bulk copies): which one wins is for a multi-GPU run to say (bench.py --gpus N times both). */
+               GPF_SHARD_EXCHANGE_P2P_ALL = 2 } gpf_shard_exchange;
 gpf_status gpf_comm_set_exchange(gpf_handle h, int32_t mode);
 gpf_status gpf_comm_exchange(gpf_handle h, int32_t* mode);
 /* Where the time of a sharded step goes (what a multi-GPU run cannot attach a profiler to): with phase timing on, gpf_shard_resample and the gpf_update that

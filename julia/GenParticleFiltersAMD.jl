@@ -472,13 +472,13 @@ end
 stores into the destination ranks' slot-addressed receive windows (no host wait, no ncclGroup; the default where the mailboxes are up), :rccl = packed
 entries through grouped ncclSend / ncclRecv (gpf.h gpf_comm_set_exchange); the same on every rank"""
 function shard_exchange!(s::ShardedDeviceParticleFilterState, mode::Symbol)
-    mode in (:p2p, :rccl) || error("exchange mode :$mode: :p2p or :rccl")
-    _status(s, ccall((:gpf_comm_set_exchange, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, mode == :p2p ? 1 : 0)); s
+    mode in (:p2p, :rccl, :p2p_all) || error("exchange mode :$mode: :p2p, :p2p_all or :rccl")
+    _status(s, ccall((:gpf_comm_set_exchange, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, mode == :rccl ? 0 : (mode == :p2p ? 1 : 2))); s
 end
 function shard_exchange(s::ShardedDeviceParticleFilterState)
     m = Ref{Cint}(0)
     _status(s, ccall((:gpf_comm_exchange, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cint}), s.handle, m))
-    m[] == 1 ? :p2p : :rccl
+    m[] == 0 ? :rccl : (m[] == 1 ? :p2p : :p2p_all)
 end
 "(us per grouped exchange of `entries` packed entries with every peer, GB/s per link, us per mailbox round, us of an empty launch) on this machine (gpf.h gpf_comm_calibrate; collective)"
 function shard_calibrate(s::ShardedDeviceParticleFilterState, entries::Integer; reps::Integer=20)

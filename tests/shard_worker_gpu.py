@@ -53,6 +53,9 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
         dist.destroy_process_group()
 
 
+EXCHANGE_SWITCH_METHODS = ("stratified", "multinomial_sorted", "multinomial", "residual")
+
+
 def run_exchange_switch(rank, world, port, model_name, n_global, T, out_dir):
     """gpf_comm_set_exchange between the resamples of one sharded filter (library engine): the receive windows and the grouped send / receive
     alternate, stratified and sorted multinomial alternate, a getter or a rejuvenation now and then forces the materialised commit"""
@@ -67,8 +70,8 @@ def run_exchange_switch(rank, world, port, model_name, n_global, T, out_dir):
         assert st.backend.lib_comm and st.backend.exchange() == "p2p"
         lml = []
         for t in range(1, T):
-            st.backend.set_exchange(("p2p", "p2p", "rccl")[t % 3])
-            sharded.pf_resample(st, ("stratified", "multinomial_sorted")[t % 2], check=False)
+            st.backend.set_exchange(("p2p", "p2p_all", "rccl")[t % 3])
+            sharded.pf_resample(st, EXCHANGE_SWITCH_METHODS[t % 4], check=False)
             if t % 4 == 0:
                 lml.append(sharded.get_lml_est(st))                   # (materialises the deferred commit out of the window / the receive buffer)
             if t % 5 == 0:

@@ -293,19 +293,19 @@ _SKEW_KEPT = (("multinomial", "all_on_first_shard"), ("stratified", "all_on_firs
 
 @pytest.mark.parametrize("method,pattern", soak_grid(["multinomial", "stratified", "residual", "multinomial_sorted"], ["all_on_first_shard", "single_particle", "middle_band"],
                                                     keep=lambda m, p: (m, p) in _SKEW_KEPT))
-def test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern):
+def test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern, n_global=300_000):
     """zero-length sends, one shard serving everything (send-buffer overflow and the repeated push) through the library engine"""
     monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
     monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
-    test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern)
+    test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern, n_global)
 
 
 @pytest.mark.parametrize("method,pattern", soak_grid(["multinomial", "stratified", "residual", "multinomial_sorted"], ["all_on_first_shard", "single_particle", "middle_band"],
                                                     keep=lambda m, p: (m, p) in _SKEW_KEPT[:4]))
-def test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern):
+def test_hip_shards_skewed_weights(g, o, tmp_path, method, pattern, n_global=300_000):
     """one shard owns every target (its push exceeds the balanced-size send buffer: the overflow path runs for real),
     the others own none (zero-length sends)"""
-    world, n_global = 3, 300_000          # 2 n_local + 64 Ki < n_global: the shard that owns everything overflows its send buffer
+    world = 3                             # 2 n_local + 64 Ki < n_global: the shard that owns everything overflows its send buffer
     mp.spawn(shard_worker_gpu.run_skew, args=(world, free_port(), method, n_global, pattern, str(tmp_path)), nprocs=world, join=True)
     f = single_skew(g, o, method, n_global, pattern)
     parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
@@ -520,13 +520,13 @@ def test_window_exchange_in_the_one_call_loop(g, o, tmp_path, monkeypatch, loopb
 
 @pytest.mark.parametrize("method,n_global,world", [pytest.param(m_, n_, w_, marks=() if (n_ in (10, 4099) or (n_ == 3 and m_ == "stratified")) else (pytest.mark.gpu_soak,))
                                                    for m_ in ("stratified", "multinomial_sorted") for n_, w_ in ((10, 3), (3, 3), (257, 2), (4099, 3))])
-def test_window_exchange_tiny_shards(g, o, tmp_path, monkeypatch, loopback_lib, method, n_global, world):
+def test_window_exchange_tiny_shards(g, o, tmp_path, monkeypatch, loopback_lib, method, n_global, world, expect="p2p"):
     """shards of 1 to a few particles: own ranges that are empty, a shard served entirely by its neighbours"""
     monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib)
     mp.spawn(shard_worker_gpu.run, args=(world, free_port(), "lgssm2", method, n_global, 5, None, None, str(tmp_path), "gloo", "library"), nprocs=world, join=True)
     f, ess_log, lml_log = single(g, o, "lgssm2", method, n_global, 5, None, None)
     parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
-    assert all(str(p["exchange"]) == "p2p" for p in parts)
+    assert all(str(p["exchange"]) == expect for p in parts)
     assert np.array_equal(np.concatenate([p["parents"] for p in parts]), f.parents)
     assert np.array_equal(np.concatenate([p["rows"] for p in parts]), f.rows)
     assert np.array_equal(np.concatenate([p["lw"] for p in parts]), f.lw)
@@ -548,13 +548,14 @@ def test_exchange_mode_switch_between_resamples(g, o, tmp_path, monkeypatch, loo
     """gpf_comm_set_exchange between the resamples of one filter: windows and grouped send / receive alternate (the window's sequence numbers skip
     the grouped rounds), deferred and materialised commits alternate; against one oracle filter"""
     monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
-    n_global, T = 50_003, 13
+    n_global, T = 50_003, 14
     mp.spawn(shard_worker_gpu.run_exchange_switch, args=(world, free_port(), "bearings4", n_global, T, str(tmp_path)), nprocs=world, join=True)
     model = g.models.bearings4(); ys = g.models.simulate(model, T + 1)
     f = o.OracleFilter(model.model_id, model.params, n_global, 77, keep_prev=True).initialize(ys[0])
     lml = []
     for t in range(1, T):
-        f.resample(("stratified", "multinomial_sorted")[t % 2], check=False, **({"sort_particles": False} if t % 2 == 0 else {}))
+        meth = shard_worker_gpu.EXCHANGE_SWITCH_METHODS[t % 4]
+        f.resample(meth, check=False, **({"sort_particles": False} if meth == "stratified" else {}))
         if t % 4 == 0:
             lml.append(f.log_ml_estimate())
         if t % 5 == 0:
@@ -595,3 +596,38 @@ def test_resample_behind_an_ess_read_with_and_without_summary_reuse(g, o, tmp_pa
     for reuse in ("1", "0"):
         monkeypatch.setenv("GPF_SHARD_REUSE_SUMMARY", reuse)
         test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=3, one_call=one_call)
+
+
+IID_WINDOW_CASES = [CASES[0], CASES[2], CASES[3], CASES[4], CASES[6], CASES[1]]      # (the last one: ascending targets keep using the windows under p2p_all)
+
+
+@pytest.mark.parametrize("case,world,one_call", soak_grid(IID_WINDOW_CASES, [2, 3], [False, True],
+                                                        keep=lambda c, w, oc: (not oc and (w == 2 or c in (CASES[0], CASES[3]))) or (oc and w == 3 and c == CASES[3])), ids=_cid)
+def test_iid_rows_through_the_windows(g, o, tmp_path, monkeypatch, loopback_lib, case, world, one_call):
+    """GPF_SHARD_EXCHANGE=p2p_all (gpf.h GPF_SHARD_EXCHANGE_P2P_ALL): the i.i.d. resamplers' rows -- :multinomial, :residual's tail and head -- also go
+    straight from the look-up kernels (k_push_multi / k_push) into the window slot of the rank that holds the slot, the commit reads the window wherever the
+    own-slot search left -1 (k_step<GATHER> masked, k_move_step, k_commit_ring): no host wait, no ncclGroup for them either.  Bit-identical to the oracle."""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    monkeypatch.setenv("GPF_SHARD_EXCHANGE", "p2p_all")
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world, one_call=one_call)
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert all(str(p["exchange"]) == "p2p_all" for p in parts)
+    sent, recv = sum(int(p["traffic"][1]) for p in parts), sum(int(p["traffic"][2]) for p in parts)
+    assert sent == recv and sent > 0 and int(parts[0]["traffic"][0]) > 0
+
+
+@pytest.mark.parametrize("method,pattern", soak_grid(["multinomial", "residual"], ["all_on_first_shard", "single_particle", "middle_band"],
+                                                    keep=lambda m, p: (m, p) in (("multinomial", "all_on_first_shard"), ("residual", "middle_band"))))
+def test_iid_rows_through_the_windows_skewed(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern):
+    """one shard serving every slot of the others (a whole shard's worth of window entries from one peer), others serving nothing.
+    Sized for ranks that SHARE a GPU (this test): every slot of the served ranks waits in their propagate for a 1024-thread look-up kernel of the serving
+    rank, and on one device the waiting workgroups hold the registers that kernel needs -- at 10^5 slots per rank it never gets a CU (a window wait that
+    times out after seconds, found here); ranks with a GPU each -- the only configuration RCCL accepts -- wait on their own device for a peer's."""
+    monkeypatch.setenv("GPF_SHARD_EXCHANGE", "p2p_all")
+    test_library_engine_skewed_weights_over_loopback(g, o, tmp_path, monkeypatch, loopback_lib, method, pattern, n_global=45_000)
+
+
+@pytest.mark.parametrize("method", ["multinomial", "residual"])
+def test_iid_rows_through_the_windows_tiny_shards(g, o, tmp_path, monkeypatch, loopback_lib, method):
+    monkeypatch.setenv("GPF_SHARD_EXCHANGE", "p2p_all")
+    test_window_exchange_tiny_shards(g, o, tmp_path, monkeypatch, loopback_lib, method, 10, 3, expect="p2p_all")

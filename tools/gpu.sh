@@ -17,6 +17,9 @@
 #   gaps:NAME:ARGS        kernel trace of the same loop; a window of it with the idle gap in front of every kernel (tools/trace_gaps.py) -> TAG_NAME_ARGS_gaps.txt
 #   sq:NAME:ARGS          SQ wait / VALU / LDS counters of the same loop (tools/gpu_pmc_kernels.sh) -> TAG_sq_NAME_ARGS
 #   sharded               one-rank sharded table (tools/sharded_loop.py; no communicator / 1-rank RCCL) -> TAG_sharded_one_rank.txt
+#   essloop               the ESS-triggered loop of BASELINE configs[3] through the sharded path on one rank (tools/sharded_ess_loop.py): separate calls / one call,
+#                         no communicator / 1-rank RCCL + mailboxes, ESS < N/2 / always / never; and without the summary reuse / the lazy move -> TAG_sharded_ess_loop.txt
+#   tworanks              bench.py --gpus 2 --steps 20 with both ranks on this GPU over tests/loopback_rccl: the SHAPE of a multi-GPU line -> TAG_bench_2ranks_one_gpu_loopback.json
 #   variant:OUT:METHOD:DEFS   tools/variant_stats.sh OUT METHOD DEFS (DEFS: comma-separated -D sets, alternating A/B rocprofv3 runs)
 #   py:SCRIPT:ARGS        python3 tools/SCRIPT.py ARGS -> TAG_SCRIPT.txt
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -33,7 +36,7 @@ for STEP in "$@"; do
   cd $R
   case $S in
     smoke)   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
-    tests)   timeout 3000 python -m pytest tests -m gpu -q ${A1:+-k "$A1"} > gpurun_out/${TAG}_pytest.log 2>&1; tail -15 gpurun_out/${TAG}_pytest.log | cut -c1-220 ;;
+    tests)   ( time timeout 3000 python -m pytest tests -m gpu -q --durations=25 ${A1:+-k "$A1"} ) > gpurun_out/${TAG}_pytest.log 2>&1; tail -15 gpurun_out/${TAG}_pytest.log | cut -c1-220 ;;
     soak)    timeout 3000 python -m pytest tests -m "gpu or gpu_soak" -q > gpurun_out/${TAG}_pytest_soak.log 2>&1; tail -8 gpurun_out/${TAG}_pytest_soak.log | cut -c1-220 ;;
     file)    timeout 3000 python -m pytest "$A1" -m gpu -x -q ${A2:+-k "$A2"} > gpurun_out/${TAG}_pytest_$(basename $A1 .py).log 2>&1; tail -25 gpurun_out/${TAG}_pytest_$(basename $A1 .py).log | cut -c1-220 ;;
     bench)   python bench.py --steps ${A1:-1000} --warmup 20 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-3000 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err ;;
@@ -75,6 +78,21 @@ for STEP in "$@"; do
                esac
              done
              cat $OUT ;;
+    essloop) OUT=gpurun_out/${TAG}_sharded_ess_loop.txt; : > $OUT
+             for F in 0.5 1.1 0; do
+               for MODE in calls one_call; do
+                 echo -n "ESS < $F N, $MODE, no communicator:        " >> $OUT; python3 tools/sharded_ess_loop.py 300 1000000 $MODE $F 2>/dev/null | grep "us/step" >> $OUT
+                 echo -n "ESS < $F N, $MODE, 1-rank RCCL + mailbox:  " >> $OUT; GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_ess_loop.py 300 1000000 $MODE $F 2>/dev/null | grep "us/step" >> $OUT
+               done
+             done
+             for F in 0.5 1.1; do
+               echo -n "ESS < $F N, one_call, 1-rank RCCL + mailbox, GPF_SHARD_REUSE_SUMMARY=0:  " >> $OUT; GPF_SHARD_REUSE_SUMMARY=0 GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_ess_loop.py 300 1000000 one_call $F 2>/dev/null | grep "us/step" >> $OUT
+               echo -n "ESS < $F N, one_call, 1-rank RCCL + mailbox, GPF_LAZY_MOVE=0:            " >> $OUT; GPF_LAZY_MOVE=0 GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_ess_loop.py 300 1000000 one_call $F 2>/dev/null | grep "us/step" >> $OUT
+             done
+             cat $OUT ;;
+    tworanks) hipcc -O2 -std=c++17 -fPIC -shared tests/loopback_rccl/loopback_rccl.cpp -o /tmp/libloopback_rccl.so
+             GPF_BENCH_ONE_DEVICE=1 GPF_SHARD_ENGINE=library GPF_RCCL_LIBRARY=/tmp/libloopback_rccl.so python bench.py --gpus 2 --steps 20 --warmup 5 --particles-per-gpu 500000 \
+               > gpurun_out/${TAG}_bench_2ranks_one_gpu_loopback.json 2> gpurun_out/${TAG}_bench_2ranks.err; cut -c1-700 gpurun_out/${TAG}_bench_2ranks_one_gpu_loopback.json; tail -2 gpurun_out/${TAG}_bench_2ranks.err ;;
     variant) bash tools/variant_stats.sh $R/gpurun_out/${TAG}_$A1 $A2 ${A3//,/ } 2>&1 | tail -30 | cut -c1-200 ;;
     py)      python3 tools/$A1.py ${A2//,/ } > gpurun_out/${TAG}_$A1.txt 2> gpurun_out/${TAG}_$A1.err; cut -c1-220 gpurun_out/${TAG}_$A1.txt | tail -40; tail -3 gpurun_out/${TAG}_$A1.err ;;
     *)       echo "unknown step $S" ;;
