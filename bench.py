@@ -352,22 +352,59 @@ def main():
                             "frac": round(gbytes / us / 1e3 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": gbytes}
 
     # ---- sharded runs: variants of the same filter reported beside the headline workload, same timing protocol
+    class Lockstep:
+        """The secondary legs below run the same collective sequence on every rank.  A leg that fails on ONE rank (a transport that has never met real
+        hardware) must not leave the others waiting in a barrier it never reaches: steps run through `step`, which remembers the first failure and turns the
+        rest of the leg into no-ops; the barriers are still met; `agree` (an all-reduce) makes every rank raise together, so the leg is reported as failed
+        on the line and the next one starts in step."""
+        def __init__(self):
+            self.err = None
+
+        def step(self, fn, *a):
+            if self.err is None:
+                try:
+                    return fn(*a)
+                except Exception as e:                               # noqa: BLE001
+                    self.err = e
+            return None
+
+        def barrier(self):
+            try:
+                state.synchronize()
+            except Exception as e:                                   # noqa: BLE001 -- (a flagged device wait surfaces here)
+                self.err = self.err or e
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        def agree(self):
+            ok = 1 if self.err is None else 0
+            if dist is not None:
+                fl = torch.tensor([ok], dtype=torch.int32, device="cpu" if one_device else "cuda")
+                dist.all_reduce(fl, op=dist.ReduceOp.MIN)
+                ok = int(fl.item())
+            if not ok:
+                raise RuntimeError(repr(self.err) if self.err is not None else "failed on another rank")
+
     def variant(step_fn, k):
         """k steps of step_fn after 5 untimed ones, barriers on both sides, MAX over ranks -> seconds"""
+        ls = Lockstep()
         for i in range(5):
-            step_fn(i)
+            ls.step(step_fn, i)
         gc.collect(); gc.disable()
-        barrier()
+        ls.barrier()
         v0 = time.perf_counter()
         for i in range(k):
-            step_fn(i)
-        barrier()
+            ls.step(step_fn, i)
+        ls.barrier()
         ve = time.perf_counter() - v0
         gc.enable()
         if dist is not None:
             tv = torch.tensor([ve], dtype=torch.float64, device="cpu" if one_device else "cuda")
             dist.all_reduce(tv, op=dist.ReduceOp.MAX)
             ve = float(tv.item())
+        ls.agree()
         return ve
 
     def variant_line(workload, k, seconds):
@@ -426,15 +463,17 @@ def main():
             A pass of its own behind the timed loop: the marks cost an event each."""
             if not lib_engine:
                 return None
+            ls = Lockstep()
             for i in range(3):
-                step_fn(i)
-            barrier()
-            state.backend.phase_timing(True)
+                ls.step(step_fn, i)
+            ls.barrier()
+            ls.step(state.backend.phase_timing, True)
             for i in range(k):
-                step_fn(i)
-            ph = state.backend.phase_times()
-            state.backend.phase_timing(False)
-            barrier()
+                ls.step(step_fn, i)
+            ph = ls.step(state.backend.phase_times)
+            ls.step(state.backend.phase_timing, False)
+            ls.barrier()
+            ls.agree()
             return ph
         try:
             headline_phases = phases_of(step_of("multinomial"))
@@ -531,6 +570,11 @@ def main():
             # ... and the push plan with its rows through the receive windows (gpf.h GPF_SHARD_EXCHANGE_P2P_ALL): the same look-ups, no host wait for the
             # split sizes, no ncclGroup -- scattered 8 (W + 2)-byte peer stores against RCCL's bulk copies on a bandwidth-bound exchange
             try:
+                if one_device:
+                    # ranks SHARING a GPU (functional checks of this command line on a 1-GPU box): a propagate whose lanes wait on the window holds the
+                    # registers the peer's 1024-thread look-up kernel needs on the same device -- with half of all slots waiting the peers starve each
+                    # other for seconds per step.  Ranks with a GPU each wait on their own device for a kernel on a peer's.
+                    raise RuntimeError("skipped: the ranks of this run share one GPU")
                 mode0 = state.backend.exchange()
                 state.backend.set_plan("push"); state.backend.set_exchange("p2p_all")
                 plans["push_windows"] = variant_line("headline workload, push plan, rows through the receive windows (p2p_all)", kp,
@@ -547,8 +591,11 @@ def main():
             # what the transports cost on this machine (gpf.h gpf_comm_calibrate): the headline's exchange shape -- n / G packed entries to and from every
             # peer, grouped ncclSend / ncclRecv -- as a measured per-link rate (the scaling worksheet of DESIGN.md 6.7 ASSUMES 76 GB/s), and one mailbox round
             try:
-                calibration = state.backend.calibrate(max(n_local // world, 1), 20)
-                calibration["slab_exchange"] = state.backend.calibrate(4096, 20)       # ... and a boundary slab's size: the group's latency floor
+                ls = Lockstep()
+                calibration = ls.step(state.backend.calibrate, max(n_local // world, 1), 20)
+                slab = ls.step(state.backend.calibrate, 4096, 20)     # ... and a boundary slab's size: the group's latency floor
+                ls.agree()
+                calibration["slab_exchange"] = slab
             except Exception as e:                                   # noqa: BLE001
                 calibration = {"error": repr(e)}
 

@@ -133,8 +133,8 @@ def test_two_ranks_line_explains_itself(built, tmp_path):
         assert out["shard_engine"].startswith("library") and "fell back" not in out["shard_engine"]
         ep = out["exchange_plans"]
         assert ep["timed"] == plan and ep["push"]["value"] > 0 and ep["pull"]["value"] > 0 and ep["push"]["steps"] == 100
-        pw = ep["push_windows"]                                               # the third way: the push plan's rows through the receive windows, no host wait
-        assert pw["value"] > 0 and pw["steps"] == 100 and pw["phases_us"]["host_wait_counts"] == 0 and pw["phases_us"]["exchange"] == 0
+        # the third way -- the push plan's rows through the receive windows (GPF_SHARD_EXCHANGE_P2P_ALL) -- is for ranks with a GPU each: this run says why not
+        assert "share one GPU" in ep["push_windows"]["error"]
         ests[plan] = out["log_ml_estimate"]
         # what the exchanges really sent (gpf_comm_traffic) beside the worksheet: the i.i.d. multinomial moves (G-1)/G of a shard's rows, the
         # sorted multinomial and the stratified resampler boundary slabs
