@@ -154,6 +154,7 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     uint64_t** mb_peers = nullptr;       // device array [world]: every rank's mailbox as mapped in this process
     std::vector<void*> mb_opened;        // peers' mailboxes opened with hipIpcOpenMemHandle (closed by gpf_comm_destroy)
     bool mb_active = false;
+    bool mb_fuse_default = false;        // every rank of the communicator has a device of its own: the (max, flags) round rides in its consumer's launch (mailbox_fuse_mf)
     // the GLOBAL weight summary of the latest one-launch reduction (k_sum_shard: the sharded ESS getter / gpf_shard_step_ess), as the host read it, and what
     // it describes: a gpf_shard_resample that finds it still valid (same weights, no newer mailbox round) does not repeat the (max, flags) round, and a
     // residual one runs no weight scan at all (shard_resample_impl)

@@ -476,6 +476,16 @@ gpf_status shard_all_gather(gpf_filter* h, const void* src, void* dst, size_t co
 }
 // The local summaries and (for the RCCL all-gathers) the gathered arrays are rings of SH_RING rounds: a prioritised resample runs
 // three summary rounds (raw weights, priorities, log_ws) and its commit still reads the first.
+// Does the (max, flags) mailbox round ride in its consumer's launch (workgroup 0 of the weight scan / of k_sum_shard pushes, every workgroup waits) instead
+// of k_pack_mflags' own launch?  1 - 2 us per step faster, but every workgroup of a GPU-filling launch then waits for pushes that only the peers' launches of
+// the same kind make: ranks that SHARE a GPU starve each other.  So: yes exactly when every rank of the communicator sits on a device of its own (decided at
+// mailbox_setup from the all-gathered PCI bus ids: the same answer on every rank); GPF_SHARD_FUSE_MF=0 / 1 overrides either way.
+bool mailbox_fuse_mf(const gpf_filter* h)
+{
+    static const char* e = getenv("GPF_SHARD_FUSE_MF");
+    if (e && (!strcmp(e, "0") || !strcmp(e, "1"))) return e[0] == '1';
+    return h->mb_fuse_default;
+}
 constexpr int SH_RING = 4;
 gpf_status shard_scratch(gpf_filter* h)
 {
@@ -529,7 +539,7 @@ gpf_status shard_summary(gpf_filter* h, int want_q, bool reuse_mf = false)
     // multinomial / stratified / sorted).  Still opt-in: every workgroup of the launch waits for pushes that only the peers' launches of the same
     // kind make, so ranks that SHARE a GPU can starve each other (shard_global_summary_launch); for ranks with a GPU each.  As an RCCL all-gather
     // the summary needs its own launch ahead of the collective.
-    static const bool fuse_mb = getenv("GPF_SHARD_FUSE_MF") && !strcmp(getenv("GPF_SHARD_FUSE_MF"), "1");
+    const bool fuse_mb = mailbox_fuse_mf(h);
     const bool fuse = alias || (mb && fuse_mb);
     if (fuse) { if ((s = shard_ready(h)) || (s = shard_max_slots(h))) return s; }
     else if ((s = gpf_shard_weight_max(h, mf))) return s;
@@ -597,7 +607,7 @@ void mailbox_teardown(gpf_filter* h)
     if (h->mbox) (void)hipFree(h->mbox);
     h->mb_peers = nullptr; h->mbox = nullptr; h->mb_active = false;
 }
-struct MboxPacket { hipIpcMemHandle_t handle; int64_t ok; int64_t pid; };
+struct MboxPacket { hipIpcMemHandle_t handle; int64_t ok; int64_t pid; char bus[32]; };
 // all-gather of `each` bytes per rank, host to host, over the handle's communicator (setup only)
 gpf_status host_all_gather(gpf_filter* h, const void* src, void* dst_host, size_t each)
 {
@@ -678,6 +688,7 @@ gpf_status mailbox_setup(gpf_filter* h)
     std::vector<MboxPacket> all((size_t)G);
     MboxPacket mine{};
     mine.pid = (int64_t)getpid();
+    if (hipDeviceGetPCIBusId(mine.bus, (int)sizeof(mine.bus), h->cfg.device) != hipSuccess) { (void)hipGetLastError(); mine.bus[0] = 0; }
     if (G > 1 && ok) {
         if (hipIpcGetMemHandle(&mine.handle, h->mbox) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
     }
@@ -707,6 +718,15 @@ gpf_status mailbox_setup(gpf_filter* h)
     HIP_TRY(h, hipMemcpy(h->mb_peers, peers.data(), (size_t)G * sizeof(uint64_t*), hipMemcpyHostToDevice));
     for (int k = 0; k < MB_KINDS; ++k) h->mb_seq[k] = h->mb_cur[k] = 0;
     h->mb_active = true;
+    // a device of its own for every rank?  (an unknown bus id counts as shared; ranks of other nodes cannot be told apart by bus id alone and may
+    // read as "shared": the separate launch is always safe)
+    bool own_device = true;
+    for (int r = 0; r < G && own_device; ++r) {
+        all[r].bus[sizeof(all[r].bus) - 1] = 0;
+        if (!all[r].bus[0]) own_device = false;
+        for (int q = 0; q < r && own_device; ++q) if (!strcmp(all[r].bus, all[q].bus)) own_device = false;
+    }
+    h->mb_fuse_default = own_device;
     return GPF_OK;
 }
 } // namespace
@@ -1382,7 +1402,7 @@ gpf_status shard_global_summary_launch(gpf_filter* h, double thr, bool* done)
     // the GPU waits for a push that only the peers' launches of the same kind make: ranks that share one GPU (the loopback tests: 2 - 3 processes on
     // one device, 256 workgroups of 1024 threads each) starve each other until the mailbox wait gives up.  Behind a separate launch the push needs
     // 256 free thread slots somewhere, which a waiting reduction always leaves.
-    static const bool fuse_mb = getenv("GPF_SHARD_FUSE_MF") && !strcmp(getenv("GPF_SHARD_FUSE_MF"), "1");
+    const bool fuse_mb = mailbox_fuse_mf(h);
     if (shard_sum_collect() || !fuse_mb) { if ((s = gpf_shard_weight_max(h, mf))) return s; }
     else {
         if ((s = shard_max_slots(h))) return s;
