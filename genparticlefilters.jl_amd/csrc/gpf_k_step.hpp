@@ -157,8 +157,8 @@ struct PackedCommit {
     // the log-ML update from the gathered summaries
     int masked; int64_t anc_off;
     const int64_t* own_range;  // masked == 2 (stratified): the own hits are the slots [own_range[0], own_range[1]) instead of the slots with anc >= 0
-    // masked == 2 && ring.base: the slots OUTSIDE the own range are not skipped -- their entries [row | global ancestor id | seal] were stored into this
-    // rank's slot-addressed receive window by the peers that serve them (gpf_k_common.hpp): ONE launch commits the whole exchange
+    // masked && ring.base: the slots that are not own hits (outside the own range / anc < 0) are not skipped -- their entries [row | global ancestor id |
+    // seal] were stored into this rank's slot-addressed receive window by the peers that serve them (gpf_k_common.hpp): ONE launch commits the whole exchange
     RingIn ring;
     // a propagate enqueued SPECULATIVELY behind the ESS reduction (gpf_step_ess, k_sum_host<GATE>): it forms the verdict from the reduction's
     // accumulators itself (gate_verdict) and, if the ESS is below the threshold -- the filter resamples first --, returns before its first store

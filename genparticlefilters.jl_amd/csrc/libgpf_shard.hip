@@ -614,12 +614,12 @@ gpf_status host_all_gather(gpf_filter* h, const void* src, void* dst_host, size_
     const int G = h->comm_world;
     if (G == 1) { memcpy(dst_host, src, each); return GPF_OK; }
     char *dsrc = nullptr, *ddst = nullptr;
+    struct Bufs { char*& a; char*& b; ~Bufs() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } bufs{dsrc, ddst};
     HIP_TRY(h, hipMalloc(&dsrc, each)); HIP_TRY(h, hipMalloc(&ddst, each * G));
     HIP_TRY(h, hipMemcpyAsync(dsrc, src, each, hipMemcpyHostToDevice, h->stream));
     NCCL_TRY(h, g_rccl.AllGather(dsrc, ddst, each, ncclInt8, h->comm, h->stream));
     HIP_TRY(h, hipMemcpyAsync(dst_host, ddst, each * G, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(dsrc); (void)hipFree(ddst);
     return GPF_OK;
 }
 // ---- slot-addressed receive windows (gpf_k_common.hpp): allocated, exported and mapped exactly like the mailboxes, behind them (a rank without
@@ -640,10 +640,9 @@ gpf_status ring_setup(gpf_filter* h)
         if (hipMalloc(&h->ring, bytes) != hipSuccess) { (void)hipGetLastError(); h->ring = nullptr; ok = 0; }
     }
     if (ok && hipMalloc(&h->tr_dev, 2 * sizeof(int64_t)) != hipSuccess) { (void)hipGetLastError(); h->tr_dev = nullptr; ok = 0; }
-    if (ok) {
-        HIP_TRY(h, hipMemsetAsync(h->ring, 0, bytes, h->stream)); HIP_TRY(h, hipMemsetAsync(h->tr_dev, 0, 2 * sizeof(int64_t), h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-    }
+    // (a failure of THIS rank alone must not keep it out of the all-gather its peers are about to enter: it only votes "no")
+    if (ok && (hipMemsetAsync(h->ring, 0, bytes, h->stream) != hipSuccess || hipMemsetAsync(h->tr_dev, 0, 2 * sizeof(int64_t), h->stream) != hipSuccess ||
+               hipStreamSynchronize(h->stream) != hipSuccess)) { (void)hipGetLastError(); ok = 0; }
     std::vector<MboxPacket> all((size_t)G);
     MboxPacket mine{};
     mine.pid = (int64_t)getpid();
