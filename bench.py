@@ -56,10 +56,20 @@ def algorithmic_bytes(d: int, W: int):
 
 
 def _free_port() -> int:
+    """a rendezvous port for the self-launched job: a random bindable port BELOW the kernel's ephemeral range (a bind(0) port can be handed to an outgoing
+    connection before rank 0 listens on it)"""
+    import random
     import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    rng = random.SystemRandom()
+    for _ in range(200):
+        p = rng.randrange(20000, 32000)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            try:
+                s.bind(("127.0.0.1", p))
+            except OSError:
+                continue
+            return p
+    raise RuntimeError("no free rendezvous port between 20000 and 32000")
 
 
 def launch_ranks(n: int, argv, timeout_s: float) -> int:

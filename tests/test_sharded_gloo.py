@@ -15,8 +15,20 @@ import shard_worker  # noqa: E402
 
 
 def free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
-    return p
+    """a rendezvous port for one spawned job.  NOT bind(0): that hands out a port of the kernel's ephemeral range (32768-60999), which the kernel may give to
+    somebody's outgoing connection -- gloo's own pairs, the next job's store clients -- between this probe and rank 0's listen (seen once in ~2 500 jobs:
+    EADDRINUSE).  A random port BELOW that range, checked to be bindable, is only ever taken by another explicit listener."""
+    import random
+    rng = random.SystemRandom()
+    for _ in range(200):
+        p = rng.randrange(20000, 32000)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            try:
+                s.bind(("127.0.0.1", p))
+            except OSError:
+                continue
+            return p
+    raise RuntimeError("no free rendezvous port between 20000 and 32000")
 
 
 def single(g, o, model_name, method, n_global, T, ess_frac, rejuv):
