@@ -234,10 +234,11 @@ def main():
             tried_library = False
         ok_all, err, state = attempt()
         if not ok_all and os.environ.get("GPF_SHARD_ENGINE") != "python" and os.environ.get("GPF_SHARD_EXCHANGE") != "rccl":
-            # the library engine with the slabs through grouped ncclSend / ncclRecv instead of the receive windows
-            engine_note = f"receive windows off, slabs through RCCL ({err})"
+            # the library engine as round 5 left it: slabs through grouped ncclSend / ncclRecv instead of the receive windows, the (max, flags) mailbox
+            # round in its own small launch instead of inside its consumer's (the default for ranks with a device each since round 6)
+            engine_note = f"receive windows and the fused (max, flags) round off ({err})"
             print(f"[bench rank {rank}] {engine_note}", file=sys.stderr)
-            os.environ["GPF_SHARD_EXCHANGE"] = "rccl"
+            os.environ["GPF_SHARD_EXCHANGE"] = "rccl"; os.environ["GPF_SHARD_FUSE_MF"] = "0"
             ok_all, err, state = attempt()
         if not ok_all:
             if os.environ.get("GPF_SHARD_ENGINE") == "python" and not tried_library:

@@ -482,7 +482,7 @@ gpf_status shard_all_gather(gpf_filter* h, const void* src, void* dst, size_t co
 // mailbox_setup from the all-gathered PCI bus ids: the same answer on every rank); GPF_SHARD_FUSE_MF=0 / 1 overrides either way.
 bool mailbox_fuse_mf(const gpf_filter* h)
 {
-    static const char* e = getenv("GPF_SHARD_FUSE_MF");
+    const char* e = getenv("GPF_SHARD_FUSE_MF");                  // (read at every call: a host may switch it between two communicators -- bench.py's guarded fall-back does)
     if (e && (!strcmp(e, "0") || !strcmp(e, "1"))) return e[0] == '1';
     return h->mb_fuse_default;
 }
