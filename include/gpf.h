@@ -428,7 +428,7 @@ gpf_status gpf_comm_destroy(gpf_handle h);
  *  -- travel: *mailbox = 1: the producing kernel stores them straight into every peer's mailbox (device
  * memory mapped with hipIpc at gpf_comm_create, xGMI peer writes) and the consuming kernel waits for them -- no collective, no
  * launch, no host; 0: RCCL all-gathers (hipIpc mapping not possible on this system, or GPF_SHARD_SUMMARY=rccl in the environment).
- * Every rank of a communicator is in the same mode.  The row exchange itself is always grouped ncclSend / ncclRecv. */
+ * Every rank of a communicator is in the same mode.  How the ROWS travel: gpf_comm_set_exchange below. */
 gpf_status gpf_comm_summary_mode(gpf_handle h, int32_t* mailbox);
 /* exchange volume of this handle's gpf_shard_resample calls so far (what a scaling run compares with the worksheet of DESIGN.md 6.7):
  * out4 = {calls, entries sent to OTHER ranks, entries received from other ranks, bytes of one exchanged entry in the latest call};
