@@ -170,6 +170,8 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     uint64_t ring_seq = 0;               // window exchanges so far: the same on every rank (SPMD call order)
     int exchange_mode = 0;               // gpf_comm_set_exchange: GPF_SHARD_EXCHANGE_RCCL | _P2P (the resamplers with ascending targets)
     bool ring_now = false;               // set by the library engine around its phase calls: this resample exchanges through the windows
+    bool splan_ride = false;             // ... this resample is stratified: its plan rides in the weight scan's launch (k_scan MODE 3, ScanExtras::splan)
+    bool splan_done = false;             // ... and did: gpf_shard_push_count launches no k_strat_plan
     bool pend_ring = false; uint64_t pend_ring_seq = 0;   // the pending commit's entries sit in the window (exchange pend_ring_seq)
     int64_t* tr_dev = nullptr;           // device {entries sent, received} of the window exchanges (the host never learns their counts: gpf_comm_traffic reads these)
     // what the shard phases summarise / pack on behalf of the engine (defaults: the raw log-weights, no extra field)

@@ -324,6 +324,103 @@ __device__ __forceinline__ uint64_t ring_load(const RingIn& in, int64_t slot, do
     return w[W];
 }
 
+// ----------------------------------------------------------------------------- the plan of a sharded STRATIFIED resample
+// Stratum j is [L(j), L(j+1)) with L ascending in j, and shard h owns the targets in [lo_h, lo_(h+1)) (lo = exclusive shard totals): the slots shard h
+// serves are the contiguous range [F[h], F[h+1]), F[h] = first slot whose target is >= lo_h -- the stratum that contains lo_h, or the one after it,
+// decided by that one slot's target.  Every shard derives all of F from the gathered totals (the same integers everywhere), the exchange counts follow
+// by intersecting slot ranges.  The body runs in a launch of its own (k_strat_plan: totals gathered by a collective, or per-phase hosts) or -- round 6 --
+// in the workgroup of the weight scan that ends up with the shard total (k_scan MODE 3, ScanExtras::splan: the plan needs nothing but the G totals,
+// and that workgroup has just pushed the last of them; one launch and its gap less on every stratified resample across shards).
+#ifndef GPF_COUNT_STRIDE
+#define GPF_COUNT_STRIDE 16
+#endif
+constexpr int COUNT_STRIDE = GPF_COUNT_STRIDE;     // int64 words between the exchange counters (each on a 128-byte line of its own)
+struct ShardPlan {
+    WSum ws;                                                          // the GLOBAL weight sum and its strata constants
+    int64_t first, count;                                             // this shard serves the global slots [first, first + count)
+    uint64_t t_off;                                                   // where this shard's CDF starts in the global one
+    int32_t n_shards, pad;
+    int64_t bounds[MAX_SHARDS + 1];                                   // first global slot of every shard (the packed entries name slots inside their shard)
+    int64_t own_range[2];                                             // the slots of THIS shard (local indices) that it serves itself: [lo, hi)
+};
+struct StratPlanJob {                              // plan == nullptr: no job
+    ShardPlan* plan;
+    uint64_t seed; uint32_t epoch; int G, me; int64_t n_global;
+    const int64_t* tot_all; MboxWait wait_tot;     // [G][5] gathered {S_local, ...} (own mailbox: wait for the round first)
+    int64_t* counts; int64_t* host_counts; int64_t ticket; int64_t* traffic;   // as PushArgs
+    int zero_words;                                // > 0 (inside the weight scan): clear this many words of `counts` first -- the scan's own clearing is off then
+};
+// contiguous shard ranges: the first n_global % G shards hold one particle more (the rule every rank applies to its own gpf_config)
+__host__ __device__ inline int64_t shard_bound(int64_t n_global, int G, int g)
+{
+    const int64_t b = n_global / G, x = n_global % G;
+    return (int64_t)g * b + (g < x ? g : x);
+}
+// block-collective (>= MAX_SHARDS + 1 threads; F: LDS scratch [MAX_SHARDS + 1]); bnd(g) = first global slot of shard g
+template <class Bnd>
+__device__ __forceinline__ void strat_plan_body(const StratPlanJob& a, Bnd bnd, int64_t* F)
+{
+    const int h = (int)threadIdx.x;
+    ShardPlan* const plan = a.plan;
+    const uint64_t N = (uint64_t)a.n_global;
+    if (a.zero_words > 0) {
+        for (int i = h; i < a.zero_words; i += (int)blockDim.x) a.counts[i] = 0;
+        __syncthreads();                                   // (the same workgroup writes its counts below)
+    }
+    uint64_t S = 0, lo = 0, lo_me = 0;
+    mbox_wait_block(a.wait_tot);
+    for (int g = 0; g < a.G; ++g) {
+        const uint64_t v = (uint64_t)ld_gathered(a.tot_all + 5 * g, a.wait_tot.tags != nullptr);
+        if (g < h) lo += v;
+        if (g < a.me) lo_me += v;
+        S += v;
+    }
+    const uint64_t B = S / N, rem = S % N;
+    if (h <= a.G) {
+        int64_t f;
+        if (h == 0) f = 0;
+        else if (h == a.G || lo >= S) f = (int64_t)N;
+        else {
+            auto L = [&](uint64_t j) { return j * B + j * rem / N; };
+            uint64_t j = (uint64_t)((double)lo * ((double)N / (double)S));   // the stratum that contains lo: estimate, then exact
+            j = j < N ? j : N - 1;
+            while (j + 1 < N && L(j + 1) <= lo) ++j;
+            while (j > 0 && L(j) > lo) --j;
+            const uint64_t L0 = L(j), L1 = L(j + 1);
+            const uint64_t T = L0 + mulhi64(resample_u64(a.seed, (uint32_t)j, a.epoch), L1 - L0);             // resample.jl:162
+            f = (int64_t)(T >= lo ? j : j + 1);
+        }
+        F[h] = f;
+    }
+    __syncthreads();
+    if (h < a.G) {
+        // sent to shard h: the served slots that lie in h's slot range; received from shard h: h's served slots in this shard's range
+        const int64_t bh0 = bnd(h), bh1 = bnd(h + 1), bm0 = bnd(a.me), bm1 = bnd(a.me + 1);
+        const int64_t s0 = F[a.me] > bh0 ? F[a.me] : bh0, s1 = F[a.me + 1] < bh1 ? F[a.me + 1] : bh1;
+        const int64_t r0 = F[h] > bm0 ? F[h] : bm0, r1 = F[h + 1] < bm1 ? F[h + 1] : bm1;
+        const int64_t ns = s1 > s0 ? s1 - s0 : 0, nr = r1 > r0 ? r1 - r0 : 0;
+        a.counts[h * COUNT_STRIDE] = ns; a.counts[(a.G + h) * COUNT_STRIDE] = nr;
+        if (a.traffic && h != a.me) {
+            if (ns) atomicAdd(reinterpret_cast<unsigned long long*>(a.traffic), (unsigned long long)ns);
+            if (nr) atomicAdd(reinterpret_cast<unsigned long long*>(a.traffic + 1), (unsigned long long)nr);
+        }
+        if (h == a.me) { plan->own_range[0] = nr > 0 ? r0 - bm0 : 0; plan->own_range[1] = nr > 0 ? r1 - bm0 : 0; }
+        if (a.host_counts) {
+            __hip_atomic_store(a.host_counts + h, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.host_counts + a.G + h, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            sys_stores_acknowledged();                       // (before the barrier in front of the ticket)
+        }
+    }
+    if (h == 0) {
+        plan->ws.S = S; plan->ws.sB = B; plan->ws.srem = rem; plan->ws.sinv = (double)N / (double)S;
+        plan->first = F[a.me]; plan->count = F[a.me + 1] - F[a.me]; plan->t_off = lo_me;
+        plan->n_shards = a.G;
+    }
+    if (h <= a.G) plan->bounds[h] = bnd(h);
+    __syncthreads();
+    if (h == 0 && a.host_counts) publish_behind_sys_stores(a.host_counts + 2 * MAX_SHARDS, a.ticket);   // (the counts: acknowledged before the barrier)
+}
+
 // order-preserving key of Julia's isless on Float64 (-0.0 < 0.0); descending sort = ascending on ~key (K10), and its inverse
 __device__ __forceinline__ uint64_t sort_key_desc(double v)
 {

@@ -170,6 +170,9 @@ struct ScanExtras {            // optional side jobs of a scan launch
     SortedGammaJob sp;         // sp.blocks > 0: the LAST sp.blocks workgroups of the launch compute the tile totals of a sorted multinomial resample
     int64_t* q_host;           // pinned [8]: flags, S, Ql0..3, ticket, check word; nullptr: untagged partials, folded later (k_publish_scalars / k_export_q)
     int64_t q_ticket;
+    // MODE 3, a sharded STRATIFIED resample with mailboxes: the workgroup that ends up with the shard total also derives the plan (gpf_k_common.hpp
+    // strat_plan_body) -- no k_strat_plan launch behind the scan; it clears the exchange counters itself (zero128 is off then)
+    StratPlanJob splan;
 };
 // Workgroup of the scan kernels: SCAN_BLOCK threads over one 2048-element tile, every wave SCAN_ROWS rows of 128.  256 threads x 4
 // rows is the measured optimum: 512 x 2 (twice the waves per CU against the kernel's three dependent round trips) ran 1.3-1.5 us
@@ -346,6 +349,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan(In in, int64_t n, int64_t n
                     ws_out->sB = Bq; ws_out->srem = Stot - Bq * (uint64_t)ex.n_slots;
                     ws_out->sinv = (double)ex.n_slots / (double)Stot;
                 }
+            }
+        }
+        if constexpr (MODE == 3) {
+            if (ex.splan.plan && tile == ntiles - 1) {  // (workgroup-uniform) the stratified plan: this workgroup has just pushed the last total the plan needs
+                static_assert(SCAN_BLOCK > MAX_SHARDS, "one thread per shard boundary");
+                __shared__ int64_t s_F[MAX_SHARDS + 1];
+                const StratPlanJob& jb = ex.splan;
+                strat_plan_body(jb, [&](int g) { return shard_bound(jb.n_global, jb.G, g); }, s_F);
             }
         }
         __syncthreads();                                // s_wave / s_red reuse

@@ -109,14 +109,7 @@ __device__ __forceinline__ int count_le_line(const uint64_t* __restrict__ line, 
 
 // sharded stratified resampling (k_strat_plan): strata are contiguous in slot order and the shards' CDF ranges are contiguous
 // in target order, so the global slots a shard serves are ONE range
-struct ShardPlan {
-    WSum ws;                                                          // the GLOBAL weight sum and its strata constants
-    int64_t first, count;                                             // this shard serves the global slots [first, first + count)
-    uint64_t t_off;                                                   // where this shard's CDF starts in the global one
-    int32_t n_shards, pad;
-    int64_t bounds[MAX_SHARDS + 1];                                   // first global slot of every shard (the packed entries name slots inside their shard)
-    int64_t own_range[2];                                             // the slots of THIS shard (local indices) that it serves itself: [lo, hi)
-};
+// (struct ShardPlan: gpf_k_common.hpp)
 // k_search_strat on a shard packs the exchange entries itself: [row | slot inside its shard << 32 | global ancestor id]
 // extra = 1 (a prioritised resample, priority_fn = w -> alpha w, resample.jl:51-52): one more double per entry, log_ws = lw[a] - lp[a]
 // (update_weights!, resample.jl:198) -- the receiver does not hold its ancestors' weights

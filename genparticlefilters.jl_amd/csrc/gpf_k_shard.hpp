@@ -98,10 +98,7 @@ static __global__ void k_export_residual(const Scalars* sc, int64_t* out2, MboxP
 constexpr int PUSH_CHUNK = 2048;                  // output slots per chunk
 // the 2G exchange counters sit on separate 128-byte lines: every chunk does one returning atomic add on its destination's counter, and
 // atomics to the same cache LINE serialise (~7-10 ns each: with G = 8 and all 16 counters on one line, ~4000 of them per launch)
-#ifndef GPF_COUNT_STRIDE
-#define GPF_COUNT_STRIDE 16
-#endif
-constexpr int COUNT_STRIDE = GPF_COUNT_STRIDE;     // int64 words between counters
+// (COUNT_STRIDE: gpf_k_common.hpp)
 // The RECEIVE counters (who serves this shard's slots) take one atomic add per workgroup and owner at the END of the kernels that count them
 // (k_search_own, k_search_own_res, k_push_scan): 256 adds on one address, ~5 ns each in a row = 1.3 us of tail per launch.  On one node (G <= 8) they
 // are striped: stripe 0 is the counter itself (index G + q), stripes 1 .. 7 use the lines of counters no shard owns (from index 2 G on; the scan
@@ -661,59 +658,8 @@ __global__ __launch_bounds__(SBLOCK, SEARCH_WAVES_PER_SIMD) void k_push(PushArgs
 static __global__ __launch_bounds__(128) void k_strat_plan(PushArgs a, ShardPlan* plan)
 {
     __shared__ int64_t F[MAX_SHARDS + 1];
-    const int h = (int)threadIdx.x;
-    const uint64_t N = (uint64_t)a.n_global;
-    uint64_t S = 0, lo = 0, lo_me = 0;
-    mbox_wait_block(a.wait_tot);
-    for (int g = 0; g < a.G; ++g) {
-        const uint64_t v = (uint64_t)ld_gathered(a.tot_all + 5 * g, a.wait_tot.tags != nullptr);
-        if (g < h) lo += v;
-        if (g < a.me) lo_me += v;
-        S += v;
-    }
-    const uint64_t B = S / N, rem = S % N;
-    if (h <= a.G) {
-        int64_t f;
-        if (h == 0) f = 0;
-        else if (h == a.G || lo >= S) f = (int64_t)N;
-        else {
-            auto L = [&](uint64_t j) { return j * B + j * rem / N; };
-            uint64_t j = (uint64_t)((double)lo * ((double)N / (double)S));   // the stratum that contains lo: estimate, then exact
-            j = j < N ? j : N - 1;
-            while (j + 1 < N && L(j + 1) <= lo) ++j;
-            while (j > 0 && L(j) > lo) --j;
-            const uint64_t L0 = L(j), L1 = L(j + 1);
-            const uint64_t T = L0 + mulhi64(resample_u64(a.seed, (uint32_t)j, a.epoch), L1 - L0);             // resample.jl:162
-            f = (int64_t)(T >= lo ? j : j + 1);
-        }
-        F[h] = f;
-    }
-    __syncthreads();
-    if (h < a.G) {
-        // sent to shard h: the served slots that lie in h's slot range; received from shard h: h's served slots in this shard's range
-        const int64_t s0 = F[a.me] > a.bounds[h] ? F[a.me] : a.bounds[h], s1 = F[a.me + 1] < a.bounds[h + 1] ? F[a.me + 1] : a.bounds[h + 1];
-        const int64_t r0 = F[h] > a.bounds[a.me] ? F[h] : a.bounds[a.me], r1 = F[h + 1] < a.bounds[a.me + 1] ? F[h + 1] : a.bounds[a.me + 1];
-        const int64_t ns = s1 > s0 ? s1 - s0 : 0, nr = r1 > r0 ? r1 - r0 : 0;
-        a.counts[h * COUNT_STRIDE] = ns; a.counts[(a.G + h) * COUNT_STRIDE] = nr;
-        if (a.traffic && h != a.me) {
-            if (ns) atomicAdd(reinterpret_cast<unsigned long long*>(a.traffic), (unsigned long long)ns);
-            if (nr) atomicAdd(reinterpret_cast<unsigned long long*>(a.traffic + 1), (unsigned long long)nr);
-        }
-        if (h == a.me) { plan->own_range[0] = nr > 0 ? r0 - a.bounds[a.me] : 0; plan->own_range[1] = nr > 0 ? r1 - a.bounds[a.me] : 0; }
-        if (a.host_counts) {
-            __hip_atomic_store(a.host_counts + h, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(a.host_counts + a.G + h, nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            sys_stores_acknowledged();                       // (before the barrier in front of the ticket)
-        }
-    }
-    if (h == 0) {
-        plan->ws.S = S; plan->ws.sB = B; plan->ws.srem = rem; plan->ws.sinv = (double)N / (double)S;
-        plan->first = F[a.me]; plan->count = F[a.me + 1] - F[a.me]; plan->t_off = lo_me;
-        plan->n_shards = a.G;
-    }
-    if (h <= a.G) plan->bounds[h] = a.bounds[h];
-    __syncthreads();
-    if (h == 0 && a.host_counts) publish_behind_sys_stores(a.host_counts + 2 * MAX_SHARDS, a.ticket);   // (the counts: acknowledged before the barrier)
+    const StratPlanJob jb{plan, a.seed, a.epoch, a.G, a.me, a.n_global, a.tot_all, a.wait_tot, a.counts, a.host_counts, a.ticket, a.traffic, 0};
+    strat_plan_body(jb, [&](int g) { return a.bounds[g]; }, F);
 }
 // ---- sharded SORTED MULTINOMIAL (GPF_RESAMPLE_MULTINOMIAL_SORTED): the targets of the N slots are non-decreasing in
 // the slot index, like the strata, so the slots shard h serves are again ONE range [F[h], F[h+1]), F[h] = the first slot whose target is

@@ -114,6 +114,19 @@ gpf_status gpf_shard_weight_scan(gpf_handle h, const double* mf_all, int32_t G, 
     }
     ex.wait = mb_wait(h, MB_MF);
     const MboxPush tot_push = mb_begin(h, MB_TOT);
+    h->splan_done = false;
+    static const bool splan_off = getenv("GPF_SHARD_PLAN_IN_SCAN") && !strcmp(getenv("GPF_SHARD_PLAN_IN_SCAN"), "0");   // (A/B measurements, tests of k_strat_plan)
+    if (h->splan_ride && !splan_off && !want_q && h->mb_active && h->mb_engine && (int)G == h->comm_world) {
+        // a stratified resample: the plan needs nothing but the G shard totals of THIS round, and the scan's workgroup that ends up with this shard's total
+        // pushes the last one of them -- it derives the plan right there (no k_strat_plan launch, no gap in front of the merge kernel)
+        if (!h->shard_plan) HIP_TRY(h, hipMalloc(&h->shard_plan, sizeof(ShardPlan)));
+        h->push_ticket += 1;
+        int64_t* const host_counts = ((h->own_direct && G == 1) || h->ring_now) ? nullptr : h->h_shard_counts;   // (as gpf_shard_push_count)
+        ex.splan = StratPlanJob{h->shard_plan, h->cfg.seed, h->epoch, (int)G, h->comm_rank, h->cfg.n_global, static_cast<const int64_t*>(mb_gathered(h, MB_TOT)), mb_wait(h, MB_TOT),
+                                h->shard_counts, host_counts, h->push_ticket, h->ring_now ? h->tr_dev : nullptr, (int)(2 * MAX_SHARDS * COUNT_STRIDE)};
+        ex.zero128 = nullptr;                                     // (the plan's workgroup clears the counters itself: two workgroups must not store to them)
+        h->splan_done = true;
+    }
     if (want_q) {
         if ((s = scan_launch_shard(h, 4, in, (int)G, slot, want_cdf, reinterpret_cast<uint64_t*>(out5), mf_all, ex))) return s;
         GPF_LAUNCH(k_export_q, dim3(1), dim3(BLOCK), 0, h->stream, h->blockQ, gs, out5, tot_push);
@@ -228,6 +241,13 @@ gpf_status gpf_shard_push_count(gpf_handle h, int32_t method, const int64_t* tot
         if (s) return s;
         HIP_TRY(h, hipGetLastError());
         h->counts_published = a.host_counts != nullptr;         // (else gpf_shard_counts copies them from the device)
+        h->push_counted = true;
+        return GPF_OK;
+    }
+    if (method == GPF_RESAMPLE_STRATIFIED && h->splan_done) {
+        // the plan rode in the weight scan's launch (gpf_shard_weight_scan, ScanExtras::splan): nothing to launch
+        h->splan_done = false;
+        h->counts_published = !((h->own_direct && G == 1) || h->ring_now);
         h->push_counted = true;
         return GPF_OK;
     }
@@ -1079,7 +1099,8 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
                                             multi_lds_bytes(h->ntiles, multi_logg(h->ntiles)) + 4096 <= (size_t)160 * 1024) ||
                                            (method == GPF_RESAMPLE_RESIDUAL && !pull && search_lds_bytes(h->ntiles, 2) + 40 * 1024 <= (size_t)160 * 1024) ||
                                            ranged);
-    struct OwnScope { gpf_filter* h; ~OwnScope() { h->own_direct = false; h->own_direct_range = false; h->ring_now = false; } } own_scope{h};
+    struct OwnScope { gpf_filter* h; ~OwnScope() { h->own_direct = false; h->own_direct_range = false; h->ring_now = false; h->splan_ride = false; h->splan_done = false; } } own_scope{h};
+    h->splan_ride = method == GPF_RESAMPLE_STRATIFIED && !prio;
     h->own_direct = own; h->own_direct_range = own && ranged;
     // The window exchange (gpf_k_common.hpp RingOut / RingIn; gpf_comm_set_exchange): the resamplers with ascending targets exchange boundary slabs -- the
     // merge kernel stores them straight into the destination ranks' slot-addressed receive windows, the next propagate reads them there.  No split

@@ -631,3 +631,14 @@ def test_iid_rows_through_the_windows_skewed(g, o, tmp_path, monkeypatch, loopba
 def test_iid_rows_through_the_windows_tiny_shards(g, o, tmp_path, monkeypatch, loopback_lib, method):
     monkeypatch.setenv("GPF_SHARD_EXCHANGE", "p2p_all")
     test_window_exchange_tiny_shards(g, o, tmp_path, monkeypatch, loopback_lib, method, 10, 3, expect="p2p_all")
+
+
+@pytest.mark.parametrize("world,exchange", soak_grid([2, 3], ["p2p", "rccl"], keep=lambda w, e: (w, e) in ((3, "p2p"), (2, "rccl"))))
+def test_stratified_plan_outside_the_weight_scan(g, o, tmp_path, monkeypatch, loopback_lib, world, exchange):
+    """Since round 6 the plan of a sharded stratified resample (served slot range, own range, exchange counts) is derived by the workgroup of the weight scan
+    that ends up with the shard total (k_scan MODE 3, ScanExtras::splan) -- every other stratified test of the library engine with mailboxes runs that way.
+    GPF_SHARD_PLAN_IN_SCAN=0 keeps the separate k_strat_plan launch (also what RCCL-carried summaries and the per-phase hosts use): the same bits."""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    monkeypatch.setenv("GPF_SHARD_PLAN_IN_SCAN", "0"); monkeypatch.setenv("GPF_SHARD_EXCHANGE", exchange)
+    for case in (CASES[1], CASES[5]):
+        test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)

@@ -74,7 +74,8 @@ for STEP in "$@"; do
                echo -n "$M, 1-rank RCCL, mailbox: " >> $OUT; GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
                case $M in stratified|multinomial_sorted)   # (the line above ran the window exchange and -- a rank with a device of its own -- the fused (max, flags) round; these: the grouped send / receive, the separate k_pack_mflags launch)
                  echo -n "$M, 1-rank RCCL, mailbox, GPF_SHARD_EXCHANGE=rccl: " >> $OUT; GPF_SHARD_EXCHANGE=rccl GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
-                 echo -n "$M, 1-rank RCCL, mailbox, GPF_SHARD_FUSE_MF=0:     " >> $OUT; GPF_SHARD_FUSE_MF=0 GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT ;;
+                 echo -n "$M, 1-rank RCCL, mailbox, GPF_SHARD_FUSE_MF=0:     " >> $OUT; GPF_SHARD_FUSE_MF=0 GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT
+                 [ $M = stratified ] && { echo -n "$M, 1-rank RCCL, mailbox, GPF_SHARD_PLAN_IN_SCAN=0: " >> $OUT; GPF_SHARD_PLAN_IN_SCAN=0 GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT; } ;;
                esac
              done
              cat $OUT ;;
