@@ -115,6 +115,7 @@ SYMBOLS = [
     ("gpf_phase_times", C.c_int, [_H, _pd, _pi64]),
     ("gpf_shard_resample", C.c_int, [_H, C.c_int32, C.c_int32, _pi32]),
     ("gpf_shard_resample_tempered", C.c_int, [_H, C.c_int32, C.c_double, C.c_int32, _pi32]),
+    ("gpf_shard_resample_sorted", C.c_int, [_H, C.c_int32, _pi32]),
     ("gpf_shard_effective_sample_size", C.c_int, [_H, _pd]),
     ("gpf_shard_log_ml_estimate", C.c_int, [_H, _pd]),
     # host-side scalar spec

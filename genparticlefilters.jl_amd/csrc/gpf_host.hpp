@@ -211,6 +211,11 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     uint64_t* sp_g = nullptr; uint64_t* sp_vlo = nullptr; int64_t sp_cap = 0;
     SortedGammaJob sp_job{}; bool sp_job_set = false;    // tile totals wanted: the next weight scan of this call carries them (scan_launch), else k_sorted_gammas
     ulonglong2* push_stage = nullptr;    // push exchange: staged hits, one 16-byte entry per global output slot at most
+    // sharded stratified resampling with sort_particles = true (gpf_shard_resample_sorted; gpf_k_shard.hpp AncPlan): the planner filter of n_global particles
+    // every rank sorts / scans / searches the gathered log-weights with, the all-gather staging of unequal shards, the pack cursors
+    gpf_filter* planner = nullptr;
+    double* sorted_src = nullptr; double* sorted_gath = nullptr; int64_t sorted_per = 0;
+    unsigned long long* anc_cursors = nullptr;
     ShardPlan* shard_plan = nullptr;     // sharded stratified / sorted multinomial resampling: the slot range this shard serves (k_strat_plan, k_sorted_plan)
     int64_t* splan_F = nullptr; unsigned int* splan_arrive = nullptr;   // k_sorted_plan: boundary scratch [MAX_SHARDS + 1], arrival counter (zero between launches)
     int64_t push_cap = 0;

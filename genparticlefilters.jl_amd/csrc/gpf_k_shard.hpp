@@ -1010,4 +1010,104 @@ static __global__ __launch_bounds__(BLOCK) void k_shard_apply_post(const double*
         lw[i] = lws[i] + off;
 }
 
+// ---- sharded STRATIFIED resampling with the reference's default sort_particles = true (src/resample.jl:145,156-157): the REPLICATED plan.  A global
+// descending sort has no shard-local form -- position p of the sorted order can hold any shard's particle -- so every rank gathers ALL log-weights (8 bytes
+// per global particle, one all-gather) and runs the unsharded sort + scan + search on them itself (a planner filter of n_global particles without rows: the
+// very kernels of the single-GPU path on the very same numbers, hence the same ancestors for any number of shards).  Every rank then holds the ancestor of
+// EVERY global slot: who serves which slot needs no message, the exchange counts no exchange.  The rows travel as the i.i.d. resamplers' do (packed
+// entries [row | slot | ancestor id], own hits in place through the ancestor array).
+struct AncPlan {
+    const int32_t* anc_g;                         // [n_global] ancestor (global id) of every global slot, on every rank
+    int64_t n_global; int G, me;
+    int64_t base, extra;                          // the contiguous-range rule: shard g holds base + (g < extra) particles
+    int64_t lo, hi;                               // this shard's particles / slots [lo, hi)
+};
+__device__ __forceinline__ int anc_owner(const AncPlan& p, int64_t x)
+{
+    const int64_t wide = p.extra * (p.base + 1);
+    return x < wide ? (int)(x / (p.base + 1)) : (int)(p.extra + (x - wide) / p.base);
+}
+__device__ __forceinline__ int64_t anc_bound(const AncPlan& p, int g) { return (int64_t)g * p.base + (g < p.extra ? g : p.extra); }
+constexpr int ANC_BLOCK = 256, ANC_PER = 8, ANC_CHUNK = ANC_BLOCK * ANC_PER;
+// counts[g] = entries this shard sends to shard g, counts[G + q] = entries (own hits included) shard q serves to this shard's slots; own != 0: the
+// shard's own hits go into anc_local as global ids (-1 = arrives packed) and are not counted as sent
+static __global__ __launch_bounds__(ANC_BLOCK) void k_anc_count(AncPlan p, int own, int32_t* __restrict__ anc_local, int64_t* __restrict__ counts)
+{
+    __shared__ unsigned int s_send[MAX_SHARDS], s_recv[MAX_SHARDS];
+    for (int g = threadIdx.x; g < MAX_SHARDS; g += ANC_BLOCK) { s_send[g] = 0; s_recv[g] = 0; }
+    __syncthreads();
+    for (int64_t j = (int64_t)blockIdx.x * ANC_BLOCK + threadIdx.x; j < p.n_global; j += (int64_t)gridDim.x * ANC_BLOCK) {
+        const int64_t a = p.anc_g[j];
+        const bool mine = a >= p.lo && a < p.hi, to_me = j >= p.lo && j < p.hi;
+        if (to_me) {
+            atomicAdd(&s_recv[mine ? p.me : anc_owner(p, a)], 1u);
+            if (own) anc_local[j - p.lo] = mine ? (int32_t)a : -1;
+        }
+        if (mine && !(own && to_me)) atomicAdd(&s_send[anc_owner(p, j)], 1u);
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < p.G; g += ANC_BLOCK) {
+        if (s_send[g]) atomicAdd(reinterpret_cast<unsigned long long*>(counts + (int64_t)g * COUNT_STRIDE), (unsigned long long)s_send[g]);
+        if (s_recv[g]) atomicAdd(reinterpret_cast<unsigned long long*>(counts + (int64_t)(p.G + g) * COUNT_STRIDE), (unsigned long long)s_recv[g]);
+    }
+}
+// the rows this shard serves, packed by destination ([row | slot inside the destination << 32 | ancestor id]; any order inside a destination's group:
+// every entry names its slot); cursors[G] start at zero; stops at the capacity (the host repeats the call with a larger buffer if the counts say so)
+template <int W>
+__global__ __launch_bounds__(ANC_BLOCK) void k_anc_pack(AncPlan p, int own, const double* __restrict__ rows, const int64_t* __restrict__ counts,
+                                                        unsigned long long* __restrict__ cursors, int64_t capacity, double* __restrict__ packed_out)
+{
+    __shared__ unsigned int s_cnt[MAX_SHARDS];
+    __shared__ int64_t s_base[MAX_SHARDS];
+    __shared__ int64_t s_off[MAX_SHARDS + 1];
+    if (threadIdx.x == 0) {
+        int64_t o = 0;
+        for (int g = 0; g < p.G; ++g) { s_off[g] = o; o += counts[(int64_t)g * COUNT_STRIDE]; }
+        s_off[p.G] = o;
+    }
+    const int64_t nch = (p.n_global + ANC_CHUNK - 1) / ANC_CHUNK;
+    for (int64_t c = blockIdx.x; c < nch; c += gridDim.x) {
+        __syncthreads();
+        for (int g = threadIdx.x; g < p.G; g += ANC_BLOCK) s_cnt[g] = 0;
+        __syncthreads();
+        int dst[ANC_PER]; unsigned int rank[ANC_PER]; int64_t anc[ANC_PER];
+#pragma unroll
+        for (int u = 0; u < ANC_PER; ++u) {
+            const int64_t j = c * ANC_CHUNK + (int64_t)u * ANC_BLOCK + threadIdx.x;
+            dst[u] = -1;
+            if (j >= p.n_global) continue;
+            const int64_t a = p.anc_g[j];
+            if (a < p.lo || a >= p.hi) continue;
+            if (own && j >= p.lo && j < p.hi) continue;
+            anc[u] = a;
+            dst[u] = anc_owner(p, j);
+            rank[u] = atomicAdd(&s_cnt[dst[u]], 1u);
+        }
+        __syncthreads();
+        for (int g = threadIdx.x; g < p.G; g += ANC_BLOCK)
+            s_base[g] = s_cnt[g] ? (int64_t)atomicAdd(cursors + g, (unsigned long long)s_cnt[g]) : 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < ANC_PER; ++u) {
+            if (dst[u] < 0) continue;
+            const int64_t j = c * ANC_CHUNK + (int64_t)u * ANC_BLOCK + threadIdx.x;
+            const int64_t e = s_off[dst[u]] + s_base[dst[u]] + rank[u];
+            if (e >= capacity) continue;
+            const double* src = rows + (anc[u] - p.lo) * W;
+            double* out = packed_out + e * (W + 1);
+#pragma unroll
+            for (int k = 0; k < W; ++k) out[k] = src[k];
+            out[W] = u2d(((uint64_t)(j - anc_bound(p, dst[u])) << 32) | (uint64_t)anc[u]);
+        }
+    }
+}
+// the gathered log-weights of shards of unequal size (n_global % G != 0: every rank contributes `per` = base + 1 words, the last of some unused) -> dense
+static __global__ __launch_bounds__(BLOCK) void k_anc_compact(AncPlan p, const double* __restrict__ gathered, int64_t per, double* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < p.n_global; i += (int64_t)gridDim.x * BLOCK) {
+        const int g = anc_owner(p, i);
+        out[i] = gathered[(int64_t)g * per + (i - anc_bound(p, g))];
+    }
+}
+
 } // namespace gpf

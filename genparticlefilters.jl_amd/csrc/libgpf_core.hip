@@ -563,6 +563,8 @@ gpf_status gpf_destroy(gpf_handle h)
         }
     }
     h->pending_packed = false;                                   // the filter goes away: nothing to scatter a deferred commit into
+    if (h->planner) { gpf_destroy(h->planner); h->planner = nullptr; }
+    for (void* q : {(void*)h->sorted_src, (void*)h->sorted_gath, (void*)h->anc_cursors}) if (q) (void)hipFree(q);
     for (gpf_filter* v : h->blk_views) gpf_destroy(v);
     h->blk_views.clear();
     gpf_comm_destroy(h);

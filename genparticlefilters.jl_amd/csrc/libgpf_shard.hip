@@ -1024,6 +1024,91 @@ static gpf_status pull_requests(gpf_filter* h, int32_t method, const int64_t* to
     return GPF_OK;
 }
 
+// ---- stratified with sort_particles = true across shards: the replicated plan (gpf_k_shard.hpp AncPlan)
+static AncPlan anc_plan(const gpf_filter* h, int G, int me)
+{
+    AncPlan p{};
+    p.anc_g = h->planner ? h->planner->anc : nullptr;
+    p.n_global = h->cfg.n_global; p.G = G; p.me = me;
+    p.base = p.n_global / G; p.extra = p.n_global % G;
+    p.lo = h->cfg.gid0; p.hi = h->cfg.gid0 + h->n;
+    return p;
+}
+// everything of the plan that can fail for reasons of this rank alone: before the first collective of the call
+static gpf_status shard_sorted_buffers(gpf_filter* h, int G)
+{
+    gpf_status s;
+    if (!h->planner) {
+        gpf_config c = h->cfg;
+        c.n_particles = c.n_global; c.gid0 = 0; c.keep_prev = 0; c.stream = (void*)h->stream; c.params = h->args.P;
+        gpf_handle p = nullptr;
+        if ((s = gpf_create(&c, &p))) return fail(h, s, std::string("planner of the sorted sharded resample (n_global particles on every rank): ") + gpf_last_error(nullptr));
+        h->planner = p;
+    }
+    if ((s = ensure_shard_counts(h))) return s;
+    if (!h->anc_cursors) HIP_TRY(h, hipMalloc(&h->anc_cursors, MAX_SHARDS * sizeof(unsigned long long)));
+    const int64_t N = h->cfg.n_global, per = N / G + (N % G ? 1 : 0);
+    if (N % G && h->sorted_per != per) {
+        for (void* q : {(void*)h->sorted_src, (void*)h->sorted_gath}) if (q) (void)hipFree(q);
+        h->sorted_src = h->sorted_gath = nullptr; h->sorted_per = 0;
+        HIP_TRY(h, hipMalloc(&h->sorted_src, (size_t)per * sizeof(double)));
+        HIP_TRY(h, hipMemsetAsync(h->sorted_src, 0, (size_t)per * sizeof(double), h->stream));
+        HIP_TRY(h, hipMalloc(&h->sorted_gath, (size_t)per * G * sizeof(double)));
+        h->sorted_per = per;
+    }
+    return GPF_OK;
+}
+// phases 3 of that plan: all log-weights on every rank, the unsharded sort + scan + search on them (the planner), the exchange counts
+static gpf_status shard_sorted_plan(gpf_filter* h, int G, int me, bool own)
+{
+    gpf_status s;
+    gpf_filter* p = h->planner;
+    const int64_t N = h->cfg.n_global;
+    if (N % G == 0) {
+        if ((s = shard_all_gather(h, h->lw, p->lw, (size_t)h->n, ncclDouble, sizeof(double)))) return s;
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->sorted_src, h->lw, (size_t)h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if ((s = shard_all_gather(h, h->sorted_src, h->sorted_gath, (size_t)h->sorted_per, ncclDouble, sizeof(double)))) return s;
+        GPF_LAUNCH(k_anc_compact, dim3(grid_for(h, N, 8)), dim3(BLOCK), 0, h->stream, anc_plan(h, G, me), h->sorted_gath, h->sorted_per, p->lw);
+        HIP_TRY(h, hipGetLastError());
+    }
+    // the planner IS the unsharded filter as far as its weights go: same seed, same epoch, same K = fix_K(n_global)
+    p->epoch = h->epoch;
+    p->pending_gather = false; p->pending_search = false;
+    p->max_valid = false; p->raw_valid = false; p->raw_sum_valid = false;
+    mutated(p);
+    s = resample_impl(p, GPF_RESAMPLE_STRATIFIED, raw_view(p), 1, GPF_CHECK_FALSE, nullptr);   // (validity was decided on the gathered flags)
+    p->pending_gather = false;                                    // (its ancestors are all this call wants: the planner has no rows worth gathering)
+    if (s) return fail(h, s, "planner: " + p->err);
+    HIP_TRY(h, hipMemsetAsync(h->shard_counts, 0, (size_t)2 * MAX_SHARDS * COUNT_STRIDE * sizeof(int64_t), h->stream));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((N + ANC_CHUNK - 1) / ANC_CHUNK, (int64_t)h->n_cu * 4));
+    s = timed(h, GPF_K_SEARCH, [&] { GPF_LAUNCH(k_anc_count, dim3(grid), dim3(ANC_BLOCK), 0, h->stream, anc_plan(h, G, me), own ? 1 : 0, h->anc, h->shard_counts); });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    h->counts_published = false;                                  // (gpf_shard_counts copies them from the device)
+    h->push_counted = true;
+    return GPF_OK;
+}
+static gpf_status shard_sorted_push(gpf_filter* h, int G, int me, bool own, int64_t capacity, double* packed_out)
+{
+    if (capacity <= 0 || !packed_out) return GPF_OK;
+    HIP_TRY(h, hipMemsetAsync(h->anc_cursors, 0, MAX_SHARDS * sizeof(unsigned long long), h->stream));
+    const int64_t N = h->cfg.n_global;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((N + ANC_CHUNK - 1) / ANC_CHUNK, (int64_t)h->n_cu * 4));
+    const AncPlan ap = anc_plan(h, G, me);
+    const double* rows = h->rows[h->cur];
+    gpf_status s = timed(h, GPF_K_GATHER, [&] {
+        switch (h->W) {
+            case 2: GPF_LAUNCH((k_anc_pack<2>), dim3(grid), dim3(ANC_BLOCK), 0, h->stream, ap, own ? 1 : 0, rows, h->shard_counts, h->anc_cursors, capacity, packed_out); break;
+            case 4: GPF_LAUNCH((k_anc_pack<4>), dim3(grid), dim3(ANC_BLOCK), 0, h->stream, ap, own ? 1 : 0, rows, h->shard_counts, h->anc_cursors, capacity, packed_out); break;
+            case 8: GPF_LAUNCH((k_anc_pack<8>), dim3(grid), dim3(ANC_BLOCK), 0, h->stream, ap, own ? 1 : 0, rows, h->shard_counts, h->anc_cursors, capacity, packed_out); break;
+        }
+    });
+    if (s) return s;
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+
 // phase 5 of a window exchange: the new population = the shard's own range through the ancestor array + the window entries of the other slots
 static gpf_status shard_commit_ring(gpf_handle h, const double* mf_all, const int64_t* tot_all, int G, bool own_is_a_range)
 {
@@ -1041,14 +1126,17 @@ static gpf_status shard_commit_ring(gpf_handle h, const double* mf_all, const in
     return GPF_OK;
 }
 
-static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double priority_alpha, int32_t check, int32_t* invalid)
+static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double priority_alpha, int32_t check, int32_t* invalid, int32_t sort_particles = 0)
 {
     gpf_status s = shard_ready(h);
     if (s) return s;
     if (method != GPF_RESAMPLE_MULTINOMIAL && method != GPF_RESAMPLE_RESIDUAL && method != GPF_RESAMPLE_STRATIFIED && method != GPF_RESAMPLE_MULTINOMIAL_SORTED)
         return fail(h, GPF_ERR_UNKNOWN_METHOD, "Resampling method not recognized.");             // resample.jl:28
     if (!h->sh_mf) return fail(h, GPF_ERR_STATE, "gpf_shard_resample needs gpf_comm_create first");
-    const bool ranged = method == GPF_RESAMPLE_STRATIFIED || method == GPF_RESAMPLE_MULTINOMIAL_SORTED;   // ascending targets: every shard serves ONE slot range
+    // stratified over the particles in descending weight order (resample.jl:145,156-157): the replicated plan (gpf_k_shard.hpp AncPlan) -- ancestors in slot
+    // order are then a permutation's worth of shards, the rows travel like the i.i.d. resamplers'
+    const bool sorted = method == GPF_RESAMPLE_STRATIFIED && sort_particles;
+    const bool ranged = (method == GPF_RESAMPLE_STRATIFIED && !sorted) || method == GPF_RESAMPLE_MULTINOMIAL_SORTED;   // ascending targets: every shard serves ONE slot range
     const int G = h->comm_world, me = h->comm_rank;
     // priority_fn = w -> alpha w (resample.jl:51-52): ancestors from the priorities' CDF, the log-ML update from the RAW weights
     // (:57), new log-weights log_ws + (log N - logsumexp(log_ws)) with log_ws = lw[a] - lp[a] (:198-200).  Across shards that is
@@ -1056,6 +1144,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     // receiver does not hold its ancestors' weights); the commit cannot be deferred (the weights need the third round).
     const bool prio = priority_alpha == priority_alpha;
     const int64_t n = h->n, E = h->W + 1 + (prio ? 1 : 0);
+    if (sorted && prio) return fail(h, GPF_ERR_INVALID_ARGUMENT, "sort_particles = true with a priority_fn is not available across shards");
     EngineScope engine(h);                                        // the phases below push / wait through the shard mailboxes when they are up
     phase_mark(h, -1);
     if (h->phases.on) h->phases.resamples += 1;
@@ -1088,8 +1177,9 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     static const bool force = getenv("GPF_SHARD_FORCE_COLLECTIVES") && !strcmp(getenv("GPF_SHARD_FORCE_COLLECTIVES"), "1");
     const bool exchange = G > 1 || (force && h->comm);            // one shard: what it "sends" is what it "receives"
     if (exchange && (s = ensure(h->sh_recv, h->sh_recv_cap, n))) return s;
-    const bool pull = h->shard_plan_kind == GPF_SHARD_PLAN_PULL && !ranged;
+    const bool pull = h->shard_plan_kind == GPF_SHARD_PLAN_PULL && !ranged && !sorted;
     if (pull && (s = pull_buffers(h, G))) return s;
+    if (sorted && ((s = materialize(h)) || (s = shard_sorted_buffers(h, G)))) return s;
     // Own-direct (multinomial, push plan, no priorities): a slot of this shard whose target falls into this shard's own part of the CDF is
     // resolved in place -- its ancestor goes into h->anc and the next propagate gathers the row through it, as on an unsharded filter;
     // only the slots other shards serve travel as packed entries.  On one rank nothing is staged, packed, counted or waited for.
@@ -1098,16 +1188,16 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
     const bool own = !own_off && !prio && h->cfg.n_global < ((int64_t)1 << 31) && ((method == GPF_RESAMPLE_MULTINOMIAL && !pull && multi_logg(h->ntiles) >= 0 &&
                                             multi_lds_bytes(h->ntiles, multi_logg(h->ntiles)) + 4096 <= (size_t)160 * 1024) ||
                                            (method == GPF_RESAMPLE_RESIDUAL && !pull && search_lds_bytes(h->ntiles, 2) + 40 * 1024 <= (size_t)160 * 1024) ||
-                                           ranged);
+                                           ranged || sorted);
     struct OwnScope { gpf_filter* h; ~OwnScope() { h->own_direct = false; h->own_direct_range = false; h->ring_now = false; h->splan_ride = false; h->splan_done = false; } } own_scope{h};
-    h->splan_ride = method == GPF_RESAMPLE_STRATIFIED && !prio;
+    h->splan_ride = method == GPF_RESAMPLE_STRATIFIED && !prio && !sorted;
     h->own_direct = own; h->own_direct_range = own && ranged;
     // The window exchange (gpf_k_common.hpp RingOut / RingIn; gpf_comm_set_exchange): the resamplers with ascending targets exchange boundary slabs -- the
     // merge kernel stores them straight into the destination ranks' slot-addressed receive windows, the next propagate reads them there.  No split
     // sizes for the host to wait for, no ncclGroup, no send / receive buffer, no overflow; the call returns as soon as its kernels are enqueued.
     // (GPF_SHARD_EXCHANGE_P2P_ALL: the i.i.d. resamplers' rows too -- every entry names its slot, so the window takes them as it takes the slabs; that
     //  exchange is bandwidth-bound, (G-1)/G of all rows as scattered 8 (W + 2)-byte peer stores: opt-in until a multi-GPU run has timed it against RCCL)
-    const bool p2p = own && h->ring_active && ((ranged && h->exchange_mode >= GPF_SHARD_EXCHANGE_P2P) || (!ranged && !pull && h->exchange_mode == GPF_SHARD_EXCHANGE_P2P_ALL));
+    const bool p2p = own && h->ring_active && ((ranged && h->exchange_mode >= GPF_SHARD_EXCHANGE_P2P) || (!ranged && !pull && !sorted && h->exchange_mode == GPF_SHARD_EXCHANGE_P2P_ALL));
     h->ring_now = p2p;
     // sorted multinomial: the tile totals of ALL global slots (they depend on seed, epoch and N alone) -- the job rides in the weight scan below
     struct SpScope { gpf_filter* h; ~SpScope() { h->sp_job_set = false; } } sp_scope{h};
@@ -1187,7 +1277,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
         phase_mark(h, GPF_PHASE_PACK);
     } else {
-        if ((s = gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
+        if ((s = sorted ? shard_sorted_plan(h, G, me, own) : gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
         phase_mark(h, GPF_PHASE_PLAN);
         if (own && G == 1) {
             // one shard, own-direct: every slot is an own hit -- nothing to exchange, so no split sizes to wait for (the host wait left a
@@ -1199,7 +1289,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         } else {
         // phase 4 is enqueued before the host learns the counts; the kernel stops at the capacity and the push is repeated if the
         // counts say it overflowed
-        if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
+        if ((s = sorted ? shard_sorted_push(h, G, me, own, pushed_cap, h->sh_send) : gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
         phase_mark(h, GPF_PHASE_PACK);
         const auto w0 = std::chrono::steady_clock::now();
         if ((s = gpf_shard_counts(h, G, counts.data()))) return s;   // ONE host wait (the exchange's split sizes), behind phase 4
@@ -1225,7 +1315,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         }
     }
     if (n_send > pushed_cap)
-        remember(gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), n_send, h->sh_send));
+        remember(sorted ? shard_sorted_push(h, G, me, own, n_send, h->sh_send) : gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), n_send, h->sh_send));
     // the exchange: [row | slot | ancestor id], grouped point-to-point sends and receives (one pair per PEER; the shard's own
     // entries never touch RCCL: one device-to-device copy on the same stream)
     const double* commit_from = h->sh_send;
@@ -1382,6 +1472,10 @@ gpf_status gpf_phase_times(gpf_handle h, double* us6, int64_t* resamples)
 gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid)
 {
     return shard_resample_impl(h, method, std::nan(""), check, invalid);
+}
+gpf_status gpf_shard_resample_sorted(gpf_handle h, int32_t check, int32_t* invalid)
+{
+    return shard_resample_impl(h, GPF_RESAMPLE_STRATIFIED, __builtin_nan(""), check, invalid, 1);
 }
 gpf_status gpf_shard_resample_tempered(gpf_handle h, int32_t method, double priority_alpha, int32_t check, int32_t* invalid)
 {

@@ -24,8 +24,8 @@ bit-identical to the single-GPU run for any number of shards.
 The collectives and their split sizes are plain torch.distributed code, the same on CPU and GPU; the
 arithmetic and the routing live behind a small backend interface: `HipShardBackend` (the
 product: libgpf_hip.so through the C ABI) -- the tests inject a CPU backend built on the oracle to
-exercise the collectives with gloo.  Restrictions: sort_particles = false; priority_fn = nothing or Tempering(alpha) (the
-latter in the library engine only).
+exercise the collectives with gloo.  Restrictions: priority_fn = nothing or Tempering(alpha), and sort_particles = true (every rank sorts the
+gathered weights: gpf_shard_resample_sorted) -- both in the library engine only.
 """
 from __future__ import annotations
 
@@ -244,12 +244,15 @@ class HipShardBackend:
         """ranks of the library's RCCL communicator (0: none)"""
         return getattr(self, "_rccl_world", 0)
 
-    def shard_resample(self, method_id: int, check, alpha=None) -> bool:
+    def shard_resample(self, method_id: int, check, alpha=None, sort_particles=False) -> bool:
         """pf_resample!(state, method; priority_fn, check) over all shards, collectives issued by the library; returns `invalid`.
-        alpha: priority_fn = w -> alpha w (gpf_shard_resample_tempered), None: priority_fn = nothing"""
+        alpha: priority_fn = w -> alpha w (gpf_shard_resample_tempered), None: priority_fn = nothing; sort_particles: the stratified resampler's strata over
+        the particles in descending weight order (gpf_shard_resample_sorted: the replicated plan)"""
         chk = 2 if check is True else (1 if check == "warn" else 0)
         inv = C.c_int32(0)
-        if alpha is None:
+        if sort_particles:
+            self._ck(self.L.gpf_shard_resample_sorted(self.h, chk, C.byref(inv) if chk else None))
+        elif alpha is None:
             self._ck(self.L.gpf_shard_resample(self.h, method_id, chk, C.byref(inv) if chk else None))
         else:
             self._ck(self.L.gpf_shard_resample_tempered(self.h, method_id, float(alpha), chk, C.byref(inv) if chk else None))
@@ -433,14 +436,16 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
     if priority_fn is not None and not isinstance(priority_fn, Tempering):
         raise ErrorException("sharded resampling supports priority_fn = nothing or Tempering(alpha) (w -> alpha w); "
                              "any other closure needs local=True")
-    if method == "stratified" and sort_particles:
-        raise ErrorException("sharded stratified resampling needs sort_particles=False (no global sort; SURVEY.md H8)")
     b, G, mid = state.backend, state.world, RESAMPLE_METHODS[method]
+    sort_particles = bool(sort_particles) and method == "stratified"   # only the stratified resampler reads it (src/resample.jl:143-145)
+    if sort_particles and (priority_fn is not None or not getattr(b, "lib_comm", False)):
+        raise ErrorException("sharded stratified resampling with sort_particles=True runs in the library engine (gpf_shard_resample_sorted: every rank sorts "
+                             "the gathered weights), without a priority_fn; the python engine needs sort_particles=False")
     if priority_fn is not None and not getattr(b, "lib_comm", False):
         raise ErrorException("a prioritised sharded resample runs in the library engine (gpf_shard_resample_tempered)")
     if getattr(b, "lib_comm", False):                                 # the whole exchange inside the library (RCCL)
         try:
-            invalid = b.shard_resample(mid, check, None if priority_fn is None else priority_fn.alpha)
+            invalid = b.shard_resample(mid, check, None if priority_fn is None else priority_fn.alpha, sort_particles)
         except ErrorException as e:
             raise ErrorException("Invalid weights.") if "Invalid weights" in str(e) else e
         if invalid and check == "warn":

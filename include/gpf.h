@@ -350,7 +350,7 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
  * calls with MPI.jl/NCCL.jl).  All pointer arguments are DEVICE pointers owned by the caller; every call
  * is asynchronous on the handle's stream.  The reference has no distributed path; these
  * restate src/resample.jl:48-120,143-175 with a global CDF.  Supported here: priority_fn = nothing and
- * sort_particles = false (a global sort is out of scope).
+ * sort_particles = false (sort_particles = true: gpf_shard_resample_sorted, the replicated plan).
  *
  *   phase 1  gpf_shard_weight_max     out2 = {local max, local flags & (NaN|+Inf)} as two doubles
  *            host: all-gather -> mf_all[G][2]
@@ -415,7 +415,7 @@ double  gpf_host_ess(uint64_t S, uint64_t Q_hi, uint64_t Q_lo);           /* S^2
  * fixed-point scan under the global maximum, all-gather of the shard totals (+ the residual counts), push count / push,
  * ONE variable-size exchange of packed rows (grouped ncclSend / ncclRecv: point-to-point pairs over xGMI), deferred commit --
  * on the handle's stream, every collective issued by the library.  It stands in for pf_resample!(state, method; check)
- * (src/resample.jl:19-30) on a sharded state; priority_fn and sort_particles are not available across shards.
+ * (src/resample.jl:19-30) on a sharded state (priority_fn = w -> alpha w: gpf_shard_resample_tempered; sort_particles = true: gpf_shard_resample_sorted).
  *   gpf_comm_unique_id: 128-byte id made by ONE process (ncclGetUniqueId) and handed to all others by the host's own means
  *   (MPI, Distributed.jl, torch.distributed, a file);  rank r of `world` owns the global range [gid0, gid0 + n) its
  *   gpf_config names; ranks are ordered by gid0.
@@ -487,8 +487,16 @@ gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32
  * tempering family of test/resample.jl:15): ancestors from the CDF of the priorities over ALL shards, log_ml_est from the raw
  * weights, new log-weights log_ws + (log N - logsumexp(log_ws)), log_ws = lw[a] - lp[a], with the logsumexp over all shards.
  * Three summary rounds instead of one and one more double (log_ws) per exchanged entry; the result is bit-identical to
- * gpf_resample(h, method, priority_alpha, ...) on the unsharded filter.  sort_particles stays unavailable across shards. */
+ * gpf_resample(h, method, priority_alpha, ...) on the unsharded filter.  Not together with sort_particles = true. */
 gpf_status gpf_shard_resample_tempered(gpf_handle h, int32_t method, double priority_alpha, int32_t check, int32_t* invalid);
+/* pf_resample!(state, :stratified; sort_particles = true, check) -- the reference's DEFAULT form of the stratified resampler (src/resample.jl:143-175: strata over
+ * the particles in descending weight order, :145,156-157) -- on a sharded state, called on every rank like gpf_shard_resample; the same ancestors as
+ * gpf_resample(h, GPF_RESAMPLE_STRATIFIED, NaN, 1, ...) on the unsharded filter, for any number of shards.  A global sort has no shard-local form: every rank
+ * gathers ALL log-weights (one all-gather of 8 bytes per global particle) and runs the unsharded sort + scan + search on them itself (a planner filter of
+ * n_global particles on every rank, created at the first call; about 130 bytes of HBM per global particle), then serves the rows its particles are ancestors
+ * of as packed entries through the grouped point-to-point exchange.  The cost grows with n_global, not with the shard: across shards
+ * gpf_shard_resample(GPF_RESAMPLE_STRATIFIED) -- sort_particles = false -- stays the fast form.  No priority_fn. */
+gpf_status gpf_shard_resample_sorted(gpf_handle h, int32_t check, int32_t* invalid);
 /* gpf_step_ess on a sharded filter -- one iteration of the README loop (README.md:66-77), called on every rank like gpf_shard_resample:
  *     if effective_sample_size(state) < ess_frac * N_global;  pf_resample!(state, method);  pf_rejuvenate!(state, ...; method);  end;  pf_update!(state, ...)
  * with the GLOBAL effective sample size; the same results as the separate calls (gpf_shard_effective_sample_size, gpf_shard_resample,

@@ -429,7 +429,10 @@ function pf_resample!(s::ShardedDeviceParticleFilterState, method::Symbol=:multi
     inv_ptr = check === false ? Ptr{Cint}(C_NULL) : Base.unsafe_convert(Ptr{Cint}, invalid)
     st = GC.@preserve invalid (local_only ?
         ccall((:gpf_resample_local, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cint}), s.handle, m, sort_particles ? 1 : 0, chk, inv_ptr) :
-        (priority_alpha === nothing ?
+        (method == :stratified && sort_particles ?   # the reference's default order of the strata (src/resample.jl:145,156-157): the replicated plan
+            (priority_alpha === nothing ? ccall((:gpf_shard_resample_sorted, libgpf), Cint, (Ptr{Cvoid}, Cint, Ptr{Cint}), s.handle, chk, inv_ptr) :
+                error("sort_particles = true with a priority_fn is not available across shards")) :
+         priority_alpha === nothing ?
             ccall((:gpf_shard_resample, libgpf), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}), s.handle, m, chk, inv_ptr) :
             ccall((:gpf_shard_resample_tempered, libgpf), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Cint}), s.handle, m, priority_alpha, chk, inv_ptr)))
     _status(s, st)

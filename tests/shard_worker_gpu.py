@@ -40,7 +40,10 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
                 continue
             ess = sharded.get_ess(st); ess_log.append(ess)
             if ess_frac is None or ess < ess_frac * n_global:
-                sharded.pf_resample(st, method, check=False)
+                if method == "stratified_sorted":                     # the reference's default order of the strata: gpf_shard_resample_sorted
+                    sharded.pf_resample(st, "stratified", sort_particles=True, check=False)
+                else:
+                    sharded.pf_resample(st, method, check=False)
                 if rejuv and rejuv != "keep":
                     sharded.pf_rejuvenate(st, None, (), 1, method=rejuv)
             sharded.pf_update(st, (t + 1,), (None,), ys[t])
@@ -110,7 +113,10 @@ def run_skew(rank, world, port, method, n_global, pattern, out_dir):
         assert st.backend.lib_comm == (os.environ.get("GPF_SHARD_ENGINE", "python") == "library")
         loc = st.local
         loc.log_weights = skew_weights(n_global, pattern)[st.gid0:st.gid0 + st.n_local]
-        sharded.pf_resample(st, method, check=False)
+        if method == "stratified_sorted":
+            sharded.pf_resample(st, "stratified", sort_particles=True, check=False)
+        else:
+            sharded.pf_resample(st, method, check=False)
         sharded.pf_update(st, (2,), (None,), ys[1])
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=loc.traces, lw=loc.log_weights, parents=loc.parents, gid0=st.gid0,
                  lml=sharded.get_lml_est(st))

@@ -642,3 +642,59 @@ def test_stratified_plan_outside_the_weight_scan(g, o, tmp_path, monkeypatch, lo
     monkeypatch.setenv("GPF_SHARD_PLAN_IN_SCAN", "0"); monkeypatch.setenv("GPF_SHARD_EXCHANGE", exchange)
     for case in (CASES[1], CASES[5]):
         test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
+
+
+SORTED_CASES = [("lgssm2", "stratified_sorted", 4100, 5, None, None),            # x 20 particles: 82 000, not a multiple of 3 (the padded all-gather)
+                ("bearings4", "stratified_sorted", 1600, 6, 0.6, "move"),      # ESS-triggered + MH: the move scatters the deferred commit; rows carry x_{t-1}
+                ("sv1", "stratified_sorted", 1500, 4, None, "reweight")]
+
+
+@pytest.mark.parametrize("case,world,mode", soak_grid(SORTED_CASES, [2, 3], ["mailbox", "rccl"],
+                                                    keep=lambda c, w, m: (c, w, m) in ((SORTED_CASES[0], 3, "mailbox"), (SORTED_CASES[1], 2, "mailbox"), (SORTED_CASES[0], 2, "rccl"))), ids=_cid)
+def test_sorted_stratified_across_shards(g, o, tmp_path, monkeypatch, loopback_lib, case, world, mode):
+    """pf_resample!(state, :stratified; sort_particles = true) -- the reference's default (src/resample.jl:145,156-157) -- on 2 - 3 shards through
+    gpf_shard_resample_sorted: every rank gathers all log-weights and runs the unsharded sort + scan + search on them (the replicated plan), rows travel as
+    packed entries, own hits in place.  Bit-identical to the single-shard oracle, for shard sizes that divide n_global and that do not."""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    if mode == "rccl":
+        monkeypatch.setenv("GPF_SHARD_SUMMARY", "rccl")
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
+
+
+@pytest.mark.parametrize("variant", ["own_off", "small_send_buffer"])
+def test_sorted_stratified_across_shards_packed_paths(g, o, tmp_path, monkeypatch, loopback_lib, variant):
+    """the same with every entry packed (GPF_SHARD_OWN=0: own hits travel through the exchange buffer too) and with a send buffer smaller than the exchange
+    (the pack kernel stops at the capacity, the host repeats it at the right size)"""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    if variant == "own_off":
+        monkeypatch.setenv("GPF_SHARD_OWN", "0")
+    else:
+        monkeypatch.setenv("GPF_PUSH_CAPACITY", "1000")
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, SORTED_CASES[0], world=3)
+
+
+@pytest.mark.parametrize("pattern", ["all_on_first_shard", "single_particle", pytest.param("middle_band", marks=pytest.mark.gpu_soak)])
+def test_sorted_stratified_across_shards_skewed(g, o, tmp_path, monkeypatch, loopback_lib, pattern):
+    """all mass on one shard / one particle / a band of EQUAL weights (long runs of equal sort keys: ties by index): one shard serves everything"""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    test_hip_shards_skewed_weights(g, o, tmp_path, "stratified_sorted", pattern, n_global=100_000)
+
+
+def test_world1_sorted_stratified_equals_unsharded(g, o):
+    """one shard through sharded.py: gpf_shard_resample_sorted against gpf_resample(..., sort_particles = 1) on the plain filter, between updates and after
+    a getter; the python engine refuses"""
+    from gpf_amd import sharded
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 6); N = 50_000
+    a = sharded.pf_initialize(model, (1,), ys[0], N, seed=5)
+    b = g.pf_initialize(model, (1,), ys[0], N, seed=5)
+    for t in range(1, 6):
+        sharded.pf_resample(a, "stratified", sort_particles=t != 3, check=False)
+        g.pf_resample(b, "stratified", sort_particles=t != 3, check=False)
+        assert np.array_equal(a.local.parents, b.parents), t
+        if t == 4:
+            assert sharded.get_lml_est(a) == g.get_lml_est(b)
+        sharded.pf_update(a, (t + 1,), (None,), ys[t]); g.pf_update(b, (t + 1,), (None,), ys[t])
+        assert np.array_equal(a.local.traces, b.traces) and np.array_equal(a.local.log_weights, b.log_weights)
+    assert sharded.get_lml_est(a) == g.get_lml_est(b) and sharded.get_ess(a) == g.get_ess(b)
+    with pytest.raises(g.ErrorException, match="priority_fn"):
+        sharded.pf_resample(a, "stratified", sort_particles=True, priority_fn=g.Tempering(0.5), check=False)

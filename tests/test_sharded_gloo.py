@@ -39,7 +39,8 @@ def single(g, o, model_name, method, n_global, T, ess_frac, rejuv):
     for t in range(1, T):
         ess = f.effective_sample_size(); ess_log.append(ess)
         if ess_frac is None or ess < ess_frac * n_global:
-            f.resample(method, sort_particles=False, check=False)
+            # ("stratified_sorted": the reference's default sort_particles = true -- the library engine's replicated plan, tests/test_gpu_sharded.py)
+            f.resample(method.replace("_sorted", "") if method == "stratified_sorted" else method, sort_particles=method == "stratified_sorted", check=False)
             if rejuv and rejuv != "keep":
                 f.rejuvenate(rejuv, 1)
         f.update(ys[t]); lml_log.append(f.log_ml_estimate())
@@ -95,7 +96,7 @@ def single_skew(g, o, method, n_global, pattern):
     model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
     f = o.OracleFilter(model.model_id, model.params, n_global, 77).initialize(ys[0])
     f.lw[:] = shard_worker.skew_weights(n_global, pattern)
-    f.resample(method, sort_particles=False, check=False)
+    f.resample("stratified" if method == "stratified_sorted" else method, sort_particles=method == "stratified_sorted", check=False)
     f.update(ys[1])
     return f
 

@@ -78,6 +78,12 @@ for STEP in "$@"; do
                  [ $M = stratified ] && { echo -n "$M, 1-rank RCCL, mailbox, GPF_SHARD_PLAN_IN_SCAN=0: " >> $OUT; GPF_SHARD_PLAN_IN_SCAN=0 GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py $M 300 2>/dev/null | grep "us/step" >> $OUT; } ;;
                esac
              done
+             # the reference's default sort_particles = true across shards: the replicated plan (every rank sorts all n_global weights); next to it the unsharded call
+             for N in 1000000 4000000 8000000; do
+               echo -n "stratified_sorted, N = $N, no communicator:      " >> $OUT; python3 tools/sharded_loop.py stratified_sorted 100 $N 2>/dev/null | grep "us/step" >> $OUT
+               echo -n "stratified_sorted, N = $N, 1-rank RCCL, mailbox: " >> $OUT; GPF_SHARD_FORCE_COLLECTIVES=1 python3 tools/sharded_loop.py stratified_sorted 100 $N 2>/dev/null | grep "us/step" >> $OUT
+               echo -n "stratified_sorted, N = $N, unsharded gpf_resample: " >> $OUT; python3 tools/resample_loop.py stratified_sorted 100 $N 2>/dev/null | grep "us/step" >> $OUT
+             done
              cat $OUT ;;
     essloop) OUT=gpurun_out/${TAG}_sharded_ess_loop.txt; : > $OUT
              for F in 0.5 1.1 0; do

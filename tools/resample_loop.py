@@ -15,8 +15,10 @@ if method == "stratified_sorted":
 model = g.models.lgssm2()
 ys = g.models.simulate(model, steps + 1)
 st = g.pf_initialize(model, (1,), ys[0], N, seed=1)
+import time  # noqa: E402
+st.synchronize(); t0 = time.perf_counter()
 for t in range(1, steps + 1):
     g.pf_resample(st, method, check=False, **kw)
     g.pf_update(st, (t + 1,), (None,), ys[t])
 st.synchronize()
-print("log-ML", g.get_lml_est(st))
+print("us/step", round((time.perf_counter() - t0) / steps * 1e6, 2), "(first steps included)", "log-ML", g.get_lml_est(st))

@@ -18,7 +18,10 @@ import time
 for rep in range(2):
     st.backend.synchronize(); t0 = time.perf_counter()
     for t in range(1, steps + 1):
-        sharded.pf_resample(st, method, check=False)
+        if method == "stratified_sorted":                   # the reference's default sort_particles = true: gpf_shard_resample_sorted (every rank sorts all n_global weights)
+            sharded.pf_resample(st, "stratified", sort_particles=True, check=False)
+        else:
+            sharded.pf_resample(st, method, check=False)
         sharded.pf_update(st, (t + 1,), (None,), ys[t])
     st.backend.synchronize(); dt = (time.perf_counter() - t0) / steps * 1e6
 print("us/step", round(dt, 2), "log-ML", sharded.get_lml_est(st))
