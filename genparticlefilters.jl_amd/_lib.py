@@ -116,6 +116,8 @@ SYMBOLS = [
     ("gpf_shard_resample", C.c_int, [_H, C.c_int32, C.c_int32, _pi32]),
     ("gpf_shard_resample_tempered", C.c_int, [_H, C.c_int32, C.c_double, C.c_int32, _pi32]),
     ("gpf_shard_resample_sorted", C.c_int, [_H, C.c_int32, _pi32]),
+    ("gpf_shard_sorted_count", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
+    ("gpf_shard_sorted_push", C.c_int, [_H, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     ("gpf_shard_effective_sample_size", C.c_int, [_H, _pd]),
     ("gpf_shard_log_ml_estimate", C.c_int, [_H, _pd]),
     # host-side scalar spec

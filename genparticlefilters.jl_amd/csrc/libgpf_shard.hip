@@ -1058,20 +1058,25 @@ static gpf_status shard_sorted_buffers(gpf_filter* h, int G)
     }
     return GPF_OK;
 }
-// phases 3 of that plan: all log-weights on every rank, the unsharded sort + scan + search on them (the planner), the exchange counts
+// phase 3 of that plan, first half (the one collective): all log-weights on every rank, dense in global order, in the planner's weight array
+static gpf_status shard_sorted_gather(gpf_filter* h, int G, int me)
+{
+    gpf_status s;
+    gpf_filter* p = h->planner;
+    const int64_t N = h->cfg.n_global;
+    if (N % G == 0) return shard_all_gather(h, h->lw, p->lw, (size_t)h->n, ncclDouble, sizeof(double));
+    HIP_TRY(h, hipMemcpyAsync(h->sorted_src, h->lw, (size_t)h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if ((s = shard_all_gather(h, h->sorted_src, h->sorted_gath, (size_t)h->sorted_per, ncclDouble, sizeof(double)))) return s;
+    GPF_LAUNCH(k_anc_compact, dim3(grid_for(h, N, 8)), dim3(BLOCK), 0, h->stream, anc_plan(h, G, me), h->sorted_gath, h->sorted_per, p->lw);
+    HIP_TRY(h, hipGetLastError());
+    return GPF_OK;
+}
+// ... second half: the unsharded sort + scan + search on them (the planner), the exchange counts
 static gpf_status shard_sorted_plan(gpf_filter* h, int G, int me, bool own)
 {
     gpf_status s;
     gpf_filter* p = h->planner;
     const int64_t N = h->cfg.n_global;
-    if (N % G == 0) {
-        if ((s = shard_all_gather(h, h->lw, p->lw, (size_t)h->n, ncclDouble, sizeof(double)))) return s;
-    } else {
-        HIP_TRY(h, hipMemcpyAsync(h->sorted_src, h->lw, (size_t)h->n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        if ((s = shard_all_gather(h, h->sorted_src, h->sorted_gath, (size_t)h->sorted_per, ncclDouble, sizeof(double)))) return s;
-        GPF_LAUNCH(k_anc_compact, dim3(grid_for(h, N, 8)), dim3(BLOCK), 0, h->stream, anc_plan(h, G, me), h->sorted_gath, h->sorted_per, p->lw);
-        HIP_TRY(h, hipGetLastError());
-    }
     // the planner IS the unsharded filter as far as its weights go: same seed, same epoch, same K = fix_K(n_global)
     p->epoch = h->epoch;
     p->pending_gather = false; p->pending_search = false;
@@ -1277,7 +1282,7 @@ static gpf_status shard_resample_impl(gpf_handle h, int32_t method, double prior
         if ((s = gpf_shard_push(h, method, tot_all, cr_all, G, me, bounds.data(), pushed_cap, h->sh_send))) return s;
         phase_mark(h, GPF_PHASE_PACK);
     } else {
-        if ((s = sorted ? shard_sorted_plan(h, G, me, own) : gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
+        if ((s = sorted ? ((s = shard_sorted_gather(h, G, me)) ? s : shard_sorted_plan(h, G, me, own)) : gpf_shard_push_count(h, method, tot_all, cr_all, G, me, bounds.data()))) return s;   // phase 3
         phase_mark(h, GPF_PHASE_PLAN);
         if (own && G == 1) {
             // one shard, own-direct: every slot is an own hit -- nothing to exchange, so no split sizes to wait for (the host wait left a
@@ -1472,6 +1477,28 @@ gpf_status gpf_phase_times(gpf_handle h, double* us6, int64_t* resamples)
 gpf_status gpf_shard_resample(gpf_handle h, int32_t method, int32_t check, int32_t* invalid)
 {
     return shard_resample_impl(h, method, std::nan(""), check, invalid);
+}
+// the phases of gpf_shard_resample_sorted for hosts that bring their own collectives (sharded.py's python engine): between the usual summary phases
+// (gpf_shard_weight_max / _weight_scan) and gpf_shard_counts / the exchange / gpf_shard_commit
+gpf_status gpf_shard_sorted_count(gpf_handle h, const double* lw_all, int32_t G, int32_t me)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    const int64_t N = h->cfg.n_global;
+    if (!lw_all || G < 1 || G > MAX_SHARDS || me < 0 || me >= G) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    if ((int64_t)me * (N / G) + std::min<int64_t>(me, N % G) != h->cfg.gid0 || N / G + (me < N % G ? 1 : 0) != h->n)
+        return fail(h, GPF_ERR_STATE, "this shard's (gid0, n_particles) is not rank's contiguous share of n_global");
+    if ((s = materialize(h)) || (s = shard_sorted_buffers(h, G))) return s;
+    HIP_TRY(h, hipMemcpyAsync(h->planner->lw, lw_all, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return shard_sorted_plan(h, G, me, h->own_direct);
+}
+gpf_status gpf_shard_sorted_push(gpf_handle h, int32_t G, int32_t me, int64_t capacity, double* packed_out)
+{
+    gpf_status s = shard_ready(h);
+    if (s) return s;
+    if (!h->planner || !h->push_counted) return fail(h, GPF_ERR_STATE, "gpf_shard_sorted_push needs gpf_shard_sorted_count of the same resample first");
+    if (G < 1 || G > MAX_SHARDS || me < 0 || me >= G || capacity < 0 || (capacity > 0 && !packed_out)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "bad arguments");
+    return shard_sorted_push(h, G, me, h->own_direct, capacity, packed_out);
 }
 gpf_status gpf_shard_resample_sorted(gpf_handle h, int32_t check, int32_t* invalid)
 {

@@ -24,8 +24,8 @@ bit-identical to the single-GPU run for any number of shards.
 The collectives and their split sizes are plain torch.distributed code, the same on CPU and GPU; the
 arithmetic and the routing live behind a small backend interface: `HipShardBackend` (the
 product: libgpf_hip.so through the C ABI) -- the tests inject a CPU backend built on the oracle to
-exercise the collectives with gloo.  Restrictions: priority_fn = nothing or Tempering(alpha), and sort_particles = true (every rank sorts the
-gathered weights: gpf_shard_resample_sorted) -- both in the library engine only.
+exercise the collectives with gloo.  Restrictions: priority_fn = nothing or Tempering(alpha) (the latter in the library engine only, and not together
+with sort_particles = true, where every rank sorts the gathered weights: gpf_shard_resample_sorted).
 """
 from __future__ import annotations
 
@@ -125,6 +125,22 @@ class HipShardBackend:
             self._sendbuf = torch.empty((capacity, self.W + 1), dtype=torch.float64, device=self.device)
         self._ck(self.L.gpf_shard_push(self.h, method_id, tot_all.data_ptr(), cr_all.data_ptr() if cr_all is not None else None, G, me,
                                        self._bounds, capacity, self._sendbuf.data_ptr() if capacity else None))
+        return self._sendbuf
+
+    # ---- stratified with sort_particles = true, phase by phase (gpf_shard_sorted_count / _push: the planner on the gathered log-weights)
+    def log_weights_tensor(self):
+        return torch.from_numpy(np.ascontiguousarray(self.state.log_weights, np.float64)).to(self.device)
+
+    def sorted_count(self, lw_all, me, bounds):
+        G = len(bounds) - 1
+        self._lw_all = lw_all.contiguous()                      # alive until the stream has consumed it
+        self._ck(self.L.gpf_shard_sorted_count(self.h, self._lw_all.data_ptr(), G, me))
+
+    def sorted_push(self, me, bounds, capacity):
+        G = len(bounds) - 1
+        if getattr(self, "_sendbuf", None) is None or self._sendbuf.shape[0] < capacity:
+            self._sendbuf = torch.empty((capacity, self.W + 1), dtype=torch.float64, device=self.device)
+        self._ck(self.L.gpf_shard_sorted_push(self.h, G, me, capacity, self._sendbuf.data_ptr() if capacity else None))
         return self._sendbuf
 
     def commit(self, packed, mf_all, tot_all):
@@ -438,9 +454,8 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
                              "any other closure needs local=True")
     b, G, mid = state.backend, state.world, RESAMPLE_METHODS[method]
     sort_particles = bool(sort_particles) and method == "stratified"   # only the stratified resampler reads it (src/resample.jl:143-145)
-    if sort_particles and (priority_fn is not None or not getattr(b, "lib_comm", False)):
-        raise ErrorException("sharded stratified resampling with sort_particles=True runs in the library engine (gpf_shard_resample_sorted: every rank sorts "
-                             "the gathered weights), without a priority_fn; the python engine needs sort_particles=False")
+    if sort_particles and priority_fn is not None:
+        raise ErrorException("sharded stratified resampling with sort_particles=True (every rank sorts the gathered weights: the replicated plan) takes no priority_fn")
     if priority_fn is not None and not getattr(b, "lib_comm", False):
         raise ErrorException("a prioritised sharded resample runs in the library engine (gpf_shard_resample_tempered)")
     if getattr(b, "lib_comm", False):                                 # the whole exchange inside the library (RCCL)
@@ -460,13 +475,29 @@ def pf_resample(state: ShardedParticleFilterState, method: str = "multinomial", 
         if flags:
             import warnings
             warnings.warn("Invalid weights (all -Inf or zero): resampled with uniform weights.")
+    cap = min(state.n_global, 2 * state.n_local + 65536)
+    if os.environ.get("GPF_PUSH_CAPACITY"):                           # tests: force the overflow path
+        cap = int(os.environ["GPF_PUSH_CAPACITY"])
+    if sort_particles:
+        # the replicated plan (gpf.h gpf_shard_resample_sorted): ALL log-weights on every rank (shards of unequal size: padded), the unsharded sort + scan +
+        # search on them by every rank itself -- so every rank knows every slot's ancestor and the exchange counts need no message
+        lw = b.log_weights_tensor()
+        per = max(state.bounds[r + 1] - state.bounds[r] for r in range(G))
+        padded = torch.zeros(per, dtype=torch.float64, device=lw.device); padded[:state.n_local] = lw
+        gathered = state._all_gather(padded)
+        lw_all = torch.cat([gathered[r, :state.bounds[r + 1] - state.bounds[r]] for r in range(G)]).contiguous()
+        b.sorted_count(lw_all, state.rank, state.bounds)
+        buf = b.sorted_push(state.rank, state.bounds, cap)
+        c = b.counts(G)
+        sc, rc = c[:G], c[G:]
+        if sum(sc) > cap:
+            buf = b.sorted_push(state.rank, state.bounds, sum(sc))
+        b.commit(state._all_to_all(buf[:sum(sc)], sc, rc), mf_all, tot_all)
+        return state
     cr_all = state._all_gather(b.residual_scan(tot_all)).contiguous() if mid == 1 else None     # phase 2b: (G, 2)
     b.push_count(mid, tot_all, cr_all, state.rank, state.bounds)     # phase 3: who owns the target of which slot
     # phase 4 is enqueued BEFORE the host learns the counts, into a buffer sized for a balanced exchange with slack
     # (any size is correct: the kernel stops at the capacity, and the call is repeated if the counts say it overflowed)
-    cap = min(state.n_global, 2 * state.n_local + 65536)
-    if os.environ.get("GPF_PUSH_CAPACITY"):                           # tests: force the overflow path
-        cap = int(os.environ["GPF_PUSH_CAPACITY"])
     buf = b.push(mid, tot_all, cr_all, state.rank, state.bounds, cap)                  # look up, gather, pack
     c = b.counts(G)                                                   # ONE host sync (the all-to-all split sizes), behind phase 4
     sc, rc = c[:G], c[G:]

@@ -497,6 +497,12 @@ gpf_status gpf_shard_resample_tempered(gpf_handle h, int32_t method, double prio
  * of as packed entries through the grouped point-to-point exchange.  The cost grows with n_global, not with the shard: across shards
  * gpf_shard_resample(GPF_RESAMPLE_STRATIFIED) -- sort_particles = false -- stays the fast form.  No priority_fn. */
 gpf_status gpf_shard_resample_sorted(gpf_handle h, int32_t check, int32_t* invalid);
+/* ... and its two phases for a host that brings its own collectives (the python engine of sharded.py; cf. gpf_shard_push_count / gpf_shard_push): after the
+ * summary phases (gpf_shard_weight_max, gpf_shard_weight_scan), with lw_all = the log-weights of ALL shards in global order on this device (the host's
+ * all-gather): gpf_shard_sorted_count runs the planner and leaves the exchange counts for gpf_shard_counts, gpf_shard_sorted_push packs this shard's
+ * entries [row | slot << 32 | ancestor id], grouped by destination, at most `capacity` of them; then the exchange and gpf_shard_commit as ever. */
+gpf_status gpf_shard_sorted_count(gpf_handle h, const double* lw_all, int32_t G, int32_t me);
+gpf_status gpf_shard_sorted_push(gpf_handle h, int32_t G, int32_t me, int64_t capacity, double* packed_out);
 /* gpf_step_ess on a sharded filter -- one iteration of the README loop (README.md:66-77), called on every rank like gpf_shard_resample:
  *     if effective_sample_size(state) < ess_frac * N_global;  pf_resample!(state, method);  pf_rejuvenate!(state, ...; method);  end;  pf_update!(state, ...)
  * with the GLOBAL effective sample size; the same results as the separate calls (gpf_shard_effective_sample_size, gpf_shard_resample,

@@ -131,6 +131,38 @@ class OracleShardBackend:
         out[:k] = np.concatenate([rows, meta.reshape(-1, 1)], axis=1)[:k]
         return torch.from_numpy(out)
 
+    # stratified with sort_particles = true: the replicated plan (every rank holds all log-weights and works the unsharded spec out itself)
+    def log_weights_tensor(self):
+        return torch.from_numpy(self.lw.copy())
+
+    def sorted_count(self, lw_all, me, bounds):
+        lw = np.ascontiguousarray(lw_all.numpy(), np.float64)
+        assert lw.size == self.N
+        sp = o.WeightSummary(lw, self.N)                        # safe_softmax of ALL weights (resample.jl:147-151)
+        order = o.argsort_desc(lw)                              # :156-157
+        cdf, S, _, _ = o.scan(sp.q[order])
+        k = o.upper_bound(cdf, o.targets_stratified(self.seed, self.epoch, 0, self.N, self.N, S))   # :160-166
+        self._anc = np.asarray(order[k], np.int64)              # ancestor (global id) of every global slot
+        b = np.asarray(bounds); G = b.size - 1
+        self._bounds = b
+        self._dest = np.searchsorted(b[1:], np.arange(self.N), side="right")
+        self._owner = np.searchsorted(b[1:], self._anc, side="right")
+        send = np.bincount(self._dest[self._owner == me], minlength=G)
+        recv = np.bincount(self._owner[self._dest == me], minlength=G)
+        self._counts = [int(x) for x in np.concatenate([send, recv])]
+        self._me = me
+
+    def sorted_push(self, me, bounds, capacity):
+        hits = np.flatnonzero(self._owner == me)                # slot order = grouped by destination
+        a = self._anc[hits] - self.gid0
+        rows = o.gather_rows(self.rows, a) if hits.size else np.zeros((0, self.W))
+        slot_local = hits - self._bounds[self._dest[hits]]
+        meta = ((slot_local.astype(np.uint64) << np.uint64(32)) | self._anc[hits].astype(np.uint64)).view(np.float64)
+        out = np.full((capacity, self.W + 1), np.nan)
+        kk = min(capacity, hits.size)
+        out[:kk] = np.concatenate([rows, meta.reshape(-1, 1)], axis=1)[:kk]
+        return torch.from_numpy(out)
+
     def commit(self, packed, mf_all, tot_all):
         pk = np.ascontiguousarray(packed.numpy())
         assert pk.shape[0] == self.n

@@ -33,7 +33,10 @@ def run(rank, world, port, model_name, method, n_global, T, ess_frac, rejuv, out
             ess = sharded.get_ess(st)
             ess_log.append(ess)
             if ess_frac is None or ess < ess_frac * n_global:
-                sharded.pf_resample(st, method, check=False)
+                if method == "stratified_sorted":             # the reference's default order of the strata: the replicated plan, phase by phase
+                    sharded.pf_resample(st, "stratified", sort_particles=True, check=False)
+                else:
+                    sharded.pf_resample(st, method, check=False)
                 if rejuv and rejuv != "keep":
                     sharded.pf_rejuvenate(st, None, (), 1, method=rejuv)
             sharded.pf_update(st, (t + 1,), (None,), ys[t])
@@ -72,7 +75,10 @@ def run_skew(rank, world, port, method, n_global, pattern, out_dir):
         st = sharded.pf_initialize(model, (1,), ys[0], n_global, seed=77, backend_factory=OracleShardBackend)
         b = st.backend
         b.lw[:] = skew_weights(n_global, pattern)[b.gid0:b.gid0 + b.n]
-        sharded.pf_resample(st, method, check=False)
+        if method == "stratified_sorted":
+            sharded.pf_resample(st, "stratified", sort_particles=True, check=False)
+        else:
+            sharded.pf_resample(st, method, check=False)
         sharded.pf_update(st, (2,), (None,), ys[1])
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=b.rows, lw=b.lw, parents=b.parents, gid0=b.gid0,
                  lml=sharded.get_lml_est(st))

@@ -183,7 +183,9 @@ def run_fuzz(rank, world, port, seed, n_global, T, out_dir):
             elif op == "resample":
                 # (library engine: every other global resample is tempered, priority_fn = w -> w / 2)
                 tempered = st.backend.lib_comm and bool(salt & 4)
-                sharded.pf_resample(st, method, check=False, priority_fn=g.Tempering(0.5) if tempered else None)
+                # (every other untempered stratified one with the reference's default sort_particles = true: the replicated plan, either engine)
+                sharded.pf_resample(st, method, check=False, priority_fn=g.Tempering(0.5) if tempered else None,
+                                    sort_particles=method == "stratified" and not tempered and bool(salt & 16))
             elif op == "rejuvenate":
                 sharded.pf_rejuvenate(st, None, (), 1, method="move")
             elif op == "getters":

@@ -364,8 +364,9 @@ def test_sharded_random_api_sequences(g, o, tmp_path, monkeypatch, loopback_lib,
         if op == "update":
             f.update(ys[t]); t += 1
         elif op == "resample":
-            f.resample(method, check=False, priority_alpha=0.5 if (engine.startswith("library") and salt & 4) else None,
-                       **({"sort_particles": False} if method == "stratified" else {}))
+            tempered = engine.startswith("library") and bool(salt & 4)
+            f.resample(method, check=False, priority_alpha=0.5 if tempered else None,
+                       **({"sort_particles": not tempered and bool(salt & 16)} if method == "stratified" else {}))
         elif op == "rejuvenate":
             f.rejuvenate("move", 1)
         elif op == "getters":

@@ -86,6 +86,26 @@ def test_sharded_step_ess_equals_single(g, o, tmp_path, case):
     test_sharded_equals_single(g, o, tmp_path, case, 2, one_call=True)
 
 
+SORTED_CASES = [("lgssm2", "stratified_sorted", 4100, 5, None, None),            # 4100 is not a multiple of 3: the padded all-gather of the log-weights
+                ("bearings4", "stratified_sorted", 1600, 6, 0.6, "move")]
+
+
+@pytest.mark.parametrize("case", SORTED_CASES, ids=lambda c: f"{c[0]}-{c[1]}")
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sorted_stratified_equals_single(g, o, tmp_path, case, world):
+    """pf_resample!(state, :stratified; sort_particles = true) (the reference's default, src/resample.jl:145,156-157) across shards, python engine: every rank
+    gathers all log-weights and works the unsharded sort + scan + search out itself (sharded.py's replicated plan), rows through the all-to-all"""
+    test_sharded_equals_single(g, o, tmp_path, case, world)
+
+
+def test_sharded_sorted_stratified_overflow_and_skew(g, o, tmp_path, monkeypatch):
+    monkeypatch.setenv("GPF_PUSH_CAPACITY", "7")
+    test_sharded_equals_single(g, o, tmp_path, SORTED_CASES[0], 2)
+    monkeypatch.delenv("GPF_PUSH_CAPACITY")
+    for pattern in ("all_on_first_shard", "middle_band"):
+        test_sharded_skewed_weights(g, o, tmp_path, "stratified_sorted", pattern)
+
+
 def test_sharded_push_overflow_path(g, o, tmp_path, monkeypatch):
     """a send buffer that is too small for the exchange: the counts reveal it and the push is repeated at the right size"""
     monkeypatch.setenv("GPF_PUSH_CAPACITY", "7")
