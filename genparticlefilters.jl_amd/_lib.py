@@ -115,6 +115,9 @@ SYMBOLS = [
     ("gpf_phase_times", C.c_int, [_H, _pd, _pi64]),
     ("gpf_shard_resample", C.c_int, [_H, C.c_int32, C.c_int32, _pi32]),
     ("gpf_shard_resample_tempered", C.c_int, [_H, C.c_int32, C.c_double, C.c_int32, _pi32]),
+    ("gpf_checkpoint_size", C.c_int, [_H, C.POINTER(C.c_int64)]),
+    ("gpf_checkpoint_save", C.c_int, [_H, C.c_void_p, C.c_int64]),
+    ("gpf_checkpoint_load", C.c_int, [_H, C.c_void_p, C.c_int64]),
     ("gpf_shard_resample_sorted", C.c_int, [_H, C.c_int32, _pi32]),
     ("gpf_shard_sorted_count", C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
     ("gpf_shard_sorted_push", C.c_int, [_H, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),

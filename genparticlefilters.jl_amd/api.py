@@ -148,6 +148,21 @@ class DeviceParticleFilterState:
     def synchronize(self):
         self._check(self._L.gpf_synchronize(self._h))
 
+    def checkpoint(self) -> np.ndarray:
+        """gpf.h gpf_checkpoint_save: the whole state (population, log-weights, parents, log-ML estimate, RNG epoch, latest observation) as one uint8 array;
+        `restore` on a state created with the same arguments continues bit for bit"""
+        nb = C.c_int64(0)
+        self._check(self._L.gpf_checkpoint_size(self._h, C.byref(nb)))
+        out = np.empty(nb.value, np.uint8)
+        self._check(self._L.gpf_checkpoint_save(self._h, out.ctypes.data, nb.value))
+        return out
+
+    def restore(self, blob):
+        """gpf.h gpf_checkpoint_load"""
+        blob = np.ascontiguousarray(np.frombuffer(blob, np.uint8) if isinstance(blob, (bytes, bytearray, memoryview)) else blob, np.uint8)
+        self._check(self._L.gpf_checkpoint_load(self._h, blob.ctypes.data, blob.size))
+        return self
+
     def set_lazy_search(self, enable: bool = True):
         """gpf.h gpf_set_lazy_search: pf_resample(state, "multinomial") leaves its ancestor search to the pf_update that follows (one fused
         kernel); same results, off by default"""

@@ -934,6 +934,98 @@ gpf_status gpf_proportion(gpf_handle h, int32_t step, int32_t column, double val
     if ((s = weighted_tree_sum(h, h->dtmp, 1, 0, 3, nullptr, value, h->dscal))) return s;
     return copy_out(h, h->dscal, out, sizeof(double));
 }
+// ---- checkpoint / resume: everything a filter needs to continue bit for bit -- the population, its log-weights and parents, the log-ML
+// estimate, the RNG epoch, the latest observation and strata -- as ONE host blob; loads into a handle created with the same gpf_config
+namespace {
+struct CkptHeader {
+    uint64_t magic; int32_t version, model, keep_prev, W, n_params, has_prev, n_strata, interleaved;
+    int64_t n, n_global, gid0; uint64_t seed; uint32_t epoch, pad;
+    double lml_est, logK;
+    double params[MAX_PARAMS], obs[MAX_OBS], strata[MAX_STRATA], q[4];
+};
+constexpr uint64_t CKPT_MAGIC = 0x4750465f434b5054ull;          // "GPF_CKPT"
+int64_t ckpt_bytes(const gpf_filter* h) { return (int64_t)sizeof(CkptHeader) + h->n * h->W * 8 + h->n * 8 + ((h->n * 4 + 7) & ~(int64_t)7); }
+gpf_status ckpt_ready(gpf_filter* h)
+{
+    if (!h) return fail(nullptr, GPF_ERR_INVALID_ARGUMENT, "null handle");
+    if (h->parent) return fail(h, GPF_ERR_STATE, "checkpoints are taken of whole filters, not of sub-state views");
+    return GPF_OK;
+}
+} // namespace
+gpf_status gpf_checkpoint_size(gpf_handle h, int64_t* bytes)
+{
+    gpf_status s = ckpt_ready(h);
+    if (s) return s;
+    if (!bytes) return fail(h, GPF_ERR_INVALID_ARGUMENT, "null output");
+    *bytes = ckpt_bytes(h);
+    return GPF_OK;
+}
+gpf_status gpf_checkpoint_save(gpf_handle h, void* out, int64_t bytes)
+{
+    gpf_status s = ckpt_ready(h);
+    if (s) return s;
+    if (!out || bytes != ckpt_bytes(h)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "the buffer must hold exactly gpf_checkpoint_size bytes");
+    // whatever is still deferred (lazy move, lazy search, un-gathered or un-scattered resample) becomes state first
+    if ((s = check_ready(h)) || (s = finish_search(h)) || (s = materialize(h))) return s;
+    CkptHeader hd{};
+    hd.magic = CKPT_MAGIC; hd.version = 1; hd.model = h->cfg.model; hd.keep_prev = h->cfg.keep_prev; hd.W = h->W; hd.n_params = h->cfg.n_params;
+    hd.has_prev = h->has_prev ? 1 : 0; hd.n_strata = h->args.n_strata; hd.interleaved = h->args.interleaved;
+    hd.n = h->n; hd.n_global = h->cfg.n_global; hd.gid0 = h->cfg.gid0; hd.seed = h->cfg.seed; hd.epoch = h->epoch;
+    hd.logK = h->args.logK;
+    for (int i = 0; i < MAX_PARAMS; ++i) hd.params[i] = h->args.P[i];
+    for (int i = 0; i < MAX_OBS; ++i) hd.obs[i] = h->args.obs[i];
+    for (int i = 0; i < MAX_STRATA; ++i) hd.strata[i] = h->args.strata[i];
+    for (int i = 0; i < 4; ++i) hd.q[i] = h->args.q[i];
+    char* o = static_cast<char*>(out) + sizeof(CkptHeader);
+    const size_t rb = (size_t)h->n * h->W * 8, wb = (size_t)h->n * 8, ab = (size_t)h->n * 4;
+    HIP_TRY(h, hipMemcpyAsync(&hd.lml_est, reinterpret_cast<const char*>(h->sc) + offsetof(Scalars, lml_est), sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(o, h->rows[h->cur], rb, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(o + rb, h->lw, wb, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(o + rb + wb, h->anc, ab, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if ((s = check_scan_timeout(h))) return s;
+    memcpy(out, &hd, sizeof(hd));
+    return GPF_OK;
+}
+gpf_status gpf_checkpoint_load(gpf_handle h, const void* in, int64_t bytes)
+{
+    gpf_status s = ckpt_ready(h);
+    if (s) return s;
+    if (!in || bytes < (int64_t)sizeof(CkptHeader)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "not a checkpoint");
+    CkptHeader hd;
+    memcpy(&hd, in, sizeof(hd));
+    if (hd.magic != CKPT_MAGIC || hd.version != 1) return fail(h, GPF_ERR_INVALID_ARGUMENT, "not a checkpoint of this library version");
+    bool same = hd.model == h->cfg.model && hd.keep_prev == h->cfg.keep_prev && hd.W == h->W && hd.n == h->n && hd.n_global == h->cfg.n_global &&
+                hd.gid0 == h->cfg.gid0 && hd.seed == h->cfg.seed && hd.n_params == h->cfg.n_params;
+    for (int i = 0; same && i < hd.n_params; ++i) same = memcmp(&hd.params[i], &h->args.P[i], sizeof(double)) == 0;
+    if (!same) return fail(h, GPF_ERR_INVALID_ARGUMENT, "the checkpoint was taken of a filter with another gpf_config (model, parameters, particle counts, gid0, seed, keep_prev)");
+    if (bytes != ckpt_bytes(h)) return fail(h, GPF_ERR_INVALID_ARGUMENT, "truncated checkpoint");
+    if (h->hist_on) return fail(h, GPF_ERR_STATE, "a filter with a trajectory store cannot load a checkpoint (the store is not part of it)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (gpf_filter* v : h->blk_views) gpf_destroy(v);
+    h->blk_views.clear();
+    // the state is replaced: nothing deferred survives
+    h->pending_move = false; h->pending_search = false; h->pending_gather = false; h->pending_fill = false;
+    h->pending_packed = false; h->pend_ring = false;
+    const char* o = static_cast<const char*>(in) + sizeof(CkptHeader);
+    const size_t rb = (size_t)h->n * h->W * 8, wb = (size_t)h->n * 8, ab = (size_t)h->n * 4;
+    HIP_TRY(h, hipMemcpyAsync(h->rows[h->cur], o, rb, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->lw, o + rb, wb, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->anc, o + rb + wb, ab, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(reinterpret_cast<char*>(h->sc) + offsetof(Scalars, lml_est), &hd.lml_est, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->epoch = hd.epoch; h->has_prev = hd.has_prev != 0; h->initialized = true;
+    h->args.n_strata = hd.n_strata; h->args.interleaved = hd.interleaved; h->args.logK = hd.logK;
+    for (int i = 0; i < MAX_OBS; ++i) h->args.obs[i] = hd.obs[i];
+    for (int i = 0; i < MAX_STRATA; ++i) h->args.strata[i] = hd.strata[i];
+    for (int i = 0; i < 4; ++i) h->args.q[i] = hd.q[i];
+    h->blk_obs_size = 0;
+    h->raw_valid = false; h->raw_sum_valid = false; h->max_valid = false; h->raw_has_q = false; h->raw_q_folded = false;
+    h->residual_scanned = false; h->push_counted = false; h->gsum_ok = false; h->ch0_offsets = false;
+    mutated(h);
+    return GPF_OK;
+}
+
 gpf_status gpf_history_mean(gpf_handle h, int32_t step, int32_t column, double* out) { return history_stat(h, step, column, out, false); }
 gpf_status gpf_history_var(gpf_handle h, int32_t step, int32_t column, double* out) { return history_stat(h, step, column, out, true); }
 

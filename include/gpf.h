@@ -521,6 +521,16 @@ gpf_status gpf_debug_levels(gpf_handle h, int32_t which, void* out, int64_t* n_b
 /* host twin of gpf_debug_math (which = 0..5, 7) */
 void    gpf_host_math(int32_t which, const double* a, const double* b, int64_t n, double* out, double* out2);
 
+/* ---- checkpoint / resume ----------------------------------------------------------------------
+ * No reference counterpart (a Gen ParticleFilterState is an ordinary Julia object: `serialize` does it there).  The whole state of a filter (or of one
+ * shard) as ONE host blob: population, log-weights, parents, log-ML estimate, RNG epoch, the latest observation and strata.  gpf_checkpoint_save first
+ * turns everything deferred (lazy move, lazy search, un-gathered resample, un-scattered sharded commit) into state; gpf_checkpoint_load takes a handle
+ * created with the SAME gpf_config (model, parameters, particle counts, gid0, seed, keep_prev -- else GPF_ERR_INVALID_ARGUMENT) and continues bit for bit
+ * where the saved filter stood.  Not part of a blob: the trajectory store (a filter that records one refuses to load), per-block observations, views. */
+gpf_status gpf_checkpoint_size(gpf_handle h, int64_t* bytes);
+gpf_status gpf_checkpoint_save(gpf_handle h, void* out, int64_t bytes);
+gpf_status gpf_checkpoint_load(gpf_handle h, const void* in, int64_t bytes);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -164,6 +164,16 @@ end
 "opt-in: pf_resample!(state, :multinomial) leaves its ancestor search to the pf_update! that follows (one fused kernel; gpf.h gpf_set_lazy_search)"
 set_lazy_search!(s::DeviceParticleFilterState, enable::Bool=true) =
     (_status(s, ccall((:gpf_set_lazy_search, libgpf), Cint, (Ptr{Cvoid}, Cint), s.handle, enable ? 1 : 0)); s)
+"checkpoint / resume (gpf.h gpf_checkpoint_*): the whole state as one byte vector; `restore!` on a state created with the same arguments continues bit for bit"
+function checkpoint(s::DeviceParticleFilterState)
+    nb = Ref{Int64}(0)
+    _status(s, ccall((:gpf_checkpoint_size, libgpf), Cint, (Ptr{Cvoid}, Ptr{Int64}), s.handle, nb))
+    blob = Vector{UInt8}(undef, nb[])
+    _status(s, ccall((:gpf_checkpoint_save, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), s.handle, blob, nb[]))
+    return blob
+end
+restore!(s::DeviceParticleFilterState, blob::Vector{UInt8}) =
+    (_status(s, ccall((:gpf_checkpoint_load, libgpf), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), s.handle, blob, length(blob))); s)
 "opt-in extension (gpf.h GPF_RESAMPLE_MULTINOMIAL_SORTED): multinomial resampling with the uniforms drawn already sorted -- state.parents non-decreasing"
 pf_multinomial_sorted_resample!(s::DeviceParticleFilterState; priority_fn=nothing, check=:warn) = _resample!(s, 4, priority_fn, check, true)
 
