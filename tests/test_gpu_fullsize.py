@@ -131,6 +131,31 @@ def test_large_single_gpu_8e6_properties(g):
     assert np.array_equal(st.parents, np.arange(1, N + 1))
 
 
+@pytest.mark.parametrize("sort_particles", [False, True])
+def test_config3_global_size_8e6_stratified_properties(g, sort_particles):
+    """BASELINE configs[2]'s GLOBAL particle count on one GPU, stratified, in both orders of the strata (the sorted one beyond the bucket sort: three coarse
+    passes + finish over 8e6 keys; it is also what every rank's planner runs in gpf_shard_resample_sorted at that size): size-independent properties"""
+    N = 8_000_000
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    st = g.pf_initialize(model, (1,), ys[0], N, seed=9)
+    lml0 = g.get_lml_est(st)
+    lw0 = st.log_weights; x0 = st.traces[:, 0].copy()
+    w = np.exp(lw0 - lw0.max())
+    g.pf_resample(st, "stratified", sort_particles=sort_particles, check=False)
+    par = st.parents
+    assert par.min() >= 1 and par.max() <= N
+    if sort_particles:
+        assert np.all(np.diff(lw0[par - 1]) <= 0)                 # strata over the particles in descending weight order (resample.jl:156-157)
+    else:
+        assert np.all(np.diff(par) >= 0)                          # monotone ancestors
+    assert np.array_equal(st.traces[:, 0], x0[par - 1])
+    assert abs(g.get_lml_est(st) - lml0) <= 1e-9 * abs(lml0)
+    counts = np.bincount(par - 1, minlength=N)
+    assert np.max(np.abs(counts - N * w / w.sum())) <= 2.0        # floor(N w) or ceil(N w) children up to the stratum jitter
+    g.pf_update(st, (2,), (None,), ys[1])
+    assert np.isfinite(g.get_lml_est(st)) and 0 < g.get_ess(st) <= N
+
+
 def test_maximum_size_64e6_global_top_level(g):
     """N = 2^26 on one GPU: the 32768 tile prefixes no longer fit the search kernel's LDS table, so the top level becomes the
     prefix of every 8th tile followed by one read of the group's 8 tile prefixes; K = 36-bit weights.  Size-independent properties only."""

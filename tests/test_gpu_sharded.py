@@ -662,6 +662,12 @@ def test_sorted_stratified_across_shards(g, o, tmp_path, monkeypatch, loopback_l
     test_hip_shards_equal_single_oracle(g, o, tmp_path, case, world=world)
 
 
+def test_sorted_stratified_across_shards_wide_bucket_sort(g, o, tmp_path, monkeypatch, loopback_lib):
+    """1.3 M global particles on 3 ranks: every rank's planner sorts them with the bucket sort's wide form (above 1 179 648 keys)"""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, ("lgssm2", "stratified_sorted", 65_000, 3, None, None), world=3)
+
+
 @pytest.mark.parametrize("variant", ["own_off", "small_send_buffer"])
 def test_sorted_stratified_across_shards_packed_paths(g, o, tmp_path, monkeypatch, loopback_lib, variant):
     """the same with every entry packed (GPF_SHARD_OWN=0: own hits travel through the exchange buffer too) and with a send buffer smaller than the exchange
