@@ -1044,6 +1044,10 @@ static gpf_status shard_sorted_buffers(gpf_filter* h, int G)
         gpf_handle p = nullptr;
         if ((s = gpf_create(&c, &p))) return fail(h, s, std::string("planner of the sorted sharded resample (n_global particles on every rank): ") + gpf_last_error(nullptr));
         h->planner = p;
+        if (p->chain_counted && p->cfg.device < 16) {            // the planner runs on its owner's stream, never beside it: not one more filter for the gate of
+            std::lock_guard<std::mutex> lk(g_chain[p->cfg.device].mu);   // chained kernels (gpf_host.hpp ChainGate)
+            g_chain[p->cfg.device].live -= 1; p->chain_counted = false;
+        }
     }
     if ((s = ensure_shard_counts(h))) return s;
     if (!h->anc_cursors) HIP_TRY(h, hipMalloc(&h->anc_cursors, MAX_SHARDS * sizeof(unsigned long long)));

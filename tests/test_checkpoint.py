@@ -5,8 +5,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("lgssm2", "multinomial", None, None, False), ("lgssm2", "multinomial", None, None, True),      # (True: lazy search pending at the save)
-         ("bearings4", "residual", 0.5, "move", False), ("sv1", "stratified", None, "reweight", False), ("object_motion", "residual", 0.9, "move", False)]
+CASES = [pytest.param("lgssm2", "multinomial", None, None, False, marks=pytest.mark.gpu_soak),
+         ("lgssm2", "multinomial", None, None, True),          # (True: lazy search pending at the save)
+         ("bearings4", "residual", 0.5, "move", False), ("sv1", "stratified", None, "reweight", False),
+         pytest.param("object_motion", "residual", 0.9, "move", False, marks=pytest.mark.gpu_soak)]
 
 
 def _loop(g, st, ys, t0, t1, method, ess, rejuv, save_at=None):
