@@ -43,6 +43,31 @@ static __global__ void k_mbox_rounds(uint64_t* const* peers, const uint64_t* own
         mbox_wait_block(w);
     }
 }
+// gpf_comm_create's self-test of the receive windows, round d (1 <= d < G): this rank stores one entry into slot 0 of rank (me + d) % G's window and waits
+// for the entry rank (me - d) % G stores into its own -- the very stores, loads and seals of a slab exchange (ring_store / ring_load), across the very
+// mappings.  One lane; W at run time.  A stalled or invisible peer store ends in the bounded wait's flag 3, which the host turns into "no windows".
+static __global__ void k_ring_selftest(uint64_t* const* peers, const uint64_t* own, int G, int me, int d, int64_t parity_words, uint64_t seq, int W, int32_t* timeout,
+                                       int32_t* bad)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t off = (int64_t)(seq & (RING_PARITIES - 1)) * parity_words;
+    double row[8];
+    for (int c = 0; c < 8; ++c) row[c] = (double)(me * 16 + c);
+    ring_store(peers[(me + d) % G] + off, row, W, (uint64_t)me, seq);
+    const int src = (me - d + G) % G;
+    const uint64_t* e = own + off;
+    bool ok = false;
+    for (unsigned spins = 0; spins <= RING_SPIN_LIMIT; ++spins) {
+        uint64_t x = seq, last = 0;
+        for (int k = 0; k < W + 2; ++k) { last = ld_sys(e + k); if (k < W + 1) x = (x ^ last) * 0x9E3779B97F4A7C15ull; }
+        if (x == last) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok) { __hip_atomic_store(timeout, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    bool same = ld_sys(e + W) == (uint64_t)src;
+    for (int c = 0; c < W; ++c) same = same && u2d(ld_sys(e + c)) == (double)(src * 16 + c);
+    if (!same) *bad = 1;
+}
 // {Ql0..3} -> out5[1..4]: limb sums of sum q^2 folded over the scan blocks (exact integers); out5[0] = S_local is written by the scan
 static __global__ void k_export_q(const uint64_t* __restrict__ blockQ, int nblk, int64_t* out5, MboxPush push)
 {

@@ -628,6 +628,8 @@ void mailbox_teardown(gpf_filter* h)
     h->mb_peers = nullptr; h->mbox = nullptr; h->mb_active = false;
 }
 struct MboxPacket { hipIpcMemHandle_t handle; int64_t ok; int64_t pid; char bus[32]; };
+// GPF_SHARD_SELFTEST: 0 = no self-test of mailboxes / windows at gpf_comm_create; fail_mailbox / fail_windows = rank 0 reports a failed test (tests of the fall-back)
+int selftest_mode() { const char* e = getenv("GPF_SHARD_SELFTEST"); return !e ? 1 : (!strcmp(e, "0") ? 0 : (!strcmp(e, "fail_mailbox") ? 2 : (!strcmp(e, "fail_windows") ? 3 : 1))); }
 // all-gather of `each` bytes per rank, host to host, over the handle's communicator (setup only)
 gpf_status host_all_gather(gpf_filter* h, const void* src, void* dst_host, size_t each)
 {
@@ -686,6 +688,31 @@ gpf_status ring_setup(gpf_filter* h)
     HIP_TRY(h, hipMalloc(&h->ring_peers, (size_t)G * sizeof(uint64_t*)));
     HIP_TRY(h, hipMemcpy(h->ring_peers, peers.data(), (size_t)G * sizeof(uint64_t*), hipMemcpyHostToDevice));
     h->ring_seq = 0;
+    // Self-test, as for the mailboxes: in round d every rank stores one entry into the window of rank (me + d) % G and waits for the one rank (me - d) % G
+    // stores into its own (k_ring_selftest: the stores, loads and seals of a slab exchange across the real mappings); the all-gather of the verdicts between
+    // the rounds is their barrier.  One "no" and every rank keeps the grouped ncclSend / ncclRecv.
+    if (G > 1 && selftest_mode() != 0) {
+        int32_t* bad = nullptr;
+        int64_t pass = hipMalloc(&bad, sizeof(int32_t)) == hipSuccess && hipMemsetAsync(bad, 0, sizeof(int32_t), h->stream) == hipSuccess ? 1 : 0;
+        if (!pass) (void)hipGetLastError();
+        bool all_pass = true;
+        for (int d = 1; d < G; ++d) {
+            h->ring_seq += 1;
+            if (pass) {
+                GPF_LAUNCH(k_ring_selftest, dim3(1), dim3(WAVE), 0, h->stream, h->ring_peers, h->ring, G, me, d, h->ring_parity_words, h->ring_seq, h->W, h->h_timeout, bad);
+                int32_t hb = 0;
+                if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&hb, bad, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                    hipStreamSynchronize(h->stream) != hipSuccess || hb != 0) { (void)hipGetLastError(); pass = 0; }
+                if (__atomic_load_n(h->h_timeout, __ATOMIC_ACQUIRE) != 0) { __atomic_store_n(h->h_timeout, 0, __ATOMIC_RELEASE); pass = 0; }
+            }
+            if (selftest_mode() == 3 && me == 0) pass = 0;         // (tests: "this rank's test failed")
+            if ((s = host_all_gather(h, &pass, oks.data(), sizeof(int64_t)))) { if (bad) (void)hipFree(bad); ring_teardown(h); return s; }
+            for (int r = 0; r < G; ++r) all_pass = all_pass && oks[r] != 0;
+            if (!all_pass) break;                                 // (every rank sees the same verdicts: every rank stops here)
+        }
+        if (bad) (void)hipFree(bad);
+        if (!all_pass) { ring_teardown(h); return GPF_OK; }
+    }
     h->ring_active = true;
     h->exchange_mode = (mode && !strcmp(mode, "p2p_all")) ? GPF_SHARD_EXCHANGE_P2P_ALL : GPF_SHARD_EXCHANGE_P2P;
     return GPF_OK;
@@ -746,6 +773,19 @@ gpf_status mailbox_setup(gpf_filter* h)
         for (int q = 0; q < r && own_device; ++q) if (!strcmp(all[r].bus, all[q].bus)) own_device = false;
     }
     h->mb_fuse_default = own_device;
+    // Self-test before anything relies on the mailboxes (they are the default transport of the small summaries, and what this code could be tried on while it
+    // was written was several ranks on ONE device): a few dependent rounds of the calibration kernel -- every rank stores into every peer's mailbox and waits
+    // for all G entries.  A rank whose wait gives up votes "no"; one "no" and every rank keeps the RCCL all-gathers.  GPF_SHARD_SELFTEST=0 skips it.
+    if (G > 1 && selftest_mode() != 0) {
+        int64_t pass = 1;
+        GPF_LAUNCH(k_mbox_rounds, dim3(1), dim3(WAVE), 0, h->stream, h->mb_peers, h->mbox, G, me, h->mb_seq[MB_CAL], 4, h->h_timeout);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { (void)hipGetLastError(); pass = 0; }
+        if (__atomic_load_n(h->h_timeout, __ATOMIC_ACQUIRE) != 0) { __atomic_store_n(h->h_timeout, 0, __ATOMIC_RELEASE); pass = 0; }
+        if (selftest_mode() == 2 && me == 0) pass = 0;            // (tests: "this rank's test failed")
+        h->mb_seq[MB_CAL] += 4;
+        if ((s = gather(&pass, oks.data(), sizeof(int64_t)))) { mailbox_teardown(h); return s; }
+        for (int r = 0; r < G; ++r) if (!oks[r]) { mailbox_teardown(h); return GPF_OK; }
+    }
     return GPF_OK;
 }
 } // namespace

@@ -707,3 +707,16 @@ def test_world1_sorted_stratified_equals_unsharded(g, o):
     assert sharded.get_lml_est(a) == g.get_lml_est(b) and sharded.get_ess(a) == g.get_ess(b)
     with pytest.raises(g.ErrorException, match="priority_fn"):
         sharded.pf_resample(a, "stratified", sort_particles=True, priority_fn=g.Tempering(0.5), check=False)
+
+
+@pytest.mark.parametrize("what,summaries,exchange", [("fail_mailbox", "rccl", "rccl"), ("fail_windows", "mailbox", "rccl")])
+def test_comm_self_test_failure_falls_back_on_every_rank(g, o, tmp_path, monkeypatch, loopback_lib, what, summaries, exchange):
+    """gpf_comm_create tries mailboxes and receive windows out before anything relies on them (a few dependent mailbox rounds; one window entry to and from
+    every peer).  One rank reporting a failed test (GPF_SHARD_SELFTEST=fail_*: rank 0 votes no) and EVERY rank keeps the RCCL all-gathers / the grouped
+    ncclSend / ncclRecv -- agreed through an all-gather, so no rank is left waiting on a transport its peers gave up.  The same bits."""
+    monkeypatch.setenv("GPF_RCCL_LIBRARY", loopback_lib); monkeypatch.setenv("GPF_SHARD_ENGINE", "library")
+    monkeypatch.setenv("GPF_SHARD_SELFTEST", what)
+    test_hip_shards_equal_single_oracle(g, o, tmp_path, CASES[1], world=3)
+    for r in range(3):
+        p = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        assert str(p["summaries"]) == summaries and str(p["exchange"]) == exchange
