@@ -63,9 +63,28 @@ def test_random_api_sequences(g, o, seed):
     log = []
     blk = None                                                        # (block size, observation rows) while the latest observations are per block
     for step in range(T):
-        op = rng.choice(["update", "resample", "rejuvenate", "getters", "view", "whole_view", "resize", "set_weights", "blocks", "step_ess"],
-                        p=[0.17, 0.17, 0.11, 0.08, 0.11, 0.07, 0.07, 0.07, 0.07, 0.08])
+        op = rng.choice(["update", "resample", "rejuvenate", "getters", "view", "whole_view", "resize", "set_weights", "blocks", "step_ess", "checkpoint"],
+                        p=[0.15, 0.15, 0.10, 0.08, 0.11, 0.07, 0.07, 0.07, 0.07, 0.08, 0.05])
         n = st.n_particles
+        if op == "checkpoint" and (hist or blk is not None):
+            op = "getters"                                              # (the trajectory store and per-block observations are not part of a blob)
+        if op == "checkpoint":
+            # gpf_checkpoint_save with whatever is deferred at this point, then either a FRESH handle takes the blob and the old one goes away, or this
+            # one moves on (an update the oracle never sees) and is set back; the oracle is not told: the sequence must go on bit for bit
+            blob = st.checkpoint()
+            if rng.random() < 0.5:
+                st2 = g.pf_initialize(model, (1,), ys[0], n, seed=seed + 5, keep_prev=True)
+                st2.set_lazy_search(bool(seed % 2)); st2.restore(blob)
+                st.close(); st = st2
+                log.append("checkpoint -> fresh handle")
+            else:
+                g.pf_update(st, (t + 1,), (None,), ys[t])
+                if rng.random() < 0.5:
+                    g.pf_resample(st, "multinomial", check=False)
+                st.restore(blob)
+                log.append("checkpoint -> moved on -> restored")
+            check(g, st, orc, f"seed {seed} {name} N={N} after {log[-6:]}")
+            continue
         if op == "blocks" and hist:
             with pytest.raises(g.ErrorException):                       # (no block-wise steps on a filter with a trajectory store)
                 g.pf_resample_blocks(st, 64, "multinomial", check=False)
