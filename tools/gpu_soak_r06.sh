@@ -1,4 +1,5 @@
-# round-6 soak of the random API sequences on the round's new code paths (window exchange, lazy move over a sharded commit, summary reuse, chain gate):
+# round-6 soak of the random API sequences on the round's new code paths (window exchange, lazy move over a sharded commit, summary reuse, chain gate, sort_particles=true
+# across shards in either engine, checkpoint -> restore among the unsharded operations):
 #   bash tools/gpu_soak_r06.sh   -> gpurun_out/r06_fuzz_soak.txt
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R
 OUT=gpurun_out/r06_fuzz_soak.txt; : > $OUT
