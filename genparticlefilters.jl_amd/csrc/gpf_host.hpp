@@ -135,6 +135,8 @@ struct __attribute__((visibility("hidden"))) gpf_filter {
     const int32_t** hist_dev_maps = nullptr;
     // sub-state view (src/view.jl:16-48): this handle aliases particles [view_start, view_start + n) of `parent`
     gpf_filter* parent = nullptr;
+    std::vector<gpf_filter*> views;      // the live view handles of THIS filter: gpf_destroy orphans them (a view used after its filter is gone fails loudly)
+    bool orphaned = false;               // view: its filter was destroyed -- parent dangles and is never followed, the stream is gone with it
     int64_t view_start = 0;
     int64_t view_step = 1;               // > 1: strided view (state[start:step:stop]); works on the compact copies below
     double* vrows[2] = {nullptr, nullptr}; double* vlw = nullptr; int32_t* vanc = nullptr;

@@ -650,6 +650,7 @@ static gpf_status view_create_impl(gpf_handle parent, int64_t start, int64_t ste
     };
     gpf_status st = body();
     if (st != GPF_OK) { parent->err = v->err; gpf_destroy(v); return st; }
+    parent->views.push_back(v);
     *out = v;
     return GPF_OK;
 }

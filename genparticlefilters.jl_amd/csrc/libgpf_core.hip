@@ -353,6 +353,7 @@ void mutated(gpf_filter* h)
 // shares the parent's epoch counter, and forces a pending gather of the parent first.
 gpf_status view_enter(gpf_filter* v)
 {
+    if (v->orphaned) return fail(v, GPF_ERR_STATE, "stale view: its filter was destroyed");
     gpf_filter* p = v->parent;
     if (p->generation != v->parent_generation) return fail(v, GPF_ERR_STATE, "stale view: the parent filter was resized or re-created");
     if (!p->initialized) return fail(v, GPF_ERR_STATE, "parent filter not initialised");
@@ -550,6 +551,10 @@ gpf_status gpf_destroy(gpf_handle h)
     if (!h) return GPF_OK;
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->parent && !h->orphaned) {                              // a view leaves its filter's list
+        auto& vs = h->parent->views;
+        vs.erase(std::remove(vs.begin(), vs.end(), h), vs.end());
+    }
     for (auto& t : h->timers) for (auto& e : t.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& m : h->phases.marks) (void)hipEventDestroy(m.second);
     h->phases.marks.clear();
@@ -565,8 +570,11 @@ gpf_status gpf_destroy(gpf_handle h)
     h->pending_packed = false;                                   // the filter goes away: nothing to scatter a deferred commit into
     if (h->planner) { gpf_destroy(h->planner); h->planner = nullptr; }
     for (void* q : {(void*)h->sorted_src, (void*)h->sorted_gath, (void*)h->anc_cursors}) if (q) (void)hipFree(q);
-    for (gpf_filter* v : h->blk_views) gpf_destroy(v);
-    h->blk_views.clear();
+    { const std::vector<gpf_filter*> own = h->blk_views; h->blk_views.clear(); for (gpf_filter* v : own) gpf_destroy(v); }
+    // view handles the host still holds outlive this filter as orphans: every later call on them fails ("stale view"), their own gpf_destroy frees
+    // what they own -- the aliased buffers and the stream (drained above) are never touched through them again
+    for (gpf_filter* v : h->views) { v->orphaned = true; v->stream = nullptr; v->rows[0] = v->rows[1] = nullptr; v->lw = nullptr; v->anc = nullptr; }
+    h->views.clear();
     gpf_comm_destroy(h);
     hist_clear(h);
     if (h->hist_dev_maps) (void)hipFree(h->hist_dev_maps);

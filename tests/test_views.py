@@ -349,3 +349,24 @@ def test_hip_index_view_errors(g, o):
     v = st[[5, 1, 99]]
     assert np.array_equal(v.traces, st.traces[[5, 1, 99]]) and np.array_equal(v.log_weights, st.log_weights[[5, 1, 99]])
     st.close()
+
+
+@pytest.mark.gpu
+def test_view_outliving_its_filter_fails_loudly(g):
+    """gpf_destroy on a filter whose view handles are still alive (state.close() with a sub-state in hand; a host that frees the filter first): the views
+    become orphans -- every call on them raises "stale view", destroying them afterwards is safe (found by the random API sequences: a segfault in the
+    view's destructor after a checkpoint moved the run to a fresh handle)"""
+    model = g.models.lgssm2(); ys = g.models.simulate(model, 3)
+    st = g.pf_initialize(model, (1,), ys[0], 20_000, seed=4)
+    v1, v2, v3 = st[100:5000], st[0:20_000:7], st[np.array([5, 17, 19_999, 3])]
+    g.pf_resample(v1, "multinomial", check=False); g.pf_resample(v2, "residual", check=False); g.pf_update(v3, (2,), (None,), ys[1])
+    st.close()
+    for v in (v1, v2, v3):
+        with pytest.raises(g.ErrorException, match="stale view"):
+            g.get_ess(v)
+        with pytest.raises(g.ErrorException, match="stale view"):
+            g.pf_resample(v, "multinomial", check=False)
+    other = g.pf_initialize(model, (1,), ys[0], 20_000, seed=4)      # (recycles the freed memory and stream)
+    g.pf_update(other, (2,), (None,), ys[1])
+    v1.close(); v2.close(); v3.close()
+    assert np.isfinite(g.get_lml_est(other))
