@@ -427,7 +427,9 @@ gpf_status gpf_comm_destroy(gpf_handle h);
 /* How the three small summaries of a sharded resample -- (max, flags), {S, sum q^2 limbs}, the residual counts; 16-40 bytes per rank
  *  -- travel: *mailbox = 1: the producing kernel stores them straight into every peer's mailbox (device
  * memory mapped with hipIpc at gpf_comm_create, xGMI peer writes) and the consuming kernel waits for them -- no collective, no
- * launch, no host; 0: RCCL all-gathers (hipIpc mapping not possible on this system, or GPF_SHARD_SUMMARY=rccl in the environment).
+ * launch, no host; 0: RCCL all-gathers (hipIpc mapping not possible on this system, the self-test failed, or GPF_SHARD_SUMMARY=rccl in the environment).
+ * Self-test: gpf_comm_create tries the mapped mailboxes out (four dependent rounds between all ranks) and the receive windows below (one entry to and
+ * from every peer) before enabling them; one rank whose test fails and every rank keeps RCCL for that transport (GPF_SHARD_SELFTEST=0: no test).
  * Every rank of a communicator is in the same mode.  How the ROWS travel: gpf_comm_set_exchange below. */
 gpf_status gpf_comm_summary_mode(gpf_handle h, int32_t* mailbox);
 /* exchange volume of this handle's gpf_shard_resample calls so far (what a scaling run compares with the worksheet of DESIGN.md 6.7):
